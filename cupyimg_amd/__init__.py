@@ -1,0 +1,14 @@
+"""cupyimg_amd -- MI355X-native n-D image filtering engine with the
+scipy.ndimage / skimage drop-in API of mritools/cupyimg.
+
+Python host code calls hand-written gfx950 HIP kernels through the ctypes
+C-ABI in include/mi355img.h (libmi355img.so).  No CuPy, no PyTorch, no CPU
+fallback: if the HIP library cannot be loaded, using the package fails.
+"""
+from .core import (  # noqa: F401
+    Event, array, asarray, ascontiguousarray, asnumpy, device_count, device_name, empty,
+    empty_like, free_all_blocks, full, get_device, is_available, ndarray, ones, pool_stats,
+    set_device, shares_memory, synchronize, zeros, zeros_like,
+)
+
+__version__ = "0.1.0"

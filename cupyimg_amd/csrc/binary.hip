@@ -1,0 +1,104 @@
+// binary.hip -- binary erosion / dilation, one iteration per launch (K4).
+//
+// Reference: cupyimg/scipy/ndimage/morphology.py:41-128 (kernel), launch at
+// :292-322.  Output is true unless a set structure tap sees a false voxel
+// (outside the array the tap sees border_value); `invert` swaps true/false and
+// the border, which is how dilation is expressed (:443-461).  With a mask,
+// voxels whose mask is 0 keep the input value (:60-72).
+//
+// The reference decides convergence of iterated morphology on the host with
+// `(tmp_in == tmp_out).all()` every iteration (:313,321).  Here the kernel
+// ORs a device flag when any voxel changed, so the host reads one int32.
+#include "nd_common.hpp"
+
+namespace mi {
+
+template <typename T, int ND>
+__global__ void __launch_bounds__(256)
+binary_erosion_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt,
+                      const uint8_t *__restrict__ mask, NdGeom g, TapTable tt, int64_t total,
+                      int border_value, int invert, int32_t *changed)
+{
+    const bool tv = !invert, fv = invert;
+    const bool bv = invert ? !border_value : (border_value != 0);
+    bool any_change = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const bool cur = in[i] != T(0);
+        bool res;
+        if (mask && !mask[i]) {
+            res = cur;
+        } else {
+            const Voxel<ND> v = locate<ND>(g, i);
+            res = tv;
+            if (v.interior) {
+                for (int t = 0; t < tt.ntaps; t++)
+                    if ((in[i + tt.lin[t]] != T(0)) == fv) { res = fv; break; }
+            } else {
+                for (int t = 0; t < tt.ntaps; t++) {
+                    // binary morphology always uses the constant boundary
+                    const int64_t pos = tap_pos<ND>(g, v, tt.idx, t, MI_MODE_CONSTANT);
+                    const bool nn = pos < 0 ? bv : ((in[pos] != T(0)) == tv);
+                    if (!nn) { res = fv; break; }
+                }
+            }
+        }
+        any_change |= (res != cur);
+        store_as(out, i, out_dt, res ? 1.0 : 0.0);
+    }
+    if (changed && __any(any_change) && (threadIdx.x & 63) == 0) atomicOr(changed, 1);
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" int mi_binary_erosion(const mi_array *in, const mi_array *out, const uint8_t *structure,
+                                 const int64_t *sshape, const int *origins, const mi_array *mask,
+                                 int border_value, int invert, int32_t *changed_dev, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(in->ndim >= 1, MI_ERR_INVALID_ARG, "input must have at least one dimension");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    MI_REQUIRE(structure && sshape && origins, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS,
+               "binary morphology needs C-contiguous arrays");
+    MI_REQUIRE(in->data != out->data, MI_ERR_INVALID_ARG, "output and input may not overlap in memory");
+    if (mask) {
+        if ((rc = check_array(mask, "mask"))) return rc;
+        MI_REQUIRE(same_shape(in, mask), MI_ERR_INVALID_ARG, "mask and input must have equal sizes");
+        MI_REQUIRE(is_contiguous(mask) && dtype_size(mask->dtype) == 1, MI_ERR_NOT_CONTIGUOUS,
+                   "mask must be a C-contiguous 1-byte array");
+    }
+    const int64_t total = numel(in);
+    if (total == 0) return MI_OK;
+    hipStream_t s = resolve_stream(stream);
+
+    // binary structures may legally have an origin that puts the centre
+    // outside (SciPy only checks the range); clamp nothing, just build taps.
+    TapBuilder tb;
+    {
+        // TapBuilder::init validates origins like the filters do; binary
+        // erosion accepts the same range (morphology.py:271).
+        if ((rc = tb.init(in, sshape, origins, "structure"))) return rc;
+    }
+    tb.fill([&](int64_t k) { return structure[k] != 0; }, [](int64_t) { return 0.0; }, false);
+    TapTable tt;
+    if ((rc = tb.upload(&tt, s))) return rc;
+
+    dim3 grid;
+    grid_for(total, 256, &grid);
+    const uint8_t *mp = mask ? (const uint8_t *)mask->data : nullptr;
+    return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
+        const T *ip = (const T *)in->data;
+        if (tb.g.ndim == 3)
+            hipLaunchKernelGGL((binary_erosion_kernel<T, 3>), grid, dim3(256), 0, s, ip, out->data, out->dtype,
+                               mp, tb.g, tt, total, border_value, invert, changed_dev);
+        else
+            hipLaunchKernelGGL((binary_erosion_kernel<T, MI_MAX_NDIM>), grid, dim3(256), 0, s, ip, out->data,
+                               out->dtype, mp, tb.g, tt, total, border_value, invert, changed_dev);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    });
+}

@@ -1,0 +1,237 @@
+// common.hpp -- shared device/host helpers for libmi355img (gfx950 only).
+//
+// Arithmetic spec followed (reference, read-only):
+//   boundary maps      cupyimg/scipy/ndimage/_util.py:170-228
+//   offset rule        cupyimg/scipy/ndimage/_filters_core.py:10-11
+//   cast<> semantics   cupyimg/scipy/ndimage/_filters_core.py:166-187
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <type_traits>
+
+#include "../../include/mi355img.h"
+
+namespace mi {
+
+// ------------------------------------------------------------------ errors
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+#define MI_HIP(call)                                   \
+    do {                                               \
+        hipError_t e__ = (call);                       \
+        if (e__ != hipSuccess) return mi::hip_fail(e__, #call); \
+    } while (0)
+
+#define MI_REQUIRE(cond, code, msg)      \
+    do {                                 \
+        if (!(cond)) {                   \
+            mi::set_error("%s", msg);    \
+            return (code);               \
+        }                                \
+    } while (0)
+
+// ------------------------------------------------------------------ runtime hooks
+hipStream_t resolve_stream(mi_stream s);   // NULL -> per-device default stream
+int pool_alloc(void **p, size_t n);
+int pool_free(void *p);
+
+// Small host -> device parameter upload (weights, offset tables) that is
+// ordered on `stream` and released back to the pool when the object dies.
+struct Scratch {
+    void *ptr = nullptr;
+    ~Scratch() { if (ptr) pool_free(ptr); }
+    int upload(const void *host, size_t nbytes, hipStream_t stream);
+};
+
+// ------------------------------------------------------------------ dtype helpers
+static inline size_t dtype_size(int dt)
+{
+    switch (dt) {
+    case MI_BOOL: case MI_I8: case MI_U8: return 1;
+    case MI_I16: case MI_U16: return 2;
+    case MI_I32: case MI_U32: case MI_F32: return 4;
+    default: return 8;
+    }
+}
+
+static inline int64_t numel(const mi_array *a)
+{
+    int64_t n = 1;
+    for (int d = 0; d < a->ndim; d++) n *= a->shape[d];
+    return n;
+}
+
+static inline bool is_contiguous(const mi_array *a)
+{
+    int64_t expect = (int64_t)dtype_size(a->dtype);
+    for (int d = a->ndim - 1; d >= 0; d--) {
+        if (a->shape[d] == 0) return true;
+        if (a->shape[d] != 1 && a->strides[d] != expect) return false;
+        expect *= a->shape[d];
+    }
+    return true;
+}
+
+static inline bool same_shape(const mi_array *a, const mi_array *b)
+{
+    if (a->ndim != b->ndim) return false;
+    for (int d = 0; d < a->ndim; d++)
+        if (a->shape[d] != b->shape[d]) return false;
+    return true;
+}
+
+static inline int check_array(const mi_array *a, const char *name)
+{
+    if (!a || a->ndim < 0 || a->ndim > MI_MAX_NDIM || a->dtype < MI_BOOL || a->dtype > MI_F64) {
+        set_error("invalid array descriptor for %s", name);
+        return MI_ERR_INVALID_ARG;
+    }
+    return MI_OK;
+}
+
+// filters treat 'wrap' as 'grid-wrap' and 'grid-constant' as 'constant'
+static inline int filter_mode(int mode)
+{
+    if (mode == MI_MODE_WRAP) return MI_MODE_GRID_WRAP;
+    if (mode == MI_MODE_GRID_CONSTANT) return MI_MODE_CONSTANT;
+    return mode;
+}
+
+// Call F.template operator()<T>() for the C type behind a dtype code.
+template <typename F>
+static inline int dispatch_dtype(int dt, F &&f)
+{
+    switch (dt) {
+    case MI_BOOL: return f.template operator()<bool>();
+    case MI_I8:   return f.template operator()<int8_t>();
+    case MI_U8:   return f.template operator()<uint8_t>();
+    case MI_I16:  return f.template operator()<int16_t>();
+    case MI_U16:  return f.template operator()<uint16_t>();
+    case MI_I32:  return f.template operator()<int32_t>();
+    case MI_U32:  return f.template operator()<uint32_t>();
+    case MI_I64:  return f.template operator()<int64_t>();
+    case MI_U64:  return f.template operator()<uint64_t>();
+    case MI_F32:  return f.template operator()<float>();
+    case MI_F64:  return f.template operator()<double>();
+    }
+    set_error("unsupported dtype code %d", dt);
+    return MI_ERR_INVALID_ARG;
+}
+
+// ------------------------------------------------------------------ device side
+
+// Boundary index map for filters; -1 = use cval.  C truncated '%' as in the spec.
+template <typename I>
+__device__ __forceinline__ I bmap(I i, I n, int mode)
+{
+    switch (mode) {
+    case MI_MODE_REFLECT:
+        if (i < 0) i = -1 - i;
+        i %= 2 * n;
+        return min(i, 2 * n - 1 - i);
+    case MI_MODE_MIRROR:
+        if (n == 1) return 0;
+        if (i < 0) i = -i;
+        i = 1 + (i - 1) % (2 * n - 2);
+        return min(i, 2 * n - 2 - i);
+    case MI_MODE_NEAREST:
+        return min(max(i, (I)0), n - 1);
+    case MI_MODE_GRID_WRAP:
+        i %= n;
+        return i < 0 ? i + n : i;
+    case MI_MODE_WRAP:
+        if (n == 1) return 0;
+        if (i < 0) i += (n - 1) * (-i / (n - 1) + 1);
+        else if (i > n - 1) i -= (n - 1) * (i / (n - 1));
+        return i;
+    default:
+        return (i < 0 || i >= n) ? (I)-1 : i;
+    }
+}
+
+// double -> T with the C-cast semantics SciPy/x86 shows: truncate toward zero
+// through a wide signed integer, low bits kept (so negative -> unsigned wraps).
+template <typename T>
+__device__ __forceinline__ T cast_from_f64(double a)
+{
+    if constexpr (std::is_same<T, uint64_t>::value) {
+        return a >= 0 ? (T)a : (T)(-(int64_t)(uint64_t)(-a));
+    } else if constexpr (std::is_floating_point<T>::value) {
+        return (T)a;
+    } else {
+        return (T)(int64_t)a;
+    }
+}
+template <>
+__device__ __forceinline__ bool cast_from_f64<bool>(double a) { return a != 0.0; }
+
+__device__ __forceinline__ void store_as(void *p, int64_t i, int dt, double v)
+{
+    switch (dt) {
+    case MI_BOOL: ((uint8_t *)p)[i] = (uint8_t)(v != 0.0); break;
+    case MI_I8:   ((int8_t *)p)[i] = cast_from_f64<int8_t>(v); break;
+    case MI_U8:   ((uint8_t *)p)[i] = cast_from_f64<uint8_t>(v); break;
+    case MI_I16:  ((int16_t *)p)[i] = cast_from_f64<int16_t>(v); break;
+    case MI_U16:  ((uint16_t *)p)[i] = cast_from_f64<uint16_t>(v); break;
+    case MI_I32:  ((int32_t *)p)[i] = cast_from_f64<int32_t>(v); break;
+    case MI_U32:  ((uint32_t *)p)[i] = cast_from_f64<uint32_t>(v); break;
+    case MI_I64:  ((int64_t *)p)[i] = cast_from_f64<int64_t>(v); break;
+    case MI_U64:  ((uint64_t *)p)[i] = cast_from_f64<uint64_t>(v); break;
+    case MI_F32:  ((float *)p)[i] = (float)v; break;
+    default:      ((double *)p)[i] = v; break;
+    }
+}
+
+// SciPy's rounding of interpolation results into integer outputs: half away
+// from zero, clipped to the output range (the reference uses rint(),
+// _interp_kernels.py:580-583; they differ only at exact .5 values).
+__device__ __forceinline__ double interp_round(double t, int dt)
+{
+    double lo, hi;
+    switch (dt) {
+    case MI_I8:  lo = -128.0; hi = 127.0; break;
+    case MI_U8:  lo = 0.0; hi = 255.0; break;
+    case MI_I16: lo = -32768.0; hi = 32767.0; break;
+    case MI_U16: lo = 0.0; hi = 65535.0; break;
+    case MI_I32: lo = -2147483648.0; hi = 2147483647.0; break;
+    case MI_U32: lo = 0.0; hi = 4294967295.0; break;
+    case MI_I64: lo = -9223372036854775808.0; hi = 9223372036854775807.0; break;
+    case MI_U64: lo = 0.0; hi = 18446744073709551615.0; break;
+    default: return t;
+    }
+    if (lo == 0.0) t = t > 0 ? t + 0.5 : 0.0;
+    else t = t > 0 ? t + 0.5 : t - 0.5;
+    return fmin(fmax(t, lo), hi);
+}
+
+__device__ __forceinline__ double load_as_f64(const void *p, int64_t i, int dt)
+{
+    switch (dt) {
+    case MI_BOOL: return (double)(((const uint8_t *)p)[i] != 0);
+    case MI_I8:   return (double)((const int8_t *)p)[i];
+    case MI_U8:   return (double)((const uint8_t *)p)[i];
+    case MI_I16:  return (double)((const int16_t *)p)[i];
+    case MI_U16:  return (double)((const uint16_t *)p)[i];
+    case MI_I32:  return (double)((const int32_t *)p)[i];
+    case MI_U32:  return (double)((const uint32_t *)p)[i];
+    case MI_I64:  return (double)((const int64_t *)p)[i];
+    case MI_U64:  return (double)((const uint64_t *)p)[i];
+    case MI_F32:  return (double)((const float *)p)[i];
+    default:      return ((const double *)p)[i];
+    }
+}
+
+// launch geometry for 1-thread-per-element kernels: cap the grid and stride
+static inline void grid_for(int64_t total, int block, dim3 *grid)
+{
+    int64_t g = (total + block - 1) / block;
+    const int64_t cap = 256 * 32;   // 256 CUs x 32 blocks: plenty of waves, bounded launch
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    *grid = dim3((unsigned)g);
+}
+
+}  // namespace mi

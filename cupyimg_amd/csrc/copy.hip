@@ -1,0 +1,194 @@
+// copy.hip -- strided copy / dtype cast / fill / compare.
+//
+// The reference gets these from CuPy (`output[...] = input`,
+// `temp[...] = output[...]`, `.astype`, `(a == b).all()`:
+// cupyimg/scipy/ndimage/_filters_core.py:94,107,154, morphology.py:313,321).
+// Cast rules follow _filters_core.py:166-187 / SciPy: truncate toward zero,
+// negative -> unsigned wraps.
+#include "common.hpp"
+
+namespace mi {
+
+struct CopyParams {
+    int ndim;
+    int64_t shape[MI_MAX_NDIM];
+    int64_t sstride[MI_MAX_NDIM];   // bytes
+    int64_t dstride[MI_MAX_NDIM];   // bytes
+};
+
+template <typename S, typename D>
+__device__ __forceinline__ D convert(S v, int rhe)
+{
+    if constexpr (std::is_same<S, D>::value) {
+        return v;
+    } else if constexpr (std::is_same<D, bool>::value) {
+        return v != S(0);
+    } else if constexpr (std::is_floating_point<D>::value) {
+        return (D)v;
+    } else if constexpr (std::is_floating_point<S>::value) {
+        double a = (double)v;
+        if (rhe) a = rint(a);
+        return cast_from_f64<D>(a);
+    } else {
+        return (D)v;   // integer -> integer: modular, like C
+    }
+}
+
+template <typename S, typename D>
+__global__ void __launch_bounds__(256) copy_strided(const char *__restrict__ src, char *__restrict__ dst,
+                                                    CopyParams p, int64_t total, int rhe)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i, so = 0, d_o = 0;
+        for (int d = p.ndim - 1; d >= 0; d--) {
+            const int64_t q = r / p.shape[d];
+            const int64_t k = r - q * p.shape[d];
+            so += k * p.sstride[d];
+            d_o += k * p.dstride[d];
+            r = q;
+        }
+        *(D *)(dst + d_o) = convert<S, D>(*(const S *)(src + so), rhe);
+    }
+}
+
+template <typename S, typename D>
+__global__ void __launch_bounds__(256) copy_linear(const S *__restrict__ src, D *__restrict__ dst,
+                                                   int64_t total, int rhe)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = convert<S, D>(src[i], rhe);
+}
+
+template <typename D>
+__global__ void __launch_bounds__(256) fill_strided(char *__restrict__ dst, CopyParams p, int64_t total, double v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i, d_o = 0;
+        for (int d = p.ndim - 1; d >= 0; d--) {
+            const int64_t q = r / p.shape[d];
+            d_o += (r - q * p.shape[d]) * p.dstride[d];
+            r = q;
+        }
+        *(D *)(dst + d_o) = cast_from_f64<D>(v);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) any_diff_kernel(const T *__restrict__ a, const T *__restrict__ b,
+                                                       int64_t total, int32_t *flag)
+{
+    bool diff = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x)
+        diff |= (a[i] != b[i]);
+    if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+int mi_copy(const mi_array *src, const mi_array *dst, int round_half_even, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(src, "src")) || (rc = check_array(dst, "dst"))) return rc;
+    MI_REQUIRE(same_shape(src, dst), MI_ERR_INVALID_ARG, "mi_copy: shapes differ");
+    const int64_t total = numel(src);
+    if (total == 0) return MI_OK;
+    hipStream_t s = resolve_stream(stream);
+    const bool lin = is_contiguous(src) && is_contiguous(dst);
+    if (lin && src->dtype == dst->dtype) {
+        if (src->data != dst->data)
+            MI_HIP(hipMemcpyAsync(dst->data, src->data, (size_t)total * dtype_size(src->dtype),
+                                  hipMemcpyDeviceToDevice, s));
+        return MI_OK;
+    }
+    CopyParams p;
+    p.ndim = src->ndim;
+    for (int d = 0; d < src->ndim; d++) {
+        p.shape[d] = src->shape[d];
+        p.sstride[d] = src->strides[d];
+        p.dstride[d] = dst->strides[d];
+    }
+    dim3 grid;
+    grid_for(total, 256, &grid);
+    return dispatch_dtype(src->dtype, [&]<typename S>() -> int {
+        return dispatch_dtype(dst->dtype, [&]<typename D>() -> int {
+            if (lin)
+                hipLaunchKernelGGL((copy_linear<S, D>), grid, dim3(256), 0, s, (const S *)src->data,
+                                   (D *)dst->data, total, round_half_even);
+            else
+                hipLaunchKernelGGL((copy_strided<S, D>), grid, dim3(256), 0, s,
+                                   (const char *)src->data, (char *)dst->data, p, total,
+                                   round_half_even);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        });
+    });
+}
+
+int mi_fill(const mi_array *dst, double value, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(dst, "dst"))) return rc;
+    const int64_t total = numel(dst);
+    if (total == 0) return MI_OK;
+    hipStream_t s = resolve_stream(stream);
+    if (value == 0.0 && is_contiguous(dst)) {
+        MI_HIP(hipMemsetAsync(dst->data, 0, (size_t)total * dtype_size(dst->dtype), s));
+        return MI_OK;
+    }
+    CopyParams p;
+    p.ndim = dst->ndim;
+    for (int d = 0; d < dst->ndim; d++) {
+        p.shape[d] = dst->shape[d];
+        p.sstride[d] = 0;
+        p.dstride[d] = dst->strides[d];
+    }
+    dim3 grid;
+    grid_for(total, 256, &grid);
+    return dispatch_dtype(dst->dtype, [&]<typename D>() -> int {
+        hipLaunchKernelGGL((fill_strided<D>), grid, dim3(256), 0, s, (char *)dst->data, p, total, value);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    });
+}
+
+int mi_any_diff(const mi_array *a, const mi_array *b, int32_t *flag_dev, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(a, "a")) || (rc = check_array(b, "b"))) return rc;
+    MI_REQUIRE(flag_dev, MI_ERR_INVALID_ARG, "flag_dev is NULL");
+    MI_REQUIRE(same_shape(a, b) && a->dtype == b->dtype, MI_ERR_INVALID_ARG,
+               "mi_any_diff: shape/dtype mismatch");
+    MI_REQUIRE(is_contiguous(a) && is_contiguous(b), MI_ERR_NOT_CONTIGUOUS,
+               "mi_any_diff needs contiguous arrays");
+    const int64_t total = numel(a);
+    if (total == 0) return MI_OK;
+    hipStream_t s = resolve_stream(stream);
+    dim3 grid;
+    grid_for(total, 256, &grid);
+    // compare raw bytes by size class
+    const size_t es = dtype_size(a->dtype);
+    if (es == 1)
+        hipLaunchKernelGGL((any_diff_kernel<uint8_t>), grid, dim3(256), 0, s, (const uint8_t *)a->data,
+                           (const uint8_t *)b->data, total, flag_dev);
+    else if (es == 2)
+        hipLaunchKernelGGL((any_diff_kernel<uint16_t>), grid, dim3(256), 0, s, (const uint16_t *)a->data,
+                           (const uint16_t *)b->data, total, flag_dev);
+    else if (es == 4)
+        hipLaunchKernelGGL((any_diff_kernel<uint32_t>), grid, dim3(256), 0, s, (const uint32_t *)a->data,
+                           (const uint32_t *)b->data, total, flag_dev);
+    else
+        hipLaunchKernelGGL((any_diff_kernel<uint64_t>), grid, dim3(256), 0, s, (const uint64_t *)a->data,
+                           (const uint64_t *)b->data, total, flag_dev);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// correlate_nd.hip -- dense n-D correlate (K1 for correlate/convolve).
+//
+// Reference launch site: cupyimg/scipy/ndimage/filters.py:65-210 -> :441-495
+// -> _filters_core.py:112-156; generated body _filters_core.py:298-324.
+// out[o] = sum over non-zero taps t (C order) of w[t] * ext(in)[o - off + t],
+// accumulated in double from 0 in that order (SciPy's NI_Correlate does the
+// same, so float64 results are bit-identical; built with -ffp-contract=off).
+// In constant mode a tap is cval as soon as one axis is outside (:276-293).
+#include "nd_common.hpp"
+
+namespace mi {
+
+template <typename T, typename Acc, int ND>
+__global__ void __launch_bounds__(256)
+corr_nd_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, NdGeom g, TapTable tt,
+               int64_t total, int mode, double cval)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const Voxel<ND> v = locate<ND>(g, i);
+        Acc acc = 0;
+        if (v.interior) {
+            for (int t = 0; t < tt.ntaps; t++)
+                acc += (Acc)in[i + tt.lin[t]] * (Acc)tt.val[t];
+        } else {
+            for (int t = 0; t < tt.ntaps; t++) {
+                const int64_t pos = tap_pos<ND>(g, v, tt.idx, t, mode);
+                const Acc x = pos < 0 ? (Acc)cval : (Acc)in[pos];
+                acc += x * (Acc)tt.val[t];
+            }
+        }
+        store_as(out, i, out_dt, (double)acc);
+    }
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" int mi_correlate_nd(const mi_array *in, const mi_array *out, const double *weights,
+                               const int64_t *wshape, const int *origins, int mode, double cval,
+                               int acc_f32, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(in->ndim >= 1, MI_ERR_INVALID_ARG, "input must have at least one dimension");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    MI_REQUIRE(weights && wshape && origins, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS,
+               "correlate needs C-contiguous arrays");
+    MI_REQUIRE(in->data != out->data, MI_ERR_INVALID_ARG, "in-place filtering is not supported by the kernel");
+    const int64_t total = numel(in);
+    if (total == 0) return MI_OK;
+    hipStream_t s = resolve_stream(stream);
+    mode = filter_mode(mode);
+
+    TapBuilder tb;
+    if ((rc = tb.init(in, wshape, origins, "weights"))) return rc;
+    tb.fill([&](int64_t k) { return weights[k] != 0.0; }, [&](int64_t k) { return weights[k]; }, true);
+    TapTable tt;
+    if ((rc = tb.upload(&tt, s))) return rc;
+
+    const bool f32ok = in->dtype == MI_F32 || in->dtype == MI_BOOL || dtype_size(in->dtype) <= 2;
+    const bool use_f32 = acc_f32 && f32ok;
+    dim3 grid;
+    grid_for(total, 256, &grid);
+    return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
+        const T *ip = (const T *)in->data;
+#define MI_LAUNCH(ACC, NDV)                                                                         \
+    hipLaunchKernelGGL((corr_nd_kernel<T, ACC, NDV>), grid, dim3(256), 0, s, ip, out->data, out->dtype, \
+                       tb.g, tt, total, mode, cval)
+        if (tb.g.ndim == 3) { if (use_f32) MI_LAUNCH(float, 3); else MI_LAUNCH(double, 3); }
+        else                { if (use_f32) MI_LAUNCH(float, MI_MAX_NDIM); else MI_LAUNCH(double, MI_MAX_NDIM); }
+#undef MI_LAUNCH
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    });
+}

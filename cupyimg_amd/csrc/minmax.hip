@@ -1,0 +1,160 @@
+// minmax.hip -- generic min / max filters (K2): one axis, and n-D footprint
+// with optional non-flat structure (grey erosion / dilation).
+//
+// Reference: cupyimg/scipy/ndimage/filters.py:1373-1557 (launch sites :1505
+// and :1417, kernel :1510-1557), morphology.py:769-884.
+//
+// Integer exactness follows SciPy (the reference's test oracle):
+//   * 1-D passes compare doubles (SciPy line buffers; the reference also
+//     promotes to double there, filters.py:1522-1528);
+//   * the n-D footprint kernel converts cval to the *input* dtype, evaluates
+//     the first set tap in double and adds the structure value to every later
+//     tap in the input dtype (unsigned types wrap), then compares as double.
+#include "nd_common.hpp"
+
+namespace mi {
+
+template <typename T, typename I>
+__global__ void __launch_bounds__(256)
+minmax1d_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, I n, I inner, I total,
+                int size, int off, int mode, double cval, int is_max)
+{
+    for (I i = (I)blockIdx.x * (I)blockDim.x + (I)threadIdx.x; i < total;
+         i += (I)gridDim.x * (I)blockDim.x) {
+        const I l = (i / inner) % n;
+        const I base = i - l * inner;
+        double best = 0.0;
+        for (int k = 0; k < size; k++) {
+            const I j = bmap<I>(l - (I)off + (I)k, n, mode);
+            const double v = j < 0 ? cval : (double)in[base + j * inner];
+            if (k == 0 || (is_max ? v > best : v < best)) best = v;
+        }
+        store_as(out, (int64_t)i, out_dt, best);
+    }
+}
+
+// value + structure in the arithmetic of T (what `_tmp += (_type)ss` does)
+template <typename T>
+__device__ __forceinline__ double add_in_type(double v, double s)
+{
+    if constexpr (std::is_same<T, double>::value) return v + s;
+    else if constexpr (std::is_same<T, float>::value) return (double)((float)v + (float)s);
+    else if constexpr (std::is_same<T, bool>::value) return (double)(((int64_t)v + (int64_t)s) != 0);
+    else return (double)(T)((int64_t)v + (int64_t)cast_from_f64<T>(s));
+}
+
+template <typename T, int ND>
+__global__ void __launch_bounds__(256)
+minmax_nd_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, NdGeom g, TapTable tt,
+                 int64_t total, int mode, double cval, int is_max)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const Voxel<ND> v = locate<ND>(g, i);
+        double best = 0.0;
+        for (int t = 0; t < tt.ntaps; t++) {
+            double x;
+            if (v.interior) {
+                x = (double)in[i + tt.lin[t]];
+            } else {
+                const int64_t pos = tap_pos<ND>(g, v, tt.idx, t, mode);
+                x = pos < 0 ? cval : (double)in[pos];
+            }
+            if (tt.val) x = (t == 0) ? x + tt.val[0] : add_in_type<T>(x, tt.val[t]);
+            if (t == 0 || (is_max ? x > best : x < best)) best = x;
+        }
+        store_as(out, i, out_dt, best);
+    }
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+int mi_minmax1d(const mi_array *in, const mi_array *out, int axis, int size, int origin, int mode,
+                double cval, int is_max, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(in->ndim >= 1, MI_ERR_INVALID_ARG, "input must have at least one dimension");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    MI_REQUIRE(axis >= 0 && axis < in->ndim, MI_ERR_INVALID_ARG, "invalid axis");
+    MI_REQUIRE(size >= 1, MI_ERR_INVALID_ARG, "incorrect filter size");
+    MI_REQUIRE(size / 2 + origin >= 0 && size / 2 + origin < size, MI_ERR_INVALID_ARG, "invalid origin");
+    MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS,
+               "min/max filter needs C-contiguous arrays");
+    MI_REQUIRE(in->data != out->data, MI_ERR_INVALID_ARG, "in-place filtering is not supported by the kernel");
+    const int64_t total = numel(in);
+    if (total == 0) return MI_OK;
+    int64_t n = in->shape[axis], inner = 1;
+    for (int d = axis + 1; d < in->ndim; d++) inner *= in->shape[d];
+    hipStream_t s = resolve_stream(stream);
+    mode = filter_mode(mode);
+    const int off = size / 2 + origin;
+    dim3 grid;
+    grid_for(total, 256, &grid);
+    const bool big = total >= ((int64_t)1 << 31) - 256 * 8192;
+    return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
+        const T *ip = (const T *)in->data;
+        if (big)
+            hipLaunchKernelGGL((minmax1d_kernel<T, int64_t>), grid, dim3(256), 0, s, ip, out->data, out->dtype,
+                               n, inner, total, size, off, mode, cval, is_max);
+        else
+            hipLaunchKernelGGL((minmax1d_kernel<T, int32_t>), grid, dim3(256), 0, s, ip, out->data, out->dtype,
+                               (int32_t)n, (int32_t)inner, (int32_t)total, size, off, mode, cval, is_max);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    });
+}
+
+int mi_minmax_nd(const mi_array *in, const mi_array *out, const uint8_t *footprint,
+                 const double *structure, const int64_t *fshape, const int *origins, int mode,
+                 double cval, int is_max, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(in->ndim >= 1, MI_ERR_INVALID_ARG, "input must have at least one dimension");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    MI_REQUIRE(footprint && fshape && origins, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS,
+               "min/max filter needs C-contiguous arrays");
+    MI_REQUIRE(in->data != out->data, MI_ERR_INVALID_ARG, "in-place filtering is not supported by the kernel");
+    const int64_t total = numel(in);
+    if (total == 0) return MI_OK;
+    hipStream_t s = resolve_stream(stream);
+    mode = filter_mode(mode);
+
+    TapBuilder tb;
+    if ((rc = tb.init(in, fshape, origins, "footprint"))) return rc;
+    tb.fill([&](int64_t k) { return footprint[k] != 0; },
+            [&](int64_t k) { return is_max ? structure[k] : -structure[k]; }, structure != nullptr);
+    MI_REQUIRE(!tb.lin.empty(), MI_ERR_INVALID_ARG, "all-zero footprint is not supported");
+    TapTable tt;
+    if ((rc = tb.upload(&tt, s))) return rc;
+
+    dim3 grid;
+    grid_for(total, 256, &grid);
+    return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
+        // cval is converted to the input dtype first (SciPy: `_cv = (_type)_cval`)
+        double cv;
+        if constexpr (std::is_same<T, double>::value) cv = cval;
+        else if constexpr (std::is_same<T, float>::value) cv = (double)(float)cval;
+        else if constexpr (std::is_same<T, bool>::value) cv = cval != 0.0;
+        else if constexpr (std::is_same<T, uint64_t>::value)
+            cv = (double)(cval >= 0 ? (uint64_t)cval : (uint64_t)(-(int64_t)(uint64_t)(-cval)));
+        else cv = (double)(T)(int64_t)cval;
+        const T *ip = (const T *)in->data;
+        if (tb.g.ndim == 3)
+            hipLaunchKernelGGL((minmax_nd_kernel<T, 3>), grid, dim3(256), 0, s, ip, out->data, out->dtype, tb.g,
+                               tt, total, mode, cv, is_max);
+        else
+            hipLaunchKernelGGL((minmax_nd_kernel<T, MI_MAX_NDIM>), grid, dim3(256), 0, s, ip, out->data,
+                               out->dtype, tb.g, tt, total, mode, cv, is_max);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,2 @@
+"""scipy look-alikes; only ``ndimage`` (the filtering hot path) is provided."""
+from . import ndimage  # noqa: F401

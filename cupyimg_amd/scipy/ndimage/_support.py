@@ -1,0 +1,192 @@
+"""Host-side argument handling shared by the ndimage API functions.
+
+Behaviour (accepted values, defaults, exception types) follows
+cupyimg/scipy/ndimage/_util.py and _filters_core.py:10-109 so the parity
+tests can assert the same errors the reference's tests do; the code is
+organised around the C-ABI rather than around CuPy kernels.
+"""
+import ctypes
+
+import numpy as np
+
+from ... import _lib, core
+from ..._lib import MODE_CODES
+
+_FILTER_MODES = ("reflect", "constant", "nearest", "mirror", "wrap", "grid-mirror", "grid-wrap",
+                 "grid-constant")
+
+
+def check_mode(mode):
+    """_util.py:105-119"""
+    if mode not in _FILTER_MODES:
+        raise RuntimeError("boundary mode not supported (actual: {})".format(mode))
+    return mode
+
+
+def mode_code(mode):
+    return MODE_CODES[check_mode(mode)]
+
+
+def check_origin(origin, width):
+    """_util.py:98-102"""
+    origin = int(origin)
+    if (width // 2 + origin < 0) or (width // 2 + origin >= width):
+        raise ValueError("invalid origin")
+    return origin
+
+
+def fix_sequence_arg(arg, ndim, name, conv=lambda x: x):
+    """_util.py:84-95"""
+    if isinstance(arg, str):
+        return [conv(arg)] * ndim
+    try:
+        arg = iter(arg)
+    except TypeError:
+        return [conv(arg)] * ndim
+    lst = [conv(x) for x in arg]
+    if len(lst) != ndim:
+        raise RuntimeError("{} must have length equal to input rank".format(name))
+    return lst
+
+
+def normalize_sequence(arr, rank):
+    """_util.py:137-151"""
+    if isinstance(arr, core.ndarray):
+        arr = arr.get()
+    if hasattr(arr, "__iter__") and not isinstance(arr, str):
+        normalized = list(arr)
+        if len(normalized) != rank:
+            raise RuntimeError("sequence argument must have length equal to arr rank")
+    else:
+        normalized = [arr] * rank
+    return normalized
+
+
+def normalize_axis(axis, ndim):
+    axis = int(axis)
+    if axis < -ndim or axis >= ndim:
+        raise ValueError("axis {} is out of bounds for array of dimension {}".format(axis, ndim))
+    return axis % ndim if ndim else 0
+
+
+def as_device(a, name="input"):
+    """Device array from a device array or anything array-like on the host."""
+    if isinstance(a, core.ndarray):
+        return a
+    arr = np.asarray(a)
+    if arr.dtype.kind == "c":
+        raise TypeError("Complex type not supported")
+    if arr.dtype == np.float16:
+        arr = arr.astype(np.float32)
+    return core.asarray(arr)
+
+
+def as_host(a, dtype=None):
+    """Small parameter arrays (weights, footprints, matrices) live on the host:
+    they are tiny and the reference's device syncs on them
+    (_filters_core.py:35,39; morphology.py:133,274) are avoided that way."""
+    if isinstance(a, core.ndarray):
+        a = a.get()
+    return np.asarray(a, dtype=dtype)
+
+
+def is_integer_output(output, input):
+    """_util.py:4-9"""
+    if output is None:
+        return input.dtype.kind in "iu"
+    if isinstance(output, core.ndarray):
+        return output.dtype.kind in "iu"
+    return np.dtype(output).kind in "iu"
+
+
+def check_cval(mode, cval, integer_output):
+    """_util.py:12-17"""
+    if mode == "constant" and integer_output and not np.isfinite(cval):
+        raise NotImplementedError("Non-finite cval is not supported for outputs with integer dtype.")
+
+
+def get_output(output, input, shape=None):
+    """Resolve the `output` argument (_util.py:43-81): a device array is
+    shape-checked and used as is; a dtype or None allocates.  Unlike the
+    reference nothing is zero-filled -- every kernel writes every element."""
+    if shape is None:
+        shape = input.shape
+    if isinstance(output, core.ndarray):
+        if output.shape != tuple(shape):
+            raise ValueError("output shape is not correct")
+        return output
+    if isinstance(output, np.ndarray):
+        raise TypeError("output must be a device array (cupyimg_amd.ndarray) or a dtype")
+    dtype = input.dtype if output is None else np.dtype(output)
+    if dtype.kind == "c":
+        raise TypeError("Complex type not supported")
+    return core.empty(shape, dtype)
+
+
+def acc_flag(dtype_mode):
+    if dtype_mode == "ndimage":
+        return 0
+    if dtype_mode == "float":
+        return 1
+    raise ValueError("dtype_mode={} is not supported".format(dtype_mode))
+
+
+def run_kernel(input, output, launch):
+    """Run ``launch(src, dst)`` with contiguous, non-overlapping src/dst and
+    deliver the result into `output` (which may be a strided view or alias the
+    input; the reference handles the latter with a temp + copy,
+    _filters_core.py:148-155)."""
+    src = core.ascontiguousarray(input)
+    if output._is_c_contiguous() and not core.shares_memory(output, src):
+        launch(src, output)
+        return output
+    tmp = core.empty(output.shape, output.dtype)
+    launch(src, tmp)
+    output[...] = tmp
+    return output
+
+
+def run_passes(input, output, passes):
+    """Chain of 1-D passes ``f(src, dst)`` ping-ponging between `output` and
+    one scratch volume so that the last pass lands in `output` and no
+    copy-back is needed (the reference pays a zero-fill plus a full copy per
+    in-place pass, _filters_core.py:148-155; filters.py:651-662)."""
+    n = len(passes)
+    if n == 0:
+        output[...] = input
+        return output
+    src = core.ascontiguousarray(input)
+    direct = output._is_c_contiguous()
+    final = output if direct else core.empty(output.shape, output.dtype)
+    if core.shares_memory(final, src):
+        src = src.copy()
+    scratch = core.empty(output.shape, output.dtype) if n > 1 else None
+    for i, f in enumerate(passes):
+        dst = final if (n - 1 - i) % 2 == 0 else scratch
+        f(src, dst)
+        src = dst
+    if not direct:
+        output[...] = final
+    return output
+
+
+def c_doubles(values):
+    arr = np.ascontiguousarray(values, dtype=np.float64)
+    return arr, arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def c_ints(values):
+    return (ctypes.c_int * max(len(values), 1))(*[int(v) for v in values])
+
+
+def c_int64s(values):
+    return (ctypes.c_int64 * max(len(values), 1))(*[int(v) for v in values])
+
+
+def lib():
+    return _lib.load()
+
+
+check = _lib.check
+MODE_CODES = MODE_CODES
+Unsupported = _lib.Unsupported

@@ -1,0 +1,286 @@
+"""scipy.ndimage morphology on device arrays.
+
+Same signatures and semantics as cupyimg/scipy/ndimage/morphology.py
+(binary_erosion :334, binary_dilation :396, binary_opening :464,
+binary_closing :540, binary_hit_or_miss :616, binary_propagation :684,
+binary_fill_holes :726, grey_erosion :769, grey_dilation :818,
+generate_binary_structure :174, iterate_structure :136).
+
+Differences in mechanism, not in results: structuring elements stay on the
+host (no device sync to inspect them, cf. morphology.py:133,274); iterated
+erosion/dilation keeps the "did anything change" flag on the device and reads
+back a single int32 per iteration instead of reducing a full-volume comparison
+on the host (morphology.py:313,321).
+"""
+import ctypes
+import operator
+
+import numpy as np
+
+from ... import core
+from . import _support as S
+from . import filters
+
+__all__ = [
+    "binary_erosion", "binary_dilation", "binary_opening", "binary_closing", "binary_hit_or_miss",
+    "binary_propagation", "binary_fill_holes", "grey_erosion", "grey_dilation",
+    "generate_binary_structure", "iterate_structure",
+]
+
+
+def generate_binary_structure(rank, connectivity):
+    """Structuring element with squared-distance connectivity
+    (morphology.py:174-201); returned as a host bool array."""
+    if connectivity < 1:
+        connectivity = 1
+    if rank < 1:
+        return np.array(True, dtype=bool)
+    dist = np.abs(np.indices([3] * rank) - 1).sum(axis=0)
+    return dist <= connectivity
+
+
+def iterate_structure(structure, iterations, origin=None):
+    """Dilate a structure with itself ``iterations - 1`` times
+    (morphology.py:136-171)."""
+    structure = S.as_host(structure)
+    if iterations < 2:
+        return structure.copy()
+    ni = iterations - 1
+    shape = [ii + ni * (ii - 1) for ii in structure.shape]
+    pos = [ni * (structure.shape[ii] // 2) for ii in range(len(shape))]
+    slc = tuple(slice(pos[ii], pos[ii] + structure.shape[ii], None) for ii in range(len(shape)))
+    out = np.zeros(shape, bool)
+    out[slc] = structure != 0
+    out = binary_dilation(out, structure, iterations=ni).get()
+    if origin is None:
+        return out
+    origin = S.fix_sequence_arg(origin, structure.ndim, "origin", int)
+    origin = [iterations * o for o in origin]
+    return out, origin
+
+
+def _binary_erosion(input, structure, iterations, mask, output, border_value, origin, invert,
+                    brute_force=True):
+    """morphology.py:204-331"""
+    try:
+        iterations = operator.index(iterations)
+    except TypeError:
+        raise TypeError("iterations parameter should be an integer")
+    if isinstance(input, np.ndarray) and input.dtype.kind == "c":
+        raise TypeError("Complex type not supported")
+    input = S.as_device(input)
+    if structure is None:
+        structure = generate_binary_structure(input.ndim, 1)
+    else:
+        structure = S.as_host(structure).astype(bool)
+    if structure.ndim != input.ndim:
+        raise RuntimeError("structure and input must have same dimensionality")
+    if structure.size < 1:
+        raise RuntimeError("structure must not be empty")
+    if mask is not None:
+        mask = S.as_device(mask)
+        if mask.shape != input.shape:
+            raise RuntimeError("mask and input must have equal sizes")
+        mask = core.ascontiguousarray(mask if mask.dtype == np.bool_ else mask.astype(np.bool_))
+    origin = S.fix_sequence_arg(origin, input.ndim, "origin", int)
+
+    if isinstance(output, core.ndarray):
+        if output.dtype.kind == "c":
+            raise TypeError("Complex output type not supported")
+    else:
+        output = bool
+    output = S.get_output(output, input)
+    if structure.ndim == 0:
+        # 0-d special case (morphology.py:262-268)
+        res = input.astype(np.bool_)
+        if not bool(structure):
+            res = core.asarray(~res.get())
+        output[...] = res
+        return output
+    for o, w in zip(origin, structure.shape):
+        S.check_origin(o, w)
+    if input.size == 0:
+        return output
+
+    center = tuple(oo + ss // 2 for ss, oo in zip(structure.shape, origin))
+    center_is_true = bool(structure[center])
+    if iterations != 1 and center_is_true and not brute_force:
+        raise NotImplementedError("only brute_force iteration has been implemented")
+
+    st = np.ascontiguousarray(structure, dtype=np.uint8)
+    stp = st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    sshape = S.c_int64s(st.shape)
+    org = S.c_ints(origin)
+    mdesc = mask._desc() if mask is not None else None
+    lib = S.lib()
+
+    def launch(src, dst, flag_ptr=None):
+        a, b = src._desc(), dst._desc()
+        S.check(lib.mi_binary_erosion(ctypes.byref(a), ctypes.byref(b), stp, sshape, org,
+                                      ctypes.byref(mdesc) if mdesc is not None else None,
+                                      int(bool(border_value)), int(invert), flag_ptr, None))
+
+    src = core.ascontiguousarray(input)
+    direct = output._is_c_contiguous() and not core.shares_memory(output, src)
+    final = output if direct else core.empty(output.shape, output.dtype)
+
+    if iterations == 1:
+        launch(src, final)
+    else:
+        # brute-force ping-pong (morphology.py:301-327) with an on-device
+        # "changed" flag; buffers are arranged so the last write hits `final`
+        # whenever the iteration count is known.
+        flag = core.zeros((1,), np.int32)
+        other = core.empty(final.shape, final.dtype)
+        bufs = [final, other]
+        which = 0 if (iterations >= 1 and iterations & 1) else 1
+        cur = src
+        it = 0
+        while True:
+            dst = bufs[which]
+            need_flag = iterations < 1
+            if need_flag:
+                flag.fill(0)
+            launch(cur, dst, ctypes.c_void_p(flag.ptr) if need_flag else None)
+            it += 1
+            cur = dst
+            which ^= 1
+            if iterations >= 1:
+                if it >= iterations:
+                    break
+            else:
+                if int(flag.get()[0]) == 0:
+                    break
+        if cur is not final:
+            final[...] = cur
+    if not direct:
+        output[...] = final
+    return output
+
+
+def binary_erosion(input, structure=None, iterations=1, mask=None, output=None, border_value=0,
+                   origin=0, brute_force=False):
+    """Multidimensional binary erosion (morphology.py:334-393)."""
+    return _binary_erosion(input, structure, iterations, mask, output, border_value, origin, 0,
+                           brute_force)
+
+
+def binary_dilation(input, structure=None, iterations=1, mask=None, output=None, border_value=0,
+                    origin=0, brute_force=False):
+    """Multidimensional binary dilation (morphology.py:396-461): erosion of
+    the complement with the mirrored structure."""
+    ndim = input.ndim if hasattr(input, "ndim") else np.ndim(input)
+    if structure is None:
+        structure = generate_binary_structure(ndim, 1)
+    structure = S.as_host(structure)
+    origin = S.fix_sequence_arg(origin, ndim, "origin", int)
+    structure = structure[tuple([slice(None, None, -1)] * structure.ndim)]
+    for ii in range(len(origin)):
+        origin[ii] = -origin[ii]
+        if ii < structure.ndim and not structure.shape[ii] & 1:
+            origin[ii] -= 1
+    return _binary_erosion(input, structure, iterations, mask, output, border_value, origin, 1,
+                           brute_force)
+
+
+def binary_opening(input, structure=None, iterations=1, output=None, origin=0, mask=None,
+                   border_value=0, brute_force=False):
+    """Erosion followed by dilation (morphology.py:464-537)."""
+    input = S.as_device(input)
+    if structure is None:
+        structure = generate_binary_structure(input.ndim, 1)
+    tmp = binary_erosion(input, structure, iterations, mask, None, border_value, origin, brute_force)
+    return binary_dilation(tmp, structure, iterations, mask, output, border_value, origin, brute_force)
+
+
+def binary_closing(input, structure=None, iterations=1, output=None, origin=0, mask=None,
+                   border_value=0, brute_force=False):
+    """Dilation followed by erosion (morphology.py:540-613)."""
+    input = S.as_device(input)
+    if structure is None:
+        structure = generate_binary_structure(input.ndim, 1)
+    tmp = binary_dilation(input, structure, iterations, mask, None, border_value, origin, brute_force)
+    return binary_erosion(tmp, structure, iterations, mask, output, border_value, origin, brute_force)
+
+
+def _logical(a, fn):
+    """tiny element-wise helpers on bool volumes, via the host only for the
+    composite operators below (not on the hot path)."""
+    return core.asarray(fn(a.get()))
+
+
+def binary_hit_or_miss(input, structure1=None, structure2=None, output=None, origin1=0, origin2=None):
+    """Hit-or-miss transform (morphology.py:616-681)."""
+    input = S.as_device(input)
+    if structure1 is None:
+        structure1 = generate_binary_structure(input.ndim, 1)
+    structure1 = S.as_host(structure1)
+    if structure2 is None:
+        structure2 = np.logical_not(structure1)
+    origin1 = S.fix_sequence_arg(origin1, input.ndim, "origin1", int)
+    if origin2 is None:
+        origin2 = origin1
+    else:
+        origin2 = S.fix_sequence_arg(origin2, input.ndim, "origin2", int)
+    tmp1 = _binary_erosion(input, structure1, 1, None, None, 0, origin1, 0, False)
+    result = _binary_erosion(input, structure2, 1, None, None, 0, origin2, 1, False)
+    res = core.asarray(np.logical_and(tmp1.get(), np.logical_not(result.get())))
+    if isinstance(output, core.ndarray):
+        output[...] = res
+        return None
+    return res
+
+
+def binary_propagation(input, structure=None, mask=None, output=None, border_value=0, origin=0):
+    """Dilation until stable inside ``mask`` (morphology.py:684-723)."""
+    return binary_dilation(input, structure, -1, mask, output, border_value, origin, brute_force=True)
+
+
+def binary_fill_holes(input, structure=None, output=None, origin=0):
+    """Fill holes in binary objects (morphology.py:726-766)."""
+    input = S.as_device(input)
+    mask = core.asarray(np.logical_not(input.get() != 0))
+    tmp = core.zeros(mask.shape, np.bool_)
+    res = binary_dilation(tmp, structure, -1, mask, None, 1, origin, brute_force=True)
+    res = core.asarray(np.logical_not(res.get()))
+    if isinstance(output, core.ndarray):
+        output[...] = res
+        return None
+    return res
+
+
+def grey_erosion(input, size=None, footprint=None, structure=None, output=None, mode="reflect",
+                 cval=0.0, origin=0):
+    """Greyscale erosion = minimum filter (morphology.py:769-815)."""
+    if size is None and footprint is None and structure is None:
+        raise ValueError("size, footprint or structure must be specified")
+    return filters._min_or_max_filter(input, size, footprint, structure, output, mode, cval, origin, "min")
+
+
+def grey_dilation(input, size=None, footprint=None, structure=None, output=None, mode="reflect",
+                  cval=0.0, origin=0):
+    """Greyscale dilation = maximum filter with footprint / structure mirrored
+    on every axis and the origin negated, minus one for even extents
+    (morphology.py:818-884)."""
+    if size is None and footprint is None and structure is None:
+        raise ValueError("size, footprint or structure must be specified")
+    ndim = input.ndim if hasattr(input, "ndim") else np.ndim(input)
+    mirror = lambda a: a[tuple([slice(None, None, -1)] * a.ndim)]
+    if structure is not None:
+        structure = mirror(S.as_host(structure))
+    if footprint is not None:
+        footprint = mirror(S.as_host(footprint))
+    origin = S.fix_sequence_arg(origin, ndim, "origin", int)
+    for i in range(len(origin)):
+        origin[i] = -origin[i]
+        if footprint is not None:
+            sz = footprint.shape[i]
+        elif structure is not None:
+            sz = structure.shape[i]
+        elif np.isscalar(size):
+            sz = size
+        else:
+            sz = size[i]
+        if sz % 2 == 0:
+            origin[i] -= 1
+    return filters._min_or_max_filter(input, size, footprint, structure, output, mode, cval, origin, "max")

@@ -1,0 +1,243 @@
+/*
+ * mi355img.h -- C-ABI of libmi355img.so, the MI355X (gfx950) n-D image
+ * filtering engine behind cupyimg_amd.
+ *
+ * The reference (mritools/cupyimg) has no FFI: its seam is Python-level.  Every
+ * hot-path API function funnels into one of three launch sites, and each entry
+ * point below replaces exactly one of them (reference file:line in the
+ * comment above each declaration):
+ *
+ *   _filters_core._call_kernel(kernel, input, weights, output, structure)
+ *       cupyimg/scipy/ndimage/_filters_core.py:112-156   (K1, K2 kernels)
+ *   erode_kernel(input, structure[, mask], output)
+ *       cupyimg/scipy/ndimage/morphology.py:292-322      (K4)
+ *   kern(filtered, coordinates | matrix, output)
+ *       cupyimg/scipy/ndimage/interpolation.py:393,545,560 (K5)
+ *
+ * plus the part of CuPy the reference leans on for memory/streams (L0 in
+ * SURVEY.md), which this library owns itself: no CuPy, no PyTorch.
+ *
+ * Conventions
+ *   - plain C linkage, POD arguments only; every function returns int:
+ *       0 = ok, < 0 = MI_ERR_*, > 0 = hipError_t of the failing HIP call.
+ *     mi_last_error() returns a thread-local human-readable message.
+ *   - device arrays are described by mi_array (pointer + dtype + shape +
+ *     byte strides).  Compute entry points require C-contiguous arrays
+ *     (MI_ERR_NOT_CONTIGUOUS otherwise); mi_copy handles arbitrary strides
+ *     and dtype conversion.
+ *   - the caller owns all buffers; the library owns only its scratch pool,
+ *     streams/events it created and RCCL communicators.
+ *   - small host-side parameter arrays (weights, footprints, matrices) are
+ *     copied during the call; they may be freed as soon as it returns.
+ *   - all work is enqueued on `stream` (NULL = the library's per-device
+ *     default stream) and is asynchronous with respect to the host.
+ *   - thread-safe: no unsynchronised global state (the reference's tests call
+ *     filters from 4 threads, tests/test_filters.py:354-412).
+ */
+#ifndef MI355IMG_H
+#define MI355IMG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_MAX_NDIM 8
+#define MI_VERSION 100 /* 0.1.0 */
+
+typedef enum mi_dtype {
+    MI_BOOL = 0, MI_I8 = 1, MI_U8 = 2, MI_I16 = 3, MI_U16 = 4, MI_I32 = 5,
+    MI_U32 = 6, MI_I64 = 7, MI_U64 = 8, MI_F32 = 9, MI_F64 = 10
+} mi_dtype;
+
+/* scipy.ndimage boundary modes (cupyimg/scipy/ndimage/_util.py:105-119).
+ * For filters WRAP == GRID_WRAP and GRID_CONSTANT == CONSTANT
+ * (_filters_core.py:224-225); interpolation distinguishes them. */
+typedef enum mi_mode {
+    MI_MODE_REFLECT = 0,      /* also 'grid-mirror' */
+    MI_MODE_CONSTANT = 1,
+    MI_MODE_NEAREST = 2,
+    MI_MODE_MIRROR = 3,
+    MI_MODE_WRAP = 4,
+    MI_MODE_GRID_WRAP = 5,
+    MI_MODE_GRID_CONSTANT = 6
+} mi_mode;
+
+enum {
+    MI_OK = 0,
+    MI_ERR_INVALID_ARG = -1,
+    MI_ERR_UNSUPPORTED = -2,   /* valid request, no kernel for it (host falls back) */
+    MI_ERR_NOMEM = -3,
+    MI_ERR_NOT_CONTIGUOUS = -4,
+    MI_ERR_RCCL = -5,
+    MI_ERR_INTERNAL = -6
+};
+
+typedef struct mi_array {
+    void *data;                    /* device pointer */
+    int32_t dtype;                 /* mi_dtype */
+    int32_t ndim;                  /* 0..MI_MAX_NDIM */
+    int64_t shape[MI_MAX_NDIM];
+    int64_t strides[MI_MAX_NDIM];  /* bytes */
+} mi_array;
+
+typedef void *mi_stream; /* hipStream_t */
+typedef void *mi_event;  /* hipEvent_t  */
+typedef void *mi_comm;   /* ncclComm_t  */
+
+/* ------------------------------------------------------------------ */
+/* runtime: replaces the CuPy runtime the reference imports             */
+/* (cupyimg/__init__.py:23-28; cupy.zeros at _util.py:80)               */
+/* ------------------------------------------------------------------ */
+int mi_version(void);
+const char *mi_last_error(void);
+int mi_device_count(int *count);
+int mi_set_device(int device);
+int mi_get_device(int *device);
+int mi_device_name(int device, char *buf, size_t buflen);
+int mi_device_attr(int device, int *cu_count, int *clock_khz, size_t *total_mem);
+int mi_mem_info(size_t *free_bytes, size_t *total_bytes);
+
+/* pooled device memory (size-bucketed free lists, mutex guarded) */
+int mi_malloc(void **ptr, size_t nbytes);
+int mi_free(void *ptr);
+int mi_pool_trim(void);
+int mi_pool_stats(size_t *bytes_in_use, size_t *bytes_cached);
+
+int mi_memcpy_h2d(void *dst, const void *src, size_t nbytes, mi_stream stream);
+int mi_memcpy_d2h(void *dst, const void *src, size_t nbytes, mi_stream stream); /* syncs */
+int mi_memcpy_d2d(void *dst, const void *src, size_t nbytes, mi_stream stream);
+int mi_memcpy_peer(void *dst, int dst_dev, const void *src, int src_dev, size_t nbytes,
+                   mi_stream stream);
+int mi_memset(void *dst, int value, size_t nbytes, mi_stream stream);
+
+int mi_stream_create(mi_stream *stream);
+int mi_stream_destroy(mi_stream stream);
+int mi_stream_sync(mi_stream stream);
+int mi_default_stream(mi_stream *stream);
+int mi_device_sync(void);
+int mi_event_create(mi_event *event);
+int mi_event_destroy(mi_event event);
+int mi_event_record(mi_event event, mi_stream stream);
+int mi_event_sync(mi_event event);
+int mi_event_elapsed_ms(mi_event start, mi_event stop, float *ms);
+
+/* ------------------------------------------------------------------ */
+/* array plumbing: `output[...] = input` and dtype casts               */
+/* (_filters_core.py:94,107,154; cast<> at :166-187)                    */
+/* ------------------------------------------------------------------ */
+/* dst[...] = (dst dtype) src, arbitrary strides, same shape.  Float ->
+ * integer conversion truncates toward zero; negative -> unsigned wraps.
+ * round_half_even != 0 applies rint() first (interpolation integer outputs,
+ * _interp_kernels.py:580-583). */
+int mi_copy(const mi_array *src, const mi_array *dst, int round_half_even, mi_stream stream);
+int mi_fill(const mi_array *dst, double value, mi_stream stream);
+/* *flag_dev (device int32) |= any(a != b); a, b contiguous, same dtype/shape */
+int mi_any_diff(const mi_array *a, const mi_array *b, int32_t *flag_dev, mi_stream stream);
+
+/* ------------------------------------------------------------------ */
+/* K1: correlate family                                                 */
+/* ------------------------------------------------------------------ */
+/* One separable pass: out[.., o, ..] = sum_k w[k] * ext(in)[.., o - (wlen/2 + origin) + k, ..]
+ * Replaces the K1 launch reached from correlate1d/convolve1d/gaussian_filter1d
+ * (filters.py:213-283 -> :441-495 -> _filters_core.py:112-156).
+ * acc_f32 != 0 selects float32 accumulation (dtype_mode="float",
+ * _util.py:28-40), only honoured when promote(in, f32) == f32. */
+int mi_correlate1d(const mi_array *in, const mi_array *out, int axis, const double *weights,
+                   int wlen, int origin, int mode, double cval, int acc_f32, mi_stream stream);
+
+/* Box mean along one axis with SciPy's sum-then-divide arithmetic (exact for
+ * integer data); replaces the K1 launch behind uniform_filter1d
+ * (filters.py:549-599). */
+int mi_uniform_filter1d(const mi_array *in, const mi_array *out, int axis, int size, int origin,
+                        int mode, double cval, mi_stream stream);
+
+/* Fused separable 3-D filter, float32 -> float32, all three 1-D passes in one
+ * launch (8 B/voxel of HBM traffic).  Replaces the three K1 launches plus the
+ * zero-fills and copy-backs of uniform_filter / gaussian_filter
+ * (filters.py:602-665, :725-792; _filters_core.py:148-155).
+ * weights[a] (host, wlen[a] doubles) may be NULL for an axis that is not
+ * filtered.  is_box != 0: all given weights are 1/wlen (sum-then-scale path).
+ * Returns MI_ERR_UNSUPPORTED when no fused kernel covers the request. */
+int mi_separable3d_f32(const mi_array *in, const mi_array *out, const double *const weights[3],
+                       const int wlen[3], const int origin[3], const int mode[3], double cval,
+                       int is_box, mi_stream stream);
+
+/* Dense n-D stencil (filters.py:65-210 -> :441-495): weights is a host array
+ * of prod(wshape) doubles in C order, already flipped for convolution by the
+ * caller; zero weights are skipped (_filters_core.py:242-246). */
+int mi_correlate_nd(const mi_array *in, const mi_array *out, const double *weights,
+                    const int64_t *wshape, const int *origins, int mode, double cval,
+                    int acc_f32, mi_stream stream);
+
+/* ------------------------------------------------------------------ */
+/* K2: min / max family (grey morphology)                               */
+/* ------------------------------------------------------------------ */
+/* 1-D running min/max (filters.py:1478-1507), compared in double like SciPy's
+ * line buffers. */
+int mi_minmax1d(const mi_array *in, const mi_array *out, int axis, int size, int origin,
+                int mode, double cval, int is_max, mi_stream stream);
+
+/* Fused separable 3-D min/max for uint8 volumes (grey_erosion/grey_dilation
+ * with `size`, morphology.py:769-884 -> filters.py:1385-1396): one launch,
+ * 2 B/voxel.  MI_ERR_UNSUPPORTED when not applicable. */
+int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int size[3],
+                   const int origin[3], const int mode[3], int cval, int is_max,
+                   mi_stream stream);
+
+/* n-D footprint (+ optional non-flat structure) min/max
+ * (filters.py:1398-1419, kernel :1510-1557).  footprint: host uint8
+ * prod(fshape); structure: host doubles or NULL. */
+int mi_minmax_nd(const mi_array *in, const mi_array *out, const uint8_t *footprint,
+                 const double *structure, const int64_t *fshape, const int *origins, int mode,
+                 double cval, int is_max, mi_stream stream);
+
+/* ------------------------------------------------------------------ */
+/* K4: binary erosion / dilation                                        */
+/* ------------------------------------------------------------------ */
+/* One iteration of erode_kernel (morphology.py:41-128, launched at :292-322).
+ * `in` any real dtype (nonzero = true); `out` any real dtype (0/1 written).
+ * structure: host uint8 prod(sshape).  mask may be NULL.  invert = 1 turns
+ * it into dilation (morphology.py:443-461).  If changed_dev is not NULL,
+ * *changed_dev (device int32) is OR-ed with 1 when any output voxel differs
+ * from the input voxel -- the on-device replacement for the host-side
+ * `(tmp_in == tmp_out).all()` sync at morphology.py:313,321. */
+int mi_binary_erosion(const mi_array *in, const mi_array *out, const uint8_t *structure,
+                      const int64_t *sshape, const int *origins, const mi_array *mask,
+                      int border_value, int invert, int32_t *changed_dev, mi_stream stream);
+
+/* ------------------------------------------------------------------ */
+/* K5: interpolation, spline order 0 and 1                              */
+/* ------------------------------------------------------------------ */
+/* coords: (ndim, *out.shape) C-contiguous f32 or f64
+ * (interpolation.py:271-394, kernel _interp_kernels.py:595-621). */
+int mi_map_coordinates(const mi_array *in, const mi_array *coords, const mi_array *out,
+                       int order, int mode, double cval, mi_stream stream);
+
+/* matrix: host doubles (ndim, ndim+1) row-major, c = M[:, :n] @ o + M[:, n]
+ * (interpolation.py:397-561, kernel _interp_kernels.py:723-751; the diagonal
+ * zoom+shift form :655-688 is the same entry point with a diagonal M). */
+int mi_affine_transform(const mi_array *in, const mi_array *out, const double *matrix,
+                        int order, int mode, double cval, mi_stream stream);
+
+/* ------------------------------------------------------------------ */
+/* multi-GPU: slab partition on axis 0, halo exchange over RCCL/xGMI    */
+/* (new design; the reference is single-GPU)      */
+/* ------------------------------------------------------------------ */
+#define MI_UNIQUE_ID_BYTES 128
+int mi_comm_unique_id(char id[MI_UNIQUE_ID_BYTES]);
+int mi_comm_init_rank(mi_comm *comm, int nranks, int rank, const char id[MI_UNIQUE_ID_BYTES]);
+int mi_comm_destroy(mi_comm comm);
+/* Slab buffer layout on every rank: [lo halo planes][n local planes][hi halo planes],
+ * plane_bytes each.  Sends the first `hi` / last `lo` local planes to the
+ * previous / next rank and receives into the halo regions, all inside one
+ * ncclGroupStart/End.  prev/next < 0 means no neighbour (global edge). */
+int mi_halo_exchange(mi_comm comm, void *slab, size_t plane_bytes, int64_t n_local, int lo,
+                     int hi, int prev_rank, int next_rank, mi_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355IMG_H */

@@ -234,25 +234,20 @@ def uniform_filter(input, size=3, output=None, mode="reflect", cval=0.0, origin=
 
 
 def gaussian_kernel1d(sigma, order, radius):
-    """filters.py:795-825 (host-side, float64)."""
+    """filters.py:795-825 (host-side, float64): Gaussian times the Hermite-like
+    polynomial obtained from q_{k+1} = q_k' - x q_k / sigma^2."""
     if order < 0:
         raise ValueError("order must be non-negative")
-    sigma2 = sigma * sigma
     x = np.arange(-radius, radius + 1)
-    phi = np.exp(-0.5 / sigma2 * x ** 2)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
     phi = phi / phi.sum()
     if order == 0:
         return phi
-    expo = np.arange(order + 1)
-    q = np.zeros(order + 1)
-    q[0] = 1
-    D = np.diag(expo[1:], 1)
-    P = np.diag(np.ones(order) / -sigma2, -1)
-    Q = D + P
+    q = np.poly1d([1.0])
+    mx = np.poly1d([-1.0 / (sigma * sigma), 0.0])
     for _ in range(order):
-        q = Q.dot(q)
-    q = (x[:, None] ** expo).dot(q)
-    return q * phi
+        q = q.deriv() + q * mx
+    return q(x.astype(np.float64)) * phi
 
 
 def gaussian_filter1d(input, sigma, axis=-1, order=0, output=None, mode="reflect",

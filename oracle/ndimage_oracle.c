@@ -569,13 +569,37 @@ int orc_affine_transform(const double *in, const int64_t *shape, int ndim,
 #define CAST_LOOP(T, EXPR) do { T *d = (T *)dst; \
     for (int64_t i = 0; i < n; i++) { double a = src[i]; d[i] = (EXPR); } } while (0)
 
-int orc_cast_from_f64(const double *src, void *dst, int64_t n, int dtype, int round_half_even)
+/* SciPy's rounding for integer outputs of the interpolation routines
+ * (CASE_INTERP_OUT_INT / _UINT in ni_interpolation.c): half away from zero,
+ * then clipped to the output range.  The reference uses rint()
+ * (_interp_kernels.py:580-583), which differs only at exact .5 values. */
+static double interp_round(double t, int dtype)
 {
-    if (round_half_even) {
-        /* integer outputs of the interpolation kernels use rint() */
+    double lo, hi;
+    switch (dtype) {
+    case ORC_I8:  lo = -128.0; hi = 127.0; break;
+    case ORC_U8:  lo = 0.0; hi = 255.0; break;
+    case ORC_I16: lo = -32768.0; hi = 32767.0; break;
+    case ORC_U16: lo = 0.0; hi = 65535.0; break;
+    case ORC_I32: lo = -2147483648.0; hi = 2147483647.0; break;
+    case ORC_U32: lo = 0.0; hi = 4294967295.0; break;
+    case ORC_I64: lo = -9223372036854775808.0; hi = 9223372036854775807.0; break;
+    case ORC_U64: lo = 0.0; hi = 18446744073709551615.0; break;
+    default: return t;
+    }
+    if (lo == 0.0) t = t > 0 ? t + 0.5 : 0.0;
+    else t = t > 0 ? t + 0.5 : t - 0.5;
+    if (t > hi) t = hi;
+    if (t < lo) t = lo;
+    return t;
+}
+
+int orc_cast_from_f64(const double *src, void *dst, int64_t n, int dtype, int interp_rounding)
+{
+    if (interp_rounding) {
         double *tmp = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
         if (!tmp) return -3;
-        for (int64_t i = 0; i < n; i++) tmp[i] = rint(src[i]);
+        for (int64_t i = 0; i < n; i++) tmp[i] = interp_round(src[i], dtype);
         int rc = orc_cast_from_f64(tmp, dst, n, dtype, 0);
         free(tmp);
         return rc;

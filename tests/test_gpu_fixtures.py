@@ -1,0 +1,57 @@
+"""HIP path vs the committed SciPy 1.15.3 fixtures, through the C-ABI
+(cupyimg_amd.scipy.ndimage -> libmi355img.so).  GPU only.
+
+Tolerances (stated, per BASELINE.json north_star):
+  * integer / bool outputs and all morphology: bit-exact;
+  * correlate1d / convolve1d / correlate / convolve: bit-exact (the kernels
+    accumulate in double in SciPy's summation order, built without FMA
+    contraction);
+  * uniform / gaussian with float output: max|y - y_ref| <= 1e-6 * max|y_ref|
+    for float32 (the fused kernel computes in float32), 1e-12 for float64;
+  * interpolation: 1e-12 absolute-relative for float outputs.
+"""
+import numpy as np
+import pytest
+
+from _cases import call, compare, load_scipy_fixtures, maxnorm_rel
+
+pytestmark = pytest.mark.gpu
+
+Z, CASES, META = load_scipy_fixtures()
+FAMILIES = sorted({c["family"] for c in CASES})
+
+
+def _check(c, got, expected):
+    what = "case {} {} {}".format(c["id"], c["func"], c["kwargs"])
+    fam = c["family"]
+    assert got.shape == expected.shape and got.dtype == expected.dtype, what
+    if expected.dtype.kind in "iub":
+        compare(got, expected, None, what)
+    elif fam in ("uniform", "gaussian") or fam.startswith("baseline_"):
+        if fam == "baseline_D":
+            compare(got, expected, c["tol"], what)
+        else:
+            lim = 1e-6 if expected.dtype == np.float32 else 1e-12
+            r = maxnorm_rel(got, expected)
+            assert r <= lim, "{}: max-norm rel err {:.3e} > {:.0e}".format(what, r, lim)
+    elif fam in ("corr1d", "corrnd"):
+        compare(got, expected, None, what)
+    elif fam == "interp":
+        compare(got, expected, c["tol"], what)
+    else:
+        compare(got, expected, None, what)
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_hip_matches_scipy_fixture(gpu, family):
+    from cupyimg_amd.scipy import ndimage as ndi
+    n = 0
+    for c in CASES:
+        if c["family"] != family:
+            continue
+        arrs = {k: Z[v] for k, v in c["arrays"].items()}
+        expected = Z[c["expected"]]
+        got = call(ndi, c["func"], arrs, c["kwargs"], to_device=gpu.asarray)
+        _check(c, got, expected)
+        n += 1
+    assert n > 0

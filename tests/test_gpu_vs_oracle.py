@@ -1,0 +1,301 @@
+"""HIP path vs the CPU oracle on the same seeded inputs, at sizes the oracle
+finishes in seconds, plus API-level behaviour the reference's tests cover
+(output argument forms, aliasing, strided views, thread safety, errors)."""
+import threading
+
+import numpy as np
+import pytest
+
+from _cases import maxnorm_rel
+from oracle import ndimage as orc
+
+pytestmark = pytest.mark.gpu
+MODES = ["reflect", "constant", "nearest", "mirror", "wrap"]
+
+
+@pytest.fixture(scope="module")
+def ndi(gpu):
+    from cupyimg_amd.scipy import ndimage
+    return ndimage
+
+
+# ------------------------------------------------------------------ fused f32
+@pytest.mark.parametrize("shape", [(40, 37, 64), (19, 50, 256), (33, 21, 264), (70, 40, 512), (9, 5, 8)])
+@pytest.mark.parametrize("size", [3, 5, 7, 9])
+def test_uniform_filter_fused_f32(gpu, ndi, shape, size):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xd = gpu.asarray(x)
+    for mode in MODES:
+        ref = orc.uniform_filter(x, size, mode=mode, cval=0.75)
+        got = ndi.uniform_filter(xd, size, mode=mode, cval=0.75).get()
+        r = maxnorm_rel(got, ref)
+        assert r <= 1e-6, (shape, size, mode, r)
+
+
+def test_uniform_filter_fused_mixed_axes(gpu, ndi):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((30, 45, 128)).astype(np.float32)
+    xd = gpu.asarray(x)
+    for size, mode, origin in [((5, 1, 3), "reflect", 0), ((1, 7, 1), "mirror", 0), ((3, 5, 9), ["wrap", "nearest", "reflect"], (1, -1, 0)),
+                               ((9, 9, 1), "constant", 0), ((1, 1, 5), "nearest", 0)]:
+        ref = orc.uniform_filter(x, size, mode=mode, origin=origin, cval=-0.5)
+        got = ndi.uniform_filter(xd, size, mode=mode, origin=origin, cval=-0.5).get()
+        assert maxnorm_rel(got, ref) <= 1e-6, (size, mode, origin)
+
+
+@pytest.mark.parametrize("sigma", [0.5, 1.0, (1.0, 0.6, 0.8)])
+def test_gaussian_filter_fused_f32(gpu, ndi, sigma):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((36, 41, 96)).astype(np.float32)
+    xd = gpu.asarray(x)
+    for mode in MODES:
+        for order in [0, 1]:
+            ref = orc.gaussian_filter(x, sigma, order=order, mode=mode, cval=0.0)
+            got = ndi.gaussian_filter(xd, sigma, order=order, mode=mode, cval=0.0).get()
+            assert maxnorm_rel(got, ref) <= 1e-6, (sigma, mode, order)
+
+
+def test_gaussian_sigma2_three_pass(gpu, ndi):
+    # 17 taps per axis: beyond the fused kernel, runs three generic passes
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((40, 40, 40)).astype(np.float32)
+    ref = orc.gaussian_filter(x, 2.0)
+    got = ndi.gaussian_filter(gpu.asarray(x), 2.0).get()
+    assert np.array_equal(got, ref) or maxnorm_rel(got, ref) <= 1e-7
+
+
+# ------------------------------------------------------------------ generic
+@pytest.mark.parametrize("dtype", ["bool", "int8", "uint8", "int16", "uint16", "int32", "uint32", "int64",
+                                   "uint64", "float32", "float64"])
+def test_dtype_matrix_correlate(gpu, ndi, dtype):
+    """every input dtype x every output dtype (reference tests/test_ndimage.py:238-263)"""
+    rng = np.random.default_rng(7)
+    x = (rng.random((9, 11)) * 20).astype(dtype)
+    w = np.array([[1, 0, 2], [0, 1, 0], [1, 0, -1]], dtype=np.float64)
+    xd = gpu.asarray(x)
+    for odt in ["int8", "uint8", "int16", "uint16", "int32", "uint32", "int64", "uint64", "float32", "float64"]:
+        ref = orc.correlate(x, w, output=odt)
+        got = ndi.correlate(xd, w, output=np.dtype(odt)).get()
+        assert got.dtype == np.dtype(odt)
+        assert np.array_equal(got, ref), (dtype, odt)
+        ref = orc.correlate1d(x, [1, 2, 1], axis=0, output=odt)
+        got = ndi.correlate1d(xd, [1, 2, 1], axis=0, output=np.dtype(odt)).get()
+        assert np.array_equal(got, ref), (dtype, odt)
+        ref = orc.minimum_filter(x, size=3, output=odt)
+        got = ndi.minimum_filter(xd, size=3, output=np.dtype(odt)).get()
+        assert np.array_equal(got, ref), (dtype, odt)
+
+
+def test_uniform_integer_exact(gpu, ndi):
+    """gh-6930 style: integer box means must truncate exact sums
+    (reference xfail: tests/test_filters.py:444-450)."""
+    x = np.arange(1, 40, dtype=np.uint8).reshape(3, 13)
+    for size in [2, 3, 4, 6]:
+        ref = orc.uniform_filter(x, size)
+        got = ndi.uniform_filter(gpu.asarray(x), size).get()
+        assert np.array_equal(got, ref)
+
+
+def test_long_kernel_and_short_signal(gpu, ndi):
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((5, 3))
+    w = rng.standard_normal(131)     # longer than the 64 inline taps -> scratch upload
+    for mode in MODES:
+        ref = orc.correlate1d(x, w, axis=1, mode=mode)
+        got = ndi.correlate1d(gpu.asarray(x), w, axis=1, mode=mode, dtype_mode="ndimage").get()
+        assert np.array_equal(got, ref), mode
+
+
+def test_4d_and_5d(gpu, ndi):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((4, 5, 6, 7)).astype(np.float32)
+    xd = gpu.asarray(x)
+    assert maxnorm_rel(ndi.uniform_filter(xd, 3).get(), orc.uniform_filter(x, 3)) <= 1e-6
+    w = rng.standard_normal((2, 3, 1, 3))
+    assert np.array_equal(ndi.correlate(xd, w, mode="mirror").get(), orc.correlate(x, w, mode="mirror"))
+    fp = rng.random((3, 2, 3, 2)) > 0.3
+    assert np.array_equal(ndi.maximum_filter(xd, footprint=fp).get(), orc.maximum_filter(x, footprint=fp))
+    b = x > 0
+    assert np.array_equal(ndi.binary_erosion(gpu.asarray(b)).get(), orc.binary_erosion(b))
+    c = rng.uniform(-1, 7, size=(4, 50))
+    got = ndi.map_coordinates(xd, c, order=1, mode="nearest").get()
+    assert np.allclose(got, orc.map_coordinates(x, c, order=1, mode="nearest"), atol=1e-6)
+    x5 = rng.integers(0, 9, size=(3, 3, 4, 3, 5)).astype(np.int32)
+    got = ndi.map_coordinates(gpu.asarray(x5), rng.uniform(0, 2, size=(5, 20)), order=1, mode="reflect").get()
+    assert got.dtype == np.int32
+
+
+# ------------------------------------------------------------------ API forms
+def test_output_forms_and_aliasing(gpu, ndi):
+    rng = np.random.default_rng(10)
+    x = rng.standard_normal((12, 14, 16)).astype(np.float32)
+    ref = orc.uniform_filter(x, 3)
+    xd = gpu.asarray(x)
+    out = gpu.empty(x.shape, np.float32)
+    r = ndi.uniform_filter(xd, 3, output=out)
+    assert r is out and maxnorm_rel(out.get(), ref) <= 1e-6
+    # output dtype
+    r = ndi.uniform_filter(xd, 3, output=np.float64)
+    assert r.dtype == np.float64 and maxnorm_rel(r.get(), orc.uniform_filter(x, 3, output=np.float64)) <= 1e-12
+    # in place (output is input): reference handles this with a temp (_filters_core.py:148-155)
+    y = gpu.asarray(x)
+    ndi.uniform_filter(y, 3, output=y)
+    assert maxnorm_rel(y.get(), ref) <= 1e-6
+    y = gpu.asarray(x)
+    ndi.correlate1d(y, [1.0, 2.0, 3.0], axis=1, output=y, dtype_mode="ndimage")
+    assert np.array_equal(y.get(), orc.correlate1d(x, [1.0, 2.0, 3.0], axis=1))
+    # wrong output shape
+    with pytest.raises(ValueError):
+        ndi.uniform_filter(xd, 3, output=gpu.empty((3, 3, 3), np.float32))
+
+
+def test_strided_views(gpu, ndi):
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((10, 12, 16)).astype(np.float32)
+    xd = gpu.asarray(x)
+    v = xd[::2, 1:, ::-1]
+    xv = x[::2, 1:, ::-1]
+    assert np.array_equal(v.get(), xv)
+    assert maxnorm_rel(ndi.uniform_filter(v, 3).get(), orc.uniform_filter(xv, 3)) <= 1e-6
+    t = xd.transpose(2, 0, 1)
+    assert np.array_equal(ndi.minimum_filter(t, size=3).get(), orc.minimum_filter(x.transpose(2, 0, 1), size=3))
+    big = gpu.zeros((10, 12, 32), np.float32)
+    ov = big[:, :, ::2]
+    ndi.gaussian_filter(xd, 1.0, output=ov)
+    assert maxnorm_rel(ov.get(), orc.gaussian_filter(x, 1.0)) <= 1e-6
+
+
+def test_thread_safety(gpu, ndi):
+    """Same op from 4 host threads on separate outputs
+    (reference tests/test_filters.py:354-412)."""
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((20, 24, 32)).astype(np.float32)
+    xd = gpu.asarray(x)
+    ref = orc.uniform_filter(x, 5)
+    refm = orc.maximum_filter(x, size=3)
+    outs = [None] * 8
+
+    def work(i):
+        if i % 2:
+            outs[i] = ndi.uniform_filter(xd, 5)
+        else:
+            outs[i] = ndi.maximum_filter(xd, size=3)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for i, o in enumerate(outs):
+        if i % 2:
+            assert maxnorm_rel(o.get(), ref) <= 1e-6
+        else:
+            assert np.array_equal(o.get(), refm)
+
+
+def test_error_behaviour(gpu, ndi):
+    """Exception types of the reference."""
+    x = gpu.asarray(np.zeros((5, 6), np.float32))
+    with pytest.raises(RuntimeError):
+        ndi.uniform_filter(x, 3, mode="bogus")
+    with pytest.raises(RuntimeError):
+        ndi.correlate(x, np.ones((3,)))                      # rank mismatch
+    with pytest.raises(RuntimeError):
+        ndi.uniform_filter1d(x, 0)
+    with pytest.raises(RuntimeError):
+        ndi.correlate1d(x, np.ones((2, 2)))
+    with pytest.raises(RuntimeError):
+        ndi.uniform_filter(x, (3, 3, 3))
+    with pytest.raises(ValueError):
+        ndi.correlate1d(x, [1, 1, 1], origin=2)
+    with pytest.raises(ValueError):
+        ndi.correlate1d(x, [1, 1, 1], origin=-2)
+    with pytest.raises(ValueError):
+        ndi.minimum_filter(x, footprint=np.zeros((3, 3), bool))
+    with pytest.raises(ValueError):
+        ndi.gaussian_filter(x, 1.0, order=-1)
+    with pytest.raises(ValueError):
+        ndi.map_coordinates(x, np.zeros((2, 3)), order=7)
+    with pytest.raises(ValueError):
+        ndi.map_coordinates(x, np.zeros((2, 3)), order=1, mode="bogus")
+    with pytest.raises(ValueError):
+        ndi.map_coordinates(x, np.zeros((2, 3), dtype=np.complex64), order=1)
+    with pytest.raises(TypeError):
+        ndi.binary_erosion(x, iterations=1.5)
+    with pytest.raises(NotImplementedError):
+        ndi.minimum_filter(x, size=3, cval=np.nan)
+    with pytest.raises(NotImplementedError):
+        ndi.uniform_filter(gpu.asarray(np.zeros((4, 4), np.int32)), 3, mode="constant", cval=np.inf)
+    with pytest.raises(RuntimeError):
+        ndi.binary_erosion(x, structure=np.ones((3,), bool))
+    with pytest.raises(ValueError):
+        ndi.grey_erosion(x)
+    with pytest.raises(RuntimeError):
+        ndi.minimum_filter(x)
+    # empty input (reference test_correlate09/10)
+    e = ndi.correlate(gpu.asarray(np.zeros((0,), np.float64)), np.array([1.0, 1.0]))
+    assert e.shape == (0,)
+    e = ndi.uniform_filter(gpu.asarray(np.zeros((3, 0), np.float32)), 3)
+    assert e.shape == (3, 0)
+
+
+# ------------------------------------------------------------------ morphology
+@pytest.mark.parametrize("shape", [(64, 70, 80), (31, 257)])
+def test_grey_morphology_u8(gpu, ndi, shape):
+    rng = np.random.default_rng(13)
+    x = rng.integers(0, 256, size=shape).astype(np.uint8)
+    xd = gpu.asarray(x)
+    for size in [3, 7]:
+        for mode in MODES:
+            assert np.array_equal(ndi.grey_erosion(xd, size=size, mode=mode, cval=9).get(),
+                                  orc.grey_erosion(x, size=size, mode=mode, cval=9)), (size, mode)
+            assert np.array_equal(ndi.grey_dilation(xd, size=size, mode=mode, cval=9).get(),
+                                  orc.grey_dilation(x, size=size, mode=mode, cval=9)), (size, mode)
+
+
+def test_binary_iterations(gpu, ndi):
+    rng = np.random.default_rng(14)
+    x = rng.random((40, 50, 60)) > 0.35
+    mask = rng.random(x.shape) > 0.2
+    xd, md = gpu.asarray(x), gpu.asarray(mask)
+    for it in [1, 2, 5, 0]:
+        for fn in ["binary_erosion", "binary_dilation"]:
+            ref = getattr(orc, fn)(x, iterations=it, mask=mask)
+            got = getattr(ndi, fn)(xd, iterations=it, mask=md).get()
+            assert got.dtype == np.bool_ and np.array_equal(got, ref), (fn, it)
+    ref = orc.binary_dilation(x, np.ones((3, 3, 3)), iterations=3, border_value=1)
+    got = ndi.binary_dilation(xd, np.ones((3, 3, 3)), iterations=3, border_value=1).get()
+    assert np.array_equal(got, ref)
+    # composites
+    import scipy.ndimage as sndi
+    assert np.array_equal(ndi.binary_opening(xd).get(), sndi.binary_opening(x))
+    assert np.array_equal(ndi.binary_closing(xd, iterations=2).get(), sndi.binary_closing(x, iterations=2))
+    assert np.array_equal(ndi.binary_fill_holes(xd).get(), sndi.binary_fill_holes(x))
+    assert np.array_equal(ndi.binary_propagation(gpu.asarray(x & mask), mask=md).get(),
+                          sndi.binary_propagation(x & mask, mask=mask))
+    assert np.array_equal(ndi.binary_hit_or_miss(xd).get(), sndi.binary_hit_or_miss(x))
+
+
+# ------------------------------------------------------------------ interpolation
+def test_affine_and_map_3d(gpu, ndi):
+    rng = np.random.default_rng(15)
+    n = 48
+    x = rng.standard_normal((n, n, n)).astype(np.float32)
+    ang = np.deg2rad(7.0)
+    R = np.array([[1, 0, 0], [0, np.cos(ang), -np.sin(ang)], [0, np.sin(ang), np.cos(ang)]])
+    M = np.diag([1.02, 1.0, 1.0]) @ R
+    ctr = (n - 1) / 2.0
+    off = ctr - M @ np.array([ctr] * 3) + np.array([0.5, -1.25, 2.0])
+    xd = gpu.asarray(x)
+    for mode in ["constant", "grid-constant", "nearest", "mirror", "reflect", "wrap", "grid-wrap"]:
+        for order in [0, 1]:
+            ref = orc.affine_transform(x, M, off, order=order, mode=mode, cval=0.25)
+            got = ndi.affine_transform(xd, M, off, order=order, mode=mode, cval=0.25).get()
+            # same double arithmetic on both sides; float32 store
+            assert np.allclose(got, ref, rtol=0, atol=1e-6), (mode, order, np.abs(got - ref).max())
+    idx = np.indices((n, n, n)).reshape(3, -1).astype(np.float64)
+    coords = (M @ idx + off[:, None]).reshape(3, n, n, n).astype(np.float32)
+    ref = orc.map_coordinates(x, coords, order=1, mode="constant")
+    got = ndi.map_coordinates(xd, gpu.asarray(coords), order=1, mode="constant").get()
+    assert np.allclose(got, ref, rtol=0, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        ndi.map_coordinates(xd, gpu.asarray(coords), order=3)
