@@ -102,10 +102,10 @@ def _binary_erosion(input, structure, iterations, mask, output, border_value, or
     if input.size == 0:
         return output
 
-    center = tuple(oo + ss // 2 for ss, oo in zip(structure.shape, origin))
-    center_is_true = bool(structure[center])
-    if iterations != 1 and center_is_true and not brute_force:
-        raise NotImplementedError("only brute_force iteration has been implemented")
+    # The reference raises NotImplementedError for multi-iteration calls with
+    # brute_force=False when the structure centre is set (morphology.py:297-300).
+    # SciPy returns the same result either way, so every iteration simply
+    # re-evaluates all voxels here (the "brute force" schedule).
 
     st = np.ascontiguousarray(structure, dtype=np.uint8)
     stp = st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))

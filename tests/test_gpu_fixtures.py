@@ -21,7 +21,7 @@ Z, CASES, META = load_scipy_fixtures()
 FAMILIES = sorted({c["family"] for c in CASES})
 
 
-def _check(c, got, expected):
+def _check(c, got, expected, inp_dtype=None):
     what = "case {} {} {}".format(c["id"], c["func"], c["kwargs"])
     fam = c["family"]
     assert got.shape == expected.shape and got.dtype == expected.dtype, what
@@ -35,7 +35,13 @@ def _check(c, got, expected):
             r = maxnorm_rel(got, expected)
             assert r <= lim, "{}: max-norm rel err {:.3e} > {:.0e}".format(what, r, lim)
     elif fam in ("corr1d", "corrnd"):
-        compare(got, expected, None, what)
+        if c["func"] in ("correlate1d", "convolve1d") and inp_dtype == np.float32:
+            # reference default for the 1-D entry points is dtype_mode="float":
+            # float32 accumulation for float32 input (filters.py:223,297)
+            r = maxnorm_rel(got, expected)
+            assert r <= 1e-6, "{}: max-norm rel err {:.3e}".format(what, r)
+        else:
+            compare(got, expected, None, what)
     elif fam == "interp":
         compare(got, expected, c["tol"], what)
     else:
@@ -52,6 +58,6 @@ def test_hip_matches_scipy_fixture(gpu, family):
         arrs = {k: Z[v] for k, v in c["arrays"].items()}
         expected = Z[c["expected"]]
         got = call(ndi, c["func"], arrs, c["kwargs"], to_device=gpu.asarray)
-        _check(c, got, expected)
+        _check(c, got, expected, arrs["input"].dtype if "input" in arrs else None)
         n += 1
     assert n > 0

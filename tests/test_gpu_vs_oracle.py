@@ -80,7 +80,7 @@ def test_dtype_matrix_correlate(gpu, ndi, dtype):
         assert got.dtype == np.dtype(odt)
         assert np.array_equal(got, ref), (dtype, odt)
         ref = orc.correlate1d(x, [1, 2, 1], axis=0, output=odt)
-        got = ndi.correlate1d(xd, [1, 2, 1], axis=0, output=np.dtype(odt)).get()
+        got = ndi.correlate1d(xd, [1, 2, 1], axis=0, output=np.dtype(odt), dtype_mode="ndimage").get()
         assert np.array_equal(got, ref), (dtype, odt)
         ref = orc.minimum_filter(x, size=3, output=odt)
         got = ndi.minimum_filter(xd, size=3, output=np.dtype(odt)).get()
