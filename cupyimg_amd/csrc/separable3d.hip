@@ -49,6 +49,7 @@ struct Sep3dParams {
     int zc;                 // output planes per chunk
     int nxt, nyt, nzc;      // tile counts
     float wx[kMaxTaps], wyv[kMaxTaps], wz[kMaxTaps];
+    int dbg;                // tuning ablations (0 in production): 1 no x/z math, 2 no stores, 4 no loads, 8 no y math
 };
 
 struct __attribute__((packed, aligned(4))) float4u { float x, y, z, w; };
@@ -84,23 +85,45 @@ __device__ __forceinline__ float comp(const float4 &v, int k)
     return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
 }
 
-// x pass for one float4 per lane; `edge` holds the halo float4 for lanes 0 and `last`
+// ---------------------------------------------------------------------------
+// v2: wave-specialised variant.  NWP producer waves own the rows (load, x pass,
+// z ring, LDS write); NWC consumer waves do the y pass and the stores.  One
+// barrier per plane hands a finished LDS buffer from producers to consumers;
+// producers fill the other buffer meanwhile.  Loads (producers) and stores
+// (consumers) therefore sit on different waves' vmcnt counters: nobody ever
+// waits for a store, the next plane's loads are issued as soon as the x pass
+// has consumed the registers, and they stay in flight across the barrier.
+// Lane shifts for the x pass use DPP wave_shr:1 / wave_shl:1 (one VALU op, no
+// LDS crossbar); lane 0 keeps `old` = its left halo value.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_from_left(float keep_for_lane0, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep_for_lane0), __float_as_int(v),
+                                                      0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_right(float keep_for_lane63, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep_for_lane63), __float_as_int(v),
+                                                      0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+// edge halo: NE floats per side held by lanes 0 and `last` (NE = 2 for reach <= 2, else 4)
 template <int WX>
-__device__ __forceinline__ float4 xpass(const float4 v, const float4 edge, int lane, int last,
-                                        const float *__restrict__ wx)
+__device__ __forceinline__ float4 xpass_dpp(const float4 v, const float (&edge)[(WX / 2 <= 2) ? 2 : 4], int lane,
+                                            int last, const float *__restrict__ wx)
 {
     if constexpr (WX == 1) {
         return make_float4(v.x * wx[0], v.y * wx[0], v.z * wx[0], v.w * wx[0]);
     } else {
         constexpr int RX = WX / 2;
+        constexpr int NE = RX <= 2 ? 2 : 4;
         float e[4 + 2 * RX];
 #pragma unroll
         for (int j = 0; j < RX; j++) {
-            // left neighbour's component 4-RX+j, right neighbour's component j
-            float l = __shfl_up(comp(v, 4 - RX + j), 1);
-            float r = __shfl_down(comp(v, j), 1);
-            if (lane == 0) l = comp(edge, 4 - RX + j);
-            if (lane == last) r = comp(edge, j);
+            // left halo: the NE floats just left of the tile, last RX of them are used
+            float l = dpp_from_left(edge[NE - RX + j], comp(v, 4 - RX + j));
+            float r = dpp_from_right(edge[j], comp(v, j));
+            if (lane == last) r = edge[j];
             e[j] = l;
             e[RX + 4 + j] = r;
         }
@@ -117,24 +140,37 @@ __device__ __forceinline__ float4 xpass(const float4 v, const float4 edge, int l
     }
 }
 
-template <int R>
-struct PlaneRegs {
+// one plane's worth of a producer wave's rows, in flight or ready
+template <int R, int NE>
+struct RowRegs {
     float4 v[R];
-    float4 e[R];
+    float t[R][NE];   // raw edge floats as loaded (lanes 0 / last only)
 };
 
-template <int WX, int WZ, int NW, int R>
-__global__ void __launch_bounds__(NW * 64)
-sep3d_kernel(const float *__restrict__ in, float *__restrict__ out, const Sep3dParams p)
+constexpr int kMaxChunk = 2048;   // planes per z chunk (plane-index table lives in LDS)
+
+template <int NE>
+__device__ __forceinline__ float pick(const float (&t)[NE], int idx)
 {
-    constexpr int ROWS = NW * R;
+    if constexpr (NE == 2) return idx ? t[1] : t[0];
+    else return idx & 2 ? (idx & 1 ? t[3] : t[2]) : (idx & 1 ? t[1] : t[0]);
+}
+
+template <int WX, int WZ, int NWP, int NWC, int R>
+__global__ void __launch_bounds__((NWP + NWC) * 64)
+sep3d_ws_kernel(const float *__restrict__ in, float *__restrict__ out, const Sep3dParams p)
+{
+    constexpr int ROWS = NWP * R;
+    constexpr int RX = WX / 2;
+    constexpr int NE = RX <= 2 ? 2 : 4;
+    constexpr int RING = WZ > 1 ? WZ - 1 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *lds = reinterpret_cast<float4 *>(smem);   // [2][ROWS][64]
+    float4 *lds = reinterpret_cast<float4 *>(smem);                    // [2][ROWS][64]
+    int *ztab = reinterpret_cast<int *>(smem + (size_t)2 * ROWS * 1024); // [zc + WZ - 1] source plane or -1
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // ---- tile decode; XCD-aware: blocks b, b+8, b+16.. share an XCD, give them one z range
     int b = blockIdx.x;
     const int total = p.nxt * p.nyt * p.nzc;
     if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
@@ -150,155 +186,557 @@ sep3d_kernel(const float *__restrict__ in, float *__restrict__ out, const Sep3dP
     const int rows_needed = ty_act + p.wy - 1;
     const int nlanes = min(64, (nx - x0) >> 2);
     const int last = nlanes - 1;
-    const bool active = lane < nlanes;
     const int64_t plane = (int64_t)ny * nx;
+    const int zi0 = zs - p.oz;
+    const int nsteps = ze - zs + WZ - 1;          // input planes zi0 .. zi0 + nsteps - 1
 
-    int es0, ek0, es1, ek1;
-    edge_desc(0, x0, x0 + 4 * nlanes, nx, p.mx, &es0, &ek0);
-    edge_desc(1, x0, x0 + 4 * nlanes, nx, p.mx, &es1, &ek1);
-    const bool is_edge_lane = (lane == 0) || (lane == last);
-    const int estart = lane == 0 ? es0 : es1;
-    const int ekind = lane == 0 ? ek0 : ek1;
-    const float4 cv4 = make_float4(p.cval, p.cval, p.cval, p.cval);
+    // source plane of every step, boundary mapped once (branchy code kept out of the loop)
+    for (int i = threadIdx.x; i < nsteps; i += (NWP + NWC) * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
+    __syncthreads();
 
-    // rows this wave owns: rr = wave * R + r; source row (boundary mapped), -1 = constant, -2 = unused
-    int ysrc[R];
+    if (wave < NWP) {
+        // ------------------------------------------------------------ producer
+        // Per-lane edge recipe (lane 0: the NE floats left of the tile; lane
+        // `last`: the NE floats right of it): ONE load of NE consecutive floats
+        // at row + eoff, then component picks idx[k] (forward / reversed / splat).
+        int es0, ek0, es1, ek1;
+        edge_desc(0, x0, x0 + 4 * nlanes, nx, p.mx, &es0, &ek0);
+        edge_desc(1, x0, x0 + 4 * nlanes, nx, p.mx, &es1, &ek1);
+        const bool is_edge_lane = (lane == 0) || (lane == last);
+        const int ekind = lane == 0 ? ek0 : ek1;
+        int eoff = lane == 0 ? es0 : es1;
+        int eidx[NE];
+        if (lane == 0) {
+            if (ekind == EDGE_FWD) eoff += 4 - NE;             // x0-NE .. x0-1
+        } else {
+            if (ekind == EDGE_REV) eoff += 4 - NE;             // last NE floats of the block
+            if (ekind == EDGE_SPLAT) eoff -= NE - 1;           // keep the load inside the row
+        }
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int rr = wave * R + r;
-        ysrc[r] = rr < rows_needed ? bmap<int>(y0 - p.oy + rr, ny, p.my) : -2;
-    }
+        for (int k = 0; k < NE; k++)
+            eidx[k] = ekind == EDGE_FWD ? k : (ekind == EDGE_REV ? NE - 1 - k : (lane == 0 ? 0 : NE - 1));
+        const bool edge_load = is_edge_lane && ekind != EDGE_CONST;
+        // lanes beyond the row end re-read the last valid float4 (never used)
+        const int xoff = x0 + 4 * min(lane, last);
 
-    auto load_plane = [&](int zi, PlaneRegs<R> &pr) {
-        const int zsrc = bmap<int>(zi, nz, p.mz);
+        // rows of this wave: element offset of the (boundary mapped) source row
+        // inside a plane; invalid rows (constant boundary / unused) read row 0
+        // and are overridden with cval afterwards
+        int64_t yoff[R];
+        bool yconst[R], yused[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            pr.v[r] = cv4;
-            pr.e[r] = cv4;
-            if (ysrc[r] >= 0 && zsrc >= 0) {
-                const float *row = in + (int64_t)zsrc * plane + (int64_t)ysrc[r] * nx;
-                if (active) pr.v[r] = *reinterpret_cast<const float4 *>(row + x0 + 4 * lane);
-                if (is_edge_lane && ekind != EDGE_CONST) {
-                    if (ekind == EDGE_SPLAT) {
-                        const float s = row[estart];
-                        pr.e[r] = make_float4(s, s, s, s);
+            const int rr = wave * R + r;
+            const int ys = rr < rows_needed ? bmap<int>(y0 - p.oy + rr, ny, p.my) : -2;
+            yused[r] = ys != -2;
+            yconst[r] = ys < 0;
+            yoff[r] = (int64_t)max(ys, 0) * nx;
+        }
+
+        auto load_row = [&](int zsrc, int r, RowRegs<R, NE> &S) {
+            const float *row = in + (int64_t)max(zsrc, 0) * plane + yoff[r];
+            S.v[r] = *reinterpret_cast<const float4 *>(row + xoff);
+            if (edge_load) {
+                if constexpr (NE == 2) {
+                    struct __attribute__((packed, aligned(4))) f2u { float a, b; };
+                    const f2u q = *reinterpret_cast<const f2u *>(row + eoff);
+                    S.t[r][0] = q.a; S.t[r][1] = q.b;
+                } else {
+                    const float4u q = *reinterpret_cast<const float4u *>(row + eoff);
+                    S.t[r][0] = q.x; S.t[r][1] = q.y; S.t[r][2] = q.z; S.t[r][3] = q.w;
+                }
+            }
+        };
+
+        float4 ring[RING][R];
+#pragma unroll
+        for (int k = 0; k < RING; k++)
+#pragma unroll
+            for (int r = 0; r < R; r++) ring[k][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        int buf = 0;
+        // One plane, row by row: x pass on the arrived row, refill the same
+        // registers with the row two planes ahead, z pass, hand over via LDS.
+        // zcur / znext: source planes (or -1 = constant plane).
+        auto step = [&](int i, RowRegs<R, NE> &S) {
+            const int zcur = ztab[i];
+            const bool more = i + 2 < nsteps;
+            const int znext = more ? ztab[i + 2] : 0;
+            const bool emit = i >= WZ - 1;
+            float4 *wbuf = lds + buf * (ROWS * 64);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const bool cst = yconst[r] || zcur < 0;
+                float4 v = S.v[r];
+                float eg[NE];
+#pragma unroll
+                for (int k = 0; k < NE; k++) eg[k] = (edge_load && !cst) ? pick<NE>(S.t[r], eidx[k]) : p.cval;
+                if (cst) v = make_float4(p.cval, p.cval, p.cval, p.cval);
+                const float4 xf = (p.dbg & 1) ? v : xpass_dpp<WX>(v, eg, lane, last, p.wx);
+                if (more && !(p.dbg & 4)) load_row(znext, r, S);
+                if (emit) {
+                    float4 a;
+                    if constexpr (WZ == 1) {
+                        a = make_float4(p.wz[0] * xf.x, p.wz[0] * xf.y, p.wz[0] * xf.z, p.wz[0] * xf.w);
                     } else {
-                        const float4u t = *reinterpret_cast<const float4u *>(row + estart);
-                        pr.e[r] = ekind == EDGE_FWD ? make_float4(t.x, t.y, t.z, t.w)
-                                                     : make_float4(t.w, t.z, t.y, t.x);
+                        a = make_float4(p.wz[0] * ring[0][r].x, p.wz[0] * ring[0][r].y, p.wz[0] * ring[0][r].z,
+                                        p.wz[0] * ring[0][r].w);
+#pragma unroll
+                        for (int k = 1; k < WZ - 1; k++) {
+                            a.x = fmaf(p.wz[k], ring[k][r].x, a.x);
+                            a.y = fmaf(p.wz[k], ring[k][r].y, a.y);
+                            a.z = fmaf(p.wz[k], ring[k][r].z, a.z);
+                            a.w = fmaf(p.wz[k], ring[k][r].w, a.w);
+                        }
+                        a.x = fmaf(p.wz[WZ - 1], xf.x, a.x);
+                        a.y = fmaf(p.wz[WZ - 1], xf.y, a.y);
+                        a.z = fmaf(p.wz[WZ - 1], xf.z, a.z);
+                        a.w = fmaf(p.wz[WZ - 1], xf.w, a.w);
                     }
+                    if (p.dbg & 1) a = xf;
+                    // a constant-mode row is exactly cval at the y stage
+                    if (yconst[r]) a = make_float4(p.cval, p.cval, p.cval, p.cval);
+                    if (yused[r]) wbuf[(wave * R + r) * 64 + lane] = a;
+                }
+                if constexpr (WZ > 1) {
+#pragma unroll
+                    for (int k = 0; k < RING - 1; k++) ring[k][r] = ring[k + 1][r];
+                    ring[RING - 1][r] = xf;
                 }
             }
-        }
-    };
+            if (emit) buf ^= 1;
+            __syncthreads();
+        };
 
-    float4 ring[WZ][R];
-#pragma unroll
-    for (int k = 0; k < WZ; k++)
-#pragma unroll
-        for (int r = 0; r < R; r++) ring[k][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const int zi0 = zs - p.oz;              // first input plane of the chunk
-    const int zi1 = ze - 1 - p.oz + WZ - 1; // last input plane
-    PlaneRegs<R> nxt;
-    load_plane(zi0, nxt);
-
-    int buf = 0;
-    for (int zi = zi0; zi <= zi1; zi++) {
-        PlaneRegs<R> cur = nxt;
-        if (zi < zi1) load_plane(zi + 1, nxt);   // prefetch: in flight while `cur` is processed
-
-        // x pass, push into the z ring
+        RowRegs<R, NE> A, B;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-#pragma unroll
-            for (int k = 0; k < WZ - 1; k++) ring[k][r] = ring[k + 1][r];
-            ring[WZ - 1][r] = xpass<WX>(cur.v[r], cur.e[r], lane, last, p.wx);
+            load_row(ztab[0], r, A);
+            load_row(ztab[nsteps > 1 ? 1 : 0], r, B);
         }
-        if (zi - zi0 < WZ - 1) continue;        // ring not full yet
-        const int zo = zi - (WZ - 1) + p.oz;    // output plane
-
-        // z pass -> LDS
-        float4 *wbuf = lds + buf * (ROWS * 64);
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            float4 a;
-            if (ysrc[r] == -1) {
-                a = cv4;   // a constant-mode row is exactly cval at the y stage
-            } else {
-                a = make_float4(p.wz[0] * ring[0][r].x, p.wz[0] * ring[0][r].y, p.wz[0] * ring[0][r].z,
-                                p.wz[0] * ring[0][r].w);
-#pragma unroll
-                for (int k = 1; k < WZ; k++) {
-                    a.x = fmaf(p.wz[k], ring[k][r].x, a.x);
-                    a.y = fmaf(p.wz[k], ring[k][r].y, a.y);
-                    a.z = fmaf(p.wz[k], ring[k][r].z, a.z);
-                    a.w = fmaf(p.wz[k], ring[k][r].w, a.w);
+        for (int i = 0; i < nsteps; i += 2) {
+            step(i, A);
+            if (i + 1 < nsteps) step(i + 1, B);
+        }
+    } else {
+        // ------------------------------------------------------------ consumer
+        const int cw = wave - NWP;
+        const bool active = lane < nlanes;
+        int buf = 0;
+        for (int i = 0; i < nsteps; i++) {
+            __syncthreads();
+            if (i < WZ - 1) continue;
+            const int zo = zs + i - (WZ - 1);
+            const float4 *rbuf = lds + buf * (ROWS * 64);
+            buf ^= 1;
+            float *oplane = out + (int64_t)zo * plane;
+            for (int j = cw; j < ty_act; j += NWC) {
+                const float4 *src = rbuf + j * 64 + lane;
+                float4 a = src[0];
+                a.x *= p.wyv[0]; a.y *= p.wyv[0]; a.z *= p.wyv[0]; a.w *= p.wyv[0];
+                for (int k = 1; k < ((p.dbg & 8) ? 1 : p.wy); k++) {
+                    const float4 t = src[k * 64];
+                    const float w = p.wyv[k];
+                    a.x = fmaf(w, t.x, a.x);
+                    a.y = fmaf(w, t.y, a.y);
+                    a.z = fmaf(w, t.z, a.z);
+                    a.w = fmaf(w, t.w, a.w);
                 }
+                if (active && !(p.dbg & 2)) *reinterpret_cast<float4 *>(oplane + (int64_t)(y0 + j) * nx + x0 + 4 * lane) = a;
             }
-            if (ysrc[r] != -2) wbuf[(wave * R + r) * 64 + lane] = a;
         }
-        __syncthreads();
-
-        // y pass: output rows j = wave, wave + NW, ...
-        float *oplane = out + (int64_t)zo * plane;
-        for (int j = wave; j < ty_act; j += NW) {
-            const float4 *src = wbuf + j * 64 + lane;
-            float4 a = src[0];
-            a.x *= p.wyv[0]; a.y *= p.wyv[0]; a.z *= p.wyv[0]; a.w *= p.wyv[0];
-            for (int k = 1; k < p.wy; k++) {
-                const float4 t = src[k * 64];
-                const float w = p.wyv[k];
-                a.x = fmaf(w, t.x, a.x);
-                a.y = fmaf(w, t.y, a.y);
-                a.z = fmaf(w, t.z, a.z);
-                a.w = fmaf(w, t.w, a.w);
-            }
-            if (active) *reinterpret_cast<float4 *>(oplane + (int64_t)(y0 + j) * nx + x0 + 4 * lane) = a;
-        }
-        buf ^= 1;
     }
 }
 
-template <int WX, int WZ, int NW, int R>
-static int launch_sep3d(const float *in, float *out, const Sep3dParams &p, hipStream_t s)
+template <int WX, int WZ, int NWP, int NWC, int R>
+static int launch_sep3d_ws(const float *in, float *out, const Sep3dParams &p, hipStream_t s)
 {
-    const size_t lds = (size_t)2 * NW * R * 64 * sizeof(float4);
-    static bool attr_done = false;   // benign race: idempotent
+    const size_t lds = (size_t)2 * NWP * R * 64 * sizeof(float4) + (size_t)(kMaxChunk + kMaxTaps) * sizeof(int);
+    static bool attr_done = false;
     if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)sep3d_kernel<WX, WZ, NW, R>,
+        MI_HIP(hipFuncSetAttribute((const void *)sep3d_ws_kernel<WX, WZ, NWP, NWC, R>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     const int total = p.nxt * p.nyt * p.nzc;
-    hipLaunchKernelGGL((sep3d_kernel<WX, WZ, NW, R>), dim3(total), dim3(NW * 64), lds, s, in, out, p);
+    hipLaunchKernelGGL((sep3d_ws_kernel<WX, WZ, NWP, NWC, R>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in,
+                       out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
 
-// tile configuration: NW waves x R rows per wave = rows staged per plane
-template <int WX, int WZ>
-static int dispatch_cfg(const float *in, float *out, Sep3dParams &p, int cfg, hipStream_t s)
+// ---------------------------------------------------------------------------
+// v4 "lean": the shipped kernel for cubic kernels (same odd tap count W on all
+// three axes: uniform_filter(size=W), isotropic gaussian_filter).  Same
+// producer / consumer structure as sep3d_ws_kernel, with the per-voxel
+// instruction overhead stripped:
+//   * buffer_load / buffer_store with an SRSRC descriptor: the plane offset is
+//     a scalar (soffset), the row + lane offset a loop-invariant VGPR, so the
+//     loop contains no address arithmetic; lanes / rows that must not touch
+//     memory get an out-of-range voffset (hardware range check: loads return 0
+//     without a fetch, stores are dropped) -- no exec-mask branches;
+//   * the z ring is rotated by unrolling W-1 steps with compile-time slot
+//     numbers instead of moving registers;
+//   * consumers read their G + W - 1 LDS rows once and slide over them.
+// Precondition (host): volume < 2 GiB (32-bit buffer offsets).
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kOOB = 0x80000000u;   // >= num_records of any descriptor we build
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
 {
-    // ring registers = WZ * R * 4; keep R small for long z kernels
-    constexpr int R = WZ <= 5 ? 6 : (WZ <= 7 ? 4 : 3);
-    if (cfg == 1) return launch_sep3d<WX, WZ, 8, R>(in, out, p, s);
-    return launch_sep3d<WX, WZ, 6, R>(in, out, p, s);
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
 }
 
-static int rows_for(int wz, int cfg)
+__device__ __forceinline__ float4 as_f4(u32x4 u)
 {
-    const int R = wz <= 5 ? 6 : (wz <= 7 ? 4 : 3);
-    return (cfg == 1 ? 8 : 6) * R;
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+
+// x pass with the tile-edge halo given as wave-uniform scalars (sL: the NE
+// floats left of the tile, sR: the NE floats right of it)
+template <int WX, int NE>
+__device__ __forceinline__ float4 xpass_scalar_edges(const float4 v, const float (&sL)[NE], const float (&sR)[NE],
+                                                     int lane, int last, const float *__restrict__ wx)
+{
+    constexpr int RX = WX / 2;
+    float e[4 + 2 * RX];
+#pragma unroll
+    for (int j = 0; j < RX; j++) {
+        float l = dpp_from_left(0.f, comp(v, 4 - RX + j));
+        float r = dpp_from_right(0.f, comp(v, j));
+        e[j] = lane == 0 ? sL[NE - RX + j] : l;
+        e[RX + 4 + j] = lane == last ? sR[j] : r;
+    }
+    e[RX + 0] = v.x; e[RX + 1] = v.y; e[RX + 2] = v.z; e[RX + 3] = v.w;
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float a = wx[0] * e[c];
+#pragma unroll
+        for (int k = 1; k < WX; k++) a = fmaf(wx[k], e[c + k], a);
+        o[c] = a;
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+template <int W, int NWP, int NWC, int R, int DEPTH, bool HAS_CONST>
+__global__ void __launch_bounds__((NWP + NWC) * 64)
+sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const Sep3dParams p)
+{
+    constexpr int ROWS = NWP * R;
+    constexpr int TY = ROWS - (W - 1);
+    constexpr int G = (TY + NWC - 1) / NWC;              // output rows per consumer wave
+    constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
+    constexpr int RX = W / 2;
+    constexpr int NE = RX <= 2 ? 2 : 4;
+    constexpr int RINGN = W - 1;                          // even (W odd), >= 2
+    static_assert(W >= 3 && (W & 1), "lean kernel: odd W >= 3");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *lds = reinterpret_cast<float4 *>(smem);                     // [2][LROWS][64]
+    int *ztab = reinterpret_cast<int *>(smem + (size_t)2 * LROWS * 1024); // source plane per step
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    int b = blockIdx.x;
+    const int total = p.nxt * p.nyt * p.nzc;
+    if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
+    const int per_chunk = p.nxt * p.nyt;
+    const int zci = b / per_chunk;
+    const int rem = b - zci * per_chunk;
+    const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
+
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int x0 = xt * 256, y0 = yt * TY, zs = zci * p.zc;
+    const int ze = min(zs + p.zc, nz);
+    const int ty_act = min(TY, ny - y0);
+    const int rows_needed = ty_act + W - 1;
+    const int nlanes = min(64, (nx - x0) >> 2);
+    const int last = nlanes - 1;
+    const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
+    const unsigned total_bytes = plane_bytes * (unsigned)nz;
+    const int zi0 = zs - p.oz;
+    const int nsteps = ze - zs + W - 1;
+
+    for (int i = threadIdx.x; i < nsteps; i += (NWP + NWC) * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
+    __syncthreads();
+
+    if (wave < NWP) {
+        // ------------------------------------------------------------ producer
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+        static_assert(R <= 16, "edge lanes");
+        // Tile-edge halo: ONE buffer_load per plane fetches the edges of all R
+        // rows -- lane r (< R) loads the NE floats left of the tile for row r,
+        // lane 32 + r the NE floats right of it; every other lane is out of
+        // range (no fetch).  Each row's x pass then reads its two edge vectors
+        // with v_readlane into scalars.
+        int es0, ek0, es1, ek1;
+        edge_desc(0, x0, x0 + 4 * nlanes, nx, p.mx, &es0, &ek0);
+        edge_desc(1, x0, x0 + 4 * nlanes, nx, p.mx, &es1, &ek1);
+        const bool left_side = lane < 32;
+        const int erow = left_side ? lane : lane - 32;          // row this lane fetches the edge of
+        const int ekind = left_side ? ek0 : ek1;
+        int eoff = left_side ? es0 : es1;
+        if (left_side) {
+            if (ekind == EDGE_FWD) eoff += 4 - NE;
+        } else {
+            if (ekind == EDGE_REV) eoff += 4 - NE;
+            if (ekind == EDGE_SPLAT) eoff -= NE - 1;
+        }
+        int eidx[NE];
+#pragma unroll
+        for (int k = 0; k < NE; k++)
+            eidx[k] = ekind == EDGE_FWD ? k : (ekind == EDGE_REV ? NE - 1 - k : (left_side ? 0 : NE - 1));
+
+        unsigned voff[R];
+        unsigned eoffv = kOOB;
+        bool yconst[R];
+        bool e_is_cval = (ekind == EDGE_CONST);   // this lane's edge value is cval
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int rr = wave * R + r;
+            const int ys = rr < rows_needed ? bmap<int>(y0 - p.oy + rr, ny, p.my) : -2;
+            yconst[r] = ys == -1;
+            voff[r] = (ys >= 0 && lane < nlanes) ? (unsigned)(ys * nx + x0 + 4 * lane) * 4u : kOOB;
+            if (erow == r) {
+                if (ys >= 0 && ekind != EDGE_CONST) eoffv = (unsigned)(ys * nx + eoff) * 4u;
+                if (ys == -1) e_is_cval = true;
+            }
+        }
+
+        struct Regs { float4 v[R]; float t[NE]; bool zconst; };
+        Regs S[DEPTH];
+        auto issue = [&](int i, Regs &s) {
+            int zsrc = zi0 + i;
+            if ((unsigned)zsrc >= (unsigned)nz) zsrc = ztab[i];
+            s.zconst = zsrc < 0;
+            const unsigned soff = (unsigned)max(zsrc, 0) * plane_bytes;
+            const bool skip = HAS_CONST && zsrc < 0;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                s.v[r] = (p.dbg & 32) ? as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], soff, 2))
+                                      : as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], soff, 0));
+            if constexpr (NE == 2) {
+                const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rin, skip ? kOOB : eoffv, soff, 0);
+                s.t[0] = __uint_as_float(q.x); s.t[1] = __uint_as_float(q.y);
+            } else {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : eoffv, soff, 0);
+                s.t[0] = __uint_as_float(q.x); s.t[1] = __uint_as_float(q.y);
+                s.t[2] = __uint_as_float(q.z); s.t[3] = __uint_as_float(q.w);
+            }
+        };
+
+        float4 ring[RINGN][R];
+#pragma unroll
+        for (int k = 0; k < RINGN; k++)
+#pragma unroll
+            for (int r = 0; r < R; r++) ring[k][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        issue(0, S[0]);
+        if constexpr (DEPTH == 2) if (nsteps > 1) issue(1, S[1]);
+
+        for (int i0 = 0; i0 < nsteps; i0 += RINGN) {
+            static_for<RINGN>([&](auto JJ) {
+                constexpr int J = decltype(JJ)::value;
+                const int i = i0 + J;
+                if (i < nsteps) {
+                    Regs &s = S[DEPTH == 2 ? (J & 1) : 0];
+                    const bool emit = i >= W - 1;
+                    float4 *wbuf = lds + (J & 1) * (LROWS * 64) + (wave * R) * 64 + lane;
+                    // this lane's edge floats, ordered / replaced by cval as the boundary mode wants
+                    float eg[NE];
+#pragma unroll
+                    for (int k = 0; k < NE; k++) {
+                        eg[k] = pick<NE>(s.t, eidx[k]);
+                        if constexpr (HAS_CONST) eg[k] = (e_is_cval || s.zconst) ? p.cval : eg[k];
+                    }
+                    float4 xf[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        float4 v = s.v[r];
+                        if constexpr (HAS_CONST)
+                            if (yconst[r] || s.zconst) v = make_float4(p.cval, p.cval, p.cval, p.cval);
+                        float sL[NE], sR[NE];
+#pragma unroll
+                        for (int k = 0; k < NE; k++) {
+                            sL[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), r));
+                            sR[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), 32 + r));
+                        }
+                        xf[r] = xpass_scalar_edges<W, NE>(v, sL, sR, lane, last, p.wx);
+                    }
+                    if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                    if (emit) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            float4 a = make_float4(p.wz[0] * ring[J % RINGN][r].x, p.wz[0] * ring[J % RINGN][r].y,
+                                                   p.wz[0] * ring[J % RINGN][r].z, p.wz[0] * ring[J % RINGN][r].w);
+#pragma unroll
+                            for (int k = 1; k < RINGN; k++) {
+                                const float4 &q = ring[(J + k) % RINGN][r];
+                                a.x = fmaf(p.wz[k], q.x, a.x);
+                                a.y = fmaf(p.wz[k], q.y, a.y);
+                                a.z = fmaf(p.wz[k], q.z, a.z);
+                                a.w = fmaf(p.wz[k], q.w, a.w);
+                            }
+                            a.x = fmaf(p.wz[W - 1], xf[r].x, a.x);
+                            a.y = fmaf(p.wz[W - 1], xf[r].y, a.y);
+                            a.z = fmaf(p.wz[W - 1], xf[r].z, a.z);
+                            a.w = fmaf(p.wz[W - 1], xf[r].w, a.w);
+                            if constexpr (HAS_CONST)
+                                if (yconst[r]) a = make_float4(p.cval, p.cval, p.cval, p.cval);
+                            wbuf[r * 64] = a;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) ring[J % RINGN][r] = xf[r];
+                    __syncthreads();
+                }
+            });
+        }
+    } else {
+        // ------------------------------------------------------------ consumer
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+        const int cw = wave - NWP;
+        const int j0 = cw * G;
+        unsigned ovoff[G];
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            ovoff[g] = (j0 + g < ty_act && lane < nlanes) ? (unsigned)((y0 + j0 + g) * nx + x0 + 4 * lane) * 4u : kOOB;
+        for (int i = 0; i < nsteps; i++) {
+            __syncthreads();
+            if (i < W - 1) continue;
+            const unsigned soff = (unsigned)(zs + i - (W - 1)) * plane_bytes;
+            const float4 *rbuf = lds + (i & 1) * (LROWS * 64) + j0 * 64 + lane;
+            float4 win[G + W - 1];
+#pragma unroll
+            for (int k = 0; k < G + W - 1; k++) win[k] = rbuf[k * 64];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                float4 a = make_float4(p.wyv[0] * win[g].x, p.wyv[0] * win[g].y, p.wyv[0] * win[g].z, p.wyv[0] * win[g].w);
+#pragma unroll
+                for (int k = 1; k < W; k++) {
+                    a.x = fmaf(p.wyv[k], win[g + k].x, a.x);
+                    a.y = fmaf(p.wyv[k], win[g + k].y, a.y);
+                    a.z = fmaf(p.wyv[k], win[g + k].z, a.z);
+                    a.w = fmaf(p.wyv[k], win[g + k].w, a.w);
+                }
+                u32x4 u;
+                u.x = __float_as_uint(a.x); u.y = __float_as_uint(a.y); u.z = __float_as_uint(a.z); u.w = __float_as_uint(a.w);
+                if (p.dbg & 16) __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[g], soff, 2);
+                else if (p.dbg & 64) __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[g], soff, 17);
+                else __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[g], soff, 0);
+            }
+        }
+    }
+}
+
+template <int W, int NWP, int NWC, int R, int DEPTH = 2>
+static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool has_const, hipStream_t s)
+{
+    constexpr int ROWS = NWP * R;
+    constexpr int TY = ROWS - (W - 1);
+    constexpr int G = (TY + NWC - 1) / NWC;
+    constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
+    const size_t lds = (size_t)2 * LROWS * 1024 + (size_t)(kMaxChunk + kMaxTaps) * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    if (p.ty != TY) { set_error("internal: lean tile mismatch"); return MI_ERR_INTERNAL; }
+    const int total = p.nxt * p.nyt * p.nzc;
+    if (has_const)
+        hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+    else
+        hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, false>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host side: kernel / tile selection
+// ---------------------------------------------------------------------------
+// plain float4 copy: the practical HBM ceiling on this chip for the same byte count
+__global__ void __launch_bounds__(256) copy_f4_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i];
+}
+
+// general kernel (any odd taps <= 9 per axis, per-axis origins on y/z, >= 2 GiB
+// volumes): rows staged per plane for a given z tap count
+static int ws_rows(int wz) { return wz <= 5 ? 24 : (wz <= 7 ? 24 : 16); }
+
+template <int WX, int WZ>
+static int launch_ws(const float *in, float *out, const Sep3dParams &p, hipStream_t s)
+{
+    if constexpr (WZ <= 5) return launch_sep3d_ws<WX, WZ, 8, 4, 3>(in, out, p, s);
+    else if constexpr (WZ <= 7) return launch_sep3d_ws<WX, WZ, 8, 4, 3>(in, out, p, s);
+    else return launch_sep3d_ws<WX, WZ, 8, 4, 2>(in, out, p, s);
+}
+
+// lean kernel tile shapes per tap count; cfg is a tuning knob
+static int lean_rows(int w, int cfg)
+{
+    switch (w) {
+    case 3: return cfg == 1 ? 32 : 36;
+    case 5: return cfg == 2 ? 24 : (cfg == 3 ? 30 : (cfg >= 4 && cfg <= 6 ? 20 : 36));
+    case 7: return 24;
+    default: return 24;
+    }
+}
+
+static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams &p, bool hc, hipStream_t s)
+{
+    switch (w) {
+    case 3:
+        if (cfg == 1) return launch_sep3d_lean<3, 8, 4, 4>(in, out, p, hc, s);
+        return launch_sep3d_lean<3, 12, 4, 3>(in, out, p, hc, s);
+    case 5:
+        if (cfg == 1) return launch_sep3d_lean<5, 9, 3, 4>(in, out, p, hc, s);
+        if (cfg == 2) return launch_sep3d_lean<5, 8, 4, 3>(in, out, p, hc, s);
+        if (cfg == 3) return launch_sep3d_lean<5, 10, 2, 3>(in, out, p, hc, s);
+        if (cfg == 4) return launch_sep3d_lean<5, 10, 2, 2>(in, out, p, hc, s);
+        if (cfg == 5) return launch_sep3d_lean<5, 10, 4, 2>(in, out, p, hc, s);
+        if (cfg == 6) return launch_sep3d_lean<5, 10, 6, 2>(in, out, p, hc, s);
+        if (cfg == 8) return launch_sep3d_lean<5, 12, 4, 3, 2>(in, out, p, hc, s);
+        return launch_sep3d_lean<5, 12, 4, 3, 1>(in, out, p, hc, s);   // measured best: 1 WG/CU, 16 waves
+    case 7:
+        return launch_sep3d_lean<7, 8, 4, 3>(in, out, p, hc, s);
+    default:
+        return launch_sep3d_lean<9, 12, 4, 2>(in, out, p, hc, s);
+    }
 }
 
 }  // namespace mi
 
 using namespace mi;
 
-// test / tuning hook: 0 = default configuration
-static int g_sep3d_cfg = 0;
+// test / tuning hooks (not part of the C-ABI in include/mi355img.h)
+static int g_sep3d_cfg = 0;       // tile shape variant
+static int g_sep3d_zchunks = 0;   // 0 = heuristic
+static int g_sep3d_dbg = 0;       // ablation flags
+static int g_sep3d_kernel = 0;    // 0 = auto, 1 = force general (ws) kernel
 extern "C" int mi_debug_set_sep3d_cfg(int cfg) { g_sep3d_cfg = cfg; return MI_OK; }
+extern "C" int mi_debug_set_sep3d_zchunks(int n) { g_sep3d_zchunks = n; return MI_OK; }
+extern "C" int mi_debug_set_sep3d_dbg(int f) { g_sep3d_dbg = f; return MI_OK; }
+extern "C" int mi_debug_set_sep3d_kernel(int k) { g_sep3d_kernel = k; return MI_OK; }
+extern "C" int mi_debug_copy_f32(const float *in, float *out, int64_t n, int blocks, mi_stream stream)
+{
+    hipLaunchKernelGGL(copy_f4_kernel, dim3(blocks), dim3(256), 0, resolve_stream(stream), (const float4 *)in,
+                       (float4 *)out, n / 4);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
 
 extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const double *const weights[3],
                                   const int wlen[3], const int origin[3], const int mode[3], double cval,
@@ -340,39 +778,44 @@ extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const
     p.mz = filter_mode(mode[0]); p.my = filter_mode(mode[1]); p.mx = filter_mode(mode[2]);
     const bool any_const = p.mz == MI_MODE_CONSTANT || p.my == MI_MODE_CONSTANT || p.mx == MI_MODE_CONSTANT;
     if (any_const && !normalised) UNSUP("constant mode needs kernels that sum to one");
-    if (p.mx == MI_MODE_MIRROR && nx < 8) UNSUP("x too short");
     p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
     p.wy = w[1];
     p.oz = w[0] / 2 + (weights[0] ? origin[0] : 0);
     p.oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
     p.cval = (float)cval;
+    p.dbg = g_sep3d_dbg;
 
     const int cfg = g_sep3d_cfg;
-    const int rows = rows_for(w[0], cfg);
+    const bool cubic = w[0] == w[1] && w[1] == w[2] && w[0] >= 3 && p.oz == w[0] / 2 && p.oy == w[1] / 2;
+    const bool lean = cubic && g_sep3d_kernel != 1 && nz * ny * nx * 4 < ((int64_t)1 << 31);
+    const int rows = lean ? lean_rows(w[0], cfg) : ws_rows(w[0]);
     p.ty = rows - (w[1] - 1);
     if (p.ty < 1) UNSUP("y kernel too long for the tile");
     p.nxt = (int)((nx + 255) / 256);
     p.nyt = (int)((ny + p.ty - 1) / p.ty);
-    // z chunking: aim at ~one workgroup per CU (256) or a multiple of it, keep
-    // the chunk long enough that the (wz-1)-plane ramp-up stays a small fraction
+    // z chunking: aim at about one workgroup per CU (256) -- every workgroup
+    // pays (wz-1) ramp-up planes, so chunks must stay long
     const int cols = p.nxt * p.nyt;
     int nzc = (256 + cols - 1) / cols;
     const int min_chunk = 8 * (w[0] - 1) + 8;
     if (nzc > (int)(nz / min_chunk)) nzc = (int)(nz / min_chunk);
     if (nzc < 1) nzc = 1;
+    if (g_sep3d_zchunks > 0) nzc = g_sep3d_zchunks;
+    if ((nz + nzc - 1) / nzc > kMaxChunk) nzc = (int)((nz + kMaxChunk - 1) / kMaxChunk);
     p.zc = (int)((nz + nzc - 1) / nzc);
     p.nzc = (int)((nz + p.zc - 1) / p.zc);
 
     hipStream_t s = resolve_stream(stream);
     const float *ip = (const float *)in->data;
     float *op = (float *)out->data;
-#define CASE_Z(WXV)                                                        \
-    switch (w[0]) {                                                        \
-    case 1: return dispatch_cfg<WXV, 1>(ip, op, p, cfg, s);                \
-    case 3: return dispatch_cfg<WXV, 3>(ip, op, p, cfg, s);                \
-    case 5: return dispatch_cfg<WXV, 5>(ip, op, p, cfg, s);                \
-    case 7: return dispatch_cfg<WXV, 7>(ip, op, p, cfg, s);                \
-    default: return dispatch_cfg<WXV, 9>(ip, op, p, cfg, s);               \
+    if (lean) return launch_lean(w[0], cfg, ip, op, p, any_const, s);
+#define CASE_Z(WXV)                                            \
+    switch (w[0]) {                                            \
+    case 1: return launch_ws<WXV, 1>(ip, op, p, s);            \
+    case 3: return launch_ws<WXV, 3>(ip, op, p, s);            \
+    case 5: return launch_ws<WXV, 5>(ip, op, p, s);            \
+    case 7: return launch_ws<WXV, 7>(ip, op, p, s);            \
+    default: return launch_ws<WXV, 9>(ip, op, p, s);           \
     }
     switch (w[2]) {
     case 1: CASE_Z(1)
