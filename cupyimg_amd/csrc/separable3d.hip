@@ -520,8 +520,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
             const bool skip = HAS_CONST && zsrc < 0;
 #pragma unroll
             for (int r = 0; r < R; r++)
-                s.v[r] = (p.dbg & 32) ? as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], soff, 2))
-                                      : as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], soff, 0));
+                s.v[r] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], soff, 0));
             if constexpr (NE == 2) {
                 const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rin, skip ? kOOB : eoffv, soff, 0);
                 s.t[0] = __uint_as_float(q.x); s.t[1] = __uint_as_float(q.y);
@@ -628,9 +627,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
                 }
                 u32x4 u;
                 u.x = __float_as_uint(a.x); u.y = __float_as_uint(a.y); u.z = __float_as_uint(a.z); u.w = __float_as_uint(a.w);
-                if (p.dbg & 16) __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[g], soff, 2);
-                else if (p.dbg & 64) __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[g], soff, 17);
-                else __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[g], soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[g], soff, 0);
             }
         }
     }

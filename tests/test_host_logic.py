@@ -1,0 +1,108 @@
+"""Host-side logic that needs no device: argument normalisation, gaussian
+kernels, structures, slab planning."""
+import numpy as np
+import pytest
+import scipy.ndimage as sndi
+from scipy.ndimage._filters import _gaussian_kernel1d as scipy_gk
+
+from cupyimg_amd.distributed import SlabPlan, halo_widths
+from cupyimg_amd.scipy.ndimage import _support as S
+from cupyimg_amd.scipy.ndimage import filters, morphology
+
+
+def test_gaussian_kernel_matches_scipy():
+    for sigma in [0.3, 1.0, 2.5, 4.0]:
+        for order in range(4):
+            r = int(4 * sigma + 0.5)
+            assert np.allclose(filters._gaussian_kernel1d(sigma, order, r), scipy_gk(sigma, order, r),
+                               rtol=1e-12, atol=1e-15)
+    with pytest.raises(ValueError):
+        filters._gaussian_kernel1d(1.0, -1, 4)
+
+
+def test_generate_binary_structure():
+    for rank in range(0, 4):
+        for conn in range(0, rank + 2):
+            assert np.array_equal(morphology.generate_binary_structure(rank, conn),
+                                  sndi.generate_binary_structure(rank, conn))
+
+
+def test_origin_mode_sequence_checks():
+    assert S.check_origin(1, 3) == 1
+    for bad in (2, -2):
+        with pytest.raises(ValueError):
+            S.check_origin(bad, 3)
+    with pytest.raises(ValueError):
+        S.check_origin(1, 2)          # even length: valid origins are -1, 0
+    assert S.check_origin(-1, 2) == -1
+    with pytest.raises(RuntimeError):
+        S.check_mode("bogus")
+    for m in ("reflect", "constant", "nearest", "mirror", "wrap", "grid-mirror", "grid-wrap", "grid-constant"):
+        assert S.check_mode(m) == m
+    assert S.fix_sequence_arg(3, 2, "size", int) == [3, 3]
+    assert S.fix_sequence_arg("wrap", 3, "mode") == ["wrap"] * 3
+    with pytest.raises(RuntimeError):
+        S.fix_sequence_arg([1, 2, 3], 2, "size")
+    with pytest.raises(RuntimeError):
+        S.normalize_sequence([1, 2], 3)
+    with pytest.raises(NotImplementedError):
+        S.check_cval("constant", np.inf, True)
+    S.check_cval("constant", np.inf, False)
+    S.check_cval("reflect", np.nan, True)
+
+
+def test_halo_widths_follow_offset_rule():
+    assert halo_widths(5) == (2, 2)
+    assert halo_widths(9) == (4, 4)
+    assert halo_widths(4) == (2, 1)
+    assert halo_widths(5, origin=1) == (3, 1)
+    with pytest.raises(ValueError):
+        halo_widths(3, origin=2)
+
+
+@pytest.mark.parametrize("nz,nranks", [(512, 1), (512, 2), (512, 8), (100, 3), (37, 4)])
+def test_slab_plan_partitions_exactly(nz, nranks):
+    lo, hi = 2, 2
+    covered = []
+    for r in range(nranks):
+        p = SlabPlan(nz, nranks, r, lo, hi)
+        covered += list(range(p.z0, p.z1))
+        assert p.n_local == p.z1 - p.z0 and p.n_local >= 1
+        assert p.prev == (r - 1 if r > 0 else -1)
+        assert p.next == (r + 1 if r < nranks - 1 else -1)
+        assert p.n_ext == p.n_local + (lo if r > 0 else 0) + (hi if r < nranks - 1 else 0)
+        g = p.global_planes_of_ext()
+        assert list(g[p.local_slice]) == list(range(p.z0, p.z1))
+        if p.recv_from_prev() is not None:
+            assert list(g[p.recv_from_prev()]) == list(range(p.z0 - lo, p.z0))
+        if p.recv_from_next() is not None:
+            assert list(g[p.recv_from_next()]) == list(range(p.z1, p.z1 + hi))
+    assert covered == list(range(nz))
+
+
+def test_slab_plan_wrap_and_too_thin():
+    p0 = SlabPlan(16, 2, 0, 2, 2, wrap=True)
+    p1 = SlabPlan(16, 2, 1, 2, 2, wrap=True)
+    assert (p0.prev, p0.next, p1.prev, p1.next) == (1, 1, 0, 0)
+    assert list(p0.global_planes_of_ext()) == [14, 15] + list(range(0, 8)) + [8, 9]
+    with pytest.raises(ValueError):
+        SlabPlan(8, 8, 0, 2, 2)
+
+
+def test_slab_split_is_bit_identical_to_unsplit():
+    """The decomposition itself (host logic + any filter): filtering every
+    rank's extended slab and keeping the local planes reproduces the unsplit
+    result exactly, for every boundary mode."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((24, 9, 10)).astype(np.float32)
+    for mode in ["reflect", "constant", "nearest", "mirror", "wrap"]:
+        ref = sndi.uniform_filter(x, 5, mode=mode)
+        lo, hi = halo_widths(5)
+        for nranks in (2, 3):
+            out = np.empty_like(x)
+            for r in range(nranks):
+                p = SlabPlan(x.shape[0], nranks, r, lo, hi, wrap=(mode == "wrap"))
+                ext = x[p.global_planes_of_ext()]
+                res = sndi.uniform_filter(ext, 5, mode=mode)
+                out[p.z0:p.z1] = res[p.local_slice]
+            assert np.array_equal(out, ref), (mode, nranks)
