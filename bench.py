@@ -40,6 +40,20 @@ def synth(shape, seed=0):
     return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
 
 
+def measured_traffic(world):
+    """HBM bytes per launch from the rocprofv3 PMC passes of this same command
+    (profiles/r1_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction
+    applied).  Counters cannot be read from inside the process, so this is the
+    committed measurement, valid for the single-GPU workload only."""
+    if world != 1:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(x, gpu_out):
     """Oracle (kind "port", 1 core) + scipy.ndimage on the same array."""
     from oracle import ndimage as orc
@@ -169,8 +183,8 @@ def main():
         achieved = ALG_BYTES_PER_VOXEL * per_gpu_voxels / kernel_s / 1e9
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "mi::sep3d_kernel<5,5,*> (fused x/z/y separable pass)",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(world),
+            "kernel": "mi::sep3d_lean_kernel<5,12,4,3,1,false> (fused x/z/y separable pass)",
             "alg_bytes_per_launch": ALG_BYTES_PER_VOXEL * per_gpu_voxels,
             "avg_launch_us": round(kernel_s * 1e6, 2),
             "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
