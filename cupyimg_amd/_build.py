@@ -27,6 +27,7 @@ SOURCES = [
     ("copy.hip", []),
     ("correlate1d.hip", ["-ffp-contract=off"]),
     ("separable3d.hip", []),
+    ("stream3d.hip", []),
     ("correlate_nd.hip", ["-ffp-contract=off"]),
     ("minmax.hip", ["-ffp-contract=off"]),
     ("minmax3d_u8.hip", []),

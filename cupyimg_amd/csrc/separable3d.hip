@@ -33,57 +33,10 @@
 // checks (otherwise MI_ERR_UNSUPPORTED and the caller runs 1-D passes).
 // Arithmetic is float32 FMA; against SciPy's double-accumulate-round-per-pass
 // the difference is ~1e-7 relative (tolerance 1e-6, tests/test_gpu_filters.py).
-#include "common.hpp"
+#include "sep_common.hpp"
+#include "stream3d.hpp"
 
 namespace mi {
-
-constexpr int kMaxTaps = 9;
-
-struct Sep3dParams {
-    int nx, ny, nz;
-    int wy;                 // taps along y (run-time loop)
-    int oy, oz;             // w/2 + origin for y and z (x offset is WX/2)
-    int mx, my, mz;         // boundary modes (filter_mode()-normalised)
-    float cval;
-    int ty;                 // output rows per tile
-    int zc;                 // output planes per chunk
-    int nxt, nyt, nzc;      // tile counts
-    float wx[kMaxTaps], wyv[kMaxTaps], wz[kMaxTaps];
-    int dbg;                // tuning ablations (0 in production): 1 no x/z math, 2 no stores, 4 no loads, 8 no y math
-};
-
-struct __attribute__((packed, aligned(4))) float4u { float x, y, z, w; };
-
-enum { EDGE_FWD = 0, EDGE_REV = 1, EDGE_SPLAT = 2, EDGE_CONST = 3 };
-
-// where the 4 floats left of x0 (side 0) / right of xe (side 1) come from
-__device__ __forceinline__ void edge_desc(int side, int x0, int xe, int nx, int mode, int *start, int *kind)
-{
-    if (side == 0) {
-        if (x0 > 0) { *start = x0 - 4; *kind = EDGE_FWD; return; }
-        switch (mode) {
-        case MI_MODE_REFLECT:   *start = 0; *kind = EDGE_REV; break;          // x[-k] = x[k-1]
-        case MI_MODE_MIRROR:    *start = 1; *kind = EDGE_REV; break;          // x[-k] = x[k]
-        case MI_MODE_NEAREST:   *start = 0; *kind = EDGE_SPLAT; break;
-        case MI_MODE_GRID_WRAP: *start = nx - 4; *kind = EDGE_FWD; break;
-        default:                *start = 0; *kind = EDGE_CONST; break;
-        }
-    } else {
-        if (xe < nx) { *start = xe; *kind = EDGE_FWD; return; }
-        switch (mode) {
-        case MI_MODE_REFLECT:   *start = nx - 4; *kind = EDGE_REV; break;     // x[n-1+k] = x[n-k]
-        case MI_MODE_MIRROR:    *start = nx - 5; *kind = EDGE_REV; break;     // x[n-1+k] = x[n-1-k]
-        case MI_MODE_NEAREST:   *start = nx - 1; *kind = EDGE_SPLAT; break;
-        case MI_MODE_GRID_WRAP: *start = 0; *kind = EDGE_FWD; break;
-        default:                *start = 0; *kind = EDGE_CONST; break;
-        }
-    }
-}
-
-__device__ __forceinline__ float comp(const float4 &v, int k)
-{
-    return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
-}
 
 // ---------------------------------------------------------------------------
 // v2: wave-specialised variant.  NWP producer waves own the rows (load, x pass,
@@ -96,17 +49,6 @@ __device__ __forceinline__ float comp(const float4 &v, int k)
 // Lane shifts for the x pass use DPP wave_shr:1 / wave_shl:1 (one VALU op, no
 // LDS crossbar); lane 0 keeps `old` = its left halo value.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float dpp_from_left(float keep_for_lane0, float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep_for_lane0), __float_as_int(v),
-                                                      0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float dpp_from_right(float keep_for_lane63, float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep_for_lane63), __float_as_int(v),
-                                                      0x130 /* wave_shl:1 */, 0xf, 0xf, false));
-}
-
 // edge halo: NE floats per side held by lanes 0 and `last` (NE = 2 for reach <= 2, else 4)
 template <int WX>
 __device__ __forceinline__ float4 xpass_dpp(const float4 v, const float (&edge)[(WX / 2 <= 2) ? 2 : 4], int lane,
@@ -148,13 +90,6 @@ struct RowRegs {
 };
 
 constexpr int kMaxChunk = 2048;   // planes per z chunk (plane-index table lives in LDS)
-
-template <int NE>
-__device__ __forceinline__ float pick(const float (&t)[NE], int idx)
-{
-    if constexpr (NE == 2) return idx ? t[1] : t[0];
-    else return idx & 2 ? (idx & 1 ? t[3] : t[2]) : (idx & 1 ? t[1] : t[0]);
-}
 
 template <int WX, int WZ, int NWP, int NWC, int R>
 __global__ void __launch_bounds__((NWP + NWC) * 64)
@@ -380,24 +315,6 @@ static int launch_sep3d_ws(const float *in, float *out, const Sep3dParams &p, hi
 //   * consumers read their G + W - 1 LDS rows once and slide over them.
 // Precondition (host): volume < 2 GiB (32-bit buffer offsets).
 // ---------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-constexpr unsigned kOOB = 0x80000000u;   // >= num_records of any descriptor we build
-
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
-
-__device__ __forceinline__ float4 as_f4(u32x4 u)
-{
-    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-}
-
 // x pass with the tile-edge halo given as wave-uniform scalars (sL: the NE
 // floats left of the tile, sR: the NE floats right of it)
 template <int WX, int NE>
@@ -714,6 +631,9 @@ static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams 
     }
 }
 
+int run_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axis, const float *wav, int wa, int oa,
+                    int ma, const float *wxv, int wx, int mx, float cval, hipStream_t s);   // stream3d.hip
+
 }  // namespace mi
 
 using namespace mi;
@@ -757,16 +677,16 @@ extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const
     memset(&p, 0, sizeof(p));
     int w[3];
     bool normalised = true;
-    float *dstw[3] = {p.wz, p.wyv, p.wx};
+    float wbuf[3][kStreamMaxTaps];
     for (int a = 0; a < 3; a++) {
         w[a] = weights[a] ? wlen[a] : 1;
-        if (w[a] < 1 || w[a] > kMaxTaps || !(w[a] & 1)) UNSUP("taps must be odd and <= 9");
+        if (w[a] < 1 || w[a] > kStreamMaxTaps || !(w[a] & 1)) UNSUP("taps must be odd and <= 33");
         const int off = w[a] / 2 + (weights[a] ? origin[a] : 0);
         if (off < 0 || off >= w[a]) { set_error("invalid origin"); return MI_ERR_INVALID_ARG; }
         double sum = 0.0;
         for (int k = 0; k < w[a]; k++) {
             const double v = weights[a] ? weights[a][k] : 1.0;
-            dstw[a][k] = (float)v;
+            wbuf[a][k] = (float)v;
             sum += v;
         }
         if (fabs(sum - 1.0) > 1e-6) normalised = false;
@@ -775,6 +695,41 @@ extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const
     p.mz = filter_mode(mode[0]); p.my = filter_mode(mode[1]); p.mx = filter_mode(mode[2]);
     const bool any_const = p.mz == MI_MODE_CONSTANT || p.my == MI_MODE_CONSTANT || p.mx == MI_MODE_CONSTANT;
     if (any_const && !normalised) UNSUP("constant mode needs kernels that sum to one");
+
+    if (w[0] > kMaxTaps || w[1] > kMaxTaps || w[2] > kMaxTaps) {
+        // long kernels: streaming passes (stream3d.hip), x fused into the z pass when the tap counts agree
+        if (nz * ny * nx * 4 >= ((int64_t)1 << 31)) UNSUP("streaming passes need a volume < 2 GiB");
+        if (nx < 16) UNSUP("x extent too small for the streaming x pass");
+        if (w[2] > 17) UNSUP("x kernels longer than 17 taps have no register x pass");
+        hipStream_t s = resolve_stream(stream);
+        const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
+        struct Pass { int axis, wa, oa, ma, wx; };
+        Pass passes[3];
+        int np = 0;
+        const bool fuse_xz = w[2] > 1 && w[2] == w[0];
+        if (w[2] > 1 && !fuse_xz) passes[np++] = {1, 1, 0, p.my, w[2]};            // x only (streams over y)
+        if (w[0] > 1) passes[np++] = {0, w[0], oz, p.mz, fuse_xz ? w[2] : 1};
+        if (w[1] > 1) passes[np++] = {1, w[1], oy, p.my, 1};
+        const size_t bytes = (size_t)(nz * ny * nx) * sizeof(float);
+        void *tmp[2] = {nullptr, nullptr};
+        for (int t = 0; t < np - 1 && t < 2; t++)
+            if ((rc = pool_alloc(&tmp[t], bytes))) { if (tmp[0]) pool_free(tmp[0]); return rc; }
+        const float *src = (const float *)in->data;
+        const float one = 1.0f;
+        for (int i = 0; i < np && rc == MI_OK; i++) {
+            float *dst = i == np - 1 ? (float *)out->data : (float *)tmp[i & 1];
+            const Pass &q = passes[i];
+            const float *wav = q.wa > 1 ? wbuf[q.axis == 0 ? 0 : 1] : &one;
+            rc = run_stream_pass(src, dst, (int)nz, (int)ny, (int)nx, q.axis, wav, q.wa, q.oa, q.ma,
+                                 q.wx > 1 ? wbuf[2] : nullptr, q.wx, p.mx, (float)cval, s);
+            src = dst;
+        }
+        for (int t = 0; t < 2; t++) if (tmp[t]) pool_free(tmp[t]);   // reuse is stream ordered
+        return rc;
+    }
+    memcpy(p.wz, wbuf[0], sizeof(float) * w[0]);
+    memcpy(p.wyv, wbuf[1], sizeof(float) * w[1]);
+    memcpy(p.wx, wbuf[2], sizeof(float) * w[2]);
     p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
     p.wy = w[1];
     p.oz = w[0] / 2 + (weights[0] ? origin[0] : 0);

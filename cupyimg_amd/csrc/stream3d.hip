@@ -1,0 +1,293 @@
+// stream3d.hip -- barrier-free streaming separable passes, float32 3-D
+// (design notes in stream3d.hpp).  Entry point for the host: run_stream_passes()
+// called from mi_separable3d_f32 (separable3d.hip).
+//
+// Reference path replaced: gaussian_filter / uniform_filter with long kernels,
+// cupyimg/scipy/ndimage/filters.py:602-665,725-792 (three K1 launches, fp64
+// taps from global memory, zero-fill + copy-back per in-place pass).
+#include "sep_common.hpp"
+#include "stream3d.hpp"
+
+namespace mi {
+
+// block j (1 = nearest, 2 = next) of 4 floats outside the tile on `side`
+// (0 left, 1 right): element offset inside the row to load 4 floats from, and
+// what to do with them
+__device__ __forceinline__ void edge_block(int side, int j, int x0, int xe, int nx, int mode, int *start, int *kind)
+{
+    if (side == 0) {
+        if (x0 - 4 * j >= 0) { *start = x0 - 4 * j; *kind = EDGE_FWD; return; }
+        const int k0 = 4 * j - x0;   // how far the block's far end reaches beyond the array (x0 is a multiple of 256: 0 here)
+        (void)k0;
+        switch (mode) {
+        case MI_MODE_REFLECT:   *start = 4 * (j - 1); *kind = EDGE_REV; break;        // ext -k = x[k-1]
+        case MI_MODE_MIRROR:    *start = 4 * (j - 1) + 1; *kind = EDGE_REV; break;    // ext -k = x[k]
+        case MI_MODE_NEAREST:   *start = 0; *kind = EDGE_SPLAT; break;
+        case MI_MODE_GRID_WRAP: *start = nx - 4 * j; *kind = EDGE_FWD; break;
+        default:                *start = 0; *kind = EDGE_CONST; break;
+        }
+    } else {
+        if (xe + 4 * j <= nx) { *start = xe + 4 * (j - 1); *kind = EDGE_FWD; return; }
+        switch (mode) {
+        case MI_MODE_REFLECT:   *start = nx - 4 * j; *kind = EDGE_REV; break;         // ext n-1+k = x[n-k]
+        case MI_MODE_MIRROR:    *start = nx - 1 - 4 * j; *kind = EDGE_REV; break;     // ext n-1+k = x[n-1-k]
+        case MI_MODE_NEAREST:   *start = nx - 4; *kind = EDGE_SPLAT; break;           // splat component 3
+        case MI_MODE_GRID_WRAP: *start = 4 * (j - 1); *kind = EDGE_FWD; break;
+        default:                *start = 0; *kind = EDGE_CONST; break;
+        }
+    }
+}
+
+__device__ __forceinline__ float4 apply_kind(float4 t, int kind, int side, float cval)
+{
+    if (kind == EDGE_REV) return make_float4(t.w, t.z, t.y, t.x);
+    if (kind == EDGE_SPLAT) { const float s = side == 0 ? t.x : t.w; return make_float4(s, s, s, s); }
+    if (kind == EDGE_CONST) return make_float4(cval, cval, cval, cval);
+    return t;
+}
+
+__device__ __forceinline__ float4 dpp4_from_left(const float4 keep, const float4 v)
+{
+    return make_float4(dpp_from_left(keep.x, v.x), dpp_from_left(keep.y, v.y), dpp_from_left(keep.z, v.z),
+                       dpp_from_left(keep.w, v.w));
+}
+__device__ __forceinline__ float4 dpp4_from_right(const float4 keep, const float4 v)
+{
+    return make_float4(dpp_from_right(keep.x, v.x), dpp_from_right(keep.y, v.y), dpp_from_right(keep.z, v.z),
+                       dpp_from_right(keep.w, v.w));
+}
+__device__ __forceinline__ float4 sel4(bool c, const float4 a, const float4 b) { return c ? a : b; }
+
+// x pass, odd WX <= 17 (reach <= 8 = two lane hops).  eL[j] / eR[j]: the j-th
+// 4-float block outside the tile, valid in lane 0 / lane `last` respectively.
+template <int WX>
+__device__ __forceinline__ float4 xpass_hops(const float4 v, const float4 (&eL)[2], const float4 (&eR)[2], int lane,
+                                             int last, const float *__restrict__ wx)
+{
+    if constexpr (WX == 1) {
+        return make_float4(v.x * wx[0], v.y * wx[0], v.z * wx[0], v.w * wx[0]);
+    } else {
+        constexpr int RX = WX / 2;
+        constexpr int NB = (RX + 3) / 4;            // blocks per side
+        // window of 4 * (2 NB + 1) floats: [L_NB .. L_1 | v | R_1 .. R_NB]
+        float4 blk[2 * NB + 1];
+        blk[NB] = v;
+        float4 l = v, r = v;
+#pragma unroll
+        for (int j = 1; j <= NB; j++) {
+            l = dpp4_from_left(eL[j - 1], l);       // lane 0 keeps the edge block, lane 1 then inherits it
+            r = sel4(lane == last, eR[j - 1], dpp4_from_right(eR[j - 1], r));
+            blk[NB - j] = l;
+            blk[NB + j] = r;
+        }
+        float e[4 * (2 * NB + 1)];
+#pragma unroll
+        for (int b = 0; b < 2 * NB + 1; b++) {
+            e[4 * b + 0] = blk[b].x; e[4 * b + 1] = blk[b].y; e[4 * b + 2] = blk[b].z; e[4 * b + 3] = blk[b].w;
+        }
+        constexpr int BASE = 4 * NB - RX;           // e[BASE + c + k] = in[x + c - RX + k]
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float a = wx[0] * e[BASE + c];
+#pragma unroll
+            for (int k = 1; k < WX; k++) a = fmaf(wx[k], e[BASE + c + k], a);
+            o[c] = a;
+        }
+        return make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
+constexpr int lcm_(int a, int b) { return a / gcd_(a, b) * b; }
+
+template <int WX, int WA, int DEPTH>
+__global__ void __launch_bounds__(256)
+stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const StreamParams p)
+{
+    constexpr int RX = WX / 2;
+    constexpr int NB = WX > 1 ? (RX + 3) / 4 : 0;
+    constexpr int RINGN = WA - 1;
+    constexpr int U = RINGN > 0 ? lcm_(RINGN, DEPTH) : DEPTH;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nother = p.axis == 0 ? ny : nz;
+    const int nA = p.axis == 0 ? nz : ny;
+    const int nlines = nother * p.nxt;
+    const int wid = blockIdx.x * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int oth = line / p.nxt, xt = line - oth * p.nxt;
+    const int x0 = xt * 256;
+    const int nlanes = min(64, (nx - x0) >> 2);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;               // elements
+    const unsigned strideA = p.axis == 0 ? plane : (unsigned)nx;      // elements between streamed samples
+    const unsigned rowbase = p.axis == 0 ? (unsigned)oth * nx : (unsigned)oth * plane;   // elements
+    const unsigned total_bytes = plane * (unsigned)nz * 4u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? (rowbase + (unsigned)(x0 + 4 * lane)) * 4u : kOOB;
+
+    // tile-edge blocks for the x pass (lane 0: left, lane `last`: right)
+    unsigned evoff[2] = {kOOB, kOOB};
+    int ekind[2] = {EDGE_FWD, EDGE_FWD};
+    const int side = lane == 0 ? 0 : 1;
+    if constexpr (WX > 1) {
+        const bool is_edge_lane = lane == 0 || lane == last;
+#pragma unroll
+        for (int j = 1; j <= NB; j++) {
+            int st, kd;
+            edge_block(side, j, x0, x0 + 4 * nlanes, nx, p.mx, &st, &kd);
+            ekind[j - 1] = kd;
+            if (is_edge_lane && kd != EDGE_CONST) evoff[j - 1] = (rowbase + (unsigned)st) * 4u;
+        }
+    }
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, nA);
+    const int nsteps = a1 - a0 + WA - 1;
+    const int ai0 = a0 - p.oa;
+
+    struct Slot { float4 v; float4 e[NB > 0 ? NB : 1]; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        const int ai = bmap<int>(ai0 + i, nA, p.ma);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * strideA * 4u;
+        s.v = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0));
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+            s.e[j] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : evoff[j], soff, 0));
+    };
+
+    float4 ring[RINGN > 0 ? RINGN : 1];
+#pragma unroll
+    for (int k = 0; k < (RINGN > 0 ? RINGN : 1); k++) ring[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    const float4 cv4 = make_float4(p.cval, p.cval, p.cval, p.cval);
+    for (int i0 = 0; i0 < nsteps; i0 += U) {
+        static_for<U>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J % DEPTH];
+                float4 v = s.cst ? cv4 : s.v;
+                float4 eL[2] = {cv4, cv4}, eR[2] = {cv4, cv4};
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const float4 t = s.cst ? cv4 : apply_kind(s.e[j], ekind[j], side, p.cval);
+                    eL[j] = t;
+                    eR[j] = t;
+                }
+                const float4 xf = xpass_hops<WX>(v, eL, eR, lane, last, p.wxv);
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                if (i >= WA - 1) {
+                    float4 a;
+                    if constexpr (WA == 1) {
+                        a = make_float4(p.wav[0] * xf.x, p.wav[0] * xf.y, p.wav[0] * xf.z, p.wav[0] * xf.w);
+                    } else {
+                        const float4 &q0 = ring[J % RINGN];
+                        a = make_float4(p.wav[0] * q0.x, p.wav[0] * q0.y, p.wav[0] * q0.z, p.wav[0] * q0.w);
+#pragma unroll
+                        for (int k = 1; k < RINGN; k++) {
+                            const float4 &q = ring[(J + k) % RINGN];
+                            a.x = fmaf(p.wav[k], q.x, a.x);
+                            a.y = fmaf(p.wav[k], q.y, a.y);
+                            a.z = fmaf(p.wav[k], q.z, a.z);
+                            a.w = fmaf(p.wav[k], q.w, a.w);
+                        }
+                        a.x = fmaf(p.wav[WA - 1], xf.x, a.x);
+                        a.y = fmaf(p.wav[WA - 1], xf.y, a.y);
+                        a.z = fmaf(p.wav[WA - 1], xf.z, a.z);
+                        a.w = fmaf(p.wav[WA - 1], xf.w, a.w);
+                    }
+                    const unsigned so = (unsigned)(a0 + i - (WA - 1)) * strideA * 4u;
+                    u32x4 u;
+                    u.x = __float_as_uint(a.x); u.y = __float_as_uint(a.y); u.z = __float_as_uint(a.z); u.w = __float_as_uint(a.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(u, rout, voff, so, 0);
+                }
+                if constexpr (RINGN > 0) ring[J % RINGN] = xf;
+            }
+        });
+    }
+}
+
+template <int WX, int WA>
+static int launch_stream(const float *in, float *out, StreamParams &p, hipStream_t s)
+{
+    constexpr int DEPTH = (WA - 1) % 4 == 0 && WA > 1 ? 4 : 2;
+    const int nA = p.axis == 0 ? p.nz : p.ny;
+    const int nother = p.axis == 0 ? p.ny : p.nz;
+    const int nlines = nother * p.nxt;
+    // chunks: enough waves to fill the chip (256 CUs x 16 waves) while keeping the
+    // (WA-1)-sample ramp-up below ~1/8 of a chunk
+    int nch = (4096 + nlines - 1) / nlines;
+    const int min_chunk = 8 * (WA - 1) + 8;
+    if (nch > nA / min_chunk) nch = nA / min_chunk;
+    if (nch < 1) nch = 1;
+    p.chunk = (nA + nch - 1) / nch;
+    p.nchunks = (nA + p.chunk - 1) / p.chunk;
+    const int waves = nlines * p.nchunks;
+    hipLaunchKernelGGL((stream_pass_kernel<WX, WA, DEPTH>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+// switch over odd tap counts 1..33 for one template slot
+#define MI_ODD_CASES(X) X(1) X(3) X(5) X(7) X(9) X(11) X(13) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31) X(33)
+
+template <int WX>
+static int launch_stream_wa(int wa, const float *in, float *out, StreamParams &p, hipStream_t s)
+{
+    switch (wa) {
+#define X(N) case N: return launch_stream<WX, N>(in, out, p, s);
+        MI_ODD_CASES(X)
+#undef X
+    }
+    set_error("stream pass: unsupported tap count %d", wa);
+    return MI_ERR_UNSUPPORTED;
+}
+
+// one streaming pass along `axis` (0 = z, 1 = y) with `wa` taps; optional
+// fused x pass with `wx` taps (1 = none; only together with the same tap count
+// or none, to bound the number of instantiations)
+int run_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axis, const float *wav, int wa, int oa,
+                    int ma, const float *wxv, int wx, int mx, float cval, hipStream_t s)
+{
+    StreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.nx = nx; p.ny = ny; p.nz = nz;
+    p.axis = axis;
+    p.wa = wa; p.oa = oa; p.ma = ma; p.mx = mx;
+    p.cval = cval;
+    p.nxt = (nx + 255) / 256;
+    for (int k = 0; k < wa; k++) p.wav[k] = wav[k];
+    for (int k = 0; k < wx; k++) p.wxv[k] = wxv ? wxv[k] : 1.0f;
+    if (wx == 1) return launch_stream_wa<1>(wa, in, out, p, s);
+    if (wa == 1) {
+        switch (wx) {
+#define X(N) case N: if constexpr (N <= 17) return launch_stream<N, 1>(in, out, p, s); break;
+            MI_ODD_CASES(X)
+#undef X
+        }
+    } else if (wx == wa) {
+        switch (wx) {
+#define X(N) case N: if constexpr (N <= 17 && N > 1) return launch_stream<N, N>(in, out, p, s); break;
+            MI_ODD_CASES(X)
+#undef X
+        }
+    }
+    set_error("stream pass: unsupported x/axis tap combination %d/%d", wx, wa);
+    return MI_ERR_UNSUPPORTED;
+}
+
+}  // namespace mi

@@ -148,7 +148,7 @@ def _try_fused_3d(input, output, weights, origins, modes, cval, is_box):
     if not any(w is not None for w in weights):
         return None
     for w, o in zip(weights, origins):
-        if w is not None and (len(w) > 9 or len(w) % 2 == 0):
+        if w is not None and (len(w) > 33 or len(w) % 2 == 0):
             return None
     if weights[2] is not None and origins[2] != 0:
         return None

@@ -56,13 +56,21 @@ def test_gaussian_filter_fused_f32(gpu, ndi, sigma):
             assert maxnorm_rel(got, ref) <= 1e-6, (sigma, mode, order)
 
 
-def test_gaussian_sigma2_three_pass(gpu, ndi):
-    # 17 taps per axis: beyond the fused kernel, runs three generic passes
+@pytest.mark.parametrize("shape", [(40, 40, 40), (37, 29, 264), (20, 70, 512)])
+def test_gaussian_long_kernels_streaming(gpu, ndi, shape):
+    """> 9 taps per axis: two streaming launches (x fused into the z pass) -- stream3d.hip"""
     rng = np.random.default_rng(6)
-    x = rng.standard_normal((40, 40, 40)).astype(np.float32)
-    ref = orc.gaussian_filter(x, 2.0)
-    got = ndi.gaussian_filter(gpu.asarray(x), 2.0).get()
-    assert np.array_equal(got, ref) or maxnorm_rel(got, ref) <= 1e-7
+    x = rng.standard_normal(shape).astype(np.float32)
+    xd = gpu.asarray(x)
+    for sigma, mode in [(2.0, "reflect"), (2.0, "mirror"), (3.0, "nearest"), (2.5, "wrap"), (2.0, "constant"),
+                        ((2.0, 1.0, 3.0), "reflect"), ((0.0, 2.0, 0.0), "mirror"), ((1.5, 0.0, 4.0), "reflect")]:
+        ref = orc.gaussian_filter(x, sigma, mode=mode, cval=0.3)
+        got = ndi.gaussian_filter(xd, sigma, mode=mode, cval=0.3).get()
+        assert maxnorm_rel(got, ref) <= 1e-6, (shape, sigma, mode, maxnorm_rel(got, ref))
+    for size in [11, 15, (13, 5, 17)]:
+        ref = orc.uniform_filter(x, size, mode="reflect")
+        got = ndi.uniform_filter(xd, size, mode="reflect").get()
+        assert maxnorm_rel(got, ref) <= 1e-6, (shape, size, maxnorm_rel(got, ref))
 
 
 # ------------------------------------------------------------------ generic
