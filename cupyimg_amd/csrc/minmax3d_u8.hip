@@ -1,12 +1,329 @@
-// minmax3d_u8.hip -- fused separable 3-D min / max for uint8 volumes
-// (grey_erosion / grey_dilation with a flat, full `size` structuring element:
-// cupyimg/scipy/ndimage/morphology.py:769-884 -> filters.py:1385-1396, three
-// K2 launches + two zero-filled ping-pong buffers in the reference).
+// minmax3d_u8.hip -- separable 3-D min / max for uint8 volumes in two
+// barrier-free streaming launches (x pass fused into the z pass, then y pass).
 //
-// Round 1: the fused kernel is not built yet; the entry point reports
-// MI_ERR_UNSUPPORTED and the host runs the three generic 1-D passes
-// (mi_minmax1d), which are bit-exact.  See DESIGN.md "next".
-#include "common.hpp"
+// Replaces, for grey_erosion / grey_dilation / minimum_filter / maximum_filter
+// with a flat full `size` structuring element on uint8 volumes
+// (cupyimg/scipy/ndimage/morphology.py:769-884 -> filters.py:1385-1396), the
+// reference's three K2 launches + two zero-filled ping-pong volumes, whose
+// generated kernel reads one byte per lane per tap and compares in double
+// (filters.py:1522-1528).  Results are integer-exact (no arithmetic, only
+// comparisons), so parity with SciPy is bit-exact.
+//
+// Data layout: lane l of a wave holds 16 consecutive voxels (one uint4), a wave
+// a 1 KiB row segment, so every access is a coalesced buffer_load/store_dwordx4.
+// gfx950 has no packed 8-bit min/max, so bytes are kept "even/odd split":
+// every dword is carried as E = bytes {0,2} and O = bytes {1,3}, each widened to
+// two u16 lanes, and all comparisons are v_pk_min_u16 / v_pk_max_u16 (two
+// voxels per lane per instruction).  A one-voxel shift along x swaps the roles
+// of E and O plus one v_alignbit; sliding windows along x are built by
+// doubling (2, 4, then W), along the streamed axis from a register ring of the
+// previous W-1 samples that is rotated by unrolling.
+#include "sep_common.hpp"
+
+namespace mi {
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <bool IS_MAX>
+__device__ __forceinline__ unsigned op2(unsigned a, unsigned b)
+{
+    // elementwise on two packed u16 (v_pk_min_u16 / v_pk_max_u16)
+    const u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    const u16x2 r = IS_MAX ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__device__ __forceinline__ unsigned align16(unsigned hi, unsigned lo)   // (lo >> 16) | (hi << 16)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, 16);
+}
+
+// 16 voxels of one lane, even/odd split: e[k] = bytes {4k, 4k+2}, o[k] = bytes {4k+1, 4k+3}
+struct Vec16 { unsigned e[4], o[4]; };
+
+__device__ __forceinline__ void split(unsigned d, unsigned &e, unsigned &o)
+{
+    e = d & 0x00FF00FFu;
+    o = (d >> 8) & 0x00FF00FFu;
+}
+__device__ __forceinline__ unsigned join(unsigned e, unsigned o) { return e | (o << 8); }
+
+template <bool IS_MAX>
+__device__ __forceinline__ Vec16 op16(const Vec16 &a, const Vec16 &b)
+{
+    Vec16 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { r.e[k] = op2<IS_MAX>(a.e[k], b.e[k]); r.o[k] = op2<IS_MAX>(a.o[k], b.o[k]); }
+    return r;
+}
+
+// Byte stream of 6 dwords in split form (dword 0 = left neighbour's last 4
+// voxels, 1..4 = own 16 voxels, 5 = right neighbour's first 4 voxels).
+struct Win { unsigned e[7], o[7]; };   // index 6 = padding (never reaches a used byte)
+
+// T[i] = S[i + s] for s = 1, 2, 3, 4 (voxels)
+template <int SH>
+__device__ __forceinline__ Win shiftw(const Win &s)
+{
+    Win t;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if constexpr (SH == 1) { t.e[k] = s.o[k]; t.o[k] = align16(s.e[k + 1], s.e[k]); }
+        else if constexpr (SH == 2) { t.e[k] = align16(s.e[k + 1], s.e[k]); t.o[k] = align16(s.o[k + 1], s.o[k]); }
+        else if constexpr (SH == 3) { t.e[k] = align16(s.o[k + 1], s.o[k]); t.o[k] = s.e[k + 1]; }
+        else { t.e[k] = s.e[k + 1]; t.o[k] = s.o[k + 1]; }
+    }
+    t.e[6] = s.e[6]; t.o[6] = s.o[6];
+    return t;
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ Win opw(const Win &a, const Win &b)
+{
+    Win r;
+#pragma unroll
+    for (int k = 0; k < 7; k++) { r.e[k] = op2<IS_MAX>(a.e[k], b.e[k]); r.o[k] = op2<IS_MAX>(a.o[k], b.o[k]); }
+    return r;
+}
+
+// sliding min/max of width WX along x, centred: out[x] = op(b[x-r .. x+r]), r = WX/2 <= 4
+template <int WX, bool IS_MAX>
+__device__ __forceinline__ Vec16 xpass_u8(const Win &b)
+{
+    constexpr int RX = WX / 2;
+    Win m;
+    if constexpr (WX == 1) {
+        m = b;
+    } else if constexpr (WX == 3) {
+        m = opw<IS_MAX>(opw<IS_MAX>(b, shiftw<1>(b)), shiftw<2>(b));
+    } else {
+        const Win m2 = opw<IS_MAX>(b, shiftw<1>(b));
+        const Win m4 = opw<IS_MAX>(m2, shiftw<2>(m2));
+        if constexpr (WX == 5) m = opw<IS_MAX>(m4, shiftw<4>(b));
+        else if constexpr (WX == 7) m = opw<IS_MAX>(m4, shiftw<3>(m4));
+        else {   // 9
+            const Win m8 = opw<IS_MAX>(m4, shiftw<4>(m4));
+            Win b8;   // b shifted by 8 voxels = two dwords
+#pragma unroll
+            for (int k = 0; k < 7; k++) { b8.e[k] = b.e[k + 2 < 7 ? k + 2 : 6]; b8.o[k] = b.o[k + 2 < 7 ? k + 2 : 6]; }
+            m = opw<IS_MAX>(m8, b8);
+        }
+    }
+    // m[i] covers b[i .. i+WX-1]; output voxel j (window byte 4 + j) = m[4 - RX + j]
+    Win s;
+    if constexpr (RX == 4 || WX == 1) {
+        // WX == 1: plain copy, own voxels start at byte 4 -> shift 4; RX == 4: shift 0
+        if constexpr (WX == 1) s = shiftw<4>(m); else s = m;
+    } else if constexpr (RX == 3) s = shiftw<1>(m);
+    else if constexpr (RX == 2) s = shiftw<2>(m);
+    else s = shiftw<3>(m);
+    Vec16 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { r.e[k] = s.e[k]; r.o[k] = s.o[k]; }
+    return r;
+}
+
+struct U8StreamParams {
+    int nx, ny, nz;
+    int axis;            // streamed axis: 0 = z, 1 = y
+    int oa, ma;          // offset (w/2 + origin) / mode along the streamed axis
+    int mx;              // x boundary mode
+    unsigned cval4;      // cval byte replicated to 4 bytes
+    int chunk, nchunks, nxt;
+};
+
+__device__ __forceinline__ unsigned bswap32(unsigned x) { return __builtin_bswap32(x); }
+
+// the 4 voxels outside the tile on `side`: byte offset inside the row to load a
+// dword from, and the fix-up
+__device__ __forceinline__ void edge_u8(int side, int x0, int xe, int nx, int mode, int *start, int *kind)
+{
+    if (side == 0) {
+        if (x0 > 0) { *start = x0 - 4; *kind = EDGE_FWD; return; }
+        switch (mode) {
+        case MI_MODE_REFLECT:   *start = 0; *kind = EDGE_REV; break;
+        case MI_MODE_MIRROR:    *start = 1; *kind = EDGE_REV; break;
+        case MI_MODE_NEAREST:   *start = 0; *kind = EDGE_SPLAT; break;
+        case MI_MODE_GRID_WRAP: *start = nx - 4; *kind = EDGE_FWD; break;
+        default:                *start = 0; *kind = EDGE_CONST; break;
+        }
+    } else {
+        if (xe < nx) { *start = xe; *kind = EDGE_FWD; return; }
+        switch (mode) {
+        case MI_MODE_REFLECT:   *start = nx - 4; *kind = EDGE_REV; break;
+        case MI_MODE_MIRROR:    *start = nx - 5; *kind = EDGE_REV; break;
+        case MI_MODE_NEAREST:   *start = nx - 4; *kind = EDGE_SPLAT; break;
+        case MI_MODE_GRID_WRAP: *start = 0; *kind = EDGE_FWD; break;
+        default:                *start = 0; *kind = EDGE_CONST; break;
+        }
+    }
+}
+
+template <int WX, int WA, bool IS_MAX>
+__global__ void __launch_bounds__(256)
+stream_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8StreamParams p)
+{
+    constexpr int DEPTH = 2;
+    constexpr int RINGN = WA - 1;
+    constexpr int U = RINGN > 0 ? (RINGN % 2 == 0 ? RINGN : 2 * RINGN) : DEPTH;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nother = p.axis == 0 ? ny : nz;
+    const int nA = p.axis == 0 ? nz : ny;
+    const int nlines = nother * p.nxt;
+    const int wid = blockIdx.x * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int oth = line / p.nxt, xt = line - oth * p.nxt;
+    const int x0 = xt * 1024;
+    const int nlanes = min(64, (nx - x0) >> 4);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;               // bytes
+    const unsigned strideA = p.axis == 0 ? plane : (unsigned)nx;
+    const unsigned rowbase = p.axis == 0 ? (unsigned)oth * nx : (unsigned)oth * plane;
+    const unsigned total_bytes = plane * (unsigned)nz;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? rowbase + (unsigned)(x0 + 16 * lane) : kOOB;
+
+    // tile-edge dword for the x pass (lane 0: the 4 voxels left of the tile, lane `last`: right of it)
+    unsigned evoff = kOOB;
+    int ekind = EDGE_FWD;
+    const int side = lane == 0 ? 0 : 1;
+    if constexpr (WX > 1) {
+        int st;
+        edge_u8(side, x0, x0 + 16 * nlanes, nx, p.mx, &st, &ekind);
+        if ((lane == 0 || lane == last) && ekind != EDGE_CONST) evoff = rowbase + (unsigned)st;
+    }
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, nA);
+    const int nsteps = a1 - a0 + WA - 1;
+    const int ai0 = a0 - p.oa;
+
+    struct Slot { u32x4 v; unsigned e; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        const int ai = bmap<int>(ai0 + i, nA, p.ma);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * strideA;
+        s.v = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0);
+        if constexpr (WX > 1) s.e = __builtin_amdgcn_raw_buffer_load_b32(rin, s.cst ? kOOB : evoff, soff, 0);
+        else s.e = 0;
+    };
+
+    Vec16 ring[RINGN > 0 ? RINGN : 1];
+
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    for (int i0 = 0; i0 < nsteps; i0 += U) {
+        static_for<U>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J % DEPTH];
+                u32x4 v = s.v;
+                unsigned ed = s.e;
+                if (s.cst) { v.x = v.y = v.z = v.w = p.cval4; ed = p.cval4; }
+                Vec16 xf;
+                if constexpr (WX > 1) {
+                    // edge dword fix-up for this lane's side
+                    if (!s.cst) {
+                        if (ekind == EDGE_REV) ed = bswap32(ed);
+                        else if (ekind == EDGE_SPLAT) ed = (side == 0 ? (ed & 0xFFu) : (ed >> 24)) * 0x01010101u;
+                        else if (ekind == EDGE_CONST) ed = p.cval4;
+                    }
+                    // neighbour dwords: left lane's last dword, right lane's first dword
+                    unsigned l = (unsigned)__builtin_amdgcn_update_dpp((int)ed, (int)v.w, 0x138, 0xf, 0xf, false);
+                    unsigned r = (unsigned)__builtin_amdgcn_update_dpp((int)ed, (int)v.x, 0x130, 0xf, 0xf, false);
+                    if (lane == last) r = ed;
+                    Win w;
+                    split(l, w.e[0], w.o[0]);
+                    split(v.x, w.e[1], w.o[1]);
+                    split(v.y, w.e[2], w.o[2]);
+                    split(v.z, w.e[3], w.o[3]);
+                    split(v.w, w.e[4], w.o[4]);
+                    split(r, w.e[5], w.o[5]);
+                    w.e[6] = w.e[5]; w.o[6] = w.o[5];
+                    xf = xpass_u8<WX, IS_MAX>(w);
+                } else {
+                    split(v.x, xf.e[0], xf.o[0]);
+                    split(v.y, xf.e[1], xf.o[1]);
+                    split(v.z, xf.e[2], xf.o[2]);
+                    split(v.w, xf.e[3], xf.o[3]);
+                }
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                if (i >= WA - 1) {
+                    Vec16 a = xf;
+                    if constexpr (RINGN > 0) {
+#pragma unroll
+                        for (int k = 0; k < RINGN; k++) a = op16<IS_MAX>(a, ring[k]);
+                    }
+                    u32x4 u;
+                    u.x = join(a.e[0], a.o[0]); u.y = join(a.e[1], a.o[1]);
+                    u.z = join(a.e[2], a.o[2]); u.w = join(a.e[3], a.o[3]);
+                    const unsigned so = (unsigned)(a0 + i - (WA - 1)) * strideA;
+                    __builtin_amdgcn_raw_buffer_store_b128(u, rout, voff, so, 0);
+                }
+                if constexpr (RINGN > 0) ring[J % RINGN] = xf;
+            }
+        });
+    }
+}
+
+template <int WX, int WA, bool IS_MAX>
+static int launch_u8(const uint8_t *in, uint8_t *out, U8StreamParams &p, hipStream_t s)
+{
+    const int nA = p.axis == 0 ? p.nz : p.ny;
+    const int nother = p.axis == 0 ? p.ny : p.nz;
+    const int nlines = nother * p.nxt;
+    int nch = (4096 + nlines - 1) / nlines;
+    const int min_chunk = 8 * (WA - 1) + 8;
+    if (nch > nA / min_chunk) nch = nA / min_chunk;
+    if (nch < 1) nch = 1;
+    p.chunk = (nA + nch - 1) / nch;
+    p.nchunks = (nA + p.chunk - 1) / p.chunk;
+    const int waves = nlines * p.nchunks;
+    hipLaunchKernelGGL((stream_minmax_u8_kernel<WX, WA, IS_MAX>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+template <int WX, bool IS_MAX>
+static int launch_u8_wa(int wa, const uint8_t *in, uint8_t *out, U8StreamParams &p, hipStream_t s)
+{
+    switch (wa) {
+    case 1: return launch_u8<WX, 1, IS_MAX>(in, out, p, s);
+    case 3: return launch_u8<WX, 3, IS_MAX>(in, out, p, s);
+    case 5: return launch_u8<WX, 5, IS_MAX>(in, out, p, s);
+    case 7: return launch_u8<WX, 7, IS_MAX>(in, out, p, s);
+    case 9: return launch_u8<WX, 9, IS_MAX>(in, out, p, s);
+    case 11: return launch_u8<WX, 11, IS_MAX>(in, out, p, s);
+    case 13: return launch_u8<WX, 13, IS_MAX>(in, out, p, s);
+    }
+    return MI_ERR_UNSUPPORTED;
+}
+
+template <bool IS_MAX>
+static int launch_u8_wx(int wx, int wa, const uint8_t *in, uint8_t *out, U8StreamParams &p, hipStream_t s)
+{
+    switch (wx) {
+    case 1: return launch_u8_wa<1, IS_MAX>(wa, in, out, p, s);
+    case 3: return launch_u8_wa<3, IS_MAX>(wa, in, out, p, s);
+    case 5: return launch_u8_wa<5, IS_MAX>(wa, in, out, p, s);
+    case 7: return launch_u8_wa<7, IS_MAX>(wa, in, out, p, s);
+    case 9: return launch_u8_wa<9, IS_MAX>(wa, in, out, p, s);
+    }
+    return MI_ERR_UNSUPPORTED;
+}
+
+}  // namespace mi
 
 using namespace mi;
 
@@ -14,7 +331,53 @@ extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int
                               const int origin[3], const int mode[3], int cval, int is_max,
                               mi_stream stream)
 {
-    (void)in; (void)out; (void)size; (void)origin; (void)mode; (void)cval; (void)is_max; (void)stream;
-    set_error("minmax3d_u8: fused kernel not built");
-    return MI_ERR_UNSUPPORTED;
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(size && origin && mode, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+#define UNSUP(msg) do { set_error("minmax3d_u8: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if (in->ndim != 3 || in->dtype != MI_U8 || out->dtype != MI_U8) UNSUP("needs 3-D uint8 in/out");
+    if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
+    if (in->data == out->data) UNSUP("in-place");
+    const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
+    if (nz < 1 || ny < 1 || nx < 32 || (nx & 15) || (nx & 1023) == 16) UNSUP("x extent must be a multiple of 16, >= 32");
+    if (nz * ny * nx >= ((int64_t)1 << 31)) UNSUP("needs a volume < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+    for (int a = 0; a < 3; a++) {
+        if (size[a] < 1 || !(size[a] & 1) || origin[a] != 0) UNSUP("sizes must be odd with origin 0");
+    }
+    if (size[2] > 9 || size[0] > 13 || size[1] > 13) UNSUP("size too large for the register kernels");
+    if (cval < 0 || cval > 255) UNSUP("cval outside uint8");
+    hipStream_t s = resolve_stream(stream);
+
+    U8StreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.nxt = (int)((nx + 1023) / 1024);
+    p.mx = filter_mode(mode[2]);
+    p.cval4 = (unsigned)cval * 0x01010101u;
+    const uint8_t *ip = (const uint8_t *)in->data;
+    uint8_t *op = (uint8_t *)out->data;
+
+    // pass A: x fused with z (into tmp if a y pass follows), pass B: y
+    const bool need_y = size[1] > 1;
+    const bool need_a = size[0] > 1 || size[2] > 1 || !need_y;
+    void *tmp = nullptr;
+    if (need_y && need_a) {
+        if ((rc = pool_alloc(&tmp, (size_t)(nz * ny * nx)))) return rc;
+    }
+    if (need_a) {
+        p.axis = 0; p.oa = size[0] / 2; p.ma = filter_mode(mode[0]);
+        uint8_t *dst = need_y ? (uint8_t *)tmp : op;
+        rc = is_max ? launch_u8_wx<true>(size[2], size[0], ip, dst, p, s) : launch_u8_wx<false>(size[2], size[0], ip, dst, p, s);
+        ip = dst;
+    }
+    if (rc == MI_OK && need_y) {
+        p.axis = 1; p.oa = size[1] / 2; p.ma = filter_mode(mode[1]);
+        rc = is_max ? launch_u8_wx<true>(1, size[1], ip, op, p, s) : launch_u8_wx<false>(1, size[1], ip, op, p, s);
+    }
+    if (tmp) pool_free(tmp);
+    if (rc == MI_ERR_UNSUPPORTED) set_error("minmax3d_u8: no kernel for this size");
+    return rc;
+#undef UNSUP
 }

@@ -366,9 +366,15 @@ def _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max):
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     dst = output if direct else core.empty(output.shape, output.dtype)
     a, b = src._desc(), dst._desc()
-    # cval arrives in SciPy's double line buffer and leaves through a uint8 cast
+    # SciPy compares cval as a double and casts after every pass; the byte
+    # kernel is only equivalent when cval is itself a uint8 value
+    if any(m in ("constant", "grid-constant") for m in modes):
+        if not (np.isfinite(cval) and 0 <= cval <= 255 and float(cval) == int(cval)):
+            return None
+    if any(int(o) != 0 for o in origins) or any(int(sz) % 2 == 0 for sz in sizes):
+        return None
     try:
-        cv = int(np.float64(cval)) & 0xFF if np.isfinite(cval) else 0
+        cv = int(cval) if np.isfinite(cval) and 0 <= cval <= 255 else 0
         S.check(S.lib().mi_minmax3d_u8(ctypes.byref(a), ctypes.byref(b), S.c_ints(sizes), S.c_ints(origins),
                                        S.c_ints([S.mode_code(m) for m in modes]), cv, int(is_max), None))
     except S.Unsupported:
@@ -399,7 +405,7 @@ def _min_or_max_filter(input, size, ftprnt, structure, output, mode, cval, origi
             return output
         if input.size == 0:
             return output
-        if input.ndim == 3 and len(axes) == 3:
+        if input.ndim == 3:
             res = _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max)
             if res is not None:
                 return res
