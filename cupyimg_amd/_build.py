@@ -33,6 +33,7 @@ SOURCES = [
     ("minmax3d_u8.hip", []),
     ("binary.hip", []),
     ("interp.hip", ["-ffp-contract=off"]),
+    ("interp_fast.hip", ["-ffp-contract=off"]),
     ("halo.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -215,9 +215,18 @@ static int check_interp(const mi_array *in, const mi_array *out, int order, int 
     return MI_OK;
 }
 
+// float32 3-D throughput kernels (interp_fast.hip); MI_ERR_UNSUPPORTED = not covered
+int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_array *out, int order, int mode,
+                         double cval, hipStream_t s);
+int affine_transform_fast(const mi_array *in, const mi_array *out, const double *matrix, int order, int mode,
+                          double cval, hipStream_t s);
+
 }  // namespace mi
 
 using namespace mi;
+
+static int g_interp_generic = 0;   // test hook: 1 = always use the generic double kernels
+extern "C" int mi_debug_set_interp_generic(int v) { g_interp_generic = v; return MI_OK; }
 
 extern "C" {
 
@@ -237,6 +246,10 @@ int mi_map_coordinates(const mi_array *in, const mi_array *coords, const mi_arra
     const int64_t nout = numel(out);
     if (nout == 0) return MI_OK;
     hipStream_t s = resolve_stream(stream);
+    if (!g_interp_generic) {
+        rc = map_coordinates_fast(in, coords, out, order, mode, cval, s);
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
+    }
     const int nd = in->ndim <= 3 ? 3 : MI_MAX_NDIM;
     InterpGeom g;
     fill_geom(&g, in, nd);
@@ -273,6 +286,10 @@ int mi_affine_transform(const mi_array *in, const mi_array *out, const double *m
     const int64_t nout = numel(out);
     if (nout == 0) return MI_OK;
     hipStream_t s = resolve_stream(stream);
+    if (!g_interp_generic && in->ndim == 3) {
+        rc = affine_transform_fast(in, out, matrix, order, mode, cval, s);
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
+    }
     const int n = in->ndim;
     const int nd = n <= 3 ? 3 : MI_MAX_NDIM;
     InterpGeom g;

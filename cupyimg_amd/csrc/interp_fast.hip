@@ -1,0 +1,315 @@
+// interp_fast.hip -- order-1 / order-0 interpolation, float32 3-D volumes:
+// the throughput kernels behind map_coordinates / affine_transform
+// (reference: cupyimg/scipy/ndimage/interpolation.py:271-394, :397-561; kernel
+// body _interp_kernels.py:277-592, launched at interpolation.py:393,545,560).
+//
+// Same tap / weight / boundary logic as the generic kernel in interp.hip, with
+// the per-voxel overhead removed: 3-D launch grid (no index division), 32-bit
+// indexing, one voxel per lane with lanes along x (a wave's gather touches
+// neighbouring input voxels), coordinates in the precision they are given in
+// (float32 coordinates of map_coordinates: floor / fraction are exact in
+// float32; affine: double, like the reference's float64 matrix path,
+// interpolation.py:476,501), weights and the 8-tap accumulation in float32.
+// Against SciPy's all-double arithmetic that is ~1e-7 relative; the stated
+// tolerance for float32 interpolation is 2e-6 * max|ref| (tests/test_gpu_*).
+// Anything else (other dtypes, ranks, float64 output) runs interp.hip.
+#include "common.hpp"
+
+namespace mi {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct FastInterpParams {
+    int nz, ny, nx;          // input
+    int oz, oy, ox;          // output
+    int order, mode;
+    float cval;
+    double m[12];            // affine 3 x 4 (row major)
+};
+
+__device__ __forceinline__ double wrapc(double c, int n)
+{
+    if (n <= 1) return 0.0;
+    const double s = (double)(n - 1);
+    if (c < 0) c += s * ((double)(long long)(-c / s) + 1.0);
+    else if (c > s) c -= s * (double)(long long)(c / s);
+    return c;
+}
+
+__device__ __forceinline__ double foldc(double c, int n, int mode)
+{
+    if (n <= 1) return 0.0;
+    const double dn = (double)n;
+    switch (mode) {
+    case MI_MODE_MIRROR: {
+        const double p = 2.0 * dn - 2.0;
+        if (c < 0) { c = p * (double)(long long)(-c / p) + c; c = c <= 1.0 - dn ? c + p : -c; }
+        else if (c > dn - 1.0) { c -= p * (double)(long long)(c / p); if (c >= dn) c = p - c; }
+        return c;
+    }
+    case MI_MODE_REFLECT: {
+        const double p = 2.0 * dn;
+        if (c < 0) {
+            if (c < -p) c = p * (double)(long long)(-c / p) + c;
+            c = c < -dn ? c + p : (c > -1e-15 ? 1e-15 : -c) - 1.0;
+        } else if (c > dn - 1.0) {
+            c -= p * (double)(long long)(c / p);
+            if (c >= dn) c = p - c - 1.0;
+        }
+        return c;
+    }
+    case MI_MODE_WRAP: return wrapc(c, n);
+    case MI_MODE_GRID_WRAP:
+        if (c < 0) c += dn * ((double)(long long)((-1.0 - c) / dn) + 1.0);
+        else if (c > dn - 1.0) c -= dn * (double)(long long)((c + 1.0) / dn);
+        return c;
+    case MI_MODE_NEAREST: return c < 0 ? 0.0 : (c > dn - 1.0 ? dn - 1.0 : c);
+    default: return c;
+    }
+}
+
+// taps along one axis for coordinate c: indices (-1 = use cval), float weights.
+// `outside` is set when mode == constant and c lies outside [0, n-1].
+template <typename CT, bool FASTC, int ORDER>
+__device__ __forceinline__ void axis_taps(CT c, int n, int mode, int order, int &i0, int &i1, float &w0, float &w1,
+                                          bool &outside)
+{
+    if constexpr (FASTC && ORDER == 1) {
+        // mode == constant, order 1: the common case, no boundary map needed
+        // (inside [0, n-1] both taps are valid; at c == n-1 the upper tap is skipped)
+        outside = outside || c < (CT)0 || c > (CT)(n - 1);
+        const CT cf = floor(c);
+        w1 = (float)(c - cf);
+        w0 = 1.0f - w1;
+        i0 = (int)cf;
+        i1 = w1 == 0.f ? i0 : i0 + 1;
+        return;
+    }
+    if (mode == MI_MODE_CONSTANT && (c < (CT)0 || c > (CT)(n - 1))) outside = true;
+    if (order == 0) {
+        int j;
+        if (mode == MI_MODE_CONSTANT) j = (int)floor((double)c + 0.5);
+        else if (mode == MI_MODE_GRID_CONSTANT) j = bmap<int>((int)floor((double)c + 0.5), n, mode);
+        else j = bmap<int>((int)floor(foldc((double)c, n, mode) + 0.5), n, mode);
+        i0 = i1 = j;
+        w0 = 1.f;
+        w1 = 0.f;
+        return;
+    }
+    const CT cf = floor(c);
+    const CT fr = c - cf;               // exact in CT
+    w1 = (float)fr;
+    w0 = (float)(((CT)1 + cf) - c);     // (cf + 1) - c as the reference / SciPy form it
+    if (mode == MI_MODE_WRAP) {
+        const double f = wrapc((double)c, n);
+        i0 = (int)floor(f);
+        i1 = (int)floor(f + 1.0);
+    } else {
+        i0 = (int)cf;
+        i1 = i0 + 1;
+        if (mode != MI_MODE_CONSTANT) {
+            i0 = bmap<int>(i0, n, mode);
+            i1 = bmap<int>(i1, n, mode);
+        }
+    }
+    if (fr == (CT)0) { i1 = i0; w1 = 0.f; }   // integral coordinate: the upper tap is skipped
+}
+
+// One output voxel in two phases so that a thread can keep several voxels'
+// gathers in flight: taps() computes indices / weights and issues the eight
+// loads, finish() blends them.  Blending is three nested linear interpolations
+// (x, then y, then z); a zero upper weight selects the lower sample outright,
+// which is the reference's "second tap skipped at integral coordinates"
+// (_interp_kernels.py:416) and keeps inf / nan of a skipped tap out.
+struct Taps { float v[8]; float wz1, wy1, wx1; unsigned oobmask; bool outside; };
+
+template <typename CT, bool FASTC, int ORDER>
+__device__ __forceinline__ void taps(const __amdgpu_buffer_rsrc_t in, const FastInterpParams &p, CT cz, CT cy, CT cx, Taps &t)
+{
+    if constexpr (FASTC && ORDER == 1) {
+        // constant mode, order 1: integer/fraction split once per axis, the range
+        // test on the integers, one base index plus three strides
+        const CT fz = floor(cz), fy = floor(cy), fx = floor(cx);
+        const int z0 = (int)fz, y0 = (int)fy, x0 = (int)fx;
+        t.wz1 = (float)(cz - fz); t.wy1 = (float)(cy - fy); t.wx1 = (float)(cx - fx);
+        const bool in_z = z0 >= 0 && (z0 < p.nz - 1 || (z0 == p.nz - 1 && t.wz1 == 0.f));
+        const bool in_y = y0 >= 0 && (y0 < p.ny - 1 || (y0 == p.ny - 1 && t.wy1 == 0.f));
+        const bool in_x = x0 >= 0 && (x0 < p.nx - 1 || (x0 == p.nx - 1 && t.wx1 == 0.f));
+        t.outside = !(in_z && in_y && in_x);
+        t.oobmask = 0;
+        // x0 / x1 sit next to each other in memory: one 8-byte gather per (z, y) pair.
+        // At the last column (only reachable with wx1 == 0) the pair is shifted left by one.
+        const bool lastcol = x0 >= p.nx - 1;
+        const int xb = lastcol ? x0 - 1 : x0;
+        const unsigned base = t.outside ? 0u : (unsigned)((z0 * p.ny + y0) * p.nx + xb) * 4u;
+        const unsigned sz = (t.outside || t.wz1 == 0.f) ? 0u : (unsigned)(p.ny * p.nx) * 4u;
+        const unsigned sy = (t.outside || t.wy1 == 0.f) ? 0u : (unsigned)p.nx * 4u;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(in, base + (m >> 1) * sz + (m & 1) * sy, 0, 0);
+            t.v[2 * m] = __uint_as_float(lastcol ? q.y : q.x);
+            t.v[2 * m + 1] = __uint_as_float(q.y);
+        }
+        return;
+    } else {
+        int zi[2], yi[2], xi[2];
+        float wz[2], wy[2], wx[2];
+        bool outside = false;
+        axis_taps<CT, FASTC, ORDER>(cz, p.nz, p.mode, p.order, zi[0], zi[1], wz[0], wz[1], outside);
+        axis_taps<CT, FASTC, ORDER>(cy, p.ny, p.mode, p.order, yi[0], yi[1], wy[0], wy[1], outside);
+        axis_taps<CT, FASTC, ORDER>(cx, p.nx, p.mode, p.order, xi[0], xi[1], wx[0], wx[1], outside);
+        t.outside = outside;
+        t.wz1 = wz[1]; t.wy1 = wy[1]; t.wx1 = wx[1];
+        t.oobmask = 0;
+        // taps that must not be read (index -1 = cval, or everything when the point is
+        // outside in constant mode) load voxel 0 instead and are replaced afterwards
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int a = m >> 2, b = (m >> 1) & 1, c = m & 1;
+            const bool oob = (zi[a] | yi[b] | xi[c]) < 0;
+            if (oob) t.oobmask |= 1u << m;
+            const unsigned off = (oob || outside) ? 0u : (unsigned)((zi[a] * p.ny + yi[b]) * p.nx + xi[c]) * 4u;
+            t.v[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in, off, 0, 0));
+        }
+    }
+}
+
+__device__ __forceinline__ float lerp_skip(float lo, float hi, float w)
+{
+    return w == 0.f ? lo : fmaf(w, hi - lo, lo);
+}
+
+__device__ __forceinline__ float finish(const Taps &t, float cval)
+{
+    float v[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = ((t.oobmask >> m) & 1u) ? cval : t.v[m];
+    const float x00 = lerp_skip(v[0], v[1], t.wx1), x01 = lerp_skip(v[2], v[3], t.wx1);
+    const float x10 = lerp_skip(v[4], v[5], t.wx1), x11 = lerp_skip(v[6], v[7], t.wx1);
+    const float y0 = lerp_skip(x00, x01, t.wy1), y1 = lerp_skip(x10, x11, t.wy1);
+    const float r = lerp_skip(y0, y1, t.wz1);
+    return t.outside ? cval : r;
+}
+
+constexpr int kNV = 4;   // voxels per thread (rows 4 apart), all gathers issued before any is used
+
+// block = (64, 4): 64 lanes along x (one voxel each, so every gather instruction of a
+// wave touches neighbouring input voxels); a thread handles kNV rows; grid = (x tiles, y tiles, z)
+template <typename CT, bool FASTC, int ORDER>
+__global__ void __launch_bounds__(256)
+map_coords3d_fast(const float *__restrict__ in, const CT *__restrict__ coords, float *__restrict__ out,
+                  const FastInterpParams p)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int z = blockIdx.z;
+    if (x >= p.ox) return;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
+    const size_t nout = (size_t)p.oz * p.oy * p.ox;
+    CT c[kNV][3];
+    size_t o[kNV];
+    bool ok[kNV];
+#pragma unroll
+    for (int k = 0; k < kNV; k++) {
+        const int y = (blockIdx.y * kNV + k) * 4 + threadIdx.y;
+        ok[k] = y < p.oy;
+        o[k] = ((size_t)z * p.oy + (ok[k] ? y : 0)) * p.ox + x;
+        c[k][0] = coords[o[k]]; c[k][1] = coords[nout + o[k]]; c[k][2] = coords[2 * nout + o[k]];
+    }
+    Taps t[kNV];
+#pragma unroll
+    for (int k = 0; k < kNV; k++) taps<CT, FASTC, ORDER>(rin, p, c[k][0], c[k][1], c[k][2], t[k]);
+#pragma unroll
+    for (int k = 0; k < kNV; k++)
+        if (ok[k]) out[o[k]] = finish(t[k], p.cval);
+}
+
+template <bool FASTC, int ORDER>
+__global__ void __launch_bounds__(256)
+affine3d_fast(const float *__restrict__ in, float *__restrict__ out, const FastInterpParams p)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int z = blockIdx.z;
+    if (x >= p.ox) return;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
+    Taps t[kNV];
+    size_t o[kNV];
+    bool ok[kNV];
+    const double dz = (double)z, dx = (double)x;
+#pragma unroll
+    for (int k = 0; k < kNV; k++) {
+        const int y = (blockIdx.y * kNV + k) * 4 + threadIdx.y;
+        ok[k] = y < p.oy;
+        o[k] = ((size_t)z * p.oy + (ok[k] ? y : 0)) * p.ox + x;
+        // same summation order as the oracle: ((m0*z + m1*y) + m2*x) + offset
+        const double dy = (double)y;
+        const double cz = ((0.0 + p.m[0] * dz) + p.m[1] * dy + p.m[2] * dx) + p.m[3];
+        const double cy = ((0.0 + p.m[4] * dz) + p.m[5] * dy + p.m[6] * dx) + p.m[7];
+        const double cx = ((0.0 + p.m[8] * dz) + p.m[9] * dy + p.m[10] * dx) + p.m[11];
+        taps<double, FASTC, ORDER>(rin, p, cz, cy, cx, t[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kNV; k++)
+        if (ok[k]) out[o[k]] = finish(t[k], p.cval);
+}
+
+static bool fast_ok(const mi_array *in, const mi_array *out, int order)
+{
+    if (in->ndim != 3 || out->ndim != 3 || in->dtype != MI_F32 || out->dtype != MI_F32) return false;
+    if (order < 0 || order > 1) return false;
+    if (numel(in) >= ((int64_t)1 << 29) || numel(out) >= ((int64_t)1 << 31)) return false;   // 32-bit byte offsets
+    if (in->shape[2] < 2) return false;
+    if (out->shape[0] > 65535 || (out->shape[1] + 3) / 4 > 65535) return false;
+    if ((uintptr_t)out->data & 15) return false;
+    return true;
+}
+
+static void fill_params(FastInterpParams *p, const mi_array *in, const mi_array *out, int order, int mode, double cval)
+{
+    p->nz = (int)in->shape[0]; p->ny = (int)in->shape[1]; p->nx = (int)in->shape[2];
+    p->oz = (int)out->shape[0]; p->oy = (int)out->shape[1]; p->ox = (int)out->shape[2];
+    p->order = order; p->mode = mode; p->cval = (float)cval;
+}
+
+// returns MI_ERR_UNSUPPORTED when the request is not covered (caller runs the generic kernel)
+int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_array *out, int order, int mode,
+                         double cval, hipStream_t s)
+{
+    if (!fast_ok(in, out, order)) return MI_ERR_UNSUPPORTED;
+    FastInterpParams p;
+    fill_params(&p, in, out, order, mode, cval);
+    const dim3 block(64, 4, 1);
+    const dim3 grid((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 4 * kNV - 1) / (4 * kNV)), (unsigned)p.oz);
+    const bool fastc = mode == MI_MODE_CONSTANT && order == 1;
+#define MI_MAP(CT, FC, ORD)                                                                                   \
+    hipLaunchKernelGGL((map_coords3d_fast<CT, FC, ORD>), grid, block, 0, s, (const float *)in->data,           \
+                       (const CT *)coords->data, (float *)out->data, p)
+    if (coords->dtype == MI_F32) {
+        if (fastc) MI_MAP(float, true, 1); else if (order == 1) MI_MAP(float, false, 1); else MI_MAP(float, false, 0);
+    } else {
+        if (fastc) MI_MAP(double, true, 1); else if (order == 1) MI_MAP(double, false, 1); else MI_MAP(double, false, 0);
+    }
+#undef MI_MAP
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int affine_transform_fast(const mi_array *in, const mi_array *out, const double *matrix, int order, int mode,
+                          double cval, hipStream_t s)
+{
+    if (!fast_ok(in, out, order)) return MI_ERR_UNSUPPORTED;
+    FastInterpParams p;
+    fill_params(&p, in, out, order, mode, cval);
+    for (int i = 0; i < 12; i++) p.m[i] = matrix[i];
+    const dim3 block(64, 4, 1);
+    const dim3 grid((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 4 * kNV - 1) / (4 * kNV)), (unsigned)p.oz);
+    if (mode == MI_MODE_CONSTANT && order == 1)
+        hipLaunchKernelGGL((affine3d_fast<true, 1>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p);
+    else if (order == 1)
+        hipLaunchKernelGGL((affine3d_fast<false, 1>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p);
+    else
+        hipLaunchKernelGGL((affine3d_fast<false, 0>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace mi
