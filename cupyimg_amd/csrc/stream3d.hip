@@ -224,7 +224,8 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
 template <int WX, int WA>
 static int launch_stream(const float *in, float *out, StreamParams &p, hipStream_t s)
 {
-    constexpr int DEPTH = (WA - 1) % 4 == 0 && WA > 1 ? 4 : 2;
+    // in-flight loads per wave: 4 where registers allow (the fused long x pass needs them for its window)
+    constexpr int DEPTH = ((WA - 1) % 4 == 0 && WA > 1 && WX <= 9) ? 4 : 2;
     const int nA = p.axis == 0 ? p.nz : p.ny;
     const int nother = p.axis == 0 ? p.ny : p.nz;
     const int nlines = nother * p.nxt;

@@ -324,3 +324,49 @@ def test_affine_and_map_3d(gpu, ndi):
     assert np.allclose(got, ref, rtol=0, atol=1e-6)
     with pytest.raises(NotImplementedError):
         ndi.map_coordinates(xd, gpu.asarray(coords), order=3)
+
+
+# ------------------------------------------------------------------ skimage facade
+def test_skimage_facade(gpu):
+    import scipy.ndimage as sndi
+
+    from cupyimg_amd.skimage import filters as skf
+    from cupyimg_amd.skimage import morphology as skm
+    from cupyimg_amd.skimage import transform as skt
+    rng = np.random.default_rng(30)
+    img = rng.integers(0, 256, size=(40, 50)).astype(np.uint8)
+    d = gpu.asarray(img)
+    # default cross element; reference literal cases live in skimage/morphology/tests/test_grey.py
+    cross = sndi.generate_binary_structure(2, 1)
+    assert np.array_equal(skm.erosion(d).get(), sndi.grey_erosion(img, footprint=cross))
+    assert np.array_equal(skm.dilation(d).get(), sndi.grey_dilation(img, footprint=cross[::-1, ::-1]))
+    sq = np.ones((4, 4), np.uint8)                                   # even-sided element: shifted
+    ref = sndi.grey_erosion(img, footprint=np.pad(sq, ((1, 0), (1, 0))))
+    assert np.array_equal(skm.erosion(d, sq).get(), ref)
+    b = img > 128
+    assert np.array_equal(skm.binary_erosion(gpu.asarray(b)).get(), sndi.binary_erosion(b, cross, border_value=True))
+    assert np.array_equal(skm.binary_dilation(gpu.asarray(b)).get(), sndi.binary_dilation(b, cross))
+    # gaussian: default mode 'nearest', uint8 -> float in [0, 1]
+    g = skf.gaussian(d, sigma=1.5).get()
+    ref = sndi.gaussian_filter(img / 255.0, 1.5, mode="nearest")
+    assert g.dtype == np.float64 and np.allclose(g, ref, atol=1e-12)
+    f = rng.standard_normal((20, 24, 3)).astype(np.float32)
+    g = skf.gaussian(gpu.asarray(f), sigma=2, multichannel=True).get()
+    assert np.abs(g - sndi.gaussian_filter(f, (2, 2, 0), mode="nearest")).max() <= 1e-6
+    with pytest.raises(ValueError):
+        skf.gaussian(d, sigma=-1)
+    # warp: callable inverse map and 3x3 matrix, order 1 default, edge mode -> nearest
+    fimg = rng.random((30, 36))
+    shift = lambda xy: xy + np.array([2.5, -1.25])
+    w = skt.warp(gpu.asarray(fimg), shift, mode="edge").get()
+    yy, xx = np.indices(fimg.shape, dtype=np.float64)
+    ref = sndi.map_coordinates(fimg, [yy - 1.25, xx + 2.5], order=1, mode="nearest")
+    assert np.allclose(w, ref, atol=1e-12)
+    H = np.array([[1.0, 0.1, 1.0], [-0.05, 0.95, 2.0], [0.0, 0.0, 1.0]])
+    w = skt.warp(gpu.asarray(fimg), H, order=1).get()
+    src = np.stack([xx.ravel(), yy.ravel(), np.ones(xx.size)]) .T @ H.T
+    ref = sndi.map_coordinates(fimg, [src[:, 1].reshape(fimg.shape), src[:, 0].reshape(fimg.shape)], order=1,
+                               mode="constant", cval=0.0)
+    exp = np.clip(ref, fimg.min(), fimg.max())
+    exp[ref == 0.0] = 0.0          # cval outside the input range is preserved (_warps.py:779-787)
+    assert np.allclose(w, exp, atol=1e-12)
