@@ -602,7 +602,7 @@ static int launch_ws(const float *in, float *out, const Sep3dParams &p, hipStrea
 static int lean_rows(int w, int cfg)
 {
     switch (w) {
-    case 3: return cfg == 1 ? 32 : 36;
+    case 3: return cfg == 1 ? 32 : (cfg == 5 ? 20 : 36);
     case 5: return cfg == 2 ? 24 : (cfg == 3 ? 30 : (cfg >= 4 && cfg <= 6 ? 20 : 36));
     case 7: return 24;
     default: return 24;
@@ -614,6 +614,7 @@ static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams 
     switch (w) {
     case 3:
         if (cfg == 1) return launch_sep3d_lean<3, 8, 4, 4>(in, out, p, hc, s);
+        if (cfg == 5) return launch_sep3d_lean<3, 10, 4, 2>(in, out, p, hc, s);
         return launch_sep3d_lean<3, 12, 4, 3>(in, out, p, hc, s);
     case 5:
         if (cfg == 1) return launch_sep3d_lean<5, 9, 3, 4>(in, out, p, hc, s);
@@ -633,6 +634,48 @@ static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams 
 
 int run_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axis, const float *wav, int wa, int oa,
                     int ma, const float *wxv, int wx, int mx, float cval, hipStream_t s);   // stream3d.hip
+
+// Tile / z-chunk choice by a small cost model.  One workgroup per CU is
+// resident, so the launch runs in ceil(workgroups / CUs) rounds; a workgroup
+// costs (chunk + w - 1) plane steps of (rows + fixed) row-units each.  Big
+// tiles (fewer halo rows) win on large volumes, small tiles keep every CU
+// busy on thin slabs (multi-GPU) and odd shapes.
+static int device_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+static void choose_plan(int w, const int *cand_rows, const int *cand_cfg, int ncand, int wy, int64_t nz, int64_t ny,
+                        int64_t nx, int *best_cfg, int *best_rows, int *best_nzc)
+{
+    const int ncu = device_cus();
+    const int nxt = (int)((nx + 255) / 256);
+    double best = 1e300;
+    for (int c = 0; c < ncand; c++) {
+        const int rows = cand_rows[c];
+        const int ty = rows - (wy - 1);
+        if (ty < 1) continue;
+        const int cols = nxt * (int)((ny + ty - 1) / ty);
+        const int max_nzc = (int)(nz < 64 ? nz : 64);
+        for (int nzc = 1; nzc <= max_nzc; nzc++) {
+            const int chunk = (int)((nz + nzc - 1) / nzc);
+            if (chunk > kMaxChunk) continue;
+            const int real_nzc = (int)((nz + chunk - 1) / chunk);
+            const int64_t wgs = (int64_t)cols * real_nzc;
+            const double rounds = (double)((wgs + ncu - 1) / ncu);
+            const double cost = rounds * (chunk + w - 1) * (rows + 6.0);
+            if (cost < best) { best = cost; *best_cfg = cand_cfg[c]; *best_rows = rows; *best_nzc = real_nzc; }
+        }
+    }
+}
 
 }  // namespace mi
 
@@ -740,18 +783,21 @@ extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const
     const int cfg = g_sep3d_cfg;
     const bool cubic = w[0] == w[1] && w[1] == w[2] && w[0] >= 3 && p.oz == w[0] / 2 && p.oy == w[1] / 2;
     const bool lean = cubic && g_sep3d_kernel != 1 && nz * ny * nx * 4 < ((int64_t)1 << 31);
-    const int rows = lean ? lean_rows(w[0], cfg) : ws_rows(w[0]);
+    int cfg_use = cfg, rows = 0, nzc = 1;
+    if (lean && cfg == 0) {
+        // candidates: the big tile and (3 / 5 taps) a small one
+        const int big = lean_rows(w[0], 0), small = lean_rows(w[0], 5);
+        const int cand_rows[2] = {big, small}, cand_cfg[2] = {0, 5};
+        choose_plan(w[0], cand_rows, cand_cfg, (w[0] <= 5 && small != big) ? 2 : 1, w[1], nz, ny, nx, &cfg_use, &rows, &nzc);
+    } else {
+        rows = lean ? lean_rows(w[0], cfg) : ws_rows(w[0]);
+        const int cand_rows[1] = {rows}, cand_cfg[1] = {cfg};
+        choose_plan(w[0], cand_rows, cand_cfg, 1, w[1], nz, ny, nx, &cfg_use, &rows, &nzc);
+    }
     p.ty = rows - (w[1] - 1);
     if (p.ty < 1) UNSUP("y kernel too long for the tile");
     p.nxt = (int)((nx + 255) / 256);
     p.nyt = (int)((ny + p.ty - 1) / p.ty);
-    // z chunking: aim at about one workgroup per CU (256) -- every workgroup
-    // pays (wz-1) ramp-up planes, so chunks must stay long
-    const int cols = p.nxt * p.nyt;
-    int nzc = (256 + cols - 1) / cols;
-    const int min_chunk = 8 * (w[0] - 1) + 8;
-    if (nzc > (int)(nz / min_chunk)) nzc = (int)(nz / min_chunk);
-    if (nzc < 1) nzc = 1;
     if (g_sep3d_zchunks > 0) nzc = g_sep3d_zchunks;
     if ((nz + nzc - 1) / nzc > kMaxChunk) nzc = (int)((nz + kMaxChunk - 1) / kMaxChunk);
     p.zc = (int)((nz + nzc - 1) / nzc);
@@ -760,7 +806,7 @@ extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const
     hipStream_t s = resolve_stream(stream);
     const float *ip = (const float *)in->data;
     float *op = (float *)out->data;
-    if (lean) return launch_lean(w[0], cfg, ip, op, p, any_const, s);
+    if (lean) return launch_lean(w[0], cfg_use, ip, op, p, any_const, s);
 #define CASE_Z(WXV)                                            \
     switch (w[0]) {                                            \
     case 1: return launch_ws<WXV, 1>(ip, op, p, s);            \
