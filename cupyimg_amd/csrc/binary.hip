@@ -49,6 +49,44 @@ binary_erosion_kernel(const T *__restrict__ in, void *__restrict__ out, int out_
     if (changed && __any(any_change) && (threadIdx.x & 63) == 0) atomicOr(changed, 1);
 }
 
+// rank <= 3 fast geometry (nd_common.hpp)
+template <typename T>
+__global__ void __launch_bounds__(256)
+binary3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, const uint8_t *__restrict__ mask, Geom3 g,
+               Taps3 tt, int border_value, int invert, int32_t *changed)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsTaps lt = stage_taps(tt, smem);
+    const Vox3 v = locate3(g);
+    bool any_change = false;
+    if (v.valid) {
+        const __amdgpu_buffer_rsrc_t rin =
+            __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)((unsigned)g.nz * g.ny * g.nx * sizeof(T)), 0x00020000);
+        const bool tv = !invert, fv = invert;
+        const bool bv = invert ? !border_value : (border_value != 0);
+        const bool cur = in[v.lin] != T(0);
+        bool res;
+        if (mask && !mask[v.lin]) {
+            res = cur;
+        } else {
+            res = tv;
+            if (v.interior) {
+                for (int t = 0; t < tt.ntaps; t++)
+                    if ((buf_load<T>(rin, (unsigned)(v.lin + lt.lin[t]) * (unsigned)sizeof(T)) != T(0)) == fv) { res = fv; break; }
+            } else {
+                for (int t = 0; t < tt.ntaps; t++) {
+                    const int pos = tap_pos3(g, v, lt, t, MI_MODE_CONSTANT);
+                    const bool nn = pos < 0 ? bv : ((buf_load<T>(rin, (unsigned)pos * (unsigned)sizeof(T)) != T(0)) == tv);
+                    if (!nn) { res = fv; break; }
+                }
+            }
+        }
+        any_change = res != cur;
+        store_as(out, v.lin, out_dt, res ? 1.0 : 0.0);
+    }
+    if (changed && __any(any_change) && (threadIdx.x & 63) == 0) atomicOr(changed, 1);
+}
+
 }  // namespace mi
 
 using namespace mi;
@@ -75,23 +113,32 @@ extern "C" int mi_binary_erosion(const mi_array *in, const mi_array *out, const 
     if (total == 0) return MI_OK;
     hipStream_t s = resolve_stream(stream);
 
-    // binary structures may legally have an origin that puts the centre
-    // outside (SciPy only checks the range); clamp nothing, just build taps.
+    Taps3Builder t3;
+    Taps3 tt3;
+    const bool fast3 = Taps3Builder::eligible(in, sshape);
     TapBuilder tb;
-    {
-        // TapBuilder::init validates origins like the filters do; binary
-        // erosion accepts the same range (morphology.py:271).
-        if ((rc = tb.init(in, sshape, origins, "structure"))) return rc;
-    }
-    tb.fill([&](int64_t k) { return structure[k] != 0; }, [](int64_t) { return 0.0; }, false);
     TapTable tt;
-    if ((rc = tb.upload(&tt, s))) return rc;
+    if (fast3) {
+        if ((rc = t3.build(in, sshape, origins, [&](int64_t k) { return structure[k] != 0; }, [](int64_t) { return 0.0; },
+                           false))) return rc;
+        if ((rc = t3.finish(&tt3, s))) return rc;
+    } else {
+        if ((rc = tb.init(in, sshape, origins, "structure"))) return rc;
+        tb.fill([&](int64_t k) { return structure[k] != 0; }, [](int64_t) { return 0.0; }, false);
+        if ((rc = tb.upload(&tt, s))) return rc;
+    }
 
     dim3 grid;
     grid_for(total, 256, &grid);
     const uint8_t *mp = mask ? (const uint8_t *)mask->data : nullptr;
     return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
         const T *ip = (const T *)in->data;
+        if (fast3) {
+            hipLaunchKernelGGL((binary3_kernel<T>), grid3(t3.g), dim3(64, 4, 1), taps3_lds_bytes(tt3), s, ip, out->data, out->dtype, mp, t3.g,
+                               tt3, border_value, invert, changed_dev);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        }
         if (tb.g.ndim == 3)
             hipLaunchKernelGGL((binary_erosion_kernel<T, 3>), grid, dim3(256), 0, s, ip, out->data, out->dtype,
                                mp, tb.g, tt, total, border_value, invert, changed_dev);

@@ -152,6 +152,23 @@ __device__ __forceinline__ I bmap(I i, I n, int mode)
     }
 }
 
+// Same map, cheap when the index is at most one array length outside (the case
+// for every window that is not longer than the array): no integer division.
+template <typename I>
+__device__ __forceinline__ I bmap_near(I i, I n, int mode)
+{
+    if (i >= 0 && i < n) return i;
+    if (i < -n || i >= 2 * n || n == 1) return bmap<I>(i, n, mode);
+    switch (mode) {
+    case MI_MODE_REFLECT:   return i < 0 ? -1 - i : 2 * n - 1 - i;
+    case MI_MODE_MIRROR:    return (i <= -n || i >= 2 * n - 1) ? bmap<I>(i, n, mode) : (i < 0 ? -i : 2 * n - 2 - i);
+    case MI_MODE_NEAREST:   return i < 0 ? (I)0 : n - 1;
+    case MI_MODE_GRID_WRAP: return i < 0 ? i + n : i - n;
+    case MI_MODE_WRAP:      return bmap<I>(i, n, mode);
+    default:                return (I)-1;
+    }
+}
+
 // double -> T with the C-cast semantics SciPy/x86 shows: truncate toward zero
 // through a wide signed integer, low bits kept (so negative -> unsigned wraps).
 template <typename T>

@@ -33,6 +33,42 @@ corr_nd_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, NdG
     }
 }
 
+// rank <= 3 fast geometry (nd_common.hpp): same arithmetic, same tap order
+template <typename T, typename Acc>
+__global__ void __launch_bounds__(256)
+corr3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Geom3 g, Taps3 tt, int mode, double cval)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsTaps lt = stage_taps(tt, smem);
+    const Vox3 v = locate3(g);
+    if (!v.valid) return;
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)((unsigned)g.nz * g.ny * g.nx * sizeof(T)), 0x00020000);
+    Acc acc = 0;
+    if (v.interior) {
+        // taps in groups of 8: the group's loads are issued back to back (one memory
+        // latency per group instead of per tap), then accumulated in tap order
+        const unsigned base = (unsigned)v.lin * (unsigned)sizeof(T);
+        int t0 = 0;
+        for (; t0 + 8 <= tt.ntaps; t0 += 8) {
+            T x[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = buf_load<T>(rin, base + (unsigned)(lt.lin[t0 + k] * (int)sizeof(T)));
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc += (Acc)x[k] * (Acc)lt.val[t0 + k];
+        }
+        for (; t0 < tt.ntaps; t0++)
+            acc += (Acc)buf_load<T>(rin, base + (unsigned)(lt.lin[t0] * (int)sizeof(T))) * (Acc)lt.val[t0];
+    } else {
+        for (int t = 0; t < tt.ntaps; t++) {
+            const int pos = tap_pos3(g, v, lt, t, mode);
+            const Acc x = pos < 0 ? (Acc)cval : (Acc)buf_load<T>(rin, (unsigned)pos * (unsigned)sizeof(T));
+            acc += x * (Acc)lt.val[t];
+        }
+    }
+    store_as(out, v.lin, out_dt, (double)acc);
+}
+
 }  // namespace mi
 
 using namespace mi;
@@ -54,14 +90,31 @@ extern "C" int mi_correlate_nd(const mi_array *in, const mi_array *out, const do
     hipStream_t s = resolve_stream(stream);
     mode = filter_mode(mode);
 
+    const bool f32ok = in->dtype == MI_F32 || in->dtype == MI_BOOL || dtype_size(in->dtype) <= 2;
+    const bool use_f32 = acc_f32 && f32ok;
+    if (Taps3Builder::eligible(in, wshape)) {
+        Taps3Builder t3;
+        if ((rc = t3.build(in, wshape, origins, [&](int64_t k) { return weights[k] != 0.0; },
+                           [&](int64_t k) { return weights[k]; }, true))) return rc;
+        Taps3 tt3;
+        if ((rc = t3.finish(&tt3, s))) return rc;
+        return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
+            const T *ip = (const T *)in->data;
+            if (use_f32)
+                hipLaunchKernelGGL((corr3_kernel<T, float>), grid3(t3.g), dim3(64, 4, 1), taps3_lds_bytes(tt3), s, ip, out->data, out->dtype,
+                                   t3.g, tt3, mode, cval);
+            else
+                hipLaunchKernelGGL((corr3_kernel<T, double>), grid3(t3.g), dim3(64, 4, 1), taps3_lds_bytes(tt3), s, ip, out->data, out->dtype,
+                                   t3.g, tt3, mode, cval);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        });
+    }
     TapBuilder tb;
     if ((rc = tb.init(in, wshape, origins, "weights"))) return rc;
     tb.fill([&](int64_t k) { return weights[k] != 0.0; }, [&](int64_t k) { return weights[k]; }, true);
     TapTable tt;
     if ((rc = tb.upload(&tt, s))) return rc;
-
-    const bool f32ok = in->dtype == MI_F32 || in->dtype == MI_BOOL || dtype_size(in->dtype) <= 2;
-    const bool use_f32 = acc_f32 && f32ok;
     dim3 grid;
     grid_for(total, 256, &grid);
     return dispatch_dtype(in->dtype, [&]<typename T>() -> int {

@@ -67,6 +67,43 @@ minmax_nd_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, N
     }
 }
 
+// rank <= 3 fast geometry (nd_common.hpp): same comparisons, same tap order
+template <typename T>
+__global__ void __launch_bounds__(256)
+minmax3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Geom3 g, Taps3 tt, int mode, double cval,
+               int is_max)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsTaps lt = stage_taps(tt, smem);
+    const Vox3 v = locate3(g);
+    if (!v.valid) return;
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)((unsigned)g.nz * g.ny * g.nx * sizeof(T)), 0x00020000);
+    double best = 0.0;
+    auto fold = [&](int t, double x) {
+        if (tt.has_val) x = (t == 0) ? x + lt.val[0] : add_in_type<T>(x, lt.val[t]);
+        if (t == 0 || (is_max ? x > best : x < best)) best = x;
+    };
+    if (v.interior) {
+        const unsigned base = (unsigned)v.lin * (unsigned)sizeof(T);
+        int t0 = 0;
+        for (; t0 + 8 <= tt.ntaps; t0 += 8) {
+            T raw[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) raw[k] = buf_load<T>(rin, base + (unsigned)(lt.lin[t0 + k] * (int)sizeof(T)));
+#pragma unroll
+            for (int k = 0; k < 8; k++) fold(t0 + k, (double)raw[k]);
+        }
+        for (; t0 < tt.ntaps; t0++) fold(t0, (double)buf_load<T>(rin, base + (unsigned)(lt.lin[t0] * (int)sizeof(T))));
+    } else {
+        for (int t = 0; t < tt.ntaps; t++) {
+            const int pos = tap_pos3(g, v, lt, t, mode);
+            fold(t, pos < 0 ? cval : (double)buf_load<T>(rin, (unsigned)pos * (unsigned)sizeof(T)));
+        }
+    }
+    store_as(out, v.lin, out_dt, best);
+}
+
 }  // namespace mi
 
 using namespace mi;
@@ -126,13 +163,24 @@ int mi_minmax_nd(const mi_array *in, const mi_array *out, const uint8_t *footpri
     hipStream_t s = resolve_stream(stream);
     mode = filter_mode(mode);
 
+    Taps3Builder t3;
+    Taps3 tt3;
+    const bool fast3 = Taps3Builder::eligible(in, fshape);
     TapBuilder tb;
-    if ((rc = tb.init(in, fshape, origins, "footprint"))) return rc;
-    tb.fill([&](int64_t k) { return footprint[k] != 0; },
-            [&](int64_t k) { return is_max ? structure[k] : -structure[k]; }, structure != nullptr);
-    MI_REQUIRE(!tb.lin.empty(), MI_ERR_INVALID_ARG, "all-zero footprint is not supported");
     TapTable tt;
-    if ((rc = tb.upload(&tt, s))) return rc;
+    if (fast3) {
+        if ((rc = t3.build(in, fshape, origins, [&](int64_t k) { return footprint[k] != 0; },
+                           [&](int64_t k) { return is_max ? structure[k] : -structure[k]; }, structure != nullptr)))
+            return rc;
+        MI_REQUIRE(!t3.lin.empty(), MI_ERR_INVALID_ARG, "all-zero footprint is not supported");
+        if ((rc = t3.finish(&tt3, s))) return rc;
+    } else {
+        if ((rc = tb.init(in, fshape, origins, "footprint"))) return rc;
+        tb.fill([&](int64_t k) { return footprint[k] != 0; },
+                [&](int64_t k) { return is_max ? structure[k] : -structure[k]; }, structure != nullptr);
+        MI_REQUIRE(!tb.lin.empty(), MI_ERR_INVALID_ARG, "all-zero footprint is not supported");
+        if ((rc = tb.upload(&tt, s))) return rc;
+    }
 
     dim3 grid;
     grid_for(total, 256, &grid);
@@ -146,6 +194,12 @@ int mi_minmax_nd(const mi_array *in, const mi_array *out, const uint8_t *footpri
             cv = (double)(cval >= 0 ? (uint64_t)cval : (uint64_t)(-(int64_t)(uint64_t)(-cval)));
         else cv = (double)(T)(int64_t)cval;
         const T *ip = (const T *)in->data;
+        if (fast3) {
+            hipLaunchKernelGGL((minmax3_kernel<T>), grid3(t3.g), dim3(64, 4, 1), taps3_lds_bytes(tt3), s, ip, out->data, out->dtype, t3.g,
+                               tt3, mode, cv, is_max);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        }
         if (tb.g.ndim == 3)
             hipLaunchKernelGGL((minmax_nd_kernel<T, 3>), grid, dim3(256), 0, s, ip, out->data, out->dtype, tb.g,
                                tt, total, mode, cv, is_max);
