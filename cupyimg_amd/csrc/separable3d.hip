@@ -742,14 +742,19 @@ extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const
     if (w[0] > kMaxTaps || w[1] > kMaxTaps || w[2] > kMaxTaps) {
         // long kernels: streaming passes (stream3d.hip), x fused into the z pass when the tap counts agree
         if (nz * ny * nx * 4 >= ((int64_t)1 << 31)) UNSUP("streaming passes need a volume < 2 GiB");
-        if (nx < 16) UNSUP("x extent too small for the streaming x pass");
-        if (w[2] > 17) UNSUP("x kernels longer than 17 taps have no register x pass");
+        {
+            // the x pass takes whole 4-float blocks from beyond the tile edge: the last (partial) tile must be
+            // followed by either the array edge or enough columns, and the array must hold the mirrored blocks
+            const int nb = (w[2] / 2 + 3) / 4;
+            const int64_t tail = nx & 255;
+            if (w[2] > 1 && (nx < 4 * nb + 4 || (tail != 0 && tail < 4 * nb))) UNSUP("x extent unsuitable for the streaming x pass");
+        }
         hipStream_t s = resolve_stream(stream);
         const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
         struct Pass { int axis, wa, oa, ma, wx; };
         Pass passes[3];
         int np = 0;
-        const bool fuse_xz = w[2] > 1 && w[2] == w[0];
+        const bool fuse_xz = w[2] > 1 && w[2] == w[0] && w[2] <= 17;   // longer x kernels: separate x pass (registers)
         if (w[2] > 1 && !fuse_xz) passes[np++] = {1, 1, 0, p.my, w[2]};            // x only (streams over y)
         if (w[0] > 1) passes[np++] = {0, w[0], oz, p.mz, fuse_xz ? w[2] : 1};
         if (w[1] > 1) passes[np++] = {1, w[1], oy, p.my, 1};

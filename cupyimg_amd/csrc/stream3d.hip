@@ -58,10 +58,10 @@ __device__ __forceinline__ float4 dpp4_from_right(const float4 keep, const float
 }
 __device__ __forceinline__ float4 sel4(bool c, const float4 a, const float4 b) { return c ? a : b; }
 
-// x pass, odd WX <= 17 (reach <= 8 = two lane hops).  eL[j] / eR[j]: the j-th
+// x pass, odd WX <= 33 (reach <= 16 = up to four lane hops).  eL[j] / eR[j]: the j-th
 // 4-float block outside the tile, valid in lane 0 / lane `last` respectively.
 template <int WX>
-__device__ __forceinline__ float4 xpass_hops(const float4 v, const float4 (&eL)[2], const float4 (&eR)[2], int lane,
+__device__ __forceinline__ float4 xpass_hops(const float4 v, const float4 (&eL)[4], const float4 (&eR)[4], int lane,
                                              int last, const float *__restrict__ wx)
 {
     if constexpr (WX == 1) {
@@ -134,8 +134,8 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     const unsigned voff = lane < nlanes ? (rowbase + (unsigned)(x0 + 4 * lane)) * 4u : kOOB;
 
     // tile-edge blocks for the x pass (lane 0: left, lane `last`: right)
-    unsigned evoff[2] = {kOOB, kOOB};
-    int ekind[2] = {EDGE_FWD, EDGE_FWD};
+    unsigned evoff[4] = {kOOB, kOOB, kOOB, kOOB};
+    int ekind[4] = {EDGE_FWD, EDGE_FWD, EDGE_FWD, EDGE_FWD};
     const int side = lane == 0 ? 0 : 1;
     if constexpr (WX > 1) {
         const bool is_edge_lane = lane == 0 || lane == last;
@@ -181,7 +181,7 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
             if (i < nsteps) {
                 Slot &s = S[J % DEPTH];
                 float4 v = s.cst ? cv4 : s.v;
-                float4 eL[2] = {cv4, cv4}, eR[2] = {cv4, cv4};
+                float4 eL[4] = {cv4, cv4, cv4, cv4}, eR[4] = {cv4, cv4, cv4, cv4};
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
                     const float4 t = s.cst ? cv4 : apply_kind(s.e[j], ekind[j], side, p.cval);
@@ -276,7 +276,7 @@ int run_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axi
     if (wx == 1) return launch_stream_wa<1>(wa, in, out, p, s);
     if (wa == 1) {
         switch (wx) {
-#define X(N) case N: if constexpr (N <= 17) return launch_stream<N, 1>(in, out, p, s); break;
+#define X(N) case N: if constexpr (N > 1) return launch_stream<N, 1>(in, out, p, s); break;
             MI_ODD_CASES(X)
 #undef X
         }

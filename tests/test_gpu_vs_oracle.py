@@ -63,11 +63,12 @@ def test_gaussian_long_kernels_streaming(gpu, ndi, shape):
     x = rng.standard_normal(shape).astype(np.float32)
     xd = gpu.asarray(x)
     for sigma, mode in [(2.0, "reflect"), (2.0, "mirror"), (3.0, "nearest"), (2.5, "wrap"), (2.0, "constant"),
+                        (4.0, "mirror"), (3.5, "wrap"), (3.0, "constant"),
                         ((2.0, 1.0, 3.0), "reflect"), ((0.0, 2.0, 0.0), "mirror"), ((1.5, 0.0, 4.0), "reflect")]:
         ref = orc.gaussian_filter(x, sigma, mode=mode, cval=0.3)
         got = ndi.gaussian_filter(xd, sigma, mode=mode, cval=0.3).get()
         assert maxnorm_rel(got, ref) <= 1e-6, (shape, sigma, mode, maxnorm_rel(got, ref))
-    for size in [11, 15, (13, 5, 17)]:
+    for size in [11, 15, (13, 5, 17), 21, (3, 3, 33), (25, 1, 29)]:
         ref = orc.uniform_filter(x, size, mode="reflect")
         got = ndi.uniform_filter(xd, size, mode="reflect").get()
         assert maxnorm_rel(got, ref) <= 1e-6, (shape, size, maxnorm_rel(got, ref))
