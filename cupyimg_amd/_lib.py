@@ -83,6 +83,7 @@ SIGNATURES = {
     "mi_event_create": [ctypes.POINTER(_vp)],
     "mi_event_destroy": [_vp],
     "mi_event_record": [_vp, _vp],
+    "mi_stream_wait_event": [_vp, _vp],
     "mi_event_sync": [_vp],
     "mi_event_elapsed_ms": [_vp, _vp, ctypes.POINTER(ctypes.c_float)],
     "mi_copy": [_arr, _arr, _i, _vp],
@@ -91,6 +92,7 @@ SIGNATURES = {
     "mi_correlate1d": [_arr, _arr, _i, _dp, _i, _i, _i, _d, _i, _vp],
     "mi_uniform_filter1d": [_arr, _arr, _i, _i, _i, _i, _d, _vp],
     "mi_separable3d_f32": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i, _vp],
+    "mi_separable3d_f32_planes": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i64p, _i, _vp],
     "mi_correlate_nd": [_arr, _arr, _dp, _i64p, _ip, _i, _d, _i, _vp],
     "mi_minmax1d": [_arr, _arr, _i, _i, _i, _i, _d, _i, _vp],
     "mi_minmax3d_u8": [_arr, _arr, _ip, _ip, _ip, _i, _i, _vp],
@@ -102,6 +104,8 @@ SIGNATURES = {
     "mi_comm_init_rank": [ctypes.POINTER(_vp), _i, _i, ctypes.c_char_p],
     "mi_comm_destroy": [_vp],
     "mi_halo_exchange": [_vp, _vp, _sz, ctypes.c_int64, _i, _i, _i, _i, _vp],
+    "mi_slab_separable3d_f32": [_vp, _arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i, _i, _i, _i, _i,
+                                _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"mi_last_error": ctypes.c_char_p}
 

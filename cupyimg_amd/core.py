@@ -463,15 +463,47 @@ def free_all_blocks():
     _lib.check(_lib.load().mi_pool_trim())
 
 
+class Stream:
+    """A hipStream besides the library's default stream (used for the halo
+    exchange so that it overlaps the interior filtering)."""
+
+    def __init__(self):
+        self._s = ctypes.c_void_p()
+        _lib.check(_lib.load().mi_stream_create(ctypes.byref(self._s)))
+
+    @property
+    def handle(self):
+        return self._s
+
+    def wait_event(self, event):
+        """Work submitted to this stream from now on waits for `event`."""
+        _lib.check(_lib.load().mi_stream_wait_event(self._s, event._e))
+
+    def synchronize(self):
+        _lib.check(_lib.load().mi_stream_sync(self._s))
+
+    def __del__(self):
+        try:
+            if self._s:
+                _lib.load().mi_stream_destroy(self._s)
+        except Exception:
+            pass
+
+
+def default_stream_wait_event(event):
+    """Work submitted to the default stream from now on waits for `event`."""
+    _lib.check(_lib.load().mi_stream_wait_event(None, event._e))
+
+
 class Event:
-    """hipEvent on the library's default stream (bench timing)."""
+    """hipEvent; recorded on the library's default stream unless a Stream is given."""
 
     def __init__(self):
         self._e = ctypes.c_void_p()
         _lib.check(_lib.load().mi_event_create(ctypes.byref(self._e)))
 
-    def record(self):
-        _lib.check(_lib.load().mi_event_record(self._e, None))
+    def record(self, stream=None):
+        _lib.check(_lib.load().mi_event_record(self._e, None if stream is None else stream.handle))
 
     def synchronize(self):
         _lib.check(_lib.load().mi_event_sync(self._e))

@@ -88,4 +88,69 @@ int mi_halo_exchange(mi_comm comm, void *slab, size_t plane_bytes, int64_t n_loc
     return MI_OK;
 }
 
+static constexpr size_t kOverlapMinHaloBytes = (size_t)8 << 20;   // per direction
+
+/* One filtering step of a slab rank with the exchange hidden behind the
+ * interior planes (see include/mi355img.h).  Composition of the two entry
+ * points above and mi_separable3d_f32_planes, kept native so that a step costs
+ * one host call: at 8 ranks the per-rank kernel time is ~30 us and Python-side
+ * marshalling of three calls would dominate it. */
+int mi_slab_separable3d_f32(mi_comm comm, const mi_array *ext_in, const mi_array *ext_out,
+                            const double *const weights[3], const int wlen[3], const int origin[3],
+                            const int mode[3], double cval, int lo, int hi, int prev_rank, int next_rank,
+                            int overlap, mi_stream comm_stream, mi_event input_free, mi_event halos_ready,
+                            mi_stream stream)
+{
+    MI_REQUIRE(ext_in && ext_out, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(ext_in->ndim == 3 && ext_out->ndim == 3, MI_ERR_INVALID_ARG, "slabs are 3-D");
+    MI_REQUIRE(lo >= 0 && hi >= 0, MI_ERR_INVALID_ARG, "negative halo");
+    const bool has_prev = prev_rank >= 0, has_next = next_rank >= 0;
+    const int64_t lo_p = has_prev ? lo : 0, hi_p = has_next ? hi : 0;
+    const int64_t n_ext = ext_in->shape[0], n_local = n_ext - lo_p - hi_p;
+    MI_REQUIRE(n_local >= 1 && n_local >= lo && n_local >= hi, MI_ERR_INVALID_ARG,
+               "slab is thinner than the halo it has to provide");
+    const int64_t a = lo_p, b = a + n_local;
+    if (!has_prev && !has_next) {
+        const int64_t all[2] = {a, b};
+        return mi_separable3d_f32_planes(ext_in, ext_out, weights, wlen, origin, mode, cval, all, 1, stream);
+    }
+    MI_REQUIRE(comm, MI_ERR_INVALID_ARG, "a communicator is required when a neighbour exists");
+    const size_t plane_bytes = (size_t)ext_in->strides[0];
+    char *base = (char *)ext_in->data - (size_t)(lo - lo_p) * plane_bytes;
+    // Overlapping costs two cross-stream waits and a second (small) launch,
+    // ~20 us on MI355X; it pays once the exchange itself takes longer than that.
+    if (overlap < 0) overlap = (size_t)(lo > hi ? lo : hi) * plane_bytes >= kOverlapMinHaloBytes;
+    if (!overlap) {
+        int rc = mi_halo_exchange(comm, base, plane_bytes, n_local, lo, hi, prev_rank, next_rank, stream);
+        if (rc != MI_OK) return rc;
+        const int64_t all[2] = {a, b};
+        rc = mi_separable3d_f32_planes(ext_in, ext_out, weights, wlen, origin, mode, cval, all, 1, stream);
+        // kernels that take no plane ranges (> 9 taps): filter the halo planes too, they are scratch
+        if (rc == MI_ERR_UNSUPPORTED)
+            rc = mi_separable3d_f32(ext_in, ext_out, weights, wlen, origin, mode, cval, 0, stream);
+        return rc;
+    }
+    MI_REQUIRE(comm_stream && input_free && halos_ready, MI_ERR_INVALID_ARG,
+               "comm stream and both events are required for the overlapped schedule");
+    hipStream_t s = resolve_stream(stream);
+    hipStream_t cs = (hipStream_t)comm_stream;
+    MI_REQUIRE(cs != s, MI_ERR_INVALID_ARG, "the comm stream must differ from the compute stream");
+    // everything queued so far (producers of the local planes, readers of the old halos)
+    MI_HIP(hipEventRecord((hipEvent_t)input_free, s));
+    const int64_t ib = a + lo_p, ie = b - hi_p;
+    const bool has_interior = ib < ie;
+    if (has_interior) {
+        const int64_t interior[2] = {ib, ie};
+        int rc = mi_separable3d_f32_planes(ext_in, ext_out, weights, wlen, origin, mode, cval, interior, 1, stream);
+        if (rc != MI_OK) return rc;        // nothing else queued yet: the caller may fall back
+    }
+    MI_HIP(hipStreamWaitEvent(cs, (hipEvent_t)input_free, 0));
+    int rc = mi_halo_exchange(comm, base, plane_bytes, n_local, lo, hi, prev_rank, next_rank, comm_stream);
+    if (rc != MI_OK) return rc;
+    MI_HIP(hipEventRecord((hipEvent_t)halos_ready, cs));
+    MI_HIP(hipStreamWaitEvent(s, (hipEvent_t)halos_ready, 0));
+    const int64_t edges[4] = {a, has_interior ? ib : b, has_interior ? ie : b, b};
+    return mi_separable3d_f32_planes(ext_in, ext_out, weights, wlen, origin, mode, cval, edges, 2, stream);
+}
+
 }  // extern "C"

@@ -306,6 +306,11 @@ int mi_event_record(mi_event event, mi_stream stream)
     MI_HIP(hipEventRecord((hipEvent_t)event, resolve_stream(stream)));
     return MI_OK;
 }
+int mi_stream_wait_event(mi_stream stream, mi_event event)
+{
+    MI_HIP(hipStreamWaitEvent(resolve_stream(stream), (hipEvent_t)event, 0));
+    return MI_OK;
+}
 int mi_event_sync(mi_event event) { MI_HIP(hipEventSynchronize((hipEvent_t)event)); return MI_OK; }
 int mi_event_elapsed_ms(mi_event start, mi_event stop, float *ms)
 {

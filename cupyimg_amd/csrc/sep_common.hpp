@@ -15,9 +15,22 @@ struct Sep3dParams {
     int ty;                 // output rows per tile
     int zc;                 // output planes per chunk
     int nxt, nyt, nzc;      // tile counts
+    // output planes to produce: up to two plane ranges [zb, zb + zn), the first
+    // covered by chunks 0 .. nzc0-1, the second by the rest (whole volume:
+    // zb0 = 0, zn0 = nz, nzc0 = nzc).  Boundary handling always refers to nz.
+    int zb0, zn0, zb1, zn1, nzc0;
     float wx[kMaxTaps], wyv[kMaxTaps], wz[kMaxTaps];
     int dbg;                // tuning ablations (0 in production): 1 no x/z math, 2 no stores, 4 no loads, 8 no y math
 };
+
+__device__ __forceinline__ void chunk_planes(const Sep3dParams &p, int zci, int *zs, int *ze)
+{
+    const bool second = zci >= p.nzc0;
+    const int zb = second ? p.zb1 : p.zb0, zn = second ? p.zn1 : p.zn0;
+    const int c = second ? zci - p.nzc0 : zci;
+    *zs = zb + c * p.zc;
+    *ze = min(*zs + p.zc, zb + zn);
+}
 
 struct __attribute__((packed, aligned(4))) float4u { float x, y, z, w; };
 

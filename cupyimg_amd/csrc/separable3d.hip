@@ -115,8 +115,9 @@ sep3d_ws_kernel(const float *__restrict__ in, float *__restrict__ out, const Sep
     const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
 
     const int nx = p.nx, ny = p.ny, nz = p.nz;
-    const int x0 = xt * 256, y0 = yt * p.ty, zs = zci * p.zc;
-    const int ze = min(zs + p.zc, nz);
+    const int x0 = xt * 256, y0 = yt * p.ty;
+    int zs, ze;
+    chunk_planes(p, zci, &zs, &ze);
     const int ty_act = min(p.ty, ny - y0);
     const int rows_needed = ty_act + p.wy - 1;
     const int nlanes = min(64, (nx - x0) >> 2);
@@ -370,14 +371,17 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
     const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
 
     const int nx = p.nx, ny = p.ny, nz = p.nz;
-    const int x0 = xt * 256, y0 = yt * TY, zs = zci * p.zc;
-    const int ze = min(zs + p.zc, nz);
+    const int x0 = xt * 256, y0 = yt * TY;
+    int zs, ze;
+    chunk_planes(p, zci, &zs, &ze);
     const int ty_act = min(TY, ny - y0);
     const int rows_needed = ty_act + W - 1;
     const int nlanes = min(64, (nx - x0) >> 2);
     const int last = nlanes - 1;
+    // one buffer descriptor per plane (base = plane start, range = one plane):
+    // offsets stay 32-bit inside a plane, the volume itself may exceed 4 GiB
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
-    const unsigned total_bytes = plane_bytes * (unsigned)nz;
+    const size_t plane_elems = (size_t)ny * (size_t)nx;
     const int zi0 = zs - p.oz;
     const int nsteps = ze - zs + W - 1;
 
@@ -386,7 +390,6 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
 
     if (wave < NWP) {
         // ------------------------------------------------------------ producer
-        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
         static_assert(R <= 16, "edge lanes");
         // Tile-edge halo: ONE buffer_load per plane fetches the edges of all R
         // rows -- lane r (< R) loads the NE floats left of the tile for row r,
@@ -433,16 +436,18 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
             int zsrc = zi0 + i;
             if ((unsigned)zsrc >= (unsigned)nz) zsrc = ztab[i];
             s.zconst = zsrc < 0;
-            const unsigned soff = (unsigned)max(zsrc, 0) * plane_bytes;
-            const bool skip = HAS_CONST && zsrc < 0;
+            zsrc = __builtin_amdgcn_readfirstlane(max(zsrc, 0));
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(in + (size_t)zsrc * plane_elems), 0, (int)plane_bytes, 0x00020000);
+            const bool skip = HAS_CONST && s.zconst;
 #pragma unroll
             for (int r = 0; r < R; r++)
-                s.v[r] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], soff, 0));
+                s.v[r] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], 0, 0));
             if constexpr (NE == 2) {
-                const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rin, skip ? kOOB : eoffv, soff, 0);
+                const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rin, skip ? kOOB : eoffv, 0, 0);
                 s.t[0] = __uint_as_float(q.x); s.t[1] = __uint_as_float(q.y);
             } else {
-                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : eoffv, soff, 0);
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : eoffv, 0, 0);
                 s.t[0] = __uint_as_float(q.x); s.t[1] = __uint_as_float(q.y);
                 s.t[2] = __uint_as_float(q.z); s.t[3] = __uint_as_float(q.w);
             }
@@ -517,7 +522,6 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
         }
     } else {
         // ------------------------------------------------------------ consumer
-        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
         const int cw = wave - NWP;
         const int j0 = cw * G;
         unsigned ovoff[G];
@@ -527,7 +531,8 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
         for (int i = 0; i < nsteps; i++) {
             __syncthreads();
             if (i < W - 1) continue;
-            const unsigned soff = (unsigned)(zs + i - (W - 1)) * plane_bytes;
+            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(out + (size_t)(zs + i - (W - 1)) * plane_elems), 0, (int)plane_bytes, 0x00020000);
             const float4 *rbuf = lds + (i & 1) * (LROWS * 64) + j0 * 64 + lane;
             float4 win[G + W - 1];
 #pragma unroll
@@ -544,7 +549,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
                 }
                 u32x4 u;
                 u.x = __float_as_uint(a.x); u.y = __float_as_uint(a.y); u.z = __float_as_uint(a.z); u.w = __float_as_uint(a.w);
-                __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[g], soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[g], 0, 0);
             }
         }
     }
@@ -698,11 +703,12 @@ extern "C" int mi_debug_copy_f32(const float *in, float *out, int64_t n, int blo
     return MI_OK;
 }
 
-extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const double *const weights[3],
-                                  const int wlen[3], const int origin[3], const int mode[3], double cval,
-                                  int is_box, mi_stream stream)
+// planes: nranges (<= 2) pairs [begin, end) of output planes to produce, or
+// nullptr for the whole volume
+static int separable3d_impl(const mi_array *in, const mi_array *out, const double *const weights[3],
+                            const int wlen[3], const int origin[3], const int mode[3], double cval,
+                            const int64_t *planes, int nranges, mi_stream stream)
 {
-    (void)is_box;
     int rc;
     if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
     MI_REQUIRE(weights && wlen && origin && mode, MI_ERR_INVALID_ARG, "NULL argument");
@@ -739,8 +745,27 @@ extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const
     const bool any_const = p.mz == MI_MODE_CONSTANT || p.my == MI_MODE_CONSTANT || p.mx == MI_MODE_CONSTANT;
     if (any_const && !normalised) UNSUP("constant mode needs kernels that sum to one");
 
+    // plane ranges: ascending, disjoint, inside the volume; empty ranges are dropped
+    int64_t zb[2] = {0, 0}, zn[2] = {nz, 0};
+    if (planes) {
+        MI_REQUIRE(nranges >= 1 && nranges <= 2, MI_ERR_INVALID_ARG, "one or two plane ranges");
+        zn[0] = 0;
+        int k = 0;
+        int64_t prev_end = 0;
+        for (int r = 0; r < nranges; r++) {
+            const int64_t b = planes[2 * r], e = planes[2 * r + 1];
+            MI_REQUIRE(b >= prev_end && e >= b && e <= nz, MI_ERR_INVALID_ARG, "plane ranges must be ascending and inside the volume");
+            prev_end = e;
+            if (e > b) { zb[k] = b; zn[k] = e - b; k++; }
+        }
+        if (k == 0) return MI_OK;
+    }
+    const bool whole = zb[0] == 0 && zn[0] == nz;
+    const int64_t nzr = zn[0] + zn[1];
+
     if (w[0] > kMaxTaps || w[1] > kMaxTaps || w[2] > kMaxTaps) {
         // long kernels: streaming passes (stream3d.hip), x fused into the z pass when the tap counts agree
+        if (!whole) UNSUP("plane ranges are not available for kernels longer than 9 taps");
         if (nz * ny * nx * 4 >= ((int64_t)1 << 31)) UNSUP("streaming passes need a volume < 2 GiB");
         {
             // the x pass takes whole 4-float blocks from beyond the tile edge: the last (partial) tile must be
@@ -787,26 +812,28 @@ extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const
 
     const int cfg = g_sep3d_cfg;
     const bool cubic = w[0] == w[1] && w[1] == w[2] && w[0] >= 3 && p.oz == w[0] / 2 && p.oy == w[1] / 2;
-    const bool lean = cubic && g_sep3d_kernel != 1 && nz * ny * nx * 4 < ((int64_t)1 << 31);
+    const bool lean = cubic && g_sep3d_kernel != 1 && ny * nx * 4 < ((int64_t)1 << 31);
     int cfg_use = cfg, rows = 0, nzc = 1;
     if (lean && cfg == 0) {
         // candidates: the big tile and (3 / 5 taps) a small one
         const int big = lean_rows(w[0], 0), small = lean_rows(w[0], 5);
         const int cand_rows[2] = {big, small}, cand_cfg[2] = {0, 5};
-        choose_plan(w[0], cand_rows, cand_cfg, (w[0] <= 5 && small != big) ? 2 : 1, w[1], nz, ny, nx, &cfg_use, &rows, &nzc);
+        choose_plan(w[0], cand_rows, cand_cfg, (w[0] <= 5 && small != big) ? 2 : 1, w[1], nzr, ny, nx, &cfg_use, &rows, &nzc);
     } else {
         rows = lean ? lean_rows(w[0], cfg) : ws_rows(w[0]);
         const int cand_rows[1] = {rows}, cand_cfg[1] = {cfg};
-        choose_plan(w[0], cand_rows, cand_cfg, 1, w[1], nz, ny, nx, &cfg_use, &rows, &nzc);
+        choose_plan(w[0], cand_rows, cand_cfg, 1, w[1], nzr, ny, nx, &cfg_use, &rows, &nzc);
     }
     p.ty = rows - (w[1] - 1);
     if (p.ty < 1) UNSUP("y kernel too long for the tile");
     p.nxt = (int)((nx + 255) / 256);
     p.nyt = (int)((ny + p.ty - 1) / p.ty);
     if (g_sep3d_zchunks > 0) nzc = g_sep3d_zchunks;
-    if ((nz + nzc - 1) / nzc > kMaxChunk) nzc = (int)((nz + kMaxChunk - 1) / kMaxChunk);
-    p.zc = (int)((nz + nzc - 1) / nzc);
-    p.nzc = (int)((nz + p.zc - 1) / p.zc);
+    if ((nzr + nzc - 1) / nzc > kMaxChunk) nzc = (int)((nzr + kMaxChunk - 1) / kMaxChunk);
+    p.zc = (int)((nzr + nzc - 1) / nzc);
+    p.zb0 = (int)zb[0]; p.zn0 = (int)zn[0]; p.zb1 = (int)zb[1]; p.zn1 = (int)zn[1];
+    p.nzc0 = (int)((zn[0] + p.zc - 1) / p.zc);
+    p.nzc = p.nzc0 + (int)((zn[1] + p.zc - 1) / p.zc);
 
     hipStream_t s = resolve_stream(stream);
     const float *ip = (const float *)in->data;
@@ -829,4 +856,20 @@ extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const
     }
 #undef CASE_Z
 #undef UNSUP
+}
+
+extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const double *const weights[3],
+                                  const int wlen[3], const int origin[3], const int mode[3], double cval,
+                                  int is_box, mi_stream stream)
+{
+    (void)is_box;
+    return separable3d_impl(in, out, weights, wlen, origin, mode, cval, nullptr, 0, stream);
+}
+
+extern "C" int mi_separable3d_f32_planes(const mi_array *in, const mi_array *out, const double *const weights[3],
+                                         const int wlen[3], const int origin[3], const int mode[3], double cval,
+                                         const int64_t *planes, int nranges, mi_stream stream)
+{
+    MI_REQUIRE(planes, MI_ERR_INVALID_ARG, "planes is NULL");
+    return separable3d_impl(in, out, weights, wlen, origin, mode, cval, planes, nranges, stream);
 }

@@ -89,6 +89,18 @@ class SlabPlan:
         return idx % self.nz if self.wrap else idx
 
 
+    def plane_ranges(self):
+        """(interior, edges): output plane ranges of the extended buffer that
+        can be filtered before / only after the halo exchange."""
+        a = self.lo_present
+        b = a + self.n_local
+        ib = a + (self.lo if self.prev >= 0 else 0)
+        ie = b - (self.hi if self.next >= 0 else 0)
+        if ib >= ie:                       # slab so thin that every plane touches a halo
+            return [], [(a, b)]
+        return [(ib, ie)], [(a, ib), (ie, b)]
+
+
 class HaloComm:
     """RCCL communicator for the neighbour exchange (one per process / GPU)."""
 
@@ -107,10 +119,10 @@ class HaloComm:
         _lib.check(lib.mi_comm_init_rank(ctypes.byref(self._comm), nranks, rank, uid))
         self.nranks, self.rank = nranks, rank
 
-    def exchange(self, ext, plan):
+    def exchange(self, ext, plan, stream=None):
         """Fill the halo planes of the extended buffer `ext` (device array,
-        C-contiguous, axis 0 = planes) from the neighbours; asynchronous on the
-        default stream."""
+        C-contiguous, axis 0 = planes) from the neighbours; asynchronous on
+        `stream` (a core.Stream; default: the library's default stream)."""
         if ext.shape[0] != plan.n_ext or not ext._is_c_contiguous():
             raise ValueError("extended buffer does not match the plan")
         plane_bytes = ext.nbytes // max(ext.shape[0], 1)
@@ -119,7 +131,8 @@ class HaloComm:
         # missing neighbour simply means that side is absent (width 0 there)
         base = ext.ptr - (plan.lo - plan.lo_present) * plane_bytes
         _lib.check(lib.mi_halo_exchange(self._comm, ctypes.c_void_p(base), plane_bytes, plan.n_local,
-                                        plan.lo, plan.hi, plan.prev, plan.next, None))
+                                        plan.lo, plan.hi, plan.prev, plan.next,
+                                        None if stream is None else stream.handle))
 
     def close(self):
         if self._comm:
@@ -135,12 +148,28 @@ class HaloComm:
 
 class SlabFilter:
     """Runs ``fn(ext_in, ext_out)`` (any filter of this package, output given)
-    on a rank's extended slab after a halo exchange."""
+    on a rank's extended slab after a halo exchange.
+
+    `step` is the plain schedule: exchange, then filter the whole extended
+    buffer, all on the default stream.  `step_overlapped` hides the exchange:
+
+        comm stream    : [ wait input ready ][ RCCL send/recv of the halos ]
+        default stream : [ filter interior planes ........ ][ wait ][ filter edge planes ]
+
+    The interior planes (those whose taps stay inside the local planes) do not
+    need the halos; only the `lo` + `hi` planes next to a neighbour wait for the
+    exchange, and they are filtered in one small launch afterwards.
+    """
 
     def __init__(self, plan, plane_shape, dtype, comm=None):
         self.plan, self.comm = plan, comm
         self.ext_in = core.empty((plan.n_ext,) + tuple(plane_shape), dtype)
         self.ext_out = core.empty((plan.n_ext,) + tuple(plane_shape), dtype)
+        self._comm_stream = None
+        self._halos_ready = None      # exchange finished (recorded on the comm stream)
+        self._input_free = None       # previous readers of ext_in finished (default stream)
+        self._overlap_ok = True
+        self._prepared = {}
 
     @property
     def local_in(self):
@@ -155,3 +184,108 @@ class SlabFilter:
             self.comm.exchange(self.ext_in, self.plan)
         fn(self.ext_in, self.ext_out)
         return self.local_out
+
+    def step_overlapped(self, fn):
+        """Same result as `step` for the local planes, with the exchange
+        overlapped with the interior filtering.  `fn` must be a fused separable
+        filter call (uniform_filter / gaussian_filter / correlate1d chains on
+        3-D float32); anything else falls back to `step`."""
+        from .scipy.ndimage import _support as S
+        if self.comm is None or self.plan.nranks == 1 or not self._overlap_ok:
+            return self.step(fn)
+        if self._comm_stream is None:
+            self._comm_stream = core.Stream()
+            self._halos_ready, self._input_free = core.Event(), core.Event()
+        interior, edges = self.plan.plane_ranges()
+        # the exchange overwrites the halo planes: it has to wait for whatever
+        # was queued on the default stream so far (producers of the local
+        # planes, readers of the old halos)
+        self._input_free.record()
+        self._comm_stream.wait_event(self._input_free)
+        self.comm.exchange(self.ext_in, self.plan, self._comm_stream)
+        self._halos_ready.record(self._comm_stream)
+        try:
+            if interior:
+                with S.output_planes(interior):
+                    fn(self.ext_in, self.ext_out)
+        except S.Unsupported:
+            self._overlap_ok = False
+            core.default_stream_wait_event(self._halos_ready)
+            fn(self.ext_in, self.ext_out)
+            return self.local_out
+        core.default_stream_wait_event(self._halos_ready)
+        with S.output_planes(edges):
+            fn(self.ext_in, self.ext_out)
+        return self.local_out
+
+    # ---------------------------------------------------------------- native step
+    def _streams(self):
+        if self._comm_stream is None:
+            self._comm_stream = core.Stream()
+            self._halos_ready, self._input_free = core.Event(), core.Event()
+
+    def separable(self, weights, modes="reflect", cval=0.0, origins=(0, 0, 0), fallback=None, overlap=None,
+                  _key=None):
+        """One overlapped step of a separable filter given per-axis 1-D weights
+        (None = axis not filtered) as ONE native call
+        (mi_slab_separable3d_f32); the marshalled arguments are cached, so a
+        repeated step costs a few microseconds of host time.  `fallback(ext_in,
+        ext_out)` runs under the plain schedule when the fused kernel does not
+        cover the request.  overlap: True / False, default None = decided by the
+        halo size (overlapping pays from ~8 MiB per direction)."""
+        from .scipy.ndimage import _support as S
+        plan = self.plan
+        key = _key
+        if key is None:
+            key = (tuple(None if w is None else tuple(np.asarray(w, dtype=np.float64)) for w in weights),
+                   str(modes), float(cval), tuple(int(o) for o in origins))
+        prep = self._prepared.get(key)
+        if prep is None:
+            modes = S.normalize_sequence(modes, 3)
+            for m in modes:
+                S.check_mode(m)
+            keep = [None if w is None else np.ascontiguousarray(w, dtype=np.float64) for w in weights]
+            dp = ctypes.POINTER(ctypes.c_double)
+            ptrs = (dp * 3)(*[ctypes.cast(None, dp) if w is None else w.ctypes.data_as(dp) for w in keep])
+            a, b = self.ext_in._desc(), self.ext_out._desc()
+            self._streams()
+            args = (self.comm._comm if self.comm is not None else None, ctypes.byref(a), ctypes.byref(b), ptrs,
+                    S.c_ints([0 if w is None else len(w) for w in keep]), S.c_ints(origins),
+                    S.c_ints([S.mode_code(m) for m in modes]), float(cval), plan.lo, plan.hi, plan.prev, plan.next, 0,
+                    self._comm_stream.handle, self._input_free._e, self._halos_ready._e, None)
+            prep = self._prepared[key] = (args, (keep, a, b))        # second item keeps the buffers alive
+        try:
+            args = prep[0]
+            mode_flag = -1 if overlap is None else int(bool(overlap))
+            _lib.check(_lib.load().mi_slab_separable3d_f32(*args[:12], mode_flag, *args[13:]))
+        except _lib.Unsupported:
+            if fallback is None:
+                raise
+            return self.step(fallback)
+        return self.local_out
+
+    def uniform_filter(self, size, mode="reflect", cval=0.0, overlap=None):
+        """uniform_filter of the whole (distributed) volume; returns this rank's planes."""
+        from .scipy import ndimage as ndi
+        from .scipy.ndimage import _support as S
+        key = ("uniform", str(size), str(mode), float(cval))
+        weights = None
+        if key not in self._prepared:
+            sizes = [int(v) for v in S.normalize_sequence(size, 3)]
+            weights = [np.full((sz,), 1.0 / sz) if sz > 1 else None for sz in sizes]
+        return self.separable(weights, mode, cval, overlap=overlap, _key=key,
+                              fallback=lambda a, b: ndi.uniform_filter(a, size=size, mode=mode, cval=cval, output=b))
+
+    def gaussian_filter(self, sigma, order=0, mode="reflect", cval=0.0, truncate=4.0, overlap=None):
+        """gaussian_filter of the whole (distributed) volume; returns this rank's planes."""
+        from .scipy import ndimage as ndi
+        from .scipy.ndimage import _support as S
+        from .scipy.ndimage.filters import _gaussian_weights
+        key = ("gaussian", str(sigma), str(order), str(mode), float(cval), float(truncate))
+        weights = None
+        if key not in self._prepared:
+            sigmas, orders = S.normalize_sequence(sigma, 3), S.normalize_sequence(order, 3)
+            weights = [_gaussian_weights(sg, od, truncate) if sg > 1e-15 else None for sg, od in zip(sigmas, orders)]
+        return self.separable(weights, mode, cval, overlap=overlap, _key=key,
+                              fallback=lambda a, b: ndi.gaussian_filter(a, sigma, order=order, mode=mode, cval=cval,
+                                                                        truncate=truncate, output=b))

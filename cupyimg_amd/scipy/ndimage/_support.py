@@ -5,7 +5,9 @@ cupyimg/scipy/ndimage/_util.py and _filters_core.py:10-109 so the parity
 tests can assert the same errors the reference's tests do; the code is
 organised around the C-ABI rather than around CuPy kernels.
 """
+import contextlib
 import ctypes
+import threading
 
 import numpy as np
 
@@ -131,11 +133,38 @@ def acc_flag(dtype_mode):
     raise ValueError("dtype_mode={} is not supported".format(dtype_mode))
 
 
+# Plane-restricted launches (multi-GPU slabs, distributed.SlabFilter): inside
+# `output_planes([(b0, e0), (b1, e1)])` a filter call computes only those
+# output planes along axis 0.  Only the fused 3-D kernel honours it; every
+# other path raises Unsupported rather than silently filtering everything.
+_scope = threading.local()
+
+
+@contextlib.contextmanager
+def output_planes(ranges):
+    prev = getattr(_scope, "planes", None)
+    _scope.planes = [(int(b), int(e)) for b, e in ranges]
+    try:
+        yield
+    finally:
+        _scope.planes = prev
+
+
+def current_planes():
+    return getattr(_scope, "planes", None)
+
+
+def _no_plane_scope():
+    if current_planes() is not None:
+        raise Unsupported("this filter cannot be restricted to a range of output planes")
+
+
 def run_kernel(input, output, launch):
     """Run ``launch(src, dst)`` with contiguous, non-overlapping src/dst and
     deliver the result into `output` (which may be a strided view or alias the
     input; the reference handles the latter with a temp + copy,
     _filters_core.py:148-155)."""
+    _no_plane_scope()
     src = core.ascontiguousarray(input)
     if output._is_c_contiguous() and not core.shares_memory(output, src):
         launch(src, output)
@@ -151,6 +180,7 @@ def run_passes(input, output, passes):
     one scratch volume so that the last pass lands in `output` and no
     copy-back is needed (the reference pays a zero-fill plus a full copy per
     in-place pass, _filters_core.py:148-155; filters.py:651-662)."""
+    _no_plane_scope()
     n = len(passes)
     if n == 0:
         output[...] = input

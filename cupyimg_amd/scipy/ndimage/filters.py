@@ -142,7 +142,18 @@ def convolve(input, weights, output=None, mode="reflect", cval=0.0, origin=0, *,
 def _try_fused_3d(input, output, weights, origins, modes, cval, is_box):
     """All 1-D passes of a 3-D float32 filter in one launch.  Returns the
     output, or None when the fused kernel does not cover the request (the
-    caller then runs generic *device* passes)."""
+    caller then runs generic *device* passes).  Inside `S.output_planes(..)`
+    only the given output planes are computed, and a request the fused kernel
+    cannot take raises instead of falling back."""
+    planes = S.current_planes()
+    res = _fused_3d(input, output, weights, origins, modes, cval, is_box, planes)
+    if res is None and planes is not None:
+        raise S.Unsupported("plane-restricted filtering needs the fused 3-D float32 kernel "
+                            "(contiguous, non-aliasing float32 volumes, odd kernels of at most 9 taps)")
+    return res
+
+
+def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
     if input.ndim != 3 or input.dtype != np.float32 or output.dtype != np.float32:
         return None
     if not any(w is not None for w in weights):
@@ -155,6 +166,9 @@ def _try_fused_3d(input, output, weights, origins, modes, cval, is_box):
     if input.shape[2] < 8 or input.shape[2] % 4 or input.shape[2] % 256 == 4:
         return None
     if input.size == 0:
+        return None
+    if planes is not None and not (input._is_c_contiguous() and output._is_c_contiguous()
+                                   and not core.shares_memory(output, input)):
         return None
     src = core.ascontiguousarray(input)
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
@@ -170,8 +184,13 @@ def _try_fused_3d(input, output, weights, origins, modes, cval, is_box):
     mds = S.c_ints([S.mode_code(m) for m in modes])
     a, b = src._desc(), dst._desc()
     try:
-        S.check(S.lib().mi_separable3d_f32(ctypes.byref(a), ctypes.byref(b), ptrs, wlen, org, mds,
-                                           float(cval), int(is_box), None))
+        if planes is None:
+            S.check(S.lib().mi_separable3d_f32(ctypes.byref(a), ctypes.byref(b), ptrs, wlen, org, mds,
+                                               float(cval), int(is_box), None))
+        else:
+            flat = S.c_int64s([v for r in planes for v in r])
+            S.check(S.lib().mi_separable3d_f32_planes(ctypes.byref(a), ctypes.byref(b), ptrs, wlen, org, mds,
+                                                      float(cval), flat, len(planes), None))
     except S.Unsupported:
         return None
     if not direct:
@@ -360,6 +379,8 @@ def _launch_minmax1d(src, dst, axis, size, origin, mode, cval, is_max):
 
 
 def _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max):
+    if S.current_planes() is not None:
+        raise S.Unsupported("min/max filters cannot be restricted to a range of output planes")
     if input.ndim != 3 or input.dtype != np.uint8 or output.dtype != np.uint8 or input.size == 0:
         return None
     src = core.ascontiguousarray(input)

@@ -121,6 +121,7 @@ int mi_device_sync(void);
 int mi_event_create(mi_event *event);
 int mi_event_destroy(mi_event event);
 int mi_event_record(mi_event event, mi_stream stream);
+int mi_stream_wait_event(mi_stream stream, mi_event event); /* later work on stream waits for event */
 int mi_event_sync(mi_event event);
 int mi_event_elapsed_ms(mi_event start, mi_event stop, float *ms);
 
@@ -164,6 +165,16 @@ int mi_uniform_filter1d(const mi_array *in, const mi_array *out, int axis, int s
 int mi_separable3d_f32(const mi_array *in, const mi_array *out, const double *const weights[3],
                        const int wlen[3], const int origin[3], const int mode[3], double cval,
                        int is_box, mi_stream stream);
+
+/* Same filter restricted to one or two ranges of OUTPUT planes (axis 0):
+ * planes = {begin0, end0[, begin1, end1]}, ascending and disjoint.  Boundary
+ * handling still refers to the whole array; planes outside the ranges are
+ * neither read for their own sake nor written.  New (the reference is
+ * single-GPU): lets a slab rank filter its interior while the halo planes are
+ * still in flight and finish the planes next to the halos afterwards. */
+int mi_separable3d_f32_planes(const mi_array *in, const mi_array *out, const double *const weights[3],
+                              const int wlen[3], const int origin[3], const int mode[3], double cval,
+                              const int64_t *planes, int nranges, mi_stream stream);
 
 /* Dense n-D stencil (filters.py:65-210 -> :441-495): weights is a host array
  * of prod(wshape) doubles in C order, already flipped for convolution by the
@@ -236,6 +247,23 @@ int mi_comm_destroy(mi_comm comm);
  * ncclGroupStart/End.  prev/next < 0 means no neighbour (global edge). */
 int mi_halo_exchange(mi_comm comm, void *slab, size_t plane_bytes, int64_t n_local, int lo,
                      int hi, int prev_rank, int next_rank, mi_stream stream);
+
+/* One filtering step of a slab rank: fused separable filter of the extended
+ * slab [lo halo | local planes | hi halo] (a side without neighbour has no
+ * halo planes) with the exchange overlapped:
+ *   stream      : record input_free | interior planes ....... | wait halos_ready | edge planes
+ *   comm_stream : wait input_free   | RCCL send/recv of halos | record halos_ready
+ * overlap = 1 selects that schedule, 0 the plain one (exchange, then one
+ * launch over all local planes, both on `stream`), -1 decides by halo size:
+ * the two cross-stream waits and the extra launch cost ~20 us, so overlapping
+ * pays from ~8 MiB of halo per direction.  Only the local planes of ext_out
+ * are meaningful (kernels longer than 9 taps also overwrite its halo planes).  With overlap = 1, MI_ERR_UNSUPPORTED is returned before anything is
+ * queued when the fused kernel does not take plane ranges for the request. */
+int mi_slab_separable3d_f32(mi_comm comm, const mi_array *ext_in, const mi_array *ext_out,
+                            const double *const weights[3], const int wlen[3], const int origin[3],
+                            const int mode[3], double cval, int lo, int hi, int prev_rank, int next_rank,
+                            int overlap, mi_stream comm_stream, mi_event input_free,
+                            mi_event halos_ready, mi_stream stream);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ def report(name, workload, voxels, alg_bytes_per_voxel, secs, extra=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--only", default="H,B,C,D,Daff")
+    ap.add_argument("--only", default="H,B,C,D,Daff,E")
     a = ap.parse_args()
     only = set(a.only.split(","))
     rng = np.random.default_rng(0)
@@ -78,6 +78,18 @@ def main():
             t = timeit(lambda: ndi.map_coordinates(xd, cd, order=1, mode="constant", output=out), a.reps)
             report("D", "map_coordinates order=1 3-D affine warp, 512^3 float32 (+1.5 GiB coords)", n ** 3, 20, t)
             del cd
+    if "E" in only:
+        # one rank's share of config E: 2048^3 split over 8 GPUs = 256 planes + 4 halo planes each side
+        xd = out = None
+        ca.free_all_blocks()
+        shape = (264, 2048, 2048)
+        ed = ca.asarray(np.random.default_rng(2).standard_normal(shape, dtype=np.float32))
+        eo = ca.empty(shape, np.float32)
+        t = timeit(lambda: ndi.uniform_filter(ed, size=9, output=eo), max(3, a.reps // 2))
+        report("E-slab", "uniform_filter size=9 on one rank's 264x2048x2048 float32 slab of the 2048^3 volume",
+               shape[0] * shape[1] * shape[2], 8, t)
+        ed = eo = None
+        ca.free_all_blocks()
     if "C" in only:
         xd = out = None
         ca.free_all_blocks()

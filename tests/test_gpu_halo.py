@@ -1,0 +1,164 @@
+"""Multi-GPU building blocks on ONE device: plane-restricted launches of the
+fused kernel, the RCCL send/recv path (a one-rank communicator exchanging with
+itself closes the chain, i.e. periodic halos) and the overlapped schedule of
+SlabFilter on top of both.  The two-rank pairing itself is covered on CPU by
+test_distributed_gloo.py."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _cases import maxnorm_rel
+from oracle import ndimage as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ndi(gpu):
+    from cupyimg_amd.scipy import ndimage
+    return ndimage
+
+
+@pytest.mark.parametrize("size,mode", [(3, "reflect"), (5, "reflect"), (5, "constant"), (7, "mirror"), (9, "nearest"),
+                                       ((3, 5, 7), "wrap"), ((1, 5, 3), "reflect")])
+def test_plane_restricted_launches_tile_the_full_result(gpu, ndi, size, mode):
+    from cupyimg_amd.scipy.ndimage import _support as S
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((70, 45, 512)).astype(np.float32)
+    xd = gpu.asarray(x)
+    full = ndi.uniform_filter(xd, size, mode=mode, cval=0.5).get()
+    sentinel = np.float32(-12345.0)
+    out = gpu.asarray(np.full(x.shape, sentinel, np.float32))
+    with S.output_planes([(4, 31)]):
+        ndi.uniform_filter(xd, size, mode=mode, cval=0.5, output=out)
+    got = out.get()
+    assert np.array_equal(got[4:31], full[4:31])
+    assert np.all(got[:4] == sentinel) and np.all(got[31:] == sentinel)     # nothing else written
+    with S.output_planes([(0, 4), (31, 70)]):
+        ndi.uniform_filter(xd, size, mode=mode, cval=0.5, output=out)
+    assert np.array_equal(out.get(), full)
+    with S.output_planes([(0, 0), (69, 70)]):                               # empty + one plane
+        ndi.uniform_filter(xd, size, mode=mode, cval=0.5, output=out)
+    assert np.array_equal(out.get(), full)
+
+
+def test_plane_restriction_refuses_unfused_filters(gpu, ndi):
+    from cupyimg_amd.scipy.ndimage import _support as S
+    x = gpu.asarray(np.zeros((12, 12, 16), np.float64))
+    with S.output_planes([(2, 4)]):
+        with pytest.raises(S.Unsupported):
+            ndi.uniform_filter(x, 3)
+        with pytest.raises(S.Unsupported):
+            ndi.minimum_filter(gpu.asarray(np.zeros((12, 12, 16), np.uint8)), 3)
+    ndi.uniform_filter(x, 3)        # scope is gone
+
+
+class _SelfLoopPlan:
+    """SlabPlan of a closed chain of ONE rank: both neighbours are the rank
+    itself, so the halos are the periodic continuation of its own planes."""
+
+    def __init__(self, nz, lo, hi):
+        self.nz, self.nranks, self.rank = nz, 2, 0      # nranks > 1 selects the exchange path
+        self.lo, self.hi, self.wrap = lo, hi, True
+        self.z0, self.z1, self.n_local = 0, nz, nz
+        self.prev = self.next = 0
+        self.lo_present, self.hi_present = lo, hi
+        self.n_ext = lo + nz + hi
+
+    @property
+    def local_slice(self):
+        return slice(self.lo, self.lo + self.nz)
+
+    def plane_ranges(self):
+        from cupyimg_amd.distributed import SlabPlan
+        return SlabPlan.plane_ranges(self)
+
+
+@pytest.fixture(scope="module")
+def self_comm(gpu):
+    from cupyimg_amd.distributed import HaloComm
+    comm = HaloComm(1, 0, lambda uid: uid)
+    yield comm
+    comm.close()
+
+
+def test_rccl_self_exchange_fills_periodic_halos(gpu, self_comm):
+    rng = np.random.default_rng(12)
+    nz, lo, hi = 10, 2, 3
+    x = rng.standard_normal((nz, 6, 8)).astype(np.float32)
+    ext = np.zeros((lo + nz + hi, 6, 8), np.float32)
+    ext[lo:lo + nz] = x
+    d = gpu.asarray(ext)
+    self_comm.exchange(d, _SelfLoopPlan(nz, lo, hi))
+    gpu.synchronize()
+    want = np.concatenate([x[-lo:], x, x[:hi]])
+    assert np.array_equal(d.get(), want)
+
+
+@pytest.mark.parametrize("size", [3, 5, 9])
+def test_overlapped_step_matches_plain_step_and_oracle(gpu, ndi, self_comm, size):
+    from cupyimg_amd.distributed import SlabFilter, halo_widths
+    rng = np.random.default_rng(13)
+    nz = 40
+    x = rng.standard_normal((nz, 33, 256)).astype(np.float32)
+    lo, hi = halo_widths(size)
+    plan = _SelfLoopPlan(nz, lo, hi)
+    sf = SlabFilter(plan, x.shape[1:], np.float32, self_comm)
+    sf.local_in[...] = gpu.asarray(x)
+    fn = lambda a, b: ndi.uniform_filter(a, size=size, mode="mirror", output=b)   # noqa: E731
+    plain = sf.step(fn).get()
+    ref = orc.uniform_filter(x, size, mode=["wrap", "mirror", "mirror"])
+    assert maxnorm_rel(plain, ref) <= 1e-6
+    sf.ext_out[...] = gpu.asarray(np.zeros(sf.ext_out.shape, np.float32))
+    # several steps back to back: the exchange of step k+1 must wait for the readers of step k
+    for _ in range(3):
+        got = sf.step_overlapped(fn)
+    assert sf._overlap_ok
+    assert np.array_equal(got.get(), plain)
+
+
+@pytest.mark.parametrize("nz", [40, 3])
+def test_native_slab_step_matches_plain_step(gpu, ndi, self_comm, nz):
+    """SlabFilter.uniform_filter / gaussian_filter: the whole overlapped step as
+    one C call (mi_slab_separable3d_f32); nz = 3 is a slab without interior."""
+    from cupyimg_amd.distributed import SlabFilter, halo_widths
+    rng = np.random.default_rng(15)
+    x = rng.standard_normal((nz, 33, 256)).astype(np.float32)
+    lo, hi = halo_widths(5)
+    sf = SlabFilter(_SelfLoopPlan(nz, lo, hi), x.shape[1:], np.float32, self_comm)
+    sf.local_in[...] = gpu.asarray(x)
+    plain = sf.step(lambda a, b: ndi.uniform_filter(a, size=5, mode="nearest", output=b)).get()
+    sf.ext_out[...] = gpu.asarray(np.zeros(sf.ext_out.shape, np.float32))
+    for overlap in (None, False, True):
+        sf.ext_out[...] = gpu.asarray(np.zeros(sf.ext_out.shape, np.float32))
+        for _ in range(3):
+            got = sf.uniform_filter(5, mode="nearest", overlap=overlap)
+        assert np.array_equal(got.get(), plain), overlap
+    assert maxnorm_rel(plain, orc.uniform_filter(x, 5, mode=["wrap", "nearest", "nearest"])) <= 1e-6
+    # gaussian sigma 0.5 -> 5 taps, same halo
+    plain = sf.step(lambda a, b: ndi.gaussian_filter(a, 0.5, mode="reflect", output=b)).get()
+    got = sf.gaussian_filter(0.5, mode="reflect").get()
+    assert np.array_equal(got, plain)
+    # 13 taps: the fused kernel takes no plane ranges -> plain schedule, same numbers
+    if nz >= 6:
+        sf2 = SlabFilter(_SelfLoopPlan(nz, 6, 6), x.shape[1:], np.float32, self_comm)
+        sf2.local_in[...] = gpu.asarray(x)
+        for overlap in (None, True):      # native plain schedule / Python fallback after UNSUPPORTED
+            got = sf2.uniform_filter(13, mode="mirror", overlap=overlap).get()
+            assert maxnorm_rel(got, orc.uniform_filter(x, 13, mode=["wrap", "mirror", "mirror"])) <= 1e-6
+
+
+def test_overlapped_step_falls_back_for_long_kernels(gpu, ndi, self_comm):
+    from cupyimg_amd.distributed import SlabFilter, halo_widths
+    rng = np.random.default_rng(14)
+    nz, size = 40, 13
+    x = rng.standard_normal((nz, 20, 256)).astype(np.float32)
+    lo, hi = halo_widths(size)
+    sf = SlabFilter(_SelfLoopPlan(nz, lo, hi), x.shape[1:], np.float32, self_comm)
+    sf.local_in[...] = gpu.asarray(x)
+    fn = lambda a, b: ndi.uniform_filter(a, size=size, mode="nearest", output=b)   # noqa: E731
+    got = sf.step_overlapped(fn).get()
+    assert not sf._overlap_ok
+    ref = orc.uniform_filter(x, size, mode=["wrap", "nearest", "nearest"])
+    assert maxnorm_rel(got, ref) <= 1e-6

@@ -106,3 +106,25 @@ def test_slab_split_is_bit_identical_to_unsplit():
                 res = sndi.uniform_filter(ext, 5, mode=mode)
                 out[p.z0:p.z1] = res[p.local_slice]
             assert np.array_equal(out, ref), (mode, nranks)
+
+
+@pytest.mark.parametrize("nz,nranks,size", [(512, 8, 5), (64, 4, 9), (20, 4, 5), (12, 3, 5), (30, 2, 3)])
+def test_plane_ranges_cover_local_planes_and_interior_needs_no_halo(nz, nranks, size):
+    """Overlapped schedule (SlabFilter.step_overlapped): interior + edge ranges
+    tile the local planes exactly, and the taps of every interior plane stay
+    inside the rank's own planes, so they can run while the halos are in flight."""
+    lo, hi = halo_widths(size)
+    for wrap in (False, True):
+        for r in range(nranks):
+            p = SlabPlan(nz, nranks, r, lo, hi, wrap=wrap)
+            interior, edges = p.plane_ranges()
+            planes = sorted(z for b, e in interior + edges for z in range(b, e))
+            assert planes == list(range(p.lo_present, p.lo_present + p.n_local))
+            local = range(p.lo_present, p.lo_present + p.n_local)
+            for b, e in interior:
+                for z in range(b, e):
+                    lo_ok = z - lo >= local.start or p.prev < 0
+                    hi_ok = z + hi < local.stop or p.next < 0
+                    assert lo_ok and hi_ok, (r, z)
+            flat = [v for rg in edges for v in rg]
+            assert flat == sorted(flat)                      # ascending, disjoint (C-ABI contract)
