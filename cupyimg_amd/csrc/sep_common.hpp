@@ -76,11 +76,21 @@ __device__ __forceinline__ float dpp_from_right(float keep_for_lane63, float v)
                                                       0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
 
+// t[idx] for a per-lane idx, as selects on VALUES.  (Taking the array by
+// reference lets instcombine turn select-of-loads into a load from a selected
+// address; after inlining that is a dynamically indexed stack array, and the
+// whole prefetch register set ends up in scratch memory.)
+__device__ __forceinline__ float pick2(float t0, float t1, int idx) { return idx ? t1 : t0; }
+__device__ __forceinline__ float pick4(float t0, float t1, float t2, float t3, int idx)
+{
+    const float a = idx & 1 ? t1 : t0, b = idx & 1 ? t3 : t2;
+    return idx & 2 ? b : a;
+}
 template <int NE>
 __device__ __forceinline__ float pick(const float (&t)[NE], int idx)
 {
-    if constexpr (NE == 2) return idx ? t[1] : t[0];
-    else return idx & 2 ? (idx & 1 ? t[3] : t[2]) : (idx & 1 ? t[1] : t[0]);
+    if constexpr (NE == 2) return pick2(t[0], t[1], idx);
+    else return pick4(t[0], t[1], t[2], t[3], idx);
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -94,6 +104,40 @@ __device__ __forceinline__ void static_for(F &&f)
         static_for<N - 1>(f);
         f(std::integral_constant<int, N - 1>{});
     }
+}
+
+// Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two floats per lane per
+// instruction, i.e. twice the FMA rate of the scalar forms on CDNA3/4).  A
+// float4 of x-consecutive voxels is kept as two aligned pairs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct F4 { f32x2 lo, hi; };
+
+__device__ __forceinline__ f32x2 splat2(float w) { return (f32x2){w, w}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ F4 f4_splat(float v) { F4 r; r.lo = splat2(v); r.hi = splat2(v); return r; }
+__device__ __forceinline__ F4 f4_from(u32x4 u)
+{
+    F4 r;
+    r.lo = (f32x2){__uint_as_float(u.x), __uint_as_float(u.y)};
+    r.hi = (f32x2){__uint_as_float(u.z), __uint_as_float(u.w)};
+    return r;
+}
+__device__ __forceinline__ F4 f4_from(float4 v) { F4 r; r.lo = (f32x2){v.x, v.y}; r.hi = (f32x2){v.z, v.w}; return r; }
+__device__ __forceinline__ float4 f4_to_float4(F4 a) { return make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y); }
+__device__ __forceinline__ u32x4 f4_to_u32(F4 a)
+{
+    u32x4 u;
+    u.x = __float_as_uint(a.lo.x); u.y = __float_as_uint(a.lo.y);
+    u.z = __float_as_uint(a.hi.x); u.w = __float_as_uint(a.hi.y);
+    return u;
+}
+__device__ __forceinline__ F4 f4_scale(float w, F4 a) { F4 r; r.lo = splat2(w) * a.lo; r.hi = splat2(w) * a.hi; return r; }
+__device__ __forceinline__ F4 f4_fma(float w, F4 q, F4 a)
+{
+    F4 r;
+    r.lo = fma2(splat2(w), q.lo, a.lo);
+    r.hi = fma2(splat2(w), q.hi, a.hi);
+    return r;
 }
 
 __device__ __forceinline__ float4 as_f4(u32x4 u)

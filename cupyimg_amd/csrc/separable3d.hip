@@ -306,41 +306,62 @@ static int launch_sep3d_ws(const float *in, float *out, const Sep3dParams &p, hi
 // three axes: uniform_filter(size=W), isotropic gaussian_filter).  Same
 // producer / consumer structure as sep3d_ws_kernel, with the per-voxel
 // instruction overhead stripped:
-//   * buffer_load / buffer_store with an SRSRC descriptor: the plane offset is
-//     a scalar (soffset), the row + lane offset a loop-invariant VGPR, so the
+//   * buffer_load / buffer_store with one SRSRC descriptor per plane (scalar
+//     base + range), the row + lane offset a loop-invariant VGPR, so the
 //     loop contains no address arithmetic; lanes / rows that must not touch
 //     memory get an out-of-range voffset (hardware range check: loads return 0
 //     without a fetch, stores are dropped) -- no exec-mask branches;
 //   * the z ring is rotated by unrolling W-1 steps with compile-time slot
 //     numbers instead of moving registers;
 //   * consumers read their G + W - 1 LDS rows once and slide over them.
-// Precondition (host): volume < 2 GiB (32-bit buffer offsets).
+//   * packed fp32 math (v_pk_fma_f32) in all three passes.
+// Precondition (host): one plane < 2 GiB (32-bit offsets inside a plane).
 // ---------------------------------------------------------------------------
 // x pass with the tile-edge halo given as wave-uniform scalars (sL: the NE
-// floats left of the tile, sR: the NE floats right of it)
+// floats left of the tile, sR: the NE floats right of it), packed math.
+// Window positions p = -RXE .. 3 + RXE (RXE = halo rounded up to an even
+// count) live in e[p + RXE]; aligned pairs
+// A[m] = (e[2m], e[2m+1]) feed the taps at even distance, the shifted pairs
+// S[m] = (e[2m+1], e[2m+2]) (one v_pk_mov each) the taps at odd distance, so an
+// output pair costs WX v_pk_fma instead of 2 WX v_fma.
 template <int WX, int NE>
-__device__ __forceinline__ float4 xpass_scalar_edges(const float4 v, const float (&sL)[NE], const float (&sR)[NE],
-                                                     int lane, int last, const float *__restrict__ wx)
+__device__ __forceinline__ F4 xpass_packed(const F4 v, const float (&sL)[NE], const float (&sR)[NE], int lane, int last,
+                                           const float *__restrict__ wx)
 {
     constexpr int RX = WX / 2;
-    float e[4 + 2 * RX];
+    constexpr int RXE = (RX + 1) & ~1;
+    constexpr int NP = (4 + 2 * RXE) / 2;
+    const float c[4] = {v.lo.x, v.lo.y, v.hi.x, v.hi.y};
+    float e[4 + 2 * RXE];
+#pragma unroll
+    for (int j = 0; j < 4 + 2 * RXE; j++) e[j] = 0.f;
 #pragma unroll
     for (int j = 0; j < RX; j++) {
-        float l = dpp_from_left(0.f, comp(v, 4 - RX + j));
-        float r = dpp_from_right(0.f, comp(v, j));
-        e[j] = lane == 0 ? sL[NE - RX + j] : l;
-        e[RX + 4 + j] = lane == last ? sR[j] : r;
+        const float l = dpp_from_left(0.f, c[4 - RX + j]);
+        const float r = dpp_from_right(0.f, c[j]);
+        e[RXE - RX + j] = lane == 0 ? sL[NE - RX + j] : l;
+        e[RXE + 4 + j] = lane == last ? sR[j] : r;
     }
-    e[RX + 0] = v.x; e[RX + 1] = v.y; e[RX + 2] = v.z; e[RX + 3] = v.w;
-    float o[4];
+    f32x2 A[NP], S[NP - 1];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        float a = wx[0] * e[c];
+    for (int m = 0; m < NP; m++) A[m] = (f32x2){e[2 * m], e[2 * m + 1]};
+    A[RXE / 2] = v.lo;
+    A[RXE / 2 + 1] = v.hi;
 #pragma unroll
-        for (int k = 1; k < WX; k++) a = fmaf(wx[k], e[c + k], a);
-        o[c] = a;
+    for (int m = 0; m < NP - 1; m++) S[m] = (f32x2){A[m].y, A[m + 1].x};
+    F4 o;
+    {
+        constexpr int d0 = RXE - RX;
+        o.lo = splat2(wx[0]) * ((d0 & 1) ? S[d0 / 2] : A[d0 / 2]);
+        o.hi = splat2(wx[0]) * ((d0 & 1) ? S[d0 / 2 + 1] : A[d0 / 2 + 1]);
     }
-    return make_float4(o[0], o[1], o[2], o[3]);
+    static_for<WX - 1>([&](auto KK) {
+        constexpr int k = decltype(KK)::value + 1;
+        constexpr int d = k - RX + RXE;
+        o.lo = fma2(splat2(wx[k]), (d & 1) ? S[d / 2] : A[d / 2], o.lo);
+        o.hi = fma2(splat2(wx[k]), (d & 1) ? S[d / 2 + 1] : A[d / 2 + 1], o.hi);
+    });
+    return o;
 }
 
 template <int W, int NWP, int NWC, int R, int DEPTH, bool HAS_CONST>
@@ -430,7 +451,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
             }
         }
 
-        struct Regs { float4 v[R]; float t[NE]; bool zconst; };
+        struct Regs { F4 v[R]; float t[NE]; bool zconst; };
         Regs S[DEPTH];
         auto issue = [&](int i, Regs &s) {
             int zsrc = zi0 + i;
@@ -442,7 +463,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
             const bool skip = HAS_CONST && s.zconst;
 #pragma unroll
             for (int r = 0; r < R; r++)
-                s.v[r] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], 0, 0));
+                s.v[r] = f4_from(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], 0, 0));
             if constexpr (NE == 2) {
                 const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rin, skip ? kOOB : eoffv, 0, 0);
                 s.t[0] = __uint_as_float(q.x); s.t[1] = __uint_as_float(q.y);
@@ -453,11 +474,11 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
             }
         };
 
-        float4 ring[RINGN][R];
+        F4 ring[RINGN][R];
 #pragma unroll
         for (int k = 0; k < RINGN; k++)
 #pragma unroll
-            for (int r = 0; r < R; r++) ring[k][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < R; r++) ring[k][r] = f4_splat(0.f);
 
         issue(0, S[0]);
         if constexpr (DEPTH == 2) if (nsteps > 1) issue(1, S[1]);
@@ -477,41 +498,31 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
                         eg[k] = pick<NE>(s.t, eidx[k]);
                         if constexpr (HAS_CONST) eg[k] = (e_is_cval || s.zconst) ? p.cval : eg[k];
                     }
-                    float4 xf[R];
+                    F4 xf[R];
 #pragma unroll
                     for (int r = 0; r < R; r++) {
-                        float4 v = s.v[r];
+                        F4 v = s.v[r];
                         if constexpr (HAS_CONST)
-                            if (yconst[r] || s.zconst) v = make_float4(p.cval, p.cval, p.cval, p.cval);
+                            if (yconst[r] || s.zconst) v = f4_splat(p.cval);
                         float sL[NE], sR[NE];
 #pragma unroll
                         for (int k = 0; k < NE; k++) {
                             sL[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), r));
                             sR[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), 32 + r));
                         }
-                        xf[r] = xpass_scalar_edges<W, NE>(v, sL, sR, lane, last, p.wx);
+                        xf[r] = xpass_packed<W, NE>(v, sL, sR, lane, last, p.wx);
                     }
                     if (i + DEPTH < nsteps) issue(i + DEPTH, s);
                     if (emit) {
 #pragma unroll
                         for (int r = 0; r < R; r++) {
-                            float4 a = make_float4(p.wz[0] * ring[J % RINGN][r].x, p.wz[0] * ring[J % RINGN][r].y,
-                                                   p.wz[0] * ring[J % RINGN][r].z, p.wz[0] * ring[J % RINGN][r].w);
+                            F4 a = f4_scale(p.wz[0], ring[J % RINGN][r]);
 #pragma unroll
-                            for (int k = 1; k < RINGN; k++) {
-                                const float4 &q = ring[(J + k) % RINGN][r];
-                                a.x = fmaf(p.wz[k], q.x, a.x);
-                                a.y = fmaf(p.wz[k], q.y, a.y);
-                                a.z = fmaf(p.wz[k], q.z, a.z);
-                                a.w = fmaf(p.wz[k], q.w, a.w);
-                            }
-                            a.x = fmaf(p.wz[W - 1], xf[r].x, a.x);
-                            a.y = fmaf(p.wz[W - 1], xf[r].y, a.y);
-                            a.z = fmaf(p.wz[W - 1], xf[r].z, a.z);
-                            a.w = fmaf(p.wz[W - 1], xf[r].w, a.w);
+                            for (int k = 1; k < RINGN; k++) a = f4_fma(p.wz[k], ring[(J + k) % RINGN][r], a);
+                            a = f4_fma(p.wz[W - 1], xf[r], a);
                             if constexpr (HAS_CONST)
-                                if (yconst[r]) a = make_float4(p.cval, p.cval, p.cval, p.cval);
-                            wbuf[r * 64] = a;
+                                if (yconst[r]) a = f4_splat(p.cval);
+                            wbuf[r * 64] = f4_to_float4(a);
                         }
                     }
 #pragma unroll
@@ -534,22 +545,15 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
             const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(out + (size_t)(zs + i - (W - 1)) * plane_elems), 0, (int)plane_bytes, 0x00020000);
             const float4 *rbuf = lds + (i & 1) * (LROWS * 64) + j0 * 64 + lane;
-            float4 win[G + W - 1];
+            F4 win[G + W - 1];
 #pragma unroll
-            for (int k = 0; k < G + W - 1; k++) win[k] = rbuf[k * 64];
+            for (int k = 0; k < G + W - 1; k++) win[k] = f4_from(rbuf[k * 64]);
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                float4 a = make_float4(p.wyv[0] * win[g].x, p.wyv[0] * win[g].y, p.wyv[0] * win[g].z, p.wyv[0] * win[g].w);
+                F4 a = f4_scale(p.wyv[0], win[g]);
 #pragma unroll
-                for (int k = 1; k < W; k++) {
-                    a.x = fmaf(p.wyv[k], win[g + k].x, a.x);
-                    a.y = fmaf(p.wyv[k], win[g + k].y, a.y);
-                    a.z = fmaf(p.wyv[k], win[g + k].z, a.z);
-                    a.w = fmaf(p.wyv[k], win[g + k].w, a.w);
-                }
-                u32x4 u;
-                u.x = __float_as_uint(a.x); u.y = __float_as_uint(a.y); u.z = __float_as_uint(a.z); u.w = __float_as_uint(a.w);
-                __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[g], 0, 0);
+                for (int k = 1; k < W; k++) a = f4_fma(p.wyv[k], win[g + k], a);
+                __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(a), rout, ovoff[g], 0, 0);
             }
         }
     }
@@ -633,7 +637,9 @@ static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams 
     case 7:
         return launch_sep3d_lean<7, 8, 4, 3>(in, out, p, hc, s);
     default:
-        return launch_sep3d_lean<9, 12, 4, 2>(in, out, p, hc, s);
+        if (cfg == 6) return launch_sep3d_lean<9, 12, 4, 2, 1>(in, out, p, hc, s);
+        // 8 waves x 251 VGPRs: the 8-plane ring of 4 rows does not fit the 128 registers of a 16-wave group
+        return launch_sep3d_lean<9, 6, 2, 4, 1>(in, out, p, hc, s);
     }
 }
 

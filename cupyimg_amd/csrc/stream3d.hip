@@ -61,11 +61,11 @@ __device__ __forceinline__ float4 sel4(bool c, const float4 a, const float4 b) {
 // x pass, odd WX <= 33 (reach <= 16 = up to four lane hops).  eL[j] / eR[j]: the j-th
 // 4-float block outside the tile, valid in lane 0 / lane `last` respectively.
 template <int WX>
-__device__ __forceinline__ float4 xpass_hops(const float4 v, const float4 (&eL)[4], const float4 (&eR)[4], int lane,
-                                             int last, const float *__restrict__ wx)
+__device__ __forceinline__ F4 xpass_hops(const float4 v, const float4 (&eL)[4], const float4 (&eR)[4], int lane,
+                                         int last, const float *__restrict__ wx)
 {
     if constexpr (WX == 1) {
-        return make_float4(v.x * wx[0], v.y * wx[0], v.z * wx[0], v.w * wx[0]);
+        return f4_scale(wx[0], f4_from(v));
     } else {
         constexpr int RX = WX / 2;
         constexpr int NB = (RX + 3) / 4;            // blocks per side
@@ -80,21 +80,26 @@ __device__ __forceinline__ float4 xpass_hops(const float4 v, const float4 (&eL)[
             blk[NB - j] = l;
             blk[NB + j] = r;
         }
-        float e[4 * (2 * NB + 1)];
+        // packed math: aligned pairs A[m] = window[2m, 2m+1], shifted pairs S[m] = window[2m+1, 2m+2]
+        constexpr int NP = 2 * (2 * NB + 1);
+        f32x2 A[NP], S[NP - 1];
 #pragma unroll
         for (int b = 0; b < 2 * NB + 1; b++) {
-            e[4 * b + 0] = blk[b].x; e[4 * b + 1] = blk[b].y; e[4 * b + 2] = blk[b].z; e[4 * b + 3] = blk[b].w;
+            A[2 * b] = (f32x2){blk[b].x, blk[b].y};
+            A[2 * b + 1] = (f32x2){blk[b].z, blk[b].w};
         }
-        constexpr int BASE = 4 * NB - RX;           // e[BASE + c + k] = in[x + c - RX + k]
-        float o[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float a = wx[0] * e[BASE + c];
-#pragma unroll
-            for (int k = 1; k < WX; k++) a = fmaf(wx[k], e[BASE + c + k], a);
-            o[c] = a;
-        }
-        return make_float4(o[0], o[1], o[2], o[3]);
+        for (int m = 0; m < NP - 1; m++) S[m] = (f32x2){A[m].y, A[m + 1].x};
+        constexpr int BASE = 4 * NB - RX;           // window[BASE + c + k] = in[x + c - RX + k]
+        F4 o;
+        o.lo = splat2(wx[0]) * ((BASE & 1) ? S[BASE / 2] : A[BASE / 2]);
+        o.hi = splat2(wx[0]) * ((BASE & 1) ? S[BASE / 2 + 1] : A[BASE / 2 + 1]);
+        static_for<WX - 1>([&](auto KK) {
+            constexpr int d = BASE + decltype(KK)::value + 1;
+            o.lo = fma2(splat2(wx[d - BASE]), (d & 1) ? S[d / 2] : A[d / 2], o.lo);
+            o.hi = fma2(splat2(wx[d - BASE]), (d & 1) ? S[d / 2 + 1] : A[d / 2 + 1], o.hi);
+        });
+        return o;
     }
 }
 
@@ -165,9 +170,9 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
             s.e[j] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : evoff[j], soff, 0));
     };
 
-    float4 ring[RINGN > 0 ? RINGN : 1];
+    F4 ring[RINGN > 0 ? RINGN : 1];
 #pragma unroll
-    for (int k = 0; k < (RINGN > 0 ? RINGN : 1); k++) ring[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < (RINGN > 0 ? RINGN : 1); k++) ring[k] = f4_splat(0.f);
 
 #pragma unroll
     for (int d = 0; d < DEPTH; d++)
@@ -188,32 +193,20 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                     eL[j] = t;
                     eR[j] = t;
                 }
-                const float4 xf = xpass_hops<WX>(v, eL, eR, lane, last, p.wxv);
+                const F4 xf = xpass_hops<WX>(v, eL, eR, lane, last, p.wxv);
                 if (i + DEPTH < nsteps) issue(i + DEPTH, s);
                 if (i >= WA - 1) {
-                    float4 a;
+                    F4 a;
                     if constexpr (WA == 1) {
-                        a = make_float4(p.wav[0] * xf.x, p.wav[0] * xf.y, p.wav[0] * xf.z, p.wav[0] * xf.w);
+                        a = f4_scale(p.wav[0], xf);
                     } else {
-                        const float4 &q0 = ring[J % RINGN];
-                        a = make_float4(p.wav[0] * q0.x, p.wav[0] * q0.y, p.wav[0] * q0.z, p.wav[0] * q0.w);
+                        a = f4_scale(p.wav[0], ring[J % RINGN]);
 #pragma unroll
-                        for (int k = 1; k < RINGN; k++) {
-                            const float4 &q = ring[(J + k) % RINGN];
-                            a.x = fmaf(p.wav[k], q.x, a.x);
-                            a.y = fmaf(p.wav[k], q.y, a.y);
-                            a.z = fmaf(p.wav[k], q.z, a.z);
-                            a.w = fmaf(p.wav[k], q.w, a.w);
-                        }
-                        a.x = fmaf(p.wav[WA - 1], xf.x, a.x);
-                        a.y = fmaf(p.wav[WA - 1], xf.y, a.y);
-                        a.z = fmaf(p.wav[WA - 1], xf.z, a.z);
-                        a.w = fmaf(p.wav[WA - 1], xf.w, a.w);
+                        for (int k = 1; k < RINGN; k++) a = f4_fma(p.wav[k], ring[(J + k) % RINGN], a);
+                        a = f4_fma(p.wav[WA - 1], xf, a);
                     }
                     const unsigned so = (unsigned)(a0 + i - (WA - 1)) * strideA * 4u;
-                    u32x4 u;
-                    u.x = __float_as_uint(a.x); u.y = __float_as_uint(a.y); u.z = __float_as_uint(a.z); u.w = __float_as_uint(a.w);
-                    __builtin_amdgcn_raw_buffer_store_b128(u, rout, voff, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(a), rout, voff, so, 0);
                 }
                 if constexpr (RINGN > 0) ring[J % RINGN] = xf;
             }
