@@ -29,6 +29,7 @@ SOURCES = [
     ("separable3d.hip", []),
     ("stream3d.hip", []),
     ("correlate_nd.hip", ["-ffp-contract=off"]),
+    ("stencil3d.hip", ["-ffp-contract=off"]),
     ("minmax.hip", ["-ffp-contract=off"]),
     ("minmax3d_u8.hip", []),
     ("binary.hip", []),

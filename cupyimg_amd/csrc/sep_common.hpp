@@ -140,6 +140,76 @@ __device__ __forceinline__ F4 f4_fma(float w, F4 q, F4 a)
     return r;
 }
 
+// x pass over a register window in "dot" form: the window is held as aligned
+// pairs A[m] = (win[2m], win[2m+1]) and output c = sum_j wx[j] * win[BASE+c+j]
+// is accumulated as a 2-vector sum_m (wx[2m-BASE-c], wx[2m+1-BASE-c]) * A[m]
+// whose halves are added at the end.  Same v_pk_fma count as the shifted-copy
+// form (xpass_packed) but no second copy of the window in registers.
+template <int WX, int NP, int BASE>
+__device__ __forceinline__ F4 xdot(const f32x2 (&A)[NP], const float *__restrict__ wx)
+{
+    float o[4];
+    static_for<4>([&](auto CC) {
+        constexpr int c = decltype(CC)::value;
+        constexpr int t0 = BASE + c, t1 = BASE + c + WX - 1;
+        constexpr int m0 = t0 / 2, m1 = t1 / 2;
+        static_assert(m1 < NP, "window too short");
+        f32x2 acc;
+        static_for<m1 - m0 + 1>([&](auto MM) {
+            constexpr int m = m0 + decltype(MM)::value;
+            constexpr int j0 = 2 * m - t0, j1 = j0 + 1;
+            const f32x2 wp = (f32x2){(j0 >= 0 && j0 < WX) ? wx[j0 >= 0 && j0 < WX ? j0 : 0] : 0.f,
+                                     (j1 >= 0 && j1 < WX) ? wx[j1 >= 0 && j1 < WX ? j1 : 0] : 0.f};
+            if constexpr (m == m0) acc = wp * A[m];
+            else acc = fma2(wp, A[m], acc);
+        });
+        o[c] = acc.x + acc.y;
+    });
+    F4 r;
+    r.lo = (f32x2){o[0], o[1]};
+    r.hi = (f32x2){o[2], o[3]};
+    return r;
+}
+
+// Weights read from the kernel-argument segment through a scalar pointer.
+// `launder` makes the pointer opaque once per loop iteration so that the
+// s_loads stay inside the loop: hoisted, 2 x 17 weights (+ their pairs) exceed
+// the SGPR file and come back as v_readlane spill code, more VALU work than
+// the filter itself.
+typedef const __attribute__((address_space(4))) float *kfloats;
+__device__ __forceinline__ kfloats kernarg_floats(int byte_offset)
+{
+    return (kfloats)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset);
+}
+__device__ __forceinline__ void launder(kfloats &p) { asm volatile("" : "+s"(p)); }
+
+// xdot with the weight pairs precomputed by the host: tab[q] + 2 (m - m0) holds
+// the pair for output parity q = c & 1 and window pair m (m0 = (BASE + c) / 2).
+template <int WX, int NP, int BASE>
+__device__ __forceinline__ F4 xdot_tab(const f32x2 (&A)[NP], kfloats tab0, kfloats tab1)
+{
+    float o[4];
+    static_for<4>([&](auto CC) {
+        constexpr int c = decltype(CC)::value;
+        constexpr int t0 = BASE + c, t1 = BASE + c + WX - 1;
+        constexpr int m0 = t0 / 2, m1 = t1 / 2;
+        static_assert(m1 < NP, "window too short");
+        kfloats tab = (c & 1) ? tab1 : tab0;
+        f32x2 acc;
+        static_for<m1 - m0 + 1>([&](auto MM) {
+            constexpr int u = decltype(MM)::value;
+            const f32x2 wp = (f32x2){tab[2 * u], tab[2 * u + 1]};
+            if constexpr (u == 0) acc = wp * A[m0];
+            else acc = fma2(wp, A[m0 + u], acc);
+        });
+        o[c] = acc.x + acc.y;
+    });
+    F4 r;
+    r.lo = (f32x2){o[0], o[1]};
+    r.hi = (f32x2){o[2], o[3]};
+    return r;
+}
+
 __device__ __forceinline__ float4 as_f4(u32x4 u)
 {
     return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));

@@ -62,10 +62,10 @@ __device__ __forceinline__ float4 sel4(bool c, const float4 a, const float4 b) {
 // 4-float block outside the tile, valid in lane 0 / lane `last` respectively.
 template <int WX>
 __device__ __forceinline__ F4 xpass_hops(const float4 v, const float4 (&eL)[4], const float4 (&eR)[4], int lane,
-                                         int last, const float *__restrict__ wx)
+                                         int last, kfloats tab0, kfloats tab1)
 {
     if constexpr (WX == 1) {
-        return f4_scale(wx[0], f4_from(v));
+        return f4_from(v);
     } else {
         constexpr int RX = WX / 2;
         constexpr int NB = (RX + 3) / 4;            // blocks per side
@@ -80,26 +80,14 @@ __device__ __forceinline__ F4 xpass_hops(const float4 v, const float4 (&eL)[4], 
             blk[NB - j] = l;
             blk[NB + j] = r;
         }
-        // packed math: aligned pairs A[m] = window[2m, 2m+1], shifted pairs S[m] = window[2m+1, 2m+2]
         constexpr int NP = 2 * (2 * NB + 1);
-        f32x2 A[NP], S[NP - 1];
+        f32x2 A[NP];
 #pragma unroll
         for (int b = 0; b < 2 * NB + 1; b++) {
             A[2 * b] = (f32x2){blk[b].x, blk[b].y};
             A[2 * b + 1] = (f32x2){blk[b].z, blk[b].w};
         }
-#pragma unroll
-        for (int m = 0; m < NP - 1; m++) S[m] = (f32x2){A[m].y, A[m + 1].x};
-        constexpr int BASE = 4 * NB - RX;           // window[BASE + c + k] = in[x + c - RX + k]
-        F4 o;
-        o.lo = splat2(wx[0]) * ((BASE & 1) ? S[BASE / 2] : A[BASE / 2]);
-        o.hi = splat2(wx[0]) * ((BASE & 1) ? S[BASE / 2 + 1] : A[BASE / 2 + 1]);
-        static_for<WX - 1>([&](auto KK) {
-            constexpr int d = BASE + decltype(KK)::value + 1;
-            o.lo = fma2(splat2(wx[d - BASE]), (d & 1) ? S[d / 2] : A[d / 2], o.lo);
-            o.hi = fma2(splat2(wx[d - BASE]), (d & 1) ? S[d / 2 + 1] : A[d / 2 + 1], o.hi);
-        });
-        return o;
+        return xdot_tab<WX, NP, 4 * NB - RX>(A, tab0, tab1);    // window[BASE + c + k] = in[x + c - RX + k]
     }
 }
 
@@ -161,7 +149,8 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     struct Slot { float4 v; float4 e[NB > 0 ? NB : 1]; bool cst; };
     Slot S[DEPTH];
     auto issue = [&](int i, Slot &s) {
-        const int ai = bmap<int>(ai0 + i, nA, p.ma);
+        int ai = ai0 + i;
+        if ((unsigned)ai >= (unsigned)nA) ai = bmap<int>(ai, nA, p.ma);    // only near the ends of the axis
         s.cst = ai < 0;
         const unsigned soff = (unsigned)max(ai, 0) * strideA * 4u;
         s.v = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0));
@@ -179,11 +168,18 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
         if (d < nsteps) issue(d, S[d]);
 
     const float4 cv4 = make_float4(p.cval, p.cval, p.cval, p.cval);
+    // weights stay in the kernel-argument segment and are s_loaded per step (see launder())
+    constexpr int kArgBase = 2 * sizeof(void *);
+    kfloats wav = kernarg_floats(kArgBase + offsetof(StreamParams, wav));
+    kfloats xt0 = kernarg_floats(kArgBase + offsetof(StreamParams, xpair));
+    kfloats xt1 = xt0 + 2 * (kStreamMaxTaps / 2 + 2);
     for (int i0 = 0; i0 < nsteps; i0 += U) {
         static_for<U>([&](auto JJ) {
             constexpr int J = decltype(JJ)::value;
             const int i = i0 + J;
             if (i < nsteps) {
+                launder(wav);
+                if constexpr (WX > 1) { launder(xt0); launder(xt1); }
                 Slot &s = S[J % DEPTH];
                 float4 v = s.cst ? cv4 : s.v;
                 float4 eL[4] = {cv4, cv4, cv4, cv4}, eR[4] = {cv4, cv4, cv4, cv4};
@@ -193,17 +189,17 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                     eL[j] = t;
                     eR[j] = t;
                 }
-                const F4 xf = xpass_hops<WX>(v, eL, eR, lane, last, p.wxv);
+                const F4 xf = xpass_hops<WX>(v, eL, eR, lane, last, xt0, xt1);
                 if (i + DEPTH < nsteps) issue(i + DEPTH, s);
                 if (i >= WA - 1) {
                     F4 a;
                     if constexpr (WA == 1) {
-                        a = f4_scale(p.wav[0], xf);
+                        a = f4_scale(wav[0], xf);
                     } else {
-                        a = f4_scale(p.wav[0], ring[J % RINGN]);
+                        a = f4_scale(wav[0], ring[J % RINGN]);
 #pragma unroll
-                        for (int k = 1; k < RINGN; k++) a = f4_fma(p.wav[k], ring[(J + k) % RINGN], a);
-                        a = f4_fma(p.wav[WA - 1], xf, a);
+                        for (int k = 1; k < RINGN; k++) a = f4_fma(wav[k], ring[(J + k) % RINGN], a);
+                        a = f4_fma(wav[WA - 1], xf, a);
                     }
                     const unsigned so = (unsigned)(a0 + i - (WA - 1)) * strideA * 4u;
                     __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(a), rout, voff, so, 0);
@@ -266,6 +262,17 @@ int run_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axi
     p.nxt = (nx + 255) / 256;
     for (int k = 0; k < wa; k++) p.wav[k] = wav[k];
     for (int k = 0; k < wx; k++) p.wxv[k] = wxv ? wxv[k] : 1.0f;
+    if (wx > 1) {
+        const int rx = wx / 2, nb = (rx + 3) / 4, base = 4 * nb - rx;
+        for (int q = 0; q < 2; q++) {
+            const int t0 = base + q, m0 = t0 / 2;
+            for (int u = 0; u < kStreamMaxTaps / 2 + 2; u++)
+                for (int h = 0; h < 2; h++) {
+                    const int j = 2 * (m0 + u) + h - t0;
+                    p.xpair[q][2 * u + h] = (j >= 0 && j < wx) ? p.wxv[j] : 0.0f;
+                }
+        }
+    }
     if (wx == 1) return launch_stream_wa<1>(wa, in, out, p, s);
     if (wa == 1) {
         switch (wx) {

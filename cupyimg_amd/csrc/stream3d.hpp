@@ -29,6 +29,10 @@ struct StreamParams {
     int nxt;             // x tiles of 256 floats
     float wav[kStreamMaxTaps];
     float wxv[kStreamMaxTaps];
+    // x weights as the pairs the packed dot product multiplies with aligned
+    // window pairs: xpair[q][2u], xpair[q][2u+1] = wx[2u - (B+q)%2], wx[2u + 1 - (B+q)%2]
+    // for output parity q (B = window offset of tap 0, see xpass_hops); 0 outside the kernel
+    float xpair[2][2 * (kStreamMaxTaps / 2 + 2)];
 };
 
 }  // namespace mi
