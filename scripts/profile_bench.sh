@@ -34,4 +34,28 @@ FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports exactly half o
 (16 B/lane) coalesced read stream (MI355X_MICROARCH.md, HBM section): HBM read bytes = 2 * FETCH_SIZE * 1024.
 WRITE_SIZE is taken as is.  Algorithmic bytes per launch: 512^3 * 8 B = 1,073,741,824.""")
 PY
-cat summary.txt
+python3 - <<'PY' > traffic.json
+import csv, glob, json, collections
+def avg(pattern, counter):
+    v = []
+    for f in glob.glob(pattern):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] == counter and 'sep3d_lean_kernel' in r['Kernel_Name']:
+                v.append(float(r['Counter_Value']))
+    return sum(v) / len(v) if v else None
+name, ns = None, None
+for f in glob.glob('stats/*kernel_stats.csv'):
+    for r in csv.DictReader(open(f)):
+        if 'sep3d_lean_kernel' in r['Name']:
+            name, ns = r['Name'], float(r['AverageNs'])
+fetch, write = avg('pmc_fetch/*counter_collection.csv', 'FETCH_SIZE'), avg('pmc_write/*counter_collection.csv', 'WRITE_SIZE')
+rd, wr = int(2 * fetch * 1024), int(write * 1024)
+print(json.dumps({
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE ... -- python3 bench.py --steps 20 --warmup 5 --no-cpu",
+    "kernel": name, "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
+    "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+    "algorithmic_bytes_per_launch": 512 ** 3 * 8,
+    "correction": "gfx950 FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads: x2 (MI355X_MICROARCH.md, HBM)",
+    "avg_kernel_ns_rocprofv3_stats": ns}, indent=1))
+PY
+cat summary.txt traffic.json
