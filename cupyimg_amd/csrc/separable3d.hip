@@ -786,9 +786,10 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
         Pass passes[3];
         int np = 0;
         const bool fuse_xz = w[2] > 1 && w[2] == w[0] && w[2] <= 17;   // longer x kernels: separate x pass (registers)
-        if (w[2] > 1 && !fuse_xz) passes[np++] = {1, 1, 0, p.my, w[2]};            // x only (streams over y)
+        const bool fuse_xy = !fuse_xz && w[0] == 1 && w[2] > 1 && w[2] == w[1] && w[2] <= 17;   // 2-D images: one launch
+        if (w[2] > 1 && !fuse_xz && !fuse_xy) passes[np++] = {1, 1, 0, p.my, w[2]};            // x only (streams over y)
         if (w[0] > 1) passes[np++] = {0, w[0], oz, p.mz, fuse_xz ? w[2] : 1};
-        if (w[1] > 1) passes[np++] = {1, w[1], oy, p.my, 1};
+        if (w[1] > 1) passes[np++] = {1, w[1], oy, p.my, fuse_xy ? w[2] : 1};
         const size_t bytes = (size_t)(nz * ny * nx) * sizeof(float);
         void *tmp[2] = {nullptr, nullptr};
         for (int t = 0; t < np - 1 && t < 2; t++)

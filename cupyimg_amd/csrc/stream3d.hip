@@ -218,12 +218,19 @@ static int launch_stream(const float *in, float *out, StreamParams &p, hipStream
     const int nA = p.axis == 0 ? p.nz : p.ny;
     const int nother = p.axis == 0 ? p.ny : p.nz;
     const int nlines = nother * p.nxt;
-    // chunks: enough waves to fill the chip (256 CUs x 16 waves) while keeping the
-    // (WA-1)-sample ramp-up below ~1/8 of a chunk
-    int nch = (4096 + nlines - 1) / nlines;
-    const int min_chunk = 8 * (WA - 1) + 8;
-    if (nch > nA / min_chunk) nch = nA / min_chunk;
-    if (nch < 1) nch = 1;
+    // chunks along the streamed axis: time ~ rounds x (chunk + ramp), with 256 CUs x 16 resident waves;
+    // many lines (3-D volumes) -> few long chunks, few lines (2-D images, thin slabs) -> many short ones
+    int nch = 1;
+    {
+        double best = 1e300;
+        for (int c = 1; c <= nA && c <= 1024; c++) {
+            const int chunk = (nA + c - 1) / c;
+            const int real = (nA + chunk - 1) / chunk;
+            const double rounds = std::max(1.0, (double)nlines * real / 4096.0);
+            const double cost = rounds * (chunk + (WA - 1) + 4.0);
+            if (cost < best * 0.999) { best = cost; nch = real; }
+        }
+    }
     p.chunk = (nA + nch - 1) / nch;
     p.nchunks = (nA + p.chunk - 1) / p.chunk;
     const int waves = nlines * p.nchunks;

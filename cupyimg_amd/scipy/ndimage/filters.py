@@ -146,6 +146,12 @@ def _try_fused_3d(input, output, weights, origins, modes, cval, is_box):
     only the given output planes are computed, and a request the fused kernel
     cannot take raises instead of falling back."""
     planes = S.current_planes()
+    if input.ndim == 2 and output.ndim == 2 and planes is None:
+        # an image is a one-plane volume: same kernels, no z taps
+        as3 = lambda a: a._view([1] + list(a.shape), [a.strides[0] * a.shape[0]] + list(a.strides), a.ptr)   # noqa: E731
+        res = _fused_3d(as3(input), as3(output), [None] + list(weights), [0] + list(origins),
+                        ["reflect"] + list(modes), cval, is_box, None)
+        return None if res is None else output
     res = _fused_3d(input, output, weights, origins, modes, cval, is_box, planes)
     if res is None and planes is not None:
         raise S.Unsupported("plane-restricted filtering needs the fused 3-D float32 kernel "
@@ -254,8 +260,9 @@ def uniform_filter(input, size=3, output=None, mode="reflect", cval=0.0, origin=
         return output
 
     # fused single-launch path (3-D float32)
-    w3, o3, m3 = [None] * 3, [0] * 3, ["reflect"] * 3
-    if input.ndim == 3:
+    if input.ndim in (2, 3):
+        nd = input.ndim
+        w3, o3, m3 = [None] * nd, [0] * nd, ["reflect"] * nd
         for ax, sz, og, m in axes:
             w3[ax], o3[ax], m3[ax] = np.full((sz,), 1.0 / sz), og, m
         res = _try_fused_3d(input, output, w3, o3, m3, cval, True)
@@ -330,8 +337,9 @@ def gaussian_filter(input, sigma, order=0, output=None, mode="reflect", cval=0.0
     if input.size == 0:
         return output
 
-    if input.ndim == 3:
-        w3, o3, m3 = [None] * 3, [0] * 3, ["reflect"] * 3
+    if input.ndim in (2, 3):
+        nd = input.ndim
+        w3, o3, m3 = [None] * nd, [0] * nd, ["reflect"] * nd
         for ax, _sg, _od, m in axes:
             w3[ax], m3[ax] = weights[ax], m
         res = _try_fused_3d(input, output, w3, o3, m3, cval, False)

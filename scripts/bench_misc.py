@@ -36,5 +36,5 @@ uo = ca.empty(u.shape, np.int16)
 rep("uniform_filter size 5 int16 (generic passes)", timeit(lambda: ndi.uniform_filter(u, 5, output=uo)))
 x2 = ca.asarray(rng.standard_normal((4096, 4096), dtype=np.float32)); o2 = ca.empty(x2.shape, np.float32)
 vox = 4096 * 4096 / 1e6
-rep("gaussian_filter sigma 2, 4096^2 f32 (2-D, generic)", timeit(lambda: ndi.gaussian_filter(x2, 2.0, output=o2)))
-rep("uniform_filter 5, 4096^2 f32 (2-D, generic)", timeit(lambda: ndi.uniform_filter(x2, 5, output=o2)))
+rep("gaussian_filter sigma 2, 4096^2 f32 (2-D)", timeit(lambda: ndi.gaussian_filter(x2, 2.0, output=o2)))
+rep("uniform_filter 5, 4096^2 f32 (2-D)", timeit(lambda: ndi.uniform_filter(x2, 5, output=o2)))

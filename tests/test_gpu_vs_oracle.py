@@ -471,3 +471,27 @@ def test_tiled_stencil_large_volume_property(gpu, ndi):
     t = ndi.correlate1d(t, b, axis=1, mode="mirror", dtype_mode="ndimage")
     ref = ndi.correlate1d(t, c, axis=2, mode="mirror", dtype_mode="ndimage").get()
     assert maxnorm_rel(got, ref) <= 2e-6
+
+
+# ------------------------------------------------------------------ 2-D images through the fused kernels
+@pytest.mark.parametrize("shape", [(300, 512), (64, 264), (33, 40), (1000, 1024)])
+def test_2d_images_take_the_fused_kernels(gpu, ndi, shape):
+    """A float32 image is filtered as a one-plane volume by the same fused /
+    streaming kernels (no z taps); results match the oracle like the 3-D case."""
+    rng = np.random.default_rng(50)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xd = gpu.asarray(x)
+    for mode in MODES:
+        for size in (3, 5, (9, 3), (1, 7)):
+            ref = orc.uniform_filter(x, size, mode=mode, cval=0.25)
+            got = ndi.uniform_filter(xd, size, mode=mode, cval=0.25).get()
+            assert maxnorm_rel(got, ref) <= 1e-6, (shape, "uniform", size, mode)
+        for sigma in (0.8, 2.0, 3.0, (2.0, 0.7)):      # 7, 17 (x fused into the y pass), 25 taps, mixed
+            if min(shape) < 30 and np.max(sigma) > 2.5:
+                continue
+            ref = orc.gaussian_filter(x, sigma, mode=mode, cval=0.25)
+            got = ndi.gaussian_filter(xd, sigma, mode=mode, cval=0.25).get()
+            assert maxnorm_rel(got, ref) <= 1e-6, (shape, "gaussian", sigma, mode)
+    out = gpu.empty(shape, np.float32)
+    assert ndi.gaussian_filter(xd, 1.0, output=out) is out
+    assert maxnorm_rel(out.get(), orc.gaussian_filter(x, 1.0)) <= 1e-6
