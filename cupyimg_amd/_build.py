@@ -33,6 +33,7 @@ SOURCES = [
     ("minmax.hip", ["-ffp-contract=off"]),
     ("minmax3d_u8.hip", []),
     ("binary.hip", []),
+    ("binary3d.hip", []),
     ("interp.hip", ["-ffp-contract=off"]),
     ("interp_fast.hip", ["-ffp-contract=off"]),
     ("halo.hip", []),

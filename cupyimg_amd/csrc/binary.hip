@@ -89,7 +89,17 @@ binary3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, con
 
 }  // namespace mi
 
+namespace mi {
+int binary3_tiled(const mi_array *in, const mi_array *out, const uint8_t *structure, const int64_t *sshape,
+                  const int *origins, const mi_array *mask, int border_value, int invert, int32_t *changed,
+                  hipStream_t s);   // binary3d.hip
+}
+
 using namespace mi;
+
+// test hook (not part of the C-ABI): 0 = never use the LDS-tiled kernel
+static int g_binary_tiled = 1;
+extern "C" int mi_debug_set_binary_tiled(int enabled) { g_binary_tiled = enabled; return MI_OK; }
 
 extern "C" int mi_binary_erosion(const mi_array *in, const mi_array *out, const uint8_t *structure,
                                  const int64_t *sshape, const int *origins, const mi_array *mask,
@@ -112,6 +122,10 @@ extern "C" int mi_binary_erosion(const mi_array *in, const mi_array *out, const 
     const int64_t total = numel(in);
     if (total == 0) return MI_OK;
     hipStream_t s = resolve_stream(stream);
+    if (g_binary_tiled) {
+        rc = binary3_tiled(in, out, structure, sshape, origins, mask, border_value, invert, changed_dev, s);
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
+    }
 
     Taps3Builder t3;
     Taps3 tt3;
