@@ -106,7 +106,16 @@ minmax3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Geo
 
 }  // namespace mi
 
+namespace mi {
+int minmax3_tiled_f32(const mi_array *in, const mi_array *out, const uint8_t *footprint, const int64_t *fshape,
+                      const int *origins, int mode, double cval, bool is_max, hipStream_t s);   // stencil3d.hip
+}
+
 using namespace mi;
+
+// test hook (not part of the C-ABI): 0 = never use the LDS-tiled kernel
+static int g_minmax_tiled = 1;
+extern "C" int mi_debug_set_minmax_tiled(int enabled) { g_minmax_tiled = enabled; return MI_OK; }
 
 extern "C" {
 
@@ -162,6 +171,11 @@ int mi_minmax_nd(const mi_array *in, const mi_array *out, const uint8_t *footpri
     if (total == 0) return MI_OK;
     hipStream_t s = resolve_stream(stream);
     mode = filter_mode(mode);
+    if (g_minmax_tiled && !structure && in->dtype == MI_F32 && out->dtype == MI_F32) {
+        // cval is converted to the input dtype first (SciPy: `_cv = (_type)_cval`)
+        rc = minmax3_tiled_f32(in, out, footprint, fshape, origins, mode, (double)(float)cval, is_max != 0, s);
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
+    }
 
     Taps3Builder t3;
     Taps3 tt3;

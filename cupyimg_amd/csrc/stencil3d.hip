@@ -45,7 +45,13 @@ struct Stencil3Params {
 
 typedef const __attribute__((address_space(4))) double *kdoubles;
 
-template <int WX, int TY, typename Acc, bool DENSE>
+// what a tap does: weighted sum (correlate) or running minimum / maximum over
+// the set footprint elements (flat grey erosion / dilation, min / max filters).
+// Min / max compare exactly like the generic kernel (`x < best` / `x > best`,
+// first tap taken as is), so NaNs propagate the same way.
+enum { ST_CORR = 0, ST_MIN = 1, ST_MAX = 2 };
+
+template <int WX, int TY, typename Acc, bool DENSE, int OP = ST_CORR>
 __global__ void __launch_bounds__(kStNW * 64)
 stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Stencil3Params p)
 {
@@ -152,10 +158,13 @@ stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Ste
         if (more) fetch(s + wz);                          // in flight during the tap loop
 
         Acc acc[RW][4];
+        bool started[RW];
 #pragma unroll
-        for (int rr = 0; rr < RW; rr++)
+        for (int rr = 0; rr < RW; rr++) {
+            started[rr] = false;
 #pragma unroll
             for (int c = 0; c < 4; c++) acc[rr][c] = (Acc)0;
+        }
 
         for (int tz = 0; tz < wz; tz++) {
             const float *slot = ring + ((s + tz) % nslots) * slot_floats + 4 * lane;
@@ -171,8 +180,10 @@ stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Ste
                     live[rr] = ty >= 0 && ty < wy;
                     const int row = tz * wy + min(max(ty, 0), wy - 1);
                     m[rr] = DENSE ? ~0u : p.mask[row];
+                    if constexpr (OP == ST_CORR) {
 #pragma unroll
-                    for (int tx = 0; tx < WX; tx++) wv[rr][tx] = (Acc)kw[row * WX + tx];
+                        for (int tx = 0; tx < WX; tx++) wv[rr][tx] = (Acc)kw[row * WX + tx];
+                    }
                 }
                 const float4 *rowp = reinterpret_cast<const float4 *>(slot + (r0 + i) * kStPitch);
                 const float4 L = rowp[0], C = rowp[1], R = rowp[2];
@@ -186,8 +197,22 @@ stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Ste
 #pragma unroll
                     for (int tx = 0; tx < WX; tx++) {
                         if (!DENSE && !(m[rr] >> tx & 1u)) continue;   // zero weight: skipped like the reference does
+                        if constexpr (OP == ST_CORR) {
 #pragma unroll
-                        for (int c = 0; c < 4; c++) acc[rr][c] += d[c + tx] * wv[rr][tx];
+                            for (int c = 0; c < 4; c++) acc[rr][c] += d[c + tx] * wv[rr][tx];
+                        } else {
+                            if (!started[rr]) {           // wave-uniform: the first set tap is taken as is
+#pragma unroll
+                                for (int c = 0; c < 4; c++) acc[rr][c] = d[c + tx];
+                                started[rr] = true;
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 4; c++) {
+                                    const Acc x = d[c + tx];
+                                    acc[rr][c] = (OP == ST_MAX ? x > acc[rr][c] : x < acc[rr][c]) ? x : acc[rr][c];
+                                }
+                            }
+                        }
                     }
                 }
             }
@@ -220,13 +245,13 @@ static int stencil_cus()
     return cus;
 }
 
-template <int WX, int TY, typename Acc, bool DENSE>
+template <int WX, int TY, typename Acc, bool DENSE, int OP = ST_CORR>
 static int launch_stencil3(const float *in, float *out, Stencil3Params &p, hipStream_t s)
 {
     const size_t lds = (size_t)(p.wz + 1) * (TY + p.wy - 1) * kStPitch * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
-        MI_HIP(hipFuncSetAttribute((const void *)stencil3_kernel<WX, TY, Acc, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        MI_HIP(hipFuncSetAttribute((const void *)stencil3_kernel<WX, TY, Acc, DENSE, OP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(160 * 1024)));
         attr = 160 * 1024;
     }
@@ -249,24 +274,26 @@ static int launch_stencil3(const float *in, float *out, Stencil3Params &p, hipSt
     p.nzc = (p.nz + p.zc - 1) / p.zc;
     const int64_t total = tiles * p.nzc;
     if (total > 0x7fffffff) { set_error("stencil: too many tiles"); return MI_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL((stencil3_kernel<WX, TY, Acc, DENSE>), dim3((unsigned)total), dim3(kStNW * 64), lds, s, in, out, p);
+    hipLaunchKernelGGL((stencil3_kernel<WX, TY, Acc, DENSE, OP>), dim3((unsigned)total), dim3(kStNW * 64), lds, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
 
-template <int WX, typename Acc>
+template <int WX, typename Acc, int OP = ST_CORR>
 static int launch_stencil3_ty(const float *in, float *out, Stencil3Params &p, bool dense, hipStream_t s)
 {
     const size_t lds16 = (size_t)(p.wz + 1) * (16 + p.wy - 1) * kStPitch * sizeof(float);
     if (lds16 <= 150 * 1024)
-        return dense ? launch_stencil3<WX, 16, Acc, true>(in, out, p, s) : launch_stencil3<WX, 16, Acc, false>(in, out, p, s);
-    return dense ? launch_stencil3<WX, 8, Acc, true>(in, out, p, s) : launch_stencil3<WX, 8, Acc, false>(in, out, p, s);
+        return dense ? launch_stencil3<WX, 16, Acc, true, OP>(in, out, p, s) : launch_stencil3<WX, 16, Acc, false, OP>(in, out, p, s);
+    return dense ? launch_stencil3<WX, 8, Acc, true, OP>(in, out, p, s) : launch_stencil3<WX, 8, Acc, false, OP>(in, out, p, s);
 }
 
-// Tries the tiled kernel; MI_ERR_UNSUPPORTED (and no launch) when the request
-// is outside its envelope -- the caller then uses the generic kernels.
-int stencil3_f32(const mi_array *in, const mi_array *out, const double *weights, const int64_t *wshape,
-                 const int *origins, int mode, double cval, bool acc_f32, hipStream_t s)
+// Geometry checks + parameter block shared by the tiled entry points.  keep(k) /
+// value(k): k = C-order index into the window.  Returns MI_ERR_UNSUPPORTED when
+// the request is outside the envelope of the tiled kernel.
+template <typename Keep, typename Value>
+static int stencil3_setup(const mi_array *in, const mi_array *out, const int64_t *wshape, const int *origins, int mode,
+                          double cval, Keep keep, Value value, Stencil3Params *pp, int *wxk, bool *dense)
 {
 #define NOPE(msg) do { set_error("stencil3: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
     if (in->dtype != MI_F32 || out->dtype != MI_F32) NOPE("float32 only");
@@ -287,7 +314,7 @@ int stencil3_f32(const mi_array *in, const mi_array *out, const double *weights,
     if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) NOPE("needs 16-byte aligned data");
     if (w[0] > 7 || w[1] > 7) NOPE("z / y extent > 7");
     // boundary maps are resolved with the cheap near map: the window must not be longer than the array
-    if (w[0] > nz || w[1] > ny || 4 > nx) NOPE("window longer than the array");
+    if (w[0] > nz || w[1] > ny) NOPE("window longer than the array");
     if (mode == MI_MODE_CONSTANT && (double)(float)cval != cval && !std::isnan(cval)) NOPE("cval is not a float32 value");
     // x extent of the kernel: odd, centred, covering taps -off .. w-1-off (zero padded)
     const int reach = std::max(off[2], w[2] - 1 - off[2]);
@@ -296,8 +323,8 @@ int stencil3_f32(const mi_array *in, const mi_array *out, const double *weights,
     if ((int64_t)w[0] * w[1] * WXk > kStMaxWeights || w[0] * w[1] > kStMaxRows) NOPE("window too large");
     const size_t lds8 = (size_t)(w[0] + 1) * (8 + w[1] - 1) * kStPitch * sizeof(float);
     if (lds8 > 150 * 1024) NOPE("window does not fit LDS");
-
-    Stencil3Params p;
+#undef NOPE
+    Stencil3Params &p = *pp;
     memset(&p, 0, sizeof(p));
     p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
     p.wz = w[0]; p.wy = w[1];
@@ -308,14 +335,29 @@ int stencil3_f32(const mi_array *in, const mi_array *out, const double *weights,
     for (int tz = 0; tz < w[0]; tz++)
         for (int ty = 0; ty < w[1]; ty++)
             for (int tx = 0; tx < w[2]; tx++) {
-                const double v = weights[((int64_t)tz * w[1] + ty) * w[2] + tx];
-                if (v == 0.0) continue;
+                const int64_t k = ((int64_t)tz * w[1] + ty) * w[2] + tx;
+                if (!keep(k)) continue;
                 const int kx = tx - off[2] + reach;              // position in the padded row
-                p.w[(tz * w[1] + ty) * WXk + kx] = v;
+                p.w[(tz * w[1] + ty) * WXk + kx] = value(k);
                 p.mask[tz * w[1] + ty] |= 1u << kx;
                 ntaps++;
             }
-    const bool dense = ntaps == w[0] * w[1] * WXk;          // no zero (or padding) taps: no mask tests in the loop
+    *wxk = WXk;
+    *dense = ntaps == w[0] * w[1] * WXk;          // no skipped (or padding) taps: no mask tests in the loop
+    return ntaps > 0 ? MI_OK : MI_ERR_UNSUPPORTED;
+}
+
+// Dense correlate.  MI_ERR_UNSUPPORTED (and no launch) when the request is
+// outside the envelope -- the caller then uses the generic kernels.
+int stencil3_f32(const mi_array *in, const mi_array *out, const double *weights, const int64_t *wshape,
+                 const int *origins, int mode, double cval, bool acc_f32, hipStream_t s)
+{
+    Stencil3Params p;
+    int WXk;
+    bool dense;
+    int rc = stencil3_setup(in, out, wshape, origins, mode, cval, [&](int64_t k) { return weights[k] != 0.0; },
+                            [&](int64_t k) { return weights[k]; }, &p, &WXk, &dense);
+    if (rc != MI_OK) return rc;
     const float *ip = (const float *)in->data;
     float *op = (float *)out->data;
 #define GO(WXV) return acc_f32 ? launch_stencil3_ty<WXV, float>(ip, op, p, dense, s) : launch_stencil3_ty<WXV, double>(ip, op, p, dense, s)
@@ -327,7 +369,29 @@ int stencil3_f32(const mi_array *in, const mi_array *out, const double *weights,
     default: GO(9);
     }
 #undef GO
-#undef NOPE
+}
+
+// Flat footprint minimum / maximum (grey erosion / dilation without structure values).
+int minmax3_tiled_f32(const mi_array *in, const mi_array *out, const uint8_t *footprint, const int64_t *fshape,
+                      const int *origins, int mode, double cval, bool is_max, hipStream_t s)
+{
+    Stencil3Params p;
+    int WXk;
+    bool dense;
+    int rc = stencil3_setup(in, out, fshape, origins, mode, cval, [&](int64_t k) { return footprint[k] != 0; },
+                            [](int64_t) { return 1.0; }, &p, &WXk, &dense);
+    if (rc != MI_OK) return rc;
+    const float *ip = (const float *)in->data;
+    float *op = (float *)out->data;
+#define GO(WXV) return is_max ? launch_stencil3_ty<WXV, float, ST_MAX>(ip, op, p, dense, s) : launch_stencil3_ty<WXV, float, ST_MIN>(ip, op, p, dense, s)
+    switch (WXk) {
+    case 1: GO(1);
+    case 3: GO(3);
+    case 5: GO(5);
+    case 7: GO(7);
+    default: GO(9);
+    }
+#undef GO
 }
 
 }  // namespace mi

@@ -60,7 +60,23 @@ __device__ __forceinline__ float4 sel4(bool c, const float4 a, const float4 b) {
 
 // x pass, odd WX <= 33 (reach <= 16 = up to four lane hops).  eL[j] / eR[j]: the j-th
 // 4-float block outside the tile, valid in lane 0 / lane `last` respectively.
-template <int WX>
+// OP: what a pass computes -- weighted sum, or running minimum / maximum (the
+// comparisons of the generic min/max kernel: first sample taken as is, then
+// `x < best` / `x > best` in ascending tap order).
+enum { SP_CORR = 0, SP_MIN = 1, SP_MAX = 2 };
+
+template <int OP>
+__device__ __forceinline__ float pick_mm(float x, float best) { return (OP == SP_MAX ? x > best : x < best) ? x : best; }
+template <int OP>
+__device__ __forceinline__ F4 f4_mm(const F4 x, const F4 best)
+{
+    F4 r;
+    r.lo = (f32x2){pick_mm<OP>(x.lo.x, best.lo.x), pick_mm<OP>(x.lo.y, best.lo.y)};
+    r.hi = (f32x2){pick_mm<OP>(x.hi.x, best.hi.x), pick_mm<OP>(x.hi.y, best.hi.y)};
+    return r;
+}
+
+template <int WX, int OP = SP_CORR>
 __device__ __forceinline__ F4 xpass_hops(const float4 v, const float4 (&eL)[4], const float4 (&eR)[4], int lane,
                                          int last, kfloats tab0, kfloats tab1)
 {
@@ -87,14 +103,31 @@ __device__ __forceinline__ F4 xpass_hops(const float4 v, const float4 (&eL)[4], 
             A[2 * b] = (f32x2){blk[b].x, blk[b].y};
             A[2 * b + 1] = (f32x2){blk[b].z, blk[b].w};
         }
-        return xdot_tab<WX, NP, 4 * NB - RX>(A, tab0, tab1);    // window[BASE + c + k] = in[x + c - RX + k]
+        constexpr int BASE = 4 * NB - RX;            // window[BASE + c + k] = in[x + c - RX + k]
+        if constexpr (OP == SP_CORR) {
+            return xdot_tab<WX, NP, BASE>(A, tab0, tab1);
+        } else {
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                auto win = [&](int t) { return (t & 1) ? A[t >> 1].y : A[t >> 1].x; };
+                float best = win(BASE + c);
+#pragma unroll
+                for (int k = 1; k < WX; k++) best = pick_mm<OP>(win(BASE + c + k), best);
+                o[c] = best;
+            }
+            F4 r;
+            r.lo = (f32x2){o[0], o[1]};
+            r.hi = (f32x2){o[2], o[3]};
+            return r;
+        }
     }
 }
 
 constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
 constexpr int lcm_(int a, int b) { return a / gcd_(a, b) * b; }
 
-template <int WX, int WA, int DEPTH>
+template <int WX, int WA, int DEPTH, int OP = SP_CORR>
 __global__ void __launch_bounds__(256)
 stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const StreamParams p)
 {
@@ -178,8 +211,10 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
             constexpr int J = decltype(JJ)::value;
             const int i = i0 + J;
             if (i < nsteps) {
-                launder(wav);
-                if constexpr (WX > 1) { launder(xt0); launder(xt1); }
+                if constexpr (OP == SP_CORR) {
+                    launder(wav);
+                    if constexpr (WX > 1) { launder(xt0); launder(xt1); }
+                }
                 Slot &s = S[J % DEPTH];
                 float4 v = s.cst ? cv4 : s.v;
                 float4 eL[4] = {cv4, cv4, cv4, cv4}, eR[4] = {cv4, cv4, cv4, cv4};
@@ -189,11 +224,20 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                     eL[j] = t;
                     eR[j] = t;
                 }
-                const F4 xf = xpass_hops<WX>(v, eL, eR, lane, last, xt0, xt1);
+                const F4 xf = xpass_hops<WX, OP>(v, eL, eR, lane, last, xt0, xt1);
                 if (i + DEPTH < nsteps) issue(i + DEPTH, s);
                 if (i >= WA - 1) {
                     F4 a;
-                    if constexpr (WA == 1) {
+                    if constexpr (OP != SP_CORR) {
+                        if constexpr (WA == 1) {
+                            a = xf;
+                        } else {
+                            a = ring[J % RINGN];                   // oldest sample = tap 0
+#pragma unroll
+                            for (int k = 1; k < RINGN; k++) a = f4_mm<OP>(ring[(J + k) % RINGN], a);
+                            a = f4_mm<OP>(xf, a);
+                        }
+                    } else if constexpr (WA == 1) {
                         a = f4_scale(wav[0], xf);
                     } else {
                         a = f4_scale(wav[0], ring[J % RINGN]);
@@ -210,7 +254,7 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     }
 }
 
-template <int WX, int WA>
+template <int WX, int WA, int OP = SP_CORR>
 static int launch_stream(const float *in, float *out, StreamParams &p, hipStream_t s)
 {
     // in-flight loads per wave: 4 where registers allow (the fused long x pass needs them for its window)
@@ -234,7 +278,7 @@ static int launch_stream(const float *in, float *out, StreamParams &p, hipStream
     p.chunk = (nA + nch - 1) / nch;
     p.nchunks = (nA + p.chunk - 1) / p.chunk;
     const int waves = nlines * p.nchunks;
-    hipLaunchKernelGGL((stream_pass_kernel<WX, WA, DEPTH>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    hipLaunchKernelGGL((stream_pass_kernel<WX, WA, DEPTH, OP>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -298,4 +342,95 @@ int run_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axi
     return MI_ERR_UNSUPPORTED;
 }
 
+// one streaming min / max pass (odd sizes <= 9): along `axis` with `wa` samples, x window `wx` fused when
+// wx == wa or one of them is 1
+template <int OP>
+static int minmax_pass_op(const float *in, float *out, StreamParams &p, int wa, int wx, hipStream_t s)
+{
+#define MM(WXV, WAV) return launch_stream<WXV, WAV, OP>(in, out, p, s)
+    if (wx == 1) {
+        switch (wa) { case 3: MM(1, 3); case 5: MM(1, 5); case 7: MM(1, 7); case 9: MM(1, 9); }
+    } else if (wa == 1) {
+        switch (wx) { case 3: MM(3, 1); case 5: MM(5, 1); case 7: MM(7, 1); case 9: MM(9, 1); }
+    } else if (wa == wx) {
+        switch (wx) { case 3: MM(3, 3); case 5: MM(5, 5); case 7: MM(7, 7); case 9: MM(9, 9); }
+    }
+#undef MM
+    set_error("stream min/max pass: unsupported sizes %d/%d", wx, wa);
+    return MI_ERR_UNSUPPORTED;
+}
+
+int run_stream_minmax_pass(const float *in, float *out, int nz, int ny, int nx, int axis, int wa, int oa, int ma, int wx,
+                           int mx, float cval, bool is_max, hipStream_t s)
+{
+    StreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.nx = nx; p.ny = ny; p.nz = nz;
+    p.axis = axis;
+    p.wa = wa; p.oa = oa; p.ma = ma; p.mx = mx;
+    p.cval = cval;
+    p.nxt = (nx + 255) / 256;
+    return is_max ? minmax_pass_op<SP_MAX>(in, out, p, wa, wx, s) : minmax_pass_op<SP_MIN>(in, out, p, wa, wx, s);
+}
+
 }  // namespace mi
+
+using namespace mi;
+
+/* Separable flat min / max filter on a float32 volume as streaming passes
+ * (declared in include/mi355img.h). */
+extern "C" int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
+                               const int mode[3], double cval, int is_max, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(size && origin && mode, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+#define UNSUP(msg) do { set_error("minmax3d_f32: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if (in->ndim != 3 || in->dtype != MI_F32 || out->dtype != MI_F32) UNSUP("needs 3-D float32 in/out");
+    if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
+    if (in->data == out->data) UNSUP("in-place");
+    const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
+    if (nz < 1 || ny < 1 || nx < 8 || (nx & 3)) UNSUP("x extent must be a multiple of 4, >= 8");
+    if (nz * ny * nx * 4 >= ((int64_t)1 << 31)) UNSUP("needs a volume < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+    int w[3], off[3];
+    for (int a = 0; a < 3; a++) {
+        w[a] = size[a];
+        if (w[a] < 1 || w[a] > 9 || !(w[a] & 1)) UNSUP("sizes must be odd and <= 9");
+        off[a] = w[a] / 2 + origin[a];
+        if (off[a] < 0 || off[a] >= w[a]) { set_error("invalid origin"); return MI_ERR_INVALID_ARG; }
+    }
+    if (origin[2] != 0) UNSUP("x origin must be 0");
+    {
+        const int nb = (w[2] / 2 + 3) / 4;
+        const int64_t tail = nx & 255;
+        if (w[2] > 1 && (nx < 4 * nb + 4 || (tail != 0 && tail < 4 * nb))) UNSUP("x extent unsuitable for the streaming x pass");
+    }
+    const int mz = filter_mode(mode[0]), my = filter_mode(mode[1]), mx = filter_mode(mode[2]);
+    hipStream_t s = resolve_stream(stream);
+    struct Pass { int axis, wa, oa, ma, wx; };
+    Pass passes[3];
+    int np = 0;
+    const bool fuse_xz = w[2] > 1 && w[2] == w[0];
+    const bool fuse_xy = !fuse_xz && w[0] == 1 && w[2] > 1 && w[2] == w[1];
+    if (w[2] > 1 && !fuse_xz && !fuse_xy) passes[np++] = {1, 1, 0, my, w[2]};      // x only (streams over y)
+    if (w[0] > 1) passes[np++] = {0, w[0], off[0], mz, fuse_xz ? w[2] : 1};
+    if (w[1] > 1) passes[np++] = {1, w[1], off[1], my, fuse_xy ? w[2] : 1};
+    if (np == 0) UNSUP("nothing to filter");
+    const size_t bytes = (size_t)(nz * ny * nx) * sizeof(float);
+    void *tmp[2] = {nullptr, nullptr};
+    for (int t = 0; t < np - 1 && t < 2; t++)
+        if ((rc = pool_alloc(&tmp[t], bytes))) { if (tmp[0]) pool_free(tmp[0]); return rc; }
+    const float *src = (const float *)in->data;
+    for (int i = 0; i < np && rc == MI_OK; i++) {
+        float *dst = i == np - 1 ? (float *)out->data : (float *)tmp[i & 1];
+        const Pass &q = passes[i];
+        rc = run_stream_minmax_pass(src, dst, (int)nz, (int)ny, (int)nx, q.axis, q.wa, q.oa, q.ma, q.wx, mx, (float)cval,
+                                    is_max != 0, s);
+        src = dst;
+    }
+    for (int t = 0; t < 2; t++) if (tmp[t]) pool_free(tmp[t]);   // reuse is stream ordered
+    return rc;
+#undef UNSUP
+}

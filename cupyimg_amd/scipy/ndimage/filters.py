@@ -413,6 +413,35 @@ def _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max):
     return output
 
 
+def _try_stream_minmax_f32(input, output, sizes, origins, modes, cval, is_max):
+    """Separable flat min / max on float32 volumes and images: streaming
+    passes (mi_minmax3d_f32) instead of one generic launch per axis."""
+    if S.current_planes() is not None:
+        raise S.Unsupported("min/max filters cannot be restricted to a range of output planes")
+    if input.dtype != np.float32 or output.dtype != np.float32 or input.size == 0:
+        return None
+    if any(int(sz) % 2 == 0 or int(sz) > 9 for sz in sizes) or int(origins[-1]) != 0:
+        return None
+    if input.ndim == 2:
+        as3 = lambda a: a._view([1] + list(a.shape), [a.strides[0] * a.shape[0]] + list(a.strides), a.ptr)   # noqa: E731
+        in3, out3 = as3(input), as3(output)
+        sizes, origins, modes = [1] + list(sizes), [0] + list(origins), ["reflect"] + list(modes)
+    else:
+        in3, out3 = input, output
+    src = core.ascontiguousarray(in3)
+    direct = out3._is_c_contiguous() and not core.shares_memory(out3, src)
+    dst = out3 if direct else core.empty(out3.shape, out3.dtype)
+    a, b = src._desc(), dst._desc()
+    try:
+        S.check(S.lib().mi_minmax3d_f32(ctypes.byref(a), ctypes.byref(b), S.c_ints(sizes), S.c_ints(origins),
+                                        S.c_ints([S.mode_code(m) for m in modes]), float(cval), int(is_max), None))
+    except S.Unsupported:
+        return None
+    if not direct:
+        out3[...] = dst
+    return output
+
+
 def _min_or_max_filter(input, size, ftprnt, structure, output, mode, cval, origin, func):
     """filters.py:1373-1419"""
     input = S.as_device(input)
@@ -436,6 +465,10 @@ def _min_or_max_filter(input, size, ftprnt, structure, output, mode, cval, origi
             return output
         if input.ndim == 3:
             res = _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max)
+            if res is not None:
+                return res
+        if input.ndim in (2, 3):
+            res = _try_stream_minmax_f32(input, output, sizes, origins, modes, cval, is_max)
             if res is not None:
                 return res
         passes = [(lambda s, d, ax=ax, sz=sz, og=og, m=m: _launch_minmax1d(s, d, ax, sz, og, m, cval, is_max))

@@ -198,6 +198,13 @@ int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int size[3],
                    const int origin[3], const int mode[3], int cval, int is_max,
                    mi_stream stream);
 
+/* Same for float32 volumes (flat odd sizes <= 9 per axis, x origin 0): streaming
+ * passes with the comparisons of the generic kernel, x window fused into the z
+ * (or, for one-plane volumes = images, the y) pass.  cval is converted to
+ * float32 first, as SciPy converts it to the input dtype. */
+int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
+                    const int mode[3], double cval, int is_max, mi_stream stream);
+
 /* n-D footprint (+ optional non-flat structure) min/max
  * (filters.py:1398-1419, kernel :1510-1557).  footprint: host uint8
  * prod(fshape); structure: host doubles or NULL. */

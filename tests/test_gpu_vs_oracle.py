@@ -539,3 +539,65 @@ def test_tiled_binary_morphology_matches_generic_kernel_and_oracle(gpu, ndi, sha
     import scipy.ndimage as sndi
     got = ndi.binary_fill_holes(gpu.asarray(u)).get()
     assert np.array_equal(got, sndi.binary_fill_holes(u))
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_tiled_footprint_minmax_matches_generic_kernel_and_oracle(gpu, ndi, case):
+    """minimum / maximum filter and flat grey erosion / dilation with a footprint
+    on float32: the LDS-tiled kernel compares like the generic one (NaNs included)."""
+    import ctypes
+    from cupyimg_amd import _lib
+    lib = _lib.load()
+    lib.mi_debug_set_minmax_tiled.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(70 + case)
+    shape, fshape, origin = [((20, 37, 64), (3, 3, 3), 0), ((9, 50, 264), (5, 3, 5), (1, -1, 0)),
+                             ((17, 40, 256), (2, 4, 6), (0, 1, -1)), ((8, 20, 72), (7, 7, 7), 0),
+                             ((40, 300), (5, 5), 0), ((12, 30, 128), (3, 1, 9), (0, 0, 2))][case]
+    x = rng.standard_normal(shape).astype(np.float32)
+    x[tuple(s // 3 for s in shape)] = np.nan
+    x[tuple(s // 2 for s in shape)] = np.inf
+    fp = rng.random(fshape) > 0.35
+    fp[tuple(s // 2 for s in fshape)] = True
+    for fp_ in (fp, np.ones(fshape, bool)):
+        if fp_.all():
+            # an all-ones footprint is filtered separably (one 1-D pass per axis, like SciPy); the order in
+            # which a NaN meets the comparisons then depends on the pass order, so no NaN in this leg
+            x = np.where(np.isnan(x), np.float32(0.5), x)
+        xd = gpu.asarray(x)
+        for fn, ofn in [(ndi.minimum_filter, orc.minimum_filter), (ndi.maximum_filter, orc.maximum_filter),
+                        (ndi.grey_erosion, orc.grey_erosion), (ndi.grey_dilation, orc.grey_dilation)]:
+            for mode in MODES:
+                try:
+                    lib.mi_debug_set_minmax_tiled(1)
+                    tiled = fn(xd, footprint=fp_, mode=mode, cval=0.3, origin=origin).get()
+                    lib.mi_debug_set_minmax_tiled(0)
+                    generic = fn(xd, footprint=fp_, mode=mode, cval=0.3, origin=origin).get()
+                finally:
+                    lib.mi_debug_set_minmax_tiled(1)
+                ref = ofn(x, footprint=fp_, mode=mode, cval=0.3, origin=origin)
+                assert np.array_equal(generic, ref, equal_nan=True), (fn.__name__, mode)
+                assert np.array_equal(tiled, ref, equal_nan=True), (fn.__name__, mode, fp_.all())
+
+
+@pytest.mark.parametrize("shape", [(20, 37, 64), (33, 21, 264), (9, 40, 512), (70, 300), (12, 5, 8)])
+def test_streaming_minmax_f32_is_exact(gpu, ndi, shape):
+    """Separable flat min / max (minimum/maximum_filter, grey erosion/dilation
+    with `size`) on float32: streaming passes, results equal to the oracle."""
+    rng = np.random.default_rng(80)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xd = gpu.asarray(x)
+    nd = len(shape)
+    cases = [(3, 0), (5, 0), (7, 0), (9, 0), ((3, 5, 7)[:nd], 0), ((1, 9, 3)[3 - nd:], 0), ((5, 5, 3)[:nd], ((1, -2, 0)[:nd]))]
+    for size, origin in cases:
+        if np.max(size) > min(shape) * 2:
+            continue
+        for fn, ofn in [(ndi.minimum_filter, orc.minimum_filter), (ndi.maximum_filter, orc.maximum_filter),
+                        (ndi.grey_erosion, orc.grey_erosion), (ndi.grey_dilation, orc.grey_dilation)]:
+            for mode in MODES:
+                got = fn(xd, size=size, mode=mode, cval=0.3, origin=origin).get()
+                ref = ofn(x, size=size, mode=mode, cval=0.3, origin=origin)
+                assert np.array_equal(got, ref), (fn.__name__, size, origin, mode)
+    # per-axis modes
+    modes = ["nearest", "wrap", "mirror"][:nd]
+    got = ndi.maximum_filter(xd, size=5, mode=modes).get()
+    assert np.array_equal(got, orc.maximum_filter(x, size=5, mode=modes))
