@@ -33,6 +33,18 @@ __device__ __forceinline__ unsigned op2(unsigned a, unsigned b)
     return __builtin_bit_cast(unsigned, r);
 }
 
+// 3-input form: byte values 0..255 in u16 lanes are ordered identically as
+// float16 bit patterns (zero and denormals), so v_pk_maximum3_f16 /
+// v_pk_minimum3_f16 do two byte comparisons per lane pair in one instruction
+template <bool IS_MAX>
+__device__ __forceinline__ unsigned op3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    if constexpr (IS_MAX) asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ unsigned align16(unsigned hi, unsigned lo)   // (lo >> 16) | (hi << 16)
 {
     return __builtin_amdgcn_alignbit(hi, lo, 16);
@@ -86,6 +98,15 @@ __device__ __forceinline__ Win opw(const Win &a, const Win &b)
     return r;
 }
 
+template <bool IS_MAX>
+__device__ __forceinline__ Win op3w(const Win &a, const Win &b, const Win &c)
+{
+    Win r;
+#pragma unroll
+    for (int k = 0; k < 7; k++) { r.e[k] = op3<IS_MAX>(a.e[k], b.e[k], c.e[k]); r.o[k] = op3<IS_MAX>(a.o[k], b.o[k], c.o[k]); }
+    return r;
+}
+
 // sliding min/max of width WX along x, centred: out[x] = op(b[x-r .. x+r]), r = WX/2 <= 4
 template <int WX, bool IS_MAX>
 __device__ __forceinline__ Vec16 xpass_u8(const Win &b)
@@ -95,7 +116,11 @@ __device__ __forceinline__ Vec16 xpass_u8(const Win &b)
     if constexpr (WX == 1) {
         m = b;
     } else if constexpr (WX == 3) {
-        m = opw<IS_MAX>(opw<IS_MAX>(b, shiftw<1>(b)), shiftw<2>(b));
+        m = op3w<IS_MAX>(b, shiftw<1>(b), shiftw<2>(b));
+    } else if constexpr (WX == 5 || WX == 7) {
+        const Win m3 = op3w<IS_MAX>(b, shiftw<1>(b), shiftw<2>(b));            // covers i .. i+2
+        if constexpr (WX == 5) m = opw<IS_MAX>(m3, shiftw<2>(m3));              // i .. i+4
+        else m = op3w<IS_MAX>(m3, shiftw<2>(m3), shiftw<4>(m3));               // i .. i+6
     } else {
         const Win m2 = opw<IS_MAX>(b, shiftw<1>(b));
         const Win m4 = opw<IS_MAX>(m2, shiftw<2>(m2));
@@ -323,9 +348,307 @@ static int launch_u8_wx(int wx, int wa, const uint8_t *in, uint8_t *out, U8Strea
     return MI_ERR_UNSUPPORTED;
 }
 
+
+// ---------------------------------------------------------------------------
+// Single-launch version for cubic sizes 3 / 5 / 7 (grey_erosion(size=7), ...):
+// the 2.5-D producer / consumer structure of sep3d_lean_kernel on bytes.
+//   * 12 producer waves own R rows each of a 1024 x (TY + W - 1) tile and stream
+//     along z: 16 voxels per lane per row, x window in registers (even/odd
+//     split + doubling, neighbours by DPP, tile edges from one extra load per
+//     plane), z window over a register ring of the W - 1 previous x-filtered
+//     rows kept PACKED (4 registers per entry) and unpacked on use;
+//   * the x/z result goes to a double-buffered LDS tile; 4 consumer waves do the
+//     y window over LDS rows and store.
+// 7-input windows along z and y use v_pk_maximum3_f16 / v_pk_minimum3_f16: byte
+// values 0..255 in u16 lanes are ordered identically as float16 bit patterns
+// (zero and denormals), so three of them replace six two-input comparisons.
+// HBM traffic: 2 B/voxel (the two-launch version above moves 4).
+// ---------------------------------------------------------------------------
+struct U8FusedParams {
+    int nx, ny, nz;
+    int mx, my, mz;
+    unsigned cval4;
+    int zc, nzc, nxt, nyt;
+};
+
+constexpr int kU8MaxChunk = 2048;
+
+// reduce NIN values (E or O halves of one dword column) with 3-input steps
+template <bool IS_MAX, int NIN>
+__device__ __forceinline__ unsigned reduce3(const unsigned (&v)[NIN])
+{
+    unsigned a = v[0];
+    static_for<(NIN - 1) / 2>([&](auto KK) {
+        constexpr int k = decltype(KK)::value;
+        a = op3<IS_MAX>(a, v[1 + 2 * k], v[2 + 2 * k]);
+    });
+    if constexpr ((NIN - 1) % 2 == 1) a = op2<IS_MAX>(a, v[NIN - 1]);
+    return a;
+}
+
+template <int W, bool IS_MAX, int NWP, int NWC, int R, bool HAS_CONST>
+__global__ void __launch_bounds__((NWP + NWC) * 64)
+mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8FusedParams p)
+{
+    constexpr int ROWS = NWP * R;
+    constexpr int TY = ROWS - (W - 1);
+    constexpr int G = (TY + NWC - 1) / NWC;
+    constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
+    constexpr int RINGN = W - 1;
+    constexpr int RX = W / 2;
+    static_assert(W == 3 || W == 5 || W == 7, "cubic sizes 3, 5, 7");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4 *lds = reinterpret_cast<u32x4 *>(smem);                        // [2][LROWS][64]
+    int *ztab = reinterpret_cast<int *>(smem + (size_t)2 * LROWS * 1024);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int b = blockIdx.x;
+    const int total = p.nxt * p.nyt * p.nzc;
+    if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
+    const int per_chunk = p.nxt * p.nyt;
+    const int zci = b / per_chunk;
+    const int rem = b - zci * per_chunk;
+    const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
+
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int x0 = xt * 1024, y0 = yt * TY, zs = zci * p.zc;
+    const int ze = min(zs + p.zc, nz);
+    const int ty_act = min(TY, ny - y0);
+    const int rows_needed = ty_act + W - 1;
+    const int nlanes = min(64, (nx - x0) >> 4);
+    const int last = nlanes - 1;
+    const unsigned plane_bytes = (unsigned)ny * (unsigned)nx;
+    const size_t plane_elems = (size_t)ny * (size_t)nx;
+    const int zi0 = zs - RX;
+    const int nsteps = ze - zs + W - 1;
+
+    for (int i = threadIdx.x; i < nsteps; i += (NWP + NWC) * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
+    __syncthreads();
+
+    if (wave < NWP) {
+        // ------------------------------------------------------------ producer
+        int es0, ek0, es1, ek1;
+        edge_u8(0, x0, x0 + 16 * nlanes, nx, p.mx, &es0, &ek0);
+        edge_u8(1, x0, x0 + 16 * nlanes, nx, p.mx, &es1, &ek1);
+        const bool left_side = lane < 32;
+        const int erow = left_side ? lane : lane - 32;       // row this lane fetches the edge dword of
+        const int ekind = left_side ? ek0 : ek1;
+        const int estart = left_side ? es0 : es1;
+        unsigned voff[R];
+        unsigned eoffv = kOOB;
+        bool yconst[R];
+        bool e_is_cval = ekind == EDGE_CONST;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int rr = wave * R + r;
+            const int ys = rr < rows_needed ? bmap<int>(y0 - RX + rr, ny, p.my) : -2;
+            yconst[r] = ys == -1;
+            voff[r] = (ys >= 0 && lane < nlanes) ? (unsigned)(ys * nx + x0 + 16 * lane) : kOOB;
+            if (erow == r) {
+                if (ys >= 0 && ekind != EDGE_CONST) eoffv = (unsigned)(ys * nx + estart);
+                if (ys == -1) e_is_cval = true;
+            }
+        }
+
+        struct Regs { u32x4 v[R]; unsigned e; bool zconst; };
+        Regs S;
+        auto issue = [&](int i) {
+            int zsrc = zi0 + i;
+            if ((unsigned)zsrc >= (unsigned)nz) zsrc = ztab[i];
+            S.zconst = zsrc < 0;
+            zsrc = __builtin_amdgcn_readfirstlane(max(zsrc, 0));
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(in + (size_t)zsrc * plane_elems), 0, (int)plane_bytes, 0x00020000);
+            const bool skip = HAS_CONST && S.zconst;
+#pragma unroll
+            for (int r = 0; r < R; r++) S.v[r] = __builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], 0, 0);
+            S.e = __builtin_amdgcn_raw_buffer_load_b32(rin, skip ? kOOB : eoffv, 0, 0);
+        };
+
+        u32x4 ring[RINGN][R];
+#pragma unroll
+        for (int k = 0; k < RINGN; k++)
+#pragma unroll
+            for (int r = 0; r < R; r++) ring[k][r] = (u32x4){0u, 0u, 0u, 0u};
+
+        issue(0);
+        for (int i0 = 0; i0 < nsteps; i0 += RINGN) {
+            static_for<RINGN>([&](auto JJ) {
+                constexpr int J = decltype(JJ)::value;
+                const int i = i0 + J;
+                if (i < nsteps) {
+                    const bool emit = i >= W - 1;
+                    u32x4 *wbuf = lds + (J & 1) * (LROWS * 64) + (wave * R) * 64 + lane;
+                    // this lane's edge dword, fixed up as the boundary mode wants
+                    unsigned ed = S.e;
+                    if (ekind == EDGE_REV) ed = bswap32(ed);
+                    else if (ekind == EDGE_SPLAT) ed = (left_side ? (ed & 0xFFu) : (ed >> 24)) * 0x01010101u;
+                    if constexpr (HAS_CONST) ed = (e_is_cval || S.zconst) ? p.cval4 : ed;
+                    Vec16 xf[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        u32x4 v = S.v[r];
+                        if constexpr (HAS_CONST)
+                            if (yconst[r] || S.zconst) v = (u32x4){p.cval4, p.cval4, p.cval4, p.cval4};
+                        const unsigned sL = (unsigned)__builtin_amdgcn_readlane((int)ed, r);
+                        const unsigned sR = (unsigned)__builtin_amdgcn_readlane((int)ed, 32 + r);
+                        const unsigned l = (unsigned)__builtin_amdgcn_update_dpp((int)sL, (int)v.w, 0x138, 0xf, 0xf, false);
+                        unsigned rg = (unsigned)__builtin_amdgcn_update_dpp((int)sR, (int)v.x, 0x130, 0xf, 0xf, false);
+                        if (lane == last) rg = sR;
+                        Win w;
+                        split(l, w.e[0], w.o[0]);
+                        split(v.x, w.e[1], w.o[1]);
+                        split(v.y, w.e[2], w.o[2]);
+                        split(v.z, w.e[3], w.o[3]);
+                        split(v.w, w.e[4], w.o[4]);
+                        split(rg, w.e[5], w.o[5]);
+                        w.e[6] = w.e[5]; w.o[6] = w.o[5];
+                        xf[r] = xpass_u8<W, IS_MAX>(w);
+                    }
+                    if (i + 1 < nsteps) issue(i + 1);
+                    if (emit) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            u32x4 u;
+                            unsigned *up = reinterpret_cast<unsigned *>(&u);
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                unsigned ve[W], vo[W];
+                                ve[0] = xf[r].e[k]; vo[0] = xf[r].o[k];
+#pragma unroll
+                                for (int t = 0; t < RINGN; t++) {
+                                    const unsigned *rp = reinterpret_cast<const unsigned *>(&ring[t][r]);
+                                    split(rp[k], ve[1 + t], vo[1 + t]);
+                                }
+                                up[k] = join(reduce3<IS_MAX, W>(ve), reduce3<IS_MAX, W>(vo));
+                            }
+                            if constexpr (HAS_CONST)
+                                if (yconst[r]) u = (u32x4){p.cval4, p.cval4, p.cval4, p.cval4};
+                            wbuf[r * 64] = u;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        u32x4 q;
+                        q.x = join(xf[r].e[0], xf[r].o[0]); q.y = join(xf[r].e[1], xf[r].o[1]);
+                        q.z = join(xf[r].e[2], xf[r].o[2]); q.w = join(xf[r].e[3], xf[r].o[3]);
+                        ring[J % RINGN][r] = q;
+                    }
+                    __syncthreads();
+                }
+            });
+        }
+    } else {
+        // ------------------------------------------------------------ consumer
+        const int cw = wave - NWP;
+        const int j0 = cw * G;
+        unsigned ovoff[G];
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            ovoff[g] = (j0 + g < ty_act && lane < nlanes) ? (unsigned)((y0 + j0 + g) * nx + x0 + 16 * lane) : kOOB;
+        for (int i = 0; i < nsteps; i++) {
+            __syncthreads();
+            if (i < W - 1) continue;
+            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(out + (size_t)(zs + i - (W - 1)) * plane_elems), 0, (int)plane_bytes, 0x00020000);
+            const u32x4 *rbuf = lds + (i & 1) * (LROWS * 64) + j0 * 64 + lane;
+            u32x4 win[G + W - 1];
+#pragma unroll
+            for (int k = 0; k < G + W - 1; k++) win[k] = rbuf[k * 64];
+            u32x4 res[G];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned e[G + W - 1], o[G + W - 1];
+#pragma unroll
+                for (int j = 0; j < G + W - 1; j++) split(reinterpret_cast<const unsigned *>(&win[j])[k], e[j], o[j]);
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    unsigned ve[W], vo[W];
+#pragma unroll
+                    for (int t = 0; t < W; t++) { ve[t] = e[g + t]; vo[t] = o[g + t]; }
+                    reinterpret_cast<unsigned *>(&res[g])[k] = join(reduce3<IS_MAX, W>(ve), reduce3<IS_MAX, W>(vo));
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; g++) __builtin_amdgcn_raw_buffer_store_b128(res[g], rout, ovoff[g], 0, 0);
+        }
+    }
+}
+
+template <int W, bool IS_MAX, int NWP, int NWC, int R>
+static int launch_u8_fused(const uint8_t *in, uint8_t *out, U8FusedParams &p, bool has_const, hipStream_t s)
+{
+    constexpr int ROWS = NWP * R;
+    constexpr int TY = ROWS - (W - 1);
+    constexpr int G = (TY + NWC - 1) / NWC;
+    constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
+    const size_t lds = (size_t)2 * LROWS * 1024 + (size_t)(kU8MaxChunk + 8) * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI_HIP(hipFuncSetAttribute((const void *)mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MI_HIP(hipFuncSetAttribute((const void *)mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    p.nxt = (p.nx + 1023) / 1024;
+    p.nyt = (p.ny + TY - 1) / TY;
+    // z chunks: one workgroup per CU resident; rounds x (chunk + ramp)
+    int cus = 256;
+    {
+        static int cached = 0;
+        if (!cached) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount;
+        }
+        if (cached > 0) cus = cached;
+    }
+    const int64_t tiles = (int64_t)p.nxt * p.nyt;
+    double best = 1e300;
+    int best_nzc = 1;
+    for (int nzc = 1; nzc <= std::min(p.nz, 64); nzc++) {
+        const int chunk = (p.nz + nzc - 1) / nzc;
+        if (chunk > kU8MaxChunk) continue;
+        const int real = (p.nz + chunk - 1) / chunk;
+        const double rounds = (double)((tiles * real + cus - 1) / cus);
+        const double cost = rounds * (chunk + W - 1 + 2.0);
+        if (cost < best) { best = cost; best_nzc = real; }
+    }
+    p.zc = (p.nz + best_nzc - 1) / best_nzc;
+    if (p.zc > kU8MaxChunk) p.zc = kU8MaxChunk;
+    p.nzc = (p.nz + p.zc - 1) / p.zc;
+    const int64_t total = tiles * p.nzc;
+    if (has_const)
+        hipLaunchKernelGGL((mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, true>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+    else
+        hipLaunchKernelGGL((mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, false>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+template <bool IS_MAX>
+static int launch_u8_fused_w(int w, int cfg, const uint8_t *in, uint8_t *out, U8FusedParams &p, bool has_const, hipStream_t s)
+{
+    switch (w) {
+    case 3: return launch_u8_fused<3, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
+    case 5: return launch_u8_fused<5, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
+    default:
+        if (cfg == 2) return launch_u8_fused<7, IS_MAX, 12, 4, 2>(in, out, p, has_const, s);
+        if (cfg == 3) return launch_u8_fused<7, IS_MAX, 8, 4, 3>(in, out, p, has_const, s);
+        if (cfg == 4) return launch_u8_fused<7, IS_MAX, 9, 3, 4>(in, out, p, has_const, s);
+        return launch_u8_fused<7, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
+    }
+}
+
 }  // namespace mi
 
 using namespace mi;
+
+// test / tuning hook (not part of the C-ABI): 0 = always take the two-launch path
+static int g_u8_fused = 1;
+extern "C" int mi_debug_set_u8_fused(int enabled) { g_u8_fused = enabled; return MI_OK; }
 
 extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int size[3],
                               const int origin[3], const int mode[3], int cval, int is_max,
@@ -342,6 +665,7 @@ extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int
     const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
     if (nz < 1 || ny < 1 || nx < 32 || (nx & 15) || (nx & 1023) == 16) UNSUP("x extent must be a multiple of 16, >= 32");
     if (nz * ny * nx >= ((int64_t)1 << 31)) UNSUP("needs a volume < 2 GiB");
+    if (ny * nx >= ((int64_t)1 << 31)) UNSUP("plane too large");
     if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
     for (int a = 0; a < 3; a++) {
         if (size[a] < 1 || !(size[a] & 1) || origin[a] != 0) UNSUP("sizes must be odd with origin 0");
@@ -358,6 +682,18 @@ extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int
     p.cval4 = (unsigned)cval * 0x01010101u;
     const uint8_t *ip = (const uint8_t *)in->data;
     uint8_t *op = (uint8_t *)out->data;
+
+    // cubic 3 / 5 / 7: one fused launch
+    if (g_u8_fused && size[0] == size[1] && size[1] == size[2] && size[0] >= 3 && size[0] <= 7 && nx >= 64) {
+        U8FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.nx = (int)nx; f.ny = (int)ny; f.nz = (int)nz;
+        f.mz = filter_mode(mode[0]); f.my = filter_mode(mode[1]); f.mx = filter_mode(mode[2]);
+        f.cval4 = p.cval4;
+        const bool has_const = f.mz == MI_MODE_CONSTANT || f.my == MI_MODE_CONSTANT || f.mx == MI_MODE_CONSTANT;
+        return is_max ? launch_u8_fused_w<true>(size[0], g_u8_fused, ip, op, f, has_const, s)
+                      : launch_u8_fused_w<false>(size[0], g_u8_fused, ip, op, f, has_const, s);
+    }
 
     // pass A: x fused with z (into tmp if a y pass follows), pass B: y
     const bool need_y = size[1] > 1;

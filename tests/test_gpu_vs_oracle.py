@@ -601,3 +601,33 @@ def test_streaming_minmax_f32_is_exact(gpu, ndi, shape):
     modes = ["nearest", "wrap", "mirror"][:nd]
     got = ndi.maximum_filter(xd, size=5, mode=modes).get()
     assert np.array_equal(got, orc.maximum_filter(x, size=5, mode=modes))
+
+
+@pytest.mark.parametrize("shape", [(20, 37, 64), (9, 50, 1040), (33, 70, 2064), (40, 16, 128), (5, 3, 1024)])
+def test_fused_uint8_minmax_matches_two_launch_path_and_oracle(gpu, ndi, shape):
+    """grey erosion / dilation, min / max filter with cubic size 3 / 5 / 7 on
+    uint8: the single-launch kernel equals the two-launch path and the oracle."""
+    import ctypes
+    from cupyimg_amd import _lib
+    lib = _lib.load()
+    lib.mi_debug_set_u8_fused.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(90)
+    x = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    xd = gpu.asarray(x)
+    for size in (3, 5, 7):
+        for fn, ofn in [(ndi.grey_erosion, orc.grey_erosion), (ndi.grey_dilation, orc.grey_dilation),
+                        (ndi.minimum_filter, orc.minimum_filter), (ndi.maximum_filter, orc.maximum_filter)]:
+            for mode in MODES:
+                try:
+                    lib.mi_debug_set_u8_fused(1)
+                    fused = fn(xd, size=size, mode=mode, cval=37).get()
+                    lib.mi_debug_set_u8_fused(0)
+                    two = fn(xd, size=size, mode=mode, cval=37).get()
+                finally:
+                    lib.mi_debug_set_u8_fused(1)
+                ref = ofn(x, size=size, mode=mode, cval=37)
+                assert np.array_equal(two, ref), (fn.__name__, size, mode)
+                assert np.array_equal(fused, ref), (fn.__name__, size, mode)
+    modes = ["nearest", "constant", "mirror"]
+    got = ndi.grey_erosion(xd, size=7, mode=modes, cval=200).get()
+    assert np.array_equal(got, orc.grey_erosion(x, size=7, mode=modes, cval=200))
