@@ -352,16 +352,18 @@ static int launch_u8_wx(int wx, int wa, const uint8_t *in, uint8_t *out, U8Strea
 // ---------------------------------------------------------------------------
 // Single-launch version for cubic sizes 3 / 5 / 7 (grey_erosion(size=7), ...):
 // the 2.5-D producer / consumer structure of sep3d_lean_kernel on bytes.
-//   * 12 producer waves own R rows each of a 1024 x (TY + W - 1) tile and stream
+//   * producer waves own R rows each of a 1024 x (TY + W - 1) tile and stream
 //     along z: 16 voxels per lane per row, x window in registers (even/odd
-//     split + doubling, neighbours by DPP, tile edges from one extra load per
-//     plane), z window over a register ring of the W - 1 previous x-filtered
-//     rows kept PACKED (4 registers per entry) and unpacked on use;
-//   * the x/z result goes to a double-buffered LDS tile; 4 consumer waves do the
+//     split, neighbours by DPP, tile edges from one extra load per plane), z
+//     window by "tripling" over a PACKED register history (x of the last two
+//     planes, 3-plane results of the last four: 4 registers per entry,
+//     unpacked on use);
+//   * the x/z result goes to a double-buffered LDS tile; consumer waves do the
 //     y window over LDS rows and store.
-// 7-input windows along z and y use v_pk_maximum3_f16 / v_pk_minimum3_f16: byte
-// values 0..255 in u16 lanes are ordered identically as float16 bit patterns
-// (zero and denormals), so three of them replace six two-input comparisons.
+// Windows are built from 3-input steps, v_pk_maximum3_f16 / v_pk_minimum3_f16:
+// byte values 0..255 in u16 lanes are ordered identically as float16 bit
+// patterns (zero and denormals), so one instruction does two comparisons per
+// lane pair; a 7-wide window is two of them (3, then 3 of those at stride 2).
 // HBM traffic: 2 B/voxel (the two-launch version above moves 4).
 // ---------------------------------------------------------------------------
 struct U8FusedParams {
@@ -394,7 +396,6 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
     constexpr int TY = ROWS - (W - 1);
     constexpr int G = (TY + NWC - 1) / NWC;
     constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
-    constexpr int RINGN = W - 1;
     constexpr int RX = W / 2;
     static_assert(W == 3 || W == 5 || W == 7, "cubic sizes 3, 5, 7");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -466,15 +467,21 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
             S.e = __builtin_amdgcn_raw_buffer_load_b32(rin, skip ? kOOB : eoffv, 0, 0);
         };
 
-        u32x4 ring[RINGN][R];
+        // z window by "tripling": t3[t] = op3(x[t], x[t-1], x[t-2]); W = 7: out = op3(t3[t], t3[t-2], t3[t-4]);
+        // W = 5: out = op2(t3[t], t3[t-2]); W = 3: out = t3[t].  History kept packed: x (2 planes), t3 (NT planes).
+        constexpr int NT = W == 7 ? 4 : (W == 5 ? 2 : 0);
+        constexpr int U = NT > 2 ? NT : 2;                    // steps per unrolled round (history slots are compile-time)
+        u32x4 hx[2][R], ht[NT > 0 ? NT : 1][R];
 #pragma unroll
-        for (int k = 0; k < RINGN; k++)
+        for (int r = 0; r < R; r++) {
+            hx[0][r] = hx[1][r] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int r = 0; r < R; r++) ring[k][r] = (u32x4){0u, 0u, 0u, 0u};
+            for (int k = 0; k < (NT > 0 ? NT : 1); k++) ht[k][r] = (u32x4){0u, 0u, 0u, 0u};
+        }
 
         issue(0);
-        for (int i0 = 0; i0 < nsteps; i0 += RINGN) {
-            static_for<RINGN>([&](auto JJ) {
+        for (int i0 = 0; i0 < nsteps; i0 += U) {
+            static_for<U>([&](auto JJ) {
                 constexpr int J = decltype(JJ)::value;
                 const int i = i0 + J;
                 if (i < nsteps) {
@@ -485,7 +492,7 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
                     if (ekind == EDGE_REV) ed = bswap32(ed);
                     else if (ekind == EDGE_SPLAT) ed = (left_side ? (ed & 0xFFu) : (ed >> 24)) * 0x01010101u;
                     if constexpr (HAS_CONST) ed = (e_is_cval || S.zconst) ? p.cval4 : ed;
-                    Vec16 xf[R];
+                    // one row at a time (x window, then its z window) to keep the live set small
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         u32x4 v = S.v[r];
@@ -504,36 +511,42 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
                         split(v.w, w.e[4], w.o[4]);
                         split(rg, w.e[5], w.o[5]);
                         w.e[6] = w.e[5]; w.o[6] = w.o[5];
-                        xf[r] = xpass_u8<W, IS_MAX>(w);
-                    }
-                    if (i + 1 < nsteps) issue(i + 1);
-                    if (emit) {
+                        const Vec16 xf = xpass_u8<W, IS_MAX>(w);
+                        if (r == R - 1 && i + 1 < nsteps) issue(i + 1);       // all rows' registers are consumed
+                        u32x4 u, t3p, xp;
+                        unsigned *up = reinterpret_cast<unsigned *>(&u), *tp = reinterpret_cast<unsigned *>(&t3p),
+                                 *xpp = reinterpret_cast<unsigned *>(&xp);
+                        const unsigned *x1 = reinterpret_cast<const unsigned *>(&hx[(J + 1) % 2][r]);     // plane t - 1
+                        const unsigned *x2 = reinterpret_cast<const unsigned *>(&hx[J % 2][r]);           // plane t - 2
 #pragma unroll
-                        for (int r = 0; r < R; r++) {
-                            u32x4 u;
-                            unsigned *up = reinterpret_cast<unsigned *>(&u);
-#pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                unsigned ve[W], vo[W];
-                                ve[0] = xf[r].e[k]; vo[0] = xf[r].o[k];
-#pragma unroll
-                                for (int t = 0; t < RINGN; t++) {
-                                    const unsigned *rp = reinterpret_cast<const unsigned *>(&ring[t][r]);
-                                    split(rp[k], ve[1 + t], vo[1 + t]);
-                                }
-                                up[k] = join(reduce3<IS_MAX, W>(ve), reduce3<IS_MAX, W>(vo));
+                        for (int k = 0; k < 4; k++) {
+                            unsigned e1, o1, e2, o2;
+                            split(x1[k], e1, o1);
+                            split(x2[k], e2, o2);
+                            const unsigned te = op3<IS_MAX>(xf.e[k], e1, e2), to = op3<IS_MAX>(xf.o[k], o1, o2);
+                            unsigned oe = te, oo = to;
+                            if constexpr (W == 5) {
+                                unsigned ea, oa;
+                                split(reinterpret_cast<const unsigned *>(&ht[J % NT][r])[k], ea, oa);            // t3[t - 2]
+                                oe = op2<IS_MAX>(te, ea); oo = op2<IS_MAX>(to, oa);
+                            } else if constexpr (W == 7) {
+                                unsigned ea, oa, eb, ob;
+                                split(reinterpret_cast<const unsigned *>(&ht[(J + 2) % NT][r])[k], ea, oa);      // t3[t - 2]
+                                split(reinterpret_cast<const unsigned *>(&ht[J % NT][r])[k], eb, ob);            // t3[t - 4]
+                                oe = op3<IS_MAX>(te, ea, eb); oo = op3<IS_MAX>(to, oa, ob);
                             }
+                            up[k] = join(oe, oo);
+                            tp[k] = join(te, to);
+                            xpp[k] = join(xf.e[k], xf.o[k]);
+                        }
+                        if (emit) {
                             if constexpr (HAS_CONST)
                                 if (yconst[r]) u = (u32x4){p.cval4, p.cval4, p.cval4, p.cval4};
                             wbuf[r * 64] = u;
                         }
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        u32x4 q;
-                        q.x = join(xf[r].e[0], xf[r].o[0]); q.y = join(xf[r].e[1], xf[r].o[1]);
-                        q.z = join(xf[r].e[2], xf[r].o[2]); q.w = join(xf[r].e[3], xf[r].o[3]);
-                        ring[J % RINGN][r] = q;
+                        hx[J % 2][r] = xp;
+                        if constexpr (NT > 0) ht[J % NT][r] = t3p;
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     __syncthreads();
                 }
@@ -636,9 +649,8 @@ static int launch_u8_fused_w(int w, int cfg, const uint8_t *in, uint8_t *out, U8
     case 5: return launch_u8_fused<5, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
     default:
         if (cfg == 2) return launch_u8_fused<7, IS_MAX, 12, 4, 2>(in, out, p, has_const, s);
-        if (cfg == 3) return launch_u8_fused<7, IS_MAX, 8, 4, 3>(in, out, p, has_const, s);
-        if (cfg == 4) return launch_u8_fused<7, IS_MAX, 9, 3, 4>(in, out, p, has_const, s);
-        return launch_u8_fused<7, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
+        // 12 waves x 168 VGPRs: three rows per producer wave need ~150 registers (packed z history 72)
+        return launch_u8_fused<7, IS_MAX, 9, 3, 3>(in, out, p, has_const, s);
     }
 }
 
