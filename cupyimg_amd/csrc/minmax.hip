@@ -107,7 +107,7 @@ minmax3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Geo
 }  // namespace mi
 
 namespace mi {
-int minmax3_tiled_f32(const mi_array *in, const mi_array *out, const uint8_t *footprint, const int64_t *fshape,
+int minmax3_tiled(const mi_array *in, const mi_array *out, const uint8_t *footprint, const int64_t *fshape,
                       const int *origins, int mode, double cval, bool is_max, hipStream_t s);   // stencil3d.hip
 }
 
@@ -171,9 +171,15 @@ int mi_minmax_nd(const mi_array *in, const mi_array *out, const uint8_t *footpri
     if (total == 0) return MI_OK;
     hipStream_t s = resolve_stream(stream);
     mode = filter_mode(mode);
-    if (g_minmax_tiled && !structure && in->dtype == MI_F32 && out->dtype == MI_F32) {
+    if (g_minmax_tiled && !structure && in->dtype == out->dtype &&
+        (in->dtype == MI_F32 || in->dtype == MI_U8 || in->dtype == MI_U16 || in->dtype == MI_I16)) {
         // cval is converted to the input dtype first (SciPy: `_cv = (_type)_cval`)
-        rc = minmax3_tiled_f32(in, out, footprint, fshape, origins, mode, (double)(float)cval, is_max != 0, s);
+        double cv = cval;
+        if (in->dtype == MI_F32) cv = (double)(float)cval;
+        else if (in->dtype == MI_U8) cv = (double)(uint8_t)(int64_t)cval;
+        else if (in->dtype == MI_U16) cv = (double)(uint16_t)(int64_t)cval;
+        else cv = (double)(int16_t)(int64_t)cval;
+        rc = minmax3_tiled(in, out, footprint, fshape, origins, mode, cv, is_max != 0, s);
         if (rc != MI_ERR_UNSUPPORTED) return rc;
     }
 

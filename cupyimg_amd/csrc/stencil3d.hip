@@ -51,9 +51,67 @@ typedef const __attribute__((address_space(4))) double *kdoubles;
 // first tap taken as is), so NaNs propagate the same way.
 enum { ST_CORR = 0, ST_MIN = 1, ST_MAX = 2 };
 
-template <int WX, int TY, typename Acc, bool DENSE, int OP = ST_CORR>
+// Element types: float32, or 8 / 16-bit integers (converted to float when a
+// plane is staged -- exact -- and back on store with the C-cast semantics of
+// the generic kernels).  A lane always owns 4 elements: 16 / 8 / 4 bytes.
+template <typename T> struct Raw4 { unsigned d[sizeof(T) == 4 ? 4 : (sizeof(T) == 2 ? 2 : 1)]; };
+
+template <typename T>
+__device__ __forceinline__ Raw4<T> load4(const __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    Raw4<T> q;
+    if constexpr (sizeof(T) == 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+        q.d[0] = v.x; q.d[1] = v.y; q.d[2] = v.z; q.d[3] = v.w;
+    } else if constexpr (sizeof(T) == 2) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+        q.d[0] = v.x; q.d[1] = v.y;
+    } else {
+        q.d[0] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
+    }
+    return q;
+}
+
+template <typename T>
+__device__ __forceinline__ void to_floats(const Raw4<T> &q, float (&f)[4])
+{
+    if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) f[c] = __uint_as_float(q.d[c]);
+    } else if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) f[c] = (float)(T)(q.d[c >> 1] >> (16 * (c & 1)));
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) f[c] = (float)(T)(q.d[0] >> (8 * c));
+    }
+}
+
+template <typename T, typename Acc>
+__device__ __forceinline__ void store4(const __amdgpu_buffer_rsrc_t r, unsigned voff, const Acc (&a)[4])
+{
+    if constexpr (std::is_same<T, float>::value) {
+        u32x4 u;
+        u.x = __float_as_uint((float)a[0]); u.y = __float_as_uint((float)a[1]);
+        u.z = __float_as_uint((float)a[2]); u.w = __float_as_uint((float)a[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, 0);
+    } else if constexpr (sizeof(T) == 2) {
+        unsigned short h[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) h[c] = (unsigned short)cast_from_f64<T>((double)a[c]);
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)},
+                                              r, voff, 0, 0);
+    } else {
+        unsigned w = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) w |= (unsigned)(unsigned char)cast_from_f64<T>((double)a[c]) << (8 * c);
+        __builtin_amdgcn_raw_buffer_store_b32(w, r, voff, 0, 0);
+    }
+}
+
+template <int WX, int TY, typename Acc, bool DENSE, int OP = ST_CORR, typename T = float>
 __global__ void __launch_bounds__(kStNW * 64)
-stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Stencil3Params p)
+stencil3_kernel(const T *__restrict__ in, T *__restrict__ out, const Stencil3Params p)
 {
     constexpr int RX = WX / 2;
     constexpr int RW = TY / kStNW;                       // output rows per wave
@@ -83,7 +141,7 @@ stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Ste
     const int rows_l = TY + wy - 1;
     const int slot_floats = rows_l * kStPitch;
     const int nslots = wz + 1;
-    const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
+    const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * (unsigned)sizeof(T);
     const size_t plane_elems = (size_t)ny * (size_t)nx;
 
     // ---------------------------------------------------------------- staging recipe (loop invariant)
@@ -103,14 +161,13 @@ stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Ste
         const int ysrc = j < rows_l ? bmap_near<int>(y0 - p.oy + j, ny, mode) : -2;
         row_const[k] = ysrc == -1;
         lds_row[k] = j < rows_l ? j * kStPitch : -1;
-        voff_main[k] = (ysrc >= 0 && lane < nlanes) ? (unsigned)(ysrc * nx + x0 + 4 * lane) * 4u : kOOB;
-        voff_halo[k] = (ysrc >= 0 && xsrc >= 0) ? (unsigned)(ysrc * nx + xsrc) * 4u : kOOB;
+        voff_main[k] = (ysrc >= 0 && lane < nlanes) ? (unsigned)(ysrc * nx + x0 + 4 * lane) * (unsigned)sizeof(T) : kOOB;
+        voff_halo[k] = (ysrc >= 0 && xsrc >= 0) ? (unsigned)(ysrc * nx + xsrc) * (unsigned)sizeof(T) : kOOB;
     }
     const bool halo_const = halo_lane && xsrc < 0;       // only in constant mode
-    const unsigned cbits = __float_as_uint(p.cval);
 
-    u32x4 pm[RPW];
-    unsigned ph[RPW];
+    Raw4<T> pm[RPW];
+    T ph[RPW];
     bool pconst = false;
     auto fetch = [&](int q) {                             // input plane q of the chunk (0 = zs - oz)
         int zsrc = zs - p.oz + q;
@@ -121,8 +178,8 @@ stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Ste
             (void *)(in + (size_t)zsrc * plane_elems), 0, (int)plane_bytes, 0x00020000);
 #pragma unroll
         for (int k = 0; k < RPW; k++) {
-            pm[k] = __builtin_amdgcn_raw_buffer_load_b128(rin, pconst ? kOOB : voff_main[k], 0, 0);
-            ph[k] = __builtin_amdgcn_raw_buffer_load_b32(rin, pconst ? kOOB : voff_halo[k], 0, 0);
+            pm[k] = load4<T>(rin, pconst ? kOOB : voff_main[k]);
+            ph[k] = buf_load<T>(rin, pconst ? kOOB : voff_halo[k]);
         }
     };
     auto stage = [&](int q) {                             // registers -> ring slot of plane q
@@ -131,10 +188,11 @@ stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Ste
         for (int k = 0; k < RPW; k++) {
             if (lds_row[k] < 0) continue;
             const bool c = pconst || row_const[k];
-            u32x4 v = pm[k];
-            if (c) v = (u32x4){cbits, cbits, cbits, cbits};
-            if (lane < nlanes) *reinterpret_cast<u32x4 *>(slot + lds_row[k] + 4 + 4 * lane) = v;
-            if (halo_lane) slot[lds_row[k] + halo_pos] = __uint_as_float((c || halo_const) ? cbits : ph[k]);
+            float f[4];
+            to_floats<T>(pm[k], f);
+            if (c) f[0] = f[1] = f[2] = f[3] = p.cval;
+            if (lane < nlanes) *reinterpret_cast<float4 *>(slot + lds_row[k] + 4 + 4 * lane) = make_float4(f[0], f[1], f[2], f[3]);
+            if (halo_lane) slot[lds_row[k] + halo_pos] = (c || halo_const) ? p.cval : (float)ph[k];
         }
     };
 
@@ -151,7 +209,7 @@ stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Ste
     unsigned ovoff[RW];
 #pragma unroll
     for (int rr = 0; rr < RW; rr++)
-        ovoff[rr] = (r0 + rr < ty_act && lane < nlanes) ? (unsigned)((y0 + r0 + rr) * nx + x0 + 4 * lane) * 4u : kOOB;
+        ovoff[rr] = (r0 + rr < ty_act && lane < nlanes) ? (unsigned)((y0 + r0 + rr) * nx + x0 + 4 * lane) * (unsigned)sizeof(T) : kOOB;
 
     for (int s = 0; s < nout; s++) {
         const bool more = s + 1 < nout;
@@ -221,12 +279,7 @@ stencil3_kernel(const float *__restrict__ in, float *__restrict__ out, const Ste
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(out + (size_t)(zs + s) * plane_elems), 0, (int)plane_bytes, 0x00020000);
 #pragma unroll
-        for (int rr = 0; rr < RW; rr++) {
-            u32x4 u;
-            u.x = __float_as_uint((float)acc[rr][0]); u.y = __float_as_uint((float)acc[rr][1]);
-            u.z = __float_as_uint((float)acc[rr][2]); u.w = __float_as_uint((float)acc[rr][3]);
-            __builtin_amdgcn_raw_buffer_store_b128(u, rout, ovoff[rr], 0, 0);
-        }
+        for (int rr = 0; rr < RW; rr++) store4<T, Acc>(rout, ovoff[rr], acc[rr]);
         if (more) stage(s + wz);                          // slot of plane s - 1: nobody reads it in this step
         __syncthreads();
     }
@@ -245,13 +298,13 @@ static int stencil_cus()
     return cus;
 }
 
-template <int WX, int TY, typename Acc, bool DENSE, int OP = ST_CORR>
-static int launch_stencil3(const float *in, float *out, Stencil3Params &p, hipStream_t s)
+template <int WX, int TY, typename Acc, bool DENSE, int OP = ST_CORR, typename T = float>
+static int launch_stencil3(const T *in, T *out, Stencil3Params &p, hipStream_t s)
 {
     const size_t lds = (size_t)(p.wz + 1) * (TY + p.wy - 1) * kStPitch * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
-        MI_HIP(hipFuncSetAttribute((const void *)stencil3_kernel<WX, TY, Acc, DENSE, OP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        MI_HIP(hipFuncSetAttribute((const void *)stencil3_kernel<WX, TY, Acc, DENSE, OP, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(160 * 1024)));
         attr = 160 * 1024;
     }
@@ -274,7 +327,7 @@ static int launch_stencil3(const float *in, float *out, Stencil3Params &p, hipSt
     p.nzc = (p.nz + p.zc - 1) / p.zc;
     const int64_t total = tiles * p.nzc;
     if (total > 0x7fffffff) { set_error("stencil: too many tiles"); return MI_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL((stencil3_kernel<WX, TY, Acc, DENSE, OP>), dim3((unsigned)total), dim3(kStNW * 64), lds, s, in, out, p);
+    hipLaunchKernelGGL((stencil3_kernel<WX, TY, Acc, DENSE, OP, T>), dim3((unsigned)total), dim3(kStNW * 64), lds, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -296,7 +349,9 @@ static int stencil3_setup(const mi_array *in, const mi_array *out, const int64_t
                           double cval, Keep keep, Value value, Stencil3Params *pp, int *wxk, bool *dense)
 {
 #define NOPE(msg) do { set_error("stencil3: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
-    if (in->dtype != MI_F32 || out->dtype != MI_F32) NOPE("float32 only");
+    if (in->dtype != out->dtype) NOPE("input and output dtypes differ");
+    if (in->dtype != MI_F32 && in->dtype != MI_U8 && in->dtype != MI_U16 && in->dtype != MI_I16)
+        NOPE("float32, uint8, uint16 or int16 only");
     if (in->ndim < 2 || in->ndim > 3) NOPE("2-D / 3-D only");
     const int pad = 3 - in->ndim;
     int64_t shape[3] = {1, 1, 1};
@@ -347,33 +402,77 @@ static int stencil3_setup(const mi_array *in, const mi_array *out, const int64_t
     return ntaps > 0 ? MI_OK : MI_ERR_UNSUPPORTED;
 }
 
+// integer element types: one shape per (WX, OP) -- 16-row tiles, mask tests kept, double accumulation
+template <int WX, int OP, typename T>
+static int launch_stencil3_int(const mi_array *in, const mi_array *out, Stencil3Params &p, hipStream_t s)
+{
+    const size_t lds16 = (size_t)(p.wz + 1) * (16 + p.wy - 1) * kStPitch * sizeof(float);
+    if (lds16 > 150 * 1024) { set_error("stencil3: window does not fit LDS for integer volumes"); return MI_ERR_UNSUPPORTED; }
+    if constexpr (OP == ST_CORR)
+        return launch_stencil3<WX, 16, double, false, OP, T>((const T *)in->data, (T *)out->data, p, s);
+    else
+        return launch_stencil3<WX, 16, float, false, OP, T>((const T *)in->data, (T *)out->data, p, s);
+}
+
+template <int OP>
+static int launch_stencil3_any(const mi_array *in, const mi_array *out, Stencil3Params &p, int WXk, bool dense, bool acc_f32,
+                               hipStream_t s)
+{
+#define BY_WX(CALL)                 \
+    switch (WXk) {                  \
+    case 1: return CALL(1);         \
+    case 3: return CALL(3);         \
+    case 5: return CALL(5);         \
+    case 7: return CALL(7);         \
+    default: return CALL(9);        \
+    }
+    if (in->dtype == MI_F32) {
+        const float *ip = (const float *)in->data;
+        float *op = (float *)out->data;
+        if constexpr (OP == ST_CORR) {
+#define CALL(WXV) (acc_f32 ? launch_stencil3_ty<WXV, float>(ip, op, p, dense, s) : launch_stencil3_ty<WXV, double>(ip, op, p, dense, s))
+            BY_WX(CALL)
+#undef CALL
+        } else {
+#define CALL(WXV) launch_stencil3_ty<WXV, float, OP>(ip, op, p, dense, s)
+            BY_WX(CALL)
+#undef CALL
+        }
+    } else if (in->dtype == MI_U8) {
+#define CALL(WXV) launch_stencil3_int<WXV, OP, uint8_t>(in, out, p, s)
+        BY_WX(CALL)
+#undef CALL
+    } else if (in->dtype == MI_U16) {
+#define CALL(WXV) launch_stencil3_int<WXV, OP, uint16_t>(in, out, p, s)
+        BY_WX(CALL)
+#undef CALL
+    } else {
+#define CALL(WXV) launch_stencil3_int<WXV, OP, int16_t>(in, out, p, s)
+        BY_WX(CALL)
+#undef CALL
+    }
+#undef BY_WX
+}
+
 // Dense correlate.  MI_ERR_UNSUPPORTED (and no launch) when the request is
 // outside the envelope -- the caller then uses the generic kernels.
-int stencil3_f32(const mi_array *in, const mi_array *out, const double *weights, const int64_t *wshape,
-                 const int *origins, int mode, double cval, bool acc_f32, hipStream_t s)
+int stencil3_tiled(const mi_array *in, const mi_array *out, const double *weights, const int64_t *wshape,
+                   const int *origins, int mode, double cval, bool acc_f32, hipStream_t s)
 {
     Stencil3Params p;
     int WXk;
     bool dense;
+    if (in->dtype != MI_F32 && acc_f32) { set_error("stencil3: float accumulation only for float32 volumes"); return MI_ERR_UNSUPPORTED; }
     int rc = stencil3_setup(in, out, wshape, origins, mode, cval, [&](int64_t k) { return weights[k] != 0.0; },
                             [&](int64_t k) { return weights[k]; }, &p, &WXk, &dense);
     if (rc != MI_OK) return rc;
-    const float *ip = (const float *)in->data;
-    float *op = (float *)out->data;
-#define GO(WXV) return acc_f32 ? launch_stencil3_ty<WXV, float>(ip, op, p, dense, s) : launch_stencil3_ty<WXV, double>(ip, op, p, dense, s)
-    switch (WXk) {
-    case 1: GO(1);
-    case 3: GO(3);
-    case 5: GO(5);
-    case 7: GO(7);
-    default: GO(9);
-    }
-#undef GO
+    return launch_stencil3_any<ST_CORR>(in, out, p, WXk, dense, acc_f32, s);
 }
 
-// Flat footprint minimum / maximum (grey erosion / dilation without structure values).
-int minmax3_tiled_f32(const mi_array *in, const mi_array *out, const uint8_t *footprint, const int64_t *fshape,
-                      const int *origins, int mode, double cval, bool is_max, hipStream_t s)
+// Flat footprint minimum / maximum (grey erosion / dilation without structure
+// values).  cval must already be converted to the input dtype.
+int minmax3_tiled(const mi_array *in, const mi_array *out, const uint8_t *footprint, const int64_t *fshape,
+                  const int *origins, int mode, double cval, bool is_max, hipStream_t s)
 {
     Stencil3Params p;
     int WXk;
@@ -381,17 +480,8 @@ int minmax3_tiled_f32(const mi_array *in, const mi_array *out, const uint8_t *fo
     int rc = stencil3_setup(in, out, fshape, origins, mode, cval, [&](int64_t k) { return footprint[k] != 0; },
                             [](int64_t) { return 1.0; }, &p, &WXk, &dense);
     if (rc != MI_OK) return rc;
-    const float *ip = (const float *)in->data;
-    float *op = (float *)out->data;
-#define GO(WXV) return is_max ? launch_stencil3_ty<WXV, float, ST_MAX>(ip, op, p, dense, s) : launch_stencil3_ty<WXV, float, ST_MIN>(ip, op, p, dense, s)
-    switch (WXk) {
-    case 1: GO(1);
-    case 3: GO(3);
-    case 5: GO(5);
-    case 7: GO(7);
-    default: GO(9);
-    }
-#undef GO
+    return is_max ? launch_stencil3_any<ST_MAX>(in, out, p, WXk, dense, false, s)
+                  : launch_stencil3_any<ST_MIN>(in, out, p, WXk, dense, false, s);
 }
 
 }  // namespace mi

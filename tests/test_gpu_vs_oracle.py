@@ -630,3 +630,43 @@ def test_fused_uint8_minmax_matches_two_launch_path_and_oracle(gpu, ndi, shape):
     modes = ["nearest", "constant", "mirror"]
     got = ndi.grey_erosion(xd, size=7, mode=modes, cval=200).get()
     assert np.array_equal(got, orc.grey_erosion(x, size=7, mode=modes, cval=200))
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "uint16", "int16"])
+def test_tiled_stencil_and_footprint_minmax_integer_volumes(gpu, ndi, dtype):
+    """8 / 16-bit integer volumes on the LDS-tiled kernels (values converted to
+    float at staging, cast back on store): identical to the generic kernels and
+    the oracle, including the truncating / wrapping output cast of correlate."""
+    import ctypes
+    from cupyimg_amd import _lib
+    lib = _lib.load()
+    lib.mi_debug_set_stencil.argtypes = [ctypes.c_int]
+    lib.mi_debug_set_minmax_tiled.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(100)
+    info = np.iinfo(dtype)
+    for shape, wshape, origin in [((20, 37, 64), (3, 3, 3), 0), ((9, 50, 264), (5, 3, 5), (1, -1, 0)), ((40, 300), (5, 5), 0),
+                                  ((17, 40, 256), (2, 4, 6), (0, 1, -1))]:
+        x = rng.integers(info.min, info.max + 1, size=shape).astype(dtype)
+        xd = gpu.asarray(x)
+        w = rng.standard_normal(wshape) * 0.2
+        fp = rng.random(wshape) > 0.35
+        fp[tuple(s // 2 for s in wshape)] = True
+        for mode in MODES:
+            try:
+                lib.mi_debug_set_stencil(1); lib.mi_debug_set_minmax_tiled(1)
+                t_corr = ndi.correlate(xd, w, mode=mode, cval=7, origin=origin).get()
+                t_conv = ndi.convolve(xd, w, mode=mode, cval=7, origin=origin).get()
+                t_min = ndi.minimum_filter(xd, footprint=fp, mode=mode, cval=7, origin=origin).get()
+                t_max = ndi.grey_dilation(xd, footprint=fp, mode=mode, cval=7, origin=origin).get()
+                lib.mi_debug_set_stencil(0); lib.mi_debug_set_minmax_tiled(0)
+                g_corr = ndi.correlate(xd, w, mode=mode, cval=7, origin=origin).get()
+                g_min = ndi.minimum_filter(xd, footprint=fp, mode=mode, cval=7, origin=origin).get()
+            finally:
+                lib.mi_debug_set_stencil(1); lib.mi_debug_set_minmax_tiled(1)
+            assert t_corr.dtype == x.dtype
+            assert np.array_equal(t_corr, g_corr), (shape, mode)
+            assert np.array_equal(t_min, g_min), (shape, mode)
+            assert np.array_equal(t_corr, orc.correlate(x, w, mode=mode, cval=7, origin=origin)), (shape, mode)
+            assert np.array_equal(t_conv, orc.convolve(x, w, mode=mode, cval=7, origin=origin)), (shape, mode)
+            assert np.array_equal(t_min, orc.minimum_filter(x, footprint=fp, mode=mode, cval=7, origin=origin)), (shape, mode)
+            assert np.array_equal(t_max, orc.grey_dilation(x, footprint=fp, mode=mode, cval=7, origin=origin)), (shape, mode)
