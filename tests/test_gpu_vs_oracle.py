@@ -603,7 +603,7 @@ def test_streaming_minmax_f32_is_exact(gpu, ndi, shape):
     assert np.array_equal(got, orc.maximum_filter(x, size=5, mode=modes))
 
 
-@pytest.mark.parametrize("shape", [(20, 37, 64), (9, 50, 1040), (33, 70, 2064), (40, 16, 128), (5, 3, 1024)])
+@pytest.mark.parametrize("shape", [(20, 37, 64), (9, 50, 1040), (9, 40, 2064), (40, 16, 128), (5, 3, 1024)])
 def test_fused_uint8_minmax_matches_two_launch_path_and_oracle(gpu, ndi, shape):
     """grey erosion / dilation, min / max filter with cubic size 3 / 5 / 7 on
     uint8: the single-launch kernel equals the two-launch path and the oracle."""
