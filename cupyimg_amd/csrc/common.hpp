@@ -169,6 +169,50 @@ __device__ __forceinline__ I bmap_near(I i, I n, int mode)
     }
 }
 
+// Iteration space of the one-axis kernels: the array viewed as (outer, n, inner)
+// around the filtered axis.  f(i, l, base): i = flat index of the output, l =
+// its position on the axis, base = flat index of (outer, 0, inner-offset).
+//   geom 0: flat grid-stride loop (two integer divisions per output);
+//   geom 1: inner > 1 -- threads along `inner`, blockIdx.y walks chunks of the
+//           axis, blockIdx.z the outer index: no division, and a whole block
+//           shares l, so the interior / boundary decision is uniform;
+//   geom 2: inner == 1 (last axis) -- threads along the axis itself, a block
+//           handles a chunk of rows.
+// A thread produces kLineChunk outputs: one block per output element per thread
+// is bound by the workgroup dispatch rate, not by memory.
+constexpr int kLineChunk = 16;
+
+template <typename I, typename F>
+__device__ __forceinline__ void for_each_line_output(int geom, I n, I inner, I total, F f)
+{
+    if (geom == 0) {
+        for (I i = (I)blockIdx.x * (I)blockDim.x + (I)threadIdx.x; i < total; i += (I)gridDim.x * (I)blockDim.x) {
+            const I l = (i / inner) % n;
+            f(i, l, i - l * inner);
+        }
+    } else if (geom == 1) {
+        const I k = (I)blockIdx.x * (I)blockDim.x + (I)threadIdx.x;
+        if (k >= inner) return;
+        const I outer = total / (n * inner);
+        const I l0 = (I)blockIdx.y * (I)kLineChunk;
+        const I l1 = l0 + (I)kLineChunk < n ? l0 + (I)kLineChunk : n;
+        for (I o = blockIdx.z; o < outer; o += gridDim.z) {
+            const I base = o * n * inner + k;
+            for (I l = l0; l < l1; l++) f(base + l * inner, l, base);
+        }
+    } else {
+        const I l = (I)blockIdx.x * (I)blockDim.x + (I)threadIdx.x;
+        if (l >= n) return;
+        const I outer = total / n;
+        const I o0 = ((I)blockIdx.y + (I)gridDim.y * (I)blockIdx.z) * (I)kLineChunk;
+        const I o1 = o0 + (I)kLineChunk < outer ? o0 + (I)kLineChunk : outer;
+        for (I o = o0; o < o1; o++) {
+            const I base = o * n;
+            f(base + l, l, base);
+        }
+    }
+}
+
 // double -> T with the C-cast semantics SciPy/x86 shows: truncate toward zero
 // through a wide signed integer, low bits kept (so negative -> unsigned wraps).
 template <typename T>
@@ -239,6 +283,31 @@ __device__ __forceinline__ double load_as_f64(const void *p, int64_t i, int dt)
     case MI_F32:  return (double)((const float *)p)[i];
     default:      return ((const double *)p)[i];
     }
+}
+
+// launch geometry for for_each_line_output(): returns geom and fills grid / block
+static inline int line_grid(int64_t total, int64_t n, int64_t inner, dim3 *grid, dim3 *block)
+{
+    const int64_t outer = (n * inner) ? total / (n * inner) : 0;
+    if (inner >= 64) {
+        const int bx = inner >= 256 ? 256 : (inner >= 128 ? 128 : 64);
+        const int64_t gy = (n + kLineChunk - 1) / kLineChunk;
+        if (gy > 65535) return 0;
+        *block = dim3(bx);
+        *grid = dim3((unsigned)((inner + bx - 1) / bx), (unsigned)gy, (unsigned)(outer < 65535 ? outer : 65535));
+        return 1;
+    }
+    if (inner == 1 && n >= 64) {
+        const int bx = n >= 256 ? 256 : (n >= 128 ? 128 : 64);
+        const int64_t groups = (outer + kLineChunk - 1) / kLineChunk;
+        const int64_t gy = groups < 65535 ? groups : 65535;
+        const int64_t gz = (groups + gy - 1) / gy;
+        if (gz > 65535) return 0;
+        *block = dim3(bx);
+        *grid = dim3((unsigned)((n + bx - 1) / bx), (unsigned)gy, (unsigned)gz);
+        return 2;
+    }
+    return 0;
 }
 
 // launch geometry for 1-thread-per-element kernels: cap the grid and stride

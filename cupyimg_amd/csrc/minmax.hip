@@ -17,20 +17,38 @@ namespace mi {
 template <typename T, typename I>
 __global__ void __launch_bounds__(256)
 minmax1d_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, I n, I inner, I total,
-                int size, int off, int mode, double cval, int is_max)
+                int size, int off, int mode, double cval, int is_max, int geom)
 {
-    for (I i = (I)blockIdx.x * (I)blockDim.x + (I)threadIdx.x; i < total;
-         i += (I)gridDim.x * (I)blockDim.x) {
-        const I l = (i / inner) % n;
-        const I base = i - l * inner;
+    for_each_line_output<I>(geom, n, inner, total, [&](I i, I l, I base) {
+        const I first = l - (I)off;
+        const bool inside = first >= 0 && first + (I)size <= n;      // whole window inside: no boundary map
         double best = 0.0;
-        for (int k = 0; k < size; k++) {
-            const I j = bmap<I>(l - (I)off + (I)k, n, mode);
-            const double v = j < 0 ? cval : (double)in[base + j * inner];
-            if (k == 0 || (is_max ? v > best : v < best)) best = v;
+        if (inside) {
+            const T *__restrict__ pf = in + base + first * inner;
+            int k = 0;
+            for (; k + 4 <= size; k += 4) {          // loads of a group first, then the comparisons in tap order
+                T x[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) x[u] = pf[(I)(k + u) * inner];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double v = (double)x[u];
+                    if (k + u == 0 || (is_max ? v > best : v < best)) best = v;
+                }
+            }
+            for (; k < size; k++) {
+                const double v = (double)pf[(I)k * inner];
+                if (k == 0 || (is_max ? v > best : v < best)) best = v;
+            }
+        } else {
+            for (int k = 0; k < size; k++) {
+                const I j = bmap<I>(first + (I)k, n, mode);
+                const double v = j < 0 ? cval : (double)in[base + j * inner];
+                if (k == 0 || (is_max ? v > best : v < best)) best = v;
+            }
         }
         store_as(out, (int64_t)i, out_dt, best);
-    }
+    });
 }
 
 // value + structure in the arithmetic of T (what `_tmp += (_type)ss` does)
@@ -139,17 +157,18 @@ int mi_minmax1d(const mi_array *in, const mi_array *out, int axis, int size, int
     hipStream_t s = resolve_stream(stream);
     mode = filter_mode(mode);
     const int off = size / 2 + origin;
-    dim3 grid;
-    grid_for(total, 256, &grid);
+    dim3 grid, block(256);
+    const int geom = line_grid(total, n, inner, &grid, &block);
+    if (geom == 0) grid_for(total, 256, &grid);
     const bool big = total >= ((int64_t)1 << 31) - 256 * 8192;
     return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
         const T *ip = (const T *)in->data;
         if (big)
-            hipLaunchKernelGGL((minmax1d_kernel<T, int64_t>), grid, dim3(256), 0, s, ip, out->data, out->dtype,
-                               n, inner, total, size, off, mode, cval, is_max);
+            hipLaunchKernelGGL((minmax1d_kernel<T, int64_t>), grid, block, 0, s, ip, out->data, out->dtype,
+                               n, inner, total, size, off, mode, cval, is_max, geom);
         else
-            hipLaunchKernelGGL((minmax1d_kernel<T, int32_t>), grid, dim3(256), 0, s, ip, out->data, out->dtype,
-                               (int32_t)n, (int32_t)inner, (int32_t)total, size, off, mode, cval, is_max);
+            hipLaunchKernelGGL((minmax1d_kernel<T, int32_t>), grid, block, 0, s, ip, out->data, out->dtype,
+                               (int32_t)n, (int32_t)inner, (int32_t)total, size, off, mode, cval, is_max, geom);
         MI_HIP(hipGetLastError());
         return MI_OK;
     });
