@@ -167,11 +167,16 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_ms(ev1)
 
+    slab_ok = None
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64)
+        # outside the timed region: every rank filters the whole volume on its own GPU and checks that its
+        # slab of the distributed result is bit-identical to it
+        full = ndi.uniform_filter(ca.asarray(x_host), size=SIZE)
+        differ = ca.arrays_differ(sf.local_out, full[plan.z0:plan.z1])
+        t = torch.tensor([elapsed, dev_ms, float(differ)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+        elapsed, dev_ms, slab_ok = float(t[0]), float(t[1]), t[2].item() == 0.0
 
     voxels = N_SIDE ** 3
     ms_per_step = elapsed / args.steps * 1e3
@@ -218,6 +223,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if slab_ok is not None:
+            line["slabs_bit_identical_to_single_gpu"] = slab_ok
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

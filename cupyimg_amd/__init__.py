@@ -6,7 +6,7 @@ C-ABI in include/mi355img.h (libmi355img.so).  No CuPy, no PyTorch, no CPU
 fallback: if the HIP library cannot be loaded, using the package fails.
 """
 from .core import (  # noqa: F401
-    Event, Stream, array, asarray, ascontiguousarray, asnumpy, device_count, device_name, empty,
+    Event, Stream, array, arrays_differ, asarray, ascontiguousarray, asnumpy, device_count, device_name, empty,
     empty_like, free_all_blocks, full, get_device, is_available, ndarray, ones, pool_stats,
     set_device, shares_memory, synchronize, zeros, zeros_like,
 )

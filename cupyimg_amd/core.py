@@ -463,6 +463,18 @@ def free_all_blocks():
     _lib.check(_lib.load().mi_pool_trim())
 
 
+def arrays_differ(a, b):
+    """True when two device arrays of equal dtype / shape differ anywhere
+    (device-side comparison, one int32 read back)."""
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError("arrays_differ needs equal shapes and dtypes")
+    a, b = ascontiguousarray(a), ascontiguousarray(b)
+    flag = zeros((1,), np.int32)
+    da, db = a._desc(), b._desc()
+    _lib.check(_lib.load().mi_any_diff(ctypes.byref(da), ctypes.byref(db), ctypes.c_void_p(flag.ptr), None))
+    return bool(flag.get()[0])
+
+
 class Stream:
     """A hipStream besides the library's default stream (used for the halo
     exchange so that it overlaps the interior filtering)."""

@@ -162,3 +162,12 @@ def test_overlapped_step_falls_back_for_long_kernels(gpu, ndi, self_comm):
     assert not sf._overlap_ok
     ref = orc.uniform_filter(x, size, mode=["wrap", "nearest", "nearest"])
     assert maxnorm_rel(got, ref) <= 1e-6
+
+
+def test_arrays_differ(gpu):
+    a = gpu.asarray(np.arange(24, dtype=np.float32).reshape(2, 3, 4))
+    b = a.copy()
+    assert not gpu.arrays_differ(a, b)
+    b[1, 2, 3:4] = gpu.asarray(np.array([-1.0], np.float32))
+    assert gpu.arrays_differ(a, b)
+    assert not gpu.arrays_differ(a[0:1], b[0:1])
