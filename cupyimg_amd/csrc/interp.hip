@@ -286,7 +286,7 @@ int mi_affine_transform(const mi_array *in, const mi_array *out, const double *m
     const int64_t nout = numel(out);
     if (nout == 0) return MI_OK;
     hipStream_t s = resolve_stream(stream);
-    if (!g_interp_generic && in->ndim == 3) {
+    if (!g_interp_generic && (in->ndim == 3 || in->ndim == 2)) {
         rc = affine_transform_fast(in, out, matrix, order, mode, cval, s);
         if (rc != MI_ERR_UNSUPPORTED) return rc;
     }

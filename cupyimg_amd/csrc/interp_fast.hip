@@ -24,6 +24,7 @@ struct FastInterpParams {
     int oz, oy, ox;          // output
     int order, mode;
     float cval;
+    int two_d;               // image (ny, nx) handled as a one-plane volume: the z coordinate is 0
     double m[12];            // affine 3 x 4 (row major)
 };
 
@@ -213,7 +214,8 @@ map_coords3d_fast(const float *__restrict__ in, const CT *__restrict__ coords, f
         const int y = (blockIdx.y * kNV + k) * 4 + threadIdx.y;
         ok[k] = y < p.oy;
         o[k] = ((size_t)z * p.oy + (ok[k] ? y : 0)) * p.ox + x;
-        c[k][0] = coords[o[k]]; c[k][1] = coords[nout + o[k]]; c[k][2] = coords[2 * nout + o[k]];
+        if (p.two_d) { c[k][0] = (CT)0; c[k][1] = coords[o[k]]; c[k][2] = coords[nout + o[k]]; }
+        else { c[k][0] = coords[o[k]]; c[k][1] = coords[nout + o[k]]; c[k][2] = coords[2 * nout + o[k]]; }
     }
     Taps t[kNV];
 #pragma unroll
@@ -254,19 +256,22 @@ affine3d_fast(const float *__restrict__ in, float *__restrict__ out, const FastI
 
 static bool fast_ok(const mi_array *in, const mi_array *out, int order)
 {
-    if (in->ndim != 3 || out->ndim != 3 || in->dtype != MI_F32 || out->dtype != MI_F32) return false;
+    if (in->ndim != out->ndim || (in->ndim != 3 && in->ndim != 2) || in->dtype != MI_F32 || out->dtype != MI_F32) return false;
     if (order < 0 || order > 1) return false;
     if (numel(in) >= ((int64_t)1 << 29) || numel(out) >= ((int64_t)1 << 31)) return false;   // 32-bit byte offsets
-    if (in->shape[2] < 2) return false;
-    if (out->shape[0] > 65535 || (out->shape[1] + 3) / 4 > 65535) return false;
+    const int nd = in->ndim;
+    if (in->shape[nd - 1] < 2) return false;
+    if ((nd == 3 && out->shape[0] > 65535) || (out->shape[nd - 2] + 3) / 4 > 65535) return false;
     if ((uintptr_t)out->data & 15) return false;
     return true;
 }
 
 static void fill_params(FastInterpParams *p, const mi_array *in, const mi_array *out, int order, int mode, double cval)
 {
-    p->nz = (int)in->shape[0]; p->ny = (int)in->shape[1]; p->nx = (int)in->shape[2];
-    p->oz = (int)out->shape[0]; p->oy = (int)out->shape[1]; p->ox = (int)out->shape[2];
+    const int pad = 3 - in->ndim;
+    p->two_d = pad;
+    p->nz = pad ? 1 : (int)in->shape[0]; p->ny = (int)in->shape[1 - pad]; p->nx = (int)in->shape[2 - pad];
+    p->oz = pad ? 1 : (int)out->shape[0]; p->oy = (int)out->shape[1 - pad]; p->ox = (int)out->shape[2 - pad];
     p->order = order; p->mode = mode; p->cval = (float)cval;
 }
 
@@ -299,7 +304,17 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
     if (!fast_ok(in, out, order)) return MI_ERR_UNSUPPORTED;
     FastInterpParams p;
     fill_params(&p, in, out, order, mode, cval);
-    for (int i = 0; i < 12; i++) p.m[i] = matrix[i];
+    if (p.two_d) {
+        // rows of a 2 x 3 matrix embedded in the 3 x 4 one; the z coordinate is exactly 0
+        for (int i = 0; i < 12; i++) p.m[i] = 0.0;
+        for (int r = 0; r < 2; r++) {
+            p.m[4 * (r + 1) + 1] = matrix[3 * r + 0];
+            p.m[4 * (r + 1) + 2] = matrix[3 * r + 1];
+            p.m[4 * (r + 1) + 3] = matrix[3 * r + 2];
+        }
+    } else {
+        for (int i = 0; i < 12; i++) p.m[i] = matrix[i];
+    }
     const dim3 block(64, 4, 1);
     const dim3 grid((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 4 * kNV - 1) / (4 * kNV)), (unsigned)p.oz);
     if (mode == MI_MODE_CONSTANT && order == 1)

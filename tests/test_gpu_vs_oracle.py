@@ -670,3 +670,30 @@ def test_tiled_stencil_and_footprint_minmax_integer_volumes(gpu, ndi, dtype):
             assert np.array_equal(t_conv, orc.convolve(x, w, mode=mode, cval=7, origin=origin)), (shape, mode)
             assert np.array_equal(t_min, orc.minimum_filter(x, footprint=fp, mode=mode, cval=7, origin=origin)), (shape, mode)
             assert np.array_equal(t_max, orc.grey_dilation(x, footprint=fp, mode=mode, cval=7, origin=origin)), (shape, mode)
+
+
+def test_affine_and_map_2d_images_take_the_fast_kernels(gpu, ndi):
+    """float32 images are one-plane volumes for the order 0 / 1 gather kernels
+    (z coordinate exactly 0); tolerance as for 3-D volumes: 2e-6 * max|ref|."""
+    rng = np.random.default_rng(16)
+    x = rng.standard_normal((150, 203)).astype(np.float32)
+    ang = np.deg2rad(11.0)
+    M = np.array([[1.03 * np.cos(ang), -np.sin(ang)], [np.sin(ang), 0.97 * np.cos(ang)]])
+    off = np.array([3.5, -7.25])
+    xd = gpu.asarray(x)
+    for mode in ["constant", "grid-constant", "nearest", "mirror", "reflect", "wrap", "grid-wrap"]:
+        for order in [0, 1]:
+            ref = orc.affine_transform(x, M, off, order=order, mode=mode, cval=0.25)
+            got = ndi.affine_transform(xd, M, off, order=order, mode=mode, cval=0.25).get()
+            assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (mode, order)
+            ref = orc.affine_transform(x, M, off, output_shape=(64, 300), order=order, mode=mode, cval=0.25)
+            got = ndi.affine_transform(xd, M, off, output_shape=(64, 300), order=order, mode=mode, cval=0.25).get()
+            assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (mode, order)
+    idx = np.indices(x.shape).reshape(2, -1).astype(np.float64)
+    for cdt in (np.float32, np.float64):
+        coords = (M @ idx + off[:, None]).reshape((2,) + x.shape).astype(cdt)
+        for mode in ["constant", "reflect", "wrap"]:
+            for order in [0, 1]:
+                ref = orc.map_coordinates(x, coords, order=order, mode=mode, cval=-1.0)
+                got = ndi.map_coordinates(xd, gpu.asarray(coords), order=order, mode=mode, cval=-1.0).get()
+                assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (cdt, mode, order)
