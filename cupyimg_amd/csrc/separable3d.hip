@@ -347,6 +347,10 @@ __device__ __forceinline__ F4 xpass_packed(const F4 v, const float (&sL)[NE], co
     for (int m = 0; m < NP; m++) A[m] = (f32x2){e[2 * m], e[2 * m + 1]};
     A[RXE / 2] = v.lo;
     A[RXE / 2 + 1] = v.hi;
+    if constexpr (WX >= 9) {
+        // 9 taps: the dot form needs no shifted copy of the window (10 registers that the 8-plane ring cannot spare)
+        return xdot<WX, NP, RXE - RX>(A, wx);
+    }
 #pragma unroll
     for (int m = 0; m < NP - 1; m++) S[m] = (f32x2){A[m].y, A[m + 1].x};
     F4 o;
@@ -497,6 +501,36 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
                     for (int k = 0; k < NE; k++) {
                         eg[k] = pick<NE>(s.t, eidx[k]);
                         if constexpr (HAS_CONST) eg[k] = (e_is_cval || s.zconst) ? p.cval : eg[k];
+                    }
+                    if constexpr (W >= 9) {
+                        // 9 taps: one row at a time (x pass, then its z pass) keeps a single x-filtered row live
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            F4 v = s.v[r];
+                            if constexpr (HAS_CONST)
+                                if (yconst[r] || s.zconst) v = f4_splat(p.cval);
+                            float sL[NE], sR[NE];
+#pragma unroll
+                            for (int k = 0; k < NE; k++) {
+                                sL[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), r));
+                                sR[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), 32 + r));
+                            }
+                            const F4 xr = xpass_packed<W, NE>(v, sL, sR, lane, last, p.wx);
+                            if (r == R - 1 && i + DEPTH < nsteps) issue(i + DEPTH, s);
+                            if (emit) {
+                                F4 a = f4_scale(p.wz[0], ring[J % RINGN][r]);
+#pragma unroll
+                                for (int k = 1; k < RINGN; k++) a = f4_fma(p.wz[k], ring[(J + k) % RINGN][r], a);
+                                a = f4_fma(p.wz[W - 1], xr, a);
+                                if constexpr (HAS_CONST)
+                                    if (yconst[r]) a = f4_splat(p.cval);
+                                wbuf[r * 64] = f4_to_float4(a);
+                            }
+                            ring[J % RINGN][r] = xr;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        __syncthreads();
+                        return;
                     }
                     F4 xf[R];
 #pragma unroll

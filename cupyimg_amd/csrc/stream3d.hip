@@ -211,7 +211,9 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
             constexpr int J = decltype(JJ)::value;
             const int i = i0 + J;
             if (i < nsteps) {
-                if constexpr (OP == SP_CORR) {
+                // few weights (no fused x pass, <= 17 taps) stay in SGPRs for the whole loop; more are re-loaded
+                // per step (see launder())
+                if constexpr (OP == SP_CORR && (WX > 1 || WA > 17)) {
                     launder(wav);
                     if constexpr (WX > 1) { launder(xt0); launder(xt1); }
                 }
