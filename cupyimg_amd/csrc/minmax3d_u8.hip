@@ -388,7 +388,33 @@ __device__ __forceinline__ unsigned reduce3(const unsigned (&v)[NIN])
     return a;
 }
 
-template <int W, bool IS_MAX, int NWP, int NWC, int R, bool HAS_CONST>
+// ND = dwords (4 voxels each) per lane: 4 -> 1024-voxel tiles, 2 -> 512-voxel tiles for narrower volumes
+template <int ND> struct LaneVec;
+template <> struct LaneVec<4> { typedef u32x4 type; };
+template <> struct LaneVec<2> { typedef u32x2 type; };
+
+template <int ND>
+__device__ __forceinline__ typename LaneVec<ND>::type lane_splat(unsigned x)
+{
+    typename LaneVec<ND>::type v;
+#pragma unroll
+    for (int k = 0; k < ND; k++) v[k] = x;
+    return v;
+}
+template <int ND>
+__device__ __forceinline__ typename LaneVec<ND>::type lane_load(const __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    if constexpr (ND == 4) return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    else return __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+}
+template <int ND>
+__device__ __forceinline__ void lane_store(typename LaneVec<ND>::type v, const __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    if constexpr (ND == 4) __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
+}
+
+template <int W, bool IS_MAX, int NWP, int NWC, int R, bool HAS_CONST, int ND>
 __global__ void __launch_bounds__((NWP + NWC) * 64)
 mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8FusedParams p)
 {
@@ -397,10 +423,12 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
     constexpr int G = (TY + NWC - 1) / NWC;
     constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
     constexpr int RX = W / 2;
+    constexpr int LB = 4 * ND;                                            // bytes (voxels) per lane
+    typedef typename LaneVec<ND>::type LV;
     static_assert(W == 3 || W == 5 || W == 7, "cubic sizes 3, 5, 7");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32x4 *lds = reinterpret_cast<u32x4 *>(smem);                        // [2][LROWS][64]
-    int *ztab = reinterpret_cast<int *>(smem + (size_t)2 * LROWS * 1024);
+    LV *lds = reinterpret_cast<LV *>(smem);                              // [2][LROWS][64]
+    int *ztab = reinterpret_cast<int *>(smem + (size_t)2 * LROWS * 64 * LB);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -413,11 +441,11 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
     const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
 
     const int nx = p.nx, ny = p.ny, nz = p.nz;
-    const int x0 = xt * 1024, y0 = yt * TY, zs = zci * p.zc;
+    const int x0 = xt * (64 * LB), y0 = yt * TY, zs = zci * p.zc;
     const int ze = min(zs + p.zc, nz);
     const int ty_act = min(TY, ny - y0);
     const int rows_needed = ty_act + W - 1;
-    const int nlanes = min(64, (nx - x0) >> 4);
+    const int nlanes = min(64, (nx - x0) / LB);
     const int last = nlanes - 1;
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx;
     const size_t plane_elems = (size_t)ny * (size_t)nx;
@@ -430,8 +458,8 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
     if (wave < NWP) {
         // ------------------------------------------------------------ producer
         int es0, ek0, es1, ek1;
-        edge_u8(0, x0, x0 + 16 * nlanes, nx, p.mx, &es0, &ek0);
-        edge_u8(1, x0, x0 + 16 * nlanes, nx, p.mx, &es1, &ek1);
+        edge_u8(0, x0, x0 + LB * nlanes, nx, p.mx, &es0, &ek0);
+        edge_u8(1, x0, x0 + LB * nlanes, nx, p.mx, &es1, &ek1);
         const bool left_side = lane < 32;
         const int erow = left_side ? lane : lane - 32;       // row this lane fetches the edge dword of
         const int ekind = left_side ? ek0 : ek1;
@@ -445,14 +473,14 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
             const int rr = wave * R + r;
             const int ys = rr < rows_needed ? bmap<int>(y0 - RX + rr, ny, p.my) : -2;
             yconst[r] = ys == -1;
-            voff[r] = (ys >= 0 && lane < nlanes) ? (unsigned)(ys * nx + x0 + 16 * lane) : kOOB;
+            voff[r] = (ys >= 0 && lane < nlanes) ? (unsigned)(ys * nx + x0 + LB * lane) : kOOB;
             if (erow == r) {
                 if (ys >= 0 && ekind != EDGE_CONST) eoffv = (unsigned)(ys * nx + estart);
                 if (ys == -1) e_is_cval = true;
             }
         }
 
-        struct Regs { u32x4 v[R]; unsigned e; bool zconst; };
+        struct Regs { LV v[R]; unsigned e; bool zconst; };
         Regs S;
         auto issue = [&](int i) {
             int zsrc = zi0 + i;
@@ -463,7 +491,7 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
                 (void *)(in + (size_t)zsrc * plane_elems), 0, (int)plane_bytes, 0x00020000);
             const bool skip = HAS_CONST && S.zconst;
 #pragma unroll
-            for (int r = 0; r < R; r++) S.v[r] = __builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], 0, 0);
+            for (int r = 0; r < R; r++) S.v[r] = lane_load<ND>(rin, skip ? kOOB : voff[r]);
             S.e = __builtin_amdgcn_raw_buffer_load_b32(rin, skip ? kOOB : eoffv, 0, 0);
         };
 
@@ -471,12 +499,12 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
         // W = 5: out = op2(t3[t], t3[t-2]); W = 3: out = t3[t].  History kept packed: x (2 planes), t3 (NT planes).
         constexpr int NT = W == 7 ? 4 : (W == 5 ? 2 : 0);
         constexpr int U = NT > 2 ? NT : 2;                    // steps per unrolled round (history slots are compile-time)
-        u32x4 hx[2][R], ht[NT > 0 ? NT : 1][R];
+        LV hx[2][R], ht[NT > 0 ? NT : 1][R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            hx[0][r] = hx[1][r] = (u32x4){0u, 0u, 0u, 0u};
+            hx[0][r] = hx[1][r] = lane_splat<ND>(0u);
 #pragma unroll
-            for (int k = 0; k < (NT > 0 ? NT : 1); k++) ht[k][r] = (u32x4){0u, 0u, 0u, 0u};
+            for (int k = 0; k < (NT > 0 ? NT : 1); k++) ht[k][r] = lane_splat<ND>(0u);
         }
 
         issue(0);
@@ -486,7 +514,7 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
                 const int i = i0 + J;
                 if (i < nsteps) {
                     const bool emit = i >= W - 1;
-                    u32x4 *wbuf = lds + (J & 1) * (LROWS * 64) + (wave * R) * 64 + lane;
+                    LV *wbuf = lds + (J & 1) * (LROWS * 64) + (wave * R) * 64 + lane;
                     // this lane's edge dword, fixed up as the boundary mode wants
                     unsigned ed = S.e;
                     if (ekind == EDGE_REV) ed = bswap32(ed);
@@ -495,31 +523,30 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
                     // one row at a time (x window, then its z window) to keep the live set small
 #pragma unroll
                     for (int r = 0; r < R; r++) {
-                        u32x4 v = S.v[r];
+                        LV v = S.v[r];
                         if constexpr (HAS_CONST)
-                            if (yconst[r] || S.zconst) v = (u32x4){p.cval4, p.cval4, p.cval4, p.cval4};
+                            if (yconst[r] || S.zconst) v = lane_splat<ND>(p.cval4);
                         const unsigned sL = (unsigned)__builtin_amdgcn_readlane((int)ed, r);
                         const unsigned sR = (unsigned)__builtin_amdgcn_readlane((int)ed, 32 + r);
-                        const unsigned l = (unsigned)__builtin_amdgcn_update_dpp((int)sL, (int)v.w, 0x138, 0xf, 0xf, false);
-                        unsigned rg = (unsigned)__builtin_amdgcn_update_dpp((int)sR, (int)v.x, 0x130, 0xf, 0xf, false);
+                        const unsigned l = (unsigned)__builtin_amdgcn_update_dpp((int)sL, (int)v[ND - 1], 0x138, 0xf, 0xf, false);
+                        unsigned rg = (unsigned)__builtin_amdgcn_update_dpp((int)sR, (int)v[0], 0x130, 0xf, 0xf, false);
                         if (lane == last) rg = sR;
                         Win w;
                         split(l, w.e[0], w.o[0]);
-                        split(v.x, w.e[1], w.o[1]);
-                        split(v.y, w.e[2], w.o[2]);
-                        split(v.z, w.e[3], w.o[3]);
-                        split(v.w, w.e[4], w.o[4]);
-                        split(rg, w.e[5], w.o[5]);
-                        w.e[6] = w.e[5]; w.o[6] = w.o[5];
+#pragma unroll
+                        for (int k = 0; k < ND; k++) split(v[k], w.e[1 + k], w.o[1 + k]);
+                        split(rg, w.e[ND + 1], w.o[ND + 1]);
+#pragma unroll
+                        for (int k = ND + 2; k < 7; k++) { w.e[k] = w.e[ND + 1]; w.o[k] = w.o[ND + 1]; }   // never reaches a used voxel
                         const Vec16 xf = xpass_u8<W, IS_MAX>(w);
                         if (r == R - 1 && i + 1 < nsteps) issue(i + 1);       // all rows' registers are consumed
-                        u32x4 u, t3p, xp;
+                        LV u, t3p, xp;
                         unsigned *up = reinterpret_cast<unsigned *>(&u), *tp = reinterpret_cast<unsigned *>(&t3p),
                                  *xpp = reinterpret_cast<unsigned *>(&xp);
                         const unsigned *x1 = reinterpret_cast<const unsigned *>(&hx[(J + 1) % 2][r]);     // plane t - 1
                         const unsigned *x2 = reinterpret_cast<const unsigned *>(&hx[J % 2][r]);           // plane t - 2
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < ND; k++) {
                             unsigned e1, o1, e2, o2;
                             split(x1[k], e1, o1);
                             split(x2[k], e2, o2);
@@ -541,7 +568,7 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
                         }
                         if (emit) {
                             if constexpr (HAS_CONST)
-                                if (yconst[r]) u = (u32x4){p.cval4, p.cval4, p.cval4, p.cval4};
+                                if (yconst[r]) u = lane_splat<ND>(p.cval4);
                             wbuf[r * 64] = u;
                         }
                         hx[J % 2][r] = xp;
@@ -559,19 +586,19 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
         unsigned ovoff[G];
 #pragma unroll
         for (int g = 0; g < G; g++)
-            ovoff[g] = (j0 + g < ty_act && lane < nlanes) ? (unsigned)((y0 + j0 + g) * nx + x0 + 16 * lane) : kOOB;
+            ovoff[g] = (j0 + g < ty_act && lane < nlanes) ? (unsigned)((y0 + j0 + g) * nx + x0 + LB * lane) : kOOB;
         for (int i = 0; i < nsteps; i++) {
             __syncthreads();
             if (i < W - 1) continue;
             const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(out + (size_t)(zs + i - (W - 1)) * plane_elems), 0, (int)plane_bytes, 0x00020000);
-            const u32x4 *rbuf = lds + (i & 1) * (LROWS * 64) + j0 * 64 + lane;
-            u32x4 win[G + W - 1];
+            const LV *rbuf = lds + (i & 1) * (LROWS * 64) + j0 * 64 + lane;
+            LV win[G + W - 1];
 #pragma unroll
             for (int k = 0; k < G + W - 1; k++) win[k] = rbuf[k * 64];
-            u32x4 res[G];
+            LV res[G];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < ND; k++) {
                 unsigned e[G + W - 1], o[G + W - 1];
 #pragma unroll
                 for (int j = 0; j < G + W - 1; j++) split(reinterpret_cast<const unsigned *>(&win[j])[k], e[j], o[j]);
@@ -584,28 +611,28 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
                 }
             }
 #pragma unroll
-            for (int g = 0; g < G; g++) __builtin_amdgcn_raw_buffer_store_b128(res[g], rout, ovoff[g], 0, 0);
+            for (int g = 0; g < G; g++) lane_store<ND>(res[g], rout, ovoff[g]);
         }
     }
 }
 
-template <int W, bool IS_MAX, int NWP, int NWC, int R>
+template <int W, bool IS_MAX, int NWP, int NWC, int R, int ND = 4>
 static int launch_u8_fused(const uint8_t *in, uint8_t *out, U8FusedParams &p, bool has_const, hipStream_t s)
 {
     constexpr int ROWS = NWP * R;
     constexpr int TY = ROWS - (W - 1);
     constexpr int G = (TY + NWC - 1) / NWC;
     constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
-    const size_t lds = (size_t)2 * LROWS * 1024 + (size_t)(kU8MaxChunk + 8) * sizeof(int);
+    const size_t lds = (size_t)2 * LROWS * 256 * ND + (size_t)(kU8MaxChunk + 8) * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, false>,
+        MI_HIP(hipFuncSetAttribute((const void *)mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, false, ND>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MI_HIP(hipFuncSetAttribute((const void *)mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, true>,
+        MI_HIP(hipFuncSetAttribute((const void *)mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, true, ND>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    p.nxt = (p.nx + 1023) / 1024;
+    p.nxt = (p.nx + 256 * ND - 1) / (256 * ND);
     p.nyt = (p.ny + TY - 1) / TY;
     // z chunks: one workgroup per CU resident; rounds x (chunk + ramp)
     int cus = 256;
@@ -634,9 +661,9 @@ static int launch_u8_fused(const uint8_t *in, uint8_t *out, U8FusedParams &p, bo
     p.nzc = (p.nz + p.zc - 1) / p.zc;
     const int64_t total = tiles * p.nzc;
     if (has_const)
-        hipLaunchKernelGGL((mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, true>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+        hipLaunchKernelGGL((mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, true, ND>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
     else
-        hipLaunchKernelGGL((mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, false>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+        hipLaunchKernelGGL((mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, false, ND>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -644,11 +671,18 @@ static int launch_u8_fused(const uint8_t *in, uint8_t *out, U8FusedParams &p, bo
 template <bool IS_MAX>
 static int launch_u8_fused_w(int w, int cfg, const uint8_t *in, uint8_t *out, U8FusedParams &p, bool has_const, hipStream_t s)
 {
+    // volumes narrower than 768 voxels: 8 voxels per lane (512-voxel tiles) keep the lanes busy
+    const bool narrow = p.nx < 768 || cfg == 3;
     switch (w) {
-    case 3: return launch_u8_fused<3, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
-    case 5: return launch_u8_fused<5, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
+    case 3:
+        return narrow ? launch_u8_fused<3, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s)
+                      : launch_u8_fused<3, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
+    case 5:
+        return narrow ? launch_u8_fused<5, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s)
+                      : launch_u8_fused<5, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
     default:
         if (cfg == 2) return launch_u8_fused<7, IS_MAX, 12, 4, 2>(in, out, p, has_const, s);
+        if (narrow) return launch_u8_fused<7, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s);
         // 12 waves x 168 VGPRs: three rows per producer wave need ~150 registers (packed z history 72)
         return launch_u8_fused<7, IS_MAX, 9, 3, 3>(in, out, p, has_const, s);
     }

@@ -20,7 +20,7 @@ PEAK = 8000.0
 
 
 def timeit(fn, reps):
-    for _ in range(3):
+    for _ in range(10):
         fn()
     ca.synchronize()
     e0, e1 = ca.Event(), ca.Event()
