@@ -502,13 +502,67 @@ def _interp_mode(mode):
     return _MODES[mode]
 
 
+def _spline_mode(mode):
+    """spline boundary condition of the prefilter for an extension mode"""
+    if mode in ("reflect", "grid-mirror", "nearest"):
+        return 1
+    if mode == "grid-wrap":
+        return 2
+    return 0
+
+
+def spline_filter1d(input, order=3, axis=-1, output=np.float64, mode="mirror"):
+    if order < 0 or order > 5:
+        raise RuntimeError("spline order not supported")
+    input = np.asarray(input)
+    _interp_mode(mode)
+    x = np.array(input, dtype=np.float64, order="C")
+    if order > 1 and x.size and x.ndim:
+        axis = axis % x.ndim
+        rc = lib().orc_spline_filter1d(_ptr(x), _shape_arr(x.shape), x.ndim, int(axis), int(order), _spline_mode(mode))
+        assert rc == 0, rc
+    dt = np.dtype(output) if not isinstance(output, np.ndarray) else output.dtype
+    res = x.astype(dt) if dt.kind == "f" else cast(x, dt)
+    if isinstance(output, np.ndarray):
+        output[...] = res
+        return output
+    return res
+
+
+def spline_filter(input, order=3, output=np.float64, mode="mirror"):
+    if order < 2 or order > 5:
+        raise RuntimeError("spline order not supported")
+    x = np.array(input, dtype=np.float64, order="C")
+    for ax in range(x.ndim):
+        x = spline_filter1d(x, order, ax, np.float64, mode)
+    dt = np.dtype(output) if not isinstance(output, np.ndarray) else output.dtype
+    res = x.astype(dt) if dt.kind == "f" else cast(x, dt)
+    if isinstance(output, np.ndarray):
+        output[...] = res
+        return output
+    return res
+
+
+def _spline_coefficients(input, order, mode, cval, prefilter):
+    """(float64 coefficients, npad): SciPy pads by 12 for nearest / grid-constant before prefiltering"""
+    x = _f64(input)
+    npad = 0
+    if order > 1 and prefilter:
+        if mode == "nearest":
+            npad, x = 12, np.pad(x, 12, mode="edge")
+        elif mode == "grid-constant":
+            npad, x = 12, np.pad(x, 12, mode="constant", constant_values=cval)
+        x = spline_filter(x, order, np.float64, mode)
+    return np.ascontiguousarray(x), npad
+
+
 def map_coordinates(input, coordinates, output=None, order=1, mode="constant", cval=0.0,
-                    prefilter=False):
-    if order not in (0, 1):
-        raise NotImplementedError("oracle covers spline orders 0 and 1")
+                    prefilter=True):
+    if order < 0 or order > 5:
+        raise RuntimeError("spline order not supported")
     input = np.asarray(input)
     coordinates = np.asarray(coordinates)
-    x = _f64(input)
+    x, npad = _spline_coefficients(input, order, mode, cval, prefilter)
     c = _f64(coordinates)
     oshape = c.shape[1:]
     nout = int(np.prod(oshape)) if oshape else 1
@@ -516,7 +570,7 @@ def map_coordinates(input, coordinates, output=None, order=1, mode="constant", c
     if nout:
         rc = lib().orc_map_coordinates(_ptr(x), _shape_arr(x.shape), x.ndim, _ptr(c),
                                        ctypes.c_int64(nout), _ptr(out), int(order),
-                                       _interp_mode(mode), ctypes.c_double(cval))
+                                       _interp_mode(mode), ctypes.c_double(cval), int(npad))
         assert rc == 0, rc
     dt = _out_dtype(output, input)
     res = cast(out, dt, round_half_even=dt.kind in "iu")
@@ -526,11 +580,7 @@ def map_coordinates(input, coordinates, output=None, order=1, mode="constant", c
     return res
 
 
-def affine_transform(input, matrix, offset=0.0, output_shape=None, output=None, order=1,
-                     mode="constant", cval=0.0, prefilter=False):
-    if order not in (0, 1):
-        raise NotImplementedError("oracle covers spline orders 0 and 1")
-    input = np.asarray(input)
+def _affine_args(input, matrix, offset):
     nd = input.ndim
     matrix = np.asarray(matrix, dtype=np.float64)
     if not hasattr(offset, "__iter__"):
@@ -550,13 +600,23 @@ def affine_transform(input, matrix, offset=0.0, output_shape=None, output=None, 
     m = np.zeros((nd, nd + 1))
     m[:, :nd] = matrix
     m[:, nd] = offset
+    return m
+
+
+def affine_transform(input, matrix, offset=0.0, output_shape=None, output=None, order=1,
+                     mode="constant", cval=0.0, prefilter=True):
+    if order < 0 or order > 5:
+        raise RuntimeError("spline order not supported")
+    input = np.asarray(input)
+    nd = input.ndim
+    m = _affine_args(input, matrix, offset)
     oshape = tuple(input.shape if output_shape is None else output_shape)
-    x = _f64(input)
+    x, npad = _spline_coefficients(input, order, mode, cval, prefilter)
     out = np.empty(oshape, np.float64)
     if out.size:
         rc = lib().orc_affine_transform(_ptr(x), _shape_arr(x.shape), nd, _ptr(_f64(m)),
                                         _ptr(out), _shape_arr(oshape), int(order),
-                                        _interp_mode(mode), ctypes.c_double(cval))
+                                        _interp_mode(mode), ctypes.c_double(cval), int(npad))
         assert rc == 0, rc
     dt = _out_dtype(output, input)
     res = cast(out, dt, round_half_even=dt.kind in "iu")
@@ -564,6 +624,25 @@ def affine_transform(input, matrix, offset=0.0, output_shape=None, output=None, 
         output[...] = res
         return output
     return res
+
+
+def shift(input, shift, output=None, order=1, mode="constant", cval=0.0, prefilter=True):
+    input = np.asarray(input)
+    sh = _seq(shift, input.ndim, float)
+    return affine_transform(input, np.ones(input.ndim), [-s for s in sh], None, output, order, mode, cval, prefilter)
+
+
+def zoom(input, zoom, output=None, order=1, mode="constant", cval=0.0, prefilter=True, grid_mode=False):
+    input = np.asarray(input)
+    zf = _seq(zoom, input.ndim, float)
+    oshape = tuple(int(round(n * z)) for n, z in zip(input.shape, zf))
+    if grid_mode:
+        scale = [n / o if o > 0 else 1.0 for n, o in zip(input.shape, oshape)]
+        off = [0.5 * s - 0.5 for s in scale]
+    else:
+        scale = [(n - 1) / (o - 1) if o > 1 else 1.0 for n, o in zip(input.shape, oshape)]
+        off = [0.0] * input.ndim
+    return affine_transform(input, np.asarray(scale), off, oshape, output, order, mode, cval, prefilter)
 
 
 # ---------------------------------------------------------- timed baselines

@@ -444,6 +444,168 @@ static double fold_coord(double c, int64_t n, int mode)
     }
 }
 
+/* ------------------------------------------------------------------ */
+/* B-spline orders 2..5 (published algorithm of scipy/ndimage/src/ni_splines.c
+ * and ni_interpolation.c, SciPy 1.15.3 -- a dependency whose source is not
+ * under /root/reference; the reference restates the same recurrences in
+ * _spline_prefilter_core.py:14-139 and _spline_kernel_weights.py).  Pinned by
+ * tests/golden fixtures generated from SciPy.                            */
+/* ------------------------------------------------------------------ */
+static int spline_poles(int order, double *z)
+{
+    switch (order) {
+    case 2: z[0] = -0.171572875253809902396622551580603843; return 1;
+    case 3: z[0] = -0.267949192431122706472553658494127633; return 1;
+    case 4: z[0] = -0.361341225900220177092212841325675255; z[1] = -0.013725429297339121360331226939128204; return 2;
+    case 5: z[0] = -0.430575347099973791851434783493520110; z[1] = -0.043096288203264653822712376822550182; return 2;
+    }
+    return 0;
+}
+
+/* in-place prefilter of one line c[0], c[st], ...; smode: 0 mirror, 1 reflect, 2 grid-wrap */
+static void spline_line(double *c, int64_t n, int64_t st, int order, int smode)
+{
+    double zs[2];
+    const int np = spline_poles(order, zs);
+    if (n <= 1) return;                       /* a single sample is left as it is */
+    double gain = 1.0;
+    for (int k = 0; k < np; k++) gain *= (1.0 - zs[k]) * (1.0 - 1.0 / zs[k]);
+    for (int64_t i = 0; i < n; i++) c[i * st] *= gain;
+    for (int k = 0; k < np; k++) {
+        const double z = zs[k];
+        double z_i = z;
+        if (smode == 0) {
+            const double z_n_1 = pow(z, (double)(n - 1));
+            c[0] = c[0] + z_n_1 * c[(n - 1) * st];
+            for (int64_t i = 1; i < n - 1; i++) { c[0] += z_i * (c[i * st] + z_n_1 * c[(n - 1 - i) * st]); z_i *= z; }
+            c[0] /= 1 - z_n_1 * z_n_1;
+        } else if (smode == 2) {
+            for (int64_t i = 1; i < n; i++) { c[0] += z_i * c[(n - i) * st]; z_i *= z; }
+            c[0] /= 1 - z_i;
+        } else {
+            const double z_n = pow(z, (double)n), c0 = c[0];
+            c[0] = c[0] + z_n * c[(n - 1) * st];
+            for (int64_t i = 1; i < n; i++) { c[0] += z_i * (c[i * st] + z_n * c[(n - 1 - i) * st]); z_i *= z; }
+            c[0] *= z / (1 - z_n * z_n);
+            c[0] += c0;
+        }
+        for (int64_t i = 1; i < n; i++) c[i * st] += z * c[(i - 1) * st];
+        if (smode == 0) {
+            c[(n - 1) * st] = (z * c[(n - 2) * st] + c[(n - 1) * st]) * z / (z * z - 1);
+        } else if (smode == 2) {
+            z_i = z;
+            for (int64_t i = 0; i < n - 1; i++) { c[(n - 1) * st] += z_i * c[i * st]; z_i *= z; }
+            c[(n - 1) * st] *= z / (z_i - 1);
+        } else {
+            c[(n - 1) * st] *= z / (z - 1);
+        }
+        for (int64_t i = n - 2; i >= 0; i--) c[i * st] = z * (c[(i + 1) * st] - c[i * st]);
+    }
+}
+
+/* in-place along `axis` of a C-contiguous float64 array */
+int orc_spline_filter1d(double *data, const int64_t *shape, int ndim, int axis, int order, int smode)
+{
+    if (ndim < 1 || ndim > ORC_MAXDIM || axis < 0 || axis >= ndim || order < 2 || order > 5) return -1;
+    int64_t inner = 1, outer = 1;
+    for (int d = axis + 1; d < ndim; d++) inner *= shape[d];
+    for (int d = 0; d < axis; d++) outer *= shape[d];
+    const int64_t n = shape[axis];
+    for (int64_t o = 0; o < outer; o++)
+        for (int64_t k = 0; k < inner; k++) spline_line(data + o * n * inner + k, n, inner, order, smode);
+    return 0;
+}
+
+static void spline_weights(double x, int order, double *w)
+{
+    double y;
+    switch (order) {
+    case 2:
+        w[1] = 0.75 - x * x; y = 0.5 - x; w[0] = 0.5 * y * y; w[2] = 1.0 - w[0] - w[1];
+        break;
+    case 3:
+        y = 1.0 - x;
+        w[1] = (x * x * (x - 2.0) * 3.0 + 4.0) / 6.0;
+        w[2] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+        w[0] = y * y * y / 6.0;
+        w[3] = 1.0 - w[0] - w[1] - w[2];
+        break;
+    case 4:
+        y = x * x;
+        w[2] = y * (y * 0.25 - 0.625) + 115.0 / 192.0;
+        y = 1.0 + x;
+        w[1] = y * (y * (y * (5.0 - y) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+        y = 1.0 - x;
+        w[3] = y * (y * (y * (5.0 - y) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+        y = 0.5 - x; y = y * y;
+        w[0] = y * y / 24.0;
+        w[4] = 1.0 - w[0] - w[1] - w[2] - w[3];
+        break;
+    default:
+        y = x * x;
+        w[2] = y * (y * (0.25 - x / 12.0) - 0.5) + 0.55;
+        y = 1.0 - x; y = y * y;
+        w[3] = y * (y * (0.25 - (1.0 - x) / 12.0) - 0.5) + 0.55;
+        y = x + 1.0;
+        w[1] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+        y = 2.0 - x;
+        w[4] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+        y = 1.0 - x; y = y * y;
+        w[0] = (1.0 - x) * y * y / 120.0;
+        w[5] = 1.0 - w[0] - w[1] - w[2] - w[3] - w[4];
+        break;
+    }
+}
+
+/* spline tap index outside [0, n): the symmetry the coefficients were computed with */
+static int64_t spline_tap(int64_t i, int64_t n, int mode)
+{
+    if (i >= 0 && i < n) return i;
+    if (mode == ORC_GRID_CONSTANT) return -1;
+    if (mode == ORC_REFLECT) return bmap(i, n, ORC_REFLECT);
+    if (mode == ORC_NEAREST) return i < 0 ? 0 : n - 1;      /* taps are clamped, the coordinate is not */
+    if (mode == ORC_GRID_WRAP) return bmap(i, n, ORC_GRID_WRAP);
+    return bmap(i, n, ORC_MIRROR);
+}
+
+/* order 2..5 on prefiltered coefficients `in` (already padded by `npad` for
+ * nearest / grid-constant); c = coordinates in the unpadded frame */
+static double spline_point(const double *in, const int64_t *shape, const int64_t *stride, int ndim, const double *c,
+                           int order, int mode, double cval, int npad)
+{
+    double w[ORC_MAXDIM][6];
+    int64_t idx[ORC_MAXDIM][6];
+    for (int d = 0; d < ndim; d++) {
+        double cc = c[d] + (double)npad;
+        const int64_t n = shape[d];
+        if (mode == ORC_CONSTANT) {
+            if (cc < 0 || cc > (double)(n - 1)) return cval;
+        } else if (mode != ORC_GRID_CONSTANT && mode != ORC_NEAREST) {
+            cc = fold_coord(cc, n, mode);
+        }
+        const double fl = (order & 1) ? floor(cc) : floor(cc + 0.5);
+        const int64_t start = (int64_t)fl - order / 2;
+        spline_weights(cc - fl, order, w[d]);
+        for (int k = 0; k <= order; k++) idx[d][k] = spline_tap(start + k, n, mode);
+    }
+    int k[ORC_MAXDIM] = {0};
+    double acc = 0.0;
+    for (;;) {
+        double wt = 1.0;
+        int64_t pos = 0;
+        int oob = 0;
+        for (int d = 0; d < ndim; d++) {
+            wt *= w[d][k[d]];
+            if (idx[d][k[d]] < 0) oob = 1; else pos += idx[d][k[d]] * stride[d];
+        }
+        acc += (oob ? cval : in[pos]) * wt;
+        int d = ndim - 1;
+        while (d >= 0 && ++k[d] > order) { k[d] = 0; d--; }
+        if (d < 0) break;
+    }
+    return acc;
+}
+
 /* value of one output sample at float coordinates c[0..ndim) */
 static double interp_point(const double *in, const int64_t *shape,
                            const int64_t *stride, int ndim, const double *c,
@@ -522,16 +684,17 @@ static double interp_point(const double *in, const int64_t *shape,
  * (_interp_kernels.py:38-46) */
 int orc_map_coordinates(const double *in, const int64_t *shape, int ndim,
                         const double *coords, int64_t nout, double *out,
-                        int order, int mode, double cval)
+                        int order, int mode, double cval, int npad)
 {
-    if (ndim < 1 || ndim > ORC_MAXDIM || order < 0 || order > 1) return -1;
+    if (ndim < 1 || ndim > ORC_MAXDIM || order < 0 || order > 5) return -1;
     int64_t stride[ORC_MAXDIM];
     double c[ORC_MAXDIM];
     stride[ndim - 1] = 1;
     for (int d = ndim - 2; d >= 0; d--) stride[d] = stride[d + 1] * shape[d + 1];
     for (int64_t i = 0; i < nout; i++) {
         for (int d = 0; d < ndim; d++) c[d] = coords[d * nout + i];
-        out[i] = interp_point(in, shape, stride, ndim, c, order, mode, cval);
+        out[i] = order > 1 ? spline_point(in, shape, stride, ndim, c, order, mode, cval, npad)
+                           : interp_point(in, shape, stride, ndim, c, order, mode, cval);
     }
     return 0;
 }
@@ -540,9 +703,9 @@ int orc_map_coordinates(const double *in, const int64_t *shape, int ndim,
  * (_interp_kernels.py:198-242) */
 int orc_affine_transform(const double *in, const int64_t *shape, int ndim,
                          const double *mat, double *out, const int64_t *oshape,
-                         int order, int mode, double cval)
+                         int order, int mode, double cval, int npad)
 {
-    if (ndim < 1 || ndim > ORC_MAXDIM || order < 0 || order > 1) return -1;
+    if (ndim < 1 || ndim > ORC_MAXDIM || order < 0 || order > 5) return -1;
     int64_t stride[ORC_MAXDIM], o[ORC_MAXDIM];
     double c[ORC_MAXDIM];
     stride[ndim - 1] = 1;
@@ -555,7 +718,8 @@ int orc_affine_transform(const double *in, const int64_t *shape, int ndim,
             for (int k = 0; k < ndim; k++) s += mat[d * (ndim + 1) + k] * (double)o[k];
             c[d] = s + mat[d * (ndim + 1) + ndim];
         }
-        out[lin] = interp_point(in, shape, stride, ndim, c, order, mode, cval);
+        out[lin] = order > 1 ? spline_point(in, shape, stride, ndim, c, order, mode, cval, npad)
+                             : interp_point(in, shape, stride, ndim, c, order, mode, cval);
     }
     return 0;
 }
