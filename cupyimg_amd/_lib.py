@@ -101,6 +101,10 @@ SIGNATURES = {
     "mi_binary_erosion": [_arr, _arr, _u8p, _i64p, _ip, _arr, _i, _i, _vp, _vp],
     "mi_map_coordinates": [_arr, _arr, _arr, _i, _i, _d, _vp],
     "mi_affine_transform": [_arr, _arr, _dp, _i, _i, _d, _vp],
+    "mi_spline_pad": [_arr, _arr, _i, _i, _d, _vp],
+    "mi_spline_filter1d": [_arr, _i, _i, _i, _vp],
+    "mi_spline_map_coordinates": [_arr, _arr, _arr, _i, _i, _d, _i, _vp],
+    "mi_spline_affine_transform": [_arr, _arr, _dp, _i, _i, _d, _i, _vp],
     "mi_comm_unique_id": [ctypes.c_char_p],
     "mi_comm_init_rank": [ctypes.POINTER(_vp), _i, _i, ctypes.c_char_p],
     "mi_comm_destroy": [_vp],

@@ -140,18 +140,132 @@ __device__ __forceinline__ double interp_point(const T *__restrict__ in, const I
     return acc;
 }
 
+// ---------------------------------------------------------------------------
+// B-spline orders 2..5 (reference: _spline_prefilter_core.py:14-139 poles and
+// boundary initialisation, _spline_kernel_weights.py weights,
+// _interp_kernels.py:473-549 tap loop; arithmetic as in SciPy 1.15.3, the
+// parity target: see oracle/ndimage_oracle.c).  `in` holds the prefiltered
+// float64 coefficients, padded by npad samples on every real axis for the
+// modes SciPy pads (nearest, grid-constant).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void spline_weights(double x, int order, double *w)
+{
+    double y;
+    switch (order) {
+    case 2:
+        w[1] = 0.75 - x * x; y = 0.5 - x; w[0] = 0.5 * y * y; w[2] = 1.0 - w[0] - w[1];
+        break;
+    case 3:
+        y = 1.0 - x;
+        w[1] = (x * x * (x - 2.0) * 3.0 + 4.0) / 6.0;
+        w[2] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+        w[0] = y * y * y / 6.0;
+        w[3] = 1.0 - w[0] - w[1] - w[2];
+        break;
+    case 4:
+        y = x * x;
+        w[2] = y * (y * 0.25 - 0.625) + 115.0 / 192.0;
+        y = 1.0 + x;
+        w[1] = y * (y * (y * (5.0 - y) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+        y = 1.0 - x;
+        w[3] = y * (y * (y * (5.0 - y) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+        y = 0.5 - x; y = y * y;
+        w[0] = y * y / 24.0;
+        w[4] = 1.0 - w[0] - w[1] - w[2] - w[3];
+        break;
+    default:
+        y = x * x;
+        w[2] = y * (y * (0.25 - x / 12.0) - 0.5) + 0.55;
+        y = 1.0 - x; y = y * y;
+        w[3] = y * (y * (0.25 - (1.0 - x) / 12.0) - 0.5) + 0.55;
+        y = x + 1.0;
+        w[1] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+        y = 2.0 - x;
+        w[4] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+        y = 1.0 - x; y = y * y;
+        w[0] = (1.0 - x) * y * y / 120.0;
+        w[5] = 1.0 - w[0] - w[1] - w[2] - w[3] - w[4];
+        break;
+    }
+}
+
+// tap index outside [0, n): the symmetry the coefficients were computed with
+__device__ __forceinline__ int64_t spline_tap(int64_t i, int64_t n, int mode)
+{
+    if (i >= 0 && i < n) return i;
+    if (mode == MI_MODE_GRID_CONSTANT) return -1;
+    if (mode == MI_MODE_REFLECT) return bmap<int64_t>(i, n, MI_MODE_REFLECT);
+    if (mode == MI_MODE_NEAREST) return i < 0 ? 0 : n - 1;       // taps are clamped, the coordinate is not
+    if (mode == MI_MODE_GRID_WRAP) return bmap<int64_t>(i, n, MI_MODE_GRID_WRAP);
+    return bmap<int64_t>(i, n, MI_MODE_MIRROR);
+}
+
+template <typename T, int ND>
+__device__ __forceinline__ double spline_point(const T *__restrict__ in, const InterpGeom &g, const double (&c)[ND],
+                                               int order, int mode, double cval, int npad)
+{
+    double w[ND][6];
+    int64_t idx[ND][6];
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+        const int64_t n = g.shape[d];
+        if (d < g.pad) {                         // unit axis added by the rank padding: a single tap
+            for (int k = 0; k <= order; k++) { w[d][k] = k == 0 ? 1.0 : 0.0; idx[d][k] = 0; }
+            continue;
+        }
+        double cc = c[d] + (double)npad;
+        if (mode == MI_MODE_CONSTANT) {
+            if (cc < 0 || cc > (double)(n - 1)) return cval;
+        } else if (mode != MI_MODE_GRID_CONSTANT && mode != MI_MODE_NEAREST) {
+            cc = fold_coord(cc, n, mode);
+        }
+        const double fl = (order & 1) ? floor(cc) : floor(cc + 0.5);
+        const int64_t start = (int64_t)fl - order / 2;
+        spline_weights(cc - fl, order, w[d]);
+        for (int k = 0; k <= order; k++) idx[d][k] = spline_tap(start + k, n, mode);
+    }
+    // taps in the oracle's order (last axis fastest)
+    int k[ND];
+#pragma unroll
+    for (int d = 0; d < ND; d++) k[d] = 0;
+    double acc = 0.0;
+    for (;;) {
+        double wt = 1.0;
+        int64_t pos = 0;
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            wt *= w[d][k[d]];
+            oob |= idx[d][k[d]] < 0;
+            pos += idx[d][k[d]] * g.stride[d];
+        }
+        acc += (oob ? cval : (double)in[oob ? 0 : pos]) * wt;
+        int d = ND - 1;
+        while (d >= 0) {
+            if (d >= g.pad && ++k[d] <= order) break;
+            k[d] = 0;
+            d--;
+        }
+        if (d < 0) break;
+    }
+    return acc;
+}
+
 template <typename T, typename C, int ND>
 __global__ void __launch_bounds__(256)
 map_coordinates_kernel(const T *__restrict__ in, const C *__restrict__ coords, void *__restrict__ out,
                        int out_dt, InterpGeom g, int64_t nout, int order, int mode, double cval,
-                       int round_out)
+                       int round_out, int npad)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout;
          i += (int64_t)gridDim.x * blockDim.x) {
         double c[ND];
 #pragma unroll
         for (int d = 0; d < ND; d++) c[d] = d < g.pad ? 0.0 : (double)coords[(int64_t)(d - g.pad) * nout + i];
-        double v = interp_point<T, ND>(in, g, c, order, mode, cval);
+        double v;
+        if constexpr (ND == 3) v = order > 1 ? spline_point<T, ND>(in, g, c, order, mode, cval, npad)
+                                             : interp_point<T, ND>(in, g, c, order, mode, cval);
+        else v = interp_point<T, ND>(in, g, c, order, mode, cval);
         if (round_out) v = interp_round(v, out_dt);
         store_as(out, i, out_dt, v);
     }
@@ -160,7 +274,7 @@ map_coordinates_kernel(const T *__restrict__ in, const C *__restrict__ coords, v
 template <typename T, int ND>
 __global__ void __launch_bounds__(256)
 affine_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, InterpGeom g, int64_t nout,
-              int order, int mode, double cval, int round_out)
+              int order, int mode, double cval, int round_out, int npad)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -179,9 +293,91 @@ affine_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Inte
             for (int k = 0; k < ND; k++) s += g.mat[d * (ND + 1) + k] * o[k];
             c[d] = s + g.mat[d * (ND + 1) + ND];
         }
-        double v = interp_point<T, ND>(in, g, c, order, mode, cval);
+        double v;
+        if constexpr (ND == 3) v = order > 1 ? spline_point<T, ND>(in, g, c, order, mode, cval, npad)
+                                             : interp_point<T, ND>(in, g, c, order, mode, cval);
+        else v = interp_point<T, ND>(in, g, c, order, mode, cval);
         if (round_out) v = interp_round(v, out_dt);
         store_as(out, i, out_dt, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// spline coefficients: padded float64 copy + in-place prefilter
+// ---------------------------------------------------------------------------
+// out (float64, shape = in.shape + 2 npad on the real axes) = in extended by edge
+// replication (pad_mode 0) or by cval (pad_mode 1); rank padded to 3
+template <typename T>
+__global__ void __launch_bounds__(256)
+spline_pad_kernel(const T *__restrict__ in, double *__restrict__ out, InterpGeom g, int64_t nout, int npad, int pad_mode,
+                  double cval)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i, pos = 0;
+        bool outside = false;
+#pragma unroll
+        for (int d = 2; d >= 0; d--) {
+            const int64_t q = r / g.oshape[d];
+            int64_t o = r - q * g.oshape[d];
+            r = q;
+            if (d >= g.pad) {
+                o -= npad;
+                if (o < 0 || o >= g.shape[d]) { outside = true; o = o < 0 ? 0 : g.shape[d] - 1; }
+            }
+            pos += o * g.stride[d];
+        }
+        out[i] = (outside && pad_mode == 1) ? cval : (double)in[pos];
+    }
+}
+
+// one thread per line; smode: 0 mirror, 1 reflect, 2 grid-wrap
+__global__ void __launch_bounds__(128)
+spline_filter1d_kernel(double *__restrict__ data, int64_t n, int64_t inner, int64_t nlines, int order, int smode)
+{
+    const int64_t line = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (line >= nlines || n <= 1) return;
+    double *c = data + (line / inner) * n * inner + (line % inner);
+    const int64_t st = inner;
+    double zs[2];
+    int np = 1;
+    switch (order) {
+    case 2: zs[0] = -0.171572875253809902396622551580603843; break;
+    case 3: zs[0] = -0.267949192431122706472553658494127633; break;
+    case 4: zs[0] = -0.361341225900220177092212841325675255; zs[1] = -0.013725429297339121360331226939128204; np = 2; break;
+    default: zs[0] = -0.430575347099973791851434783493520110; zs[1] = -0.043096288203264653822712376822550182; np = 2; break;
+    }
+    double gain = 1.0;
+    for (int k = 0; k < np; k++) gain *= (1.0 - zs[k]) * (1.0 - 1.0 / zs[k]);
+    for (int64_t i = 0; i < n; i++) c[i * st] *= gain;
+    for (int k = 0; k < np; k++) {
+        const double z = zs[k];
+        double z_i = z;
+        if (smode == 0) {
+            const double z_n_1 = pow(z, (double)(n - 1));
+            c[0] = c[0] + z_n_1 * c[(n - 1) * st];
+            for (int64_t i = 1; i < n - 1; i++) { c[0] += z_i * (c[i * st] + z_n_1 * c[(n - 1 - i) * st]); z_i *= z; }
+            c[0] /= 1 - z_n_1 * z_n_1;
+        } else if (smode == 2) {
+            for (int64_t i = 1; i < n; i++) { c[0] += z_i * c[(n - i) * st]; z_i *= z; }
+            c[0] /= 1 - z_i;
+        } else {
+            const double z_n = pow(z, (double)n), c0 = c[0];
+            c[0] = c[0] + z_n * c[(n - 1) * st];
+            for (int64_t i = 1; i < n; i++) { c[0] += z_i * (c[i * st] + z_n * c[(n - 1 - i) * st]); z_i *= z; }
+            c[0] *= z / (1 - z_n * z_n);
+            c[0] += c0;
+        }
+        for (int64_t i = 1; i < n; i++) c[i * st] += z * c[(i - 1) * st];
+        if (smode == 0) {
+            c[(n - 1) * st] = (z * c[(n - 2) * st] + c[(n - 1) * st]) * z / (z * z - 1);
+        } else if (smode == 2) {
+            z_i = z;
+            for (int64_t i = 0; i < n - 1; i++) { c[(n - 1) * st] += z_i * c[i * st]; z_i *= z; }
+            c[(n - 1) * st] *= z / (z_i - 1);
+        } else {
+            c[(n - 1) * st] *= z / (z - 1);
+        }
+        for (int64_t i = n - 2; i >= 0; i--) c[i * st] = z * (c[(i + 1) * st] - c[i * st]);
     }
 }
 
@@ -205,7 +401,7 @@ static int check_interp(const mi_array *in, const mi_array *out, int order, int 
     if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
     MI_REQUIRE(in->ndim >= 1, MI_ERR_INVALID_ARG, "input must have at least one dimension");
     if (order < 0 || order > 5) { set_error("spline order is not supported"); return MI_ERR_INVALID_ARG; }
-    if (order > 1) { set_error("spline order %d has no kernel yet (orders 0 and 1 are built)", order); return MI_ERR_UNSUPPORTED; }
+    if (order > 1 && in->ndim > 3) { set_error("spline orders 2-5 are built for rank <= 3"); return MI_ERR_UNSUPPORTED; }
     MI_REQUIRE(mode >= MI_MODE_REFLECT && mode <= MI_MODE_GRID_CONSTANT, MI_ERR_INVALID_ARG,
                "boundary mode is not supported");
     MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS,
@@ -265,7 +461,7 @@ int mi_map_coordinates(const mi_array *in, const mi_array *coords, const mi_arra
         constexpr bool kHighRank = std::is_floating_point<T>::value;
 #define MI_LAUNCH(C, NDV)                                                                              \
     hipLaunchKernelGGL((map_coordinates_kernel<T, C, NDV>), grid, dim3(256), 0, s, ip,                 \
-                       (const C *)coords->data, out->data, out->dtype, g, nout, order, mode, cval, round_out)
+                       (const C *)coords->data, out->data, out->dtype, g, nout, order, mode, cval, round_out, 0)
         if (nd == 3) { if (coords->dtype == MI_F32) MI_LAUNCH(float, 3); else MI_LAUNCH(double, 3); }
         else if constexpr (kHighRank) {
             if (coords->dtype == MI_F32) MI_LAUNCH(float, MI_MAX_NDIM); else MI_LAUNCH(double, MI_MAX_NDIM);
@@ -312,13 +508,128 @@ int mi_affine_transform(const mi_array *in, const mi_array *out, const double *m
         const T *ip = (const T *)in->data;
         if (nd == 3)
             hipLaunchKernelGGL((affine_kernel<T, 3>), grid, dim3(256), 0, s, ip, out->data, out->dtype, g, nout,
-                               order, mode, cval, round_out);
+                               order, mode, cval, round_out, 0);
         else if constexpr (std::is_floating_point<T>::value)
             hipLaunchKernelGGL((affine_kernel<T, MI_MAX_NDIM>), grid, dim3(256), 0, s, ip, out->data, out->dtype,
-                               g, nout, order, mode, cval, round_out);
+                               g, nout, order, mode, cval, round_out, 0);
         MI_HIP(hipGetLastError());
         return MI_OK;
     });
+}
+
+/* ---- B-spline orders 2..5 (declared in include/mi355img.h) ---- */
+int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mode, double cval, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(in->ndim >= 1 && in->ndim <= 3 && out->ndim == in->ndim, MI_ERR_INVALID_ARG, "rank 1..3");
+    MI_REQUIRE(out->dtype == MI_F64, MI_ERR_INVALID_ARG, "coefficients are float64");
+    MI_REQUIRE(npad >= 0 && (pad_mode == 0 || pad_mode == 1), MI_ERR_INVALID_ARG, "bad padding");
+    MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "needs C-contiguous arrays");
+    for (int d = 0; d < in->ndim; d++)
+        MI_REQUIRE(out->shape[d] == in->shape[d] + 2 * npad && in->shape[d] > 0, MI_ERR_INVALID_ARG, "output shape is not correct");
+    InterpGeom g;
+    fill_geom(&g, in, 3);
+    for (int d = 0; d < in->ndim; d++) g.oshape[g.pad + d] = out->shape[d];
+    const int64_t nout = numel(out);
+    dim3 grid;
+    grid_for(nout, 256, &grid);
+    hipStream_t s = resolve_stream(stream);
+    return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
+        hipLaunchKernelGGL((spline_pad_kernel<T>), grid, dim3(256), 0, s, (const T *)in->data, (double *)out->data, g, nout,
+                           npad, pad_mode, cval);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    });
+}
+
+int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mode, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(data, "data"))) return rc;
+    MI_REQUIRE(data->dtype == MI_F64, MI_ERR_INVALID_ARG, "coefficients are float64");
+    MI_REQUIRE(data->ndim >= 1 && axis >= 0 && axis < data->ndim, MI_ERR_INVALID_ARG, "invalid axis");
+    MI_REQUIRE(order >= 2 && order <= 5, MI_ERR_INVALID_ARG, "spline order is not supported");
+    MI_REQUIRE(spline_mode >= 0 && spline_mode <= 2, MI_ERR_INVALID_ARG, "bad spline boundary mode");
+    MI_REQUIRE(is_contiguous(data), MI_ERR_NOT_CONTIGUOUS, "needs a C-contiguous array");
+    const int64_t total = numel(data);
+    if (total == 0) return MI_OK;
+    int64_t inner = 1;
+    for (int d = axis + 1; d < data->ndim; d++) inner *= data->shape[d];
+    const int64_t n = data->shape[axis], nlines = total / n;
+    hipLaunchKernelGGL(spline_filter1d_kernel, dim3((unsigned)((nlines + 127) / 128)), dim3(128), 0, resolve_stream(stream),
+                       (double *)data->data, n, inner, nlines, order, spline_mode);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+static int check_spline(const mi_array *coef, const mi_array *out, int order, int mode, int npad)
+{
+    int rc = check_interp(coef, out, order, mode);
+    if (rc) return rc;
+    MI_REQUIRE(order >= 2, MI_ERR_INVALID_ARG, "orders 0 and 1 use mi_map_coordinates / mi_affine_transform");
+    MI_REQUIRE(coef->dtype == MI_F64, MI_ERR_INVALID_ARG, "coefficients are float64");
+    MI_REQUIRE(npad >= 0, MI_ERR_INVALID_ARG, "negative padding");
+    if (coef->ndim > 3) { set_error("spline orders 2-5 are built for rank <= 3"); return MI_ERR_UNSUPPORTED; }
+    return MI_OK;
+}
+
+int mi_spline_map_coordinates(const mi_array *coef, const mi_array *coords, const mi_array *out, int order, int mode,
+                              double cval, int npad, mi_stream stream)
+{
+    int rc = check_spline(coef, out, order, mode, npad);
+    if (rc) return rc;
+    if ((rc = check_array(coords, "coordinates"))) return rc;
+    MI_REQUIRE(coords->dtype == MI_F32 || coords->dtype == MI_F64, MI_ERR_INVALID_ARG,
+               "coordinates should have floating point dtype");
+    MI_REQUIRE(coords->ndim == out->ndim + 1 && coords->shape[0] == coef->ndim, MI_ERR_INVALID_ARG,
+               "invalid shape for coordinate array");
+    for (int d = 0; d < out->ndim; d++)
+        MI_REQUIRE(coords->shape[d + 1] == out->shape[d], MI_ERR_INVALID_ARG, "output shape is not correct");
+    MI_REQUIRE(is_contiguous(coords), MI_ERR_NOT_CONTIGUOUS, "coordinates must be C-contiguous");
+    const int64_t nout = numel(out);
+    if (nout == 0) return MI_OK;
+    InterpGeom g;
+    fill_geom(&g, coef, 3);
+    const int round_out = out->dtype != MI_F32 && out->dtype != MI_F64 && out->dtype != MI_BOOL;
+    dim3 grid;
+    grid_for(nout, 256, &grid);
+    hipStream_t s = resolve_stream(stream);
+    if (coords->dtype == MI_F32)
+        hipLaunchKernelGGL((map_coordinates_kernel<double, float, 3>), grid, dim3(256), 0, s, (const double *)coef->data,
+                           (const float *)coords->data, out->data, out->dtype, g, nout, order, mode, cval, round_out, npad);
+    else
+        hipLaunchKernelGGL((map_coordinates_kernel<double, double, 3>), grid, dim3(256), 0, s, (const double *)coef->data,
+                           (const double *)coords->data, out->data, out->dtype, g, nout, order, mode, cval, round_out, npad);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const double *matrix, int order, int mode,
+                               double cval, int npad, mi_stream stream)
+{
+    int rc = check_spline(coef, out, order, mode, npad);
+    if (rc) return rc;
+    MI_REQUIRE(matrix, MI_ERR_INVALID_ARG, "matrix is NULL");
+    MI_REQUIRE(out->ndim == coef->ndim, MI_ERR_INVALID_ARG, "output rank must equal input rank");
+    const int64_t nout = numel(out);
+    if (nout == 0) return MI_OK;
+    const int n = coef->ndim, nd = 3;
+    InterpGeom g;
+    fill_geom(&g, coef, nd);
+    for (int d = 0; d < n; d++) g.oshape[g.pad + d] = out->shape[d];
+    for (int i = 0; i < nd * (nd + 1); i++) g.mat[i] = 0.0;
+    for (int d = 0; d < n; d++) {
+        for (int k = 0; k < n; k++) g.mat[(g.pad + d) * (nd + 1) + g.pad + k] = matrix[d * (n + 1) + k];
+        g.mat[(g.pad + d) * (nd + 1) + nd] = matrix[d * (n + 1) + n];
+    }
+    const int round_out = out->dtype != MI_F32 && out->dtype != MI_F64 && out->dtype != MI_BOOL;
+    dim3 grid;
+    grid_for(nout, 256, &grid);
+    hipLaunchKernelGGL((affine_kernel<double, 3>), grid, dim3(256), 0, resolve_stream(stream), (const double *)coef->data,
+                       out->data, out->dtype, g, nout, order, mode, cval, round_out, npad);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
 }
 
 }  // extern "C"

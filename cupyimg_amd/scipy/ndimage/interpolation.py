@@ -1,11 +1,14 @@
-"""scipy.ndimage interpolation on device arrays: map_coordinates and
-affine_transform, spline orders 0 and 1.
+"""scipy.ndimage interpolation on device arrays: spline_filter(1d),
+map_coordinates, affine_transform, shift, zoom, rotate; spline orders 0-5.
 
-Signatures follow cupyimg/scipy/ndimage/interpolation.py (map_coordinates
-:271-394, affine_transform :397-561).  Orders 2-5 need the spline prefilter
-(_spline_prefilter_core.py), which is the first "next" item of the scope table
-and not built yet: they raise NotImplementedError instead of silently using a
-different algorithm.
+Signatures follow cupyimg/scipy/ndimage/interpolation.py (spline_filter1d
+:105-182, spline_filter :185-268, map_coordinates :271-394, affine_transform
+:397-561, rotate :576-709, shift :712-802, zoom :805-990).  Orders 0 and 1 run
+the gather kernels directly; orders 2-5 first build float64 B-spline
+coefficients on the device (SciPy's rule: pad by 12 samples for `nearest` /
+`grid-constant`, then prefilter every axis with the boundary condition that
+matches the mode) and interpolate those -- rank <= 3, results equal to
+SciPy 1.15's to rounding.
 """
 import ctypes
 import warnings
@@ -15,7 +18,7 @@ import numpy as np
 from ... import core
 from . import _support as S
 
-__all__ = ["map_coordinates", "affine_transform"]
+__all__ = ["spline_filter1d", "spline_filter", "map_coordinates", "affine_transform", "shift", "zoom", "rotate"]
 
 _INTERP_MODES = ("constant", "grid-constant", "nearest", "mirror", "reflect", "grid-mirror", "wrap",
                  "grid-wrap")
@@ -31,11 +34,88 @@ def _check_parameter(func_name, order, mode):
         raise NotImplementedError("the 'opencv' pseudo-modes are not part of the scipy.ndimage API")
     if mode not in _INTERP_MODES:
         raise ValueError("boundary mode is not supported")
-    if order > 1:
-        raise NotImplementedError(
-            "{}: spline order {} needs the B-spline prefilter, which is not built yet "
-            "(orders 0 and 1 are)".format(func_name, order))
     return order
+
+
+def _spline_mode_code(mode):
+    """boundary condition of the prefilter for an extension mode (0 mirror, 1 reflect, 2 grid-wrap)"""
+    if mode in ("reflect", "grid-mirror", "nearest"):
+        return 1
+    if mode == "grid-wrap":
+        return 2
+    return 0
+
+
+def _to_coefficients(input, order, mode, cval, prefilter):
+    """(float64 device array of B-spline coefficients, npad) for orders 2-5.
+    SciPy pads by 12 samples for `nearest` / `grid-constant` before filtering;
+    prefilter=False interpolates the samples as if they were coefficients."""
+    if input.ndim > 3:
+        raise NotImplementedError("spline orders 2-5 are built for rank <= 3")
+    src = core.ascontiguousarray(input)
+    npad, pad_mode = 0, 0
+    if prefilter and mode in ("nearest", "grid-constant"):
+        npad, pad_mode = 12, (0 if mode == "nearest" else 1)
+    coef = core.empty(tuple(n + 2 * npad for n in src.shape), np.float64)
+    a, b = src._desc(), coef._desc()
+    lib = S.lib()
+    S.check(lib.mi_spline_pad(ctypes.byref(a), ctypes.byref(b), npad, pad_mode, float(cval), None))
+    if prefilter:
+        for ax in range(coef.ndim):
+            if coef.shape[ax] > 1:
+                S.check(lib.mi_spline_filter1d(ctypes.byref(b), ax, int(order), _spline_mode_code(mode), None))
+    return coef, npad
+
+
+def _spline_output(output, input):
+    if isinstance(output, core.ndarray):
+        if output.shape != input.shape:
+            raise ValueError("output shape is not correct")
+        return output
+    return core.empty(input.shape, np.dtype(output))
+
+
+def spline_filter1d(input, order=3, axis=-1, output=np.float64, mode="mirror", *, allow_float32=False):
+    """B-spline prefilter along one axis (interpolation.py:105-182)."""
+    if order < 0 or order > 5:
+        raise RuntimeError("spline order not supported")
+    input = S.as_device(input)
+    if mode not in _INTERP_MODES:
+        raise ValueError("boundary mode is not supported")
+    ret = _spline_output(output, input)
+    if order in (0, 1) or input.size == 0:
+        ret[...] = input
+        return ret
+    axis = S.normalize_axis(axis, input.ndim)
+    coef = core.ascontiguousarray(input).astype(np.float64)
+    if core.shares_memory(coef, input):
+        coef = coef.copy()
+    d = coef._desc()
+    if coef.shape[axis] > 1:
+        S.check(S.lib().mi_spline_filter1d(ctypes.byref(d), axis, int(order), _spline_mode_code(mode), None))
+    ret[...] = coef
+    return ret
+
+
+def spline_filter(input, order=3, output=np.float64, mode="mirror", *, allow_float32=False):
+    """Multidimensional B-spline prefilter (interpolation.py:185-268)."""
+    if order < 2 or order > 5:
+        raise RuntimeError("spline order not supported")
+    input = S.as_device(input)
+    if mode not in _INTERP_MODES:
+        raise ValueError("boundary mode is not supported")
+    ret = _spline_output(output, input)
+    if input.size == 0:
+        return ret
+    coef = core.ascontiguousarray(input).astype(np.float64)
+    if core.shares_memory(coef, input):
+        coef = coef.copy()
+    d = coef._desc()
+    for ax in range(coef.ndim):
+        if coef.shape[ax] > 1:
+            S.check(S.lib().mi_spline_filter1d(ctypes.byref(d), ax, int(order), _spline_mode_code(mode), None))
+    ret[...] = coef
+    return ret
 
 
 def _get_output(output, input, shape):
@@ -96,6 +176,15 @@ def map_coordinates(input, coordinates, output=None, order=3, mode="constant", c
     coords = core.ascontiguousarray(coords)
     cd = coords._desc()
     lib = S.lib()
+    if order > 1:
+        coef, npad = _to_coefficients(src, order, mode, cval, prefilter)
+        ca_ = coef._desc()
+
+        def launch_spline(dst):
+            b = dst._desc()
+            S.check(lib.mi_spline_map_coordinates(ctypes.byref(ca_), ctypes.byref(cd), ctypes.byref(b), order,
+                                                  S.MODE_CODES[mode], float(cval), npad, None), ValueError)
+        return _deliver(ret, launch_spline)
 
     def launch(dst):
         def fn(s):
@@ -148,9 +237,23 @@ def affine_transform(input, matrix, offset=0.0, output_shape=None, output=None, 
     m = np.zeros((ndim, ndim + 1), dtype=np.float64)
     m[:, :ndim] = matrix
     m[:, ndim] = offset
+    return _affine(input, m, out, order, mode, cval, prefilter)
+
+
+def _affine(input, m, out, order, mode, cval, prefilter):
+    """out[o] = interp(input, m[:, :n] @ o + m[:, n]) -- the launch behind affine_transform / shift / zoom / rotate"""
     mk, mp = S.c_doubles(m)
     src = core.ascontiguousarray(input)
     lib = S.lib()
+    if order > 1:
+        coef, npad = _to_coefficients(src, order, mode, cval, prefilter)
+        ca_ = coef._desc()
+
+        def launch_spline(dst):
+            b = dst._desc()
+            S.check(lib.mi_spline_affine_transform(ctypes.byref(ca_), ctypes.byref(b), mp, order, S.MODE_CODES[mode],
+                                                   float(cval), npad, None), ValueError)
+        return _deliver(out, launch_spline)
 
     def launch(dst):
         def fn(s):
@@ -162,3 +265,100 @@ def affine_transform(input, matrix, offset=0.0, output_shape=None, output=None, 
     if core.shares_memory(out, src):
         src = src.copy()
     return _deliver(out, launch)
+
+
+def shift(input, shift, output=None, order=3, mode="constant", cval=0.0, prefilter=True, *, allow_float32=True):
+    """Shift an array (interpolation.py:712-802): output[o] = input[o - shift]."""
+    order = _check_parameter("shift", order, mode)
+    input = S.as_device(input)
+    nd = input.ndim
+    sh = [float(v) for v in S.normalize_sequence(shift, nd)]
+    out = _get_output(output, input, input.shape)
+    if out.size == 0:
+        return out
+    m = np.zeros((nd, nd + 1))
+    m[:, :nd] = np.eye(nd)
+    m[:, nd] = [-v for v in sh]
+    return _affine(input, m, out, order, mode, cval, prefilter)
+
+
+def zoom(input, zoom, output=None, order=3, mode="constant", cval=0.0, prefilter=True, *, grid_mode=False,
+         allow_float32=True):
+    """Zoom an array (interpolation.py:805-990).  Output extents are
+    round(n * zoom); without grid_mode the corner samples map onto each other
+    (scale (n - 1) / (m - 1)), with it pixel edges do (scale n / m)."""
+    order = _check_parameter("zoom", order, mode)
+    input = S.as_device(input)
+    nd = input.ndim
+    zf = [float(v) for v in S.normalize_sequence(zoom, nd)]
+    oshape = tuple(int(round(n * z)) for n, z in zip(input.shape, zf))
+    if grid_mode:
+        if mode in ("constant", "wrap"):
+            warnings.warn("It is recommended to use mode = grid-{0} instead of {0} when grid_mode is True.".format(mode),
+                          stacklevel=2)
+        scale = [n / o if o > 0 else 1.0 for n, o in zip(input.shape, oshape)]
+        off = [0.5 * s - 0.5 for s in scale]
+    else:
+        scale = [(n - 1) / (o - 1) if o > 1 else 1.0 for n, o in zip(input.shape, oshape)]
+        off = [0.0] * nd
+    out = _get_output(output, input, oshape)
+    if out.size == 0:
+        return out
+    m = np.zeros((nd, nd + 1))
+    m[:, :nd] = np.diag(scale)
+    m[:, nd] = off
+    return _affine(input, m, out, order, mode, cval, prefilter)
+
+
+def _cos_sin_deg(angle):
+    """cos / sin of an angle in degrees, exact at multiples of 90 (like scipy.special.cosdg / sindg)"""
+    a = float(angle) % 360.0
+    if a % 90.0 == 0.0:
+        return [(1.0, 0.0), (0.0, 1.0), (-1.0, 0.0), (0.0, -1.0)][int(a // 90) % 4]
+    r = np.deg2rad(a)
+    return float(np.cos(r)), float(np.sin(r))
+
+
+def rotate(input, angle, axes=(1, 0), reshape=True, output=None, order=3, mode="constant", cval=0.0,
+           prefilter=True, *, allow_float32=True):
+    """Rotate an array in the plane of two axes (interpolation.py:576-709)."""
+    order = _check_parameter("rotate", order, mode)
+    input = S.as_device(input)
+    nd = input.ndim
+    if nd < 2:
+        raise ValueError("input array should be at least 2D")
+    axes = list(axes)
+    if len(axes) != 2:
+        raise ValueError("axes should contain exactly two values")
+    if not all(float(ax).is_integer() for ax in axes):
+        raise ValueError("axes should contain only integer values")
+    axes = [int(ax) + nd if ax < 0 else int(ax) for ax in axes]
+    if axes[0] >= nd or axes[1] >= nd or axes[0] < 0 or axes[1] < 0:
+        raise ValueError("invalid rotation plane specified")
+    axes.sort()
+    c, s = _cos_sin_deg(angle)
+    rot = np.array([[c, s], [-s, c]])
+    img_shape = np.asarray(input.shape)
+    in_plane = img_shape[axes]
+    if reshape:
+        iy, ix = in_plane
+        bounds = rot @ np.array([[0, 0, iy, iy], [0, ix, 0, ix]], dtype=np.float64)
+        out_plane = (np.ptp(bounds, axis=1) + 0.5).astype(int)
+    else:
+        out_plane = img_shape[axes]
+    out_center = rot @ ((out_plane - 1) / 2.0)
+    in_center = (in_plane - 1) / 2.0
+    offset = in_center - out_center
+    oshape = img_shape.copy()
+    oshape[axes] = out_plane
+    out = _get_output(output, input, tuple(int(v) for v in oshape))
+    if out.size == 0:
+        return out
+    # identity on the other axes: one launch instead of SciPy's loop over planes (the samples on those axes sit
+    # at integral coordinates, where the spline reproduces them)
+    m = np.zeros((nd, nd + 1))
+    m[:, :nd] = np.eye(nd)
+    m[axes[0], axes[0]], m[axes[0], axes[1]] = rot[0]
+    m[axes[1], axes[0]], m[axes[1], axes[1]] = rot[1]
+    m[axes[0], nd], m[axes[1], nd] = offset
+    return _affine(input, m, out, order, mode, cval, prefilter)

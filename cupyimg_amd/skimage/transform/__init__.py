@@ -4,8 +4,8 @@
 
 `inverse_map` may be a coordinate array of shape (ndim, *output_shape), a 3x3
 homogeneous matrix acting on (x, y) column/row coordinates, or a callable
-mapping (N, 2) output (x, y) pairs to input (x, y) pairs.  Spline orders 0 and
-1 are available (the default for non-bool images is 1, as in the reference)."""
+mapping (N, 2) output (x, y) pairs to input (x, y) pairs.  Spline orders 0-5
+(prefilter for orders > 1; the default for non-bool images is 1, as in the reference)."""
 import numpy as np
 
 from ... import core

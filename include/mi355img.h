@@ -240,6 +240,24 @@ int mi_map_coordinates(const mi_array *in, const mi_array *coords, const mi_arra
 int mi_affine_transform(const mi_array *in, const mi_array *out, const double *matrix,
                         int order, int mode, double cval, mi_stream stream);
 
+/* B-spline interpolation of order 2..5 (interpolation.py:105-268 spline_filter,
+ * :271-561 map_coordinates / affine_transform with order > 1; kernels
+ * _spline_prefilter_core.py, _spline_kernel_weights.py, _interp_kernels.py:473-549).
+ * The caller builds the float64 coefficient array -- mi_spline_pad (copy of any
+ * real dtype, extended by npad samples per side on every axis: pad_mode 0 edge
+ * replication, 1 cval; SciPy pads by 12 for `nearest` / `grid-constant`, else 0)
+ * followed by mi_spline_filter1d along every axis (spline_mode 0 mirror,
+ * 1 reflect, 2 grid-wrap: reflect for reflect / nearest, grid-wrap for grid-wrap,
+ * mirror otherwise) -- and interpolates it; coordinates refer to the unpadded
+ * array.  Rank <= 3. */
+int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mode, double cval,
+                  mi_stream stream);
+int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mode, mi_stream stream);
+int mi_spline_map_coordinates(const mi_array *coef, const mi_array *coords, const mi_array *out,
+                              int order, int mode, double cval, int npad, mi_stream stream);
+int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const double *matrix,
+                               int order, int mode, double cval, int npad, mi_stream stream);
+
 /* ------------------------------------------------------------------ */
 /* multi-GPU: slab partition on axis 0, halo exchange over RCCL/xGMI    */
 /* (new design; the reference is single-GPU)      */

@@ -15,8 +15,8 @@ _POSITIONAL = {
 _DEVICE_ARRAYS = {"input", "mask", "coordinates"}
 
 
-def load_scipy_fixtures():
-    z = np.load(os.path.join(GOLDEN, "scipy_fixtures.npz"))
+def load_scipy_fixtures(name="scipy_fixtures.npz"):
+    z = np.load(os.path.join(GOLDEN, name))
     cases = json.loads(str(z["__cases__"]))
     meta = json.loads(str(z["__meta__"]))
     return z, cases, meta

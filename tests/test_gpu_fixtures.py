@@ -63,3 +63,28 @@ def test_hip_matches_scipy_fixture(gpu, family):
         _check(c, got, expected, arrs["input"].dtype if "input" in arrs else None)
         n += 1
     assert n > 0
+
+
+ZS, SCASES, SMETA = load_scipy_fixtures("scipy_spline_fixtures.npz")
+SFAMILIES = sorted({c["family"] for c in SCASES})
+
+
+@pytest.mark.parametrize("family", SFAMILIES)
+def test_hip_matches_scipy_spline_fixture(gpu, family):
+    """B-spline prefilter and interpolation of order 2-5 against SciPy's own
+    outputs: 1e-11 for float64, 1e-6 for float32 results, exact for uint8."""
+    import warnings
+
+    from cupyimg_amd.scipy import ndimage as ndi
+    n = 0
+    for c in SCASES:
+        if c["family"] != family:
+            continue
+        arrs = {k: ZS[v] for k, v in c["arrays"].items()}
+        expected = ZS[c["expected"]]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = call(ndi, c["func"], arrs, c["kwargs"], to_device=gpu.asarray)
+        compare(got, expected, c["tol"], "case {} {} {}".format(c["id"], c["func"], c["kwargs"]))
+        n += 1
+    assert n > 0

@@ -323,8 +323,8 @@ def test_affine_and_map_3d(gpu, ndi):
     ref = orc.map_coordinates(x, coords, order=1, mode="constant")
     got = ndi.map_coordinates(xd, gpu.asarray(coords), order=1, mode="constant").get()
     assert np.allclose(got, ref, rtol=0, atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        ndi.map_coordinates(xd, gpu.asarray(coords), order=3)
+    with pytest.raises(ValueError):
+        ndi.map_coordinates(xd, gpu.asarray(coords), order=6)
 
 
 # ------------------------------------------------------------------ skimage facade
@@ -697,3 +697,90 @@ def test_affine_and_map_2d_images_take_the_fast_kernels(gpu, ndi):
                 ref = orc.map_coordinates(x, coords, order=order, mode=mode, cval=-1.0)
                 got = ndi.map_coordinates(xd, gpu.asarray(coords), order=order, mode=mode, cval=-1.0).get()
                 assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (cdt, mode, order)
+
+
+# ------------------------------------------------------------------ B-spline orders 2-5
+SPLINE_MODES = ["constant", "grid-constant", "nearest", "mirror", "reflect", "wrap", "grid-wrap"]
+
+
+def _close(got, ref, tol=1e-9):
+    return np.abs(np.asarray(got, dtype=np.float64) - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("shape", [(23,), (17, 19), (9, 10, 11), (1, 12), (6, 1, 7)])
+def test_spline_filter_matches_oracle(gpu, ndi, shape):
+    rng = np.random.default_rng(110)
+    x = rng.standard_normal(shape)
+    xd = gpu.asarray(x)
+    for order in (2, 3, 4, 5):
+        for mode in SPLINE_MODES + ["grid-mirror"]:
+            assert _close(ndi.spline_filter(xd, order, mode=mode).get(), orc.spline_filter(x, order, mode=mode)), (order, mode)
+            for ax in range(len(shape)):
+                got = ndi.spline_filter1d(xd, order, axis=ax, mode=mode).get()
+                assert _close(got, orc.spline_filter1d(x, order, ax, mode=mode)), (order, mode, ax)
+    assert ndi.spline_filter(gpu.asarray(x.astype(np.float32)), 3, output=np.float32).dtype == np.float32
+    assert np.array_equal(ndi.spline_filter1d(xd, 1).get(), x)
+    with pytest.raises(RuntimeError):
+        ndi.spline_filter(xd, 6)
+
+
+@pytest.mark.parametrize("shape", [(40,), (21, 26), (9, 12, 14)])
+@pytest.mark.parametrize("order", [2, 3, 4, 5])
+def test_spline_interpolation_matches_oracle(gpu, ndi, shape, order):
+    """map_coordinates / affine_transform / shift / zoom with spline orders 2-5:
+    device coefficients (pad + prefilter) and tap loop against the oracle, which
+    restates SciPy 1.15.3 (agreement 1e-14 there)."""
+    rng = np.random.default_rng(111)
+    nd = len(shape)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xd = gpu.asarray(x)
+    coords = rng.uniform(-20, max(shape) + 20, size=(nd, 300))
+    coords[:, 0] = 0.0
+    coords[:, 1] = [n - 1 for n in shape]
+    cdev = gpu.asarray(coords)
+    M = np.eye(nd) * 0.93 + rng.standard_normal((nd, nd)) * 0.08
+    off = rng.standard_normal(nd) * 2
+    for mode in SPLINE_MODES:
+        for pf in (True, False):
+            ref = orc.map_coordinates(x.astype(np.float64), coords, order=order, mode=mode, cval=0.7, prefilter=pf)
+            got = ndi.map_coordinates(xd, cdev, order=order, mode=mode, cval=0.7, prefilter=pf, output=np.float64).get()
+            assert _close(got, ref), ("map", mode, pf)
+        ref = orc.affine_transform(x.astype(np.float64), M, off, order=order, mode=mode, cval=0.7)
+        got = ndi.affine_transform(xd, M, off, order=order, mode=mode, cval=0.7, output=np.float64).get()
+        assert _close(got, ref), ("affine", mode)
+        # float32 in / out like a user would call it: same values rounded to float32
+        got32 = ndi.affine_transform(xd, M, off, order=order, mode=mode, cval=0.7).get()
+        assert got32.dtype == np.float32 and _close(got32, ref, 1e-6), ("affine f32", mode)
+        ref = orc.shift(x.astype(np.float64), 1.3, order=order, mode=mode, cval=0.7)
+        assert _close(ndi.shift(xd, 1.3, order=order, mode=mode, cval=0.7, output=np.float64).get(), ref), ("shift", mode)
+        for gm in (False, True):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = orc.zoom(x.astype(np.float64), 1.7, order=order, mode=mode, cval=0.7, grid_mode=gm)
+                got = ndi.zoom(xd, 1.7, order=order, mode=mode, cval=0.7, grid_mode=gm, output=np.float64).get()
+            assert got.shape == ref.shape and _close(got, ref), ("zoom", mode, gm)
+
+
+def test_spline_defaults_integers_and_rotate(gpu, ndi):
+    """default order 3 (what scipy.ndimage callers get), integer images (rounded
+    output), rotate against scipy.ndimage itself"""
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(112)
+    u = rng.integers(0, 256, size=(31, 37)).astype(np.uint8)
+    ud = gpu.asarray(u)
+    assert np.array_equal(ndi.zoom(ud, 2.0).get(), sndi.zoom(u, 2.0))
+    assert np.array_equal(ndi.shift(ud, (1.5, -2.25)).get(), sndi.shift(u, (1.5, -2.25)))
+    x = rng.standard_normal((24, 30))
+    xd = gpu.asarray(x)
+    for angle, reshape in [(30.0, True), (90.0, True), (-17.5, False), (180.0, False)]:
+        for order in (0, 1, 3):
+            ref = sndi.rotate(x, angle, reshape=reshape, order=order, mode="nearest")
+            got = ndi.rotate(xd, angle, reshape=reshape, order=order, mode="nearest").get()
+            assert got.shape == ref.shape and _close(got, ref, 1e-9), (angle, reshape, order)
+    v = rng.standard_normal((7, 12, 10))
+    ref = sndi.rotate(v, 25.0, axes=(2, 0), order=3, mode="mirror")
+    got = ndi.rotate(gpu.asarray(v), 25.0, axes=(2, 0), order=3, mode="mirror").get()
+    assert got.shape == ref.shape and _close(got, ref, 1e-9)
+    c = rng.uniform(0, 20, size=(2, 50))
+    assert _close(ndi.map_coordinates(xd, gpu.asarray(c)).get(), sndi.map_coordinates(x, c))     # defaults: order 3, constant

@@ -37,6 +37,26 @@ def test_oracle_matches_scipy_fixture(family):
     assert n > 0
 
 
+ZS, SCASES, SMETA = load_scipy_fixtures("scipy_spline_fixtures.npz")
+SFAMILIES = sorted({c["family"] for c in SCASES})
+
+
+@pytest.mark.parametrize("family", SFAMILIES)
+def test_oracle_matches_scipy_spline_fixture(family):
+    """B-spline prefilter / orders 2-5 (tests/golden/make_scipy_spline_fixtures.py)"""
+    n = 0
+    for c in SCASES:
+        if c["family"] != family:
+            continue
+        arrs = {k: ZS[v] for k, v in c["arrays"].items()}
+        expected = ZS[c["expected"]]
+        got = call(orc, c["func"], arrs, c["kwargs"])
+        compare(got, expected, c["tol"], "case {} {} {}".format(c["id"], c["func"], c["kwargs"]))
+        n += 1
+    assert n > 0
+    assert SMETA["scipy"] == "1.15.3"
+
+
 def test_fixture_metadata():
     assert META["scipy"] == "1.15.3"
     assert META["n_cases"] == len(CASES)
