@@ -302,6 +302,107 @@ affine_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Inte
     }
 }
 
+// Orders 2..5 with the order as a template parameter: weights and tap indices
+// stay in registers (every index is static after unrolling) -- the run-time
+// order version above keeps them in scratch memory.  Same arithmetic, same tap
+// order (z, y, x; weight product (wz * wy) * wx).
+template <int ORDER>
+__device__ __forceinline__ double spline_point_t(const double *__restrict__ in, const InterpGeom &g, const double (&c)[3],
+                                                 int mode, double cval, int npad)
+{
+    constexpr int NT = ORDER + 1;
+    double w[3][NT];
+    int64_t off[3][NT];            // element offset of the tap along its axis, or -1: the tap reads cval
+    int ntap[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const int64_t n = g.shape[d];
+        if (d < g.pad) {
+            ntap[d] = 1;
+#pragma unroll
+            for (int k = 0; k < NT; k++) { w[d][k] = 1.0; off[d][k] = 0; }
+            continue;
+        }
+        ntap[d] = NT;
+        double cc = c[d] + (double)npad;
+        if (mode == MI_MODE_CONSTANT) {
+            if (cc < 0 || cc > (double)(n - 1)) return cval;
+        } else if (mode != MI_MODE_GRID_CONSTANT && mode != MI_MODE_NEAREST) {
+            cc = fold_coord(cc, n, mode);
+        }
+        const double fl = (ORDER & 1) ? floor(cc) : floor(cc + 0.5);
+        const int64_t start = (int64_t)fl - ORDER / 2;
+        spline_weights(cc - fl, ORDER, w[d]);
+        const bool interior = start >= 0 && start + ORDER < n;
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const int64_t j = interior ? start + k : spline_tap(start + k, n, mode);
+            off[d][k] = j < 0 ? -1 : j * g.stride[d];
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int kz = 0; kz < NT; kz++) {
+        if (kz >= ntap[0]) break;
+#pragma unroll
+        for (int ky = 0; ky < NT; ky++) {
+            if (ky >= ntap[1]) break;
+            const double wzy = w[0][kz] * w[1][ky];
+            const bool oob_zy = off[0][kz] < 0 || off[1][ky] < 0;
+            const int64_t base = off[0][kz] + off[1][ky];
+#pragma unroll
+            for (int kx = 0; kx < NT; kx++) {
+                const bool oob = oob_zy || off[2][kx] < 0;
+                const double v = oob ? cval : in[base + off[2][kx]];
+                acc += v * (wzy * w[2][kx]);
+            }
+        }
+    }
+    return acc;
+}
+
+template <typename C, int ORDER>
+__global__ void __launch_bounds__(256)
+spline_map_kernel(const double *__restrict__ in, const C *__restrict__ coords, void *__restrict__ out, int out_dt,
+                  InterpGeom g, int64_t nout, int mode, double cval, int round_out, int npad)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (int64_t)gridDim.x * blockDim.x) {
+        double c[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) c[d] = d < g.pad ? 0.0 : (double)coords[(int64_t)(d - g.pad) * nout + i];
+        double v = spline_point_t<ORDER>(in, g, c, mode, cval, npad);
+        if (round_out) v = interp_round(v, out_dt);
+        store_as(out, i, out_dt, v);
+    }
+}
+
+template <int ORDER>
+__global__ void __launch_bounds__(256)
+spline_affine_kernel(const double *__restrict__ in, void *__restrict__ out, int out_dt, InterpGeom g, int64_t nout,
+                     int mode, double cval, int round_out, int npad)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (int64_t)gridDim.x * blockDim.x) {
+        double o[3], c[3];
+        int64_t r = i;
+#pragma unroll
+        for (int d = 2; d >= 0; d--) {
+            const int64_t q = r / g.oshape[d];
+            o[d] = (double)(r - q * g.oshape[d]);
+            r = q;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += g.mat[d * 4 + k] * o[k];
+            c[d] = s + g.mat[d * 4 + 3];
+        }
+        double v = spline_point_t<ORDER>(in, g, c, mode, cval, npad);
+        if (round_out) v = interp_round(v, out_dt);
+        store_as(out, i, out_dt, v);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // spline coefficients: padded float64 copy + in-place prefilter
 // ---------------------------------------------------------------------------
@@ -330,8 +431,15 @@ spline_pad_kernel(const T *__restrict__ in, double *__restrict__ out, InterpGeom
     }
 }
 
-// one thread per line; smode: 0 mirror, 1 reflect, 2 grid-wrap
-__global__ void __launch_bounds__(128)
+// One thread per line; smode: 0 mirror, 1 reflect, 2 grid-wrap.  The recursions
+// are sequential along the line, so the kernel is latency-bound: samples are
+// fetched eight at a time (independent loads in flight) before the dependent
+// chain runs over them in registers, the boundary sums stop once z^i is below
+// 1e-20 (SciPy sums the whole line; the neglected tail is far below one ulp), and
+// the gain is applied with the last store (the filter is linear).
+constexpr int kSplBatch = 8;
+
+__global__ void __launch_bounds__(64)
 spline_filter1d_kernel(double *__restrict__ data, int64_t n, int64_t inner, int64_t nlines, int order, int smode)
 {
     const int64_t line = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,36 +456,82 @@ spline_filter1d_kernel(double *__restrict__ data, int64_t n, int64_t inner, int6
     }
     double gain = 1.0;
     for (int k = 0; k < np; k++) gain *= (1.0 - zs[k]) * (1.0 - 1.0 / zs[k]);
-    for (int64_t i = 0; i < n; i++) c[i * st] *= gain;
     for (int k = 0; k < np; k++) {
         const double z = zs[k];
-        double z_i = z;
-        if (smode == 0) {
-            const double z_n_1 = pow(z, (double)(n - 1));
-            c[0] = c[0] + z_n_1 * c[(n - 1) * st];
-            for (int64_t i = 1; i < n - 1; i++) { c[0] += z_i * (c[i * st] + z_n_1 * c[(n - 1 - i) * st]); z_i *= z; }
-            c[0] /= 1 - z_n_1 * z_n_1;
-        } else if (smode == 2) {
-            for (int64_t i = 1; i < n; i++) { c[0] += z_i * c[(n - i) * st]; z_i *= z; }
-            c[0] /= 1 - z_i;
-        } else {
-            const double z_n = pow(z, (double)n), c0 = c[0];
-            c[0] = c[0] + z_n * c[(n - 1) * st];
-            for (int64_t i = 1; i < n; i++) { c[0] += z_i * (c[i * st] + z_n * c[(n - 1 - i) * st]); z_i *= z; }
-            c[0] *= z / (1 - z_n * z_n);
-            c[0] += c0;
+        const bool last_pole = k == np - 1;
+        int64_t H = (int64_t)ceil(-46.0517 / log(fabs(z)));        // |z|^H < 1e-20
+        // ---- causal initialisation
+        double c0 = c[0];
+        {
+            double z_i = z;
+            if (smode == 0) {
+                const double z_n_1 = pow(z, (double)(n - 1));
+                double acc = c0 + z_n_1 * c[(n - 1) * st];
+                const int64_t m = (n - 1 < H + 1) ? n - 1 : H + 1;
+                for (int64_t i = 1; i < m; i++) { acc += z_i * (c[i * st] + z_n_1 * c[(n - 1 - i) * st]); z_i *= z; }
+                c0 = acc / (1 - z_n_1 * z_n_1);
+            } else if (smode == 2) {
+                double acc = c0;
+                const int64_t m = (n < H + 1) ? n : H + 1;
+                for (int64_t i = 1; i < m; i++) { acc += z_i * c[(n - i) * st]; z_i *= z; }
+                const double z_n = pow(z, (double)n);
+                c0 = acc / (1 - z_n);
+            } else {
+                const double z_n = pow(z, (double)n);
+                double acc = c0 + z_n * c[(n - 1) * st];
+                const int64_t m = (n < H + 1) ? n : H + 1;
+                for (int64_t i = 1; i < m; i++) {
+                    // SciPy updates c[0] in place: the last term (i == n - 1) sees the partially summed value
+                    const double mirror_term = (i == n - 1) ? acc : c[(n - 1 - i) * st];
+                    acc += z_i * (c[i * st] + z_n * mirror_term);
+                    z_i *= z;
+                }
+                acc *= z / (1 - z_n * z_n);
+                c0 = acc + c0;
+            }
         }
-        for (int64_t i = 1; i < n; i++) c[i * st] += z * c[(i - 1) * st];
-        if (smode == 0) {
-            c[(n - 1) * st] = (z * c[(n - 2) * st] + c[(n - 1) * st]) * z / (z * z - 1);
-        } else if (smode == 2) {
-            z_i = z;
-            for (int64_t i = 0; i < n - 1; i++) { c[(n - 1) * st] += z_i * c[i * st]; z_i *= z; }
-            c[(n - 1) * st] *= z / (z_i - 1);
-        } else {
-            c[(n - 1) * st] *= z / (z - 1);
+        c[0] = c0;
+        // ---- causal sweep
+        double prev = c0;
+        int64_t i = 1;
+        for (; i + kSplBatch <= n; i += kSplBatch) {
+            double v[kSplBatch];
+#pragma unroll
+            for (int u = 0; u < kSplBatch; u++) v[u] = c[(i + u) * st];
+#pragma unroll
+            for (int u = 0; u < kSplBatch; u++) { prev = v[u] + z * prev; v[u] = prev; }
+#pragma unroll
+            for (int u = 0; u < kSplBatch; u++) c[(i + u) * st] = v[u];
         }
-        for (int64_t i = n - 2; i >= 0; i--) c[i * st] = z * (c[(i + 1) * st] - c[i * st]);
+        for (; i < n; i++) { prev = c[i * st] + z * prev; c[i * st] = prev; }
+        // ---- anti-causal initialisation (prev == c[n - 1] after the causal sweep)
+        double last = prev;
+        if (smode == 0) {
+            last = (z * c[(n - 2) * st] + last) * z / (z * z - 1);
+        } else if (smode == 2) {
+            double z_i = z, acc = last;
+            const int64_t m = (n - 1 < H) ? n - 1 : H;
+            for (int64_t j = 0; j < m; j++) { acc += z_i * c[j * st]; z_i *= z; }
+            const double z_n = pow(z, (double)n);
+            last = acc * z / (z_n - 1);
+        } else {
+            last *= z / (z - 1);
+        }
+        const double scale = last_pole ? gain : 1.0;
+        c[(n - 1) * st] = last * scale;
+        // ---- anti-causal sweep
+        double nxt = last;
+        int64_t j = n - 2;
+        for (; j - (kSplBatch - 1) >= 0; j -= kSplBatch) {
+            double v[kSplBatch];
+#pragma unroll
+            for (int u = 0; u < kSplBatch; u++) v[u] = c[(j - u) * st];
+#pragma unroll
+            for (int u = 0; u < kSplBatch; u++) { nxt = z * (nxt - v[u]); v[u] = nxt; }
+#pragma unroll
+            for (int u = 0; u < kSplBatch; u++) c[(j - u) * st] = v[u] * scale;
+        }
+        for (; j >= 0; j--) { nxt = z * (nxt - c[j * st]); c[j * st] = nxt * scale; }
     }
 }
 
@@ -557,7 +711,7 @@ int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mod
     int64_t inner = 1;
     for (int d = axis + 1; d < data->ndim; d++) inner *= data->shape[d];
     const int64_t n = data->shape[axis], nlines = total / n;
-    hipLaunchKernelGGL(spline_filter1d_kernel, dim3((unsigned)((nlines + 127) / 128)), dim3(128), 0, resolve_stream(stream),
+    hipLaunchKernelGGL(spline_filter1d_kernel, dim3((unsigned)((nlines + 63) / 64)), dim3(64), 0, resolve_stream(stream),
                        (double *)data->data, n, inner, nlines, order, spline_mode);
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -595,12 +749,19 @@ int mi_spline_map_coordinates(const mi_array *coef, const mi_array *coords, cons
     dim3 grid;
     grid_for(nout, 256, &grid);
     hipStream_t s = resolve_stream(stream);
-    if (coords->dtype == MI_F32)
-        hipLaunchKernelGGL((map_coordinates_kernel<double, float, 3>), grid, dim3(256), 0, s, (const double *)coef->data,
-                           (const float *)coords->data, out->data, out->dtype, g, nout, order, mode, cval, round_out, npad);
-    else
-        hipLaunchKernelGGL((map_coordinates_kernel<double, double, 3>), grid, dim3(256), 0, s, (const double *)coef->data,
-                           (const double *)coords->data, out->data, out->dtype, g, nout, order, mode, cval, round_out, npad);
+#define MI_SPL_MAP(C, ORD)                                                                                         \
+    hipLaunchKernelGGL((spline_map_kernel<C, ORD>), grid, dim3(256), 0, s, (const double *)coef->data,            \
+                       (const C *)coords->data, out->data, out->dtype, g, nout, mode, cval, round_out, npad)
+#define MI_SPL_MAP_ORD(C)                                                              \
+    switch (order) {                                                                   \
+    case 2: MI_SPL_MAP(C, 2); break;                                                   \
+    case 3: MI_SPL_MAP(C, 3); break;                                                   \
+    case 4: MI_SPL_MAP(C, 4); break;                                                   \
+    default: MI_SPL_MAP(C, 5); break;                                                  \
+    }
+    if (coords->dtype == MI_F32) { MI_SPL_MAP_ORD(float) } else { MI_SPL_MAP_ORD(double) }
+#undef MI_SPL_MAP_ORD
+#undef MI_SPL_MAP
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -626,8 +787,17 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
     const int round_out = out->dtype != MI_F32 && out->dtype != MI_F64 && out->dtype != MI_BOOL;
     dim3 grid;
     grid_for(nout, 256, &grid);
-    hipLaunchKernelGGL((affine_kernel<double, 3>), grid, dim3(256), 0, resolve_stream(stream), (const double *)coef->data,
-                       out->data, out->dtype, g, nout, order, mode, cval, round_out, npad);
+    hipStream_t s = resolve_stream(stream);
+#define MI_SPL_AFF(ORD)                                                                                           \
+    hipLaunchKernelGGL((spline_affine_kernel<ORD>), grid, dim3(256), 0, s, (const double *)coef->data, out->data, \
+                       out->dtype, g, nout, mode, cval, round_out, npad)
+    switch (order) {
+    case 2: MI_SPL_AFF(2); break;
+    case 3: MI_SPL_AFF(3); break;
+    case 4: MI_SPL_AFF(4); break;
+    default: MI_SPL_AFF(5); break;
+    }
+#undef MI_SPL_AFF
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
