@@ -87,6 +87,34 @@ __global__ void __launch_bounds__(256) any_diff_kernel(const T *__restrict__ a, 
     if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// out = a (op) b elementwise on contiguous arrays of one dtype, in that dtype's
+// own arithmetic (integers wrap like NumPy's same-dtype ufuncs); the building
+// block of the composite filters (laplace, gradient magnitude, top-hats ...).
+//   0 add, 1 subtract, 2 multiply, 3 sqrt(a) (integers: computed in double,
+//   truncated), 4 a + b - 2 c is not needed: composites chain the binary forms.
+template <typename T>
+__global__ void __launch_bounds__(256) elementwise_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+                                                          int64_t n, int op)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T x = a[i];
+        const T y = b ? b[i] : T(0);
+        T r;
+        if constexpr (std::is_same<T, bool>::value) {
+            r = op == 0 ? (x || y) : (op == 1 ? (x != y) : (op == 2 ? (x && y) : x));   // numpy: bool - bool is an error; xor is what the top-hats use
+        } else if constexpr (std::is_floating_point<T>::value) {
+            r = op == 0 ? x + y : (op == 1 ? x - y : (op == 2 ? x * y : (T)sqrt((double)x)));
+        } else {
+            typedef typename std::make_unsigned<T>::type U;
+            if (op == 0) r = (T)((U)x + (U)y);
+            else if (op == 1) r = (T)((U)x - (U)y);
+            else if (op == 2) r = (T)((U)x * (U)y);
+            else r = cast_from_f64<T>(sqrt((double)x));
+        }
+        out[i] = r;
+    }
+}
+
 }  // namespace mi
 
 using namespace mi;
@@ -189,6 +217,30 @@ int mi_any_diff(const mi_array *a, const mi_array *b, int32_t *flag_dev, mi_stre
                            (const uint64_t *)b->data, total, flag_dev);
     MI_HIP(hipGetLastError());
     return MI_OK;
+}
+
+int mi_elementwise(int op, const mi_array *a, const mi_array *b, const mi_array *out, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(a, "a")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(op >= 0 && op <= 3, MI_ERR_INVALID_ARG, "unknown elementwise operation");
+    MI_REQUIRE(op == 3 || b, MI_ERR_INVALID_ARG, "binary operation needs two operands");
+    if (b && (rc = check_array(b, "b"))) return rc;
+    MI_REQUIRE(same_shape(a, out) && a->dtype == out->dtype, MI_ERR_INVALID_ARG, "operands must agree in shape and dtype");
+    MI_REQUIRE(!b || (same_shape(a, b) && a->dtype == b->dtype), MI_ERR_INVALID_ARG, "operands must agree in shape and dtype");
+    MI_REQUIRE(is_contiguous(a) && is_contiguous(out) && (!b || is_contiguous(b)), MI_ERR_NOT_CONTIGUOUS,
+               "elementwise operations need C-contiguous arrays");
+    const int64_t n = numel(a);
+    if (n == 0) return MI_OK;
+    hipStream_t s = resolve_stream(stream);
+    dim3 grid;
+    grid_for(n, 256, &grid);
+    return dispatch_dtype(a->dtype, [&]<typename T>() -> int {
+        hipLaunchKernelGGL((elementwise_kernel<T>), grid, dim3(256), 0, s, (const T *)a->data, b ? (const T *)b->data : nullptr,
+                           (T *)out->data, n, op);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    });
 }
 
 }  // extern "C"

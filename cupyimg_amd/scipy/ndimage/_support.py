@@ -200,6 +200,27 @@ def run_passes(input, output, passes):
     return output
 
 
+_EW_OPS = {"add": 0, "subtract": 1, "multiply": 2, "sqrt": 3}
+
+
+def elementwise(op, a, b, out):
+    """out[...] = a (op) b in out's dtype (operands of another dtype are cast
+    first, like a NumPy ufunc with `out=`); integers wrap.  mi_elementwise."""
+    a = core.ascontiguousarray(a if a.dtype == out.dtype else a.astype(out.dtype))
+    if b is not None:
+        b = core.ascontiguousarray(b if b.dtype == out.dtype else b.astype(out.dtype))
+    dst = out if out._is_c_contiguous() else core.empty(out.shape, out.dtype)
+    da, dd = a._desc(), dst._desc()
+    if b is None:
+        check(lib().mi_elementwise(_EW_OPS[op], ctypes.byref(da), None, ctypes.byref(dd), None))
+    else:
+        db = b._desc()
+        check(lib().mi_elementwise(_EW_OPS[op], ctypes.byref(da), ctypes.byref(db), ctypes.byref(dd), None))
+    if dst is not out:
+        out[...] = dst
+    return out
+
+
 def c_doubles(values):
     arr = np.ascontiguousarray(values, dtype=np.float64)
     return arr, arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))

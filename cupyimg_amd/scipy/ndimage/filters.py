@@ -27,7 +27,8 @@ from . import _support as S
 __all__ = [
     "correlate1d", "convolve1d", "gaussian_filter1d", "gaussian_filter", "correlate", "convolve",
     "uniform_filter1d", "uniform_filter", "minimum_filter1d", "maximum_filter1d", "minimum_filter",
-    "maximum_filter",
+    "maximum_filter", "prewitt", "sobel", "generic_laplace", "laplace", "gaussian_laplace",
+    "generic_gradient_magnitude", "gaussian_gradient_magnitude",
 ]
 
 
@@ -540,3 +541,97 @@ def minimum_filter1d(input, size, axis=-1, output=None, mode="reflect", cval=0.0
 def maximum_filter1d(input, size, axis=-1, output=None, mode="reflect", cval=0.0, origin=0):
     """Maximum filter along a single axis (filters.py:1450-1475)."""
     return _min_or_max_1d(input, size, axis, output, mode, cval, origin, "max")
+
+
+# ----------------------------------------------------------------------------
+# derivative filters: compositions of the 1-D passes (filters.py:828-1252)
+# ----------------------------------------------------------------------------
+def _derivative_then_smooth(input, axis, output, mode, cval, smooth):
+    input = S.as_device(input)
+    axis = S.normalize_axis(axis, input.ndim)
+    output = S.get_output(output, input)
+    modes = S.normalize_sequence(mode, input.ndim)
+    correlate1d(input, [-1, 0, 1], axis, output, modes[axis], cval, 0, dtype_mode="ndimage")
+    for ii in range(input.ndim):
+        if ii != axis:
+            correlate1d(output, smooth, ii, output, modes[ii], cval, 0, dtype_mode="ndimage")
+    return output
+
+
+def prewitt(input, axis=-1, output=None, mode="reflect", cval=0.0):
+    """Prewitt filter (filters.py:828-862): derivative along `axis`, [1, 1, 1] along the others."""
+    return _derivative_then_smooth(input, axis, output, mode, cval, [1, 1, 1])
+
+
+def sobel(input, axis=-1, output=None, mode="reflect", cval=0.0):
+    """Sobel filter (filters.py:865-899): derivative along `axis`, [1, 2, 1] along the others."""
+    return _derivative_then_smooth(input, axis, output, mode, cval, [1, 2, 1])
+
+
+def generic_laplace(input, derivative2, output=None, mode="reflect", cval=0.0, extra_arguments=(),
+                    extra_keywords=None):
+    """Sum over the axes of a caller-supplied second derivative (filters.py:902-1011)."""
+    if extra_keywords is None:
+        extra_keywords = {}
+    input = S.as_device(input)
+    output = S.get_output(output, input)
+    if input.ndim == 0:
+        output[...] = input
+        return output
+    modes = S.normalize_sequence(mode, input.ndim)
+    derivative2(input, 0, output, modes[0], cval, *extra_arguments, **extra_keywords)
+    for ii in range(1, input.ndim):
+        tmp = derivative2(input, ii, output.dtype, modes[ii], cval, *extra_arguments, **extra_keywords)
+        S.elementwise("add", output, tmp, output)
+    return output
+
+
+def laplace(input, output=None, mode="reflect", cval=0.0):
+    """Laplace filter from [1, -2, 1] second differences (filters.py:1014-1043)."""
+    def derivative2(input, axis, output, mode, cval):
+        return correlate1d(input, [1, -2, 1], axis, output, mode, cval, 0, dtype_mode="ndimage")
+    return generic_laplace(input, derivative2, output, mode, cval)
+
+
+def gaussian_laplace(input, sigma, output=None, mode="reflect", cval=0.0, **kwargs):
+    """Laplace filter from Gaussian second derivatives (filters.py:1046-1087)."""
+    input = S.as_device(input)
+
+    def derivative2(input, axis, output, mode, cval, sigma, **kwargs):
+        order = [0] * input.ndim
+        order[axis] = 2
+        return gaussian_filter(input, sigma, order, output, mode, cval, **kwargs)
+    return generic_laplace(input, derivative2, output, mode, cval, extra_arguments=(sigma,), extra_keywords=kwargs)
+
+
+def generic_gradient_magnitude(input, derivative, output=None, mode="reflect", cval=0.0, extra_arguments=(),
+                               extra_keywords=None):
+    """sqrt of the summed squares of a caller-supplied first derivative (filters.py:1090-1150)."""
+    if extra_keywords is None:
+        extra_keywords = {}
+    input = S.as_device(input)
+    output = S.get_output(output, input)
+    if input.ndim == 0:
+        output[...] = input
+        return output
+    modes = S.normalize_sequence(mode, input.ndim)
+    derivative(input, 0, output, modes[0], cval, *extra_arguments, **extra_keywords)
+    S.elementwise("multiply", output, output, output)
+    for ii in range(1, input.ndim):
+        tmp = derivative(input, ii, output.dtype, modes[ii], cval, *extra_arguments, **extra_keywords)
+        S.elementwise("multiply", tmp, tmp, tmp)
+        S.elementwise("add", output, tmp, output)
+    S.elementwise("sqrt", output, None, output)
+    return output
+
+
+def gaussian_gradient_magnitude(input, sigma, output=None, mode="reflect", cval=0.0, **kwargs):
+    """Gradient magnitude from Gaussian first derivatives (filters.py:1153-1197)."""
+    input = S.as_device(input)
+
+    def derivative(input, axis, output, mode, cval, sigma, **kwargs):
+        order = [0] * input.ndim
+        order[axis] = 1
+        return gaussian_filter(input, sigma, order, output, mode, cval, **kwargs)
+    return generic_gradient_magnitude(input, derivative, output, mode, cval, extra_arguments=(sigma,),
+                                      extra_keywords=kwargs)

@@ -23,7 +23,8 @@ from . import filters
 
 __all__ = [
     "binary_erosion", "binary_dilation", "binary_opening", "binary_closing", "binary_hit_or_miss",
-    "binary_propagation", "binary_fill_holes", "grey_erosion", "grey_dilation",
+    "binary_propagation", "binary_fill_holes", "grey_erosion", "grey_dilation", "grey_opening", "grey_closing",
+    "morphological_gradient", "morphological_laplace", "white_tophat", "black_tophat",
     "generate_binary_structure", "iterate_structure",
 ]
 
@@ -94,7 +95,7 @@ def _binary_erosion(input, structure, iterations, mask, output, border_value, or
         # 0-d special case (morphology.py:262-268)
         res = input.astype(np.bool_)
         if not bool(structure):
-            res = core.asarray(~res.get())
+            res = _logical_not(res)
         output[...] = res
         return output
     for o, w in zip(origin, structure.shape):
@@ -203,10 +204,20 @@ def binary_closing(input, structure=None, iterations=1, output=None, origin=0, m
     return binary_erosion(tmp, structure, iterations, mask, output, border_value, origin, brute_force)
 
 
-def _logical(a, fn):
-    """tiny element-wise helpers on bool volumes, via the host only for the
-    composite operators below (not on the hot path)."""
-    return core.asarray(fn(a.get()))
+def _as_bool(a):
+    """a != 0 as a bool device array"""
+    return a if a.dtype == np.bool_ else a.astype(np.bool_)
+
+
+def _logical_not(a):
+    """~a for a bool device array (xor with ones, mi_elementwise)"""
+    out = core.empty(a.shape, np.bool_)
+    return S.elementwise("subtract", a, core.ones(a.shape, np.bool_), out)
+
+
+def _logical_and(a, b):
+    out = core.empty(a.shape, np.bool_)
+    return S.elementwise("multiply", a, b, out)
 
 
 def binary_hit_or_miss(input, structure1=None, structure2=None, output=None, origin1=0, origin2=None):
@@ -224,7 +235,7 @@ def binary_hit_or_miss(input, structure1=None, structure2=None, output=None, ori
         origin2 = S.fix_sequence_arg(origin2, input.ndim, "origin2", int)
     tmp1 = _binary_erosion(input, structure1, 1, None, None, 0, origin1, 0, False)
     result = _binary_erosion(input, structure2, 1, None, None, 0, origin2, 1, False)
-    res = core.asarray(np.logical_and(tmp1.get(), np.logical_not(result.get())))
+    res = _logical_and(_as_bool(tmp1), _logical_not(_as_bool(result)))
     if isinstance(output, core.ndarray):
         output[...] = res
         return None
@@ -239,10 +250,10 @@ def binary_propagation(input, structure=None, mask=None, output=None, border_val
 def binary_fill_holes(input, structure=None, output=None, origin=0):
     """Fill holes in binary objects (morphology.py:726-766)."""
     input = S.as_device(input)
-    mask = core.asarray(np.logical_not(input.get() != 0))
+    mask = _logical_not(_as_bool(input))
     tmp = core.zeros(mask.shape, np.bool_)
     res = binary_dilation(tmp, structure, -1, mask, None, 1, origin, brute_force=True)
-    res = core.asarray(np.logical_not(res.get()))
+    res = _logical_not(_as_bool(res))
     if isinstance(output, core.ndarray):
         output[...] = res
         return None
@@ -284,3 +295,53 @@ def grey_dilation(input, size=None, footprint=None, structure=None, output=None,
         if sz % 2 == 0:
             origin[i] -= 1
     return filters._min_or_max_filter(input, size, footprint, structure, output, mode, cval, origin, "max")
+
+
+def grey_opening(input, size=None, footprint=None, structure=None, output=None, mode="reflect", cval=0.0, origin=0):
+    """Greyscale opening: erosion, then dilation (morphology.py:887-935)."""
+    tmp = grey_erosion(input, size, footprint, structure, None, mode, cval, origin)
+    return grey_dilation(tmp, size, footprint, structure, output, mode, cval, origin)
+
+
+def grey_closing(input, size=None, footprint=None, structure=None, output=None, mode="reflect", cval=0.0, origin=0):
+    """Greyscale closing: dilation, then erosion (morphology.py:938-986)."""
+    tmp = grey_dilation(input, size, footprint, structure, None, mode, cval, origin)
+    return grey_erosion(tmp, size, footprint, structure, output, mode, cval, origin)
+
+
+def morphological_gradient(input, size=None, footprint=None, structure=None, output=None, mode="reflect",
+                           cval=0.0, origin=0):
+    """dilation - erosion (morphology.py:989-1047)."""
+    input = S.as_device(input)
+    tmp = grey_dilation(input, size, footprint, structure, None, mode, cval, origin)
+    ero = grey_erosion(input, size, footprint, structure, output if isinstance(output, core.ndarray) else None,
+                       mode, cval, origin)
+    return S.elementwise("subtract", tmp, ero, ero)
+
+
+def morphological_laplace(input, size=None, footprint=None, structure=None, output=None, mode="reflect",
+                          cval=0.0, origin=0):
+    """dilation + erosion - 2 input (morphology.py:1050-1105)."""
+    input = S.as_device(input)
+    tmp1 = grey_dilation(input, size, footprint, structure, None, mode, cval, origin)
+    tmp2 = grey_erosion(input, size, footprint, structure, output if isinstance(output, core.ndarray) else None,
+                        mode, cval, origin)
+    S.elementwise("add", tmp1, tmp2, tmp2)
+    S.elementwise("subtract", tmp2, input, tmp2)
+    return S.elementwise("subtract", tmp2, input, tmp2)
+
+
+def white_tophat(input, size=None, footprint=None, structure=None, output=None, mode="reflect", cval=0.0, origin=0):
+    """input - opening (xor for bool images) (morphology.py:1108-1166)."""
+    input = S.as_device(input)
+    tmp = grey_erosion(input, size, footprint, structure, None, mode, cval, origin)
+    tmp = grey_dilation(tmp, size, footprint, structure, output, mode, cval, origin)
+    return S.elementwise("subtract", input, tmp, tmp)       # bool - bool is xor
+
+
+def black_tophat(input, size=None, footprint=None, structure=None, output=None, mode="reflect", cval=0.0, origin=0):
+    """closing - input (xor for bool images) (morphology.py:1169-1226)."""
+    input = S.as_device(input)
+    tmp = grey_dilation(input, size, footprint, structure, None, mode, cval, origin)
+    tmp = grey_erosion(tmp, size, footprint, structure, output, mode, cval, origin)
+    return S.elementwise("subtract", tmp, input, tmp)

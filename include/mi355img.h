@@ -137,6 +137,12 @@ int mi_copy(const mi_array *src, const mi_array *dst, int round_half_even, mi_st
 int mi_fill(const mi_array *dst, double value, mi_stream stream);
 /* *flag_dev (device int32) |= any(a != b); a, b contiguous, same dtype/shape */
 int mi_any_diff(const mi_array *a, const mi_array *b, int32_t *flag_dev, mi_stream stream);
+/* out = a (op) b, elementwise, one dtype, C-contiguous; op: 0 add, 1 subtract,
+ * 2 multiply, 3 sqrt(a) (b may be NULL).  Integers wrap like NumPy's same-dtype
+ * ufuncs.  Used by the composite filters built on the path (generic_laplace
+ * `output += tmp` filters.py:1005-1011, generic_gradient_magnitude :1134-1147,
+ * top-hats / morphological gradient morphology.py:887-1226). */
+int mi_elementwise(int op, const mi_array *a, const mi_array *b, const mi_array *out, mi_stream stream);
 
 /* ------------------------------------------------------------------ */
 /* K1: correlate family                                                 */

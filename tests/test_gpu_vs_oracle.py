@@ -784,3 +784,47 @@ def test_spline_defaults_integers_and_rotate(gpu, ndi):
     assert got.shape == ref.shape and _close(got, ref, 1e-9)
     c = rng.uniform(0, 20, size=(2, 50))
     assert _close(ndi.map_coordinates(xd, gpu.asarray(c)).get(), sndi.map_coordinates(x, c))     # defaults: order 3, constant
+
+
+# ------------------------------------------------------------------ composite filters (derivatives, top-hats)
+@pytest.mark.parametrize("dtype", ["float32", "float64", "uint8", "int16"])
+def test_derivative_and_morphological_composites_match_scipy(gpu, ndi, dtype):
+    """prewitt / sobel / laplace / gaussian_laplace / gaussian_gradient_magnitude and
+    the grey-morphology composites are chains of the path's filters plus
+    element-wise device arithmetic (mi_elementwise); compared with scipy.ndimage."""
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(120)
+    for shape in [(20, 33), (9, 14, 16)]:
+        if np.dtype(dtype).kind == "f":
+            x = rng.standard_normal(shape).astype(dtype)
+        else:
+            x = rng.integers(0, 100, size=shape).astype(dtype)
+        xd = gpu.asarray(x)
+        tol = 0 if np.dtype(dtype).kind in "iu" else (2e-6 if dtype == "float32" else 1e-12)
+
+        def same(got, ref, what):
+            got = got.get()
+            assert got.dtype == ref.dtype and got.shape == ref.shape, what
+            if tol == 0:
+                assert np.array_equal(got, ref), what
+            else:
+                assert np.abs(got.astype(np.float64) - ref).max() <= tol * max(1.0, np.abs(ref).max()), what
+        for mode in ["reflect", "constant", "nearest", "mirror", "wrap"]:
+            for ax in range(len(shape)):
+                same(ndi.prewitt(xd, axis=ax, mode=mode, cval=2.0), sndi.prewitt(x, axis=ax, mode=mode, cval=2.0), ("prewitt", mode, ax))
+                same(ndi.sobel(xd, axis=ax, mode=mode, cval=2.0), sndi.sobel(x, axis=ax, mode=mode, cval=2.0), ("sobel", mode, ax))
+            same(ndi.laplace(xd, mode=mode, cval=2.0), sndi.laplace(x, mode=mode, cval=2.0), ("laplace", mode))
+            if np.dtype(dtype).kind == "f":
+                same(ndi.gaussian_laplace(xd, 1.0, mode=mode), sndi.gaussian_laplace(x, 1.0, mode=mode), ("glaplace", mode))
+                same(ndi.gaussian_gradient_magnitude(xd, 1.2, mode=mode), sndi.gaussian_gradient_magnitude(x, 1.2, mode=mode),
+                     ("ggm", mode))
+            for fn, sfn in [(ndi.morphological_gradient, sndi.morphological_gradient), (ndi.morphological_laplace, sndi.morphological_laplace),
+                            (ndi.white_tophat, sndi.white_tophat), (ndi.black_tophat, sndi.black_tophat),
+                            (ndi.grey_opening, sndi.grey_opening), (ndi.grey_closing, sndi.grey_closing)]:
+                same(fn(xd, size=3, mode=mode, cval=2.0), sfn(x, size=3, mode=mode, cval=2.0), (fn.__name__, mode))
+    b = rng.random((20, 33)) > 0.5
+    fp = np.ones((3, 3), bool)
+    assert np.array_equal(ndi.white_tophat(gpu.asarray(b), footprint=fp).get(), sndi.white_tophat(b, footprint=fp))
+    assert np.array_equal(ndi.black_tophat(gpu.asarray(b), footprint=fp).get(), sndi.black_tophat(b, footprint=fp))
+    assert np.array_equal(ndi.binary_hit_or_miss(gpu.asarray(b)).get(), sndi.binary_hit_or_miss(b))
+    assert np.array_equal(ndi.binary_fill_holes(gpu.asarray(b)).get(), sndi.binary_fill_holes(b))
