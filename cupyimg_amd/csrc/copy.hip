@@ -5,6 +5,8 @@
 // cupyimg/scipy/ndimage/_filters_core.py:94,107,154, morphology.py:313,321).
 // Cast rules follow _filters_core.py:166-187 / SciPy: truncate toward zero,
 // negative -> unsigned wraps.
+#include <vector>
+
 #include "common.hpp"
 
 namespace mi {
@@ -113,6 +115,45 @@ __global__ void __launch_bounds__(256) elementwise_kernel(const T *__restrict__ 
         }
         out[i] = r;
     }
+}
+
+// out = a * s + t (op 0) or clip(a, lo, hi) keeping entries equal to `keep`
+// when keep_flag is set (op 1); floating-point arrays (skimage facade: dtype
+// range scaling, warp's output clipping, _warps.py:745-787)
+template <typename T>
+__global__ void __launch_bounds__(256) scalar_op_kernel(const T *__restrict__ a, T *__restrict__ out, int64_t n, int op,
+                                                        double p0, double p1, double keep, int keep_flag)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = (double)a[i];
+        double r;
+        if (op == 0) r = x * p0 + p1;
+        else r = (keep_flag && x == keep) ? x : fmin(fmax(x, p0), p1);
+        out[i] = (T)r;
+    }
+}
+
+// per-block minimum / maximum of a contiguous array (NaNs are skipped, like fmin / fmax)
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_reduce_kernel(const T *__restrict__ a, int64_t n, double *__restrict__ part)
+{
+    __shared__ double slo[256], shi[256];
+    double lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = (double)a[i];
+        lo = fmin(lo, x);
+        hi = fmax(hi, x);
+    }
+    slo[threadIdx.x] = lo; shi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) {
+            slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + sft]);
+            shi[threadIdx.x] = fmax(shi[threadIdx.x], shi[threadIdx.x + sft]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = slo[0]; part[2 * blockIdx.x + 1] = shi[0]; }
 }
 
 }  // namespace mi
@@ -241,6 +282,62 @@ int mi_elementwise(int op, const mi_array *a, const mi_array *b, const mi_array 
         MI_HIP(hipGetLastError());
         return MI_OK;
     });
+}
+
+int mi_scalar_op(int op, const mi_array *a, const mi_array *out, double p0, double p1, double keep, int keep_flag,
+                 mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(a, "a")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(op == 0 || op == 1, MI_ERR_INVALID_ARG, "unknown scalar operation");
+    MI_REQUIRE(same_shape(a, out) && a->dtype == out->dtype && (a->dtype == MI_F32 || a->dtype == MI_F64), MI_ERR_INVALID_ARG,
+               "float32 / float64 arrays of one shape");
+    MI_REQUIRE(is_contiguous(a) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "needs C-contiguous arrays");
+    const int64_t n = numel(a);
+    if (n == 0) return MI_OK;
+    dim3 grid;
+    grid_for(n, 256, &grid);
+    hipStream_t s = resolve_stream(stream);
+    if (a->dtype == MI_F32)
+        hipLaunchKernelGGL((scalar_op_kernel<float>), grid, dim3(256), 0, s, (const float *)a->data, (float *)out->data, n, op, p0,
+                           p1, keep, keep_flag);
+    else
+        hipLaunchKernelGGL((scalar_op_kernel<double>), grid, dim3(256), 0, s, (const double *)a->data, (double *)out->data, n, op,
+                           p0, p1, keep, keep_flag);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_min_max(const mi_array *a, double *lo, double *hi, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(a, "a"))) return rc;
+    MI_REQUIRE(lo && hi, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(is_contiguous(a), MI_ERR_NOT_CONTIGUOUS, "needs a C-contiguous array");
+    const int64_t n = numel(a);
+    MI_REQUIRE(n > 0, MI_ERR_INVALID_ARG, "empty array");
+    const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+    void *part = nullptr;
+    if ((rc = pool_alloc(&part, (size_t)blocks * 2 * sizeof(double)))) return rc;
+    hipStream_t s = resolve_stream(stream);
+    rc = dispatch_dtype(a->dtype, [&]<typename T>() -> int {
+        hipLaunchKernelGGL((minmax_reduce_kernel<T>), dim3(blocks), dim3(256), 0, s, (const T *)a->data, n, (double *)part);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    });
+    if (rc == MI_OK) {
+        std::vector<double> host((size_t)blocks * 2);
+        hipError_t e = hipMemcpyAsync(host.data(), part, host.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_error("HIP error: %s", hipGetErrorString(e)); rc = MI_ERR_INTERNAL; }
+        else {
+            double l = INFINITY, h = -INFINITY;
+            for (int b = 0; b < blocks; b++) { l = fmin(l, host[2 * b]); h = fmax(h, host[2 * b + 1]); }
+            *lo = l; *hi = h;
+        }
+    }
+    pool_free(part);
+    return rc;
 }
 
 }  // extern "C"

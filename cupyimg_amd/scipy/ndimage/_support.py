@@ -221,6 +221,34 @@ def elementwise(op, a, b, out):
     return out
 
 
+def scale_shift(a, scale, shift):
+    """a * scale + shift for a float device array (mi_scalar_op)"""
+    a = core.ascontiguousarray(a)
+    out = core.empty(a.shape, a.dtype)
+    da, dd = a._desc(), out._desc()
+    check(lib().mi_scalar_op(0, ctypes.byref(da), ctypes.byref(dd), float(scale), float(shift), 0.0, 0, None))
+    return out
+
+
+def clip(a, lo, hi, keep=None):
+    """clip a float device array to [lo, hi]; entries equal to `keep` stay"""
+    a = core.ascontiguousarray(a)
+    out = core.empty(a.shape, a.dtype)
+    da, dd = a._desc(), out._desc()
+    check(lib().mi_scalar_op(1, ctypes.byref(da), ctypes.byref(dd), float(lo), float(hi),
+                             0.0 if keep is None else float(keep), int(keep is not None), None))
+    return out
+
+
+def min_max(a):
+    """(min, max) of a device array as Python floats (one small read-back)"""
+    a = core.ascontiguousarray(a)
+    lo, hi = ctypes.c_double(), ctypes.c_double()
+    da = a._desc()
+    check(lib().mi_min_max(ctypes.byref(da), ctypes.byref(lo), ctypes.byref(hi), None))
+    return lo.value, hi.value
+
+
 def c_doubles(values):
     arr = np.ascontiguousarray(values, dtype=np.float64)
     return arr, arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))

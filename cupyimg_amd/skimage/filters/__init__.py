@@ -6,6 +6,7 @@ import numpy as np
 
 from ... import core
 from ...scipy import ndimage as ndi
+from ...scipy.ndimage import _support as S
 
 __all__ = ["gaussian"]
 
@@ -38,12 +39,9 @@ def _img_as_float(image):
         raise ValueError("cannot convert {} images to float".format(dt))
     lo, hi = _INT_RANGE[dt]
     out = image.astype(np.float64)
-    host_scale = 1.0 / hi if dt.kind == "u" else None
-    # scaling is an element-wise multiply: expressed as a 1-tap correlate on the device
     if dt.kind == "u":
-        return ndi.correlate1d(out, [host_scale], axis=0, dtype_mode="ndimage")
-    res = ndi.correlate1d(out, [2.0 / (hi - lo)], axis=0, dtype_mode="ndimage")      # (x*2 + 1) / (hi - lo)
-    return core.asarray(res.get() + 1.0 / (hi - lo))
+        return S.scale_shift(out, 1.0 / hi, 0.0)
+    return S.scale_shift(out, 2.0 / (hi - lo), 1.0 / (hi - lo))      # (2 x + 1) / (hi - lo)
 
 
 def convert_to_float(image, preserve_range):

@@ -10,6 +10,7 @@ import numpy as np
 
 from ... import core
 from ...scipy import ndimage as ndi
+from ...scipy.ndimage import _support as S
 from ..filters import convert_to_float
 
 __all__ = ["warp", "warp_coords"]
@@ -89,15 +90,8 @@ def warp(image, inverse_map, map_args={}, output_shape=None, order=None, mode="c
     warped = ndi.map_coordinates(image, coords, prefilter=order > 1, mode=_to_ndimage_mode(mode), order=order,
                                  cval=cval)
     if clip and order != 0:
-        # clip to the input range, keeping cval where it marks the outside (_warps.py:745-787);
-        # a tiny reduction done through the host (not on the hot path)
-        img = image.get()
-        lo, hi = float(img.min()), float(img.max())
-        out = warped.get()
+        # clip to the input range, keeping cval where it marks the outside (_warps.py:745-787)
+        lo, hi = S.min_max(image)
         keep = (mode == "constant") and not (lo <= cval <= hi)
-        mask = out == cval if keep else None
-        np.clip(out, lo, hi, out=out)
-        if keep:
-            out[mask] = cval
-        warped = core.asarray(out)
+        warped = S.clip(warped, lo, hi, cval if keep else None)
     return warped

@@ -371,6 +371,18 @@ def test_skimage_facade(gpu):
     exp = np.clip(ref, fimg.min(), fimg.max())
     exp[ref == 0.0] = 0.0          # cval outside the input range is preserved (_warps.py:779-787)
     assert np.allclose(w, exp, atol=1e-12)
+    # cubic warp (prefilter on the device); clipping keeps the overshoot inside the input range
+    w3 = skt.warp(gpu.asarray(fimg), H, order=3).get()
+    ref3 = sndi.map_coordinates(fimg, [src[:, 1].reshape(fimg.shape), src[:, 0].reshape(fimg.shape)], order=3,
+                                mode="constant", cval=0.0)
+    exp3 = np.clip(ref3, fimg.min(), fimg.max())
+    exp3[ref3 == 0.0] = 0.0
+    assert np.allclose(w3, exp3, atol=1e-10)
+    # signed integer images scale to [-1, 1]: (2 x + 1) / (max - min)
+    i16 = rng.integers(-3000, 3000, size=(12, 14)).astype(np.int16)
+    g = skf.gaussian(gpu.asarray(i16), sigma=1.0).get()
+    ref = sndi.gaussian_filter((2.0 * i16.astype(np.float64) + 1.0) / 65535.0, 1.0, mode="nearest")
+    assert np.allclose(g, ref, atol=1e-12)
 
 
 # ------------------------------------------------------------------ > 4 GiB volumes
