@@ -122,6 +122,54 @@ minmax3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Geo
     store_as(out, v.lin, out_dt, best);
 }
 
+// rank / median / percentile filters (reference: filters.py:1560-1848, kernel
+// _get_rank_kernel :1716-1800): the footprint's samples are gathered like in
+// minmax3_kernel and the `rank`-th smallest is found by partial selection on a
+// per-thread array (footprints up to kMaxRankTaps samples, rank <= 3 arrays).
+constexpr int kMaxRankTaps = 128;
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+rank3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Geom3 g, Taps3 tt, int mode, double cval, int rank)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsTaps lt = stage_taps(tt, smem);
+    const Vox3 v = locate3(g);
+    if (!v.valid) return;
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)((unsigned)g.nz * g.ny * g.nx * sizeof(T)), 0x00020000);
+    double vals[kMaxRankTaps];
+    const int n = tt.ntaps;
+    if (v.interior) {
+        const unsigned base = (unsigned)v.lin * (unsigned)sizeof(T);
+        for (int t = 0; t < n; t++) vals[t] = (double)buf_load<T>(rin, base + (unsigned)(lt.lin[t] * (int)sizeof(T)));
+    } else {
+        for (int t = 0; t < n; t++) {
+            const int pos = tap_pos3(g, v, lt, t, mode);
+            vals[t] = pos < 0 ? cval : (double)buf_load<T>(rin, (unsigned)pos * (unsigned)sizeof(T));
+        }
+    }
+    // partial selection from whichever end is closer
+    double res;
+    if (rank <= n / 2) {
+        for (int k = 0; k <= rank; k++) {
+            int m = k;
+            for (int j = k + 1; j < n; j++) if (vals[j] < vals[m]) m = j;
+            const double tmp = vals[k]; vals[k] = vals[m]; vals[m] = tmp;
+        }
+        res = vals[rank];
+    } else {
+        const int r = n - 1 - rank;
+        for (int k = 0; k <= r; k++) {
+            int m = k;
+            for (int j = k + 1; j < n; j++) if (vals[j] > vals[m]) m = j;
+            const double tmp = vals[k]; vals[k] = vals[m]; vals[m] = tmp;
+        }
+        res = vals[r];
+    }
+    store_as(out, v.lin, out_dt, res);
+}
+
 }  // namespace mi
 
 namespace mi {
@@ -245,6 +293,44 @@ int mi_minmax_nd(const mi_array *in, const mi_array *out, const uint8_t *footpri
         else
             hipLaunchKernelGGL((minmax_nd_kernel<T, MI_MAX_NDIM>), grid, dim3(256), 0, s, ip, out->data,
                                out->dtype, tb.g, tt, total, mode, cv, is_max);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    });
+}
+
+int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footprint, const int64_t *fshape,
+                   const int *origins, int rank, int mode, double cval, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(in->ndim >= 1, MI_ERR_INVALID_ARG, "input must have at least one dimension");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    MI_REQUIRE(footprint && fshape && origins, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "rank filter needs C-contiguous arrays");
+    MI_REQUIRE(in->data != out->data, MI_ERR_INVALID_ARG, "in-place filtering is not supported by the kernel");
+    if (numel(in) == 0) return MI_OK;
+    if (!Taps3Builder::eligible(in, fshape)) { set_error("rank filter: rank <= 3 arrays below 4 GiB only"); return MI_ERR_UNSUPPORTED; }
+    hipStream_t s = resolve_stream(stream);
+    mode = filter_mode(mode);
+    Taps3Builder t3;
+    Taps3 tt3;
+    if ((rc = t3.build(in, fshape, origins, [&](int64_t k) { return footprint[k] != 0; }, [](int64_t) { return 0.0; }, false)))
+        return rc;
+    const int n = (int)t3.lin.size();
+    MI_REQUIRE(n > 0, MI_ERR_INVALID_ARG, "all-zero footprint is not supported");
+    MI_REQUIRE(rank >= 0 && rank < n, MI_ERR_INVALID_ARG, "rank not within filter footprint size");
+    if (n > kMaxRankTaps) { set_error("rank filter: footprints of more than %d samples are not built", kMaxRankTaps); return MI_ERR_UNSUPPORTED; }
+    if ((rc = t3.finish(&tt3, s))) return rc;
+    return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
+        double cv;
+        if constexpr (std::is_same<T, double>::value) cv = cval;
+        else if constexpr (std::is_same<T, float>::value) cv = (double)(float)cval;
+        else if constexpr (std::is_same<T, bool>::value) cv = cval != 0.0;
+        else if constexpr (std::is_same<T, uint64_t>::value)
+            cv = (double)(cval >= 0 ? (uint64_t)cval : (uint64_t)(-(int64_t)(uint64_t)(-cval)));
+        else cv = (double)(T)(int64_t)cval;
+        hipLaunchKernelGGL((rank3_kernel<T>), grid3(t3.g), dim3(64, 4, 1), taps3_lds_bytes(tt3), s, (const T *)in->data, out->data,
+                           out->dtype, t3.g, tt3, mode, cv, rank);
         MI_HIP(hipGetLastError());
         return MI_OK;
     });

@@ -28,7 +28,8 @@ __all__ = [
     "correlate1d", "convolve1d", "gaussian_filter1d", "gaussian_filter", "correlate", "convolve",
     "uniform_filter1d", "uniform_filter", "minimum_filter1d", "maximum_filter1d", "minimum_filter",
     "maximum_filter", "prewitt", "sobel", "generic_laplace", "laplace", "gaussian_laplace",
-    "generic_gradient_magnitude", "gaussian_gradient_magnitude",
+    "generic_gradient_magnitude", "gaussian_gradient_magnitude", "rank_filter", "median_filter",
+    "percentile_filter",
 ]
 
 
@@ -635,3 +636,79 @@ def gaussian_gradient_magnitude(input, sigma, output=None, mode="reflect", cval=
         return gaussian_filter(input, sigma, order, output, mode, cval, **kwargs)
     return generic_gradient_magnitude(input, derivative, output, mode, cval, extra_arguments=(sigma,),
                                       extra_keywords=kwargs)
+
+
+# ----------------------------------------------------------------------------
+# rank / median / percentile (filters.py:1560-1848)
+# ----------------------------------------------------------------------------
+def _rank_filter(input, rank, size, footprint, output, mode, cval, origin, operation):
+    if size is not None and footprint is not None:
+        warnings.warn("ignoring size because footprint is set", UserWarning, stacklevel=3)
+    input = S.as_device(input)
+    _check_real(input)
+    if footprint is None:
+        if size is None:
+            raise RuntimeError("no footprint or filter size provided")
+        sizes = S.normalize_sequence(size, input.ndim)
+        footprint = np.ones([int(v) for v in sizes], dtype=bool)
+    else:
+        footprint = S.as_host(footprint).astype(bool)
+    origins = S.fix_sequence_arg(origin, input.ndim, "origin", int)
+    fshape = [ii for ii in footprint.shape if ii > 0]
+    if len(fshape) != input.ndim:
+        raise RuntimeError("filter footprint array has incorrect shape.")
+    for o, lenf in zip(origins, fshape):
+        S.check_origin(o, lenf)
+    filter_size = int(np.count_nonzero(footprint))
+    if operation == "median":
+        rank = filter_size // 2
+    elif operation == "percentile":
+        percentile = rank
+        if percentile < 0.0:
+            percentile += 100.0
+        if percentile < 0 or percentile > 100:
+            raise RuntimeError("invalid percentile")
+        rank = filter_size - 1 if percentile == 100.0 else int(float(filter_size) * percentile / 100.0)
+    rank = int(rank)
+    if rank < 0:
+        rank += filter_size
+    if rank < 0 or rank >= filter_size:
+        raise RuntimeError("rank not within filter footprint size")
+    if rank == 0:
+        return minimum_filter(input, None, footprint, output, mode, cval, origins)
+    if rank == filter_size - 1:
+        return maximum_filter(input, None, footprint, output, mode, cval, origins)
+    if not isinstance(mode, str):
+        raise RuntimeError("A sequence of modes is not supported by non-separable rank filters")
+    S.check_mode(mode)
+    output = S.get_output(output, input)
+    if input.size == 0:
+        return output
+    fp = np.ascontiguousarray(footprint, dtype=np.uint8)
+    fpp = fp.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    fsh = S.c_int64s(fp.shape)
+    org = S.c_ints(origins)
+
+    def launch(src, dst):
+        a, b = src._desc(), dst._desc()
+        try:
+            S.check(S.lib().mi_rank_filter(ctypes.byref(a), ctypes.byref(b), fpp, fsh, org, rank, S.mode_code(mode),
+                                           float(cval), None))
+        except S.Unsupported as exc:
+            raise NotImplementedError(str(exc))
+    return S.run_kernel(input, output, launch)
+
+
+def rank_filter(input, rank, size=None, footprint=None, output=None, mode="reflect", cval=0.0, origin=0):
+    """Multidimensional rank filter (filters.py:1704-1748)."""
+    return _rank_filter(input, int(rank), size, footprint, output, mode, cval, origin, "rank")
+
+
+def median_filter(input, size=None, footprint=None, output=None, mode="reflect", cval=0.0, origin=0):
+    """Multidimensional median filter (filters.py:1751-1792)."""
+    return _rank_filter(input, 0, size, footprint, output, mode, cval, origin, "median")
+
+
+def percentile_filter(input, percentile, size=None, footprint=None, output=None, mode="reflect", cval=0.0, origin=0):
+    """Multidimensional percentile filter (filters.py:1795-1848)."""
+    return _rank_filter(input, percentile, size, footprint, output, mode, cval, origin, "percentile")

@@ -225,6 +225,14 @@ int mi_minmax_nd(const mi_array *in, const mi_array *out, const uint8_t *footpri
                  const double *structure, const int64_t *fshape, const int *origins, int mode,
                  double cval, int is_max, mi_stream stream);
 
+/* rank-th smallest sample under the footprint (rank_filter / median_filter /
+ * percentile_filter, filters.py:1560-1848); rank <= 3 arrays, footprints of at
+ * most 128 set elements, MI_ERR_UNSUPPORTED otherwise.  cval is converted to
+ * the input dtype like SciPy does. */
+int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footprint,
+                   const int64_t *fshape, const int *origins, int rank, int mode, double cval,
+                   mi_stream stream);
+
 /* ------------------------------------------------------------------ */
 /* K4: binary erosion / dilation                                        */
 /* ------------------------------------------------------------------ */

@@ -840,3 +840,26 @@ def test_derivative_and_morphological_composites_match_scipy(gpu, ndi, dtype):
     assert np.array_equal(ndi.black_tophat(gpu.asarray(b), footprint=fp).get(), sndi.black_tophat(b, footprint=fp))
     assert np.array_equal(ndi.binary_hit_or_miss(gpu.asarray(b)).get(), sndi.binary_hit_or_miss(b))
     assert np.array_equal(ndi.binary_fill_holes(gpu.asarray(b)).get(), sndi.binary_fill_holes(b))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "uint8", "int16", "float64"])
+def test_rank_median_percentile_filters_match_scipy(gpu, ndi, dtype):
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(130)
+    for shape, size in [((30, 41), 3), ((30, 41), (5, 3)), ((9, 14, 16), 3), ((64,), 5)]:
+        x = rng.standard_normal(shape).astype(dtype) if np.dtype(dtype).kind == "f" else rng.integers(0, 200, size=shape).astype(dtype)
+        xd = gpu.asarray(x)
+        for mode in ["reflect", "constant", "nearest", "mirror", "wrap"]:
+            assert np.array_equal(ndi.median_filter(xd, size=size, mode=mode, cval=3).get(), sndi.median_filter(x, size=size, mode=mode, cval=3))
+            assert np.array_equal(ndi.rank_filter(xd, 2, size=size, mode=mode, cval=3).get(), sndi.rank_filter(x, 2, size=size, mode=mode, cval=3))
+            assert np.array_equal(ndi.rank_filter(xd, -2, size=size, mode=mode, cval=3).get(), sndi.rank_filter(x, -2, size=size, mode=mode, cval=3))
+            for pct in (0, 20, 50, 75.5, 100, -30):
+                assert np.array_equal(ndi.percentile_filter(xd, pct, size=size, mode=mode, cval=3).get(),
+                                      sndi.percentile_filter(x, pct, size=size, mode=mode, cval=3)), (pct, mode)
+    fp = rng.random((3, 5)) > 0.4
+    fp[1, 2] = True
+    x = rng.standard_normal((25, 28)).astype(np.float32)
+    got = ndi.median_filter(gpu.asarray(x), footprint=fp, origin=(0, 1), mode="mirror").get()
+    assert np.array_equal(got, sndi.median_filter(x, footprint=fp, origin=(0, 1), mode="mirror"))
+    with pytest.raises(RuntimeError):
+        ndi.rank_filter(gpu.asarray(x), 99, size=3)
