@@ -37,6 +37,7 @@ SOURCES = [
     ("interp.hip", ["-ffp-contract=off"]),
     ("interp_fast.hip", ["-ffp-contract=off"]),
     ("halo.hip", []),
+    ("metrics.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function",
           "-I" + os.path.join(os.path.dirname(HERE), "include")]

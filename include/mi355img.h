@@ -150,6 +150,17 @@ int mi_scalar_op(int op, const mi_array *a, const mi_array *out, double p0, doub
                  int keep_flag, mi_stream stream);
 /* minimum and maximum of a contiguous array (synchronises the stream) */
 int mi_min_max(const mi_array *a, double *lo, double *hi, mi_stream stream);
+/* Reductions in double over an arbitrarily strided array (synchronises the stream): op 0 sum(a),
+ * op 1 sum((a - b)^2), op 2 sum(a^2).  Serves the cropped mean of the SSIM map
+ * (skimage/metrics/_structural_similarity.py:229-233) and skimage/metrics/simple_metrics.py. */
+int mi_sum(int op, const mi_array *a, const mi_array *b, double *result, mi_stream stream);
+/* SSIM map from the five filtered moments in one pass, float32 / float64, contiguous:
+ * S = ((2 ux uy + C1)(2 vxy + C2)) / ((ux^2 + uy^2 + C1)(vx + vy + C2)), v* = cov_norm (u** - u* u*)
+ * (skimage/metrics/_structural_similarity.py:206-227).  gA/gB/gC (all or none) receive the three
+ * fields the gradient filters (A1/D, -S/B2, (ux(A2-A1) - uy(B2-B1)S)/D; :235-243). */
+int mi_ssim_combine(const mi_array *ux, const mi_array *uy, const mi_array *uxx, const mi_array *uyy,
+                    const mi_array *uxy, const mi_array *S, const mi_array *gA, const mi_array *gB,
+                    const mi_array *gC, double cov_norm, double C1, double C2, mi_stream stream);
 
 /* ------------------------------------------------------------------ */
 /* K1: correlate family                                                 */
