@@ -12,3 +12,9 @@ from .core import (  # noqa: F401
 )
 
 __version__ = "0.1.0"
+
+
+def convolve_separable(x, w, axes=None, **kwargs):
+    """n-D convolution as separable convolve1d passes (cupyimg/_misc.py:39-77)"""
+    from ._misc import convolve_separable as impl
+    return impl(x, w, axes, **kwargs)

@@ -109,8 +109,16 @@ def _correlate_or_convolve(input, weights, output, mode, cval, origin, convoluti
         for o, wd in zip(origins, weights.shape):
             S.check_origin(o, wd)
     if dtype_mode == "numpy":
-        raise NotImplementedError("dtype_mode='numpy' (scipy.signal helper) is outside the filtering path")
-    acc = S.acc_flag(dtype_mode)
+        # scipy.signal's callers: the result has NumPy's promoted dtype, not a float (filters.py:470-487)
+        if output is not None:
+            raise ValueError("dtype_mode == 'numpy' does not support the output argument")
+        dtype = np.promote_types(input.dtype, weights.dtype)
+        if input.dtype != dtype:
+            input = input.astype(dtype)
+        output = dtype
+        acc = 0
+    else:
+        acc = S.acc_flag(dtype_mode)
     output = S.get_output(output, input)
     if input.size == 0:
         return output

@@ -9,7 +9,7 @@ import functools
 
 import numpy as np
 
-from ... import core
+from ... import core, _pad
 from ...scipy import ndimage as ndi
 
 from ...scipy.ndimage import _support as S
@@ -105,13 +105,8 @@ def binary_dilation(image, selem=None, out=None):
 
 
 def _pad_edge(image, widths):
-    """numpy.pad(image, widths, mode="edge") on the device: an order-0 resampling on a
-    larger grid with clamped coordinates (one gather kernel, any real dtype)."""
-    shape = tuple(n + 2 * w for n, w in zip(image.shape, widths))
-    src = image.astype(np.uint8) if image.dtype == np.bool_ else image
-    out = ndi.affine_transform(src, np.eye(image.ndim), offset=[-float(w) for w in widths], output_shape=shape,
-                               order=0, mode="nearest", prefilter=False)
-    return out.astype(np.bool_) if image.dtype == np.bool_ else out
+    """numpy.pad(image, widths, mode="edge") on the device"""
+    return _pad.pad(image, [(w, w) for w in widths], mode="edge")
 
 
 def pad_for_eccentric_selems(func):
