@@ -214,15 +214,23 @@ map_coords3d_fast(const float *__restrict__ in, const CT *__restrict__ coords, f
         const int y = (blockIdx.y * kNV + k) * 4 + threadIdx.y;
         ok[k] = y < p.oy;
         o[k] = ((size_t)z * p.oy + (ok[k] ? y : 0)) * p.ox + x;
-        if (p.two_d) { c[k][0] = (CT)0; c[k][1] = coords[o[k]]; c[k][2] = coords[nout + o[k]]; }
-        else { c[k][0] = coords[o[k]]; c[k][1] = coords[nout + o[k]]; c[k][2] = coords[2 * nout + o[k]]; }
+        // coordinates are read once: keep them out of the caches the gathered volume lives in
+        if (p.two_d) {
+            c[k][0] = (CT)0;
+            c[k][1] = __builtin_nontemporal_load(coords + o[k]);
+            c[k][2] = __builtin_nontemporal_load(coords + nout + o[k]);
+        } else {
+            c[k][0] = __builtin_nontemporal_load(coords + o[k]);
+            c[k][1] = __builtin_nontemporal_load(coords + nout + o[k]);
+            c[k][2] = __builtin_nontemporal_load(coords + 2 * nout + o[k]);
+        }
     }
     Taps t[kNV];
 #pragma unroll
     for (int k = 0; k < kNV; k++) taps<CT, FASTC, ORDER>(rin, p, c[k][0], c[k][1], c[k][2], t[k]);
 #pragma unroll
     for (int k = 0; k < kNV; k++)
-        if (ok[k]) out[o[k]] = finish(t[k], p.cval);
+        if (ok[k]) __builtin_nontemporal_store(finish(t[k], p.cval), out + o[k]);
 }
 
 template <bool FASTC, int ORDER>
@@ -251,7 +259,7 @@ affine3d_fast(const float *__restrict__ in, float *__restrict__ out, const FastI
     }
 #pragma unroll
     for (int k = 0; k < kNV; k++)
-        if (ok[k]) out[o[k]] = finish(t[k], p.cval);
+        if (ok[k]) __builtin_nontemporal_store(finish(t[k], p.cval), out + o[k]);
 }
 
 static bool fast_ok(const mi_array *in, const mi_array *out, int order)
