@@ -403,14 +403,146 @@ spline_affine_kernel(const double *__restrict__ in, void *__restrict__ out, int 
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Cubic interpolation on float32 coefficients (float32 in / out, the reference's
+// `allow_float32` route, interpolation.py:330-335): same tap selection as
+// spline_point_t<3> (double coordinate arithmetic), float weights and float
+// accumulation, and the four x taps of a (z, y) pair fetched with one 16-byte gather
+// whenever they are consecutive in memory -- 16 gathers per voxel instead of 64.
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Cubic3 {
+    float w[3][4];
+    int off[3][4];      // element offset along the axis, -1: the tap reads cval
+    int ntap[2];        // taps on z and y (1 on rank-padding axes)
+    bool outside;       // constant mode, coordinate beyond the array: the voxel is cval
+};
+
+__device__ __forceinline__ void cubic3_setup(const InterpGeom &g, const double (&c)[3], int mode, int npad, Cubic3 &t)
+{
+    t.outside = false;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        if (d < g.pad) {
+            if (d < 2) t.ntap[d] = 1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { t.w[d][k] = 1.f; t.off[d][k] = 0; }
+            continue;
+        }
+        if (d < 2) t.ntap[d] = 4;
+        const int64_t n = g.shape[d];
+        double cc = c[d] + (double)npad;
+        if (mode == MI_MODE_CONSTANT) {
+            if (cc < 0 || cc > (double)(n - 1)) { t.outside = true; cc = 0.0; }
+        } else if (mode != MI_MODE_GRID_CONSTANT && mode != MI_MODE_NEAREST) {
+            cc = fold_coord(cc, n, mode);
+        }
+        const double fl = floor(cc);
+        const int64_t start = (int64_t)fl - 1;
+        const float x = (float)(cc - fl), y = 1.f - x;
+        t.w[d][1] = (x * x * (x - 2.f) * 3.f + 4.f) * (1.f / 6.f);
+        t.w[d][2] = (y * y * (y - 2.f) * 3.f + 4.f) * (1.f / 6.f);
+        t.w[d][0] = y * y * y * (1.f / 6.f);
+        t.w[d][3] = 1.f - t.w[d][0] - t.w[d][1] - t.w[d][2];
+        const bool interior = start >= 0 && start + 3 < n;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t j = interior ? start + k : spline_tap(start + k, n, mode);
+            t.off[d][k] = j < 0 ? -1 : (int)(j * g.stride[d]);
+        }
+    }
+}
+
+__device__ __forceinline__ float cubic3_gather(const __amdgpu_buffer_rsrc_t rin, const Cubic3 &t, float cval)
+{
+    const bool consec = t.off[2][0] >= 0 && t.off[2][3] == t.off[2][0] + 3;
+    float acc = 0.f;
+#pragma unroll
+    for (int kz = 0; kz < 4; kz++) {
+        if (kz >= t.ntap[0]) break;
+#pragma unroll
+        for (int ky = 0; ky < 4; ky++) {
+            if (ky >= t.ntap[1]) break;
+            const float wzy = t.w[0][kz] * t.w[1][ky];
+            const bool oob_zy = t.off[0][kz] < 0 || t.off[1][ky] < 0;
+            const int base = oob_zy ? 0 : t.off[0][kz] + t.off[1][ky];
+            float v[4];
+            if (consec) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)(base + t.off[2][0]) * 4u, 0, 0);
+                v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y);
+                v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
+                if (oob_zy) v[0] = v[1] = v[2] = v[3] = cval;
+            } else {
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) {
+                    const bool oob = oob_zy || t.off[2][kx] < 0;
+                    const float q = __uint_as_float(
+                        __builtin_amdgcn_raw_buffer_load_b32(rin, oob ? 0u : (unsigned)(base + t.off[2][kx]) * 4u, 0, 0));
+                    v[kx] = oob ? cval : q;
+                }
+            }
+            float row = v[0] * t.w[2][0];
+            row = fmaf(v[1], t.w[2][1], row);
+            row = fmaf(v[2], t.w[2][2], row);
+            row = fmaf(v[3], t.w[2][3], row);
+            acc = fmaf(row, wzy, acc);
+        }
+    }
+    return t.outside ? cval : acc;
+}
+
+// block (64, 4): 64 lanes along the output x axis, so that the gathers of a wave touch neighbouring
+// coefficients; grid (x tiles, y tiles, z) -- no index divisions
+template <typename C, bool AFFINE>
+__global__ void __launch_bounds__(256)
+cubic3_f32_kernel(const float *__restrict__ in, const C *__restrict__ coords, float *__restrict__ out, InterpGeom g,
+                  int64_t nout, int64_t nin, int mode, float cval, int npad)
+{
+    const int ox = (int)g.oshape[2], oy = (int)g.oshape[1];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z;
+    if (x >= ox || y >= oy) return;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)(nin * 4), 0x00020000);
+    const int64_t i = ((int64_t)z * oy + y) * ox + x;
+    double c[3];
+    if constexpr (AFFINE) {
+        const double o[3] = {(double)z, (double)y, (double)x};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += g.mat[d * 4 + k] * o[k];
+            c[d] = s + g.mat[d * 4 + 3];
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+            c[d] = d < g.pad ? 0.0 : (double)__builtin_nontemporal_load(coords + (int64_t)(d - g.pad) * nout + i);
+    }
+    Cubic3 t;
+    cubic3_setup(g, c, mode, npad, t);
+    __builtin_nontemporal_store(cubic3_gather(rin, t, cval), out + i);
+}
+
+// output geometry of the cubic kernel: the output's own shape, rank-padded with leading ones
+static bool cubic3_grid(const mi_array *out, InterpGeom *g, dim3 *grid)
+{
+    const int pad = 3 - out->ndim;
+    for (int d = 0; d < 3; d++) g->oshape[d] = d < pad ? 1 : out->shape[d - pad];
+    if (g->oshape[0] > 65535 || (g->oshape[1] + 3) / 4 > 65535 || g->oshape[2] >= ((int64_t)1 << 31)) return false;
+    *grid = dim3((unsigned)((g->oshape[2] + 63) / 64), (unsigned)((g->oshape[1] + 3) / 4), (unsigned)g->oshape[0]);
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // spline coefficients: padded float64 copy + in-place prefilter
 // ---------------------------------------------------------------------------
 // out (float64, shape = in.shape + 2 npad on the real axes) = in extended by edge
 // replication (pad_mode 0) or by cval (pad_mode 1); rank padded to 3
-template <typename T>
+template <typename T, typename CF>
 __global__ void __launch_bounds__(256)
-spline_pad_kernel(const T *__restrict__ in, double *__restrict__ out, InterpGeom g, int64_t nout, int npad, int pad_mode,
+spline_pad_kernel(const T *__restrict__ in, CF *__restrict__ out, InterpGeom g, int64_t nout, int npad, int pad_mode,
                   double cval)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (int64_t)gridDim.x * blockDim.x) {
@@ -427,7 +559,7 @@ spline_pad_kernel(const T *__restrict__ in, double *__restrict__ out, InterpGeom
             }
             pos += o * g.stride[d];
         }
-        out[i] = (outside && pad_mode == 1) ? cval : (double)in[pos];
+        out[i] = (CF)((outside && pad_mode == 1) ? cval : (double)in[pos]);
     }
 }
 
@@ -439,12 +571,26 @@ spline_pad_kernel(const T *__restrict__ in, double *__restrict__ out, InterpGeom
 // the gain is applied with the last store (the filter is linear).
 constexpr int kSplBatch = 8;
 
+// coefficient storage that reads / writes double whatever the element type (float32 coefficients
+// for the float32 interpolation path: the recursion itself always runs in double)
+template <typename CF>
+struct CoefLine {
+    CF *p;
+    struct Ref {
+        CF *q;
+        __device__ __forceinline__ operator double() const { return (double)*q; }
+        __device__ __forceinline__ Ref &operator=(double v) { *q = (CF)v; return *this; }
+    };
+    __device__ __forceinline__ Ref operator[](int64_t i) const { return Ref{p + i}; }
+};
+
+template <typename CF>
 __global__ void __launch_bounds__(64)
-spline_filter1d_kernel(double *__restrict__ data, int64_t n, int64_t inner, int64_t nlines, int order, int smode)
+spline_filter1d_kernel(CF *__restrict__ data, int64_t n, int64_t inner, int64_t nlines, int order, int smode)
 {
     const int64_t line = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (line >= nlines || n <= 1) return;
-    double *c = data + (line / inner) * n * inner + (line % inner);
+    const CoefLine<CF> c{data + (line / inner) * n * inner + (line % inner)};
     const int64_t st = inner;
     double zs[2];
     int np = 1;
@@ -535,6 +681,177 @@ spline_filter1d_kernel(double *__restrict__ data, int64_t n, int64_t inner, int6
     }
 }
 
+// The same filter for lines that are contiguous in memory (the last axis), where one thread per
+// line would read 64 different cache lines per step: a wave owns 64 lines and moves 64 x 64 sample
+// tiles through LDS -- coalesced row loads, each thread runs the recursion along its own row of
+// the tile, coalesced row stores.  Arithmetic, rounding points and summation order are those of
+// spline_filter1d_kernel (the results are identical).  The rows of a tile are written by other lanes
+// than the one that filters them, hence the fences between the sweeps.
+constexpr int kSplTile = 64;
+constexpr int kSplRows = 16;      // tile rows moved per batch: that many loads in flight per lane
+
+template <typename CF>
+__device__ __forceinline__ void spline_tile_load(CF (&tile)[kSplTile][kSplTile + 1], const CF *__restrict__ base, int64_t n,
+                                                 int64_t s0, int cnt, int nrows, int lane)
+{
+    for (int r0 = 0; r0 < nrows; r0 += kSplRows) {
+        CF v[kSplRows];
+#pragma unroll
+        for (int u = 0; u < kSplRows; u++)
+            v[u] = (r0 + u < nrows && lane < cnt) ? base[(int64_t)(r0 + u) * n + s0 + lane] : (CF)0;
+#pragma unroll
+        for (int u = 0; u < kSplRows; u++) tile[r0 + u][lane] = v[u];
+    }
+}
+
+template <typename CF>
+__device__ __forceinline__ void spline_tile_store(const CF (&tile)[kSplTile][kSplTile + 1], CF *__restrict__ base, int64_t n,
+                                                  int64_t s0, int cnt, int nrows, int lane)
+{
+    for (int r0 = 0; r0 < nrows; r0 += kSplRows) {
+#pragma unroll
+        for (int u = 0; u < kSplRows; u++)
+            if (r0 + u < nrows && lane < cnt) base[(int64_t)(r0 + u) * n + s0 + lane] = tile[r0 + u][lane];
+    }
+}
+
+template <typename CF>
+__global__ void __launch_bounds__(64)
+spline_filter_rows_kernel(CF *__restrict__ data, int64_t n, int64_t nlines, int order, int smode)
+{
+    __shared__ CF tile[kSplTile][kSplTile + 1];
+    const int lane = threadIdx.x;
+    const int64_t line0 = (int64_t)blockIdx.x * kSplTile;
+    const int nrows = (int)((nlines - line0 < kSplTile) ? nlines - line0 : kSplTile);
+    const bool valid = lane < nrows;
+    CF *base = data + line0 * n;
+    const CoefLine<CF> c{base + (int64_t)(valid ? lane : 0) * n};
+    double zs[2];
+    int np = 1;
+    switch (order) {
+    case 2: zs[0] = -0.171572875253809902396622551580603843; break;
+    case 3: zs[0] = -0.267949192431122706472553658494127633; break;
+    case 4: zs[0] = -0.361341225900220177092212841325675255; zs[1] = -0.013725429297339121360331226939128204; np = 2; break;
+    default: zs[0] = -0.430575347099973791851434783493520110; zs[1] = -0.043096288203264653822712376822550182; np = 2; break;
+    }
+    double gain = 1.0;
+    for (int k = 0; k < np; k++) gain *= (1.0 - zs[k]) * (1.0 - 1.0 / zs[k]);
+    const int ntiles = (int)((n + kSplTile - 1) / kSplTile);
+    for (int k = 0; k < np; k++) {
+        const double z = zs[k];
+        const bool last_pole = k == np - 1;
+        const int64_t H = (int64_t)ceil(-46.0517 / log(fabs(z)));
+        // ---- causal initialisation (reads the line as the previous sweep left it)
+        double c0 = c[0];
+        {
+            double z_i = z;
+            if (smode == 0) {
+                const double z_n_1 = pow(z, (double)(n - 1));
+                double acc = c0 + z_n_1 * c[n - 1];
+                const int64_t m = (n - 1 < H + 1) ? n - 1 : H + 1;
+                for (int64_t i = 1; i < m; i++) { acc += z_i * (c[i] + z_n_1 * c[n - 1 - i]); z_i *= z; }
+                c0 = acc / (1 - z_n_1 * z_n_1);
+            } else if (smode == 2) {
+                double acc = c0;
+                const int64_t m = (n < H + 1) ? n : H + 1;
+                for (int64_t i = 1; i < m; i++) { acc += z_i * c[n - i]; z_i *= z; }
+                const double z_n = pow(z, (double)n);
+                c0 = acc / (1 - z_n);
+            } else {
+                const double z_n = pow(z, (double)n);
+                double acc = c0 + z_n * c[n - 1];
+                const int64_t m = (n < H + 1) ? n : H + 1;
+                for (int64_t i = 1; i < m; i++) {
+                    const double mirror_term = (i == n - 1) ? acc : (double)c[n - 1 - i];
+                    acc += z_i * (c[i] + z_n * mirror_term);
+                    z_i *= z;
+                }
+                acc *= z / (1 - z_n * z_n);
+                c0 = acc + c0;
+            }
+        }
+        // ---- causal sweep, tile by tile
+        double prev = c0, prev2 = 0.0;          // c+[i - 1], c+[i - 2]
+        double wrap_acc = 0.0, wrap_zi = z;     // grid-wrap: sum_j z^(j+1) c+[j], j < min(n - 1, H)
+        const int64_t wrap_m = (n - 1 < H) ? n - 1 : H;
+        for (int t = 0; t < ntiles; t++) {
+            const int64_t s0 = (int64_t)t * kSplTile;
+            const int cnt = (int)((n - s0 < kSplTile) ? n - s0 : kSplTile);
+            spline_tile_load(tile, base, n, s0, cnt, nrows, lane);
+            __syncthreads();
+            if (valid) {
+                for (int i0 = 0; i0 < cnt; i0 += kSplBatch) {
+                    CF v[kSplBatch];
+#pragma unroll
+                    for (int u = 0; u < kSplBatch; u++) v[u] = tile[lane][i0 + u];
+#pragma unroll
+                    for (int u = 0; u < kSplBatch; u++) {
+                        const int i = i0 + u;
+                        if (i < cnt) {
+                            double w;
+                            if (t == 0 && i == 0) w = c0;
+                            else { w = (double)v[u] + z * prev; prev2 = prev; }
+                            prev = w;
+                            v[u] = (CF)w;
+                            if (smode == 2 && s0 + i < wrap_m) { wrap_acc += wrap_zi * (double)v[u]; wrap_zi *= z; }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kSplBatch; u++) tile[lane][i0 + u] = v[u];
+                }
+            }
+            __syncthreads();
+            spline_tile_store(tile, base, n, s0, cnt, nrows, lane);
+            __syncthreads();
+        }
+        __threadfence();
+        // c+[n - 2] is read back from the array (rounded to the coefficient type) by the one-thread-per-line kernel
+        prev2 = (double)(CF)prev2;
+        // ---- anti-causal initialisation
+        double last = prev;
+        if (smode == 0) {
+            last = (z * prev2 + last) * z / (z * z - 1);
+        } else if (smode == 2) {
+            const double z_n = pow(z, (double)n);
+            last = (last + wrap_acc) * z / (z_n - 1);
+        } else {
+            last *= z / (z - 1);
+        }
+        const double scale = last_pole ? gain : 1.0;
+        // ---- anti-causal sweep
+        double nxt = last;
+        for (int t = ntiles - 1; t >= 0; t--) {
+            const int64_t s0 = (int64_t)t * kSplTile;
+            const int cnt = (int)((n - s0 < kSplTile) ? n - s0 : kSplTile);
+            spline_tile_load(tile, base, n, s0, cnt, nrows, lane);
+            __syncthreads();
+            if (valid) {
+                for (int i0 = kSplTile - kSplBatch; i0 >= 0; i0 -= kSplBatch) {
+                    if (i0 >= cnt) continue;
+                    CF v[kSplBatch];
+#pragma unroll
+                    for (int u = 0; u < kSplBatch; u++) v[u] = tile[lane][i0 + u];
+#pragma unroll
+                    for (int u = kSplBatch - 1; u >= 0; u--) {
+                        const int i = i0 + u;
+                        if (i < cnt) {
+                            if (t == ntiles - 1 && i == cnt - 1) nxt = last;
+                            else nxt = z * (nxt - (double)v[u]);
+                            v[u] = (CF)(nxt * scale);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kSplBatch; u++) tile[lane][i0 + u] = v[u];
+                }
+            }
+            __syncthreads();
+            spline_tile_store(tile, base, n, s0, cnt, nrows, lane);
+            __syncthreads();
+        }
+        __threadfence();
+    }
+}
+
 static int fill_geom(InterpGeom *g, const mi_array *in, int nd)
 {
     const int pad = nd - in->ndim;
@@ -576,6 +893,9 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
 using namespace mi;
 
 static int g_interp_generic = 0;   // test hook: 1 = always use the generic double kernels
+static int g_spline_rows_off = 0;  // test hook: 1 = one thread per line also for contiguous lines
+static int g_spline_rows_force = 0; // test hook: 2 = tiled kernel whatever the line count
+extern "C" int mi_debug_set_spline_rows(int on) { g_spline_rows_off = on == 0; g_spline_rows_force = on == 2; return MI_OK; }
 extern "C" int mi_debug_set_interp_generic(int v) { g_interp_generic = v; return MI_OK; }
 
 extern "C" {
@@ -677,7 +997,7 @@ int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mod
     int rc;
     if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
     MI_REQUIRE(in->ndim >= 1 && in->ndim <= 3 && out->ndim == in->ndim, MI_ERR_INVALID_ARG, "rank 1..3");
-    MI_REQUIRE(out->dtype == MI_F64, MI_ERR_INVALID_ARG, "coefficients are float64");
+    MI_REQUIRE(out->dtype == MI_F64 || out->dtype == MI_F32, MI_ERR_INVALID_ARG, "coefficients are float64 or float32");
     MI_REQUIRE(npad >= 0 && (pad_mode == 0 || pad_mode == 1), MI_ERR_INVALID_ARG, "bad padding");
     MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "needs C-contiguous arrays");
     for (int d = 0; d < in->ndim; d++)
@@ -690,8 +1010,12 @@ int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mod
     grid_for(nout, 256, &grid);
     hipStream_t s = resolve_stream(stream);
     return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
-        hipLaunchKernelGGL((spline_pad_kernel<T>), grid, dim3(256), 0, s, (const T *)in->data, (double *)out->data, g, nout,
-                           npad, pad_mode, cval);
+        if (out->dtype == MI_F64)
+            hipLaunchKernelGGL((spline_pad_kernel<T, double>), grid, dim3(256), 0, s, (const T *)in->data, (double *)out->data,
+                               g, nout, npad, pad_mode, cval);
+        else
+            hipLaunchKernelGGL((spline_pad_kernel<T, float>), grid, dim3(256), 0, s, (const T *)in->data, (float *)out->data,
+                               g, nout, npad, pad_mode, cval);
         MI_HIP(hipGetLastError());
         return MI_OK;
     });
@@ -701,7 +1025,7 @@ int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mod
 {
     int rc;
     if ((rc = check_array(data, "data"))) return rc;
-    MI_REQUIRE(data->dtype == MI_F64, MI_ERR_INVALID_ARG, "coefficients are float64");
+    MI_REQUIRE(data->dtype == MI_F64 || data->dtype == MI_F32, MI_ERR_INVALID_ARG, "coefficients are float64 or float32");
     MI_REQUIRE(data->ndim >= 1 && axis >= 0 && axis < data->ndim, MI_ERR_INVALID_ARG, "invalid axis");
     MI_REQUIRE(order >= 2 && order <= 5, MI_ERR_INVALID_ARG, "spline order is not supported");
     MI_REQUIRE(spline_mode >= 0 && spline_mode <= 2, MI_ERR_INVALID_ARG, "bad spline boundary mode");
@@ -711,8 +1035,24 @@ int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mod
     int64_t inner = 1;
     for (int d = axis + 1; d < data->ndim; d++) inner *= data->shape[d];
     const int64_t n = data->shape[axis], nlines = total / n;
-    hipLaunchKernelGGL(spline_filter1d_kernel, dim3((unsigned)((nlines + 63) / 64)), dim3(64), 0, resolve_stream(stream),
-                       (double *)data->data, n, inner, nlines, order, spline_mode);
+    // enough lines to fill the chip with one wave per 64 lines; images with few, long lines keep one thread per line
+    if (inner == 1 && n >= 2 * kSplTile && (nlines >= 16384 || g_spline_rows_force) && !g_spline_rows_off) {
+        const dim3 grid((unsigned)((nlines + kSplTile - 1) / kSplTile));
+        if (data->dtype == MI_F64)
+            hipLaunchKernelGGL(spline_filter_rows_kernel<double>, grid, dim3(64), 0, resolve_stream(stream),
+                               (double *)data->data, n, nlines, order, spline_mode);
+        else
+            hipLaunchKernelGGL(spline_filter_rows_kernel<float>, grid, dim3(64), 0, resolve_stream(stream),
+                               (float *)data->data, n, nlines, order, spline_mode);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
+    if (data->dtype == MI_F64)
+        hipLaunchKernelGGL(spline_filter1d_kernel<double>, dim3((unsigned)((nlines + 63) / 64)), dim3(64), 0,
+                           resolve_stream(stream), (double *)data->data, n, inner, nlines, order, spline_mode);
+    else
+        hipLaunchKernelGGL(spline_filter1d_kernel<float>, dim3((unsigned)((nlines + 63) / 64)), dim3(64), 0,
+                           resolve_stream(stream), (float *)data->data, n, inner, nlines, order, spline_mode);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -722,7 +1062,8 @@ static int check_spline(const mi_array *coef, const mi_array *out, int order, in
     int rc = check_interp(coef, out, order, mode);
     if (rc) return rc;
     MI_REQUIRE(order >= 2, MI_ERR_INVALID_ARG, "orders 0 and 1 use mi_map_coordinates / mi_affine_transform");
-    MI_REQUIRE(coef->dtype == MI_F64, MI_ERR_INVALID_ARG, "coefficients are float64");
+    MI_REQUIRE(coef->dtype == MI_F64 || (coef->dtype == MI_F32 && order == 3 && out->dtype == MI_F32), MI_ERR_INVALID_ARG,
+               "coefficients are float64 (float32 only for order 3 with a float32 output)");
     MI_REQUIRE(npad >= 0, MI_ERR_INVALID_ARG, "negative padding");
     if (coef->ndim > 3) { set_error("spline orders 2-5 are built for rank <= 3"); return MI_ERR_UNSUPPORTED; }
     return MI_OK;
@@ -749,6 +1090,22 @@ int mi_spline_map_coordinates(const mi_array *coef, const mi_array *coords, cons
     dim3 grid;
     grid_for(nout, 256, &grid);
     hipStream_t s = resolve_stream(stream);
+    if (coef->dtype == MI_F32) {
+        // float32 coefficients: the cubic gather kernel (32-bit element offsets)
+        MI_REQUIRE(numel(coef) < ((int64_t)1 << 29), MI_ERR_UNSUPPORTED, "float32 coefficient volume too large");
+        MI_REQUIRE(is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "needs a C-contiguous output");
+        MI_REQUIRE(out->ndim >= 1 && out->ndim <= 3, MI_ERR_UNSUPPORTED, "float32 cubic route: output rank 1..3");
+        dim3 cgrid;
+        MI_REQUIRE(cubic3_grid(out, &g, &cgrid), MI_ERR_UNSUPPORTED, "float32 cubic route: output too large");
+        if (coords->dtype == MI_F32)
+            hipLaunchKernelGGL((cubic3_f32_kernel<float, false>), cgrid, dim3(64, 4), 0, s, (const float *)coef->data,
+                               (const float *)coords->data, (float *)out->data, g, nout, numel(coef), mode, (float)cval, npad);
+        else
+            hipLaunchKernelGGL((cubic3_f32_kernel<double, false>), cgrid, dim3(64, 4), 0, s, (const float *)coef->data,
+                               (const double *)coords->data, (float *)out->data, g, nout, numel(coef), mode, (float)cval, npad);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
 #define MI_SPL_MAP(C, ORD)                                                                                         \
     hipLaunchKernelGGL((spline_map_kernel<C, ORD>), grid, dim3(256), 0, s, (const double *)coef->data,            \
                        (const C *)coords->data, out->data, out->dtype, g, nout, mode, cval, round_out, npad)
@@ -788,6 +1145,16 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
     dim3 grid;
     grid_for(nout, 256, &grid);
     hipStream_t s = resolve_stream(stream);
+    if (coef->dtype == MI_F32) {
+        MI_REQUIRE(numel(coef) < ((int64_t)1 << 29), MI_ERR_UNSUPPORTED, "float32 coefficient volume too large");
+        MI_REQUIRE(is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "needs a C-contiguous output");
+        dim3 cgrid;
+        MI_REQUIRE(cubic3_grid(out, &g, &cgrid), MI_ERR_UNSUPPORTED, "float32 cubic route: output too large");
+        hipLaunchKernelGGL((cubic3_f32_kernel<float, true>), cgrid, dim3(64, 4), 0, s, (const float *)coef->data,
+                           (const float *)nullptr, (float *)out->data, g, nout, numel(coef), mode, (float)cval, npad);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
 #define MI_SPL_AFF(ORD)                                                                                           \
     hipLaunchKernelGGL((spline_affine_kernel<ORD>), grid, dim3(256), 0, s, (const double *)coef->data, out->data, \
                        out->dtype, g, nout, mode, cval, round_out, npad)

@@ -46,8 +46,17 @@ def _spline_mode_code(mode):
     return 0
 
 
-def _to_coefficients(input, order, mode, cval, prefilter):
-    """(float64 device array of B-spline coefficients, npad) for orders 2-5.
+def _float32_route(src, out_dtype, order, allow_float32):
+    """float32 image, float32 result, cubic spline: coefficients are stored as float32 and the
+    gather kernel works in float32 (the reference's `allow_float32`, interpolation.py:330-335;
+    about 1e-6 of the data range away from SciPy's double arithmetic)"""
+    return (allow_float32 and order == 3 and src.dtype == np.float32 and np.dtype(out_dtype) == np.float32
+            and src.ndim <= 3 and src.size < (1 << 28))
+
+
+def _to_coefficients(input, order, mode, cval, prefilter, f32=False):
+    """(device array of B-spline coefficients, npad) for orders 2-5: float64, or float32
+    on the float32 cubic route (the recursion itself always runs in double).
     SciPy pads by 12 samples for `nearest` / `grid-constant` before filtering;
     prefilter=False interpolates the samples as if they were coefficients."""
     if input.ndim > 3:
@@ -56,7 +65,9 @@ def _to_coefficients(input, order, mode, cval, prefilter):
     npad, pad_mode = 0, 0
     if prefilter and mode in ("nearest", "grid-constant"):
         npad, pad_mode = 12, (0 if mode == "nearest" else 1)
-    coef = core.empty(tuple(n + 2 * npad for n in src.shape), np.float64)
+    if f32 and npad == 0 and not prefilter:
+        return src, 0                      # the samples are the coefficients
+    coef = core.empty(tuple(n + 2 * npad for n in src.shape), np.float32 if f32 else np.float64)
     a, b = src._desc(), coef._desc()
     lib = S.lib()
     S.check(lib.mi_spline_pad(ctypes.byref(a), ctypes.byref(b), npad, pad_mode, float(cval), None))
@@ -65,6 +76,12 @@ def _to_coefficients(input, order, mode, cval, prefilter):
             if coef.shape[ax] > 1:
                 S.check(lib.mi_spline_filter1d(ctypes.byref(b), ax, int(order), _spline_mode_code(mode), None))
     return coef, npad
+
+
+def _coef_dtype(input, ret, allow_float32):
+    """coefficients are kept in float64 unless a float32 image is filtered into a float32 result
+    with allow_float32 (interpolation.py:144-150); the recursion runs in double either way"""
+    return np.float32 if (allow_float32 and input.dtype == np.float32 and ret.dtype == np.float32) else np.float64
 
 
 def _spline_output(output, input):
@@ -87,7 +104,7 @@ def spline_filter1d(input, order=3, axis=-1, output=np.float64, mode="mirror", *
         ret[...] = input
         return ret
     axis = S.normalize_axis(axis, input.ndim)
-    coef = core.ascontiguousarray(input).astype(np.float64)
+    coef = core.ascontiguousarray(input).astype(_coef_dtype(input, ret, allow_float32))
     if core.shares_memory(coef, input):
         coef = coef.copy()
     d = coef._desc()
@@ -107,7 +124,7 @@ def spline_filter(input, order=3, output=np.float64, mode="mirror", *, allow_flo
     ret = _spline_output(output, input)
     if input.size == 0:
         return ret
-    coef = core.ascontiguousarray(input).astype(np.float64)
+    coef = core.ascontiguousarray(input).astype(_coef_dtype(input, ret, allow_float32))
     if core.shares_memory(coef, input):
         coef = coef.copy()
     d = coef._desc()
@@ -177,7 +194,10 @@ def map_coordinates(input, coordinates, output=None, order=3, mode="constant", c
     cd = coords._desc()
     lib = S.lib()
     if order > 1:
-        coef, npad = _to_coefficients(src, order, mode, cval, prefilter)
+        coef, npad = _to_coefficients(src, order, mode, cval, prefilter,
+                                      ret.ndim <= 3 and _float32_route(src, ret.dtype, order, allow_float32))
+        if coef is src and core.shares_memory(ret, src):
+            coef = src.copy()
         ca_ = coef._desc()
 
         def launch_spline(dst):
@@ -237,16 +257,18 @@ def affine_transform(input, matrix, offset=0.0, output_shape=None, output=None, 
     m = np.zeros((ndim, ndim + 1), dtype=np.float64)
     m[:, :ndim] = matrix
     m[:, ndim] = offset
-    return _affine(input, m, out, order, mode, cval, prefilter)
+    return _affine(input, m, out, order, mode, cval, prefilter, allow_float32)
 
 
-def _affine(input, m, out, order, mode, cval, prefilter):
+def _affine(input, m, out, order, mode, cval, prefilter, allow_float32=True):
     """out[o] = interp(input, m[:, :n] @ o + m[:, n]) -- the launch behind affine_transform / shift / zoom / rotate"""
     mk, mp = S.c_doubles(m)
     src = core.ascontiguousarray(input)
     lib = S.lib()
     if order > 1:
-        coef, npad = _to_coefficients(src, order, mode, cval, prefilter)
+        coef, npad = _to_coefficients(src, order, mode, cval, prefilter, _float32_route(src, out.dtype, order, allow_float32))
+        if coef is src and core.shares_memory(out, src):
+            coef = src.copy()
         ca_ = coef._desc()
 
         def launch_spline(dst):
@@ -279,7 +301,7 @@ def shift(input, shift, output=None, order=3, mode="constant", cval=0.0, prefilt
     m = np.zeros((nd, nd + 1))
     m[:, :nd] = np.eye(nd)
     m[:, nd] = [-v for v in sh]
-    return _affine(input, m, out, order, mode, cval, prefilter)
+    return _affine(input, m, out, order, mode, cval, prefilter, allow_float32)
 
 
 def zoom(input, zoom, output=None, order=3, mode="constant", cval=0.0, prefilter=True, *, grid_mode=False,
@@ -307,7 +329,7 @@ def zoom(input, zoom, output=None, order=3, mode="constant", cval=0.0, prefilter
     m = np.zeros((nd, nd + 1))
     m[:, :nd] = np.diag(scale)
     m[:, nd] = off
-    return _affine(input, m, out, order, mode, cval, prefilter)
+    return _affine(input, m, out, order, mode, cval, prefilter, allow_float32)
 
 
 def _cos_sin_deg(angle):
@@ -361,4 +383,4 @@ def rotate(input, angle, axes=(1, 0), reshape=True, output=None, order=3, mode="
     m[axes[0], axes[0]], m[axes[0], axes[1]] = rot[0]
     m[axes[1], axes[0]], m[axes[1], axes[1]] = rot[1]
     m[axes[0], nd], m[axes[1], nd] = offset
-    return _affine(input, m, out, order, mode, cval, prefilter)
+    return _affine(input, m, out, order, mode, cval, prefilter, allow_float32)

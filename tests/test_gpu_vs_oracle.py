@@ -863,3 +863,86 @@ def test_rank_median_percentile_filters_match_scipy(gpu, ndi, dtype):
     assert np.array_equal(got, sndi.median_filter(x, footprint=fp, origin=(0, 1), mode="mirror"))
     with pytest.raises(RuntimeError):
         ndi.rank_filter(gpu.asarray(x), 99, size=3)
+
+
+def test_float32_cubic_route_matches_scipy(gpu, ndi):
+    """float32 image -> float32 result at order 3 stores float32 coefficients and gathers in
+    float32 (allow_float32, the reference's interpolation.py:330-335); SciPy works in double,
+    so the comparison carries a tolerance: 2e-5 of the data range (the survey proposes 1e-5
+    abs/rel for identical arithmetic; the reference itself claims 1e-4)."""
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(170)
+    modes = ["constant", "nearest", "mirror", "reflect", "wrap", "grid-wrap", "grid-constant", "grid-mirror"]
+    for shape in [(33, 38), (14, 17, 19), (41,)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        nd = len(shape)
+        coords = (rng.random((nd, 2000)) * (np.array(shape)[:, None] + 6) - 3).astype(np.float32)
+        # exact grid points and edges too
+        coords[:, :50] = np.round(coords[:, :50])
+        A = np.eye(nd) + 0.1 * rng.standard_normal((nd, nd))
+        off = rng.standard_normal(nd)
+        tol = 2e-5 * float(np.abs(x).max())
+        for mode in modes:
+            for prefilter in (True, False):
+                want = sndi.map_coordinates(x.astype(np.float64), coords.astype(np.float64), order=3, mode=mode, cval=0.5,
+                                            prefilter=prefilter)
+                got = ndi.map_coordinates(xd, gpu.asarray(coords), order=3, mode=mode, cval=0.5, prefilter=prefilter)
+                assert got.dtype == np.float32
+                assert np.abs(got.get() - want).max() <= tol * 4, (shape, mode, prefilter)
+            want = sndi.affine_transform(x.astype(np.float64), A, offset=off, order=3, mode=mode, cval=-1.0)
+            got = ndi.affine_transform(xd, A, offset=off, order=3, mode=mode, cval=-1.0)
+            assert got.dtype == np.float32
+            assert np.abs(got.get() - want).max() <= tol * 4, (shape, mode)
+            # the double route stays available and is much closer
+            exact = ndi.affine_transform(xd, A, offset=off, order=3, mode=mode, cval=-1.0, allow_float32=False)
+            assert np.abs(exact.get() - want).max() <= 2e-6 * float(np.abs(x).max()), (shape, mode)
+        for mode in ("constant", "nearest", "reflect"):
+            want = sndi.shift(x.astype(np.float64), 1.7, order=3, mode=mode)
+            assert np.abs(ndi.shift(xd, 1.7, order=3, mode=mode).get() - want).max() <= tol * 4
+            want = sndi.zoom(x.astype(np.float64), 1.3, order=3, mode=mode)
+            assert np.abs(ndi.zoom(xd, 1.3, order=3, mode=mode).get() - want).max() <= tol * 4
+    img = rng.standard_normal((64, 80)).astype(np.float32)
+    want = sndi.rotate(img.astype(np.float64), 17.0, order=3, reshape=True)
+    got = ndi.rotate(gpu.asarray(img), 17.0, order=3, reshape=True)
+    assert got.shape == want.shape and np.abs(got.get() - want).max() <= 8e-5 * float(np.abs(img).max())
+    # in-place request and a float64 output keep working
+    out64 = gpu.empty(img.shape, np.float64)
+    ndi.affine_transform(gpu.asarray(img), np.eye(2) * 0.9, order=3, output=out64)
+    np.testing.assert_allclose(out64.get(), sndi.affine_transform(img.astype(np.float64), np.eye(2) * 0.9, order=3),
+                               rtol=1e-9, atol=1e-9)
+
+
+def test_spline_prefilter_contiguous_lines_kernel(gpu, ndi):
+    """Lines along the last axis go through the LDS-tiled kernel (>= 128 samples): same results as
+    the one-thread-per-line kernel and as SciPy, every order and boundary rule, ragged sizes."""
+    import ctypes
+    import scipy.ndimage as sndi
+    from cupyimg_amd import _lib
+    hook = _lib.load().mi_debug_set_spline_rows
+    hook.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(171)
+    hook(2)         # the kernel is normally chosen for >= 16384 lines; force it for the small cases
+    try:
+        for shape in [(70, 130), (3, 5, 257), (129,), (64, 128)]:
+            x = rng.standard_normal(shape)
+            for order in (2, 3, 4, 5):
+                for mode in ("mirror", "reflect", "grid-wrap", "nearest", "constant", "wrap"):
+                    want = sndi.spline_filter1d(x, order, axis=-1, mode=mode)
+                    got = ndi.spline_filter1d(gpu.asarray(x), order, axis=-1, mode=mode).get()
+                    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12, err_msg=str((shape, order, mode)))
+                    hook(0)
+                    old = ndi.spline_filter1d(gpu.asarray(x), order, axis=-1, mode=mode).get()
+                    hook(2)
+                    np.testing.assert_allclose(got, old, rtol=1e-14, atol=1e-14, err_msg=str((shape, order, mode)))
+            xf = x.astype(np.float32)
+            got = ndi.spline_filter(gpu.asarray(xf), 3, output=np.float32, allow_float32=True)
+            assert got.dtype == np.float32
+            np.testing.assert_allclose(got.get(), sndi.spline_filter(xf.astype(np.float64), 3), rtol=0,
+                                       atol=2e-6 * np.abs(xf).max())
+    finally:
+        hook(1)
+    # the default choice on a volume with many lines
+    v = rng.standard_normal((130, 130, 140)).astype(np.float32)
+    got = ndi.spline_filter(gpu.asarray(v), 3, output=np.float64)
+    np.testing.assert_allclose(got.get(), sndi.spline_filter(v.astype(np.float64), 3), rtol=1e-11, atol=1e-11)
