@@ -109,6 +109,7 @@ SIGNATURES = {
     "mi_affine_transform": [_arr, _arr, _dp, _i, _i, _d, _vp],
     "mi_spline_pad": [_arr, _arr, _i, _i, _d, _vp],
     "mi_spline_filter1d": [_arr, _i, _i, _i, _vp],
+    "mi_spline_prefilter": [_arr, _arr, _i, _i, _i, _i, _d, _vp],
     "mi_spline_map_coordinates": [_arr, _arr, _arr, _i, _i, _d, _i, _vp],
     "mi_spline_affine_transform": [_arr, _arr, _dp, _i, _i, _d, _i, _vp],
     "mi_comm_unique_id": [ctypes.c_char_p],

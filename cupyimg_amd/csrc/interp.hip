@@ -586,11 +586,15 @@ struct CoefLine {
 
 template <typename CF>
 __global__ void __launch_bounds__(64)
-spline_filter1d_kernel(CF *__restrict__ data, int64_t n, int64_t inner, int64_t nlines, int order, int smode)
+spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_t n, int64_t inner, int64_t nlines, int order,
+                       int smode)
 {
     const int64_t line = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (line >= nlines || n <= 1) return;
-    const CoefLine<CF> c{data + (line / inner) * n * inner + (line % inner)};
+    const int64_t line_off = (line / inner) * n * inner + (line % inner);
+    const CoefLine<CF> c{data + line_off};
+    // out of place: the first pole's causal phase reads the source, everything else the coefficients
+    const CoefLine<CF> first{src ? const_cast<CF *>(src) + line_off : data + line_off};
     const int64_t st = inner;
     double zs[2];
     int np = 1;
@@ -607,29 +611,30 @@ spline_filter1d_kernel(CF *__restrict__ data, int64_t n, int64_t inner, int64_t 
         const bool last_pole = k == np - 1;
         int64_t H = (int64_t)ceil(-46.0517 / log(fabs(z)));        // |z|^H < 1e-20
         // ---- causal initialisation
-        double c0 = c[0];
+        const CoefLine<CF> rd = k == 0 ? first : c;
+        double c0 = rd[0];
         {
             double z_i = z;
             if (smode == 0) {
                 const double z_n_1 = pow(z, (double)(n - 1));
-                double acc = c0 + z_n_1 * c[(n - 1) * st];
+                double acc = c0 + z_n_1 * rd[(n - 1) * st];
                 const int64_t m = (n - 1 < H + 1) ? n - 1 : H + 1;
-                for (int64_t i = 1; i < m; i++) { acc += z_i * (c[i * st] + z_n_1 * c[(n - 1 - i) * st]); z_i *= z; }
+                for (int64_t i = 1; i < m; i++) { acc += z_i * (rd[i * st] + z_n_1 * rd[(n - 1 - i) * st]); z_i *= z; }
                 c0 = acc / (1 - z_n_1 * z_n_1);
             } else if (smode == 2) {
                 double acc = c0;
                 const int64_t m = (n < H + 1) ? n : H + 1;
-                for (int64_t i = 1; i < m; i++) { acc += z_i * c[(n - i) * st]; z_i *= z; }
+                for (int64_t i = 1; i < m; i++) { acc += z_i * rd[(n - i) * st]; z_i *= z; }
                 const double z_n = pow(z, (double)n);
                 c0 = acc / (1 - z_n);
             } else {
                 const double z_n = pow(z, (double)n);
-                double acc = c0 + z_n * c[(n - 1) * st];
+                double acc = c0 + z_n * rd[(n - 1) * st];
                 const int64_t m = (n < H + 1) ? n : H + 1;
                 for (int64_t i = 1; i < m; i++) {
                     // SciPy updates c[0] in place: the last term (i == n - 1) sees the partially summed value
-                    const double mirror_term = (i == n - 1) ? acc : c[(n - 1 - i) * st];
-                    acc += z_i * (c[i * st] + z_n * mirror_term);
+                    const double mirror_term = (i == n - 1) ? acc : rd[(n - 1 - i) * st];
+                    acc += z_i * (rd[i * st] + z_n * mirror_term);
                     z_i *= z;
                 }
                 acc *= z / (1 - z_n * z_n);
@@ -643,13 +648,13 @@ spline_filter1d_kernel(CF *__restrict__ data, int64_t n, int64_t inner, int64_t 
         for (; i + kSplBatch <= n; i += kSplBatch) {
             double v[kSplBatch];
 #pragma unroll
-            for (int u = 0; u < kSplBatch; u++) v[u] = c[(i + u) * st];
+            for (int u = 0; u < kSplBatch; u++) v[u] = rd[(i + u) * st];
 #pragma unroll
             for (int u = 0; u < kSplBatch; u++) { prev = v[u] + z * prev; v[u] = prev; }
 #pragma unroll
             for (int u = 0; u < kSplBatch; u++) c[(i + u) * st] = v[u];
         }
-        for (; i < n; i++) { prev = c[i * st] + z * prev; c[i * st] = prev; }
+        for (; i < n; i++) { prev = rd[i * st] + z * prev; c[i * st] = prev; }
         // ---- anti-causal initialisation (prev == c[n - 1] after the causal sweep)
         double last = prev;
         if (smode == 0) {
@@ -1021,6 +1026,38 @@ int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mod
     });
 }
 
+// one prefilter pass along `axis` of the contiguous array `data`; `src` (same dtype and shape) makes the
+// pass out of place -- only the per-line kernel, i.e. not for the tiled last-axis case
+static int spline_pass(const mi_array *data, const void *src, int axis, int order, int spline_mode, hipStream_t s)
+{
+    const int64_t total = numel(data);
+    if (total == 0) return MI_OK;
+    int64_t inner = 1;
+    for (int d = axis + 1; d < data->ndim; d++) inner *= data->shape[d];
+    const int64_t n = data->shape[axis], nlines = total / n;
+    // enough lines to fill the chip with one wave per 64 lines; images with few, long lines keep one thread per line
+    if (!src && inner == 1 && n >= 2 * kSplTile && (nlines >= 16384 || g_spline_rows_force) && !g_spline_rows_off) {
+        const dim3 grid((unsigned)((nlines + kSplTile - 1) / kSplTile));
+        if (data->dtype == MI_F64)
+            hipLaunchKernelGGL(spline_filter_rows_kernel<double>, grid, dim3(64), 0, s, (double *)data->data, n, nlines, order,
+                               spline_mode);
+        else
+            hipLaunchKernelGGL(spline_filter_rows_kernel<float>, grid, dim3(64), 0, s, (float *)data->data, n, nlines, order,
+                               spline_mode);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
+    const dim3 grid((unsigned)((nlines + 63) / 64));
+    if (data->dtype == MI_F64)
+        hipLaunchKernelGGL(spline_filter1d_kernel<double>, grid, dim3(64), 0, s, (double *)data->data, (const double *)src, n,
+                           inner, nlines, order, spline_mode);
+    else
+        hipLaunchKernelGGL(spline_filter1d_kernel<float>, grid, dim3(64), 0, s, (float *)data->data, (const float *)src, n,
+                           inner, nlines, order, spline_mode);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
 int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mode, mi_stream stream)
 {
     int rc;
@@ -1030,30 +1067,34 @@ int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mod
     MI_REQUIRE(order >= 2 && order <= 5, MI_ERR_INVALID_ARG, "spline order is not supported");
     MI_REQUIRE(spline_mode >= 0 && spline_mode <= 2, MI_ERR_INVALID_ARG, "bad spline boundary mode");
     MI_REQUIRE(is_contiguous(data), MI_ERR_NOT_CONTIGUOUS, "needs a C-contiguous array");
-    const int64_t total = numel(data);
-    if (total == 0) return MI_OK;
-    int64_t inner = 1;
-    for (int d = axis + 1; d < data->ndim; d++) inner *= data->shape[d];
-    const int64_t n = data->shape[axis], nlines = total / n;
-    // enough lines to fill the chip with one wave per 64 lines; images with few, long lines keep one thread per line
-    if (inner == 1 && n >= 2 * kSplTile && (nlines >= 16384 || g_spline_rows_force) && !g_spline_rows_off) {
-        const dim3 grid((unsigned)((nlines + kSplTile - 1) / kSplTile));
-        if (data->dtype == MI_F64)
-            hipLaunchKernelGGL(spline_filter_rows_kernel<double>, grid, dim3(64), 0, resolve_stream(stream),
-                               (double *)data->data, n, nlines, order, spline_mode);
-        else
-            hipLaunchKernelGGL(spline_filter_rows_kernel<float>, grid, dim3(64), 0, resolve_stream(stream),
-                               (float *)data->data, n, nlines, order, spline_mode);
-        MI_HIP(hipGetLastError());
-        return MI_OK;
+    return spline_pass(data, nullptr, axis, order, spline_mode, resolve_stream(stream));
+}
+
+int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int spline_mode, int npad, int pad_mode,
+                        double cval, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(order >= 2 && order <= 5, MI_ERR_INVALID_ARG, "spline order is not supported");
+    MI_REQUIRE(spline_mode >= 0 && spline_mode <= 2, MI_ERR_INVALID_ARG, "bad spline boundary mode");
+    MI_REQUIRE(out->dtype == MI_F64 || out->dtype == MI_F32, MI_ERR_INVALID_ARG, "coefficients are float64 or float32");
+    MI_REQUIRE(in->data != out->data, MI_ERR_INVALID_ARG, "mi_spline_prefilter works out of place");
+    // the first filtered axis can read the source directly when no padding or conversion is asked for
+    int first = -1;
+    for (int d = 0; d < out->ndim && first < 0; d++)
+        if (out->shape[d] > 1) first = d;
+    int64_t inner_first = 1;
+    for (int d = first + 1; first >= 0 && d < out->ndim; d++) inner_first *= out->shape[d];
+    const bool direct = npad == 0 && in->dtype == out->dtype && same_shape(in, out) && is_contiguous(in) && is_contiguous(out)
+                        && first >= 0 && inner_first > 1;
+    hipStream_t s = resolve_stream(stream);
+    if (!direct) {
+        if ((rc = mi_spline_pad(in, out, npad, pad_mode, cval, stream))) return rc;
     }
-    if (data->dtype == MI_F64)
-        hipLaunchKernelGGL(spline_filter1d_kernel<double>, dim3((unsigned)((nlines + 63) / 64)), dim3(64), 0,
-                           resolve_stream(stream), (double *)data->data, n, inner, nlines, order, spline_mode);
-    else
-        hipLaunchKernelGGL(spline_filter1d_kernel<float>, dim3((unsigned)((nlines + 63) / 64)), dim3(64), 0,
-                           resolve_stream(stream), (float *)data->data, n, inner, nlines, order, spline_mode);
-    MI_HIP(hipGetLastError());
+    for (int d = 0; d < out->ndim; d++) {
+        if (out->shape[d] <= 1) continue;
+        if ((rc = spline_pass(out, (direct && d == first) ? in->data : nullptr, d, order, spline_mode, s))) return rc;
+    }
     return MI_OK;
 }
 

@@ -70,11 +70,11 @@ def _to_coefficients(input, order, mode, cval, prefilter, f32=False):
     coef = core.empty(tuple(n + 2 * npad for n in src.shape), np.float32 if f32 else np.float64)
     a, b = src._desc(), coef._desc()
     lib = S.lib()
-    S.check(lib.mi_spline_pad(ctypes.byref(a), ctypes.byref(b), npad, pad_mode, float(cval), None))
     if prefilter:
-        for ax in range(coef.ndim):
-            if coef.shape[ax] > 1:
-                S.check(lib.mi_spline_filter1d(ctypes.byref(b), ax, int(order), _spline_mode_code(mode), None))
+        S.check(lib.mi_spline_prefilter(ctypes.byref(a), ctypes.byref(b), int(order), _spline_mode_code(mode), npad,
+                                        pad_mode, float(cval), None))
+    else:
+        S.check(lib.mi_spline_pad(ctypes.byref(a), ctypes.byref(b), npad, pad_mode, float(cval), None))
     return coef, npad
 
 
@@ -124,14 +124,15 @@ def spline_filter(input, order=3, output=np.float64, mode="mirror", *, allow_flo
     ret = _spline_output(output, input)
     if input.size == 0:
         return ret
-    coef = core.ascontiguousarray(input).astype(_coef_dtype(input, ret, allow_float32))
-    if core.shares_memory(coef, input):
-        coef = coef.copy()
-    d = coef._desc()
-    for ax in range(coef.ndim):
-        if coef.shape[ax] > 1:
-            S.check(S.lib().mi_spline_filter1d(ctypes.byref(d), ax, int(order), _spline_mode_code(mode), None))
-    ret[...] = coef
+    cdt = _coef_dtype(input, ret, allow_float32)
+    src = core.ascontiguousarray(input)
+    direct = ret._is_c_contiguous() and ret.dtype == cdt and not core.shares_memory(ret, src)
+    coef = ret if direct else core.empty(src.shape, cdt)
+    a, b = src._desc(), coef._desc()
+    S.check(S.lib().mi_spline_prefilter(ctypes.byref(a), ctypes.byref(b), int(order), _spline_mode_code(mode), 0, 0, 0.0,
+                                        None))
+    if not direct:
+        ret[...] = coef
     return ret
 
 

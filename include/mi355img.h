@@ -285,6 +285,11 @@ int mi_affine_transform(const mi_array *in, const mi_array *out, const double *m
 int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mode, double cval,
                   mi_stream stream);
 int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mode, mi_stream stream);
+/* mi_spline_pad followed by mi_spline_filter1d along every axis longer than one sample, in one call
+ * (the loop of spline_filter, interpolation.py:185-268); without padding and conversion the first
+ * pass reads `in` directly instead of copying it first. */
+int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int spline_mode, int npad,
+                        int pad_mode, double cval, mi_stream stream);
 int mi_spline_map_coordinates(const mi_array *coef, const mi_array *coords, const mi_array *out,
                               int order, int mode, double cval, int npad, mi_stream stream);
 int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const double *matrix,
