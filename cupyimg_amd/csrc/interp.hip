@@ -413,12 +413,59 @@ spline_affine_kernel(const double *__restrict__ in, void *__restrict__ out, int 
 // ---------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr unsigned kOobOffset = 0x80000000u;   // beyond any buffer: the load returns 0 without touching memory
+
 struct Cubic3 {
     float w[3][4];
     int off[3][4];      // element offset along the axis, -1: the tap reads cval
     int ntap[2];        // taps on z and y (1 on rank-padding axes)
     bool outside;       // constant mode, coordinate beyond the array: the voxel is cval
 };
+
+// 32-bit tap index outside [0, n): the symmetry the coefficients were computed with (spline_tap in int)
+__device__ __forceinline__ int spline_tap32(int i, int n, int mode)
+{
+    if (i >= 0 && i < n) return i;
+    if (mode == MI_MODE_GRID_CONSTANT) return -1;
+    if (mode == MI_MODE_REFLECT) return bmap<int>(i, n, MI_MODE_REFLECT);
+    if (mode == MI_MODE_NEAREST) return i < 0 ? 0 : n - 1;
+    if (mode == MI_MODE_GRID_WRAP) return bmap<int>(i, n, MI_MODE_GRID_WRAP);
+    return bmap<int>(i, n, MI_MODE_MIRROR);
+}
+
+// one axis of the tap selection: coordinate in double (as the double route), everything after the
+// integer / fraction split in 32 bits.  Returns true when the coordinate is beyond the array in constant mode.
+__device__ __forceinline__ bool cubic3_axis(int n, int stride, double cc, int mode, int npad, float (&w)[4], int (&off)[4])
+{
+    bool outside = false;
+    cc += (double)npad;
+    if (mode == MI_MODE_CONSTANT) {
+        if (cc < 0 || cc > (double)(n - 1)) { outside = true; cc = 0.0; }
+    } else if (mode != MI_MODE_GRID_CONSTANT && mode != MI_MODE_NEAREST) {
+        cc = fold_coord(cc, n, mode);
+    } else {
+        // taps are mapped one by one below; keep the integer part inside 32 bits for far-away coordinates
+        cc = cc < -1.0e9 ? -1.0e9 : (cc > 1.0e9 ? 1.0e9 : cc);
+    }
+    const double fl = floor(cc);
+    const int start = (int)fl - 1;
+    const float x = (float)(cc - fl), y = 1.f - x;
+    w[1] = (x * x * (x - 2.f) * 3.f + 4.f) * (1.f / 6.f);
+    w[2] = (y * y * (y - 2.f) * 3.f + 4.f) * (1.f / 6.f);
+    w[0] = y * y * y * (1.f / 6.f);
+    w[3] = 1.f - w[0] - w[1] - w[2];
+    if (start >= 0 && start + 3 < n) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) off[k] = (start + k) * stride;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = spline_tap32(start + k, n, mode);
+            off[k] = j < 0 ? -1 : j * stride;
+        }
+    }
+    return outside;
+}
 
 __device__ __forceinline__ void cubic3_setup(const InterpGeom &g, const double (&c)[3], int mode, int npad, Cubic3 &t)
 {
@@ -432,70 +479,101 @@ __device__ __forceinline__ void cubic3_setup(const InterpGeom &g, const double (
             continue;
         }
         if (d < 2) t.ntap[d] = 4;
-        const int64_t n = g.shape[d];
-        double cc = c[d] + (double)npad;
-        if (mode == MI_MODE_CONSTANT) {
-            if (cc < 0 || cc > (double)(n - 1)) { t.outside = true; cc = 0.0; }
-        } else if (mode != MI_MODE_GRID_CONSTANT && mode != MI_MODE_NEAREST) {
-            cc = fold_coord(cc, n, mode);
-        }
-        const double fl = floor(cc);
-        const int64_t start = (int64_t)fl - 1;
-        const float x = (float)(cc - fl), y = 1.f - x;
-        t.w[d][1] = (x * x * (x - 2.f) * 3.f + 4.f) * (1.f / 6.f);
-        t.w[d][2] = (y * y * (y - 2.f) * 3.f + 4.f) * (1.f / 6.f);
-        t.w[d][0] = y * y * y * (1.f / 6.f);
-        t.w[d][3] = 1.f - t.w[d][0] - t.w[d][1] - t.w[d][2];
-        const bool interior = start >= 0 && start + 3 < n;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int64_t j = interior ? start + k : spline_tap(start + k, n, mode);
-            t.off[d][k] = j < 0 ? -1 : (int)(j * g.stride[d]);
-        }
+        t.outside |= cubic3_axis((int)g.shape[d], (int)g.stride[d], c[d], mode, npad, t.w[d], t.off[d]);
     }
 }
 
-__device__ __forceinline__ float cubic3_gather(const __amdgpu_buffer_rsrc_t rin, const Cubic3 &t, float cval)
+// Diagonal transforms: taps and weights of an axis depend on the output index along that axis only, so
+// they are tabulated once per call (oz + oy + ox entries) instead of once per voxel.
+struct AxisTaps { float w[4]; int off[4]; int outside; int pad_[3]; };
+
+__global__ void __launch_bounds__(256)
+cubic3_axis_table_kernel(AxisTaps *__restrict__ tab, InterpGeom g, int mode, int npad)
+{
+    const int d = blockIdx.y;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= (int)g.oshape[d]) return;
+    int base = 0;
+    for (int k = 0; k < d; k++) base += (int)g.oshape[k];
+    AxisTaps e;
+    e.pad_[0] = e.pad_[1] = e.pad_[2] = 0;
+    if (d < g.pad) {
+        e.outside = 0;
+        for (int k = 0; k < 4; k++) { e.w[k] = 1.f; e.off[k] = 0; }
+    } else {
+        const double c = g.mat[d * 4 + d] * (double)o + g.mat[d * 4 + 3];
+        e.outside = cubic3_axis((int)g.shape[d], (int)g.stride[d], c, mode, npad, e.w, e.off) ? 1 : 0;
+    }
+    tab[base + o] = e;
+}
+
+// CVTAPS: taps may read cval (grid-constant only); otherwise no tap offset is ever negative
+template <int NTZ, int NTY, bool CVTAPS>
+__device__ __forceinline__ float cubic3_gather_t(const __amdgpu_buffer_rsrc_t rin, const Cubic3 &t, float cval)
 {
     const bool consec = t.off[2][0] >= 0 && t.off[2][3] == t.off[2][0] + 3;
-    float acc = 0.f;
+    float v[NTZ][NTY][4];
+    if (consec) {
+        u32x4 q[NTZ][NTY];
 #pragma unroll
-    for (int kz = 0; kz < 4; kz++) {
-        if (kz >= t.ntap[0]) break;
+        for (int kz = 0; kz < NTZ; kz++)
 #pragma unroll
-        for (int ky = 0; ky < 4; ky++) {
-            if (ky >= t.ntap[1]) break;
-            const float wzy = t.w[0][kz] * t.w[1][ky];
-            const bool oob_zy = t.off[0][kz] < 0 || t.off[1][ky] < 0;
-            const int base = oob_zy ? 0 : t.off[0][kz] + t.off[1][ky];
-            float v[4];
-            if (consec) {
-                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)(base + t.off[2][0]) * 4u, 0, 0);
-                v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y);
-                v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
-                if (oob_zy) v[0] = v[1] = v[2] = v[3] = cval;
-            } else {
+            for (int ky = 0; ky < NTY; ky++) {
+                const bool oob_zy = CVTAPS && (t.off[0][kz] < 0 || t.off[1][ky] < 0);
+                const int base = oob_zy ? 0 : t.off[0][kz] + t.off[1][ky];
+                q[kz][ky] = __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)(base + t.off[2][0]) * 4u, 0, 0);
+            }
+#pragma unroll
+        for (int kz = 0; kz < NTZ; kz++)
+#pragma unroll
+            for (int ky = 0; ky < NTY; ky++) {
+                const bool oob_zy = CVTAPS && (t.off[0][kz] < 0 || t.off[1][ky] < 0);
+                v[kz][ky][0] = oob_zy ? cval : __uint_as_float(q[kz][ky].x);
+                v[kz][ky][1] = oob_zy ? cval : __uint_as_float(q[kz][ky].y);
+                v[kz][ky][2] = oob_zy ? cval : __uint_as_float(q[kz][ky].z);
+                v[kz][ky][3] = oob_zy ? cval : __uint_as_float(q[kz][ky].w);
+            }
+    } else {
+#pragma unroll
+        for (int kz = 0; kz < NTZ; kz++)
+#pragma unroll
+            for (int ky = 0; ky < NTY; ky++) {
+                const bool oob_zy = CVTAPS && (t.off[0][kz] < 0 || t.off[1][ky] < 0);
+                const int base = oob_zy ? 0 : t.off[0][kz] + t.off[1][ky];
 #pragma unroll
                 for (int kx = 0; kx < 4; kx++) {
-                    const bool oob = oob_zy || t.off[2][kx] < 0;
+                    const bool oob = CVTAPS && (oob_zy || t.off[2][kx] < 0);
                     const float q = __uint_as_float(
                         __builtin_amdgcn_raw_buffer_load_b32(rin, oob ? 0u : (unsigned)(base + t.off[2][kx]) * 4u, 0, 0));
-                    v[kx] = oob ? cval : q;
+                    v[kz][ky][kx] = oob ? cval : q;
                 }
             }
-            float row = v[0] * t.w[2][0];
-            row = fmaf(v[1], t.w[2][1], row);
-            row = fmaf(v[2], t.w[2][2], row);
-            row = fmaf(v[3], t.w[2][3], row);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int kz = 0; kz < NTZ; kz++)
+#pragma unroll
+        for (int ky = 0; ky < NTY; ky++) {
+            const float wzy = t.w[0][kz] * t.w[1][ky];
+            float row = v[kz][ky][0] * t.w[2][0];
+            row = fmaf(v[kz][ky][1], t.w[2][1], row);
+            row = fmaf(v[kz][ky][2], t.w[2][2], row);
+            row = fmaf(v[kz][ky][3], t.w[2][3], row);
             acc = fmaf(row, wzy, acc);
         }
-    }
     return t.outside ? cval : acc;
+}
+
+template <int NTZ, int NTY>
+__device__ __forceinline__ float cubic3_gather(const __amdgpu_buffer_rsrc_t rin, const Cubic3 &t, float cval, int mode)
+{
+    if (mode == MI_MODE_GRID_CONSTANT) return cubic3_gather_t<NTZ, NTY, true>(rin, t, cval);
+    return cubic3_gather_t<NTZ, NTY, false>(rin, t, cval);
 }
 
 // block (64, 4): 64 lanes along the output x axis, so that the gathers of a wave touch neighbouring
 // coefficients; grid (x tiles, y tiles, z) -- no index divisions
-template <typename C, bool AFFINE>
+template <typename C, bool AFFINE, int NTZ, int NTY>
 __global__ void __launch_bounds__(256)
 cubic3_f32_kernel(const float *__restrict__ in, const C *__restrict__ coords, float *__restrict__ out, InterpGeom g,
                   int64_t nout, int64_t nin, int mode, float cval, int npad)
@@ -522,7 +600,94 @@ cubic3_f32_kernel(const float *__restrict__ in, const C *__restrict__ coords, fl
     }
     Cubic3 t;
     cubic3_setup(g, c, mode, npad, t);
-    __builtin_nontemporal_store(cubic3_gather(rin, t, cval), out + i);
+    __builtin_nontemporal_store((cubic3_gather<NTZ, NTY>(rin, t, cval, mode)), out + i);
+}
+
+// Diagonal transforms (zoom, shift; the reference's zoom/shift kernel, _interp_kernels.py:655-688): the 64
+// voxels of a wave share their z and y taps and read one contiguous run of coefficients per (z, y) row.
+// The 16 rows are blended first (coalesced loads, wave-uniform weights) into a strip of <= 128 values in
+// LDS, then every lane takes its four x taps from the strip.  Waves whose x taps are not consecutive runs
+// (boundary folds) or span more than 128 coefficients use the gather path.
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = min(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+template <int NTZ, int NTY>
+__global__ void __launch_bounds__(256)
+cubic3_diag_f32_kernel(const float *__restrict__ in, float *__restrict__ out, const AxisTaps *__restrict__ tab, InterpGeom g,
+                       int64_t nin, int mode, float cval)
+{
+    __shared__ float strips[4][128];
+    const int ox = (int)g.oshape[2], oy = (int)g.oshape[1], oz = (int)g.oshape[0];
+    const int x = blockIdx.x * 64 + threadIdx.x, z = blockIdx.z;
+    const int y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);     // one row per wave
+    if (y >= oy) return;
+    const bool live = x < ox;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)(nin * 4), 0x00020000);
+    const AxisTaps ez = tab[z], ey = tab[oz + y];                   // wave-uniform: scalar loads
+    const AxisTaps ex = tab[oz + oy + (live ? x : ox - 1)];
+    Cubic3 t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        t.w[0][k] = ez.w[k]; t.off[0][k] = ez.off[k];
+        t.w[1][k] = ey.w[k]; t.off[1][k] = ey.off[k];
+        t.w[2][k] = ex.w[k]; t.off[2][k] = ex.off[k];
+    }
+    t.ntap[0] = NTZ; t.ntap[1] = NTY;
+    t.outside = (ez.outside | ey.outside | ex.outside) != 0;
+    // lanes beyond the array in constant mode produce cval whatever they read: they do not constrain the strip
+    const bool consec = t.outside || (t.off[2][0] >= 0 && t.off[2][3] == t.off[2][0] + 3);
+    const int x0 = wave_min((consec && !t.outside) ? t.off[2][0] : 0x7fffffff);
+    const int x1 = wave_max((consec && !t.outside) ? t.off[2][0] : -1);
+    const bool strip_ok = __all(consec) && x1 >= x0 && x1 - x0 + 4 <= 128;
+    float res;
+    if (strip_ok) {
+        const int lane = threadIdx.x;
+        const bool second = x1 - x0 + 4 > 64;
+        float s0 = 0.f, s1 = 0.f;
+        float a0[NTZ][NTY], a1[NTZ][NTY];
+#pragma unroll
+        for (int kz = 0; kz < NTZ; kz++)
+#pragma unroll
+            for (int ky = 0; ky < NTY; ky++) {
+                const bool oob_zy = t.off[0][kz] < 0 || t.off[1][ky] < 0;
+                const unsigned b = oob_zy ? 0u : (unsigned)(t.off[0][kz] + t.off[1][ky] + x0 + lane) * 4u;
+                a0[kz][ky] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rin, b, 0, 0));
+                a1[kz][ky] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rin, second ? b + 256u : kOobOffset, 0, 0));
+            }
+#pragma unroll
+        for (int kz = 0; kz < NTZ; kz++)
+#pragma unroll
+            for (int ky = 0; ky < NTY; ky++) {
+                const float wzy = t.w[0][kz] * t.w[1][ky];
+                const bool oob_zy = t.off[0][kz] < 0 || t.off[1][ky] < 0;
+                s0 = fmaf(oob_zy ? cval : a0[kz][ky], wzy, s0);
+                s1 = fmaf(oob_zy ? cval : a1[kz][ky], wzy, s1);
+            }
+        float *strip = strips[threadIdx.y];
+        strip[lane] = s0;
+        strip[lane + 64] = s1;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the strip is written by this wave only
+        const int j = t.outside ? 0 : t.off[2][0] - x0;
+        float r = strip[j] * t.w[2][0];
+        r = fmaf(strip[j + 1], t.w[2][1], r);
+        r = fmaf(strip[j + 2], t.w[2][2], r);
+        r = fmaf(strip[j + 3], t.w[2][3], r);
+        res = t.outside ? cval : r;
+    } else {
+        res = cubic3_gather<NTZ, NTY>(rin, t, cval, mode);
+    }
+    if (live) __builtin_nontemporal_store(res, out + ((int64_t)z * oy + y) * ox + x);
 }
 
 // output geometry of the cubic kernel: the output's own shape, rank-padded with leading ones
@@ -899,6 +1064,8 @@ using namespace mi;
 
 static int g_interp_generic = 0;   // test hook: 1 = always use the generic double kernels
 static int g_spline_rows_off = 0;  // test hook: 1 = one thread per line also for contiguous lines
+static int g_cubic_diag_off = 0;    // test hook: 1 = diagonal transforms use the gather kernel too
+extern "C" int mi_debug_set_cubic_diag(int on) { g_cubic_diag_off = !on; return MI_OK; }
 static int g_spline_rows_force = 0; // test hook: 2 = tiled kernel whatever the line count
 extern "C" int mi_debug_set_spline_rows(int on) { g_spline_rows_off = on == 0; g_spline_rows_force = on == 2; return MI_OK; }
 extern "C" int mi_debug_set_interp_generic(int v) { g_interp_generic = v; return MI_OK; }
@@ -1138,12 +1305,16 @@ int mi_spline_map_coordinates(const mi_array *coef, const mi_array *coords, cons
         MI_REQUIRE(out->ndim >= 1 && out->ndim <= 3, MI_ERR_UNSUPPORTED, "float32 cubic route: output rank 1..3");
         dim3 cgrid;
         MI_REQUIRE(cubic3_grid(out, &g, &cgrid), MI_ERR_UNSUPPORTED, "float32 cubic route: output too large");
-        if (coords->dtype == MI_F32)
-            hipLaunchKernelGGL((cubic3_f32_kernel<float, false>), cgrid, dim3(64, 4), 0, s, (const float *)coef->data,
-                               (const float *)coords->data, (float *)out->data, g, nout, numel(coef), mode, (float)cval, npad);
-        else
-            hipLaunchKernelGGL((cubic3_f32_kernel<double, false>), cgrid, dim3(64, 4), 0, s, (const float *)coef->data,
-                               (const double *)coords->data, (float *)out->data, g, nout, numel(coef), mode, (float)cval, npad);
+#define MI_CUBIC_MAP(C, NTZ, NTY)                                                                                     \
+    hipLaunchKernelGGL((cubic3_f32_kernel<C, false, NTZ, NTY>), cgrid, dim3(64, 4), 0, s, (const float *)coef->data,   \
+                       (const C *)coords->data, (float *)out->data, g, nout, numel(coef), mode, (float)cval, npad)
+#define MI_CUBIC_MAP_RANK(C)                                                   \
+    if (g.pad == 0) MI_CUBIC_MAP(C, 4, 4);                                     \
+    else if (g.pad == 1) MI_CUBIC_MAP(C, 1, 4);                                \
+    else MI_CUBIC_MAP(C, 1, 1)
+        if (coords->dtype == MI_F32) { MI_CUBIC_MAP_RANK(float); } else { MI_CUBIC_MAP_RANK(double); }
+#undef MI_CUBIC_MAP_RANK
+#undef MI_CUBIC_MAP
         MI_HIP(hipGetLastError());
         return MI_OK;
     }
@@ -1191,8 +1362,30 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
         MI_REQUIRE(is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "needs a C-contiguous output");
         dim3 cgrid;
         MI_REQUIRE(cubic3_grid(out, &g, &cgrid), MI_ERR_UNSUPPORTED, "float32 cubic route: output too large");
-        hipLaunchKernelGGL((cubic3_f32_kernel<float, true>), cgrid, dim3(64, 4), 0, s, (const float *)coef->data,
-                           (const float *)nullptr, (float *)out->data, g, nout, numel(coef), mode, (float)cval, npad);
+        bool diagonal = !g_cubic_diag_off;
+        for (int d = 0; d < n; d++)
+            for (int k = 0; k < n; k++)
+                if (d != k && matrix[d * (n + 1) + k] != 0.0) diagonal = false;
+        void *tab = nullptr;
+        if (diagonal) {
+            const int64_t entries = g.oshape[0] + g.oshape[1] + g.oshape[2];
+            int64_t longest = g.oshape[0] > g.oshape[1] ? g.oshape[0] : g.oshape[1];
+            if (g.oshape[2] > longest) longest = g.oshape[2];
+            if ((rc = pool_alloc(&tab, (size_t)entries * sizeof(AxisTaps)))) return rc;
+            hipLaunchKernelGGL(cubic3_axis_table_kernel, dim3((unsigned)((longest + 255) / 256), 3), dim3(256), 0, s,
+                               (AxisTaps *)tab, g, mode, npad);
+        }
+#define MI_CUBIC_AFF(NTZ, NTY)                                                                                          \
+    if (diagonal)                                                                                                       \
+        hipLaunchKernelGGL((cubic3_diag_f32_kernel<NTZ, NTY>), cgrid, dim3(64, 4), 0, s, (const float *)coef->data,     \
+                           (float *)out->data, (const AxisTaps *)tab, g, numel(coef), mode, (float)cval);               \
+    else                                                                                                                \
+        hipLaunchKernelGGL((cubic3_f32_kernel<float, true, NTZ, NTY>), cgrid, dim3(64, 4), 0, s,                        \
+                           (const float *)coef->data, (const float *)nullptr, (float *)out->data, g, nout, numel(coef), \
+                           mode, (float)cval, npad)
+        if (g.pad == 0) { MI_CUBIC_AFF(4, 4); } else if (g.pad == 1) { MI_CUBIC_AFF(1, 4); } else { MI_CUBIC_AFF(1, 1); }
+#undef MI_CUBIC_AFF
+        if (tab) pool_free(tab);       // stream-ordered pool: the block is reused only by later work on the stream
         MI_HIP(hipGetLastError());
         return MI_OK;
     }

@@ -946,3 +946,41 @@ def test_spline_prefilter_contiguous_lines_kernel(gpu, ndi):
     v = rng.standard_normal((130, 130, 140)).astype(np.float32)
     got = ndi.spline_filter(gpu.asarray(v), 3, output=np.float64)
     np.testing.assert_allclose(got.get(), sndi.spline_filter(v.astype(np.float64), 3), rtol=1e-11, atol=1e-11)
+
+
+def test_float32_cubic_zoom_shift_strip_kernel(gpu, ndi):
+    """Diagonal transforms on the float32 cubic route blend rows into an LDS strip; same results as
+    the gather kernel (float rounding apart) and SciPy within the route's tolerance."""
+    import ctypes
+    import scipy.ndimage as sndi
+    from cupyimg_amd import _lib
+    hook = _lib.load().mi_debug_set_cubic_diag
+    hook.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(172)
+    modes = ["constant", "nearest", "mirror", "reflect", "wrap", "grid-wrap", "grid-constant"]
+    for shape in [(70, 200), (9, 33, 150), (300,)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        tol = 8e-5 * float(np.abs(x).max())
+        for mode in modes:
+            for zf in (0.37, 0.8, 1.0, 1.25, 2.6):
+                want = sndi.zoom(x.astype(np.float64), zf, order=3, mode=mode)
+                got = ndi.zoom(xd, zf, order=3, mode=mode)
+                assert got.shape == want.shape
+                assert np.abs(got.get() - want).max() <= tol, (shape, mode, zf)
+                hook(0)
+                try:
+                    ref = ndi.zoom(xd, zf, order=3, mode=mode).get()
+                finally:
+                    hook(1)
+                assert np.abs(got.get() - ref).max() <= 2e-6 * float(np.abs(x).max()), (shape, mode, zf)
+            for sh in (1.7, -3.25, [0.5, -2.0, 4.75][:len(shape)]):
+                want = sndi.shift(x.astype(np.float64), sh, order=3, mode=mode, cval=2.0)
+                got = ndi.shift(xd, sh, order=3, mode=mode, cval=2.0)
+                assert np.abs(got.get() - want).max() <= tol, (shape, mode, sh)
+        # diagonal affine with a flip (negative x step)
+        d = np.array([1.1, -0.9, 0.7][:len(shape)])
+        off = np.where(d < 0, np.array(shape) - 1.0, 0.0)
+        want = sndi.affine_transform(x.astype(np.float64), d, offset=off, order=3, mode="mirror")
+        got = ndi.affine_transform(xd, d, offset=off, order=3, mode="mirror")
+        assert np.abs(got.get() - want).max() <= tol
