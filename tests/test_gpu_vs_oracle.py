@@ -984,3 +984,22 @@ def test_float32_cubic_zoom_shift_strip_kernel(gpu, ndi):
         want = sndi.affine_transform(x.astype(np.float64), d, offset=off, order=3, mode="mirror")
         got = ndi.affine_transform(xd, d, offset=off, order=3, mode="mirror")
         assert np.abs(got.get() - want).max() <= tol
+
+
+def test_rank_filter_sorting_network_sizes(gpu, ndi):
+    """Footprints of 9 ... 64 samples take the register sorting network (three padded sizes); beyond that and
+    for wide dtypes the selection kernel.  Both against SciPy."""
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(131)
+    img = rng.integers(0, 255, size=(45, 52)).astype(np.uint8)
+    vol = rng.standard_normal((12, 20, 22)).astype(np.float32)
+    for x in (img, vol, img.astype(np.uint16) * 200, vol.astype(np.float64), img.astype(np.int32) - 100):
+        xd = gpu.asarray(x)
+        sizes = [3, 4, 5, 7, 8, 9] if x.ndim == 2 else [2, 3, 4]
+        for size in sizes:
+            n = size ** x.ndim
+            for rank in sorted({0, 1, n // 3, n // 2, n - 2, n - 1}):
+                want = sndi.rank_filter(x, rank, size=size, mode="reflect")
+                assert np.array_equal(ndi.rank_filter(xd, rank, size=size, mode="reflect").get(), want), (x.dtype, size, rank)
+        assert np.array_equal(ndi.median_filter(xd, size=3, mode="constant", cval=7).get(),
+                              sndi.median_filter(x, size=3, mode="constant", cval=7))
