@@ -179,14 +179,14 @@ __device__ __forceinline__ void rank_static_for(F &&f)
     }
 }
 
-// Footprints of up to 64 samples on dtypes a float holds exactly (float32, 8- and 16-bit integers): the
-// samples stay in registers (every index below is static after unrolling) and go through a bitonic
+// Footprints of up to 64 samples, values held as float (float32, 8- and 16-bit integers: exact) or as
+// double (float64, 32-bit integers): the samples stay in registers (every index below is static after unrolling) and go through a bitonic
 // sorting network padded with +inf -- P (log2 P)(log2 P + 1) / 4 compare-exchanges of one v_min + one
 // v_max each, no scratch memory.  The reference picks per-size selection networks
 // (_filters_optimal_medians.py); one network per padded size covers every rank.
-template <typename T, int P>
+template <typename T, typename V, int P>
 __global__ void __launch_bounds__(256)
-rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps3 tt, int mode, float cval, int rank)
+rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps3 tt, int mode, V cval, int rank)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LdsTaps lt = stage_taps(tt, smem);
@@ -194,22 +194,22 @@ rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps
     if (!v.valid) return;
     const __amdgpu_buffer_rsrc_t rin =
         __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)((unsigned)g.nz * g.ny * g.nx * sizeof(T)), 0x00020000);
-    float vals[P];
+    V vals[P];
     const int n = tt.ntaps;
     if (v.interior) {
         const unsigned base = (unsigned)v.lin * (unsigned)sizeof(T);
         rank_static_for<P>([&](auto TT) {
             constexpr int t = decltype(TT)::value;
-            vals[t] = t < n ? (float)buf_load<T>(rin, base + (unsigned)(lt.lin[t] * (int)sizeof(T))) : INFINITY;
+            vals[t] = t < n ? (V)buf_load<T>(rin, base + (unsigned)(lt.lin[t] * (int)sizeof(T))) : (V)INFINITY;
         });
     } else {
         rank_static_for<P>([&](auto TT) {
             constexpr int t = decltype(TT)::value;
             if (t < n) {
                 const int pos = tap_pos3(g, v, lt, t, mode);
-                vals[t] = pos < 0 ? cval : (float)buf_load<T>(rin, (unsigned)pos * (unsigned)sizeof(T));
+                vals[t] = pos < 0 ? cval : (V)buf_load<T>(rin, (unsigned)pos * (unsigned)sizeof(T));
             } else {
-                vals[t] = INFINITY;
+                vals[t] = (V)INFINITY;
             }
         });
     }
@@ -223,15 +223,15 @@ rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps
                 constexpr int i = decltype(II)::value;
                 constexpr int l = i ^ j;
                 if constexpr (l > i) {
-                    const float a = vals[i], b = vals[l];
-                    const float lo = fminf(a, b), hi = fmaxf(a, b);
+                    const V a = vals[i], b = vals[l];
+                    const V lo = a < b ? a : b, hi = a < b ? b : a;
                     if constexpr ((i & k) == 0) { vals[i] = lo; vals[l] = hi; }
                     else { vals[i] = hi; vals[l] = lo; }
                 }
             });
         });
     });
-    float res = vals[0];
+    V res = vals[0];
     rank_static_for<P - 1>([&](auto TT) {
         constexpr int t = decltype(TT)::value + 1;
         res = rank == t ? vals[t] : res;
@@ -400,14 +400,17 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
         else if constexpr (std::is_same<T, uint64_t>::value)
             cv = (double)(cval >= 0 ? (uint64_t)cval : (uint64_t)(-(int64_t)(uint64_t)(-cval)));
         else cv = (double)(T)(int64_t)cval;
-        constexpr bool float_exact = std::is_same<T, float>::value || std::is_same<T, uint8_t>::value ||
-                                     std::is_same<T, int8_t>::value || std::is_same<T, uint16_t>::value ||
-                                     std::is_same<T, int16_t>::value;
-        if constexpr (float_exact) {
+        constexpr bool as_float = std::is_same<T, float>::value || std::is_same<T, uint8_t>::value ||
+                                  std::is_same<T, int8_t>::value || std::is_same<T, uint16_t>::value ||
+                                  std::is_same<T, int16_t>::value;
+        constexpr bool as_double = std::is_same<T, double>::value || std::is_same<T, int32_t>::value ||
+                                   std::is_same<T, uint32_t>::value;
+        if constexpr (as_float || as_double) {
+            using V = std::conditional_t<as_float, float, double>;
             if (tt3.ntaps <= 64 && out->dtype == in->dtype && g_rank_sorted) {
 #define MI_RANK_SORTED(P)                                                                                               \
-    hipLaunchKernelGGL((rank3_sorted_kernel<T, P>), grid3(t3.g), dim3(64, 4, 1), taps3_lds_bytes(tt3), s,               \
-                       (const T *)in->data, (T *)out->data, t3.g, tt3, mode, (float)cv, rank)
+    hipLaunchKernelGGL((rank3_sorted_kernel<T, V, P>), grid3(t3.g), dim3(64, 4, 1), taps3_lds_bytes(tt3), s,            \
+                       (const T *)in->data, (T *)out->data, t3.g, tt3, mode, (V)cv, rank)
                 if (tt3.ntaps <= 16) MI_RANK_SORTED(16);
                 else if (tt3.ntaps <= 32) MI_RANK_SORTED(32);
                 else MI_RANK_SORTED(64);
