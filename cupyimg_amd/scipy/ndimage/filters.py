@@ -560,6 +560,14 @@ def _derivative_then_smooth(input, axis, output, mode, cval, smooth):
     axis = S.normalize_axis(axis, input.ndim)
     output = S.get_output(output, input)
     modes = S.normalize_sequence(mode, input.ndim)
+    if input.ndim in (2, 3) and input.dtype == np.float32 and output.dtype == np.float32 and input.size:
+        # a separable product of 3-tap kernels: one fused launch for float32 images / volumes
+        for m in modes:
+            S.check_mode(m)
+        w = [np.asarray([-1.0, 0.0, 1.0]) if ii == axis else np.asarray(smooth, dtype=np.float64) for ii in range(input.ndim)]
+        res = _try_fused_3d(input, output, w, [0] * input.ndim, list(modes), cval, False)
+        if res is not None:
+            return res
     correlate1d(input, [-1, 0, 1], axis, output, modes[axis], cval, 0, dtype_mode="ndimage")
     for ii in range(input.ndim):
         if ii != axis:
@@ -599,6 +607,19 @@ def laplace(input, output=None, mode="reflect", cval=0.0):
     """Laplace filter from [1, -2, 1] second differences (filters.py:1014-1043)."""
     def derivative2(input, axis, output, mode, cval):
         return correlate1d(input, [1, -2, 1], axis, output, mode, cval, 0, dtype_mode="ndimage")
+    input = S.as_device(input)
+    if input.ndim in (2, 3) and input.dtype == np.float32 and isinstance(mode, str) and (
+            output is None or (isinstance(output, core.ndarray) and output.dtype == np.float32)):
+        # the sum of the second differences is one (2 ndim + 1)-point stencil: a single tiled launch for float32
+        cross = np.zeros((3,) * input.ndim)
+        centre = (1,) * input.ndim
+        cross[centre] = -2.0 * input.ndim
+        for ax in range(input.ndim):
+            for d in (0, 2):
+                idx = list(centre)
+                idx[ax] = d
+                cross[tuple(idx)] = 1.0
+        return correlate(input, cross, output, mode, cval)
     return generic_laplace(input, derivative2, output, mode, cval)
 
 
