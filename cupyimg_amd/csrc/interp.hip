@@ -488,7 +488,7 @@ __device__ __forceinline__ void cubic3_setup(const InterpGeom &g, const double (
 struct AxisTaps { float w[4]; int off[4]; int outside; int pad_[3]; };
 
 __global__ void __launch_bounds__(256)
-cubic3_axis_table_kernel(AxisTaps *__restrict__ tab, InterpGeom g, int mode, int npad)
+cubic3_axis_table_kernel(AxisTaps *__restrict__ tab, InterpGeom g, int mode, int npad, int unit_stride)
 {
     const int d = blockIdx.y;
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -502,9 +502,101 @@ cubic3_axis_table_kernel(AxisTaps *__restrict__ tab, InterpGeom g, int mode, int
         for (int k = 0; k < 4; k++) { e.w[k] = 1.f; e.off[k] = 0; }
     } else {
         const double c = g.mat[d * 4 + d] * (double)o + g.mat[d * 4 + 3];
-        e.outside = cubic3_axis((int)g.shape[d], (int)g.stride[d], c, mode, npad, e.w, e.off) ? 1 : 0;
+        e.outside = cubic3_axis((int)g.shape[d], unit_stride ? 1 : (int)g.stride[d], c, mode, npad, e.w, e.off) ? 1 : 0;
     }
     tab[base + o] = e;
+}
+
+// Diagonal transforms as separable 1-D resampling passes (x, then y, then z): every pass reads four taps
+// per output sample -- rows (y, z passes: wave-uniform taps, coalesced loads) or neighbours within a row
+// (x pass) -- so the traffic is one read and one write of each intermediate instead of 16 rows per voxel.
+// Tap indices in `tab` are plain indices along the axis (unit stride), -1 = the tap reads cval.
+// The last pass writes cval where any axis' coordinate is beyond the array (constant mode).
+//   AXIS 2: in (n0, n1, nin) -> out (n0, n1, nout);  AXIS 1: in (n0, nin, n2) -> out (n0, nout, n2);
+//   AXIS 0: in (nin, n1, n2) -> out (nout, n1, n2).   Grid over the pass's output: (x tiles, y / 4, z).
+template <int AXIS>
+__global__ void __launch_bounds__(256)
+cubic_resample_axis_kernel(const float *__restrict__ in, float *__restrict__ out, const AxisTaps *__restrict__ tab,
+                           int d0, int d1, int d2, int nin, float cval, const AxisTaps *__restrict__ all_tabs, int oz, int oy,
+                           int last)
+{
+    // (d0, d1, d2): output shape of this pass
+    const int x = blockIdx.x * 64 + threadIdx.x, z = blockIdx.z;
+    const int y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    if (y >= d1 || x >= d2) return;
+    float w[4];
+    int off[4];
+    size_t base, step;
+    if constexpr (AXIS == 2) {
+        const AxisTaps e = tab[x];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { w[k] = e.w[k]; off[k] = e.off[k]; }
+        base = ((size_t)z * d1 + y) * (size_t)nin;
+        step = 1;
+    } else if constexpr (AXIS == 1) {
+        const AxisTaps e = tab[y];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { w[k] = e.w[k]; off[k] = e.off[k]; }
+        base = (size_t)z * nin * (size_t)d2 + x;
+        step = (size_t)d2;
+    } else {
+        const AxisTaps e = tab[z];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { w[k] = e.w[k]; off[k] = e.off[k]; }
+        base = (size_t)y * d2 + x;
+        step = (size_t)d1 * d2;
+    }
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = in[base + (size_t)(off[k] < 0 ? 0 : off[k]) * step];
+    float r = (off[0] < 0 ? cval : v[0]) * w[0];
+#pragma unroll
+    for (int k = 1; k < 4; k++) r = fmaf(off[k] < 0 ? cval : v[k], w[k], r);
+    if (last) {
+        const int outside = all_tabs[z].outside | all_tabs[oz + y].outside | all_tabs[oz + oy + x].outside;
+        if (outside) r = cval;
+    }
+    out[((size_t)z * d1 + y) * (size_t)d2 + x] = r;
+}
+
+// y / z passes on four x-consecutive samples per thread (16-byte loads and stores; d2 % 4 == 0)
+template <int AXIS>
+__global__ void __launch_bounds__(256)
+cubic_resample_rows4_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, const AxisTaps *__restrict__ tab,
+                            int d0, int d1, int d2q, int nin, float cval, const AxisTaps *__restrict__ all_tabs, int oz, int oy,
+                            int last)
+{
+    const int xq = blockIdx.x * 64 + threadIdx.x, z = blockIdx.z;
+    const int y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    if (y >= d1 || xq >= d2q) return;
+    const AxisTaps e = tab[AXIS == 1 ? y : z];
+    size_t base, step;
+    if constexpr (AXIS == 1) { base = (size_t)z * nin * (size_t)d2q + xq; step = (size_t)d2q; }
+    else { base = (size_t)y * d2q + xq; step = (size_t)d1 * d2q; }
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = in[base + (size_t)(e.off[k] < 0 ? 0 : e.off[k]) * step];
+    float4 r;
+    {
+        const bool c0 = e.off[0] < 0;
+        r.x = (c0 ? cval : v[0].x) * e.w[0]; r.y = (c0 ? cval : v[0].y) * e.w[0];
+        r.z = (c0 ? cval : v[0].z) * e.w[0]; r.w = (c0 ? cval : v[0].w) * e.w[0];
+    }
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        const bool c = e.off[k] < 0;
+        r.x = fmaf(c ? cval : v[k].x, e.w[k], r.x); r.y = fmaf(c ? cval : v[k].y, e.w[k], r.y);
+        r.z = fmaf(c ? cval : v[k].z, e.w[k], r.z); r.w = fmaf(c ? cval : v[k].w, e.w[k], r.w);
+    }
+    if (last) {
+        const int ozy = all_tabs[z].outside | all_tabs[oz + y].outside;
+        const AxisTaps *tx = all_tabs + oz + oy + 4 * xq;
+        if (ozy | tx[0].outside) r.x = cval;
+        if (ozy | tx[1].outside) r.y = cval;
+        if (ozy | tx[2].outside) r.z = cval;
+        if (ozy | tx[3].outside) r.w = cval;
+    }
+    out[((size_t)z * d1 + y) * (size_t)d2q + xq] = r;
 }
 
 // CVTAPS: taps may read cval (grid-constant only); otherwise no tap offset is ever negative
@@ -1064,6 +1156,8 @@ using namespace mi;
 
 static int g_interp_generic = 0;   // test hook: 1 = always use the generic double kernels
 static int g_spline_rows_off = 0;  // test hook: 1 = one thread per line also for contiguous lines
+static int g_cubic_separable_off = 0;   // test hook: 1 = diagonal transforms use the one-launch strip kernel
+extern "C" int mi_debug_set_cubic_separable(int on) { g_cubic_separable_off = !on; return MI_OK; }
 static int g_cubic_diag_off = 0;    // test hook: 1 = diagonal transforms use the gather kernel too
 extern "C" int mi_debug_set_cubic_diag(int on) { g_cubic_diag_off = !on; return MI_OK; }
 static int g_spline_rows_force = 0; // test hook: 2 = tiled kernel whatever the line count
@@ -1372,8 +1466,56 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
             int64_t longest = g.oshape[0] > g.oshape[1] ? g.oshape[0] : g.oshape[1];
             if (g.oshape[2] > longest) longest = g.oshape[2];
             if ((rc = pool_alloc(&tab, (size_t)entries * sizeof(AxisTaps)))) return rc;
+            const bool separable = !g_cubic_separable_off && g.oshape[0] <= 65535 && (g.oshape[1] + 3) / 4 <= 65535 &&
+                                   g.shape[0] <= 65535 && (g.shape[1] + 3) / 4 <= 65535;
             hipLaunchKernelGGL(cubic3_axis_table_kernel, dim3((unsigned)((longest + 255) / 256), 3), dim3(256), 0, s,
-                               (AxisTaps *)tab, g, mode, npad);
+                               (AxisTaps *)tab, g, mode, npad, separable ? 1 : 0);
+            if (separable) {
+                // x, then y, then z; rank-padding axes have nothing to resample
+                const AxisTaps *T = (const AxisTaps *)tab;
+                const int nz = (int)g.shape[0], ny = (int)g.shape[1], nx = (int)g.shape[2];
+                const int oz = (int)g.oshape[0], oy = (int)g.oshape[1], ox = (int)g.oshape[2];
+                const bool do_y = g.pad < 2, do_z = g.pad < 1;
+                void *bufA = nullptr, *bufB = nullptr;
+                float *dst_x = (float *)out->data, *dst_y = (float *)out->data;
+                if (do_y) {
+                    if ((rc = pool_alloc(&bufA, (size_t)nz * ny * ox * sizeof(float)))) { pool_free(tab); return rc; }
+                    dst_x = (float *)bufA;
+                }
+                if (do_z) {
+                    if ((rc = pool_alloc(&bufB, (size_t)nz * oy * ox * sizeof(float)))) { pool_free(bufA); pool_free(tab); return rc; }
+                    dst_y = (float *)bufB;
+                }
+                const dim3 blk(64, 4);
+                hipLaunchKernelGGL(cubic_resample_axis_kernel<2>, dim3((ox + 63) / 64, (ny + 3) / 4, nz), blk, 0, s,
+                                   (const float *)coef->data, dst_x, T + oz + oy, nz, ny, ox, nx, (float)cval, T, oz, oy,
+                                   do_y ? 0 : 1);
+                const bool quad = ox % 4 == 0 && ((uintptr_t)out->data & 15) == 0;     // pool blocks are 256-byte aligned
+                const int oxq = ox / 4;
+                if (do_y) {
+                    if (quad)
+                        hipLaunchKernelGGL(cubic_resample_rows4_kernel<1>, dim3((oxq + 63) / 64, (oy + 3) / 4, nz), blk, 0, s,
+                                           (const float4 *)bufA, (float4 *)dst_y, T + oz, nz, oy, oxq, ny, (float)cval, T, oz, oy,
+                                           do_z ? 0 : 1);
+                    else
+                        hipLaunchKernelGGL(cubic_resample_axis_kernel<1>, dim3((ox + 63) / 64, (oy + 3) / 4, nz), blk, 0, s,
+                                           (const float *)bufA, dst_y, T + oz, nz, oy, ox, ny, (float)cval, T, oz, oy,
+                                           do_z ? 0 : 1);
+                }
+                if (do_z) {
+                    if (quad)
+                        hipLaunchKernelGGL(cubic_resample_rows4_kernel<0>, dim3((oxq + 63) / 64, (oy + 3) / 4, oz), blk, 0, s,
+                                           (const float4 *)bufB, (float4 *)out->data, T, oz, oy, oxq, nz, (float)cval, T, oz, oy, 1);
+                    else
+                        hipLaunchKernelGGL(cubic_resample_axis_kernel<0>, dim3((ox + 63) / 64, (oy + 3) / 4, oz), blk, 0, s,
+                                           (const float *)bufB, (float *)out->data, T, oz, oy, ox, nz, (float)cval, T, oz, oy, 1);
+                }
+                pool_free(bufA);
+                pool_free(bufB);
+                pool_free(tab);
+                MI_HIP(hipGetLastError());
+                return MI_OK;
+            }
         }
 #define MI_CUBIC_AFF(NTZ, NTY)                                                                                          \
     if (diagonal)                                                                                                       \
