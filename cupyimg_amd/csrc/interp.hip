@@ -110,6 +110,7 @@ __device__ __forceinline__ double interp_point(const T *__restrict__ in, const I
             const double f = wrap_coord(c[d], g.shape[d]);
             lo[d] = (int64_t)floor(f);
             hi[d] = (int64_t)floor(f + 1.0);
+            if (g.shape[d] <= 1) hi[d] = 0;      // a single sample: SciPy maps every coordinate to it
         } else {
             lo[d] = (int64_t)cf;
             hi[d] = lo[d] + 1;

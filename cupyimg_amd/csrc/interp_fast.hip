@@ -104,7 +104,7 @@ __device__ __forceinline__ void axis_taps(CT c, int n, int mode, int order, int 
     if (mode == MI_MODE_WRAP) {
         const double f = wrapc((double)c, n);
         i0 = (int)floor(f);
-        i1 = (int)floor(f + 1.0);
+        i1 = n <= 1 ? 0 : (int)floor(f + 1.0);      // a single sample: SciPy maps every coordinate to it
     } else {
         i0 = (int)cf;
         i1 = i0 + 1;

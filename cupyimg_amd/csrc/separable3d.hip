@@ -813,7 +813,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
             // followed by either the array edge or enough columns, and the array must hold the mirrored blocks
             const int nb = (w[2] / 2 + 3) / 4;
             const int64_t tail = nx & 255;
-            if (w[2] > 1 && (nx < 4 * nb + 4 || (tail != 0 && tail < 4 * nb))) UNSUP("x extent unsuitable for the streaming x pass");
+            if (w[2] > 1 && (nx < 4 * nb + 4 || (tail != 0 && tail < 4 * nb + 4))) UNSUP("x extent unsuitable for the streaming x pass");
         }
         hipStream_t s = resolve_stream(stream);
         const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);

@@ -407,7 +407,7 @@ extern "C" int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const in
     {
         const int nb = (w[2] / 2 + 3) / 4;
         const int64_t tail = nx & 255;
-        if (w[2] > 1 && (nx < 4 * nb + 4 || (tail != 0 && tail < 4 * nb))) UNSUP("x extent unsuitable for the streaming x pass");
+        if (w[2] > 1 && (nx < 4 * nb + 4 || (tail != 0 && tail < 4 * nb + 4))) UNSUP("x extent unsuitable for the streaming x pass");
     }
     const int mz = filter_mode(mode[0]), my = filter_mode(mode[1]), mx = filter_mode(mode[2]);
     hipStream_t s = resolve_stream(stream);

@@ -1,0 +1,184 @@
+"""Randomised differential test of the HIP path against scipy.ndimage (run on the GPU box).
+usage: python scripts/fuzz_vs_scipy.py [seconds] [seed]   -- prints every mismatch with its parameters."""
+import os, sys, time, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import scipy.ndimage as sndi
+import cupyimg_amd as ca
+from cupyimg_amd.scipy import ndimage as ndi
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+MODES = ["reflect", "constant", "nearest", "mirror", "wrap"]
+DTYPES = ["float32", "float32", "float32", "float64", "uint8", "uint8", "int16", "uint16", "int32"]
+
+def rand_shape():
+    nd = int(rng.choice([1, 2, 2, 3, 3, 3]))
+    if nd == 3:
+        last = int(rng.choice([rng.integers(1, 40), 4 * rng.integers(2, 24), 256, 260, 264, 268, 272, 516, 520]))
+        return (int(rng.integers(1, 24)), int(rng.integers(1, 40)), last)
+    if nd == 2:
+        return (int(rng.integers(1, 70)), int(rng.choice([rng.integers(1, 90), 4 * rng.integers(2, 40), 1024, 1028, 1032, 260, 264])))
+    return (int(rng.integers(1, 300)),)
+
+def rand_array(shape, dtype):
+    if np.dtype(dtype).kind == "f":
+        return rng.standard_normal(shape).astype(dtype)
+    info = np.iinfo(dtype)
+    return rng.integers(max(info.min, -200), min(info.max, 250) + 1, size=shape).astype(dtype)
+
+def tol_for(dtype, ref):
+    k = np.dtype(dtype).kind
+    if k in "iub":
+        return 0
+    return (3e-6 if dtype == "float32" else 1e-11) * max(1.0, float(np.abs(ref).max()) if ref.size else 1.0)
+
+def origin_for(size):
+    lo, hi = -(size // 2), (size - 1) // 2
+    return int(rng.integers(lo, hi + 1))
+
+def case():
+    shape = rand_shape()
+    dtype = str(rng.choice(DTYPES))
+    x = rand_array(shape, dtype)
+    mode = str(rng.choice(MODES))
+    cval = float(rng.choice([0.0, 3.0, -2.0]))
+    if np.dtype(dtype).kind == "u":
+        cval = abs(cval)        # negative cval on unsigned data: SciPy's own paths disagree with each other
+    op = str(rng.choice(["uniform", "gaussian", "correlate1d", "correlate", "minmax", "minmax_fp", "grey", "median", "binary",
+                         "sobel", "laplace", "map1", "affine3", "zoom", "shift"]))
+    nd = x.ndim
+    kw = dict(mode=mode, cval=cval)
+    if op == "uniform":
+        size = [int(rng.integers(1, 8)) for _ in range(nd)]
+        origin = [origin_for(s) for s in size]
+        return op, (shape, dtype, size, origin, kw), lambda m, a: m.uniform_filter(a, size=size, origin=origin, **kw), 1
+    if op == "gaussian":
+        sigma = [float(rng.choice([0.0, 0.6, 1.0, 1.7])) for _ in range(nd)]
+        order = [int(rng.integers(0, 3)) for _ in range(nd)]
+        return op, (shape, dtype, sigma, order, kw), lambda m, a: m.gaussian_filter(a, sigma, order=order, **kw), 4
+    if op == "correlate1d":
+        w = rng.standard_normal(int(rng.integers(1, 9)))
+        ax = int(rng.integers(0, nd))
+        origin = origin_for(len(w))
+        return op, (shape, dtype, w.tolist(), ax, origin, kw), lambda m, a: m.correlate1d(a, w, axis=ax, origin=origin, **kw) if m is sndi else m.correlate1d(a, w, axis=ax, origin=origin, dtype_mode="ndimage", **kw), 4
+    if op == "correlate":
+        wshape = tuple(int(rng.integers(1, 5)) for _ in range(nd))
+        w = rng.standard_normal(wshape)
+        origin = [origin_for(s) for s in wshape]
+        f = "correlate" if rng.random() < 0.5 else "convolve"
+        if f == "convolve":
+            origin = [o if -(s // 2) <= -o - (1 if s % 2 == 0 else 0) <= (s - 1) // 2 else 0 for o, s in zip(origin, wshape)]
+        return op + ":" + f, (shape, dtype, wshape, origin, kw), lambda m, a: getattr(m, f)(a, w, origin=origin, **kw), 8
+    if op == "minmax":
+        size = [int(rng.integers(1, 8)) for _ in range(nd)]
+        origin = [origin_for(s) for s in size]
+        f = str(rng.choice(["minimum_filter", "maximum_filter"]))
+        return op + ":" + f, (shape, dtype, size, origin, kw), lambda m, a: getattr(m, f)(a, size=size, origin=origin, **kw), 0
+    if op == "minmax_fp":
+        fshape = tuple(int(rng.integers(1, 5)) for _ in range(nd))
+        fp = rng.random(fshape) > 0.4
+        if not fp.any():
+            fp.flat[0] = True
+        f = str(rng.choice(["minimum_filter", "maximum_filter"]))
+        return op + ":" + f, (shape, dtype, fp.astype(int).tolist(), kw), lambda m, a: getattr(m, f)(a, footprint=fp, **kw), 0
+    if op == "grey":
+        size = [int(rng.integers(1, 8))] * nd
+        f = str(rng.choice(["grey_erosion", "grey_dilation"]))
+        return op + ":" + f, (shape, dtype, size, kw), lambda m, a: getattr(m, f)(a, size=size, **kw), 0
+    if op == "median":
+        size = int(rng.integers(2, 4 if nd == 3 else 6))
+        return op, (shape, dtype, size, kw), lambda m, a: m.median_filter(a, size=size, **kw), 0
+    if op == "binary":
+        st = sndi.generate_binary_structure(nd, int(rng.integers(1, nd + 1)))
+        it = int(rng.choice([1, 1, 2, 3]))
+        bv = int(rng.integers(0, 2))
+        f = str(rng.choice(["binary_erosion", "binary_dilation"]))
+        return op + ":" + f, (shape, dtype, it, bv), lambda m, a: getattr(m, f)(a, structure=st, iterations=it, border_value=bv), 0
+    if op == "sobel":
+        ax = int(rng.integers(0, nd))
+        return op, (shape, dtype, ax, kw), lambda m, a: m.sobel(a, axis=ax, **kw), 4
+    if op == "laplace":
+        return op, (shape, dtype, kw), lambda m, a: m.laplace(a, **kw), 8
+    imode = str(rng.choice(["constant", "nearest", "mirror", "reflect", "wrap", "grid-wrap", "grid-constant"]))
+    ikw = dict(mode=imode, cval=cval)
+    if op == "map1":
+        npts = int(rng.integers(1, 500))
+        coords = (rng.random((nd, npts)) * (np.array(shape)[:, None] + 4) - 2)
+        order = int(rng.choice([0, 1, 1, 3]))
+        if order == 0:
+            coords = np.floor(coords * 4) / 4 + 0.1      # keep away from the .5 ties (documented deviation of the reference)
+        return op, (shape, dtype, npts, order, ikw), lambda m, a: m.map_coordinates(a, coords if m is sndi else ca.asarray(coords), order=order, **ikw), 40
+    if op == "affine3":
+        A = np.eye(nd) + 0.15 * rng.standard_normal((nd, nd))
+        off = rng.standard_normal(nd) * 2
+        order = int(rng.choice([1, 3, 3, 2, 5]))
+        return op, (shape, dtype, order, ikw), lambda m, a: m.affine_transform(a, A, offset=off, order=order, **ikw), 40
+    if op == "zoom":
+        zf = float(rng.choice([0.5, 0.8, 1.0, 1.3, 2.0]))
+        order = int(rng.choice([0, 1, 3, 3]))
+        return op, (shape, dtype, zf, order, ikw), lambda m, a: m.zoom(a, zf, order=order, **ikw), 40
+    sh = [float(rng.choice([0.0, 1.5, -2.25, 0.3])) for _ in range(nd)]
+    order = int(rng.choice([0, 1, 3, 3]))
+    return "shift", (shape, dtype, sh, order, ikw), lambda m, a: m.shift(a, sh, order=order, **ikw), 40
+
+def ndi_gt0(a):
+    return a          # binary ops treat any non-zero as foreground
+
+t_end = time.time() + budget
+n = fails = skipped = 0
+counts = {}
+cats = {}
+while time.time() < t_end:
+    st = rng.bit_generator.state
+    try:
+        name, params, fn, slack = case()
+        shape, dtype = params[0], params[1]
+        x = rand_array(shape, dtype)
+    except Exception:
+        traceback.print_exc()
+        break
+    try:
+        if name.startswith("binary"):
+            want = fn(sndi, x)
+            got = fn(ndi, ca.asarray(x)).get()
+        else:
+            want = fn(sndi, x)
+            got = fn(ndi, ca.asarray(x)).get()
+    except (NotImplementedError, RuntimeError, ValueError, ZeroDivisionError) as exc:
+        # both sides are allowed to refuse; a refusal on one side only is worth a look
+        try:
+            fn(sndi, x)
+            print("REFUSED by the HIP path only:", name, params, type(exc).__name__, str(exc)[:100], flush=True)
+            fails += 1
+        except Exception:
+            skipped += 1
+        continue
+    n += 1
+    counts[name.split(":")[0]] = counts.get(name.split(":")[0], 0) + 1
+    ok = got.shape == want.shape and got.dtype == want.dtype
+    if ok and want.size:
+        tol = tol_for(dtype, want)
+        if tol == 0 and name.split(":")[0] in ("map1", "affine3", "zoom", "shift"):
+            # integer outputs of interpolation: equal up to the rounding of a value that sits within 1e-9 of a tie
+            diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+            ok = (diff <= 1).all() and (diff > 0).mean() <= 1e-3
+        elif tol == 0:
+            ok = np.array_equal(got, want)
+        else:
+            t = tol * (1 + slack)
+            if dtype == "float32" and name.split(":")[0] in ("affine3", "zoom", "shift", "map1"):
+                t = max(t, 8e-5 * max(1.0, float(np.abs(want).max())))
+            ok = np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= t
+    if not ok:
+        fails += 1
+        err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max() if got.shape == want.shape else "shape"
+        key = (name, dtype)
+        cats[key] = cats.get(key, 0) + 1
+        if cats[key] <= 3:
+            nbad = int((got != want).sum()) if got.shape == want.shape else -1
+            print("MISMATCH", name, params, "err", err, "nbad", nbad, "of", want.size, flush=True)
+for k in sorted(cats):
+    print("  failures", k, cats[k])
+print("cases %d, refused on both sides %d, failures %d, per op %s" % (n, skipped, fails, counts))

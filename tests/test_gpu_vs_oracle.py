@@ -1012,3 +1012,37 @@ def test_rank_filter_sorting_network_sizes(gpu, ndi):
                 assert np.array_equal(ndi.rank_filter(xd, rank, size=size, mode="reflect").get(), want), (x.dtype, size, rank)
         assert np.array_equal(ndi.median_filter(xd, size=3, mode="constant", cval=7).get(),
                               sndi.median_filter(x, size=3, mode="constant", cval=7))
+
+
+def test_regressions_found_by_differential_fuzzing(gpu, ndi):
+    """Cases scripts/fuzz_vs_scipy.py caught: float32 separable min/max on rows of 256 k + 4 samples (a one-lane
+    last tile in the streaming x pass), and order 0/1 interpolation in wrap mode across an axis of length one."""
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(180)
+    for nx in (260, 264, 268, 516, 520):
+        x = rng.standard_normal((7, 19, nx)).astype(np.float32)
+        xd = gpu.asarray(x)
+        for size, origin in [((1, 3, 7), 0), ((7, 1, 5), (2, 0, 0)), ((3, 5, 7), (-1, 1, 0)), ((7, 7, 7), 0), ((1, 1, 3), 0)]:
+            for mode in ("mirror", "reflect", "nearest", "constant", "wrap"):
+                for f in ("minimum_filter", "maximum_filter"):
+                    want = getattr(sndi, f)(x, size=size, origin=origin, mode=mode, cval=-2.0)
+                    got = getattr(ndi, f)(xd, size=size, origin=origin, mode=mode, cval=-2.0).get()
+                    assert np.array_equal(got, want), (nx, size, origin, mode, f)
+        assert np.array_equal(ndi.grey_dilation(xd, size=(7, 7, 7), mode="mirror").get(), sndi.grey_dilation(x, size=(7, 7, 7), mode="mirror"))
+    for shape, dtype in [((1, 34, 88), np.float32), ((7, 1, 8), np.float64), ((1, 2, 80), np.float32), ((1, 7, 256), np.int32),
+                         ((1, 1024), np.float32)]:
+        x = (rng.standard_normal(shape) * 50).astype(dtype)
+        nd = len(shape)
+        coords = rng.random((nd, 300)) * (np.array(shape)[:, None] + 4) - 2
+        for mode in ("wrap", "grid-wrap", "mirror", "reflect", "nearest"):
+            for order in (0, 1):
+                cc = np.floor(coords * 4) / 4 + 0.1 if order == 0 else coords
+                want = sndi.map_coordinates(x, cc, order=order, mode=mode)
+                got = ndi.map_coordinates(gpu.asarray(x), gpu.asarray(cc), order=order, mode=mode).get()
+                if np.dtype(dtype).kind == "f":
+                    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * np.abs(x).max(), err_msg=str((shape, mode, order)))
+                else:
+                    assert np.abs(got.astype(np.int64) - want).max() <= 1, (shape, mode, order)
+            want = sndi.shift(x, [0.3] * nd, order=1, mode=mode)
+            got = ndi.shift(gpu.asarray(x), [0.3] * nd, order=1, mode=mode).get()
+            assert np.abs(got.astype(np.float64) - want).max() <= max(1.0 if np.dtype(dtype).kind == "i" else 0.0, 1e-4 * np.abs(x).max())
