@@ -97,33 +97,32 @@ __device__ __forceinline__ double interp_point(const T *__restrict__ in, const I
         }
         return oob ? cval : (double)in[pos];
     }
+    // order 1 with SciPy 1.15's arithmetic (ni_interpolation.c / ni_splines.c), so that integer outputs agree at
+    // exact ties: fold the coordinate first, weights 1 - x and 1 - (1 - x) from the folded coordinate's fraction,
+    // every sample multiplied by its weights one axis at a time before it is added
     int64_t lo[ND], hi[ND];
     double wlo[ND], whi[ND];
     bool two[ND];
 #pragma unroll
     for (int d = 0; d < ND; d++) {
-        const double cf = floor(c[d]);
-        two[d] = c[d] != cf;
-        wlo[d] = (cf + 1.0) - c[d];
-        whi[d] = c[d] - cf;
-        if (mode == MI_MODE_WRAP) {
-            const double f = wrap_coord(c[d], g.shape[d]);
-            lo[d] = (int64_t)floor(f);
-            hi[d] = (int64_t)floor(f + 1.0);
-            if (g.shape[d] <= 1) hi[d] = 0;      // a single sample: SciPy maps every coordinate to it
-        } else {
-            lo[d] = (int64_t)cf;
-            hi[d] = lo[d] + 1;
-            if (mode != MI_MODE_CONSTANT) {
-                lo[d] = bmap<int64_t>(lo[d], g.shape[d], mode);
-                hi[d] = bmap<int64_t>(hi[d], g.shape[d], mode);
-            }
+        double cc = c[d];
+        if (mode != MI_MODE_CONSTANT && mode != MI_MODE_GRID_CONSTANT && mode != MI_MODE_NEAREST)
+            cc = fold_coord(cc, g.shape[d], mode);
+        const double cf = floor(cc);
+        two[d] = cc != cf;
+        wlo[d] = 1.0 - (cc - cf);
+        whi[d] = 1.0 - wlo[d];
+        lo[d] = (int64_t)cf;
+        hi[d] = lo[d] + 1;
+        if (mode != MI_MODE_CONSTANT) {
+            const int tm = mode == MI_MODE_WRAP ? MI_MODE_MIRROR : mode;
+            lo[d] = bmap<int64_t>(lo[d], g.shape[d], tm);
+            hi[d] = bmap<int64_t>(hi[d], g.shape[d], tm);
         }
     }
     double acc = 0.0;
     // enumerate corners in the oracle's order: axis 0 is the most significant bit
     for (int m = 0; m < (1 << ND); m++) {
-        double wt = 1.0;
         int64_t pos = 0;
         bool skip = false, oob = false;
 #pragma unroll
@@ -131,12 +130,14 @@ __device__ __forceinline__ double interp_point(const T *__restrict__ in, const I
             const bool up = (m >> (ND - 1 - d)) & 1;
             skip |= up && !two[d];
             const int64_t j = up ? hi[d] : lo[d];
-            wt *= up ? whi[d] : wlo[d];
             oob |= j < 0;
             pos += j * g.stride[d];
         }
         if (skip) continue;
-        acc += (oob ? cval : (double)in[pos]) * wt;
+        double coeff = oob ? cval : (double)in[oob ? 0 : pos];
+#pragma unroll
+        for (int d = 0; d < ND; d++) coeff *= ((m >> (ND - 1 - d)) & 1) ? whi[d] : wlo[d];
+        acc += coeff;
     }
     return acc;
 }

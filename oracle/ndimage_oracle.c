@@ -639,43 +639,43 @@ static double interp_point(const double *in, const int64_t *shape,
         return in[pos];
     }
 
-    /* order 1: 2^ndim taps, second tap skipped at integral coordinates */
+    /* order 1: 2^ndim taps.  Arithmetic as SciPy 1.15 does it (ni_interpolation.c / ni_splines.c), so that
+     * integer outputs agree at exact ties: the coordinate is folded first, the weights are 1 - x and
+     * 1 - (1 - x) with x the fraction of the folded coordinate, and each sample is multiplied by its weights
+     * one axis at a time before it is added.  The upper tap is skipped at integral coordinates
+     * (_interp_kernels.py:416), which only matters for non-finite samples. */
     int64_t lo[ORC_MAXDIM], hi[ORC_MAXDIM];
     double wlo[ORC_MAXDIM], whi[ORC_MAXDIM];
     int npt[ORC_MAXDIM];
     for (int d = 0; d < ndim; d++) {
-        double cf = floor(c[d]);
-        npt[d] = (c[d] == cf) ? 1 : 2;
-        wlo[d] = (cf + 1.0) - c[d];
-        whi[d] = c[d] - cf;
-        if (mode == ORC_WRAP) {
-            double f = wrap_coord(c[d], shape[d]);
-            lo[d] = (int64_t)floor(f);
-            hi[d] = (int64_t)floor(f + 1.0);
-        } else {
-            lo[d] = (int64_t)cf;
-            hi[d] = lo[d] + 1;
-            if (mode != ORC_CONSTANT) {
-                lo[d] = bmap(lo[d], shape[d], mode);
-                hi[d] = bmap(hi[d], shape[d], mode);
-            }
+        double cc = c[d];
+        if (mode != ORC_CONSTANT && mode != ORC_GRID_CONSTANT && mode != ORC_NEAREST) cc = fold_coord(cc, shape[d], mode);
+        double cf = floor(cc);
+        npt[d] = (cc == cf) ? 1 : 2;
+        wlo[d] = 1.0 - (cc - cf);
+        whi[d] = 1.0 - wlo[d];
+        lo[d] = (int64_t)cf;
+        hi[d] = lo[d] + 1;
+        if (mode != ORC_CONSTANT) {
+            lo[d] = bmap(lo[d], shape[d], mode == ORC_WRAP ? ORC_MIRROR : mode);
+            hi[d] = bmap(hi[d], shape[d], mode == ORC_WRAP ? ORC_MIRROR : mode);
         }
     }
     double acc = 0.0;
     const int ncorner = 1 << ndim;
     for (int m = 0; m < ncorner; m++) {
-        double wt = 1.0;
         int64_t pos = 0;
         int skip = 0, oob = 0;
         for (int d = 0; d < ndim; d++) {
             int up = (m >> (ndim - 1 - d)) & 1;
             if (up && npt[d] == 1) { skip = 1; break; }
             int64_t j = up ? hi[d] : lo[d];
-            wt *= up ? whi[d] : wlo[d];
             if (j < 0) oob = 1; else pos += j * stride[d];
         }
         if (skip) continue;
-        acc += (oob ? cval : in[pos]) * wt;
+        double coeff = oob ? cval : in[pos];
+        for (int d = 0; d < ndim; d++) coeff *= ((m >> (ndim - 1 - d)) & 1) ? whi[d] : wlo[d];
+        acc += coeff;
     }
     return acc;
 }
