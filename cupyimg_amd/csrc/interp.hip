@@ -232,16 +232,18 @@ __device__ __forceinline__ double spline_point(const T *__restrict__ in, const I
     for (int d = 0; d < ND; d++) k[d] = 0;
     double acc = 0.0;
     for (;;) {
-        double wt = 1.0;
         int64_t pos = 0;
         bool oob = false;
 #pragma unroll
         for (int d = 0; d < ND; d++) {
-            wt *= w[d][k[d]];
             oob |= idx[d][k[d]] < 0;
             pos += idx[d][k[d]] * g.stride[d];
         }
-        acc += (oob ? cval : (double)in[oob ? 0 : pos]) * wt;
+        // SciPy multiplies the sample by its weights one axis at a time (matters at exact ties of integer outputs)
+        double coeff = oob ? cval : (double)in[oob ? 0 : pos];
+#pragma unroll
+        for (int d = 0; d < ND; d++) coeff *= w[d][k[d]];
+        acc += coeff;
         int d = ND - 1;
         while (d >= 0) {
             if (d >= g.pad && ++k[d] <= order) break;
@@ -349,14 +351,14 @@ __device__ __forceinline__ double spline_point_t(const double *__restrict__ in, 
 #pragma unroll
         for (int ky = 0; ky < NT; ky++) {
             if (ky >= ntap[1]) break;
-            const double wzy = w[0][kz] * w[1][ky];
             const bool oob_zy = off[0][kz] < 0 || off[1][ky] < 0;
             const int64_t base = off[0][kz] + off[1][ky];
 #pragma unroll
             for (int kx = 0; kx < NT; kx++) {
                 const bool oob = oob_zy || off[2][kx] < 0;
                 const double v = oob ? cval : in[base + off[2][kx]];
-                acc += v * (wzy * w[2][kx]);
+                // the sample times its weights one axis at a time, as SciPy does (exact ties of integer outputs)
+                acc += ((v * w[0][kz]) * w[1][ky]) * w[2][kx];
             }
         }
     }

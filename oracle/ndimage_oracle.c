@@ -591,14 +591,15 @@ static double spline_point(const double *in, const int64_t *shape, const int64_t
     int k[ORC_MAXDIM] = {0};
     double acc = 0.0;
     for (;;) {
-        double wt = 1.0;
         int64_t pos = 0;
         int oob = 0;
         for (int d = 0; d < ndim; d++) {
-            wt *= w[d][k[d]];
             if (idx[d][k[d]] < 0) oob = 1; else pos += idx[d][k[d]] * stride[d];
         }
-        acc += (oob ? cval : in[pos]) * wt;
+        /* SciPy multiplies the sample by its weights one axis at a time (matters at exact ties of integer outputs) */
+        double coeff = oob ? cval : in[pos];
+        for (int d = 0; d < ndim; d++) coeff *= w[d][k[d]];
+        acc += coeff;
         int d = ndim - 1;
         while (d >= 0 && ++k[d] > order) { k[d] = 0; d--; }
         if (d < 0) break;
