@@ -1,5 +1,6 @@
 """Randomised differential test of the HIP path against scipy.ndimage (run on the GPU box).
-usage: python scripts/fuzz_vs_scipy.py [seconds] [seed]   -- prints every mismatch with its parameters."""
+usage: python scripts/fuzz_vs_scipy.py [seconds] [seed] [max cases]   -- prints mismatches with their parameters.
+env FUZZ_ONLY=op1,op2 restricts the op families, FUZZ_TRACE=1 prints every case before it runs."""
 import os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +10,7 @@ from cupyimg_amd.scipy import ndimage as ndi
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 60
 rng = np.random.default_rng(seed)
 MODES = ["reflect", "constant", "nearest", "mirror", "wrap"]
 DTYPES = ["float32", "float32", "float32", "float64", "uint8", "uint8", "int16", "uint16", "int32"]
@@ -47,17 +49,24 @@ def case():
     if np.dtype(dtype).kind == "u":
         cval = abs(cval)        # negative cval on unsigned data: SciPy's own paths disagree with each other
     op = str(rng.choice(["uniform", "gaussian", "correlate1d", "correlate", "minmax", "minmax_fp", "grey", "median", "binary",
-                         "sobel", "laplace", "map1", "affine3", "zoom", "shift"]))
+                         "sobel", "laplace", "map1", "affine3", "zoom", "shift", "binary2", "grey_st", "percentile", "spline_filter",
+                         "uniform1d", "convolve1d"]))
+    if os.environ.get("FUZZ_ONLY"):
+        op = str(rng.choice(os.environ["FUZZ_ONLY"].split(",")))
     nd = x.ndim
     kw = dict(mode=mode, cval=cval)
     if op == "uniform":
         size = [int(rng.integers(1, 8)) for _ in range(nd)]
         origin = [origin_for(s) for s in size]
-        return op, (shape, dtype, size, origin, kw), lambda m, a: m.uniform_filter(a, size=size, origin=origin, **kw), 1
+        odt = rng.choice([None, "float32", "float64", "int16"])
+        okw = dict(kw) if odt is None else dict(kw, output=np.dtype(str(odt)))
+        return op, (shape, dtype, size, origin, okw), lambda m, a: m.uniform_filter(a, size=size, origin=origin, **okw), 1
     if op == "gaussian":
         sigma = [float(rng.choice([0.0, 0.6, 1.0, 1.7])) for _ in range(nd)]
         order = [int(rng.integers(0, 3)) for _ in range(nd)]
-        return op, (shape, dtype, sigma, order, kw), lambda m, a: m.gaussian_filter(a, sigma, order=order, **kw), 4
+        odt = rng.choice([None, None, "float32", "float64"])
+        okw = dict(kw) if odt is None else dict(kw, output=np.dtype(str(odt)))
+        return op, (shape, dtype, sigma, order, okw), lambda m, a: m.gaussian_filter(a, sigma, order=order, **okw), 4
     if op == "correlate1d":
         w = rng.standard_normal(int(rng.integers(1, 9)))
         ax = int(rng.integers(0, nd))
@@ -75,7 +84,9 @@ def case():
         size = [int(rng.integers(1, 8)) for _ in range(nd)]
         origin = [origin_for(s) for s in size]
         f = str(rng.choice(["minimum_filter", "maximum_filter"]))
-        return op + ":" + f, (shape, dtype, size, origin, kw), lambda m, a: getattr(m, f)(a, size=size, origin=origin, **kw), 0
+        odt = rng.choice([None, None, "float32", "float64", "int32"])
+        okw = dict(kw) if odt is None else dict(kw, output=np.dtype(str(odt)))
+        return op + ":" + f, (shape, dtype, size, origin, okw), lambda m, a: getattr(m, f)(a, size=size, origin=origin, **okw), 0
     if op == "minmax_fp":
         fshape = tuple(int(rng.integers(1, 5)) for _ in range(nd))
         fp = rng.random(fshape) > 0.4
@@ -96,6 +107,52 @@ def case():
         bv = int(rng.integers(0, 2))
         f = str(rng.choice(["binary_erosion", "binary_dilation"]))
         return op + ":" + f, (shape, dtype, it, bv), lambda m, a: getattr(m, f)(a, structure=st, iterations=it, border_value=bv), 0
+    if op == "binary2":
+        sshape = tuple(int(rng.integers(1, 5)) for _ in range(nd))
+        st = rng.random(sshape) > 0.35
+        if not st.any():
+            st.flat[0] = True
+        origin = [origin_for(k) for k in sshape]
+        mask = rng.random(shape) > 0.3 if rng.random() < 0.5 else None
+        it = int(rng.choice([1, 2]))
+        bv = int(rng.integers(0, 2))
+        f = str(rng.choice(["binary_erosion", "binary_dilation"]))
+        if f == "binary_dilation":      # dilation mirrors the structure: keep the mirrored origin legal for even sizes
+            origin = [o if -(k // 2) <= -o - (1 if k % 2 == 0 else 0) <= (k - 1) // 2 else 0 for o, k in zip(origin, sshape)]
+        return op + ":" + f, (shape, dtype, st.astype(int).tolist(), origin, it, bv, mask is not None), \
+            lambda m, a: getattr(m, f)(a, structure=st, iterations=it, border_value=bv, origin=origin, brute_force=True,
+                                       mask=(mask if (m is sndi or mask is None) else ca.asarray(mask))), 0
+        # brute_force=True: SciPy 1.15's coordinate-list path (iterations > 1) corrupts the heap for even-sized
+        # structures with an origin ("double free or corruption" in pure SciPy); the reference only has brute force
+    if op == "grey_st":
+        sshape = tuple(int(rng.integers(1, 4)) for _ in range(nd))
+        fp = rng.random(sshape) > 0.3
+        if not fp.any():
+            fp.flat[0] = True
+        stv = rng.integers(0, 5, size=sshape).astype(np.float64)
+        f = str(rng.choice(["grey_erosion", "grey_dilation"]))
+        return op + ":" + f, (shape, dtype, fp.astype(int).tolist(), stv.tolist(), kw), \
+            lambda m, a: getattr(m, f)(a, footprint=fp, structure=stv, **kw), 0
+    if op == "percentile":
+        size = int(rng.integers(2, 4 if nd == 3 else 5))
+        pct = float(rng.choice([0, 10, 35.5, 50, 80, 100, -20]))
+        return op, (shape, dtype, size, pct, kw), lambda m, a: m.percentile_filter(a, pct, size=size, **kw), 0
+    if op == "spline_filter":
+        order = int(rng.integers(2, 6))
+        smode = str(rng.choice(["mirror", "reflect", "grid-wrap", "nearest", "constant"]))
+        return op, (shape, "float64", order, smode), lambda m, a: m.spline_filter(a.astype(np.float64) if m is sndi else a, order=order, mode=smode), 1000
+    if op == "uniform1d":
+        size = int(rng.integers(1, 9))
+        ax = int(rng.integers(0, nd))
+        origin = origin_for(size)
+        return op, (shape, dtype, size, ax, origin, kw), lambda m, a: m.uniform_filter1d(a, size, axis=ax, origin=origin, **kw), 1
+    if op == "convolve1d":
+        w = rng.integers(-3, 4, size=int(rng.integers(1, 8))).astype(np.float64)
+        ax = int(rng.integers(0, nd))
+        origin = origin_for(len(w))
+        if not (-(len(w) // 2) <= -origin - (1 if len(w) % 2 == 0 else 0) <= (len(w) - 1) // 2):
+            origin = 0
+        return op, (shape, dtype, w.tolist(), ax, origin, kw), lambda m, a: m.convolve1d(a, w, axis=ax, origin=origin, **kw) if m is sndi else m.convolve1d(a, w, axis=ax, origin=origin, dtype_mode="ndimage", **kw), 4
     if op == "sobel":
         ax = int(rng.integers(0, nd))
         return op, (shape, dtype, ax, kw), lambda m, a: m.sobel(a, axis=ax, **kw), 4
@@ -130,7 +187,7 @@ t_end = time.time() + budget
 n = fails = skipped = 0
 counts = {}
 cats = {}
-while time.time() < t_end:
+while time.time() < t_end and n < max_cases:
     st = rng.bit_generator.state
     try:
         name, params, fn, slack = case()
@@ -139,13 +196,22 @@ while time.time() < t_end:
     except Exception:
         traceback.print_exc()
         break
+    if os.environ.get("FUZZ_TRACE"):
+        print("TRACE", name, params, flush=True)
     try:
-        if name.startswith("binary"):
-            want = fn(sndi, x)
-            got = fn(ndi, ca.asarray(x)).get()
+        view = int(rng.integers(0, 4))           # 0/1: contiguous, 2: every other sample of a larger array, 3: transposed
+        if view == 2 and x.ndim >= 2:
+            big = np.repeat(x, 2, axis=-1)
+            big[..., 1::2] = 77
+            xh, xd = big[..., ::2], ca.asarray(big)[..., ::2]
+        elif view == 3 and x.ndim >= 2:
+            xt = np.ascontiguousarray(np.swapaxes(x, 0, -1))
+            xh, xd = np.swapaxes(xt, 0, -1), ca.asarray(xt).transpose(*([x.ndim - 1] + list(range(1, x.ndim - 1)) + [0]))
         else:
-            want = fn(sndi, x)
-            got = fn(ndi, ca.asarray(x)).get()
+            xh, xd = x, ca.asarray(x)
+        assert xh.shape == tuple(xd.shape) == x.shape
+        want = fn(sndi, xh)
+        got = fn(ndi, xd).get()
     except (NotImplementedError, RuntimeError, ValueError, ZeroDivisionError) as exc:
         # both sides are allowed to refuse; a refusal on one side only is worth a look
         try:
@@ -159,11 +225,22 @@ while time.time() < t_end:
     counts[name.split(":")[0]] = counts.get(name.split(":")[0], 0) + 1
     ok = got.shape == want.shape and got.dtype == want.dtype
     if ok and want.size:
+        in_dtype, dtype = dtype, str(want.dtype)
+        mixed_int = np.dtype(dtype).kind in "iu" and np.dtype(in_dtype).kind == "f"
         tol = tol_for(dtype, want)
-        if tol == 0 and name.split(":")[0] in ("map1", "affine3", "zoom", "shift"):
+        if np.dtype(dtype).kind == "f" and in_dtype == "float32":
+            tol = max(tol, tol_for("float32", want))
+        if mixed_int:
+            # a float result truncated into an integer output: one unit at values that sit on an integer
+            diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+            ok = (diff <= 1).all() and (diff > 0).mean() <= 2e-3
+            tol = None
+        if tol is None:
+            pass
+        elif tol == 0 and name.split(":")[0] in ("map1", "affine3", "zoom", "shift"):
             # integer outputs of interpolation: equal up to the rounding of a value that sits within 1e-9 of a tie
             diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
-            ok = (diff <= 1).all() and (diff > 0).mean() <= 1e-3
+            ok = (diff <= 1).all() and (diff > 0).mean() <= (2e-2 if params[-2] >= 2 else 0.0)   # ties of spline orders only
         elif tol == 0:
             ok = np.array_equal(got, want)
         else:
@@ -174,7 +251,7 @@ while time.time() < t_end:
     if not ok:
         fails += 1
         err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max() if got.shape == want.shape else "shape"
-        key = (name, dtype)
+        key = (name, in_dtype if 'in_dtype' in dir() else dtype, dtype)
         cats[key] = cats.get(key, 0) + 1
         if cats[key] <= 3:
             nbad = int((got != want).sum()) if got.shape == want.shape else -1
