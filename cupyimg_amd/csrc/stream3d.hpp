@@ -33,6 +33,7 @@ struct StreamParams {
     // window pairs: xpair[q][2u], xpair[q][2u+1] = wx[2u - (B+q)%2], wx[2u + 1 - (B+q)%2]
     // for output parity q (B = window offset of tap 0, see xpass_hops); 0 outside the kernel
     float xpair[2][2 * (kStreamMaxTaps / 2 + 2)];
+    int wid_base;        // first wave index of this launch (a pass is issued in slices of waves)
 };
 
 }  // namespace mi

@@ -14,8 +14,17 @@ max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 60
 rng = np.random.default_rng(seed)
 MODES = ["reflect", "constant", "nearest", "mirror", "wrap"]
 DTYPES = ["float32", "float32", "float32", "float64", "uint8", "uint8", "int16", "uint16", "int32"]
+if os.environ.get("FUZZ_BIG"):
+    DTYPES = ["float32", "float32", "uint8", "uint8", "int16", "uint16"]
+
+BIG = bool(os.environ.get("FUZZ_BIG"))      # mid-size volumes / images: the tiling and chunk planning of the fast kernels
+
 
 def rand_shape():
+    if BIG:
+        if rng.random() < 0.7:
+            return (int(rng.integers(20, 140)), int(rng.integers(30, 200)), int(rng.choice([4 * rng.integers(16, 160), 256, 512, 768, 1024])))
+        return (int(rng.integers(200, 1500)), int(rng.choice([4 * rng.integers(60, 500), 1024, 2048, rng.integers(300, 1500)])))
     nd = int(rng.choice([1, 2, 2, 3, 3, 3]))
     if nd == 3:
         last = int(rng.choice([rng.integers(1, 40), 4 * rng.integers(2, 24), 256, 260, 264, 268, 272, 516, 520]))
