@@ -1046,3 +1046,20 @@ def test_regressions_found_by_differential_fuzzing(gpu, ndi):
             want = sndi.shift(x, [0.3] * nd, order=1, mode=mode)
             got = ndi.shift(gpu.asarray(x), [0.3] * nd, order=1, mode=mode).get()
             assert np.abs(got.astype(np.float64) - want).max() <= max(1.0 if np.dtype(dtype).kind == "i" else 0.0, 1e-4 * np.abs(x).max())
+
+
+def test_streaming_passes_on_many_workgroups(gpu, ndi):
+    """Volumes whose streaming passes need more than 256 workgroups (the mid-size fuzz found wrong samples in
+    lanes 12-15 of each DPP row beyond the first 256 workgroups of a launch; passes are now issued in slices)."""
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(190)
+    for shape in [(256, 256, 256), (200, 300, 256), (150, 600, 64)]:
+        v = rng.standard_normal(shape).astype(np.float32)
+        vd = gpu.asarray(v)
+        for size in [(3, 1, 3), (1, 3, 3), (3, 3, 3), (5, 3, 7)]:
+            assert np.array_equal(ndi.minimum_filter(vd, size=size, mode="mirror").get(), sndi.minimum_filter(v, size=size, mode="mirror")), (shape, size)
+        for sigma in (2.0, [1.0, 1.7, 1.0]):
+            want = sndi.gaussian_filter(v, sigma)
+            assert np.abs(ndi.gaussian_filter(vd, sigma).get() - want).max() <= 2e-6 * np.abs(want).max(), (shape, sigma)
+        want = sndi.uniform_filter(v, size=(3, 5, 7))
+        assert np.abs(ndi.uniform_filter(vd, size=(3, 5, 7)).get() - want).max() <= 2e-6 * np.abs(want).max()
