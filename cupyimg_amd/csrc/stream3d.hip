@@ -142,7 +142,7 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     const int nother = p.axis == 0 ? ny : nz;
     const int nA = p.axis == 0 ? nz : ny;
     const int nlines = nother * p.nxt;
-    const int wid = p.wid_base + blockIdx.x * 4 + wave;
+    const int wid = p.wid_base + blockIdx.x * p.wpb + wave;
     if (wid >= nlines * p.nchunks) return;
     const int c = wid / nlines;
     const int line = wid - c * nlines;
@@ -259,8 +259,10 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
 // A pass is issued in launches of at most 1000 waves (250 workgroups, < one per CU).  With more workgroups
 // per launch the ones beyond the first 256 produced wrong samples in lanes 12-15 of each DPP row (found by
 // the mid-size differential fuzz at the end of round 1; every slice size <= 1000 tested clean, the cause --
-// the behaviour of second-generation workgroups sharing a CU -- is not understood yet and is the first item
-// of the next round).  The launches run back to back on the stream.
+// it appears as soon as two waves of this kernel share a SIMD, whatever the workgroup shape -- is not understood
+// yet and is the first item of the next round).  The launches run back to back on the stream.
+static int g_stream_wpb = 4;             // test hook: waves per workgroup (1, 2 or 4)
+extern "C" int mi_debug_set_stream_wpb(int n) { g_stream_wpb = n; return MI_OK; }
 static int g_stream_slice = 1000;        // test hook: waves per launch of a pass (0 = one launch)
 extern "C" int mi_debug_set_stream_slice(int n) { g_stream_slice = n; return MI_OK; }
 static int g_stream_min_chunk = 32;      // test hook: shortest chunk the planner may choose
@@ -292,10 +294,12 @@ static int launch_stream(const float *in, float *out, StreamParams &p, hipStream
     p.nchunks = (nA + p.chunk - 1) / p.chunk;
     const int waves = nlines * p.nchunks;
     const int slice = g_stream_slice > 0 ? g_stream_slice : waves;
+    const int wpb = g_stream_wpb;
+    p.wpb = wpb;
     for (int base = 0; base < waves; base += slice) {
         p.wid_base = base;
         const int n = std::min(slice, waves - base);
-        hipLaunchKernelGGL((stream_pass_kernel<WX, WA, DEPTH, OP>), dim3((n + 3) / 4), dim3(256), 0, s, in, out, p);
+        hipLaunchKernelGGL((stream_pass_kernel<WX, WA, DEPTH, OP>), dim3((n + wpb - 1) / wpb), dim3(64 * wpb), 0, s, in, out, p);
     }
     MI_HIP(hipGetLastError());
     return MI_OK;

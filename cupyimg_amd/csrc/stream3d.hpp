@@ -34,6 +34,7 @@ struct StreamParams {
     // for output parity q (B = window offset of tap 0, see xpass_hops); 0 outside the kernel
     float xpair[2][2 * (kStreamMaxTaps / 2 + 2)];
     int wid_base;        // first wave index of this launch (a pass is issued in slices of waves)
+    int wpb;             // waves per workgroup of this launch
 };
 
 }  // namespace mi
