@@ -294,7 +294,7 @@ stream_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
                     u.x = join(a.e[0], a.o[0]); u.y = join(a.e[1], a.o[1]);
                     u.z = join(a.e[2], a.o[2]); u.w = join(a.e[3], a.o[3]);
                     const unsigned so = (unsigned)(a0 + i - (WA - 1)) * strideA;
-                    __builtin_amdgcn_raw_buffer_store_b128(u, rout, voff, so, 0);
+                    buffer_store_b128_soff(u, rout, voff, so);
                 }
                 if constexpr (RINGN > 0) ring[J % RINGN] = xf;
             }

@@ -210,6 +210,24 @@ __device__ __forceinline__ F4 xdot_tab(const f32x2 (&A)[NP], kfloats tab0, kfloa
     return r;
 }
 
+// buffer_store_dwordx4 with a REGISTER soffset, followed by two wait states.
+// A VMEM store of more than 64 bits reads its data VGPRs late; a VALU write to one
+// of them in the next instruction slots can overtake that read.  LLVM (ROCm 7.2)
+// inserts the wait states for the soffset-less form only (GCNHazardRecognizer:
+// "no hazard if the instruction uses a register in the soffset field", which is
+// what the ISA manual says), but on gfx950 the soffset form is exposed as well as
+// soon as two waves of the kernel share a SIMD: the register overwritten right
+// after the store arrived in memory with the NEW value in lanes 12-15 of every
+// 16-lane group (root cause of the round-1 streaming-pass failure; reproducer:
+// scripts/diag/stream_diag.hip, one `s_nop 0` after the store is enough there).
+// The fake "v"(d) input keeps every later writer of the data registers behind
+// the s_nop.
+__device__ __forceinline__ void buffer_store_b128_soff(u32x4 d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 0);
+    asm volatile("s_nop 1" ::"v"(d) : "memory");
+}
+
 __device__ __forceinline__ float4 as_f4(u32x4 u)
 {
     return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));

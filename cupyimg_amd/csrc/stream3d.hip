@@ -248,7 +248,7 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                         a = f4_fma(wav[WA - 1], xf, a);
                     }
                     const unsigned so = (unsigned)(a0 + i - (WA - 1)) * strideA * 4u;
-                    __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(a), rout, voff, so, 0);
+                    buffer_store_b128_soff(f4_to_u32(a), rout, voff, so);
                 }
                 if constexpr (RINGN > 0) ring[J % RINGN] = xf;
             }
@@ -256,14 +256,12 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     }
 }
 
-// A pass is issued in launches of at most 1000 waves (250 workgroups, < one per CU).  With more workgroups
-// per launch the ones beyond the first 256 produced wrong samples in lanes 12-15 of each DPP row (found by
-// the mid-size differential fuzz at the end of round 1; every slice size <= 1000 tested clean, the cause --
-// it appears as soon as two waves of this kernel share a SIMD, whatever the workgroup shape -- is not understood
-// yet and is the first item of the next round).  The launches run back to back on the stream.
+// Round 1 issued a pass in launches of at most 1000 waves because larger launches produced wrong samples; the
+// cause was the store-data hazard described at buffer_store_b128_soff() (sep_common.hpp), not the launch size.
+// The slice hook stays for tests (0 = one launch, the default).
 static int g_stream_wpb = 4;             // test hook: waves per workgroup (1, 2 or 4)
 extern "C" int mi_debug_set_stream_wpb(int n) { g_stream_wpb = n; return MI_OK; }
-static int g_stream_slice = 1000;        // test hook: waves per launch of a pass (0 = one launch)
+static int g_stream_slice = 0;           // test hook: waves per launch of a pass (0 = one launch)
 extern "C" int mi_debug_set_stream_slice(int n) { g_stream_slice = n; return MI_OK; }
 static int g_stream_min_chunk = 32;      // test hook: shortest chunk the planner may choose
 extern "C" int mi_debug_set_stream_min_chunk(int n) { g_stream_min_chunk = n; return MI_OK; }
@@ -398,6 +396,13 @@ int run_stream_minmax_pass(const float *in, float *out, int nz, int ny, int nx, 
 }  // namespace mi
 
 using namespace mi;
+
+// test hook: one streaming pass with arbitrary float weights (not part of the C-ABI)
+extern "C" int mi_debug_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axis, const float *wav,
+                                    int wa, int oa, int ma, const float *wxv, int wx, int mx, float cval, mi_stream stream)
+{
+    return run_stream_pass(in, out, nz, ny, nx, axis, wav, wa, oa, ma, wxv, wx, mx, cval, resolve_stream(stream));
+}
 
 /* Separable flat min / max filter on a float32 volume as streaming passes
  * (declared in include/mi355img.h). */
