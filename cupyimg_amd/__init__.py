@@ -5,6 +5,7 @@ Python host code calls hand-written gfx950 HIP kernels through the ctypes
 C-ABI in include/mi355img.h (libmi355img.so).  No CuPy, no PyTorch, no CPU
 fallback: if the HIP library cannot be loaded, using the package fails.
 """
+from . import core  # noqa: F401
 from .core import (  # noqa: F401
     Event, Stream, array, arrays_differ, asarray, ascontiguousarray, asnumpy, device_count, device_name, empty,
     empty_like, free_all_blocks, full, get_device, is_available, ndarray, ones, pool_stats,

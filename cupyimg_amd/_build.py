@@ -76,7 +76,21 @@ def _compile(args):
 
 
 def build(force=False, jobs=None, verbose=True):
+    """Compile and link under an exclusive file lock: N ranks importing the
+    package at once (torchrun) build once, the others wait and find the library
+    up to date.  The link goes to a temporary name and is moved into place, so a
+    concurrent dlopen never sees a half-written file."""
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, jobs, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, jobs, verbose):
     present = [(s, f) for s, f in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     missing = [s for s, _ in SOURCES if not os.path.exists(os.path.join(CSRC, s))]
     if missing:
@@ -88,11 +102,15 @@ def build(force=False, jobs=None, verbose=True):
     objs = [o for o, _ in results]
     rebuilt = any(r for _, r in results)
     if rebuilt or not os.path.exists(LIB):
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + [
+        tmp = "{}.{}.tmp".format(LIB, os.getpid())
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs + [
             "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
         proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if proc.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError("link failed:\n" + proc.stdout)
+        os.replace(tmp, LIB)
         if verbose:
             print("built", LIB)
     elif verbose:

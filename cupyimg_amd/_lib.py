@@ -84,6 +84,7 @@ SIGNATURES = {
     "mi_event_destroy": [_vp],
     "mi_event_record": [_vp, _vp],
     "mi_stream_wait_event": [_vp, _vp],
+    "mi_stream_wait_stream": [_vp, _vp],
     "mi_event_sync": [_vp],
     "mi_event_elapsed_ms": [_vp, _vp, ctypes.POINTER(ctypes.c_float)],
     "mi_copy": [_arr, _arr, _i, _vp],

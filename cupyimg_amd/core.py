@@ -166,9 +166,19 @@ class ndarray:
 
     @property
     def __cuda_array_interface__(self):
+        """Version 3.  By default the library's default stream is synchronised
+        before the pointer is handed out and `stream` is None ("no
+        synchronisation required"): torch.as_tensor ignores the `stream` entry
+        (measured: it read the array before the filter had run), so naming the
+        stream alone is not safe.  With ``core.EXPORT_SYNC = False`` the entry
+        names the library's default stream instead and a protocol-abiding
+        consumer (CuPy) orders its own stream behind it without a host sync."""
+        if EXPORT_SYNC:
+            _lib.check(_lib.load().mi_stream_sync(None))
         return {
             "shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False),
             "strides": None if self._is_c_contiguous() else self.strides, "version": 3,
+            "stream": None if EXPORT_SYNC else default_stream_handle(),
         }
 
     # ------------------------------------------------------------- C-ABI view
@@ -370,8 +380,44 @@ def asarray(obj, dtype=None):
 array = asarray
 
 
+EXPORT_SYNC = True      # see ndarray.__cuda_array_interface__
+
+
+def default_stream_handle():
+    """The library's default stream (a non-blocking hipStream_t) as an integer."""
+    h = ctypes.c_void_p()
+    _lib.check(_lib.load().mi_default_stream(ctypes.byref(h)))
+    return int(h.value or 0)
+
+
+def wait_for_stream(producer):
+    """Work queued on the library's default stream from now on waits for what is
+    queued on `producer` (a foreign stream handle as an integer, or 1 / 2 for the
+    legacy / per-thread default stream)."""
+    _lib.check(_lib.load().mi_stream_wait_stream(None, ctypes.c_void_p(int(producer))))
+
+
+def stream_waits_for_us(consumer):
+    """The foreign stream `consumer` (integer handle, or 1 / 2) waits for the work
+    queued on the library's default stream so far -- call it before another
+    runtime reads an array this library wrote in place (a torch tensor passed as
+    `output=`); arrays exported through __cuda_array_interface__ carry the
+    stream themselves."""
+    _lib.check(_lib.load().mi_stream_wait_stream(ctypes.c_void_p(int(consumer)), None))
+
+
 def from_cuda_array_interface(obj):
+    """Zero-copy view of a foreign device array.  Stream ordering: when the
+    producer names a stream (protocol version 3) the library's default stream
+    waits for the work queued there.  Without one -- torch exports version 2,
+    which has no `stream` entry -- it waits for the legacy default stream,
+    which is where torch's default stream runs; a producer working on a
+    non-blocking side stream has to name it or synchronise itself."""
     cai = obj.__cuda_array_interface__
+    producer = cai.get("stream")
+    if producer is not None and int(producer) == 0:
+        raise ValueError("__cuda_array_interface__: stream 0 is not allowed by the protocol")
+    wait_for_stream(1 if producer is None else int(producer))
     dtype = np.dtype(cai["typestr"])
     shape = tuple(cai["shape"])
     strides = cai.get("strides") or _c_strides(shape, dtype.itemsize)

@@ -35,7 +35,8 @@ int hip_fail(hipError_t e, const char *what);
 
 // ------------------------------------------------------------------ runtime hooks
 hipStream_t resolve_stream(mi_stream s);   // NULL -> per-device default stream
-int pool_alloc(void **p, size_t n);
+// block for work on `stream` (NULL = the default stream); pool_free returns it to that stream's arena
+int pool_alloc(void **p, size_t n, hipStream_t stream);
 int pool_free(void *p);
 
 // Small host -> device parameter upload (weights, offset tables) that is

@@ -318,7 +318,7 @@ int mi_min_max(const mi_array *a, double *lo, double *hi, mi_stream stream)
     MI_REQUIRE(n > 0, MI_ERR_INVALID_ARG, "empty array");
     const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
     void *part = nullptr;
-    if ((rc = pool_alloc(&part, (size_t)blocks * 2 * sizeof(double)))) return rc;
+    if ((rc = pool_alloc(&part, (size_t)blocks * 2 * sizeof(double), resolve_stream(stream)))) return rc;
     hipStream_t s = resolve_stream(stream);
     rc = dispatch_dtype(a->dtype, [&]<typename T>() -> int {
         hipLaunchKernelGGL((minmax_reduce_kernel<T>), dim3(blocks), dim3(256), 0, s, (const T *)a->data, n, (double *)part);

@@ -109,6 +109,15 @@ int mi_slab_separable3d_f32(mi_comm comm, const mi_array *ext_in, const mi_array
     const int64_t n_ext = ext_in->shape[0], n_local = n_ext - lo_p - hi_p;
     MI_REQUIRE(n_local >= 1 && n_local >= lo && n_local >= hi, MI_ERR_INVALID_ARG,
                "slab is thinner than the halo it has to provide");
+    // the axis-0 kernel must fit the halo the plan exchanges: otherwise the planes next to a neighbour would be
+    // filtered with the boundary mode applied at an interior slab edge
+    MI_REQUIRE(weights && wlen && origin, MI_ERR_INVALID_ARG, "NULL argument");
+    if (weights[0] && wlen[0] > 1) {
+        const int need_lo = wlen[0] / 2 + origin[0], need_hi = wlen[0] - 1 - need_lo;
+        MI_REQUIRE(need_lo >= 0 && need_hi >= 0, MI_ERR_INVALID_ARG, "invalid origin");
+        MI_REQUIRE((!has_prev || need_lo <= lo) && (!has_next || need_hi <= hi), MI_ERR_INVALID_ARG,
+                   "the axis-0 kernel reaches beyond the halo of the slab plan");
+    }
     const int64_t a = lo_p, b = a + n_local;
     if (!has_prev && !has_next) {
         const int64_t all[2] = {a, b};

@@ -1469,7 +1469,7 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
             const int64_t entries = g.oshape[0] + g.oshape[1] + g.oshape[2];
             int64_t longest = g.oshape[0] > g.oshape[1] ? g.oshape[0] : g.oshape[1];
             if (g.oshape[2] > longest) longest = g.oshape[2];
-            if ((rc = pool_alloc(&tab, (size_t)entries * sizeof(AxisTaps)))) return rc;
+            if ((rc = pool_alloc(&tab, (size_t)entries * sizeof(AxisTaps), s))) return rc;
             const bool separable = !g_cubic_separable_off && g.oshape[0] <= 65535 && (g.oshape[1] + 3) / 4 <= 65535 &&
                                    g.shape[0] <= 65535 && (g.shape[1] + 3) / 4 <= 65535;
             hipLaunchKernelGGL(cubic3_axis_table_kernel, dim3((unsigned)((longest + 255) / 256), 3), dim3(256), 0, s,
@@ -1483,11 +1483,11 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
                 void *bufA = nullptr, *bufB = nullptr;
                 float *dst_x = (float *)out->data, *dst_y = (float *)out->data;
                 if (do_y) {
-                    if ((rc = pool_alloc(&bufA, (size_t)nz * ny * ox * sizeof(float)))) { pool_free(tab); return rc; }
+                    if ((rc = pool_alloc(&bufA, (size_t)nz * ny * ox * sizeof(float), s))) { pool_free(tab); return rc; }
                     dst_x = (float *)bufA;
                 }
                 if (do_z) {
-                    if ((rc = pool_alloc(&bufB, (size_t)nz * oy * ox * sizeof(float)))) { pool_free(bufA); pool_free(tab); return rc; }
+                    if ((rc = pool_alloc(&bufB, (size_t)nz * oy * ox * sizeof(float), s))) { pool_free(bufA); pool_free(tab); return rc; }
                     dst_y = (float *)bufB;
                 }
                 const dim3 blk(64, 4);

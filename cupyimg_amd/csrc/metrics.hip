@@ -139,7 +139,7 @@ int mi_sum(int op, const mi_array *a, const mi_array *b, double *result, mi_stre
     }
     const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
     void *part = nullptr;
-    if ((rc = pool_alloc(&part, (size_t)blocks * sizeof(double)))) return rc;
+    if ((rc = pool_alloc(&part, (size_t)blocks * sizeof(double), resolve_stream(stream)))) return rc;
     hipStream_t s = resolve_stream(stream);
     rc = dispatch_dtype(a->dtype, [&]<typename T>() -> int {
         hipLaunchKernelGGL((sum_kernel<T>), dim3(blocks), dim3(256), 0, s, (const char *)a->data,

@@ -746,7 +746,7 @@ extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int
     const bool need_a = size[0] > 1 || size[2] > 1 || !need_y;
     void *tmp = nullptr;
     if (need_y && need_a) {
-        if ((rc = pool_alloc(&tmp, (size_t)(nz * ny * nx)))) return rc;
+        if ((rc = pool_alloc(&tmp, (size_t)(nz * ny * nx), s))) return rc;
     }
     if (need_a) {
         p.axis = 0; p.oa = size[0] / 2; p.ma = filter_mode(mode[0]);

@@ -59,12 +59,26 @@ hipStream_t resolve_stream(mi_stream s)
 // Size-bucketed caching allocator.  Blocks are rounded up to 512 B below
 // 1 MiB and to 2 MiB multiples above; a freed block goes back to its
 // (device, size) free list and is reused by the next request of that size.
-// Reuse is stream-ordered with respect to the library's default stream, the
-// same contract CuPy's pool gives the reference.
+// Free lists are per stream ("arenas", the contract CuPy's pool gives the
+// reference): a block returns to the arena of the stream it was allocated for
+// and is only handed out again for work on that stream, so reuse is stream
+// ordered without events -- also when callers pass their own streams.
+// mi_malloc / mi_free use the arena of the library's default stream.
+struct PoolKey {
+    int dev;
+    size_t size;
+    hipStream_t stream;
+    bool operator<(const PoolKey &o) const
+    {
+        if (dev != o.dev) return dev < o.dev;
+        if (size != o.size) return size < o.size;
+        return stream < o.stream;
+    }
+};
 struct Pool {
     std::mutex mu;
-    std::map<std::pair<int, size_t>, std::vector<void *>> free_lists;
-    std::unordered_map<void *, std::pair<int, size_t>> live;
+    std::map<PoolKey, std::vector<void *>> free_lists;
+    std::unordered_map<void *, PoolKey> live;
     size_t in_use = 0, cached = 0;
 };
 static Pool g_pool;
@@ -83,10 +97,10 @@ static int pool_trim_locked()
     (void)hipGetDevice(&keep);
     for (auto &kv : g_pool.free_lists) {
         if (kv.second.empty()) continue;
-        (void)hipSetDevice(kv.first.first);
+        (void)hipSetDevice(kv.first.dev);
         for (void *p : kv.second) {
             (void)hipFree(p);
-            g_pool.cached -= kv.first.second;
+            g_pool.cached -= kv.first.size;
         }
         kv.second.clear();
     }
@@ -94,13 +108,14 @@ static int pool_trim_locked()
     return MI_OK;
 }
 
-int pool_alloc(void **p, size_t n)
+int pool_alloc(void **p, size_t n, hipStream_t stream)
 {
     int dev = 0;
     MI_HIP(hipGetDevice(&dev));
     const size_t sz = round_size(n);
+    if (!stream) stream = resolve_stream(nullptr);
     std::lock_guard<std::mutex> lk(g_pool.mu);
-    auto &fl = g_pool.free_lists[{dev, sz}];
+    auto &fl = g_pool.free_lists[{dev, sz, stream}];
     if (!fl.empty()) {
         *p = fl.back();
         fl.pop_back();
@@ -123,7 +138,7 @@ int pool_alloc(void **p, size_t n)
             return hip_fail(e, "hipMalloc");
         }
     }
-    g_pool.live[*p] = {dev, sz};
+    g_pool.live[*p] = {dev, sz, stream};
     g_pool.in_use += sz;
     return MI_OK;
 }
@@ -138,15 +153,15 @@ int pool_free(void *p)
         return MI_ERR_INVALID_ARG;
     }
     g_pool.free_lists[it->second].push_back(p);
-    g_pool.in_use -= it->second.second;
-    g_pool.cached += it->second.second;
+    g_pool.in_use -= it->second.size;
+    g_pool.cached += it->second.size;
     g_pool.live.erase(it);
     return MI_OK;
 }
 
 int Scratch::upload(const void *host, size_t nbytes, hipStream_t stream)
 {
-    int rc = pool_alloc(&ptr, nbytes);
+    int rc = pool_alloc(&ptr, nbytes, stream);
     if (rc != MI_OK) return rc;
     // pageable source: the runtime stages it before returning, so the caller's
     // buffer may go away; the copy itself is ordered on `stream`.
@@ -204,9 +219,19 @@ int mi_mem_info(size_t *free_bytes, size_t *total_bytes)
 int mi_malloc(void **ptr, size_t nbytes)
 {
     MI_REQUIRE(ptr, MI_ERR_INVALID_ARG, "ptr is NULL");
-    return pool_alloc(ptr, nbytes);
+    return pool_alloc(ptr, nbytes, nullptr);
 }
 int mi_free(void *ptr) { return pool_free(ptr); }
+
+// test hook (not part of the C-ABI): allocate `nbytes` for work on `stream`, report the block and free it again
+int mi_debug_pool_probe(size_t nbytes, mi_stream stream, void **block)
+{
+    void *p = nullptr;
+    int rc = pool_alloc(&p, nbytes, resolve_stream(stream));
+    if (rc != MI_OK) return rc;
+    if (block) *block = p;
+    return pool_free(p);
+}
 
 int mi_pool_trim(void)
 {
@@ -309,6 +334,26 @@ int mi_event_record(mi_event event, mi_stream stream)
 int mi_stream_wait_event(mi_stream stream, mi_event event)
 {
     MI_HIP(hipStreamWaitEvent(resolve_stream(stream), (hipEvent_t)event, 0));
+    return MI_OK;
+}
+// `producer` / `waiter`: a hipStream_t, NULL = the library's default stream, or the
+// __cuda_array_interface__ codes 1 (legacy default stream) / 2 (per-thread default stream)
+static hipStream_t foreign_or_own_stream(mi_stream s)
+{
+    if (s == (mi_stream)(uintptr_t)1) return (hipStream_t) nullptr;   // the null stream IS the legacy default stream
+    if (s == (mi_stream)(uintptr_t)2) return hipStreamPerThread;
+    return resolve_stream(s);
+}
+int mi_stream_wait_stream(mi_stream waiter, mi_stream producer)
+{
+    hipStream_t w = foreign_or_own_stream(waiter), p = foreign_or_own_stream(producer);
+    if (w == p) return MI_OK;
+    hipEvent_t e;
+    MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t err = hipEventRecord(e, p);
+    if (err == hipSuccess) err = hipStreamWaitEvent(w, e, 0);
+    hipEventDestroy(e);          // released once the recorded work has completed
+    MI_HIP(err);
     return MI_OK;
 }
 int mi_event_sync(mi_event event) { MI_HIP(hipEventSynchronize((hipEvent_t)event)); return MI_OK; }

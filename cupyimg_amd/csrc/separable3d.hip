@@ -828,7 +828,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
         const size_t bytes = (size_t)(nz * ny * nx) * sizeof(float);
         void *tmp[2] = {nullptr, nullptr};
         for (int t = 0; t < np - 1 && t < 2; t++)
-            if ((rc = pool_alloc(&tmp[t], bytes))) { if (tmp[0]) pool_free(tmp[0]); return rc; }
+            if ((rc = pool_alloc(&tmp[t], bytes, s))) { if (tmp[0]) pool_free(tmp[0]); return rc; }
         const float *src = (const float *)in->data;
         const float one = 1.0f;
         for (int i = 0; i < np && rc == MI_OK; i++) {

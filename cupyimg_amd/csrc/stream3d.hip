@@ -448,7 +448,7 @@ extern "C" int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const in
     const size_t bytes = (size_t)(nz * ny * nx) * sizeof(float);
     void *tmp[2] = {nullptr, nullptr};
     for (int t = 0; t < np - 1 && t < 2; t++)
-        if ((rc = pool_alloc(&tmp[t], bytes))) { if (tmp[0]) pool_free(tmp[0]); return rc; }
+        if ((rc = pool_alloc(&tmp[t], bytes, s))) { if (tmp[0]) pool_free(tmp[0]); return rc; }
     const float *src = (const float *)in->data;
     for (int i = 0; i < np && rc == MI_OK; i++) {
         float *dst = i == np - 1 ? (float *)out->data : (float *)tmp[i & 1];

@@ -89,6 +89,15 @@ class SlabPlan:
         return idx % self.nz if self.wrap else idx
 
 
+    def check_reach(self, size, origin=0):
+        """Raise ValueError unless an axis-0 kernel of `size` taps stays inside
+        the halo this plan exchanges (otherwise the planes next to a neighbour
+        would see the boundary mode at an interior slab edge)."""
+        lo, hi = halo_widths(int(size), int(origin))
+        if (self.prev >= 0 and lo > self.lo) or (self.next >= 0 and hi > self.hi):
+            raise ValueError("axis-0 kernel of {} taps (origin {}) needs a halo of ({}, {}) planes; the slab plan "
+                             "exchanges ({}, {})".format(size, origin, lo, hi, self.lo, self.hi))
+
     def plane_ranges(self):
         """(interior, edges): output plane ranges of the extended buffer that
         can be filtered before / only after the halo exchange."""
@@ -179,7 +188,16 @@ class SlabFilter:
     def local_out(self):
         return self.ext_out[self.plan.local_slice]
 
+    def check_reach(self, size, origin=0):
+        """See SlabPlan.check_reach."""
+        self.plan.check_reach(size, origin)
+
     def step(self, fn):
+        """Exchange the halos, then run ``fn(ext_in, ext_out)``.  Contract: along
+        axis 0 `fn` may read at most `plan.lo` planes below and `plan.hi` planes
+        above an output plane (`check_reach` tests a kernel length against the
+        plan); a wider filter silently applies its boundary mode at the slab
+        edges."""
         if self.comm is not None and self.plan.nranks > 1:
             self.comm.exchange(self.ext_in, self.plan)
         fn(self.ext_in, self.ext_out)
@@ -241,6 +259,8 @@ class SlabFilter:
                    str(modes), float(cval), tuple(int(o) for o in origins))
         prep = self._prepared.get(key)
         if prep is None:
+            if weights[0] is not None and len(weights[0]) > 1:
+                self.check_reach(len(weights[0]), origins[0])
             modes = S.normalize_sequence(modes, 3)
             for m in modes:
                 S.check_mode(m)

@@ -122,6 +122,13 @@ int mi_event_create(mi_event *event);
 int mi_event_destroy(mi_event event);
 int mi_event_record(mi_event event, mi_stream stream);
 int mi_stream_wait_event(mi_stream stream, mi_event event); /* later work on stream waits for event */
+/* Later work on `waiter` waits for everything queued on `producer` so far.  Either
+ * argument: a hipStream_t (also one owned by another runtime: torch, CuPy), NULL = the
+ * library's default stream, or the __cuda_array_interface__ stream codes 1 (legacy
+ * default stream) / 2 (per-thread default stream).  This is how zero-copy imports and
+ * exports are ordered against the other runtime's stream: the library's default stream
+ * is non-blocking, it never synchronises with the null stream by itself. */
+int mi_stream_wait_stream(mi_stream waiter, mi_stream producer);
 int mi_event_sync(mi_event event);
 int mi_event_elapsed_ms(mi_event start, mi_event stop, float *ms);
 

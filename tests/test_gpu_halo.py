@@ -74,6 +74,10 @@ class _SelfLoopPlan:
         from cupyimg_amd.distributed import SlabPlan
         return SlabPlan.plane_ranges(self)
 
+    def check_reach(self, size, origin=0):
+        from cupyimg_amd.distributed import SlabPlan
+        return SlabPlan.check_reach(self, size, origin)
+
 
 @pytest.fixture(scope="module")
 def self_comm(gpu):
@@ -147,6 +151,31 @@ def test_native_slab_step_matches_plain_step(gpu, ndi, self_comm, nz):
         for overlap in (None, True):      # native plain schedule / Python fallback after UNSUPPORTED
             got = sf2.uniform_filter(13, mode="mirror", overlap=overlap).get()
             assert maxnorm_rel(got, orc.uniform_filter(x, 13, mode=["wrap", "mirror", "mirror"])) <= 1e-6
+
+
+def test_slab_step_refuses_kernels_wider_than_the_halo(gpu, ndi, self_comm):
+    """A plan built for 5 taps refuses a 17-tap axis-0 kernel in Python (ValueError) and in C
+    (MI_ERR_INVALID_ARG), instead of filtering across the slab edge."""
+    import ctypes
+    from cupyimg_amd import _lib
+    from cupyimg_amd.distributed import SlabFilter, halo_widths
+    lo, hi = halo_widths(5)
+    sf = SlabFilter(_SelfLoopPlan(40, lo, hi), (33, 256), np.float32, self_comm)
+    sf.local_in[...] = gpu.asarray(np.ones((40, 33, 256), np.float32))
+    with pytest.raises(ValueError):
+        sf.gaussian_filter(2.0)                       # 17 taps
+    with pytest.raises(ValueError):
+        sf.separable([np.full(5, 0.2), None, None], origins=(1, 0, 0))
+    sf.uniform_filter((5, 17, 17))                    # long kernels along y / x are fine
+    # the C entry point checks on its own
+    w = np.full(17, 1.0 / 17)
+    dp = ctypes.POINTER(ctypes.c_double)
+    ptrs = (dp * 3)(w.ctypes.data_as(dp), ctypes.cast(None, dp), ctypes.cast(None, dp))
+    ints = lambda v: (ctypes.c_int * 3)(*v)           # noqa: E731
+    a, b = sf.ext_in._desc(), sf.ext_out._desc()
+    rc = _lib.load().mi_slab_separable3d_f32(self_comm._comm, ctypes.byref(a), ctypes.byref(b), ptrs, ints([17, 0, 0]),
+                                            ints([0, 0, 0]), ints([0, 0, 0]), 0.0, lo, hi, 0, 0, 0, None, None, None, None)
+    assert rc == _lib.MI_ERR_INVALID_ARG and "halo" in _lib.last_error()
 
 
 def test_overlapped_step_falls_back_for_long_kernels(gpu, ndi, self_comm):

@@ -89,6 +89,25 @@ def test_slab_plan_wrap_and_too_thin():
         SlabPlan(8, 8, 0, 2, 2)
 
 
+def test_slab_plan_refuses_kernels_wider_than_its_halo():
+    """A plan built for 5 taps must not run a 17-tap axis-0 kernel: the planes
+    next to a neighbour would be filtered across a slab edge."""
+    lo, hi = halo_widths(5)
+    p = SlabPlan(64, 4, 1, lo, hi)
+    p.check_reach(5)
+    p.check_reach(3)
+    p.check_reach(4, -1)          # lo 1, hi 2
+    with pytest.raises(ValueError):
+        p.check_reach(17)
+    with pytest.raises(ValueError):
+        p.check_reach(5, 1)       # lo 3 > 2
+    # an edge rank only needs the side that has a neighbour
+    first = SlabPlan(64, 4, 0, 0, 8)
+    with pytest.raises(ValueError):
+        first.check_reach(17, -8)  # lo 0, hi 16 > 8
+    SlabPlan(64, 1, 0, 0, 0).check_reach(17)     # a single rank has no interior edges
+
+
 def test_slab_split_is_bit_identical_to_unsplit():
     """The decomposition itself (host logic + any filter): filtering every
     rank's extended slab and keeping the local planes reproduces the unsplit
