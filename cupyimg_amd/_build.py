@@ -28,6 +28,7 @@ SOURCES = [
     ("correlate1d.hip", ["-ffp-contract=off"]),
     ("separable3d.hip", []),
     ("stream3d.hip", []),
+    ("sep3d_long.hip", []),
     ("correlate_nd.hip", ["-ffp-contract=off"]),
     ("stencil3d.hip", ["-ffp-contract=off"]),
     ("minmax.hip", ["-ffp-contract=off"]),
