@@ -1,34 +1,35 @@
-// sep3d_long.hip -- fused separable 3-D filter for LONG cubic kernels (11..17
-// taps per axis, e.g. gaussian sigma=2 -> 17 taps, BASELINE config B), float32,
-// ONE launch at the algorithmic 8 B/voxel.
+// sep3d_long.hip -- fused separable 3-D filter for LONG cubic kernels (9..17
+// taps per axis, e.g. gaussian sigma=2 -> 17 taps, BASELINE config B; 9 taps =
+// config E), float32, ONE launch at the algorithmic 8 B/voxel.
 //
 // Reference path replaced: gaussian_filter / uniform_filter as three K1 launches
 // with fp64 taps from global memory, zero-fill + copy-back per in-place pass
 // (cupyimg/scipy/ndimage/filters.py:602-665,725-792, _filters_core.py:148-155).
-// Round 1 ran long kernels as two streaming launches (stream3d.hip, 16 B/voxel,
-// latency bound: two 1 KiB loads in flight per wave).
+// Round 1 ran kernels beyond 9 taps as two streaming launches (stream3d.hip,
+// 16 B/voxel, latency bound: two 1 KiB loads in flight per wave).
 //
 // Design (one workgroup of 16 waves per CU, tile = 256 x by TY = 16 y, streaming
 // along z over a chunk of planes):
 //   * LDS-DMA staging: every raw input row of the tile's (16 + W - 1)-row window
 //     goes global -> LDS with `buffer_load_dwordx4 ... lds` (1 KiB per wave
-//     instruction, no VGPRs), three planes deep, so ~100 KiB per CU are in flight
-//     while the registers hold the z state.  The 8-float x halo of a row is a
-//     second, 16-lane `buffer_load_dword ... lds` whose per-lane source address is
-//     already boundary mapped (reflect / mirror / nearest / wrap resolved here).
-//   * x pass: wave w filters raw rows w and w + 16 straight out of LDS (five
-//     lane-contiguous ds_read_b128 give the 20-float window, no lane shuffles),
-//     packed fp32 dot product against host-made weight pairs, result to an LDS
-//     row buffer.
-//   * y pass: wave w owns output row w: W lane-contiguous ds_read_b128.
+//     instruction, no VGPRs) into a ring of four planes, so two planes (~68 KiB
+//     per CU) are in flight while the registers hold the z state.  The 8-float x
+//     halo of a row is a second, 16-lane `buffer_load_dword ... lds` whose per-lane
+//     source address is already boundary mapped (reflect / mirror / nearest / wrap
+//     resolved here).
+//   * y pass: wave w owns output row w and reads its W raw rows straight from the
+//     staged plane (W lane-contiguous ds_read_b128).
+//   * x pass: on that ONE y-filtered row, in registers (DPP lane shifts, packed fp32
+//     dot product against host-made weight pairs); the y-filtered halo blocks come
+//     from a small LDS table that one wave per plane fills one plane ahead.
 //   * z pass: in registers as a scatter -- the x/y-filtered sample is added into
 //     W pending output accumulators (68 VGPRs), the oldest one is complete and is
 //     stored (non-temporal buffer_store_dwordx4).  The rotation is by unrolling W
 //     steps, like the rings of the other kernels.
-//   * two s_barriers per plane; DMA completion is counted by hand
-//     (s_waitcnt vmcnt(8): the two younger planes stay in flight across barriers).
+//   * one s_barrier per plane; DMA completion is counted by hand (s_waitcnt
+//     vmcnt(4): the youngest plane stays in flight across the barrier).
 // Boundary modes: every index-mapping mode on every axis; `constant` is left to
-// the streaming passes (DMA cannot substitute cval).
+// the lean kernel / the streaming passes (DMA cannot substitute cval).
 #include "sep_common.hpp"
 #include "stream3d.hpp"
 
@@ -37,9 +38,8 @@ namespace mi {
 constexpr int kLongTY = 16;           // output rows per tile = waves per workgroup
 constexpr int kLongRowsMax = 32;      // raw rows per plane (TY + 17 - 1)
 constexpr int kLongRec = 1024 + 64;   // LDS bytes per raw row: 256 floats + 16 halo floats
-constexpr int kLongNB = 3;            // raw planes in LDS
+constexpr int kLongNB = 4;            // planes in LDS: one being x-filtered, one being y-read, two in flight
 constexpr int kLongRawBytes = kLongNB * kLongRowsMax * kLongRec;
-constexpr int kLongXfBytes = kLongRowsMax * 1024;
 constexpr int kLongMaxChunk = 1024;   // planes per z chunk (ztab in LDS)
 
 struct LongParams {
@@ -48,26 +48,41 @@ struct LongParams {
     int mx, my, mz;         // boundary modes (filter_mode()-normalised, never constant)
     int zc;                 // output planes per chunk
     int nxt, nyt, nzc;      // tile counts
+    // output planes to produce: up to two plane ranges [zb, zb + zn), the first covered by chunks 0 .. nzc0-1, the
+    // second by the rest (whole volume: zb0 = 0, zn0 = nz, nzc0 = nzc).  Boundary handling always refers to nz.
+    int zb0, zn0, zb1, zn1, nzc0;
     float wyv[kStreamMaxTaps], wzv[kStreamMaxTaps];
     float xpair[2][2 * (kStreamMaxTaps / 2 + 2)];   // see StreamParams::xpair
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-// global -> LDS, 16 bytes per lane, LDS destination = lds_dst + 16 * lane (wave uniform base in M0)
-__device__ __forceinline__ void dma_row16(u32x4_t rsrc, unsigned voff, unsigned lds_dst)
+// The four LDS-DMAs a wave issues per plane, as ONE statement (M0 = wave-uniform LDS destination, saved and
+// restored around it): row A (16 bytes per lane, destination rec + 16 * lane), its halo (4 bytes per lane, lanes
+// 0..15 only, at rec + 1024), then the same for row B, whose record lies 16 records further.
+__device__ __forceinline__ void dma_two_rows(u32x4_t rsrc, unsigned va, unsigned vha, unsigned vb, unsigned vhb, unsigned rec)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
-}
-// global -> LDS, 4 bytes per lane, lanes 0..15 only (64 bytes at lds_dst)
-__device__ __forceinline__ void dma_halo16(u32x4_t rsrc, unsigned voff, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, 0xffff\n\t"
-                 "buffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %5, 0 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_mov_b64 exec, 0xffff\n\t"
+        "buffer_load_dword %2, %5, 0 offen lds\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_add_u32 m0, m0, %7\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %3, %5, 0 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_mov_b64 exec, 0xffff\n\t"
+        "buffer_load_dword %4, %5, 0 offen lds\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(va), "v"(vha), "v"(vb), "v"(vhb), "s"(rsrc), "s"(rec), "n"(16 * kLongRec - 1024)
+        : "memory", "scc");
 }
 
 __device__ __forceinline__ u32x4_t plane_rsrc(const float *base, unsigned bytes)
@@ -81,27 +96,80 @@ __device__ __forceinline__ u32x4_t plane_rsrc(const float *base, unsigned bytes)
     return r;
 }
 
+// SAME: the three axes share one weight vector (uniform_filter(size=W), isotropic gaussian_filter): x pair tables
+// plus ONE set of 17 splat weights fit the SGPR file for the whole loop.  Otherwise the tables are re-loaded from
+// the kernel-argument segment every step (launder()): hoisted, 2 x 17 weights + the pair tables exceed the SGPR
+// file and come back as v_readlane spill code.
+
+// ---------------------------------------------------------------------------
+// Pass order y, x, z.  The first version of this kernel filtered along x first (window reads out of LDS, result
+// written back in place, then the y pass): ablating its phases on 512^3 / 17 taps showed the cost was the LDS
+// traffic of the x pass (five window reads + one write-back per raw row, on twice as many rows as are output:
+// 162 us of 388) and of the y pass (105 us), not the FMAs (the whole z pass: 22 us); DMA + stores alone ran 230 us.
+// Here a wave reads the W raw rows of ITS output row once (y pass, straight from the DMA-staged rows), filters that
+// one row along x in registers (lane shifts by DPP, as the streaming passes do) and scatters it along z: 19 LDS
+// reads per wave and plane instead of 27 reads and 2 writes, and no x pass on the 16 halo rows (388 -> 302 us
+// before the clocks drop).  The y-filtered x HALO of a row (two 4-float blocks per side) is not
+// something the wave's own lanes hold: one wave per plane (rotating) filters the halo blocks of all 16 rows in one
+// extra pass, one plane ahead, and leaves them in a small LDS table for the edge lanes.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float4 dpp4_shr(const float4 keep, const float4 v)
+{
+    return make_float4(dpp_from_left(keep.x, v.x), dpp_from_left(keep.y, v.y), dpp_from_left(keep.z, v.z), dpp_from_left(keep.w, v.w));
+}
+__device__ __forceinline__ float4 dpp4_shl(const float4 keep, const float4 v)
+{
+    return make_float4(dpp_from_right(keep.x, v.x), dpp_from_right(keep.y, v.y), dpp_from_right(keep.z, v.z), dpp_from_right(keep.w, v.w));
+}
+
+// x pass over the row a wave holds one float4 per lane of: eL[j] / eR[j] = the (j+1)-th 4-float block left / right of
+// the tile (valid in lane 0 / lane `last`)
 template <int W>
+__device__ __forceinline__ F4 xhops(const float4 v, const float4 (&eL)[2], const float4 (&eR)[2], int lane, int last,
+                                    kfloats tab0, kfloats tab1)
+{
+    constexpr int RX = W / 2;
+    constexpr int NBK = (RX + 3) / 4;
+    float4 blk[2 * NBK + 1];
+    blk[NBK] = v;
+    float4 l = v, r = v;
+#pragma unroll
+    for (int j = 1; j <= NBK; j++) {
+        l = dpp4_shr(eL[j - 1], l);
+        const float4 rr = dpp4_shl(eR[j - 1], r);
+        r = lane == last ? eR[j - 1] : rr;
+        blk[NBK - j] = l;
+        blk[NBK + j] = r;
+    }
+    constexpr int NP = 2 * (2 * NBK + 1);
+    f32x2 A[NP];
+#pragma unroll
+    for (int b = 0; b < 2 * NBK + 1; b++) {
+        A[2 * b] = (f32x2){blk[b].x, blk[b].y};
+        A[2 * b + 1] = (f32x2){blk[b].z, blk[b].w};
+    }
+    return xdot_tab<W, NP, 4 * NBK - RX>(A, tab0, tab1);
+}
+
+constexpr int kLongHyBytes = 2 * kLongTY * 64;     // y-filtered halo blocks: [2 planes][16 rows][4 blocks of 16 bytes]
+
+template <int W, bool SAME>
 __global__ void __launch_bounds__(kLongTY * 64)
 sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const LongParams p)
 {
-    constexpr int RX = W / 2;
-    constexpr int NBK = (RX + 3) / 4;                 // 4-float blocks per side in the x window
-    constexpr int NP = 2 * (2 * NBK + 1);             // window pairs
-    constexpr int BASE = 4 * NBK - RX;                // window[BASE + c + k] = in[x + c - RX + k]
     constexpr int ROWS = kLongTY + W - 1;
-    static_assert(W >= 3 && (W & 1) && ROWS <= kLongRowsMax && NBK <= 2, "long kernel: odd W, 3..17");
+    static_assert(W >= 3 && (W & 1) && ROWS <= kLongRowsMax && W / 2 <= 8, "long kernel: odd W, 3..17");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // layout: raw[kLongNB][32] records | xf[32][1024] | ztab
-    constexpr unsigned XF0 = kLongRawBytes;
-    int *ztab = reinterpret_cast<int *>(smem + kLongRawBytes + kLongXfBytes);
+    // layout: planes[kLongNB][32] records | hy[2][16][4] float4 | ztab
+    constexpr unsigned HY0 = kLongRawBytes;
+    int *ztab = reinterpret_cast<int *>(smem + kLongRawBytes + kLongHyBytes);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     int b = blockIdx.x;
     const int total = p.nxt * p.nyt * p.nzc;
-    if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);      // an XCD gets one contiguous range of tiles
+    if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
     const int per_chunk = p.nxt * p.nyt;
     const int zci = b / per_chunk;
     const int rem = b - zci * per_chunk;
@@ -109,7 +177,13 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
 
     const int nx = p.nx, ny = p.ny, nz = p.nz;
     const int x0 = xt * 256, y0 = yt * kLongTY;
-    const int zs = zci * p.zc, ze = min(zs + p.zc, nz);
+    int zs, ze;
+    {
+        const bool second = zci >= p.nzc0;
+        const int zb = second ? p.zb1 : p.zb0, zn = second ? p.zn1 : p.zn0;
+        zs = zb + (second ? zci - p.nzc0 : zci) * p.zc;
+        ze = min(zs + p.zc, zb + zn);
+    }
     const int ty_act = min(kLongTY, ny - y0);
     const int rows_needed = ty_act + W - 1;
     const int nlanes = min(64, (nx - x0) >> 2);
@@ -123,7 +197,6 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     for (int i = threadIdx.x; i < nsteps; i += kLongTY * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
     __syncthreads();
 
-    // ---- per-lane DMA source offsets (bytes inside a plane) of this wave's two raw rows
     unsigned vmain[2], vhalo[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -135,102 +208,112 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
         const int xsrc = bmap<int>(j < 8 ? x0 - 8 + j : xe + j - 8, nx, p.mx);
         vhalo[h] = valid ? (unsigned)(ys * nx + xsrc) * 4u : kOOB;
     }
-    // ---- x window: LDS byte offsets of the 2 NBK + 1 blocks inside a record
-    unsigned cb[2 * NBK + 1];
-#pragma unroll
-    for (int k = 0; k < 2 * NBK + 1; k++) {
-        const int idx = lane + k - NBK;
-        unsigned off;
-        if (idx < 0) off = 1024u + (unsigned)(2 + idx) * 16u;                 // left halo: floats x0-8 .. x0-1
-        else if (idx > last) off = 1024u + 32u + (unsigned)min(idx - last - 1, 1) * 16u;   // right halo
-        else off = (unsigned)idx * 16u;
-        cb[k] = (unsigned)wave * kLongRec + off;
-    }
-    const unsigned xfw = XF0 + (unsigned)wave * 1024u + (unsigned)lane * 16u;   // xf[wave][lane]
+    const unsigned own = (unsigned)wave * kLongRec + (unsigned)lane * 16u;      // this lane's block of record `wave`
+    // halo pass (one wave per plane): lane -> (row = lane / 4, block = lane % 4) of the record's 64 halo bytes
+    const unsigned hsrc = (unsigned)(lane >> 2) * kLongRec + 1024u + (unsigned)(lane & 3) * 16u;
+    // edge lanes' view of the table: lane 0 takes blocks 1 (nearest), 0; lane `last` (and everyone else) blocks 2, 3
+    const unsigned hy_near = HY0 + (unsigned)wave * 64u + (lane == 0 ? 16u : 32u);
+    const unsigned hy_far = HY0 + (unsigned)wave * 64u + (lane == 0 ? 0u : 48u);
     const unsigned ovoff = (wave < ty_act && lane < nlanes) ? (unsigned)((y0 + wave) * nx + x0 + 4 * lane) * 4u : kOOB;
+    constexpr unsigned kPlane = kLongRowsMax * kLongRec;
 
-    auto issue = [&](int i, int buf) {
-        // plane of step i into raw[buf]; beyond the last step: four no-fetch DMAs keep the vmcnt arithmetic uniform
+    auto issue = [&](int i, unsigned bufoff) {
         const bool live = i < nsteps;
-        int zsrc = live ? ztab[i] : 0;
+        int zsrc = ztab[live ? i : 0];
         zsrc = __builtin_amdgcn_readfirstlane(zsrc);
-        const u32x4_t rin = plane_rsrc(in + (size_t)zsrc * plane_elems, plane_bytes);
-        const unsigned rec0 = (unsigned)(buf * kLongRowsMax + wave) * kLongRec;
+        const u32x4_t rin = plane_rsrc(in + (size_t)zsrc * plane_elems, live ? plane_bytes : 0u);
+        dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec);
+    };
+    constexpr int kArgBase = 2 * sizeof(void *);
+    kfloats wyk = kernarg_floats(kArgBase + offsetof(LongParams, wyv));
+    kfloats wzk = SAME ? wyk : kernarg_floats(kArgBase + offsetof(LongParams, wzv));
+    kfloats xt0 = kernarg_floats(kArgBase + offsetof(LongParams, xpair));
+    kfloats xt1 = xt0 + 2 * (kStreamMaxTaps / 2 + 2);
+
+    // y pass of W consecutive records starting at LDS byte address `at`
+    auto ypass = [&](unsigned at) {
+        const float4 t0 = *reinterpret_cast<const float4 *>(smem + at);
+        F4 yv = f4_scale(wyk[0], f4_from(t0));
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const unsigned rec = rec0 + (unsigned)h * 16u * kLongRec;
-            dma_row16(rin, live ? vmain[h] : kOOB, rec);
-            dma_halo16(rin, live ? vhalo[h] : kOOB, rec + 1024u);
+        for (int k = 1; k < W; k++) {
+            const float4 t = *reinterpret_cast<const float4 *>(smem + at + k * kLongRec);
+            yv = f4_fma(wyk[k], f4_from(t), yv);
         }
+        return yv;
     };
 
     F4 acc[W];
 #pragma unroll
     for (int k = 0; k < W; k++) acc[k] = f4_splat(0.f);
 
+    // prologue: planes 0..2 in flight; plane 0 complete -> its halo table
     issue(0, 0);
-    issue(1, 1);
-    issue(2, 2);
+    issue(1, kPlane);
+    issue(2, 2 * kPlane);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    if (wave == 15) {
+        const F4 hv = ypass(hsrc);
+        *reinterpret_cast<float4 *>(smem + HY0 + (unsigned)lane * 16u) = f4_to_float4(hv);
+    }
 
-    constexpr int kArgBase = 2 * sizeof(void *);
-    kfloats wyk = kernarg_floats(kArgBase + offsetof(LongParams, wyv));
-    kfloats wzk = kernarg_floats(kArgBase + offsetof(LongParams, wzv));
-    kfloats xt0 = kernarg_floats(kArgBase + offsetof(LongParams, xpair));
-    kfloats xt1 = xt0 + 2 * (kStreamMaxTaps / 2 + 2);
-
-    int buf = 0;
+    // Interval i (after barrier i): planes i and i + 1 have landed (each wave waited for its own DMAs of plane i + 1;
+    // those of plane i + 2 may be in flight: vmcnt(4)), the halo table of plane i is complete, nobody reads plane i - 1
+    // any more: its slot takes plane i + 3.  Then y / x / z of plane i, and one wave makes the halo table of plane i + 1.
+    unsigned bi = 0;                    // LDS offset of plane i
     for (int i0 = 0; i0 < nsteps; i0 += W) {
         static_for<W>([&](auto JJ) {
             constexpr int J = decltype(JJ)::value;
             const int i = i0 + J;
             if (i < nsteps) {
-                launder(wyk); launder(wzk); launder(xt0); launder(xt1);
-                // [A] this wave's part of plane i has landed (the two younger planes = 8 DMAs may stay in flight);
-                // after the barrier everybody's has, and nobody reads xf any more
-                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-                const unsigned bufoff = (unsigned)buf * (kLongRowsMax * kLongRec);
-                // ---- x pass: raw rows wave and wave + 16 -> xf
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    f32x2 A[NP];
-#pragma unroll
-                    for (int k = 0; k < 2 * NBK + 1; k++) {
-                        const float4 t = *reinterpret_cast<const float4 *>(smem + cb[k] + bufoff + h * 16 * kLongRec);
-                        A[2 * k] = (f32x2){t.x, t.y};
-                        A[2 * k + 1] = (f32x2){t.z, t.w};
-                    }
-                    const F4 xr = xdot_tab<W, NP, BASE>(A, xt0, xt1);
-                    *reinterpret_cast<float4 *>(smem + xfw + h * 16 * 1024) = f4_to_float4(xr);
-                }
-                // [B] xf complete, raw[buf] free
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                issue(i + kLongNB, buf);
-                buf = buf == kLongNB - 1 ? 0 : buf + 1;
-                // ---- y pass: output row `wave`
-                F4 yv;
+                if constexpr (!SAME) { launder(wyk); launder(wzk); launder(xt0); launder(xt1); }
+                const unsigned b1 = bi == (kLongNB - 1) * kPlane ? 0u : bi + kPlane;     // plane i + 1
+                const unsigned b3 = bi == 0u ? (kLongNB - 1) * kPlane : bi - kPlane;     // slot of plane i - 1
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue(i + 3, b3);
+                const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
+                // ---- y pass of output row `wave`, then its x pass in registers
+                const F4 yv = ypass(own + bi);
+                float4 eL[2], eR[2];
                 {
-                    const float4 t0 = *reinterpret_cast<const float4 *>(smem + xfw);
-                    yv = f4_scale(wyk[0], f4_from(t0));
-#pragma unroll
-                    for (int k = 1; k < W; k++) {
-                        const float4 t = *reinterpret_cast<const float4 *>(smem + xfw + k * 1024);
-                        yv = f4_fma(wyk[k], f4_from(t), yv);
-                    }
+                    const float4 n = *reinterpret_cast<const float4 *>(smem + hy_near + hyoff);
+                    const float4 f = *reinterpret_cast<const float4 *>(smem + hy_far + hyoff);
+                    eL[0] = n; eL[1] = f; eR[0] = n; eR[1] = f;
                 }
+                const F4 xy = xhops<W>(f4_to_float4(yv), eL, eR, lane, last, xt0, xt1);
                 // ---- z pass: scatter into the pending outputs; output i - k takes tap k
-                acc[J] = f4_scale(wzk[0], yv);
+                acc[J] = f4_scale(wzk[0], xy);
 #pragma unroll
-                for (int k = 1; k < W; k++) acc[(J - k + W) % W] = f4_fma(wzk[k], yv, acc[(J - k + W) % W]);
+                for (int k = 1; k < W; k++) acc[(J - k + W) % W] = f4_fma(wzk[k], xy, acc[(J - k + W) % W]);
                 if (i >= W - 1) {
                     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
                         (void *)(out + (size_t)(zs + i - (W - 1)) * plane_elems), 0, (int)plane_bytes, 0x00020000);
                     __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(acc[(J + 1) % W]), rout, ovoff, 0, 2);
                 }
+                // ---- halo table of plane i + 1 (the wave changes every plane)
+                if (i + 1 < nsteps && wave == (i & 15)) {
+                    const F4 hv = ypass(hsrc + b1);
+                    *reinterpret_cast<float4 *>(smem + HY0 + (kLongHyBytes / 2 - hyoff) + (unsigned)lane * 16u) = f4_to_float4(hv);
+                }
+                bi = b1;
             }
         });
     }
-    // the no-fetch DMAs of the last steps are still counted: drain before the LDS allocation goes away
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int W, bool SAME>
+static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s)
+{
+    const size_t lds = (size_t)kLongRawBytes + kLongHyBytes + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI_HIP(hipFuncSetAttribute((const void *)sep3d_long_kernel<W, SAME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int total = p.nxt * p.nyt * p.nzc;
+    hipLaunchKernelGGL((sep3d_long_kernel<W, SAME>), dim3(total), dim3(kLongTY * 64), lds, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
 }
 
 static int long_cus()
@@ -245,27 +328,14 @@ static int long_cus()
     return cus;
 }
 
-template <int W>
-static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s)
-{
-    const size_t lds = (size_t)kLongRawBytes + kLongXfBytes + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int);
-    static bool attr_done = false;
-    if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)sep3d_long_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    const int total = p.nxt * p.nyt * p.nzc;
-    hipLaunchKernelGGL((sep3d_long_kernel<W>), dim3(total), dim3(kLongTY * 64), lds, s, in, out, p);
-    MI_HIP(hipGetLastError());
-    return MI_OK;
-}
-
 static int g_long_zchunks = 0;     // test hook: number of z chunks (0 = cost model)
+static int g_long_same = 1;        // test hook: 0 = always the reloading variant
 
 // Fused long-kernel path: cubic odd W in 11..17 (9 behind the test hook), origins on y / z allowed, no constant mode.
 // Returns MI_ERR_UNSUPPORTED when the request is outside that (the caller runs the streaming passes).
 int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, const float *wx, const float *wy,
-                   const float *wz, int oy, int oz, int mx, int my, int mz, hipStream_t s)
+                   const float *wz, int oy, int oz, int mx, int my, int mz, const int64_t zb[2], const int64_t zn[2],
+                   hipStream_t s)
 {
     if (w < 3 || w > 17 || !(w & 1)) return MI_ERR_UNSUPPORTED;
     if (mx == MI_MODE_CONSTANT || my == MI_MODE_CONSTANT || mz == MI_MODE_CONSTANT) return MI_ERR_UNSUPPORTED;
@@ -292,30 +362,34 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
     // z chunks: rounds of (columns x chunks) workgroups over the CUs, each costing chunk + ramp plane steps
     const int ncu = long_cus();
     const int cols = p.nxt * p.nyt;
+    const int nzr = (int)(zn[0] + zn[1]);                 // planes to produce
     int best_nzc = 1;
     double best = 1e300;
-    for (int nzc = 1; nzc <= nz && nzc <= 256; nzc++) {
-        const int chunk = (nz + nzc - 1) / nzc;
+    for (int nzc = 1; nzc <= nzr && nzc <= 256; nzc++) {
+        const int chunk = (nzr + nzc - 1) / nzc;
         if (chunk > kLongMaxChunk) continue;
-        const int real = (nz + chunk - 1) / chunk;
+        const int real = (nzr + chunk - 1) / chunk;
         const double rounds = (double)(((int64_t)cols * real + ncu - 1) / ncu);
         const double cost = rounds * (chunk + w - 1 + 3);
         if (cost < best) { best = cost; best_nzc = real; }
     }
-    if (g_long_zchunks > 0) best_nzc = std::min(g_long_zchunks, nz);
-    p.zc = (nz + best_nzc - 1) / best_nzc;
+    if (g_long_zchunks > 0) best_nzc = std::min(g_long_zchunks, nzr);
+    p.zc = (nzr + best_nzc - 1) / best_nzc;
     if (p.zc > kLongMaxChunk) p.zc = kLongMaxChunk;
-    p.nzc = (nz + p.zc - 1) / p.zc;
+    p.zb0 = (int)zb[0]; p.zn0 = (int)zn[0]; p.zb1 = (int)zb[1]; p.zn1 = (int)zn[1];
+    p.nzc0 = (int)((zn[0] + p.zc - 1) / p.zc);
+    p.nzc = p.nzc0 + (int)((zn[1] + p.zc - 1) / p.zc);
+    bool same = g_long_same != 0;
+    for (int k = 0; k < w; k++) same = same && wx[k] == wy[k] && wy[k] == wz[k];
+#define MI_LONG_CASE(N) case N: return same ? launch_long<N, true>(in, out, p, s) : launch_long<N, false>(in, out, p, s);
     switch (w) {
-    case 9: return launch_long<9>(in, out, p, s);
-    case 11: return launch_long<11>(in, out, p, s);
-    case 13: return launch_long<13>(in, out, p, s);
-    case 15: return launch_long<15>(in, out, p, s);
-    case 17: return launch_long<17>(in, out, p, s);
+        MI_LONG_CASE(3) MI_LONG_CASE(5) MI_LONG_CASE(7) MI_LONG_CASE(9) MI_LONG_CASE(11) MI_LONG_CASE(13) MI_LONG_CASE(15) MI_LONG_CASE(17)
     }
+#undef MI_LONG_CASE
     return MI_ERR_UNSUPPORTED;
 }
 
 }  // namespace mi
 
 extern "C" int mi_debug_set_long_zchunks(int n) { mi::g_long_zchunks = n; return MI_OK; }
+extern "C" int mi_debug_set_long_same(int n) { mi::g_long_same = n; return MI_OK; }

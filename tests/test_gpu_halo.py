@@ -21,6 +21,7 @@ def ndi(gpu):
 
 
 @pytest.mark.parametrize("size,mode", [(3, "reflect"), (5, "reflect"), (5, "constant"), (7, "mirror"), (9, "nearest"),
+                                       (9, "constant"), (13, "wrap"), (17, "reflect"),
                                        ((3, 5, 7), "wrap"), ((1, 5, 3), "reflect")])
 def test_plane_restricted_launches_tile_the_full_result(gpu, ndi, size, mode):
     from cupyimg_amd.scipy.ndimage import _support as S
@@ -144,11 +145,11 @@ def test_native_slab_step_matches_plain_step(gpu, ndi, self_comm, nz):
     plain = sf.step(lambda a, b: ndi.gaussian_filter(a, 0.5, mode="reflect", output=b)).get()
     got = sf.gaussian_filter(0.5, mode="reflect").get()
     assert np.array_equal(got, plain)
-    # 13 taps: the fused kernel takes no plane ranges -> plain schedule, same numbers
+    # 13 taps: the long fused kernel, with plane ranges as well
     if nz >= 6:
         sf2 = SlabFilter(_SelfLoopPlan(nz, 6, 6), x.shape[1:], np.float32, self_comm)
         sf2.local_in[...] = gpu.asarray(x)
-        for overlap in (None, True):      # native plain schedule / Python fallback after UNSUPPORTED
+        for overlap in (None, True):      # plain / overlapped native schedule
             got = sf2.uniform_filter(13, mode="mirror", overlap=overlap).get()
             assert maxnorm_rel(got, orc.uniform_filter(x, 13, mode=["wrap", "mirror", "mirror"])) <= 1e-6
 
@@ -178,7 +179,10 @@ def test_slab_step_refuses_kernels_wider_than_the_halo(gpu, ndi, self_comm):
     assert rc == _lib.MI_ERR_INVALID_ARG and "halo" in _lib.last_error()
 
 
-def test_overlapped_step_falls_back_for_long_kernels(gpu, ndi, self_comm):
+def test_overlapped_step_with_long_kernels(gpu, ndi, self_comm):
+    """13 taps: the fused long kernel (sep3d_long.hip) takes plane ranges, so the overlapped schedule runs and is
+    bit-identical to the plain one; in `constant` mode the streaming passes serve the request, they take no plane
+    ranges and the step falls back to the plain schedule."""
     from cupyimg_amd.distributed import SlabFilter, halo_widths
     rng = np.random.default_rng(14)
     nz, size = 40, 13
@@ -187,9 +191,16 @@ def test_overlapped_step_falls_back_for_long_kernels(gpu, ndi, self_comm):
     sf = SlabFilter(_SelfLoopPlan(nz, lo, hi), x.shape[1:], np.float32, self_comm)
     sf.local_in[...] = gpu.asarray(x)
     fn = lambda a, b: ndi.uniform_filter(a, size=size, mode="nearest", output=b)   # noqa: E731
+    plain = sf.step(fn).get()
     got = sf.step_overlapped(fn).get()
-    assert not sf._overlap_ok
+    assert sf._overlap_ok
+    assert np.array_equal(got, plain)
     ref = orc.uniform_filter(x, size, mode=["wrap", "nearest", "nearest"])
+    assert maxnorm_rel(got, ref) <= 1e-6
+    fc = lambda a, b: ndi.uniform_filter(a, size=size, mode=["wrap", "constant", "constant"], cval=0.5, output=b)   # noqa: E731
+    got = sf.step_overlapped(fc).get()
+    assert not sf._overlap_ok
+    ref = orc.uniform_filter(x, size, mode=["wrap", "constant", "constant"], cval=0.5)
     assert maxnorm_rel(got, ref) <= 1e-6
 
 

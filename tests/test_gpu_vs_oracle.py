@@ -1064,3 +1064,42 @@ def test_streaming_passes_on_many_workgroups(gpu, ndi):
             assert np.abs(ndi.gaussian_filter(vd, sigma).get() - want).max() <= 2e-6 * np.abs(want).max(), (shape, sigma)
         want = sndi.uniform_filter(v, size=(3, 5, 7))
         assert np.abs(ndi.uniform_filter(vd, size=(3, 5, 7)).get() - want).max() <= 2e-6 * np.abs(want).max()
+
+
+def test_fused_long_kernel_against_scipy(gpu, ndi):
+    """sep3d_long.hip (cubic 11..17 taps in ONE launch: LDS-DMA staging, x / y passes out of LDS, z as a register
+    scatter): every index-mapping mode, partial tiles in x and y, several z chunks, origins on y / z; the streaming
+    passes (constant mode, hook) must agree with it."""
+    import ctypes
+    import scipy.ndimage as sndi
+    from cupyimg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    for shape in [(40, 48, 256), (33, 21, 260), (70, 100, 512), (20, 16, 64), (9, 9, 16), (5, 70, 300), (130, 40, 252)]:
+        v = rng.standard_normal(shape).astype(np.float32)
+        vd = gpu.asarray(v)
+        for mode in ["reflect", "mirror", "nearest", "wrap"]:
+            for size in (11, 17):
+                want = sndi.uniform_filter(v.astype(np.float64), size, mode=mode)
+                got = ndi.uniform_filter(vd, size, mode=mode).get()
+                assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max(), (shape, mode, size)
+            want = sndi.gaussian_filter(v.astype(np.float64), 1.6, mode=mode)      # 13 taps
+            got = ndi.gaussian_filter(vd, 1.6, mode=mode).get()
+            assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max(), (shape, mode)
+        want = sndi.uniform_filter(v.astype(np.float64), 15, mode="reflect", origin=(3, -6, 0))
+        got = ndi.uniform_filter(vd, 15, mode="reflect", origin=(3, -6, 0)).get()
+        assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max(), shape
+        # forced z chunking (ramp planes at every chunk start) and the two-launch streaming route
+        fused = ndi.gaussian_filter(vd, 2.0).get()
+        for nch in (1, 3):
+            lib.mi_debug_set_long_zchunks(nch)
+            try:
+                assert np.array_equal(ndi.gaussian_filter(vd, 2.0).get(), fused), (shape, nch)
+            finally:
+                lib.mi_debug_set_long_zchunks(0)
+        lib.mi_debug_set_sep3d_long(1)
+        try:
+            streamed = ndi.gaussian_filter(vd, 2.0).get()
+        finally:
+            lib.mi_debug_set_sep3d_long(0)
+        assert np.abs(streamed - fused).max() <= 1e-6 * np.abs(fused).max(), shape
