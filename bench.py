@@ -42,13 +42,13 @@ def synth(shape, seed=0):
 
 def measured_traffic(world):
     """HBM bytes per launch from the rocprofv3 PMC passes of this same command
-    (profiles/r1_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction
+    (profiles/r2_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction
     applied).  Counters cannot be read from inside the process, so this is the
     committed measurement, valid for the single-GPU workload only."""
     if world != 1:
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
             return json.load(f)["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None

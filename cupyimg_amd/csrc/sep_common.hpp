@@ -21,6 +21,7 @@ struct Sep3dParams {
     int zb0, zn0, zb1, zn1, nzc0;
     float wx[kMaxTaps], wyv[kMaxTaps], wz[kMaxTaps];
     int dbg;                // tuning ablations (0 in production): 1 no x/z math, 2 no stores, 4 no loads, 8 no y math
+    int zrev;               // lean kernel: odd z chunks stream DOWNWARDS (see sep3d_lean_kernel)
 };
 
 __device__ __forceinline__ void chunk_planes(const Sep3dParams &p, int zci, int *zs, int *ze)

@@ -407,10 +407,16 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
     // offsets stay 32-bit inside a plane, the volume itself may exceed 4 GiB
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
     const size_t plane_elems = (size_t)ny * (size_t)nx;
-    const int zi0 = zs - p.oz;
     const int nsteps = ze - zs + W - 1;
+    // Every other z chunk streams DOWNWARDS.  Neighbouring chunks re-read each other's W - 1 ramp planes; with
+    // alternating directions the two chunks that share a boundary are both there at the same time (both start or
+    // both end at it), so the second read is served by the L2 / the memory-side cache instead of HBM again.  The
+    // z taps are still accumulated in ascending tap order (see `rev` below): results do not depend on the direction.
+    const bool rev = p.zrev && (((zci >= p.nzc0 ? zci - p.nzc0 : zci) & 1) != 0);
+    const int zi0 = rev ? ze - 1 - p.oz + (W - 1) : zs - p.oz;      // input plane of step 0
+    const int zdir = rev ? -1 : 1;
 
-    for (int i = threadIdx.x; i < nsteps; i += (NWP + NWC) * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
+    for (int i = threadIdx.x; i < nsteps; i += (NWP + NWC) * 64) ztab[i] = bmap<int>(zi0 + zdir * i, nz, p.mz);
     __syncthreads();
 
     if (wave < NWP) {
@@ -458,7 +464,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
         struct Regs { F4 v[R]; float t[NE]; bool zconst; };
         Regs S[DEPTH];
         auto issue = [&](int i, Regs &s) {
-            int zsrc = zi0 + i;
+            int zsrc = zi0 + zdir * i;
             if ((unsigned)zsrc >= (unsigned)nz) zsrc = ztab[i];
             s.zconst = zsrc < 0;
             zsrc = __builtin_amdgcn_readfirstlane(max(zsrc, 0));
@@ -518,10 +524,17 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
                             const F4 xr = xpass_packed<W, NE>(v, sL, sR, lane, last, p.wx);
                             if (r == R - 1 && i + DEPTH < nsteps) issue(i + DEPTH, s);
                             if (emit) {
-                                F4 a = f4_scale(p.wz[0], ring[J % RINGN][r]);
+                                F4 a;
+                                if (rev) {      // the newest plane is the lowest: tap 0 first, the ring newest to oldest
+                                    a = f4_scale(p.wz[0], xr);
 #pragma unroll
-                                for (int k = 1; k < RINGN; k++) a = f4_fma(p.wz[k], ring[(J + k) % RINGN][r], a);
-                                a = f4_fma(p.wz[W - 1], xr, a);
+                                    for (int k = 1; k < W; k++) a = f4_fma(p.wz[k], ring[(J + RINGN - k) % RINGN][r], a);
+                                } else {
+                                    a = f4_scale(p.wz[0], ring[J % RINGN][r]);
+#pragma unroll
+                                    for (int k = 1; k < RINGN; k++) a = f4_fma(p.wz[k], ring[(J + k) % RINGN][r], a);
+                                    a = f4_fma(p.wz[W - 1], xr, a);
+                                }
                                 if constexpr (HAS_CONST)
                                     if (yconst[r]) a = f4_splat(p.cval);
                                 wbuf[r * 64] = f4_to_float4(a);
@@ -550,10 +563,17 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
                     if (emit) {
 #pragma unroll
                         for (int r = 0; r < R; r++) {
-                            F4 a = f4_scale(p.wz[0], ring[J % RINGN][r]);
+                            F4 a;
+                            if (rev) {          // the newest plane is the lowest: tap 0 first, the ring newest to oldest
+                                a = f4_scale(p.wz[0], xf[r]);
 #pragma unroll
-                            for (int k = 1; k < RINGN; k++) a = f4_fma(p.wz[k], ring[(J + k) % RINGN][r], a);
-                            a = f4_fma(p.wz[W - 1], xf[r], a);
+                                for (int k = 1; k < W; k++) a = f4_fma(p.wz[k], ring[(J + RINGN - k) % RINGN][r], a);
+                            } else {
+                                a = f4_scale(p.wz[0], ring[J % RINGN][r]);
+#pragma unroll
+                                for (int k = 1; k < RINGN; k++) a = f4_fma(p.wz[k], ring[(J + k) % RINGN][r], a);
+                                a = f4_fma(p.wz[W - 1], xf[r], a);
+                            }
                             if constexpr (HAS_CONST)
                                 if (yconst[r]) a = f4_splat(p.cval);
                             wbuf[r * 64] = f4_to_float4(a);
@@ -576,8 +596,9 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
         for (int i = 0; i < nsteps; i++) {
             __syncthreads();
             if (i < W - 1) continue;
+            const int zo = rev ? ze - 1 - (i - (W - 1)) : zs + i - (W - 1);
             const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(out + (size_t)(zs + i - (W - 1)) * plane_elems), 0, (int)plane_bytes, 0x00020000);
+                (void *)(out + (size_t)zo * plane_elems), 0, (int)plane_bytes, 0x00020000);
             const float4 *rbuf = lds + (i & 1) * (LROWS * 64) + j0 * 64 + lane;
             F4 win[G + W - 1];
 #pragma unroll
@@ -735,6 +756,8 @@ static int g_sep3d_cfg = 0;       // tile shape variant
 static int g_sep3d_zchunks = 0;   // 0 = heuristic
 static int g_sep3d_dbg = 0;       // ablation flags
 static int g_sep3d_kernel = 0;    // 0 = auto, 1 = force general (ws) kernel
+static int g_sep3d_zrev = 1;      // 1 = odd z chunks of the lean kernel stream downwards (ramp planes shared in time)
+extern "C" int mi_debug_set_sep3d_zrev(int k) { g_sep3d_zrev = k; return MI_OK; }
 static int g_sep3d_long = 0;      // 0 = auto (cubic 9..17 taps), 1 = off (lean kernel / streaming passes), 2 = also for 3..7 taps
 extern "C" int mi_debug_set_sep3d_long(int k) { g_sep3d_long = k; return MI_OK; }
 extern "C" int mi_debug_set_sep3d_cfg(int cfg) { g_sep3d_cfg = cfg; return MI_OK; }
@@ -865,6 +888,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     p.oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
     p.cval = (float)cval;
     p.dbg = g_sep3d_dbg;
+    p.zrev = g_sep3d_zrev;
 
     const int cfg = g_sep3d_cfg;
     const bool cubic = w[0] == w[1] && w[1] == w[2] && w[0] >= 3 && p.oz == w[0] / 2 && p.oy == w[1] / 2;

@@ -13,6 +13,7 @@ lib = _lib.load()
 lib.mi_debug_set_sep3d_cfg(int(os.environ.get("CFG", "0")))
 lib.mi_debug_set_sep3d_zchunks(int(os.environ.get("ZCH", "0")))
 lib.mi_debug_set_sep3d_long(int(os.environ.get("LONG", "0")))
+lib.mi_debug_set_sep3d_zrev(int(os.environ.get("ZREV", "1")))
 lib.mi_debug_set_long_zchunks(int(os.environ.get("LZCH", "0")))
 x = np.random.default_rng(0).standard_normal((n, n, n), dtype=np.float32)
 xd = ca.asarray(x)
