@@ -51,7 +51,8 @@ struct LongParams {
     // output planes to produce: up to two plane ranges [zb, zb + zn), the first covered by chunks 0 .. nzc0-1, the
     // second by the rest (whole volume: zb0 = 0, zn0 = nz, nzc0 = nzc).  Boundary handling always refers to nz.
     int zb0, zn0, zb1, zn1, nzc0;
-    float wyv[kStreamMaxTaps], wzv[kStreamMaxTaps];
+    // y / z weights, each one TWICE (an aligned SGPR pair is what v_pk_fma_f32 takes: no s_mov per odd tap)
+    float wyv[2 * kStreamMaxTaps], wzv[2 * kStreamMaxTaps];
     float xpair[2][2 * (kStreamMaxTaps / 2 + 2)];   // see StreamParams::xpair
 };
 
@@ -83,17 +84,6 @@ __device__ __forceinline__ void dma_two_rows(u32x4_t rsrc, unsigned va, unsigned
         : "=&s"(keep)
         : "v"(va), "v"(vha), "v"(vb), "v"(vhb), "s"(rsrc), "s"(rec), "n"(16 * kLongRec - 1024)
         : "memory", "scc");
-}
-
-__device__ __forceinline__ u32x4_t plane_rsrc(const float *base, unsigned bytes)
-{
-    const unsigned long long a = (unsigned long long)base;
-    u32x4_t r;
-    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-    r.z = bytes;
-    r.w = 0x00020000u;
-    return r;
 }
 
 // SAME: the three axes share one weight vector (uniform_filter(size=W), isotropic gaussian_filter): x pair tables
@@ -190,7 +180,6 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     const int last = nlanes - 1;
     const int xe = x0 + 4 * nlanes;
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
-    const size_t plane_elems = (size_t)ny * (size_t)nx;
     const int zi0 = zs - p.oz;
     const int nsteps = ze - zs + W - 1;
 
@@ -218,10 +207,19 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     constexpr unsigned kPlane = kLongRowsMax * kLongRec;
 
     auto issue = [&](int i, unsigned bufoff) {
+        // plane of step i; beyond the last step the descriptor has zero records (no fetch), so that every step
+        // issues the same four DMAs and the vmcnt arithmetic stays uniform.  Scalar work is kept short here: the
+        // sixteen waves of the workgroup share ONE scalar unit (the empty loop -- barrier, address arithmetic and
+        // DMA issue only -- cost 0.47 us per plane in the first version).
         const bool live = i < nsteps;
-        int zsrc = ztab[live ? i : 0];
-        zsrc = __builtin_amdgcn_readfirstlane(zsrc);
-        const u32x4_t rin = plane_rsrc(in + (size_t)zsrc * plane_elems, live ? plane_bytes : 0u);
+        int zsrc = zi0 + i;
+        if ((unsigned)zsrc >= (unsigned)nz) zsrc = __builtin_amdgcn_readfirstlane(ztab[live ? i : 0]);   // boundary planes only
+        const unsigned long long a = (unsigned long long)in + (unsigned long long)(unsigned)zsrc * (unsigned long long)plane_bytes;
+        u32x4_t rin;
+        rin.x = (unsigned)a;
+        rin.y = (unsigned)(a >> 32);       // stride 0: the upper 16 bits of a device address are zero
+        rin.z = live ? plane_bytes : 0u;
+        rin.w = 0x00020000u;
         dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec);
     };
     constexpr int kArgBase = 2 * sizeof(void *);
@@ -233,11 +231,11 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     // y pass of W consecutive records starting at LDS byte address `at`
     auto ypass = [&](unsigned at) {
         const float4 t0 = *reinterpret_cast<const float4 *>(smem + at);
-        F4 yv = f4_scale(wyk[0], f4_from(t0));
+        F4 yv = f4_scale2((f32x2){wyk[0], wyk[1]}, f4_from(t0));
 #pragma unroll
         for (int k = 1; k < W; k++) {
             const float4 t = *reinterpret_cast<const float4 *>(smem + at + k * kLongRec);
-            yv = f4_fma(wyk[k], f4_from(t), yv);
+            yv = f4_fma2((f32x2){wyk[2 * k], wyk[2 * k + 1]}, f4_from(t), yv);
         }
         return yv;
     };
@@ -281,12 +279,14 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
                 }
                 const F4 xy = xhops<W>(f4_to_float4(yv), eL, eR, lane, last, xt0, xt1);
                 // ---- z pass: scatter into the pending outputs; output i - k takes tap k
-                acc[J] = f4_scale(wzk[0], xy);
+                acc[J] = f4_scale2((f32x2){wzk[0], wzk[1]}, xy);
 #pragma unroll
-                for (int k = 1; k < W; k++) acc[(J - k + W) % W] = f4_fma(wzk[k], xy, acc[(J - k + W) % W]);
+                for (int k = 1; k < W; k++)
+                    acc[(J - k + W) % W] = f4_fma2((f32x2){wzk[2 * k], wzk[2 * k + 1]}, xy, acc[(J - k + W) % W]);
                 if (i >= W - 1) {
-                    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-                        (void *)(out + (size_t)(zs + i - (W - 1)) * plane_elems), 0, (int)plane_bytes, 0x00020000);
+                    const unsigned long long oa = (unsigned long long)out +
+                                                  (unsigned long long)(unsigned)(zs + i - (W - 1)) * (unsigned long long)plane_bytes;
+                    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)oa, 0, (int)plane_bytes, 0x00020000);
                     __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(acc[(J + 1) % W]), rout, ovoff, 0, 2);
                 }
                 // ---- halo table of plane i + 1 (the wave changes every plane)
@@ -347,7 +347,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
     p.mx = mx; p.my = my; p.mz = mz;
     p.nxt = (nx + 255) / 256;
     p.nyt = (ny + kLongTY - 1) / kLongTY;
-    for (int k = 0; k < w; k++) { p.wyv[k] = wy[k]; p.wzv[k] = wz[k]; }
+    for (int k = 0; k < w; k++) { p.wyv[2 * k] = p.wyv[2 * k + 1] = wy[k]; p.wzv[2 * k] = p.wzv[2 * k + 1] = wz[k]; }
     {
         const int rx = w / 2, nb = (rx + 3) / 4, base = 4 * nb - rx;
         for (int q = 0; q < 2; q++) {

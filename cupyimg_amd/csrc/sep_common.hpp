@@ -141,6 +141,16 @@ __device__ __forceinline__ F4 f4_fma(float w, F4 q, F4 a)
     return r;
 }
 
+// the same with the weight given as an (w, w) pair, e.g. an aligned SGPR pair loaded from a table of doubled weights
+__device__ __forceinline__ F4 f4_scale2(f32x2 w, F4 a) { F4 r; r.lo = w * a.lo; r.hi = w * a.hi; return r; }
+__device__ __forceinline__ F4 f4_fma2(f32x2 w, F4 q, F4 a)
+{
+    F4 r;
+    r.lo = fma2(w, q.lo, a.lo);
+    r.hi = fma2(w, q.hi, a.hi);
+    return r;
+}
+
 // x pass over a register window in "dot" form: the window is held as aligned
 // pairs A[m] = (win[2m], win[2m+1]) and output c = sum_j wx[j] * win[BASE+c+j]
 // is accumulated as a 2-vector sum_m (wx[2m-BASE-c], wx[2m+1-BASE-c]) * A[m]
