@@ -616,6 +616,288 @@ mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
     }
 }
 
+// ---------------------------------------------------------------------------
+// r2: the same producer / consumer tile with the voxels kept "even/odd split" (two u16 per register) from the load
+// to the store.  The kernel above keeps its z history and its LDS tile PACKED (bytes) to save registers, and pays
+// for it: every step re-splits the history and the tile and re-joins the results, its x window works on seven-dword
+// windows, its y window reduces seven rows per output -- 0.29 VALU instructions per voxel where the three 7-wide
+// windows themselves need about 0.08.  Here a lane holds 8 voxels (512-voxel tiles), so the split z history of a
+// row is 24 registers and three rows per producer wave fit; the windows are built in two 3-input stages that share
+// their first stage between neighbouring outputs:
+//     t[i] = op3(v[i], v[i+1], v[i+2]);   out[p] = op3(t[p-3], t[p-1], t[p+1])   (W = 7)
+// along x (shifts by v_alignbit on the split registers), along z (register history) and along y (consumers, rows in
+// LDS in split form: 16 bytes per lane and row = (E0, O0, E1, O1)); bytes are joined once, at the store.
+// ---------------------------------------------------------------------------
+struct Split8 { unsigned e0, o0, e1, o1; };      // 8 voxels: dword 0 = (e0, o0), dword 1 = (e1, o1)
+
+template <bool IS_MAX>
+__device__ __forceinline__ Split8 op3s(const Split8 &a, const Split8 &b, const Split8 &c)
+{
+    return {op3<IS_MAX>(a.e0, b.e0, c.e0), op3<IS_MAX>(a.o0, b.o0, c.o0), op3<IS_MAX>(a.e1, b.e1, c.e1), op3<IS_MAX>(a.o1, b.o1, c.o1)};
+}
+template <bool IS_MAX>
+__device__ __forceinline__ Split8 op2s(const Split8 &a, const Split8 &b)
+{
+    return {op2<IS_MAX>(a.e0, b.e0), op2<IS_MAX>(a.o0, b.o0), op2<IS_MAX>(a.e1, b.e1), op2<IS_MAX>(a.o1, b.o1)};
+}
+
+// x window of width W over [left dword | own 2 dwords | right dword] (raw bytes), result for the own 8 voxels
+template <int W, bool IS_MAX>
+__device__ __forceinline__ Split8 xwin_split(unsigned l, unsigned v0, unsigned v1, unsigned rg)
+{
+    unsigned E[4], O[4];
+    split(l, E[0], O[0]); split(v0, E[1], O[1]); split(v1, E[2], O[2]); split(rg, E[3], O[3]);
+    if constexpr (W == 1) return {E[1], O[1], E[2], O[2]};
+    // stage 1: t[i] = op3(x[i], x[i+1], x[i+2]);  tE[k] = (t[4k], t[4k+2]),  tO[k] = (t[4k+1], t[4k+3])
+    unsigned AE[4], AO[3], tE[4], tO[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { AE[k] = align16(E[k + 1], E[k]); AO[k] = align16(O[k + 1], O[k]); }
+    AE[3] = E[3] >> 16;
+#pragma unroll
+    for (int k = 0; k < 4; k++) tE[k] = op3<IS_MAX>(E[k], O[k], AE[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) tO[k] = op3<IS_MAX>(O[k], AE[k], AO[k]);
+    Split8 r;
+    unsigned *re[2] = {&r.e0, &r.e1}, *ro[2] = {&r.o0, &r.o1};
+#pragma unroll
+    for (int k = 1; k <= 2; k++) {
+        if constexpr (W == 3) {            // out[p] = t[p-1]
+            *re[k - 1] = align16(tO[k], tO[k - 1]);
+            *ro[k - 1] = tE[k];
+        } else if constexpr (W == 5) {     // out[p] = op2(t[p-2], t[p])
+            *re[k - 1] = op2<IS_MAX>(align16(tE[k], tE[k - 1]), tE[k]);
+            *ro[k - 1] = op2<IS_MAX>(align16(tO[k], tO[k - 1]), tO[k]);
+        } else {                           // W == 7: out[p] = op3(t[p-3], t[p-1], t[p+1])
+            *re[k - 1] = op3<IS_MAX>(tO[k - 1], align16(tO[k], tO[k - 1]), tO[k]);
+            *ro[k - 1] = op3<IS_MAX>(align16(tE[k], tE[k - 1]), tE[k], align16(tE[k + 1], tE[k]));
+        }
+    }
+    return r;
+}
+
+template <int W, bool IS_MAX, int NWP, int NWC, int R, int TY, bool HAS_CONST>
+__global__ void __launch_bounds__((NWP + NWC) * 64)
+mm3u8_split_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8FusedParams p)
+{
+    constexpr int ROWS = TY + W - 1;                                     // rows staged per plane
+    constexpr int G = (TY + NWC - 1) / NWC;                              // output rows per consumer wave
+    constexpr int LROWS = (NWC * G + W - 1) > NWP * R ? (NWC * G + W - 1) : NWP * R;
+    constexpr int RX = W / 2;
+    static_assert((W == 3 || W == 5 || W == 7) && ROWS <= NWP * R && R <= 16, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4 *lds = reinterpret_cast<u32x4 *>(smem);                         // [2][LROWS][64] x (E0, O0, E1, O1)
+    int *ztab = reinterpret_cast<int *>(smem + (size_t)2 * LROWS * 1024);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int b = blockIdx.x;
+    const int total = p.nxt * p.nyt * p.nzc;
+    if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
+    const int per_chunk = p.nxt * p.nyt;
+    const int zci = b / per_chunk;
+    const int rem = b - zci * per_chunk;
+    const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
+
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int x0 = xt * 512, y0 = yt * TY, zs = zci * p.zc;
+    const int ze = min(zs + p.zc, nz);
+    const int ty_act = min(TY, ny - y0);
+    const int rows_needed = ty_act + W - 1;
+    const int nlanes = min(64, (nx - x0) >> 3);
+    const int last = nlanes - 1;
+    const unsigned plane_bytes = (unsigned)ny * (unsigned)nx;
+    const int zi0 = zs - RX;
+    const int nsteps = ze - zs + W - 1;
+
+    for (int i = threadIdx.x; i < nsteps; i += (NWP + NWC) * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
+    __syncthreads();
+
+    if (wave < NWP) {
+        // ------------------------------------------------------------ producer
+        int es0, ek0, es1, ek1;
+        edge_u8(0, x0, x0 + 8 * nlanes, nx, p.mx, &es0, &ek0);
+        edge_u8(1, x0, x0 + 8 * nlanes, nx, p.mx, &es1, &ek1);
+        const bool left_side = lane < 32;
+        const int erow = left_side ? lane : lane - 32;       // row this lane fetches the edge dword of
+        const int ekind = left_side ? ek0 : ek1;
+        const int estart = left_side ? es0 : es1;
+        unsigned voff[R];
+        unsigned eoffv = kOOB;
+        bool yconst[R];
+        bool e_is_cval = ekind == EDGE_CONST;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int rr = wave * R + r;
+            const int ys = rr < rows_needed ? bmap<int>(y0 - RX + rr, ny, p.my) : -2;
+            yconst[r] = ys == -1;
+            voff[r] = (ys >= 0 && lane < nlanes) ? (unsigned)(ys * nx + x0 + 8 * lane) : kOOB;
+            if (erow == r) {
+                if (ys >= 0 && ekind != EDGE_CONST) eoffv = (unsigned)(ys * nx + estart);
+                if (ys == -1) e_is_cval = true;
+            }
+        }
+
+        struct Regs { u32x2 v[R]; unsigned e; bool zconst; };
+        Regs S[2];
+        auto issue = [&](int i, Regs &s) {
+            int zsrc = zi0 + i;
+            if ((unsigned)zsrc >= (unsigned)nz) zsrc = ztab[i];
+            s.zconst = zsrc < 0;
+            zsrc = __builtin_amdgcn_readfirstlane(max(zsrc, 0));
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(in + (unsigned long long)(unsigned)zsrc * (unsigned long long)plane_bytes), 0, (int)plane_bytes, 0x00020000);
+            const bool skip = HAS_CONST && s.zconst;
+#pragma unroll
+            for (int r = 0; r < R; r++) s.v[r] = __builtin_amdgcn_raw_buffer_load_b64(rin, skip ? kOOB : voff[r], 0, 0);
+            s.e = __builtin_amdgcn_raw_buffer_load_b32(rin, skip ? kOOB : eoffv, 0, 0);
+        };
+
+        // z window: t3[t] = op3(x[t], x[t-1], x[t-2]); W = 7: out = op3(t3[t], t3[t-2], t3[t-4]); W = 5: op2(t3[t], t3[t-2])
+        constexpr int NT = W == 7 ? 4 : (W == 5 ? 2 : 0);
+        constexpr int U = NT > 2 ? NT : 2;                    // steps per unrolled round (history slots are compile-time)
+        Split8 hx[2][R], ht[NT > 0 ? NT : 1][R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            hx[0][r] = hx[1][r] = Split8{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < (NT > 0 ? NT : 1); k++) ht[k][r] = Split8{0u, 0u, 0u, 0u};
+        }
+
+        issue(0, S[0]);
+        if (nsteps > 1) issue(1, S[1]);
+        for (int i0 = 0; i0 < nsteps; i0 += U) {
+            static_for<U>([&](auto JJ) {
+                constexpr int J = decltype(JJ)::value;
+                const int i = i0 + J;
+                if (i < nsteps) {
+                    Regs &s = S[J & 1];
+                    const bool emit = i >= W - 1;
+                    u32x4 *wbuf = lds + (J & 1) * (LROWS * 64) + (wave * R) * 64 + lane;
+                    unsigned ed = s.e;
+                    if (ekind == EDGE_REV) ed = bswap32(ed);
+                    else if (ekind == EDGE_SPLAT) ed = (left_side ? (ed & 0xFFu) : (ed >> 24)) * 0x01010101u;
+                    if constexpr (HAS_CONST) ed = (e_is_cval || s.zconst) ? p.cval4 : ed;
+                    Split8 xf[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        u32x2 v = s.v[r];
+                        if constexpr (HAS_CONST)
+                            if (yconst[r] || s.zconst) v = (u32x2){p.cval4, p.cval4};
+                        const unsigned sL = (unsigned)__builtin_amdgcn_readlane((int)ed, r);
+                        const unsigned sR = (unsigned)__builtin_amdgcn_readlane((int)ed, 32 + r);
+                        const unsigned l = (unsigned)__builtin_amdgcn_update_dpp((int)sL, (int)v.y, 0x138, 0xf, 0xf, false);
+                        unsigned rg = (unsigned)__builtin_amdgcn_update_dpp((int)sR, (int)v.x, 0x130, 0xf, 0xf, false);
+                        if (lane == last) rg = sR;
+                        xf[r] = xwin_split<W, IS_MAX>(l, v.x, v.y, rg);
+                    }
+                    if (i + 2 < nsteps) issue(i + 2, s);                  // all rows' registers are consumed
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const Split8 t3 = op3s<IS_MAX>(xf[r], hx[(J + 1) % 2][r], hx[J % 2][r]);     // planes t, t-1, t-2
+                        Split8 o = t3;
+                        if constexpr (W == 5) o = op2s<IS_MAX>(t3, ht[J % NT][r]);                           // t3[t-2]
+                        else if constexpr (W == 7) o = op3s<IS_MAX>(t3, ht[(J + 2) % NT][r], ht[J % NT][r]);   // t3[t-2], t3[t-4]
+                        if (emit) {
+                            if constexpr (HAS_CONST)
+                                if (yconst[r]) {
+                                    unsigned ce, co;
+                                    split(p.cval4, ce, co);
+                                    o = Split8{ce, co, ce, co};
+                                }
+                            wbuf[r * 64] = (u32x4){o.e0, o.o0, o.e1, o.o1};
+                        }
+                        hx[J % 2][r] = xf[r];
+                        if constexpr (NT > 0) ht[J % NT][r] = t3;
+                    }
+                    __syncthreads();
+                }
+            });
+        }
+    } else {
+        // ------------------------------------------------------------ consumer
+        const int cw = wave - NWP;
+        const int j0 = cw * G;
+        unsigned ovoff[G];
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            ovoff[g] = (j0 + g < ty_act && lane < nlanes) ? (unsigned)((y0 + j0 + g) * nx + x0 + 8 * lane) : kOOB;
+        for (int i = 0; i < nsteps; i++) {
+            __syncthreads();
+            if (i < W - 1) continue;
+            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(out + (unsigned long long)(unsigned)(zs + i - (W - 1)) * (unsigned long long)plane_bytes), 0,
+                (int)plane_bytes, 0x00020000);
+            const u32x4 *rbuf = lds + (i & 1) * (LROWS * 64) + j0 * 64 + lane;
+            Split8 row[G + W - 1];
+#pragma unroll
+            for (int k = 0; k < G + W - 1; k++) {
+                const u32x4 q = rbuf[k * 64];
+                row[k] = Split8{q.x, q.y, q.z, q.w};
+            }
+            Split8 s1[G + W - 3];
+#pragma unroll
+            for (int k = 0; k < G + W - 3; k++) s1[k] = op3s<IS_MAX>(row[k], row[k + 1], row[k + 2]);
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                Split8 o = s1[g];
+                if constexpr (W == 5) o = op2s<IS_MAX>(s1[g], s1[g + 2]);
+                else if constexpr (W == 7) o = op3s<IS_MAX>(s1[g], s1[g + 2], s1[g + 4]);
+                // written once, never read back by this launch: non-temporal
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2){join(o.e0, o.o0), join(o.e1, o.o1)}, rout, ovoff[g], 0, 2);
+            }
+        }
+    }
+}
+
+template <int W, bool IS_MAX, int NWP, int NWC, int R, int TY>
+static int launch_u8_split(const uint8_t *in, uint8_t *out, U8FusedParams &p, bool has_const, hipStream_t s)
+{
+    constexpr int G = (TY + NWC - 1) / NWC;
+    constexpr int LROWS = (NWC * G + W - 1) > NWP * R ? (NWC * G + W - 1) : NWP * R;
+    const size_t lds = (size_t)2 * LROWS * 1024 + (size_t)(kU8MaxChunk + 8) * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI_HIP(hipFuncSetAttribute((const void *)mm3u8_split_kernel<W, IS_MAX, NWP, NWC, R, TY, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MI_HIP(hipFuncSetAttribute((const void *)mm3u8_split_kernel<W, IS_MAX, NWP, NWC, R, TY, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    p.nxt = (p.nx + 511) / 512;
+    p.nyt = (p.ny + TY - 1) / TY;
+    int cus = 256;
+    {
+        static int cached = 0;
+        if (!cached) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount;
+        }
+        if (cached > 0) cus = cached;
+    }
+    const int64_t tiles = (int64_t)p.nxt * p.nyt;
+    double best = 1e300;
+    int best_nzc = 1;
+    for (int nzc = 1; nzc <= std::min(p.nz, 64); nzc++) {
+        const int chunk = (p.nz + nzc - 1) / nzc;
+        if (chunk > kU8MaxChunk) continue;
+        const int real = (p.nz + chunk - 1) / chunk;
+        const double rounds = (double)((tiles * real + cus - 1) / cus);
+        const double cost = rounds * (chunk + W - 1 + 2.0);
+        if (cost < best) { best = cost; best_nzc = real; }
+    }
+    p.zc = (p.nz + best_nzc - 1) / best_nzc;
+    if (p.zc > kU8MaxChunk) p.zc = kU8MaxChunk;
+    p.nzc = (p.nz + p.zc - 1) / p.zc;
+    const int64_t total = tiles * p.nzc;
+    if (has_const)
+        hipLaunchKernelGGL((mm3u8_split_kernel<W, IS_MAX, NWP, NWC, R, TY, true>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+    else
+        hipLaunchKernelGGL((mm3u8_split_kernel<W, IS_MAX, NWP, NWC, R, TY, false>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
 template <int W, bool IS_MAX, int NWP, int NWC, int R, int ND = 4>
 static int launch_u8_fused(const uint8_t *in, uint8_t *out, U8FusedParams &p, bool has_const, hipStream_t s)
 {
@@ -681,6 +963,7 @@ static int launch_u8_fused_w(int w, int cfg, const uint8_t *in, uint8_t *out, U8
         return narrow ? launch_u8_fused<5, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s)
                       : launch_u8_fused<5, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
     default:
+        if (cfg == 1 || cfg == 5) return launch_u8_split<7, IS_MAX, 13, 3, 3, 32>(in, out, p, has_const, s);
         if (cfg == 2) return launch_u8_fused<7, IS_MAX, 12, 4, 2>(in, out, p, has_const, s);
         if (narrow) return launch_u8_fused<7, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s);
         // 12 waves x 168 VGPRs: three rows per producer wave need ~150 registers (packed z history 72)
