@@ -957,13 +957,15 @@ static int launch_u8_fused_w(int w, int cfg, const uint8_t *in, uint8_t *out, U8
     const bool narrow = p.nx < 768 || cfg == 3;
     switch (w) {
     case 3:
+        if (cfg == 1) return launch_u8_split<3, IS_MAX, 12, 4, 3, 32>(in, out, p, has_const, s);
         return narrow ? launch_u8_fused<3, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s)
                       : launch_u8_fused<3, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
     case 5:
+        if (cfg == 1) return launch_u8_split<5, IS_MAX, 12, 4, 3, 32>(in, out, p, has_const, s);
         return narrow ? launch_u8_fused<5, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s)
                       : launch_u8_fused<5, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
     default:
-        if (cfg == 1 || cfg == 5) return launch_u8_split<7, IS_MAX, 13, 3, 3, 32>(in, out, p, has_const, s);
+        if (cfg == 1) return launch_u8_split<7, IS_MAX, 13, 3, 3, 32>(in, out, p, has_const, s);
         if (cfg == 2) return launch_u8_fused<7, IS_MAX, 12, 4, 2>(in, out, p, has_const, s);
         if (narrow) return launch_u8_fused<7, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s);
         // 12 waves x 168 VGPRs: three rows per producer wave need ~150 registers (packed z history 72)
@@ -975,7 +977,8 @@ static int launch_u8_fused_w(int w, int cfg, const uint8_t *in, uint8_t *out, U8
 
 using namespace mi;
 
-// test / tuning hook (not part of the C-ABI): 0 = always take the two-launch path
+// test / tuning hook (not part of the C-ABI): 0 = always take the two-launch path, 1 = split-form kernel (default),
+// 2-4 = round-1 packed kernels (tile variants)
 static int g_u8_fused = 1;
 extern "C" int mi_debug_set_u8_fused(int enabled) { g_u8_fused = enabled; return MI_OK; }
 
