@@ -128,23 +128,27 @@ template <typename CT, bool FASTC, int ORDER>
 __device__ __forceinline__ void taps(const __amdgpu_buffer_rsrc_t in, const FastInterpParams &p, CT cz, CT cy, CT cx, Taps &t)
 {
     if constexpr (FASTC && ORDER == 1) {
-        // constant mode, order 1: integer/fraction split once per axis, the range
-        // test on the integers, one base index plus three strides
+        // constant mode, order 1: integer/fraction split once per axis, the range test on the integers, one base
+        // index plus three strides.  r2: written branch-free (bitwise logic instead of && / ||: the short-circuit
+        // form compiled into twenty exec-masked branches per four voxels) -- the kernel is VALU bound, not gather bound
+        // (rocprofv3: 93 VALU instructions per voxel, VALU 78 % busy), so every instruction counts.
         const CT fz = floor(cz), fy = floor(cy), fx = floor(cx);
         const int z0 = (int)fz, y0 = (int)fy, x0 = (int)fx;
         t.wz1 = (float)(cz - fz); t.wy1 = (float)(cy - fy); t.wx1 = (float)(cx - fx);
-        const bool in_z = z0 >= 0 && (z0 < p.nz - 1 || (z0 == p.nz - 1 && t.wz1 == 0.f));
-        const bool in_y = y0 >= 0 && (y0 < p.ny - 1 || (y0 == p.ny - 1 && t.wy1 == 0.f));
-        const bool in_x = x0 >= 0 && (x0 < p.nx - 1 || (x0 == p.nx - 1 && t.wx1 == 0.f));
-        t.outside = !(in_z && in_y && in_x);
+        const bool zz = t.wz1 == 0.f, yz = t.wy1 == 0.f, xz = t.wx1 == 0.f;
+        // 0 <= i < n - 1, or i == n - 1 with a zero fraction (unsigned compare folds the sign test in)
+        const bool in_z = ((unsigned)z0 < (unsigned)(p.nz - 1)) | ((z0 == p.nz - 1) & zz);
+        const bool in_y = ((unsigned)y0 < (unsigned)(p.ny - 1)) | ((y0 == p.ny - 1) & yz);
+        const bool in_x = ((unsigned)x0 < (unsigned)(p.nx - 1)) | ((x0 == p.nx - 1) & xz);
+        t.outside = !(in_z & in_y & in_x);
         t.oobmask = 0;
         // x0 / x1 sit next to each other in memory: one 8-byte gather per (z, y) pair.
         // At the last column (only reachable with wx1 == 0) the pair is shifted left by one.
         const bool lastcol = x0 >= p.nx - 1;
-        const int xb = lastcol ? x0 - 1 : x0;
+        const int xb = x0 - (lastcol ? 1 : 0);
         const unsigned base = t.outside ? 0u : (unsigned)((z0 * p.ny + y0) * p.nx + xb) * 4u;
-        const unsigned sz = (t.outside || t.wz1 == 0.f) ? 0u : (unsigned)(p.ny * p.nx) * 4u;
-        const unsigned sy = (t.outside || t.wy1 == 0.f) ? 0u : (unsigned)p.nx * 4u;
+        const unsigned sz = (t.outside | zz) ? 0u : (unsigned)(p.ny * p.nx) * 4u;
+        const unsigned sy = (t.outside | yz) ? 0u : (unsigned)p.nx * 4u;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(in, base + (m >> 1) * sz + (m & 1) * sy, 0, 0);
