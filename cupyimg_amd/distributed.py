@@ -179,6 +179,8 @@ class SlabFilter:
         self._input_free = None       # previous readers of ext_in finished (default stream)
         self._overlap_ok = True
         self._prepared = {}
+        self._tuning = {}             # per filter: schedule measurements / choice (see _tuned_schedule)
+        self.autotune = True          # overlap=None: measure plain vs overlapped on the first four steps
 
     @property
     def local_in(self):
@@ -249,8 +251,9 @@ class SlabFilter:
         (mi_slab_separable3d_f32); the marshalled arguments are cached, so a
         repeated step costs a few microseconds of host time.  `fallback(ext_in,
         ext_out)` runs under the plain schedule when the fused kernel does not
-        cover the request.  overlap: True / False, default None = decided by the
-        halo size (overlapping pays from ~8 MiB per direction)."""
+        cover the request.  overlap: True / False; default None = measured on
+        the first four steps (`_tuned_schedule`; with `autotune = False`: decided by
+        the halo size in C, overlapping from ~8 MiB per direction)."""
         from .scipy.ndimage import _support as S
         plan = self.plan
         key = _key
@@ -276,13 +279,48 @@ class SlabFilter:
             prep = self._prepared[key] = (args, (keep, a, b))        # second item keeps the buffers alive
         try:
             args = prep[0]
-            mode_flag = -1 if overlap is None else int(bool(overlap))
+            if overlap is not None:
+                mode_flag = int(bool(overlap))
+            elif self.comm is None or plan.nranks == 1 or not self.autotune:
+                mode_flag = -1
+            else:
+                mode_flag = self._tuned_schedule(key, args)
+                if mode_flag is None:           # that call was a tuning step and has been issued
+                    return self.local_out
             _lib.check(_lib.load().mi_slab_separable3d_f32(*args[:12], mode_flag, *args[13:]))
         except _lib.Unsupported:
             if fallback is None:
                 raise
             return self.step(fallback)
         return self.local_out
+
+    def _tuned_schedule(self, key, args):
+        """Plain or overlapped schedule for this filter, measured instead of guessed: whether hiding the exchange
+        behind the interior planes pays depends on the link (xGMI latency and bandwidth for THIS halo size) and on
+        the cost of the cross-stream waits, and neither can be known from a one-GPU box.  The first four steps of
+        a filter are used for it: one warm step of each schedule, then one timed step of each (HIP events on the
+        default stream); from the fifth step on the faster one runs.  Every step, tuning or not, performs exactly
+        one exchange, so ranks that decide differently still pair their sends and receives.  Returns the flag for
+        mi_slab_separable3d_f32, or None when the call was consumed as a tuning step."""
+        st = self._tuning.setdefault(key, {"n": 0, "t": [None, None]})
+        if "choice" in st:
+            return st["choice"]
+        lib = _lib.load()
+        n = st["n"]
+        st["n"] = n + 1
+        flag = n & 1                            # steps 0, 2: plain; steps 1, 3: overlapped
+        if n < 2:
+            _lib.check(lib.mi_slab_separable3d_f32(*args[:12], flag, *args[13:]))
+            return None
+        e0, e1 = core.Event(), core.Event()
+        e0.record()
+        _lib.check(lib.mi_slab_separable3d_f32(*args[:12], flag, *args[13:]))
+        e1.record()
+        e1.synchronize()
+        st["t"][flag] = e0.elapsed_ms(e1)
+        if n == 3:
+            st["choice"] = 1 if st["t"][1] < 0.97 * st["t"][0] else 0
+        return None
 
     def uniform_filter(self, size, mode="reflect", cval=0.0, overlap=None):
         """uniform_filter of the whole (distributed) volume; returns this rank's planes."""

@@ -154,6 +154,25 @@ def test_native_slab_step_matches_plain_step(gpu, ndi, self_comm, nz):
             assert maxnorm_rel(got, orc.uniform_filter(x, 13, mode=["wrap", "mirror", "mirror"])) <= 1e-6
 
 
+def test_slab_schedule_is_measured_on_the_first_steps(gpu, ndi, self_comm):
+    """overlap=None: steps 0-3 of a filter try the plain and the overlapped schedule (one warm, one timed step each),
+    from the fifth step on the faster one runs; every step gives the same (bit-identical) planes."""
+    from cupyimg_amd.distributed import SlabFilter, halo_widths
+    rng = np.random.default_rng(21)
+    nz = 40
+    x = rng.standard_normal((nz, 48, 256)).astype(np.float32)
+    lo, hi = halo_widths(5)
+    sf = SlabFilter(_SelfLoopPlan(nz, lo, hi), x.shape[1:], np.float32, self_comm)
+    sf.local_in[...] = gpu.asarray(x)
+    want = sf.uniform_filter(5, mode="nearest", overlap=False).get()
+    outs = [sf.uniform_filter(5, mode="nearest").get() for _ in range(7)]
+    assert all(np.array_equal(o, want) for o in outs)
+    (st,) = sf._tuning.values()
+    assert st["n"] == 4 and st["choice"] in (0, 1) and all(t is not None and t > 0 for t in st["t"])
+    sf.autotune = False
+    assert np.array_equal(sf.uniform_filter(5, mode="nearest").get(), want)
+
+
 def test_slab_step_refuses_kernels_wider_than_the_halo(gpu, ndi, self_comm):
     """A plan built for 5 taps refuses a 17-tap axis-0 kernel in Python (ValueError) and in C
     (MI_ERR_INVALID_ARG), instead of filtering across the slab edge."""
