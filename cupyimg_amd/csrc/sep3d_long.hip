@@ -28,8 +28,9 @@
 //     steps, like the rings of the other kernels.
 //   * one s_barrier per plane; DMA completion is counted by hand (s_waitcnt
 //     vmcnt(4): the youngest plane stays in flight across the barrier).
-// Boundary modes: every index-mapping mode on every axis; `constant` is left to
-// the lean kernel / the streaming passes (DMA cannot substitute cval).
+// Boundary modes: every index-mapping mode on every axis; `constant` as zero fill
+// (what the DMA writes for out-of-range lanes, rows and planes) plus a separable
+// coverage correction at the store (HAS_CONST).
 #include "sep_common.hpp"
 #include "stream3d.hpp"
 
@@ -54,6 +55,9 @@ struct LongParams {
     // y / z weights, each one TWICE (an aligned SGPR pair is what v_pk_fma_f32 takes: no s_mov per odd tap)
     float wyv[2 * kStreamMaxTaps], wzv[2 * kStreamMaxTaps];
     float xpair[2][2 * (kStreamMaxTaps / 2 + 2)];   // see StreamParams::xpair
+    // constant mode (HAS_CONST kernels): plain x weights, cval, cval * (product of the three weight sums)
+    float wxs[kStreamMaxTaps];
+    float cval, cval_sum;
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -143,7 +147,7 @@ __device__ __forceinline__ F4 xhops(const float4 v, const float4 (&eL)[2], const
 
 constexpr int kLongHyBytes = 2 * kLongTY * 64;     // y-filtered halo blocks: [2 planes][16 rows][4 blocks of 16 bytes]
 
-template <int W, bool SAME>
+template <int W, bool SAME, bool HAS_CONST>
 __global__ void __launch_bounds__(kLongTY * 64)
 sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const LongParams p)
 {
@@ -153,6 +157,7 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     // layout: planes[kLongNB][32] records | hy[2][16][4] float4 | ztab
     constexpr unsigned HY0 = kLongRawBytes;
     int *ztab = reinterpret_cast<int *>(smem + kLongRawBytes + kLongHyBytes);
+    float *cztab = reinterpret_cast<float *>(ztab + kLongMaxChunk + kStreamMaxTaps);     // HAS_CONST: z coverage per output plane
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -184,18 +189,47 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     const int nsteps = ze - zs + W - 1;
 
     for (int i = threadIdx.x; i < nsteps; i += kLongTY * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
+    // Constant mode: the DMA cannot substitute cval, but it zero-fills what lies outside (out-of-range lanes, rows and
+    // planes), and  filter(x extended by cval) = filter(x extended by 0) + cval * (S - cz(z) cy(y) cx(x)),  S = product
+    // of the three weight sums, c_a(i) = sum of the axis-a weights whose tap lands inside the volume (all of them on
+    // an axis that is not in constant mode).  cz per output plane goes to an LDS table, cy is one number per wave,
+    // cx four per lane: the correction is two packed FMAs per output float4.
+    [[maybe_unused]] float cyv = 0.f;
+    [[maybe_unused]] F4 cxv = f4_splat(0.f);
+    if constexpr (HAS_CONST) {
+        for (int t = threadIdx.x; t < ze - zs; t += kLongTY * 64) {
+            float c = 0.f;
+            for (int k = 0; k < W; k++) {
+                const int q = zs + t - p.oz + k;
+                c += (p.mz != MI_MODE_CONSTANT || (q >= 0 && q < nz)) ? p.wzv[2 * k] : 0.f;
+            }
+            cztab[t] = c;
+        }
+        float cx4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < W; k++) {
+            const int qy = y0 + wave - p.oy + k;
+            cyv += (p.my != MI_MODE_CONSTANT || (qy >= 0 && qy < ny)) ? p.wyv[2 * k] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int qx = x0 + 4 * lane + c - W / 2 + k;
+                cx4[c] += (p.mx != MI_MODE_CONSTANT || (qx >= 0 && qx < nx)) ? p.wxs[k] : 0.f;
+            }
+        }
+        cxv.lo = (f32x2){cx4[0], cx4[1]};
+        cxv.hi = (f32x2){cx4[2], cx4[3]};
+    }
     __syncthreads();
 
     unsigned vmain[2], vhalo[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int r = wave + 16 * h;
-        const bool valid = r < rows_needed;
         const int ys = bmap<int>(y0 - p.oy + r, ny, p.my);
+        const bool valid = r < rows_needed && ys >= 0;          // ys < 0: a row of cval (constant mode) = zeros here
         vmain[h] = (valid && lane < nlanes) ? (unsigned)(ys * nx + x0 + 4 * lane) * 4u : kOOB;
         const int j = lane & 15;
         const int xsrc = bmap<int>(j < 8 ? x0 - 8 + j : xe + j - 8, nx, p.mx);
-        vhalo[h] = valid ? (unsigned)(ys * nx + xsrc) * 4u : kOOB;
+        vhalo[h] = (valid && xsrc >= 0) ? (unsigned)(ys * nx + xsrc) * 4u : kOOB;
     }
     const unsigned own = (unsigned)wave * kLongRec + (unsigned)lane * 16u;      // this lane's block of record `wave`
     // halo pass (one wave per plane): lane -> (row = lane / 4, block = lane % 4) of the record's 64 halo bytes
@@ -211,9 +245,13 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
         // issues the same four DMAs and the vmcnt arithmetic stays uniform.  Scalar work is kept short here: the
         // sixteen waves of the workgroup share ONE scalar unit (the empty loop -- barrier, address arithmetic and
         // DMA issue only -- cost 0.47 us per plane in the first version).
-        const bool live = i < nsteps;
+        bool live = i < nsteps;
         int zsrc = zi0 + i;
         if ((unsigned)zsrc >= (unsigned)nz) zsrc = __builtin_amdgcn_readfirstlane(ztab[live ? i : 0]);   // boundary planes only
+        if constexpr (HAS_CONST) {
+            live = live && zsrc >= 0;           // a plane of cval = a plane of zeros here
+            zsrc = max(zsrc, 0);
+        }
         const unsigned long long a = (unsigned long long)in + (unsigned long long)(unsigned)zsrc * (unsigned long long)plane_bytes;
         u32x4_t rin;
         rin.x = (unsigned)a;
@@ -287,7 +325,13 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
                     const unsigned long long oa = (unsigned long long)out +
                                                   (unsigned long long)(unsigned)(zs + i - (W - 1)) * (unsigned long long)plane_bytes;
                     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)oa, 0, (int)plane_bytes, 0x00020000);
-                    __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(acc[(J + 1) % W]), rout, ovoff, 0, 2);
+                    F4 o = acc[(J + 1) % W];
+                    if constexpr (HAS_CONST) {
+                        const float g = -p.cval * cztab[i - (W - 1)] * cyv;
+                        o.lo = fma2(splat2(g), cxv.lo, o.lo + splat2(p.cval_sum));
+                        o.hi = fma2(splat2(g), cxv.hi, o.hi + splat2(p.cval_sum));
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(o), rout, ovoff, 0, 2);
                 }
                 // ---- halo table of plane i + 1 (the wave changes every plane)
                 if (i + 1 < nsteps && wave == (i & 15)) {
@@ -301,17 +345,18 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int W, bool SAME>
+template <int W, bool SAME, bool HAS_CONST>
 static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s)
 {
-    const size_t lds = (size_t)kLongRawBytes + kLongHyBytes + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int);
+    const size_t lds = (size_t)kLongRawBytes + kLongHyBytes + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int) +
+                       (HAS_CONST ? (size_t)kLongMaxChunk * sizeof(float) : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)sep3d_long_kernel<W, SAME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MI_HIP(hipFuncSetAttribute((const void *)sep3d_long_kernel<W, SAME, HAS_CONST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     const int total = p.nxt * p.nyt * p.nzc;
-    hipLaunchKernelGGL((sep3d_long_kernel<W, SAME>), dim3(total), dim3(kLongTY * 64), lds, s, in, out, p);
+    hipLaunchKernelGGL((sep3d_long_kernel<W, SAME, HAS_CONST>), dim3(total), dim3(kLongTY * 64), lds, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -334,11 +379,11 @@ static int g_long_same = 1;        // test hook: 0 = always the reloading varian
 // Fused long-kernel path: cubic odd W in 11..17 (9 behind the test hook), origins on y / z allowed, no constant mode.
 // Returns MI_ERR_UNSUPPORTED when the request is outside that (the caller runs the streaming passes).
 int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, const float *wx, const float *wy,
-                   const float *wz, int oy, int oz, int mx, int my, int mz, const int64_t zb[2], const int64_t zn[2],
-                   hipStream_t s)
+                   const float *wz, int oy, int oz, int mx, int my, int mz, float cval, const int64_t zb[2],
+                   const int64_t zn[2], hipStream_t s)
 {
     if (w < 3 || w > 17 || !(w & 1)) return MI_ERR_UNSUPPORTED;
-    if (mx == MI_MODE_CONSTANT || my == MI_MODE_CONSTANT || mz == MI_MODE_CONSTANT) return MI_ERR_UNSUPPORTED;
+    const bool has_const = mx == MI_MODE_CONSTANT || my == MI_MODE_CONSTANT || mz == MI_MODE_CONSTANT;
     if ((int64_t)ny * nx * 4 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
     LongParams p;
     memset(&p, 0, sizeof(p));
@@ -347,7 +392,15 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
     p.mx = mx; p.my = my; p.mz = mz;
     p.nxt = (nx + 255) / 256;
     p.nyt = (ny + kLongTY - 1) / kLongTY;
-    for (int k = 0; k < w; k++) { p.wyv[2 * k] = p.wyv[2 * k + 1] = wy[k]; p.wzv[2 * k] = p.wzv[2 * k + 1] = wz[k]; }
+    double sx = 0, sy = 0, sz = 0;
+    for (int k = 0; k < w; k++) {
+        p.wyv[2 * k] = p.wyv[2 * k + 1] = wy[k];
+        p.wzv[2 * k] = p.wzv[2 * k + 1] = wz[k];
+        p.wxs[k] = wx[k];
+        sx += wx[k]; sy += wy[k]; sz += wz[k];
+    }
+    p.cval = cval;
+    p.cval_sum = (float)((double)cval * sx * sy * sz);
     {
         const int rx = w / 2, nb = (rx + 3) / 4, base = 4 * nb - rx;
         for (int q = 0; q < 2; q++) {
@@ -381,7 +434,10 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
     p.nzc = p.nzc0 + (int)((zn[1] + p.zc - 1) / p.zc);
     bool same = g_long_same != 0;
     for (int k = 0; k < w; k++) same = same && wx[k] == wy[k] && wy[k] == wz[k];
-#define MI_LONG_CASE(N) case N: return same ? launch_long<N, true>(in, out, p, s) : launch_long<N, false>(in, out, p, s);
+#define MI_LONG_CASE(N)                                                                                   \
+    case N:                                                                                               \
+        if (has_const) return same ? launch_long<N, true, true>(in, out, p, s) : launch_long<N, false, true>(in, out, p, s); \
+        return same ? launch_long<N, true, false>(in, out, p, s) : launch_long<N, false, false>(in, out, p, s);
     switch (w) {
         MI_LONG_CASE(3) MI_LONG_CASE(5) MI_LONG_CASE(7) MI_LONG_CASE(9) MI_LONG_CASE(11) MI_LONG_CASE(13) MI_LONG_CASE(15) MI_LONG_CASE(17)
     }

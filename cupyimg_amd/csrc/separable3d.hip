@@ -702,8 +702,8 @@ static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams 
 int run_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axis, const float *wav, int wa, int oa,
                     int ma, const float *wxv, int wx, int mx, float cval, hipStream_t s);   // stream3d.hip
 int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, const float *wx, const float *wy,
-                   const float *wz, int oy, int oz, int mx, int my, int mz, const int64_t zb[2], const int64_t zn[2],
-                   hipStream_t s);   // sep3d_long.hip
+                   const float *wz, int oy, int oz, int mx, int my, int mz, float cval, const int64_t zb[2],
+                   const int64_t zn[2], hipStream_t s);   // sep3d_long.hip
 
 // Tile / z-chunk choice by a small cost model.  One workgroup per CU is
 // resident, so the launch runs in ceil(workgroups / CUs) rounds; a workgroup
@@ -833,12 +833,12 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     const int64_t nzr = zn[0] + zn[1];
 
     const bool cubic_w = w[0] == w[1] && w[1] == w[2];
-    if (cubic_w && !any_const && g_sep3d_long != 1 && nx >= 16 &&
+    if (cubic_w && g_sep3d_long != 1 && nx >= 16 &&
         ((w[0] >= 9 && w[0] <= 17) || (w[0] >= 3 && w[0] <= 7 && g_sep3d_long == 2))) {
         // long cubic kernels: ONE launch with LDS-DMA staging and the z state in registers (sep3d_long.hip)
         const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
         rc = run_sep3d_long((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w[0], wbuf[2], wbuf[1],
-                            wbuf[0], oy, oz, p.mx, p.my, p.mz, zb, zn, resolve_stream(stream));
+                            wbuf[0], oy, oz, p.mx, p.my, p.mz, (float)cval, zb, zn, resolve_stream(stream));
         if (rc != MI_ERR_UNSUPPORTED) return rc;
     }
     if (w[0] > kMaxTaps || w[1] > kMaxTaps || w[2] > kMaxTaps) {

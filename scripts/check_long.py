@@ -29,6 +29,22 @@ for shape in shapes:
             if err > 1e-6:
                 bad += 1
                 print("gauss", shape, mode, sigma, err, flush=True)
+    for mode, cval in [("constant", 0.0), ("constant", 2.5), (["constant", "reflect", "nearest"], -1.0), (["wrap", "constant", "constant"], 0.75)]:
+        for size in (9, 11, 17):
+            want = sndi.uniform_filter(x.astype(np.float64), size, mode=mode, cval=cval)
+            got = ndi.uniform_filter(xd, size, mode=mode, cval=cval).get()
+            err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+            cases += 1
+            if err > 1e-6:
+                bad += 1
+                print("const uniform", shape, mode, cval, size, err, flush=True)
+        want = sndi.gaussian_filter(x.astype(np.float64), 2.0, mode=mode, cval=cval)
+        got = ndi.gaussian_filter(xd, 2.0, mode=mode, cval=cval).get()
+        err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+        cases += 1
+        if err > 1e-6:
+            bad += 1
+            print("const gauss", shape, mode, cval, err, flush=True)
     for origin in [(2, -3, 0), (-5, 5, 0)]:
         want = sndi.uniform_filter(x.astype(np.float64), 11, mode="reflect", origin=origin)
         got = ndi.uniform_filter(xd, 11, mode="reflect", origin=origin).get()

@@ -200,8 +200,9 @@ def test_slab_step_refuses_kernels_wider_than_the_halo(gpu, ndi, self_comm):
 
 def test_overlapped_step_with_long_kernels(gpu, ndi, self_comm):
     """13 taps: the fused long kernel (sep3d_long.hip) takes plane ranges, so the overlapped schedule runs and is
-    bit-identical to the plain one; in `constant` mode the streaming passes serve the request, they take no plane
-    ranges and the step falls back to the plain schedule."""
+    bit-identical to the plain one (also in `constant` mode, which the kernel handles by zero fill + a coverage
+    correction); a NON-cubic long kernel is served by the streaming passes, they take no plane ranges and the step
+    falls back to the plain schedule."""
     from cupyimg_amd.distributed import SlabFilter, halo_widths
     rng = np.random.default_rng(14)
     nz, size = 40, 13
@@ -218,8 +219,13 @@ def test_overlapped_step_with_long_kernels(gpu, ndi, self_comm):
     assert maxnorm_rel(got, ref) <= 1e-6
     fc = lambda a, b: ndi.uniform_filter(a, size=size, mode=["wrap", "constant", "constant"], cval=0.5, output=b)   # noqa: E731
     got = sf.step_overlapped(fc).get()
-    assert not sf._overlap_ok
+    assert sf._overlap_ok and np.array_equal(got, sf.step(fc).get())
     ref = orc.uniform_filter(x, size, mode=["wrap", "constant", "constant"], cval=0.5)
+    assert maxnorm_rel(got, ref) <= 1e-6
+    fm = lambda a, b: ndi.uniform_filter(a, size=(size, 5, 5), mode="nearest", output=b)   # noqa: E731
+    got = sf.step_overlapped(fm).get()
+    assert not sf._overlap_ok
+    ref = orc.uniform_filter(x, (size, 5, 5), mode=["wrap", "nearest", "nearest"])
     assert maxnorm_rel(got, ref) <= 1e-6
 
 

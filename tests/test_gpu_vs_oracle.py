@@ -1067,9 +1067,9 @@ def test_streaming_passes_on_many_workgroups(gpu, ndi):
 
 
 def test_fused_long_kernel_against_scipy(gpu, ndi):
-    """sep3d_long.hip (cubic 11..17 taps in ONE launch: LDS-DMA staging, x / y passes out of LDS, z as a register
-    scatter): every index-mapping mode, partial tiles in x and y, several z chunks, origins on y / z; the streaming
-    passes (constant mode, hook) must agree with it."""
+    """sep3d_long.hip (cubic 9..17 taps in ONE launch: LDS-DMA staging, y pass out of LDS, x in registers, z as a
+    register scatter): every boundary mode (constant = zero fill + coverage correction), partial tiles in x and y,
+    several z chunks, origins on y / z; the streaming passes (hook) must agree with it."""
     import ctypes
     import scipy.ndimage as sndi
     from cupyimg_amd import _lib
@@ -1085,6 +1085,10 @@ def test_fused_long_kernel_against_scipy(gpu, ndi):
                 assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max(), (shape, mode, size)
             want = sndi.gaussian_filter(v.astype(np.float64), 1.6, mode=mode)      # 13 taps
             got = ndi.gaussian_filter(vd, 1.6, mode=mode).get()
+            assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max(), (shape, mode)
+        for mode, cval in [("constant", 1.25), (["constant", "mirror", "wrap"], -3.0)]:
+            want = sndi.gaussian_filter(v.astype(np.float64), 2.0, mode=mode, cval=cval)
+            got = ndi.gaussian_filter(vd, 2.0, mode=mode, cval=cval).get()
             assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max(), (shape, mode)
         want = sndi.uniform_filter(v.astype(np.float64), 15, mode="reflect", origin=(3, -6, 0))
         got = ndi.uniform_filter(vd, 15, mode="reflect", origin=(3, -6, 0)).get()
