@@ -29,6 +29,7 @@ SOURCES = [
     ("separable3d.hip", []),
     ("stream3d.hip", []),
     ("sep3d_long.hip", []),
+    ("minmax3d_f32.hip", []),
     ("correlate_nd.hip", ["-ffp-contract=off"]),
     ("stencil3d.hip", ["-ffp-contract=off"]),
     ("minmax.hip", ["-ffp-contract=off"]),

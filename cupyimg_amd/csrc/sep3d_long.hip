@@ -31,17 +31,9 @@
 // Boundary modes: every index-mapping mode on every axis; `constant` as zero fill
 // (what the DMA writes for out-of-range lanes, rows and planes) plus a separable
 // coverage correction at the store (HAS_CONST).
-#include "sep_common.hpp"
-#include "stream3d.hpp"
+#include "long_common.hpp"
 
 namespace mi {
-
-constexpr int kLongTY = 16;           // output rows per tile = waves per workgroup
-constexpr int kLongRowsMax = 32;      // raw rows per plane (TY + 17 - 1)
-constexpr int kLongRec = 1024 + 64;   // LDS bytes per raw row: 256 floats + 16 halo floats
-constexpr int kLongNB = 4;            // planes in LDS: one being x-filtered, one being y-read, two in flight
-constexpr int kLongRawBytes = kLongNB * kLongRowsMax * kLongRec;
-constexpr int kLongMaxChunk = 1024;   // planes per z chunk (ztab in LDS)
 
 struct LongParams {
     int nx, ny, nz;
@@ -60,36 +52,6 @@ struct LongParams {
     float cval, cval_sum;
 };
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-// The four LDS-DMAs a wave issues per plane, as ONE statement (M0 = wave-uniform LDS destination, saved and
-// restored around it): row A (16 bytes per lane, destination rec + 16 * lane), its halo (4 bytes per lane, lanes
-// 0..15 only, at rec + 1024), then the same for row B, whose record lies 16 records further.
-__device__ __forceinline__ void dma_two_rows(u32x4_t rsrc, unsigned va, unsigned vha, unsigned vb, unsigned vhb, unsigned rec)
-{
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %6\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %5, 0 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_mov_b64 exec, 0xffff\n\t"
-        "buffer_load_dword %2, %5, 0 offen lds\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_add_u32 m0, m0, %7\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %3, %5, 0 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_mov_b64 exec, 0xffff\n\t"
-        "buffer_load_dword %4, %5, 0 offen lds\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(va), "v"(vha), "v"(vb), "v"(vhb), "s"(rsrc), "s"(rec), "n"(16 * kLongRec - 1024)
-        : "memory", "scc");
-}
-
 // SAME: the three axes share one weight vector (uniform_filter(size=W), isotropic gaussian_filter): x pair tables
 // plus ONE set of 17 splat weights fit the SGPR file for the whole loop.  Otherwise the tables are re-loaded from
 // the kernel-argument segment every step (launder()): hoisted, 2 x 17 weights + the pair tables exceed the SGPR
@@ -107,15 +69,6 @@ __device__ __forceinline__ void dma_two_rows(u32x4_t rsrc, unsigned va, unsigned
 // something the wave's own lanes hold: one wave per plane (rotating) filters the halo blocks of all 16 rows in one
 // extra pass, one plane ahead, and leaves them in a small LDS table for the edge lanes.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float4 dpp4_shr(const float4 keep, const float4 v)
-{
-    return make_float4(dpp_from_left(keep.x, v.x), dpp_from_left(keep.y, v.y), dpp_from_left(keep.z, v.z), dpp_from_left(keep.w, v.w));
-}
-__device__ __forceinline__ float4 dpp4_shl(const float4 keep, const float4 v)
-{
-    return make_float4(dpp_from_right(keep.x, v.x), dpp_from_right(keep.y, v.y), dpp_from_right(keep.z, v.z), dpp_from_right(keep.w, v.w));
-}
-
 // x pass over the row a wave holds one float4 per lane of: eL[j] / eR[j] = the (j+1)-th 4-float block left / right of
 // the tile (valid in lane 0 / lane `last`)
 template <int W>
@@ -145,7 +98,6 @@ __device__ __forceinline__ F4 xhops(const float4 v, const float4 (&eL)[2], const
     return xdot_tab<W, NP, 4 * NBK - RX>(A, tab0, tab1);
 }
 
-constexpr int kLongHyBytes = 2 * kLongTY * 64;     // y-filtered halo blocks: [2 planes][16 rows][4 blocks of 16 bytes]
 
 template <int W, bool SAME, bool HAS_CONST>
 __global__ void __launch_bounds__(kLongTY * 64)

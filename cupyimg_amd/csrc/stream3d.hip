@@ -395,7 +395,15 @@ int run_stream_minmax_pass(const float *in, float *out, int nz, int ny, int nx, 
 
 }  // namespace mi
 
+namespace mi {
+int run_minmax3d_f32_fused(const float *in, float *out, int nz, int ny, int nx, int w, int oy, int oz, int mx, int my, int mz,
+                           bool is_max, hipStream_t s);     // minmax3d_f32.hip
+}
+
 using namespace mi;
+
+static int g_minmax_f32_fused = 1;      // test hook: 0 = always the two streaming launches
+extern "C" int mi_debug_set_minmax_f32_fused(int k) { g_minmax_f32_fused = k; return MI_OK; }
 
 // test hook: one streaming pass with arbitrary float weights (not part of the C-ABI)
 extern "C" int mi_debug_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axis, const float *wav,
@@ -436,6 +444,12 @@ extern "C" int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const in
     }
     const int mz = filter_mode(mode[0]), my = filter_mode(mode[1]), mx = filter_mode(mode[2]);
     hipStream_t s = resolve_stream(stream);
+    if (g_minmax_f32_fused && w[0] == w[1] && w[1] == w[2] && w[0] >= 3) {
+        // cubic sizes: ONE launch (minmax3d_f32.hip); it refuses what it does not cover (constant mode, tiny rows)
+        rc = run_minmax3d_f32_fused((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w[0], off[1], off[0],
+                                    mx, my, mz, is_max != 0, s);
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
+    }
     struct Pass { int axis, wa, oa, ma, wx; };
     Pass passes[3];
     int np = 0;
