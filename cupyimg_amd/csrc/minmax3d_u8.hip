@@ -350,21 +350,10 @@ static int launch_u8_wx(int wx, int wa, const uint8_t *in, uint8_t *out, U8Strea
 
 
 // ---------------------------------------------------------------------------
-// Single-launch version for cubic sizes 3 / 5 / 7 (grey_erosion(size=7), ...):
-// the 2.5-D producer / consumer structure of sep3d_lean_kernel on bytes.
-//   * producer waves own R rows each of a 1024 x (TY + W - 1) tile and stream
-//     along z: 16 voxels per lane per row, x window in registers (even/odd
-//     split, neighbours by DPP, tile edges from one extra load per plane), z
-//     window by "tripling" over a PACKED register history (x of the last two
-//     planes, 3-plane results of the last four: 4 registers per entry,
-//     unpacked on use);
-//   * the x/z result goes to a double-buffered LDS tile; consumer waves do the
-//     y window over LDS rows and store.
-// Windows are built from 3-input steps, v_pk_maximum3_f16 / v_pk_minimum3_f16:
-// byte values 0..255 in u16 lanes are ordered identically as float16 bit
-// patterns (zero and denormals), so one instruction does two comparisons per
-// lane pair; a 7-wide window is two of them (3, then 3 of those at stride 2).
-// HBM traffic: 2 B/voxel (the two-launch version above moves 4).
+// Single-launch version for cubic sizes 3 / 5 / 7 (grey_erosion(size=7), ...): the 2.5-D producer / consumer structure
+// of sep3d_lean_kernel on bytes.  Windows are built from 3-input steps, v_pk_maximum3_f16 / v_pk_minimum3_f16: byte
+// values 0..255 in u16 lanes are ordered identically as float16 bit patterns (zero and denormals), so one instruction
+// does two comparisons per lane pair.  HBM traffic: 2 B/voxel (the two-launch version above moves 4).
 // ---------------------------------------------------------------------------
 struct U8FusedParams {
     int nx, ny, nz;
@@ -375,253 +364,12 @@ struct U8FusedParams {
 
 constexpr int kU8MaxChunk = 2048;
 
-// reduce NIN values (E or O halves of one dword column) with 3-input steps
-template <bool IS_MAX, int NIN>
-__device__ __forceinline__ unsigned reduce3(const unsigned (&v)[NIN])
-{
-    unsigned a = v[0];
-    static_for<(NIN - 1) / 2>([&](auto KK) {
-        constexpr int k = decltype(KK)::value;
-        a = op3<IS_MAX>(a, v[1 + 2 * k], v[2 + 2 * k]);
-    });
-    if constexpr ((NIN - 1) % 2 == 1) a = op2<IS_MAX>(a, v[NIN - 1]);
-    return a;
-}
-
-// ND = dwords (4 voxels each) per lane: 4 -> 1024-voxel tiles, 2 -> 512-voxel tiles for narrower volumes
-template <int ND> struct LaneVec;
-template <> struct LaneVec<4> { typedef u32x4 type; };
-template <> struct LaneVec<2> { typedef u32x2 type; };
-
-template <int ND>
-__device__ __forceinline__ typename LaneVec<ND>::type lane_splat(unsigned x)
-{
-    typename LaneVec<ND>::type v;
-#pragma unroll
-    for (int k = 0; k < ND; k++) v[k] = x;
-    return v;
-}
-template <int ND>
-__device__ __forceinline__ typename LaneVec<ND>::type lane_load(const __amdgpu_buffer_rsrc_t r, unsigned voff)
-{
-    if constexpr (ND == 4) return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
-    else return __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
-}
-template <int ND>
-__device__ __forceinline__ void lane_store(typename LaneVec<ND>::type v, const __amdgpu_buffer_rsrc_t r, unsigned voff)
-{
-    if constexpr (ND == 4) __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
-    else __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
-}
-
-template <int W, bool IS_MAX, int NWP, int NWC, int R, bool HAS_CONST, int ND>
-__global__ void __launch_bounds__((NWP + NWC) * 64)
-mm3u8_fused_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8FusedParams p)
-{
-    constexpr int ROWS = NWP * R;
-    constexpr int TY = ROWS - (W - 1);
-    constexpr int G = (TY + NWC - 1) / NWC;
-    constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
-    constexpr int RX = W / 2;
-    constexpr int LB = 4 * ND;                                            // bytes (voxels) per lane
-    typedef typename LaneVec<ND>::type LV;
-    static_assert(W == 3 || W == 5 || W == 7, "cubic sizes 3, 5, 7");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    LV *lds = reinterpret_cast<LV *>(smem);                              // [2][LROWS][64]
-    int *ztab = reinterpret_cast<int *>(smem + (size_t)2 * LROWS * 64 * LB);
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int b = blockIdx.x;
-    const int total = p.nxt * p.nyt * p.nzc;
-    if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
-    const int per_chunk = p.nxt * p.nyt;
-    const int zci = b / per_chunk;
-    const int rem = b - zci * per_chunk;
-    const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
-
-    const int nx = p.nx, ny = p.ny, nz = p.nz;
-    const int x0 = xt * (64 * LB), y0 = yt * TY, zs = zci * p.zc;
-    const int ze = min(zs + p.zc, nz);
-    const int ty_act = min(TY, ny - y0);
-    const int rows_needed = ty_act + W - 1;
-    const int nlanes = min(64, (nx - x0) / LB);
-    const int last = nlanes - 1;
-    const unsigned plane_bytes = (unsigned)ny * (unsigned)nx;
-    const size_t plane_elems = (size_t)ny * (size_t)nx;
-    const int zi0 = zs - RX;
-    const int nsteps = ze - zs + W - 1;
-
-    for (int i = threadIdx.x; i < nsteps; i += (NWP + NWC) * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
-    __syncthreads();
-
-    if (wave < NWP) {
-        // ------------------------------------------------------------ producer
-        int es0, ek0, es1, ek1;
-        edge_u8(0, x0, x0 + LB * nlanes, nx, p.mx, &es0, &ek0);
-        edge_u8(1, x0, x0 + LB * nlanes, nx, p.mx, &es1, &ek1);
-        const bool left_side = lane < 32;
-        const int erow = left_side ? lane : lane - 32;       // row this lane fetches the edge dword of
-        const int ekind = left_side ? ek0 : ek1;
-        const int estart = left_side ? es0 : es1;
-        unsigned voff[R];
-        unsigned eoffv = kOOB;
-        bool yconst[R];
-        bool e_is_cval = ekind == EDGE_CONST;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int rr = wave * R + r;
-            const int ys = rr < rows_needed ? bmap<int>(y0 - RX + rr, ny, p.my) : -2;
-            yconst[r] = ys == -1;
-            voff[r] = (ys >= 0 && lane < nlanes) ? (unsigned)(ys * nx + x0 + LB * lane) : kOOB;
-            if (erow == r) {
-                if (ys >= 0 && ekind != EDGE_CONST) eoffv = (unsigned)(ys * nx + estart);
-                if (ys == -1) e_is_cval = true;
-            }
-        }
-
-        struct Regs { LV v[R]; unsigned e; bool zconst; };
-        Regs S;
-        auto issue = [&](int i) {
-            int zsrc = zi0 + i;
-            if ((unsigned)zsrc >= (unsigned)nz) zsrc = ztab[i];
-            S.zconst = zsrc < 0;
-            zsrc = __builtin_amdgcn_readfirstlane(max(zsrc, 0));
-            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(in + (size_t)zsrc * plane_elems), 0, (int)plane_bytes, 0x00020000);
-            const bool skip = HAS_CONST && S.zconst;
-#pragma unroll
-            for (int r = 0; r < R; r++) S.v[r] = lane_load<ND>(rin, skip ? kOOB : voff[r]);
-            S.e = __builtin_amdgcn_raw_buffer_load_b32(rin, skip ? kOOB : eoffv, 0, 0);
-        };
-
-        // z window by "tripling": t3[t] = op3(x[t], x[t-1], x[t-2]); W = 7: out = op3(t3[t], t3[t-2], t3[t-4]);
-        // W = 5: out = op2(t3[t], t3[t-2]); W = 3: out = t3[t].  History kept packed: x (2 planes), t3 (NT planes).
-        constexpr int NT = W == 7 ? 4 : (W == 5 ? 2 : 0);
-        constexpr int U = NT > 2 ? NT : 2;                    // steps per unrolled round (history slots are compile-time)
-        LV hx[2][R], ht[NT > 0 ? NT : 1][R];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            hx[0][r] = hx[1][r] = lane_splat<ND>(0u);
-#pragma unroll
-            for (int k = 0; k < (NT > 0 ? NT : 1); k++) ht[k][r] = lane_splat<ND>(0u);
-        }
-
-        issue(0);
-        for (int i0 = 0; i0 < nsteps; i0 += U) {
-            static_for<U>([&](auto JJ) {
-                constexpr int J = decltype(JJ)::value;
-                const int i = i0 + J;
-                if (i < nsteps) {
-                    const bool emit = i >= W - 1;
-                    LV *wbuf = lds + (J & 1) * (LROWS * 64) + (wave * R) * 64 + lane;
-                    // this lane's edge dword, fixed up as the boundary mode wants
-                    unsigned ed = S.e;
-                    if (ekind == EDGE_REV) ed = bswap32(ed);
-                    else if (ekind == EDGE_SPLAT) ed = (left_side ? (ed & 0xFFu) : (ed >> 24)) * 0x01010101u;
-                    if constexpr (HAS_CONST) ed = (e_is_cval || S.zconst) ? p.cval4 : ed;
-                    // one row at a time (x window, then its z window) to keep the live set small
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        LV v = S.v[r];
-                        if constexpr (HAS_CONST)
-                            if (yconst[r] || S.zconst) v = lane_splat<ND>(p.cval4);
-                        const unsigned sL = (unsigned)__builtin_amdgcn_readlane((int)ed, r);
-                        const unsigned sR = (unsigned)__builtin_amdgcn_readlane((int)ed, 32 + r);
-                        const unsigned l = (unsigned)__builtin_amdgcn_update_dpp((int)sL, (int)v[ND - 1], 0x138, 0xf, 0xf, false);
-                        unsigned rg = (unsigned)__builtin_amdgcn_update_dpp((int)sR, (int)v[0], 0x130, 0xf, 0xf, false);
-                        if (lane == last) rg = sR;
-                        Win w;
-                        split(l, w.e[0], w.o[0]);
-#pragma unroll
-                        for (int k = 0; k < ND; k++) split(v[k], w.e[1 + k], w.o[1 + k]);
-                        split(rg, w.e[ND + 1], w.o[ND + 1]);
-#pragma unroll
-                        for (int k = ND + 2; k < 7; k++) { w.e[k] = w.e[ND + 1]; w.o[k] = w.o[ND + 1]; }   // never reaches a used voxel
-                        const Vec16 xf = xpass_u8<W, IS_MAX>(w);
-                        if (r == R - 1 && i + 1 < nsteps) issue(i + 1);       // all rows' registers are consumed
-                        LV u, t3p, xp;
-                        unsigned *up = reinterpret_cast<unsigned *>(&u), *tp = reinterpret_cast<unsigned *>(&t3p),
-                                 *xpp = reinterpret_cast<unsigned *>(&xp);
-                        const unsigned *x1 = reinterpret_cast<const unsigned *>(&hx[(J + 1) % 2][r]);     // plane t - 1
-                        const unsigned *x2 = reinterpret_cast<const unsigned *>(&hx[J % 2][r]);           // plane t - 2
-#pragma unroll
-                        for (int k = 0; k < ND; k++) {
-                            unsigned e1, o1, e2, o2;
-                            split(x1[k], e1, o1);
-                            split(x2[k], e2, o2);
-                            const unsigned te = op3<IS_MAX>(xf.e[k], e1, e2), to = op3<IS_MAX>(xf.o[k], o1, o2);
-                            unsigned oe = te, oo = to;
-                            if constexpr (W == 5) {
-                                unsigned ea, oa;
-                                split(reinterpret_cast<const unsigned *>(&ht[J % NT][r])[k], ea, oa);            // t3[t - 2]
-                                oe = op2<IS_MAX>(te, ea); oo = op2<IS_MAX>(to, oa);
-                            } else if constexpr (W == 7) {
-                                unsigned ea, oa, eb, ob;
-                                split(reinterpret_cast<const unsigned *>(&ht[(J + 2) % NT][r])[k], ea, oa);      // t3[t - 2]
-                                split(reinterpret_cast<const unsigned *>(&ht[J % NT][r])[k], eb, ob);            // t3[t - 4]
-                                oe = op3<IS_MAX>(te, ea, eb); oo = op3<IS_MAX>(to, oa, ob);
-                            }
-                            up[k] = join(oe, oo);
-                            tp[k] = join(te, to);
-                            xpp[k] = join(xf.e[k], xf.o[k]);
-                        }
-                        if (emit) {
-                            if constexpr (HAS_CONST)
-                                if (yconst[r]) u = lane_splat<ND>(p.cval4);
-                            wbuf[r * 64] = u;
-                        }
-                        hx[J % 2][r] = xp;
-                        if constexpr (NT > 0) ht[J % NT][r] = t3p;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    __syncthreads();
-                }
-            });
-        }
-    } else {
-        // ------------------------------------------------------------ consumer
-        const int cw = wave - NWP;
-        const int j0 = cw * G;
-        unsigned ovoff[G];
-#pragma unroll
-        for (int g = 0; g < G; g++)
-            ovoff[g] = (j0 + g < ty_act && lane < nlanes) ? (unsigned)((y0 + j0 + g) * nx + x0 + LB * lane) : kOOB;
-        for (int i = 0; i < nsteps; i++) {
-            __syncthreads();
-            if (i < W - 1) continue;
-            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(out + (size_t)(zs + i - (W - 1)) * plane_elems), 0, (int)plane_bytes, 0x00020000);
-            const LV *rbuf = lds + (i & 1) * (LROWS * 64) + j0 * 64 + lane;
-            LV win[G + W - 1];
-#pragma unroll
-            for (int k = 0; k < G + W - 1; k++) win[k] = rbuf[k * 64];
-            LV res[G];
-#pragma unroll
-            for (int k = 0; k < ND; k++) {
-                unsigned e[G + W - 1], o[G + W - 1];
-#pragma unroll
-                for (int j = 0; j < G + W - 1; j++) split(reinterpret_cast<const unsigned *>(&win[j])[k], e[j], o[j]);
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    unsigned ve[W], vo[W];
-#pragma unroll
-                    for (int t = 0; t < W; t++) { ve[t] = e[g + t]; vo[t] = o[g + t]; }
-                    reinterpret_cast<unsigned *>(&res[g])[k] = join(reduce3<IS_MAX, W>(ve), reduce3<IS_MAX, W>(vo));
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < G; g++) lane_store<ND>(res[g], rout, ovoff[g]);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// r2: the same producer / consumer tile with the voxels kept "even/odd split" (two u16 per register) from the load
-// to the store.  The kernel above keeps its z history and its LDS tile PACKED (bytes) to save registers, and pays
-// for it: every step re-splits the history and the tile and re-joins the results, its x window works on seven-dword
-// windows, its y window reduces seven rows per output -- 0.29 VALU instructions per voxel where the three 7-wide
-// windows themselves need about 0.08.  Here a lane holds 8 voxels (512-voxel tiles), so the split z history of a
+// Single-launch min / max for cubic sizes 3 / 5 / 7: producer / consumer tile with the voxels kept "even/odd split"
+// (two u16 per register) from the load to the store.  The round-1 kernel (mm3u8_fused_kernel, in the history) kept its
+// z history and its LDS tile PACKED (bytes) to save registers, and paid for it: every step re-split the history and
+// the tile and re-joined the results, its x window worked on seven-dword windows, its y window reduced seven rows per
+// output -- 0.29 VALU instructions per voxel where the three 7-wide windows themselves need about 0.08.  Here a lane holds 8 voxels (512-voxel tiles), so the split z history of a
 // row is 24 registers and three rows per producer wave fit; the windows are built in two 3-input stages that share
 // their first stage between neighbouring outputs:
 //     t[i] = op3(v[i], v[i+1], v[i+2]);   out[p] = op3(t[p-3], t[p-1], t[p+1])   (W = 7)
@@ -898,78 +646,13 @@ static int launch_u8_split(const uint8_t *in, uint8_t *out, U8FusedParams &p, bo
     return MI_OK;
 }
 
-template <int W, bool IS_MAX, int NWP, int NWC, int R, int ND = 4>
-static int launch_u8_fused(const uint8_t *in, uint8_t *out, U8FusedParams &p, bool has_const, hipStream_t s)
-{
-    constexpr int ROWS = NWP * R;
-    constexpr int TY = ROWS - (W - 1);
-    constexpr int G = (TY + NWC - 1) / NWC;
-    constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
-    const size_t lds = (size_t)2 * LROWS * 256 * ND + (size_t)(kU8MaxChunk + 8) * sizeof(int);
-    static bool attr_done = false;
-    if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, false, ND>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MI_HIP(hipFuncSetAttribute((const void *)mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, true, ND>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    p.nxt = (p.nx + 256 * ND - 1) / (256 * ND);
-    p.nyt = (p.ny + TY - 1) / TY;
-    // z chunks: one workgroup per CU resident; rounds x (chunk + ramp)
-    int cus = 256;
-    {
-        static int cached = 0;
-        if (!cached) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount;
-        }
-        if (cached > 0) cus = cached;
-    }
-    const int64_t tiles = (int64_t)p.nxt * p.nyt;
-    double best = 1e300;
-    int best_nzc = 1;
-    for (int nzc = 1; nzc <= std::min(p.nz, 64); nzc++) {
-        const int chunk = (p.nz + nzc - 1) / nzc;
-        if (chunk > kU8MaxChunk) continue;
-        const int real = (p.nz + chunk - 1) / chunk;
-        const double rounds = (double)((tiles * real + cus - 1) / cus);
-        const double cost = rounds * (chunk + W - 1 + 2.0);
-        if (cost < best) { best = cost; best_nzc = real; }
-    }
-    p.zc = (p.nz + best_nzc - 1) / best_nzc;
-    if (p.zc > kU8MaxChunk) p.zc = kU8MaxChunk;
-    p.nzc = (p.nz + p.zc - 1) / p.zc;
-    const int64_t total = tiles * p.nzc;
-    if (has_const)
-        hipLaunchKernelGGL((mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, true, ND>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
-    else
-        hipLaunchKernelGGL((mm3u8_fused_kernel<W, IS_MAX, NWP, NWC, R, false, ND>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
-    MI_HIP(hipGetLastError());
-    return MI_OK;
-}
-
 template <bool IS_MAX>
-static int launch_u8_fused_w(int w, int cfg, const uint8_t *in, uint8_t *out, U8FusedParams &p, bool has_const, hipStream_t s)
+static int launch_u8_fused_w(int w, const uint8_t *in, uint8_t *out, U8FusedParams &p, bool has_const, hipStream_t s)
 {
-    // volumes narrower than 768 voxels: 8 voxels per lane (512-voxel tiles) keep the lanes busy
-    const bool narrow = p.nx < 768 || cfg == 3;
     switch (w) {
-    case 3:
-        if (cfg == 1) return launch_u8_split<3, IS_MAX, 12, 4, 3, 32>(in, out, p, has_const, s);
-        return narrow ? launch_u8_fused<3, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s)
-                      : launch_u8_fused<3, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
-    case 5:
-        if (cfg == 1) return launch_u8_split<5, IS_MAX, 12, 4, 3, 32>(in, out, p, has_const, s);
-        return narrow ? launch_u8_fused<5, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s)
-                      : launch_u8_fused<5, IS_MAX, 12, 4, 3>(in, out, p, has_const, s);
-    default:
-        if (cfg == 1) return launch_u8_split<7, IS_MAX, 13, 3, 3, 32>(in, out, p, has_const, s);
-        if (cfg == 2) return launch_u8_fused<7, IS_MAX, 12, 4, 2>(in, out, p, has_const, s);
-        if (narrow) return launch_u8_fused<7, IS_MAX, 12, 4, 3, 2>(in, out, p, has_const, s);
-        // 12 waves x 168 VGPRs: three rows per producer wave need ~150 registers (packed z history 72)
-        return launch_u8_fused<7, IS_MAX, 9, 3, 3>(in, out, p, has_const, s);
+    case 3: return launch_u8_split<3, IS_MAX, 12, 4, 3, 32>(in, out, p, has_const, s);
+    case 5: return launch_u8_split<5, IS_MAX, 12, 4, 3, 32>(in, out, p, has_const, s);
+    default: return launch_u8_split<7, IS_MAX, 13, 3, 3, 32>(in, out, p, has_const, s);
     }
 }
 
@@ -977,8 +660,7 @@ static int launch_u8_fused_w(int w, int cfg, const uint8_t *in, uint8_t *out, U8
 
 using namespace mi;
 
-// test / tuning hook (not part of the C-ABI): 0 = always take the two-launch path, 1 = split-form kernel (default),
-// 2-4 = round-1 packed kernels (tile variants)
+// test / tuning hook (not part of the C-ABI): 0 = always take the two-launch path
 static int g_u8_fused = 1;
 extern "C" int mi_debug_set_u8_fused(int enabled) { g_u8_fused = enabled; return MI_OK; }
 
@@ -1023,8 +705,8 @@ extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int
         f.mz = filter_mode(mode[0]); f.my = filter_mode(mode[1]); f.mx = filter_mode(mode[2]);
         f.cval4 = p.cval4;
         const bool has_const = f.mz == MI_MODE_CONSTANT || f.my == MI_MODE_CONSTANT || f.mx == MI_MODE_CONSTANT;
-        return is_max ? launch_u8_fused_w<true>(size[0], g_u8_fused, ip, op, f, has_const, s)
-                      : launch_u8_fused_w<false>(size[0], g_u8_fused, ip, op, f, has_const, s);
+        return is_max ? launch_u8_fused_w<true>(size[0], ip, op, f, has_const, s)
+                      : launch_u8_fused_w<false>(size[0], ip, op, f, has_const, s);
     }
 
     // pass A: x fused with z (into tmp if a y pass follows), pass B: y
