@@ -347,10 +347,6 @@ __device__ __forceinline__ F4 xpass_packed(const F4 v, const float (&sL)[NE], co
     for (int m = 0; m < NP; m++) A[m] = (f32x2){e[2 * m], e[2 * m + 1]};
     A[RXE / 2] = v.lo;
     A[RXE / 2 + 1] = v.hi;
-    if constexpr (WX >= 9) {
-        // 9 taps: the dot form needs no shifted copy of the window (10 registers that the 8-plane ring cannot spare)
-        return xdot<WX, NP, RXE - RX>(A, wx);
-    }
 #pragma unroll
     for (int m = 0; m < NP - 1; m++) S[m] = (f32x2){A[m].y, A[m + 1].x};
     F4 o;
@@ -379,7 +375,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
     constexpr int RX = W / 2;
     constexpr int NE = RX <= 2 ? 2 : 4;
     constexpr int RINGN = W - 1;                          // even (W odd), >= 2
-    static_assert(W >= 3 && (W & 1), "lean kernel: odd W >= 3");
+    static_assert(W >= 3 && W <= 7 && (W & 1), "lean kernel: odd W, 3 .. 7 (9 .. 17: sep3d_long.hip)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *lds = reinterpret_cast<float4 *>(smem);                     // [2][LROWS][64]
     int *ztab = reinterpret_cast<int *>(smem + (size_t)2 * LROWS * 1024); // source plane per step
@@ -507,43 +503,6 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
                     for (int k = 0; k < NE; k++) {
                         eg[k] = pick<NE>(s.t, eidx[k]);
                         if constexpr (HAS_CONST) eg[k] = (e_is_cval || s.zconst) ? p.cval : eg[k];
-                    }
-                    if constexpr (W >= 9) {
-                        // 9 taps: one row at a time (x pass, then its z pass) keeps a single x-filtered row live
-#pragma unroll
-                        for (int r = 0; r < R; r++) {
-                            F4 v = s.v[r];
-                            if constexpr (HAS_CONST)
-                                if (yconst[r] || s.zconst) v = f4_splat(p.cval);
-                            float sL[NE], sR[NE];
-#pragma unroll
-                            for (int k = 0; k < NE; k++) {
-                                sL[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), r));
-                                sR[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), 32 + r));
-                            }
-                            const F4 xr = xpass_packed<W, NE>(v, sL, sR, lane, last, p.wx);
-                            if (r == R - 1 && i + DEPTH < nsteps) issue(i + DEPTH, s);
-                            if (emit) {
-                                F4 a;
-                                if (rev) {      // the newest plane is the lowest: tap 0 first, the ring newest to oldest
-                                    a = f4_scale(p.wz[0], xr);
-#pragma unroll
-                                    for (int k = 1; k < W; k++) a = f4_fma(p.wz[k], ring[(J + RINGN - k) % RINGN][r], a);
-                                } else {
-                                    a = f4_scale(p.wz[0], ring[J % RINGN][r]);
-#pragma unroll
-                                    for (int k = 1; k < RINGN; k++) a = f4_fma(p.wz[k], ring[(J + k) % RINGN][r], a);
-                                    a = f4_fma(p.wz[W - 1], xr, a);
-                                }
-                                if constexpr (HAS_CONST)
-                                    if (yconst[r]) a = f4_splat(p.cval);
-                                wbuf[r * 64] = f4_to_float4(a);
-                            }
-                            ring[J % RINGN][r] = xr;
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        __syncthreads();
-                        return;
                     }
                     F4 xf[R];
 #pragma unroll
@@ -690,12 +649,8 @@ static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams 
         if (cfg == 6) return launch_sep3d_lean<5, 10, 6, 2>(in, out, p, hc, s);
         if (cfg == 8) return launch_sep3d_lean<5, 12, 4, 3, 2>(in, out, p, hc, s);
         return launch_sep3d_lean<5, 12, 4, 3, 1>(in, out, p, hc, s);   // measured best: 1 WG/CU, 16 waves
-    case 7:
-        return launch_sep3d_lean<7, 8, 4, 3>(in, out, p, hc, s);
     default:
-        if (cfg == 6) return launch_sep3d_lean<9, 12, 4, 2, 1>(in, out, p, hc, s);
-        // 8 waves x 251 VGPRs: the 8-plane ring of 4 rows does not fit the 128 registers of a 16-wave group
-        return launch_sep3d_lean<9, 6, 2, 4, 1>(in, out, p, hc, s);
+        return launch_sep3d_lean<7, 8, 4, 3>(in, out, p, hc, s);
     }
 }
 
@@ -892,7 +847,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
 
     const int cfg = g_sep3d_cfg;
     const bool cubic = w[0] == w[1] && w[1] == w[2] && w[0] >= 3 && p.oz == w[0] / 2 && p.oy == w[1] / 2;
-    const bool lean = cubic && g_sep3d_kernel != 1 && ny * nx * 4 < ((int64_t)1 << 31);
+    const bool lean = cubic && w[0] <= 7 && g_sep3d_kernel != 1 && ny * nx * 4 < ((int64_t)1 << 31);    // 9 taps: sep3d_long.hip
     int cfg_use = cfg, rows = 0, nzc = 1;
     if (lean && cfg == 0) {
         // candidates: the big tile and (3 / 5 taps) a small one
