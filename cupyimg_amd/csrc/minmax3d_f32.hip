@@ -21,6 +21,7 @@ struct MmLongParams {
     int oy, oz;             // w/2 + origin along y and z (x: W/2)
     int mx, my, mz;         // boundary modes (never constant)
     int zc, nxt, nyt, nzc;
+    int tw;                 // tile width in floats (<= 256, multiple of 4)
 };
 
 template <bool IS_MAX> __device__ __forceinline__ float mm2(float a, float b) { return IS_MAX ? fmaxf(a, b) : fminf(a, b); }
@@ -66,11 +67,11 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
 
     const int nx = p.nx, ny = p.ny, nz = p.nz;
-    const int x0 = xt * 256, y0 = yt * kLongTY;
+    const int x0 = xt * p.tw, y0 = yt * kLongTY;
     const int zs = zci * p.zc, ze = min(zs + p.zc, nz);
     const int ty_act = min(kLongTY, ny - y0);
     const int rows_needed = ty_act + W - 1;
-    const int nlanes = min(64, (nx - x0) >> 2);
+    const int nlanes = min(p.tw >> 2, (nx - x0) >> 2);
     const int last = nlanes - 1;
     const int xe = x0 + 4 * nlanes;
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
@@ -231,6 +232,7 @@ int run_minmax3d_f32_fused(const float *in, float *out, int nz, int ny, int nx, 
     p.oy = oy; p.oz = oz;
     p.mx = mx; p.my = my; p.mz = mz;
     p.nxt = (nx + 255) / 256;
+    p.tw = (((nx + p.nxt - 1) / p.nxt) + 3) & ~3;          // equal tiles (see separable3d.hip)
     p.nyt = (ny + kLongTY - 1) / kLongTY;
     const int ncu = mm_long_cus();
     const int cols = p.nxt * p.nyt;

@@ -41,6 +41,7 @@ struct LongParams {
     int mx, my, mz;         // boundary modes (filter_mode()-normalised, never constant)
     int zc;                 // output planes per chunk
     int nxt, nyt, nzc;      // tile counts
+    int tw;                 // tile width in floats (<= 256, multiple of 4)
     // output planes to produce: up to two plane ranges [zb, zb + zn), the first covered by chunks 0 .. nzc0-1, the
     // second by the rest (whole volume: zb0 = 0, zn0 = nz, nzc0 = nzc).  Boundary handling always refers to nz.
     int zb0, zn0, zb1, zn1, nzc0;
@@ -123,7 +124,7 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
 
     const int nx = p.nx, ny = p.ny, nz = p.nz;
-    const int x0 = xt * 256, y0 = yt * kLongTY;
+    const int x0 = xt * p.tw, y0 = yt * kLongTY;
     int zs, ze;
     {
         const bool second = zci >= p.nzc0;
@@ -133,7 +134,7 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     }
     const int ty_act = min(kLongTY, ny - y0);
     const int rows_needed = ty_act + W - 1;
-    const int nlanes = min(64, (nx - x0) >> 2);
+    const int nlanes = min(p.tw >> 2, (nx - x0) >> 2);
     const int last = nlanes - 1;
     const int xe = x0 + 4 * nlanes;
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
@@ -343,6 +344,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
     p.oy = oy; p.oz = oz;
     p.mx = mx; p.my = my; p.mz = mz;
     p.nxt = (nx + 255) / 256;
+    p.tw = (((nx + p.nxt - 1) / p.nxt) + 3) & ~3;          // equal tiles (see separable3d.hip)
     p.nyt = (ny + kLongTY - 1) / kLongTY;
     double sx = 0, sy = 0, sz = 0;
     for (int k = 0; k < w; k++) {

@@ -15,6 +15,7 @@ struct Sep3dParams {
     int ty;                 // output rows per tile
     int zc;                 // output planes per chunk
     int nxt, nyt, nzc;      // tile counts
+    int tw;                 // tile width in floats (<= 256, multiple of 4): the row is split into nxt EQUAL tiles
     // output planes to produce: up to two plane ranges [zb, zb + zn), the first
     // covered by chunks 0 .. nzc0-1, the second by the rest (whole volume:
     // zb0 = 0, zn0 = nz, nzc0 = nzc).  Boundary handling always refers to nz.
