@@ -179,7 +179,8 @@ def main():
 
     if not ca.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible")
-    ca.set_device(local_rank)
+    # one rank per GPU; on a box with fewer GPUs than ranks (functional dry runs only) ranks share devices
+    ca.set_device(local_rank % max(ca.device_count(), 1))
 
     dist = None
     if world > 1:
