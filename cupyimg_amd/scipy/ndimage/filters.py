@@ -179,7 +179,7 @@ def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
             return None
     if weights[2] is not None and origins[2] != 0:
         return None
-    if input.shape[2] < 8 or input.shape[2] % 4 or input.shape[2] % 256 == 4:
+    if input.shape[2] < 8 or input.shape[2] % 4:
         return None
     if input.size == 0:
         return None

@@ -110,6 +110,17 @@ def test_convolve_separable(gpu):
     want = sndi.convolve1d(sndi.convolve1d(x, ws[0], axis=0, mode="nearest"), ws[1], axis=2, mode="nearest")
     got = ca.convolve_separable(gpu.asarray(x), [gpu.asarray(ws[0]), ws[1]], axes=(0, 2), mode="nearest")
     np.testing.assert_allclose(got.get(), want, rtol=1e-12, atol=1e-12)
+    # float32 volumes with odd kernels: all passes in one fused launch (float32 accumulation, like convolve1d's default)
+    v = rng.standard_normal((40, 36, 264)).astype(np.float32)
+    for ws_, axes, kw in [([rng.standard_normal(5)] * 3, None, {}), ([rng.standard_normal(3), rng.standard_normal(9)], (2, 0), {"mode": "mirror"}),
+                          ([rng.standard_normal(13)], (1,), {"mode": "wrap", "origin": 2}), ([rng.standard_normal(7)] * 3, None, {"mode": "constant", "cval": 0.5})]:
+        wl = ws_[0] if axes is None else ws_
+        want = v.astype(np.float64)
+        for ax, w0 in zip(range(3) if axes is None else axes, ws_ if axes is not None else ws_):
+            want = sndi.convolve1d(want, w0, axis=ax, **kw)
+        got = ca.convolve_separable(gpu.asarray(v), wl, axes=axes, **kw)
+        assert got.dtype == np.float32
+        assert np.abs(got.get() - want).max() <= 2e-6 * np.abs(want).max(), (axes, kw)
     with pytest.raises(ValueError):
         ca.convolve_separable(gpu.asarray(x), [w], axes=(0, 1))
     with pytest.raises(ValueError):
