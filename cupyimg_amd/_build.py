@@ -34,6 +34,7 @@ SOURCES = [
     ("stencil3d.hip", ["-ffp-contract=off"]),
     ("minmax.hip", ["-ffp-contract=off"]),
     ("minmax3d_u8.hip", []),
+    ("median2d.hip", []),
     ("binary.hip", []),
     ("binary3d.hip", []),
     ("interp.hip", ["-ffp-contract=off"]),

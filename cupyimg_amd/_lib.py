@@ -105,6 +105,7 @@ SIGNATURES = {
     "mi_minmax3d_f32": [_arr, _arr, _ip, _ip, _ip, _d, _i, _vp],
     "mi_minmax_nd": [_arr, _arr, _u8p, _dp, _i64p, _ip, _i, _d, _i, _vp],
     "mi_rank_filter": [_arr, _arr, _u8p, _i64p, _ip, _i, _i, _d, _vp],
+    "mi_median3x3": [_arr, _arr, _ip, _d, _vp],
     "mi_binary_erosion": [_arr, _arr, _u8p, _i64p, _ip, _arr, _i, _i, _vp, _vp],
     "mi_map_coordinates": [_arr, _arr, _arr, _i, _i, _d, _vp],
     "mi_affine_transform": [_arr, _arr, _dp, _i, _i, _d, _vp],

@@ -188,9 +188,10 @@ template <int WX, int WA, bool IS_MAX>
 __global__ void __launch_bounds__(256)
 stream_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8StreamParams p)
 {
-    constexpr int DEPTH = 2;
     constexpr int RINGN = WA - 1;
-    constexpr int U = RINGN > 0 ? (RINGN % 2 == 0 ? RINGN : 2 * RINGN) : DEPTH;
+    constexpr int DEPTH = WA == 11 ? 2 : 4;          // loads in flight per wave (11 samples: the unrolled ring would be 20 steps)
+    constexpr int U = RINGN > 0 ? (RINGN % DEPTH == 0 ? RINGN : (RINGN % 2 == 0 && DEPTH == 4 ? 2 * RINGN : DEPTH * RINGN)) : DEPTH;
+    static_assert(U % DEPTH == 0 && (RINGN == 0 || U % RINGN == 0), "unroll must cover ring and slots");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -302,16 +303,194 @@ stream_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     }
 }
 
+// ---------------------------------------------------------------------------
+// 3 x 3 median of uint8 images, one streaming launch (entry point: mi_median3x3, median2d.hip; the float32 kernel and
+// the method are described there).  16 pixels per lane in even/odd split form; med3 = max(min(a,b), min(max(a,b),c)).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned med3u(unsigned a, unsigned b, unsigned c)
+{
+    const unsigned mn = op2<false>(a, b), mx = op2<true>(a, b);
+    return op2<true>(mn, op2<false>(mx, c));
+}
+__device__ __forceinline__ void sort3u(unsigned a, unsigned b, unsigned c, unsigned &lo, unsigned &mid, unsigned &hi)
+{
+    lo = op3<false>(a, b, c);
+    hi = op3<true>(a, b, c);
+    mid = med3u(a, b, c);
+}
+// T[i] = S[i - 1] (prev_o3 = the O register that ends just left of the lane) / T[i] = S[i + 1] (next_e0 likewise)
+__device__ __forceinline__ Vec16 shl1(const Vec16 &s, unsigned prev_o3)
+{
+    Vec16 t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { t.e[k] = align16(s.o[k], k ? s.o[k - 1] : prev_o3); t.o[k] = s.e[k]; }
+    return t;
+}
+__device__ __forceinline__ Vec16 shr1(const Vec16 &s, unsigned next_e0)
+{
+    Vec16 t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { t.e[k] = s.o[k]; t.o[k] = align16(k < 3 ? s.e[k + 1] : next_e0, s.e[k]); }
+    return t;
+}
+
+__global__ void __launch_bounds__(256)
+median3x3_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8StreamParams p)
+{
+    constexpr int DEPTH = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nlines = nz * p.nxt;
+    const int wid = blockIdx.x * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int z = line / p.nxt, xt = line - z * p.nxt;
+    const int x0 = xt * 1024;
+    const int nlanes = min(64, (nx - x0) >> 4);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;
+    const unsigned rowbase = (unsigned)z * plane;
+    const unsigned total_bytes = plane * (unsigned)nz;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? rowbase + (unsigned)(x0 + 16 * lane) : kOOB;
+    const int side = lane == 0 ? 0 : 1;
+    int est, ekind;
+    edge_u8(side, x0, x0 + 16 * nlanes, nx, p.mx, &est, &ekind);
+    const unsigned evoff = ((lane == 0 || lane == last) && ekind != EDGE_CONST) ? rowbase + (unsigned)est : kOOB;
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, ny);
+    const int nsteps = a1 - a0 + 2;
+    const int ai0 = a0 - 1;
+
+    struct Slot { u32x4 v; unsigned e; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        const int ai = bmap<int>(ai0 + i, ny, p.ma);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * (unsigned)nx;
+        s.v = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0);
+        s.e = __builtin_amdgcn_raw_buffer_load_b32(rin, s.cst ? kOOB : evoff, soff, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    Vec16 rv[2];
+    unsigned ree[2], reo[2];            // edge dword of the two previous rows, split
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) rv[h].e[k] = rv[h].o[k] = 0;
+        ree[h] = reo[h] = 0;
+    }
+    for (int i0 = 0; i0 < nsteps; i0 += DEPTH) {
+        static_for<DEPTH>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J];
+                u32x4 v = s.v;
+                unsigned ed = s.e;
+                if (s.cst) { v.x = v.y = v.z = v.w = p.cval4; ed = p.cval4; }
+                else {
+                    if (ekind == EDGE_REV) ed = bswap32(ed);
+                    else if (ekind == EDGE_SPLAT) ed = (side == 0 ? (ed & 0xFFu) : (ed >> 24)) * 0x01010101u;
+                    else if (ekind == EDGE_CONST) ed = p.cval4;
+                }
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                Vec16 cur;
+                split(v.x, cur.e[0], cur.o[0]); split(v.y, cur.e[1], cur.o[1]);
+                split(v.z, cur.e[2], cur.o[2]); split(v.w, cur.e[3], cur.o[3]);
+                unsigned ce, co;
+                split(ed, ce, co);
+                if (i >= 2) {
+                    Vec16 lo, mid, hi;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        sort3u(rv[0].e[k], rv[1].e[k], cur.e[k], lo.e[k], mid.e[k], hi.e[k]);
+                        sort3u(rv[0].o[k], rv[1].o[k], cur.o[k], lo.o[k], mid.o[k], hi.o[k]);
+                    }
+                    // edge column, sorted: the left neighbour is byte 3 of the edge dword (high half of O), the right
+                    // neighbour byte 0 (low half of E)
+                    unsigned elo_e, emid_e, ehi_e, elo_o, emid_o, ehi_o;
+                    sort3u(ree[0], ree[1], ce, elo_e, emid_e, ehi_e);
+                    sort3u(reo[0], reo[1], co, elo_o, emid_o, ehi_o);
+                    auto from_left = [&](unsigned keep, unsigned x) {
+                        return (unsigned)__builtin_amdgcn_update_dpp((int)keep, (int)x, 0x138, 0xf, 0xf, false);
+                    };
+                    auto from_right = [&](unsigned keep, unsigned x) {
+                        const unsigned r = (unsigned)__builtin_amdgcn_update_dpp((int)keep, (int)x, 0x130, 0xf, 0xf, false);
+                        return lane == last ? keep : r;
+                    };
+                    const Vec16 lo_l = shl1(lo, from_left(elo_o, lo.o[3])), lo_r = shr1(lo, from_right(elo_e, lo.e[0]));
+                    const Vec16 mid_l = shl1(mid, from_left(emid_o, mid.o[3])), mid_r = shr1(mid, from_right(emid_e, mid.e[0]));
+                    const Vec16 hi_l = shl1(hi, from_left(ehi_o, hi.o[3])), hi_r = shr1(hi, from_right(ehi_e, hi.e[0]));
+                    u32x4 u;
+                    unsigned oe[4], oo[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        oe[k] = med3u(op3<true>(lo_l.e[k], lo.e[k], lo_r.e[k]), med3u(mid_l.e[k], mid.e[k], mid_r.e[k]),
+                                      op3<false>(hi_l.e[k], hi.e[k], hi_r.e[k]));
+                        oo[k] = med3u(op3<true>(lo_l.o[k], lo.o[k], lo_r.o[k]), med3u(mid_l.o[k], mid.o[k], mid_r.o[k]),
+                                      op3<false>(hi_l.o[k], hi.o[k], hi_r.o[k]));
+                    }
+                    u.x = join(oe[0], oo[0]); u.y = join(oe[1], oo[1]); u.z = join(oe[2], oo[2]); u.w = join(oe[3], oo[3]);
+                    const unsigned so = (unsigned)(a0 + i - 2) * (unsigned)nx;
+                    buffer_store_b128_soff(u, rout, voff, so);
+                }
+                rv[J % 2] = cur;        // overwrites the older of the two rows (the sorts are symmetric in their inputs)
+                ree[J % 2] = ce;
+                reo[J % 2] = co;
+            }
+        });
+    }
+}
+
+int run_median3x3_u8(const uint8_t *in, uint8_t *out, int nz, int ny, int nx, int mx, int my, int cval, hipStream_t s)
+{
+    U8StreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.nx = nx; p.ny = ny; p.nz = nz;
+    p.axis = 1; p.oa = 1; p.ma = my; p.mx = mx;
+    p.cval4 = (unsigned)cval * 0x01010101u;
+    p.nxt = (nx + 1023) / 1024;
+    const int nlines = nz * p.nxt;
+    int nch = (4096 + nlines - 1) / nlines;
+    if (nch > ny / 8) nch = ny / 8;
+    if (nch < 1) nch = 1;
+    p.chunk = (ny + nch - 1) / nch;
+    p.nchunks = (ny + p.chunk - 1) / p.chunk;
+    const int waves = nlines * p.nchunks;
+    hipLaunchKernelGGL(median3x3_u8_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
 template <int WX, int WA, bool IS_MAX>
 static int launch_u8(const uint8_t *in, uint8_t *out, U8StreamParams &p, hipStream_t s)
 {
     const int nA = p.axis == 0 ? p.nz : p.ny;
     const int nother = p.axis == 0 ? p.ny : p.nz;
     const int nlines = nother * p.nxt;
-    int nch = (4096 + nlines - 1) / nlines;
-    const int min_chunk = 8 * (WA - 1) + 8;
-    if (nch > nA / min_chunk) nch = nA / min_chunk;
-    if (nch < 1) nch = 1;
+    // chunks along the streamed axis: time ~ rounds x (chunk + ramp) with 256 CUs x 16 resident waves; volumes have
+    // many lines and get long chunks, images (a handful of 1024-pixel columns) many short ones
+    int nch = 1;
+    {
+        double best = 1e300;
+        for (int c = 1; c <= nA && c <= 2048; c++) {
+            const int chunk = (nA + c - 1) / c;
+            if (c > 1 && chunk < 8) break;
+            const int real = (nA + chunk - 1) / chunk;
+            const double rounds = std::max(1.0, (double)nlines * real / 4096.0);
+            const double cost = rounds * (chunk + (WA - 1) + 4.0);
+            if (cost < best * 0.999) { best = cost; nch = real; }
+        }
+    }
     p.chunk = (nA + nch - 1) / nch;
     p.nchunks = (nA + p.chunk - 1) / p.chunk;
     const int waves = nlines * p.nchunks;
@@ -707,6 +886,14 @@ extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int
         const bool has_const = f.mz == MI_MODE_CONSTANT || f.my == MI_MODE_CONSTANT || f.mx == MI_MODE_CONSTANT;
         return is_max ? launch_u8_fused_w<true>(size[0], ip, op, f, has_const, s)
                       : launch_u8_fused_w<false>(size[0], ip, op, f, has_const, s);
+    }
+
+    // images (one plane) and volumes without a z window: x fused into the y pass, one launch
+    if (size[0] == 1 && size[1] > 1 && size[2] > 1) {
+        p.axis = 1; p.oa = size[1] / 2; p.ma = filter_mode(mode[1]);
+        rc = is_max ? launch_u8_wx<true>(size[2], size[1], ip, op, p, s) : launch_u8_wx<false>(size[2], size[1], ip, op, p, s);
+        if (rc == MI_ERR_UNSUPPORTED) set_error("minmax3d_u8: no kernel for this size");
+        return rc;
     }
 
     // pass A: x fused with z (into tmp if a y pass follows), pass B: y

@@ -713,6 +713,8 @@ static int g_sep3d_dbg = 0;       // ablation flags
 static int g_sep3d_kernel = 0;    // 0 = auto, 1 = force general (ws) kernel
 static int g_sep3d_zrev = 1;      // 1 = odd z chunks of the lean kernel stream downwards (ramp planes shared in time)
 extern "C" int mi_debug_set_sep3d_zrev(int k) { g_sep3d_zrev = k; return MI_OK; }
+static int g_sep3d_image2d = 1;   // test hook: 0 = images with <= 9 taps take the tiled volume kernel (round-1 behaviour)
+extern "C" int mi_debug_set_sep3d_image2d(int k) { g_sep3d_image2d = k; return MI_OK; }
 static int g_sep3d_long = 0;      // 0 = auto (cubic 9..17 taps), 1 = off (lean kernel / streaming passes), 2 = also for 3..7 taps
 extern "C" int mi_debug_set_sep3d_long(int k) { g_sep3d_long = k; return MI_OK; }
 extern "C" int mi_debug_set_sep3d_cfg(int cfg) { g_sep3d_cfg = cfg; return MI_OK; }
@@ -796,7 +798,17 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
                             wbuf[0], oy, oz, p.mx, p.my, p.mz, (float)cval, zb, zn, resolve_stream(stream));
         if (rc != MI_ERR_UNSUPPORTED) return rc;
     }
-    if (w[0] > kMaxTaps || w[1] > kMaxTaps || w[2] > kMaxTaps) {
+    // 2-D images (one-plane volumes) with the same tap count on both axes: the streaming pass along y with the x
+    // pass fused is ONE launch at 8 B/pixel for every odd tap count up to 17 (r2: 3..9 taps used to take the tiled
+    // volume kernel below, whose one-plane "chunks" have no pipeline: 8192^2 uniform 5 ran at 37 % of the roofline)
+    bool image2d = false;
+    if (g_sep3d_image2d && nz == 1 && w[0] == 1 && w[1] == w[2] && w[1] >= 3 && w[1] <= kMaxTaps && whole &&
+        ny * nx * 4 < ((int64_t)1 << 31)) {
+        const int nb = (w[2] / 2 + 3) / 4;
+        const int64_t tail = nx & 255;
+        image2d = !(nx < 4 * nb + 4 || (tail != 0 && tail < 4 * nb + 4));
+    }
+    if (image2d || w[0] > kMaxTaps || w[1] > kMaxTaps || w[2] > kMaxTaps) {
         // long kernels: streaming passes (stream3d.hip), x fused into the z pass when the tap counts agree
         if (!whole) UNSUP("plane ranges are not available for kernels longer than 9 taps");
         if (nz * ny * nx * 4 >= ((int64_t)1 << 31)) UNSUP("streaming passes need a volume < 2 GiB");

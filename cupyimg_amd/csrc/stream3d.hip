@@ -10,42 +10,6 @@
 
 namespace mi {
 
-// block j (1 = nearest, 2 = next) of 4 floats outside the tile on `side`
-// (0 left, 1 right): element offset inside the row to load 4 floats from, and
-// what to do with them
-__device__ __forceinline__ void edge_block(int side, int j, int x0, int xe, int nx, int mode, int *start, int *kind)
-{
-    if (side == 0) {
-        if (x0 - 4 * j >= 0) { *start = x0 - 4 * j; *kind = EDGE_FWD; return; }
-        const int k0 = 4 * j - x0;   // how far the block's far end reaches beyond the array (x0 is a multiple of 256: 0 here)
-        (void)k0;
-        switch (mode) {
-        case MI_MODE_REFLECT:   *start = 4 * (j - 1); *kind = EDGE_REV; break;        // ext -k = x[k-1]
-        case MI_MODE_MIRROR:    *start = 4 * (j - 1) + 1; *kind = EDGE_REV; break;    // ext -k = x[k]
-        case MI_MODE_NEAREST:   *start = 0; *kind = EDGE_SPLAT; break;
-        case MI_MODE_GRID_WRAP: *start = nx - 4 * j; *kind = EDGE_FWD; break;
-        default:                *start = 0; *kind = EDGE_CONST; break;
-        }
-    } else {
-        if (xe + 4 * j <= nx) { *start = xe + 4 * (j - 1); *kind = EDGE_FWD; return; }
-        switch (mode) {
-        case MI_MODE_REFLECT:   *start = nx - 4 * j; *kind = EDGE_REV; break;         // ext n-1+k = x[n-k]
-        case MI_MODE_MIRROR:    *start = nx - 1 - 4 * j; *kind = EDGE_REV; break;     // ext n-1+k = x[n-1-k]
-        case MI_MODE_NEAREST:   *start = nx - 4; *kind = EDGE_SPLAT; break;           // splat component 3
-        case MI_MODE_GRID_WRAP: *start = 4 * (j - 1); *kind = EDGE_FWD; break;
-        default:                *start = 0; *kind = EDGE_CONST; break;
-        }
-    }
-}
-
-__device__ __forceinline__ float4 apply_kind(float4 t, int kind, int side, float cval)
-{
-    if (kind == EDGE_REV) return make_float4(t.w, t.z, t.y, t.x);
-    if (kind == EDGE_SPLAT) { const float s = side == 0 ? t.x : t.w; return make_float4(s, s, s, s); }
-    if (kind == EDGE_CONST) return make_float4(cval, cval, cval, cval);
-    return t;
-}
-
 __device__ __forceinline__ float4 dpp4_from_left(const float4 keep, const float4 v)
 {
     return make_float4(dpp_from_left(keep.x, v.x), dpp_from_left(keep.y, v.y), dpp_from_left(keep.z, v.z),

@@ -399,11 +399,17 @@ def _launch_minmax1d(src, dst, axis, size, origin, mode, cval, is_max):
 def _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max):
     if S.current_planes() is not None:
         raise S.Unsupported("min/max filters cannot be restricted to a range of output planes")
-    if input.ndim != 3 or input.dtype != np.uint8 or output.dtype != np.uint8 or input.size == 0:
+    if input.ndim not in (2, 3) or input.dtype != np.uint8 or output.dtype != np.uint8 or input.size == 0:
         return None
+    out3 = output
+    if input.ndim == 2:
+        # an image is a one-plane volume: x and y windows in one streaming launch
+        as3 = lambda a: a._view([1] + list(a.shape), [a.strides[0] * a.shape[0]] + list(a.strides), a.ptr)   # noqa: E731
+        input, out3 = as3(input), as3(output)
+        sizes, origins, modes = [1] + list(sizes), [0] + list(origins), ["reflect"] + list(modes)
     src = core.ascontiguousarray(input)
-    direct = output._is_c_contiguous() and not core.shares_memory(output, src)
-    dst = output if direct else core.empty(output.shape, output.dtype)
+    direct = out3._is_c_contiguous() and not core.shares_memory(out3, src)
+    dst = out3 if direct else core.empty(out3.shape, out3.dtype)
     a, b = src._desc(), dst._desc()
     # SciPy compares cval as a double and casts after every pass; the byte
     # kernel is only equivalent when cval is itself a uint8 value
@@ -419,7 +425,7 @@ def _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max):
     except S.Unsupported:
         return None
     if not direct:
-        output[...] = dst
+        out3[...] = dst
     return output
 
 
@@ -473,7 +479,7 @@ def _min_or_max_filter(input, size, ftprnt, structure, output, mode, cval, origi
             return output
         if input.size == 0:
             return output
-        if input.ndim == 3:
+        if input.ndim in (2, 3):
             res = _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max)
             if res is not None:
                 return res
@@ -670,6 +676,21 @@ def gaussian_gradient_magnitude(input, sigma, output=None, mode="reflect", cval=
 # ----------------------------------------------------------------------------
 # rank / median / percentile (filters.py:1560-1848)
 # ----------------------------------------------------------------------------
+def _try_median3x3(input, output, mode, cval):
+    """3 x 3 median of float32 / uint8 images (volumes: footprint (1, 3, 3)) as one streaming launch."""
+    src = core.ascontiguousarray(input)
+    direct = output._is_c_contiguous() and not core.shares_memory(output, src)
+    dst = output if direct else core.empty(output.shape, output.dtype)
+    a, b = src._desc(), dst._desc()
+    try:
+        S.check(S.lib().mi_median3x3(ctypes.byref(a), ctypes.byref(b), S.c_ints([S.mode_code(mode)] * 2), float(cval), None))
+    except S.Unsupported:
+        return None
+    if not direct:
+        output[...] = dst
+    return output
+
+
 def _rank_filter(input, rank, size, footprint, output, mode, cval, origin, operation):
     if size is not None and footprint is not None:
         warnings.warn("ignoring size because footprint is set", UserWarning, stacklevel=3)
@@ -714,6 +735,12 @@ def _rank_filter(input, rank, size, footprint, output, mode, cval, origin, opera
     if input.size == 0:
         return output
     fp = np.ascontiguousarray(footprint, dtype=np.uint8)
+    if (rank == 4 and filter_size == 9 and fp.shape[-2:] == (3, 3) and fp.ndim == input.ndim and fp.ndim in (2, 3)
+            and not any(origins) and input.dtype in (np.float32, np.uint8) and output.dtype == input.dtype
+            and S.current_planes() is None):
+        res = _try_median3x3(input, output, mode, cval)
+        if res is not None:
+            return res
     fpp = fp.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
     fsh = S.c_int64s(fp.shape)
     org = S.c_ints(origins)

@@ -251,6 +251,15 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
                    const int64_t *fshape, const int *origins, int rank, int mode, double cval,
                    mi_stream stream);
 
+/* 3 x 3 median over the last two axes of a 2-D / 3-D float32 or uint8 array
+ * (median_filter(size=3) / rank_filter(rank=4) with a full 3 x 3 footprint,
+ * filters.py:1560-1701,1751-1792; skimage.filters.median's default on images):
+ * one streaming launch at 8 (float32) / 2 (uint8) B/pixel instead of the
+ * generic gather-and-sort kernel.  mode[2]: boundary modes along y and x.
+ * MI_ERR_UNSUPPORTED when not applicable (the caller runs mi_rank_filter). */
+int mi_median3x3(const mi_array *in, const mi_array *out, const int mode[2], double cval,
+                 mi_stream stream);
+
 /* ------------------------------------------------------------------ */
 /* K4: binary erosion / dilation                                        */
 /* ------------------------------------------------------------------ */

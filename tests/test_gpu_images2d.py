@@ -1,0 +1,110 @@
+"""2-D images (the shapes skimage callers pass) through the single-launch streaming kernels: separable float32
+filters with 3..17 taps, uint8 / float32 flat min / max, 3 x 3 median -- against scipy.ndimage on the same inputs.
+Integer and selection results bit-exact, float32 filters within 1e-6 (max-norm relative)."""
+import numpy as np
+import pytest
+import scipy.ndimage as sndi
+
+from _cases import maxnorm_rel
+
+pytestmark = pytest.mark.gpu
+MODES = ["reflect", "constant", "nearest", "mirror", "wrap"]
+
+
+@pytest.fixture(scope="module")
+def ndi(gpu):
+    from cupyimg_amd.scipy import ndimage
+    return ndimage
+
+
+@pytest.mark.parametrize("shape", [(37, 64), (150, 264), (61, 512), (300, 1032), (8, 8)])
+def test_separable_filters_on_images(gpu, ndi, shape):
+    rng = np.random.default_rng(70)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xd = gpu.asarray(x)
+    for mode in MODES:
+        for size in (3, 5, 7, 9):
+            ref = sndi.uniform_filter(x.astype(np.float64), size, mode=mode, cval=0.75)
+            got = ndi.uniform_filter(xd, size, mode=mode, cval=0.75).get()
+            assert got.dtype == np.float32
+            assert maxnorm_rel(got, ref) <= 1e-6, (shape, "uniform", size, mode)
+        for sigma in (0.6, 1.0, 2.0):
+            ref = sndi.gaussian_filter(x.astype(np.float64), sigma, mode=mode, cval=-0.5)
+            got = ndi.gaussian_filter(xd, sigma, mode=mode, cval=-0.5).get()
+            assert maxnorm_rel(got, ref) <= 1e-6, (shape, "gaussian", sigma, mode)
+        ref = sndi.sobel(x.astype(np.float64), axis=0, mode=mode, cval=0.25)
+        got = ndi.sobel(xd, axis=0, mode=mode, cval=0.25).get()
+        assert maxnorm_rel(got, ref) <= 1e-6, (shape, "sobel", mode)
+
+
+def test_image_kernel_matches_volume_kernel(gpu, ndi):
+    """The image path (streaming launch) against the tiled volume kernel it replaced for <= 9 taps."""
+    from cupyimg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(71)
+    x = rng.standard_normal((200, 520)).astype(np.float32)
+    xd = gpu.asarray(x)
+    for size, mode in [(3, "reflect"), (5, "mirror"), (7, "wrap"), (9, "nearest"), (5, "constant")]:
+        new = ndi.uniform_filter(xd, size, mode=mode, cval=2.0).get()
+        lib.mi_debug_set_sep3d_image2d(0)
+        try:
+            old = ndi.uniform_filter(xd, size, mode=mode, cval=2.0).get()
+        finally:
+            lib.mi_debug_set_sep3d_image2d(1)
+        assert np.abs(new - old).max() <= 1e-6 * np.abs(old).max(), (size, mode)
+
+
+@pytest.mark.parametrize("shape", [(50, 64), (33, 1040), (120, 2048 + 32), (7, 32)])
+def test_uint8_minmax_on_images(gpu, ndi, shape):
+    rng = np.random.default_rng(72)
+    x = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    xd = gpu.asarray(x)
+    for mode in MODES:
+        for size in (3, 5, 7, 9, (3, 7), (5, 1), (1, 9)):
+            for name in ("grey_erosion", "grey_dilation"):
+                ref = getattr(sndi, name)(x, size=size, mode=mode, cval=7)
+                got = getattr(ndi, name)(xd, size=size, mode=mode, cval=7).get()
+                assert got.dtype == np.uint8
+                assert np.array_equal(got, ref), (shape, name, size, mode)
+    # footprint of ones = size; output argument; maximum_filter
+    out = gpu.empty(shape, np.uint8)
+    ndi.maximum_filter(xd, footprint=np.ones((5, 5), bool), output=out)
+    assert np.array_equal(out.get(), sndi.maximum_filter(x, size=5))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "uint8"])
+@pytest.mark.parametrize("shape", [(40, 64), (65, 264), (19, 1040), (130, 2048 + 48), (3, 32), (1, 64), (2, 48)])
+def test_median3x3(gpu, ndi, dtype, shape):
+    rng = np.random.default_rng(73)
+    if dtype == "uint8":
+        x = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        x[::3, ::5] = 255
+        x[1::4, 2::7] = 0
+    else:
+        x = rng.standard_normal(shape).astype(np.float32)
+        x[::3, ::5] = np.float32(np.inf)
+        x[1::4, 2::7] = -np.float32(np.inf)
+        x[2::5, 1::3] = x[0, 0]            # ties
+    xd = gpu.asarray(x)
+    for mode in MODES:
+        ref = sndi.median_filter(x, size=3, mode=mode, cval=3)
+        got = ndi.median_filter(xd, size=3, mode=mode, cval=3).get()
+        assert got.dtype == x.dtype
+        assert np.array_equal(got, ref), (dtype, shape, mode)
+    assert np.array_equal(ndi.rank_filter(xd, 4, size=3).get(), sndi.rank_filter(x, 4, size=3))
+    assert np.array_equal(ndi.percentile_filter(xd, 50, footprint=np.ones((3, 3))).get(), sndi.percentile_filter(x, 50, size=3))
+    # other ranks / footprints / origins keep the generic kernel
+    assert np.array_equal(ndi.rank_filter(xd, 3, size=3).get(), sndi.rank_filter(x, 3, size=3))
+    if shape[0] >= 3:
+        assert np.array_equal(ndi.median_filter(xd, size=3, origin=(0, 1)).get(), sndi.median_filter(x, size=3, origin=(0, 1)))
+
+
+def test_median3x3_planes_of_a_volume(gpu, ndi):
+    rng = np.random.default_rng(74)
+    x = rng.standard_normal((5, 33, 72)).astype(np.float32)
+    u = rng.integers(0, 256, size=(4, 21, 96), dtype=np.uint8)
+    for a in (x, u):
+        for mode in ("reflect", "constant", "wrap"):
+            ref = sndi.median_filter(a, size=(1, 3, 3), mode=mode, cval=1)
+            got = ndi.median_filter(gpu.asarray(a), size=(1, 3, 3), mode=mode, cval=1).get()
+            assert np.array_equal(got, ref), (a.dtype, mode)
