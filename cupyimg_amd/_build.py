@@ -33,6 +33,13 @@ SOURCES = [
     ("correlate_nd.hip", ["-ffp-contract=off"]),
     ("stencil3d.hip", ["-ffp-contract=off"]),
     ("minmax.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p16.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p32a.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p32b.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p64a.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p64b.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p64c.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p64d.hip", ["-ffp-contract=off"]),
     ("minmax3d_u8.hip", []),
     ("median2d.hip", []),
     ("binary.hip", []),

@@ -713,6 +713,8 @@ static int g_sep3d_dbg = 0;       // ablation flags
 static int g_sep3d_kernel = 0;    // 0 = auto, 1 = force general (ws) kernel
 static int g_sep3d_zrev = 1;      // 1 = odd z chunks of the lean kernel stream downwards (ramp planes shared in time)
 extern "C" int mi_debug_set_sep3d_zrev(int k) { g_sep3d_zrev = k; return MI_OK; }
+static int g_stream_fused_max = kStreamFusedMax;    // test hook: longest kernel with the x pass fused into the streamed pass
+extern "C" int mi_debug_set_stream_fused_max(int k) { g_stream_fused_max = k; return MI_OK; }
 static int g_sep3d_image2d = 1;   // test hook: 0 = images with <= 9 taps take the tiled volume kernel (round-1 behaviour)
 extern "C" int mi_debug_set_sep3d_image2d(int k) { g_sep3d_image2d = k; return MI_OK; }
 static int g_sep3d_long = 0;      // 0 = auto (cubic 9..17 taps), 1 = off (lean kernel / streaming passes), 2 = also for 3..7 taps
@@ -824,8 +826,8 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
         struct Pass { int axis, wa, oa, ma, wx; };
         Pass passes[3];
         int np = 0;
-        const bool fuse_xz = w[2] > 1 && w[2] == w[0] && w[2] <= 17;   // longer x kernels: separate x pass (registers)
-        const bool fuse_xy = !fuse_xz && w[0] == 1 && w[2] > 1 && w[2] == w[1] && w[2] <= 17;   // 2-D images: one launch
+        const bool fuse_xz = w[2] > 1 && w[2] == w[0] && w[2] <= g_stream_fused_max;   // longer x kernels: separate x pass (registers)
+        const bool fuse_xy = !fuse_xz && w[0] == 1 && w[2] > 1 && w[2] == w[1] && w[2] <= g_stream_fused_max;   // 2-D images: one launch
         if (w[2] > 1 && !fuse_xz && !fuse_xy) passes[np++] = {1, 1, 0, p.my, w[2]};            // x only (streams over y)
         if (w[0] > 1) passes[np++] = {0, w[0], oz, p.mz, fuse_xz ? w[2] : 1};
         if (w[1] > 1) passes[np++] = {1, w[1], oy, p.my, fuse_xy ? w[2] : 1};

@@ -317,7 +317,7 @@ int run_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axi
         }
     } else if (wx == wa) {
         switch (wx) {
-#define X(N) case N: if constexpr (N <= 17 && N > 1) return launch_stream<N, N>(in, out, p, s); break;
+#define X(N) case N: if constexpr (N <= kStreamFusedMax && N > 1) return launch_stream<N, N>(in, out, p, s); break;
             MI_ODD_CASES(X)
 #undef X
         }

@@ -17,6 +17,7 @@
 namespace mi {
 
 constexpr int kStreamMaxTaps = 33;
+constexpr int kStreamFusedMax = 17;    // longest kernel whose x pass is fused into the streamed pass (same tap count on both)
 
 struct StreamParams {
     int nx, ny, nz;
