@@ -108,3 +108,25 @@ def test_median3x3_planes_of_a_volume(gpu, ndi):
             ref = sndi.median_filter(a, size=(1, 3, 3), mode=mode, cval=1)
             got = ndi.median_filter(gpu.asarray(a), size=(1, 3, 3), mode=mode, cval=1).get()
             assert np.array_equal(got, ref), (a.dtype, mode)
+
+
+def test_slicewise_and_anisotropic_volumes(gpu, ndi):
+    """Volumes filtered slice by slice (no z taps: the image kernel over all planes) and with a z kernel that differs
+    from the in-plane one (z pass + fused y/x pass)."""
+    rng = np.random.default_rng(75)
+    x = rng.standard_normal((21, 45, 264)).astype(np.float32)
+    xd = gpu.asarray(x)
+    x64 = x.astype(np.float64)
+    for mode in MODES:
+        for size in [(1, 3, 3), (1, 5, 5), (1, 9, 9), (1, 7, 7)]:
+            ref = sndi.uniform_filter(x64, size, mode=mode, cval=1.5)
+            got = ndi.uniform_filter(xd, size, mode=mode, cval=1.5).get()
+            assert maxnorm_rel(got, ref) <= 1e-6, ("uniform", size, mode)
+        for sigma in [(0, 1, 1), (0, 2, 2), (1, 2, 2), (2, 1, 1), (0.5, 2.5, 2.5), (3, 1.5, 1.5)]:
+            ref = sndi.gaussian_filter(x64, sigma, mode=mode, cval=-1.0)
+            got = ndi.gaussian_filter(xd, sigma, mode=mode, cval=-1.0).get()
+            assert maxnorm_rel(got, ref) <= 1e-6, ("gaussian", sigma, mode)
+    # per-axis modes and a y origin
+    ref = sndi.uniform_filter(x64, (1, 5, 5), mode=["nearest", "wrap", "mirror"], origin=(0, 1, 0))
+    got = ndi.uniform_filter(xd, (1, 5, 5), mode=["nearest", "wrap", "mirror"], origin=(0, 1, 0)).get()
+    assert maxnorm_rel(got, ref) <= 1e-6
