@@ -28,6 +28,7 @@ SOURCES = [
     ("correlate1d.hip", ["-ffp-contract=off"]),
     ("separable3d.hip", []),
     ("stream3d.hip", []),
+    ("stream_f64.hip", []),
     ("sep3d_long.hip", []),
     ("minmax3d_f32.hip", []),
     ("correlate_nd.hip", ["-ffp-contract=off"]),

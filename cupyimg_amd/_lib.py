@@ -98,11 +98,13 @@ SIGNATURES = {
     "mi_correlate1d": [_arr, _arr, _i, _dp, _i, _i, _i, _d, _i, _vp],
     "mi_uniform_filter1d": [_arr, _arr, _i, _i, _i, _i, _d, _vp],
     "mi_separable3d_f32": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i, _vp],
+    "mi_separable3d_f64": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _vp],
     "mi_separable3d_f32_planes": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i64p, _i, _vp],
     "mi_correlate_nd": [_arr, _arr, _dp, _i64p, _ip, _i, _d, _i, _vp],
     "mi_minmax1d": [_arr, _arr, _i, _i, _i, _i, _d, _i, _vp],
     "mi_minmax3d_u8": [_arr, _arr, _ip, _ip, _ip, _i, _i, _vp],
     "mi_minmax3d_f32": [_arr, _arr, _ip, _ip, _ip, _d, _i, _vp],
+    "mi_minmax3d_f64": [_arr, _arr, _ip, _ip, _ip, _d, _i, _vp],
     "mi_minmax_nd": [_arr, _arr, _u8p, _dp, _i64p, _ip, _i, _d, _i, _vp],
     "mi_rank_filter": [_arr, _arr, _u8p, _i64p, _ip, _i, _i, _d, _vp],
     "mi_median3x3": [_arr, _arr, _ip, _d, _vp],

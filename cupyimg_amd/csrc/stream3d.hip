@@ -27,7 +27,6 @@ __device__ __forceinline__ float4 sel4(bool c, const float4 a, const float4 b) {
 // OP: what a pass computes -- weighted sum, or running minimum / maximum (the
 // comparisons of the generic min/max kernel: first sample taken as is, then
 // `x < best` / `x > best` in ascending tap order).
-enum { SP_CORR = 0, SP_MIN = 1, SP_MAX = 2 };
 
 template <int OP>
 __device__ __forceinline__ float pick_mm(float x, float best) { return (OP == SP_MAX ? x > best : x < best) ? x : best; }
@@ -88,8 +87,6 @@ __device__ __forceinline__ F4 xpass_hops(const float4 v, const float4 (&eL)[4], 
     }
 }
 
-constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
-constexpr int lcm_(int a, int b) { return a / gcd_(a, b) * b; }
 
 template <int WX, int WA, int DEPTH, int OP = SP_CORR>
 __global__ void __launch_bounds__(256)

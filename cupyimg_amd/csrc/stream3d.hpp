@@ -38,6 +38,12 @@ struct StreamParams {
     int wpb;             // waves per workgroup of this launch
 };
 
+// what a pass computes: weighted sum, or running minimum / maximum
+enum { SP_CORR = 0, SP_MIN = 1, SP_MAX = 2 };
+
+constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
+constexpr int lcm_(int a, int b) { return a / gcd_(a, b) * b; }
+
 // block j (1 = nearest, 2 = next) of 4 floats outside the tile on `side`
 // (0 left, 1 right): element offset inside the row to load 4 floats from, and
 // what to do with them

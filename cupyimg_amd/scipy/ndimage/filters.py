@@ -170,6 +170,8 @@ def _try_fused_3d(input, output, weights, origins, modes, cval, is_box):
 
 
 def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
+    if input.ndim == 3 and input.dtype == np.float64 and output.dtype == np.float64 and planes is None:
+        return _fused_3d_f64(input, output, weights, origins, modes, cval)
     if input.ndim != 3 or input.dtype != np.float32 or output.dtype != np.float32:
         return None
     if not any(w is not None for w in weights):
@@ -207,6 +209,35 @@ def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
             flat = S.c_int64s([v for r in planes for v in r])
             S.check(S.lib().mi_separable3d_f32_planes(ctypes.byref(a), ctypes.byref(b), ptrs, wlen, org, mds,
                                                       float(cval), flat, len(planes), None))
+    except S.Unsupported:
+        return None
+    if not direct:
+        output[...] = dst
+    return output
+
+
+def _fused_3d_f64(input, output, weights, origins, modes, cval):
+    """float64 volumes / images: streaming passes with the x pass fused (mi_separable3d_f64)."""
+    if not any(w is not None for w in weights) or input.size == 0:
+        return None
+    for w in weights:
+        if w is not None and (len(w) > 33 or len(w) % 2 == 0):
+            return None
+    if (weights[2] is not None and origins[2] != 0) or input.shape[2] < 4 or input.shape[2] % 2:
+        return None
+    src = core.ascontiguousarray(input)
+    direct = output._is_c_contiguous() and not core.shares_memory(output, src)
+    dst = output if direct else core.empty(output.shape, output.dtype)
+    if src.ptr % 16 or dst.ptr % 16:
+        return None
+    keep = [None if w is None else np.ascontiguousarray(w, dtype=np.float64) for w in weights]
+    ptrs = (ctypes.POINTER(ctypes.c_double) * 3)(*[
+        ctypes.cast(None, ctypes.POINTER(ctypes.c_double)) if w is None
+        else w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for w in keep])
+    a, b = src._desc(), dst._desc()
+    try:
+        S.check(S.lib().mi_separable3d_f64(ctypes.byref(a), ctypes.byref(b), ptrs, S.c_ints([0 if w is None else len(w) for w in keep]),
+                                           S.c_ints(origins), S.c_ints([S.mode_code(m) for m in modes]), float(cval), None))
     except S.Unsupported:
         return None
     if not direct:
@@ -434,10 +465,11 @@ def _try_stream_minmax_f32(input, output, sizes, origins, modes, cval, is_max):
     passes (mi_minmax3d_f32) instead of one generic launch per axis."""
     if S.current_planes() is not None:
         raise S.Unsupported("min/max filters cannot be restricted to a range of output planes")
-    if input.dtype != np.float32 or output.dtype != np.float32 or input.size == 0:
+    if input.dtype not in (np.float32, np.float64) or output.dtype != input.dtype or input.size == 0:
         return None
     if any(int(sz) % 2 == 0 or int(sz) > 9 for sz in sizes) or int(origins[-1]) != 0:
         return None
+    entry = S.lib().mi_minmax3d_f32 if input.dtype == np.float32 else S.lib().mi_minmax3d_f64
     if input.ndim == 2:
         as3 = lambda a: a._view([1] + list(a.shape), [a.strides[0] * a.shape[0]] + list(a.strides), a.ptr)   # noqa: E731
         in3, out3 = as3(input), as3(output)
@@ -449,8 +481,8 @@ def _try_stream_minmax_f32(input, output, sizes, origins, modes, cval, is_max):
     dst = out3 if direct else core.empty(out3.shape, out3.dtype)
     a, b = src._desc(), dst._desc()
     try:
-        S.check(S.lib().mi_minmax3d_f32(ctypes.byref(a), ctypes.byref(b), S.c_ints(sizes), S.c_ints(origins),
-                                        S.c_ints([S.mode_code(m) for m in modes]), float(cval), int(is_max), None))
+        S.check(entry(ctypes.byref(a), ctypes.byref(b), S.c_ints(sizes), S.c_ints(origins),
+                      S.c_ints([S.mode_code(m) for m in modes]), float(cval), int(is_max), None))
     except S.Unsupported:
         return None
     if not direct:
@@ -566,8 +598,8 @@ def _derivative_then_smooth(input, axis, output, mode, cval, smooth):
     axis = S.normalize_axis(axis, input.ndim)
     output = S.get_output(output, input)
     modes = S.normalize_sequence(mode, input.ndim)
-    if input.ndim in (2, 3) and input.dtype == np.float32 and output.dtype == np.float32 and input.size:
-        # a separable product of 3-tap kernels: one fused launch for float32 images / volumes
+    if input.ndim in (2, 3) and input.dtype in (np.float32, np.float64) and output.dtype == input.dtype and input.size:
+        # a separable product of 3-tap kernels: one fused launch for float32 / float64 images and volumes
         for m in modes:
             S.check_mode(m)
         w = [np.asarray([-1.0, 0.0, 1.0]) if ii == axis else np.asarray(smooth, dtype=np.float64) for ii in range(input.ndim)]

@@ -236,6 +236,18 @@ int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int size[3],
 int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
                     const int mode[3], double cval, int is_max, mi_stream stream);
 
+/* float64 images and volumes (skimage's working dtype): the separable filter and the
+ * flat min / max as streaming passes, x fused into the streamed pass when the tap
+ * counts agree -- an image or a slice-wise filter is one launch (16 B/pixel), a volume
+ * two.  weights[a] NULL = axis not filtered; odd tap counts <= 33 (min / max: odd
+ * sizes <= 9), x origin 0, even x extent.  MI_ERR_UNSUPPORTED otherwise (the caller
+ * runs mi_correlate1d / mi_minmax1d per axis). */
+int mi_separable3d_f64(const mi_array *in, const mi_array *out, const double *const weights[3],
+                       const int wlen[3], const int origin[3], const int mode[3], double cval,
+                       mi_stream stream);
+int mi_minmax3d_f64(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
+                    const int mode[3], double cval, int is_max, mi_stream stream);
+
 /* n-D footprint (+ optional non-flat structure) min/max
  * (filters.py:1398-1419, kernel :1510-1557).  footprint: host uint8
  * prod(fshape); structure: host doubles or NULL. */

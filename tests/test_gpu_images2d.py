@@ -130,3 +130,41 @@ def test_slicewise_and_anisotropic_volumes(gpu, ndi):
     ref = sndi.uniform_filter(x64, (1, 5, 5), mode=["nearest", "wrap", "mirror"], origin=(0, 1, 0))
     got = ndi.uniform_filter(xd, (1, 5, 5), mode=["nearest", "wrap", "mirror"], origin=(0, 1, 0)).get()
     assert maxnorm_rel(got, ref) <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(37, 64), (150, 260), (61, 512), (9, 4), (21, 45, 136)])
+def test_float64_streaming_kernels(gpu, ndi, shape):
+    """float64 images / volumes (skimage's working dtype): separable filters and flat min / max."""
+    rng = np.random.default_rng(76)
+    x = rng.standard_normal(shape)
+    xd = gpu.asarray(x)
+    nd = len(shape)
+    for mode in MODES:
+        for size in (3, 5, 9) if shape[-1] >= 8 else (3,):
+            ref = sndi.uniform_filter(x, size, mode=mode, cval=0.75)
+            got = ndi.uniform_filter(xd, size, mode=mode, cval=0.75).get()
+            assert got.dtype == np.float64
+            assert maxnorm_rel(got, ref) <= 1e-12, (shape, "uniform", size, mode)
+            for name in ("minimum_filter", "maximum_filter"):
+                ref = getattr(sndi, name)(x, size=size, mode=mode, cval=0.25)
+                got = getattr(ndi, name)(xd, size=size, mode=mode, cval=0.25).get()
+                assert np.array_equal(got, ref), (shape, name, size, mode)
+        for sigma in (0.6, 1.0, 2.0, 4.0) if shape[-1] >= 40 else (0.6,):
+            ref = sndi.gaussian_filter(x, sigma, mode=mode, cval=-0.5)
+            got = ndi.gaussian_filter(xd, sigma, mode=mode, cval=-0.5).get()
+            assert maxnorm_rel(got, ref) <= 1e-12, (shape, "gaussian", sigma, mode)
+        ref = sndi.sobel(x, axis=nd - 2, mode=mode, cval=0.25)
+        got = ndi.sobel(xd, axis=nd - 2, mode=mode, cval=0.25).get()
+        assert maxnorm_rel(got, ref) <= 1e-12, (shape, "sobel", mode)
+    if nd == 3:
+        for sigma in [(0, 1, 1), (1, 2, 2), (2, 1, 0), (1.5, 0, 0)]:
+            ref = sndi.gaussian_filter(x, sigma, mode="mirror")
+            got = ndi.gaussian_filter(xd, sigma, mode="mirror").get()
+            assert maxnorm_rel(got, ref) <= 1e-12, (shape, sigma)
+        ref = sndi.grey_erosion(x, size=(3, 5, 5))
+        assert np.array_equal(ndi.grey_erosion(xd, size=(3, 5, 5)).get(), ref)
+    # origins along y, per-axis modes
+    org = (0,) * (nd - 2) + (1, 0)
+    modes = ["nearest", "wrap", "mirror"][-nd:]
+    ref = sndi.uniform_filter(x, 3, mode=modes, origin=org)
+    assert maxnorm_rel(ndi.uniform_filter(xd, 3, mode=modes, origin=org).get(), ref) <= 1e-12
