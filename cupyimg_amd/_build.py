@@ -43,6 +43,7 @@ SOURCES = [
     ("rank_sorted_p64d.hip", ["-ffp-contract=off"]),
     ("minmax3d_u8.hip", []),
     ("median2d.hip", []),
+    ("minmax_16.hip", []),
     ("binary.hip", []),
     ("binary3d.hip", []),
     ("interp.hip", ["-ffp-contract=off"]),

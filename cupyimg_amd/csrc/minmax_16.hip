@@ -1,0 +1,454 @@
+// minmax_16.hip -- flat min / max and 3 x 3 median for 16-bit images and volumes (uint16 / int16: raw microscopy,
+// CT and MRI data), as barrier-free streaming passes.
+//
+// Replaces, for grey_erosion / grey_dilation / minimum_filter / maximum_filter with a flat `size` and for
+// median_filter(size=3) on 16-bit arrays (cupyimg/scipy/ndimage/morphology.py:769-884 -> filters.py:1385-1396,
+// :1560-1701), the generic one-thread-per-output kernels (2-byte loads, compares in double).  Same layout as the uint8
+// kernels (minmax3d_u8.hip): lane l of a wave holds 8 consecutive pixels (one uint4, two pixels per dword), a wave a
+// 1 KiB row segment, every access a coalesced 16-byte buffer load / store; comparisons are v_pk_min/max_u16 (i16), two
+// pixels per lane and instruction, a one-pixel shift along x is one v_alignbit.  The wave streams along y (images,
+// slice-wise filters: x window fused, ONE launch at 4 B/pixel) or z then y (volumes: two launches).  Results are
+// bit-exact (comparisons only).
+#include "sep_common.hpp"
+#include "stream3d.hpp"
+
+namespace mi {
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+
+template <bool IS_MAX, bool SIGNED>
+__device__ __forceinline__ unsigned op16(unsigned a, unsigned b)
+{
+    if constexpr (SIGNED) {
+        const i16x2_t x = __builtin_bit_cast(i16x2_t, a), y = __builtin_bit_cast(i16x2_t, b);
+        return __builtin_bit_cast(unsigned, IS_MAX ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y));
+    } else {
+        const u16x2_t x = __builtin_bit_cast(u16x2_t, a), y = __builtin_bit_cast(u16x2_t, b);
+        return __builtin_bit_cast(unsigned, IS_MAX ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y));
+    }
+}
+template <bool IS_MAX, bool SIGNED>
+__device__ __forceinline__ u32x4 op16v(const u32x4 a, const u32x4 b)
+{
+    u32x4 r;
+    r.x = op16<IS_MAX, SIGNED>(a.x, b.x); r.y = op16<IS_MAX, SIGNED>(a.y, b.y);
+    r.z = op16<IS_MAX, SIGNED>(a.z, b.z); r.w = op16<IS_MAX, SIGNED>(a.w, b.w);
+    return r;
+}
+__device__ __forceinline__ unsigned al16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }   // (lo >> 16) | (hi << 16)
+
+struct P16Params {
+    int nx, ny, nz;
+    int axis;            // streamed axis: 0 = z, 1 = y
+    int oa, ma;          // offset (w/2 + origin) / mode along the streamed axis
+    int mx;              // x boundary mode
+    unsigned cval2;      // cval replicated into both halves of a dword
+    int chunk, nchunks, nxt;
+};
+
+// the 4-pixel block outside the tile after its boundary fix-up (two dwords, pixel order preserved)
+__device__ __forceinline__ u32x2 fix_edge16(u32x2 e, int kind, int side, unsigned cval2)
+{
+    if (kind == EDGE_REV) return (u32x2){al16(e.y, e.y), al16(e.x, e.x)};            // p3 p2 | p1 p0
+    if (kind == EDGE_SPLAT) { const unsigned s = side == 0 ? (e.x & 0xFFFFu) * 0x10001u : (e.y >> 16) * 0x10001u; return (u32x2){s, s}; }
+    if (kind == EDGE_CONST) return (u32x2){cval2, cval2};
+    return e;
+}
+
+// sliding min / max of width WX along x for the lane's 8 pixels; D = { L0 L1 | V0 V1 V2 V3 | R0 R1 } (2 pixels a dword)
+template <int WX, bool IS_MAX, bool SIGNED>
+__device__ __forceinline__ u32x4 xwin16(const unsigned (&D)[8])
+{
+    if constexpr (WX == 1) {
+        return (u32x4){D[2], D[3], D[4], D[5]};
+    } else {
+        constexpr int RX = WX / 2;
+        unsigned A[7];                                   // A[m] = pixels (2m + 1, 2m + 2)
+#pragma unroll
+        for (int m = 0; m < 7; m++) A[m] = al16(D[m + 1], D[m]);
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // output dword k = pixels (4 + 2k, 5 + 2k); the view shifted by s pixels starts at pixel 4 + 2k + s
+            unsigned r = 0;
+#pragma unroll
+            for (int s = -RX; s <= RX; s++) {
+                const int p = 4 + 2 * k + s;
+                const unsigned v = (p & 1) ? A[(p - 1) / 2] : D[p / 2];
+                r = s == -RX ? v : op16<IS_MAX, SIGNED>(r, v);
+            }
+            o[k] = r;
+        }
+        return (u32x4){o[0], o[1], o[2], o[3]};
+    }
+}
+
+template <int WX, int WA, bool IS_MAX, bool SIGNED>
+__global__ void __launch_bounds__(256)
+stream_minmax16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, const P16Params p)
+{
+    constexpr int RINGN = WA - 1;
+    constexpr int DEPTH = 4;
+    constexpr int U = RINGN > 0 ? lcm_(RINGN, DEPTH) : DEPTH;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nother = p.axis == 0 ? ny : nz;
+    const int nA = p.axis == 0 ? nz : ny;
+    const int nlines = nother * p.nxt;
+    const int wid = blockIdx.x * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int oth = line / p.nxt, xt = line - oth * p.nxt;
+    const int x0 = xt * 512;
+    const int nlanes = min(64, (nx - x0) >> 3);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;               // elements
+    const unsigned strideA = p.axis == 0 ? plane : (unsigned)nx;
+    const unsigned rowbase = p.axis == 0 ? (unsigned)oth * nx : (unsigned)oth * plane;
+    const unsigned total_bytes = plane * (unsigned)nz * 2u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? (rowbase + (unsigned)(x0 + 8 * lane)) * 2u : kOOB;
+
+    unsigned evoff = kOOB;
+    int ekind = EDGE_FWD;
+    const int side = lane == 0 ? 0 : 1;
+    if constexpr (WX > 1) {
+        int st;
+        edge_block(side, 1, x0, x0 + 8 * nlanes, nx, p.mx, &st, &ekind);
+        if ((lane == 0 || lane == last) && ekind != EDGE_CONST) evoff = (rowbase + (unsigned)st) * 2u;
+    }
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, nA);
+    const int nsteps = a1 - a0 + WA - 1;
+    const int ai0 = a0 - p.oa;
+
+    struct Slot { u32x4 v; u32x2 e; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        int ai = ai0 + i;
+        if ((unsigned)ai >= (unsigned)nA) ai = bmap<int>(ai, nA, p.ma);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * strideA * 2u;
+        s.v = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0);
+        if constexpr (WX > 1) s.e = __builtin_amdgcn_raw_buffer_load_b64(rin, s.cst ? kOOB : evoff, soff, 0);
+        else s.e = (u32x2){0u, 0u};
+    };
+
+    u32x4 ring[RINGN > 0 ? RINGN : 1];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    for (int i0 = 0; i0 < nsteps; i0 += U) {
+        static_for<U>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J % DEPTH];
+                u32x4 v = s.v;
+                u32x2 ed = s.e;
+                if (s.cst) { v = (u32x4){p.cval2, p.cval2, p.cval2, p.cval2}; ed = (u32x2){p.cval2, p.cval2}; }
+                else ed = fix_edge16(ed, ekind, side, p.cval2);
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                u32x4 xf;
+                if constexpr (WX > 1) {
+                    unsigned D[8];
+                    // neighbours: the left lane's last two dwords, the right lane's first two (edge lanes: the edge block)
+                    D[0] = (unsigned)__builtin_amdgcn_update_dpp((int)ed.x, (int)v.z, 0x138, 0xf, 0xf, false);
+                    D[1] = (unsigned)__builtin_amdgcn_update_dpp((int)ed.y, (int)v.w, 0x138, 0xf, 0xf, false);
+                    unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp((int)ed.x, (int)v.x, 0x130, 0xf, 0xf, false);
+                    unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp((int)ed.y, (int)v.y, 0x130, 0xf, 0xf, false);
+                    if (lane == last) { r0 = ed.x; r1 = ed.y; }
+                    D[2] = v.x; D[3] = v.y; D[4] = v.z; D[5] = v.w; D[6] = r0; D[7] = r1;
+                    xf = xwin16<WX, IS_MAX, SIGNED>(D);
+                } else {
+                    xf = v;
+                }
+                if (i >= WA - 1) {
+                    u32x4 a = xf;
+                    if constexpr (RINGN > 0) {
+#pragma unroll
+                        for (int k = 0; k < RINGN; k++) a = op16v<IS_MAX, SIGNED>(a, ring[k]);
+                    }
+                    const unsigned so = (unsigned)(a0 + i - (WA - 1)) * strideA * 2u;
+                    buffer_store_b128_soff(a, rout, voff, so);
+                }
+                if constexpr (RINGN > 0) ring[J % RINGN] = xf;
+            }
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 3 x 3 median (method: median2d.hip), two pixels per dword
+// ---------------------------------------------------------------------------
+template <bool SIGNED>
+__device__ __forceinline__ unsigned med3_16(unsigned a, unsigned b, unsigned c)
+{
+    const unsigned mn = op16<false, SIGNED>(a, b), mx = op16<true, SIGNED>(a, b);
+    return op16<true, SIGNED>(mn, op16<false, SIGNED>(mx, c));
+}
+template <bool SIGNED>
+__device__ __forceinline__ void sort3_16(unsigned a, unsigned b, unsigned c, unsigned &lo, unsigned &mid, unsigned &hi)
+{
+    const unsigned mn = op16<false, SIGNED>(a, b), mx = op16<true, SIGNED>(a, b);
+    lo = op16<false, SIGNED>(mn, c);
+    hi = op16<true, SIGNED>(mx, c);
+    mid = op16<true, SIGNED>(mn, op16<false, SIGNED>(mx, c));
+}
+
+template <bool SIGNED>
+__global__ void __launch_bounds__(256)
+median3x3_16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, const P16Params p)
+{
+    constexpr int DEPTH = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nlines = nz * p.nxt;
+    const int wid = blockIdx.x * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int z = line / p.nxt, xt = line - z * p.nxt;
+    const int x0 = xt * 512;
+    const int nlanes = min(64, (nx - x0) >> 3);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;
+    const unsigned rowbase = (unsigned)z * plane;
+    const unsigned total_bytes = plane * (unsigned)nz * 2u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? (rowbase + (unsigned)(x0 + 8 * lane)) * 2u : kOOB;
+    const int side = lane == 0 ? 0 : 1;
+    int est, ekind;
+    edge_block(side, 1, x0, x0 + 8 * nlanes, nx, p.mx, &est, &ekind);
+    const unsigned evoff = ((lane == 0 || lane == last) && ekind != EDGE_CONST) ? (rowbase + (unsigned)est) * 2u : kOOB;
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, ny);
+    const int nsteps = a1 - a0 + 2;
+    const int ai0 = a0 - 1;
+
+    struct Slot { u32x4 v; u32x2 e; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        const int ai = bmap<int>(ai0 + i, ny, p.ma);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * (unsigned)nx * 2u;
+        s.v = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0);
+        s.e = __builtin_amdgcn_raw_buffer_load_b64(rin, s.cst ? kOOB : evoff, soff, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    u32x4 rv[2] = {(u32x4){0u, 0u, 0u, 0u}, (u32x4){0u, 0u, 0u, 0u}};
+    unsigned re[2] = {0u, 0u};          // the neighbouring pixel of the two previous rows, in the half the shifts read
+    for (int i0 = 0; i0 < nsteps; i0 += DEPTH) {
+        static_for<DEPTH>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J];
+                u32x4 v = s.v;
+                u32x2 ed = s.e;
+                if (s.cst) { v = (u32x4){p.cval2, p.cval2, p.cval2, p.cval2}; ed = (u32x2){p.cval2, p.cval2}; }
+                else ed = fix_edge16(ed, ekind, side, p.cval2);
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                // lane 0 needs the LAST pixel of the left block (high half of its second dword), lane `last` the FIRST
+                // pixel of the right block (low half of its first dword)
+                const unsigned ce = side == 0 ? ed.y : ed.x;
+                if (i >= 2) {
+                    unsigned lo[4], mid[4], hi[4];
+                    const unsigned a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w}, b[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
+                    const unsigned cc[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) sort3_16<SIGNED>(a[k], b[k], cc[k], lo[k], mid[k], hi[k]);
+                    unsigned elo, emid, ehi;
+                    sort3_16<SIGNED>(re[0], re[1], ce, elo, emid, ehi);
+                    auto from_left = [&](unsigned keep, unsigned x) {
+                        return (unsigned)__builtin_amdgcn_update_dpp((int)keep, (int)x, 0x138, 0xf, 0xf, false);
+                    };
+                    auto from_right = [&](unsigned keep, unsigned x) {
+                        const unsigned r = (unsigned)__builtin_amdgcn_update_dpp((int)keep, (int)x, 0x130, 0xf, 0xf, false);
+                        return lane == last ? keep : r;
+                    };
+                    const unsigned lo_p = from_left(elo, lo[3]), mid_p = from_left(emid, mid[3]), hi_p = from_left(ehi, hi[3]);
+                    const unsigned lo_n = from_right(elo, lo[0]), mid_n = from_right(emid, mid[0]), hi_n = from_right(ehi, hi[0]);
+                    unsigned o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        // views shifted by one pixel: left = (prev.hi, cur.lo), right = (cur.hi, next.lo)
+                        const unsigned lo_l = al16(lo[k], k ? lo[k - 1] : lo_p), lo_r = al16(k < 3 ? lo[k + 1] : lo_n, lo[k]);
+                        const unsigned mid_l = al16(mid[k], k ? mid[k - 1] : mid_p), mid_r = al16(k < 3 ? mid[k + 1] : mid_n, mid[k]);
+                        const unsigned hi_l = al16(hi[k], k ? hi[k - 1] : hi_p), hi_r = al16(k < 3 ? hi[k + 1] : hi_n, hi[k]);
+                        const unsigned mxlo = op16<true, SIGNED>(op16<true, SIGNED>(lo_l, lo[k]), lo_r);
+                        const unsigned mnhi = op16<false, SIGNED>(op16<false, SIGNED>(hi_l, hi[k]), hi_r);
+                        o[k] = med3_16<SIGNED>(mxlo, med3_16<SIGNED>(mid_l, mid[k], mid_r), mnhi);
+                    }
+                    const unsigned so = (unsigned)(a0 + i - 2) * (unsigned)nx * 2u;
+                    buffer_store_b128_soff((u32x4){o[0], o[1], o[2], o[3]}, rout, voff, so);
+                }
+                rv[J % 2] = v;
+                re[J % 2] = ce;
+            }
+        });
+    }
+}
+
+static void plan_chunks16(int nlines, int nA, int ramp, int *chunk, int *nchunks)
+{
+    int nch = 1;
+    double best = 1e300;
+    for (int c = 1; c <= nA && c <= 2048; c++) {
+        const int ck = (nA + c - 1) / c;
+        if (c > 1 && ck < 8) break;
+        const int real = (nA + ck - 1) / ck;
+        const double rounds = std::max(1.0, (double)nlines * real / 4096.0);
+        const double cost = rounds * (ck + ramp + 4.0);
+        if (cost < best * 0.999) { best = cost; nch = real; }
+    }
+    *chunk = (nA + nch - 1) / nch;
+    *nchunks = (nA + *chunk - 1) / *chunk;
+}
+
+template <int WX, int WA, bool IS_MAX, bool SIGNED>
+static int launch16(const uint16_t *in, uint16_t *out, P16Params &p, hipStream_t s)
+{
+    const int nA = p.axis == 0 ? p.nz : p.ny;
+    const int nlines = (p.axis == 0 ? p.ny : p.nz) * p.nxt;
+    plan_chunks16(nlines, nA, WA - 1, &p.chunk, &p.nchunks);
+    const int waves = nlines * p.nchunks;
+    hipLaunchKernelGGL((stream_minmax16_kernel<WX, WA, IS_MAX, SIGNED>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+template <bool IS_MAX, bool SIGNED>
+static int pass16(const uint16_t *in, uint16_t *out, P16Params &p, int wx, int wa, hipStream_t s)
+{
+#define MM(WXV, WAV) return launch16<WXV, WAV, IS_MAX, SIGNED>(in, out, p, s)
+    if (wx == 1) {
+        switch (wa) { case 3: MM(1, 3); case 5: MM(1, 5); case 7: MM(1, 7); case 9: MM(1, 9); }
+    } else if (wa == 1) {
+        switch (wx) { case 3: MM(3, 1); case 5: MM(5, 1); case 7: MM(7, 1); case 9: MM(9, 1); }
+    } else if (wa == wx) {
+        switch (wx) { case 3: MM(3, 3); case 5: MM(5, 5); case 7: MM(7, 7); case 9: MM(9, 9); }
+    }
+#undef MM
+    set_error("16-bit min/max pass: unsupported sizes %d/%d", wx, wa);
+    return MI_ERR_UNSUPPORTED;
+}
+
+static int pass16_any(bool is_max, bool is_signed, const uint16_t *in, uint16_t *out, P16Params &p, int wx, int wa, hipStream_t s)
+{
+    if (is_signed) return is_max ? pass16<true, true>(in, out, p, wx, wa, s) : pass16<false, true>(in, out, p, wx, wa, s);
+    return is_max ? pass16<true, false>(in, out, p, wx, wa, s) : pass16<false, false>(in, out, p, wx, wa, s);
+}
+
+// geometry shared by the two entry points below; 2-D arrays are one-plane volumes
+static int geometry16(const mi_array *in, const mi_array *out, const char *who, int64_t *nz, int64_t *ny, int64_t *nx)
+{
+#define UNSUP(msg) do { set_error("%s: %s", who, msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if ((in->ndim != 2 && in->ndim != 3) || in->dtype != out->dtype || (in->dtype != MI_U16 && in->dtype != MI_I16))
+        UNSUP("needs 2-D / 3-D uint16 or int16 in/out");
+    if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
+    if (in->data == out->data) UNSUP("in-place");
+    const int nd = in->ndim;
+    *nz = nd == 3 ? in->shape[0] : 1; *ny = in->shape[nd - 2]; *nx = in->shape[nd - 1];
+    if (*nz < 1 || *ny < 1 || *nx < 16 || (*nx & 7)) UNSUP("x extent must be a multiple of 8, >= 16");
+    // the last tile needs two lanes: lane 0 takes the block left of the tile, lane `last` the block right of it
+    { const int64_t tail = *nx & 511; if (tail != 0 && tail < 16) UNSUP("x extent unsuitable for the streaming x window"); }
+    if (*nz * *ny * *nx * 2 >= ((int64_t)1 << 31)) UNSUP("needs an array < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+#undef UNSUP
+    return MI_OK;
+}
+
+int run_median3x3_16(const mi_array *in, const mi_array *out, int mx, int my, double cval, hipStream_t s)
+{
+    int64_t nz, ny, nx;
+    int rc = geometry16(in, out, "median3x3", &nz, &ny, &nx);
+    if (rc) return rc;
+    const bool is_signed = in->dtype == MI_I16;
+    if (my == MI_MODE_CONSTANT || mx == MI_MODE_CONSTANT) {
+        const double lo = is_signed ? -32768.0 : 0.0, hi = is_signed ? 32767.0 : 65535.0;
+        if (!(cval >= lo && cval <= hi && cval == (double)(int)cval)) { set_error("median3x3: cval is not a value of the dtype"); return MI_ERR_UNSUPPORTED; }
+    }
+    P16Params p;
+    memset(&p, 0, sizeof(p));
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.axis = 1; p.oa = 1; p.ma = my; p.mx = mx;
+    p.cval2 = ((unsigned)(int)cval & 0xFFFFu) * 0x10001u;
+    p.nxt = (int)((nx + 511) / 512);
+    plan_chunks16(p.nz * p.nxt, p.ny, 2, &p.chunk, &p.nchunks);
+    const int waves = p.nz * p.nxt * p.nchunks;
+    if (is_signed)
+        hipLaunchKernelGGL(median3x3_16_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, s, (const uint16_t *)in->data, (uint16_t *)out->data, p);
+    else
+        hipLaunchKernelGGL(median3x3_16_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, s, (const uint16_t *)in->data, (uint16_t *)out->data, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+/* Separable flat min / max on a uint16 / int16 image or volume (declared in include/mi355img.h). */
+extern "C" int mi_minmax3d_16(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
+                              const int mode[3], int cval, int is_max, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(size && origin && mode, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    int64_t nz, ny, nx;
+    if ((rc = geometry16(in, out, "minmax3d_16", &nz, &ny, &nx))) return rc;
+#define UNSUP(msg) do { set_error("minmax3d_16: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    for (int a = 0; a < 3; a++)
+        if (size[a] < 1 || size[a] > 9 || !(size[a] & 1) || origin[a] != 0) UNSUP("sizes must be odd, <= 9, with origin 0");
+    const bool is_signed = in->dtype == MI_I16;
+    if (cval < (is_signed ? -32768 : 0) || cval > (is_signed ? 32767 : 65535)) UNSUP("cval outside the dtype");
+    const int mz = filter_mode(mode[0]), my = filter_mode(mode[1]), mx = filter_mode(mode[2]);
+    hipStream_t s = resolve_stream(stream);
+    struct Pass { int axis, wa, oa, ma, wx; };
+    Pass passes[3];
+    int np = 0;
+    const int *w = size;
+    const bool fuse_xz = w[2] > 1 && w[2] == w[0];
+    const bool fuse_xy = !fuse_xz && w[2] > 1 && w[2] == w[1];
+    if (w[2] > 1 && !fuse_xz && !fuse_xy) passes[np++] = {1, 1, 0, my, w[2]};
+    if (w[0] > 1) passes[np++] = {0, w[0], w[0] / 2, mz, fuse_xz ? w[2] : 1};
+    if (w[1] > 1) passes[np++] = {1, w[1], w[1] / 2, my, fuse_xy ? w[2] : 1};
+    if (np == 0) UNSUP("nothing to filter");
+    const size_t bytes = (size_t)(nz * ny * nx) * 2;
+    void *tmp[2] = {nullptr, nullptr};
+    for (int t = 0; t < np - 1 && t < 2; t++)
+        if ((rc = pool_alloc(&tmp[t], bytes, s))) { if (tmp[0]) pool_free(tmp[0]); return rc; }
+    const uint16_t *src = (const uint16_t *)in->data;
+    for (int i = 0; i < np && rc == MI_OK; i++) {
+        uint16_t *dst = i == np - 1 ? (uint16_t *)out->data : (uint16_t *)tmp[i & 1];
+        const Pass &q = passes[i];
+        P16Params p;
+        memset(&p, 0, sizeof(p));
+        p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+        p.axis = q.axis; p.oa = q.oa; p.ma = q.ma; p.mx = mx;
+        p.cval2 = ((unsigned)cval & 0xFFFFu) * 0x10001u;
+        p.nxt = (int)((nx + 511) / 512);
+        rc = pass16_any(is_max != 0, is_signed, src, dst, p, q.wx, q.wa, s);
+        src = dst;
+    }
+    for (int t = 0; t < 2; t++) if (tmp[t]) pool_free(tmp[t]);
+    return rc;
+#undef UNSUP
+}

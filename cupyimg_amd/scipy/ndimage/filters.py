@@ -430,8 +430,10 @@ def _launch_minmax1d(src, dst, axis, size, origin, mode, cval, is_max):
 def _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max):
     if S.current_planes() is not None:
         raise S.Unsupported("min/max filters cannot be restricted to a range of output planes")
-    if input.ndim not in (2, 3) or input.dtype != np.uint8 or output.dtype != np.uint8 or input.size == 0:
+    if (input.ndim not in (2, 3) or input.dtype not in (np.uint8, np.uint16, np.int16) or output.dtype != input.dtype
+            or input.size == 0):
         return None
+    info = np.iinfo(input.dtype)
     out3 = output
     if input.ndim == 2:
         # an image is a one-plane volume: x and y windows in one streaming launch
@@ -445,14 +447,15 @@ def _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max):
     # SciPy compares cval as a double and casts after every pass; the byte
     # kernel is only equivalent when cval is itself a uint8 value
     if any(m in ("constant", "grid-constant") for m in modes):
-        if not (np.isfinite(cval) and 0 <= cval <= 255 and float(cval) == int(cval)):
+        if not (np.isfinite(cval) and info.min <= cval <= info.max and float(cval) == int(cval)):
             return None
     if any(int(o) != 0 for o in origins) or any(int(sz) % 2 == 0 for sz in sizes):
         return None
+    entry = S.lib().mi_minmax3d_u8 if input.dtype == np.uint8 else S.lib().mi_minmax3d_16
     try:
-        cv = int(cval) if np.isfinite(cval) and 0 <= cval <= 255 else 0
-        S.check(S.lib().mi_minmax3d_u8(ctypes.byref(a), ctypes.byref(b), S.c_ints(sizes), S.c_ints(origins),
-                                       S.c_ints([S.mode_code(m) for m in modes]), cv, int(is_max), None))
+        cv = int(cval) if np.isfinite(cval) and info.min <= cval <= info.max else 0
+        S.check(entry(ctypes.byref(a), ctypes.byref(b), S.c_ints(sizes), S.c_ints(origins),
+                      S.c_ints([S.mode_code(m) for m in modes]), cv, int(is_max), None))
     except S.Unsupported:
         return None
     if not direct:
@@ -768,7 +771,7 @@ def _rank_filter(input, rank, size, footprint, output, mode, cval, origin, opera
         return output
     fp = np.ascontiguousarray(footprint, dtype=np.uint8)
     if (rank == 4 and filter_size == 9 and fp.shape[-2:] == (3, 3) and fp.ndim == input.ndim and fp.ndim in (2, 3)
-            and not any(origins) and input.dtype in (np.float32, np.uint8) and output.dtype == input.dtype
+            and not any(origins) and input.dtype in (np.float32, np.uint8, np.uint16, np.int16) and output.dtype == input.dtype
             and S.current_planes() is None):
         res = _try_median3x3(input, output, mode, cval)
         if res is not None:

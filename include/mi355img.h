@@ -236,6 +236,13 @@ int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int size[3],
 int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
                     const int mode[3], double cval, int is_max, mi_stream stream);
 
+/* uint16 / int16 images and volumes (2-D or 3-D arrays; size / origin / mode always have
+ * three entries, the first one for the absent axis of an image): flat min / max with odd
+ * sizes <= 9 and origin 0 as streaming passes on packed 16-bit pairs -- images and
+ * slice-wise filters one launch (4 B/pixel), volumes two.  MI_ERR_UNSUPPORTED otherwise. */
+int mi_minmax3d_16(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
+                   const int mode[3], int cval, int is_max, mi_stream stream);
+
 /* float64 images and volumes (skimage's working dtype): the separable filter and the
  * flat min / max as streaming passes, x fused into the streamed pass when the tap
  * counts agree -- an image or a slice-wise filter is one launch (16 B/pixel), a volume
@@ -263,10 +270,10 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
                    const int64_t *fshape, const int *origins, int rank, int mode, double cval,
                    mi_stream stream);
 
-/* 3 x 3 median over the last two axes of a 2-D / 3-D float32 or uint8 array
+/* 3 x 3 median over the last two axes of a 2-D / 3-D float32, uint8, uint16 or int16 array
  * (median_filter(size=3) / rank_filter(rank=4) with a full 3 x 3 footprint,
  * filters.py:1560-1701,1751-1792; skimage.filters.median's default on images):
- * one streaming launch at 8 (float32) / 2 (uint8) B/pixel instead of the
+ * one streaming launch at 8 (float32) / 2 (uint8) / 4 (16-bit) B/pixel instead of the
  * generic gather-and-sort kernel.  mode[2]: boundary modes along y and x.
  * MI_ERR_UNSUPPORTED when not applicable (the caller runs mi_rank_filter). */
 int mi_median3x3(const mi_array *in, const mi_array *out, const int mode[2], double cval,

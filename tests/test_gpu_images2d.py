@@ -168,3 +168,28 @@ def test_float64_streaming_kernels(gpu, ndi, shape):
     modes = ["nearest", "wrap", "mirror"][-nd:]
     ref = sndi.uniform_filter(x, 3, mode=modes, origin=org)
     assert maxnorm_rel(ndi.uniform_filter(xd, 3, mode=modes, origin=org).get(), ref) <= 1e-12
+
+
+@pytest.mark.parametrize("dtype", ["uint16", "int16"])
+@pytest.mark.parametrize("shape", [(50, 64), (33, 520), (33, 528), (40, 1024 + 24), (7, 16), (9, 20, 72)])
+def test_16bit_minmax_and_median(gpu, ndi, dtype, shape):
+    """uint16 / int16 images and volumes: flat min / max and the 3 x 3 median, bit-exact."""
+    rng = np.random.default_rng(77)
+    info = np.iinfo(dtype)
+    x = rng.integers(info.min, info.max + 1, size=shape, dtype=dtype)
+    x[..., ::3, ::5] = info.max
+    x[..., 1::4, 2::7] = info.min
+    xd = gpu.asarray(x)
+    nd = len(shape)
+    sizes = [3, 5, 9, (3, 7), (5, 1), (1, 9)] if nd == 2 else [3, 5, (1, 5, 5), (3, 5, 5), (7, 1, 7), (1, 1, 3), (3, 1, 1)]
+    for mode in MODES:
+        for size in sizes:
+            for name in ("grey_erosion", "grey_dilation"):
+                ref = getattr(sndi, name)(x, size=size, mode=mode, cval=-7 if dtype == "int16" else 40000)
+                got = getattr(ndi, name)(xd, size=size, mode=mode, cval=-7 if dtype == "int16" else 40000).get()
+                assert got.dtype == x.dtype
+                assert np.array_equal(got, ref), (dtype, shape, name, size, mode)
+        msize = 3 if nd == 2 else (1, 3, 3)
+        ref = sndi.median_filter(x, size=msize, mode=mode, cval=3)
+        got = ndi.median_filter(xd, size=msize, mode=mode, cval=3).get()
+        assert np.array_equal(got, ref), (dtype, shape, "median", mode)
