@@ -1118,6 +1118,131 @@ spline_filter_rows_kernel(CF *__restrict__ data, int64_t n, int64_t nlines, int 
     }
 }
 
+// ---------------------------------------------------------------------------
+// r2: blocked prefilter for arrays with FEW, LONG lines (images: 4096 x 4096 has 4096 lines = 64 waves, each running
+// two dependent sweeps of 4096 steps: 0.5 ms per axis, latency bound).  Orders 2 and 3 have one pole z, |z| < 0.27:
+// the influence of a sample decays as |z|^k and is below 1e-22 of the data range after kSplHorizon = 40 steps, i.e.
+// far below one ulp of a double.  A thread therefore filters one CHUNK of one line:
+//   causal sweep from 40 samples before the chunk (started from the plain sample there; the first chunk uses the exact
+//   boundary initialisation) to 40 samples past its end -- c+ of the chunk goes to the output, c+ of the 40 samples past
+//   the end to an LDS column of the thread;
+//   anti-causal sweep back from there (started with the steady-state value; the last chunk uses the exact boundary
+//   initialisation), writing the chunk.
+// Out of place (threads read source samples of neighbouring chunks); 1.3x the arithmetic, chunks x the parallelism.
+// mirror / reflect initialisations only (grid-wrap needs c+ of the line start at the line end): smode 0 / 1.
+// ---------------------------------------------------------------------------
+constexpr int kSplHorizon = 40;
+
+template <typename CF>
+__global__ void __launch_bounds__(64)
+spline_filter_chunked_kernel(const CF *__restrict__ src, CF *__restrict__ dst, int64_t n, int64_t inner, int64_t nlines, int order,
+                             int smode, int64_t L)
+{
+    __shared__ double ext[kSplHorizon][64];
+    const int lane = threadIdx.x;
+    int64_t line = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = line < nlines;
+    if (!valid) line = nlines - 1;                    // keeps the lane's loads in range; it stores nothing
+    const int64_t line_off = (line / inner) * n * inner + (line % inner);
+    const CF *__restrict__ rd = src + line_off;
+    CF *__restrict__ wr = dst + line_off;
+    const int64_t st = inner;
+    const double z = order == 2 ? -0.171572875253809902396622551580603843 : -0.267949192431122706472553658494127633;
+    const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+    const int64_t s0 = (int64_t)blockIdx.y * L, e0 = (s0 + L < n) ? s0 + L : n;
+    const int64_t hi = (e0 + kSplHorizon < n) ? e0 + kSplHorizon : n;      // causal sweep runs to hi - 1
+
+    // ---- causal start
+    int64_t i0;
+    double prev;
+    if (s0 - kSplHorizon <= 0) {
+        i0 = 0;
+        const int64_t H = (int64_t)ceil(-46.0517 / log(fabs(z)));
+        double c0 = (double)rd[0];
+        double z_i = z;
+        if (smode == 0) {
+            const double z_n_1 = pow(z, (double)(n - 1));
+            double acc = c0 + z_n_1 * (double)rd[(n - 1) * st];
+            const int64_t m = (n - 1 < H + 1) ? n - 1 : H + 1;
+            for (int64_t i = 1; i < m; i++) { acc += z_i * ((double)rd[i * st] + z_n_1 * (double)rd[(n - 1 - i) * st]); z_i *= z; }
+            c0 = acc / (1 - z_n_1 * z_n_1);
+        } else {
+            const double z_n = pow(z, (double)n);
+            double acc = c0 + z_n * (double)rd[(n - 1) * st];
+            const int64_t m = (n < H + 1) ? n : H + 1;
+            for (int64_t i = 1; i < m; i++) {
+                const double mirror_term = (i == n - 1) ? acc : (double)rd[(n - 1 - i) * st];
+                acc += z_i * ((double)rd[i * st] + z_n * mirror_term);
+                z_i *= z;
+            }
+            acc *= z / (1 - z_n * z_n);
+            c0 = acc + c0;
+        }
+        prev = c0;
+        if (valid && s0 == 0) wr[0] = (CF)prev;
+    } else {
+        i0 = s0 - kSplHorizon;
+        prev = (double)rd[i0 * st];
+    }
+    double prev2 = 0.0;                               // c+[i - 1] before the last update: c+[n - 2] for the mirror end
+    int64_t i = i0 + 1;
+    // warm-up before the chunk
+    for (; i + kSplBatch <= s0; i += kSplBatch) {
+        double v[kSplBatch];
+#pragma unroll
+        for (int u = 0; u < kSplBatch; u++) v[u] = (double)rd[(i + u) * st];
+#pragma unroll
+        for (int u = 0; u < kSplBatch; u++) prev = v[u] + z * prev;
+    }
+    for (; i < s0; i++) prev = (double)rd[i * st] + z * prev;
+    // the chunk
+    for (; i + kSplBatch <= e0; i += kSplBatch) {
+        double v[kSplBatch];
+#pragma unroll
+        for (int u = 0; u < kSplBatch; u++) v[u] = (double)rd[(i + u) * st];
+#pragma unroll
+        for (int u = 0; u < kSplBatch; u++) { prev2 = prev; prev = v[u] + z * prev; v[u] = prev; }
+        if (valid) {
+#pragma unroll
+            for (int u = 0; u < kSplBatch; u++) wr[(i + u) * st] = (CF)v[u];
+        }
+    }
+    for (; i < e0; i++) { prev2 = prev; prev = (double)rd[i * st] + z * prev; if (valid) wr[i * st] = (CF)prev; }
+    // past the chunk: c+ into the LDS column
+    for (; i < hi; i++) { prev2 = prev; prev = (double)rd[i * st] + z * prev; ext[i - e0][lane] = prev; }
+
+    // ---- anti-causal start at hi - 1 (prev == c+[hi - 1])
+    double nxt;
+    if (hi == n) {
+        // the sequential kernel reads c+[n - 2] back from the array, i.e. rounded to the coefficient type
+        if (smode == 0) nxt = (z * (double)(CF)prev2 + prev) * z / (z * z - 1);
+        else nxt = prev * z / (z - 1);
+    } else {
+        nxt = prev * z / (z - 1);
+    }
+    int64_t j = hi - 1;
+    if (j >= e0) {
+        // samples past the chunk (from the LDS column); nothing is stored
+        for (j = hi - 2; j >= e0; j--) nxt = z * (nxt - ext[j - e0][lane]);
+    } else {
+        // the chunk ends the line: its last sample is the start value itself
+        if (valid) wr[j * st] = (CF)(nxt * gain);
+        j--;
+    }
+    for (; j - (kSplBatch - 1) >= s0; j -= kSplBatch) {
+        double v[kSplBatch];
+#pragma unroll
+        for (int u = 0; u < kSplBatch; u++) v[u] = (double)wr[(j - u) * st];
+#pragma unroll
+        for (int u = 0; u < kSplBatch; u++) { nxt = z * (nxt - v[u]); v[u] = nxt; }
+        if (valid) {
+#pragma unroll
+            for (int u = 0; u < kSplBatch; u++) wr[(j - u) * st] = (CF)(v[u] * gain);
+        }
+    }
+    for (; j >= s0; j--) { nxt = z * (nxt - (double)wr[j * st]); if (valid) wr[j * st] = (CF)(nxt * gain); }
+}
+
 static int fill_geom(InterpGeom *g, const mi_array *in, int nd)
 {
     const int pad = nd - in->ndim;
@@ -1159,6 +1284,10 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
 using namespace mi;
 
 static int g_interp_generic = 0;   // test hook: 1 = always use the generic double kernels
+static int g_spline_threads = 65536;   // threads the blocked prefilter aims for
+extern "C" int mi_debug_set_spline_threads(int k) { g_spline_threads = k; return MI_OK; }
+static int g_spline_chunk = 0;     // test hook: -1 = never the blocked prefilter, > 0 = force it with this minimum chunk length
+extern "C" int mi_debug_set_spline_chunk(int k) { g_spline_chunk = k; return MI_OK; }
 static int g_spline_rows_off = 0;  // test hook: 1 = one thread per line also for contiguous lines
 static int g_cubic_separable_off = 0;   // test hook: 1 = diagonal transforms use the one-launch strip kernel
 extern "C" int mi_debug_set_cubic_separable(int on) { g_cubic_separable_off = !on; return MI_OK; }
@@ -1291,34 +1420,76 @@ int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mod
     });
 }
 
-// one prefilter pass along `axis` of the contiguous array `data`; `src` (same dtype and shape) makes the
-// pass out of place -- only the per-line kernel, i.e. not for the tiled last-axis case
-static int spline_pass(const mi_array *data, const void *src, int axis, int order, int spline_mode, hipStream_t s)
+// chunk length of the blocked prefilter for one pass, 0 = the pass does not qualify (few long lines; orders 2 / 3;
+// mirror / reflect ends)
+static int64_t spline_chunk_len(const mi_array *a, int axis, int order, int spline_mode)
 {
-    const int64_t total = numel(data);
+    const int64_t total = numel(a);
+    if (total == 0 || a->shape[axis] <= 1) return 0;
+    const int64_t n = a->shape[axis], nlines = total / n;
+    const int64_t min_chunk = g_spline_chunk > 0 ? g_spline_chunk : 128;
+    if (!(g_spline_chunk >= 0 && order <= 3 && spline_mode != 2 && n >= 2 * min_chunk && n > 2 * kSplHorizon &&
+          (nlines < 32768 || g_spline_chunk > 0)))
+        return 0;
+    // as many chunks as it takes to get ~64k threads, at least min_chunk samples each
+    int64_t nch = (g_spline_threads + nlines - 1) / nlines;
+    if (nch > n / min_chunk) nch = n / min_chunk;
+    return nch >= 2 ? (n + nch - 1) / nch : 0;
+}
+
+// one prefilter pass along `axis`: `shape` describes the (contiguous) array, the samples are read from `src` and the
+// coefficients written to `dst` (src == dst: in place).  The blocked kernel works out of place (an in-place request
+// goes through a temporary and is copied back); the LDS-tiled kernel for contiguous lines works in place only.
+static int spline_pass(const mi_array *shape, const void *src, void *dst, int axis, int order, int spline_mode, hipStream_t s)
+{
+    const int64_t total = numel(shape);
     if (total == 0) return MI_OK;
     int64_t inner = 1;
-    for (int d = axis + 1; d < data->ndim; d++) inner *= data->shape[d];
-    const int64_t n = data->shape[axis], nlines = total / n;
-    // enough lines to fill the chip with one wave per 64 lines; images with few, long lines keep one thread per line
-    if (!src && inner == 1 && n >= 2 * kSplTile && (nlines >= 16384 || g_spline_rows_force) && !g_spline_rows_off) {
-        const dim3 grid((unsigned)((nlines + kSplTile - 1) / kSplTile));
-        if (data->dtype == MI_F64)
-            hipLaunchKernelGGL(spline_filter_rows_kernel<double>, grid, dim3(64), 0, s, (double *)data->data, n, nlines, order,
-                               spline_mode);
+    for (int d = axis + 1; d < shape->ndim; d++) inner *= shape->shape[d];
+    const int64_t n = shape->shape[axis], nlines = total / n;
+    const int64_t L = spline_chunk_len(shape, axis, order, spline_mode);
+    if (L > 0) {
+        const unsigned gy = (unsigned)((n + L - 1) / L);
+        const size_t bytes = (size_t)total * dtype_size(shape->dtype);
+        void *tmp = nullptr;
+        if (src == dst) {
+            int rc = pool_alloc(&tmp, bytes, s);
+            if (rc) return rc;
+        }
+        void *to = tmp ? tmp : dst;
+        const dim3 grid((unsigned)((nlines + 63) / 64), gy);
+        if (shape->dtype == MI_F64)
+            hipLaunchKernelGGL(spline_filter_chunked_kernel<double>, grid, dim3(64), 0, s, (const double *)src, (double *)to, n, inner,
+                               nlines, order, spline_mode, L);
         else
-            hipLaunchKernelGGL(spline_filter_rows_kernel<float>, grid, dim3(64), 0, s, (float *)data->data, n, nlines, order,
-                               spline_mode);
+            hipLaunchKernelGGL(spline_filter_chunked_kernel<float>, grid, dim3(64), 0, s, (const float *)src, (float *)to, n, inner,
+                               nlines, order, spline_mode, L);
+        hipError_t err = hipGetLastError();
+        if (tmp) {
+            if (err == hipSuccess) err = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToDevice, s);
+            pool_free(tmp);            // reuse is stream ordered
+        }
+        MI_HIP(err);
+        return MI_OK;
+    }
+    // enough lines to fill the chip with one wave per 64 lines; images with few, long lines keep one thread per line
+    if (src == dst && inner == 1 && n >= 2 * kSplTile && (nlines >= 16384 || g_spline_rows_force) && !g_spline_rows_off) {
+        const dim3 grid((unsigned)((nlines + kSplTile - 1) / kSplTile));
+        if (shape->dtype == MI_F64)
+            hipLaunchKernelGGL(spline_filter_rows_kernel<double>, grid, dim3(64), 0, s, (double *)dst, n, nlines, order, spline_mode);
+        else
+            hipLaunchKernelGGL(spline_filter_rows_kernel<float>, grid, dim3(64), 0, s, (float *)dst, n, nlines, order, spline_mode);
         MI_HIP(hipGetLastError());
         return MI_OK;
     }
+    const void *from = src == dst ? nullptr : src;
     const dim3 grid((unsigned)((nlines + 63) / 64));
-    if (data->dtype == MI_F64)
-        hipLaunchKernelGGL(spline_filter1d_kernel<double>, grid, dim3(64), 0, s, (double *)data->data, (const double *)src, n,
-                           inner, nlines, order, spline_mode);
+    if (shape->dtype == MI_F64)
+        hipLaunchKernelGGL(spline_filter1d_kernel<double>, grid, dim3(64), 0, s, (double *)dst, (const double *)from, n, inner, nlines,
+                           order, spline_mode);
     else
-        hipLaunchKernelGGL(spline_filter1d_kernel<float>, grid, dim3(64), 0, s, (float *)data->data, (const float *)src, n,
-                           inner, nlines, order, spline_mode);
+        hipLaunchKernelGGL(spline_filter1d_kernel<float>, grid, dim3(64), 0, s, (float *)dst, (const float *)from, n, inner, nlines,
+                           order, spline_mode);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -1332,7 +1503,7 @@ int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mod
     MI_REQUIRE(order >= 2 && order <= 5, MI_ERR_INVALID_ARG, "spline order is not supported");
     MI_REQUIRE(spline_mode >= 0 && spline_mode <= 2, MI_ERR_INVALID_ARG, "bad spline boundary mode");
     MI_REQUIRE(is_contiguous(data), MI_ERR_NOT_CONTIGUOUS, "needs a C-contiguous array");
-    return spline_pass(data, nullptr, axis, order, spline_mode, resolve_stream(stream));
+    return spline_pass(data, data->data, data->data, axis, order, spline_mode, resolve_stream(stream));
 }
 
 int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int spline_mode, int npad, int pad_mode,
@@ -1353,14 +1524,43 @@ int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int 
     const bool direct = npad == 0 && in->dtype == out->dtype && same_shape(in, out) && is_contiguous(in) && is_contiguous(out)
                         && first >= 0 && inner_first > 1;
     hipStream_t s = resolve_stream(stream);
-    if (!direct) {
-        if ((rc = mi_spline_pad(in, out, npad, pad_mode, cval, stream))) return rc;
+    // Passes of the blocked kernel work out of place, the others in place: the data hops between `out` and one
+    // temporary, laid out so that the last hop lands in `out` (K blocked passes: start in `out` when K is even).
+    int nblocked = 0;
+    for (int d = 0; d < out->ndim; d++)
+        if (out->shape[d] > 1 && spline_chunk_len(out, d, order, spline_mode) > 0) nblocked++;
+    void *tmp = nullptr;
+    if (nblocked > 0 && (rc = pool_alloc(&tmp, (size_t)numel(out) * dtype_size(out->dtype), s))) return rc;
+    auto other = [&](const void *p) { return p == out->data ? tmp : out->data; };
+    const void *cur;
+    if (direct) {
+        cur = in->data;
+    } else {
+        mi_array first_home = *out;
+        first_home.data = (nblocked % 2 == 0) ? out->data : tmp;
+        if ((rc = mi_spline_pad(in, &first_home, npad, pad_mode, cval, stream))) { if (tmp) pool_free(tmp); return rc; }
+        cur = first_home.data;
     }
-    for (int d = 0; d < out->ndim; d++) {
+    int left = nblocked;
+    for (int d = 0; d < out->ndim && rc == MI_OK; d++) {
         if (out->shape[d] <= 1) continue;
-        if ((rc = spline_pass(out, (direct && d == first) ? in->data : nullptr, d, order, spline_mode, s))) return rc;
+        const bool blocked = spline_chunk_len(out, d, order, spline_mode) > 0;
+        void *dst;
+        if (blocked) {
+            left--;
+            dst = cur == in->data ? ((left % 2 == 0) ? out->data : tmp) : other(cur);
+        } else {
+            dst = cur == in->data ? ((left % 2 == 0) ? out->data : tmp) : const_cast<void *>(cur);
+        }
+        rc = spline_pass(out, cur, dst, d, order, spline_mode, s);
+        cur = dst;
     }
-    return MI_OK;
+    if (rc == MI_OK && cur != out->data && cur != in->data) {
+        hipError_t err = hipMemcpyAsync(out->data, cur, (size_t)numel(out) * dtype_size(out->dtype), hipMemcpyDeviceToDevice, s);
+        if (err != hipSuccess) rc = (int)err;
+    }
+    if (tmp) pool_free(tmp);           // reuse is stream ordered
+    return rc;
 }
 
 static int check_spline(const mi_array *coef, const mi_array *out, int order, int mode, int npad)

@@ -193,3 +193,32 @@ def test_16bit_minmax_and_median(gpu, ndi, dtype, shape):
         ref = sndi.median_filter(x, size=msize, mode=mode, cval=3)
         got = ndi.median_filter(xd, size=msize, mode=mode, cval=3).get()
         assert np.array_equal(got, ref), (dtype, shape, "median", mode)
+
+
+def test_blocked_spline_prefilter(gpu, ndi):
+    """Orders 2 / 3 on arrays with few long lines: chunks of a line filtered in parallel with a 40-sample horizon.
+    Same coefficients as the sequential kernel (and as SciPy) to 1e-13; short chunks forced by the hook."""
+    from cupyimg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(78)
+    try:
+        for shape in [(300, 520), (97, 1031), (600,), (12, 200, 150)]:
+            x = rng.standard_normal(shape) * 100.0
+            xd = gpu.asarray(x)
+            for order in (2, 3):
+                for mode in ("mirror", "reflect", "nearest", "constant", "grid-wrap"):
+                    ref = sndi.spline_filter(x, order=order, mode=mode)
+                    for hook in (0, 16, 50):
+                        lib.mi_debug_set_spline_chunk(hook)
+                        got = ndi.spline_filter(xd, order=order, mode=mode).get()
+                        assert maxnorm_rel(got, ref) <= 1e-13, (shape, order, mode, hook)
+            lib.mi_debug_set_spline_chunk(16)
+            ref = sndi.spline_filter1d(x, order=3, axis=0, mode="mirror")
+            assert maxnorm_rel(ndi.spline_filter1d(xd, order=3, axis=0, mode="mirror").get(), ref) <= 1e-13
+            # float32 coefficients (the float32 cubic interpolation route)
+            x32 = x.astype(np.float32)
+            ref = sndi.shift(x32.astype(np.float64), 0.3, order=3, mode="mirror")
+            got = ndi.shift(gpu.asarray(x32), 0.3, order=3, mode="mirror").get()
+            assert got.dtype == np.float32 and maxnorm_rel(got, ref) <= 2e-6, shape
+    finally:
+        lib.mi_debug_set_spline_chunk(0)
