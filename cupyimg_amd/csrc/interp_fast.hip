@@ -23,7 +23,7 @@ struct FastInterpParams {
     int nz, ny, nx;          // input
     int oz, oy, ox;          // output
     int order, mode;
-    float cval;
+    double cval;
     int two_d;               // image (ny, nx) handled as a one-plane volume: the z coordinate is 0
     double m[12];            // affine 3 x 4 (row major)
 };
@@ -71,8 +71,8 @@ __device__ __forceinline__ double foldc(double c, int n, int mode)
 
 // taps along one axis for coordinate c: indices (-1 = use cval), float weights.
 // `outside` is set when mode == constant and c lies outside [0, n-1].
-template <typename CT, bool FASTC, int ORDER>
-__device__ __forceinline__ void axis_taps(CT c, int n, int mode, int order, int &i0, int &i1, float &w0, float &w1,
+template <typename CT, bool FASTC, int ORDER, typename WT>
+__device__ __forceinline__ void axis_taps(CT c, int n, int mode, int order, int &i0, int &i1, WT &w0, WT &w1,
                                           bool &outside)
 {
     if constexpr (FASTC && ORDER == 1) {
@@ -80,10 +80,10 @@ __device__ __forceinline__ void axis_taps(CT c, int n, int mode, int order, int 
         // (inside [0, n-1] both taps are valid; at c == n-1 the upper tap is skipped)
         outside = outside || c < (CT)0 || c > (CT)(n - 1);
         const CT cf = floor(c);
-        w1 = (float)(c - cf);
-        w0 = 1.0f - w1;
+        w1 = (WT)(c - cf);
+        w0 = (WT)1 - w1;
         i0 = (int)cf;
-        i1 = w1 == 0.f ? i0 : i0 + 1;
+        i1 = w1 == (WT)0 ? i0 : i0 + 1;
         return;
     }
     if (mode == MI_MODE_CONSTANT && (c < (CT)0 || c > (CT)(n - 1))) outside = true;
@@ -93,14 +93,14 @@ __device__ __forceinline__ void axis_taps(CT c, int n, int mode, int order, int 
         else if (mode == MI_MODE_GRID_CONSTANT) j = bmap<int>((int)floor((double)c + 0.5), n, mode);
         else j = bmap<int>((int)floor(foldc((double)c, n, mode) + 0.5), n, mode);
         i0 = i1 = j;
-        w0 = 1.f;
-        w1 = 0.f;
+        w0 = (WT)1;
+        w1 = (WT)0;
         return;
     }
     const CT cf = floor(c);
     const CT fr = c - cf;               // exact in CT
-    w1 = (float)fr;
-    w0 = (float)(((CT)1 + cf) - c);     // (cf + 1) - c as the reference / SciPy form it
+    w1 = (WT)fr;
+    w0 = (WT)(((CT)1 + cf) - c);     // (cf + 1) - c as the reference / SciPy form it
     if (mode == MI_MODE_WRAP) {
         const double f = wrapc((double)c, n);
         i0 = (int)floor(f);
@@ -113,7 +113,7 @@ __device__ __forceinline__ void axis_taps(CT c, int n, int mode, int order, int 
             i1 = bmap<int>(i1, n, mode);
         }
     }
-    if (fr == (CT)0) { i1 = i0; w1 = 0.f; }   // integral coordinate: the upper tap is skipped
+    if (fr == (CT)0) { i1 = i0; w1 = (WT)0; }   // integral coordinate: the upper tap is skipped
 }
 
 // One output voxel in two phases so that a thread can keep several voxels'
@@ -122,11 +122,34 @@ __device__ __forceinline__ void axis_taps(CT c, int n, int mode, int order, int 
 // (x, then y, then z); a zero upper weight selects the lower sample outright,
 // which is the reference's "second tap skipped at integral coordinates"
 // (_interp_kernels.py:416) and keeps inf / nan of a skipped tap out.
-struct Taps { float v[8]; float wz1, wy1, wx1; unsigned oobmask; bool outside; };
+template <typename T> struct Taps { T v[8]; T wz1, wy1, wx1; unsigned oobmask; bool outside; };
 
-template <typename CT, bool FASTC, int ORDER>
-__device__ __forceinline__ void taps(const __amdgpu_buffer_rsrc_t in, const FastInterpParams &p, CT cz, CT cy, CT cx, Taps &t)
+// two neighbouring samples with one gather (8 bytes of float32, 16 bytes of float64) / one sample
+__device__ __forceinline__ void load_pair(const __amdgpu_buffer_rsrc_t in, unsigned off, float &a, float &b)
 {
+    const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(in, off, 0, 0);
+    a = __uint_as_float(q.x); b = __uint_as_float(q.y);
+}
+__device__ __forceinline__ void load_pair(const __amdgpu_buffer_rsrc_t in, unsigned off, double &a, double &b)
+{
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ q = __builtin_amdgcn_raw_buffer_load_b128(in, off, 0, 0);
+    a = __hiloint2double((int)q.y, (int)q.x); b = __hiloint2double((int)q.w, (int)q.z);
+}
+__device__ __forceinline__ void load_one(const __amdgpu_buffer_rsrc_t in, unsigned off, float &a)
+{
+    a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in, off, 0, 0));
+}
+__device__ __forceinline__ void load_one(const __amdgpu_buffer_rsrc_t in, unsigned off, double &a)
+{
+    const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(in, off, 0, 0);
+    a = __hiloint2double((int)q.y, (int)q.x);
+}
+
+template <typename T, typename CT, bool FASTC, int ORDER>
+__device__ __forceinline__ void taps(const __amdgpu_buffer_rsrc_t in, const FastInterpParams &p, CT cz, CT cy, CT cx, Taps<T> &t)
+{
+    constexpr unsigned ES = sizeof(T);
     if constexpr (FASTC && ORDER == 1) {
         // constant mode, order 1: integer/fraction split once per axis, the range test on the integers, one base
         // index plus three strides.  r2: written branch-free (bitwise logic instead of && / ||: the short-circuit
@@ -134,8 +157,8 @@ __device__ __forceinline__ void taps(const __amdgpu_buffer_rsrc_t in, const Fast
         // (rocprofv3: 93 VALU instructions per voxel, VALU 78 % busy), so every instruction counts.
         const CT fz = floor(cz), fy = floor(cy), fx = floor(cx);
         const int z0 = (int)fz, y0 = (int)fy, x0 = (int)fx;
-        t.wz1 = (float)(cz - fz); t.wy1 = (float)(cy - fy); t.wx1 = (float)(cx - fx);
-        const bool zz = t.wz1 == 0.f, yz = t.wy1 == 0.f, xz = t.wx1 == 0.f;
+        t.wz1 = (T)(cz - fz); t.wy1 = (T)(cy - fy); t.wx1 = (T)(cx - fx);
+        const bool zz = t.wz1 == (T)0, yz = t.wy1 == (T)0, xz = t.wx1 == (T)0;
         // 0 <= i < n - 1, or i == n - 1 with a zero fraction (unsigned compare folds the sign test in)
         const bool in_z = ((unsigned)z0 < (unsigned)(p.nz - 1)) | ((z0 == p.nz - 1) & zz);
         const bool in_y = ((unsigned)y0 < (unsigned)(p.ny - 1)) | ((y0 == p.ny - 1) & yz);
@@ -146,23 +169,24 @@ __device__ __forceinline__ void taps(const __amdgpu_buffer_rsrc_t in, const Fast
         // At the last column (only reachable with wx1 == 0) the pair is shifted left by one.
         const bool lastcol = x0 >= p.nx - 1;
         const int xb = x0 - (lastcol ? 1 : 0);
-        const unsigned base = t.outside ? 0u : (unsigned)((z0 * p.ny + y0) * p.nx + xb) * 4u;
-        const unsigned sz = (t.outside | zz) ? 0u : (unsigned)(p.ny * p.nx) * 4u;
-        const unsigned sy = (t.outside | yz) ? 0u : (unsigned)p.nx * 4u;
+        const unsigned base = t.outside ? 0u : (unsigned)((z0 * p.ny + y0) * p.nx + xb) * ES;
+        const unsigned sz = (t.outside | zz) ? 0u : (unsigned)(p.ny * p.nx) * ES;
+        const unsigned sy = (t.outside | yz) ? 0u : (unsigned)p.nx * ES;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(in, base + (m >> 1) * sz + (m & 1) * sy, 0, 0);
-            t.v[2 * m] = __uint_as_float(lastcol ? q.y : q.x);
-            t.v[2 * m + 1] = __uint_as_float(q.y);
+            T a, b;
+            load_pair(in, base + (m >> 1) * sz + (m & 1) * sy, a, b);
+            t.v[2 * m] = lastcol ? b : a;
+            t.v[2 * m + 1] = b;
         }
         return;
     } else {
         int zi[2], yi[2], xi[2];
-        float wz[2], wy[2], wx[2];
+        T wz[2], wy[2], wx[2];
         bool outside = false;
-        axis_taps<CT, FASTC, ORDER>(cz, p.nz, p.mode, p.order, zi[0], zi[1], wz[0], wz[1], outside);
-        axis_taps<CT, FASTC, ORDER>(cy, p.ny, p.mode, p.order, yi[0], yi[1], wy[0], wy[1], outside);
-        axis_taps<CT, FASTC, ORDER>(cx, p.nx, p.mode, p.order, xi[0], xi[1], wx[0], wx[1], outside);
+        axis_taps<CT, FASTC, ORDER, T>(cz, p.nz, p.mode, p.order, zi[0], zi[1], wz[0], wz[1], outside);
+        axis_taps<CT, FASTC, ORDER, T>(cy, p.ny, p.mode, p.order, yi[0], yi[1], wy[0], wy[1], outside);
+        axis_taps<CT, FASTC, ORDER, T>(cx, p.nx, p.mode, p.order, xi[0], xi[1], wx[0], wx[1], outside);
         t.outside = outside;
         t.wz1 = wz[1]; t.wy1 = wy[1]; t.wx1 = wx[1];
         t.oobmask = 0;
@@ -173,8 +197,8 @@ __device__ __forceinline__ void taps(const __amdgpu_buffer_rsrc_t in, const Fast
             const int a = m >> 2, b = (m >> 1) & 1, c = m & 1;
             const bool oob = (zi[a] | yi[b] | xi[c]) < 0;
             if (oob) t.oobmask |= 1u << m;
-            const unsigned off = (oob || outside) ? 0u : (unsigned)((zi[a] * p.ny + yi[b]) * p.nx + xi[c]) * 4u;
-            t.v[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in, off, 0, 0));
+            const unsigned off = (oob || outside) ? 0u : (unsigned)((zi[a] * p.ny + yi[b]) * p.nx + xi[c]) * ES;
+            load_one(in, off, t.v[m]);
         }
     }
 }
@@ -183,16 +207,21 @@ __device__ __forceinline__ float lerp_skip(float lo, float hi, float w)
 {
     return w == 0.f ? lo : fmaf(w, hi - lo, lo);
 }
-
-__device__ __forceinline__ float finish(const Taps &t, float cval)
+__device__ __forceinline__ double lerp_skip(double lo, double hi, double w)
 {
-    float v[8];
+    return w == 0.0 ? lo : fma(w, hi - lo, lo);
+}
+
+template <typename T>
+__device__ __forceinline__ T finish(const Taps<T> &t, T cval)
+{
+    T v[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) v[m] = ((t.oobmask >> m) & 1u) ? cval : t.v[m];
-    const float x00 = lerp_skip(v[0], v[1], t.wx1), x01 = lerp_skip(v[2], v[3], t.wx1);
-    const float x10 = lerp_skip(v[4], v[5], t.wx1), x11 = lerp_skip(v[6], v[7], t.wx1);
-    const float y0 = lerp_skip(x00, x01, t.wy1), y1 = lerp_skip(x10, x11, t.wy1);
-    const float r = lerp_skip(y0, y1, t.wz1);
+    const T x00 = lerp_skip(v[0], v[1], t.wx1), x01 = lerp_skip(v[2], v[3], t.wx1);
+    const T x10 = lerp_skip(v[4], v[5], t.wx1), x11 = lerp_skip(v[6], v[7], t.wx1);
+    const T y0 = lerp_skip(x00, x01, t.wy1), y1 = lerp_skip(x10, x11, t.wy1);
+    const T r = lerp_skip(y0, y1, t.wz1);
     return t.outside ? cval : r;
 }
 
@@ -200,15 +229,15 @@ constexpr int kNV = 4;   // voxels per thread (rows 4 apart), all gathers issued
 
 // block = (64, 4): 64 lanes along x (one voxel each, so every gather instruction of a
 // wave touches neighbouring input voxels); a thread handles kNV rows; grid = (x tiles, y tiles, z)
-template <typename CT, bool FASTC, int ORDER>
+template <typename T, typename CT, bool FASTC, int ORDER>
 __global__ void __launch_bounds__(256)
-map_coords3d_fast(const float *__restrict__ in, const CT *__restrict__ coords, float *__restrict__ out,
+map_coords3d_fast(const T *__restrict__ in, const CT *__restrict__ coords, T *__restrict__ out,
                   const FastInterpParams p)
 {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int z = blockIdx.z;
     if (x >= p.ox) return;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * (int)sizeof(T), 0x00020000);
     const size_t nout = (size_t)p.oz * p.oy * p.ox;
     CT c[kNV][3];
     size_t o[kNV];
@@ -229,23 +258,23 @@ map_coords3d_fast(const float *__restrict__ in, const CT *__restrict__ coords, f
             c[k][2] = __builtin_nontemporal_load(coords + 2 * nout + o[k]);
         }
     }
-    Taps t[kNV];
+    Taps<T> t[kNV];
 #pragma unroll
-    for (int k = 0; k < kNV; k++) taps<CT, FASTC, ORDER>(rin, p, c[k][0], c[k][1], c[k][2], t[k]);
+    for (int k = 0; k < kNV; k++) taps<T, CT, FASTC, ORDER>(rin, p, c[k][0], c[k][1], c[k][2], t[k]);
 #pragma unroll
     for (int k = 0; k < kNV; k++)
-        if (ok[k]) __builtin_nontemporal_store(finish(t[k], p.cval), out + o[k]);
+        if (ok[k]) __builtin_nontemporal_store(finish<T>(t[k], (T)p.cval), out + o[k]);
 }
 
-template <bool FASTC, int ORDER>
+template <typename T, bool FASTC, int ORDER>
 __global__ void __launch_bounds__(256)
-affine3d_fast(const float *__restrict__ in, float *__restrict__ out, const FastInterpParams p)
+affine3d_fast(const T *__restrict__ in, T *__restrict__ out, const FastInterpParams p)
 {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int z = blockIdx.z;
     if (x >= p.ox) return;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
-    Taps t[kNV];
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * (int)sizeof(T), 0x00020000);
+    Taps<T> t[kNV];
     size_t o[kNV];
     bool ok[kNV];
     const double dz = (double)z, dx = (double)x;
@@ -259,18 +288,20 @@ affine3d_fast(const float *__restrict__ in, float *__restrict__ out, const FastI
         const double cz = ((0.0 + p.m[0] * dz) + p.m[1] * dy + p.m[2] * dx) + p.m[3];
         const double cy = ((0.0 + p.m[4] * dz) + p.m[5] * dy + p.m[6] * dx) + p.m[7];
         const double cx = ((0.0 + p.m[8] * dz) + p.m[9] * dy + p.m[10] * dx) + p.m[11];
-        taps<double, FASTC, ORDER>(rin, p, cz, cy, cx, t[k]);
+        taps<T, double, FASTC, ORDER>(rin, p, cz, cy, cx, t[k]);
     }
 #pragma unroll
     for (int k = 0; k < kNV; k++)
-        if (ok[k]) __builtin_nontemporal_store(finish(t[k], p.cval), out + o[k]);
+        if (ok[k]) __builtin_nontemporal_store(finish<T>(t[k], (T)p.cval), out + o[k]);
 }
 
 static bool fast_ok(const mi_array *in, const mi_array *out, int order)
 {
-    if (in->ndim != out->ndim || (in->ndim != 3 && in->ndim != 2) || in->dtype != MI_F32 || out->dtype != MI_F32) return false;
+    if (in->ndim != out->ndim || (in->ndim != 3 && in->ndim != 2) || (in->dtype != MI_F32 && in->dtype != MI_F64) ||
+        out->dtype != in->dtype)
+        return false;
     if (order < 0 || order > 1) return false;
-    if (numel(in) >= ((int64_t)1 << 29) || numel(out) >= ((int64_t)1 << 31)) return false;   // 32-bit byte offsets
+    if (numel(in) * (int64_t)dtype_size(in->dtype) >= ((int64_t)1 << 31) || numel(out) >= ((int64_t)1 << 31)) return false;   // 32-bit byte offsets
     const int nd = in->ndim;
     if (in->shape[nd - 1] < 2) return false;
     if ((nd == 3 && out->shape[0] > 65535) || (out->shape[nd - 2] + 3) / 4 > 65535) return false;
@@ -284,7 +315,7 @@ static void fill_params(FastInterpParams *p, const mi_array *in, const mi_array 
     p->two_d = pad;
     p->nz = pad ? 1 : (int)in->shape[0]; p->ny = (int)in->shape[1 - pad]; p->nx = (int)in->shape[2 - pad];
     p->oz = pad ? 1 : (int)out->shape[0]; p->oy = (int)out->shape[1 - pad]; p->ox = (int)out->shape[2 - pad];
-    p->order = order; p->mode = mode; p->cval = (float)cval;
+    p->order = order; p->mode = mode; p->cval = in->dtype == MI_F32 ? (double)(float)cval : cval;
 }
 
 // returns MI_ERR_UNSUPPORTED when the request is not covered (caller runs the generic kernel)
@@ -297,9 +328,15 @@ int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_ar
     const dim3 block(64, 4, 1);
     const dim3 grid((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 4 * kNV - 1) / (4 * kNV)), (unsigned)p.oz);
     const bool fastc = mode == MI_MODE_CONSTANT && order == 1;
-#define MI_MAP(CT, FC, ORD)                                                                                   \
-    hipLaunchKernelGGL((map_coords3d_fast<CT, FC, ORD>), grid, block, 0, s, (const float *)in->data,           \
-                       (const CT *)coords->data, (float *)out->data, p)
+#define MI_MAP(CT, FC, ORD)                                                                                        \
+    do {                                                                                                           \
+        if (in->dtype == MI_F32)                                                                                   \
+            hipLaunchKernelGGL((map_coords3d_fast<float, CT, FC, ORD>), grid, block, 0, s, (const float *)in->data, \
+                               (const CT *)coords->data, (float *)out->data, p);                                   \
+        else                                                                                                       \
+            hipLaunchKernelGGL((map_coords3d_fast<double, CT, FC, ORD>), grid, block, 0, s, (const double *)in->data, \
+                               (const CT *)coords->data, (double *)out->data, p);                                  \
+    } while (0)
     if (coords->dtype == MI_F32) {
         if (fastc) MI_MAP(float, true, 1); else if (order == 1) MI_MAP(float, false, 1); else MI_MAP(float, false, 0);
     } else {
@@ -329,12 +366,17 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
     }
     const dim3 block(64, 4, 1);
     const dim3 grid((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 4 * kNV - 1) / (4 * kNV)), (unsigned)p.oz);
-    if (mode == MI_MODE_CONSTANT && order == 1)
-        hipLaunchKernelGGL((affine3d_fast<true, 1>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p);
-    else if (order == 1)
-        hipLaunchKernelGGL((affine3d_fast<false, 1>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p);
-    else
-        hipLaunchKernelGGL((affine3d_fast<false, 0>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p);
+#define MI_AFF(FC, ORD)                                                                                                    \
+    do {                                                                                                                   \
+        if (in->dtype == MI_F32)                                                                                           \
+            hipLaunchKernelGGL((affine3d_fast<float, FC, ORD>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p); \
+        else                                                                                                               \
+            hipLaunchKernelGGL((affine3d_fast<double, FC, ORD>), grid, block, 0, s, (const double *)in->data, (double *)out->data, p); \
+    } while (0)
+    if (mode == MI_MODE_CONSTANT && order == 1) MI_AFF(true, 1);
+    else if (order == 1) MI_AFF(false, 1);
+    else MI_AFF(false, 0);
+#undef MI_AFF
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
