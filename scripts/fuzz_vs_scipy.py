@@ -15,7 +15,7 @@ rng = np.random.default_rng(seed)
 MODES = ["reflect", "constant", "nearest", "mirror", "wrap"]
 DTYPES = ["float32", "float32", "float32", "float64", "uint8", "uint8", "int16", "uint16", "int32"]
 if os.environ.get("FUZZ_BIG"):
-    DTYPES = ["float32", "float32", "uint8", "uint8", "int16", "uint16"]
+    DTYPES = ["float32", "float32", "uint8", "uint8", "int16", "uint16", "float64"]
 
 BIG = bool(os.environ.get("FUZZ_BIG"))      # mid-size volumes / images: the tiling and chunk planning of the fast kernels
 
