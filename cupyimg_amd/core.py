@@ -89,7 +89,7 @@ def _c_strides(shape, itemsize):
 class ndarray:
     """Device array: pointer + shape + byte strides + dtype."""
 
-    __slots__ = ("_mem", "ptr", "shape", "strides", "dtype", "base")
+    __slots__ = ("_mem", "ptr", "shape", "strides", "dtype", "base", "_dc", "_v3")
 
     def __init__(self, shape, dtype=np.float32, _mem=None, _ptr=None, _strides=None, _base=None):
         if np.isscalar(shape):
@@ -106,6 +106,8 @@ class ndarray:
         self.ptr = int(_ptr)
         self.strides = tuple(_strides) if _strides is not None else _c_strides(self.shape, self.dtype.itemsize)
         self.base = _base
+        self._dc = None         # cached C-ABI descriptor: (shape, strides, ptr, MiArray)
+        self._v3 = None         # cached one-plane-volume view of an image
 
     # ------------------------------------------------------------- properties
     @property
@@ -183,6 +185,11 @@ class ndarray:
 
     # ------------------------------------------------------------- C-ABI view
     def _desc(self):
+        # the descriptor is read-only for the library, so one per array object is enough (a filter call on a small
+        # image is bound by this Python layer: building two descriptors cost 3 of its ~20 us)
+        c = self._dc
+        if c is not None and c[0] is self.shape and c[1] is self.strides and c[2] == self.ptr:
+            return c[3]
         d = MiArray()
         d.data = self.ptr
         d.dtype = dtype_code(self.dtype)
@@ -190,7 +197,16 @@ class ndarray:
         for i, (s, st) in enumerate(zip(self.shape, self.strides)):
             d.shape[i] = s
             d.strides[i] = st
+        self._dc = (self.shape, self.strides, self.ptr, d)
         return d
+
+    def _as3(self):
+        """An image as a one-plane volume (what the fused 3-D kernels take); cached."""
+        v = self._v3
+        if v is None or v.ptr != self.ptr or v.shape[1:] != self.shape:
+            v = self._view((1,) + self.shape, (self.strides[0] * self.shape[0],) + self.strides, self.ptr)
+            self._v3 = v
+        return v
 
     # ------------------------------------------------------------- transfers
     def get(self):

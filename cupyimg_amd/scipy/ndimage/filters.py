@@ -158,7 +158,7 @@ def _try_fused_3d(input, output, weights, origins, modes, cval, is_box):
     planes = S.current_planes()
     if input.ndim == 2 and output.ndim == 2 and planes is None:
         # an image is a one-plane volume: same kernels, no z taps
-        as3 = lambda a: a._view([1] + list(a.shape), [a.strides[0] * a.shape[0]] + list(a.strides), a.ptr)   # noqa: E731
+        as3 = lambda a: a._as3()   # noqa: E731
         res = _fused_3d(as3(input), as3(output), [None] + list(weights), [0] + list(origins),
                         ["reflect"] + list(modes), cval, is_box, None)
         return None if res is None else output
@@ -167,6 +167,36 @@ def _try_fused_3d(input, output, weights, origins, modes, cval, is_box):
         raise S.Unsupported("plane-restricted filtering needs the fused 3-D float32 kernel "
                             "(contiguous, non-aliasing float32 volumes, odd kernels of at most 9 taps)")
     return res
+
+
+_NULL_DP = ctypes.cast(None, ctypes.POINTER(ctypes.c_double))
+_WEIGHT_CACHE = {}
+_INTS_CACHE = {}
+
+
+def _marshal_weights(weights):
+    """(arrays kept alive, double *[3], lengths) for three optional host weight vectors; memoised on the values --
+    the same few kernels are requested over and over, and marshalling them was a quarter of a small call."""
+    key = tuple(None if w is None else np.asarray(w, dtype=np.float64).tobytes() for w in weights)
+    hit = _WEIGHT_CACHE.get(key)
+    if hit is None:
+        keep = [None if w is None else np.ascontiguousarray(w, dtype=np.float64).copy() for w in weights]
+        ptrs = (ctypes.POINTER(ctypes.c_double) * 3)(*[
+            _NULL_DP if w is None else w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for w in keep])
+        hit = (keep, ptrs, S.c_ints([0 if w is None else len(w) for w in keep]))
+        if len(_WEIGHT_CACHE) > 256:
+            _WEIGHT_CACHE.clear()
+        _WEIGHT_CACHE[key] = hit
+    return hit
+
+
+def _cached_ints(values):
+    hit = _INTS_CACHE.get(values)
+    if hit is None:
+        if len(_INTS_CACHE) > 1024:
+            _INTS_CACHE.clear()
+        hit = _INTS_CACHE[values] = S.c_ints(values)
+    return hit
 
 
 def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
@@ -193,13 +223,9 @@ def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
     dst = output if direct else core.empty(output.shape, output.dtype)
     if src.ptr % 16 or dst.ptr % 16:
         return None
-    keep = [None if w is None else np.ascontiguousarray(w, dtype=np.float64) for w in weights]
-    ptrs = (ctypes.POINTER(ctypes.c_double) * 3)(*[
-        ctypes.cast(None, ctypes.POINTER(ctypes.c_double)) if w is None
-        else w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for w in keep])
-    wlen = S.c_ints([0 if w is None else len(w) for w in keep])
-    org = S.c_ints(origins)
-    mds = S.c_ints([S.mode_code(m) for m in modes])
+    keep, ptrs, wlen = _marshal_weights(weights)
+    org = _cached_ints(tuple(origins))
+    mds = _cached_ints(tuple(S.mode_code(m) for m in modes))
     a, b = src._desc(), dst._desc()
     try:
         if planes is None:
@@ -230,14 +256,11 @@ def _fused_3d_f64(input, output, weights, origins, modes, cval):
     dst = output if direct else core.empty(output.shape, output.dtype)
     if src.ptr % 16 or dst.ptr % 16:
         return None
-    keep = [None if w is None else np.ascontiguousarray(w, dtype=np.float64) for w in weights]
-    ptrs = (ctypes.POINTER(ctypes.c_double) * 3)(*[
-        ctypes.cast(None, ctypes.POINTER(ctypes.c_double)) if w is None
-        else w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for w in keep])
+    keep, ptrs, wlen = _marshal_weights(weights)
     a, b = src._desc(), dst._desc()
     try:
-        S.check(S.lib().mi_separable3d_f64(ctypes.byref(a), ctypes.byref(b), ptrs, S.c_ints([0 if w is None else len(w) for w in keep]),
-                                           S.c_ints(origins), S.c_ints([S.mode_code(m) for m in modes]), float(cval), None))
+        S.check(S.lib().mi_separable3d_f64(ctypes.byref(a), ctypes.byref(b), ptrs, wlen, _cached_ints(tuple(origins)),
+                                           _cached_ints(tuple(S.mode_code(m) for m in modes)), float(cval), None))
     except S.Unsupported:
         return None
     if not direct:
@@ -343,11 +366,22 @@ def _gaussian_kernel1d(sigma, order, radius):
     return poly.polyval(x.astype(np.float64), q) * phi
 
 
+_GAUSS_CACHE = {}
+
+
 def _gaussian_weights(sigma, order, truncate):
-    sd = float(sigma)
-    lw = int(truncate * sd + 0.5)
-    # correlate, not convolve: revert the kernel (filters.py:716-718)
-    return _gaussian_kernel1d(sigma, order, lw)[::-1].copy()
+    key = (float(sigma), int(order), float(truncate))
+    w = _GAUSS_CACHE.get(key)
+    if w is None:
+        sd = float(sigma)
+        lw = int(truncate * sd + 0.5)
+        # correlate, not convolve: revert the kernel (filters.py:716-718)
+        w = _gaussian_kernel1d(sigma, order, lw)[::-1].copy()
+        w.setflags(write=False)         # shared between calls
+        if len(_GAUSS_CACHE) > 256:
+            _GAUSS_CACHE.clear()
+        _GAUSS_CACHE[key] = w
+    return w
 
 
 def gaussian_filter1d(input, sigma, axis=-1, order=0, output=None, mode="reflect", cval=0.0,
@@ -437,7 +471,7 @@ def _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max):
     out3 = output
     if input.ndim == 2:
         # an image is a one-plane volume: x and y windows in one streaming launch
-        as3 = lambda a: a._view([1] + list(a.shape), [a.strides[0] * a.shape[0]] + list(a.strides), a.ptr)   # noqa: E731
+        as3 = lambda a: a._as3()   # noqa: E731
         input, out3 = as3(input), as3(output)
         sizes, origins, modes = [1] + list(sizes), [0] + list(origins), ["reflect"] + list(modes)
     src = core.ascontiguousarray(input)
@@ -454,8 +488,9 @@ def _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max):
     entry = S.lib().mi_minmax3d_u8 if input.dtype == np.uint8 else S.lib().mi_minmax3d_16
     try:
         cv = int(cval) if np.isfinite(cval) and info.min <= cval <= info.max else 0
-        S.check(entry(ctypes.byref(a), ctypes.byref(b), S.c_ints(sizes), S.c_ints(origins),
-                      S.c_ints([S.mode_code(m) for m in modes]), cv, int(is_max), None))
+        S.check(entry(ctypes.byref(a), ctypes.byref(b), _cached_ints(tuple(int(v) for v in sizes)),
+                      _cached_ints(tuple(int(v) for v in origins)), _cached_ints(tuple(S.mode_code(m) for m in modes)),
+                      cv, int(is_max), None))
     except S.Unsupported:
         return None
     if not direct:
@@ -474,7 +509,7 @@ def _try_stream_minmax_f32(input, output, sizes, origins, modes, cval, is_max):
         return None
     entry = S.lib().mi_minmax3d_f32 if input.dtype == np.float32 else S.lib().mi_minmax3d_f64
     if input.ndim == 2:
-        as3 = lambda a: a._view([1] + list(a.shape), [a.strides[0] * a.shape[0]] + list(a.strides), a.ptr)   # noqa: E731
+        as3 = lambda a: a._as3()   # noqa: E731
         in3, out3 = as3(input), as3(output)
         sizes, origins, modes = [1] + list(sizes), [0] + list(origins), ["reflect"] + list(modes)
     else:
@@ -484,8 +519,9 @@ def _try_stream_minmax_f32(input, output, sizes, origins, modes, cval, is_max):
     dst = out3 if direct else core.empty(out3.shape, out3.dtype)
     a, b = src._desc(), dst._desc()
     try:
-        S.check(entry(ctypes.byref(a), ctypes.byref(b), S.c_ints(sizes), S.c_ints(origins),
-                      S.c_ints([S.mode_code(m) for m in modes]), float(cval), int(is_max), None))
+        S.check(entry(ctypes.byref(a), ctypes.byref(b), _cached_ints(tuple(int(v) for v in sizes)),
+                      _cached_ints(tuple(int(v) for v in origins)), _cached_ints(tuple(S.mode_code(m) for m in modes)),
+                      float(cval), int(is_max), None))
     except S.Unsupported:
         return None
     if not direct:
@@ -718,7 +754,7 @@ def _try_median3x3(input, output, mode, cval):
     dst = output if direct else core.empty(output.shape, output.dtype)
     a, b = src._desc(), dst._desc()
     try:
-        S.check(S.lib().mi_median3x3(ctypes.byref(a), ctypes.byref(b), S.c_ints([S.mode_code(mode)] * 2), float(cval), None))
+        S.check(S.lib().mi_median3x3(ctypes.byref(a), ctypes.byref(b), _cached_ints((S.mode_code(mode),) * 2), float(cval), None))
     except S.Unsupported:
         return None
     if not direct:
