@@ -224,7 +224,7 @@ static int g_stream_wpb = 4;             // test hook: waves per workgroup (1, 2
 extern "C" int mi_debug_set_stream_wpb(int n) { g_stream_wpb = n; return MI_OK; }
 static int g_stream_slice = 0;           // test hook: waves per launch of a pass (0 = one launch)
 extern "C" int mi_debug_set_stream_slice(int n) { g_stream_slice = n; return MI_OK; }
-static int g_stream_min_chunk = 32;      // test hook: shortest chunk the planner may choose
+static int g_stream_min_chunk = 16;      // test hook: shortest chunk the planner may choose
 extern "C" int mi_debug_set_stream_min_chunk(int n) { g_stream_min_chunk = n; return MI_OK; }
 
 template <int WX, int WA, int OP = SP_CORR>
