@@ -23,6 +23,7 @@ struct Med2dParams {
     int mx, my;          // boundary modes along x / y (filter_mode()-normalised)
     float cval;
     int chunk, nchunks, nxt;
+    int swz;             // XCD-aware workgroup order (xcd_block())
 };
 
 __device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
@@ -49,7 +50,7 @@ median3x3_f32_kernel(const float *__restrict__ in, float *__restrict__ out, cons
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nx = p.nx, ny = p.ny, nz = p.nz;
     const int nlines = nz * p.nxt;
-    const int wid = blockIdx.x * 4 + wave;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
     if (wid >= nlines * p.nchunks) return;
     const int c = wid / nlines;
     const int line = wid - c * nlines;
@@ -184,6 +185,7 @@ extern "C" int mi_median3x3(const mi_array *in, const mi_array *out, const int m
     p.nxt = (int)((nx + 255) / 256);
     median_chunks(p.nz * p.nxt, p.ny, &p.chunk, &p.nchunks);
     const int waves = p.nz * p.nxt * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz * 4);
     hipLaunchKernelGGL(median3x3_f32_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, (const float *)in->data, (float *)out->data, p);
     MI_HIP(hipGetLastError());
     return MI_OK;

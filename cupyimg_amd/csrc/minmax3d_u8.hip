@@ -19,6 +19,7 @@
 // doubling (2, 4, then W), along the streamed axis from a register ring of the
 // previous W-1 samples that is rotated by unrolling.
 #include "sep_common.hpp"
+#include "stream3d.hpp"
 
 namespace mi {
 
@@ -155,6 +156,7 @@ struct U8StreamParams {
     int mx;              // x boundary mode
     unsigned cval4;      // cval byte replicated to 4 bytes
     int chunk, nchunks, nxt;
+    int swz;             // XCD-aware workgroup order (xcd_block())
 };
 
 __device__ __forceinline__ unsigned bswap32(unsigned x) { return __builtin_bswap32(x); }
@@ -199,7 +201,7 @@ stream_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     const int nother = p.axis == 0 ? ny : nz;
     const int nA = p.axis == 0 ? nz : ny;
     const int nlines = nother * p.nxt;
-    const int wid = blockIdx.x * 4 + wave;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
     if (wid >= nlines * p.nchunks) return;
     const int c = wid / nlines;
     const int line = wid - c * nlines;
@@ -342,7 +344,7 @@ median3x3_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, c
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nx = p.nx, ny = p.ny, nz = p.nz;
     const int nlines = nz * p.nxt;
-    const int wid = blockIdx.x * 4 + wave;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
     if (wid >= nlines * p.nchunks) return;
     const int c = wid / nlines;
     const int line = wid - c * nlines;
@@ -466,6 +468,7 @@ int run_median3x3_u8(const uint8_t *in, uint8_t *out, int nz, int ny, int nx, in
     p.chunk = (ny + nch - 1) / nch;
     p.nchunks = (ny + p.chunk - 1) / p.chunk;
     const int waves = nlines * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz);
     hipLaunchKernelGGL(median3x3_u8_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -494,6 +497,7 @@ static int launch_u8(const uint8_t *in, uint8_t *out, U8StreamParams &p, hipStre
     p.chunk = (nA + nch - 1) / nch;
     p.nchunks = (nA + p.chunk - 1) / p.chunk;
     const int waves = nlines * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz);
     hipLaunchKernelGGL((stream_minmax_u8_kernel<WX, WA, IS_MAX>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;

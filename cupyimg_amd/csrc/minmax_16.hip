@@ -45,6 +45,7 @@ struct P16Params {
     int mx;              // x boundary mode
     unsigned cval2;      // cval replicated into both halves of a dword
     int chunk, nchunks, nxt;
+    int swz;             // XCD-aware workgroup order (xcd_block())
 };
 
 // the 4-pixel block outside the tile after its boundary fix-up (two dwords, pixel order preserved)
@@ -98,7 +99,7 @@ stream_minmax16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ o
     const int nother = p.axis == 0 ? ny : nz;
     const int nA = p.axis == 0 ? nz : ny;
     const int nlines = nother * p.nxt;
-    const int wid = blockIdx.x * 4 + wave;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
     if (wid >= nlines * p.nchunks) return;
     const int c = wid / nlines;
     const int line = wid - c * nlines;
@@ -213,7 +214,7 @@ median3x3_16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nx = p.nx, ny = p.ny, nz = p.nz;
     const int nlines = nz * p.nxt;
-    const int wid = blockIdx.x * 4 + wave;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
     if (wid >= nlines * p.nchunks) return;
     const int c = wid / nlines;
     const int line = wid - c * nlines;
@@ -328,6 +329,7 @@ static int launch16(const uint16_t *in, uint16_t *out, P16Params &p, hipStream_t
     const int nlines = (p.axis == 0 ? p.ny : p.nz) * p.nxt;
     plan_chunks16(nlines, nA, WA - 1, &p.chunk, &p.nchunks);
     const int waves = nlines * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz * 2);
     hipLaunchKernelGGL((stream_minmax16_kernel<WX, WA, IS_MAX, SIGNED>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -392,6 +394,7 @@ int run_median3x3_16(const mi_array *in, const mi_array *out, int mx, int my, do
     p.nxt = (int)((nx + 511) / 512);
     plan_chunks16(p.nz * p.nxt, p.ny, 2, &p.chunk, &p.nchunks);
     const int waves = p.nz * p.nxt * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz * 2);
     if (is_signed)
         hipLaunchKernelGGL(median3x3_16_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, s, (const uint16_t *)in->data, (uint16_t *)out->data, p);
     else

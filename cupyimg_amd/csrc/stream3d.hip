@@ -103,7 +103,7 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     const int nother = p.axis == 0 ? ny : nz;
     const int nA = p.axis == 0 ? nz : ny;
     const int nlines = nother * p.nxt;
-    const int wid = p.wid_base + blockIdx.x * p.wpb + wave;
+    const int wid = p.wid_base + xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * p.wpb + wave;
     if (wid >= nlines * p.nchunks) return;
     const int c = wid / nlines;
     const int line = wid - c * nlines;
@@ -220,6 +220,8 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
 // Round 1 issued a pass in launches of at most 1000 waves because larger launches produced wrong samples; the
 // cause was the store-data hazard described at buffer_store_b128_soff() (sep_common.hpp), not the launch size.
 // The slice hook stays for tests (0 = one launch, the default).
+int g_xcd_swizzle = 2;               // test hook: 0 = plain workgroup order, 1 = always XCD-contiguous, 2 = auto
+extern "C" int mi_debug_set_xcd_swizzle(int k) { g_xcd_swizzle = k; return MI_OK; }
 static int g_stream_wpb = 4;             // test hook: waves per workgroup (1, 2 or 4)
 extern "C" int mi_debug_set_stream_wpb(int n) { g_stream_wpb = n; return MI_OK; }
 static int g_stream_slice = 0;           // test hook: waves per launch of a pass (0 = one launch)
@@ -255,6 +257,7 @@ static int launch_stream(const float *in, float *out, StreamParams &p, hipStream
     const int slice = g_stream_slice > 0 ? g_stream_slice : waves;
     const int wpb = g_stream_wpb;
     p.wpb = wpb;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz * 4);
     for (int base = 0; base < waves; base += slice) {
         p.wid_base = base;
         const int n = std::min(slice, waves - base);

@@ -36,7 +36,24 @@ struct StreamParams {
     float xpair[2][2 * (kStreamMaxTaps / 2 + 2)];
     int wid_base;        // first wave index of this launch (a pass is issued in slices of waves)
     int wpb;             // waves per workgroup of this launch
+    int swz;             // XCD-aware workgroup order (xcd_block())
 };
+
+// Workgroups are handed to the 8 XCDs round robin (workgroup i -> XCD i % 8), and every XCD has its own L2: with the
+// plain order, neighbouring chunks of an image -- which share their ramp rows -- land on different XCDs and each L2
+// fetches those rows from HBM again (measured 1.3-1.4x the algorithmic reads for 7-17-row windows).  This order gives
+// every XCD a contiguous run of workgroups.  g_xcd_swizzle: test hook (0 = plain order).
+extern int g_xcd_swizzle;        // 0 = plain order, 1 = always, 2 = auto
+// auto: arrays up to 128 MiB (4096^2 float32 +7 %, 8192^2 float32 +4 %; a 1 GiB image LOSES 7 %: eight distant streams
+// instead of one front moving through the DRAM pages)
+static inline int xcd_swizzle_for(size_t array_bytes)
+{
+    return g_xcd_swizzle == 1 || (g_xcd_swizzle == 2 && array_bytes <= ((size_t)128 << 20));
+}
+__device__ __forceinline__ int xcd_block(int b, int nblocks, int enabled)
+{
+    return (enabled && (nblocks & 7) == 0) ? (b & 7) * (nblocks >> 3) + (b >> 3) : b;
+}
 
 // what a pass computes: weighted sum, or running minimum / maximum
 enum { SP_CORR = 0, SP_MIN = 1, SP_MAX = 2 };

@@ -24,6 +24,7 @@ struct StreamParamsD {
     int mx;              // x boundary mode
     double cval;
     int chunk, nchunks, nxt;
+    int swz;             // XCD-aware workgroup order (xcd_block())
     double wav[kStreamMaxTaps];
     double wxv[kStreamMaxTaps];
 };
@@ -150,7 +151,7 @@ stream_pass_f64_kernel(const double *__restrict__ in, double *__restrict__ out, 
     const int nother = p.axis == 0 ? ny : nz;
     const int nA = p.axis == 0 ? nz : ny;
     const int nlines = nother * p.nxt;
-    const int wid = blockIdx.x * 4 + wave;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
     if (wid >= nlines * p.nchunks) return;
     const int c = wid / nlines;
     const int line = wid - c * nlines;
@@ -282,6 +283,7 @@ static int launch_stream_d(const double *in, double *out, StreamParamsD &p, hipS
     p.chunk = (nA + nch - 1) / nch;
     p.nchunks = (nA + p.chunk - 1) / p.chunk;
     const int waves = nlines * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz * 8);
     hipLaunchKernelGGL((stream_pass_f64_kernel<WX, WA, DEPTH, OP>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;

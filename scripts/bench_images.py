@@ -10,6 +10,8 @@ from cupyimg_amd import _lib
 if "IMG2D" in os.environ:
     _lib.load().mi_debug_set_sep3d_image2d(int(os.environ["IMG2D"]))
 ONLY = os.environ.get("ONLY", "").split(",") if os.environ.get("ONLY") else None
+if "SWZ" in os.environ:
+    _lib.load().mi_debug_set_xcd_swizzle(int(os.environ["SWZ"]))
 if "MINCHUNK" in os.environ:
     _lib.load().mi_debug_set_stream_min_chunk(int(os.environ["MINCHUNK"]))
 
