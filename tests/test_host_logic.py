@@ -147,3 +147,25 @@ def test_plane_ranges_cover_local_planes_and_interior_needs_no_halo(nz, nranks, 
                     assert lo_ok and hi_ok, (r, z)
             flat = [v for rg in edges for v in rg]
             assert flat == sorted(flat)                      # ascending, disjoint (C-ABI contract)
+
+
+def test_memoised_call_parameters():
+    """Gaussian kernels, marshalled weight vectors and small int arrays are memoised by value (a call on a small image is
+    bound by this Python layer): same values -> same objects, shared kernels are read-only, different values differ."""
+    w1 = filters._gaussian_weights(1.5, 0, 4.0)
+    assert filters._gaussian_weights(1.5, 0, 4.0) is w1 and not w1.flags.writeable
+    assert np.array_equal(w1, scipy_gk(1.5, 0, 6)[::-1])
+    assert filters._gaussian_weights(1.5, 1, 4.0) is not w1
+    keep, ptrs, wlen = filters._marshal_weights([None, w1, np.array([0.25, 0.5, 0.25])])
+    again = filters._marshal_weights([None, w1.copy(), [0.25, 0.5, 0.25]])
+    assert again[1] is ptrs and list(wlen) == [0, len(w1), 3]
+    assert not bool(ptrs[0]) and ptrs[1][0] == w1[0] and ptrs[2][1] == 0.5
+    other = filters._marshal_weights([None, w1, np.array([0.25, 0.5, 0.26])])
+    assert other[1] is not ptrs and other[1][2][2] == 0.26
+    # the marshalled copy does not alias the caller's array
+    mine = np.array([1.0, 2.0, 3.0])
+    k2, p2, _ = filters._marshal_weights([mine, None, None])
+    mine[0] = 9.0
+    assert p2[0][0] == 1.0
+    assert filters._cached_ints((1, 2, 3)) is filters._cached_ints((1, 2, 3))
+    assert list(filters._cached_ints((4, 0, 1))) == [4, 0, 1]
