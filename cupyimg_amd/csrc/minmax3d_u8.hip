@@ -306,6 +306,165 @@ stream_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 }
 
 // ---------------------------------------------------------------------------
+// Flat footprints whose rows are centred runs (disk, diamond / cross, octagon, square: what skimage's morphology
+// passes) on uint8 images and slice-wise on volumes, ONE streaming launch:
+//     out(y, x) = op over rows dy of [ sliding op of width 2 hw[dy] + 1 along x of row y + dy ]
+// The wave streams down the image with the previous WA - 1 raw rows in registers as split windows (the six-dword
+// window xpass_u8 works on); per output row every footprint row contributes one x window of its own width.  Replaces
+// the LDS-tiled footprint kernel for these shapes (a 2.5-D tile kernel has no pipeline on a one-plane volume:
+// 8192^2 disk(1) ran 139 us, disk(3) 263 us).  Bit-exact (comparisons only).
+// ---------------------------------------------------------------------------
+struct U8RunParams {
+    int nx, ny, nz;
+    int mx, my;
+    unsigned cval4;
+    int chunk, nchunks, nxt;
+    int swz;
+    int hw[9];           // half width of the run of footprint row r (0 .. WA-1), -1 = empty row
+};
+
+template <bool IS_MAX>
+__device__ __forceinline__ Vec16 xrun_u8(const Win &w, int hw)
+{
+    switch (hw) {           // wave-uniform
+    case 0: return xpass_u8<1, IS_MAX>(w);
+    case 1: return xpass_u8<3, IS_MAX>(w);
+    case 2: return xpass_u8<5, IS_MAX>(w);
+    case 3: return xpass_u8<7, IS_MAX>(w);
+    default: return xpass_u8<9, IS_MAX>(w);
+    }
+}
+
+template <int WA, bool IS_MAX>
+__global__ void __launch_bounds__(256)
+runs_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8RunParams p)
+{
+    constexpr int DEPTH = 2;
+    constexpr int RINGN = WA - 1;
+    constexpr int U = RINGN > 0 ? (RINGN % DEPTH == 0 ? RINGN : DEPTH * RINGN) : DEPTH;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nlines = nz * p.nxt;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int z = line / p.nxt, xt = line - z * p.nxt;
+    const int x0 = xt * 1024;
+    const int nlanes = min(64, (nx - x0) >> 4);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;
+    const unsigned rowbase = (unsigned)z * plane;
+    const unsigned total_bytes = plane * (unsigned)nz;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? rowbase + (unsigned)(x0 + 16 * lane) : kOOB;
+    const int side = lane == 0 ? 0 : 1;
+    int est, ekind;
+    edge_u8(side, x0, x0 + 16 * nlanes, nx, p.mx, &est, &ekind);
+    const unsigned evoff = ((lane == 0 || lane == last) && ekind != EDGE_CONST) ? rowbase + (unsigned)est : kOOB;
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, ny);
+    const int nsteps = a1 - a0 + WA - 1;
+    const int ai0 = a0 - WA / 2;
+
+    struct Slot { u32x4 v; unsigned e; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        int ai = ai0 + i;
+        if ((unsigned)ai >= (unsigned)ny) ai = bmap<int>(ai, ny, p.my);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * (unsigned)nx;
+        s.v = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0);
+        s.e = __builtin_amdgcn_raw_buffer_load_b32(rin, s.cst ? kOOB : evoff, soff, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    Win ring[RINGN > 0 ? RINGN : 1];        // raw rows as split windows, ring[(J + k) % RINGN] = footprint row k at unrolled step J
+    for (int i0 = 0; i0 < nsteps; i0 += U) {
+        static_for<U>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J % DEPTH];
+                u32x4 v = s.v;
+                unsigned ed = s.e;
+                if (s.cst) { v.x = v.y = v.z = v.w = p.cval4; ed = p.cval4; }
+                else {
+                    if (ekind == EDGE_REV) ed = bswap32(ed);
+                    else if (ekind == EDGE_SPLAT) ed = (side == 0 ? (ed & 0xFFu) : (ed >> 24)) * 0x01010101u;
+                    else if (ekind == EDGE_CONST) ed = p.cval4;
+                }
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                const unsigned l = (unsigned)__builtin_amdgcn_update_dpp((int)ed, (int)v.w, 0x138, 0xf, 0xf, false);
+                unsigned r = (unsigned)__builtin_amdgcn_update_dpp((int)ed, (int)v.x, 0x130, 0xf, 0xf, false);
+                if (lane == last) r = ed;
+                Win w;
+                split(l, w.e[0], w.o[0]);
+                split(v.x, w.e[1], w.o[1]);
+                split(v.y, w.e[2], w.o[2]);
+                split(v.z, w.e[3], w.o[3]);
+                split(v.w, w.e[4], w.o[4]);
+                split(r, w.e[5], w.o[5]);
+                w.e[6] = w.e[5]; w.o[6] = w.o[5];
+                if (i >= WA - 1) {
+                    // footprint row WA - 1 is the row just loaded, row k < WA - 1 sits in ring[(J + k) % RINGN]
+                    Vec16 a;
+                    bool have = false;
+                    static_for<WA>([&](auto KK) {
+                        constexpr int k = decltype(KK)::value;
+                        const int hw = p.hw[k];
+                        if (hw >= 0) {
+                            Vec16 t;
+                            if constexpr (k == WA - 1) t = xrun_u8<IS_MAX>(w, hw);
+                            else t = xrun_u8<IS_MAX>(ring[(J + k) % (RINGN > 0 ? RINGN : 1)], hw);
+                            a = have ? op16<IS_MAX>(a, t) : t;
+                            have = true;
+                        }
+                    });
+                    u32x4 u;
+                    u.x = join(a.e[0], a.o[0]); u.y = join(a.e[1], a.o[1]);
+                    u.z = join(a.e[2], a.o[2]); u.w = join(a.e[3], a.o[3]);
+                    const unsigned so = (unsigned)(a0 + i - (WA - 1)) * (unsigned)nx;
+                    buffer_store_b128_soff(u, rout, voff, so);
+                }
+                if constexpr (RINGN > 0) ring[J % RINGN] = w;
+            }
+        });
+    }
+}
+
+template <int WA, bool IS_MAX>
+static int launch_runs_u8(const uint8_t *in, uint8_t *out, U8RunParams &p, hipStream_t s)
+{
+    const int nlines = p.nz * p.nxt;
+    int nch = 1;
+    {
+        double best = 1e300;
+        for (int c = 1; c <= p.ny && c <= 2048; c++) {
+            const int chunk = (p.ny + c - 1) / c;
+            if (c > 1 && chunk < 8) break;
+            const int real = (p.ny + chunk - 1) / chunk;
+            const double rounds = std::max(1.0, (double)nlines * real / 4096.0);
+            const double cost = rounds * (chunk + (WA - 1) + 4.0);
+            if (cost < best * 0.999) { best = cost; nch = real; }
+        }
+    }
+    p.chunk = (p.ny + nch - 1) / nch;
+    p.nchunks = (p.ny + p.chunk - 1) / p.chunk;
+    const int waves = nlines * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz);
+    hipLaunchKernelGGL((runs_minmax_u8_kernel<WA, IS_MAX>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------
 // 3 x 3 median of uint8 images, one streaming launch (entry point: mi_median3x3, median2d.hip; the float32 kernel and
 // the method are described there).  16 pixels per lane in even/odd split form; med3 = max(min(a,b), min(max(a,b),c)).
 // ---------------------------------------------------------------------------
@@ -920,5 +1079,53 @@ extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int
     if (tmp) pool_free(tmp);
     if (rc == MI_ERR_UNSUPPORTED) set_error("minmax3d_u8: no kernel for this size");
     return rc;
+#undef UNSUP
+}
+
+/* Flat footprint given as centred runs per row (declared in include/mi355img.h). */
+extern "C" int mi_minmax_runs_u8(const mi_array *in, const mi_array *out, int nrows, const int *half_width, const int mode[2],
+                                 int cval, int is_max, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(half_width && mode, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+#define UNSUP(msg) do { set_error("minmax_runs_u8: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if ((in->ndim != 2 && in->ndim != 3) || in->dtype != MI_U8 || out->dtype != MI_U8) UNSUP("needs 2-D / 3-D uint8 in/out");
+    if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
+    if (in->data == out->data) UNSUP("in-place");
+    const int nd = in->ndim;
+    const int64_t nz = nd == 3 ? in->shape[0] : 1, ny = in->shape[nd - 2], nx = in->shape[nd - 1];
+    if (nz < 1 || ny < 1 || nx < 32 || (nx & 15) || (nx & 1023) == 16) UNSUP("x extent must be a multiple of 16, >= 32");
+    if (nz * ny * nx >= ((int64_t)1 << 31)) UNSUP("needs an array < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+    if (nrows < 1 || nrows > 9 || !(nrows & 1)) UNSUP("1, 3, 5, 7 or 9 footprint rows");
+    if (cval < 0 || cval > 255) UNSUP("cval outside uint8");
+    U8RunParams p;
+    memset(&p, 0, sizeof(p));
+    bool any = false;
+    for (int r = 0; r < 9; r++) p.hw[r] = -1;
+    for (int r = 0; r < nrows; r++) {
+        if (half_width[r] < -1 || half_width[r] > 4) UNSUP("runs of at most 9 pixels");
+        p.hw[r] = half_width[r];
+        any = any || half_width[r] >= 0;
+    }
+    if (!any) UNSUP("empty footprint");
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.my = filter_mode(mode[0]); p.mx = filter_mode(mode[1]);
+    p.cval4 = (unsigned)cval * 0x01010101u;
+    p.nxt = (int)((nx + 1023) / 1024);
+    hipStream_t s = resolve_stream(stream);
+    const uint8_t *ip = (const uint8_t *)in->data;
+    uint8_t *op = (uint8_t *)out->data;
+#define RUNS(N) return is_max ? launch_runs_u8<N, true>(ip, op, p, s) : launch_runs_u8<N, false>(ip, op, p, s)
+    switch (nrows) {
+    case 1: RUNS(1);
+    case 3: RUNS(3);
+    case 5: RUNS(5);
+    case 7: RUNS(7);
+    default: RUNS(9);
+    }
+#undef RUNS
 #undef UNSUP
 }

@@ -529,6 +529,54 @@ def _try_stream_minmax_f32(input, output, sizes, origins, modes, cval, is_max):
     return output
 
 
+def _footprint_runs(fp):
+    """Half widths of the rows of a 2-D footprint whose rows are centred runs (disk, diamond, cross, square, octagon),
+    or None: row r covers columns -hw[r] .. +hw[r] about the centre column, -1 = empty row."""
+    h, w = fp.shape
+    if h % 2 == 0 or w % 2 == 0 or h > 9 or w > 9:
+        return None
+    c = w // 2
+    runs = []
+    for row in fp:
+        nz = np.flatnonzero(row)
+        if nz.size == 0:
+            runs.append(-1)
+            continue
+        lo, hi = int(nz[0]), int(nz[-1])
+        if hi - lo + 1 != nz.size or c - lo != hi - c:
+            return None
+        runs.append(hi - c)
+    return runs
+
+
+def _try_runs_minmax_u8(input, output, fp, mode, cval, is_max):
+    """uint8 images (volumes with a one-plane footprint): footprints made of centred runs in one streaming launch."""
+    if S.current_planes() is not None or input.ndim not in (2, 3) or fp.ndim != input.ndim or input.size == 0:
+        return None
+    if fp.ndim == 3:
+        if fp.shape[0] != 1:
+            return None
+        fp = fp[0]
+    runs = _footprint_runs(fp)
+    if runs is None:
+        return None
+    if mode in ("constant", "grid-constant") and not (np.isfinite(cval) and 0 <= cval <= 255 and float(cval) == int(cval)):
+        return None
+    src = core.ascontiguousarray(input)
+    direct = output._is_c_contiguous() and not core.shares_memory(output, src)
+    dst = output if direct else core.empty(output.shape, output.dtype)
+    a, b = src._desc(), dst._desc()
+    try:
+        cv = int(cval) if np.isfinite(cval) and 0 <= cval <= 255 else 0
+        S.check(S.lib().mi_minmax_runs_u8(ctypes.byref(a), ctypes.byref(b), len(runs), _cached_ints(tuple(runs)),
+                                          _cached_ints((S.mode_code(mode),) * 2), cv, int(is_max), None))
+    except S.Unsupported:
+        return None
+    if not direct:
+        output[...] = dst
+    return output
+
+
 def _min_or_max_filter(input, size, ftprnt, structure, output, mode, cval, origin, func):
     """filters.py:1373-1419"""
     input = S.as_device(input)
@@ -577,6 +625,10 @@ def _min_or_max_filter(input, size, ftprnt, structure, output, mode, cval, origi
     if input.size == 0:
         return output
     fp = np.ascontiguousarray(ftprnt, dtype=np.uint8)
+    if structure is None and input.dtype == np.uint8 and output.dtype == np.uint8 and not any(origins):
+        res = _try_runs_minmax_u8(input, output, fp, mode, cval, is_max)
+        if res is not None:
+            return res
     fpp = fp.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
     if structure is not None:
         st, stp = S.c_doubles(structure)

@@ -243,6 +243,15 @@ int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const int size[3], 
 int mi_minmax3d_16(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
                    const int mode[3], int cval, int is_max, mi_stream stream);
 
+/* Flat footprint min / max on uint8 images (volumes: slice by slice) for footprints whose
+ * rows are centred runs -- disk, diamond / cross, octagon, square, i.e. what skimage's
+ * morphology passes (skimage/morphology/grey.py -> morphology.py:769-884 ->
+ * filters.py:1398-1419): footprint row r (0 .. nrows-1, nrows odd <= 9) covers the columns
+ * -half_width[r] .. +half_width[r] (<= 4; -1 = empty row), origin 0.  One streaming
+ * launch, bit-exact.  mode[2]: y and x.  MI_ERR_UNSUPPORTED otherwise (-> mi_minmax_nd). */
+int mi_minmax_runs_u8(const mi_array *in, const mi_array *out, int nrows, const int *half_width,
+                      const int mode[2], int cval, int is_max, mi_stream stream);
+
 /* float64 images and volumes (skimage's working dtype): the separable filter and the
  * flat min / max as streaming passes, x fused into the streamed pass when the tap
  * counts agree -- an image or a slice-wise filter is one launch (16 B/pixel), a volume

@@ -222,3 +222,34 @@ def test_blocked_spline_prefilter(gpu, ndi):
             assert got.dtype == np.float32 and maxnorm_rel(got, ref) <= 2e-6, shape
     finally:
         lib.mi_debug_set_spline_chunk(0)
+
+
+def _disk(r):
+    y, x = np.mgrid[-r:r + 1, -r:r + 1]
+    return (x * x + y * y) <= r * r
+
+
+@pytest.mark.parametrize("shape", [(50, 64), (33, 1040), (90, 2048 + 32), (5, 32), (6, 40, 96)])
+def test_uint8_footprints_of_centred_runs(gpu, ndi, shape):
+    """skimage-style footprints (disk, diamond, square, ...) on uint8 images: one streaming launch, bit-exact."""
+    rng = np.random.default_rng(79)
+    x = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    xd = gpu.asarray(x)
+    diamond2 = np.abs(np.mgrid[-2:3, -2:3]).sum(0) <= 2
+    fps = [_disk(1), _disk(2), _disk(3), _disk(4), diamond2, np.ones((3, 5), bool), np.ones((7, 1), bool),
+           np.array([[0, 1, 0], [1, 1, 1], [1, 1, 1]], bool),                       # rows differ top / bottom
+           np.array([[1, 1, 1], [0, 0, 0], [1, 1, 1]], bool),                       # an empty row
+           np.array([[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [0, 1, 1, 1, 0]], bool),
+           np.array([[1, 0, 1], [1, 1, 1], [0, 1, 0]], bool),                       # not runs: generic kernel
+           np.array([[1, 1, 0], [1, 1, 1], [0, 1, 0]], bool)]                       # not centred: generic kernel
+    for fp in fps:
+        f = fp if x.ndim == 2 else fp[None]
+        for mode in MODES:
+            for name in ("grey_erosion", "grey_dilation", "minimum_filter", "maximum_filter"):
+                ref = getattr(sndi, name)(x, footprint=f, mode=mode, cval=9)
+                got = getattr(ndi, name)(xd, footprint=f, mode=mode, cval=9).get()
+                assert np.array_equal(got, ref), (shape, fp.astype(int).tolist(), name, mode)
+    out = gpu.empty(shape, np.uint8)
+    f = _disk(2) if x.ndim == 2 else _disk(2)[None]
+    ndi.grey_opening(xd, footprint=f, output=out)
+    assert np.array_equal(out.get(), sndi.grey_opening(x, footprint=f))
