@@ -187,6 +187,146 @@ stream_minmax16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ o
     }
 }
 
+static void plan_chunks16(int nlines, int nA, int ramp, int *chunk, int *nchunks);
+
+// ---------------------------------------------------------------------------
+// Flat footprints whose rows are centred runs (disk, diamond, cross, square; see runs_minmax_u8_kernel in
+// minmax3d_u8.hip): the previous WA - 1 raw rows stay in registers as eight-dword windows, every footprint row
+// contributes one x window of its own width.
+// ---------------------------------------------------------------------------
+struct P16RunParams {
+    int nx, ny, nz;
+    int mx, my;
+    unsigned cval2;
+    int chunk, nchunks, nxt;
+    int swz;
+    int hw[9];           // half width of the run of footprint row r, -1 = empty row
+};
+
+struct Win16 { unsigned d[8]; };
+
+template <bool IS_MAX, bool SIGNED>
+__device__ __forceinline__ u32x4 xrun16(const Win16 &w, int hw)
+{
+    switch (hw) {           // wave-uniform
+    case 0: return xwin16<1, IS_MAX, SIGNED>(w.d);
+    case 1: return xwin16<3, IS_MAX, SIGNED>(w.d);
+    case 2: return xwin16<5, IS_MAX, SIGNED>(w.d);
+    case 3: return xwin16<7, IS_MAX, SIGNED>(w.d);
+    default: return xwin16<9, IS_MAX, SIGNED>(w.d);
+    }
+}
+
+template <int WA, bool IS_MAX, bool SIGNED>
+__global__ void __launch_bounds__(256)
+runs_minmax16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, const P16RunParams p)
+{
+    constexpr int DEPTH = 2;
+    constexpr int RINGN = WA - 1;
+    constexpr int U = RINGN > 0 ? lcm_(RINGN, DEPTH) : DEPTH;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nlines = nz * p.nxt;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int z = line / p.nxt, xt = line - z * p.nxt;
+    const int x0 = xt * 512;
+    const int nlanes = min(64, (nx - x0) >> 3);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;
+    const unsigned rowbase = (unsigned)z * plane;
+    const unsigned total_bytes = plane * (unsigned)nz * 2u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? (rowbase + (unsigned)(x0 + 8 * lane)) * 2u : kOOB;
+    const int side = lane == 0 ? 0 : 1;
+    int est, ekind;
+    edge_block(side, 1, x0, x0 + 8 * nlanes, nx, p.mx, &est, &ekind);
+    const unsigned evoff = ((lane == 0 || lane == last) && ekind != EDGE_CONST) ? (rowbase + (unsigned)est) * 2u : kOOB;
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, ny);
+    const int nsteps = a1 - a0 + WA - 1;
+    const int ai0 = a0 - WA / 2;
+
+    struct Slot { u32x4 v; u32x2 e; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        int ai = ai0 + i;
+        if ((unsigned)ai >= (unsigned)ny) ai = bmap<int>(ai, ny, p.my);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * (unsigned)nx * 2u;
+        s.v = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0);
+        s.e = __builtin_amdgcn_raw_buffer_load_b64(rin, s.cst ? kOOB : evoff, soff, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    Win16 ring[RINGN > 0 ? RINGN : 1];
+    for (int i0 = 0; i0 < nsteps; i0 += U) {
+        static_for<U>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J % DEPTH];
+                u32x4 v = s.v;
+                u32x2 ed = s.e;
+                if (s.cst) { v = (u32x4){p.cval2, p.cval2, p.cval2, p.cval2}; ed = (u32x2){p.cval2, p.cval2}; }
+                else ed = fix_edge16(ed, ekind, side, p.cval2);
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                Win16 w;
+                w.d[0] = (unsigned)__builtin_amdgcn_update_dpp((int)ed.x, (int)v.z, 0x138, 0xf, 0xf, false);
+                w.d[1] = (unsigned)__builtin_amdgcn_update_dpp((int)ed.y, (int)v.w, 0x138, 0xf, 0xf, false);
+                unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp((int)ed.x, (int)v.x, 0x130, 0xf, 0xf, false);
+                unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp((int)ed.y, (int)v.y, 0x130, 0xf, 0xf, false);
+                if (lane == last) { r0 = ed.x; r1 = ed.y; }
+                w.d[2] = v.x; w.d[3] = v.y; w.d[4] = v.z; w.d[5] = v.w; w.d[6] = r0; w.d[7] = r1;
+                if (i >= WA - 1) {
+                    u32x4 a = (u32x4){0u, 0u, 0u, 0u};
+                    bool have = false;
+                    static_for<WA>([&](auto KK) {
+                        constexpr int k = decltype(KK)::value;
+                        const int hw = p.hw[k];
+                        if (hw >= 0) {
+                            u32x4 t;
+                            if constexpr (k == WA - 1) t = xrun16<IS_MAX, SIGNED>(w, hw);
+                            else t = xrun16<IS_MAX, SIGNED>(ring[(J + k) % (RINGN > 0 ? RINGN : 1)], hw);
+                            a = have ? op16v<IS_MAX, SIGNED>(a, t) : t;
+                            have = true;
+                        }
+                    });
+                    const unsigned so = (unsigned)(a0 + i - (WA - 1)) * (unsigned)nx * 2u;
+                    buffer_store_b128_soff(a, rout, voff, so);
+                }
+                if constexpr (RINGN > 0) ring[J % RINGN] = w;
+            }
+        });
+    }
+}
+
+template <int WA>
+static int launch_runs16(const uint16_t *in, uint16_t *out, P16RunParams &p, bool is_max, bool is_signed, hipStream_t s)
+{
+    plan_chunks16(p.nz * p.nxt, p.ny, WA - 1, &p.chunk, &p.nchunks);
+    const int waves = p.nz * p.nxt * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz * 2);
+    const dim3 grid((waves + 3) / 4), block(256);
+    if (is_signed) {
+        if (is_max) hipLaunchKernelGGL((runs_minmax16_kernel<WA, true, true>), grid, block, 0, s, in, out, p);
+        else hipLaunchKernelGGL((runs_minmax16_kernel<WA, false, true>), grid, block, 0, s, in, out, p);
+    } else {
+        if (is_max) hipLaunchKernelGGL((runs_minmax16_kernel<WA, true, false>), grid, block, 0, s, in, out, p);
+        else hipLaunchKernelGGL((runs_minmax16_kernel<WA, false, false>), grid, block, 0, s, in, out, p);
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
 // ---------------------------------------------------------------------------
 // 3 x 3 median (method: median2d.hip), two pixels per dword
 // ---------------------------------------------------------------------------
@@ -453,5 +593,46 @@ extern "C" int mi_minmax3d_16(const mi_array *in, const mi_array *out, const int
     }
     for (int t = 0; t < 2; t++) if (tmp[t]) pool_free(tmp[t]);
     return rc;
+#undef UNSUP
+}
+
+/* Flat footprint given as centred runs per row, uint16 / int16 (declared in include/mi355img.h). */
+extern "C" int mi_minmax_runs_16(const mi_array *in, const mi_array *out, int nrows, const int *half_width, const int mode[2],
+                                 int cval, int is_max, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(half_width && mode, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    int64_t nz, ny, nx;
+    if ((rc = geometry16(in, out, "minmax_runs_16", &nz, &ny, &nx))) return rc;
+#define UNSUP(msg) do { set_error("minmax_runs_16: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if (nrows < 1 || nrows > 9 || !(nrows & 1)) UNSUP("1, 3, 5, 7 or 9 footprint rows");
+    const bool is_signed = in->dtype == MI_I16;
+    if (cval < (is_signed ? -32768 : 0) || cval > (is_signed ? 32767 : 65535)) UNSUP("cval outside the dtype");
+    P16RunParams p;
+    memset(&p, 0, sizeof(p));
+    bool any = false;
+    for (int r = 0; r < 9; r++) p.hw[r] = -1;
+    for (int r = 0; r < nrows; r++) {
+        if (half_width[r] < -1 || half_width[r] > 4) UNSUP("runs of at most 9 pixels");
+        p.hw[r] = half_width[r];
+        any = any || half_width[r] >= 0;
+    }
+    if (!any) UNSUP("empty footprint");
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.my = filter_mode(mode[0]); p.mx = filter_mode(mode[1]);
+    p.cval2 = ((unsigned)cval & 0xFFFFu) * 0x10001u;
+    p.nxt = (int)((nx + 511) / 512);
+    hipStream_t s = resolve_stream(stream);
+    const uint16_t *ip = (const uint16_t *)in->data;
+    uint16_t *op = (uint16_t *)out->data;
+    switch (nrows) {
+    case 1: return launch_runs16<1>(ip, op, p, is_max != 0, is_signed, s);
+    case 3: return launch_runs16<3>(ip, op, p, is_max != 0, is_signed, s);
+    case 5: return launch_runs16<5>(ip, op, p, is_max != 0, is_signed, s);
+    case 7: return launch_runs16<7>(ip, op, p, is_max != 0, is_signed, s);
+    default: return launch_runs16<9>(ip, op, p, is_max != 0, is_signed, s);
+    }
 #undef UNSUP
 }

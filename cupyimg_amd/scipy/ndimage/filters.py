@@ -550,7 +550,8 @@ def _footprint_runs(fp):
 
 
 def _try_runs_minmax_u8(input, output, fp, mode, cval, is_max):
-    """uint8 images (volumes with a one-plane footprint): footprints made of centred runs in one streaming launch."""
+    """uint8 / uint16 / int16 images (volumes with a one-plane footprint): footprints made of centred runs in one
+    streaming launch."""
     if S.current_planes() is not None or input.ndim not in (2, 3) or fp.ndim != input.ndim or input.size == 0:
         return None
     if fp.ndim == 3:
@@ -560,16 +561,18 @@ def _try_runs_minmax_u8(input, output, fp, mode, cval, is_max):
     runs = _footprint_runs(fp)
     if runs is None:
         return None
-    if mode in ("constant", "grid-constant") and not (np.isfinite(cval) and 0 <= cval <= 255 and float(cval) == int(cval)):
+    info = np.iinfo(input.dtype)
+    if mode in ("constant", "grid-constant") and not (np.isfinite(cval) and info.min <= cval <= info.max and float(cval) == int(cval)):
         return None
+    entry = S.lib().mi_minmax_runs_u8 if input.dtype == np.uint8 else S.lib().mi_minmax_runs_16
     src = core.ascontiguousarray(input)
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     dst = output if direct else core.empty(output.shape, output.dtype)
     a, b = src._desc(), dst._desc()
     try:
-        cv = int(cval) if np.isfinite(cval) and 0 <= cval <= 255 else 0
-        S.check(S.lib().mi_minmax_runs_u8(ctypes.byref(a), ctypes.byref(b), len(runs), _cached_ints(tuple(runs)),
-                                          _cached_ints((S.mode_code(mode),) * 2), cv, int(is_max), None))
+        cv = int(cval) if np.isfinite(cval) and info.min <= cval <= info.max else 0
+        S.check(entry(ctypes.byref(a), ctypes.byref(b), len(runs), _cached_ints(tuple(runs)),
+                      _cached_ints((S.mode_code(mode),) * 2), cv, int(is_max), None))
     except S.Unsupported:
         return None
     if not direct:
@@ -625,7 +628,7 @@ def _min_or_max_filter(input, size, ftprnt, structure, output, mode, cval, origi
     if input.size == 0:
         return output
     fp = np.ascontiguousarray(ftprnt, dtype=np.uint8)
-    if structure is None and input.dtype == np.uint8 and output.dtype == np.uint8 and not any(origins):
+    if structure is None and input.dtype in (np.uint8, np.uint16, np.int16) and output.dtype == input.dtype and not any(origins):
         res = _try_runs_minmax_u8(input, output, fp, mode, cval, is_max)
         if res is not None:
             return res

@@ -251,6 +251,9 @@ int mi_minmax3d_16(const mi_array *in, const mi_array *out, const int size[3], c
  * launch, bit-exact.  mode[2]: y and x.  MI_ERR_UNSUPPORTED otherwise (-> mi_minmax_nd). */
 int mi_minmax_runs_u8(const mi_array *in, const mi_array *out, int nrows, const int *half_width,
                       const int mode[2], int cval, int is_max, mi_stream stream);
+/* the same for uint16 / int16 images */
+int mi_minmax_runs_16(const mi_array *in, const mi_array *out, int nrows, const int *half_width,
+                      const int mode[2], int cval, int is_max, mi_stream stream);
 
 /* float64 images and volumes (skimage's working dtype): the separable filter and the
  * flat min / max as streaming passes, x fused into the streamed pass when the tap

@@ -229,11 +229,13 @@ def _disk(r):
     return (x * x + y * y) <= r * r
 
 
+@pytest.mark.parametrize("dtype", ["uint8", "uint16", "int16"])
 @pytest.mark.parametrize("shape", [(50, 64), (33, 1040), (90, 2048 + 32), (5, 32), (6, 40, 96)])
-def test_uint8_footprints_of_centred_runs(gpu, ndi, shape):
-    """skimage-style footprints (disk, diamond, square, ...) on uint8 images: one streaming launch, bit-exact."""
+def test_uint8_footprints_of_centred_runs(gpu, ndi, shape, dtype):
+    """skimage-style footprints (disk, diamond, square, ...) on uint8 / 16-bit images: one streaming launch, bit-exact."""
     rng = np.random.default_rng(79)
-    x = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    info = np.iinfo(dtype)
+    x = rng.integers(info.min, info.max + 1, size=shape, dtype=dtype)
     xd = gpu.asarray(x)
     diamond2 = np.abs(np.mgrid[-2:3, -2:3]).sum(0) <= 2
     fps = [_disk(1), _disk(2), _disk(3), _disk(4), diamond2, np.ones((3, 5), bool), np.ones((7, 1), bool),
@@ -249,7 +251,7 @@ def test_uint8_footprints_of_centred_runs(gpu, ndi, shape):
                 ref = getattr(sndi, name)(x, footprint=f, mode=mode, cval=9)
                 got = getattr(ndi, name)(xd, footprint=f, mode=mode, cval=9).get()
                 assert np.array_equal(got, ref), (shape, fp.astype(int).tolist(), name, mode)
-    out = gpu.empty(shape, np.uint8)
+    out = gpu.empty(shape, x.dtype)
     f = _disk(2) if x.ndim == 2 else _disk(2)[None]
     ndi.grey_opening(xd, footprint=f, output=out)
     assert np.array_equal(out.get(), sndi.grey_opening(x, footprint=f))
