@@ -89,7 +89,7 @@ def _c_strides(shape, itemsize):
 class ndarray:
     """Device array: pointer + shape + byte strides + dtype."""
 
-    __slots__ = ("_mem", "ptr", "shape", "strides", "dtype", "base", "_dc", "_v3")
+    __slots__ = ("_mem", "ptr", "shape", "strides", "dtype", "base", "_dc", "_v3", "_hc")
 
     def __init__(self, shape, dtype=np.float32, _mem=None, _ptr=None, _strides=None, _base=None):
         if np.isscalar(shape):
@@ -108,6 +108,7 @@ class ndarray:
         self.base = _base
         self._dc = None         # cached C-ABI descriptor: (shape, strides, ptr, MiArray)
         self._v3 = None         # cached one-plane-volume view of an image
+        self._hc = None         # host copy of a small constant array (structuring elements), see host_hint()
 
     # ------------------------------------------------------------- properties
     @property
@@ -245,6 +246,7 @@ class ndarray:
         return out
 
     def fill(self, value):
+        self._hc = None
         d = self._desc()
         _lib.check(_lib.load().mi_fill(ctypes.byref(d), float(value), None))
 
@@ -319,6 +321,7 @@ class ndarray:
         return self._view(shape, strides, ptr)
 
     def __setitem__(self, key, value):
+        self._hc = None
         dst = self[key]
         if isinstance(value, ndarray):
             src = value
@@ -456,6 +459,24 @@ def ascontiguousarray(a, dtype=None):
     if dtype is not None and np.dtype(dtype) != a.dtype:
         return a.astype(dtype)
     return a if a._is_c_contiguous() else a.copy()
+
+
+def with_host_hint(a, host):
+    """Remember the host array a small device array was uploaded from (structuring elements: the morphology calls
+    need them on the host again, and fetching one back costs a stream synchronisation plus a copy, ~50 us per call).
+    `__setitem__` and `fill` drop the hint; code that writes the array any other way (as an `output=`) must not rely on
+    it -- only the footprint constructors of skimage.morphology set it."""
+    a._hc = np.array(host, copy=True)
+    a._hc.setflags(write=False)
+    return a
+
+
+def host_copy(a):
+    """NumPy copy of a device array: the remembered upload source if there is one, else a device-to-host copy."""
+    hc = a._hc
+    if hc is not None and hc.shape == a.shape and hc.dtype == a.dtype:
+        return hc.copy()
+    return a.get()
 
 
 def _bounds(a):

@@ -88,7 +88,7 @@ def as_host(a, dtype=None):
     they are tiny and the reference's device syncs on them
     (_filters_core.py:35,39; morphology.py:133,274) are avoided that way."""
     if isinstance(a, core.ndarray):
-        a = a.get()
+        a = core.host_copy(a)
     return np.asarray(a, dtype=dtype)
 
 

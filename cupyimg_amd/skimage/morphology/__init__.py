@@ -34,7 +34,13 @@ def default_selem(func):
 
 
 def _host(selem):
-    return selem.get() if isinstance(selem, core.ndarray) else np.asarray(selem)
+    return core.host_copy(selem) if isinstance(selem, core.ndarray) else np.asarray(selem)
+
+
+def _upload(host):
+    """Device array that remembers its host source (core.with_host_hint): erosion(image, disk(3)) does not fetch
+    the element back from the device on every call."""
+    return core.with_host_hint(core.asarray(host), host)
 
 
 def _shift_selem(selem, shift_x, shift_y):
@@ -222,39 +228,39 @@ def _host_star(a, dtype=np.uint8):
 
 
 def square(width, dtype=np.uint8):
-    return core.asarray(np.ones((width, width), dtype=dtype))
+    return _upload(np.ones((width, width), dtype=dtype))
 
 
 def rectangle(nrows, ncols, dtype=np.uint8):
-    return core.asarray(np.ones((nrows, ncols), dtype=dtype))
+    return _upload(np.ones((nrows, ncols), dtype=dtype))
 
 
 def cube(width, dtype=np.uint8):
-    return core.asarray(np.ones((width, width, width), dtype=dtype))
+    return _upload(np.ones((width, width, width), dtype=dtype))
 
 
 def diamond(radius, dtype=np.uint8):
     """|i| + |j| <= radius on a (2 radius + 1)^2 grid"""
-    return core.asarray(_host_ball_like(int(radius), 2, 1, dtype))
+    return _upload(_host_ball_like(int(radius), 2, 1, dtype))
 
 
 def disk(radius, dtype=np.uint8):
     """i^2 + j^2 <= radius^2"""
-    return core.asarray(_host_ball_like(int(radius), 2, 2, dtype))
+    return _upload(_host_ball_like(int(radius), 2, 2, dtype))
 
 
 def octahedron(radius, dtype=np.uint8):
     """3-D |.|_1 ball; non-integer radii allowed as in the reference"""
-    return core.asarray(_host_ball_like(radius, 3, 1, dtype))
+    return _upload(_host_ball_like(radius, 3, 1, dtype))
 
 
 def ball(radius, dtype=np.uint8):
-    return core.asarray(_host_ball_like(radius, 3, 2, dtype))
+    return _upload(_host_ball_like(radius, 3, 2, dtype))
 
 
 def octagon(m, n, dtype=np.uint8):
-    return core.asarray(_host_octagon(m, n, dtype))
+    return _upload(_host_octagon(m, n, dtype))
 
 
 def star(a, dtype=np.uint8):
-    return core.asarray(_host_star(a, dtype))
+    return _upload(_host_star(a, dtype))

@@ -255,3 +255,23 @@ def test_uint8_footprints_of_centred_runs(gpu, ndi, shape, dtype):
     f = _disk(2) if x.ndim == 2 else _disk(2)[None]
     ndi.grey_opening(xd, footprint=f, output=out)
     assert np.array_equal(out.get(), sndi.grey_opening(x, footprint=f))
+
+
+def test_structuring_element_host_hint(gpu, ndi):
+    """The footprint constructors remember their host source (no device round trip per morphology call); writing the
+    device array drops the hint."""
+    from cupyimg_amd import core
+    from cupyimg_amd.skimage import morphology as skm
+    rng = np.random.default_rng(80)
+    x = rng.integers(0, 256, size=(40, 64), dtype=np.uint8)
+    xd = gpu.asarray(x)
+    d = skm.disk(2)
+    assert d._hc is not None and np.array_equal(core.host_copy(d), d.get())
+    assert np.array_equal(skm.erosion(xd, d).get(), sndi.grey_erosion(x, footprint=d.get()))
+    d[0, 0] = 1                      # now a different element: the hint must not be used any more
+    assert d._hc is None
+    fp = d.get()
+    assert fp[0, 0] == 1
+    assert np.array_equal(skm.erosion(xd, d).get(), sndi.grey_erosion(x, footprint=fp))
+    v = d[::-1]                      # views never carry the hint
+    assert v._hc is None
