@@ -465,6 +465,148 @@ static int launch_runs_u8(const uint8_t *in, uint8_t *out, U8RunParams &p, hipSt
 }
 
 // ---------------------------------------------------------------------------
+// 3 x 3 x 3 footprints whose x rows are centred runs -- generate_binary_structure(3, 1 / 2 / 3), i.e. the 6- / 18- /
+// 26-connected structures of grey and binary morphology on volumes -- on uint8 / bool volumes, ONE streaming launch:
+// a wave owns one (y, 1024-voxel x segment) line and streams along z; per plane it loads the rows y-1, y, y+1 (the
+// neighbouring lines load them too: L1 / L2 hits, HBM sees every row about once), keeps the rows of the two previous
+// planes in registers as split windows, and takes  op over (dz, dy) of [x window of half width hw(dz, dy)].
+// hw: -1 = no sample in that row, 0 = the centre voxel, 1 = three voxels.
+// Replaces the LDS-tiled footprint kernel for these structures on uint8 volumes (512^3, 6-connected: 328 -> 186 us;
+// 512-wide rows fill only half of the 1024-voxel wave segment).  Binary erosion / dilation of bool volumes was tried on
+// top of it and is NOT routed here: 199 us against 143 us for the byte-parallel tiled binary kernel.  Bit-exact.
+// ---------------------------------------------------------------------------
+struct U8Run3Params {
+    int nx, ny, nz;
+    int mx, my, mz;
+    unsigned cval4;
+    int chunk, nchunks, nxt;
+    int swz;
+    int hw[3][3];        // [dz + 1][dy + 1]
+};
+
+template <bool IS_MAX>
+__device__ __forceinline__ Vec16 xrun3_u8(const Win &w, int hw)
+{
+    return hw == 0 ? xpass_u8<1, IS_MAX>(w) : xpass_u8<3, IS_MAX>(w);       // wave-uniform
+}
+
+template <bool IS_MAX>
+__global__ void __launch_bounds__(256)
+runs3d_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8Run3Params p)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nlines = ny * p.nxt;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int y = line / p.nxt, xt = line - y * p.nxt;
+    const int x0 = xt * 1024;
+    const int nlanes = min(64, (nx - x0) >> 4);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;
+    const unsigned total_bytes = plane * (unsigned)nz;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const int side = lane == 0 ? 0 : 1;
+    int est, ekind;
+    edge_u8(side, x0, x0 + 16 * nlanes, nx, p.mx, &est, &ekind);
+    const bool edge_lane = (lane == 0 || lane == last) && ekind != EDGE_CONST;
+    // the three rows of a plane this wave reads: y - 1, y, y + 1 after the y boundary map (-1: a row of cval)
+    int ys[3];
+    unsigned voff[3], evoff[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        ys[r] = bmap<int>(y - 1 + r, ny, p.my);
+        const unsigned rb = (unsigned)max(ys[r], 0) * (unsigned)nx;
+        voff[r] = (lane < nlanes && ys[r] >= 0) ? rb + (unsigned)(x0 + 16 * lane) : kOOB;
+        evoff[r] = (edge_lane && ys[r] >= 0) ? rb + (unsigned)est : kOOB;
+    }
+    const unsigned ovoff = lane < nlanes ? (unsigned)y * (unsigned)nx + (unsigned)(x0 + 16 * lane) : kOOB;
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, nz);
+    const int nsteps = a1 - a0 + 2;
+    const int ai0 = a0 - 1;
+
+    struct Slot { u32x4 v[3]; unsigned e[3]; bool cst; };
+    Slot S[2];
+    auto issue = [&](int i, Slot &s) {
+        int ai = ai0 + i;
+        if ((unsigned)ai >= (unsigned)nz) ai = bmap<int>(ai, nz, p.mz);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * plane;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            s.v[r] = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff[r], soff, 0);
+            s.e[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, s.cst ? kOOB : evoff[r], soff, 0);
+        }
+    };
+    issue(0, S[0]);
+    if (1 < nsteps) issue(1, S[1]);
+
+    Win ring[2][3];                  // the rows of the two previous planes; ring[(J + k) % 2] = plane dz = k - 1 at step J
+    for (int i0 = 0; i0 < nsteps; i0 += 2) {
+        static_for<2>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J];
+                Win w[3];
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    u32x4 v = s.v[r];
+                    unsigned ed = s.e[r];
+                    if (s.cst || ys[r] < 0) { v.x = v.y = v.z = v.w = p.cval4; ed = p.cval4; }
+                    else {
+                        if (ekind == EDGE_REV) ed = bswap32(ed);
+                        else if (ekind == EDGE_SPLAT) ed = (side == 0 ? (ed & 0xFFu) : (ed >> 24)) * 0x01010101u;
+                        else if (ekind == EDGE_CONST) ed = p.cval4;
+                    }
+                    const unsigned l = (unsigned)__builtin_amdgcn_update_dpp((int)ed, (int)v.w, 0x138, 0xf, 0xf, false);
+                    unsigned rr = (unsigned)__builtin_amdgcn_update_dpp((int)ed, (int)v.x, 0x130, 0xf, 0xf, false);
+                    if (lane == last) rr = ed;
+                    split(l, w[r].e[0], w[r].o[0]);
+                    split(v.x, w[r].e[1], w[r].o[1]);
+                    split(v.y, w[r].e[2], w[r].o[2]);
+                    split(v.z, w[r].e[3], w[r].o[3]);
+                    split(v.w, w[r].e[4], w[r].o[4]);
+                    split(rr, w[r].e[5], w[r].o[5]);
+                    w[r].e[6] = w[r].e[5]; w[r].o[6] = w[r].o[5];
+                }
+                if (i + 2 < nsteps) issue(i + 2, s);
+                if (i >= 2) {
+                    Vec16 a;
+                    bool have = false;
+                    static_for<9>([&](auto KK) {
+                        constexpr int k = decltype(KK)::value;
+                        constexpr int dz = k / 3, dy = k % 3;
+                        const int hw = p.hw[dz][dy];
+                        if (hw >= 0) {
+                            Vec16 t;
+                            if constexpr (dz == 2) t = xrun3_u8<IS_MAX>(w[dy], hw);
+                            else t = xrun3_u8<IS_MAX>(ring[(J + dz) % 2][dy], hw);
+                            a = have ? op16<IS_MAX>(a, t) : t;
+                            have = true;
+                        }
+                    });
+                    u32x4 u;
+                    u.x = join(a.e[0], a.o[0]); u.y = join(a.e[1], a.o[1]);
+                    u.z = join(a.e[2], a.o[2]); u.w = join(a.e[3], a.o[3]);
+                    const unsigned so = (unsigned)(a0 + i - 2) * plane;
+                    buffer_store_b128_soff(u, rout, ovoff, so);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; r++) ring[J][r] = w[r];
+            }
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------
 // 3 x 3 median of uint8 images, one streaming launch (entry point: mi_median3x3, median2d.hip; the float32 kernel and
 // the method are described there).  16 pixels per lane in even/odd split form; med3 = max(min(a,b), min(max(a,b),c)).
 // ---------------------------------------------------------------------------
@@ -1127,5 +1269,62 @@ extern "C" int mi_minmax_runs_u8(const mi_array *in, const mi_array *out, int nr
     default: RUNS(9);
     }
 #undef RUNS
+#undef UNSUP
+}
+
+/* 3 x 3 x 3 footprint of centred x runs on a uint8 / bool volume (declared in include/mi355img.h). */
+extern "C" int mi_minmax_runs3d_u8(const mi_array *in, const mi_array *out, const int half_width[9], const int mode[3],
+                                   int cval, int is_max, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(half_width && mode, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+#define UNSUP(msg) do { set_error("minmax_runs3d_u8: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if (in->ndim != 3 || (in->dtype != MI_U8 && in->dtype != MI_BOOL) || out->dtype != in->dtype) UNSUP("needs 3-D uint8 / bool in/out");
+    if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
+    if (in->data == out->data) UNSUP("in-place");
+    const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
+    if (nz < 1 || ny < 1 || nx < 32 || (nx & 15) || (nx & 1023) == 16) UNSUP("x extent must be a multiple of 16, >= 32");
+    if (nz * ny * nx >= ((int64_t)1 << 31)) UNSUP("needs a volume < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+    if (cval < 0 || cval > 255) UNSUP("cval outside uint8");
+    U8Run3Params p;
+    memset(&p, 0, sizeof(p));
+    bool any = false;
+    for (int k = 0; k < 9; k++) {
+        if (half_width[k] < -1 || half_width[k] > 1) UNSUP("runs of at most 3 voxels");
+        p.hw[k / 3][k % 3] = half_width[k];
+        any = any || half_width[k] >= 0;
+    }
+    if (!any) UNSUP("empty footprint");
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.mz = filter_mode(mode[0]); p.my = filter_mode(mode[1]); p.mx = filter_mode(mode[2]);
+    p.cval4 = (unsigned)cval * 0x01010101u;
+    p.nxt = (int)((nx + 1023) / 1024);
+    const int nlines = p.ny * p.nxt;
+    int nch = 1;
+    {
+        double best = 1e300;
+        for (int c = 1; c <= p.nz && c <= 1024; c++) {
+            const int chunk = (p.nz + c - 1) / c;
+            if (c > 1 && chunk < 8) break;
+            const int real = (p.nz + chunk - 1) / chunk;
+            const double rounds = std::max(1.0, (double)nlines * real / 4096.0);
+            const double cost = rounds * (chunk + 2 + 4.0);
+            if (cost < best * 0.999) { best = cost; nch = real; }
+        }
+    }
+    p.chunk = (p.nz + nch - 1) / nch;
+    p.nchunks = (p.nz + p.chunk - 1) / p.chunk;
+    const int waves = nlines * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)nx * ny * nz);
+    hipStream_t s = resolve_stream(stream);
+    if (is_max)
+        hipLaunchKernelGGL(runs3d_minmax_u8_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, s, (const uint8_t *)in->data, (uint8_t *)out->data, p);
+    else
+        hipLaunchKernelGGL(runs3d_minmax_u8_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, s, (const uint8_t *)in->data, (uint8_t *)out->data, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
 #undef UNSUP
 }

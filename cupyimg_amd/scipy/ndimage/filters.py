@@ -549,14 +549,47 @@ def _footprint_runs(fp):
     return runs
 
 
+def _footprint_runs3d(fp):
+    """half widths (-1 / 0 / 1) of the nine x rows of a 3 x 3 x (1 or 3) footprint, or None"""
+    if fp.ndim != 3 or fp.shape[0] != 3 or fp.shape[1] != 3 or fp.shape[2] not in (1, 3):
+        return None
+    runs = _footprint_runs(fp.reshape(9, fp.shape[2]))
+    return runs
+
+
+def _try_runs3d_minmax_u8(input, output, fp, mode, cval, is_max):
+    """uint8 / bool volumes, 3 x 3 x 3 footprints of centred runs (6- / 18- / 26-connected structures): one streaming
+    launch."""
+    if input.ndim != 3 or input.dtype not in (np.uint8, np.bool_) or output.dtype != input.dtype or input.size == 0:
+        return None
+    runs = _footprint_runs3d(fp)
+    if runs is None:
+        return None
+    if mode in ("constant", "grid-constant") and not (np.isfinite(cval) and 0 <= cval <= 255 and float(cval) == int(cval)):
+        return None
+    src = core.ascontiguousarray(input)
+    direct = output._is_c_contiguous() and not core.shares_memory(output, src)
+    dst = output if direct else core.empty(output.shape, output.dtype)
+    a, b = src._desc(), dst._desc()
+    try:
+        cv = int(cval) if np.isfinite(cval) and 0 <= cval <= 255 else 0
+        S.check(S.lib().mi_minmax_runs3d_u8(ctypes.byref(a), ctypes.byref(b), _cached_ints(tuple(runs)),
+                                            _cached_ints((S.mode_code(mode),) * 3), cv, int(is_max), None))
+    except S.Unsupported:
+        return None
+    if not direct:
+        output[...] = dst
+    return output
+
+
 def _try_runs_minmax_u8(input, output, fp, mode, cval, is_max):
     """uint8 / uint16 / int16 images (volumes with a one-plane footprint): footprints made of centred runs in one
     streaming launch."""
     if S.current_planes() is not None or input.ndim not in (2, 3) or fp.ndim != input.ndim or input.size == 0:
         return None
+    if fp.ndim == 3 and fp.shape[0] != 1:
+        return _try_runs3d_minmax_u8(input, output, fp, mode, cval, is_max)
     if fp.ndim == 3:
-        if fp.shape[0] != 1:
-            return None
         fp = fp[0]
     runs = _footprint_runs(fp)
     if runs is None:

@@ -251,6 +251,13 @@ int mi_minmax3d_16(const mi_array *in, const mi_array *out, const int size[3], c
  * launch, bit-exact.  mode[2]: y and x.  MI_ERR_UNSUPPORTED otherwise (-> mi_minmax_nd). */
 int mi_minmax_runs_u8(const mi_array *in, const mi_array *out, int nrows, const int *half_width,
                       const int mode[2], int cval, int is_max, mi_stream stream);
+/* 3 x 3 x 3 footprints of centred x runs on uint8 / bool volumes -- the 6- / 18- / 26-connected
+ * structures of generate_binary_structure(3, k), morphology.py:174-201 -- as one streaming
+ * launch: half_width[3 * (dz + 1) + (dy + 1)] in {-1 (no sample), 0 (centre voxel), 1 (three
+ * voxels)}, mode[3] = z, y, x.  Grey erosion / dilation with such a footprint
+ * (morphology.py:769-884 -> filters.py:1398-1419).  MI_ERR_UNSUPPORTED otherwise. */
+int mi_minmax_runs3d_u8(const mi_array *in, const mi_array *out, const int half_width[9],
+                        const int mode[3], int cval, int is_max, mi_stream stream);
 /* the same for uint16 / int16 images */
 int mi_minmax_runs_16(const mi_array *in, const mi_array *out, int nrows, const int *half_width,
                       const int mode[2], int cval, int is_max, mi_stream stream);

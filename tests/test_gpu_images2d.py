@@ -275,3 +275,33 @@ def test_structuring_element_host_hint(gpu, ndi):
     assert np.array_equal(skm.erosion(xd, d).get(), sndi.grey_erosion(x, footprint=fp))
     v = d[::-1]                      # views never carry the hint
     assert v._hc is None
+
+
+@pytest.mark.parametrize("shape", [(20, 30, 64), (9, 17, 1040), (33, 40, 2048 + 32), (3, 3, 32), (1, 5, 48)])
+def test_volume_footprints_of_centred_runs(gpu, ndi, shape):
+    """6- / 18- / 26-connected structures (and other 3 x 3 x 3 footprints of centred runs) on uint8 volumes: grey
+    erosion / dilation in one streaming launch; the same kernel behind binary erosion / dilation of bool volumes."""
+    rng = np.random.default_rng(81)
+    x = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    xd = gpu.asarray(x)
+    odd = np.zeros((3, 3, 3), bool)
+    odd[0, 1, 1] = odd[1, 0, :] = odd[1, 1, 1] = odd[2, 2, :] = odd[2, 1, 1] = True
+    fps = [sndi.generate_binary_structure(3, 1), sndi.generate_binary_structure(3, 2), sndi.generate_binary_structure(3, 3), odd,
+           np.ones((3, 3, 1), bool)]
+    for fp in fps:
+        for mode in MODES:
+            for name in ("grey_erosion", "grey_dilation"):
+                ref = getattr(sndi, name)(x, footprint=fp, mode=mode, cval=9)
+                got = getattr(ndi, name)(xd, footprint=fp, mode=mode, cval=9).get()
+                assert np.array_equal(got, ref), (shape, fp.astype(int).tolist(), name, mode)
+    b = rng.random(shape) > 0.35
+    bd = gpu.asarray(b)
+    for st in (None, sndi.generate_binary_structure(3, 2), np.ones((3, 3, 3), bool), odd):
+        for bv in (0, 1):
+            for it in (1, 2, 3, -1):
+                for name in ("binary_erosion", "binary_dilation"):
+                    ref = getattr(sndi, name)(b, structure=st, iterations=it, border_value=bv)
+                    got = getattr(ndi, name)(bd, structure=st, iterations=it, border_value=bv).get()
+                    assert got.dtype == np.bool_ and np.array_equal(got, ref), (shape, name, it, bv)
+        assert np.array_equal(ndi.binary_opening(bd, structure=st).get(), sndi.binary_opening(b, structure=st))
+        assert np.array_equal(ndi.binary_closing(bd, structure=st, iterations=2).get(), sndi.binary_closing(b, structure=st, iterations=2))
