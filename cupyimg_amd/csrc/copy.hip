@@ -120,8 +120,8 @@ __global__ void __launch_bounds__(256) elementwise_kernel(const T *__restrict__ 
 // out = a * s + t (op 0) or clip(a, lo, hi) keeping entries equal to `keep`
 // when keep_flag is set (op 1); floating-point arrays (skimage facade: dtype
 // range scaling, warp's output clipping, _warps.py:745-787)
-template <typename T>
-__global__ void __launch_bounds__(256) scalar_op_kernel(const T *__restrict__ a, T *__restrict__ out, int64_t n, int op,
+template <typename T, typename TO = T>
+__global__ void __launch_bounds__(256) scalar_op_kernel(const T *__restrict__ a, TO *__restrict__ out, int64_t n, int op,
                                                         double p0, double p1, double keep, int keep_flag)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) scalar_op_kernel(const T *__restrict__ a,
         double r;
         if (op == 0) r = x * p0 + p1;
         else r = (keep_flag && x == keep) ? x : fmin(fmax(x, p0), p1);
-        out[i] = (T)r;
+        out[i] = (TO)r;
     }
 }
 
@@ -290,14 +290,31 @@ int mi_scalar_op(int op, const mi_array *a, const mi_array *out, double p0, doub
     int rc;
     if ((rc = check_array(a, "a")) || (rc = check_array(out, "out"))) return rc;
     MI_REQUIRE(op == 0 || op == 1, MI_ERR_INVALID_ARG, "unknown scalar operation");
-    MI_REQUIRE(same_shape(a, out) && a->dtype == out->dtype && (a->dtype == MI_F32 || a->dtype == MI_F64), MI_ERR_INVALID_ARG,
-               "float32 / float64 arrays of one shape");
     MI_REQUIRE(is_contiguous(a) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "needs C-contiguous arrays");
     const int64_t n = numel(a);
-    if (n == 0) return MI_OK;
     dim3 grid;
-    grid_for(n, 256, &grid);
+    grid_for(n > 0 ? n : 1, 256, &grid);
     hipStream_t s = resolve_stream(stream);
+    if (op == 0 && same_shape(a, out) && a->dtype != out->dtype && (out->dtype == MI_F32 || out->dtype == MI_F64) &&
+        (a->dtype == MI_U8 || a->dtype == MI_I8 || a->dtype == MI_U16 || a->dtype == MI_I16 || a->dtype == MI_BOOL)) {
+        // integer image -> float image with the range scaling in the same pass (img_as_float: convert, then scale)
+        if (n == 0) return MI_OK;
+        return dispatch_dtype(a->dtype, [&]<typename T>() -> int {
+            if constexpr (sizeof(T) <= 2) {
+                if (out->dtype == MI_F32)
+                    hipLaunchKernelGGL((scalar_op_kernel<T, float>), grid, dim3(256), 0, s, (const T *)a->data, (float *)out->data, n, 0,
+                                       p0, p1, 0.0, 0);
+                else
+                    hipLaunchKernelGGL((scalar_op_kernel<T, double>), grid, dim3(256), 0, s, (const T *)a->data, (double *)out->data, n,
+                                       0, p0, p1, 0.0, 0);
+                MI_HIP(hipGetLastError());
+            }
+            return MI_OK;
+        });
+    }
+    MI_REQUIRE(same_shape(a, out) && a->dtype == out->dtype && (a->dtype == MI_F32 || a->dtype == MI_F64), MI_ERR_INVALID_ARG,
+               "float32 / float64 arrays of one shape (or an 8- / 16-bit integer input with a float output for op 0)");
+    if (n == 0) return MI_OK;
     if (a->dtype == MI_F32)
         hipLaunchKernelGGL((scalar_op_kernel<float>), grid, dim3(256), 0, s, (const float *)a->data, (float *)out->data, n, op, p0,
                            p1, keep, keep_flag);

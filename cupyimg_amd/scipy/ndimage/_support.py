@@ -221,10 +221,11 @@ def elementwise(op, a, b, out):
     return out
 
 
-def scale_shift(a, scale, shift):
-    """a * scale + shift for a float device array (mi_scalar_op)"""
+def scale_shift(a, scale, shift, dtype=None):
+    """a * scale + shift for a float device array (mi_scalar_op); with `dtype` (float32 / float64) an 8- / 16-bit
+    integer array is converted and scaled in the same pass"""
     a = core.ascontiguousarray(a)
-    out = core.empty(a.shape, a.dtype)
+    out = core.empty(a.shape, a.dtype if dtype is None else dtype)
     da, dd = a._desc(), out._desc()
     check(lib().mi_scalar_op(0, ctypes.byref(da), ctypes.byref(dd), float(scale), float(shift), 0.0, 0, None))
     return out

@@ -38,6 +38,11 @@ def _img_as_float(image):
     if dt not in _INT_RANGE:
         raise ValueError("cannot convert {} images to float".format(dt))
     lo, hi = _INT_RANGE[dt]
+    if dt.itemsize <= 2:
+        # conversion and scaling in one pass (same arithmetic: the sample as a double, one multiply-add)
+        if dt.kind == "u":
+            return S.scale_shift(image, 1.0 / hi, 0.0, dtype=np.float64)
+        return S.scale_shift(image, 2.0 / (hi - lo), 1.0 / (hi - lo), dtype=np.float64)
     out = image.astype(np.float64)
     if dt.kind == "u":
         return S.scale_shift(out, 1.0 / hi, 0.0)

@@ -152,7 +152,9 @@ int mi_any_diff(const mi_array *a, const mi_array *b, int32_t *flag_dev, mi_stre
 int mi_elementwise(int op, const mi_array *a, const mi_array *b, const mi_array *out, mi_stream stream);
 /* float32 / float64: op 0: out = a * p0 + p1; op 1: out = clip(a, p0, p1), entries equal
  * to `keep` left alone when keep_flag != 0 (skimage warp's output clipping,
- * skimage/transform/_warps.py:745-787; dtype range scaling of img_as_float). */
+ * skimage/transform/_warps.py:745-787; dtype range scaling of img_as_float).  op 0 also
+ * takes an 8- / 16-bit integer or bool input with a float32 / float64 output: conversion
+ * and scaling in one pass. */
 int mi_scalar_op(int op, const mi_array *a, const mi_array *out, double p0, double p1, double keep,
                  int keep_flag, mi_stream stream);
 /* minimum and maximum of a contiguous array (synchronises the stream) */
