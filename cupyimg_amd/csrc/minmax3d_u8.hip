@@ -607,6 +607,238 @@ runs3d_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 }
 
 // ---------------------------------------------------------------------------
+// uniform_filter on uint8 images (volumes: slice by slice) with a uint8 result, ONE streaming launch in integer
+// arithmetic.  SciPy filters axis by axis and stores every intermediate in the OUTPUT dtype
+// (cupyimg/scipy/ndimage/filters.py:602-665: `uniform_filter1d(input, ..., output); input = output`), i.e. for uint8 in
+// and out:  q1 = trunc(sum of the wy rows / wy)  as uint8, then  out = trunc(sum of wx columns of q1 / wx).  The sums are
+// small integers (<= 9 x 255), exact in u16 lanes; trunc(S / w) is taken as  (unsigned)(S * fl(1 / w) + 0.001): the
+// product is within 1e-4 of S / w and a non-integral quotient is at least 1 / 9 away from the next integer.  The wave
+// streams down the image with a running row sum (ring of the last wy raw rows, split byte form), divides, and runs the
+// x window on the quotient row.  Replaces two generic launches with a double accumulate per sample (8192^2: 370 us).
+// ---------------------------------------------------------------------------
+struct U8BoxParams {
+    int nx, ny, nz;
+    int oy;              // wy / 2 + origin along y
+    int mx, my;
+    unsigned cval4;
+    int chunk, nchunks, nxt;
+    int swz;
+    float ry, rx;        // fl(1 / wy), fl(1 / wx)
+};
+
+__device__ __forceinline__ unsigned div_pk(unsigned s, float r)
+{
+    const unsigned ql = (unsigned)fmaf((float)(s & 0xFFFFu), r, 0.001f), qh = (unsigned)fmaf((float)(s >> 16), r, 0.001f);
+    return ql | (qh << 16);
+}
+
+__device__ __forceinline__ Win addw(const Win &a, const Win &b)
+{
+    Win r;
+#pragma unroll
+    for (int k = 0; k < 7; k++) { r.e[k] = a.e[k] + b.e[k]; r.o[k] = a.o[k] + b.o[k]; }      // u16 lanes, no carry (sums < 65536)
+    return r;
+}
+
+// sum of the WX voxels centred on each of the lane's 16 voxels; b = [left dword | own 4 dwords | right dword], split
+template <int WX>
+__device__ __forceinline__ Vec16 xsum_u8(const Win &b)
+{
+    constexpr int RX = WX / 2;
+    Win m;                                   // m[i] = b[i] + ... + b[i + WX - 1]
+    if constexpr (WX == 1) {
+        m = b;
+    } else {
+        const Win m2 = addw(b, shiftw<1>(b));
+        if constexpr (WX == 3) {
+            m = addw(m2, shiftw<2>(b));
+        } else {
+            const Win m4 = addw(m2, shiftw<2>(m2));
+            if constexpr (WX == 5) m = addw(m4, shiftw<4>(b));
+            else if constexpr (WX == 7) m = addw(addw(m4, shiftw<4>(m2)), shiftw<2>(shiftw<4>(b)));
+            else {
+                Win b8;
+#pragma unroll
+                for (int k = 0; k < 7; k++) { b8.e[k] = b.e[k + 2 < 7 ? k + 2 : 6]; b8.o[k] = b.o[k + 2 < 7 ? k + 2 : 6]; }
+                m = addw(addw(m4, shiftw<4>(m4)), b8);
+            }
+        }
+    }
+    Win s;
+    if constexpr (RX == 4) s = m;
+    else if constexpr (RX == 3) s = shiftw<1>(m);
+    else if constexpr (RX == 2) s = shiftw<2>(m);
+    else if constexpr (RX == 1) s = shiftw<3>(m);
+    else s = shiftw<4>(m);
+    Vec16 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { r.e[k] = s.e[k]; r.o[k] = s.o[k]; }
+    return r;
+}
+
+template <int WX, int WY>
+__global__ void __launch_bounds__(256)
+box2d_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8BoxParams p)
+{
+    constexpr int DEPTH = 2;
+    constexpr int U = WY % DEPTH == 0 ? WY : WY * DEPTH;       // ring of WY rows, DEPTH slots
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nlines = nz * p.nxt;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int z = line / p.nxt, xt = line - z * p.nxt;
+    const int x0 = xt * 1024;
+    const int nlanes = min(64, (nx - x0) >> 4);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;
+    const unsigned rowbase = (unsigned)z * plane;
+    const unsigned total_bytes = plane * (unsigned)nz;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? rowbase + (unsigned)(x0 + 16 * lane) : kOOB;
+    const int side = lane == 0 ? 0 : 1;
+    int est, ekind;
+    edge_u8(side, x0, x0 + 16 * nlanes, nx, p.mx, &est, &ekind);
+    const unsigned evoff = ((lane == 0 || lane == last) && ekind != EDGE_CONST) ? rowbase + (unsigned)est : kOOB;
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, ny);
+    const int nsteps = a1 - a0 + WY - 1;
+    const int ai0 = a0 - p.oy;
+
+    struct Slot { u32x4 v; unsigned e; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        int ai = ai0 + i;
+        if ((unsigned)ai >= (unsigned)ny) ai = bmap<int>(ai, ny, p.my);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * (unsigned)nx;
+        s.v = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0);
+        s.e = __builtin_amdgcn_raw_buffer_load_b32(rin, s.cst ? kOOB : evoff, soff, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    // rows in split form: e[0..3] / o[0..3] own voxels, e[4] / o[4] the edge dword
+    struct Row { unsigned e[5], o[5]; };
+    Row ring[WY];
+    Row sum;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { sum.e[k] = 0u; sum.o[k] = 0u; }
+#pragma unroll
+    for (int r = 0; r < WY; r++)
+#pragma unroll
+        for (int k = 0; k < 5; k++) { ring[r].e[k] = 0u; ring[r].o[k] = 0u; }
+
+    for (int i0 = 0; i0 < nsteps; i0 += U) {
+        static_for<U>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J % DEPTH];
+                u32x4 v = s.v;
+                unsigned ed = s.e;
+                if (s.cst) { v.x = v.y = v.z = v.w = p.cval4; ed = p.cval4; }
+                else {
+                    if (ekind == EDGE_REV) ed = bswap32(ed);
+                    else if (ekind == EDGE_SPLAT) ed = (side == 0 ? (ed & 0xFFu) : (ed >> 24)) * 0x01010101u;
+                    else if (ekind == EDGE_CONST) ed = p.cval4;
+                }
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                Row cur;
+                split(v.x, cur.e[0], cur.o[0]); split(v.y, cur.e[1], cur.o[1]);
+                split(v.z, cur.e[2], cur.o[2]); split(v.w, cur.e[3], cur.o[3]);
+                split(ed, cur.e[4], cur.o[4]);
+                // running sum of the last WY rows: ring[J % WY] holds the row that leaves the window
+                Row &old = ring[J % WY];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    sum.e[k] += cur.e[k] - old.e[k];
+                    sum.o[k] += cur.o[k] - old.o[k];
+                }
+                old = cur;
+                if (i >= WY - 1) {
+                    Row q;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        if constexpr (WY == 1) { q.e[k] = sum.e[k]; q.o[k] = sum.o[k]; }
+                        else { q.e[k] = div_pk(sum.e[k], p.ry); q.o[k] = div_pk(sum.o[k], p.ry); }
+                    }
+                    Vec16 a;
+                    if constexpr (WX == 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { a.e[k] = q.e[k]; a.o[k] = q.o[k]; }
+                    } else {
+                        Win w;
+                        // neighbour dwords of the quotient row (split): the left lane's last dword, the right lane's first
+                        w.e[0] = (unsigned)__builtin_amdgcn_update_dpp((int)q.e[4], (int)q.e[3], 0x138, 0xf, 0xf, false);
+                        w.o[0] = (unsigned)__builtin_amdgcn_update_dpp((int)q.o[4], (int)q.o[3], 0x138, 0xf, 0xf, false);
+                        unsigned re = (unsigned)__builtin_amdgcn_update_dpp((int)q.e[4], (int)q.e[0], 0x130, 0xf, 0xf, false);
+                        unsigned ro = (unsigned)__builtin_amdgcn_update_dpp((int)q.o[4], (int)q.o[0], 0x130, 0xf, 0xf, false);
+                        if (lane == last) { re = q.e[4]; ro = q.o[4]; }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { w.e[k + 1] = q.e[k]; w.o[k + 1] = q.o[k]; }
+                        w.e[5] = re; w.o[5] = ro;
+                        w.e[6] = re; w.o[6] = ro;
+                        const Vec16 sx = xsum_u8<WX>(w);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { a.e[k] = div_pk(sx.e[k], p.rx); a.o[k] = div_pk(sx.o[k], p.rx); }
+                    }
+                    u32x4 u;
+                    u.x = join(a.e[0], a.o[0]); u.y = join(a.e[1], a.o[1]);
+                    u.z = join(a.e[2], a.o[2]); u.w = join(a.e[3], a.o[3]);
+                    const unsigned so = (unsigned)(a0 + i - (WY - 1)) * (unsigned)nx;
+                    buffer_store_b128_soff(u, rout, voff, so);
+                }
+            }
+        });
+    }
+}
+
+template <int WX, int WY>
+static int launch_box2d_u8(const uint8_t *in, uint8_t *out, U8BoxParams &p, hipStream_t s)
+{
+    const int nlines = p.nz * p.nxt;
+    int nch = 1;
+    {
+        double best = 1e300;
+        for (int c = 1; c <= p.ny && c <= 2048; c++) {
+            const int chunk = (p.ny + c - 1) / c;
+            if (c > 1 && chunk < 8) break;
+            const int real = (p.ny + chunk - 1) / chunk;
+            const double rounds = std::max(1.0, (double)nlines * real / 4096.0);
+            const double cost = rounds * (chunk + (WY - 1) + 4.0);
+            if (cost < best * 0.999) { best = cost; nch = real; }
+        }
+    }
+    p.chunk = (p.ny + nch - 1) / nch;
+    p.nchunks = (p.ny + p.chunk - 1) / p.chunk;
+    const int waves = nlines * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz);
+    hipLaunchKernelGGL((box2d_u8_kernel<WX, WY>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+template <int WX>
+static int launch_box2d_u8_wy(int wy, const uint8_t *in, uint8_t *out, U8BoxParams &p, hipStream_t s)
+{
+    switch (wy) {
+    case 1: return launch_box2d_u8<WX, 1>(in, out, p, s);
+    case 3: return launch_box2d_u8<WX, 3>(in, out, p, s);
+    case 5: return launch_box2d_u8<WX, 5>(in, out, p, s);
+    case 7: return launch_box2d_u8<WX, 7>(in, out, p, s);
+    default: return launch_box2d_u8<WX, 9>(in, out, p, s);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // 3 x 3 median of uint8 images, one streaming launch (entry point: mi_median3x3, median2d.hip; the float32 kernel and
 // the method are described there).  16 pixels per lane in even/odd split form; med3 = max(min(a,b), min(max(a,b),c)).
 // ---------------------------------------------------------------------------
@@ -1326,5 +1558,49 @@ extern "C" int mi_minmax_runs3d_u8(const mi_array *in, const mi_array *out, cons
         hipLaunchKernelGGL(runs3d_minmax_u8_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, s, (const uint8_t *)in->data, (uint8_t *)out->data, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
+#undef UNSUP
+}
+
+/* uniform_filter on a uint8 image / slice-wise on a uint8 volume, uint8 result (declared in include/mi355img.h). */
+extern "C" int mi_uniform2d_u8(const mi_array *in, const mi_array *out, const int size[2], int origin_y, const int mode[2],
+                               int cval, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(size && mode, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+#define UNSUP(msg) do { set_error("uniform2d_u8: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if ((in->ndim != 2 && in->ndim != 3) || in->dtype != MI_U8 || out->dtype != MI_U8) UNSUP("needs 2-D / 3-D uint8 in/out");
+    if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
+    if (in->data == out->data) UNSUP("in-place");
+    const int nd = in->ndim;
+    const int64_t nz = nd == 3 ? in->shape[0] : 1, ny = in->shape[nd - 2], nx = in->shape[nd - 1];
+    if (nz < 1 || ny < 1 || nx < 32 || (nx & 15) || (nx & 1023) == 16) UNSUP("x extent must be a multiple of 16, >= 32");
+    if (nz * ny * nx >= ((int64_t)1 << 31)) UNSUP("needs an array < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+    const int wy = size[0], wx = size[1];
+    if (wy < 1 || wy > 9 || !(wy & 1) || wx < 1 || wx > 9 || !(wx & 1)) UNSUP("sizes must be odd and <= 9");
+    if (wy == 1 && wx == 1) UNSUP("nothing to filter");
+    const int oy = wy / 2 + origin_y;
+    if (oy < 0 || oy >= wy) { set_error("invalid origin"); return MI_ERR_INVALID_ARG; }
+    if (cval < 0 || cval > 255) UNSUP("cval outside uint8");
+    U8BoxParams p;
+    memset(&p, 0, sizeof(p));
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.oy = oy;
+    p.my = filter_mode(mode[0]); p.mx = filter_mode(mode[1]);
+    p.cval4 = (unsigned)cval * 0x01010101u;
+    p.nxt = (int)((nx + 1023) / 1024);
+    p.ry = (float)(1.0 / wy); p.rx = (float)(1.0 / wx);
+    hipStream_t s = resolve_stream(stream);
+    const uint8_t *ip = (const uint8_t *)in->data;
+    uint8_t *op = (uint8_t *)out->data;
+    switch (wx) {
+    case 1: return launch_box2d_u8_wy<1>(wy, ip, op, p, s);
+    case 3: return launch_box2d_u8_wy<3>(wy, ip, op, p, s);
+    case 5: return launch_box2d_u8_wy<5>(wy, ip, op, p, s);
+    case 7: return launch_box2d_u8_wy<7>(wy, ip, op, p, s);
+    default: return launch_box2d_u8_wy<9>(wy, ip, op, p, s);
+    }
 #undef UNSUP
 }

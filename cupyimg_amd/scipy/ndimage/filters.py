@@ -300,6 +300,39 @@ def uniform_filter1d(input, size, axis=-1, output=None, mode="reflect", cval=0.0
                         lambda s, d: _launch_uniform1d(s, d, axis, size, origin, mode, cval))
 
 
+def _try_uniform2d_u8(input, output, sizes, origins, modes, cval):
+    """uint8 image (volume: slice by slice) -> uint8: both box passes in one integer-arithmetic launch
+    (mi_uniform2d_u8); None when the request is not covered."""
+    if S.current_planes() is not None or input.size == 0:
+        return None
+    nd = input.ndim
+    sz = [int(v) for v in sizes]
+    og = [int(v) for v in origins]
+    if nd == 3 and (sz[0] != 1):
+        return None
+    if any(v < 1 or v > 9 or v % 2 == 0 for v in sz[-2:]) or og[-1] != 0 or (sz[-2] == 1 and sz[-1] == 1):
+        return None
+    if sz[-2] == 1 and og[-2] != 0:
+        return None
+    md = list(modes)[-2:]
+    if any(m in ("constant", "grid-constant") for m in md):
+        if not (np.isfinite(cval) and 0 <= cval <= 255 and float(cval) == int(cval)):
+            return None
+    src = core.ascontiguousarray(input)
+    direct = output._is_c_contiguous() and not core.shares_memory(output, src)
+    dst = output if direct else core.empty(output.shape, output.dtype)
+    a, b = src._desc(), dst._desc()
+    try:
+        cv = int(cval) if np.isfinite(cval) and 0 <= cval <= 255 else 0
+        S.check(S.lib().mi_uniform2d_u8(ctypes.byref(a), ctypes.byref(b), _cached_ints(tuple(sz[-2:])), og[-2],
+                                        _cached_ints(tuple(S.mode_code(m) for m in md)), cv, None))
+    except S.Unsupported:
+        return None
+    if not direct:
+        output[...] = dst
+    return output
+
+
 def uniform_filter(input, size=3, output=None, mode="reflect", cval=0.0, origin=0, *,
                    dtype_mode="ndimage"):
     """Multi-dimensional uniform filter (filters.py:602-665)."""
@@ -330,6 +363,11 @@ def uniform_filter(input, size=3, output=None, mode="reflect", cval=0.0, origin=
         for ax, sz, og, m in axes:
             w3[ax], o3[ax], m3[ax] = np.full((sz,), 1.0 / sz), og, m
         res = _try_fused_3d(input, output, w3, o3, m3, cval, True)
+        if res is not None:
+            return res
+
+    if dtype_mode != "float" and input.dtype == np.uint8 and output.dtype == np.uint8 and input.ndim in (2, 3):
+        res = _try_uniform2d_u8(input, output, sizes, origins, modes, cval)
         if res is not None:
             return res
 

@@ -245,6 +245,14 @@ int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const int size[3], 
 int mi_minmax3d_16(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
                    const int mode[3], int cval, int is_max, mi_stream stream);
 
+/* uniform_filter on a uint8 image (a uint8 volume: slice by slice) with a uint8 result
+ * (filters.py:602-665 -> :549-599, every intermediate stored in the output dtype): one
+ * streaming launch in integer arithmetic -- q = trunc(row sum / size[0]) as uint8, then
+ * trunc(column sum of q / size[1]).  Odd sizes <= 9 (1 = axis not filtered), origin along y
+ * only, mode[2] = y, x.  MI_ERR_UNSUPPORTED otherwise (-> mi_uniform_filter1d per axis). */
+int mi_uniform2d_u8(const mi_array *in, const mi_array *out, const int size[2], int origin_y,
+                    const int mode[2], int cval, mi_stream stream);
+
 /* Flat footprint min / max on uint8 images (volumes: slice by slice) for footprints whose
  * rows are centred runs -- disk, diamond / cross, octagon, square, i.e. what skimage's
  * morphology passes (skimage/morphology/grey.py -> morphology.py:769-884 ->
