@@ -133,7 +133,11 @@ def structural_similarity(im1, im2, *, win_size=None, gradient=False, data_range
     cov_norm = NP / (NP - 1) if use_sample_covariance else 1.0
 
     ux, uy = filt(x), filt(y)
-    uxx, uyy, uxy = filt(_mul(x, x)), filt(_mul(y, y)), filt(_mul(x, y))
+    xx, yy, xy = (core.empty(x.shape, x.dtype) for _ in range(3))
+    pd = [a._desc() for a in (x, y, xx, yy, xy)]
+    S.check(S.lib().mi_ssim_products(*[ctypes.byref(d) for d in pd], None))       # one read of the pair, three writes
+    uxx, uyy, uxy = filt(xx), filt(yy), filt(xy)
+    del xx, yy, xy
     C1 = (K1 * data_range) ** 2
     C2 = (K2 * data_range) ** 2
 

@@ -163,6 +163,10 @@ int mi_min_max(const mi_array *a, double *lo, double *hi, mi_stream stream);
  * op 1 sum((a - b)^2), op 2 sum(a^2).  Serves the cropped mean of the SSIM map
  * (skimage/metrics/_structural_similarity.py:229-233) and skimage/metrics/simple_metrics.py. */
 int mi_sum(int op, const mi_array *a, const mi_array *b, double *result, mi_stream stream);
+/* x*x, y*y, x*y of two float images in one pass: the second-moment inputs of SSIM
+ * (skimage/metrics/_structural_similarity.py:189-214 forms them with three multiplies). */
+int mi_ssim_products(const mi_array *x, const mi_array *y, const mi_array *xx, const mi_array *yy,
+                     const mi_array *xy, mi_stream stream);
 /* SSIM map from the five filtered moments in one pass, float32 / float64, contiguous:
  * S = ((2 ux uy + C1)(2 vxy + C2)) / ((ux^2 + uy^2 + C1)(vx + vy + C2)), v* = cov_norm (u** - u* u*)
  * (skimage/metrics/_structural_similarity.py:206-227).  gA/gB/gC (all or none) receive the three
