@@ -95,6 +95,7 @@ SIGNATURES = {
     "mi_min_max": [_arr, _dp, _dp, _vp],
     "mi_sum": [_i, _arr, _arr, _dp, _vp],
     "mi_ssim_products": [_arr, _arr, _arr, _arr, _arr, _vp],
+    "mi_ssim_combine_mean": [_arr, _arr, _arr, _arr, _arr, _arr, _i, _d, _d, _d, _dp, _vp],
     "mi_ssim_combine": [_arr] * 9 + [_d, _d, _d, _vp],
     "mi_correlate1d": [_arr, _arr, _i, _dp, _i, _i, _i, _d, _i, _vp],
     "mi_uniform_filter1d": [_arr, _arr, _i, _i, _i, _i, _d, _vp],

@@ -34,6 +34,46 @@ ssim_combine_kernel(const T *__restrict__ ux, const T *__restrict__ uy, const T 
     }
 }
 
+// the same with the mean over the map cropped by `pad` samples on every side accumulated on the way (double partial
+// sums per workgroup): a workgroup walks whole rows, rows and columns outside the crop box do not count.  S may be null
+// (mean only).  Arrays are C-contiguous of shape (n0, n1, n2) (leading unit axes for lower ranks).
+template <typename T>
+__global__ void __launch_bounds__(256)
+ssim_combine_mean_kernel(const T *__restrict__ ux, const T *__restrict__ uy, const T *__restrict__ uxx, const T *__restrict__ uyy,
+                         const T *__restrict__ uxy, T *__restrict__ S, int64_t n0, int64_t n1, int64_t n2, int p0, int p1, int p2,
+                         T cov, T C1, T C2, double *__restrict__ part)
+{
+    __shared__ double sh[256];
+    double acc = 0.0;
+    const int64_t nrows = n0 * n1;
+    for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int64_t i0 = row / n1, i1 = row - i0 * n1;
+        const bool row_in = i0 >= p0 && i0 < n0 - p0 && i1 >= p1 && i1 < n1 - p1;
+        const int64_t base = row * n2;
+        for (int64_t c = threadIdx.x; c < n2; c += blockDim.x) {
+            const int64_t i = base + c;
+            const T mx = ux[i], my = uy[i];
+            const T vx = cov * (uxx[i] - mx * mx);
+            const T vy = cov * (uyy[i] - my * my);
+            const T vxy = cov * (uxy[i] - mx * my);
+            const T A1 = (T)2 * mx * my + C1;
+            const T A2 = (T)2 * vxy + C2;
+            const T B1 = mx * mx + my * my + C1;
+            const T B2 = vx + vy + C2;
+            const T s = (A1 * A2) / (B1 * B2);
+            if (S) S[i] = s;
+            if (row_in && c >= p2 && c < n2 - p2) acc += (double)s;
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) sh[threadIdx.x] += sh[threadIdx.x + sft];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
 struct SumParams {
     int ndim;
     int64_t shape[MI_MAX_NDIM];
@@ -158,6 +198,53 @@ int mi_ssim_combine(const mi_array *ux, const mi_array *uy, const mi_array *uxx,
                            (const double *)uxy->data, (double *)S->data, gA ? (double *)gA->data : nullptr,
                            gA ? (double *)gB->data : nullptr, gA ? (double *)gC->data : nullptr, n, cov_norm, C1, C2);
     MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_ssim_combine_mean(const mi_array *ux, const mi_array *uy, const mi_array *uxx, const mi_array *uyy, const mi_array *uxy,
+                         const mi_array *S, int pad, double cov_norm, double C1, double C2, double *sum_out, mi_stream stream)
+{
+    int rc;
+    const mi_array *req[5] = {ux, uy, uxx, uyy, uxy};
+    for (const mi_array *a : req) {
+        if ((rc = check_array(a, "moment"))) return rc;
+        MI_REQUIRE(same_shape(a, ux) && a->dtype == ux->dtype, MI_ERR_INVALID_ARG, "moments must agree in shape and dtype");
+        MI_REQUIRE(is_contiguous(a), MI_ERR_NOT_CONTIGUOUS, "mi_ssim_combine_mean needs C-contiguous arrays");
+    }
+    if (S) {
+        if ((rc = check_array(S, "S"))) return rc;
+        MI_REQUIRE(same_shape(S, ux) && S->dtype == ux->dtype && is_contiguous(S), MI_ERR_INVALID_ARG, "S must match the moments");
+    }
+    MI_REQUIRE(ux->dtype == MI_F32 || ux->dtype == MI_F64, MI_ERR_INVALID_ARG, "float32 / float64 moments");
+    MI_REQUIRE(sum_out && pad >= 0, MI_ERR_INVALID_ARG, "bad argument");
+    if (ux->ndim < 1 || ux->ndim > 3) { set_error("ssim_combine_mean: rank 1..3"); return MI_ERR_UNSUPPORTED; }
+    *sum_out = 0.0;
+    if (numel(ux) == 0) return MI_OK;
+    int64_t n[3] = {1, 1, 1};
+    int pd[3] = {0, 0, 0};
+    for (int d = 0; d < ux->ndim; d++) { n[3 - ux->ndim + d] = ux->shape[d]; pd[3 - ux->ndim + d] = pad; }
+    hipStream_t s = resolve_stream(stream);
+    const int blocks = (int)std::min<int64_t>(4096, n[0] * n[1]);
+    void *part = nullptr;
+    if ((rc = pool_alloc(&part, (size_t)blocks * sizeof(double), s))) return rc;
+    if (ux->dtype == MI_F32)
+        hipLaunchKernelGGL((ssim_combine_mean_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float *)ux->data,
+                           (const float *)uy->data, (const float *)uxx->data, (const float *)uyy->data, (const float *)uxy->data,
+                           S ? (float *)S->data : nullptr, n[0], n[1], n[2], pd[0], pd[1], pd[2], (float)cov_norm, (float)C1, (float)C2,
+                           (double *)part);
+    else
+        hipLaunchKernelGGL((ssim_combine_mean_kernel<double>), dim3(blocks), dim3(256), 0, s, (const double *)ux->data,
+                           (const double *)uy->data, (const double *)uxx->data, (const double *)uyy->data, (const double *)uxy->data,
+                           S ? (double *)S->data : nullptr, n[0], n[1], n[2], pd[0], pd[1], pd[2], cov_norm, C1, C2, (double *)part);
+    hipError_t e = hipGetLastError();
+    std::vector<double> host((size_t)blocks);
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), part, host.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    pool_free(part);
+    if (e != hipSuccess) { set_error("HIP error: %s", hipGetErrorString(e)); return MI_ERR_INTERNAL; }
+    double t = 0.0;
+    for (int k = 0; k < blocks; k++) t += host[k];
+    *sum_out = t;
     return MI_OK;
 }
 

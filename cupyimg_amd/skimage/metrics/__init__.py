@@ -141,6 +141,21 @@ def structural_similarity(im1, im2, *, win_size=None, gradient=False, data_range
     C1 = (K1 * data_range) ** 2
     C2 = (K2 * data_range) ** 2
 
+    pad = (win_size - 1) // 2
+    if not gradient and 1 <= x.ndim <= 3:
+        # the map (only when asked for) and its cropped mean in one pass
+        Smap = core.empty(x.shape, data_dtype) if full else None
+        descs = [a._desc() for a in (ux, uy, uxx, uyy, uxy)]
+        sd = Smap._desc() if full else None
+        total = ctypes.c_double(0.0)
+        S.check(S.lib().mi_ssim_combine_mean(*[ctypes.byref(d) for d in descs], ctypes.byref(sd) if full else None, pad,
+                                             float(cov_norm), float(C1), float(C2), ctypes.byref(total), None))
+        count = 1
+        for n_ in x.shape:
+            count *= n_ - 2 * pad
+        mssim = total.value / count
+        return (mssim, Smap) if full else mssim
+
     Smap = core.empty(x.shape, data_dtype)
     fields = [core.empty(x.shape, data_dtype) for _ in range(3)] if gradient else [None] * 3
     descs = [a._desc() for a in (ux, uy, uxx, uyy, uxy, Smap)]

@@ -174,6 +174,13 @@ int mi_ssim_products(const mi_array *x, const mi_array *y, const mi_array *xx, c
 int mi_ssim_combine(const mi_array *ux, const mi_array *uy, const mi_array *uxx, const mi_array *uyy,
                     const mi_array *uxy, const mi_array *S, const mi_array *gA, const mi_array *gB,
                     const mi_array *gC, double cov_norm, double C1, double C2, mi_stream stream);
+/* The SSIM map (optional: S may be NULL) and the SUM of the map cropped by `pad` samples on
+ * every side (the mean of _structural_similarity.py:240-243) in the same pass; rank 1..3,
+ * no gradient fields.  *sum_out is a host double (the call synchronises the stream). */
+int mi_ssim_combine_mean(const mi_array *ux, const mi_array *uy, const mi_array *uxx,
+                         const mi_array *uyy, const mi_array *uxy, const mi_array *S, int pad,
+                         double cov_norm, double C1, double C2, double *sum_out,
+                         mi_stream stream);
 
 /* ------------------------------------------------------------------ */
 /* K1: correlate family                                                 */
