@@ -35,6 +35,7 @@ SOURCES = [
     ("stencil3d.hip", ["-ffp-contract=off"]),
     ("minmax.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p16.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_med.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p32a.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p32b.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p64a.hip", ["-ffp-contract=off"]),

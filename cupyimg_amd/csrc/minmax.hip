@@ -173,6 +173,8 @@ rank3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Geom3
 // sorting-network rank kernel: rank_sorted.hpp, instantiated in rank_sorted_*.hip
 template <typename T, typename V, int P>
 int run_rank_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, int rank, hipStream_t s);
+template <typename T, typename V, int N>
+int run_median_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, hipStream_t s);   // rank_sorted_med.hip
 
 }  // namespace mi
 
@@ -185,6 +187,8 @@ using namespace mi;
 
 // test hook (not part of the C-ABI): 0 = never use the LDS-tiled kernel
 static int g_rank_sorted = 1;     // test hook: 0 = rank filters always use the selection kernel
+static int g_rank_median = 1;     // test hook: 0 = medians of 25 / 27 samples take the full 32-sample network
+extern "C" int mi_debug_set_rank_median(int enabled) { g_rank_median = enabled; return MI_OK; }
 extern "C" int mi_debug_set_rank_sorted(int enabled) { g_rank_sorted = enabled; return MI_OK; }
 static int g_minmax_tiled = 1;
 extern "C" int mi_debug_set_minmax_tiled(int enabled) { g_minmax_tiled = enabled; return MI_OK; }
@@ -345,6 +349,12 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
             if (tt3.ntaps <= 64 && out->dtype == in->dtype && g_rank_sorted) {
                 const T *ip = (const T *)in->data;
                 T *op = (T *)out->data;
+                if constexpr (std::is_same<T, float>::value || std::is_same<T, uint8_t>::value || std::is_same<T, uint16_t>::value ||
+                              std::is_same<T, int16_t>::value) {
+                    // the medians of 5 x 5 and 3 x 3 x 3 windows: network pruned for the one output that is needed
+                    if (g_rank_median && tt3.ntaps == 25 && rank == 12) return run_median_sorted<T, V, 25>(ip, op, t3.g, tt3, mode, (V)cv, s);
+                    if (g_rank_median && tt3.ntaps == 27 && rank == 13) return run_median_sorted<T, V, 27>(ip, op, t3.g, tt3, mode, (V)cv, s);
+                }
                 if (tt3.ntaps <= 16) return run_rank_sorted<T, V, 16>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
                 if (tt3.ntaps <= 32) return run_rank_sorted<T, V, 32>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
                 return run_rank_sorted<T, V, 64>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);

@@ -21,7 +21,9 @@ __device__ __forceinline__ void rank_static_for(F &&f)
 // sorting network padded with +inf -- P (log2 P)(log2 P + 1) / 4 compare-exchanges of one v_min + one
 // v_max each, no scratch memory.  The reference picks per-size selection networks
 // (_filters_optimal_medians.py); one network per padded size covers every rank.
-template <typename T, typename V, int P>
+// N > 0 / RANK >= 0: tap count and rank known at compile time (the medians of 5 x 5 and 3 x 3 x 3 windows): the +inf
+// padding folds away and every compare-exchange that cannot reach output RANK is dead code.
+template <typename T, typename V, int P, int N = 0, int RANK = -1>
 __global__ void __launch_bounds__(256)
 rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps3 tt, int mode, V cval, int rank)
 {
@@ -32,7 +34,7 @@ rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps
     const __amdgpu_buffer_rsrc_t rin =
         __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)((unsigned)g.nz * g.ny * g.nx * sizeof(T)), 0x00020000);
     V vals[P];
-    const int n = tt.ntaps;
+    const int n = N > 0 ? N : tt.ntaps;
     if (v.interior) {
         const unsigned base = (unsigned)v.lin * (unsigned)sizeof(T);
         rank_static_for<P>([&](auto TT) {
@@ -69,10 +71,14 @@ rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps
         });
     });
     V res = vals[0];
-    rank_static_for<P - 1>([&](auto TT) {
-        constexpr int t = decltype(TT)::value + 1;
-        res = rank == t ? vals[t] : res;
-    });
+    if constexpr (RANK >= 0) {
+        res = vals[RANK];
+    } else {
+        rank_static_for<P - 1>([&](auto TT) {
+            constexpr int t = decltype(TT)::value + 1;
+            res = rank == t ? vals[t] : res;
+        });
+    }
     out[v.lin] = (T)res;
 }
 
@@ -84,6 +90,19 @@ int run_rank_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mo
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
+
+// the median of N samples (N = 25: 5 x 5, N = 27: 3 x 3 x 3), network pruned at compile time
+template <typename T, typename V, int N>
+int run_median_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, hipStream_t s)
+{
+    hipLaunchKernelGGL((rank3_sorted_kernel<T, V, 32, N, N / 2>), grid3(g), dim3(64, 4, 1), taps3_lds_bytes(tt), s, in, out, g, tt, mode,
+                       cval, N / 2);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+#define MI_MEDIAN_SORTED_INST(T, V, N) \
+    template int run_median_sorted<T, V, N>(const T *, T *, const Geom3 &, const Taps3 &, int, V, hipStream_t)
 
 #define MI_RANK_SORTED_INST(T, V, P) \
     template int run_rank_sorted<T, V, P>(const T *, T *, const Geom3 &, const Taps3 &, int, V, int, hipStream_t)

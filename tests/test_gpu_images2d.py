@@ -332,3 +332,24 @@ def test_uint8_uniform_filter_integer_kernel(gpu, ndi, shape):
         c = np.full(shape, val, np.uint8)
         for size in (3, 5, 7, 9):
             assert np.array_equal(ndi.uniform_filter(gpu.asarray(c), lead + (size, size)).get(), sndi.uniform_filter(c, lead + (size, size)))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "uint8", "int16"])
+def test_medians_of_25_and_27_samples(gpu, ndi, dtype):
+    """5 x 5 and 3 x 3 x 3 medians: the sorting network with the tap count and the rank fixed at compile time."""
+    rng = np.random.default_rng(83)
+    if dtype == "float32":
+        img = rng.standard_normal((45, 70)).astype(dtype)
+        vol = rng.standard_normal((9, 20, 33)).astype(dtype)
+        img[::4, ::5] = np.inf
+        vol[::2, ::3, ::4] = -np.inf
+    else:
+        info = np.iinfo(dtype)
+        img = rng.integers(info.min, info.max + 1, size=(45, 70), dtype=dtype)
+        vol = rng.integers(info.min, info.max + 1, size=(9, 20, 33), dtype=dtype)
+    for mode in MODES:
+        assert np.array_equal(ndi.median_filter(gpu.asarray(img), size=5, mode=mode, cval=2).get(), sndi.median_filter(img, size=5, mode=mode, cval=2))
+        assert np.array_equal(ndi.median_filter(gpu.asarray(vol), size=3, mode=mode, cval=2).get(), sndi.median_filter(vol, size=3, mode=mode, cval=2))
+    # the same window with another rank keeps the run-time network
+    assert np.array_equal(ndi.rank_filter(gpu.asarray(img), 7, size=5).get(), sndi.rank_filter(img, 7, size=5))
+    assert np.array_equal(ndi.percentile_filter(gpu.asarray(vol), 50, size=3).get(), sndi.percentile_filter(vol, 50, size=3))
