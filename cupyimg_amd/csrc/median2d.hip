@@ -132,6 +132,7 @@ median3x3_f32_kernel(const float *__restrict__ in, float *__restrict__ out, cons
 
 int run_median3x3_u8(const uint8_t *in, uint8_t *out, int nz, int ny, int nx, int mx, int my, int cval, hipStream_t s);  // minmax3d_u8.hip
 int run_median3x3_16(const mi_array *in, const mi_array *out, int mx, int my, double cval, hipStream_t s);                   // minmax_16.hip
+int run_median3x3_f64(const mi_array *in, const mi_array *out, int mx, int my, double cval, hipStream_t s);                  // stream_f64.hip
 
 // chunks along y: enough waves to fill the chip (256 CUs x 16 resident waves), chunks of at least 16 rows
 static void median_chunks(int nlines, int ny, int *chunk, int *nchunks)
@@ -155,10 +156,12 @@ extern "C" int mi_median3x3(const mi_array *in, const mi_array *out, const int m
     MI_REQUIRE(mode, MI_ERR_INVALID_ARG, "NULL argument");
     MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
 #define UNSUP(msg) do { set_error("median3x3: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if (in->dtype == MI_F64 && out->dtype == MI_F64)
+        return run_median3x3_f64(in, out, filter_mode(mode[1]), filter_mode(mode[0]), cval, resolve_stream(stream));
     if (in->dtype == out->dtype && (in->dtype == MI_U16 || in->dtype == MI_I16))
         return run_median3x3_16(in, out, filter_mode(mode[1]), filter_mode(mode[0]), cval, resolve_stream(stream));
     if ((in->ndim != 2 && in->ndim != 3) || in->dtype != out->dtype || (in->dtype != MI_F32 && in->dtype != MI_U8))
-        UNSUP("needs 2-D / 3-D float32, uint8, uint16 or int16 in/out");
+        UNSUP("needs 2-D / 3-D float32, float64, uint8, uint16 or int16 in/out");
     if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
     if (in->data == out->data) UNSUP("in-place");
     const int nd = in->ndim;

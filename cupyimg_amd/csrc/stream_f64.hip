@@ -369,6 +369,141 @@ static bool x_extent_ok(int64_t nx, int wx)
     return !(nx < 2 * nb + 2 || (tail != 0 && tail < 2 * nb + 2));
 }
 
+// ---------------------------------------------------------------------------
+// 3 x 3 median of float64 images (method: median2d.hip), two pixels per lane
+// ---------------------------------------------------------------------------
+struct Med2dParamsD {
+    int nx, ny, nz;
+    int mx, my;
+    double cval;
+    int chunk, nchunks, nxt;
+    int swz;
+};
+
+__device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ double dmed3(double a, double b, double c) { return dmax(dmin(a, b), dmin(dmax(a, b), c)); }
+__device__ __forceinline__ void dsort3(double a, double b, double c, double &lo, double &mid, double &hi)
+{
+    const double mn = dmin(a, b), mx = dmax(a, b);
+    lo = dmin(mn, c);
+    hi = dmax(mx, c);
+    mid = dmax(mn, dmin(mx, c));
+}
+
+__global__ void __launch_bounds__(256)
+median3x3_f64_kernel(const double *__restrict__ in, double *__restrict__ out, const Med2dParamsD p)
+{
+    constexpr int DEPTH = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nlines = nz * p.nxt;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int z = line / p.nxt, xt = line - z * p.nxt;
+    const int x0 = xt * 128;
+    const int nlanes = min(64, (nx - x0) >> 1);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;
+    const unsigned rowbase = (unsigned)z * plane;
+    const unsigned total_bytes = plane * (unsigned)nz * 8u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? (rowbase + (unsigned)(x0 + 2 * lane)) * 8u : kOOB;
+    const int side = lane == 0 ? 0 : 1;
+    int est, ekind;
+    edge_block2(side, 1, x0, x0 + 2 * nlanes, nx, p.mx, &est, &ekind);
+    const unsigned evoff = ((lane == 0 || lane == last) && ekind != EDGE_CONST) ? (rowbase + (unsigned)est) * 8u : kOOB;
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, ny);
+    const int nsteps = a1 - a0 + 2;
+    const int ai0 = a0 - 1;
+
+    struct Slot { double2 v; double2 e; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        int ai = ai0 + i;
+        if ((unsigned)ai >= (unsigned)ny) ai = bmap<int>(ai, ny, p.my);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * (unsigned)nx * 8u;
+        s.v = as_d2(__builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0));
+        s.e = as_d2(__builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : evoff, soff, 0));
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    const double2 cv2 = make_double2(p.cval, p.cval);
+    double2 rv[2] = {cv2, cv2};
+    double re[2] = {p.cval, p.cval};
+    for (int i0 = 0; i0 < nsteps; i0 += DEPTH) {
+        static_for<DEPTH>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J];
+                const double2 v = s.cst ? cv2 : s.v;
+                const double2 eb = s.cst ? cv2 : apply_kind2(s.e, ekind, side, p.cval);
+                const double ec = side == 0 ? eb.y : eb.x;
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                if (i >= 2) {
+                    double lo0, mid0, hi0, lo1, mid1, hi1, elo, emid, ehi;
+                    dsort3(rv[0].x, rv[1].x, v.x, lo0, mid0, hi0);
+                    dsort3(rv[0].y, rv[1].y, v.y, lo1, mid1, hi1);
+                    dsort3(re[0], re[1], ec, elo, emid, ehi);
+                    const double lo_l = dppd_from_left(elo, lo1), mid_l = dppd_from_left(emid, mid1), hi_l = dppd_from_left(ehi, hi1);
+                    double lo_r = dppd_from_right(elo, lo0), mid_r = dppd_from_right(emid, mid0), hi_r = dppd_from_right(ehi, hi0);
+                    if (lane == last) { lo_r = elo; mid_r = emid; hi_r = ehi; }
+                    double2 o;
+                    o.x = dmed3(dmax(dmax(lo_l, lo0), lo1), dmed3(mid_l, mid0, mid1), dmin(dmin(hi_l, hi0), hi1));
+                    o.y = dmed3(dmax(dmax(lo0, lo1), lo_r), dmed3(mid0, mid1, mid_r), dmin(dmin(hi0, hi1), hi_r));
+                    const unsigned so = (unsigned)(a0 + i - 2) * (unsigned)nx * 8u;
+                    buffer_store_b128_soff(d2_to_u32(o), rout, voff, so);
+                }
+                rv[J % 2] = v;
+                re[J % 2] = ec;
+            }
+        });
+    }
+}
+
+int run_median3x3_f64(const mi_array *in, const mi_array *out, int mx, int my, double cval, hipStream_t s)
+{
+#define UNSUP(msg) do { set_error("median3x3: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if ((in->ndim != 2 && in->ndim != 3) || in->dtype != MI_F64 || out->dtype != MI_F64) UNSUP("needs 2-D / 3-D float64 in/out");
+    if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
+    if (in->data == out->data) UNSUP("in-place");
+    const int nd = in->ndim;
+    const int64_t nz = nd == 3 ? in->shape[0] : 1, ny = in->shape[nd - 2], nx = in->shape[nd - 1];
+    if (nz < 1 || ny < 1 || nx < 4 || (nx & 1)) UNSUP("x extent must be even, >= 4");
+    { const int64_t tail = nx & 127; if (tail != 0 && tail < 4) UNSUP("x extent unsuitable for the streaming x window"); }
+    if (nz * ny * nx * 8 >= ((int64_t)1 << 31)) UNSUP("needs an array < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+#undef UNSUP
+    Med2dParamsD p;
+    memset(&p, 0, sizeof(p));
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.mx = mx; p.my = my;
+    p.cval = cval;
+    p.nxt = (int)((nx + 127) / 128);
+    const int nlines = p.nz * p.nxt;
+    int nch = (4096 + nlines - 1) / nlines;
+    if (nch > p.ny / 16) nch = p.ny / 16;
+    if (nch < 1) nch = 1;
+    p.chunk = (p.ny + nch - 1) / nch;
+    p.nchunks = (p.ny + p.chunk - 1) / p.chunk;
+    const int waves = nlines * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)nx * ny * nz * 8);
+    hipLaunchKernelGGL(median3x3_f64_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, (const double *)in->data, (double *)out->data, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
 }  // namespace mi
 
 using namespace mi;

@@ -933,7 +933,7 @@ def _rank_filter(input, rank, size, footprint, output, mode, cval, origin, opera
         return output
     fp = np.ascontiguousarray(footprint, dtype=np.uint8)
     if (rank == 4 and filter_size == 9 and fp.shape[-2:] == (3, 3) and fp.ndim == input.ndim and fp.ndim in (2, 3)
-            and not any(origins) and input.dtype in (np.float32, np.uint8, np.uint16, np.int16) and output.dtype == input.dtype
+            and not any(origins) and input.dtype in (np.float32, np.float64, np.uint8, np.uint16, np.int16) and output.dtype == input.dtype
             and S.current_planes() is None):
         res = _try_median3x3(input, output, mode, cval)
         if res is not None:

@@ -310,7 +310,7 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
                    const int64_t *fshape, const int *origins, int rank, int mode, double cval,
                    mi_stream stream);
 
-/* 3 x 3 median over the last two axes of a 2-D / 3-D float32, uint8, uint16 or int16 array
+/* 3 x 3 median over the last two axes of a 2-D / 3-D float32, float64, uint8, uint16 or int16 array
  * (median_filter(size=3) / rank_filter(rank=4) with a full 3 x 3 footprint,
  * filters.py:1560-1701,1751-1792; skimage.filters.median's default on images):
  * one streaming launch at 8 (float32) / 2 (uint8) / 4 (16-bit) B/pixel instead of the

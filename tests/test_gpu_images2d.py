@@ -72,7 +72,7 @@ def test_uint8_minmax_on_images(gpu, ndi, shape):
     assert np.array_equal(out.get(), sndi.maximum_filter(x, size=5))
 
 
-@pytest.mark.parametrize("dtype", ["float32", "uint8"])
+@pytest.mark.parametrize("dtype", ["float32", "uint8", "float64"])
 @pytest.mark.parametrize("shape", [(40, 64), (65, 264), (19, 1040), (130, 2048 + 48), (3, 32), (1, 64), (2, 48)])
 def test_median3x3(gpu, ndi, dtype, shape):
     rng = np.random.default_rng(73)
@@ -81,9 +81,9 @@ def test_median3x3(gpu, ndi, dtype, shape):
         x[::3, ::5] = 255
         x[1::4, 2::7] = 0
     else:
-        x = rng.standard_normal(shape).astype(np.float32)
-        x[::3, ::5] = np.float32(np.inf)
-        x[1::4, 2::7] = -np.float32(np.inf)
+        x = rng.standard_normal(shape).astype(dtype)
+        x[::3, ::5] = np.inf
+        x[1::4, 2::7] = -np.inf
         x[2::5, 1::3] = x[0, 0]            # ties
     xd = gpu.asarray(x)
     for mode in MODES:
