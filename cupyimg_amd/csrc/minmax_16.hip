@@ -328,6 +328,175 @@ static int launch_runs16(const uint16_t *in, uint16_t *out, P16RunParams &p, boo
 }
 
 // ---------------------------------------------------------------------------
+// uniform_filter on uint16 / int16 images with a result of the same dtype, in integer arithmetic (method and the
+// argument for the division: box2d_u8_kernel, minmax3d_u8.hip).  Sums need 32 bits here (9 x 65535), so the pixels of a
+// lane are unpacked to one int each; |S| < 2^24 is exact in float32, the quotient is at most 65535 (product error below
+// 0.008), the offset is 0.02 with the sign of S (truncation toward zero, as the C cast of SciPy's double).
+// ---------------------------------------------------------------------------
+struct Box16Params {
+    int nx, ny, nz;
+    int oy;
+    int mx, my;
+    unsigned cval2;
+    int chunk, nchunks, nxt;
+    int swz;
+    float ry, rx;
+};
+
+template <bool SIGNED> __device__ __forceinline__ int px_lo(unsigned d) { return SIGNED ? ((int)(d << 16)) >> 16 : (int)(d & 0xFFFFu); }
+template <bool SIGNED> __device__ __forceinline__ int px_hi(unsigned d) { return SIGNED ? ((int)d) >> 16 : (int)(d >> 16); }
+__device__ __forceinline__ int div_trunc(int s, float r) { return (int)fmaf((float)s, r, s >= 0 ? 0.02f : -0.02f); }
+
+template <int WX, int WY, bool SIGNED>
+__global__ void __launch_bounds__(256)
+box2d_16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, const Box16Params p)
+{
+    constexpr int DEPTH = 2;
+    constexpr int U = WY % DEPTH == 0 ? WY : WY * DEPTH;
+    constexpr int RX = WX / 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nlines = nz * p.nxt;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int z = line / p.nxt, xt = line - z * p.nxt;
+    const int x0 = xt * 512;
+    const int nlanes = min(64, (nx - x0) >> 3);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;
+    const unsigned rowbase = (unsigned)z * plane;
+    const unsigned total_bytes = plane * (unsigned)nz * 2u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? (rowbase + (unsigned)(x0 + 8 * lane)) * 2u : kOOB;
+    const int side = lane == 0 ? 0 : 1;
+    int est, ekind;
+    edge_block(side, 1, x0, x0 + 8 * nlanes, nx, p.mx, &est, &ekind);
+    const unsigned evoff = ((lane == 0 || lane == last) && ekind != EDGE_CONST) ? (rowbase + (unsigned)est) * 2u : kOOB;
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, ny);
+    const int nsteps = a1 - a0 + WY - 1;
+    const int ai0 = a0 - p.oy;
+
+    struct Slot { u32x4 v; u32x2 e; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        int ai = ai0 + i;
+        if ((unsigned)ai >= (unsigned)ny) ai = bmap<int>(ai, ny, p.my);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * (unsigned)nx * 2u;
+        s.v = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0);
+        s.e = __builtin_amdgcn_raw_buffer_load_b64(rin, s.cst ? kOOB : evoff, soff, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    // a row: the lane's 8 pixels and the 4 pixels of its edge block, one int each
+    struct Row { int v[12]; };
+    auto unpack = [&](const u32x4 v, const u32x2 e) {
+        Row r;
+        r.v[0] = px_lo<SIGNED>(v.x); r.v[1] = px_hi<SIGNED>(v.x); r.v[2] = px_lo<SIGNED>(v.y); r.v[3] = px_hi<SIGNED>(v.y);
+        r.v[4] = px_lo<SIGNED>(v.z); r.v[5] = px_hi<SIGNED>(v.z); r.v[6] = px_lo<SIGNED>(v.w); r.v[7] = px_hi<SIGNED>(v.w);
+        r.v[8] = px_lo<SIGNED>(e.x); r.v[9] = px_hi<SIGNED>(e.x); r.v[10] = px_lo<SIGNED>(e.y); r.v[11] = px_hi<SIGNED>(e.y);
+        return r;
+    };
+    struct Packed { u32x4 v; u32x2 e; };
+    Packed ring[WY];                                  // the last WY raw rows, packed (unpacked again when they leave the window)
+    Row sum;
+#pragma unroll
+    for (int k = 0; k < 12; k++) sum.v[k] = 0;
+#pragma unroll
+    for (int r = 0; r < WY; r++) { ring[r].v = (u32x4){0u, 0u, 0u, 0u}; ring[r].e = (u32x2){0u, 0u}; }
+
+    for (int i0 = 0; i0 < nsteps; i0 += U) {
+        static_for<U>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J % DEPTH];
+                u32x4 v = s.v;
+                u32x2 ed = s.e;
+                if (s.cst) { v = (u32x4){p.cval2, p.cval2, p.cval2, p.cval2}; ed = (u32x2){p.cval2, p.cval2}; }
+                else ed = fix_edge16(ed, ekind, side, p.cval2);
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                const Row cur = unpack(v, ed);
+                const Row old = unpack(ring[J % WY].v, ring[J % WY].e);
+#pragma unroll
+                for (int k = 0; k < 12; k++) sum.v[k] += cur.v[k] - old.v[k];
+                ring[J % WY].v = v; ring[J % WY].e = ed;
+                if (i >= WY - 1) {
+                    int q[12];
+#pragma unroll
+                    for (int k = 0; k < 12; k++) q[k] = WY == 1 ? sum.v[k] : div_trunc(sum.v[k], p.ry);
+                    int o[8];
+                    if constexpr (WX == 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) o[k] = q[k];
+                    } else {
+                        // Q = [4 pixels left | own 8 | 4 pixels right] of the quotient row
+                        int Q[16];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            Q[k] = __builtin_amdgcn_update_dpp(q[8 + k], q[4 + k], 0x138, 0xf, 0xf, false);
+                            const int r = __builtin_amdgcn_update_dpp(q[8 + k], q[k], 0x130, 0xf, 0xf, false);
+                            Q[12 + k] = lane == last ? q[8 + k] : r;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; k++) Q[4 + k] = q[k];
+                        int acc = 0;
+#pragma unroll
+                        for (int t = -RX; t <= RX; t++) acc += Q[4 + t];
+                        o[0] = div_trunc(acc, p.rx);
+#pragma unroll
+                        for (int j = 1; j < 8; j++) {
+                            acc += Q[4 + j + RX] - Q[4 + j - 1 - RX];
+                            o[j] = div_trunc(acc, p.rx);
+                        }
+                    }
+                    u32x4 u;
+                    u.x = ((unsigned)o[0] & 0xFFFFu) | ((unsigned)o[1] << 16);
+                    u.y = ((unsigned)o[2] & 0xFFFFu) | ((unsigned)o[3] << 16);
+                    u.z = ((unsigned)o[4] & 0xFFFFu) | ((unsigned)o[5] << 16);
+                    u.w = ((unsigned)o[6] & 0xFFFFu) | ((unsigned)o[7] << 16);
+                    const unsigned so = (unsigned)(a0 + i - (WY - 1)) * (unsigned)nx * 2u;
+                    buffer_store_b128_soff(u, rout, voff, so);
+                }
+            }
+        });
+    }
+}
+
+template <int WX, int WY>
+static int launch_box16(const uint16_t *in, uint16_t *out, Box16Params &p, bool is_signed, hipStream_t s)
+{
+    plan_chunks16(p.nz * p.nxt, p.ny, WY - 1, &p.chunk, &p.nchunks);
+    const int waves = p.nz * p.nxt * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz * 2);
+    if (is_signed) hipLaunchKernelGGL((box2d_16_kernel<WX, WY, true>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    else hipLaunchKernelGGL((box2d_16_kernel<WX, WY, false>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+template <int WX>
+static int launch_box16_wy(int wy, const uint16_t *in, uint16_t *out, Box16Params &p, bool is_signed, hipStream_t s)
+{
+    switch (wy) {
+    case 1: return launch_box16<WX, 1>(in, out, p, is_signed, s);
+    case 3: return launch_box16<WX, 3>(in, out, p, is_signed, s);
+    case 5: return launch_box16<WX, 5>(in, out, p, is_signed, s);
+    case 7: return launch_box16<WX, 7>(in, out, p, is_signed, s);
+    default: return launch_box16<WX, 9>(in, out, p, is_signed, s);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // 3 x 3 median (method: median2d.hip), two pixels per dword
 // ---------------------------------------------------------------------------
 template <bool SIGNED>
@@ -633,6 +802,46 @@ extern "C" int mi_minmax_runs_16(const mi_array *in, const mi_array *out, int nr
     case 5: return launch_runs16<5>(ip, op, p, is_max != 0, is_signed, s);
     case 7: return launch_runs16<7>(ip, op, p, is_max != 0, is_signed, s);
     default: return launch_runs16<9>(ip, op, p, is_max != 0, is_signed, s);
+    }
+#undef UNSUP
+}
+
+/* uniform_filter on a uint16 / int16 image (volume: slice by slice), result in the same dtype (declared in
+ * include/mi355img.h). */
+extern "C" int mi_uniform2d_16(const mi_array *in, const mi_array *out, const int size[2], int origin_y, const int mode[2],
+                               int cval, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(size && mode, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    int64_t nz, ny, nx;
+    if ((rc = geometry16(in, out, "uniform2d_16", &nz, &ny, &nx))) return rc;
+#define UNSUP(msg) do { set_error("uniform2d_16: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    const int wy = size[0], wx = size[1];
+    if (wy < 1 || wy > 9 || !(wy & 1) || wx < 1 || wx > 9 || !(wx & 1)) UNSUP("sizes must be odd and <= 9");
+    if (wy == 1 && wx == 1) UNSUP("nothing to filter");
+    const int oy = wy / 2 + origin_y;
+    if (oy < 0 || oy >= wy) { set_error("invalid origin"); return MI_ERR_INVALID_ARG; }
+    const bool is_signed = in->dtype == MI_I16;
+    if (cval < (is_signed ? -32768 : 0) || cval > (is_signed ? 32767 : 65535)) UNSUP("cval outside the dtype");
+    Box16Params p;
+    memset(&p, 0, sizeof(p));
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.oy = oy;
+    p.my = filter_mode(mode[0]); p.mx = filter_mode(mode[1]);
+    p.cval2 = ((unsigned)cval & 0xFFFFu) * 0x10001u;
+    p.nxt = (int)((nx + 511) / 512);
+    p.ry = (float)(1.0 / wy); p.rx = (float)(1.0 / wx);
+    hipStream_t s = resolve_stream(stream);
+    const uint16_t *ip = (const uint16_t *)in->data;
+    uint16_t *op = (uint16_t *)out->data;
+    switch (wx) {
+    case 1: return launch_box16_wy<1>(wy, ip, op, p, is_signed, s);
+    case 3: return launch_box16_wy<3>(wy, ip, op, p, is_signed, s);
+    case 5: return launch_box16_wy<5>(wy, ip, op, p, is_signed, s);
+    case 7: return launch_box16_wy<7>(wy, ip, op, p, is_signed, s);
+    default: return launch_box16_wy<9>(wy, ip, op, p, is_signed, s);
     }
 #undef UNSUP
 }

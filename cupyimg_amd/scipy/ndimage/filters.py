@@ -301,8 +301,8 @@ def uniform_filter1d(input, size, axis=-1, output=None, mode="reflect", cval=0.0
 
 
 def _try_uniform2d_u8(input, output, sizes, origins, modes, cval):
-    """uint8 image (volume: slice by slice) -> uint8: both box passes in one integer-arithmetic launch
-    (mi_uniform2d_u8); None when the request is not covered."""
+    """uint8 / uint16 / int16 image (volume: slice by slice), same dtype out: both box passes in one integer-arithmetic
+    launch (mi_uniform2d_u8 / mi_uniform2d_16); None when the request is not covered."""
     if S.current_planes() is not None or input.size == 0:
         return None
     nd = input.ndim
@@ -315,17 +315,19 @@ def _try_uniform2d_u8(input, output, sizes, origins, modes, cval):
     if sz[-2] == 1 and og[-2] != 0:
         return None
     md = list(modes)[-2:]
+    info = np.iinfo(input.dtype)
     if any(m in ("constant", "grid-constant") for m in md):
-        if not (np.isfinite(cval) and 0 <= cval <= 255 and float(cval) == int(cval)):
+        if not (np.isfinite(cval) and info.min <= cval <= info.max and float(cval) == int(cval)):
             return None
+    entry = S.lib().mi_uniform2d_u8 if input.dtype == np.uint8 else S.lib().mi_uniform2d_16
     src = core.ascontiguousarray(input)
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     dst = output if direct else core.empty(output.shape, output.dtype)
     a, b = src._desc(), dst._desc()
     try:
-        cv = int(cval) if np.isfinite(cval) and 0 <= cval <= 255 else 0
-        S.check(S.lib().mi_uniform2d_u8(ctypes.byref(a), ctypes.byref(b), _cached_ints(tuple(sz[-2:])), og[-2],
-                                        _cached_ints(tuple(S.mode_code(m) for m in md)), cv, None))
+        cv = int(cval) if np.isfinite(cval) and info.min <= cval <= info.max else 0
+        S.check(entry(ctypes.byref(a), ctypes.byref(b), _cached_ints(tuple(sz[-2:])), og[-2],
+                      _cached_ints(tuple(S.mode_code(m) for m in md)), cv, None))
     except S.Unsupported:
         return None
     if not direct:
@@ -366,7 +368,8 @@ def uniform_filter(input, size=3, output=None, mode="reflect", cval=0.0, origin=
         if res is not None:
             return res
 
-    if dtype_mode != "float" and input.dtype == np.uint8 and output.dtype == np.uint8 and input.ndim in (2, 3):
+    if (dtype_mode != "float" and input.dtype in (np.uint8, np.uint16, np.int16) and output.dtype == input.dtype
+            and input.ndim in (2, 3)):
         res = _try_uniform2d_u8(input, output, sizes, origins, modes, cval)
         if res is not None:
             return res

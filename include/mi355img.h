@@ -263,6 +263,9 @@ int mi_minmax3d_16(const mi_array *in, const mi_array *out, const int size[3], c
  * only, mode[2] = y, x.  MI_ERR_UNSUPPORTED otherwise (-> mi_uniform_filter1d per axis). */
 int mi_uniform2d_u8(const mi_array *in, const mi_array *out, const int size[2], int origin_y,
                     const int mode[2], int cval, mi_stream stream);
+/* the same for uint16 / int16 images (32-bit sums) */
+int mi_uniform2d_16(const mi_array *in, const mi_array *out, const int size[2], int origin_y,
+                    const int mode[2], int cval, mi_stream stream);
 
 /* Flat footprint min / max on uint8 images (volumes: slice by slice) for footprints whose
  * rows are centred runs -- disk, diamond / cross, octagon, square, i.e. what skimage's

@@ -307,29 +307,31 @@ def test_volume_footprints_of_centred_runs(gpu, ndi, shape):
         assert np.array_equal(ndi.binary_closing(bd, structure=st, iterations=2).get(), sndi.binary_closing(b, structure=st, iterations=2))
 
 
+@pytest.mark.parametrize("dtype", ["uint8", "uint16", "int16"])
 @pytest.mark.parametrize("shape", [(50, 64), (33, 1040), (90, 2048 + 32), (5, 32), (6, 40, 96)])
-def test_uint8_uniform_filter_integer_kernel(gpu, ndi, shape):
-    """uniform_filter on uint8 images with a uint8 result: one integer-arithmetic launch, bit-exact (SciPy truncates to
-    uint8 after every axis)."""
+def test_uint8_uniform_filter_integer_kernel(gpu, ndi, shape, dtype):
+    """uniform_filter on uint8 / 16-bit images with a result of the same dtype: one integer-arithmetic launch, bit-exact
+    (SciPy truncates to the integer dtype after every axis)."""
     rng = np.random.default_rng(82)
-    x = rng.integers(0, 256, size=shape, dtype=np.uint8)
-    x[..., ::7, ::3] = 255
-    x[..., 1::5, 1::4] = 0
+    info = np.iinfo(dtype)
+    x = rng.integers(info.min, info.max + 1, size=shape, dtype=dtype)
+    x[..., ::7, ::3] = info.max
+    x[..., 1::5, 1::4] = info.min
     xd = gpu.asarray(x)
     lead = (1,) * (x.ndim - 2)
     for mode in MODES:
         for size in [(3, 3), (5, 5), (9, 9), (7, 3), (1, 5), (9, 1), (3, 7)]:
             ref = sndi.uniform_filter(x, lead + size, mode=mode, cval=7)
             got = ndi.uniform_filter(xd, lead + size, mode=mode, cval=7).get()
-            assert got.dtype == np.uint8
-            assert np.array_equal(got, ref), (shape, size, mode)
+            assert got.dtype == x.dtype
+            assert np.array_equal(got, ref), (dtype, shape, size, mode)
     org = (0,) * (x.ndim - 2) + (1, 0)
     ref = sndi.uniform_filter(x, lead + (5, 3), mode=["nearest", "mirror", "wrap"][-x.ndim:], origin=org)
     got = ndi.uniform_filter(xd, lead + (5, 3), mode=["nearest", "mirror", "wrap"][-x.ndim:], origin=org).get()
     assert np.array_equal(got, ref)
     # worst cases for the division: constant images at every level and sizes
-    for val in (0, 1, 254, 255):
-        c = np.full(shape, val, np.uint8)
+    for val in (info.min, info.min + 1, -1 if info.min < 0 else 1, info.max - 1, info.max):
+        c = np.full(shape, val, x.dtype)
         for size in (3, 5, 7, 9):
             assert np.array_equal(ndi.uniform_filter(gpu.asarray(c), lead + (size, size)).get(), sndi.uniform_filter(c, lead + (size, size)))
 
