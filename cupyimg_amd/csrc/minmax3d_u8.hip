@@ -413,16 +413,25 @@ runs_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                 split(r, w.e[5], w.o[5]);
                 w.e[6] = w.e[5]; w.o[6] = w.o[5];
                 if (i >= WA - 1) {
-                    // footprint row WA - 1 is the row just loaded, row k < WA - 1 sits in ring[(J + k) % RINGN]
+                    // footprint row WA - 1 is the row just loaded, row k < WA - 1 sits in ring[(J + k) % RINGN].
+                    // min / max commute: rows that share a half width are combined first (14 operations per row) and
+                    // ONE x window per distinct half width follows -- disk(3) needs three windows, not seven
                     Vec16 a;
                     bool have = false;
-                    static_for<WA>([&](auto KK) {
-                        constexpr int k = decltype(KK)::value;
-                        const int hw = p.hw[k];
-                        if (hw >= 0) {
-                            Vec16 t;
-                            if constexpr (k == WA - 1) t = xrun_u8<IS_MAX>(w, hw);
-                            else t = xrun_u8<IS_MAX>(ring[(J + k) % (RINGN > 0 ? RINGN : 1)], hw);
+                    static_for<5>([&](auto HH) {
+                        constexpr int h = decltype(HH)::value;
+                        Win g;
+                        bool any = false;
+                        static_for<WA>([&](auto KK) {
+                            constexpr int k = decltype(KK)::value;
+                            if (p.hw[k] == h) {
+                                if constexpr (k == WA - 1) g = any ? opw<IS_MAX>(g, w) : w;
+                                else g = any ? opw<IS_MAX>(g, ring[(J + k) % (RINGN > 0 ? RINGN : 1)]) : ring[(J + k) % (RINGN > 0 ? RINGN : 1)];
+                                any = true;
+                            }
+                        });
+                        if (any) {
+                            const Vec16 t = xpass_u8<2 * h + 1, IS_MAX>(g);
                             a = have ? op16<IS_MAX>(a, t) : t;
                             have = true;
                         }

@@ -287,15 +287,28 @@ runs_minmax16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out
                 if (lane == last) { r0 = ed.x; r1 = ed.y; }
                 w.d[2] = v.x; w.d[3] = v.y; w.d[4] = v.z; w.d[5] = v.w; w.d[6] = r0; w.d[7] = r1;
                 if (i >= WA - 1) {
+                    // rows that share a half width are combined first, then ONE x window per distinct half width
                     u32x4 a = (u32x4){0u, 0u, 0u, 0u};
                     bool have = false;
-                    static_for<WA>([&](auto KK) {
-                        constexpr int k = decltype(KK)::value;
-                        const int hw = p.hw[k];
-                        if (hw >= 0) {
-                            u32x4 t;
-                            if constexpr (k == WA - 1) t = xrun16<IS_MAX, SIGNED>(w, hw);
-                            else t = xrun16<IS_MAX, SIGNED>(ring[(J + k) % (RINGN > 0 ? RINGN : 1)], hw);
+                    static_for<5>([&](auto HH) {
+                        constexpr int h = decltype(HH)::value;
+                        Win16 g;
+                        bool any = false;
+                        static_for<WA>([&](auto KK) {
+                            constexpr int k = decltype(KK)::value;
+                            if (p.hw[k] == h) {
+                                const Win16 &r = k == WA - 1 ? w : ring[(J + k) % (RINGN > 0 ? RINGN : 1)];
+                                if (any) {
+#pragma unroll
+                                    for (int d = 0; d < 8; d++) g.d[d] = op16<IS_MAX, SIGNED>(g.d[d], r.d[d]);
+                                } else {
+                                    g = r;
+                                }
+                                any = true;
+                            }
+                        });
+                        if (any) {
+                            const u32x4 t = xwin16<2 * h + 1, IS_MAX, SIGNED>(g.d);
                             a = have ? op16v<IS_MAX, SIGNED>(a, t) : t;
                             have = true;
                         }
