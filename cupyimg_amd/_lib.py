@@ -111,6 +111,7 @@ SIGNATURES = {
     "mi_uniform2d_16": [_arr, _arr, _ip, _i, _ip, _i, _vp],
     "mi_minmax_runs_u8": [_arr, _arr, _i, _ip, _ip, _i, _i, _vp],
     "mi_minmax_runs_16": [_arr, _arr, _i, _ip, _ip, _i, _i, _vp],
+    "mi_minmax_runs_f32": [_arr, _arr, _i, _ip, _ip, _d, _i, _vp],
     "mi_minmax_runs3d_u8": [_arr, _arr, _ip, _ip, _i, _i, _vp],
     "mi_minmax3d_f64": [_arr, _arr, _ip, _ip, _ip, _d, _i, _vp],
     "mi_minmax_nd": [_arr, _arr, _u8p, _dp, _i64p, _ip, _i, _d, _i, _vp],

@@ -217,6 +217,148 @@ stream_pass_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Flat footprints whose rows are centred runs (disk, diamond, cross, square; see runs_minmax_u8_kernel in
+// minmax3d_u8.hip) on float32 images / slice-wise on volumes, one streaming launch: the previous WA - 1 raw rows (a
+// float4 and the edge block per lane) stay in registers; rows that share a half width are combined first (min / max
+// commute), then one x window per distinct half width (xpass_hops with compare-select).
+// ---------------------------------------------------------------------------
+struct RunsF32Params {
+    int nx, ny, nz;
+    int mx, my;
+    float cval;
+    int chunk, nchunks, nxt;
+    int swz;
+    int hw[9];           // half width of the run of footprint row r, -1 = empty row
+};
+
+template <int WA, int OP>
+__global__ void __launch_bounds__(256)
+runs_minmax_f32_kernel(const float *__restrict__ in, float *__restrict__ out, const RunsF32Params p)
+{
+    constexpr int DEPTH = 2;
+    constexpr int RINGN = WA - 1;
+    constexpr int U = RINGN > 0 ? lcm_(RINGN, DEPTH) : DEPTH;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int nlines = nz * p.nxt;
+    const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
+    if (wid >= nlines * p.nchunks) return;
+    const int c = wid / nlines;
+    const int line = wid - c * nlines;
+    const int z = line / p.nxt, xt = line - z * p.nxt;
+    const int x0 = xt * 256;
+    const int nlanes = min(64, (nx - x0) >> 2);
+    const int last = nlanes - 1;
+
+    const unsigned plane = (unsigned)ny * (unsigned)nx;
+    const unsigned rowbase = (unsigned)z * plane;
+    const unsigned total_bytes = plane * (unsigned)nz * 4u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned voff = lane < nlanes ? (rowbase + (unsigned)(x0 + 4 * lane)) * 4u : kOOB;
+    const int side = lane == 0 ? 0 : 1;
+    int est, ekind;
+    edge_block(side, 1, x0, x0 + 4 * nlanes, nx, p.mx, &est, &ekind);
+    const unsigned evoff = ((lane == 0 || lane == last) && ekind != EDGE_CONST) ? (rowbase + (unsigned)est) * 4u : kOOB;
+
+    const int a0 = c * p.chunk;
+    const int a1 = min(a0 + p.chunk, ny);
+    const int nsteps = a1 - a0 + WA - 1;
+    const int ai0 = a0 - WA / 2;
+
+    struct Slot { float4 v; float4 e; bool cst; };
+    Slot S[DEPTH];
+    auto issue = [&](int i, Slot &s) {
+        int ai = ai0 + i;
+        if ((unsigned)ai >= (unsigned)ny) ai = bmap<int>(ai, ny, p.my);
+        s.cst = ai < 0;
+        const unsigned soff = (unsigned)max(ai, 0) * (unsigned)nx * 4u;
+        s.v = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0));
+        s.e = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : evoff, soff, 0));
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < nsteps) issue(d, S[d]);
+
+    struct Row { float4 v, e; };
+    Row ring[RINGN > 0 ? RINGN : 1];
+    const float4 cv4 = make_float4(p.cval, p.cval, p.cval, p.cval);
+    auto mm4 = [](const float4 a, const float4 b) {
+        return make_float4(pick_mm<OP>(b.x, a.x), pick_mm<OP>(b.y, a.y), pick_mm<OP>(b.z, a.z), pick_mm<OP>(b.w, a.w));
+    };
+    for (int i0 = 0; i0 < nsteps; i0 += U) {
+        static_for<U>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                Slot &s = S[J % DEPTH];
+                Row cur;
+                cur.v = s.cst ? cv4 : s.v;
+                cur.e = s.cst ? cv4 : apply_kind(s.e, ekind, side, p.cval);
+                if (i + DEPTH < nsteps) issue(i + DEPTH, s);
+                if (i >= WA - 1) {
+                    float4 a = cv4;
+                    bool have = false;
+                    static_for<5>([&](auto HH) {
+                        constexpr int h = decltype(HH)::value;
+                        Row g;
+                        bool any = false;
+                        static_for<WA>([&](auto KK) {
+                            constexpr int k = decltype(KK)::value;
+                            if (p.hw[k] == h) {
+                                const Row &r = k == WA - 1 ? cur : ring[(J + k) % (RINGN > 0 ? RINGN : 1)];
+                                if (any) { g.v = mm4(g.v, r.v); g.e = mm4(g.e, r.e); }
+                                else g = r;
+                                any = true;
+                            }
+                        });
+                        if (any) {
+                            float4 eL[4] = {g.e, g.e, g.e, g.e}, eR[4] = {g.e, g.e, g.e, g.e};
+                            const F4 t = xpass_hops<2 * h + 1, OP>(g.v, eL, eR, lane, last, nullptr, nullptr);
+                            const float4 tf = f4_to_float4(t);
+                            a = have ? mm4(a, tf) : tf;
+                            have = true;
+                        }
+                    });
+                    const unsigned so = (unsigned)(a0 + i - (WA - 1)) * (unsigned)nx * 4u;
+                    u32x4 u;
+                    u.x = __float_as_uint(a.x); u.y = __float_as_uint(a.y); u.z = __float_as_uint(a.z); u.w = __float_as_uint(a.w);
+                    buffer_store_b128_soff(u, rout, voff, so);
+                }
+                if constexpr (RINGN > 0) ring[J % RINGN] = cur;
+            }
+        });
+    }
+}
+
+template <int WA>
+static int launch_runs_f32(const float *in, float *out, RunsF32Params &p, bool is_max, hipStream_t s)
+{
+    const int nlines = p.nz * p.nxt;
+    int nch = 1;
+    {
+        double best = 1e300;
+        for (int c = 1; c <= p.ny && c <= 1024; c++) {
+            const int chunk = (p.ny + c - 1) / c;
+            if (c > 1 && chunk < 16) break;
+            const int real = (p.ny + chunk - 1) / chunk;
+            const double rounds = std::max(1.0, (double)nlines * real / 4096.0);
+            const double cost = rounds * (chunk + (WA - 1) + 4.0);
+            if (cost < best * 0.999) { best = cost; nch = real; }
+        }
+    }
+    p.chunk = (p.ny + nch - 1) / nch;
+    p.nchunks = (p.ny + p.chunk - 1) / p.chunk;
+    const int waves = nlines * p.nchunks;
+    p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz * 4);
+    if (is_max) hipLaunchKernelGGL((runs_minmax_f32_kernel<WA, SP_MAX>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    else hipLaunchKernelGGL((runs_minmax_f32_kernel<WA, SP_MIN>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
 // Round 1 issued a pass in launches of at most 1000 waves because larger launches produced wrong samples; the
 // cause was the store-data hazard described at buffer_store_b128_soff() (sep_common.hpp), not the launch size.
 // The slice hook stays for tests (0 = one launch, the default).
@@ -437,5 +579,51 @@ extern "C" int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const in
     }
     for (int t = 0; t < 2; t++) if (tmp[t]) pool_free(tmp[t]);   // reuse is stream ordered
     return rc;
+#undef UNSUP
+}
+
+/* Flat footprint given as centred runs per row, float32 images (declared in include/mi355img.h). */
+extern "C" int mi_minmax_runs_f32(const mi_array *in, const mi_array *out, int nrows, const int *half_width, const int mode[2],
+                                  double cval, int is_max, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(half_width && mode, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+#define UNSUP(msg) do { set_error("minmax_runs_f32: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if ((in->ndim != 2 && in->ndim != 3) || in->dtype != MI_F32 || out->dtype != MI_F32) UNSUP("needs 2-D / 3-D float32 in/out");
+    if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
+    if (in->data == out->data) UNSUP("in-place");
+    const int nd = in->ndim;
+    const int64_t nz = nd == 3 ? in->shape[0] : 1, ny = in->shape[nd - 2], nx = in->shape[nd - 1];
+    if (nz < 1 || ny < 1 || nx < 8 || (nx & 3)) UNSUP("x extent must be a multiple of 4, >= 8");
+    { const int64_t tail = nx & 255; if (tail != 0 && tail < 8) UNSUP("x extent unsuitable for the streaming x window"); }
+    if (nz * ny * nx * 4 >= ((int64_t)1 << 31)) UNSUP("needs an array < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+    if (nrows < 1 || nrows > 9 || !(nrows & 1)) UNSUP("1, 3, 5, 7 or 9 footprint rows");
+    RunsF32Params p;
+    memset(&p, 0, sizeof(p));
+    bool any = false;
+    for (int r = 0; r < 9; r++) p.hw[r] = -1;
+    for (int r = 0; r < nrows; r++) {
+        if (half_width[r] < -1 || half_width[r] > 4) UNSUP("runs of at most 9 pixels");
+        p.hw[r] = half_width[r];
+        any = any || half_width[r] >= 0;
+    }
+    if (!any) UNSUP("empty footprint");
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.my = filter_mode(mode[0]); p.mx = filter_mode(mode[1]);
+    p.cval = (float)cval;
+    p.nxt = (int)((nx + 255) / 256);
+    hipStream_t s = resolve_stream(stream);
+    const float *ip = (const float *)in->data;
+    float *op = (float *)out->data;
+    switch (nrows) {
+    case 1: return launch_runs_f32<1>(ip, op, p, is_max != 0, s);
+    case 3: return launch_runs_f32<3>(ip, op, p, is_max != 0, s);
+    case 5: return launch_runs_f32<5>(ip, op, p, is_max != 0, s);
+    case 7: return launch_runs_f32<7>(ip, op, p, is_max != 0, s);
+    default: return launch_runs_f32<9>(ip, op, p, is_max != 0, s);
+    }
 #undef UNSUP
 }

@@ -635,16 +635,25 @@ def _try_runs_minmax_u8(input, output, fp, mode, cval, is_max):
     runs = _footprint_runs(fp)
     if runs is None:
         return None
-    info = np.iinfo(input.dtype)
-    if mode in ("constant", "grid-constant") and not (np.isfinite(cval) and info.min <= cval <= info.max and float(cval) == int(cval)):
-        return None
-    entry = S.lib().mi_minmax_runs_u8 if input.dtype == np.uint8 else S.lib().mi_minmax_runs_16
+    is_float = input.dtype == np.float32
+    if not is_float:
+        info = np.iinfo(input.dtype)
+        if mode in ("constant", "grid-constant") and not (np.isfinite(cval) and info.min <= cval <= info.max
+                                                          and float(cval) == int(cval)):
+            return None
+    if is_float:
+        entry = S.lib().mi_minmax_runs_f32
+    else:
+        entry = S.lib().mi_minmax_runs_u8 if input.dtype == np.uint8 else S.lib().mi_minmax_runs_16
     src = core.ascontiguousarray(input)
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     dst = output if direct else core.empty(output.shape, output.dtype)
     a, b = src._desc(), dst._desc()
     try:
-        cv = int(cval) if np.isfinite(cval) and info.min <= cval <= info.max else 0
+        if is_float:
+            cv = float(cval)
+        else:
+            cv = int(cval) if np.isfinite(cval) and info.min <= cval <= info.max else 0
         S.check(entry(ctypes.byref(a), ctypes.byref(b), len(runs), _cached_ints(tuple(runs)),
                       _cached_ints((S.mode_code(mode),) * 2), cv, int(is_max), None))
     except S.Unsupported:
@@ -702,7 +711,8 @@ def _min_or_max_filter(input, size, ftprnt, structure, output, mode, cval, origi
     if input.size == 0:
         return output
     fp = np.ascontiguousarray(ftprnt, dtype=np.uint8)
-    if structure is None and input.dtype in (np.uint8, np.uint16, np.int16) and output.dtype == input.dtype and not any(origins):
+    if (structure is None and input.dtype in (np.uint8, np.uint16, np.int16, np.float32) and output.dtype == input.dtype
+            and not any(origins)):
         res = _try_runs_minmax_u8(input, output, fp, mode, cval, is_max)
         if res is not None:
             return res

@@ -282,6 +282,10 @@ int mi_minmax_runs_u8(const mi_array *in, const mi_array *out, int nrows, const 
  * (morphology.py:769-884 -> filters.py:1398-1419).  MI_ERR_UNSUPPORTED otherwise. */
 int mi_minmax_runs3d_u8(const mi_array *in, const mi_array *out, const int half_width[9],
                         const int mode[3], int cval, int is_max, mi_stream stream);
+/* the same for float32 images (compare-select like the generic kernel; cval converted to
+ * float32 first) */
+int mi_minmax_runs_f32(const mi_array *in, const mi_array *out, int nrows, const int *half_width,
+                       const int mode[2], double cval, int is_max, mi_stream stream);
 /* the same for uint16 / int16 images */
 int mi_minmax_runs_16(const mi_array *in, const mi_array *out, int nrows, const int *half_width,
                       const int mode[2], int cval, int is_max, mi_stream stream);

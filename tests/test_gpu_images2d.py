@@ -229,13 +229,18 @@ def _disk(r):
     return (x * x + y * y) <= r * r
 
 
-@pytest.mark.parametrize("dtype", ["uint8", "uint16", "int16"])
+@pytest.mark.parametrize("dtype", ["uint8", "uint16", "int16", "float32"])
 @pytest.mark.parametrize("shape", [(50, 64), (33, 1040), (90, 2048 + 32), (5, 32), (6, 40, 96)])
 def test_uint8_footprints_of_centred_runs(gpu, ndi, shape, dtype):
     """skimage-style footprints (disk, diamond, square, ...) on uint8 / 16-bit images: one streaming launch, bit-exact."""
     rng = np.random.default_rng(79)
-    info = np.iinfo(dtype)
-    x = rng.integers(info.min, info.max + 1, size=shape, dtype=dtype)
+    if dtype == "float32":
+        x = rng.standard_normal(shape).astype(np.float32)
+        x[..., ::5, ::7] = np.inf
+        x[..., 2::6, 1::5] = -np.inf
+    else:
+        info = np.iinfo(dtype)
+        x = rng.integers(info.min, info.max + 1, size=shape, dtype=dtype)
     xd = gpu.asarray(x)
     diamond2 = np.abs(np.mgrid[-2:3, -2:3]).sum(0) <= 2
     fps = [_disk(1), _disk(2), _disk(3), _disk(4), diamond2, np.ones((3, 5), bool), np.ones((7, 1), bool),
