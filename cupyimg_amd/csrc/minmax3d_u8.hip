@@ -339,9 +339,9 @@ template <int WA, bool IS_MAX>
 __global__ void __launch_bounds__(256)
 runs_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const U8RunParams p)
 {
-    constexpr int DEPTH = 2;
+    constexpr int DEPTH = 2;             // 4 loads in flight measured slower here (longer unrolled ring, more registers)
     constexpr int RINGN = WA - 1;
-    constexpr int U = RINGN > 0 ? (RINGN % DEPTH == 0 ? RINGN : DEPTH * RINGN) : DEPTH;
+    constexpr int U = RINGN > 0 ? lcm_(RINGN, DEPTH) : DEPTH;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nx = p.nx, ny = p.ny, nz = p.nz;
