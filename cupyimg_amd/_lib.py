@@ -109,6 +109,8 @@ SIGNATURES = {
     "mi_minmax3d_16": [_arr, _arr, _ip, _ip, _ip, _i, _i, _vp],
     "mi_uniform2d_u8": [_arr, _arr, _ip, _i, _ip, _i, _vp],
     "mi_uniform2d_16": [_arr, _arr, _ip, _i, _ip, _i, _vp],
+    "mi_uniform_z_u8": [_arr, _arr, _i, _i, _i, _i, _vp],
+    "mi_uniform_z_16": [_arr, _arr, _i, _i, _i, _i, _vp],
     "mi_minmax_runs_u8": [_arr, _arr, _i, _ip, _ip, _i, _i, _vp],
     "mi_minmax_runs_16": [_arr, _arr, _i, _ip, _ip, _i, _i, _vp],
     "mi_minmax_runs_f32": [_arr, _arr, _i, _ip, _ip, _d, _i, _vp],

@@ -627,7 +627,8 @@ runs3d_minmax_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 // ---------------------------------------------------------------------------
 struct U8BoxParams {
     int nx, ny, nz;
-    int oy;              // wy / 2 + origin along y
+    int axis;            // streamed axis: 1 = y (x window fused), 0 = z (WX == 1: the z pass of a volume)
+    int oy;              // w / 2 + origin along the streamed axis
     int mx, my;
     unsigned cval4;
     int chunk, nchunks, nxt;
@@ -694,18 +695,21 @@ box2d_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nx = p.nx, ny = p.ny, nz = p.nz;
-    const int nlines = nz * p.nxt;
+    const int nother = p.axis == 0 ? ny : nz;             // lines: (other axis, x segment)
+    const int nA = p.axis == 0 ? nz : ny;                 // extent of the streamed axis
+    const int nlines = nother * p.nxt;
     const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
     if (wid >= nlines * p.nchunks) return;
     const int c = wid / nlines;
     const int line = wid - c * nlines;
-    const int z = line / p.nxt, xt = line - z * p.nxt;
+    const int z = line / p.nxt, xt = line - z * p.nxt;    // z: index along the other axis
     const int x0 = xt * 1024;
     const int nlanes = min(64, (nx - x0) >> 4);
     const int last = nlanes - 1;
 
     const unsigned plane = (unsigned)ny * (unsigned)nx;
-    const unsigned rowbase = (unsigned)z * plane;
+    const unsigned strideA = p.axis == 0 ? plane : (unsigned)nx;
+    const unsigned rowbase = p.axis == 0 ? (unsigned)z * (unsigned)nx : (unsigned)z * plane;
     const unsigned total_bytes = plane * (unsigned)nz;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
@@ -716,7 +720,7 @@ box2d_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const
     const unsigned evoff = ((lane == 0 || lane == last) && ekind != EDGE_CONST) ? rowbase + (unsigned)est : kOOB;
 
     const int a0 = c * p.chunk;
-    const int a1 = min(a0 + p.chunk, ny);
+    const int a1 = min(a0 + p.chunk, nA);
     const int nsteps = a1 - a0 + WY - 1;
     const int ai0 = a0 - p.oy;
 
@@ -724,9 +728,9 @@ box2d_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const
     Slot S[DEPTH];
     auto issue = [&](int i, Slot &s) {
         int ai = ai0 + i;
-        if ((unsigned)ai >= (unsigned)ny) ai = bmap<int>(ai, ny, p.my);
+        if ((unsigned)ai >= (unsigned)nA) ai = bmap<int>(ai, nA, p.my);
         s.cst = ai < 0;
-        const unsigned soff = (unsigned)max(ai, 0) * (unsigned)nx;
+        const unsigned soff = (unsigned)max(ai, 0) * strideA;
         s.v = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0);
         s.e = __builtin_amdgcn_raw_buffer_load_b32(rin, s.cst ? kOOB : evoff, soff, 0);
     };
@@ -802,7 +806,7 @@ box2d_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const
                     u32x4 u;
                     u.x = join(a.e[0], a.o[0]); u.y = join(a.e[1], a.o[1]);
                     u.z = join(a.e[2], a.o[2]); u.w = join(a.e[3], a.o[3]);
-                    const unsigned so = (unsigned)(a0 + i - (WY - 1)) * (unsigned)nx;
+                    const unsigned so = (unsigned)(a0 + i - (WY - 1)) * strideA;
                     buffer_store_b128_soff(u, rout, voff, so);
                 }
             }
@@ -813,21 +817,22 @@ box2d_u8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const
 template <int WX, int WY>
 static int launch_box2d_u8(const uint8_t *in, uint8_t *out, U8BoxParams &p, hipStream_t s)
 {
-    const int nlines = p.nz * p.nxt;
+    const int nlines = (p.axis == 0 ? p.ny : p.nz) * p.nxt;
+    const int nA = p.axis == 0 ? p.nz : p.ny;
     int nch = 1;
     {
         double best = 1e300;
-        for (int c = 1; c <= p.ny && c <= 2048; c++) {
-            const int chunk = (p.ny + c - 1) / c;
+        for (int c = 1; c <= nA && c <= 2048; c++) {
+            const int chunk = (nA + c - 1) / c;
             if (c > 1 && chunk < 8) break;
-            const int real = (p.ny + chunk - 1) / chunk;
+            const int real = (nA + chunk - 1) / chunk;
             const double rounds = std::max(1.0, (double)nlines * real / 4096.0);
             const double cost = rounds * (chunk + (WY - 1) + 4.0);
             if (cost < best * 0.999) { best = cost; nch = real; }
         }
     }
-    p.chunk = (p.ny + nch - 1) / nch;
-    p.nchunks = (p.ny + p.chunk - 1) / p.chunk;
+    p.chunk = (nA + nch - 1) / nch;
+    p.nchunks = (nA + p.chunk - 1) / p.chunk;
     const int waves = nlines * p.nchunks;
     p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz);
     hipLaunchKernelGGL((box2d_u8_kernel<WX, WY>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
@@ -1596,6 +1601,7 @@ extern "C" int mi_uniform2d_u8(const mi_array *in, const mi_array *out, const in
     U8BoxParams p;
     memset(&p, 0, sizeof(p));
     p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.axis = 1;
     p.oy = oy;
     p.my = filter_mode(mode[0]); p.mx = filter_mode(mode[1]);
     p.cval4 = (unsigned)cval * 0x01010101u;
@@ -1611,5 +1617,38 @@ extern "C" int mi_uniform2d_u8(const mi_array *in, const mi_array *out, const in
     case 7: return launch_box2d_u8_wy<7>(wy, ip, op, p, s);
     default: return launch_box2d_u8_wy<9>(wy, ip, op, p, s);
     }
+#undef UNSUP
+}
+
+/* The z pass of uniform_filter on a uint8 volume (uint8 intermediate, as SciPy stores it): trunc(sum of size_z planes /
+ * size_z); mi_uniform2d_u8 on the result completes the filter (declared in include/mi355img.h). */
+extern "C" int mi_uniform_z_u8(const mi_array *in, const mi_array *out, int size_z, int origin_z, int mode_z, int cval,
+                               mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+#define UNSUP(msg) do { set_error("uniform_z_u8: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if (in->ndim != 3 || in->dtype != MI_U8 || out->dtype != MI_U8) UNSUP("needs 3-D uint8 in/out");
+    if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
+    if (in->data == out->data) UNSUP("in-place");
+    const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
+    if (nz < 1 || ny < 1 || nx < 32 || (nx & 15)) UNSUP("x extent must be a multiple of 16, >= 32");
+    if (nz * ny * nx >= ((int64_t)1 << 31)) UNSUP("needs an array < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+    if (size_z < 3 || size_z > 9 || !(size_z & 1)) UNSUP("odd size 3 .. 9");
+    const int oz = size_z / 2 + origin_z;
+    if (oz < 0 || oz >= size_z) { set_error("invalid origin"); return MI_ERR_INVALID_ARG; }
+    if (cval < 0 || cval > 255) UNSUP("cval outside uint8");
+    U8BoxParams p;
+    memset(&p, 0, sizeof(p));
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.axis = 0;
+    p.oy = oz;
+    p.my = filter_mode(mode_z); p.mx = MI_MODE_REFLECT;
+    p.cval4 = (unsigned)cval * 0x01010101u;
+    p.nxt = (int)((nx + 1023) / 1024);
+    p.ry = (float)(1.0 / size_z); p.rx = 1.0f;
+    return launch_box2d_u8_wy<1>(size_z, (const uint8_t *)in->data, (uint8_t *)out->data, p, resolve_stream(stream));
 #undef UNSUP
 }

@@ -348,6 +348,7 @@ static int launch_runs16(const uint16_t *in, uint16_t *out, P16RunParams &p, boo
 // ---------------------------------------------------------------------------
 struct Box16Params {
     int nx, ny, nz;
+    int axis;            // streamed axis: 1 = y (x window fused), 0 = z (WX == 1)
     int oy;
     int mx, my;
     unsigned cval2;
@@ -370,18 +371,21 @@ box2d_16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, con
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nx = p.nx, ny = p.ny, nz = p.nz;
-    const int nlines = nz * p.nxt;
+    const int nother = p.axis == 0 ? ny : nz;
+    const int nA = p.axis == 0 ? nz : ny;
+    const int nlines = nother * p.nxt;
     const int wid = xcd_block((int)blockIdx.x, (int)gridDim.x, p.swz) * 4 + wave;
     if (wid >= nlines * p.nchunks) return;
     const int c = wid / nlines;
     const int line = wid - c * nlines;
-    const int z = line / p.nxt, xt = line - z * p.nxt;
+    const int z = line / p.nxt, xt = line - z * p.nxt;    // z: index along the other axis
     const int x0 = xt * 512;
     const int nlanes = min(64, (nx - x0) >> 3);
     const int last = nlanes - 1;
 
     const unsigned plane = (unsigned)ny * (unsigned)nx;
-    const unsigned rowbase = (unsigned)z * plane;
+    const unsigned strideA = p.axis == 0 ? plane : (unsigned)nx;
+    const unsigned rowbase = p.axis == 0 ? (unsigned)z * (unsigned)nx : (unsigned)z * plane;
     const unsigned total_bytes = plane * (unsigned)nz * 2u;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)total_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)total_bytes, 0x00020000);
@@ -392,7 +396,7 @@ box2d_16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, con
     const unsigned evoff = ((lane == 0 || lane == last) && ekind != EDGE_CONST) ? (rowbase + (unsigned)est) * 2u : kOOB;
 
     const int a0 = c * p.chunk;
-    const int a1 = min(a0 + p.chunk, ny);
+    const int a1 = min(a0 + p.chunk, nA);
     const int nsteps = a1 - a0 + WY - 1;
     const int ai0 = a0 - p.oy;
 
@@ -400,9 +404,9 @@ box2d_16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, con
     Slot S[DEPTH];
     auto issue = [&](int i, Slot &s) {
         int ai = ai0 + i;
-        if ((unsigned)ai >= (unsigned)ny) ai = bmap<int>(ai, ny, p.my);
+        if ((unsigned)ai >= (unsigned)nA) ai = bmap<int>(ai, nA, p.my);
         s.cst = ai < 0;
-        const unsigned soff = (unsigned)max(ai, 0) * (unsigned)nx * 2u;
+        const unsigned soff = (unsigned)max(ai, 0) * strideA * 2u;
         s.v = __builtin_amdgcn_raw_buffer_load_b128(rin, s.cst ? kOOB : voff, soff, 0);
         s.e = __builtin_amdgcn_raw_buffer_load_b64(rin, s.cst ? kOOB : evoff, soff, 0);
     };
@@ -477,7 +481,7 @@ box2d_16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, con
                     u.y = ((unsigned)o[2] & 0xFFFFu) | ((unsigned)o[3] << 16);
                     u.z = ((unsigned)o[4] & 0xFFFFu) | ((unsigned)o[5] << 16);
                     u.w = ((unsigned)o[6] & 0xFFFFu) | ((unsigned)o[7] << 16);
-                    const unsigned so = (unsigned)(a0 + i - (WY - 1)) * (unsigned)nx * 2u;
+                    const unsigned so = (unsigned)(a0 + i - (WY - 1)) * strideA * 2u;
                     buffer_store_b128_soff(u, rout, voff, so);
                 }
             }
@@ -488,8 +492,9 @@ box2d_16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, con
 template <int WX, int WY>
 static int launch_box16(const uint16_t *in, uint16_t *out, Box16Params &p, bool is_signed, hipStream_t s)
 {
-    plan_chunks16(p.nz * p.nxt, p.ny, WY - 1, &p.chunk, &p.nchunks);
-    const int waves = p.nz * p.nxt * p.nchunks;
+    const int nlines = (p.axis == 0 ? p.ny : p.nz) * p.nxt;
+    plan_chunks16(nlines, p.axis == 0 ? p.nz : p.ny, WY - 1, &p.chunk, &p.nchunks);
+    const int waves = nlines * p.nchunks;
     p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz * 2);
     if (is_signed) hipLaunchKernelGGL((box2d_16_kernel<WX, WY, true>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
     else hipLaunchKernelGGL((box2d_16_kernel<WX, WY, false>), dim3((waves + 3) / 4), dim3(256), 0, s, in, out, p);
@@ -841,6 +846,7 @@ extern "C" int mi_uniform2d_16(const mi_array *in, const mi_array *out, const in
     Box16Params p;
     memset(&p, 0, sizeof(p));
     p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.axis = 1;
     p.oy = oy;
     p.my = filter_mode(mode[0]); p.mx = filter_mode(mode[1]);
     p.cval2 = ((unsigned)cval & 0xFFFFu) * 0x10001u;
@@ -856,5 +862,34 @@ extern "C" int mi_uniform2d_16(const mi_array *in, const mi_array *out, const in
     case 7: return launch_box16_wy<7>(wy, ip, op, p, is_signed, s);
     default: return launch_box16_wy<9>(wy, ip, op, p, is_signed, s);
     }
+#undef UNSUP
+}
+
+/* The z pass of uniform_filter on a uint16 / int16 volume (declared in include/mi355img.h). */
+extern "C" int mi_uniform_z_16(const mi_array *in, const mi_array *out, int size_z, int origin_z, int mode_z, int cval,
+                               mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    int64_t nz, ny, nx;
+    if ((rc = geometry16(in, out, "uniform_z_16", &nz, &ny, &nx))) return rc;
+#define UNSUP(msg) do { set_error("uniform_z_16: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if (in->ndim != 3) UNSUP("needs a volume");
+    if (size_z < 3 || size_z > 9 || !(size_z & 1)) UNSUP("odd size 3 .. 9");
+    const int oz = size_z / 2 + origin_z;
+    if (oz < 0 || oz >= size_z) { set_error("invalid origin"); return MI_ERR_INVALID_ARG; }
+    const bool is_signed = in->dtype == MI_I16;
+    if (cval < (is_signed ? -32768 : 0) || cval > (is_signed ? 32767 : 65535)) UNSUP("cval outside the dtype");
+    Box16Params p;
+    memset(&p, 0, sizeof(p));
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.axis = 0;
+    p.oy = oz;
+    p.my = filter_mode(mode_z); p.mx = MI_MODE_REFLECT;
+    p.cval2 = ((unsigned)cval & 0xFFFFu) * 0x10001u;
+    p.nxt = (int)((nx + 511) / 512);
+    p.ry = (float)(1.0 / size_z); p.rx = 1.0f;
+    return launch_box16_wy<1>(size_z, (const uint16_t *)in->data, (uint16_t *)out->data, p, is_signed, resolve_stream(stream));
 #undef UNSUP
 }

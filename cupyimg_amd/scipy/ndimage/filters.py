@@ -301,33 +301,42 @@ def uniform_filter1d(input, size, axis=-1, output=None, mode="reflect", cval=0.0
 
 
 def _try_uniform2d_u8(input, output, sizes, origins, modes, cval):
-    """uint8 / uint16 / int16 image (volume: slice by slice), same dtype out: both box passes in one integer-arithmetic
-    launch (mi_uniform2d_u8 / mi_uniform2d_16); None when the request is not covered."""
+    """uint8 / uint16 / int16 image or volume, same dtype out: the box passes in integer arithmetic -- y and x in one
+    launch (mi_uniform2d_*), a z window of a volume as one more launch before it (mi_uniform_z_*; SciPy filters axis 0
+    first and keeps the intermediate in the integer dtype).  None when the request is not covered."""
     if S.current_planes() is not None or input.size == 0:
         return None
     nd = input.ndim
     sz = [int(v) for v in sizes]
     og = [int(v) for v in origins]
-    if nd == 3 and (sz[0] != 1):
+    md_all = list(modes)
+    if any(v < 1 or v > 9 or v % 2 == 0 for v in sz) or og[-1] != 0 or all(v == 1 for v in sz):
         return None
-    if any(v < 1 or v > 9 or v % 2 == 0 for v in sz[-2:]) or og[-1] != 0 or (sz[-2] == 1 and sz[-1] == 1):
+    if any(s_ == 1 and o_ != 0 for s_, o_ in zip(sz, og)):
         return None
-    if sz[-2] == 1 and og[-2] != 0:
-        return None
-    md = list(modes)[-2:]
+    md = md_all[-2:]
     info = np.iinfo(input.dtype)
-    if any(m in ("constant", "grid-constant") for m in md):
+    if any(m in ("constant", "grid-constant") for m in md_all):
         if not (np.isfinite(cval) and info.min <= cval <= info.max and float(cval) == int(cval)):
             return None
-    entry = S.lib().mi_uniform2d_u8 if input.dtype == np.uint8 else S.lib().mi_uniform2d_16
+    cv = int(cval) if np.isfinite(cval) and info.min <= cval <= info.max else 0
+    is8 = input.dtype == np.uint8
+    lib = S.lib()
     src = core.ascontiguousarray(input)
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     dst = output if direct else core.empty(output.shape, output.dtype)
-    a, b = src._desc(), dst._desc()
+    plane_pass = not (sz[-2] == 1 and sz[-1] == 1)
     try:
-        cv = int(cval) if np.isfinite(cval) and info.min <= cval <= info.max else 0
-        S.check(entry(ctypes.byref(a), ctypes.byref(b), _cached_ints(tuple(sz[-2:])), og[-2],
-                      _cached_ints(tuple(S.mode_code(m) for m in md)), cv, None))
+        if nd == 3 and sz[0] > 1:
+            mid = core.empty(src.shape, src.dtype) if plane_pass else dst
+            a, b = src._desc(), mid._desc()
+            S.check((lib.mi_uniform_z_u8 if is8 else lib.mi_uniform_z_16)(ctypes.byref(a), ctypes.byref(b), sz[0], og[0],
+                                                                          S.mode_code(md_all[0]), cv, None))
+            src = mid
+        if plane_pass:
+            a, b = src._desc(), dst._desc()
+            S.check((lib.mi_uniform2d_u8 if is8 else lib.mi_uniform2d_16)(ctypes.byref(a), ctypes.byref(b), _cached_ints(tuple(sz[-2:])),
+                                                                          og[-2], _cached_ints(tuple(S.mode_code(m) for m in md)), cv, None))
     except S.Unsupported:
         return None
     if not direct:

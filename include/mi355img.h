@@ -266,6 +266,13 @@ int mi_uniform2d_u8(const mi_array *in, const mi_array *out, const int size[2], 
 /* the same for uint16 / int16 images (32-bit sums) */
 int mi_uniform2d_16(const mi_array *in, const mi_array *out, const int size[2], int origin_y,
                     const int mode[2], int cval, mi_stream stream);
+/* The z pass of uniform_filter on a uint8 / 16-bit VOLUME, intermediate in the same dtype
+ * (SciPy filters axis 0 first): trunc(sum of size_z planes / size_z), odd size 3 .. 9;
+ * mi_uniform2d_* on the result completes the filter. */
+int mi_uniform_z_u8(const mi_array *in, const mi_array *out, int size_z, int origin_z, int mode_z,
+                    int cval, mi_stream stream);
+int mi_uniform_z_16(const mi_array *in, const mi_array *out, int size_z, int origin_z, int mode_z,
+                    int cval, mi_stream stream);
 
 /* Flat footprint min / max on uint8 images (volumes: slice by slice) for footprints whose
  * rows are centred runs -- disk, diamond / cross, octagon, square, i.e. what skimage's

@@ -360,3 +360,22 @@ def test_medians_of_25_and_27_samples(gpu, ndi, dtype):
     # the same window with another rank keeps the run-time network
     assert np.array_equal(ndi.rank_filter(gpu.asarray(img), 7, size=5).get(), sndi.rank_filter(img, 7, size=5))
     assert np.array_equal(ndi.percentile_filter(gpu.asarray(vol), 50, size=3).get(), sndi.percentile_filter(vol, 50, size=3))
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "uint16", "int16"])
+def test_integer_uniform_filter_on_volumes(gpu, ndi, dtype):
+    """uniform_filter on integer volumes: z pass + fused y/x pass in integer arithmetic, bit-exact."""
+    rng = np.random.default_rng(84)
+    info = np.iinfo(dtype)
+    for shape in [(20, 30, 64), (9, 17, 1040), (5, 6, 32)]:
+        x = rng.integers(info.min, info.max + 1, size=shape, dtype=dtype)
+        x[::3, ::4, ::5] = info.max
+        x[1::3, 1::4, 2::5] = info.min
+        xd = gpu.asarray(x)
+        for mode in MODES:
+            for size in [3, 5, (3, 5, 7), (9, 1, 1), (5, 1, 3), (3, 3, 1), (7, 9, 5)]:
+                ref = sndi.uniform_filter(x, size, mode=mode, cval=5)
+                got = ndi.uniform_filter(xd, size, mode=mode, cval=5).get()
+                assert got.dtype == x.dtype and np.array_equal(got, ref), (dtype, shape, size, mode)
+        ref = sndi.uniform_filter(x, (3, 5, 3), mode=["wrap", "nearest", "mirror"], origin=(1, -1, 0))
+        assert np.array_equal(ndi.uniform_filter(xd, (3, 5, 3), mode=["wrap", "nearest", "mirror"], origin=(1, -1, 0)).get(), ref)
