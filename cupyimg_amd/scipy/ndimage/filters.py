@@ -300,7 +300,7 @@ def uniform_filter1d(input, size, axis=-1, output=None, mode="reflect", cval=0.0
                         lambda s, d: _launch_uniform1d(s, d, axis, size, origin, mode, cval))
 
 
-def _try_uniform2d_u8(input, output, sizes, origins, modes, cval):
+def _try_uniform_integer(input, output, sizes, origins, modes, cval):
     """uint8 / uint16 / int16 image or volume, same dtype out: the box passes in integer arithmetic -- y and x in one
     launch (mi_uniform2d_*), a z window of a volume as one more launch before it (mi_uniform_z_*; SciPy filters axis 0
     first and keeps the intermediate in the integer dtype).  None when the request is not covered."""
@@ -379,7 +379,7 @@ def uniform_filter(input, size=3, output=None, mode="reflect", cval=0.0, origin=
 
     if (dtype_mode != "float" and input.dtype in (np.uint8, np.uint16, np.int16) and output.dtype == input.dtype
             and input.ndim in (2, 3)):
-        res = _try_uniform2d_u8(input, output, sizes, origins, modes, cval)
+        res = _try_uniform_integer(input, output, sizes, origins, modes, cval)
         if res is not None:
             return res
 
