@@ -579,9 +579,21 @@ def _try_stream_minmax_f32(input, output, sizes, origins, modes, cval, is_max):
     return output
 
 
+_RUNS_CACHE = {}
+
+
 def _footprint_runs(fp):
     """Half widths of the rows of a 2-D footprint whose rows are centred runs (disk, diamond, cross, square, octagon),
-    or None: row r covers columns -hw[r] .. +hw[r] about the centre column, -1 = empty row."""
+    or None: row r covers columns -hw[r] .. +hw[r] about the centre column, -1 = empty row.  Memoised on the mask."""
+    key = (fp.shape, fp.tobytes())
+    if key not in _RUNS_CACHE:
+        if len(_RUNS_CACHE) > 256:
+            _RUNS_CACHE.clear()
+        _RUNS_CACHE[key] = _footprint_runs_uncached(fp)
+    return _RUNS_CACHE[key]
+
+
+def _footprint_runs_uncached(fp):
     h, w = fp.shape
     if h % 2 == 0 or w % 2 == 0 or h > 9 or w > 9:
         return None
