@@ -848,7 +848,7 @@ struct CoefLine {
 template <typename CF>
 __global__ void __launch_bounds__(64)
 spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_t n, int64_t inner, int64_t nlines, int order,
-                       int smode)
+                       int smode, int gain_first)
 {
     const int64_t line = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (line >= nlines || n <= 1) return;
@@ -872,7 +872,14 @@ spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_
         const bool last_pole = k == np - 1;
         int64_t H = (int64_t)ceil(-46.0517 / log(fabs(z)));        // |z|^H < 1e-20
         // ---- causal initialisation
-        const CoefLine<CF> rd = k == 0 ? first : c;
+        // gain_first: the samples are scaled by the pole gain as they are read (SciPy scales the line before it filters;
+        // the roundings then agree with SciPy's, which matters where an integer output sits on a tie)
+        struct ScaledLine {
+            CoefLine<CF> l;
+            double g;
+            __device__ __forceinline__ double operator[](int64_t i) const { return (double)l[i] * g; }
+        };
+        const ScaledLine rd{k == 0 ? first : c, (k == 0 && gain_first) ? gain : 1.0};
         double c0 = rd[0];
         {
             double z_i = z;
@@ -929,7 +936,7 @@ spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_
         } else {
             last *= z / (z - 1);
         }
-        const double scale = last_pole ? gain : 1.0;
+        const double scale = (last_pole && !gain_first) ? gain : 1.0;
         c[(n - 1) * st] = last * scale;
         // ---- anti-causal sweep
         double nxt = last;
@@ -1408,6 +1415,8 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
 using namespace mi;
 
 static int g_interp_generic = 0;   // test hook: 1 = always use the generic double kernels
+static int g_spline_gain_first = 1;     // test hook: 0 = the one-thread-per-line kernel applies the gain with its last store
+extern "C" int mi_debug_set_spline_gain_first(int k) { g_spline_gain_first = k; return MI_OK; }
 static int g_spline_threads = 65536;   // threads the blocked prefilter aims for
 extern "C" int mi_debug_set_spline_threads(int k) { g_spline_threads = k; return MI_OK; }
 static int g_spline_chunk = 0;     // test hook: -1 = never the blocked prefilter, > 0 = force it with this minimum chunk length
@@ -1629,10 +1638,10 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
     const dim3 grid((unsigned)((nlines + 63) / 64));
     if (shape->dtype == MI_F64)
         hipLaunchKernelGGL(spline_filter1d_kernel<double>, grid, dim3(64), 0, s, (double *)dst, (const double *)from, n, inner, nlines,
-                           order, spline_mode);
+                           order, spline_mode, g_spline_gain_first);
     else
         hipLaunchKernelGGL(spline_filter1d_kernel<float>, grid, dim3(64), 0, s, (float *)dst, (const float *)from, n, inner, nlines,
-                           order, spline_mode);
+                           order, spline_mode, g_spline_gain_first);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
