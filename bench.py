@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: uniform_filter(size=5) on a 512^3 float32 volume.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config H|E] [--scaling strong|weak]
 
-N = 1: one fused HIP launch per step on a device-resident volume
+Default (--config H, the metric of BASELINE.json).  N = 1: one fused HIP launch per step on a device-resident volume
 (cupyimg_amd.scipy.ndimage.uniform_filter -> mi_separable3d_f32).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the same 512^3
 volume is slab-partitioned on axis 0 (strong scaling); a step is one RCCL halo
@@ -18,6 +18,15 @@ section 8d), timed live with HIP events on the library's stream.
 `cpu_baseline` times the CPU oracle (scalar single-thread port) and
 scipy.ndimage on the host cores of this box, on the full 512^3 volume, and the
 oracle's output doubles as a full-size parity check of the GPU result.
+
+--scaling weak: every rank filters its own 512^3 slab of a (512 N) x 512 x 512
+volume (per-GPU work fixed).  --config E: BASELINE config 4, uniform_filter
+size=9 on a 2048^3 float32 volume slab-split over the N ranks (N = 8: 256 + 8
+planes per rank; N = 1: the whole 32 GiB volume on one GPU), generated on the
+device by a counter-based generator (csrc/synth.hip) so the volume never exists
+on the host; outside the timed region every rank rebuilds the planes around its
+two slab faces on the host (oracle/synth.py) and checks seams and outer faces
+against scipy.ndimage.
 """
 import argparse
 import json
@@ -40,18 +49,56 @@ def synth(shape, seed=0):
     return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
 
 
-def measured_traffic(world):
-    """HBM bytes per launch from the rocprofv3 PMC passes of this same command
-    (profiles/r2_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction
-    applied).  Counters cannot be read from inside the process, so this is the
-    committed measurement, valid for the single-GPU workload only."""
-    if world != 1:
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+TRAFFIC_FILES = ("r3_traffic.json", "r2_traffic.json")
+
+
+def measured_traffic(world, config):
+    """(HBM bytes per launch, source) from the rocprofv3 PMC passes of this same command (profiles/r*_traffic.json:
+    2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied).  Counters cannot be read from inside the process, so this
+    is the committed measurement -- labelled as such in the JSON line -- valid for the single-GPU headline workload."""
+    if world != 1 or config != "H":
+        return None, None
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["hbm_bytes_per_launch"], "profiles/{} (rocprofv3 PMC passes of this command, not live)".format(name)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def last_kernel():
+    """Name of the kernel the last separable-filter call of this thread dispatched, from the library itself."""
+    import ctypes
+    from cupyimg_amd import _lib
+    buf = ctypes.create_string_buffer(200)
+    fn = _lib.load().mi_debug_last_kernel
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    fn(buf, 200)
+    return buf.value.decode()
+
+
+def copy_kernel_ceiling(ca, xd, out):
+    """The in-tree float4 copy kernel (csrc/separable3d.hip copy_f4_kernel) on the same 2 x 512 MiB, best grid size:
+    the practical HBM ceiling of THIS box for the same byte count (hipMemcpy is a weaker comparator)."""
+    import ctypes
+    from cupyimg_amd import _lib
+    fn = _lib.load().mi_debug_copy_f32
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    best, best_blocks = None, None
+    for blocks in (1024, 2048, 4096, 8192, 16384):
+        for _ in range(3):
+            fn(xd.ptr, out.ptr, xd.size, blocks, None)
+        e0, e1 = ca.Event(), ca.Event()
+        e0.record()
+        for _ in range(10):
+            fn(xd.ptr, out.ptr, xd.size, blocks, None)
+        e1.record()
+        ca.synchronize()
+        t = e0.elapsed_ms(e1) / 10 / 1e3
+        if best is None or t < best:
+            best, best_blocks = t, blocks
+    return 2 * xd.nbytes / best / 1e9, best_blocks
 
 
 def _allcores_worker(args):
@@ -154,11 +201,47 @@ def cpu_baseline(x, gpu_out):
     return res
 
 
+E_SIDE = 2048
+E_SIZE = 9
+E_SEED = 20260
+
+
+def fill_synthetic(ca, dst, first_index, seed):
+    """dst (C-contiguous float32 device array) <- synthetic values of global indices first_index .. (csrc/synth.hip)"""
+    import ctypes
+    from cupyimg_amd import _lib
+    fn = _lib.load().mi_debug_fill_synthetic_f32
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    _lib.check(fn(dst.ptr, dst.size, int(first_index), int(seed), None))
+
+
+def e_seam_parity(plan, local_out, nz, plane_shape, size, seed):
+    """Config E, outside the timed region: this rank's first and last 6 output planes (the planes whose taps cross a
+    slab seam, or the outer faces of the volume on the edge ranks) against scipy.ndimage on host planes rebuilt from
+    the same counter-based generator.  Returns the worst max-norm relative error."""
+    import scipy.ndimage as sndi
+    from oracle import synth as osynth
+    r = size // 2
+    worst = 0.0
+    for a, b in ((plan.z0, min(plan.z0 + 6, plan.z1)), (max(plan.z1 - 6, plan.z0), plan.z1)):
+        e0, e1 = max(a - r, 0), min(b + r, nz)              # at a global edge the block edge is the volume edge
+        host = osynth.synthetic_planes(e0, e1, plane_shape, seed)
+        ref = sndi.uniform_filter(host.astype(np.float64), size=size)[a - e0:a - e0 + (b - a)]
+        got = local_out[a - plan.z0:b - plan.z0].get().astype(np.float64)
+        worst = max(worst, float(np.abs(got - ref).max() / np.abs(ref).max()))
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=["H", "E"], default="H",
+                    help="H: uniform_filter 5 on 512^3 (BASELINE metric, default); E: uniform_filter 9 on 2048^3 slab-split")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="config H with N > 1: the 512^3 volume split over the ranks (strong, default) or one 512^3 slab "
+                         "per rank (weak)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-allcores-helper", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -192,30 +275,43 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def exchange_id(uid):
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
     # ------------------------------------------------------------ workload
-    x_host = synth((N_SIDE,) * 3) if rank == 0 or world > 1 else None
-    if world == 1:
+    cfg = args.config
+    weak = cfg == "H" and args.scaling == "weak" and world > 1
+    size = SIZE if cfg == "H" else E_SIZE
+    side = N_SIDE if cfg == "H" else E_SIDE
+    nz_total = side * world if weak else side
+    plane_shape = (side, side)
+    sf = plan = None
+    x_host = xd = out = None
+    if cfg == "H" and world == 1:
+        x_host = synth((N_SIDE,) * 3)
         xd = ca.asarray(x_host)
         out = ca.empty(xd.shape, np.float32)
 
         def step():
             ndi.uniform_filter(xd, size=SIZE, output=out)
     else:
-        lo, hi = dist_.halo_widths(SIZE)
-        plan = dist_.SlabPlan(N_SIDE, world, rank, lo, hi, wrap=False)
-
-        def exchange_id(uid):
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-
-        comm = dist_.HaloComm(world, rank, exchange_id)
-        sf = dist_.SlabFilter(plan, (N_SIDE, N_SIDE), np.float32, comm)
-        sf.local_in[...] = ca.asarray(x_host[plan.z0:plan.z1])
+        lo, hi = dist_.halo_widths(size)
+        plan = dist_.SlabPlan(nz_total, world, rank, lo, hi, wrap=False)
+        comm = dist_.HaloComm(world, rank, exchange_id) if world > 1 else None
+        sf = dist_.SlabFilter(plan, plane_shape, np.float32, comm)
+        if cfg == "H" and not weak:
+            x_host = synth((N_SIDE,) * 3)
+            sf.local_in[...] = ca.asarray(x_host[plan.z0:plan.z1])
+        else:
+            # per-rank generation on the device, keyed by the GLOBAL linear index: no rank ever holds the volume
+            fill_synthetic(ca, sf.local_in, plan.z0 * side * side, E_SEED)
 
         def step():
-            sf.uniform_filter(SIZE)
+            sf.uniform_filter(size)
 
+        sf.warm(step)                   # marshalling + (N > 1) the plain / overlapped schedule measurement
     for _ in range(args.warmup):
         step()
     barrier()
@@ -228,35 +324,52 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_ms(ev1)
+    kernel_name = last_kernel()
 
-    slab_ok = None
+    # ------------------------------------------------------------ parity of the distributed / slab result (untimed)
+    slab_ok = seam_err = None
+    if sf is not None:
+        if cfg == "H" and not weak:
+            # every rank filters the whole volume on its own GPU and checks that its slab of the distributed result
+            # is bit-identical to it
+            full = ndi.uniform_filter(ca.asarray(x_host), size=SIZE)
+            slab_ok = not ca.arrays_differ(sf.local_out, full[plan.z0:plan.z1])
+            del full
+        else:
+            seam_err = e_seam_parity(plan, sf.local_out, nz_total, plane_shape, size, E_SEED)
     if dist is not None:
         import torch
-        # outside the timed region: every rank filters the whole volume on its own GPU and checks that its
-        # slab of the distributed result is bit-identical to it
-        full = ndi.uniform_filter(ca.asarray(x_host), size=SIZE)
-        differ = ca.arrays_differ(sf.local_out, full[plan.z0:plan.z1])
-        t = torch.tensor([elapsed, dev_ms, float(differ)], dtype=torch.float64)
+        t = torch.tensor([elapsed, dev_ms, 0.0 if slab_ok in (None, True) else 1.0, seam_err or 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms, slab_ok = float(t[0]), float(t[1]), t[2].item() == 0.0
+        elapsed, dev_ms = float(t[0]), float(t[1])
+        if slab_ok is not None:
+            slab_ok = t[2].item() == 0.0
+        if seam_err is not None:
+            seam_err = float(t[3])
 
-    voxels = N_SIDE ** 3
+    voxels = nz_total * side * side
     ms_per_step = elapsed / args.steps * 1e3
     value = voxels / (elapsed / args.steps) / 1e6
 
     if rank == 0:
-        kernel_s = dev_ms / 1e3 / args.steps          # HIP-event time per step on the launch stream
+        kernel_s = dev_ms / 1e3 / args.steps          # HIP-event time per step on the launch stream (max over ranks)
         per_gpu_voxels = voxels / world
         achieved = ALG_BYTES_PER_VOXEL * per_gpu_voxels / kernel_s / 1e9
+        traffic, traffic_source = measured_traffic(world, cfg)
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(world),
-            "kernel": "mi::sep3d_lean_kernel<5,12,4,3,1,false> (fused x/z/y separable pass)",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": kernel_name, "kernel_source": "mi_debug_last_kernel() after the timed region",
             "alg_bytes_per_launch": ALG_BYTES_PER_VOXEL * per_gpu_voxels,
             "avg_launch_us": round(kernel_s * 1e6, 2),
         }
-        if world == 1:
-            # the practical ceiling of this box: a device-to-device copy of the same 512 MiB (read + write)
+        if cfg == "H" and world == 1:
+            # the practical ceiling of this box for the same 2 x 512 MiB: the in-tree float4 copy kernel (best grid)
+            # and, for continuity with earlier rounds, a hipMemcpy device-to-device copy
+            ck_gbs, ck_blocks = copy_kernel_ceiling(ca, xd, out)
+            roofline["copy_kernel_GBps_same_bytes"] = round(ck_gbs, 1)
+            roofline["copy_kernel_blocks"] = ck_blocks
+            roofline["frac_of_copy_kernel"] = round(achieved / ck_gbs, 4)
             for _ in range(3):
                 out[...] = xd
             c0, c1 = ca.Event(), ca.Event()
@@ -270,23 +383,36 @@ def main():
             roofline["frac_of_d2d_copy"] = round(achieved / copy_gbs, 4)
             step()                                        # `out` holds the filter result again (parity leg below)
             ca.synchronize()
-        if world == 1 and not args.no_cpu:
+        if cfg == "H" and world == 1 and not args.no_cpu:
             cpu = cpu_baseline(x_host, out.get())
         else:
             cpu = None
+        if world == 1:
+            partition = "single GPU"
+        else:
+            sched = sf.schedule_of("uniform") or {}
+            partition = "z-slabs x{} + RCCL halo exchange ({} schedule, measured in warm(): plain / overlapped median {} ms)".format(
+                world, "overlapped" if sched.get("choice") == 1 else "plain", sched.get("median_ms"))
+        if cfg == "H":
+            metric = "Mvoxels/s, uniform_filter size=5 on 512^3 float32"
+            workload = ("uniform_filter size=5 mode=reflect on {}x512x512 float32, device resident".format(nz_total))
+        else:
+            metric = "Mvoxels/s, uniform_filter size=9 on 2048^3 float32 (BASELINE config 4)"
+            workload = "uniform_filter size=9 mode=reflect on 2048x2048x2048 float32, counter-based synthetic data generated per rank on the device"
         line = {
-            "metric": "Mvoxels/s, uniform_filter size=5 on 512^3 float32",
+            "metric": metric,
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "uniform_filter size=5 mode=reflect on 512x512x512 float32, device resident",
-                       "partition": "z-slabs x{} + RCCL halo exchange overlapped with the interior planes".format(world) if world > 1 else "single GPU",
-                       "device": ca.device_name()},
+            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "partition": partition, "device": ca.device_name()},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         if slab_ok is not None:
             line["slabs_bit_identical_to_single_gpu"] = slab_ok
+        if seam_err is not None:
+            line["seam_and_face_parity_vs_scipy_maxnorm_rel"] = seam_err
+            line["parity_tol"] = 1e-6
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

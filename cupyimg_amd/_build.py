@@ -25,6 +25,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("runtime.hip", []),
     ("copy.hip", []),
+    ("synth.hip", []),
     ("correlate1d.hip", ["-ffp-contract=off"]),
     ("separable3d.hip", []),
     ("stream3d.hip", []),
@@ -64,6 +65,7 @@ def hipcc():
 
 
 def _deps_mtime():
+    """Newest header of the tree: the fallback dependency of an object whose own dependency file is missing."""
     newest = 0.0
     for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
         for name in os.listdir(root):
@@ -72,14 +74,32 @@ def _deps_mtime():
     return newest
 
 
+def _obj_deps_mtime(depfile, fallback):
+    """Newest in-tree header the object was built from (hipcc -MMD writes them to <object>.d), so that editing one
+    kernel's header does not rebuild the whole library (a full build is minutes)."""
+    try:
+        text = open(depfile).read().replace("\\\n", " ")
+    except OSError:
+        return fallback
+    newest = 0.0
+    for tok in text.split()[1:]:
+        if tok.endswith((".hpp", ".h")) and not tok.startswith("/opt/"):
+            try:
+                newest = max(newest, os.path.getmtime(os.path.join(CSRC, tok)))      # absolute tokens stay as they are
+            except OSError:
+                return fallback          # a header was renamed / removed: rebuild
+    return newest
+
+
 def _compile(args):
     src, flags, force, hdr_mtime = args
     s = os.path.join(CSRC, src)
     o = os.path.join(OBJ, src.replace(".hip", ".o"))
+    d = o + ".d"
     if (not force and os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(s)
-            and os.path.getmtime(o) >= hdr_mtime):
+            and os.path.getmtime(o) >= _obj_deps_mtime(d, hdr_mtime)):
         return o, False
-    cmd = [hipcc()] + COMMON + flags + ["-c", s, "-o", o]
+    cmd = [hipcc()] + COMMON + flags + ["-MMD", "-MF", d, "-c", s, "-o", o]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise RuntimeError("hipcc failed for {}:\n{}".format(src, proc.stdout))

@@ -2,7 +2,7 @@
 n-D convolution as separable convolve1d passes (cupyimg/_misc.py:39-77)."""
 import numpy as np
 
-from . import core
+from . import _lib, core
 from .scipy.ndimage import convolve1d
 
 __all__ = ["convolve_separable"]
@@ -56,6 +56,6 @@ def _fused_separable(x, w, axes, kwargs):
     out = core.empty(x.shape, np.float32)
     try:
         res = F._fused_3d(x, out, weights, origins, [mode] * 3, float(kwargs.get("cval", 0.0)), False, None)
-    except Exception:
+    except (_lib.Unsupported, ValueError):      # not covered / refused by argument validation: the per-axis passes run
         return None
     return res

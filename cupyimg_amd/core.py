@@ -205,7 +205,10 @@ class ndarray:
         """An image as a one-plane volume (what the fused 3-D kernels take); cached."""
         v = self._v3
         if v is None or v.ptr != self.ptr or v.shape[1:] != self.shape:
-            v = self._view((1,) + self.shape, (self.strides[0] * self.shape[0],) + self.strides, self.ptr)
+            # no strong reference back to `self` (array -> _v3 -> base -> array would keep the device buffer alive
+            # until the cyclic collector runs): the view shares `_mem`, which is what owns the allocation
+            v = ndarray((1,) + self.shape, self.dtype, _mem=self._mem, _ptr=self.ptr,
+                        _strides=(self.strides[0] * self.shape[0],) + self.strides, _base=self.base)
             self._v3 = v
         return v
 
@@ -222,6 +225,7 @@ class ndarray:
         arr = np.ascontiguousarray(arr, dtype=self.dtype)
         if arr.shape != self.shape:
             raise ValueError("shape mismatch")
+        self._touch()
         if self._is_c_contiguous():
             if arr.nbytes:
                 lib = _lib.load()
@@ -245,8 +249,16 @@ class ndarray:
         _copy(self, out)
         return out
 
-    def fill(self, value):
+    def _touch(self):
+        """The array is about to be written: drop the remembered host copy (with_host_hint) of this array and of the
+        array it is a view of."""
         self._hc = None
+        b = self.base
+        if b is not None:
+            b._hc = None
+
+    def fill(self, value):
+        self._touch()
         d = self._desc()
         _lib.check(_lib.load().mi_fill(ctypes.byref(d), float(value), None))
 
@@ -321,7 +333,7 @@ class ndarray:
         return self._view(shape, strides, ptr)
 
     def __setitem__(self, key, value):
-        self._hc = None
+        self._touch()
         dst = self[key]
         if isinstance(value, ndarray):
             src = value
@@ -341,6 +353,7 @@ class ndarray:
 
 
 def _copy(src, dst, round_half_even=False):
+    dst._touch()
     a, b = src._desc(), dst._desc()
     _lib.check(_lib.load().mi_copy(ctypes.byref(a), ctypes.byref(b), int(round_half_even), None))
 
@@ -464,8 +477,9 @@ def ascontiguousarray(a, dtype=None):
 def with_host_hint(a, host):
     """Remember the host array a small device array was uploaded from (structuring elements: the morphology calls
     need them on the host again, and fetching one back costs a stream synchronisation plus a copy, ~50 us per call).
-    `__setitem__` and `fill` drop the hint; code that writes the array any other way (as an `output=`) must not rely on
-    it -- only the footprint constructors of skimage.morphology set it."""
+    Every write path of this package drops the hint -- `__setitem__`, `fill`, `set`, copies into the array, and its
+    use as an `output=` (scipy.ndimage._support.get_output), also through a view (`ndarray._touch`); only the
+    footprint constructors of skimage.morphology set it."""
     a._hc = np.array(host, copy=True)
     a._hc.setflags(write=False)
     return a

@@ -98,7 +98,7 @@ int binary3_tiled(const mi_array *in, const mi_array *out, const uint8_t *struct
 using namespace mi;
 
 // test hook (not part of the C-ABI): 0 = never use the LDS-tiled kernel
-static int g_binary_tiled = 1;
+static mi::Knob g_binary_tiled{1};
 extern "C" int mi_debug_set_binary_tiled(int enabled) { g_binary_tiled = enabled; return MI_OK; }
 
 extern "C" int mi_binary_erosion(const mi_array *in, const mi_array *out, const uint8_t *structure,

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <type_traits>
 
 #include "../../include/mi355img.h"
@@ -32,6 +33,17 @@ int hip_fail(hipError_t e, const char *what);
             return (code);               \
         }                                \
     } while (0)
+
+// ------------------------------------------------------------------ test / tuning knobs
+// Process-wide switches behind the mi_debug_set_* entry points (include/mi355img_debug.h): relaxed atomics, so a
+// thread flipping one while other threads dispatch is a benign race (each call reads a knob once and sees either
+// value), never a data race.  They exist for tests and tuning sweeps; production code never writes them.
+struct Knob {
+    std::atomic<int> v;
+    constexpr explicit Knob(int x) : v(x) {}
+    operator int() const { return v.load(std::memory_order_relaxed); }
+    Knob &operator=(int x) { v.store(x, std::memory_order_relaxed); return *this; }
+};
 
 // ------------------------------------------------------------------ runtime hooks
 hipStream_t resolve_stream(mi_stream s);   // NULL -> per-device default stream

@@ -79,7 +79,7 @@ int stencil3_tiled(const mi_array *in, const mi_array *out, const double *weight
 using namespace mi;
 
 // test hook (not part of the C-ABI): 0 = never use the LDS-tiled stencil kernel
-static int g_stencil_enabled = 1;
+static mi::Knob g_stencil_enabled{1};
 extern "C" int mi_debug_set_stencil(int enabled) { g_stencil_enabled = enabled; return MI_OK; }
 
 extern "C" int mi_correlate_nd(const mi_array *in, const mi_array *out, const double *weights,

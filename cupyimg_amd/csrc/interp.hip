@@ -1414,19 +1414,19 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
 
 using namespace mi;
 
-static int g_interp_generic = 0;   // test hook: 1 = always use the generic double kernels
-static int g_spline_gain_first = 1;     // test hook: 0 = the one-thread-per-line kernel applies the gain with its last store
+static mi::Knob g_interp_generic{0};   // test hook: 1 = always use the generic double kernels
+static mi::Knob g_spline_gain_first{1};     // test hook: 0 = the one-thread-per-line kernel applies the gain with its last store
 extern "C" int mi_debug_set_spline_gain_first(int k) { g_spline_gain_first = k; return MI_OK; }
-static int g_spline_threads = 65536;   // threads the blocked prefilter aims for
+static mi::Knob g_spline_threads{65536};   // threads the blocked prefilter aims for
 extern "C" int mi_debug_set_spline_threads(int k) { g_spline_threads = k; return MI_OK; }
-static int g_spline_chunk = 0;     // test hook: -1 = never the blocked prefilter, > 0 = force it with this minimum chunk length
+static mi::Knob g_spline_chunk{0};     // test hook: -1 = never the blocked prefilter, > 0 = force it with this minimum chunk length
 extern "C" int mi_debug_set_spline_chunk(int k) { g_spline_chunk = k; return MI_OK; }
-static int g_spline_rows_off = 0;  // test hook: 1 = one thread per line also for contiguous lines
-static int g_cubic_separable_off = 0;   // test hook: 1 = diagonal transforms use the one-launch strip kernel
+static mi::Knob g_spline_rows_off{0};  // test hook: 1 = one thread per line also for contiguous lines
+static mi::Knob g_cubic_separable_off{0};   // test hook: 1 = diagonal transforms use the one-launch strip kernel
 extern "C" int mi_debug_set_cubic_separable(int on) { g_cubic_separable_off = !on; return MI_OK; }
-static int g_cubic_diag_off = 0;    // test hook: 1 = diagonal transforms use the gather kernel too
+static mi::Knob g_cubic_diag_off{0};    // test hook: 1 = diagonal transforms use the gather kernel too
 extern "C" int mi_debug_set_cubic_diag(int on) { g_cubic_diag_off = !on; return MI_OK; }
-static int g_spline_rows_force = 0; // test hook: 2 = tiled kernel whatever the line count
+static mi::Knob g_spline_rows_force{0}; // test hook: 2 = tiled kernel whatever the line count
 extern "C" int mi_debug_set_spline_rows(int on) { g_spline_rows_off = on == 0; g_spline_rows_force = on == 2; return MI_OK; }
 extern "C" int mi_debug_set_interp_generic(int v) { g_interp_generic = v; return MI_OK; }
 

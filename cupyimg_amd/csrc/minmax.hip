@@ -186,11 +186,11 @@ int minmax3_tiled(const mi_array *in, const mi_array *out, const uint8_t *footpr
 using namespace mi;
 
 // test hook (not part of the C-ABI): 0 = never use the LDS-tiled kernel
-static int g_rank_sorted = 1;     // test hook: 0 = rank filters always use the selection kernel
-static int g_rank_median = 1;     // test hook: 0 = medians of 25 / 27 samples take the full 32-sample network
+static mi::Knob g_rank_sorted{1};     // test hook: 0 = rank filters always use the selection kernel
+static mi::Knob g_rank_median{1};     // test hook: 0 = medians of 25 / 27 samples take the full 32-sample network
 extern "C" int mi_debug_set_rank_median(int enabled) { g_rank_median = enabled; return MI_OK; }
 extern "C" int mi_debug_set_rank_sorted(int enabled) { g_rank_sorted = enabled; return MI_OK; }
-static int g_minmax_tiled = 1;
+static mi::Knob g_minmax_tiled{1};
 extern "C" int mi_debug_set_minmax_tiled(int enabled) { g_minmax_tiled = enabled; return MI_OK; }
 
 extern "C" {

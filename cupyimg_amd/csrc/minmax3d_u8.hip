@@ -1391,7 +1391,7 @@ static int launch_u8_fused_w(int w, const uint8_t *in, uint8_t *out, U8FusedPara
 using namespace mi;
 
 // test / tuning hook (not part of the C-ABI): 0 = always take the two-launch path
-static int g_u8_fused = 1;
+static mi::Knob g_u8_fused{1};
 extern "C" int mi_debug_set_u8_fused(int enabled) { g_u8_fused = enabled; return MI_OK; }
 
 extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int size[3],

@@ -309,6 +309,8 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
         attr_done = true;
     }
     const int total = p.nxt * p.nyt * p.nzc;
+    note_kernel("mi::sep3d_long_kernel<%d,%s,%s> grid=%d (fused y/x/z separable pass, LDS-DMA staged)", W,
+                SAME ? "true" : "false", HAS_CONST ? "true" : "false", total);
     hipLaunchKernelGGL((sep3d_long_kernel<W, SAME, HAS_CONST>), dim3(total), dim3(kLongTY * 64), lds, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -326,8 +328,8 @@ static int long_cus()
     return cus;
 }
 
-static int g_long_zchunks = 0;     // test hook: number of z chunks (0 = cost model)
-static int g_long_same = 1;        // test hook: 0 = always the reloading variant
+static mi::Knob g_long_zchunks{0};     // test hook: number of z chunks (0 = cost model)
+static mi::Knob g_long_same{1};        // test hook: 0 = always the reloading variant
 
 // Fused long-kernel path: cubic odd W in 11..17 (9 behind the test hook), origins on y / z allowed, no constant mode.
 // Returns MI_ERR_UNSUPPORTED when the request is outside that (the caller runs the streaming passes).
@@ -380,7 +382,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
         const double cost = rounds * (chunk + w - 1 + 3);
         if (cost < best) { best = cost; best_nzc = real; }
     }
-    if (g_long_zchunks > 0) best_nzc = std::min(g_long_zchunks, nzr);
+    if (g_long_zchunks > 0) best_nzc = std::min((int)g_long_zchunks, nzr);
     p.zc = (nzr + best_nzc - 1) / best_nzc;
     if (p.zc > kLongMaxChunk) p.zc = kLongMaxChunk;
     p.zb0 = (int)zb[0]; p.zn0 = (int)zn[0]; p.zb1 = (int)zb[1]; p.zn1 = (int)zn[1];

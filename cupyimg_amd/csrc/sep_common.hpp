@@ -6,6 +6,10 @@ namespace mi {
 
 constexpr int kMaxTaps = 9;
 
+// remembers (per host thread) which kernel a separable-filter call dispatched: mi_debug_last_kernel (bench.py names
+// the kernel it timed from this, not from a literal)
+void note_kernel(const char *fmt, ...);
+
 struct Sep3dParams {
     int nx, ny, nz;
     int wy;                 // taps along y (run-time loop)

@@ -33,10 +33,21 @@
 // checks (otherwise MI_ERR_UNSUPPORTED and the caller runs 1-D passes).
 // Arithmetic is float32 FMA; against SciPy's double-accumulate-round-per-pass
 // the difference is ~1e-7 relative (tolerance 1e-6, tests/test_gpu_filters.py).
+#include <stdarg.h>
+
 #include "sep_common.hpp"
 #include "stream3d.hpp"
 
 namespace mi {
+
+static thread_local char t_last_kernel[160] = "";
+void note_kernel(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_last_kernel, sizeof(t_last_kernel), fmt, ap);
+    va_end(ap);
+}
 
 // ---------------------------------------------------------------------------
 // v2: wave-specialised variant.  NWP producer waves own the rows (load, x pass,
@@ -295,6 +306,7 @@ static int launch_sep3d_ws(const float *in, float *out, const Sep3dParams &p, hi
         attr_done = true;
     }
     const int total = p.nxt * p.nyt * p.nzc;
+    note_kernel("mi::sep3d_ws_kernel<%d,%d,%d,%d,%d> grid=%d", WX, WZ, NWP, NWC, R, total);
     hipLaunchKernelGGL((sep3d_ws_kernel<WX, WZ, NWP, NWC, R>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in,
                        out, p);
     MI_HIP(hipGetLastError());
@@ -592,6 +604,8 @@ static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool h
     }
     if (p.ty != TY) { set_error("internal: lean tile mismatch"); return MI_ERR_INTERNAL; }
     const int total = p.nxt * p.nyt * p.nzc;
+    note_kernel("mi::sep3d_lean_kernel<%d,%d,%d,%d,%d,%s> grid=%d (fused x/z/y separable pass)", W, NWP, NWC, R, DEPTH,
+                has_const ? "true" : "false", total);
     if (has_const)
         hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
     else
@@ -707,22 +721,30 @@ static void choose_plan(int w, const int *cand_rows, const int *cand_cfg, int nc
 using namespace mi;
 
 // test / tuning hooks (not part of the C-ABI in include/mi355img.h)
-static int g_sep3d_cfg = 0;       // tile shape variant
-static int g_sep3d_zchunks = 0;   // 0 = heuristic
-static int g_sep3d_dbg = 0;       // ablation flags
-static int g_sep3d_kernel = 0;    // 0 = auto, 1 = force general (ws) kernel
-static int g_sep3d_zrev = 1;      // 1 = odd z chunks of the lean kernel stream downwards (ramp planes shared in time)
+static mi::Knob g_sep3d_cfg{0};       // tile shape variant
+static mi::Knob g_sep3d_zchunks{0};   // 0 = heuristic
+static mi::Knob g_sep3d_dbg{0};       // ablation flags
+static mi::Knob g_sep3d_kernel{0};    // 0 = auto, 1 = force general (ws) kernel
+static mi::Knob g_sep3d_zrev{1};      // 1 = odd z chunks of the lean kernel stream downwards (ramp planes shared in time)
 extern "C" int mi_debug_set_sep3d_zrev(int k) { g_sep3d_zrev = k; return MI_OK; }
-static int g_stream_fused_max = kStreamFusedMax;    // test hook: longest kernel with the x pass fused into the streamed pass
+static mi::Knob g_stream_fused_max{kStreamFusedMax};    // test hook: longest kernel with the x pass fused into the streamed pass
 extern "C" int mi_debug_set_stream_fused_max(int k) { g_stream_fused_max = k; return MI_OK; }
-static int g_sep3d_image2d = 1;   // test hook: 0 = images with <= 9 taps take the tiled volume kernel (round-1 behaviour)
+static mi::Knob g_sep3d_image2d{1};   // test hook: 0 = images with <= 9 taps take the tiled volume kernel (round-1 behaviour)
 extern "C" int mi_debug_set_sep3d_image2d(int k) { g_sep3d_image2d = k; return MI_OK; }
-static int g_sep3d_long = 0;      // 0 = auto (cubic 9..17 taps), 1 = off (lean kernel / streaming passes), 2 = also for 3..7 taps
+static mi::Knob g_sep3d_long{0};      // 0 = auto (cubic 9..17 taps), 1 = off (lean kernel / streaming passes), 2 = also for 3..7 taps
 extern "C" int mi_debug_set_sep3d_long(int k) { g_sep3d_long = k; return MI_OK; }
 extern "C" int mi_debug_set_sep3d_cfg(int cfg) { g_sep3d_cfg = cfg; return MI_OK; }
 extern "C" int mi_debug_set_sep3d_zchunks(int n) { g_sep3d_zchunks = n; return MI_OK; }
 extern "C" int mi_debug_set_sep3d_dbg(int f) { g_sep3d_dbg = f; return MI_OK; }
 extern "C" int mi_debug_set_sep3d_kernel(int k) { g_sep3d_kernel = k; return MI_OK; }
+static mi::Knob g_sep3d_box{0};       // 0 = auto (running-sum box kernel where it applies), 1 = off
+extern "C" int mi_debug_set_sep3d_box(int k) { g_sep3d_box = k; return MI_OK; }
+extern "C" int mi_debug_last_kernel(char *buf, size_t n)
+{
+    MI_REQUIRE(buf && n > 0, MI_ERR_INVALID_ARG, "NULL buffer");
+    snprintf(buf, n, "%s", mi::t_last_kernel);
+    return MI_OK;
+}
 extern "C" int mi_debug_copy_f32(const float *in, float *out, int64_t n, int blocks, mi_stream stream)
 {
     hipLaunchKernelGGL(copy_f4_kernel, dim3(blocks), dim3(256), 0, resolve_stream(stream), (const float4 *)in,

@@ -362,13 +362,13 @@ static int launch_runs_f32(const float *in, float *out, RunsF32Params &p, bool i
 // Round 1 issued a pass in launches of at most 1000 waves because larger launches produced wrong samples; the
 // cause was the store-data hazard described at buffer_store_b128_soff() (sep_common.hpp), not the launch size.
 // The slice hook stays for tests (0 = one launch, the default).
-int g_xcd_swizzle = 2;               // test hook: 0 = plain workgroup order, 1 = always XCD-contiguous, 2 = auto
+mi::Knob g_xcd_swizzle{2};               // test hook: 0 = plain workgroup order, 1 = always XCD-contiguous, 2 = auto
 extern "C" int mi_debug_set_xcd_swizzle(int k) { g_xcd_swizzle = k; return MI_OK; }
-static int g_stream_wpb = 4;             // test hook: waves per workgroup (1, 2 or 4)
+static mi::Knob g_stream_wpb{4};             // test hook: waves per workgroup (1, 2 or 4)
 extern "C" int mi_debug_set_stream_wpb(int n) { g_stream_wpb = n; return MI_OK; }
-static int g_stream_slice = 0;           // test hook: waves per launch of a pass (0 = one launch)
+static mi::Knob g_stream_slice{0};           // test hook: waves per launch of a pass (0 = one launch)
 extern "C" int mi_debug_set_stream_slice(int n) { g_stream_slice = n; return MI_OK; }
-static int g_stream_min_chunk = 16;      // test hook: shortest chunk the planner may choose
+static mi::Knob g_stream_min_chunk{16};      // test hook: shortest chunk the planner may choose
 extern "C" int mi_debug_set_stream_min_chunk(int n) { g_stream_min_chunk = n; return MI_OK; }
 
 template <int WX, int WA, int OP = SP_CORR>
@@ -396,13 +396,14 @@ static int launch_stream(const float *in, float *out, StreamParams &p, hipStream
     p.chunk = (nA + nch - 1) / nch;
     p.nchunks = (nA + p.chunk - 1) / p.chunk;
     const int waves = nlines * p.nchunks;
-    const int slice = g_stream_slice > 0 ? g_stream_slice : waves;
+    const int slice = g_stream_slice > 0 ? (int)g_stream_slice : waves;
     const int wpb = g_stream_wpb;
     p.wpb = wpb;
     p.swz = xcd_swizzle_for((size_t)p.nx * p.ny * p.nz * 4);
     for (int base = 0; base < waves; base += slice) {
         p.wid_base = base;
         const int n = std::min(slice, waves - base);
+        note_kernel("mi::stream_pass_kernel<%d,%d,%d,%d> grid=%d", WX, WA, DEPTH, (int)OP, (n + wpb - 1) / wpb);
         hipLaunchKernelGGL((stream_pass_kernel<WX, WA, DEPTH, OP>), dim3((n + wpb - 1) / wpb), dim3(64 * wpb), 0, s, in, out, p);
     }
     MI_HIP(hipGetLastError());
@@ -508,7 +509,7 @@ int run_minmax3d_f32_fused(const float *in, float *out, int nz, int ny, int nx, 
 
 using namespace mi;
 
-static int g_minmax_f32_fused = 1;      // test hook: 0 = always the two streaming launches
+static mi::Knob g_minmax_f32_fused{1};      // test hook: 0 = always the two streaming launches
 extern "C" int mi_debug_set_minmax_f32_fused(int k) { g_minmax_f32_fused = k; return MI_OK; }
 
 // test hook: one streaming pass with arbitrary float weights (not part of the C-ABI)

@@ -43,7 +43,7 @@ struct StreamParams {
 // plain order, neighbouring chunks of an image -- which share their ramp rows -- land on different XCDs and each L2
 // fetches those rows from HBM again (measured 1.3-1.4x the algorithmic reads for 7-17-row windows).  This order gives
 // every XCD a contiguous run of workgroups.  g_xcd_swizzle: test hook (0 = plain order).
-extern int g_xcd_swizzle;        // 0 = plain order, 1 = always, 2 = auto
+extern Knob g_xcd_swizzle;        // 0 = plain order, 1 = always, 2 = auto
 // auto: arrays up to 128 MiB (4096^2 float32 +7 %, 8192^2 float32 +4 %; a 1 GiB image LOSES 7 %: eight distant streams
 // instead of one front moving through the DRAM pages)
 static inline int xcd_swizzle_for(size_t array_bytes)

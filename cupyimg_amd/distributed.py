@@ -179,8 +179,9 @@ class SlabFilter:
         self._input_free = None       # previous readers of ext_in finished (default stream)
         self._overlap_ok = True
         self._prepared = {}
+        self._native_refused = set()  # filters mi_slab_separable3d_f32 answered UNSUPPORTED for (generic step instead)
         self._tuning = {}             # per filter: schedule measurements / choice (see _tuned_schedule)
-        self.autotune = True          # overlap=None: measure plain vs overlapped on the first four steps
+        self.autotune = True          # overlap=None: measure plain vs overlapped inside the first call (warm)
 
     @property
     def local_in(self):
@@ -251,8 +252,8 @@ class SlabFilter:
         (mi_slab_separable3d_f32); the marshalled arguments are cached, so a
         repeated step costs a few microseconds of host time.  `fallback(ext_in,
         ext_out)` runs under the plain schedule when the fused kernel does not
-        cover the request.  overlap: True / False; default None = measured on
-        the first four steps (`_tuned_schedule`; with `autotune = False`: decided by
+        cover the request.  overlap: True / False; default None = measured
+        inside the first call (`_tuned_schedule`, `warm`; with `autotune = False`: decided by
         the halo size in C, overlapping from ~8 MiB per direction)."""
         from .scipy.ndimage import _support as S
         plan = self.plan
@@ -277,6 +278,8 @@ class SlabFilter:
                     S.c_ints([S.mode_code(m) for m in modes]), float(cval), plan.lo, plan.hi, plan.prev, plan.next, 0,
                     self._comm_stream.handle, self._input_free._e, self._halos_ready._e, None)
             prep = self._prepared[key] = (args, (keep, a, b))        # second item keeps the buffers alive
+        if key in self._native_refused and fallback is not None:
+            return self.step(fallback)             # the fused kernels do not take this request: remembered, not re-probed
         try:
             args = prep[0]
             if overlap is not None:
@@ -285,41 +288,74 @@ class SlabFilter:
                 mode_flag = -1
             else:
                 mode_flag = self._tuned_schedule(key, args)
-                if mode_flag is None:           # that call was a tuning step and has been issued
-                    return self.local_out
             _lib.check(_lib.load().mi_slab_separable3d_f32(*args[:12], mode_flag, *args[13:]))
         except _lib.Unsupported:
             if fallback is None:
                 raise
+            self._native_refused.add(key)
             return self.step(fallback)
         return self.local_out
 
-    def _tuned_schedule(self, key, args):
+    def _tuned_schedule(self, key, args, samples=3):
         """Plain or overlapped schedule for this filter, measured instead of guessed: whether hiding the exchange
         behind the interior planes pays depends on the link (xGMI latency and bandwidth for THIS halo size) and on
-        the cost of the cross-stream waits, and neither can be known from a one-GPU box.  The first four steps of
-        a filter are used for it: one warm step of each schedule, then one timed step of each (HIP events on the
-        default stream); from the fifth step on the faster one runs.  Every step, tuning or not, performs exactly
-        one exchange, so ranks that decide differently still pair their sends and receives.  Returns the flag for
-        mi_slab_separable3d_f32, or None when the call was consumed as a tuning step."""
-        st = self._tuning.setdefault(key, {"n": 0, "t": [None, None]})
-        if "choice" in st:
+        the cost of the cross-stream waits, and neither can be known from a one-GPU box.  The FIRST call of a filter
+        tunes: one warm step of each schedule, then `samples` timed steps of each, alternating (HIP events on the
+        default stream, host-synchronised -- which is why all of it happens inside that one call, `warm()`, and never
+        inside a later step); the medians decide.  Every probe performs exactly one exchange -- also when the
+        overlapped form is refused (kernels that take no plane ranges: the refusal comes before anything is queued,
+        and the plain step runs in its place) -- so ranks that decide differently still pair their sends and receives.
+        Returns the flag for mi_slab_separable3d_f32."""
+        st = self._tuning.get(key)
+        if st is not None:
             return st["choice"]
         lib = _lib.load()
-        n = st["n"]
-        st["n"] = n + 1
-        flag = n & 1                            # steps 0, 2: plain; steps 1, 3: overlapped
-        if n < 2:
-            _lib.check(lib.mi_slab_separable3d_f32(*args[:12], flag, *args[13:]))
-            return None
+        st = {"t": [[], []], "overlap_supported": True}
+
+        def probe(flag):
+            if flag == 1 and not st["overlap_supported"]:
+                flag = 0
+            try:
+                _lib.check(lib.mi_slab_separable3d_f32(*args[:12], flag, *args[13:]))
+            except _lib.Unsupported:
+                if flag == 0:
+                    raise                         # not even the plain schedule: the caller falls back
+                st["overlap_supported"] = False
+                _lib.check(lib.mi_slab_separable3d_f32(*args[:12], 0, *args[13:]))
+            return flag
+
+        probe(0)
+        probe(1)
         e0, e1 = core.Event(), core.Event()
-        e0.record()
-        _lib.check(lib.mi_slab_separable3d_f32(*args[:12], flag, *args[13:]))
-        e1.record()
-        e1.synchronize()
-        st["t"][flag] = e0.elapsed_ms(e1)
-        if n == 3:
-            st["choice"] = 1 if st["t"][1] < 0.97 * st["t"][0] else 0
+        for _ in range(max(int(samples), 1)):
+            for flag in (0, 1):
+                e0.record()
+                used = probe(flag)
+                e1.record()
+                e1.synchronize()
+                if used == flag:
+                    st["t"][flag].append(e0.elapsed_ms(e1))
+        med = [float(np.median(t)) if t else float("inf") for t in st["t"]]
+        st["median_ms"] = med
+        st["choice"] = 1 if st["overlap_supported"] and med[1] < 0.97 * med[0] else 0
+        self._tuning[key] = st
+        return st["choice"]
+
+    def warm(self, step):
+        """Run ``step()`` once so that everything a repeated step amortises is done: argument marshalling, the
+        streams / events, and -- with more than one rank and `autotune` -- the schedule measurement of
+        `_tuned_schedule`.  Benchmarks call it before their own warm-up, so no tuning step can fall into a timed
+        region whatever `--warmup` is.  Collective: every rank must call it (it exchanges halos)."""
+        step()
+        core.synchronize()
+
+    def schedule_of(self, key_prefix):
+        """{"choice": 0 plain / 1 overlapped, "median_ms": [plain, overlapped]} of the tuned filters whose key starts
+        with `key_prefix` (e.g. "uniform"), or None -- what bench.py prints as the partition label."""
+        for k, st in self._tuning.items():
+            if isinstance(k, tuple) and k and k[0] == key_prefix:
+                return {"choice": st["choice"], "median_ms": st.get("median_ms"),
+                        "overlap_supported": st["overlap_supported"]}
         return None
 
     def uniform_filter(self, size, mode="reflect", cval=0.0, overlap=None):

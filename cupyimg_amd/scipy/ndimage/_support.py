@@ -116,6 +116,7 @@ def get_output(output, input, shape=None):
     if isinstance(output, core.ndarray):
         if output.shape != tuple(shape):
             raise ValueError("output shape is not correct")
+        output._touch()            # about to be overwritten: a remembered host copy (core.with_host_hint) is stale
         return output
     if isinstance(output, np.ndarray):
         raise TypeError("output must be a device array (cupyimg_amd.ndarray) or a dtype")

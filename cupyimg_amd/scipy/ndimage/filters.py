@@ -966,7 +966,9 @@ def _rank_filter(input, rank, size, footprint, output, mode, cval, origin, opera
     if input.size == 0:
         return output
     fp = np.ascontiguousarray(footprint, dtype=np.uint8)
-    if (rank == 4 and filter_size == 9 and fp.shape[-2:] == (3, 3) and fp.ndim == input.ndim and fp.ndim in (2, 3)
+    # the streaming 3 x 3 median never sees the footprint: only the FULL in-plane 3 x 3 window qualifies (a (3, 3, 3)
+    # footprint with nine ones in another plane has the same count and trailing shape)
+    if (rank == 4 and filter_size == 9 and fp.shape in ((3, 3), (1, 3, 3)) and bool(fp.all()) and fp.ndim == input.ndim
             and not any(origins) and input.dtype in (np.float32, np.float64, np.uint8, np.uint16, np.int16) and output.dtype == input.dtype
             and S.current_planes() is None):
         res = _try_median3x3(input, output, mode, cval)

@@ -1,0 +1,63 @@
+/* mi355img_debug.h -- test and tuning entry points of libmi355img.so.
+ *
+ * NOT part of the drop-in boundary (include/mi355img.h): nothing in the product path calls these; they exist so
+ * that tests can force a particular kernel (to compare two device paths bit for bit), tuning sweeps can walk tile
+ * shapes, and bench.py can name the kernel it timed.  The setters write process-wide knobs held as relaxed atomics
+ * (mi::Knob, csrc/common.hpp): flipping one while other threads dispatch is not a data race, but it does change
+ * which kernel those threads' NEXT calls take -- keep them out of production code.  All return MI_OK.
+ */
+#ifndef MI355IMG_DEBUG_H
+#define MI355IMG_DEBUG_H
+
+#include "mi355img.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- fused separable float32 kernels (csrc/separable3d.hip, sep3d_long.hip, stream3d.hip) */
+int mi_debug_set_sep3d_cfg(int cfg);          /* lean kernel tile shape variant (0 = cost model) */
+int mi_debug_set_sep3d_zchunks(int n);        /* number of z chunks (0 = cost model) */
+int mi_debug_set_sep3d_dbg(int flags);        /* ablations: 1 no x/z math, 2 no stores, 4 no loads, 8 no y math */
+int mi_debug_set_sep3d_kernel(int k);         /* 1 = always the general (ws) kernel */
+int mi_debug_set_sep3d_zrev(int on);          /* 0 = every z chunk streams upwards */
+int mi_debug_set_sep3d_image2d(int on);       /* 0 = images take the tiled volume kernel */
+int mi_debug_set_sep3d_long(int k);           /* 0 auto, 1 never the long kernel, 2 long kernel also for 3..7 taps */
+int mi_debug_set_sep3d_box(int k);            /* 0 auto, 1 never the running-sum box kernel */
+int mi_debug_set_long_zchunks(int n);
+int mi_debug_set_long_same(int on);
+int mi_debug_set_stream_fused_max(int taps);
+int mi_debug_set_xcd_swizzle(int k);
+int mi_debug_set_stream_wpb(int n);
+int mi_debug_set_stream_slice(int n);
+int mi_debug_set_stream_min_chunk(int n);
+int mi_debug_set_minmax_f32_fused(int on);
+int mi_debug_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axis, const float *wav, int wa,
+                         int oa, int ma, const float *wxv, int wx, int mx, float cval, mi_stream stream);
+/* plain float4 copy kernel (grid-stride, `blocks` workgroups of 256): the practical HBM ceiling for a byte count */
+int mi_debug_copy_f32(const float *in, float *out, int64_t n, int blocks, mi_stream stream);
+/* name of the last kernel the calling thread's separable-filter call dispatched ("" if none), NUL terminated */
+int mi_debug_last_kernel(char *buf, size_t n);
+
+/* counter-based synthetic float32 data (csrc/synth.hip; CPU twin: oracle/synth.py): value i = f(first_index + i, seed) */
+int mi_debug_fill_synthetic_f32(float *out, int64_t n, uint64_t first_index, uint64_t seed, mi_stream stream);
+
+/* ---- other kernel families */
+int mi_debug_set_binary_tiled(int on);        /* csrc/binary.hip: 0 = generic binary erosion kernel */
+int mi_debug_set_stencil(int on);             /* csrc/correlate_nd.hip: 0 = generic n-D correlate */
+int mi_debug_set_minmax_tiled(int on);
+int mi_debug_set_rank_sorted(int on);
+int mi_debug_set_rank_median(int on);
+int mi_debug_set_u8_fused(int k);
+int mi_debug_set_interp_generic(int on);
+int mi_debug_set_spline_gain_first(int on);
+int mi_debug_set_spline_threads(int n);
+int mi_debug_set_spline_chunk(int n);
+int mi_debug_set_spline_rows(int k);
+int mi_debug_set_cubic_separable(int on);
+int mi_debug_set_cubic_diag(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -874,3 +874,28 @@ int orc_minmax3d_u8(const uint8_t *in, uint8_t *out, uint8_t *tmp, int64_t n0,
     minmax_axis_u8(tmp, out, n0, n1, n2, 2, size, mode, cval, is_max);
     return 0;
 }
+
+/* ------------------------------------------------------------------------
+ * Counter-based synthetic volume (bench.py --config E): the CPU restatement of
+ * cupyimg_amd/csrc/synth.hip, bit-identical to it (exact float32 sums of 22-bit
+ * uniforms, one correctly rounded product).  oracle/synth.py is the front end.
+ * ---------------------------------------------------------------------- */
+static uint64_t orc_splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int orc_synth_f32(float *out, int64_t n, uint64_t first_index, uint64_t seed)
+{
+    const float scale = 1.7320508075688772f;
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t c = seed + 4ull * (first_index + (uint64_t)i);
+        float s = 0.f;
+        for (int k = 0; k < 4; k++) s += (float)(uint32_t)(orc_splitmix64(c + (uint64_t)k) >> 42) * 0x1p-22f;
+        out[i] = (s - 2.0f) * scale;
+    }
+    return 0;
+}

@@ -1,8 +1,16 @@
 """Mvoxels/s and %HBM-roofline for every BASELINE.json config that fits one GPU
-(config 0 is the CPU plumbing case, config 4 the 8-GPU case).  Prints one JSON
-line per config.  Algorithmic bytes per voxel: SURVEY.md section 8(d).
+(config 0 is the CPU plumbing case: scripts/bench_config_a.py; config 4's multi-rank
+leg: bench.py --config E), each with a full-size parity field.  One JSON line per
+config.  Algorithmic bytes per voxel: SURVEY.md section 8(d).
 
-    python scripts/bench_configs.py [--reps N] [--only H,B,C,D,Daff]
+    python scripts/bench_configs.py [--reps N] [--only H,B,C,D,Daff,E] [--no-parity]
+
+Timing: 10 warm launches, then `reps` (default 40) back-to-back launches between two
+HIP events -- long enough that the clocks have settled to the power budget (DESIGN.md,
+throttling note), i.e. the SUSTAINED number; `first_ms` is the mean of the first five
+launches of a cold burst for comparison.  `parity` compares the result of the timed
+call with scipy.ndimage on z sub-slabs (tests/helpers/fullsize.py; same checks as
+tests/test_gpu_baseline_full.py), outside the timed region.
 """
 import argparse
 import json
@@ -10,11 +18,14 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 import cupyimg_amd as ca
 from cupyimg_amd.scipy import ndimage as ndi
+from helpers import fullsize as fs
 
 PEAK = 8000.0
 
@@ -29,13 +40,20 @@ def timeit(fn, reps):
         fn()
     e1.record()
     ca.synchronize()
-    return e0.elapsed_ms(e1) / reps / 1e3
+    sustained = e0.elapsed_ms(e1) / reps / 1e3
+    time.sleep(0.5)                       # let the chip cool: the first launches of a burst run at full clocks
+    e0.record()
+    for _ in range(5):
+        fn()
+    e1.record()
+    ca.synchronize()
+    return sustained, e0.elapsed_ms(e1) / 5 / 1e3
 
 
-def report(name, workload, voxels, alg_bytes_per_voxel, secs, extra=None):
+def report(name, workload, voxels, alg_bytes_per_voxel, secs, first, extra=None):
     gbs = voxels * alg_bytes_per_voxel / secs / 1e9
     line = {"config": name, "workload": workload, "Mvoxels_per_s": round(voxels / secs / 1e6, 1),
-            "ms": round(secs * 1e3, 4), "alg_bytes_per_voxel": alg_bytes_per_voxel,
+            "ms": round(secs * 1e3, 4), "first_ms": round(first * 1e3, 4), "alg_bytes_per_voxel": alg_bytes_per_voxel,
             "achieved_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 4)}
     if extra:
         line.update(extra)
@@ -44,61 +62,73 @@ def report(name, workload, voxels, alg_bytes_per_voxel, secs, extra=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--only", default="H,B,C,D,Daff,E")
+    ap.add_argument("--no-parity", action="store_true")
     a = ap.parse_args()
     only = set(a.only.split(","))
-    rng = np.random.default_rng(0)
-    n = 512
+    import scipy.ndimage as sndi
+    par = not a.no_parity
+    n = fs.N_H
     if only & {"H", "B", "D", "Daff"}:
-        x = rng.standard_normal((n, n, n), dtype=np.float32)
+        x = fs.volume_f32((n, n, n), seed=0)
         xd = ca.asarray(x)
         out = ca.empty(xd.shape, np.float32)
     if "H" in only:
-        t = timeit(lambda: ndi.uniform_filter(xd, size=5, output=out), a.reps)
-        report("H", "uniform_filter size=5, 512^3 float32", n ** 3, 8, t)
+        t, t1 = timeit(lambda: ndi.uniform_filter(xd, size=5, output=out), a.reps)
+        p = {"parity": {"maxnorm_rel_vs_scipy": fs.check_filter_slabs(
+            x, out, 2, 2, lambda s: sndi.uniform_filter(s.astype(np.float64), size=5), fs.z_slabs(n, extra=(64, 128, 448))),
+            "tol": 1e-6}} if par else None
+        report("H", "uniform_filter size=5, 512^3 float32", n ** 3, 8, t, t1, p)
     if "B" in only:
-        t = timeit(lambda: ndi.gaussian_filter(xd, sigma=2, output=out), a.reps)
-        report("B", "gaussian_filter sigma=2 (17 taps/axis), 512^3 float32", n ** 3, 8, t)
+        t, t1 = timeit(lambda: ndi.gaussian_filter(xd, sigma=2, output=out), a.reps)
+        p = {"parity": {"maxnorm_rel_vs_scipy": fs.check_filter_slabs(
+            x, out, 8, 8, lambda s: sndi.gaussian_filter(s.astype(np.float64), sigma=2), fs.z_slabs(n, extra=(128, 256, 384))),
+            "tol": 1e-6}} if par else None
+        report("B", "gaussian_filter sigma=2 (17 taps/axis), 512^3 float32", n ** 3, 8, t, t1, p)
     if "D" in only or "Daff" in only:
-        ang = np.deg2rad(7.0)
-        R = np.array([[1, 0, 0], [0, np.cos(ang), -np.sin(ang)], [0, np.sin(ang), np.cos(ang)]])
-        M = np.diag([1.02, 1.0, 1.0]) @ R
-        ctr = (n - 1) / 2.0
-        off = ctr - M @ np.array([ctr] * 3) + np.array([0.5, -1.25, 2.0])
+        M, off = fs.affine_case(n)
         if "Daff" in only:
-            t = timeit(lambda: ndi.affine_transform(xd, M, off, order=1, mode="constant", output=out), a.reps)
-            report("D-affine", "affine_transform order=1 3-D warp, 512^3 float32", n ** 3, 8, t)
+            t, t1 = timeit(lambda: ndi.affine_transform(xd, M, off, order=1, mode="constant", output=out), a.reps)
+            p = {"parity": {"abs_err_over_max1_vs_scipy": fs.check_affine_slabs(x, M, off, out, fs.z_slabs(n, width=4)),
+                            "tol": 2e-6}} if par else None
+            report("D-affine", "affine_transform order=1 3-D warp, 512^3 float32", n ** 3, 8, t, t1, p)
         if "D" in only:
-            idx = np.indices((n, n, n), dtype=np.float32).reshape(3, -1)
-            coords = (M.astype(np.float32) @ idx + off.astype(np.float32)[:, None]).reshape(3, n, n, n)
-            del idx
+            coords = fs.affine_coords_f32(n)
             cd = ca.asarray(coords)
-            del coords
-            t = timeit(lambda: ndi.map_coordinates(xd, cd, order=1, mode="constant", output=out), a.reps)
-            report("D", "map_coordinates order=1 3-D affine warp, 512^3 float32 (+1.5 GiB coords)", n ** 3, 20, t)
-            del cd
+            t, t1 = timeit(lambda: ndi.map_coordinates(xd, cd, order=1, mode="constant", output=out), a.reps)
+            p = {"parity": {"abs_err_over_max1_vs_scipy": fs.check_map_coordinates_slabs(x, coords, out, fs.z_slabs(n, width=4)),
+                            "tol": 2e-6}} if par else None
+            report("D", "map_coordinates order=1 3-D affine warp, 512^3 float32 (+1.5 GiB coords)", n ** 3, 20, t, t1, p)
+            del cd, coords
     if "E" in only:
         # one rank's share of config E: 2048^3 split over 8 GPUs = 256 planes + 4 halo planes each side
         xd = out = None
         ca.free_all_blocks()
-        shape = (264, 2048, 2048)
-        ed = ca.asarray(np.random.default_rng(2).standard_normal(shape, dtype=np.float32))
+        shape = fs.E_SLAB
+        xe = fs.slab_volume_f32(shape)
+        ed = ca.asarray(xe)
         eo = ca.empty(shape, np.float32)
-        t = timeit(lambda: ndi.uniform_filter(ed, size=9, output=eo), max(3, a.reps // 2))
+        t, t1 = timeit(lambda: ndi.uniform_filter(ed, size=9, output=eo), max(5, a.reps // 2))
+        p = {"parity": {"maxnorm_rel_vs_scipy": fs.check_filter_slabs(
+            xe, eo, 4, 4, lambda s: sndi.uniform_filter(s.astype(np.float64), size=9),
+            fs.z_slabs(shape[0], width=4, extra=(128, 256))), "tol": 1e-6}} if par else None
         report("E-slab", "uniform_filter size=9 on one rank's 264x2048x2048 float32 slab of the 2048^3 volume",
-               shape[0] * shape[1] * shape[2], 8, t)
-        ed = eo = None
+               shape[0] * shape[1] * shape[2], 8, t, t1, p)
+        ed = eo = xe = None
         ca.free_all_blocks()
     if "C" in only:
         xd = out = None
         ca.free_all_blocks()
-        m = 1024
-        u = np.random.default_rng(1).integers(0, 256, size=(m, m, m), dtype=np.uint8)
+        m = fs.N_C
+        u = fs.volume_u8((m, m, m), seed=1)
         ud = ca.asarray(u)
         uo = ca.empty(ud.shape, np.uint8)
-        t = timeit(lambda: ndi.grey_erosion(ud, size=7, output=uo), max(3, a.reps // 2))
-        report("C", "grey_erosion size=7, 1024^3 uint8", m ** 3, 2, t)
+        t, t1 = timeit(lambda: ndi.grey_erosion(ud, size=7, output=uo), max(5, a.reps // 2))
+        p = {"parity": {"voxels_differing_from_scipy": fs.check_filter_slabs(
+            u, uo, 3, 3, lambda s: sndi.grey_erosion(s, size=7), fs.z_slabs(m, extra=(256, 512, 768)), exact=True),
+            "tol": 0}} if par else None
+        report("C", "grey_erosion size=7, 1024^3 uint8", m ** 3, 2, t, t1, p)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,130 @@
+"""Full-size parity legs for the BASELINE.json configs (last bullet / 8d): the GPU result of a
+whole 512^3 / 1024^3 / 264 x 2048^2 call is compared with scipy.ndimage on z sub-slabs (with the halo the filter
+needs), so a leg costs seconds of host time instead of the minutes SciPy needs for the whole volume.  At a global
+edge the sub-slab edge IS the volume edge, so index-mapping boundary modes are evaluated exactly as unsplit.
+
+Test infrastructure: used by tests/test_gpu_baseline_full.py and scripts/bench_configs.py (`parity` field), never by
+the package.  Inputs follow SURVEY.md 8(d): N(0,1) float32 seed 0 (H, B, D), uint8 uniform seed 1 (C), the fixed
+affine M = diag(1.02, 1, 1) . R_x(7 deg) about the centre plus (0.5, -1.25, 2.0) (D, D'); tolerances BASELINE.md
+section 2: 1e-6 max-norm relative (filters), bit-exact (integer morphology), 2e-6 . max(1, max|ref|) (order-1
+interpolation with float32 weights)."""
+import numpy as np
+
+N_H = 512
+N_C = 1024
+E_SLAB = (264, 2048, 2048)
+
+
+def volume_f32(shape, seed=0):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+def volume_u8(shape, seed=1):
+    return np.random.default_rng(seed).integers(0, 256, size=shape, dtype=np.uint8)
+
+
+def slab_volume_f32(shape, seed=2, block=66):
+    """E-sized float32 slab without 10 s of host RNG: one random block of planes repeated along z with a per-plane
+    offset and scale (so no two planes agree and a z shift of the result would be seen)."""
+    nz = shape[0]
+    base = np.random.default_rng(seed).standard_normal((block,) + tuple(shape[1:]), dtype=np.float32)
+    x = np.empty(shape, np.float32)
+    for z0 in range(0, nz, block):
+        n = min(block, nz - z0)
+        k = z0 // block
+        np.multiply(base[:n], np.float32(1.0 + 0.125 * k), out=x[z0:z0 + n])
+        x[z0:z0 + n] += (np.float32(0.01) * np.arange(z0, z0 + n, dtype=np.float32))[:, None, None]
+    return x
+
+
+def affine_case(n=N_H):
+    """(M, offset) of SURVEY.md 8(d)."""
+    ang = np.deg2rad(7.0)
+    R = np.array([[1, 0, 0], [0, np.cos(ang), -np.sin(ang)], [0, np.sin(ang), np.cos(ang)]])
+    M = np.diag([1.02, 1.0, 1.0]) @ R
+    ctr = (n - 1) / 2.0
+    off = ctr - M @ np.array([ctr] * 3) + np.array([0.5, -1.25, 2.0])
+    return M, off
+
+
+def affine_coords_f32(n=N_H):
+    """The same warp materialised as float32 coordinates (3, n, n, n) = 1.5 GiB, plane by plane (np.indices of the
+    whole grid would need another 1.5 GiB)."""
+    M, off = affine_case(n)
+    Mf, of = M.astype(np.float32), off.astype(np.float32)
+    coords = np.empty((3, n, n, n), np.float32)
+    yy, xx = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), indexing="ij")
+    for z in range(n):
+        zf = np.float32(z)
+        for a in range(3):
+            # same association as (M @ idx + off): ((m0 z + m1 y) + m2 x) + off in float32
+            coords[a, z] = (Mf[a, 0] * zf + Mf[a, 1] * yy + Mf[a, 2] * xx) + of[a]
+    return coords
+
+
+def z_slabs(nz, width=6, interior=3, extra=()):
+    """[(a, b)]: the first and last `width` planes, `interior` slabs spread over the inside, plus slabs centred on
+    the planes in `extra` (e.g. a 2 GiB byte-offset crossing)."""
+    out = [(0, min(width, nz)), (max(nz - width, 0), nz)]
+    for k in range(interior):
+        c = (k + 1) * nz // (interior + 1) + (7 * k) % 5            # not aligned with any tile / chunk size
+        out.append((max(c - width // 2, 0), min(c + width // 2, nz)))
+    for c in extra:
+        if 0 <= c < nz:
+            out.append((max(c - width // 2, 0), min(c + width // 2, nz)))
+    return sorted(set(out))
+
+
+def ref_on_slab(x, a, b, lo, hi, fn):
+    """fn(sub-slab incl. halo)[planes a..b) -- valid for index-mapping boundary modes (see module docstring)."""
+    nz = x.shape[0]
+    e0, e1 = max(a - lo, 0), min(b + hi, nz)
+    return fn(x[e0:e1])[a - e0:a - e0 + (b - a)]
+
+
+def maxnorm_rel(got, ref):
+    e = np.asarray(ref, dtype=np.float64)
+    d = float(np.abs(np.asarray(got, dtype=np.float64) - e).max())
+    m = float(np.abs(e).max())
+    return d / m if m > 0 else d
+
+
+def check_filter_slabs(x, out_dev, lo, hi, fn, slabs, exact=False):
+    """Worst max-norm relative error (or number of differing voxels when `exact`) of the device result `out_dev`
+    against fn() on the given z sub-slabs of the host volume `x`."""
+    worst = 0
+    for a, b in slabs:
+        ref = ref_on_slab(x, a, b, lo, hi, fn)
+        got = out_dev[a:b].get()
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        if exact:
+            worst += int(np.count_nonzero(got != ref))
+        else:
+            worst = max(worst, maxnorm_rel(got, ref))
+    return worst
+
+
+def check_map_coordinates_slabs(x, coords, out_dev, slabs):
+    """max |got - ref| / max(1, max|ref|) of an order-1 `map_coordinates(mode="constant")` result on z sub-slabs of
+    the OUTPUT (the whole input is gathered from)."""
+    import scipy.ndimage as sndi
+    worst = 0.0
+    for a, b in slabs:
+        ref = sndi.map_coordinates(x, coords[:, a:b], output=np.float64, order=1, mode="constant", cval=0.0,
+                                   prefilter=False)
+        got = out_dev[a:b].get().astype(np.float64)
+        worst = max(worst, float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max())))
+    return worst
+
+
+def check_affine_slabs(x, M, off, out_dev, slabs):
+    """The same for `affine_transform(order=1, mode="constant")`: output planes a..b of the full call are the
+    transform with offset + M[:, 0] * a and output_shape (b - a, ny, nx)."""
+    import scipy.ndimage as sndi
+    worst = 0.0
+    for a, b in slabs:
+        ref = sndi.affine_transform(x, M, off + M[:, 0] * a, output_shape=(b - a,) + x.shape[1:], output=np.float64,
+                                    order=1, mode="constant", cval=0.0, prefilter=False)
+        got = out_dev[a:b].get().astype(np.float64)
+        worst = max(worst, float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max())))
+    return worst

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "mi355img.h")).read()
+def declared_symbols(header="mi355img.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", text)))
 
@@ -22,6 +22,23 @@ def test_header_symbols_are_exported():
     assert len(names) >= 40
     for n in names:
         assert hasattr(lib, n), "libmi355img.so does not export " + n
+
+
+def test_debug_header_lists_every_debug_export():
+    """include/mi355img_debug.h declares exactly the mi_debug_* entry points the library exports (the test / tuning
+    hooks are documented, not hidden)."""
+    import subprocess
+    from cupyimg_amd import _lib
+    lib = _lib.load()
+    declared = [n for n in declared_symbols("mi355img_debug.h") if n.startswith("mi_debug_")]
+    assert len(declared) >= 30
+    for n in declared:
+        assert hasattr(lib, n), "libmi355img.so does not export " + n
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.library_path()], stdout=subprocess.PIPE, text=True).stdout
+    exported = sorted(set(re.findall(r"\b(mi_debug_[a-z0-9_]+)\b", out)))
+    assert exported == sorted(declared)
+    # and none of them leaks into the drop-in boundary
+    assert not [n for n in declared_symbols() if n.startswith("mi_debug_")]
 
 
 def test_ctypes_table_matches_header():

@@ -1,0 +1,88 @@
+"""Every single-GPU BASELINE.json config at FULL size through the C-ABI, checked against scipy.ndimage on z sub-slabs
+(first / last planes, >= 3 interior slabs, byte-offset crossings) -- tests/helpers/fullsize.py.  Grid geometry
+(1024-wide tiles, 1.5 GiB coordinate arrays, 32-bit offset guards, > 4 GiB slabs) is only exercised at these sizes."""
+import numpy as np
+import pytest
+import scipy.ndimage as sndi
+
+from helpers import fullsize as fs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ndi(gpu):
+    from cupyimg_amd.scipy import ndimage
+    return ndimage
+
+
+@pytest.fixture(scope="module")
+def vol512(gpu):
+    x = fs.volume_f32((fs.N_H,) * 3, seed=0)
+    xd = gpu.asarray(x)
+    yield x, xd
+    del xd
+    gpu.free_all_blocks()
+
+
+def test_H_uniform5_512(gpu, ndi, vol512):
+    x, xd = vol512
+    out = ndi.uniform_filter(xd, size=5)
+    err = fs.check_filter_slabs(x, out, 2, 2, lambda s: sndi.uniform_filter(s.astype(np.float64), size=5),
+                                fs.z_slabs(fs.N_H, extra=(64, 128, 448)))
+    assert err <= 1e-6, err
+
+
+def test_B_gaussian_sigma2_512(gpu, ndi, vol512):
+    x, xd = vol512
+    out = ndi.gaussian_filter(xd, sigma=2)
+    # 17 taps per axis: halo 8; chunk seams of the long kernel lie at multiples of 128 planes
+    err = fs.check_filter_slabs(x, out, 8, 8, lambda s: sndi.gaussian_filter(s.astype(np.float64), sigma=2),
+                                fs.z_slabs(fs.N_H, extra=(128, 256, 384)))
+    assert err <= 1e-6, err
+
+
+def test_D_map_coordinates_order1_512(gpu, ndi, vol512):
+    x, xd = vol512
+    coords = fs.affine_coords_f32(fs.N_H)
+    cd = gpu.asarray(coords)
+    out = ndi.map_coordinates(xd, cd, order=1, mode="constant")
+    assert out.dtype == np.float32 and out.shape == x.shape
+    err = fs.check_map_coordinates_slabs(x, coords, out, fs.z_slabs(fs.N_H, width=4))
+    del cd
+    assert err <= 2e-6, err
+
+
+def test_Dprime_affine_transform_order1_512(gpu, ndi, vol512):
+    x, xd = vol512
+    M, off = fs.affine_case(fs.N_H)
+    out = ndi.affine_transform(xd, M, off, order=1, mode="constant")
+    err = fs.check_affine_slabs(x, M, off, out, fs.z_slabs(fs.N_H, width=4))
+    assert err <= 2e-6, err
+
+
+def test_C_grey_erosion7_1024_u8(gpu, ndi):
+    gpu.free_all_blocks()
+    u = fs.volume_u8((fs.N_C,) * 3, seed=1)
+    ud = gpu.asarray(u)
+    out = ndi.grey_erosion(ud, size=7)
+    assert out.dtype == np.uint8
+    bad = fs.check_filter_slabs(u, out, 3, 3, lambda s: sndi.grey_erosion(s, size=7),
+                                fs.z_slabs(fs.N_C, extra=(256, 512, 768)), exact=True)
+    del ud, out
+    gpu.free_all_blocks()
+    assert bad == 0, bad
+
+
+def test_E_slab_uniform9_264x2048x2048(gpu, ndi):
+    """One rank's slab of config E (4.3 GiB per array): planes 128 and 256 start at 2 GiB / 4 GiB byte offsets."""
+    gpu.free_all_blocks()
+    x = fs.slab_volume_f32(fs.E_SLAB)
+    xd = gpu.asarray(x)
+    out = gpu.empty(x.shape, np.float32)
+    ndi.uniform_filter(xd, size=9, output=out)
+    err = fs.check_filter_slabs(x, out, 4, 4, lambda s: sndi.uniform_filter(s.astype(np.float64), size=9),
+                                fs.z_slabs(fs.E_SLAB[0], width=4, extra=(128, 256)))
+    del xd, out
+    gpu.free_all_blocks()
+    assert err <= 1e-6, err

@@ -282,6 +282,66 @@ def test_structuring_element_host_hint(gpu, ndi):
     assert v._hc is None
 
 
+def test_host_hint_dropped_by_every_write_path(gpu, ndi):
+    """Writes through views, `set`, copies into the array and use as `output=` all invalidate the remembered host
+    copy of a structuring element (a stale hint made morphology silently use the old mask)."""
+    from cupyimg_amd import core
+    from cupyimg_amd.skimage import morphology as skm
+    writes = [
+        lambda d: d[1].__setitem__(2, 0),                       # write through an integer-indexed view
+        lambda d: d[1:].__setitem__(Ellipsis, 0),               # ... a sliced view
+        lambda d: d.reshape(-1).__setitem__(3, 0),              # ... a reshaped view
+        lambda d: d.T.__setitem__(Ellipsis, gpu.asarray(np.zeros(d.shape[::-1], d.dtype))),
+        lambda d: d.set(np.zeros(d.shape, d.dtype)),
+        lambda d: d[2:3].fill(0),
+        lambda d: ndi.grey_erosion(gpu.asarray(np.ones(d.shape, d.dtype)), size=3, output=d),
+    ]
+    for w in writes:
+        d = skm.disk(2)
+        assert d._hc is not None
+        w(d)
+        assert d._hc is None
+        assert np.array_equal(core.host_copy(d), d.get())
+
+
+def test_image_view_cache_is_not_a_reference_cycle(gpu, ndi):
+    """ndarray._as3() caches the one-plane-volume view; the device buffer must be released by reference counting
+    (the cached view used to point back at the array: freed only when the cyclic collector ran)."""
+    import gc
+    import weakref
+    gc.collect()
+    gc.disable()
+    try:
+        a = gpu.asarray(np.random.default_rng(1).standard_normal((64, 64)).astype(np.float32))
+        ndi.uniform_filter(a, 3)                                  # takes the image path -> a._as3()
+        assert a._v3 is not None
+        mem = weakref.ref(a._mem)
+        del a
+        assert mem() is None
+    finally:
+        gc.enable()
+
+
+def test_median_fast_path_needs_the_full_inplane_window(gpu, ndi):
+    """Footprints with nine ones and trailing shape (3, 3) that are NOT the in-plane 3 x 3 window must not take the
+    streaming 3 x 3 median (which never sees the footprint)."""
+    rng = np.random.default_rng(82)
+    x = rng.standard_normal((9, 12, 16)).astype(np.float32)
+    xd = gpu.asarray(x)
+    fps = []
+    f = np.zeros((3, 3, 3), bool); f[:, 1, :] = True; fps.append(f)          # a z-x plane
+    f = np.zeros((3, 3, 3), bool); f[:, :, 1] = True; fps.append(f)          # a z-y plane
+    f = np.zeros((5, 3, 3), bool); f.reshape(-1)[[0, 5, 9, 13, 20, 22, 31, 40, 44]] = True; fps.append(f)
+    f = np.zeros((1, 3, 3), bool); f[...] = True; fps.append(f)              # the one that qualifies
+    for f in fps:
+        assert f.sum() == 9
+        for fn, sfn, kw in [(ndi.median_filter, sndi.median_filter, {}),
+                            (ndi.rank_filter, sndi.rank_filter, {"rank": 4}),
+                            (ndi.percentile_filter, sndi.percentile_filter, {"percentile": 50})]:
+            got = fn(xd, footprint=f, **kw).get()
+            assert np.array_equal(got, sfn(x, footprint=f, **kw)), (f.shape, fn.__name__)
+
+
 @pytest.mark.parametrize("shape", [(20, 30, 64), (9, 17, 1040), (33, 40, 2048 + 32), (3, 3, 32), (1, 5, 48)])
 def test_volume_footprints_of_centred_runs(gpu, ndi, shape):
     """6- / 18- / 26-connected structures (and other 3 x 3 x 3 footprints of centred runs) on uint8 volumes: grey
