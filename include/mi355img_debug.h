@@ -42,6 +42,9 @@ int mi_debug_last_kernel(char *buf, size_t n);
 /* counter-based synthetic float32 data (csrc/synth.hip; CPU twin: oracle/synth.py): value i = f(first_index + i, seed) */
 int mi_debug_fill_synthetic_f32(float *out, int64_t n, uint64_t first_index, uint64_t seed, mi_stream stream);
 
+/* pool test hook (csrc/runtime.hip): allocate `nbytes` for work on `stream`, report the block, free it again */
+int mi_debug_pool_probe(size_t nbytes, mi_stream stream, void **block);
+
 /* ---- other kernel families */
 int mi_debug_set_binary_tiled(int on);        /* csrc/binary.hip: 0 = generic binary erosion kernel */
 int mi_debug_set_stencil(int on);             /* csrc/correlate_nd.hip: 0 = generic n-D correlate */
