@@ -239,6 +239,184 @@ __device__ __forceinline__ T finish(const Taps<T> &t, T cval)
     return t.outside ? cval : r;
 }
 
+
+// ---------------------------------------------------------------------------
+// r3: constant mode, order 1, 3-D float32 -- the BASELINE D / D' kernels.
+//
+// rocprofv3 (profiles/r3_affine_counters.txt) shows both kernels bound by the texture addresser, i.e. by the NUMBER of
+// vector-memory instructions a wave issues (a wave instruction occupies the TA for >= 16 cycles whatever its width),
+// with the VALU second (affine: 28 float64 operations per voxel).  What these kernels change against
+// map_coords3d_fast / affine3d_fast above, results unchanged:
+//   * stores (and the coordinate loads of map_coordinates) are 16 bytes per lane: a wave owns four output rows of 64
+//     voxels; the interpolated values cross the wave through a 1 KiB LDS tile (written [row][lane], read back as
+//     float4 by lane -> (row = lane / 16, 4 x (lane % 16))), one buffer_store_dwordx4 instead of four dword stores,
+//     three dwordx4 coordinate loads instead of twelve dword loads: 20 instead of 32 vector-memory instructions per
+//     four voxels for map_coordinates, 17 instead of 20 for affine_transform;
+//   * affine: the row prefix (m0 z + m1 y) of the coordinate -- the same for the 64 lanes of a wave -- is computed once
+//     per workgroup (48 lanes, LDS table) in the oracle's summation order, so a voxel adds two terms per axis; the
+//     integer / fraction split is v_cvt_i32_f64 + v_fract_f64 (exact for the non-negative coordinates that can be
+//     inside; negative ones are outside by their sign bit): 15 instead of 28 float64 operations per voxel.
+// ---------------------------------------------------------------------------
+typedef float f32x4n __attribute__((ext_vector_type(4)));      // what the non-temporal builtins take
+struct C1Split { int i0; float w1; bool frz; bool neg; };
+
+// c -> (trunc(c), fraction as float, fraction == 0 in double, c < 0).  For c >= 0: trunc = floor and v_fract_f64 =
+// c - floor(c) exactly; c < 0 (incl. (-1, 0), where trunc gives 0) is reported by `neg` and never read.
+__device__ __forceinline__ C1Split c1_split(double c)
+{
+    C1Split r;
+    r.neg = c < 0.0;
+    r.i0 = __double2int_rz(c);
+    const double fr = __builtin_amdgcn_fract(c);
+    r.w1 = (float)fr;
+    r.frz = fr == 0.0;
+    return r;
+}
+__device__ __forceinline__ C1Split c1_split(float c)
+{
+    C1Split r;
+    const float f = floorf(c);
+    r.neg = c < 0.f;
+    r.i0 = (int)f;
+    r.w1 = c - f;                      // exact in float
+    r.frz = r.w1 == 0.f;
+    return r;
+}
+
+// the eight taps of one voxel as four 8-byte gathers (same addressing as taps<..., FASTC = true, 1>)
+__device__ __forceinline__ void c1_gather(const __amdgpu_buffer_rsrc_t in, const FastInterpParams &p, const C1Split &sz,
+                                          const C1Split &sy, const C1Split &sx, Taps<float> &t)
+{
+    t.wz1 = sz.w1; t.wy1 = sy.w1; t.wx1 = sx.w1;
+    const bool in_z = !sz.neg & (((unsigned)sz.i0 < (unsigned)(p.nz - 1)) | ((sz.i0 == p.nz - 1) & sz.frz));
+    const bool in_y = !sy.neg & (((unsigned)sy.i0 < (unsigned)(p.ny - 1)) | ((sy.i0 == p.ny - 1) & sy.frz));
+    const bool in_x = !sx.neg & (((unsigned)sx.i0 < (unsigned)(p.nx - 1)) | ((sx.i0 == p.nx - 1) & sx.frz));
+    t.outside = !(in_z & in_y & in_x);
+    t.oobmask = 0;
+    // an upper tap is skipped when the FLOAT weight is zero (a double fraction below the float range blends to the
+    // same value either way); at the last sample the double test above has already decided inside / outside
+    const bool zz = t.wz1 == 0.f, yz = t.wy1 == 0.f, xz = t.wx1 == 0.f;
+    const bool lastcol = sx.i0 >= p.nx - 1;
+    const int xb = sx.i0 - (lastcol ? 1 : 0);
+    const unsigned base = t.outside ? 0u : (unsigned)((sz.i0 * p.ny + sy.i0) * p.nx + xb) * 4u;
+    const unsigned stz = (t.outside | zz | (sz.i0 >= p.nz - 1)) ? 0u : (unsigned)(p.ny * p.nx) * 4u;
+    const unsigned sty = (t.outside | yz | (sy.i0 >= p.ny - 1)) ? 0u : (unsigned)p.nx * 4u;
+    (void)xz;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        float a, b;
+        load_pair(in, base + (m >> 1) * stz + (m & 1) * sty, a, b);
+        t.v[2 * m] = lastcol ? b : a;
+        t.v[2 * m + 1] = b;
+    }
+}
+
+constexpr int kC1Rows = 16;      // output rows per workgroup: 4 waves x 4 rows (rows of a wave are 4 apart)
+
+// values r[k] (row k of this wave, voxel x = x0w + lane) -> one 16-byte store per lane through the wave's LDS tile
+__device__ __forceinline__ void c1_store_rows(float *__restrict__ out, const FastInterpParams &p, float *tile, int lane, int z,
+                                              int ybase, int ty, int x0w, const float (&r)[4], bool full)
+{
+    if (full) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) tile[k * 64 + lane] = r[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int i = lane >> 4, q = lane & 15;
+        const f32x4n v = *reinterpret_cast<const f32x4n *>(tile + i * 64 + 4 * q);
+        const int y = ybase + 4 * i + ty;
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)z * p.oy + y) * p.ox + x0w + 4 * q));
+    } else {
+        const int x = x0w + lane;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = ybase + 4 * k + ty;
+            if (x < p.ox && y < p.oy) __builtin_nontemporal_store(r[k], out + ((size_t)z * p.oy + y) * p.ox + x);
+        }
+    }
+}
+
+template <int VAR>
+__global__ void __launch_bounds__(256)
+affine3d_c1_kernel(const float *__restrict__ in, float *__restrict__ out, const FastInterpParams p)
+{
+    __shared__ double ptab[kC1Rows][3];
+    __shared__ __attribute__((aligned(16))) float tiles[4][4 * 64];
+    const int lane = threadIdx.x, ty = threadIdx.y;
+    const int z = blockIdx.z, ybase = blockIdx.y * kC1Rows, x0w = blockIdx.x * 64;
+    const int tid = ty * 64 + lane;
+    if (tid < kC1Rows * 3) {
+        // row prefix in the oracle's order: (m0 * z) + m1 * y   (rr = 4 k + ty  <->  y = ybase + rr)
+        const int rr = tid / 3, a = tid - 3 * rr;
+        ptab[rr][a] = p.m[4 * a] * (double)z + p.m[4 * a + 1] * (double)(ybase + rr);
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
+    const double dx = (double)(x0w + lane);
+    const double xz_ = p.m[2] * dx, xy_ = p.m[6] * dx, xx_ = p.m[10] * dx;
+    Taps<float> t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int rr = 4 * k + ty;
+        const double cz = (ptab[rr][0] + xz_) + p.m[3];
+        const double cy = (ptab[rr][1] + xy_) + p.m[7];
+        const double cx = (ptab[rr][2] + xx_) + p.m[11];
+        c1_gather(rin, p, c1_split(cz), c1_split(cy), c1_split(cx), t[k]);
+    }
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = finish<float>(t[k], (float)p.cval);
+    const bool full = (VAR & 1) && x0w + 64 <= p.ox && ybase + kC1Rows <= p.oy;       // block-uniform
+    c1_store_rows(out, p, tiles[ty], lane, z, ybase, ty, x0w, r, full);
+}
+
+template <int VAR>
+__global__ void __launch_bounds__(256)
+map_coords3d_c1_kernel(const float *__restrict__ in, const float *__restrict__ coords, float *__restrict__ out,
+                       const FastInterpParams p)
+{
+    __shared__ __attribute__((aligned(16))) float tiles[4][3 * 4 * 64];
+    const int lane = threadIdx.x, ty = threadIdx.y;
+    const int z = blockIdx.z, ybase = blockIdx.y * kC1Rows, x0w = blockIdx.x * 64;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
+    const size_t nout = (size_t)p.oz * p.oy * p.ox;
+    const bool full = x0w + 64 <= p.ox && ybase + kC1Rows <= p.oy;                      // block-uniform
+    float *tile = tiles[ty];
+    float c[4][3];
+    if ((VAR & 1) && full) {
+        // coordinates: one 16-byte load per lane, row and axis (lane -> row lane / 16, x = 4 (lane % 16)), handed to
+        // the lane that owns the voxel through the wave's LDS tile
+        const int i = lane >> 4, q = lane & 15;
+        const size_t o = ((size_t)z * p.oy + (ybase + 4 * i + ty)) * p.ox + x0w + 4 * q;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n *>(coords + a * nout + o));
+            *reinterpret_cast<f32x4n *>(tile + (a * 4 + i) * 64 + 4 * q) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) c[k][a] = tile[(a * 4 + k) * 64 + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is reused for the results below
+    } else {
+        const int x = min(x0w + lane, p.ox - 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = min(ybase + 4 * k + ty, p.oy - 1);
+            const size_t o = ((size_t)z * p.oy + y) * p.ox + x;
+#pragma unroll
+            for (int a = 0; a < 3; a++) c[k][a] = __builtin_nontemporal_load(coords + a * nout + o);
+        }
+    }
+    Taps<float> t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) c1_gather(rin, p, c1_split(c[k][0]), c1_split(c[k][1]), c1_split(c[k][2]), t[k]);
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = finish<float>(t[k], (float)p.cval);
+    c1_store_rows(out, p, tile, lane, z, ybase, ty, x0w, r, (VAR & 1) && full);
+}
+
 constexpr int kNV = 4;   // voxels per thread (rows 4 apart), all gathers issued before any is used
 
 // block = (64, 4): 64 lanes along x (one voxel each, so every gather instruction of a
@@ -309,6 +487,8 @@ affine3d_fast(const T *__restrict__ in, T *__restrict__ out, const FastInterpPar
         if (ok[k]) __builtin_nontemporal_store(finish<T>(t[k], (T)p.cval), out + o[k]);
 }
 
+Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads
+
 static bool fast_ok(const mi_array *in, const mi_array *out, int order)
 {
     if (in->ndim != out->ndim || (in->ndim != 3 && in->ndim != 2) || (in->dtype != MI_F32 && in->dtype != MI_F64) ||
@@ -342,6 +522,14 @@ int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_ar
     const dim3 block(64, 4, 1);
     const dim3 grid((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 4 * kNV - 1) / (4 * kNV)), (unsigned)p.oz);
     const bool fastc = mode == MI_MODE_CONSTANT && order == 1;
+    const int var = g_interp_c1;
+    if (fastc && var && !p.two_d && in->dtype == MI_F32 && coords->dtype == MI_F32 && (p.ox & 3) == 0 &&
+        ((uintptr_t)coords->data & 15) == 0) {
+        if (var == 1) hipLaunchKernelGGL((map_coords3d_c1_kernel<1>), grid, block, 0, s, (const float *)in->data, (const float *)coords->data, (float *)out->data, p);
+        else hipLaunchKernelGGL((map_coords3d_c1_kernel<0>), grid, block, 0, s, (const float *)in->data, (const float *)coords->data, (float *)out->data, p);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
 #define MI_MAP(CT, FC, ORD)                                                                                        \
     do {                                                                                                           \
         if (in->dtype == MI_F32)                                                                                   \
@@ -380,6 +568,13 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
     }
     const dim3 block(64, 4, 1);
     const dim3 grid((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 4 * kNV - 1) / (4 * kNV)), (unsigned)p.oz);
+    const int var = g_interp_c1;
+    if (mode == MI_MODE_CONSTANT && order == 1 && var && !p.two_d && in->dtype == MI_F32 && (p.ox & 3) == 0) {
+        if (var == 1) hipLaunchKernelGGL((affine3d_c1_kernel<1>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p);
+        else hipLaunchKernelGGL((affine3d_c1_kernel<0>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
 #define MI_AFF(FC, ORD)                                                                                                    \
     do {                                                                                                                   \
         if (in->dtype == MI_F32)                                                                                           \
@@ -396,3 +591,5 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
 }
 
 }  // namespace mi
+
+extern "C" int mi_debug_set_interp_c1(int k) { mi::g_interp_c1 = k; return MI_OK; }

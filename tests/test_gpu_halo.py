@@ -154,9 +154,10 @@ def test_native_slab_step_matches_plain_step(gpu, ndi, self_comm, nz):
             assert maxnorm_rel(got, orc.uniform_filter(x, 13, mode=["wrap", "mirror", "mirror"])) <= 1e-6
 
 
-def test_slab_schedule_is_measured_on_the_first_steps(gpu, ndi, self_comm):
-    """overlap=None: steps 0-3 of a filter try the plain and the overlapped schedule (one warm, one timed step each),
-    from the fifth step on the faster one runs; every step gives the same (bit-identical) planes."""
+def test_slab_schedule_is_measured_in_the_first_call(gpu, ndi, self_comm):
+    """overlap=None: the first call of a filter (`warm`) probes the plain and the overlapped schedule (one warm step
+    and three timed steps each, medians decide); later steps run the chosen one with no host synchronisation; every
+    step gives the same (bit-identical) planes."""
     from cupyimg_amd.distributed import SlabFilter, halo_widths
     rng = np.random.default_rng(21)
     nz = 40
@@ -165,12 +166,37 @@ def test_slab_schedule_is_measured_on_the_first_steps(gpu, ndi, self_comm):
     sf = SlabFilter(_SelfLoopPlan(nz, lo, hi), x.shape[1:], np.float32, self_comm)
     sf.local_in[...] = gpu.asarray(x)
     want = sf.uniform_filter(5, mode="nearest", overlap=False).get()
-    outs = [sf.uniform_filter(5, mode="nearest").get() for _ in range(7)]
-    assert all(np.array_equal(o, want) for o in outs)
+    sf.warm(lambda: sf.uniform_filter(5, mode="nearest"))
     (st,) = sf._tuning.values()
-    assert st["n"] == 4 and st["choice"] in (0, 1) and all(t is not None and t > 0 for t in st["t"])
+    assert st["choice"] in (0, 1) and st["overlap_supported"]
+    assert all(len(t) == 3 and min(t) > 0 for t in st["t"]) and len(st["median_ms"]) == 2
+    assert sf.schedule_of("uniform")["choice"] == st["choice"]
+    outs = [sf.uniform_filter(5, mode="nearest").get() for _ in range(4)]
+    assert all(np.array_equal(o, want) for o in outs)
     sf.autotune = False
     assert np.array_equal(sf.uniform_filter(5, mode="nearest").get(), want)
+
+
+def test_slab_schedule_when_the_overlapped_form_is_refused(gpu, ndi, self_comm):
+    """Kernels the plane-range launches do not take (19 .. 33 taps): the tuning pins the plain schedule instead of
+    alternating between a refused probe and the fallback for ever (round-2 advisor finding), and every step still
+    performs exactly one exchange."""
+    from cupyimg_amd.distributed import SlabFilter, halo_widths
+    rng = np.random.default_rng(22)
+    nz = 48
+    x = rng.standard_normal((nz, 40, 256)).astype(np.float32)
+    lo, hi = halo_widths(21)
+    sf = SlabFilter(_SelfLoopPlan(nz, lo, hi), x.shape[1:], np.float32, self_comm)
+    sf.local_in[...] = gpu.asarray(x)
+    ref = orc.uniform_filter(x, 21, mode=["wrap", "reflect", "reflect"])
+    for _ in range(3):
+        got = sf.uniform_filter(21).get()
+        assert maxnorm_rel(got, ref) <= 1e-6
+    st = sf.schedule_of("uniform")
+    if st is not None:                       # native plain schedule taken: the overlapped probe was refused once
+        assert st["choice"] == 0 and not st["overlap_supported"]
+    else:                                    # not even the plain native step: remembered, generic step from then on
+        assert len(sf._native_refused) == 1
 
 
 def test_slab_step_refuses_kernels_wider_than_the_halo(gpu, ndi, self_comm):

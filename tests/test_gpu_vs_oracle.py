@@ -1150,3 +1150,87 @@ def test_fused_float32_minmax(gpu, ndi):
                 lib.mi_debug_set_minmax_f32_fused(1)
             assert np.array_equal(np.isnan(fused), np.isnan(streamed)), (shape, ref.__name__)
             assert np.array_equal(fused[clean], ref(np.where(np.isnan(w), np.float32(0), w), size=7, mode="mirror")[clean]), (shape, ref.__name__)
+
+
+# ------------------------------------------------------------------ r3: order-1 constant-mode kernels (wide stores / loads)
+def _c1_cases():
+    rng = np.random.default_rng(151)
+    ang = np.deg2rad(11.0)
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    return [
+        # (input shape, matrix, offset, output shape): full 64 x 16 blocks, partial blocks, up / down scaling
+        ((20, 37, 136), np.eye(3), np.zeros(3), None),                               # identity: every coordinate integral
+        ((20, 37, 136), np.eye(3), np.array([1.0, -2.0, 3.0]), None),                # integer shift: exact boundary hits
+        ((24, 40, 128), np.diag([1.02, 1.0, 1.0]) @ R, np.array([0.5, -1.25, 2.0]), None),
+        ((24, 40, 128), np.diag([0.5, 0.75, 0.9]), np.array([0.25, 0.5, 0.125]), (30, 48, 192)),
+        ((17, 33, 72), np.diag([(17 - 1) / (21 - 1.0), (33 - 1) / (47 - 1.0), (72 - 1) / (139 - 1.0)]), np.zeros(3), (21, 47, 140)),
+        ((16, 16, 64), R @ np.diag([1.3, 0.8, 1.1]), rng.standard_normal(3) * 3, (18, 35, 68)),
+    ]
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_order1_constant_kernels_r3(gpu, ndi, case):
+    """affine_transform / map_coordinates, order 1, mode constant, float32 volumes: the r3 kernels (16-byte stores and
+    coordinate loads through an LDS tile, hoisted row prefix, v_fract_f64 split) against the oracle and, voxel for
+    voxel, against the round-2 kernels they replace."""
+    from cupyimg_amd import _lib
+    lib = _lib.load()
+    shape, M, off, oshape = _c1_cases()[case]
+    rng = np.random.default_rng(152 + case)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xd = gpu.asarray(x)
+    oshape = shape if oshape is None else oshape
+    ref = orc.affine_transform(x, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75)
+    outs = {}
+    for var in (1, 2, 0):
+        lib.mi_debug_set_interp_c1(var)
+        try:
+            outs[var] = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75).get()
+        finally:
+            lib.mi_debug_set_interp_c1(1)
+    assert np.allclose(outs[1], ref, rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max())), np.abs(outs[1] - ref).max()
+    assert np.array_equal(outs[1], outs[2])
+    # the round-2 kernel tests "inside" on the float32 weight; a double fraction < 2^-149 at the last sample is the
+    # only way the two can differ, and none of these cases has one
+    assert np.array_equal(outs[1], outs[0])
+    # the same warp as explicit float32 coordinates
+    idx = np.indices(oshape).reshape(3, -1).astype(np.float64)
+    coords = (M @ idx + off[:, None]).reshape((3,) + tuple(oshape)).astype(np.float32)
+    refm = orc.map_coordinates(x, coords, order=1, mode="constant", cval=-0.75)
+    cd = gpu.asarray(coords)
+    outm = {}
+    for var in (1, 2, 0):
+        lib.mi_debug_set_interp_c1(var)
+        try:
+            outm[var] = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
+        finally:
+            lib.mi_debug_set_interp_c1(1)
+    assert np.allclose(outm[1], refm, rtol=0, atol=2e-6 * max(1.0, np.abs(refm).max()))
+    assert np.array_equal(outm[1], outm[2]) and np.array_equal(outm[1], outm[0])
+
+
+def test_order1_constant_kernels_r3_nonfinite_and_edges(gpu, ndi):
+    """inf / nan samples stay out of voxels whose skipped upper tap would touch them; coordinates exactly on the last
+    sample are inside, one ulp beyond is outside (cval)."""
+    import scipy.ndimage as sndi
+    x = np.random.default_rng(160).standard_normal((8, 16, 64)).astype(np.float32)
+    x[3, 5, 20] = np.inf
+    x[4, 7, 30] = np.nan
+    x[7, 15, 63] = -np.inf
+    xd = gpu.asarray(x)
+    for off in ([0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.0, 0.25, 0.0], [0.0, 0.0, 0.75], [1.0, 1.0, 1.0]):
+        ref = sndi.affine_transform(x.astype(np.float64), np.eye(3), off, order=1, mode="constant", cval=2.0)
+        got = ndi.affine_transform(xd, np.eye(3), off, order=1, mode="constant", cval=2.0).get()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), off
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isposinf(got), np.isposinf(ref)) and np.array_equal(np.isneginf(got), np.isneginf(ref)), off
+        assert np.allclose(got[ok], ref[ok], rtol=0, atol=2e-6 * np.abs(ref[ok]).max()), off
+    # coordinates straddling the last sample of every axis
+    c = np.zeros((3, 4, 16, 64), np.float32)
+    c[0] = 7.0; c[1] = 15.0; c[2] = 63.0
+    c[0, 1] = np.nextafter(np.float32(7.0), np.float32(8.0))
+    c[1, 2] = np.nextafter(np.float32(15.0), np.float32(16.0))
+    c[2, 3] = np.nextafter(np.float32(63.0), np.float32(64.0))
+    ref = sndi.map_coordinates(x.astype(np.float64), c.astype(np.float64), order=1, mode="constant", cval=2.0)
+    got = ndi.map_coordinates(xd, gpu.asarray(c), order=1, mode="constant", cval=2.0).get()
+    assert np.array_equal(got, ref.astype(np.float32))
