@@ -1210,27 +1210,29 @@ def test_order1_constant_kernels_r3(gpu, ndi, case):
 
 
 def test_order1_constant_kernels_r3_nonfinite_and_edges(gpu, ndi):
-    """inf / nan samples stay out of voxels whose skipped upper tap would touch them; coordinates exactly on the last
+    """inf / nan samples stay out of voxels whose skipped upper tap would touch them (the reference skips the second
+    tap at integral coordinates, _interp_kernels.py:416; the oracle restates that); coordinates exactly on the last
     sample are inside, one ulp beyond is outside (cval)."""
     import scipy.ndimage as sndi
     x = np.random.default_rng(160).standard_normal((8, 16, 64)).astype(np.float32)
-    x[3, 5, 20] = np.inf
-    x[4, 7, 30] = np.nan
-    x[7, 15, 63] = -np.inf
-    xd = gpu.asarray(x)
+    xn = x.copy()
+    xn[3, 5, 20] = np.inf
+    xn[4, 7, 30] = np.nan
+    xn[7, 15, 63] = -np.inf
+    xd = gpu.asarray(xn)
     for off in ([0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.0, 0.25, 0.0], [0.0, 0.0, 0.75], [1.0, 1.0, 1.0]):
-        ref = sndi.affine_transform(x.astype(np.float64), np.eye(3), off, order=1, mode="constant", cval=2.0)
+        ref = orc.affine_transform(xn, np.eye(3), off, order=1, mode="constant", cval=2.0)
         got = ndi.affine_transform(xd, np.eye(3), off, order=1, mode="constant", cval=2.0).get()
         assert np.array_equal(np.isnan(got), np.isnan(ref)), off
-        ok = np.isfinite(ref)
         assert np.array_equal(np.isposinf(got), np.isposinf(ref)) and np.array_equal(np.isneginf(got), np.isneginf(ref)), off
+        ok = np.isfinite(ref)
         assert np.allclose(got[ok], ref[ok], rtol=0, atol=2e-6 * np.abs(ref[ok]).max()), off
-    # coordinates straddling the last sample of every axis
+    # coordinates straddling the last sample of every axis (finite data, SciPy as the judge)
     c = np.zeros((3, 4, 16, 64), np.float32)
     c[0] = 7.0; c[1] = 15.0; c[2] = 63.0
     c[0, 1] = np.nextafter(np.float32(7.0), np.float32(8.0))
     c[1, 2] = np.nextafter(np.float32(15.0), np.float32(16.0))
     c[2, 3] = np.nextafter(np.float32(63.0), np.float32(64.0))
     ref = sndi.map_coordinates(x.astype(np.float64), c.astype(np.float64), order=1, mode="constant", cval=2.0)
-    got = ndi.map_coordinates(xd, gpu.asarray(c), order=1, mode="constant", cval=2.0).get()
+    got = ndi.map_coordinates(gpu.asarray(x), gpu.asarray(c), order=1, mode="constant", cval=2.0).get()
     assert np.array_equal(got, ref.astype(np.float32))
