@@ -217,13 +217,15 @@ __device__ __forceinline__ void taps(const __amdgpu_buffer_rsrc_t in, const Fast
     }
 }
 
+// (1 - w) lo + w hi, the upper sample skipped when its weight is zero.  Not lo + w (hi - lo): with an infinite `lo`
+// that form gives inf - inf = NaN where SciPy's weighted sum gives the infinity.
 __device__ __forceinline__ float lerp_skip(float lo, float hi, float w)
 {
-    return w == 0.f ? lo : fmaf(w, hi - lo, lo);
+    return w == 0.f ? lo : fmaf(w, hi, (1.f - w) * lo);
 }
 __device__ __forceinline__ double lerp_skip(double lo, double hi, double w)
 {
-    return w == 0.0 ? lo : fma(w, hi - lo, lo);
+    return w == 0.0 ? lo : fma(w, hi, (1.0 - w) * lo);
 }
 
 template <typename T>
@@ -311,43 +313,60 @@ __device__ __forceinline__ void c1_gather(const __amdgpu_buffer_rsrc_t in, const
     }
 }
 
-constexpr int kC1Rows = 16;      // output rows per workgroup: 4 waves x 4 rows (rows of a wave are 4 apart)
+// Which four voxels a lane owns (k = 0..3) and which four "rows" a wave's tile holds:
+//   ZMAJ = false: one plane, rows ybase + 4 k + ty                 (workgroup = 64 x by 16 y by 1 z)
+//   ZMAJ = true : planes zbase + k, row ybase + ty                  (workgroup = 64 x by 4 y by 4 z)
+// The second form reads fewer distinct cache lines per workgroup when the warp is close to the identity along z
+// (output planes z and z + 1 share an input plane, rows y and y + 1 share an input row: 5 x 5 row segments per
+// workgroup instead of ~17 x 2), which is what the per-CU L1 (32 KiB for eight resident workgroups) needs.
+template <bool ZMAJ>
+struct C1Map {
+    int zb, yb;
+    __device__ __forceinline__ C1Map(const dim3 &b) : zb(ZMAJ ? (int)b.z * 4 : (int)b.z), yb(ZMAJ ? (int)b.y * 4 : (int)b.y * 16) {}
+    __device__ __forceinline__ int z(int k) const { return ZMAJ ? zb + k : zb; }
+    __device__ __forceinline__ int y(int k, int ty) const { return ZMAJ ? yb + ty : yb + 4 * k + ty; }
+    __device__ __forceinline__ bool full(const FastInterpParams &p, int x0w) const
+    {
+        return x0w + 64 <= p.ox && (ZMAJ ? (yb + 4 <= p.oy && zb + 4 <= p.oz) : (yb + 16 <= p.oy));
+    }
+};
 
-// values r[k] (row k of this wave, voxel x = x0w + lane) -> one 16-byte store per lane through the wave's LDS tile
-__device__ __forceinline__ void c1_store_rows(float *__restrict__ out, const FastInterpParams &p, float *tile, int lane, int z,
-                                              int ybase, int ty, int x0w, const float (&r)[4], bool full)
+// values r[k] (voxel k of this lane, x = x0w + lane) -> one 16-byte store per lane through the wave's LDS tile
+template <bool ZMAJ>
+__device__ __forceinline__ void c1_store_rows(float *__restrict__ out, const FastInterpParams &p, float *tile, int lane,
+                                              const C1Map<ZMAJ> &mp, int ty, int x0w, const float (&r)[4], bool wide)
 {
-    if (full) {
+    if (wide) {
 #pragma unroll
         for (int k = 0; k < 4; k++) tile[k * 64 + lane] = r[k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int i = lane >> 4, q = lane & 15;
         const f32x4n v = *reinterpret_cast<const f32x4n *>(tile + i * 64 + 4 * q);
-        const int y = ybase + 4 * i + ty;
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)z * p.oy + y) * p.ox + x0w + 4 * q));
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)mp.z(i) * p.oy + mp.y(i, ty)) * p.ox + x0w + 4 * q));
     } else {
         const int x = x0w + lane;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int y = ybase + 4 * k + ty;
-            if (x < p.ox && y < p.oy) __builtin_nontemporal_store(r[k], out + ((size_t)z * p.oy + y) * p.ox + x);
+            const int y = mp.y(k, ty), z = mp.z(k);
+            if (x < p.ox && y < p.oy && z < p.oz) __builtin_nontemporal_store(r[k], out + ((size_t)z * p.oy + y) * p.ox + x);
         }
     }
 }
 
-template <int VAR>
+template <bool WIDE, bool ZMAJ>
 __global__ void __launch_bounds__(256)
 affine3d_c1_kernel(const float *__restrict__ in, float *__restrict__ out, const FastInterpParams p)
 {
-    __shared__ double ptab[kC1Rows][3];
+    __shared__ double ptab[16][3];
     __shared__ __attribute__((aligned(16))) float tiles[4][4 * 64];
     const int lane = threadIdx.x, ty = threadIdx.y;
-    const int z = blockIdx.z, ybase = blockIdx.y * kC1Rows, x0w = blockIdx.x * 64;
+    const C1Map<ZMAJ> mp(blockIdx);
+    const int x0w = blockIdx.x * 64;
     const int tid = ty * 64 + lane;
-    if (tid < kC1Rows * 3) {
-        // row prefix in the oracle's order: (m0 * z) + m1 * y   (rr = 4 k + ty  <->  y = ybase + rr)
+    if (tid < 48) {
+        // row prefix of (k, ty) in the oracle's order: (m0 * z) + m1 * y
         const int rr = tid / 3, a = tid - 3 * rr;
-        ptab[rr][a] = p.m[4 * a] * (double)z + p.m[4 * a + 1] * (double)(ybase + rr);
+        ptab[rr][a] = p.m[4 * a] * (double)mp.z(rr >> 2) + p.m[4 * a + 1] * (double)mp.y(rr >> 2, rr & 3);
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
@@ -365,28 +384,28 @@ affine3d_c1_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     float r[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) r[k] = finish<float>(t[k], (float)p.cval);
-    const bool full = (VAR & 1) && x0w + 64 <= p.ox && ybase + kC1Rows <= p.oy;       // block-uniform
-    c1_store_rows(out, p, tiles[ty], lane, z, ybase, ty, x0w, r, full);
+    c1_store_rows<ZMAJ>(out, p, tiles[ty], lane, mp, ty, x0w, r, WIDE && mp.full(p, x0w));      // block-uniform
 }
 
-template <int VAR>
+template <bool WIDE, bool ZMAJ>
 __global__ void __launch_bounds__(256)
 map_coords3d_c1_kernel(const float *__restrict__ in, const float *__restrict__ coords, float *__restrict__ out,
                        const FastInterpParams p)
 {
     __shared__ __attribute__((aligned(16))) float tiles[4][3 * 4 * 64];
     const int lane = threadIdx.x, ty = threadIdx.y;
-    const int z = blockIdx.z, ybase = blockIdx.y * kC1Rows, x0w = blockIdx.x * 64;
+    const C1Map<ZMAJ> mp(blockIdx);
+    const int x0w = blockIdx.x * 64;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
     const size_t nout = (size_t)p.oz * p.oy * p.ox;
-    const bool full = x0w + 64 <= p.ox && ybase + kC1Rows <= p.oy;                      // block-uniform
+    const bool wide = WIDE && mp.full(p, x0w);                      // block-uniform
     float *tile = tiles[ty];
     float c[4][3];
-    if ((VAR & 1) && full) {
-        // coordinates: one 16-byte load per lane, row and axis (lane -> row lane / 16, x = 4 (lane % 16)), handed to
+    if (wide) {
+        // coordinates: one 16-byte load per lane, "row" and axis (lane -> row lane / 16, x = 4 (lane % 16)), handed to
         // the lane that owns the voxel through the wave's LDS tile
         const int i = lane >> 4, q = lane & 15;
-        const size_t o = ((size_t)z * p.oy + (ybase + 4 * i + ty)) * p.ox + x0w + 4 * q;
+        const size_t o = ((size_t)mp.z(i) * p.oy + mp.y(i, ty)) * p.ox + x0w + 4 * q;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n *>(coords + a * nout + o));
@@ -402,8 +421,7 @@ map_coords3d_c1_kernel(const float *__restrict__ in, const float *__restrict__ c
         const int x = min(x0w + lane, p.ox - 1);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int y = min(ybase + 4 * k + ty, p.oy - 1);
-            const size_t o = ((size_t)z * p.oy + y) * p.ox + x;
+            const size_t o = ((size_t)min(mp.z(k), p.oz - 1) * p.oy + min(mp.y(k, ty), p.oy - 1)) * p.ox + x;
 #pragma unroll
             for (int a = 0; a < 3; a++) c[k][a] = __builtin_nontemporal_load(coords + a * nout + o);
         }
@@ -414,7 +432,7 @@ map_coords3d_c1_kernel(const float *__restrict__ in, const float *__restrict__ c
     float r[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) r[k] = finish<float>(t[k], (float)p.cval);
-    c1_store_rows(out, p, tile, lane, z, ybase, ty, x0w, r, (VAR & 1) && full);
+    c1_store_rows<ZMAJ>(out, p, tile, lane, mp, ty, x0w, r, wide);
 }
 
 constexpr int kNV = 4;   // voxels per thread (rows 4 apart), all gathers issued before any is used
@@ -487,7 +505,7 @@ affine3d_fast(const T *__restrict__ in, T *__restrict__ out, const FastInterpPar
         if (ok[k]) __builtin_nontemporal_store(finish<T>(t[k], (T)p.cval), out + o[k]);
 }
 
-Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads
+Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads, 3 = r3 with z-major voxel ownership
 
 static bool fast_ok(const mi_array *in, const mi_array *out, int order)
 {
@@ -525,8 +543,12 @@ int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_ar
     const int var = g_interp_c1;
     if (fastc && var && !p.two_d && in->dtype == MI_F32 && coords->dtype == MI_F32 && (p.ox & 3) == 0 &&
         ((uintptr_t)coords->data & 15) == 0) {
-        if (var == 1) hipLaunchKernelGGL((map_coords3d_c1_kernel<1>), grid, block, 0, s, (const float *)in->data, (const float *)coords->data, (float *)out->data, p);
-        else hipLaunchKernelGGL((map_coords3d_c1_kernel<0>), grid, block, 0, s, (const float *)in->data, (const float *)coords->data, (float *)out->data, p);
+        const float *ip = (const float *)in->data, *cp = (const float *)coords->data;
+        float *op = (float *)out->data;
+        const dim3 gridz((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 3) / 4), (unsigned)((p.oz + 3) / 4));
+        if (var == 3 && gridz.y <= 65535 && gridz.z <= 65535) hipLaunchKernelGGL((map_coords3d_c1_kernel<true, true>), gridz, block, 0, s, ip, cp, op, p);
+        else if (var == 2) hipLaunchKernelGGL((map_coords3d_c1_kernel<false, false>), grid, block, 0, s, ip, cp, op, p);
+        else hipLaunchKernelGGL((map_coords3d_c1_kernel<true, false>), grid, block, 0, s, ip, cp, op, p);
         MI_HIP(hipGetLastError());
         return MI_OK;
     }
@@ -570,8 +592,12 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
     const dim3 grid((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 4 * kNV - 1) / (4 * kNV)), (unsigned)p.oz);
     const int var = g_interp_c1;
     if (mode == MI_MODE_CONSTANT && order == 1 && var && !p.two_d && in->dtype == MI_F32 && (p.ox & 3) == 0) {
-        if (var == 1) hipLaunchKernelGGL((affine3d_c1_kernel<1>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p);
-        else hipLaunchKernelGGL((affine3d_c1_kernel<0>), grid, block, 0, s, (const float *)in->data, (float *)out->data, p);
+        const float *ip = (const float *)in->data;
+        float *op = (float *)out->data;
+        const dim3 gridz((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 3) / 4), (unsigned)((p.oz + 3) / 4));
+        if (var == 3 && gridz.y <= 65535 && gridz.z <= 65535) hipLaunchKernelGGL((affine3d_c1_kernel<true, true>), gridz, block, 0, s, ip, op, p);
+        else if (var == 2) hipLaunchKernelGGL((affine3d_c1_kernel<false, false>), grid, block, 0, s, ip, op, p);
+        else hipLaunchKernelGGL((affine3d_c1_kernel<true, false>), grid, block, 0, s, ip, op, p);
         MI_HIP(hipGetLastError());
         return MI_OK;
     }

@@ -51,6 +51,7 @@ struct LongParams {
     // constant mode (HAS_CONST kernels): plain x weights, cval, cval * (product of the three weight sums)
     float wxs[kStreamMaxTaps];
     float cval, cval_sum;
+    int dbg;                // tuning ablations (0 in production): 1 y pass reads one row, 2 no x pass, 4 no z scatter, 8 no DMA, 16 no stores, 32 no halo table
 };
 
 // SAME: the three axes share one weight vector (uniform_filter(size=W), isotropic gaussian_filter): x pair tables
@@ -211,7 +212,7 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
         rin.y = (unsigned)(a >> 32);       // stride 0: the upper 16 bits of a device address are zero
         rin.z = live ? plane_bytes : 0u;
         rin.w = 0x00020000u;
-        dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec);
+        if (!(p.dbg & 8)) dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec);
     };
     constexpr int kArgBase = 2 * sizeof(void *);
     kfloats wyk = kernarg_floats(kArgBase + offsetof(LongParams, wyv));
@@ -223,6 +224,7 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     auto ypass = [&](unsigned at) {
         const float4 t0 = *reinterpret_cast<const float4 *>(smem + at);
         F4 yv = f4_scale2((f32x2){wyk[0], wyk[1]}, f4_from(t0));
+        if (p.dbg & 1) return yv;
 #pragma unroll
         for (int k = 1; k < W; k++) {
             const float4 t = *reinterpret_cast<const float4 *>(smem + at + k * kLongRec);
@@ -268,12 +270,14 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
                     const float4 f = *reinterpret_cast<const float4 *>(smem + hy_far + hyoff);
                     eL[0] = n; eL[1] = f; eR[0] = n; eR[1] = f;
                 }
-                const F4 xy = xhops<W>(f4_to_float4(yv), eL, eR, lane, last, xt0, xt1);
+                const F4 xy = (p.dbg & 2) ? yv : xhops<W>(f4_to_float4(yv), eL, eR, lane, last, xt0, xt1);
                 // ---- z pass: scatter into the pending outputs; output i - k takes tap k
                 acc[J] = f4_scale2((f32x2){wzk[0], wzk[1]}, xy);
+                if (!(p.dbg & 4)) {
 #pragma unroll
-                for (int k = 1; k < W; k++)
-                    acc[(J - k + W) % W] = f4_fma2((f32x2){wzk[2 * k], wzk[2 * k + 1]}, xy, acc[(J - k + W) % W]);
+                    for (int k = 1; k < W; k++)
+                        acc[(J - k + W) % W] = f4_fma2((f32x2){wzk[2 * k], wzk[2 * k + 1]}, xy, acc[(J - k + W) % W]);
+                }
                 if (i >= W - 1) {
                     const unsigned long long oa = (unsigned long long)out +
                                                   (unsigned long long)(unsigned)(zs + i - (W - 1)) * (unsigned long long)plane_bytes;
@@ -284,10 +288,10 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
                         o.lo = fma2(splat2(g), cxv.lo, o.lo + splat2(p.cval_sum));
                         o.hi = fma2(splat2(g), cxv.hi, o.hi + splat2(p.cval_sum));
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(o), rout, ovoff, 0, 2);
+                    if (!(p.dbg & 16)) __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(o), rout, ovoff, 0, 2);
                 }
                 // ---- halo table of plane i + 1 (the wave changes every plane)
-                if (i + 1 < nsteps && wave == (i & 15)) {
+                if (i + 1 < nsteps && wave == (i & 15) && !(p.dbg & 32)) {
                     const F4 hv = ypass(hsrc + b1);
                     *reinterpret_cast<float4 *>(smem + HY0 + (kLongHyBytes / 2 - hyoff) + (unsigned)lane * 16u) = f4_to_float4(hv);
                 }
@@ -330,6 +334,7 @@ static int long_cus()
 
 static mi::Knob g_long_zchunks{0};     // test hook: number of z chunks (0 = cost model)
 static mi::Knob g_long_same{1};        // test hook: 0 = always the reloading variant
+static mi::Knob g_long_dbg{0};         // tuning ablations, see LongParams::dbg
 
 // Fused long-kernel path: cubic odd W in 11..17 (9 behind the test hook), origins on y / z allowed, no constant mode.
 // Returns MI_ERR_UNSUPPORTED when the request is outside that (the caller runs the streaming passes).
@@ -355,6 +360,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
         p.wxs[k] = wx[k];
         sx += wx[k]; sy += wy[k]; sz += wz[k];
     }
+    p.dbg = g_long_dbg;
     p.cval = cval;
     p.cval_sum = (float)((double)cval * sx * sy * sz);
     {
@@ -405,3 +411,4 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
 
 extern "C" int mi_debug_set_long_zchunks(int n) { mi::g_long_zchunks = n; return MI_OK; }
 extern "C" int mi_debug_set_long_same(int n) { mi::g_long_same = n; return MI_OK; }
+extern "C" int mi_debug_set_long_dbg(int f) { mi::g_long_dbg = f; return MI_OK; }

@@ -1182,14 +1182,14 @@ def test_order1_constant_kernels_r3(gpu, ndi, case):
     oshape = shape if oshape is None else oshape
     ref = orc.affine_transform(x, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75)
     outs = {}
-    for var in (1, 2, 0):
+    for var in (1, 2, 3, 0):
         lib.mi_debug_set_interp_c1(var)
         try:
             outs[var] = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75).get()
         finally:
             lib.mi_debug_set_interp_c1(1)
     assert np.allclose(outs[1], ref, rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max())), np.abs(outs[1] - ref).max()
-    assert np.array_equal(outs[1], outs[2])
+    assert np.array_equal(outs[1], outs[2]) and np.array_equal(outs[1], outs[3])
     # the round-2 kernel tests "inside" on the float32 weight; a double fraction < 2^-149 at the last sample is the
     # only way the two can differ, and none of these cases has one
     assert np.array_equal(outs[1], outs[0])
@@ -1199,14 +1199,14 @@ def test_order1_constant_kernels_r3(gpu, ndi, case):
     refm = orc.map_coordinates(x, coords, order=1, mode="constant", cval=-0.75)
     cd = gpu.asarray(coords)
     outm = {}
-    for var in (1, 2, 0):
+    for var in (1, 2, 3, 0):
         lib.mi_debug_set_interp_c1(var)
         try:
             outm[var] = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
         finally:
             lib.mi_debug_set_interp_c1(1)
     assert np.allclose(outm[1], refm, rtol=0, atol=2e-6 * max(1.0, np.abs(refm).max()))
-    assert np.array_equal(outm[1], outm[2]) and np.array_equal(outm[1], outm[0])
+    assert np.array_equal(outm[1], outm[2]) and np.array_equal(outm[1], outm[3]) and np.array_equal(outm[1], outm[0])
 
 
 def test_order1_constant_kernels_r3_nonfinite_and_edges(gpu, ndi):
