@@ -144,7 +144,14 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
             if (i < nsteps) {
                 const unsigned b1 = bi == (kLongNB - 1) * kPlane ? 0u : bi + kPlane;
                 const unsigned b3 = bi == 0u ? (kLongNB - 1) * kPlane : bi - kPlane;
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // Oldest first, this wave has in flight: the 4 DMAs of plane i + 1 (issued two steps ago), the store of
+                // step i - 2, the 4 DMAs of plane i + 2 and the store of step i - 1 (vector memory operations of a wave
+                // retire in issue order on gfx9).  Plane i + 1 must have landed; plane i + 2 AND the store behind it stay
+                // in flight: vmcnt(5) once stores have begun.  (r2 waited vmcnt(4) throughout, i.e. for the first DMA of
+                // the plane issued one step earlier: a prefetch distance of one plane, not two -- removing the DMAs
+                // altogether saved 86 us of 358 on config B, the waves were stalling on them.)
+                if (i >= W) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue(i + 3, b3);
                 const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
                 // ---- y window of output row `wave`, then its x window in registers

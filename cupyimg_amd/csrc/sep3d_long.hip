@@ -259,7 +259,14 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
                 if constexpr (!SAME) { launder(wyk); launder(wzk); launder(xt0); launder(xt1); }
                 const unsigned b1 = bi == (kLongNB - 1) * kPlane ? 0u : bi + kPlane;     // plane i + 1
                 const unsigned b3 = bi == 0u ? (kLongNB - 1) * kPlane : bi - kPlane;     // slot of plane i - 1
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // Oldest first, this wave has in flight: the 4 DMAs of plane i + 1 (issued two steps ago), the store of
+                // step i - 2, the 4 DMAs of plane i + 2 and the store of step i - 1 (vector memory operations of a wave
+                // retire in issue order on gfx9).  Plane i + 1 must have landed; plane i + 2 AND the store behind it stay
+                // in flight: vmcnt(5) once stores have begun.  (r2 waited vmcnt(4) throughout, i.e. for the first DMA of
+                // the plane issued one step earlier: a prefetch distance of one plane, not two -- removing the DMAs
+                // altogether saved 86 us of 358 on config B, the waves were stalling on them.)
+                if (i >= W && !(p.dbg & 16)) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue(i + 3, b3);
                 const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
                 // ---- y pass of output row `wave`, then its x pass in registers

@@ -725,7 +725,7 @@ static mi::Knob g_sep3d_cfg{0};       // tile shape variant
 static mi::Knob g_sep3d_zchunks{0};   // 0 = heuristic
 static mi::Knob g_sep3d_dbg{0};       // ablation flags
 static mi::Knob g_sep3d_kernel{0};    // 0 = auto, 1 = force general (ws) kernel
-static mi::Knob g_sep3d_zrev{1};      // 1 = odd z chunks of the lean kernel stream downwards (ramp planes shared in time)
+static mi::Knob g_sep3d_zrev{0};      // 1 = odd z chunks of the lean kernel stream downwards (ramp planes shared in time); r3: off by default (measured 1-2 % slower on three boxes)
 extern "C" int mi_debug_set_sep3d_zrev(int k) { g_sep3d_zrev = k; return MI_OK; }
 static mi::Knob g_stream_fused_max{kStreamFusedMax};    // test hook: longest kernel with the x pass fused into the streamed pass
 extern "C" int mi_debug_set_stream_fused_max(int k) { g_stream_fused_max = k; return MI_OK; }
