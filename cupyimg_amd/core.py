@@ -20,6 +20,7 @@ _DTYPE_CODES = {
     np.dtype(np.int16): 3, np.dtype(np.uint16): 4, np.dtype(np.int32): 5,
     np.dtype(np.uint32): 6, np.dtype(np.int64): 7, np.dtype(np.uint64): 8,
     np.dtype(np.float32): 9, np.dtype(np.float64): 10,
+    np.dtype(np.float16): 11,      # storage only (mi_copy converts); see scipy.ndimage._support.float16_aware
 }
 
 
@@ -401,7 +402,7 @@ def asarray(obj, dtype=None):
     if not isinstance(obj, np.ndarray) and hasattr(obj, "__cuda_array_interface__"):
         return from_cuda_array_interface(obj)
     arr = np.asarray(obj, dtype=dtype)
-    if arr.dtype == np.float16 or arr.dtype.kind in "cOSU":
+    if arr.dtype.kind in "cOSU":
         raise TypeError("dtype {} is not supported by cupyimg_amd".format(arr.dtype))
     arr = np.ascontiguousarray(arr)
     out = ndarray(arr.shape, arr.dtype)

@@ -64,7 +64,7 @@ static inline size_t dtype_size(int dt)
 {
     switch (dt) {
     case MI_BOOL: case MI_I8: case MI_U8: return 1;
-    case MI_I16: case MI_U16: return 2;
+    case MI_I16: case MI_U16: case MI_F16: return 2;
     case MI_I32: case MI_U32: case MI_F32: return 4;
     default: return 8;
     }
@@ -98,7 +98,7 @@ static inline bool same_shape(const mi_array *a, const mi_array *b)
 
 static inline int check_array(const mi_array *a, const char *name)
 {
-    if (!a || a->ndim < 0 || a->ndim > MI_MAX_NDIM || a->dtype < MI_BOOL || a->dtype > MI_F64) {
+    if (!a || a->ndim < 0 || a->ndim > MI_MAX_NDIM || a->dtype < MI_BOOL || a->dtype > MI_F16) {
         set_error("invalid array descriptor for %s", name);
         return MI_ERR_INVALID_ARG;
     }
@@ -130,6 +130,7 @@ static inline int dispatch_dtype(int dt, F &&f)
     case MI_F32:  return f.template operator()<float>();
     case MI_F64:  return f.template operator()<double>();
     }
+    if (dt == MI_F16) { set_error("float16 arrays are storage only: convert with mi_copy (to float32) around this call"); return MI_ERR_INVALID_ARG; }
     set_error("unsupported dtype code %d", dt);
     return MI_ERR_INVALID_ARG;
 }

@@ -78,6 +78,32 @@ __global__ void __launch_bounds__(256) fill_strided(char *__restrict__ dst, Copy
     }
 }
 
+// float16 (MI_F16) is a storage dtype: converted through float32 on the way in and out (r3)
+template <typename S, typename D>
+__device__ __forceinline__ D convert16(S v, int rhe)
+{
+    if constexpr (std::is_same<S, _Float16>::value && std::is_same<D, _Float16>::value) return v;
+    else if constexpr (std::is_same<S, _Float16>::value) return convert<float, D>((float)v, rhe);
+    else return (_Float16)convert<S, float>(v, rhe);
+}
+
+template <typename S, typename D>
+__global__ void __launch_bounds__(256) copy16_strided(const char *__restrict__ src, char *__restrict__ dst, CopyParams p,
+                                                      int64_t total, int rhe)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i, so = 0, d_o = 0;
+        for (int d = p.ndim - 1; d >= 0; d--) {
+            const int64_t q = r / p.shape[d];
+            const int64_t k = r - q * p.shape[d];
+            so += k * p.sstride[d];
+            d_o += k * p.dstride[d];
+            r = q;
+        }
+        *(D *)(dst + d_o) = convert16<S, D>(*(const S *)(src + so), rhe);
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) any_diff_kernel(const T *__restrict__ a, const T *__restrict__ b,
                                                        int64_t total, int32_t *flag)
@@ -186,6 +212,27 @@ int mi_copy(const mi_array *src, const mi_array *dst, int round_half_even, mi_st
     }
     dim3 grid;
     grid_for(total, 256, &grid);
+    if (src->dtype == MI_F16 || dst->dtype == MI_F16) {
+        if (src->dtype == MI_F16 && dst->dtype == MI_F16)
+            hipLaunchKernelGGL((copy16_strided<_Float16, _Float16>), grid, dim3(256), 0, s, (const char *)src->data, (char *)dst->data, p,
+                               total, round_half_even);
+        else if (src->dtype == MI_F16)
+            return dispatch_dtype(dst->dtype, [&]<typename D>() -> int {
+                hipLaunchKernelGGL((copy16_strided<_Float16, D>), grid, dim3(256), 0, s, (const char *)src->data, (char *)dst->data, p,
+                                   total, round_half_even);
+                MI_HIP(hipGetLastError());
+                return MI_OK;
+            });
+        else
+            return dispatch_dtype(src->dtype, [&]<typename S>() -> int {
+                hipLaunchKernelGGL((copy16_strided<S, _Float16>), grid, dim3(256), 0, s, (const char *)src->data, (char *)dst->data, p,
+                                   total, round_half_even);
+                MI_HIP(hipGetLastError());
+                return MI_OK;
+            });
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
     return dispatch_dtype(src->dtype, [&]<typename S>() -> int {
         return dispatch_dtype(dst->dtype, [&]<typename D>() -> int {
             if (lin)

@@ -408,6 +408,52 @@ spline_affine_kernel(const double *__restrict__ in, void *__restrict__ out, int 
 }
 
 
+// Orders 2..5 on arrays of rank 4 .. 8 (r3; the reference's generator is rank-generic, _interp_kernels.py:473-549):
+// the run-time-order tap loop of spline_point over eight (padded) axes, float64 coefficients, (order + 1)^rank taps
+// per output sample in the oracle's order.  A correctness path: no tiling, weights and indices in scratch memory.
+template <typename C>
+__global__ void __launch_bounds__(256)
+spline_map_nd_kernel(const double *__restrict__ in, const C *__restrict__ coords, void *__restrict__ out, int out_dt,
+                     InterpGeom g, int64_t nout, int order, int mode, double cval, int round_out, int npad)
+{
+    constexpr int ND = MI_MAX_NDIM;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (int64_t)gridDim.x * blockDim.x) {
+        double c[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) c[d] = d < g.pad ? 0.0 : (double)coords[(int64_t)(d - g.pad) * nout + i];
+        double v = spline_point<double, ND>(in, g, c, order, mode, cval, npad);
+        if (round_out) v = interp_round(v, out_dt);
+        store_as(out, i, out_dt, v);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+spline_affine_nd_kernel(const double *__restrict__ in, void *__restrict__ out, int out_dt, InterpGeom g, int64_t nout,
+                        int order, int mode, double cval, int round_out, int npad)
+{
+    constexpr int ND = MI_MAX_NDIM;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (int64_t)gridDim.x * blockDim.x) {
+        double o[ND], c[ND];
+        int64_t r = i;
+#pragma unroll
+        for (int d = ND - 1; d >= 0; d--) {
+            const int64_t q = r / g.oshape[d];
+            o[d] = (double)(r - q * g.oshape[d]);
+            r = q;
+        }
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < ND; k++) s += g.mat[d * (ND + 1) + k] * o[k];
+            c[d] = s + g.mat[d * (ND + 1) + ND];
+        }
+        double v = spline_point<double, ND>(in, g, c, order, mode, cval, npad);
+        if (round_out) v = interp_round(v, out_dt);
+        store_as(out, i, out_dt, v);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Cubic interpolation on float32 coefficients (float32 in / out, the reference's
 // `allow_float32` route, interpolation.py:330-335): same tap selection as
@@ -801,7 +847,7 @@ static bool cubic3_grid(const mi_array *out, InterpGeom *g, dim3 *grid)
 // ---------------------------------------------------------------------------
 // out (float64, shape = in.shape + 2 npad on the real axes) = in extended by edge
 // replication (pad_mode 0) or by cval (pad_mode 1); rank padded to 3
-template <typename T, typename CF>
+template <typename T, typename CF, int ND = 3>
 __global__ void __launch_bounds__(256)
 spline_pad_kernel(const T *__restrict__ in, CF *__restrict__ out, InterpGeom g, int64_t nout, int npad, int pad_mode,
                   double cval)
@@ -810,7 +856,7 @@ spline_pad_kernel(const T *__restrict__ in, CF *__restrict__ out, InterpGeom g, 
         int64_t r = i, pos = 0;
         bool outside = false;
 #pragma unroll
-        for (int d = 2; d >= 0; d--) {
+        for (int d = ND - 1; d >= 0; d--) {
             const int64_t q = r / g.oshape[d];
             int64_t o = r - q * g.oshape[d];
             r = q;
@@ -1528,21 +1574,28 @@ int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mod
 {
     int rc;
     if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
-    MI_REQUIRE(in->ndim >= 1 && in->ndim <= 3 && out->ndim == in->ndim, MI_ERR_INVALID_ARG, "rank 1..3");
+    MI_REQUIRE(in->ndim >= 1 && in->ndim <= MI_MAX_NDIM && out->ndim == in->ndim, MI_ERR_INVALID_ARG, "rank 1..8");
     MI_REQUIRE(out->dtype == MI_F64 || out->dtype == MI_F32, MI_ERR_INVALID_ARG, "coefficients are float64 or float32");
     MI_REQUIRE(npad >= 0 && (pad_mode == 0 || pad_mode == 1), MI_ERR_INVALID_ARG, "bad padding");
     MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "needs C-contiguous arrays");
     for (int d = 0; d < in->ndim; d++)
         MI_REQUIRE(out->shape[d] == in->shape[d] + 2 * npad && in->shape[d] > 0, MI_ERR_INVALID_ARG, "output shape is not correct");
+    const int nd = in->ndim <= 3 ? 3 : MI_MAX_NDIM;
     InterpGeom g;
-    fill_geom(&g, in, 3);
+    fill_geom(&g, in, nd);
+    for (int d = 0; d < nd; d++) g.oshape[d] = 1;
     for (int d = 0; d < in->ndim; d++) g.oshape[g.pad + d] = out->shape[d];
     const int64_t nout = numel(out);
     dim3 grid;
     grid_for(nout, 256, &grid);
     hipStream_t s = resolve_stream(stream);
     return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
-        if (out->dtype == MI_F64)
+        if (nd != 3) {
+            // rank 4 .. 8 (r3): same kernel over eight (padded) axes, float64 coefficients only
+            if (out->dtype != MI_F64) { set_error("float32 spline coefficients are built for rank <= 3"); return MI_ERR_UNSUPPORTED; }
+            hipLaunchKernelGGL((spline_pad_kernel<T, double, MI_MAX_NDIM>), grid, dim3(256), 0, s, (const T *)in->data,
+                               (double *)out->data, g, nout, npad, pad_mode, cval);
+        } else if (out->dtype == MI_F64)
             hipLaunchKernelGGL((spline_pad_kernel<T, double>), grid, dim3(256), 0, s, (const T *)in->data, (double *)out->data,
                                g, nout, npad, pad_mode, cval);
         else
@@ -1723,7 +1776,7 @@ static int check_spline(const mi_array *coef, const mi_array *out, int order, in
     MI_REQUIRE(coef->dtype == MI_F64 || (coef->dtype == MI_F32 && order == 3 && out->dtype == MI_F32), MI_ERR_INVALID_ARG,
                "coefficients are float64 (float32 only for order 3 with a float32 output)");
     MI_REQUIRE(npad >= 0, MI_ERR_INVALID_ARG, "negative padding");
-    if (coef->ndim > 3) { set_error("spline orders 2-5 are built for rank <= 3"); return MI_ERR_UNSUPPORTED; }
+    if (coef->ndim > 3 && coef->dtype != MI_F64) { set_error("float32 spline coefficients are built for rank <= 3"); return MI_ERR_UNSUPPORTED; }
     return MI_OK;
 }
 
@@ -1743,11 +1796,21 @@ int mi_spline_map_coordinates(const mi_array *coef, const mi_array *coords, cons
     const int64_t nout = numel(out);
     if (nout == 0) return MI_OK;
     InterpGeom g;
-    fill_geom(&g, coef, 3);
+    fill_geom(&g, coef, coef->ndim <= 3 ? 3 : MI_MAX_NDIM);
     const int round_out = out->dtype != MI_F32 && out->dtype != MI_F64 && out->dtype != MI_BOOL;
     dim3 grid;
     grid_for(nout, 256, &grid);
     hipStream_t s = resolve_stream(stream);
+    if (coef->ndim > 3) {
+        if (coords->dtype == MI_F32)
+            hipLaunchKernelGGL((spline_map_nd_kernel<float>), grid, dim3(256), 0, s, (const double *)coef->data, (const float *)coords->data,
+                               out->data, out->dtype, g, nout, order, mode, cval, round_out, npad);
+        else
+            hipLaunchKernelGGL((spline_map_nd_kernel<double>), grid, dim3(256), 0, s, (const double *)coef->data, (const double *)coords->data,
+                               out->data, out->dtype, g, nout, order, mode, cval, round_out, npad);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
     if (coef->dtype == MI_F32) {
         // float32 coefficients: the cubic gather kernel (32-bit element offsets)
         MI_REQUIRE(numel(coef) < ((int64_t)1 << 29), MI_ERR_UNSUPPORTED, "float32 coefficient volume too large");
@@ -1794,9 +1857,10 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
     MI_REQUIRE(out->ndim == coef->ndim, MI_ERR_INVALID_ARG, "output rank must equal input rank");
     const int64_t nout = numel(out);
     if (nout == 0) return MI_OK;
-    const int n = coef->ndim, nd = 3;
+    const int n = coef->ndim, nd = n <= 3 ? 3 : MI_MAX_NDIM;
     InterpGeom g;
     fill_geom(&g, coef, nd);
+    for (int d = 0; d < nd; d++) g.oshape[d] = 1;
     for (int d = 0; d < n; d++) g.oshape[g.pad + d] = out->shape[d];
     for (int i = 0; i < nd * (nd + 1); i++) g.mat[i] = 0.0;
     for (int d = 0; d < n; d++) {
@@ -1807,6 +1871,12 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
     dim3 grid;
     grid_for(nout, 256, &grid);
     hipStream_t s = resolve_stream(stream);
+    if (n > 3) {
+        hipLaunchKernelGGL(spline_affine_nd_kernel, grid, dim3(256), 0, s, (const double *)coef->data, out->data, out->dtype, g,
+                           nout, order, mode, cval, round_out, npad);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
     if (coef->dtype == MI_F32) {
         MI_REQUIRE(numel(coef) < ((int64_t)1 << 29), MI_ERR_UNSUPPORTED, "float32 coefficient volume too large");
         MI_REQUIRE(is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "needs a C-contiguous output");

@@ -170,6 +170,50 @@ rank3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Geom3
     store_as(out, v.lin, out_dt, res);
 }
 
+// Rank filter for everything the register kernels above do not take (arrays of rank 4 .. 8, footprints of more
+// than kMaxRankTaps samples, volumes beyond the 32-bit geometry): the window of a voxel is gathered into a scratch
+// column in device memory (element t of thread q at scratch[t * nthreads + q]: neighbouring threads touch
+// neighbouring addresses) and shell-sorted there, the counterpart of the reference's per-thread shell sort
+// (cupyimg/scipy/ndimage/filters.py:1753-1768, 1829-1835), which has no size limit either.  Values stay in the input
+// dtype (exact for 64-bit integers).  A correctness path: ~n log^2 n scratch accesses per voxel.
+template <typename T, int ND>
+__global__ void __launch_bounds__(256)
+rank_nd_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, NdGeom g, TapTable tt, int64_t total, int mode,
+               T cval, int rank, T *__restrict__ scratch, int64_t nthreads)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nthreads) return;
+    T *v = scratch + q;
+    const int n = tt.ntaps;
+    for (int64_t i = q; i < total; i += nthreads) {
+        const Voxel<ND> vx = locate<ND>(g, i);
+        for (int t = 0; t < n; t++) {
+            T x;
+            if (vx.interior) {
+                x = in[i + tt.lin[t]];
+            } else {
+                const int64_t pos = tap_pos<ND>(g, vx, tt.idx, t, mode);
+                x = pos < 0 ? cval : in[pos];
+            }
+            v[(int64_t)t * nthreads] = x;
+        }
+        for (int gap = n / 2; gap > 0; gap = gap == 2 ? 1 : (int)(gap / 2.2)) {
+            for (int j = gap; j < n; j++) {
+                const T tmp = v[(int64_t)j * nthreads];
+                int k = j;
+                while (k >= gap) {
+                    const T lo = v[(int64_t)(k - gap) * nthreads];
+                    if (!(lo > tmp)) break;
+                    v[(int64_t)k * nthreads] = lo;
+                    k -= gap;
+                }
+                v[(int64_t)k * nthreads] = tmp;
+            }
+        }
+        store_as(out, i, out_dt, (double)v[(int64_t)rank * nthreads]);
+    }
+}
+
 // sorting-network rank kernel: rank_sorted.hpp, instantiated in rank_sorted_*.hip
 template <typename T, typename V, int P>
 int run_rank_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, int rank, hipStream_t s);
@@ -319,17 +363,53 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
     MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "rank filter needs C-contiguous arrays");
     MI_REQUIRE(in->data != out->data, MI_ERR_INVALID_ARG, "in-place filtering is not supported by the kernel");
     if (numel(in) == 0) return MI_OK;
-    if (!Taps3Builder::eligible(in, fshape)) { set_error("rank filter: rank <= 3 arrays below 4 GiB only"); return MI_ERR_UNSUPPORTED; }
     hipStream_t s = resolve_stream(stream);
     mode = filter_mode(mode);
+    int64_t nset = 0, fsize = 1;
+    for (int d = 0; d < in->ndim; d++) fsize *= fshape[d];
+    for (int64_t k = 0; k < fsize; k++) nset += footprint[k] != 0;
+    MI_REQUIRE(nset > 0, MI_ERR_INVALID_ARG, "all-zero footprint is not supported");
+    MI_REQUIRE(rank >= 0 && rank < nset, MI_ERR_INVALID_ARG, "rank not within filter footprint size");
+    if (!Taps3Builder::eligible(in, fshape) || nset > kMaxRankTaps) {
+        // r3: any rank up to 8, any footprint size: window in a scratch column, shell sort (rank_nd_kernel)
+        TapBuilder tb;
+        TapTable tt;
+        if ((rc = tb.init(in, fshape, origins, "footprint"))) return rc;
+        tb.fill([&](int64_t k) { return footprint[k] != 0; }, [](int64_t) { return 0.0; }, false);
+        if ((rc = tb.upload(&tt, s))) return rc;
+        const int64_t total = numel(in);
+        const size_t esz = dtype_size(in->dtype);
+        // threads: as many as a 256 MiB scratch holds columns for, at most 64 Ki, at least one workgroup
+        int64_t nthreads = (int64_t)(((size_t)256 << 20) / ((size_t)nset * esz));
+        nthreads = std::min<int64_t>(nthreads, 65536);
+        nthreads = std::min<int64_t>(nthreads, (total + 255) / 256 * 256);
+        nthreads = std::max<int64_t>(nthreads / 256 * 256, 256);
+        void *scratch = nullptr;
+        if ((rc = pool_alloc(&scratch, (size_t)nset * (size_t)nthreads * esz, s))) return rc;
+        rc = dispatch_dtype(in->dtype, [&]<typename T>() -> int {
+            T cv;
+            if constexpr (std::is_same<T, double>::value) cv = cval;
+            else if constexpr (std::is_same<T, float>::value) cv = (float)cval;
+            else if constexpr (std::is_same<T, bool>::value) cv = cval != 0.0;
+            else if constexpr (std::is_same<T, uint64_t>::value) cv = cval >= 0 ? (uint64_t)cval : (uint64_t)(-(int64_t)(uint64_t)(-cval));
+            else cv = (T)(int64_t)cval;
+            const dim3 grid((unsigned)(nthreads / 256));
+            if (tb.g.ndim == 3)
+                hipLaunchKernelGGL((rank_nd_kernel<T, 3>), grid, dim3(256), 0, s, (const T *)in->data, out->data, out->dtype, tb.g, tt,
+                                   total, mode, cv, rank, (T *)scratch, nthreads);
+            else
+                hipLaunchKernelGGL((rank_nd_kernel<T, MI_MAX_NDIM>), grid, dim3(256), 0, s, (const T *)in->data, out->data, out->dtype,
+                                   tb.g, tt, total, mode, cv, rank, (T *)scratch, nthreads);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        });
+        pool_free(scratch);             // reuse is stream ordered
+        return rc;
+    }
     Taps3Builder t3;
     Taps3 tt3;
     if ((rc = t3.build(in, fshape, origins, [&](int64_t k) { return footprint[k] != 0; }, [](int64_t) { return 0.0; }, false)))
         return rc;
-    const int n = (int)t3.lin.size();
-    MI_REQUIRE(n > 0, MI_ERR_INVALID_ARG, "all-zero footprint is not supported");
-    MI_REQUIRE(rank >= 0 && rank < n, MI_ERR_INVALID_ARG, "rank not within filter footprint size");
-    if (n > kMaxRankTaps) { set_error("rank filter: footprints of more than %d samples are not built", kMaxRankTaps); return MI_ERR_UNSUPPORTED; }
     if ((rc = t3.finish(&tt3, s))) return rc;
     return dispatch_dtype(in->dtype, [&]<typename T>() -> int {
         double cv;

@@ -7,6 +7,8 @@ organised around the C-ABI rather than around CuPy kernels.
 """
 import contextlib
 import ctypes
+import functools
+import inspect
 import threading
 
 import numpy as np
@@ -78,9 +80,59 @@ def as_device(a, name="input"):
     arr = np.asarray(a)
     if arr.dtype.kind == "c":
         raise TypeError("Complex type not supported")
-    if arr.dtype == np.float16:
+    if arr.dtype == np.float16:      # reached only by functions without `output` (float16_aware handles the rest)
         arr = arr.astype(np.float32)
     return core.asarray(arr)
+
+
+_F16 = np.dtype(np.float16)
+
+
+def _is_f16(a):
+    if isinstance(a, (core.ndarray, np.ndarray)):
+        return a.dtype == _F16
+    if isinstance(a, (type, np.dtype, str)):
+        try:
+            return np.dtype(a) == _F16
+        except TypeError:
+            return False
+    return False
+
+
+def float16_aware(fn):
+    """float16 images keep their dtype, as in the reference (_filters_core.py:169-171: float16 in, float16 out, the
+    arithmetic in float32 / float64): the kernels of this library have no float16 arithmetic, so a float16 input is
+    converted to float32 on the device (exact), the call runs in float32, and the result is rounded to float16 when
+    the caller asked for float16 (explicitly, or by passing a float16 image without `output`).  Calls that involve no
+    float16 pass straight through (the test costs a few attribute look-ups)."""
+    sig = inspect.signature(fn)
+    if "output" not in sig.parameters:
+        return fn
+    first = next(iter(sig.parameters))
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if not (any(_is_f16(a) for a in args) or any(_is_f16(v) for v in kwargs.values())):
+            return fn(*args, **kwargs)
+        bound = sig.bind(*args, **kwargs)
+        ba = bound.arguments
+        image = ba[first]
+        in16 = _is_f16(image)
+        if in16:
+            ba[first] = image.astype(np.float32)
+        out = ba.get("output", None)
+        out_arr = out if isinstance(out, core.ndarray) and _is_f16(out) else None
+        out16 = out_arr is not None or (out is not None and not isinstance(out, core.ndarray) and _is_f16(out)) or (out is None and in16)
+        if out16:
+            ba["output"] = np.float32
+        res = fn(*bound.args, **bound.kwargs)
+        if not out16 or not isinstance(res, core.ndarray):
+            return res
+        if out_arr is not None:
+            out_arr[...] = res
+            return out_arr
+        return res.astype(np.float16)
+    return wrapper
 
 
 def as_host(a, dtype=None):

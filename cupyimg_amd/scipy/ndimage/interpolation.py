@@ -7,8 +7,8 @@ Signatures follow cupyimg/scipy/ndimage/interpolation.py (spline_filter1d
 the gather kernels directly; orders 2-5 first build float64 B-spline
 coefficients on the device (SciPy's rule: pad by 12 samples for `nearest` /
 `grid-constant`, then prefilter every axis with the boundary condition that
-matches the mode) and interpolate those -- rank <= 3, results equal to
-SciPy 1.15's to rounding.
+matches the mode) and interpolate those -- any rank up to 8 (rank > 3: a plain
+(order + 1)^rank tap loop in float64), results equal to SciPy 1.15's to rounding.
 """
 import ctypes
 import warnings
@@ -59,8 +59,6 @@ def _to_coefficients(input, order, mode, cval, prefilter, f32=False):
     on the float32 cubic route (the recursion itself always runs in double).
     SciPy pads by 12 samples for `nearest` / `grid-constant` before filtering;
     prefilter=False interpolates the samples as if they were coefficients."""
-    if input.ndim > 3:
-        raise NotImplementedError("spline orders 2-5 are built for rank <= 3")
     src = core.ascontiguousarray(input)
     npad, pad_mode = 0, 0
     if prefilter and mode in ("nearest", "grid-constant"):

@@ -49,7 +49,10 @@ extern "C" {
 
 typedef enum mi_dtype {
     MI_BOOL = 0, MI_I8 = 1, MI_U8 = 2, MI_I16 = 3, MI_U16 = 4, MI_I32 = 5,
-    MI_U32 = 6, MI_I64 = 7, MI_U64 = 8, MI_F32 = 9, MI_F64 = 10
+    MI_U32 = 6, MI_I64 = 7, MI_U64 = 8, MI_F32 = 9, MI_F64 = 10,
+    MI_F16 = 11   /* storage only: mi_copy converts to / from it (the reference keeps float16 results in float16,
+                     _filters_core.py:169-171, computing in float32 / float64); every compute entry point answers
+                     MI_ERR_INVALID_ARG for it and the Python layer converts around the call */
 } mi_dtype;
 
 /* scipy.ndimage boundary modes (cupyimg/scipy/ndimage/_util.py:105-119).

@@ -1236,3 +1236,103 @@ def test_order1_constant_kernels_r3_nonfinite_and_edges(gpu, ndi):
     ref = sndi.map_coordinates(x.astype(np.float64), c.astype(np.float64), order=1, mode="constant", cval=2.0)
     got = ndi.map_coordinates(gpu.asarray(x), gpu.asarray(c), order=1, mode="constant", cval=2.0).get()
     assert np.array_equal(got, ref.astype(np.float32))
+
+
+# ------------------------------------------------------------------ r3: spline orders 2-5 on rank > 3 arrays
+@pytest.mark.parametrize("order", [2, 3, 4, 5])
+def test_spline_orders_on_rank4_and_rank5(gpu, ndi, order):
+    """The reference's interpolation kernels are rank-generic (_interp_kernels.py:473-549); orders 2-5 used to stop at
+    rank 3 here.  Against scipy.ndimage (double arithmetic on both sides: 1e-11; integer outputs exact)."""
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(170 + order)
+    x4 = rng.standard_normal((5, 6, 7, 9))
+    x5 = rng.standard_normal((3, 4, 5, 4, 6)).astype(np.float32)
+    u4 = rng.integers(0, 200, size=(4, 5, 6, 8)).astype(np.uint8)
+    for mode in ["constant", "nearest", "mirror", "reflect", "grid-wrap", "grid-constant", "wrap"]:
+        # affine (incl. shift / zoom through it) on rank 4
+        M = np.eye(4) + 0.05 * rng.standard_normal((4, 4))
+        off = rng.standard_normal(4)
+        ref = sndi.affine_transform(x4, M, off, order=order, mode=mode, cval=0.5)
+        got = ndi.affine_transform(gpu.asarray(x4), M, off, order=order, mode=mode, cval=0.5).get()
+        assert np.allclose(got, ref, rtol=0, atol=1e-11 * max(1.0, np.abs(ref).max())), (mode, "affine4")
+        ref = sndi.shift(x4, [0.3, -1.2, 0.7, 2.1], order=order, mode=mode, cval=-1.0)
+        got = ndi.shift(gpu.asarray(x4), [0.3, -1.2, 0.7, 2.1], order=order, mode=mode, cval=-1.0).get()
+        assert np.allclose(got, ref, rtol=0, atol=1e-11 * max(1.0, np.abs(ref).max())), (mode, "shift4")
+        # map_coordinates on rank 5, float32 data (SciPy and the device both filter in double)
+        coords = np.stack([rng.uniform(-1.5, n + 0.5, size=(7, 11)) for n in x5.shape])
+        ref = sndi.map_coordinates(x5.astype(np.float64), coords, order=order, mode=mode, cval=0.25)
+        got = ndi.map_coordinates(gpu.asarray(x5), gpu.asarray(coords), order=order, mode=mode, cval=0.25, output=np.float64).get()
+        assert np.allclose(got, ref, rtol=0, atol=1e-11 * max(1.0, np.abs(ref).max())), (mode, "map5")
+    ref = sndi.zoom(u4, 1.3, order=order, mode="mirror")
+    got = ndi.zoom(gpu.asarray(u4), 1.3, order=order, mode="mirror").get()
+    assert got.dtype == np.uint8 and got.shape == ref.shape
+    assert np.count_nonzero(got != ref) <= ref.size // 2000          # exact up to .5 ties decided by the last bit
+    pre = sndi.spline_filter(x4, order=order, mode="mirror")
+    assert np.allclose(ndi.spline_filter(gpu.asarray(x4), order=order, mode="mirror").get(), pre, rtol=0, atol=1e-11)
+
+
+# ------------------------------------------------------------------ r3: rank filters without a size / rank limit
+def test_rank_filters_beyond_128_taps_and_rank3(gpu, ndi):
+    """median / rank / percentile filters with footprints of more than 128 samples and on rank-4 / rank-5 arrays (the
+    scratch-column shell-sort kernel; the reference's shell-sort path has no limit either, filters.py:1753-1768,
+    1829-1835).  Selection results are exact."""
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(180)
+    x3 = rng.standard_normal((12, 14, 18)).astype(np.float32)
+    for mode in ("reflect", "constant", "wrap"):
+        ref = sndi.median_filter(x3, size=7, mode=mode, cval=0.5)                         # 343 samples
+        assert np.array_equal(ndi.median_filter(gpu.asarray(x3), size=7, mode=mode, cval=0.5).get(), ref), mode
+    img = rng.integers(0, 1 << 16, size=(40, 52)).astype(np.uint16)
+    fp = rng.random((11, 13)) > 0.2                                                      # ~114 .. 143 samples, some > 128
+    fp[0, :] = True; fp[:, 0] = True
+    assert fp.sum() > 128
+    for rank in (0, 5, int(fp.sum()) // 2, int(fp.sum()) - 2):
+        ref = sndi.rank_filter(img, rank, footprint=fp, mode="mirror", origin=(1, -2))
+        assert np.array_equal(ndi.rank_filter(gpu.asarray(img), rank, footprint=fp, mode="mirror", origin=(1, -2)).get(), ref), rank
+    x4 = rng.integers(-50, 50, size=(5, 6, 7, 8)).astype(np.int64) * (1 << 40) + rng.integers(0, 7, size=(5, 6, 7, 8))
+    ref = sndi.median_filter(x4, size=(3, 3, 3, 3), mode="nearest")                      # rank 4, 81 samples, 64-bit exact
+    assert np.array_equal(ndi.median_filter(gpu.asarray(x4), size=(3, 3, 3, 3), mode="nearest").get(), ref)
+    x5 = rng.standard_normal((3, 4, 5, 4, 6))
+    ref = sndi.percentile_filter(x5, 30, size=(1, 3, 3, 2, 3), mode="reflect")
+    assert np.array_equal(ndi.percentile_filter(gpu.asarray(x5), 30, size=(1, 3, 3, 2, 3), mode="reflect").get(), ref)
+    big = rng.standard_normal((40, 300, 300)).astype(np.float32)                          # more voxels than scratch columns
+    ref = sndi.median_filter(big, size=(5, 6, 6), mode="reflect")                         # 180 samples, even sizes
+    assert np.array_equal(ndi.median_filter(gpu.asarray(big), size=(5, 6, 6), mode="reflect").get(), ref)
+
+
+# ------------------------------------------------------------------ r3: float16 images keep their dtype
+def test_float16_images_keep_their_dtype(gpu, ndi):
+    """The reference filters a float16 image into a float16 result (_filters_core.py:169-171, arithmetic in float32 /
+    float64); round 2 silently returned float32.  Here: converted to float32 on the device (exact), filtered, rounded
+    to float16 -- compared with SciPy on the exactly-converted float32 image, rounded the same way."""
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(190)
+    h = rng.standard_normal((24, 40, 64)).astype(np.float16)
+    hd = gpu.asarray(h)
+    assert hd.dtype == np.float16 and np.array_equal(hd.get(), h)
+    f = h.astype(np.float32)
+    cases = [
+        (lambda a, **k: ndi.uniform_filter(a, 5, **k), lambda a: sndi.uniform_filter(a, 5), 2),
+        (lambda a, **k: ndi.gaussian_filter(a, 1.5, **k), lambda a: sndi.gaussian_filter(a, 1.5), 2),
+        (lambda a, **k: ndi.correlate1d(a, [1, 2, 1], axis=1, **k), lambda a: sndi.correlate1d(a, [1, 2, 1], axis=1), 2),
+        (lambda a, **k: ndi.grey_erosion(a, size=3, **k), lambda a: sndi.grey_erosion(a, size=3), 0),
+        (lambda a, **k: ndi.median_filter(a, size=3, **k), lambda a: sndi.median_filter(a, size=3), 0),
+        (lambda a, **k: ndi.affine_transform(a, np.eye(3) * 0.9, order=1, **k), lambda a: sndi.affine_transform(a, np.eye(3) * 0.9, order=1), 2),
+    ]
+    for got_fn, ref_fn, ulps in cases:
+        got = got_fn(hd)
+        assert got.dtype == np.float16
+        ref = ref_fn(f.astype(np.float64)).astype(np.float16)
+        g = got.get()
+        if ulps == 0:
+            assert np.array_equal(g, ref)
+        else:
+            # float32 arithmetic rounded to float16 against float64 arithmetic rounded to float16: at most one ulp
+            assert np.abs(g.view(np.int16).astype(np.int32) - ref.view(np.int16).astype(np.int32)).max() <= 1
+        out16 = gpu.empty(h.shape, np.float16)
+        assert got_fn(hd, output=out16) is out16 and np.array_equal(out16.get(), g)
+        assert got_fn(gpu.asarray(f), output=np.float16).dtype == np.float16           # float16 asked for explicitly
+        assert got_fn(hd, output=np.float32).dtype == np.float32                        # ... or not
+    assert ndi.uniform_filter(h, 3).dtype == np.float16                                # host float16 arrays as well
+    b = ndi.binary_erosion(hd)                                                          # float16 as a mask source
+    assert b.dtype == np.bool_ and np.array_equal(b.get(), sndi.binary_erosion(f))
