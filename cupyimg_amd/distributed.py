@@ -383,3 +383,83 @@ class SlabFilter:
         return self.separable(weights, mode, cval, overlap=overlap, _key=key,
                               fallback=lambda a, b: ndi.gaussian_filter(a, sigma, order=order, mode=mode, cval=cval,
                                                                         truncate=truncate, output=b))
+
+    # ---------------------------------------------------------------- filters on the plain schedule
+    # Everything below runs `step(fn)`: one exchange, then the package's own single-GPU kernel on the extended slab
+    # (the halo planes are filtered too -- (lo + hi) / n_ext of wasted work, 3 % for config E -- and are scratch).
+
+    def _minmax(self, name, size, mode, cval, origin):
+        from .scipy import ndimage as ndi
+        from .scipy.ndimage import _support as S
+        sizes = [int(v) for v in S.normalize_sequence(size, 3)]
+        origins = [int(v) for v in S.normalize_sequence(origin, 3)]
+        # grey dilation mirrors the window: its reach along axis 0 is that of the flipped kernel
+        o0 = origins[0] if name != "grey_dilation" else -origins[0] - (1 if sizes[0] % 2 == 0 else 0)
+        self.check_reach(sizes[0], o0)
+        fn = getattr(ndi, name)
+        return self.step(lambda a, b: fn(a, size=tuple(sizes), mode=mode, cval=cval, origin=tuple(origins), output=b))
+
+    def minimum_filter(self, size, mode="reflect", cval=0.0, origin=0):
+        """minimum_filter(size=...) of the distributed volume; returns this rank's planes."""
+        return self._minmax("minimum_filter", size, mode, cval, origin)
+
+    def maximum_filter(self, size, mode="reflect", cval=0.0, origin=0):
+        return self._minmax("maximum_filter", size, mode, cval, origin)
+
+    def grey_erosion(self, size, mode="reflect", cval=0.0, origin=0):
+        """grey_erosion(size=...) (BASELINE config C's operation) of the distributed volume."""
+        return self._minmax("grey_erosion", size, mode, cval, origin)
+
+    def grey_dilation(self, size, mode="reflect", cval=0.0, origin=0):
+        return self._minmax("grey_dilation", size, mode, cval, origin)
+
+    def _binary(self, name, structure, iterations, border_value, origin, any_changed):
+        from .scipy import ndimage as ndi
+        from .scipy.ndimage import _support as S
+        fn = getattr(ndi, name)
+        if structure is None:
+            structure = ndi.generate_binary_structure(3, 1)
+        st = S.as_host(structure).astype(bool)
+        if st.ndim != 3:
+            raise RuntimeError("structure and input must have same dimensionality")
+        origins = [int(v) for v in S.normalize_sequence(origin, 3)]
+        n0 = st.shape[0]
+        # planes an output plane reaches below / above per iteration (dilation mirrors the structure)
+        o0 = origins[0] if name == "binary_erosion" else -origins[0] - (1 if n0 % 2 == 0 else 0)
+        lo1, hi1 = halo_widths(n0, o0)
+        iterations = int(iterations)
+        if iterations >= 1:
+            # ONE exchange of iterations x reach planes: what the slab edges get wrong moves one reach inwards per
+            # iteration and never arrives at a local plane (SURVEY.md section 8e)
+            plan = self.plan
+            if (plan.prev >= 0 and iterations * lo1 > plan.lo) or (plan.next >= 0 and iterations * hi1 > plan.hi):
+                raise ValueError("{} iterations of a structure reaching ({}, {}) planes need a halo of ({}, {}); the slab "
+                                 "plan exchanges ({}, {})".format(iterations, lo1, hi1, iterations * lo1, iterations * hi1,
+                                                                  plan.lo, plan.hi))
+            return self.step(lambda a, b: fn(a, structure=st, iterations=iterations, border_value=border_value,
+                                             origin=tuple(origins), output=b))
+        # until nothing changes anywhere: one iteration per exchange, the "changed" flags of the ranks OR-ed on the host
+        if self.plan.nranks > 1 and any_changed is None:
+            raise ValueError("iterations < 1 on a distributed volume needs `any_changed` (a callable that ORs one bool "
+                             "over the ranks, e.g. an all-reduce of the host flag)")
+        self.check_reach(n0, o0)
+        while True:
+            self.step(lambda a, b: fn(a, structure=st, iterations=1, border_value=border_value, origin=tuple(origins),
+                                      output=b))
+            changed = bool(core.arrays_differ(self.local_out, self.local_in))
+            if any_changed is not None:
+                changed = bool(any_changed(changed))
+            if not changed:
+                return self.local_out
+            self.local_in[...] = self.local_out
+
+    def binary_erosion(self, structure=None, iterations=1, border_value=0, origin=0, any_changed=None):
+        """binary_erosion of the distributed volume (reference loop: cupyimg/scipy/ndimage/morphology.py:292-322).
+        `iterations >= 1`: ONE halo exchange of iterations x (structure reach) planes -- the plan must have been built
+        with that halo -- then the iterated single-GPU kernel on the extended slab.  `iterations < 1` (until stable):
+        one iteration per exchange; `any_changed(flag) -> bool` ORs the per-rank "changed" flag over the ranks (the
+        only other communication, one int per iteration).  Returns this rank's planes."""
+        return self._binary("binary_erosion", structure, iterations, border_value, origin, any_changed)
+
+    def binary_dilation(self, structure=None, iterations=1, border_value=0, origin=0, any_changed=None):
+        return self._binary("binary_dilation", structure, iterations, border_value, origin, any_changed)

@@ -122,16 +122,20 @@ def float16_aware(fn):
             ba[first] = image.astype(np.float32)
         out = ba.get("output", None)
         out_arr = out if isinstance(out, core.ndarray) and _is_f16(out) else None
-        out16 = out_arr is not None or (out is not None and not isinstance(out, core.ndarray) and _is_f16(out)) or (out is None and in16)
+        out16 = out_arr is not None or (out is not None and not isinstance(out, core.ndarray) and _is_f16(out))
         if out16:
             ba["output"] = np.float32
         res = fn(*bound.args, **bound.kwargs)
-        if not out16 or not isinstance(res, core.ndarray):
+        if not isinstance(res, core.ndarray):
             return res
         if out_arr is not None:
             out_arr[...] = res
             return out_arr
-        return res.astype(np.float16)
+        # no `output` given: functions whose result takes the input dtype (now float32) give float16 back; the
+        # others (bool masks of binary morphology, float64 spline coefficients) keep their own default
+        if out16 or (out is None and in16 and res.dtype == np.float32):
+            return res.astype(np.float16)
+        return res
     return wrapper
 
 

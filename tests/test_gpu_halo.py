@@ -262,3 +262,45 @@ def test_arrays_differ(gpu):
     b[1, 2, 3:4] = gpu.asarray(np.array([-1.0], np.float32))
     assert gpu.arrays_differ(a, b)
     assert not gpu.arrays_differ(a[0:1], b[0:1])
+
+
+def test_slab_minmax_and_binary_morphology(gpu, ndi, self_comm):
+    """SlabFilter.grey_erosion / maximum_filter / binary_erosion / binary_dilation on a closed one-rank chain (the halos
+    are the periodic continuation): uint8 min / max bit-exact against the oracle with `wrap` on axis 0; iterated
+    binary erosion with ONE exchange of iterations x reach planes; until-stable with the OR callback."""
+    from cupyimg_amd.distributed import SlabFilter
+    rng = np.random.default_rng(30)
+    nz = 24
+    u = rng.integers(0, 256, size=(nz, 40, 64)).astype(np.uint8)
+    sf = SlabFilter(_SelfLoopPlan(nz, 3, 3), u.shape[1:], np.uint8, self_comm)
+    sf.local_in[...] = gpu.asarray(u)
+    got = sf.grey_erosion(7, mode="reflect").get()
+    assert np.array_equal(got, orc.grey_erosion(u, size=7, mode=["wrap", "reflect", "reflect"]))
+    got = sf.maximum_filter((5, 3, 7), mode="nearest").get()
+    assert np.array_equal(got, orc.maximum_filter(u, size=(5, 3, 7), mode=["wrap", "nearest", "nearest"]))
+    with pytest.raises(ValueError):
+        sf.minimum_filter(9)                                   # reach 4 > halo 3
+
+    b = rng.random((nz, 30, 64)) > 0.3
+    st = orc.generate_binary_structure(3, 1)
+    sfb = SlabFilter(_SelfLoopPlan(nz, 2, 2), b.shape[1:], np.bool_, self_comm)
+    sfb.local_in[...] = gpu.asarray(b)
+    # reference: the periodic volume = three copies stacked, middle one compared
+    b3 = np.concatenate([b, b, b])
+    for it in (1, 2):
+        ref = orc.binary_erosion(b3, structure=st, iterations=it)[nz:2 * nz]
+        assert np.array_equal(sfb.binary_erosion(st, iterations=it).get(), ref), it
+        ref = orc.binary_dilation(b3, structure=st, iterations=it)[nz:2 * nz]
+        assert np.array_equal(sfb.binary_dilation(st, iterations=it).get(), ref), it
+    with pytest.raises(ValueError):
+        sfb.binary_erosion(st, iterations=3)                   # 3 x 1 planes > halo 2
+    calls = []
+    res = sfb.binary_erosion(st, iterations=0, border_value=1, any_changed=lambda f: (calls.append(f), f)[1]).get()
+    n_it = len(calls)
+    ref = b3
+    for _ in range(n_it + 2):
+        ref = orc.binary_erosion(ref, structure=st, iterations=1, border_value=1)
+    # periodic in z, border_value=1 in y / x: iterate the stacked volume as often (the middle copy is exact for
+    # n_it <= nz iterations) and it must have converged
+    assert n_it >= 2 and calls[-1] is False and n_it <= nz
+    assert np.array_equal(res, ref[nz:2 * nz])
