@@ -1440,7 +1440,6 @@ static int check_interp(const mi_array *in, const mi_array *out, int order, int 
     if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
     MI_REQUIRE(in->ndim >= 1, MI_ERR_INVALID_ARG, "input must have at least one dimension");
     if (order < 0 || order > 5) { set_error("spline order is not supported"); return MI_ERR_INVALID_ARG; }
-    if (order > 1 && in->ndim > 3) { set_error("spline orders 2-5 are built for rank <= 3"); return MI_ERR_UNSUPPORTED; }
     MI_REQUIRE(mode >= MI_MODE_REFLECT && mode <= MI_MODE_GRID_CONSTANT, MI_ERR_INVALID_ARG,
                "boundary mode is not supported");
     MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS,
@@ -1483,6 +1482,7 @@ int mi_map_coordinates(const mi_array *in, const mi_array *coords, const mi_arra
 {
     int rc = check_interp(in, out, order, mode);
     if (rc) return rc;
+    if (order > 1 && in->ndim > 3) { set_error("orders 2-5 on rank > 3 arrays: mi_spline_map_coordinates (on coefficients)"); return MI_ERR_UNSUPPORTED; }
     if ((rc = check_array(coords, "coordinates"))) return rc;
     MI_REQUIRE(coords->dtype == MI_F32 || coords->dtype == MI_F64, MI_ERR_INVALID_ARG,
                "coordinates should have floating point dtype");
@@ -1529,6 +1529,7 @@ int mi_affine_transform(const mi_array *in, const mi_array *out, const double *m
 {
     int rc = check_interp(in, out, order, mode);
     if (rc) return rc;
+    if (order > 1 && in->ndim > 3) { set_error("orders 2-5 on rank > 3 arrays: mi_spline_affine_transform (on coefficients)"); return MI_ERR_UNSUPPORTED; }
     MI_REQUIRE(matrix, MI_ERR_INVALID_ARG, "matrix is NULL");
     MI_REQUIRE(out->ndim == in->ndim, MI_ERR_INVALID_ARG, "output rank must equal input rank");
     const int64_t nout = numel(out);
