@@ -876,6 +876,12 @@ spline_pad_kernel(const T *__restrict__ in, CF *__restrict__ out, InterpGeom g, 
 // chain runs over them in registers, the boundary sums stop once z^i is below
 // 1e-20 (SciPy sums the whole line; the neglected tail is far below one ulp), and
 // the gain is applied with the last store (the filter is linear).
+// z^(n-1) and z^n of the (up to two) poles for a line length n, computed on the HOST with the C library's pow() --
+// the function SciPy's ni_splines.c calls -- and handed to the kernels: the device pow() is accurate to an ulp, not
+// bit-identical, and on very short lines (n = 2: the power IS the pole) that last bit decided exact .5 ties of
+// integer outputs (the one mismatch class the round-2 fuzzer kept finding).
+struct SplPow { double zn1[2], zn[2]; };
+
 constexpr int kSplBatch = 8;
 
 // coefficient storage that reads / writes double whatever the element type (float32 coefficients
@@ -894,7 +900,7 @@ struct CoefLine {
 template <typename CF>
 __global__ void __launch_bounds__(64)
 spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_t n, int64_t inner, int64_t nlines, int order,
-                       int smode, int gain_first)
+                       int smode, int gain_first, SplPow pw)
 {
     const int64_t line = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (line >= nlines || n <= 1) return;
@@ -930,7 +936,7 @@ spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_
         {
             double z_i = z;
             if (smode == 0) {
-                const double z_n_1 = pow(z, (double)(n - 1));
+                const double z_n_1 = pw.zn1[k];
                 double acc = c0 + z_n_1 * rd[(n - 1) * st];
                 const int64_t m = (n - 1 < H + 1) ? n - 1 : H + 1;
                 for (int64_t i = 1; i < m; i++) { acc += z_i * (rd[i * st] + z_n_1 * rd[(n - 1 - i) * st]); z_i *= z; }
@@ -939,10 +945,10 @@ spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_
                 double acc = c0;
                 const int64_t m = (n < H + 1) ? n : H + 1;
                 for (int64_t i = 1; i < m; i++) { acc += z_i * rd[(n - i) * st]; z_i *= z; }
-                const double z_n = pow(z, (double)n);
+                const double z_n = pw.zn[k];
                 c0 = acc / (1 - z_n);
             } else {
-                const double z_n = pow(z, (double)n);
+                const double z_n = pw.zn[k];
                 double acc = c0 + z_n * rd[(n - 1) * st];
                 const int64_t m = (n < H + 1) ? n : H + 1;
                 for (int64_t i = 1; i < m; i++) {
@@ -977,7 +983,7 @@ spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_
             double z_i = z, acc = last;
             const int64_t m = (n - 1 < H) ? n - 1 : H;
             for (int64_t j = 0; j < m; j++) { acc += z_i * c[j * st]; z_i *= z; }
-            const double z_n = pow(z, (double)n);
+            const double z_n = pw.zn[k];
             last = acc * z / (z_n - 1);
         } else {
             last *= z / (z - 1);
@@ -1036,7 +1042,7 @@ __device__ __forceinline__ void spline_tile_store(const CF (&tile)[kSplTile][kSp
 
 template <typename CF>
 __global__ void __launch_bounds__(64)
-spline_filter_rows_kernel(CF *__restrict__ data, int64_t n, int64_t nlines, int order, int smode)
+spline_filter_rows_kernel(CF *__restrict__ data, int64_t n, int64_t nlines, int order, int smode, SplPow pw)
 {
     __shared__ CF tile[kSplTile][kSplTile + 1];
     const int lane = threadIdx.x;
@@ -1065,7 +1071,7 @@ spline_filter_rows_kernel(CF *__restrict__ data, int64_t n, int64_t nlines, int 
         {
             double z_i = z;
             if (smode == 0) {
-                const double z_n_1 = pow(z, (double)(n - 1));
+                const double z_n_1 = pw.zn1[k];
                 double acc = c0 + z_n_1 * c[n - 1];
                 const int64_t m = (n - 1 < H + 1) ? n - 1 : H + 1;
                 for (int64_t i = 1; i < m; i++) { acc += z_i * (c[i] + z_n_1 * c[n - 1 - i]); z_i *= z; }
@@ -1074,10 +1080,10 @@ spline_filter_rows_kernel(CF *__restrict__ data, int64_t n, int64_t nlines, int 
                 double acc = c0;
                 const int64_t m = (n < H + 1) ? n : H + 1;
                 for (int64_t i = 1; i < m; i++) { acc += z_i * c[n - i]; z_i *= z; }
-                const double z_n = pow(z, (double)n);
+                const double z_n = pw.zn[k];
                 c0 = acc / (1 - z_n);
             } else {
-                const double z_n = pow(z, (double)n);
+                const double z_n = pw.zn[k];
                 double acc = c0 + z_n * c[n - 1];
                 const int64_t m = (n < H + 1) ? n : H + 1;
                 for (int64_t i = 1; i < m; i++) {
@@ -1131,7 +1137,7 @@ spline_filter_rows_kernel(CF *__restrict__ data, int64_t n, int64_t nlines, int 
         if (smode == 0) {
             last = (z * prev2 + last) * z / (z * z - 1);
         } else if (smode == 2) {
-            const double z_n = pow(z, (double)n);
+            const double z_n = pw.zn[k];
             last = (last + wrap_acc) * z / (z_n - 1);
         } else {
             last *= z / (z - 1);
@@ -1189,7 +1195,7 @@ constexpr int kSplHorizon = 40;
 template <typename CF>
 __global__ void __launch_bounds__(64)
 spline_filter_chunked_kernel(const CF *__restrict__ src, CF *__restrict__ dst, int64_t n, int64_t inner, int64_t nlines, int order,
-                             int smode, int64_t L)
+                             int smode, int64_t L, SplPow pw)
 {
     __shared__ double ext[kSplHorizon][64];
     const int lane = threadIdx.x;
@@ -1214,13 +1220,13 @@ spline_filter_chunked_kernel(const CF *__restrict__ src, CF *__restrict__ dst, i
         double c0 = (double)rd[0];
         double z_i = z;
         if (smode == 0) {
-            const double z_n_1 = pow(z, (double)(n - 1));
+            const double z_n_1 = pw.zn1[0];
             double acc = c0 + z_n_1 * (double)rd[(n - 1) * st];
             const int64_t m = (n - 1 < H + 1) ? n - 1 : H + 1;
             for (int64_t i = 1; i < m; i++) { acc += z_i * ((double)rd[i * st] + z_n_1 * (double)rd[(n - 1 - i) * st]); z_i *= z; }
             c0 = acc / (1 - z_n_1 * z_n_1);
         } else {
-            const double z_n = pow(z, (double)n);
+            const double z_n = pw.zn[0];
             double acc = c0 + z_n * (double)rd[(n - 1) * st];
             const int64_t m = (n < H + 1) ? n : H + 1;
             for (int64_t i = 1; i < m; i++) {
@@ -1304,7 +1310,7 @@ spline_filter_chunked_kernel(const CF *__restrict__ src, CF *__restrict__ dst, i
 template <typename CF>
 __global__ void __launch_bounds__(64)
 spline_filter_rows_chunked_kernel(const CF *__restrict__ src, CF *__restrict__ dst, int64_t n, int64_t nlines, int order, int smode,
-                                  int tiles_per_chunk)
+                                  int tiles_per_chunk, SplPow pw)
 {
     __shared__ CF tile[kSplTile][kSplTile + 1];
     __shared__ double ext[kSplTile][kSplHorizon + 1];
@@ -1329,13 +1335,13 @@ spline_filter_rows_chunked_kernel(const CF *__restrict__ src, CF *__restrict__ d
         double c0 = (double)rd[0];
         double z_i = z;
         if (smode == 0) {
-            const double z_n_1 = pow(z, (double)(n - 1));
+            const double z_n_1 = pw.zn1[0];
             double acc = c0 + z_n_1 * (double)rd[n - 1];
             const int64_t m = (n - 1 < H + 1) ? n - 1 : H + 1;
             for (int64_t i = 1; i < m; i++) { acc += z_i * ((double)rd[i] + z_n_1 * (double)rd[n - 1 - i]); z_i *= z; }
             c0 = acc / (1 - z_n_1 * z_n_1);
         } else {
-            const double z_n = pow(z, (double)n);
+            const double z_n = pw.zn[0];
             double acc = c0 + z_n * (double)rd[n - 1];
             const int64_t m = (n < H + 1) ? n : H + 1;
             for (int64_t i = 1; i < m; i++) {
@@ -1634,6 +1640,18 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
     int64_t inner = 1;
     for (int d = axis + 1; d < shape->ndim; d++) inner *= shape->shape[d];
     const int64_t n = shape->shape[axis], nlines = total / n;
+    SplPow pw;
+    {
+        static const double poles[4][2] = {{-0.171572875253809902396622551580603843, 0.0},
+                                           {-0.267949192431122706472553658494127633, 0.0},
+                                           {-0.361341225900220177092212841325675255, -0.013725429297339121360331226939128204},
+                                           {-0.430575347099973791851434783493520110, -0.043096288203264653822712376822550182}};
+        for (int k = 0; k < 2; k++) {
+            const double z = poles[order - 2][k];
+            pw.zn1[k] = z != 0.0 ? pow(z, (double)(n - 1)) : 0.0;
+            pw.zn[k] = z != 0.0 ? pow(z, (double)n) : 0.0;
+        }
+    }
     const int64_t L = spline_chunk_len(shape, axis, order, spline_mode);
     if (L > 0) {
         const unsigned gy = (unsigned)((n + L - 1) / L);
@@ -1651,10 +1669,10 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
             const dim3 grid((unsigned)((nlines + kSplTile - 1) / kSplTile), (unsigned)((ntiles + tpc - 1) / tpc));
             if (shape->dtype == MI_F64)
                 hipLaunchKernelGGL(spline_filter_rows_chunked_kernel<double>, grid, dim3(64), 0, s, (const double *)src, (double *)to, n,
-                                   nlines, order, spline_mode, tpc);
+                                   nlines, order, spline_mode, tpc, pw);
             else
                 hipLaunchKernelGGL(spline_filter_rows_chunked_kernel<float>, grid, dim3(64), 0, s, (const float *)src, (float *)to, n,
-                                   nlines, order, spline_mode, tpc);
+                                   nlines, order, spline_mode, tpc, pw);
             hipError_t err = hipGetLastError();
             if (tmp) {
                 if (err == hipSuccess) err = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToDevice, s);
@@ -1666,10 +1684,10 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
         const dim3 grid((unsigned)((nlines + 63) / 64), gy);
         if (shape->dtype == MI_F64)
             hipLaunchKernelGGL(spline_filter_chunked_kernel<double>, grid, dim3(64), 0, s, (const double *)src, (double *)to, n, inner,
-                               nlines, order, spline_mode, L);
+                               nlines, order, spline_mode, L, pw);
         else
             hipLaunchKernelGGL(spline_filter_chunked_kernel<float>, grid, dim3(64), 0, s, (const float *)src, (float *)to, n, inner,
-                               nlines, order, spline_mode, L);
+                               nlines, order, spline_mode, L, pw);
         hipError_t err = hipGetLastError();
         if (tmp) {
             if (err == hipSuccess) err = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToDevice, s);
@@ -1682,9 +1700,9 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
     if (src == dst && inner == 1 && n >= 2 * kSplTile && (nlines >= 16384 || g_spline_rows_force) && !g_spline_rows_off) {
         const dim3 grid((unsigned)((nlines + kSplTile - 1) / kSplTile));
         if (shape->dtype == MI_F64)
-            hipLaunchKernelGGL(spline_filter_rows_kernel<double>, grid, dim3(64), 0, s, (double *)dst, n, nlines, order, spline_mode);
+            hipLaunchKernelGGL(spline_filter_rows_kernel<double>, grid, dim3(64), 0, s, (double *)dst, n, nlines, order, spline_mode, pw);
         else
-            hipLaunchKernelGGL(spline_filter_rows_kernel<float>, grid, dim3(64), 0, s, (float *)dst, n, nlines, order, spline_mode);
+            hipLaunchKernelGGL(spline_filter_rows_kernel<float>, grid, dim3(64), 0, s, (float *)dst, n, nlines, order, spline_mode, pw);
         MI_HIP(hipGetLastError());
         return MI_OK;
     }
@@ -1692,10 +1710,10 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
     const dim3 grid((unsigned)((nlines + 63) / 64));
     if (shape->dtype == MI_F64)
         hipLaunchKernelGGL(spline_filter1d_kernel<double>, grid, dim3(64), 0, s, (double *)dst, (const double *)from, n, inner, nlines,
-                           order, spline_mode, g_spline_gain_first);
+                           order, spline_mode, g_spline_gain_first, pw);
     else
         hipLaunchKernelGGL(spline_filter1d_kernel<float>, grid, dim3(64), 0, s, (float *)dst, (const float *)from, n, inner, nlines,
-                           order, spline_mode, g_spline_gain_first);
+                           order, spline_mode, g_spline_gain_first, pw);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }

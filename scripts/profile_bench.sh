@@ -11,10 +11,10 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 ARGS="$R/bench.py --steps 20 --warmup 5 --no-cpu"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $ARGS > $O/bench_stats.json 2> $O/stats.err
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o b -- python3 $ARGS > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $O/pmc_write -o b -- python3 $ARGS > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU -d $O/pmc_sq -o b -- python3 $ARGS > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $ARGS > $O/bench_stats.json 2> $O/stats.err
+timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o b -- python3 $ARGS > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $O/pmc_write -o b -- python3 $ARGS > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU -d $O/pmc_sq -o b -- python3 $ARGS > /dev/null 2>&1
 cd $O && python3 - <<'PY' > summary.txt
 import csv, glob, collections
 print("# rocprofv3 summary for: python3 bench.py --steps 20 --warmup 5 --no-cpu")

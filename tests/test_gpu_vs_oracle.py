@@ -1283,9 +1283,9 @@ def test_rank_filters_beyond_128_taps_and_rank3(gpu, ndi):
         ref = sndi.median_filter(x3, size=7, mode=mode, cval=0.5)                         # 343 samples
         assert np.array_equal(ndi.median_filter(gpu.asarray(x3), size=7, mode=mode, cval=0.5).get(), ref), mode
     img = rng.integers(0, 1 << 16, size=(40, 52)).astype(np.uint16)
-    fp = rng.random((11, 13)) > 0.2                                                      # ~114 .. 143 samples, some > 128
+    fp = rng.random((11, 13)) > 0.06                                                     # 143 positions, a few dropped
     fp[0, :] = True; fp[:, 0] = True
-    assert fp.sum() > 128
+    assert 128 < fp.sum() < 143
     for rank in (0, 5, int(fp.sum()) // 2, int(fp.sum()) - 2):
         ref = sndi.rank_filter(img, rank, footprint=fp, mode="mirror", origin=(1, -2))
         assert np.array_equal(ndi.rank_filter(gpu.asarray(img), rank, footprint=fp, mode="mirror", origin=(1, -2)).get(), ref), rank
