@@ -46,6 +46,9 @@ def _spline_mode_code(mode):
     return 0
 
 
+_SPLINE_EXACT = 0x100      # csrc/interp.hip kSplExact
+
+
 def _float32_route(src, out_dtype, order, allow_float32):
     """float32 image, float32 result, cubic spline: coefficients are stored as float32 and the
     gather kernel works in float32 (the reference's `allow_float32`, interpolation.py:330-335;
@@ -54,11 +57,13 @@ def _float32_route(src, out_dtype, order, allow_float32):
             and src.ndim <= 3 and src.size < (1 << 28))
 
 
-def _to_coefficients(input, order, mode, cval, prefilter, f32=False):
+def _to_coefficients(input, order, mode, cval, prefilter, f32=False, exact=False):
     """(device array of B-spline coefficients, npad) for orders 2-5: float64, or float32
     on the float32 cubic route (the recursion itself always runs in double).
     SciPy pads by 12 samples for `nearest` / `grid-constant` before filtering;
-    prefilter=False interpolates the samples as if they were coefficients."""
+    prefilter=False interpolates the samples as if they were coefficients.
+    `exact`: only prefilter kernels whose arithmetic is SciPy's operation for operation (no blocked recursion) --
+    set when the result is rounded to an integer dtype, where the last bit of a coefficient decides exact .5 ties."""
     src = core.ascontiguousarray(input)
     npad, pad_mode = 0, 0
     if prefilter and mode in ("nearest", "grid-constant"):
@@ -69,8 +74,8 @@ def _to_coefficients(input, order, mode, cval, prefilter, f32=False):
     a, b = src._desc(), coef._desc()
     lib = S.lib()
     if prefilter:
-        S.check(lib.mi_spline_prefilter(ctypes.byref(a), ctypes.byref(b), int(order), _spline_mode_code(mode), npad,
-                                        pad_mode, float(cval), None))
+        S.check(lib.mi_spline_prefilter(ctypes.byref(a), ctypes.byref(b), int(order),
+                                        _spline_mode_code(mode) | (_SPLINE_EXACT if exact else 0), npad, pad_mode, float(cval), None))
     else:
         S.check(lib.mi_spline_pad(ctypes.byref(a), ctypes.byref(b), npad, pad_mode, float(cval), None))
     return coef, npad
@@ -194,7 +199,8 @@ def map_coordinates(input, coordinates, output=None, order=3, mode="constant", c
     lib = S.lib()
     if order > 1:
         coef, npad = _to_coefficients(src, order, mode, cval, prefilter,
-                                      ret.ndim <= 3 and _float32_route(src, ret.dtype, order, allow_float32))
+                                      ret.ndim <= 3 and _float32_route(src, ret.dtype, order, allow_float32),
+                                      exact=ret.dtype.kind in "iub")
         if coef is src and core.shares_memory(ret, src):
             coef = src.copy()
         ca_ = coef._desc()
@@ -265,7 +271,8 @@ def _affine(input, m, out, order, mode, cval, prefilter, allow_float32=True):
     src = core.ascontiguousarray(input)
     lib = S.lib()
     if order > 1:
-        coef, npad = _to_coefficients(src, order, mode, cval, prefilter, _float32_route(src, out.dtype, order, allow_float32))
+        coef, npad = _to_coefficients(src, order, mode, cval, prefilter, _float32_route(src, out.dtype, order, allow_float32),
+                                      exact=out.dtype.kind in "iub")
         if coef is src and core.shares_memory(out, src):
             coef = src.copy()
         ca_ = coef._desc()
