@@ -254,3 +254,36 @@ def test_simple_metrics(gpu, metrics):
     f = rng.random((16, 16)).astype(np.float32) * 3       # outside [-1, 1]
     with pytest.raises(ValueError):
         metrics.peak_signal_noise_ratio(gpu.asarray(f), gpu.asarray(f))
+
+
+# ------------------------------------------------------------------ r3: committed known-answer fixture
+def test_skimage_known_answer_fixture(gpu, skm):
+    """tests/golden/skimage_kat.json: the reference's literal vectors (test_grey.py:222-333, test_binary.py:52-58,
+    134-148, the grey.py docstrings) replayed through the facade -- float images with assert_allclose's 1e-7, integer
+    and bool images exactly, strided `out`, default elements."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "skimage_kat.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 20
+    for c in cases:
+        img = np.array(c["image"], dtype=c["dtype"])
+        want = np.array(c["expected"], dtype=c["expected_dtype"])
+        fn = getattr(skm, c["func"])
+        args = [gpu.asarray(img)]
+        if "selem_ones" in c:
+            args.append(gpu.asarray(np.ones(c["selem_ones"], np.uint8)))
+        if "out_step" in c:
+            big = gpu.zeros(tuple(c["out_big_shape"]), want.dtype)
+            view = big[::c["out_step"], ::c["out_step"]]
+            fn(*args, out=view)
+            got = big.get()
+        else:
+            got = fn(*args).get()
+        assert got.shape == want.shape, c["name"]
+        if img.dtype.kind == "f":
+            assert np.allclose(got, want, rtol=1e-7, atol=0), c["name"]
+        else:
+            assert np.array_equal(got.astype(want.dtype), want), c["name"]
+            if c["func"].startswith("binary"):
+                assert got.dtype == np.bool_, c["name"]
