@@ -952,7 +952,9 @@ spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_
                 double acc = c0;
                 const int64_t m = (n < H + 1) ? n : H + 1;
                 for (int64_t i = 1; i < m; i++) { acc += z_i * rd[(n - i) * st]; z_i *= z; }
-                const double z_n = pw.zn[k];
+                // SciPy divides by 1 - z_i with the RUNNING product of its loop (z^n by repeated multiplication, not
+                // pow): the same value here whenever the loop ran to the end; beyond the horizon 1 - z^n is 1 either way
+                const double z_n = m == n ? z_i : pw.zn[k];
                 c0 = acc / (1 - z_n);
             } else {
                 const double z_n = pw.zn[k];
@@ -990,7 +992,7 @@ spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_
             double z_i = z, acc = last;
             const int64_t m = (n - 1 < H) ? n - 1 : H;
             for (int64_t j = 0; j < m; j++) { acc += z_i * c[j * st]; z_i *= z; }
-            const double z_n = pw.zn[k];
+            const double z_n = m == n - 1 ? z_i : pw.zn[k];        // running product, as SciPy (see the causal start)
             last = acc * z / (z_n - 1);
         } else {
             last *= z / (z - 1);
@@ -1087,7 +1089,7 @@ spline_filter_rows_kernel(CF *__restrict__ data, int64_t n, int64_t nlines, int 
                 double acc = c0;
                 const int64_t m = (n < H + 1) ? n : H + 1;
                 for (int64_t i = 1; i < m; i++) { acc += z_i * c[n - i]; z_i *= z; }
-                const double z_n = pw.zn[k];
+                const double z_n = m == n ? z_i : pw.zn[k];
                 c0 = acc / (1 - z_n);
             } else {
                 const double z_n = pw.zn[k];
@@ -1649,6 +1651,9 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
     for (int d = axis + 1; d < shape->ndim; d++) inner *= shape->shape[d];
     const int64_t n = shape->shape[axis], nlines = total / n;
     const int64_t L = spline_chunk_len(shape, axis, order, spline_mode);
+    // grid-wrap in the tiled rows kernel: the anti-causal start adds its boundary sum to c[n-1] in one piece, SciPy term
+    // by term -- equal to an ulp, not to the bit
+    const bool rows_ok = !((spline_mode & kSplExact) && (spline_mode & 0xff) == 2);
     spline_mode &= 0xff;
     SplPow pw;
     {
@@ -1706,7 +1711,7 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
         return MI_OK;
     }
     // enough lines to fill the chip with one wave per 64 lines; images with few, long lines keep one thread per line
-    if (src == dst && inner == 1 && n >= 2 * kSplTile && (nlines >= 16384 || g_spline_rows_force) && !g_spline_rows_off) {
+    if (src == dst && inner == 1 && n >= 2 * kSplTile && (nlines >= 16384 || g_spline_rows_force) && !g_spline_rows_off && rows_ok) {
         const dim3 grid((unsigned)((nlines + kSplTile - 1) / kSplTile));
         if (shape->dtype == MI_F64)
             hipLaunchKernelGGL(spline_filter_rows_kernel<double>, grid, dim3(64), 0, s, (double *)dst, n, nlines, order, spline_mode, pw);

@@ -435,6 +435,194 @@ map_coords3d_c1_kernel(const float *__restrict__ in, const float *__restrict__ c
     c1_store_rows<ZMAJ>(out, p, tile, lane, mp, ty, x0w, r, wide);
 }
 
+// ---------------------------------------------------------------------------
+// r3: affine_transform, order 1, constant mode, float32 volumes -- gathers out of LDS.
+//
+// Why: the gather kernels above are bound by the L1's tag pipeline, not by HBM and not by the VALU: rocprofv3 counts
+// 99 cache accesses per 64 voxels (TCP_TOTAL_CACHE_ACCESSES; ~25 per 8-byte gather instruction, the L1 serves a wave
+// four lanes at a time) = 386 us of the 414 us config D' takes, while a ds_read2_b32 serves the same pair in 4 cycles
+// per wave.  An affine map sends an output tile to a parallelepiped whose bounding box is known from |M| alone, so:
+//   * a workgroup (8 waves) owns 64 x 8 x 8 output voxels; the bounding box of their taps -- BZ x BY x BX input
+//     samples, dimensions computed by the host from the matrix, origin from the tile's eight corners -- is staged
+//     global -> LDS with `buffer_load_dwordx4 ... lds` (16 bytes per lane, no VGPRs, LDS layout = the box row-major, so
+//     a wave's 64 chunks are consecutive LDS addresses); rows / planes beyond the volume are zero-filled by the
+//     descriptor's range check and never read;
+//   * coordinates, in-range tests and blending are those of affine3d_c1_kernel (same c1_split, same finish): the
+//     results are bit-identical to it;
+//   * the eight taps of a voxel are four ds_read2_b32 (x and x + 1 in one instruction);
+//   * two workgroups per CU (<= 64 KiB of box each): one computes while the other's box is in flight.
+// Transforms whose box exceeds that budget (large rotations about z / y with this tile, down-scaling by > 2) keep the
+// L1 gather kernel -- the choice is made on the host from the matrix.
+// ---------------------------------------------------------------------------
+constexpr int kLdsTX = 64, kLdsTY = 8, kLdsTZ = 8;
+constexpr int kLdsBoxBytesMax = 64 * 1024 - 12 * 1024;      // box budget per workgroup (+ prefix table + store tiles: two workgroups per CU)
+
+struct LdsAffineParams {
+    FastInterpParams f;
+    int bz, by, bx;          // box dimensions (bx a multiple of 4)
+    int nchunks;             // bz * by * bx / 4 sixteen-byte chunks
+    float inv_cpr;           // 1 / (chunks per box row), for the chunk -> row division
+};
+
+__device__ __forceinline__ void dma_16(u32x2 dummy, const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_base)
+{
+    (void)dummy;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(lds_base)
+        : "memory");
+}
+
+__global__ void __launch_bounds__(512)
+affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const LdsAffineParams q)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_lds[];
+    const FastInterpParams &p = q.f;
+    float *box = reinterpret_cast<float *>(smem_lds);
+    const unsigned box_bytes = ((unsigned)q.nchunks * 16u + 8191u) & ~8191u;          // whole rounds of 512 chunks
+    double (*ptab)[3] = reinterpret_cast<double (*)[3]>(smem_lds + box_bytes);        // [kLdsTZ * kLdsTY][3]
+    float *tiles = reinterpret_cast<float *>(smem_lds + box_bytes + kLdsTZ * kLdsTY * 3 * sizeof(double));   // [8 waves][256]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0w = blockIdx.x * kLdsTX, y0 = blockIdx.y * kLdsTY, z0 = blockIdx.z * kLdsTZ;
+
+    // ---- box origin: floor of the smallest coordinate over the tile's corners (the map is affine: extremes sit at
+    // corners), clamped into the volume; x aligned down to a multiple of four samples (16-byte chunks)
+    int b0[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        double lo = 1e300;
+#pragma unroll
+        for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+            for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+                for (int cx = 0; cx < 2; cx++) {
+                    const double c = ((p.m[4 * a] * (double)(z0 + cz * (kLdsTZ - 1)) + p.m[4 * a + 1] * (double)(y0 + cy * (kLdsTY - 1))) +
+                                      p.m[4 * a + 2] * (double)(x0w + cx * (kLdsTX - 1))) + p.m[4 * a + 3];
+                    lo = c < lo ? c : lo;
+                }
+        const int n = a == 0 ? p.nz : (a == 1 ? p.ny : p.nx);
+        // one below the floor: the corner sums above are not the per-voxel sums to the last bit
+        double f = floor(lo) - 1.0;
+        f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
+        b0[a] = (int)f;
+    }
+    b0[2] &= ~3;
+
+    // ---- stage the box
+    {
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
+        const int cpr = q.bx >> 2;
+        const int rounds = (q.nchunks + 511) >> 9;
+        for (int j = 0; j < rounds; j++) {
+            const int ch = tid + (j << 9);
+            int row = (int)(((float)ch + 0.5f) * q.inv_cpr);
+            int c4 = ch - row * cpr;
+            if (c4 < 0) { row--; c4 += cpr; } else if (c4 >= cpr) { row++; c4 -= cpr; }
+            const int rz = row / q.by, ry = row - rz * q.by;         // by is small; once per chunk
+            const int sz_ = b0[0] + rz, sy_ = b0[1] + ry, sx_ = b0[2] + 4 * c4;
+            const bool ok = ch < q.nchunks && sz_ < p.nz && sy_ < p.ny && sx_ < p.nx;
+            const unsigned voff = ok ? (unsigned)((sz_ * p.ny + sy_) * p.nx + sx_) * 4u : 0x80000000u;
+            dma_16((u32x2){0u, 0u}, rin, voff, (unsigned)((wave << 6) + (j << 9)) * 16u);
+        }
+    }
+    if (tid < kLdsTZ * kLdsTY * 3) {
+        const int rr = tid / 3, a = tid - 3 * rr;                  // rr = 8 k + w  <->  plane z0 + k, row y0 + w
+        ptab[rr][a] = p.m[4 * a] * (double)(z0 + (rr >> 3)) + p.m[4 * a + 1] * (double)(y0 + (rr & 7));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- interpolate: lane = x, wave = row, k = plane; two batches of four planes
+    const double dx = (double)(x0w + lane);
+    const double xz_ = p.m[2] * dx, xy_ = p.m[6] * dx, xx_ = p.m[10] * dx;
+    const int plane_f = q.by * q.bx;
+    float *tile = tiles + wave * 256;
+    const bool wide = x0w + kLdsTX <= p.ox && y0 + kLdsTY <= p.oy && z0 + kLdsTZ <= p.oz;      // block-uniform
+#pragma unroll 1
+    for (int bt = 0; bt < 2; bt++) {
+        float r[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int k = 4 * bt + kk;
+            const int rr = 8 * k + wave;
+            const C1Split sz = c1_split((ptab[rr][0] + xz_) + p.m[3]);
+            const C1Split sy = c1_split((ptab[rr][1] + xy_) + p.m[7]);
+            const C1Split sx = c1_split((ptab[rr][2] + xx_) + p.m[11]);
+            Taps<float> t;
+            t.wz1 = sz.w1; t.wy1 = sy.w1; t.wx1 = sx.w1;
+            const bool in_z = !sz.neg & (((unsigned)sz.i0 < (unsigned)(p.nz - 1)) | ((sz.i0 == p.nz - 1) & sz.frz));
+            const bool in_y = !sy.neg & (((unsigned)sy.i0 < (unsigned)(p.ny - 1)) | ((sy.i0 == p.ny - 1) & sy.frz));
+            const bool in_x = !sx.neg & (((unsigned)sx.i0 < (unsigned)(p.nx - 1)) | ((sx.i0 == p.nx - 1) & sx.frz));
+            t.outside = !(in_z & in_y & in_x);
+            t.oobmask = 0;
+            const bool zz = t.wz1 == 0.f, yz = t.wy1 == 0.f;
+            // at the last column the pair (x0, x0 + 1) reaches one sample past the row: whatever the box holds there is
+            // never used (wx1 == 0 selects the lower sample)
+            const int li = t.outside ? 0 : ((sz.i0 - b0[0]) * q.by + (sy.i0 - b0[1])) * q.bx + (sx.i0 - b0[2]);
+            const int stz = (t.outside | zz | (sz.i0 >= p.nz - 1)) ? 0 : plane_f;
+            const int sty = (t.outside | yz | (sy.i0 >= p.ny - 1)) ? 0 : q.bx;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const float *src = box + li + (m >> 1) * stz + (m & 1) * sty;
+                t.v[2 * m] = src[0];
+                t.v[2 * m + 1] = src[1];
+            }
+            r[kk] = finish<float>(t, (float)p.cval);
+        }
+        if (wide) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) tile[kk * 64 + lane] = r[kk];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int i = lane >> 4, c = lane & 15;
+            const f32x4n v = *reinterpret_cast<const f32x4n *>(tile + i * 64 + 4 * c);
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)(z0 + 4 * bt + i) * p.oy + (y0 + wave)) * p.ox + x0w + 4 * c));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            const int x = x0w + lane, y = y0 + wave;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int z = z0 + 4 * bt + kk;
+                if (x < p.ox && y < p.oy && z < p.oz) __builtin_nontemporal_store(r[kk], out + ((size_t)z * p.oy + y) * p.ox + x);
+            }
+        }
+    }
+}
+
+// box dimensions of a kLdsTZ x kLdsTY x kLdsTX output tile under the matrix (upper bound from |M|), or false when the
+// box does not fit the LDS budget of two workgroups per CU
+static bool lds_affine_plan(const FastInterpParams &p, LdsAffineParams *q)
+{
+    const int T[3] = {kLdsTZ - 1, kLdsTY - 1, kLdsTX - 1};
+    int dim[3];
+    for (int a = 0; a < 3; a++) {
+        double ext = 0.0;
+        for (int j = 0; j < 3; j++) ext += fabs(p.m[4 * a + j]) * T[j];
+        if (!(ext < 4096.0)) return false;
+        // + 1 upper tap, + 1 the floor of the start, + 1 the margin below the corner minimum, + 1 rounding
+        dim[a] = (int)ceil(ext) + 4;
+    }
+    dim[2] = (dim[2] + 3 + 3) & ~3;                 // origin aligned down by up to 3, length a multiple of 4
+    const int n[3] = {p.nz, p.ny, p.nx};
+    for (int a = 0; a < 2; a++) if (dim[a] > n[a]) dim[a] = n[a];
+    if (dim[2] > ((n[2] + 3) & ~3) + 4) dim[2] = ((n[2] + 3) & ~3) + 4;
+    const long long floats = (long long)dim[0] * dim[1] * dim[2];
+    if (floats * 4 > kLdsBoxBytesMax) return false;
+    q->f = p;
+    q->bz = dim[0]; q->by = dim[1]; q->bx = dim[2];
+    q->nchunks = (int)(floats / 4);
+    q->inv_cpr = 1.0f / (float)(dim[2] / 4);
+    return true;
+}
+
 constexpr int kNV = 4;   // voxels per thread (rows 4 apart), all gathers issued before any is used
 
 // block = (64, 4): 64 lanes along x (one voxel each, so every gather instruction of a
@@ -505,7 +693,7 @@ affine3d_fast(const T *__restrict__ in, T *__restrict__ out, const FastInterpPar
         if (ok[k]) __builtin_nontemporal_store(finish<T>(t[k], (T)p.cval), out + o[k]);
 }
 
-Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads, 3 = r3 with z-major voxel ownership
+Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads, 3 = r3 with z-major voxel ownership, 5 = r3 (L1 gathers) without the LDS-staged affine kernel; 1 (default) and 4 use the LDS-staged affine kernel when the box fits
 
 static bool fast_ok(const mi_array *in, const mi_array *out, int order)
 {
@@ -591,6 +779,23 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
     const dim3 block(64, 4, 1);
     const dim3 grid((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 4 * kNV - 1) / (4 * kNV)), (unsigned)p.oz);
     const int var = g_interp_c1;
+    if (mode == MI_MODE_CONSTANT && order == 1 && (var == 1 || var == 4) && !p.two_d && in->dtype == MI_F32 && (p.ox & 3) == 0 &&
+        (int64_t)p.oz * p.oy * p.ox >= (1 << 18)) {
+        // gathers out of LDS when the tile's bounding box fits (the choice depends on the matrix only)
+        LdsAffineParams q;
+        const dim3 gl((unsigned)((p.ox + kLdsTX - 1) / kLdsTX), (unsigned)((p.oy + kLdsTY - 1) / kLdsTY), (unsigned)((p.oz + kLdsTZ - 1) / kLdsTZ));
+        if (lds_affine_plan(p, &q) && gl.y <= 65535 && gl.z <= 65535) {
+            const size_t lds = (((size_t)q.nchunks * 16 + 8191) & ~(size_t)8191) + kLdsTZ * kLdsTY * 3 * sizeof(double) + 8 * 256 * sizeof(float);
+            static bool attr_done = false;
+            if (!attr_done) {
+                MI_HIP(hipFuncSetAttribute((const void *)affine3d_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(affine3d_lds_kernel, gl, dim3(512), lds, s, (const float *)in->data, (float *)out->data, q);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        }
+    }
     if (mode == MI_MODE_CONSTANT && order == 1 && var && !p.two_d && in->dtype == MI_F32 && (p.ox & 3) == 0) {
         const float *ip = (const float *)in->data;
         float *op = (float *)out->data;
