@@ -693,7 +693,7 @@ affine3d_fast(const T *__restrict__ in, T *__restrict__ out, const FastInterpPar
         if (ok[k]) __builtin_nontemporal_store(finish<T>(t[k], (T)p.cval), out + o[k]);
 }
 
-Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads, 3 = r3 with z-major voxel ownership, 5 = r3 (L1 gathers) without the LDS-staged affine kernel; 1 (default) and 4 use the LDS-staged affine kernel when the box fits
+Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads, 3 = r3 with z-major voxel ownership, 5 = r3 (L1 gathers) without the LDS-staged affine kernel; 1 (default) and 4 use the LDS-staged affine kernel when the box fits, 6 = row-major ownership for map_coordinates
 
 static bool fast_ok(const mi_array *in, const mi_array *out, int order)
 {
@@ -734,8 +734,9 @@ int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_ar
         const float *ip = (const float *)in->data, *cp = (const float *)coords->data;
         float *op = (float *)out->data;
         const dim3 gridz((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 3) / 4), (unsigned)((p.oz + 3) / 4));
-        if (var == 3 && gridz.y <= 65535 && gridz.z <= 65535) hipLaunchKernelGGL((map_coords3d_c1_kernel<true, true>), gridz, block, 0, s, ip, cp, op, p);
-        else if (var == 2) hipLaunchKernelGGL((map_coords3d_c1_kernel<false, false>), grid, block, 0, s, ip, cp, op, p);
+        // default: z-major voxel ownership (config D: 605 us against 623 us row-major, profiles/r3_interp_variants.txt)
+        if (var == 2) hipLaunchKernelGGL((map_coords3d_c1_kernel<false, false>), grid, block, 0, s, ip, cp, op, p);
+        else if (var != 6 && gridz.y <= 65535 && gridz.z <= 65535) hipLaunchKernelGGL((map_coords3d_c1_kernel<true, true>), gridz, block, 0, s, ip, cp, op, p);
         else hipLaunchKernelGGL((map_coords3d_c1_kernel<true, false>), grid, block, 0, s, ip, cp, op, p);
         MI_HIP(hipGetLastError());
         return MI_OK;

@@ -1199,14 +1199,14 @@ def test_order1_constant_kernels_r3(gpu, ndi, case):
     refm = orc.map_coordinates(x, coords, order=1, mode="constant", cval=-0.75)
     cd = gpu.asarray(coords)
     outm = {}
-    for var in (1, 2, 3, 0):
+    for var in (1, 2, 3, 6, 0):
         lib.mi_debug_set_interp_c1(var)
         try:
             outm[var] = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
         finally:
             lib.mi_debug_set_interp_c1(1)
     assert np.allclose(outm[1], refm, rtol=0, atol=2e-6 * max(1.0, np.abs(refm).max()))
-    assert np.array_equal(outm[1], outm[2]) and np.array_equal(outm[1], outm[3]) and np.array_equal(outm[1], outm[0])
+    assert all(np.array_equal(outm[1], outm[v]) for v in (2, 3, 6, 0))
 
 
 def test_order1_constant_kernels_r3_nonfinite_and_edges(gpu, ndi):
