@@ -494,10 +494,11 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
     const int x0w = blockIdx.x * kLdsTX, y0 = blockIdx.y * kLdsTY, z0 = blockIdx.z * kLdsTZ;
 
     // ---- box origin: floor of the smallest coordinate over the tile's corners (the map is affine: extremes sit at
-    // corners), clamped into the volume; x aligned down to a multiple of four samples (16-byte chunks)
-    int b0[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
+    // corners), clamped into the volume; x aligned down to a multiple of four samples (16-byte chunks).  Computed by
+    // three lanes (one per axis) and broadcast through LDS: it is the same for the whole workgroup.
+    int *b0s = reinterpret_cast<int *>(tiles);           // the store tiles are not in use yet
+    if (tid < 3) {
+        const int a = tid;
         double lo = 1e300;
 #pragma unroll
         for (int cz = 0; cz < 2; cz++)
@@ -510,28 +511,33 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
                     lo = c < lo ? c : lo;
                 }
         const int n = a == 0 ? p.nz : (a == 1 ? p.ny : p.nx);
-        // one below the floor: the corner sums above are not the per-voxel sums to the last bit
-        double f = floor(lo) - 1.0;
+        // the corner sums are not the per-voxel sums to the last bit: a hair below the minimum
+        double f = floor(lo - 1e-6 * (1.0 + fabs(lo)));
         f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
-        b0[a] = (int)f;
+        b0s[a] = a == 2 ? ((int)f & ~3) : (int)f;
     }
-    b0[2] &= ~3;
+    __syncthreads();
+    const int b0[3] = {__builtin_amdgcn_readfirstlane(b0s[0]), __builtin_amdgcn_readfirstlane(b0s[1]), __builtin_amdgcn_readfirstlane(b0s[2])};
 
-    // ---- stage the box
+    // ---- stage the box: chunk ch = tid + 512 j  ->  (box row, 16-byte chunk of the row); the division is done once,
+    // the later rounds advance (row, chunk) and (plane, row in plane) by constants
     {
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
         const int cpr = q.bx >> 2;
         const int rounds = (q.nchunks + 511) >> 9;
+        int row = tid / cpr, c4 = tid - row * cpr;
+        int rz = row / q.by, ry = row - rz * q.by;
+        const int drow = 512 / cpr, dc4 = 512 - drow * cpr;
+        const int drz = drow / q.by, dry = drow - drz * q.by;
         for (int j = 0; j < rounds; j++) {
-            const int ch = tid + (j << 9);
-            int row = (int)(((float)ch + 0.5f) * q.inv_cpr);
-            int c4 = ch - row * cpr;
-            if (c4 < 0) { row--; c4 += cpr; } else if (c4 >= cpr) { row++; c4 -= cpr; }
-            const int rz = row / q.by, ry = row - rz * q.by;         // by is small; once per chunk
             const int sz_ = b0[0] + rz, sy_ = b0[1] + ry, sx_ = b0[2] + 4 * c4;
-            const bool ok = ch < q.nchunks && sz_ < p.nz && sy_ < p.ny && sx_ < p.nx;
+            const bool ok = tid + (j << 9) < q.nchunks && sz_ < p.nz && sy_ < p.ny && sx_ < p.nx;
             const unsigned voff = ok ? (unsigned)((sz_ * p.ny + sy_) * p.nx + sx_) * 4u : 0x80000000u;
             dma_16((u32x2){0u, 0u}, rin, voff, (unsigned)((wave << 6) + (j << 9)) * 16u);
+            c4 += dc4; ry += dry; rz += drz;
+            if (c4 >= cpr) { c4 -= cpr; ry++; }
+            if (ry >= q.by) { ry -= q.by; rz++; }
+            if (ry >= q.by) { ry -= q.by; rz++; }
         }
     }
     if (tid < kLdsTZ * kLdsTY * 3) {
@@ -607,8 +613,9 @@ static bool lds_affine_plan(const FastInterpParams &p, LdsAffineParams *q)
         double ext = 0.0;
         for (int j = 0; j < 3; j++) ext += fabs(p.m[4 * a + j]) * T[j];
         if (!(ext < 4096.0)) return false;
-        // + 1 upper tap, + 1 the floor of the start, + 1 the margin below the corner minimum, + 1 rounding
-        dim[a] = (int)ceil(ext) + 4;
+        // samples floor(min - hair) .. floor(max) + 1 with max - min <= ext: at most floor(ext + hair) + 3 of them (the
+        // hair: what the origin is moved below the corner minimum, 1e-6 (1 + |c|) <= 2e-3)
+        dim[a] = (int)floor(ext * (1.0 + 1e-6) + 2e-3) + 3;
     }
     dim[2] = (dim[2] + 3 + 3) & ~3;                 // origin aligned down by up to 3, length a multiple of 4
     const int n[3] = {p.nz, p.ny, p.nx};

@@ -6,7 +6,7 @@ import numpy as np, scipy.ndimage as sndi
 import cupyimg_amd as ca
 from cupyimg_amd.scipy import ndimage as ndi
 rng = np.random.default_rng(5)
-for shape, sh, mode in [((12, 2, 260), [0.0, 1.5, 0.0], 'wrap'), ((21, 2), [0.0, -2.25], 'mirror'), ((2, 1, 29), [1.5, 0.3, 0.0], 'mirror'),
+for shape, sh, mode in [((2, 36, 264), [1.5, 0.0, 0.0], 'grid-wrap'), ((2, 36, 264), [1.5, 0.0, 0.0], 'reflect'), ((12, 2, 260), [0.0, 1.5, 0.0], 'wrap'), ((21, 2), [0.0, -2.25], 'mirror'), ((2, 1, 29), [1.5, 0.3, 0.0], 'mirror'),
                         ((8, 2, 520), [0.0, 1.5, 0.0], 'mirror'), ((9, 7, 33), [0.5, 1.5, 0.25], 'reflect')]:
     x = rng.integers(-200, 250, size=shape).astype(np.float64)
     xd = ca.asarray(x)
@@ -26,4 +26,6 @@ for shape, sh, mode in [((12, 2, 260), [0.0, 1.5, 0.0], 'wrap'), ((21, 2), [0.0,
     gotf = ndi.shift(xd, sh, order=3, mode=mode).get()
     print(shape, mode, "full shift (float64): bit mismatches", int((gotf != reff).sum()), "of", reff.size)
     xi = x.astype(np.int32)
+    xu = np.abs(x).astype(np.uint16)
+    print(shape, mode, 'full shift (uint16):  mismatches', int((ndi.shift(ca.asarray(xu), sh, order=3, mode=mode).get() != sndi.shift(xu, sh, order=3, mode=mode)).sum()))
     print(shape, mode, "full shift (int32):   mismatches", int((ndi.shift(ca.asarray(xi), sh, order=3, mode=mode).get() != sndi.shift(xi, sh, order=3, mode=mode)).sum()))
