@@ -454,19 +454,19 @@ map_coords3d_c1_kernel(const float *__restrict__ in, const float *__restrict__ c
 // Transforms whose box exceeds that budget (large rotations about z / y with this tile, down-scaling by > 2) keep the
 // L1 gather kernel -- the choice is made on the host from the matrix.
 // ---------------------------------------------------------------------------
-constexpr int kLdsTX = 64, kLdsTY = 8, kLdsTZ = 8;
-constexpr int kLdsBoxBytesMax = 64 * 1024 - 12 * 1024;      // box budget per workgroup (+ prefix table + store tiles: two workgroups per CU)
+constexpr int kLdsTZ = 8;                                   // tile: TX x (512 / TX) x 8 output voxels, TX = 64 or 32
+constexpr int kLdsBoxBytesMax = 36 * 1024;                  // box budget per workgroup: three or four workgroups per CU.  Bigger
+                                                            // boxes (amplification > ~2.2, two workgroups per CU) measured SLOWER
+                                                            // than the L1 gathers (config D' with the 64-wide tile: 443 vs 414 us)
 
 struct LdsAffineParams {
     FastInterpParams f;
     int bz, by, bx;          // box dimensions (bx a multiple of 4)
     int nchunks;             // bz * by * bx / 4 sixteen-byte chunks
-    float inv_cpr;           // 1 / (chunks per box row), for the chunk -> row division
 };
 
-__device__ __forceinline__ void dma_16(u32x2 dummy, const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_base)
+__device__ __forceinline__ void dma_16(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_base)
 {
-    (void)dummy;
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -479,19 +479,23 @@ __device__ __forceinline__ void dma_16(u32x2 dummy, const __amdgpu_buffer_rsrc_t
         : "memory");
 }
 
+template <int TX>
 __global__ void __launch_bounds__(512)
 affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const LdsAffineParams q)
 {
+    constexpr int RW = 64 / TX;              // output rows per wave
+    constexpr int TY = 8 * RW, TZ = kLdsTZ;
     extern __shared__ __attribute__((aligned(16))) char smem_lds[];
     const FastInterpParams &p = q.f;
     float *box = reinterpret_cast<float *>(smem_lds);
     const unsigned box_bytes = ((unsigned)q.nchunks * 16u + 8191u) & ~8191u;          // whole rounds of 512 chunks
-    double (*ptab)[3] = reinterpret_cast<double (*)[3]>(smem_lds + box_bytes);        // [kLdsTZ * kLdsTY][3]
-    float *tiles = reinterpret_cast<float *>(smem_lds + box_bytes + kLdsTZ * kLdsTY * 3 * sizeof(double));   // [8 waves][256]
+    double (*ptab)[3] = reinterpret_cast<double (*)[3]>(smem_lds + box_bytes);        // [TZ * TY][3]
+    float *tiles = reinterpret_cast<float *>(smem_lds + box_bytes + TZ * TY * 3 * sizeof(double));   // [8 waves][256]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0w = blockIdx.x * kLdsTX, y0 = blockIdx.y * kLdsTY, z0 = blockIdx.z * kLdsTZ;
+    const int lx = lane & (TX - 1), yy = lane / TX;
+    const int x0w = blockIdx.x * TX, y0 = blockIdx.y * TY, z0 = blockIdx.z * TZ;
 
     // ---- box origin: floor of the smallest coordinate over the tile's corners (the map is affine: extremes sit at
     // corners), clamped into the volume; x aligned down to a multiple of four samples (16-byte chunks).  Computed by
@@ -506,8 +510,8 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
             for (int cy = 0; cy < 2; cy++)
 #pragma unroll
                 for (int cx = 0; cx < 2; cx++) {
-                    const double c = ((p.m[4 * a] * (double)(z0 + cz * (kLdsTZ - 1)) + p.m[4 * a + 1] * (double)(y0 + cy * (kLdsTY - 1))) +
-                                      p.m[4 * a + 2] * (double)(x0w + cx * (kLdsTX - 1))) + p.m[4 * a + 3];
+                    const double c = ((p.m[4 * a] * (double)(z0 + cz * (TZ - 1)) + p.m[4 * a + 1] * (double)(y0 + cy * (TY - 1))) +
+                                      p.m[4 * a + 2] * (double)(x0w + cx * (TX - 1))) + p.m[4 * a + 3];
                     lo = c < lo ? c : lo;
                 }
         const int n = a == 0 ? p.nz : (a == 1 ? p.ny : p.nx);
@@ -533,33 +537,34 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
             const int sz_ = b0[0] + rz, sy_ = b0[1] + ry, sx_ = b0[2] + 4 * c4;
             const bool ok = tid + (j << 9) < q.nchunks && sz_ < p.nz && sy_ < p.ny && sx_ < p.nx;
             const unsigned voff = ok ? (unsigned)((sz_ * p.ny + sy_) * p.nx + sx_) * 4u : 0x80000000u;
-            dma_16((u32x2){0u, 0u}, rin, voff, (unsigned)((wave << 6) + (j << 9)) * 16u);
+            dma_16(rin, voff, (unsigned)((wave << 6) + (j << 9)) * 16u);
             c4 += dc4; ry += dry; rz += drz;
             if (c4 >= cpr) { c4 -= cpr; ry++; }
             if (ry >= q.by) { ry -= q.by; rz++; }
             if (ry >= q.by) { ry -= q.by; rz++; }
         }
     }
-    if (tid < kLdsTZ * kLdsTY * 3) {
-        const int rr = tid / 3, a = tid - 3 * rr;                  // rr = 8 k + w  <->  plane z0 + k, row y0 + w
-        ptab[rr][a] = p.m[4 * a] * (double)(z0 + (rr >> 3)) + p.m[4 * a + 1] * (double)(y0 + (rr & 7));
+    if (tid < TZ * TY * 3) {
+        const int rr = tid / 3, a = tid - 3 * rr;                  // rr = TY k + row  <->  plane z0 + k, row y0 + row
+        ptab[rr][a] = p.m[4 * a] * (double)(z0 + rr / TY) + p.m[4 * a + 1] * (double)(y0 + rr % TY);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- interpolate: lane = x, wave = row, k = plane; two batches of four planes
-    const double dx = (double)(x0w + lane);
+    // ---- interpolate: lane = (x, row of the wave), k = plane; two batches of four planes
+    const int yrow = RW * wave + yy;
+    const double dx = (double)(x0w + lx);
     const double xz_ = p.m[2] * dx, xy_ = p.m[6] * dx, xx_ = p.m[10] * dx;
     const int plane_f = q.by * q.bx;
     float *tile = tiles + wave * 256;
-    const bool wide = x0w + kLdsTX <= p.ox && y0 + kLdsTY <= p.oy && z0 + kLdsTZ <= p.oz;      // block-uniform
+    const bool wide = x0w + TX <= p.ox && y0 + TY <= p.oy && z0 + TZ <= p.oz;      // block-uniform
 #pragma unroll 1
     for (int bt = 0; bt < 2; bt++) {
         float r[4];
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             const int k = 4 * bt + kk;
-            const int rr = 8 * k + wave;
+            const int rr = TY * k + yrow;
             const C1Split sz = c1_split((ptab[rr][0] + xz_) + p.m[3]);
             const C1Split sy = c1_split((ptab[rr][1] + xy_) + p.m[7]);
             const C1Split sx = c1_split((ptab[rr][2] + xx_) + p.m[11]);
@@ -588,12 +593,13 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) tile[kk * 64 + lane] = r[kk];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int i = lane >> 4, c = lane & 15;
+            const int i = lane >> 4, c = lane & 15;                 // plane of the batch, 16-byte chunk of the wave's 64 voxels
             const f32x4n v = *reinterpret_cast<const f32x4n *>(tile + i * 64 + 4 * c);
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)(z0 + 4 * bt + i) * p.oy + (y0 + wave)) * p.ox + x0w + 4 * c));
+            const int orow = y0 + RW * wave + (4 * c) / TX, ox4 = x0w + ((4 * c) & (TX - 1));
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)(z0 + 4 * bt + i) * p.oy + orow) * p.ox + ox4));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
-            const int x = x0w + lane, y = y0 + wave;
+            const int x = x0w + lx, y = y0 + yrow;
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
                 const int z = z0 + 4 * bt + kk;
@@ -603,16 +609,16 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
     }
 }
 
-// box dimensions of a kLdsTZ x kLdsTY x kLdsTX output tile under the matrix (upper bound from |M|), or false when the
-// box does not fit the LDS budget of two workgroups per CU
-static bool lds_affine_plan(const FastInterpParams &p, LdsAffineParams *q)
+// box dimensions of a TZ x TY x TX output tile under the matrix (upper bound from |M|); returns the number of floats,
+// or 0 when the box does not fit the LDS budget
+static long long lds_affine_plan(const FastInterpParams &p, int tx, LdsAffineParams *q)
 {
-    const int T[3] = {kLdsTZ - 1, kLdsTY - 1, kLdsTX - 1};
+    const int T[3] = {kLdsTZ - 1, 8 * (64 / tx) - 1, tx - 1};
     int dim[3];
     for (int a = 0; a < 3; a++) {
         double ext = 0.0;
         for (int j = 0; j < 3; j++) ext += fabs(p.m[4 * a + j]) * T[j];
-        if (!(ext < 4096.0)) return false;
+        if (!(ext < 4096.0)) return 0;
         // samples floor(min - hair) .. floor(max) + 1 with max - min <= ext: at most floor(ext + hair) + 3 of them (the
         // hair: what the origin is moved below the corner minimum, 1e-6 (1 + |c|) <= 2e-3)
         dim[a] = (int)floor(ext * (1.0 + 1e-6) + 2e-3) + 3;
@@ -622,12 +628,29 @@ static bool lds_affine_plan(const FastInterpParams &p, LdsAffineParams *q)
     for (int a = 0; a < 2; a++) if (dim[a] > n[a]) dim[a] = n[a];
     if (dim[2] > ((n[2] + 3) & ~3) + 4) dim[2] = ((n[2] + 3) & ~3) + 4;
     const long long floats = (long long)dim[0] * dim[1] * dim[2];
-    if (floats * 4 > kLdsBoxBytesMax) return false;
+    if (floats * 4 > kLdsBoxBytesMax) return 0;
     q->f = p;
     q->bz = dim[0]; q->by = dim[1]; q->bx = dim[2];
     q->nchunks = (int)(floats / 4);
-    q->inv_cpr = 1.0f / (float)(dim[2] / 4);
-    return true;
+    return floats;
+}
+
+template <int TX>
+static int launch_affine_lds(const float *in, float *out, const LdsAffineParams &q, hipStream_t s)
+{
+    constexpr int TY = 8 * (64 / TX);
+    const FastInterpParams &p = q.f;
+    const dim3 gl((unsigned)((p.ox + TX - 1) / TX), (unsigned)((p.oy + TY - 1) / TY), (unsigned)((p.oz + kLdsTZ - 1) / kLdsTZ));
+    if (gl.y > 65535 || gl.z > 65535) return MI_ERR_UNSUPPORTED;
+    const size_t lds = (((size_t)q.nchunks * 16 + 8191) & ~(size_t)8191) + kLdsTZ * TY * 3 * sizeof(double) + 8 * 256 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_lds_kernel<TX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(affine3d_lds_kernel<TX>, gl, dim3(512), lds, s, in, out, q);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
 }
 
 constexpr int kNV = 4;   // voxels per thread (rows 4 apart), all gathers issued before any is used
@@ -789,20 +812,14 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
     const int var = g_interp_c1;
     if (mode == MI_MODE_CONSTANT && order == 1 && (var == 1 || var == 4) && !p.two_d && in->dtype == MI_F32 && (p.ox & 3) == 0 &&
         (int64_t)p.oz * p.oy * p.ox >= (1 << 18)) {
-        // gathers out of LDS when the tile's bounding box fits (the choice depends on the matrix only)
-        LdsAffineParams q;
-        const dim3 gl((unsigned)((p.ox + kLdsTX - 1) / kLdsTX), (unsigned)((p.oy + kLdsTY - 1) / kLdsTY), (unsigned)((p.oz + kLdsTZ - 1) / kLdsTZ));
-        if (lds_affine_plan(p, &q) && gl.y <= 65535 && gl.z <= 65535) {
-            const size_t lds = (((size_t)q.nchunks * 16 + 8191) & ~(size_t)8191) + kLdsTZ * kLdsTY * 3 * sizeof(double) + 8 * 256 * sizeof(float);
-            static bool attr_done = false;
-            if (!attr_done) {
-                MI_HIP(hipFuncSetAttribute((const void *)affine3d_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-                attr_done = true;
-            }
-            hipLaunchKernelGGL(affine3d_lds_kernel, gl, dim3(512), lds, s, (const float *)in->data, (float *)out->data, q);
-            MI_HIP(hipGetLastError());
-            return MI_OK;
-        }
+        // gathers out of LDS when a tile's bounding box is small enough (decided from the matrix alone): the tile shape
+        // with the smaller box of 64 x 8 x 8 and 32 x 16 x 8
+        LdsAffineParams q64, q32;
+        const long long f64 = lds_affine_plan(p, 64, &q64), f32 = (p.ox & 31) == 0 || p.ox > 256 ? lds_affine_plan(p, 32, &q32) : 0;
+        int rc = MI_ERR_UNSUPPORTED;
+        if (f64 && (!f32 || f64 <= f32)) rc = launch_affine_lds<64>((const float *)in->data, (float *)out->data, q64, s);
+        else if (f32) rc = launch_affine_lds<32>((const float *)in->data, (float *)out->data, q32, s);
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
     }
     if (mode == MI_MODE_CONSTANT && order == 1 && var && !p.two_d && in->dtype == MI_F32 && (p.ox & 3) == 0) {
         const float *ip = (const float *)in->data;

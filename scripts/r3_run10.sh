@@ -37,4 +37,4 @@ for v in (6,1,6,1):
     tm=t(lambda: ndi.map_coordinates(xd,cd,order=1,mode="constant",output=out))
     print("interp_c1=%d  map_coordinates %.1f us (%.3f @20B)" % (v, tm, 20*n**3/tm/1e3/8000), flush=True)
 PY
-FUZZ_ONLY=map1,affine3,zoom,shift,spline_filter timeout 220 python scripts/fuzz_vs_scipy.py 150 777111 2>&1 | tail -4 | tee $O/fuzz_777111.txt
+timeout 200 python scripts/diag_spline_bits.py 2>&1 | head -24 | tee $O/spline_bits.txt
