@@ -993,7 +993,7 @@ spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_
             const int64_t m = (n - 1 < H) ? n - 1 : H;
             for (int64_t j = 0; j < m; j++) { acc += z_i * c[j * st]; z_i *= z; }
             const double z_n = m == n - 1 ? z_i : pw.zn[k];        // running product, as SciPy (see the causal start)
-            last = acc * z / (z_n - 1);
+            last = acc * (z / (z_n - 1));       // SciPy: c[n-1] *= z / (z_i - 1) -- the quotient first
         } else {
             last *= z / (z - 1);
         }
@@ -1147,7 +1147,7 @@ spline_filter_rows_kernel(CF *__restrict__ data, int64_t n, int64_t nlines, int 
             last = (z * prev2 + last) * z / (z * z - 1);
         } else if (smode == 2) {
             const double z_n = pw.zn[k];
-            last = (last + wrap_acc) * z / (z_n - 1);
+            last = (last + wrap_acc) * (z / (z_n - 1));
         } else {
             last *= z / (z - 1);
         }
