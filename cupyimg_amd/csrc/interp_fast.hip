@@ -653,6 +653,198 @@ static int launch_affine_lds(const float *in, float *out, const LdsAffineParams 
     return MI_OK;
 }
 
+// ---------------------------------------------------------------------------
+// r3: map_coordinates, order 1, constant mode, float32 -- the same LDS gathers for ARBITRARY coordinates (config D).
+// The box of a 32 x 16 x 8 output tile is not known in advance: every workgroup reduces the integer parts of its own
+// coordinates (per lane, DPP / shuffle per wave, six LDS atomics per wave) to the bounding box of the taps it will read,
+// stages that box if it fits the LDS budget (smooth warps: it does) and otherwise gathers through the L1 as
+// map_coords3d_c1_kernel does -- decided per workgroup, so a warp that is smooth in most places keeps the fast path
+// there.  Coordinates are loaded 16 bytes per lane and handed to their lanes through LDS (the region the box occupies
+// afterwards), results leave 16 bytes per lane as well.  Same splits, same in-range tests, same blend: bit-identical
+// to the other order-1 kernels.
+// ---------------------------------------------------------------------------
+constexpr int kMapBoxFloats = 9216;          // 36 KiB
+
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(v, m, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+    return v;
+}
+
+__global__ void __launch_bounds__(512)
+map_coords3d_lds_kernel(const float *__restrict__ in, const float *__restrict__ coords, float *__restrict__ out,
+                        const FastInterpParams p)
+{
+    constexpr int TX = 32, RW = 2, TY = 16, TZ = 8;
+    __shared__ __attribute__((aligned(16))) float box[kMapBoxFloats + 2048];      // + slack: whole rounds of 512 chunks
+    __shared__ int ctl[8];                                                         // lo[3], hi[3]
+    __shared__ __attribute__((aligned(16))) float tiles[8][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lx = lane & (TX - 1), yy = lane / TX;
+    const int x0w = blockIdx.x * TX, y0 = blockIdx.y * TY, z0 = blockIdx.z * TZ;
+    const int yrow = RW * wave + yy;
+    const size_t nout = (size_t)p.oz * p.oy * p.ox;
+    const bool wide = x0w + TX <= p.ox && y0 + TY <= p.oy && z0 + TZ <= p.oz;      // block-uniform
+    if (tid < 3) ctl[tid] = 0x7fffffff;
+    else if (tid < 6) ctl[tid] = -1;
+
+    // ---- phase 1: the coordinates of this lane's eight voxels (planes z0 .. z0 + 7 at (y0 + yrow, x0w + lx))
+    float c[8][3];
+    if (wide) {
+        float *stage = box + wave * (3 * 4 * 64);             // 3 KiB per wave, inside the future box
+        const int i = lane >> 4, cc = lane & 15;
+        const int srow = y0 + RW * wave + (4 * cc) / TX, sx = x0w + ((4 * cc) & (TX - 1));
+#pragma unroll
+        for (int bt = 0; bt < 2; bt++) {
+            const size_t o = ((size_t)(z0 + 4 * bt + i) * p.oy + srow) * p.ox + sx;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n *>(coords + a * nout + o));
+                *reinterpret_cast<f32x4n *>(stage + (a * 4 + i) * 64 + 4 * cc) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) c[4 * bt + kk][a] = stage[(a * 4 + kk) * 64 + lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else {
+        const int x = min(x0w + lx, p.ox - 1), y = min(y0 + yrow, p.oy - 1);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const size_t o = ((size_t)min(z0 + k, p.oz - 1) * p.oy + y) * p.ox + x;
+#pragma unroll
+            for (int a = 0; a < 3; a++) c[k][a] = __builtin_nontemporal_load(coords + a * nout + o);
+        }
+    }
+    // ---- bounding box of the taps of the voxels that are inside the volume
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const C1Split sz = c1_split(c[k][0]), sy = c1_split(c[k][1]), sx = c1_split(c[k][2]);
+        const bool in_z = !sz.neg & (((unsigned)sz.i0 < (unsigned)(p.nz - 1)) | ((sz.i0 == p.nz - 1) & sz.frz));
+        const bool in_y = !sy.neg & (((unsigned)sy.i0 < (unsigned)(p.ny - 1)) | ((sy.i0 == p.ny - 1) & sy.frz));
+        const bool in_x = !sx.neg & (((unsigned)sx.i0 < (unsigned)(p.nx - 1)) | ((sx.i0 == p.nx - 1) & sx.frz));
+        if (in_z & in_y & in_x) {
+            lo[0] = min(lo[0], sz.i0); hi[0] = max(hi[0], sz.i0);
+            lo[1] = min(lo[1], sy.i0); hi[1] = max(hi[1], sy.i0);
+            lo[2] = min(lo[2], sx.i0); hi[2] = max(hi[2], sx.i0);
+        }
+    }
+    __syncthreads();                      // ctl initialised; (coordinates staging is wave-private)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int l = wave_min_i32(lo[a]), h = wave_max_i32(hi[a]);
+        if (lane == 0) { atomicMin(&ctl[a], l); atomicMax(&ctl[3 + a], h); }
+    }
+    __syncthreads();                      // every wave has read its coordinates back: the box may overwrite the staging area
+    int b0[3], bd[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        b0[a] = __builtin_amdgcn_readfirstlane(ctl[a]);
+        bd[a] = __builtin_amdgcn_readfirstlane(ctl[3 + a]);
+    }
+    const bool any_inside = bd[0] >= 0;
+    b0[2] &= ~3;
+#pragma unroll
+    for (int a = 0; a < 3; a++) bd[a] = any_inside ? bd[a] + 2 - b0[a] : 0;            // samples lo .. hi + 1
+    bd[2] = (bd[2] + 3) & ~3;
+    const long long box_floats = (long long)bd[0] * bd[1] * bd[2];
+    const bool use_box = any_inside && box_floats <= kMapBoxFloats;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
+    if (use_box) {
+        const int nchunks = (int)(box_floats >> 2);
+        const int cpr = bd[2] >> 2;
+        const int rounds = (nchunks + 511) >> 9;
+        int row = tid / cpr, c4 = tid - row * cpr;
+        int rz = row / bd[1], ry = row - rz * bd[1];
+        const int drow = 512 / cpr, dc4 = 512 - drow * cpr;
+        const int drz = drow / bd[1], dry = drow - drz * bd[1];
+        for (int j = 0; j < rounds; j++) {
+            const int sz_ = b0[0] + rz, sy_ = b0[1] + ry, sx_ = b0[2] + 4 * c4;
+            const bool ok = tid + (j << 9) < nchunks && sz_ < p.nz && sy_ < p.ny && sx_ < p.nx;
+            const unsigned voff = ok ? (unsigned)((sz_ * p.ny + sy_) * p.nx + sx_) * 4u : 0x80000000u;
+            dma_16(rin, voff, (unsigned)(size_t)box + (unsigned)((wave << 6) + (j << 9)) * 16u);
+            c4 += dc4; ry += dry; rz += drz;
+            if (c4 >= cpr) { c4 -= cpr; ry++; }
+            if (ry >= bd[1]) { ry -= bd[1]; rz++; }
+            if (ry >= bd[1]) { ry -= bd[1]; rz++; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    // ---- phase 2: interpolate, two batches of four planes
+    const int plane_f = bd[1] * bd[2];
+    float *tile = tiles[wave];
+#pragma unroll 1
+    for (int bt = 0; bt < 2; bt++) {
+        float r[4];
+        // this batch's coordinates, selected by value (a run-time index into c[] would put the array into scratch memory)
+        float cb[4][3];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) cb[kk][a] = bt ? c[4 + kk][a] : c[kk][a];
+        if (use_box) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const C1Split sz = c1_split(cb[kk][0]), sy = c1_split(cb[kk][1]), sx = c1_split(cb[kk][2]);
+                Taps<float> t;
+                t.wz1 = sz.w1; t.wy1 = sy.w1; t.wx1 = sx.w1;
+                const bool in_z = !sz.neg & (((unsigned)sz.i0 < (unsigned)(p.nz - 1)) | ((sz.i0 == p.nz - 1) & sz.frz));
+                const bool in_y = !sy.neg & (((unsigned)sy.i0 < (unsigned)(p.ny - 1)) | ((sy.i0 == p.ny - 1) & sy.frz));
+                const bool in_x = !sx.neg & (((unsigned)sx.i0 < (unsigned)(p.nx - 1)) | ((sx.i0 == p.nx - 1) & sx.frz));
+                t.outside = !(in_z & in_y & in_x);
+                t.oobmask = 0;
+                const bool zz = t.wz1 == 0.f, yz = t.wy1 == 0.f;
+                const int li = t.outside ? 0 : ((sz.i0 - b0[0]) * bd[1] + (sy.i0 - b0[1])) * bd[2] + (sx.i0 - b0[2]);
+                const int stz = (t.outside | zz | (sz.i0 >= p.nz - 1)) ? 0 : plane_f;
+                const int sty = (t.outside | yz | (sy.i0 >= p.ny - 1)) ? 0 : bd[2];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const float *src = box + li + (m >> 1) * stz + (m & 1) * sty;
+                    t.v[2 * m] = src[0];
+                    t.v[2 * m + 1] = src[1];
+                }
+                r[kk] = finish<float>(t, (float)p.cval);
+            }
+        } else {
+            Taps<float> t[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) c1_gather(rin, p, c1_split(cb[kk][0]), c1_split(cb[kk][1]), c1_split(cb[kk][2]), t[kk]);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) r[kk] = finish<float>(t[kk], (float)p.cval);
+        }
+        if (wide) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) tile[kk * 64 + lane] = r[kk];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int i = lane >> 4, cc = lane & 15;
+            const f32x4n v = *reinterpret_cast<const f32x4n *>(tile + i * 64 + 4 * cc);
+            const int orow = y0 + RW * wave + (4 * cc) / TX, ox4 = x0w + ((4 * cc) & (TX - 1));
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)(z0 + 4 * bt + i) * p.oy + orow) * p.ox + ox4));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            const int x = x0w + lx, y = y0 + yrow;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int z = z0 + 4 * bt + kk;
+                if (x < p.ox && y < p.oy && z < p.oz) __builtin_nontemporal_store(r[kk], out + ((size_t)z * p.oy + y) * p.ox + x);
+            }
+        }
+    }
+}
+
 constexpr int kNV = 4;   // voxels per thread (rows 4 apart), all gathers issued before any is used
 
 // block = (64, 4): 64 lanes along x (one voxel each, so every gather instruction of a
@@ -764,7 +956,14 @@ int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_ar
         const float *ip = (const float *)in->data, *cp = (const float *)coords->data;
         float *op = (float *)out->data;
         const dim3 gridz((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 3) / 4), (unsigned)((p.oz + 3) / 4));
-        // default: z-major voxel ownership (config D: 605 us against 623 us row-major, profiles/r3_interp_variants.txt)
+        // default for large outputs: gathers out of an LDS-staged box found per workgroup (map_coords3d_lds_kernel)
+        const dim3 gridl((unsigned)((p.ox + 31) / 32), (unsigned)((p.oy + 15) / 16), (unsigned)((p.oz + 7) / 8));
+        if ((var == 1 || var == 4) && (int64_t)p.oz * p.oy * p.ox >= (1 << 18) && gridl.y <= 65535 && gridl.z <= 65535) {
+            hipLaunchKernelGGL(map_coords3d_lds_kernel, gridl, dim3(512), 0, s, ip, cp, op, p);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        }
+        // otherwise z-major voxel ownership (config D: 605 us against 623 us row-major, profiles/r3_interp_variants.txt)
         if (var == 2) hipLaunchKernelGGL((map_coords3d_c1_kernel<false, false>), grid, block, 0, s, ip, cp, op, p);
         else if (var != 6 && gridz.y <= 65535 && gridz.z <= 65535) hipLaunchKernelGGL((map_coords3d_c1_kernel<true, true>), gridz, block, 0, s, ip, cp, op, p);
         else hipLaunchKernelGGL((map_coords3d_c1_kernel<true, false>), grid, block, 0, s, ip, cp, op, p);

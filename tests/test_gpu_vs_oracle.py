@@ -1384,3 +1384,39 @@ def test_affine_lds_staged_kernel(gpu, ndi):
         ok = np.isfinite(ref)
         assert np.array_equal(np.isfinite(outs[1]), ok), shape
         assert np.allclose(outs[1][ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref[ok]).max())), shape
+        # the same warp as explicit float32 coordinates: map_coordinates finds the box of every tile itself
+        idx = np.indices(oshape).reshape(3, -1).astype(np.float64)
+        coords = (M @ idx + off[:, None]).reshape((3,) + tuple(oshape)).astype(np.float32)
+        cd = gpu.asarray(coords)
+        outm = {}
+        for var in (1, 6):
+            lib.mi_debug_set_interp_c1(var)
+            try:
+                outm[var] = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
+            finally:
+                lib.mi_debug_set_interp_c1(1)
+        assert np.array_equal(outm[1], outm[6], equal_nan=True), (shape, "map_coordinates")
+    # coordinates with no structure at all (every workgroup's box is the whole volume: the L1 path inside the LDS kernel),
+    # smooth ones with wild outliers, NaN / inf coordinates
+    x = rng.standard_normal((40, 50, 60)).astype(np.float32)
+    xd = gpu.asarray(x)
+    oshape = (64, 64, 96)
+    wild = np.stack([rng.uniform(-3, n + 2, size=oshape) for n in x.shape]).astype(np.float32)
+    smooth = np.stack(np.meshgrid(*[np.linspace(-1, n, m) for n, m in zip(x.shape, oshape)], indexing="ij")).astype(np.float32)
+    smooth += 0.3 * rng.standard_normal(smooth.shape).astype(np.float32)
+    spiky = smooth.copy()
+    spiky[:, ::7, ::5, ::11] = wild[:, ::7, ::5, ::11]
+    spiky[0, 3, 4, 5] = np.nan; spiky[1, 8, 9, 10] = np.inf; spiky[2, 20, 21, 22] = -np.inf
+    for coords in (wild, smooth, spiky):
+        cd = gpu.asarray(coords)
+        outm = {}
+        for var in (1, 6):
+            lib.mi_debug_set_interp_c1(var)
+            try:
+                outm[var] = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=1.5).get()
+            finally:
+                lib.mi_debug_set_interp_c1(1)
+        assert np.array_equal(outm[1], outm[6], equal_nan=True)
+        ok = np.isfinite(coords).all(axis=0)
+        ref = orc.map_coordinates(x, np.where(np.isfinite(coords), coords, -5.0), order=1, mode="constant", cval=1.5)
+        assert np.allclose(outm[1][ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max()))
