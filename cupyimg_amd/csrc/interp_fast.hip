@@ -956,9 +956,11 @@ int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_ar
         const float *ip = (const float *)in->data, *cp = (const float *)coords->data;
         float *op = (float *)out->data;
         const dim3 gridz((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 3) / 4), (unsigned)((p.oz + 3) / 4));
-        // default for large outputs: gathers out of an LDS-staged box found per workgroup (map_coords3d_lds_kernel)
+        // knob 4 only: gathers out of an LDS-staged box found per workgroup (map_coords3d_lds_kernel).  Measured on config D:
+        // 773 us against 608 us for the L1 gathers below -- two dependent long-latency phases per tile (coordinates, then
+        // the box) with two workgroups per CU (118 VGPRs) leave the CU idle; kept for the record, not the default.
         const dim3 gridl((unsigned)((p.ox + 31) / 32), (unsigned)((p.oy + 15) / 16), (unsigned)((p.oz + 7) / 8));
-        if ((var == 1 || var == 4) && (int64_t)p.oz * p.oy * p.ox >= (1 << 18) && gridl.y <= 65535 && gridl.z <= 65535) {
+        if (var == 4 && (int64_t)p.oz * p.oy * p.ox >= (1 << 18) && gridl.y <= 65535 && gridl.z <= 65535) {
             hipLaunchKernelGGL(map_coords3d_lds_kernel, gridl, dim3(512), 0, s, ip, cp, op, p);
             MI_HIP(hipGetLastError());
             return MI_OK;

@@ -1389,13 +1389,14 @@ def test_affine_lds_staged_kernel(gpu, ndi):
         coords = (M @ idx + off[:, None]).reshape((3,) + tuple(oshape)).astype(np.float32)
         cd = gpu.asarray(coords)
         outm = {}
-        for var in (1, 6):
+        for var in (4, 1, 6):
             lib.mi_debug_set_interp_c1(var)
             try:
                 outm[var] = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
             finally:
                 lib.mi_debug_set_interp_c1(1)
-        assert np.array_equal(outm[1], outm[6], equal_nan=True), (shape, "map_coordinates")
+        assert np.array_equal(outm[4], outm[6], equal_nan=True) and np.array_equal(outm[1], outm[6], equal_nan=True), (shape, "map_coordinates")
+    # (knob 4 = the LDS-staged map_coordinates kernel, not the default: slower on config D, see interp_fast.hip)
     # coordinates with no structure at all (every workgroup's box is the whole volume: the L1 path inside the LDS kernel),
     # smooth ones with wild outliers, NaN / inf coordinates
     x = rng.standard_normal((40, 50, 60)).astype(np.float32)
@@ -1410,13 +1411,13 @@ def test_affine_lds_staged_kernel(gpu, ndi):
     for coords in (wild, smooth, spiky):
         cd = gpu.asarray(coords)
         outm = {}
-        for var in (1, 6):
+        for var in (4, 1, 6):
             lib.mi_debug_set_interp_c1(var)
             try:
                 outm[var] = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=1.5).get()
             finally:
                 lib.mi_debug_set_interp_c1(1)
-        assert np.array_equal(outm[1], outm[6], equal_nan=True)
+        assert np.array_equal(outm[4], outm[6], equal_nan=True) and np.array_equal(outm[1], outm[6], equal_nan=True)
         ok = np.isfinite(coords).all(axis=0)
         ref = orc.map_coordinates(x, np.where(np.isfinite(coords), coords, -5.0), order=1, mode="constant", cval=1.5)
         assert np.allclose(outm[1][ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max()))
