@@ -845,6 +845,120 @@ map_coords3d_lds_kernel(const float *__restrict__ in, const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------
+// r3: map_coordinates, order 1, constant mode, float32 -- two x-neighbouring voxels per lane sharing their gathers.
+// The L1 serves a gather four lanes at a time and pays per cache line touched (profiles/r3_affine_counters.txt): what
+// costs is the NUMBER of lane-quads that gather, not the bytes.  A lane owns voxels x and x + 1 of a row; when the second
+// voxel's taps lie in the same two rows / planes and start 0, 1 or 2 samples after the first one's (every smooth warp:
+// ~85 % of the pairs of config D), ONE 16-byte gather per (plane, row) serves both voxels: four gathers per pair
+// instead of eight.  Pairs that do not qualify (row change between the two voxels, one of them outside, zoom-out by
+// more than 2) issue the second voxel's own 8-byte gathers under the lane mask -- any coordinates are handled, the
+// result is bit-identical to the other order-1 kernels (same splits, same finish()).
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+
+struct C1Addr { unsigned base, stz, sty; bool lastcol; int xb; };
+
+__device__ __forceinline__ void c1_address(const FastInterpParams &p, const C1Split &sz, const C1Split &sy, const C1Split &sx, Taps<float> &t,
+                                           C1Addr &ad)
+{
+    t.wz1 = sz.w1; t.wy1 = sy.w1; t.wx1 = sx.w1;
+    const bool in_z = !sz.neg & (((unsigned)sz.i0 < (unsigned)(p.nz - 1)) | ((sz.i0 == p.nz - 1) & sz.frz));
+    const bool in_y = !sy.neg & (((unsigned)sy.i0 < (unsigned)(p.ny - 1)) | ((sy.i0 == p.ny - 1) & sy.frz));
+    const bool in_x = !sx.neg & (((unsigned)sx.i0 < (unsigned)(p.nx - 1)) | ((sx.i0 == p.nx - 1) & sx.frz));
+    t.outside = !(in_z & in_y & in_x);
+    t.oobmask = 0;
+    const bool zz = t.wz1 == 0.f, yz = t.wy1 == 0.f;
+    ad.lastcol = sx.i0 >= p.nx - 1;
+    ad.xb = sx.i0 - (ad.lastcol ? 1 : 0);
+    ad.base = t.outside ? 0u : (unsigned)((sz.i0 * p.ny + sy.i0) * p.nx + ad.xb) * 4u;
+    ad.stz = (t.outside | zz | (sz.i0 >= p.nz - 1)) ? 0u : (unsigned)(p.ny * p.nx) * 4u;
+    ad.sty = (t.outside | yz | (sy.i0 >= p.ny - 1)) ? 0u : (unsigned)p.nx * 4u;
+}
+
+__device__ __forceinline__ float pick3(const u32x4g &q, int d)      // component d of q, d in 0..3
+{
+    const unsigned lo = d & 1 ? q.y : q.x, hi = d & 1 ? q.w : q.z;
+    return __uint_as_float(d & 2 ? hi : lo);
+}
+
+__global__ void __launch_bounds__(256)
+map_coords3d_pair_kernel(const float *__restrict__ in, const float *__restrict__ coords, float *__restrict__ out,
+                         const FastInterpParams p)
+{
+    // block (64, 4): lane -> voxels x0w + 2 lane, + 1; ty -> row; four planes per thread (z-major ownership)
+    const int lane = threadIdx.x, ty = threadIdx.y;
+    const int x = blockIdx.x * 128 + 2 * lane, y = blockIdx.y * 4 + ty, zb = blockIdx.z * 4;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
+    const size_t nout = (size_t)p.oz * p.oy * p.ox;
+    const bool live = x < p.ox && y < p.oy;                       // ox is even: x + 1 < ox as well
+    const int xc = min(x, p.ox - 2), yc = min(y, p.oy - 1);
+    typedef float f32x2n __attribute__((ext_vector_type(2)));
+    f32x2n c[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const size_t o = ((size_t)min(zb + k, p.oz - 1) * p.oy + yc) * p.ox + xc;
+#pragma unroll
+        for (int a = 0; a < 3; a++) c[k][a] = __builtin_nontemporal_load(reinterpret_cast<const f32x2n *>(coords + a * nout + o));
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {                                 // two planes at a time: eight 16-byte gathers in flight
+        Taps<float> tA[2], tB[2];
+        C1Addr aA[2], aB[2];
+        u32x4g q[2][4];
+        bool shared[2];
+        int d[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const int k = 2 * h + kk;
+            c1_address(p, c1_split(c[k][0].x), c1_split(c[k][1].x), c1_split(c[k][2].x), tA[kk], aA[kk]);
+            c1_address(p, c1_split(c[k][0].y), c1_split(c[k][1].y), c1_split(c[k][2].y), tB[kk], aB[kk]);
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                q[kk][m] = __builtin_amdgcn_raw_buffer_load_b128(rin, aA[kk].base + (m >> 1) * aA[kk].stz + (m & 1) * aA[kk].sty, 0, 0);
+            // B's taps inside A's four 16-byte rows?  same (z0, y0), strides equal or not needed, x start 0..2 after A's
+            const unsigned rowA = aA[kk].base - (unsigned)aA[kk].xb * 4u, rowB = aB[kk].base - (unsigned)aB[kk].xb * 4u;
+            d[kk] = aB[kk].xb + (aB[kk].lastcol ? 1 : 0) - aA[kk].xb;               // B's x0 relative to A's first sample
+            shared[kk] = !tA[kk].outside & !tB[kk].outside & (rowA == rowB) & ((aB[kk].stz == aA[kk].stz) | (aB[kk].stz == 0u)) &
+                         ((aB[kk].sty == aA[kk].sty) | (aB[kk].sty == 0u)) & ((unsigned)d[kk] <= 2u);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            // A: components 0, 1 (at the last column the pair was shifted left: the sample is component 1)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const float a0 = __uint_as_float(q[kk][m].x), a1 = __uint_as_float(q[kk][m].y);
+                tA[kk].v[2 * m] = aA[kk].lastcol ? a1 : a0;
+                tA[kk].v[2 * m + 1] = a1;
+            }
+            if (shared[kk]) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    // a row / plane B skips (its stride 0) has weight 0 in finish(): whatever A loaded there is never used
+                    tB[kk].v[2 * m] = pick3(q[kk][m], d[kk]);
+                    tB[kk].v[2 * m + 1] = pick3(q[kk][m], d[kk] + 1);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    float a, b;
+                    load_pair(rin, aB[kk].base + (m >> 1) * aB[kk].stz + (m & 1) * aB[kk].sty, a, b);
+                    tB[kk].v[2 * m] = aB[kk].lastcol ? b : a;
+                    tB[kk].v[2 * m + 1] = b;
+                }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const int z = zb + 2 * h + kk;
+            f32x2n r;
+            r.x = finish<float>(tA[kk], (float)p.cval);
+            r.y = finish<float>(tB[kk], (float)p.cval);
+            if (live && z < p.oz) __builtin_nontemporal_store(r, reinterpret_cast<f32x2n *>(out + ((size_t)z * p.oy + y) * p.ox + x));
+        }
+    }
+}
+
 constexpr int kNV = 4;   // voxels per thread (rows 4 apart), all gathers issued before any is used
 
 // block = (64, 4): 64 lanes along x (one voxel each, so every gather instruction of a
@@ -962,6 +1076,13 @@ int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_ar
         const dim3 gridl((unsigned)((p.ox + 31) / 32), (unsigned)((p.oy + 15) / 16), (unsigned)((p.oz + 7) / 8));
         if (var == 4 && (int64_t)p.oz * p.oy * p.ox >= (1 << 18) && gridl.y <= 65535 && gridl.z <= 65535) {
             hipLaunchKernelGGL(map_coords3d_lds_kernel, gridl, dim3(512), 0, s, ip, cp, op, p);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        }
+        // default: two x-neighbours per lane sharing their gathers (map_coords3d_pair_kernel)
+        const dim3 gridp((unsigned)((p.ox + 127) / 128), (unsigned)((p.oy + 3) / 4), (unsigned)((p.oz + 3) / 4));
+        if ((var == 1 || var == 7) && (p.ox & 1) == 0 && p.ox >= 2 && gridp.y <= 65535 && gridp.z <= 65535) {
+            hipLaunchKernelGGL(map_coords3d_pair_kernel, gridp, block, 0, s, ip, cp, op, p);
             MI_HIP(hipGetLastError());
             return MI_OK;
         }
