@@ -1029,7 +1029,7 @@ affine3d_fast(const T *__restrict__ in, T *__restrict__ out, const FastInterpPar
         if (ok[k]) __builtin_nontemporal_store(finish<T>(t[k], (T)p.cval), out + o[k]);
 }
 
-Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads, 3 = r3 with z-major voxel ownership, 5 = r3 (L1 gathers) without the LDS-staged affine kernel; 1 (default) and 4 use the LDS-staged affine kernel when the box fits, 6 = row-major ownership for map_coordinates
+Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads, 3 = r3 with z-major voxel ownership, 5 = r3 (L1 gathers) without the LDS-staged affine kernel; 1 (default) and 4 use the LDS-staged affine kernel when the box fits, 6 = row-major ownership for map_coordinates, 7 = pair-sharing map_coordinates kernel (4 = LDS-staged map_coordinates)
 
 static bool fast_ok(const mi_array *in, const mi_array *out, int order)
 {
@@ -1079,9 +1079,11 @@ int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_ar
             MI_HIP(hipGetLastError());
             return MI_OK;
         }
-        // default: two x-neighbours per lane sharing their gathers (map_coords3d_pair_kernel)
+        // knob 7 only: two x-neighbours per lane sharing their gathers (map_coords3d_pair_kernel).  Measured on config D:
+        // 721 us against 590-611 us for the kernel below (half the gather instructions, but 24 selects per shared voxel,
+        // 89 VGPRs and 8-byte coordinate loads / stores) -- correct (tests, fuzz), slower, kept for the record.
         const dim3 gridp((unsigned)((p.ox + 127) / 128), (unsigned)((p.oy + 3) / 4), (unsigned)((p.oz + 3) / 4));
-        if ((var == 1 || var == 7) && (p.ox & 1) == 0 && p.ox >= 2 && gridp.y <= 65535 && gridp.z <= 65535) {
+        if (var == 7 && (p.ox & 1) == 0 && p.ox >= 2 && gridp.y <= 65535 && gridp.z <= 65535) {
             hipLaunchKernelGGL(map_coords3d_pair_kernel, gridp, block, 0, s, ip, cp, op, p);
             MI_HIP(hipGetLastError());
             return MI_OK;

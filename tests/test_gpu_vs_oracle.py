@@ -1199,14 +1199,14 @@ def test_order1_constant_kernels_r3(gpu, ndi, case):
     refm = orc.map_coordinates(x, coords, order=1, mode="constant", cval=-0.75)
     cd = gpu.asarray(coords)
     outm = {}
-    for var in (1, 2, 3, 6, 0):
+    for var in (1, 2, 3, 6, 7, 0):
         lib.mi_debug_set_interp_c1(var)
         try:
             outm[var] = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
         finally:
             lib.mi_debug_set_interp_c1(1)
     assert np.allclose(outm[1], refm, rtol=0, atol=2e-6 * max(1.0, np.abs(refm).max()))
-    assert all(np.array_equal(outm[1], outm[v]) for v in (2, 3, 6, 0))
+    assert all(np.array_equal(outm[1], outm[v]) for v in (2, 3, 6, 7, 0))
 
 
 def test_order1_constant_kernels_r3_nonfinite_and_edges(gpu, ndi):
@@ -1389,13 +1389,13 @@ def test_affine_lds_staged_kernel(gpu, ndi):
         coords = (M @ idx + off[:, None]).reshape((3,) + tuple(oshape)).astype(np.float32)
         cd = gpu.asarray(coords)
         outm = {}
-        for var in (4, 1, 6):
+        for var in (4, 7, 1, 6):
             lib.mi_debug_set_interp_c1(var)
             try:
                 outm[var] = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
             finally:
                 lib.mi_debug_set_interp_c1(1)
-        assert np.array_equal(outm[4], outm[6], equal_nan=True) and np.array_equal(outm[1], outm[6], equal_nan=True), (shape, "map_coordinates")
+        assert all(np.array_equal(outm[v], outm[6], equal_nan=True) for v in (4, 7, 1)), (shape, "map_coordinates")
     # (knob 4 = the LDS-staged map_coordinates kernel, not the default: slower on config D, see interp_fast.hip)
     # coordinates with no structure at all (every workgroup's box is the whole volume: the L1 path inside the LDS kernel),
     # smooth ones with wild outliers, NaN / inf coordinates
@@ -1411,13 +1411,13 @@ def test_affine_lds_staged_kernel(gpu, ndi):
     for coords in (wild, smooth, spiky):
         cd = gpu.asarray(coords)
         outm = {}
-        for var in (4, 1, 6):
+        for var in (4, 7, 1, 6):
             lib.mi_debug_set_interp_c1(var)
             try:
                 outm[var] = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=1.5).get()
             finally:
                 lib.mi_debug_set_interp_c1(1)
-        assert np.array_equal(outm[4], outm[6], equal_nan=True) and np.array_equal(outm[1], outm[6], equal_nan=True)
+        assert all(np.array_equal(outm[v], outm[6], equal_nan=True) for v in (4, 7, 1))
         ok = np.isfinite(coords).all(axis=0)
         ref = orc.map_coordinates(x, np.where(np.isfinite(coords), coords, -5.0), order=1, mode="constant", cval=1.5)
         assert np.allclose(outm[1][ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max()))
