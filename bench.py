@@ -201,6 +201,19 @@ def cpu_baseline(x, gpu_out):
     return res
 
 
+def _self_loop_plan(dist_, nz, lo, hi):
+    """SlabPlan of a closed chain of ONE rank: both neighbours are the rank itself (`--self-loop`)."""
+    plan = dist_.SlabPlan.__new__(dist_.SlabPlan)
+    plan.nz, plan.nranks, plan.rank = nz, 2, 0          # nranks > 1 selects the exchange path
+    plan.lo, plan.hi, plan.wrap = lo, hi, True
+    plan.z0, plan.z1, plan.n_local = 0, nz, nz
+    plan.counts = [nz]
+    plan.prev = plan.next = 0
+    plan.lo_present, plan.hi_present = lo, hi
+    plan.n_ext = lo + nz + hi
+    return plan
+
+
 E_SIDE = 2048
 E_SIZE = 9
 E_SEED = 20260
@@ -243,6 +256,10 @@ def main():
                     help="config H with N > 1: the 512^3 volume split over the ranks (strong, default) or one 512^3 slab "
                          "per rank (weak)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--self-loop", action="store_true",
+                    help="functional dry run of the N > 1 code path on ONE GPU: the rank is both neighbours of itself (closed chain, "
+                         "`wrap` along z) over a one-rank RCCL communicator -- exchange, schedule tuning, seam parity all execute; "
+                         "the number it prints is not a benchmark result")
     ap.add_argument("--cpu-allcores-helper", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_allcores_helper:
@@ -289,7 +306,7 @@ def main():
     plane_shape = (side, side)
     sf = plan = None
     x_host = xd = out = None
-    if cfg == "H" and world == 1:
+    if cfg == "H" and world == 1 and not args.self_loop:
         x_host = synth((N_SIDE,) * 3)
         xd = ca.asarray(x_host)
         out = ca.empty(xd.shape, np.float32)
@@ -298,8 +315,12 @@ def main():
             ndi.uniform_filter(xd, size=SIZE, output=out)
     else:
         lo, hi = dist_.halo_widths(size)
-        plan = dist_.SlabPlan(nz_total, world, rank, lo, hi, wrap=False)
-        comm = dist_.HaloComm(world, rank, exchange_id) if world > 1 else None
+        if args.self_loop:
+            plan = _self_loop_plan(dist_, nz_total, lo, hi)
+            comm = dist_.HaloComm(1, 0, lambda uid: uid)
+        else:
+            plan = dist_.SlabPlan(nz_total, world, rank, lo, hi, wrap=False)
+            comm = dist_.HaloComm(world, rank, exchange_id) if world > 1 else None
         sf = dist_.SlabFilter(plan, plane_shape, np.float32, comm)
         if cfg == "H" and not weak:
             x_host = synth((N_SIDE,) * 3)
@@ -329,7 +350,12 @@ def main():
     # ------------------------------------------------------------ parity of the distributed / slab result (untimed)
     slab_ok = seam_err = None
     if sf is not None:
-        if cfg == "H" and not weak:
+        if args.self_loop:
+            # closed chain of one rank: the halos are the periodic continuation, i.e. `wrap` along z
+            full = ndi.uniform_filter(sf.local_in, size=size, mode=["wrap", "reflect", "reflect"])
+            slab_ok = not ca.arrays_differ(sf.local_out, full)
+            del full
+        elif cfg == "H" and not weak:
             # every rank filters the whole volume on its own GPU and checks that its slab of the distributed result
             # is bit-identical to it
             full = ndi.uniform_filter(ca.asarray(x_host), size=SIZE)
@@ -387,12 +413,14 @@ def main():
             cpu = cpu_baseline(x_host, out.get())
         else:
             cpu = None
-        if world == 1:
+        if world == 1 and not args.self_loop:
             partition = "single GPU"
         else:
             sched = sf.schedule_of("uniform") or {}
             partition = "z-slabs x{} + RCCL halo exchange ({} schedule, measured in warm(): plain / overlapped median {} ms)".format(
                 world, "overlapped" if sched.get("choice") == 1 else "plain", sched.get("median_ms"))
+            if args.self_loop:
+                partition = "SELF-LOOP DRY RUN (one GPU is both neighbours of itself; not a benchmark result): " + partition
         if cfg == "H":
             metric = "Mvoxels/s, uniform_filter size=5 on 512^3 float32"
             workload = ("uniform_filter size=5 mode=reflect on {}x512x512 float32, device resident".format(nz_total))

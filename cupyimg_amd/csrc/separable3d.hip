@@ -479,9 +479,21 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
             const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(in + (size_t)zsrc * plane_elems), 0, (int)plane_bytes, 0x00020000);
             const bool skip = HAS_CONST && s.zconst;
+            // tuning knob (mi_debug_set_sep3d_dbg(256 * k)): cache policy of the row loads -- 0 default, 1 nt, 2 sc1, 3 sc0 sc1
+            const int ldpol = (p.dbg >> 8) & 3;
+            if (ldpol == 0) {
 #pragma unroll
-            for (int r = 0; r < R; r++)
-                s.v[r] = f4_from(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], 0, 0));
+                for (int r = 0; r < R; r++) s.v[r] = f4_from(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], 0, 0));
+            } else if (ldpol == 1) {
+#pragma unroll
+                for (int r = 0; r < R; r++) s.v[r] = f4_from(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], 0, 2));
+            } else if (ldpol == 2) {
+#pragma unroll
+                for (int r = 0; r < R; r++) s.v[r] = f4_from(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], 0, 16));
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) s.v[r] = f4_from(__builtin_amdgcn_raw_buffer_load_b128(rin, skip ? kOOB : voff[r], 0, 17));
+            }
             if constexpr (NE == 2) {
                 const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rin, skip ? kOOB : eoffv, 0, 0);
                 s.t[0] = __uint_as_float(q.x); s.t[1] = __uint_as_float(q.y);
