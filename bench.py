@@ -389,7 +389,7 @@ def main():
             "alg_bytes_per_launch": ALG_BYTES_PER_VOXEL * per_gpu_voxels,
             "avg_launch_us": round(kernel_s * 1e6, 2),
         }
-        if cfg == "H" and world == 1:
+        if cfg == "H" and world == 1 and not args.self_loop:
             # the practical ceiling of this box for the same 2 x 512 MiB: the in-tree float4 copy kernel (best grid)
             # and, for continuity with earlier rounds, a hipMemcpy device-to-device copy
             ck_gbs, ck_blocks = copy_kernel_ceiling(ca, xd, out)
@@ -409,7 +409,7 @@ def main():
             roofline["frac_of_d2d_copy"] = round(achieved / copy_gbs, 4)
             step()                                        # `out` holds the filter result again (parity leg below)
             ca.synchronize()
-        if cfg == "H" and world == 1 and not args.no_cpu:
+        if cfg == "H" and world == 1 and not args.no_cpu and not args.self_loop:
             cpu = cpu_baseline(x_host, out.get())
         else:
             cpu = None
