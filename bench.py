@@ -219,6 +219,22 @@ E_SIZE = 9
 E_SEED = 20260
 
 
+def quiet_c_stdout(fn):
+    """Run fn() with the C-level stdout (fd 1) pointed at stderr: RCCL prints a version banner to stdout when a
+    communicator is created, and the one JSON line is the only thing this program may write there."""
+    import ctypes
+    sys.stdout.flush()
+    libc = ctypes.CDLL(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return fn()
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def fill_synthetic(ca, dst, first_index, seed):
     """dst (C-contiguous float32 device array) <- synthetic values of global indices first_index .. (csrc/synth.hip)"""
     import ctypes
@@ -317,10 +333,10 @@ def main():
         lo, hi = dist_.halo_widths(size)
         if args.self_loop:
             plan = _self_loop_plan(dist_, nz_total, lo, hi)
-            comm = dist_.HaloComm(1, 0, lambda uid: uid)
+            comm = quiet_c_stdout(lambda: dist_.HaloComm(1, 0, lambda uid: uid))
         else:
             plan = dist_.SlabPlan(nz_total, world, rank, lo, hi, wrap=False)
-            comm = dist_.HaloComm(world, rank, exchange_id) if world > 1 else None
+            comm = quiet_c_stdout(lambda: dist_.HaloComm(world, rank, exchange_id)) if world > 1 else None
         sf = dist_.SlabFilter(plan, plane_shape, np.float32, comm)
         if cfg == "H" and not weak:
             x_host = synth((N_SIDE,) * 3)
