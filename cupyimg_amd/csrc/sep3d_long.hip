@@ -554,7 +554,8 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
         attr_done = true;
     }
     const int total = p.nxt * p.nyt * p.nzc;
-    if (long_two_rows(W)) {
+    // the two-row variant is instantiated for 9, 13 and 17 taps only (it is a measured-slower knob, not a product path)
+    if constexpr (W == 9 || W == 13 || W == 17) if (long_two_rows(W)) {
         static bool attr2_done = false;
         if (!attr2_done) {
             MI_HIP(hipFuncSetAttribute((const void *)sep3d_long2_kernel<W, SAME, HAS_CONST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1421,3 +1421,25 @@ def test_affine_lds_staged_kernel(gpu, ndi):
         ok = np.isfinite(coords).all(axis=0)
         ref = orc.map_coordinates(x, np.where(np.isfinite(coords), coords, -5.0), order=1, mode="constant", cval=1.5)
         assert np.allclose(outm[1][ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max()))
+
+
+def test_long_kernel_two_rows_per_wave_variant(gpu, ndi):
+    """sep3d_long2_kernel (two output rows per wave; behind mi_debug_set_long_rows(2) because it measured slower): the same
+    voxels as the one-row kernel, bit for bit, for 9 / 13 / 17 taps, every boundary mode, partial tiles."""
+    from cupyimg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(210)
+    for shape in [(40, 37, 64), (33, 21, 264), (19, 50, 256)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        for mode in MODES:
+            for size in (9, 13, 17):
+                try:
+                    lib.mi_debug_set_long_rows(1)
+                    a = ndi.uniform_filter(xd, size, mode=mode, cval=0.75).get()
+                    lib.mi_debug_set_long_rows(2)
+                    b = ndi.uniform_filter(xd, size, mode=mode, cval=0.75).get()
+                finally:
+                    lib.mi_debug_set_long_rows(0)
+                assert np.array_equal(a, b), (shape, mode, size)
+                assert maxnorm_rel(b, orc.uniform_filter(x, size, mode=mode, cval=0.75)) <= 1e-6
