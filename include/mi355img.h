@@ -320,9 +320,11 @@ int mi_minmax_nd(const mi_array *in, const mi_array *out, const uint8_t *footpri
                  double cval, int is_max, mi_stream stream);
 
 /* rank-th smallest sample under the footprint (rank_filter / median_filter /
- * percentile_filter, filters.py:1560-1848); rank <= 3 arrays, footprints of at
- * most 128 set elements, MI_ERR_UNSUPPORTED otherwise.  cval is converted to
- * the input dtype like SciPy does. */
+ * percentile_filter, filters.py:1560-1848).  Arrays of rank <= 3 with footprints of at
+ * most 128 set elements take register kernels (sorting networks / partial selection);
+ * anything else -- rank 4..8, larger footprints -- a scratch-column shell sort (r3; the
+ * reference's shell-sort path, filters.py:1753-1768, has no limit either; scratch from the
+ * pool, at most 256 MiB).  cval is converted to the input dtype like SciPy does. */
 int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footprint,
                    const int64_t *fshape, const int *origins, int rank, int mode, double cval,
                    mi_stream stream);
@@ -373,7 +375,11 @@ int mi_affine_transform(const mi_array *in, const mi_array *out, const double *m
  * followed by mi_spline_filter1d along every axis (spline_mode 0 mirror,
  * 1 reflect, 2 grid-wrap: reflect for reflect / nearest, grid-wrap for grid-wrap,
  * mirror otherwise) -- and interpolates it; coordinates refer to the unpadded
- * array.  Rank <= 3. */
+ * array.  Rank <= 8 (r3; float32 coefficients: rank <= 3).
+ * spline_mode | 0x100 (mi_spline_filter1d, mi_spline_prefilter): only the kernels whose
+ * arithmetic is SciPy's operation for operation (no blocked recursion) -- pass it when the
+ * interpolated result will be rounded to an integer dtype, where the last bit of a
+ * coefficient decides exact .5 ties. */
 int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mode, double cval,
                   mi_stream stream);
 int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mode, mi_stream stream);
