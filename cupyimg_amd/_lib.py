@@ -106,6 +106,8 @@ SIGNATURES = {
     "mi_minmax1d": [_arr, _arr, _i, _i, _i, _i, _d, _i, _vp],
     "mi_minmax3d_u8": [_arr, _arr, _ip, _ip, _ip, _i, _i, _vp],
     "mi_minmax3d_f32": [_arr, _arr, _ip, _ip, _ip, _d, _i, _vp],
+    "mi_minmax3d_f32_planes": [_arr, _arr, _ip, _ip, _ip, _d, _i, _i64p, _i, _vp],
+    "mi_minmax3d_u8_planes": [_arr, _arr, _ip, _ip, _ip, _i, _i, _i64p, _i, _vp],
     "mi_minmax3d_16": [_arr, _arr, _ip, _ip, _ip, _i, _i, _vp],
     "mi_uniform2d_u8": [_arr, _arr, _ip, _i, _ip, _i, _vp],
     "mi_uniform2d_16": [_arr, _arr, _ip, _i, _ip, _i, _vp],

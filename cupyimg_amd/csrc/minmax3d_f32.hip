@@ -22,6 +22,7 @@ struct MmLongParams {
     int mx, my, mz;         // boundary modes (never constant)
     int zc, nxt, nyt, nzc;
     int tw;                 // tile width in floats (<= 256, multiple of 4)
+    int zb, zn;             // output planes to produce: [zb, zb + zn) (whole volume: 0, nz); boundary handling refers to nz
 };
 
 template <bool IS_MAX> __device__ __forceinline__ float mm2(float a, float b) { return IS_MAX ? fmaxf(a, b) : fminf(a, b); }
@@ -68,7 +69,7 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
 
     const int nx = p.nx, ny = p.ny, nz = p.nz;
     const int x0 = xt * p.tw, y0 = yt * kLongTY;
-    const int zs = zci * p.zc, ze = min(zs + p.zc, nz);
+    const int zs = p.zb + zci * p.zc, ze = min(zs + p.zc, p.zb + p.zn);
     const int ty_act = min(kLongTY, ny - y0);
     const int rows_needed = ty_act + W - 1;
     const int nlanes = min(p.tw >> 2, (nx - x0) >> 2);
@@ -227,9 +228,20 @@ static int launch_mm_long(const float *in, float *out, MmLongParams &p, hipStrea
 
 // Fused min / max: cubic odd w in 3..9, origin 0 along x, no constant mode; MI_ERR_UNSUPPORTED otherwise (the caller runs
 // the streaming passes).
+int run_minmax3d_f32_fused_planes(const float *in, float *out, int nz, int ny, int nx, int w, int oy, int oz, int mx, int my, int mz,
+                                  bool is_max, int zb, int zn, hipStream_t s);
+
 int run_minmax3d_f32_fused(const float *in, float *out, int nz, int ny, int nx, int w, int oy, int oz, int mx, int my, int mz,
                            bool is_max, hipStream_t s)
 {
+    return run_minmax3d_f32_fused_planes(in, out, nz, ny, nx, w, oy, oz, mx, my, mz, is_max, 0, nz, s);
+}
+
+// output planes [zb, zb + zn) only (multi-GPU slabs: the planes next to a neighbour wait for the halo exchange)
+int run_minmax3d_f32_fused_planes(const float *in, float *out, int nz, int ny, int nx, int w, int oy, int oz, int mx, int my, int mz,
+                                  bool is_max, int zb, int zn, hipStream_t s)
+{
+    if (zn <= 0) return MI_OK;
     if (w < 3 || w > 9 || !(w & 1) || nx < 16) return MI_ERR_UNSUPPORTED;
     if (mx == MI_MODE_CONSTANT || my == MI_MODE_CONSTANT || mz == MI_MODE_CONSTANT) return MI_ERR_UNSUPPORTED;
     if ((int64_t)ny * nx * 4 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
@@ -245,17 +257,18 @@ int run_minmax3d_f32_fused(const float *in, float *out, int nz, int ny, int nx, 
     const int cols = p.nxt * p.nyt;
     int best_nzc = 1;
     double best = 1e300;
-    for (int nzc = 1; nzc <= nz && nzc <= 256; nzc++) {
-        const int chunk = (nz + nzc - 1) / nzc;
+    p.zb = zb; p.zn = zn;
+    for (int nzc = 1; nzc <= zn && nzc <= 256; nzc++) {
+        const int chunk = (zn + nzc - 1) / nzc;
         if (chunk > kLongMaxChunk) continue;
-        const int real = (nz + chunk - 1) / chunk;
+        const int real = (zn + chunk - 1) / chunk;
         const double rounds = (double)(((int64_t)cols * real + ncu - 1) / ncu);
         const double cost = rounds * (chunk + w - 1 + 3);
         if (cost < best) { best = cost; best_nzc = real; }
     }
-    p.zc = (nz + best_nzc - 1) / best_nzc;
+    p.zc = (zn + best_nzc - 1) / best_nzc;
     if (p.zc > kLongMaxChunk) p.zc = kLongMaxChunk;
-    p.nzc = (nz + p.zc - 1) / p.zc;
+    p.nzc = (zn + p.zc - 1) / p.zc;
 #define MI_MM_CASE(N) case N: return is_max ? launch_mm_long<N, true>(in, out, p, s) : launch_mm_long<N, false>(in, out, p, s);
     switch (w) { MI_MM_CASE(3) MI_MM_CASE(5) MI_MM_CASE(7) MI_MM_CASE(9) }
 #undef MI_MM_CASE
@@ -263,3 +276,52 @@ int run_minmax3d_f32_fused(const float *in, float *out, int nz, int ny, int nx, 
 }
 
 }  // namespace mi
+
+/* Separable flat min / max filter restricted to one or two ranges of output planes (float32 volumes, cubic odd sizes
+ * 3 .. 9, index-mapping boundary modes: what the fused kernel takes; MI_ERR_UNSUPPORTED otherwise).  The multi-GPU slab
+ * schedule filters the planes whose taps stay inside a rank's own planes while the halo exchange is in flight and the
+ * planes next to a neighbour afterwards (include/mi355img.h). */
+extern "C" int mi_minmax3d_f32_planes(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
+                                      const int mode[3], double cval, int is_max, const int64_t *planes, int nranges,
+                                      mi_stream stream)
+{
+    using namespace mi;
+    (void)cval;
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(size && origin && mode && planes, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(nranges >= 1 && nranges <= 2, MI_ERR_INVALID_ARG, "one or two plane ranges");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+#define UNSUP(msg) do { set_error("minmax3d_f32_planes: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if (in->ndim != 3 || in->dtype != MI_F32 || out->dtype != MI_F32) UNSUP("needs 3-D float32 in/out");
+    if (!is_contiguous(in) || !is_contiguous(out) || in->data == out->data) UNSUP("needs distinct C-contiguous arrays");
+    const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
+    if (nz < 1 || ny < 1 || nx < 16 || (nx & 3)) UNSUP("x extent must be a multiple of 4, >= 16");
+    if (nz * ny * nx * 4 >= ((int64_t)1 << 31)) UNSUP("needs a volume < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+    const int w = size[0];
+    if (size[1] != w || size[2] != w || w < 3 || w > 9 || !(w & 1)) UNSUP("cubic odd sizes 3 .. 9 only");
+    if (origin[2] != 0) UNSUP("x origin must be 0");
+    int off[2];
+    for (int a = 0; a < 2; a++) {
+        off[a] = w / 2 + origin[a];
+        if (off[a] < 0 || off[a] >= w) { set_error("invalid origin"); return MI_ERR_INVALID_ARG; }
+    }
+    int64_t prev_end = 0;
+    for (int r = 0; r < nranges; r++) {
+        const int64_t b = planes[2 * r], e = planes[2 * r + 1];
+        MI_REQUIRE(b >= prev_end && e >= b && e <= nz, MI_ERR_INVALID_ARG, "plane ranges must be ascending and inside the volume");
+        prev_end = e;
+    }
+    hipStream_t s = resolve_stream(stream);
+    for (int r = 0; r < nranges; r++) {
+        const int64_t b = planes[2 * r], e = planes[2 * r + 1];
+        if (e == b) continue;
+        rc = run_minmax3d_f32_fused_planes((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w, off[1], off[0],
+                                           filter_mode(mode[2]), filter_mode(mode[1]), filter_mode(mode[0]), is_max != 0, (int)b,
+                                           (int)(e - b), s);
+        if (rc != MI_OK) return rc;
+    }
+    return MI_OK;
+#undef UNSUP
+}

@@ -1090,6 +1090,7 @@ struct U8FusedParams {
     int mx, my, mz;
     unsigned cval4;
     int zc, nzc, nxt, nyt;
+    int zb, zn;             // output planes to produce: [zb, zb + zn) (0 / 0 = the whole volume); boundary handling refers to nz
 };
 
 constexpr int kU8MaxChunk = 2048;
@@ -1177,8 +1178,8 @@ mm3u8_split_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
     const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
 
     const int nx = p.nx, ny = p.ny, nz = p.nz;
-    const int x0 = xt * 512, y0 = yt * TY, zs = zci * p.zc;
-    const int ze = min(zs + p.zc, nz);
+    const int x0 = xt * 512, y0 = yt * TY, zs = p.zb + zci * p.zc;
+    const int ze = min(zs + p.zc, p.zb + p.zn);
     const int ty_act = min(TY, ny - y0);
     const int rows_needed = ty_act + W - 1;
     const int nlanes = min(64, (nx - x0) >> 3);
@@ -1356,17 +1357,19 @@ static int launch_u8_split(const uint8_t *in, uint8_t *out, U8FusedParams &p, bo
     const int64_t tiles = (int64_t)p.nxt * p.nyt;
     double best = 1e300;
     int best_nzc = 1;
-    for (int nzc = 1; nzc <= std::min(p.nz, 64); nzc++) {
-        const int chunk = (p.nz + nzc - 1) / nzc;
+    if (p.zn <= 0) { p.zb = 0; p.zn = p.nz; }
+    const int zn = p.zn;
+    for (int nzc = 1; nzc <= std::min(zn, 64); nzc++) {
+        const int chunk = (zn + nzc - 1) / nzc;
         if (chunk > kU8MaxChunk) continue;
-        const int real = (p.nz + chunk - 1) / chunk;
+        const int real = (zn + chunk - 1) / chunk;
         const double rounds = (double)((tiles * real + cus - 1) / cus);
         const double cost = rounds * (chunk + W - 1 + 2.0);
         if (cost < best) { best = cost; best_nzc = real; }
     }
-    p.zc = (p.nz + best_nzc - 1) / best_nzc;
+    p.zc = (zn + best_nzc - 1) / best_nzc;
     if (p.zc > kU8MaxChunk) p.zc = kU8MaxChunk;
-    p.nzc = (p.nz + p.zc - 1) / p.zc;
+    p.nzc = (zn + p.zc - 1) / p.zc;
     const int64_t total = tiles * p.nzc;
     if (has_const)
         hipLaunchKernelGGL((mm3u8_split_kernel<W, IS_MAX, NWP, NWC, R, TY, true>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
@@ -1393,6 +1396,53 @@ using namespace mi;
 // test / tuning hook (not part of the C-ABI): 0 = always take the two-launch path
 static mi::Knob g_u8_fused{1};
 extern "C" int mi_debug_set_u8_fused(int enabled) { g_u8_fused = enabled; return MI_OK; }
+
+/* The same restricted to one or two ranges of output planes (uint8 volumes, cubic sizes 3 / 5 / 7: the fused split kernel;
+ * MI_ERR_UNSUPPORTED otherwise) -- what the multi-GPU slab schedule needs to overlap the halo exchange (config C's kernel). */
+extern "C" int mi_minmax3d_u8_planes(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
+                                     const int mode[3], int cval, int is_max, const int64_t *planes, int nranges,
+                                     mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(size && origin && mode && planes, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(nranges >= 1 && nranges <= 2, MI_ERR_INVALID_ARG, "one or two plane ranges");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+#define UNSUP(msg) do { set_error("minmax3d_u8_planes: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if (in->ndim != 3 || in->dtype != MI_U8 || out->dtype != MI_U8) UNSUP("needs 3-D uint8 in/out");
+    if (!is_contiguous(in) || !is_contiguous(out) || in->data == out->data) UNSUP("needs distinct C-contiguous arrays");
+    const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
+    if (nz < 1 || ny < 1 || nx < 64 || (nx & 15) || (nx & 1023) == 16) UNSUP("x extent must be a multiple of 16, >= 64");
+    if (nz * ny * nx >= ((int64_t)1 << 31)) UNSUP("needs a volume < 2 GiB");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+    const int w = size[0];
+    if (size[1] != w || size[2] != w || (w != 3 && w != 5 && w != 7)) UNSUP("cubic sizes 3 / 5 / 7 only");
+    if (origin[0] || origin[1] || origin[2]) UNSUP("origin must be 0");
+    if (cval < 0 || cval > 255) UNSUP("cval outside uint8");
+    int64_t prev_end = 0;
+    for (int r = 0; r < nranges; r++) {
+        const int64_t b = planes[2 * r], e = planes[2 * r + 1];
+        MI_REQUIRE(b >= prev_end && e >= b && e <= nz, MI_ERR_INVALID_ARG, "plane ranges must be ascending and inside the volume");
+        prev_end = e;
+    }
+    hipStream_t s = resolve_stream(stream);
+    for (int r = 0; r < nranges; r++) {
+        const int64_t b = planes[2 * r], e = planes[2 * r + 1];
+        if (e == b) continue;
+        U8FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.nx = (int)nx; f.ny = (int)ny; f.nz = (int)nz;
+        f.mz = filter_mode(mode[0]); f.my = filter_mode(mode[1]); f.mx = filter_mode(mode[2]);
+        f.cval4 = (unsigned)cval * 0x01010101u;
+        f.zb = (int)b; f.zn = (int)(e - b);
+        const bool has_const = f.mz == MI_MODE_CONSTANT || f.my == MI_MODE_CONSTANT || f.mx == MI_MODE_CONSTANT;
+        rc = is_max ? launch_u8_fused_w<true>(w, (const uint8_t *)in->data, (uint8_t *)out->data, f, has_const, s)
+                    : launch_u8_fused_w<false>(w, (const uint8_t *)in->data, (uint8_t *)out->data, f, has_const, s);
+        if (rc != MI_OK) return rc;
+    }
+    return MI_OK;
+#undef UNSUP
+}
 
 extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int size[3],
                               const int origin[3], const int mode[3], int cval, int is_max,

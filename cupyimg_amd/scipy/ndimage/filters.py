@@ -511,9 +511,31 @@ def _launch_minmax1d(src, dst, axis, size, origin, mode, cval, is_max):
                                 S.mode_code(mode), float(cval), int(is_max), None))
 
 
+def _minmax_planes(input, output, sizes, origins, modes, cval, is_max, planes):
+    """Plane-restricted separable min / max (multi-GPU slabs): uint8 cubic 3 / 5 / 7 and float32 cubic 3 .. 9 volumes
+    through mi_minmax3d_u8_planes / mi_minmax3d_f32_planes; anything else raises Unsupported (the caller falls back to
+    the plain schedule on the whole extended slab)."""
+    if (input.ndim != 3 or input.dtype not in (np.uint8, np.float32) or output.dtype != input.dtype or
+            not input._is_c_contiguous() or not output._is_c_contiguous() or core.shares_memory(output, input)):
+        raise S.Unsupported("plane-restricted min/max filters need contiguous, distinct uint8 / float32 volumes")
+    flat = [int(v) for pr in planes for v in pr]
+    pl = S.c_int64s(flat)
+    a, b = input._desc(), output._desc()
+    args = (ctypes.byref(a), ctypes.byref(b), _cached_ints(tuple(int(v) for v in sizes)), _cached_ints(tuple(int(v) for v in origins)),
+            _cached_ints(tuple(S.mode_code(m) for m in modes)))
+    if input.dtype == np.uint8:
+        if any(m in ("constant", "grid-constant") for m in modes) and not (np.isfinite(cval) and 0 <= cval <= 255 and float(cval) == int(cval)):
+            raise S.Unsupported("cval outside uint8")
+        cv = int(cval) if np.isfinite(cval) and 0 <= cval <= 255 else 0
+        S.check(S.lib().mi_minmax3d_u8_planes(*args, cv, int(is_max), pl, len(planes), None))
+    else:
+        S.check(S.lib().mi_minmax3d_f32_planes(*args, float(cval), int(is_max), pl, len(planes), None))
+    return output
+
+
 def _try_fused_minmax_u8(input, output, sizes, origins, modes, cval, is_max):
     if S.current_planes() is not None:
-        raise S.Unsupported("min/max filters cannot be restricted to a range of output planes")
+        return _minmax_planes(input, output, sizes, origins, modes, cval, is_max, S.current_planes())
     if (input.ndim not in (2, 3) or input.dtype not in (np.uint8, np.uint16, np.int16) or output.dtype != input.dtype
             or input.size == 0):
         return None

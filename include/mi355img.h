@@ -251,6 +251,18 @@ int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int size[3],
  * float32 first, as SciPy converts it to the input dtype. */
 int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
                     const int mode[3], double cval, int is_max, mi_stream stream);
+/* mi_minmax3d_u8 / mi_minmax3d_f32 restricted to one or two ranges of output planes [b0, e0), [b1, e1) along axis 0
+ * (ascending, inside the volume) -- the multi-GPU slab schedule filters a rank's interior planes while the halo exchange
+ * is in flight and the planes next to a neighbour afterwards (r3).  Only what the single-launch kernels take: uint8
+ * cubic sizes 3 / 5 / 7 with origin 0; float32 cubic odd sizes 3 .. 9, index-mapping boundary modes;
+ * MI_ERR_UNSUPPORTED otherwise (callers then use the plain schedule on the whole extended slab). */
+int mi_minmax3d_u8_planes(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
+                          const int mode[3], int cval, int is_max, const int64_t *planes, int nranges,
+                          mi_stream stream);
+int mi_minmax3d_f32_planes(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
+                           const int mode[3], double cval, int is_max, const int64_t *planes, int nranges,
+                           mi_stream stream);
+
 
 /* uint16 / int16 images and volumes (2-D or 3-D arrays; size / origin / mode always have
  * three entries, the first one for the absent axis of an image): flat min / max with odd

@@ -304,3 +304,42 @@ def test_slab_minmax_and_binary_morphology(gpu, ndi, self_comm):
     # moves one plane per iteration: the middle copy is exact for n_it <= nz iterations)
     assert n_it >= 2 and calls[-1] is False and n_it <= nz
     assert np.array_equal(res, ref[nz:2 * nz])
+
+
+def test_minmax_plane_ranges_and_overlapped_slab_step(gpu, ndi, self_comm):
+    """mi_minmax3d_u8_planes / mi_minmax3d_f32_planes: output planes produced range by range equal the whole-volume
+    launch bit for bit (uint8 cubic 3 / 5 / 7, float32 cubic 3 .. 9, every index-mapping mode, ranges that cut chunks);
+    what the fused kernels do not take raises Unsupported; SlabFilter's overlapped min / max step equals the plain one."""
+    from cupyimg_amd.scipy.ndimage import _support as S
+    from cupyimg_amd.distributed import SlabFilter
+    rng = np.random.default_rng(40)
+    u = rng.integers(0, 256, size=(37, 40, 128)).astype(np.uint8)
+    f = rng.standard_normal((37, 33, 264)).astype(np.float32)
+    for x, sizes in ((u, (3, 5, 7)), (f, (3, 5, 7, 9))):
+        xd = gpu.asarray(x)
+        for size in sizes:
+            for mode in ("reflect", "nearest", "mirror", "wrap"):
+                for fn in (ndi.minimum_filter, ndi.maximum_filter):
+                    full = fn(xd, size=size, mode=mode).get()
+                    out = gpu.zeros(x.shape, x.dtype)
+                    for ranges in ([(0, 5), (5, 30)], [(30, 37)]):
+                        with S.output_planes(ranges):
+                            fn(xd, size=size, mode=mode, output=out)
+                    assert np.array_equal(out.get(), full), (x.dtype, size, mode, fn.__name__)
+    with pytest.raises(S.Unsupported):
+        with S.output_planes([(0, 4)]):
+            ndi.minimum_filter(gpu.asarray(u), size=(3, 5, 5))          # not cubic: no plane-restricted kernel
+    with pytest.raises(S.Unsupported):
+        with S.output_planes([(0, 4)]):
+            ndi.minimum_filter(gpu.asarray(u.astype(np.int16)), size=3)
+    nz = u.shape[0]
+    sf = SlabFilter(_SelfLoopPlan(nz, 3, 3), u.shape[1:], np.uint8, self_comm)
+    sf.local_in[...] = gpu.asarray(u)
+    plain = sf.grey_erosion(7).get()
+    assert np.array_equal(sf.grey_erosion(7, overlap=True).get(), plain)
+    assert np.array_equal(plain, orc.grey_erosion(u, size=7, mode=["wrap", "reflect", "reflect"]))
+    sff = SlabFilter(_SelfLoopPlan(nz, 2, 2), f.shape[1:], np.float32, self_comm)
+    sff.local_in[...] = gpu.asarray(f)
+    plain = sff.maximum_filter(5, mode="mirror").get()
+    assert np.array_equal(sff.maximum_filter(5, mode="mirror", overlap=True).get(), plain)
+    assert np.array_equal(sff.minimum_filter((5, 3, 3), overlap=True).get(), sff.minimum_filter((5, 3, 3)).get())   # falls back
