@@ -9,6 +9,7 @@ hipcc cross-compiles for gfx950 without a GPU being present.
 import argparse
 import concurrent.futures
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -30,7 +31,8 @@ SOURCES = [
     ("separable3d.hip", []),
     ("stream3d.hip", []),
     ("stream_f64.hip", []),
-    ("sep3d_long.hip", []),
+    # MI_LONG_TUNE=1 in the environment adds the tuning variants of the 17-tap kernel (mi_debug_set_long_cfg)
+    ("sep3d_long.hip", ["-DMI_LONG_TUNE"] if os.environ.get("MI_LONG_TUNE") else []),
     ("minmax3d_f32.hip", []),
     ("correlate_nd.hip", ["-ffp-contract=off"]),
     ("stencil3d.hip", ["-ffp-contract=off"]),
@@ -103,9 +105,70 @@ def _compile(args):
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise RuntimeError("hipcc failed for {}:\n{}".format(src, proc.stdout))
+    if src in NO_SCRATCH:
+        spilled = _scratch_users(o, NO_SCRATCH[src])
+        if spilled:
+            os.unlink(o)
+            raise RuntimeError("{}: kernels that count their vector-memory operations by hand (s_waitcnt vmcnt) were "
+                               "compiled with scratch-memory accesses, which add uncounted ones: {}".format(src, spilled))
     if proc.stdout.strip():
         sys.stderr.write(proc.stdout)
     return o, True
+
+
+# Sources whose kernels wait on vmcnt by count (LDS-DMA rings): the name fragment selects the kernels that must not
+# touch scratch memory (a spill store or reload is one more vector-memory operation in flight than the count assumes).
+# The ablation builds of the r3 long kernel (<W, SAME, DBG = true, 0>) are exempt: timing aids, not product kernels.
+NO_SCRATCH = {"sep3d_long.hip": "sep3d_long", "minmax3d_f32.hip": "mm3f32_long"}
+
+
+def _device_code_object(obj):
+    """The gfx950 code object out of a hipcc host object (section .hip_fatbin, clang offload bundle)."""
+    import struct
+    import tempfile
+    objcopy = os.path.join(os.path.dirname(os.path.realpath(hipcc())), "..", "lib", "llvm", "bin", "llvm-objcopy")
+    if not os.path.exists(objcopy):
+        objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    with tempfile.TemporaryDirectory() as tmp:
+        fb = os.path.join(tmp, "fb.bin")
+        subprocess.run([objcopy, "--dump-section", ".hip_fatbin=" + fb, obj], check=True)
+        blob = open(fb, "rb").read()
+    if blob[:24] != b"__CLANG_OFFLOAD_BUNDLE__":
+        raise RuntimeError("unexpected fat binary layout in " + obj)
+    n = struct.unpack_from("<Q", blob, 24)[0]
+    off = 32
+    for _ in range(n):
+        o, sz, ts = struct.unpack_from("<QQQ", blob, off)
+        off += 24
+        triple = blob[off:off + ts].decode()
+        off += ts
+        if ARCH in triple:
+            return blob[o:o + sz]
+    raise RuntimeError("no {} code object in {}".format(ARCH, obj))
+
+
+def _scratch_users(obj, fragment):
+    """Kernels of `obj` whose name contains `fragment` and whose code has scratch_* instructions."""
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    with tempfile.TemporaryDirectory() as tmp:
+        co = os.path.join(tmp, "dev.co")
+        with open(co, "wb") as f:
+            f.write(_device_code_object(obj))
+        text = subprocess.run([objdump, "-d", co], stdout=subprocess.PIPE, text=True, check=True).stdout
+    bad, name, count = [], None, 0
+    def close():
+        if name and count and fragment in name and not ("sep3d_long3_kernel" in name and name.endswith("ELb1ELi0EEEvPKfPfNS_10LongParamsE")):
+            bad.append("{} ({} scratch instructions)".format(name, count))
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+        if m:
+            close()
+            name, count = m.group(1), 0
+        elif "\tscratch_" in line or " scratch_" in line:
+            count += 1
+    close()
+    return bad
 
 
 def build(force=False, jobs=None, verbose=True):

@@ -35,8 +35,6 @@
 
 namespace mi {
 
-constexpr int kLongTwoRowsFrom = 99;     // tap count from which the two-rows-per-wave kernel is the default (99 = never; set from measurements)
-
 struct LongParams {
     int nx, ny, nz;
     int oy, oz;             // w/2 + origin along y and z (x: W/2)
@@ -53,7 +51,11 @@ struct LongParams {
     // constant mode (HAS_CONST kernels): plain x weights, cval, cval * (product of the three weight sums)
     float wxs[kStreamMaxTaps];
     float cval, cval_sum;
-    int dbg;                // tuning ablations (0 in production): 1 y pass reads one row, 2 no x pass, 4 no z scatter, 8 no DMA, 16 no stores, 32 no halo table
+    // sep3d_long3_kernel: plain weights padded with a zero (pairs starting at an even tap); wxo[2k] = wx[2k-1],
+    // wxo[2k+1] = wx[2k] (pairs starting at an odd tap; wxo[0] = 0)
+    float wyp[kStreamMaxTaps + 1], wzp[kStreamMaxTaps + 1], wxe[kStreamMaxTaps + 1], wxo[kStreamMaxTaps + 1];
+    int dbg;                // tuning ablations (0 in production): 1 y pass reads one row, 2 no x pass, 4 no z scatter, 8 no DMA, 16 no stores, 32 no halo table,
+                            // 64 halo table at the end of the step (r3 kernel), 128 nothing (selects the ablation build)
 };
 
 // SAME: the three axes share one weight vector (uniform_filter(size=W), isotropic gaussian_filter): x pair tables
@@ -313,23 +315,124 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
 
 
 // ---------------------------------------------------------------------------
-// r3: the same kernel with TWO output rows per wave (8 waves, 256 x 16 tile, same LDS ring and DMA scheme).
-// The y pass of rows j and j + 1 reads W + 1 raw rows instead of 2 W (the 17-tap kernel is bound by VALU issue and by
-// the LDS reads the y pass waits for: rocprofv3 showed the VALU 61 % busy and ~600 k cycles per CU for ~365 k cycles of
-// VALU work; ablations in DESIGN.md): 9.5 instead of 17 ds_read_b128 per output row, twice the independent FMA work
-// behind every LDS wait, two waves per SIMD (up to 256 VGPRs: the 2 x W z accumulators take 136).
+// r3 kernel (`sep3d_long3_kernel`): same tile, ring, DMA and barrier scheme; what changed is the instruction stream,
+// after the ablations showed the 17-tap kernel bound by VALU issue (158 VALU instructions per wave and plane for 102
+// FMAs) with the VALU idle while the four waves of a SIMD all wait for the y-pass LDS reads right after the barrier.
+//   * Software pipelining: in step i a wave runs the x and z passes of plane i on the y-filtered row it made one
+//     step EARLIER, and in the same basic block the y pass of plane i + 1 (which barrier i already certifies as
+//     landed): the 17 LDS reads travel under 70 FMAs of independent work instead of in front of them.
+//   * x pass as 2 x (W + 1) packed FMAs with operand selection (op_sel) instead of a 2-vector dot product:
+//     (out0, out1) += (win[q], win[q]) * (w[t], w[t-1]),  (out2, out3) += (win[q], win[q]) * (w[t-2], w[t-3]),  t = q - BASE.
+//     The broadcast of win[q] and the swap of an aligned weight pair are free (op_sel / op_sel_hi), so there is no
+//     horizontal add and no register shuffling, and the weight pairs are the plain weights (pairs starting at an
+//     even tap) plus ONE shifted copy (pairs starting at an odd tap): 36 SGPRs for all three passes when the axes
+//     share a kernel, instead of 34 doubled weights + 40 pair-table entries that had to be re-loaded per phase.
+//   * The DPP lane shifts take the left halo blocks straight from their own LDS reads as the `old` operand (no
+//     v_mov per shifted register) and the right-hand shifts leave lane 63 undefined (the select for lane `last`
+//     follows anyway).
+//   * The ablation flags are a template parameter: the production instance is straight-line code.
+// Index-mapping boundary modes only: constant mode (zero fill + correction terms, five more live registers) stays on
+// sep3d_long_kernel, whose register budget has room for them.
 // ---------------------------------------------------------------------------
-template <int W, bool SAME, bool HAS_CONST>
-__global__ void __launch_bounds__(512)
-sep3d_long2_kernel(const float *__restrict__ in, float *__restrict__ out, const LongParams p)
+template <int I> __device__ __forceinline__ float f4_comp(const float4 &v)
 {
-    constexpr int NW = 8;                       // waves; wave w owns output rows 2 w, 2 w + 1
+    if constexpr (I == 0) return v.x;
+    else if constexpr (I == 1) return v.y;
+    else if constexpr (I == 2) return v.z;
+    else return v.w;
+}
+
+__device__ __forceinline__ float dpp_from_right_any(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+
+// (w[t], w[t-1]) out of te = plain weights (te[W] = 0) and to[2k] = w[2k-1], to[2k+1] = w[2k] (to[0] = 0)
+template <int T> __device__ __forceinline__ f32x2 xpair_rev(kfloats te, kfloats to)
+{
+    if constexpr (T & 1) return (f32x2){te[T], te[T - 1]};
+    else return (f32x2){to[T + 1], to[T]};
+}
+
+// x pass in two stages, so that the caller can place LDS reads between them and the register peak stays low:
+// `left` consumes the blocks left of the lane's own float4 (oL[j] = the (j+1)-th block left of the tile, what lane 0
+// takes instead of a neighbour's), `right` the own block and the blocks to the right (eR[j], for lane `last`).
+// Window float q = BASE + t feeds (out0, out1) with (w[t], w[t-1]) and (out2, out3) with (w[t-2], w[t-3]).
+template <int W>
+struct XPass3 {
+    static constexpr int RX = W / 2;
+    static constexpr int NBK = (RX + 3) / 4;
+    static constexpr int BASE = 4 * NBK - RX;
+    f32x2 P0, P1;
+
+    template <int Q>
+    __device__ __forceinline__ void feed(float wq, kfloats te, kfloats to)
+    {
+        constexpr int t = Q - BASE;
+        if constexpr (t >= 0 && t <= W + 2) {
+            const f32x2 ws = splat2(wq);
+            if constexpr (t <= W) {
+                if constexpr (t == 0) P0 = ws * xpair_rev<t>(te, to);
+                else P0 = fma2(ws, xpair_rev<t>(te, to), P0);
+            }
+            if constexpr (t >= 2) {
+                if constexpr (t == 2) P1 = ws * xpair_rev<t - 2>(te, to);
+                else P1 = fma2(ws, xpair_rev<t - 2>(te, to), P1);
+            }
+        }
+    }
+    template <int B>
+    __device__ __forceinline__ void feed_block(const float4 &v, kfloats te, kfloats to)
+    {
+        feed<4 * B>(v.x, te, to);
+        feed<4 * B + 1>(v.y, te, to);
+        feed<4 * B + 2>(v.z, te, to);
+        feed<4 * B + 3>(v.w, te, to);
+    }
+    __device__ __forceinline__ void left(const float4 v, const float4 (&oL)[2], kfloats te, kfloats to)
+    {
+        float4 l[NBK];
+        float4 c = v;
+#pragma unroll
+        for (int j = 0; j < NBK; j++) {
+            c = dpp4_shr(oL[j], c);
+            l[j] = c;
+        }
+        // taps in ascending order: farthest block first
+        static_for<NBK>([&](auto BB) {
+            constexpr int bq = decltype(BB)::value;
+            feed_block<bq>(l[NBK - 1 - bq], te, to);
+        });
+    }
+    __device__ __forceinline__ F4 right(const float4 v, const float4 (&eR)[2], int lane, int last, kfloats te, kfloats to)
+    {
+        feed_block<NBK>(v, te, to);
+        float4 c = v;
+        static_for<NBK>([&](auto BB) {
+            constexpr int j = decltype(BB)::value;
+            const float4 rr = make_float4(dpp_from_right_any(c.x), dpp_from_right_any(c.y), dpp_from_right_any(c.z), dpp_from_right_any(c.w));
+            c = lane == last ? eR[j] : rr;
+            feed_block<NBK + 1 + j>(c, te, to);
+        });
+        F4 o;
+        o.lo = P0;
+        o.hi = P1;
+        return o;
+    }
+};
+
+// CFG (tuning, see launch_long): bits 0-2 first y read group, bits 3-6 end of the second group, bit 7 halo table at
+// the end of the step instead of the start; 0 = the defaults below.
+template <int W, bool SAME, bool DBG, int CFG = 0>
+__global__ void __launch_bounds__(kLongTY * 64)
+sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const LongParams p)
+{
     constexpr int ROWS = kLongTY + W - 1;
     static_assert(W >= 3 && (W & 1) && ROWS <= kLongRowsMax && W / 2 <= 8, "long kernel: odd W, 3..17");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr unsigned HY0 = kLongRawBytes;
     int *ztab = reinterpret_cast<int *>(smem + kLongRawBytes + kLongHyBytes);
-    float *cztab = reinterpret_cast<float *>(ztab + kLongMaxChunk + kStreamMaxTaps);
+    const int dbg = DBG ? p.dbg : 0;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -360,179 +463,184 @@ sep3d_long2_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     const int zi0 = zs - p.oz;
     const int nsteps = ze - zs + W - 1;
 
-    for (int i = threadIdx.x; i < nsteps; i += NW * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
-    [[maybe_unused]] float cyv[2] = {0.f, 0.f};
-    [[maybe_unused]] F4 cxv = f4_splat(0.f);
-    if constexpr (HAS_CONST) {
-        for (int t = threadIdx.x; t < ze - zs; t += NW * 64) {
-            float c = 0.f;
-            for (int k = 0; k < W; k++) {
-                const int q = zs + t - p.oz + k;
-                c += (p.mz != MI_MODE_CONSTANT || (q >= 0 && q < nz)) ? p.wzv[2 * k] : 0.f;
-            }
-            cztab[t] = c;
-        }
-        float cx4[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < W; k++) {
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const int qy = y0 + 2 * wave + r - p.oy + k;
-                cyv[r] += (p.my != MI_MODE_CONSTANT || (qy >= 0 && qy < ny)) ? p.wyv[2 * k] : 0.f;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int qx = x0 + 4 * lane + c - W / 2 + k;
-                cx4[c] += (p.mx != MI_MODE_CONSTANT || (qx >= 0 && qx < nx)) ? p.wxs[k] : 0.f;
-            }
-        }
-        cxv.lo = (f32x2){cx4[0], cx4[1]};
-        cxv.hi = (f32x2){cx4[2], cx4[3]};
-    }
+    for (int i = threadIdx.x; i < nsteps; i += kLongTY * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
     __syncthreads();
 
-    // raw rows this wave stages per plane: wave, wave + 8, wave + 16, wave + 24
-    unsigned vmain[4], vhalo[4];
+    unsigned vmain[2], vhalo[2];
 #pragma unroll
-    for (int h = 0; h < 4; h++) {
-        const int r = wave + NW * h;
+    for (int h = 0; h < 2; h++) {
+        const int r = wave + 16 * h;
         const int ys = bmap<int>(y0 - p.oy + r, ny, p.my);
-        const bool valid = r < rows_needed && ys >= 0;
+        const bool valid = r < rows_needed;
         vmain[h] = (valid && lane < nlanes) ? (unsigned)(ys * nx + x0 + 4 * lane) * 4u : kOOB;
         const int j = lane & 15;
         const int xsrc = bmap<int>(j < 8 ? x0 - 8 + j : xe + j - 8, nx, p.mx);
         vhalo[h] = (valid && xsrc >= 0) ? (unsigned)(ys * nx + xsrc) * 4u : kOOB;
     }
-    const unsigned own = (unsigned)(2 * wave) * kLongRec + (unsigned)lane * 16u;    // first raw record of output row 2 w
+    const unsigned own = (unsigned)wave * kLongRec + (unsigned)lane * 16u;      // this lane's block of record `wave`
+    // halo pass (one wave per plane): lane -> (row = lane / 4, block = lane % 4) of the record's 64 halo bytes
     const unsigned hsrc = (unsigned)(lane >> 2) * kLongRec + 1024u + (unsigned)(lane & 3) * 16u;
-    unsigned hy_near[2], hy_far[2], ovoff[2];
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int j = 2 * wave + r;
-        hy_near[r] = HY0 + (unsigned)j * 64u + (lane == 0 ? 16u : 32u);
-        hy_far[r] = HY0 + (unsigned)j * 64u + (lane == 0 ? 0u : 48u);
-        ovoff[r] = (j < ty_act && lane < nlanes) ? (unsigned)((y0 + j) * nx + x0 + 4 * lane) * 4u : kOOB;
-    }
+    // this row's four y-filtered halo blocks in the table: far left, near left, near right, far right
+    const unsigned hy_row = HY0 + (unsigned)wave * 64u;
+    const unsigned ovoff = (wave < ty_act && lane < nlanes) ? (unsigned)((y0 + wave) * nx + x0 + 4 * lane) * 4u : kOOB;
     constexpr unsigned kPlane = kLongRowsMax * kLongRec;
 
     auto issue = [&](int i, unsigned bufoff) {
-        bool live = i < nsteps;
+        // plane of step i; beyond the last step the descriptor has zero records (no fetch), so that every step issues
+        // the same four DMAs and the vmcnt arithmetic stays uniform
+        const bool live = i < nsteps;
         int zsrc = zi0 + i;
-        if ((unsigned)zsrc >= (unsigned)nz) zsrc = __builtin_amdgcn_readfirstlane(ztab[live ? i : 0]);
-        if constexpr (HAS_CONST) {
-            live = live && zsrc >= 0;
-            zsrc = max(zsrc, 0);
-        }
+        if ((unsigned)zsrc >= (unsigned)nz) zsrc = __builtin_amdgcn_readfirstlane(ztab[live ? i : 0]);   // boundary planes only
         const unsigned long long a = (unsigned long long)in + (unsigned long long)(unsigned)zsrc * (unsigned long long)plane_bytes;
         u32x4_t rin;
         rin.x = (unsigned)a;
-        rin.y = (unsigned)(a >> 32);
+        rin.y = (unsigned)(a >> 32);       // stride 0: the upper 16 bits of a device address are zero
         rin.z = live ? plane_bytes : 0u;
         rin.w = 0x00020000u;
-        if (!(p.dbg & 8)) {
-            dma_two_rows(rin, vmain[0], vhalo[0], vmain[2], vhalo[2], bufoff + (unsigned)wave * kLongRec);            // rows w, w + 16
-            dma_two_rows(rin, vmain[1], vhalo[1], vmain[3], vhalo[3], bufoff + (unsigned)(wave + NW) * kLongRec);     // rows w + 8, w + 24
-        }
+        if (!(dbg & 8)) dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec);
     };
     constexpr int kArgBase = 2 * sizeof(void *);
-    kfloats wyk = kernarg_floats(kArgBase + offsetof(LongParams, wyv));
-    kfloats wzk = SAME ? wyk : kernarg_floats(kArgBase + offsetof(LongParams, wzv));
-    kfloats xt0 = kernarg_floats(kArgBase + offsetof(LongParams, xpair));
-    kfloats xt1 = xt0 + 2 * (kStreamMaxTaps / 2 + 2);
+    kfloats wyk = kernarg_floats(kArgBase + offsetof(LongParams, wyp));
+    kfloats wzk = SAME ? wyk : kernarg_floats(kArgBase + offsetof(LongParams, wzp));
+    kfloats xte = SAME ? wyk : kernarg_floats(kArgBase + offsetof(LongParams, wxe));
+    kfloats xto = kernarg_floats(kArgBase + offsetof(LongParams, wxo));
 
-    // y pass of ONE row (the halo table): W consecutive records starting at LDS byte address `at`
+    // y pass of W consecutive records starting at LDS byte address `at`
     auto ypass = [&](unsigned at) {
         const float4 t0 = *reinterpret_cast<const float4 *>(smem + at);
-        F4 yv = f4_scale2((f32x2){wyk[0], wyk[1]}, f4_from(t0));
+        F4 yv = f4_scale(wyk[0], f4_from(t0));
+        if (dbg & 1) return yv;
 #pragma unroll
         for (int k = 1; k < W; k++) {
             const float4 t = *reinterpret_cast<const float4 *>(smem + at + k * kLongRec);
-            yv = f4_fma2((f32x2){wyk[2 * k], wyk[2 * k + 1]}, f4_from(t), yv);
+            yv = f4_fma(wyk[k], f4_from(t), yv);
         }
         return yv;
     };
-    // y pass of rows j and j + 1 from the W + 1 records starting at `at`: raw row k is tap k of row j, tap k - 1 of row j + 1
-    auto ypass2 = [&](unsigned at, F4 &ya, F4 &yb) {
-        const float4 t0 = *reinterpret_cast<const float4 *>(smem + at);
-        ya = f4_scale2((f32x2){wyk[0], wyk[1]}, f4_from(t0));
-        if (p.dbg & 1) { yb = ya; return; }
+
+    // the same for the wave that makes the halo table on top of its own step: all reads in flight as early as the
+    // registers allow (9, then 4 more as each 4 are consumed) -- what this pass costs the workgroup is its latency
+    auto ypass_batched = [&](unsigned at) {
+        constexpr int H = W < 9 ? W : 9;
+        float4 t[W];
+        const int rows = (dbg & 1) ? 1 : W;
+        const char *src = smem + at;
 #pragma unroll
-        for (int k = 1; k < W; k++) {
-            const F4 t = f4_from(*reinterpret_cast<const float4 *>(smem + at + k * kLongRec));
-            ya = f4_fma2((f32x2){wyk[2 * k], wyk[2 * k + 1]}, t, ya);
-            if (k == 1) yb = f4_scale2((f32x2){wyk[0], wyk[1]}, t);
-            else yb = f4_fma2((f32x2){wyk[2 * k - 2], wyk[2 * k - 1]}, t, yb);
-        }
-        const F4 t = f4_from(*reinterpret_cast<const float4 *>(smem + at + W * kLongRec));
-        yb = f4_fma2((f32x2){wyk[2 * W - 2], wyk[2 * W - 1]}, t, yb);
+        for (int k = 0; k < H; k++) if (k < rows) t[k] = *reinterpret_cast<const float4 *>(src + k * kLongRec);
+        __builtin_amdgcn_sched_barrier(0);
+        F4 hv = f4_scale(wyk[0], f4_from(t[0]));
+        static_for<(W + 3) / 4>([&](auto GG) {
+            constexpr int g = decltype(GG)::value;
+#pragma unroll
+            for (int k = 4 * g; k < 4 * g + 4 && k < W; k++) if (k >= 1 && k < rows) hv = f4_fma(wyk[k], f4_from(t[k]), hv);
+#pragma unroll
+            for (int k = H + 4 * g; k < H + 4 * g + 4 && k < W; k++) if (k < rows) t[k] = *reinterpret_cast<const float4 *>(src + k * kLongRec);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        return hv;
     };
 
-    F4 acc[2][W];
+    F4 acc[W];
 #pragma unroll
-    for (int r = 0; r < 2; r++)
-#pragma unroll
-        for (int k = 0; k < W; k++) acc[r][k] = f4_splat(0.f);
+    for (int k = 0; k < W; k++) acc[k] = f4_splat(0.f);
 
+    // prologue: planes 0..2 in flight; plane 0 complete -> its y pass (every wave) and its halo table (wave 15)
     issue(0, 0);
     issue(1, kPlane);
     issue(2, 2 * kPlane);
-    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-    if (wave == NW - 1) {
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    F4 yv = ypass(own);
+    if (wave == 15) {
         const F4 hv = ypass(hsrc);
         *reinterpret_cast<float4 *>(smem + HY0 + (unsigned)lane * 16u) = f4_to_float4(hv);
     }
 
-    unsigned bi = 0;
+    // Interval i (after barrier i): plane i + 1 has landed (each wave waited for its own DMAs of plane i + 1; those of
+    // plane i + 2 and the store behind them may be in flight), the halo table of plane i is complete, the y-filtered row
+    // of plane i is in `yv`; nobody reads plane i - 1 any more (nor plane i): its slot takes plane i + 3.
+    unsigned bi = 0;                    // LDS offset of plane i
     for (int i0 = 0; i0 < nsteps; i0 += W) {
         static_for<W>([&](auto JJ) {
             constexpr int J = decltype(JJ)::value;
             const int i = i0 + J;
             if (i < nsteps) {
-                if constexpr (!SAME) { launder(wyk); launder(wzk); launder(xt0); launder(xt1); }
-                const unsigned b1 = bi == (kLongNB - 1) * kPlane ? 0u : bi + kPlane;
-                const unsigned b3 = bi == 0u ? (kLongNB - 1) * kPlane : bi - kPlane;
-                // in flight, oldest first: 8 DMAs of plane i + 1, 2 stores, 8 DMAs of plane i + 2, 2 stores (see the
-                // one-row kernel): plane i + 1 must have landed, the rest stays in flight
-                if (i >= W && !(p.dbg & 16)) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                issue(i + 3, b3);
+                if constexpr (!SAME) { launder(wyk); launder(wzk); launder(xte); launder(xto); }
+                const unsigned b1 = bi == (kLongNB - 1) * kPlane ? 0u : bi + kPlane;     // plane i + 1
+                const unsigned b3 = bi == 0u ? (kLongNB - 1) * kPlane : bi - kPlane;     // slot of plane i - 1
+                // In flight from this wave, oldest first: the 4 DMAs of plane i + 1, the store of step i - 2, the 4 DMAs
+                // of plane i + 2, the store of step i - 1 (a store is issued in EVERY step: before the first complete
+                // output it goes to a descriptor of zero records).  Plane i + 1 must have landed: vmcnt(5); step 0 has
+                // only the 8 DMAs of the prologue behind it: vmcnt(4).
+                if ((J == 0 && i0 == 0) || (dbg & 16)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
-                F4 yv[2];
-                ypass2(own + bi, yv[0], yv[1]);
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    float4 eL[2], eR[2];
-                    {
-                        const float4 n = *reinterpret_cast<const float4 *>(smem + hy_near[r] + hyoff);
-                        const float4 f = *reinterpret_cast<const float4 *>(smem + hy_far[r] + hyoff);
-                        eL[0] = n; eL[1] = f; eR[0] = n; eR[1] = f;
+                // ---- halo table of plane i + 1 (the wave changes every plane).  First thing in the step: its reads travel
+                // while the other waves of the SIMD have their whole step to issue.
+                auto halo_job = [&]() {
+                    if (i + 1 < nsteps && wave == (i & 15) && !(dbg & 32)) {
+                        const F4 hv = ypass_batched(hsrc + b1);
+                        *reinterpret_cast<float4 *>(smem + HY0 + (kLongHyBytes / 2 - hyoff) + (unsigned)lane * 16u) = f4_to_float4(hv);
                     }
-                    const F4 xy = (p.dbg & 2) ? yv[r] : xhops<W>(f4_to_float4(yv[r]), eL, eR, lane, last, xt0, xt1);
-                    acc[r][J] = f4_scale2((f32x2){wzk[0], wzk[1]}, xy);
-                    if (!(p.dbg & 4)) {
+                };
+                constexpr bool kHaloEnd = (CFG >> 7) & 1;
+                if (kHaloEnd ? (dbg & 64) != 0 : !(dbg & 64)) halo_job();
+                // ---- x and z passes of plane i, with the y pass of plane i + 1 (for the next step; past the last plane it
+                // reads a slot nobody needs) threaded through them by hand: the LDS reads of a group are issued one block
+                // of FMAs before they are consumed (sched_barrier keeps the compiler from regrouping them; the group
+                // sizes are what the register file allows: 128 VGPRs, 68 of them z accumulators).  
+#ifndef MI_LONG_GA
+#define MI_LONG_GA 4
+#endif
+                constexpr int GA0 = CFG ? (CFG & 7) : MI_LONG_GA;
+                constexpr int GB0 = CFG ? ((CFG >> 3) & 15) : (SAME && !DBG) ? 12 : 10;     // the re-loading variants keep more scalars alive
+                constexpr int GA = W < GA0 ? W : GA0, GB = W < GB0 ? W : GB0, ZH = W / 2;
+                const int wy_rows = (dbg & 1) ? 1 : W, wz_taps = (dbg & 4) ? 1 : W;
+                float4 oL[2], eR[2], R[W];
+                const char *ysrc = smem + own + b1;
+                issue(i + 3, b3);
+                oL[1] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff);
+                oL[0] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 16u);
+                __builtin_amdgcn_sched_barrier(0);
+                XPass3<W> xp;
+                const float4 yv4 = f4_to_float4(yv);
+                if (!(dbg & 2)) xp.left(yv4, oL, xte, xto);
+                eR[0] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 32u);
+                eR[1] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 48u);
 #pragma unroll
-                        for (int k = 1; k < W; k++)
-                            acc[r][(J - k + W) % W] = f4_fma2((f32x2){wzk[2 * k], wzk[2 * k + 1]}, xy, acc[r][(J - k + W) % W]);
-                    }
-                }
-                if (i >= W - 1) {
+                for (int k = 0; k < GA; k++) if (k < wy_rows) R[k] = *reinterpret_cast<const float4 *>(ysrc + k * kLongRec);
+                __builtin_amdgcn_sched_barrier(0);
+                const F4 xy = (dbg & 2) ? yv : xp.right(yv4, eR, lane, last, xte, xto);
+                __builtin_amdgcn_sched_barrier(0);
+                yv = f4_scale(wyk[0], f4_from(R[0]));
+#pragma unroll
+                for (int k = 1; k < GA; k++) if (k < wy_rows) yv = f4_fma(wyk[k], f4_from(R[k]), yv);
+#pragma unroll
+                for (int k = GA; k < GB; k++) if (k < wy_rows) R[k] = *reinterpret_cast<const float4 *>(ysrc + k * kLongRec);
+                __builtin_amdgcn_sched_barrier(0);
+                // z pass: scatter into the pending outputs; output i - k takes tap k
+                acc[J] = f4_scale(wzk[0], xy);
+#pragma unroll
+                for (int k = 1; k < ZH; k++) if (k < wz_taps) acc[(J - k + W) % W] = f4_fma(wzk[k], xy, acc[(J - k + W) % W]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = GA; k < GB; k++) if (k < wy_rows) yv = f4_fma(wyk[k], f4_from(R[k]), yv);
+#pragma unroll
+                for (int k = GB; k < W; k++) if (k < wy_rows) R[k] = *reinterpret_cast<const float4 *>(ysrc + k * kLongRec);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = ZH < 1 ? 1 : ZH; k < W; k++) if (k < wz_taps) acc[(J - k + W) % W] = f4_fma(wzk[k], xy, acc[(J - k + W) % W]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = GB; k < W; k++) if (k < wy_rows) yv = f4_fma(wyk[k], f4_from(R[k]), yv);
+                {
                     const unsigned long long oa = (unsigned long long)out +
                                                   (unsigned long long)(unsigned)(zs + i - (W - 1)) * (unsigned long long)plane_bytes;
-                    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)oa, 0, (int)plane_bytes, 0x00020000);
-#pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        F4 o = acc[r][(J + 1) % W];
-                        if constexpr (HAS_CONST) {
-                            const float g = -p.cval * cztab[i - (W - 1)] * cyv[r];
-                            o.lo = fma2(splat2(g), cxv.lo, o.lo + splat2(p.cval_sum));
-                            o.hi = fma2(splat2(g), cxv.hi, o.hi + splat2(p.cval_sum));
-                        }
-                        if (!(p.dbg & 16)) __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(o), rout, ovoff[r], 0, 2);
-                    }
+                    const __amdgpu_buffer_rsrc_t rout =
+                        __builtin_amdgcn_make_buffer_rsrc((void *)oa, 0, i >= W - 1 ? (int)plane_bytes : 0, 0x00020000);
+                    const F4 o = acc[(J + 1) % W];
+                    if (!(dbg & 16)) __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(o), rout, ovoff, 0, 2);
                 }
-                if (i + 1 < nsteps && wave == (i & (NW - 1)) && !(p.dbg & 32)) {
-                    const F4 hv = ypass(hsrc + b1);
-                    *reinterpret_cast<float4 *>(smem + HY0 + (kLongHyBytes / 2 - hyoff) + (unsigned)lane * 16u) = f4_to_float4(hv);
-                }
+                if (kHaloEnd ? !(dbg & 64) : (dbg & 64) != 0) halo_job();
                 bi = b1;
             }
         });
@@ -540,38 +648,74 @@ sep3d_long2_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-static mi::Knob g_long_rows{0};        // rows per wave: 0 = auto, 1 = one row (16 waves), 2 = two rows (8 waves)
-static bool long_two_rows(int w) { const int k = g_long_rows; return k == 2 || (k == 0 && w >= kLongTwoRowsFrom); }
+static mi::Knob g_long_rows{0};        // kernel generation: 0 = auto (r3 pipelined kernel), 1 = the r2 kernel (kept for 9 / 13 / 17 taps as the comparator)
+static mi::Knob g_long_dbg{0};         // tuning ablations, see LongParams::dbg
+static mi::Knob g_long_cfg{0};         // MI_LONG_TUNE builds: which tuning variant of the 17-tap kernel runs
+
+#ifdef MI_LONG_DEV
+#define MI_LONG_OLD(W) ((W) == 17)
+#else
+#define MI_LONG_OLD(W) ((W) == 9 || (W) == 13 || (W) == 17)
+#endif
+
+template <typename K>
+static int long_launch_one(K kernel, bool &attr_done, size_t lds, int total, const float *in, float *out, const LongParams &p, hipStream_t s)
+{
+    if (!attr_done) {
+        MI_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(total), dim3(kLongTY * 64), lds, s, in, out, p);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
 
 template <int W, bool SAME, bool HAS_CONST>
 static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s)
 {
     const size_t lds = (size_t)kLongRawBytes + kLongHyBytes + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int) +
                        (HAS_CONST ? (size_t)kLongMaxChunk * sizeof(float) : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)sep3d_long_kernel<W, SAME, HAS_CONST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
     const int total = p.nxt * p.nyt * p.nzc;
-    // the two-row variant is instantiated for 9, 13 and 17 taps only (it is a measured-slower knob, not a product path)
-    if constexpr (W == 9 || W == 13 || W == 17) if (long_two_rows(W)) {
-        static bool attr2_done = false;
-        if (!attr2_done) {
-            MI_HIP(hipFuncSetAttribute((const void *)sep3d_long2_kernel<W, SAME, HAS_CONST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr2_done = true;
+    if constexpr (HAS_CONST) {
+        // constant mode keeps the r2 kernel: its correction terms (five more live registers) do not fit beside the r3
+        // kernel's read groups without spilling, and a spill is a vector-memory operation the vmcnt arithmetic does not count
+        static bool attr_c = false;
+        note_kernel("mi::sep3d_long_kernel<%d,%s,true> grid=%d (fused y/x/z separable pass, LDS-DMA staged, constant mode)", W,
+                    SAME ? "true" : "false", total);
+        return long_launch_one(sep3d_long_kernel<W, SAME, true>, attr_c, lds, total, in, out, p, s);
+    } else {
+        if constexpr (MI_LONG_OLD(W)) {
+            if (g_long_rows == 1) {
+                static bool attr_old = false;
+                note_kernel("mi::sep3d_long_kernel<%d,%s,false> grid=%d (fused y/x/z separable pass, LDS-DMA staged, r2 instruction stream)", W,
+                            SAME ? "true" : "false", total);
+                return long_launch_one(sep3d_long_kernel<W, SAME, false>, attr_old, lds, total, in, out, p, s);
+            }
+            // the ablation flags exist in these instances only
+            if (p.dbg != 0) {
+                static bool attr_dbg = false;
+                note_kernel("mi::sep3d_long3_kernel<%d,%s,true> grid=%d (ablation build, dbg=%d)", W, SAME ? "true" : "false", total, p.dbg);
+                return long_launch_one(sep3d_long3_kernel<W, SAME, true>, attr_dbg, lds, total, in, out, p, s);
+            }
         }
-        note_kernel("mi::sep3d_long2_kernel<%d,%s,%s> grid=%d (fused y/x/z separable pass, LDS-DMA staged, two rows per wave)", W,
-                    SAME ? "true" : "false", HAS_CONST ? "true" : "false", total);
-        hipLaunchKernelGGL((sep3d_long2_kernel<W, SAME, HAS_CONST>), dim3(total), dim3(512), lds, s, in, out, p);
-        MI_HIP(hipGetLastError());
-        return MI_OK;
+#ifdef MI_LONG_TUNE
+        if constexpr (W == 17 && SAME) {
+            const int cfg = g_long_cfg;
+#define MI_LONG_CFG(C)                                                                                           \
+            if (cfg == (C)) {                                                                                    \
+                static bool attr_c = false;                                                                      \
+                note_kernel("mi::sep3d_long3_kernel<17,true,false,%d> grid=%d (tuning variant)", (C), total);    \
+                return long_launch_one(sep3d_long3_kernel<17, true, false, (C)>, attr_c, lds, total, in, out, p, s); \
+            }
+            MI_LONG_CFG(4 | (10 << 3)) MI_LONG_CFG(4 | (8 << 3)) MI_LONG_CFG(3 | (10 << 3))
+#undef MI_LONG_CFG
+        }
+#endif
+        static bool attr_done = false;
+        note_kernel("mi::sep3d_long3_kernel<%d,%s> grid=%d (fused y/x/z separable pass, LDS-DMA staged, y pass one plane ahead)", W,
+                    SAME ? "true" : "false", total);
+        return long_launch_one(sep3d_long3_kernel<W, SAME, false>, attr_done, lds, total, in, out, p, s);
     }
-    note_kernel("mi::sep3d_long_kernel<%d,%s,%s> grid=%d (fused y/x/z separable pass, LDS-DMA staged)", W,
-                SAME ? "true" : "false", HAS_CONST ? "true" : "false", total);
-    hipLaunchKernelGGL((sep3d_long_kernel<W, SAME, HAS_CONST>), dim3(total), dim3(kLongTY * 64), lds, s, in, out, p);
-    MI_HIP(hipGetLastError());
-    return MI_OK;
 }
 
 static int long_cus()
@@ -588,7 +732,6 @@ static int long_cus()
 
 static mi::Knob g_long_zchunks{0};     // test hook: number of z chunks (0 = cost model)
 static mi::Knob g_long_same{1};        // test hook: 0 = always the reloading variant
-static mi::Knob g_long_dbg{0};         // tuning ablations, see LongParams::dbg
 
 // Fused long-kernel path: cubic odd W in 11..17 (9 behind the test hook), origins on y / z allowed, no constant mode.
 // Returns MI_ERR_UNSUPPORTED when the request is outside that (the caller runs the streaming passes).
@@ -612,6 +755,8 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
         p.wyv[2 * k] = p.wyv[2 * k + 1] = wy[k];
         p.wzv[2 * k] = p.wzv[2 * k + 1] = wz[k];
         p.wxs[k] = wx[k];
+        p.wyp[k] = wy[k]; p.wzp[k] = wz[k]; p.wxe[k] = wx[k];
+        p.wxo[k + 1] = wx[k];                               // wxo[2m] = wx[2m-1], wxo[2m+1] = wx[2m]
         sx += wx[k]; sy += wy[k]; sz += wz[k];
     }
     p.dbg = g_long_dbg;
@@ -655,7 +800,11 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
         if (has_const) return same ? launch_long<N, true, true>(in, out, p, s) : launch_long<N, false, true>(in, out, p, s); \
         return same ? launch_long<N, true, false>(in, out, p, s) : launch_long<N, false, false>(in, out, p, s);
     switch (w) {
+#ifdef MI_LONG_DEV
+        MI_LONG_CASE(17)
+#else
         MI_LONG_CASE(3) MI_LONG_CASE(5) MI_LONG_CASE(7) MI_LONG_CASE(9) MI_LONG_CASE(11) MI_LONG_CASE(13) MI_LONG_CASE(15) MI_LONG_CASE(17)
+#endif
     }
 #undef MI_LONG_CASE
     return MI_ERR_UNSUPPORTED;
@@ -667,3 +816,4 @@ extern "C" int mi_debug_set_long_zchunks(int n) { mi::g_long_zchunks = n; return
 extern "C" int mi_debug_set_long_same(int n) { mi::g_long_same = n; return MI_OK; }
 extern "C" int mi_debug_set_long_dbg(int f) { mi::g_long_dbg = f; return MI_OK; }
 extern "C" int mi_debug_set_long_rows(int k) { mi::g_long_rows = k; return MI_OK; }
+extern "C" int mi_debug_set_long_cfg(int k) { mi::g_long_cfg = k; return MI_OK; }
