@@ -422,7 +422,8 @@ struct XPass3 {
 };
 
 // CFG (tuning, see launch_long): bits 0-2 first y read group, bits 3-6 end of the second group, bit 7 halo table at
-// the end of the step instead of the start; 0 = the defaults below.
+// the end of the step instead of the start, bit 8 no priority raise for the wave that makes the halo table; 0 = the
+// defaults below.
 template <int W, bool SAME, bool DBG, int CFG = 0>
 __global__ void __launch_bounds__(kLongTY * 64)
 sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const LongParams p)
@@ -578,6 +579,9 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 // while the other waves of the SIMD have their whole step to issue.
                 auto halo_job = [&]() {
                     if (i + 1 < nsteps && wave == (i & 15) && !(dbg & 32)) {
+                        // this wave has one row more to filter than the other three of its SIMD: it goes first for the rest
+                        // of the step, so that the extra work is shared out instead of left over at the barrier
+                        if constexpr (((CFG >> 8) & 1) == 0) __builtin_amdgcn_s_setprio(3);
                         const F4 hv = ypass_batched(hsrc + b1);
                         *reinterpret_cast<float4 *>(smem + HY0 + (kLongHyBytes / 2 - hyoff) + (unsigned)lane * 16u) = f4_to_float4(hv);
                     }
@@ -641,6 +645,7 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                     if (!(dbg & 16)) __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(o), rout, ovoff, 0, 2);
                 }
                 if (kHaloEnd ? !(dbg & 64) : (dbg & 64) != 0) halo_job();
+                if constexpr (((CFG >> 8) & 1) == 0) __builtin_amdgcn_s_setprio(0);
                 bi = b1;
             }
         });
@@ -707,7 +712,7 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
                 note_kernel("mi::sep3d_long3_kernel<17,true,false,%d> grid=%d (tuning variant)", (C), total);    \
                 return long_launch_one(sep3d_long3_kernel<17, true, false, (C)>, attr_c, lds, total, in, out, p, s); \
             }
-            MI_LONG_CFG(4 | (10 << 3)) MI_LONG_CFG(4 | (8 << 3)) MI_LONG_CFG(3 | (10 << 3))
+            MI_LONG_CFG(4 | (12 << 3) | 256) MI_LONG_CFG(4 | (10 << 3))
 #undef MI_LONG_CFG
         }
 #endif
