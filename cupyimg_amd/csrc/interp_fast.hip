@@ -219,9 +219,18 @@ __device__ __forceinline__ void taps(const __amdgpu_buffer_rsrc_t in, const Fast
 
 // (1 - w) lo + w hi, the upper sample skipped when its weight is zero.  Not lo + w (hi - lo): with an infinite `lo`
 // that form gives inf - inf = NaN where SciPy's weighted sum gives the infinity.
+// float32: the skip is the multiply itself -- v_mul_legacy_f32 returns 0 for 0 x anything (infinities and NaNs
+// included), so a zero weight removes the upper sample without a compare and a select per blend (r3: 10 of the 72
+// VALU instructions per voxel of the order-1 kernels were those), and (1 - 0) lo + 0 = lo.
+__device__ __forceinline__ float mul_zero_wins(float a, float b)
+{
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float lerp_skip(float lo, float hi, float w)
 {
-    return w == 0.f ? lo : fmaf(w, hi, (1.f - w) * lo);
+    return fmaf(1.f - w, lo, mul_zero_wins(w, hi));
 }
 __device__ __forceinline__ double lerp_skip(double lo, double hi, double w)
 {
@@ -260,28 +269,29 @@ __device__ __forceinline__ T finish(const Taps<T> &t, T cval)
 //     inside; negative ones are outside by their sign bit): 15 instead of 28 float64 operations per voxel.
 // ---------------------------------------------------------------------------
 typedef float f32x4n __attribute__((ext_vector_type(4)));      // what the non-temporal builtins take
-struct C1Split { int i0; float w1; bool frz; bool neg; };
+struct C1Split { int i0; float w1; bool in; };
 
-// c -> (trunc(c), fraction as float, fraction == 0 in double, c < 0).  For c >= 0: trunc = floor and v_fract_f64 =
-// c - floor(c) exactly; c < 0 (incl. (-1, 0), where trunc gives 0) is reported by `neg` and never read.
-__device__ __forceinline__ C1Split c1_split(double c)
+// c -> (trunc(c), fraction as float, 0 <= c <= n - 1) for an axis of n samples.  For c >= 0: trunc = floor and
+// v_fract_f64 = c - floor(c) exactly.  `in` is the closed interval on the coordinate itself, which is what the tap
+// logic of the reference amounts to in `constant` mode (lower tap floor(c) inside, and the upper tap either inside or
+// unused because the fraction is zero): c in [0, n - 1) has both taps inside, c == n - 1 has fraction 0, anything else
+// is cval -- two float64 compares instead of six mixed ones per axis.  -0.0 is inside, a NaN coordinate stays "inside"
+// and blends to NaN as before.
+__device__ __forceinline__ C1Split c1_split(double c, int n)
 {
     C1Split r;
-    r.neg = c < 0.0;
+    r.in = !(c < 0.0) & !(c > (double)(n - 1));
     r.i0 = __double2int_rz(c);
-    const double fr = __builtin_amdgcn_fract(c);
-    r.w1 = (float)fr;
-    r.frz = fr == 0.0;
+    r.w1 = (float)__builtin_amdgcn_fract(c);
     return r;
 }
-__device__ __forceinline__ C1Split c1_split(float c)
+__device__ __forceinline__ C1Split c1_split(float c, int n)
 {
     C1Split r;
     const float f = floorf(c);
-    r.neg = c < 0.f;
+    r.in = !(c < 0.f) & !(c > (float)(n - 1));
     r.i0 = (int)f;
     r.w1 = c - f;                      // exact in float
-    r.frz = r.w1 == 0.f;
     return r;
 }
 
@@ -290,27 +300,21 @@ __device__ __forceinline__ void c1_gather(const __amdgpu_buffer_rsrc_t in, const
                                           const C1Split &sy, const C1Split &sx, Taps<float> &t)
 {
     t.wz1 = sz.w1; t.wy1 = sy.w1; t.wx1 = sx.w1;
-    const bool in_z = !sz.neg & (((unsigned)sz.i0 < (unsigned)(p.nz - 1)) | ((sz.i0 == p.nz - 1) & sz.frz));
-    const bool in_y = !sy.neg & (((unsigned)sy.i0 < (unsigned)(p.ny - 1)) | ((sy.i0 == p.ny - 1) & sy.frz));
-    const bool in_x = !sx.neg & (((unsigned)sx.i0 < (unsigned)(p.nx - 1)) | ((sx.i0 == p.nx - 1) & sx.frz));
+    const bool in_z = sz.in;
+    const bool in_y = sy.in;
+    const bool in_x = sx.in;
     t.outside = !(in_z & in_y & in_x);
     t.oobmask = 0;
-    // an upper tap is skipped when the FLOAT weight is zero (a double fraction below the float range blends to the
-    // same value either way); at the last sample the double test above has already decided inside / outside
-    const bool zz = t.wz1 == 0.f, yz = t.wy1 == 0.f, xz = t.wx1 == 0.f;
-    const bool lastcol = sx.i0 >= p.nx - 1;
-    const int xb = sx.i0 - (lastcol ? 1 : 0);
-    const unsigned base = t.outside ? 0u : (unsigned)((sz.i0 * p.ny + sy.i0) * p.nx + xb) * 4u;
-    const unsigned stz = (t.outside | zz | (sz.i0 >= p.nz - 1)) ? 0u : (unsigned)(p.ny * p.nx) * 4u;
-    const unsigned sty = (t.outside | yz | (sy.i0 >= p.ny - 1)) ? 0u : (unsigned)p.nx * 4u;
-    (void)xz;
+    // An upper tap is skipped when the FLOAT weight is zero (a double fraction below the float range blends to the
+    // same value either way) -- by the blend itself (lerp_skip), so the upper row and plane are read unconditionally:
+    // a row or plane past the end of the volume fails the descriptor's range check and reads as zero.
+    // The same holds along x: at the last column the pair (x, x + 1) takes the first sample of the next row (or zero
+    // past the end of the volume) as its upper half, with weight zero.
+    const unsigned base = t.outside ? 0u : (unsigned)((sz.i0 * p.ny + sy.i0) * p.nx + sx.i0) * 4u;
+    const unsigned stz = (unsigned)(p.ny * p.nx) * 4u;
+    const unsigned sty = (unsigned)p.nx * 4u;
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        float a, b;
-        load_pair(in, base + (m >> 1) * stz + (m & 1) * sty, a, b);
-        t.v[2 * m] = lastcol ? b : a;
-        t.v[2 * m + 1] = b;
-    }
+    for (int m = 0; m < 4; m++) load_pair(in, base + (m >> 1) * stz + (m & 1) * sty, t.v[2 * m], t.v[2 * m + 1]);
 }
 
 // Which four voxels a lane owns (k = 0..3) and which four "rows" a wave's tile holds:
@@ -379,7 +383,7 @@ affine3d_c1_kernel(const float *__restrict__ in, float *__restrict__ out, const 
         const double cz = (ptab[rr][0] + xz_) + p.m[3];
         const double cy = (ptab[rr][1] + xy_) + p.m[7];
         const double cx = (ptab[rr][2] + xx_) + p.m[11];
-        c1_gather(rin, p, c1_split(cz), c1_split(cy), c1_split(cx), t[k]);
+        c1_gather(rin, p, c1_split(cz, p.nz), c1_split(cy, p.ny), c1_split(cx, p.nx), t[k]);
     }
     float r[4];
 #pragma unroll
@@ -428,7 +432,7 @@ map_coords3d_c1_kernel(const float *__restrict__ in, const float *__restrict__ c
     }
     Taps<float> t[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) c1_gather(rin, p, c1_split(c[k][0]), c1_split(c[k][1]), c1_split(c[k][2]), t[k]);
+    for (int k = 0; k < 4; k++) c1_gather(rin, p, c1_split(c[k][0], p.nz), c1_split(c[k][1], p.ny), c1_split(c[k][2], p.nx), t[k]);
     float r[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) r[k] = finish<float>(t[k], (float)p.cval);
@@ -463,7 +467,32 @@ struct LdsAffineParams {
     FastInterpParams f;
     int bz, by, bx;          // box dimensions (bx a multiple of 4)
     int nchunks;             // bz * by * bx / 4 sixteen-byte chunks
+    // staging loop without divisions: chunk -> (row, 16-byte chunk of the row), row -> (plane, row of the plane) by
+    // multiply-high with ceil(2^32 / d) (exact for the few thousand chunks of a box); the per-round increments
+    unsigned cpr_magic, by_magic;
+    int drow, dc4, drz, dry;
+    // box origin in closed form: the minimum of an affine coordinate over the tile is its value at the tile's first
+    // voxel plus cmin[a] = sum_j min(0, m[a][j] (T_j - 1))
+    double cmin[3];
+    int dbg;                 // tuning ablations (0 in production): 1 no box DMA, 2 no interpolation (stores only), 4 no stores
 };
+
+constexpr int kLdsRoundsMax = 5;                            // staging rounds of 512 chunks (8 KiB) a box can take
+
+// the same with a scalar byte offset added to every lane's
+__device__ __forceinline__ void dma_16s(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_base)
+{
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
+        : "memory");
+}
 
 __device__ __forceinline__ void dma_16(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_base)
 {
@@ -492,53 +521,84 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
     double (*ptab)[3] = reinterpret_cast<double (*)[3]>(smem_lds + box_bytes);        // [TZ * TY][3]
     float *tiles = reinterpret_cast<float *>(smem_lds + box_bytes + TZ * TY * 3 * sizeof(double));   // [8 waves][256]
 
+    int (*org)[4] = reinterpret_cast<int (*)[4]>(tiles + 8 * 256);                   // [2][4]: box origin of this / the next tile
+
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lx = lane & (TX - 1), yy = lane / TX;
-    const int x0w = blockIdx.x * TX, y0 = blockIdx.y * TY, z0 = blockIdx.z * TZ;
-
-    // ---- box origin: floor of the smallest coordinate over the tile's corners (the map is affine: extremes sit at
-    // corners), clamped into the volume; x aligned down to a multiple of four samples (16-byte chunks).  Computed by
-    // three lanes (one per axis) and broadcast through LDS: it is the same for the whole workgroup.
-    int *b0s = reinterpret_cast<int *>(tiles);           // the store tiles are not in use yet
-    if (tid < 3) {
-        const int a = tid;
-        double lo = 1e300;
-#pragma unroll
-        for (int cz = 0; cz < 2; cz++)
-#pragma unroll
-            for (int cy = 0; cy < 2; cy++)
-#pragma unroll
-                for (int cx = 0; cx < 2; cx++) {
-                    const double c = ((p.m[4 * a] * (double)(z0 + cz * (TZ - 1)) + p.m[4 * a + 1] * (double)(y0 + cy * (TY - 1))) +
-                                      p.m[4 * a + 2] * (double)(x0w + cx * (TX - 1))) + p.m[4 * a + 3];
-                    lo = c < lo ? c : lo;
-                }
-        const int n = a == 0 ? p.nz : (a == 1 ? p.ny : p.nx);
-        // the corner sums are not the per-voxel sums to the last bit: a hair below the minimum
-        double f = floor(lo - 1e-6 * (1.0 + fabs(lo)));
-        f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
-        b0s[a] = a == 2 ? ((int)f & ~3) : (int)f;
-    }
-    __syncthreads();
-    const int b0[3] = {__builtin_amdgcn_readfirstlane(b0s[0]), __builtin_amdgcn_readfirstlane(b0s[1]), __builtin_amdgcn_readfirstlane(b0s[2])};
-
-    // ---- stage the box: chunk ch = tid + 512 j  ->  (box row, 16-byte chunk of the row); the division is done once,
-    // the later rounds advance (row, chunk) and (plane, row in plane) by constants
+    const int x0w = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
+    const int cpr = q.bx >> 2;
+    const int rounds = (q.nchunks + 511) >> 9;
+    // chunk tid of the box -> (plane, row, chunk of the row): the same for every tile, and so is the byte offset of the
+    // chunks tid + 512 j from the box origin (rel[j]; chunks past the box fail the range check and write zeros)
+    const int row0 = (int)__umulhi((unsigned)tid, q.cpr_magic), c40 = tid - row0 * cpr;
+    const int rz0 = (int)__umulhi((unsigned)row0, q.by_magic), ry0 = row0 - rz0 * q.by;
+    unsigned rel[kLdsRoundsMax];
     {
-        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, p.nz * p.ny * p.nx * 4, 0x00020000);
-        const int cpr = q.bx >> 2;
-        const int rounds = (q.nchunks + 511) >> 9;
-        int row = tid / cpr, c4 = tid - row * cpr;
-        int rz = row / q.by, ry = row - rz * q.by;
-        const int drow = 512 / cpr, dc4 = 512 - drow * cpr;
-        const int drz = drow / q.by, dry = drow - drz * q.by;
+        int c4 = c40, ry = ry0, rz = rz0;
+#pragma unroll
+        for (int j = 0; j < kLdsRoundsMax; j++) {
+            rel[j] = tid + (j << 9) < q.nchunks ? (unsigned)((rz * p.ny + ry) * p.nx + 4 * c4) * 4u : 0x80000000u;
+            c4 += q.dc4; ry += q.dry; rz += q.drz;
+            if (c4 >= cpr) { c4 -= cpr; ry++; }
+            if (ry >= q.by) { ry -= q.by; rz++; }
+            if (ry >= q.by) { ry -= q.by; rz++; }
+        }
+    }
+    const int yrow = RW * wave + yy;
+    const double dx = (double)(x0w + lx);
+    const double xz_ = p.m[2] * dx, xy_ = p.m[6] * dx, xx_ = p.m[10] * dx;
+    const int plane_f = q.by * q.bx;
+    float *tile = tiles + wave * 256;
+
+    // Box origin of the tile at z tile index tz_: floor of the smallest coordinate over the tile (the map is affine: its
+    // minimum is the value at the first voxel plus a constant of the matrix), a hair below it because this sum is not
+    // the per-voxel sum to the last bit; clamped into the volume; x aligned down to a multiple of four samples (16-byte
+    // chunks).  Three lanes (one per axis) compute it for the whole workgroup, one tile AHEAD (while the box of the
+    // current tile is in flight), and leave it in LDS.
+    auto origin_to = [&](int tz_, int slot) {
+        if (tid < 3) {
+            const int a = tid;
+            const double lo = ((p.m[4 * a] * (double)(tz_ * TZ) + p.m[4 * a + 1] * (double)y0) + p.m[4 * a + 2] * (double)x0w) +
+                              (p.m[4 * a + 3] + q.cmin[a]);
+            const int n = a == 0 ? p.nz : (a == 1 ? p.ny : p.nx);
+            double f = floor(lo - 1e-6 * (1.0 + fabs(lo)));
+            f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
+            org[slot][a] = a == 2 ? ((int)f & ~3) : (int)f;
+        }
+    };
+    origin_to((int)blockIdx.z, 0);
+    __syncthreads();
+
+    // A workgroup owns the tiles (blockIdx.x, blockIdx.y, blockIdx.z + k gridDim.z) -- one tile with the default grid.
+    // What a tile costs besides its voxels was 126 us of config D's 392 (profiles/r3_affine_ablation.txt): two integer
+    // divisions and the address arithmetic of five staging rounds per thread, the origin by three lanes and a barrier.
+    // Here the divisions are multiplications, the staging rounds are one DMA each with a precomputed offset, and a
+    // workgroup that walks several tiles computes the next origin while the current box is in flight.
+    int slot = 0;
+#pragma unroll 1
+    for (int tz = blockIdx.z; tz * TZ < p.oz; tz += gridDim.z, slot ^= 1) {
+    const int z0 = tz * TZ;
+    const int b0[3] = {__builtin_amdgcn_readfirstlane(org[slot][0]), __builtin_amdgcn_readfirstlane(org[slot][1]),
+                       __builtin_amdgcn_readfirstlane(org[slot][2])};
+
+    // ---- stage the box.  Away from the upper faces of the volume every chunk of the box exists: the rounds are one DMA
+    // each (offset from the box origin in the VGPR, the origin itself in the scalar offset).  A box that sticks out of
+    // the volume checks its chunks one by one (rows and planes past the end read as zeros).
+    if (b0[0] + q.bz <= p.nz && b0[1] + q.by <= p.ny && b0[2] + q.bx <= p.nx) {
+        const unsigned base = (unsigned)((b0[0] * p.ny + b0[1]) * p.nx + b0[2]) * 4u;
+#pragma unroll
+        for (int j = 0; j < kLdsRoundsMax; j++)
+            if (j < rounds && !(q.dbg & 1)) dma_16s(rin, rel[j], base, (unsigned)((wave << 6) + (j << 9)) * 16u);
+    } else {
+        int c4 = c40, ry = ry0, rz = rz0;
         for (int j = 0; j < rounds; j++) {
             const int sz_ = b0[0] + rz, sy_ = b0[1] + ry, sx_ = b0[2] + 4 * c4;
             const bool ok = tid + (j << 9) < q.nchunks && sz_ < p.nz && sy_ < p.ny && sx_ < p.nx;
             const unsigned voff = ok ? (unsigned)((sz_ * p.ny + sy_) * p.nx + sx_) * 4u : 0x80000000u;
-            dma_16(rin, voff, (unsigned)((wave << 6) + (j << 9)) * 16u);
-            c4 += dc4; ry += dry; rz += drz;
+            if (!(q.dbg & 1)) dma_16(rin, voff, (unsigned)((wave << 6) + (j << 9)) * 16u);
+            c4 += q.dc4; ry += q.dry; rz += q.drz;
             if (c4 >= cpr) { c4 -= cpr; ry++; }
             if (ry >= q.by) { ry -= q.by; rz++; }
             if (ry >= q.by) { ry -= q.by; rz++; }
@@ -548,47 +608,44 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
         const int rr = tid / 3, a = tid - 3 * rr;                  // rr = TY k + row  <->  plane z0 + k, row y0 + row
         ptab[rr][a] = p.m[4 * a] * (double)(z0 + rr / TY) + p.m[4 * a + 1] * (double)(y0 + rr % TY);
     }
+    origin_to(tz + (int)gridDim.z, slot ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // ---- interpolate: lane = (x, row of the wave), k = plane; two batches of four planes
-    const int yrow = RW * wave + yy;
-    const double dx = (double)(x0w + lx);
-    const double xz_ = p.m[2] * dx, xy_ = p.m[6] * dx, xx_ = p.m[10] * dx;
-    const int plane_f = q.by * q.bx;
-    float *tile = tiles + wave * 256;
+    const int lorg = (b0[0] * q.by + b0[1]) * q.bx + b0[2];      // box index of sample (z, y, x) = (z by + y) bx + x - lorg
     const bool wide = x0w + TX <= p.ox && y0 + TY <= p.oy && z0 + TZ <= p.oz;      // block-uniform
 #pragma unroll 1
     for (int bt = 0; bt < 2; bt++) {
-        float r[4];
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!(q.dbg & 2))
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             const int k = 4 * bt + kk;
             const int rr = TY * k + yrow;
-            const C1Split sz = c1_split((ptab[rr][0] + xz_) + p.m[3]);
-            const C1Split sy = c1_split((ptab[rr][1] + xy_) + p.m[7]);
-            const C1Split sx = c1_split((ptab[rr][2] + xx_) + p.m[11]);
+            const C1Split sz = c1_split((ptab[rr][0] + xz_) + p.m[3], p.nz);
+            const C1Split sy = c1_split((ptab[rr][1] + xy_) + p.m[7], p.ny);
+            const C1Split sx = c1_split((ptab[rr][2] + xx_) + p.m[11], p.nx);
             Taps<float> t;
             t.wz1 = sz.w1; t.wy1 = sy.w1; t.wx1 = sx.w1;
-            const bool in_z = !sz.neg & (((unsigned)sz.i0 < (unsigned)(p.nz - 1)) | ((sz.i0 == p.nz - 1) & sz.frz));
-            const bool in_y = !sy.neg & (((unsigned)sy.i0 < (unsigned)(p.ny - 1)) | ((sy.i0 == p.ny - 1) & sy.frz));
-            const bool in_x = !sx.neg & (((unsigned)sx.i0 < (unsigned)(p.nx - 1)) | ((sx.i0 == p.nx - 1) & sx.frz));
+            const bool in_z = sz.in;
+            const bool in_y = sy.in;
+            const bool in_x = sx.in;
             t.outside = !(in_z & in_y & in_x);
             t.oobmask = 0;
-            const bool zz = t.wz1 == 0.f, yz = t.wy1 == 0.f;
-            // at the last column the pair (x0, x0 + 1) reaches one sample past the row: whatever the box holds there is
-            // never used (wx1 == 0 selects the lower sample)
-            const int li = t.outside ? 0 : ((sz.i0 - b0[0]) * q.by + (sy.i0 - b0[1])) * q.bx + (sx.i0 - b0[2]);
-            const int stz = (t.outside | zz | (sz.i0 >= p.nz - 1)) ? 0 : plane_f;
-            const int sty = (t.outside | yz | (sy.i0 >= p.ny - 1)) ? 0 : q.bx;
+            // The upper taps are read unconditionally: a zero weight removes them in the blend (lerp_skip), whatever they
+            // read then -- one sample past the row / the plane (zero-filled by the DMA beyond the volume), the tables behind
+            // the box, or nothing at all (an LDS read beyond the workgroup's allocation returns zero).
+            const int li = t.outside ? 0 : (sz.i0 * q.by + sy.i0) * q.bx + sx.i0 - lorg;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const float *src = box + li + (m >> 1) * stz + (m & 1) * sty;
+                const float *src = box + li + (m >> 1) * plane_f + (m & 1) * q.bx;
                 t.v[2 * m] = src[0];
                 t.v[2 * m + 1] = src[1];
             }
             r[kk] = finish<float>(t, (float)p.cval);
         }
+        if (q.dbg & 4) continue;
         if (wide) {
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) tile[kk * 64 + lane] = r[kk];
@@ -607,7 +664,12 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
             }
         }
     }
+    __syncthreads();            // the box and the prefix table are rewritten for the next tile
+    }
 }
+
+Knob g_affine_dbg{0};     // tuning ablations of affine3d_lds_kernel, see LdsAffineParams::dbg
+Knob g_affine_gz{0};      // test hook: workgroups along z of affine3d_lds_kernel (0 = auto; the number of z tiles = one tile per workgroup)
 
 // box dimensions of a TZ x TY x TX output tile under the matrix (upper bound from |M|); returns the number of floats,
 // or 0 when the box does not fit the LDS budget
@@ -628,10 +690,23 @@ static long long lds_affine_plan(const FastInterpParams &p, int tx, LdsAffinePar
     for (int a = 0; a < 2; a++) if (dim[a] > n[a]) dim[a] = n[a];
     if (dim[2] > ((n[2] + 3) & ~3) + 4) dim[2] = ((n[2] + 3) & ~3) + 4;
     const long long floats = (long long)dim[0] * dim[1] * dim[2];
-    if (floats * 4 > kLdsBoxBytesMax) return 0;
+    if (floats * 4 > kLdsBoxBytesMax || (floats / 4 + 511) / 512 > kLdsRoundsMax) return 0;
     q->f = p;
     q->bz = dim[0]; q->by = dim[1]; q->bx = dim[2];
     q->nchunks = (int)(floats / 4);
+    {
+        const unsigned cpr = (unsigned)dim[2] / 4u, by = (unsigned)dim[1];
+        q->cpr_magic = (unsigned)((((unsigned long long)1 << 32) + cpr - 1) / cpr);
+        q->by_magic = (unsigned)((((unsigned long long)1 << 32) + by - 1) / by);
+        q->drow = (int)(512u / cpr); q->dc4 = (int)(512u - (unsigned)q->drow * cpr);
+        q->drz = q->drow / (int)by; q->dry = q->drow - q->drz * (int)by;
+    }
+    for (int a = 0; a < 3; a++) {
+        double c = 0.0;
+        for (int j = 0; j < 3; j++) { const double e = p.m[4 * a + j] * T[j]; if (e < 0.0) c += e; }
+        q->cmin[a] = c;
+    }
+    q->dbg = g_affine_dbg;
     return floats;
 }
 
@@ -640,9 +715,16 @@ static int launch_affine_lds(const float *in, float *out, const LdsAffineParams 
 {
     constexpr int TY = 8 * (64 / TX);
     const FastInterpParams &p = q.f;
-    const dim3 gl((unsigned)((p.ox + TX - 1) / TX), (unsigned)((p.oy + TY - 1) / TY), (unsigned)((p.oz + kLdsTZ - 1) / kLdsTZ));
+    // Workgroups along z: one per tile by default.  The kernel can walk several tiles of a column (gz < ntz), which
+    // measured slower on config D' (346 us with one tile each; 360-405 us with 3 ... 12 tiles each: the tiles of a
+    // workgroup run strictly one after the other, a fresh workgroup overlaps with its neighbours on the CU).
+    const unsigned ntz = (unsigned)((p.oz + kLdsTZ - 1) / kLdsTZ);
+    unsigned gz = g_affine_gz > 0 ? (unsigned)g_affine_gz : ntz;
+    if (gz > ntz) gz = ntz;
+    if (gz < 1) gz = 1;
+    const dim3 gl((unsigned)((p.ox + TX - 1) / TX), (unsigned)((p.oy + TY - 1) / TY), gz);
     if (gl.y > 65535 || gl.z > 65535) return MI_ERR_UNSUPPORTED;
-    const size_t lds = (((size_t)q.nchunks * 16 + 8191) & ~(size_t)8191) + kLdsTZ * TY * 3 * sizeof(double) + 8 * 256 * sizeof(float);
+    const size_t lds = (((size_t)q.nchunks * 16 + 8191) & ~(size_t)8191) + kLdsTZ * TY * 3 * sizeof(double) + 8 * 256 * sizeof(float) + 2 * 4 * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)affine3d_lds_kernel<TX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -730,10 +812,10 @@ map_coords3d_lds_kernel(const float *__restrict__ in, const float *__restrict__ 
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const C1Split sz = c1_split(c[k][0]), sy = c1_split(c[k][1]), sx = c1_split(c[k][2]);
-        const bool in_z = !sz.neg & (((unsigned)sz.i0 < (unsigned)(p.nz - 1)) | ((sz.i0 == p.nz - 1) & sz.frz));
-        const bool in_y = !sy.neg & (((unsigned)sy.i0 < (unsigned)(p.ny - 1)) | ((sy.i0 == p.ny - 1) & sy.frz));
-        const bool in_x = !sx.neg & (((unsigned)sx.i0 < (unsigned)(p.nx - 1)) | ((sx.i0 == p.nx - 1) & sx.frz));
+        const C1Split sz = c1_split(c[k][0], p.nz), sy = c1_split(c[k][1], p.ny), sx = c1_split(c[k][2], p.nx);
+        const bool in_z = sz.in;
+        const bool in_y = sy.in;
+        const bool in_x = sx.in;
         if (in_z & in_y & in_x) {
             lo[0] = min(lo[0], sz.i0); hi[0] = max(hi[0], sz.i0);
             lo[1] = min(lo[1], sy.i0); hi[1] = max(hi[1], sy.i0);
@@ -798,18 +880,18 @@ map_coords3d_lds_kernel(const float *__restrict__ in, const float *__restrict__ 
         if (use_box) {
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
-                const C1Split sz = c1_split(cb[kk][0]), sy = c1_split(cb[kk][1]), sx = c1_split(cb[kk][2]);
+                const C1Split sz = c1_split(cb[kk][0], p.nz), sy = c1_split(cb[kk][1], p.ny), sx = c1_split(cb[kk][2], p.nx);
                 Taps<float> t;
                 t.wz1 = sz.w1; t.wy1 = sy.w1; t.wx1 = sx.w1;
-                const bool in_z = !sz.neg & (((unsigned)sz.i0 < (unsigned)(p.nz - 1)) | ((sz.i0 == p.nz - 1) & sz.frz));
-                const bool in_y = !sy.neg & (((unsigned)sy.i0 < (unsigned)(p.ny - 1)) | ((sy.i0 == p.ny - 1) & sy.frz));
-                const bool in_x = !sx.neg & (((unsigned)sx.i0 < (unsigned)(p.nx - 1)) | ((sx.i0 == p.nx - 1) & sx.frz));
+                const bool in_z = sz.in;
+                const bool in_y = sy.in;
+                const bool in_x = sx.in;
                 t.outside = !(in_z & in_y & in_x);
                 t.oobmask = 0;
                 const bool zz = t.wz1 == 0.f, yz = t.wy1 == 0.f;
                 const int li = t.outside ? 0 : ((sz.i0 - b0[0]) * bd[1] + (sy.i0 - b0[1])) * bd[2] + (sx.i0 - b0[2]);
-                const int stz = (t.outside | zz | (sz.i0 >= p.nz - 1)) ? 0 : plane_f;
-                const int sty = (t.outside | yz | (sy.i0 >= p.ny - 1)) ? 0 : bd[2];
+                const int stz = (t.outside | zz) ? 0 : plane_f;
+                const int sty = (t.outside | yz) ? 0 : bd[2];
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const float *src = box + li + (m >> 1) * stz + (m & 1) * sty;
@@ -821,7 +903,7 @@ map_coords3d_lds_kernel(const float *__restrict__ in, const float *__restrict__ 
         } else {
             Taps<float> t[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) c1_gather(rin, p, c1_split(cb[kk][0]), c1_split(cb[kk][1]), c1_split(cb[kk][2]), t[kk]);
+            for (int kk = 0; kk < 4; kk++) c1_gather(rin, p, c1_split(cb[kk][0], p.nz), c1_split(cb[kk][1], p.ny), c1_split(cb[kk][2], p.nx), t[kk]);
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) r[kk] = finish<float>(t[kk], (float)p.cval);
         }
@@ -863,17 +945,17 @@ __device__ __forceinline__ void c1_address(const FastInterpParams &p, const C1Sp
                                            C1Addr &ad)
 {
     t.wz1 = sz.w1; t.wy1 = sy.w1; t.wx1 = sx.w1;
-    const bool in_z = !sz.neg & (((unsigned)sz.i0 < (unsigned)(p.nz - 1)) | ((sz.i0 == p.nz - 1) & sz.frz));
-    const bool in_y = !sy.neg & (((unsigned)sy.i0 < (unsigned)(p.ny - 1)) | ((sy.i0 == p.ny - 1) & sy.frz));
-    const bool in_x = !sx.neg & (((unsigned)sx.i0 < (unsigned)(p.nx - 1)) | ((sx.i0 == p.nx - 1) & sx.frz));
+    const bool in_z = sz.in;
+    const bool in_y = sy.in;
+    const bool in_x = sx.in;
     t.outside = !(in_z & in_y & in_x);
     t.oobmask = 0;
     const bool zz = t.wz1 == 0.f, yz = t.wy1 == 0.f;
     ad.lastcol = sx.i0 >= p.nx - 1;
     ad.xb = sx.i0 - (ad.lastcol ? 1 : 0);
     ad.base = t.outside ? 0u : (unsigned)((sz.i0 * p.ny + sy.i0) * p.nx + ad.xb) * 4u;
-    ad.stz = (t.outside | zz | (sz.i0 >= p.nz - 1)) ? 0u : (unsigned)(p.ny * p.nx) * 4u;
-    ad.sty = (t.outside | yz | (sy.i0 >= p.ny - 1)) ? 0u : (unsigned)p.nx * 4u;
+    ad.stz = (t.outside | zz) ? 0u : (unsigned)(p.ny * p.nx) * 4u;
+    ad.sty = (t.outside | yz) ? 0u : (unsigned)p.nx * 4u;
 }
 
 __device__ __forceinline__ float pick3(const u32x4g &q, int d)      // component d of q, d in 0..3
@@ -911,8 +993,8 @@ map_coords3d_pair_kernel(const float *__restrict__ in, const float *__restrict__
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             const int k = 2 * h + kk;
-            c1_address(p, c1_split(c[k][0].x), c1_split(c[k][1].x), c1_split(c[k][2].x), tA[kk], aA[kk]);
-            c1_address(p, c1_split(c[k][0].y), c1_split(c[k][1].y), c1_split(c[k][2].y), tB[kk], aB[kk]);
+            c1_address(p, c1_split(c[k][0].x, p.nz), c1_split(c[k][1].x, p.ny), c1_split(c[k][2].x, p.nx), tA[kk], aA[kk]);
+            c1_address(p, c1_split(c[k][0].y, p.nz), c1_split(c[k][1].y, p.ny), c1_split(c[k][2].y, p.nx), tB[kk], aB[kk]);
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 q[kk][m] = __builtin_amdgcn_raw_buffer_load_b128(rin, aA[kk].base + (m >> 1) * aA[kk].stz + (m & 1) * aA[kk].sty, 0, 0);
@@ -1173,3 +1255,5 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
 }  // namespace mi
 
 extern "C" int mi_debug_set_interp_c1(int k) { mi::g_interp_c1 = k; return MI_OK; }
+extern "C" int mi_debug_set_affine_dbg(int k) { mi::g_affine_dbg = k; return MI_OK; }
+extern "C" int mi_debug_set_affine_gz(int k) { mi::g_affine_gz = k; return MI_OK; }

@@ -1380,6 +1380,14 @@ def test_affine_lds_staged_kernel(gpu, ndi):
             finally:
                 lib.mi_debug_set_interp_c1(1)
         assert np.array_equal(outs[1], outs[5], equal_nan=True), (shape, np.abs(outs[1] - outs[5]).max())
+        # workgroups that walk several tiles of a column (next origin computed one tile ahead): same voxels
+        for gz in (1, 3):
+            lib.mi_debug_set_affine_gz(gz)
+            try:
+                walked = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75).get()
+            finally:
+                lib.mi_debug_set_affine_gz(0)
+            assert np.array_equal(walked, outs[1], equal_nan=True), (shape, gz)
         ref = orc.affine_transform(x, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75)
         ok = np.isfinite(ref)
         assert np.array_equal(np.isfinite(outs[1]), ok), shape
