@@ -552,36 +552,32 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
     const int plane_f = q.by * q.bx;
     float *tile = tiles + wave * 256;
 
-    // Box origin of the tile at z tile index tz_: floor of the smallest coordinate over the tile (the map is affine: its
-    // minimum is the value at the first voxel plus a constant of the matrix), a hair below it because this sum is not
-    // the per-voxel sum to the last bit; clamped into the volume; x aligned down to a multiple of four samples (16-byte
-    // chunks).  Three lanes (one per axis) compute it for the whole workgroup, one tile AHEAD (while the box of the
-    // current tile is in flight), and leave it in LDS.
-    auto origin_to = [&](int tz_, int slot) {
-        if (tid < 3) {
-            const int a = tid;
-            const double lo = ((p.m[4 * a] * (double)(tz_ * TZ) + p.m[4 * a + 1] * (double)y0) + p.m[4 * a + 2] * (double)x0w) +
-                              (p.m[4 * a + 3] + q.cmin[a]);
-            const int n = a == 0 ? p.nz : (a == 1 ? p.ny : p.nx);
-            double f = floor(lo - 1e-6 * (1.0 + fabs(lo)));
-            f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
-            org[slot][a] = a == 2 ? ((int)f & ~3) : (int)f;
-        }
+    // Box origin of the tile at z tile index tz_, axis a: floor of the smallest coordinate over the tile (the map is
+    // affine: its minimum is the value at the first voxel plus a constant of the matrix), a hair below it because this
+    // sum is not the per-voxel sum to the last bit; clamped into the volume; x aligned down to a multiple of four samples
+    // (16-byte chunks).
+    auto origin = [&](int tz_, int a) {
+        const double lo = ((p.m[4 * a] * (double)(tz_ * TZ) + p.m[4 * a + 1] * (double)y0) + p.m[4 * a + 2] * (double)x0w) +
+                          (p.m[4 * a + 3] + q.cmin[a]);
+        const int n = a == 0 ? p.nz : (a == 1 ? p.ny : p.nx);
+        double f = floor(lo - 1e-6 * (1.0 + fabs(lo)));
+        f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
+        return a == 2 ? ((int)f & ~3) : (int)f;
     };
-    origin_to((int)blockIdx.z, 0);
-    __syncthreads();
+    // the first tile's: every lane computes the same three numbers (no table, no barrier before the first DMA)
+    int b0[3] = {__builtin_amdgcn_readfirstlane(origin((int)blockIdx.z, 0)), __builtin_amdgcn_readfirstlane(origin((int)blockIdx.z, 1)),
+                 __builtin_amdgcn_readfirstlane(origin((int)blockIdx.z, 2))};
 
     // A workgroup owns the tiles (blockIdx.x, blockIdx.y, blockIdx.z + k gridDim.z) -- one tile with the default grid.
     // What a tile costs besides its voxels was 126 us of config D's 392 (profiles/r3_affine_ablation.txt): two integer
     // divisions and the address arithmetic of five staging rounds per thread, the origin by three lanes and a barrier.
     // Here the divisions are multiplications, the staging rounds are one DMA each with a precomputed offset, and a
-    // workgroup that walks several tiles computes the next origin while the current box is in flight.
+    // workgroup that walks several tiles has three lanes compute the next origin while the current box is in flight.
     int slot = 0;
 #pragma unroll 1
     for (int tz = blockIdx.z; tz * TZ < p.oz; tz += gridDim.z, slot ^= 1) {
     const int z0 = tz * TZ;
-    const int b0[3] = {__builtin_amdgcn_readfirstlane(org[slot][0]), __builtin_amdgcn_readfirstlane(org[slot][1]),
-                       __builtin_amdgcn_readfirstlane(org[slot][2])};
+    const bool more = (tz + (int)gridDim.z) * TZ < p.oz;
 
     // ---- stage the box.  Away from the upper faces of the volume every chunk of the box exists: the rounds are one DMA
     // each (offset from the box origin in the VGPR, the origin itself in the scalar offset).  A box that sticks out of
@@ -608,7 +604,7 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
         const int rr = tid / 3, a = tid - 3 * rr;                  // rr = TY k + row  <->  plane z0 + k, row y0 + row
         ptab[rr][a] = p.m[4 * a] * (double)(z0 + rr / TY) + p.m[4 * a + 1] * (double)(y0 + rr % TY);
     }
-    origin_to(tz + (int)gridDim.z, slot ^ 1);
+    if (more && tid < 3) org[slot][tid] = origin(tz + (int)gridDim.z, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -664,7 +660,11 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
             }
         }
     }
+    if (!more) break;
     __syncthreads();            // the box and the prefix table are rewritten for the next tile
+    b0[0] = __builtin_amdgcn_readfirstlane(org[slot][0]);
+    b0[1] = __builtin_amdgcn_readfirstlane(org[slot][1]);
+    b0[2] = __builtin_amdgcn_readfirstlane(org[slot][2]);
     }
 }
 

@@ -743,7 +743,7 @@ static mi::Knob g_stream_fused_max{kStreamFusedMax};    // test hook: longest ke
 extern "C" int mi_debug_set_stream_fused_max(int k) { g_stream_fused_max = k; return MI_OK; }
 static mi::Knob g_sep3d_image2d{1};   // test hook: 0 = images with <= 9 taps take the tiled volume kernel (round-1 behaviour)
 extern "C" int mi_debug_set_sep3d_image2d(int k) { g_sep3d_image2d = k; return MI_OK; }
-static mi::Knob g_sep3d_long{0};      // 0 = auto (cubic 9..17 taps), 1 = off (lean kernel / streaming passes), 2 = also for 3..7 taps
+static mi::Knob g_sep3d_long{0};      // 0 = auto (cubic 9..17 taps; 3..7 taps where it measured faster, see separable3d_impl), 1 = off (lean kernel / streaming passes), 2 = always for 3..17 taps
 extern "C" int mi_debug_set_sep3d_long(int k) { g_sep3d_long = k; return MI_OK; }
 extern "C" int mi_debug_set_sep3d_cfg(int cfg) { g_sep3d_cfg = cfg; return MI_OK; }
 extern "C" int mi_debug_set_sep3d_zchunks(int n) { g_sep3d_zchunks = n; return MI_OK; }
@@ -826,8 +826,17 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     const int64_t nzr = zn[0] + zn[1];
 
     const bool cubic_w = w[0] == w[1] && w[1] == w[2];
+    // r3: with its re-scheduled instruction stream (sep3d_long3_kernel) the LDS-DMA kernel also beats the lean kernel
+    // below 9 taps on volumes that fill the chip (profiles/r3_long3_small_taps.txt, sustained, lean -> long: 7 taps
+    // 15-31 % faster on every shape of 4 Mvoxels and more; 5 and 3 taps 3-5 % faster on 512^3, 256^3, 64 x 1024^2 and
+    // 1024 x 128^2, but 4-6 % SLOWER on 300^3 and 200 x 500 x 760, whose rows do not fill its 256-voxel wave tiles, and
+    // equal or 3 % slower where the launch is latency bound).  Constant mode stays on the lean kernel below 9 taps.
+    const int64_t nvox_out = nz * ny * nx;      // of the whole array: plane-range launches of one filter call take the same kernel
+    const bool long_small = !any_const && w[0] >= 3 && w[0] <= 7 &&
+                            (w[0] == 7 ? nvox_out >= ((int64_t)1 << 22)
+                                       : nvox_out >= ((int64_t)1 << 23) && ((nx & 255) == 0 || nx == 128) && (ny & 15) == 0);
     if (cubic_w && g_sep3d_long != 1 && nx >= 16 &&
-        ((w[0] >= 9 && w[0] <= 17) || (w[0] >= 3 && w[0] <= 7 && g_sep3d_long == 2))) {
+        ((w[0] >= 9 && w[0] <= 17) || (w[0] >= 3 && w[0] <= 7 && (g_sep3d_long == 2 || long_small)))) {
         // long cubic kernels: ONE launch with LDS-DMA staging and the z state in registers (sep3d_long.hip)
         const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
         rc = run_sep3d_long((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w[0], wbuf[2], wbuf[1],

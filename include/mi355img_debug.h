@@ -22,7 +22,7 @@ int mi_debug_set_sep3d_dbg(int flags);        /* ablations: 1 no x/z math, 2 no 
 int mi_debug_set_sep3d_kernel(int k);         /* 1 = always the general (ws) kernel */
 int mi_debug_set_sep3d_zrev(int on);          /* 0 = every z chunk streams upwards */
 int mi_debug_set_sep3d_image2d(int on);       /* 0 = images take the tiled volume kernel */
-int mi_debug_set_sep3d_long(int k);           /* 0 auto, 1 never the long kernel, 2 long kernel also for 3..7 taps */
+int mi_debug_set_sep3d_long(int k);           /* 0 auto (9..17 taps, and 3..7 taps on large volumes with full tiles), 1 never the long kernel, 2 long kernel for all of 3..17 taps */
 int mi_debug_set_sep3d_box(int k);            /* 0 auto, 1 never the running-sum box kernel */
 int mi_debug_set_long_zchunks(int n);
 int mi_debug_set_long_same(int on);

@@ -40,13 +40,13 @@ def avg(pattern, counter):
     v = []
     for f in glob.glob(pattern):
         for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter and 'sep3d_lean_kernel' in r['Kernel_Name']:
+            if r['Counter_Name'] == counter and ('sep3d_lean_kernel' in r['Kernel_Name'] or 'sep3d_long3_kernel' in r['Kernel_Name']):
                 v.append(float(r['Counter_Value']))
     return sum(v) / len(v) if v else None
 name, ns = None, None
 for f in glob.glob('stats/*kernel_stats.csv'):
     for r in csv.DictReader(open(f)):
-        if 'sep3d_lean_kernel' in r['Name']:
+        if 'sep3d_lean_kernel' in r['Name'] or 'sep3d_long3_kernel' in r['Name']:
             name, ns = r['Name'], float(r['AverageNs'])
 fetch, write = avg('pmc_fetch/*counter_collection.csv', 'FETCH_SIZE'), avg('pmc_write/*counter_collection.csv', 'WRITE_SIZE')
 rd, wr = int(2 * fetch * 1024), int(write * 1024)
