@@ -1457,5 +1457,24 @@ def test_long_kernel_generations_agree(gpu, ndi):
                 assert maxnorm_rel(a, b) <= 1e-6, (shape, mode, size)
             g = ndi.gaussian_filter(xd, [2.0, 1.6, 1.9], mode=mode, cval=-0.5).get()
             assert maxnorm_rel(g, orc.gaussian_filter(x, [2.0, 1.6, 1.9], mode=mode, cval=-0.5)) <= 1e-6, (shape, mode)
+            # equal tap counts with DIFFERENT weights per axis: the variants that re-load their weights every step
+            # (17, 9, 7 and 5 taps; the last two take the long kernel behind the knob at these sizes)
+            for sig in ([2.0, 1.9, 1.95], [1.0, 1.1, 1.05], [0.75, 0.8, 0.7], [0.5, 0.6, 0.55]):
+                try:
+                    lib.mi_debug_set_sep3d_long(2)
+                    g = ndi.gaussian_filter(xd, sig, mode=mode, cval=-0.5).get()
+                finally:
+                    lib.mi_debug_set_sep3d_long(0)
+                assert maxnorm_rel(g, orc.gaussian_filter(x, sig, mode=mode, cval=-0.5)) <= 1e-6, (shape, mode, sig)
+            # 3 / 5 / 7 taps through the long kernel (the default on chip-filling volumes), incl. origins
+            for size in (3, 5, 7):
+                try:
+                    lib.mi_debug_set_sep3d_long(2)
+                    b = ndi.uniform_filter(xd, size, mode=mode, cval=0.75).get()
+                    c = ndi.uniform_filter(xd, size, mode=mode, cval=0.75, origin=[1, -1, 0]).get()
+                finally:
+                    lib.mi_debug_set_sep3d_long(0)
+                assert maxnorm_rel(b, orc.uniform_filter(x, size, mode=mode, cval=0.75)) <= 1e-6, (shape, mode, size)
+                assert maxnorm_rel(c, orc.uniform_filter(x, size, mode=mode, cval=0.75, origin=[1, -1, 0])) <= 1e-6, (shape, mode, size)
             u = ndi.uniform_filter(xd, 11, mode=mode, origin=[2, -3, 0]).get()
             assert maxnorm_rel(u, orc.uniform_filter(x, 11, mode=mode, origin=[2, -3, 0])) <= 1e-6, (shape, mode)
