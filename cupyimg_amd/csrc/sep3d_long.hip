@@ -389,6 +389,18 @@ struct XPass3 {
         feed<4 * B + 2>(v.z, te, to);
         feed<4 * B + 3>(v.w, te, to);
     }
+    // the whole window at once: blk[b] = the b-th 4-float block of the 2 NBK + 1 around (and including) the lane's own
+    __device__ __forceinline__ F4 window(const float4 (&blk)[2 * NBK + 1], kfloats te, kfloats to)
+    {
+        static_for<2 * NBK + 1>([&](auto BB) {
+            constexpr int b = decltype(BB)::value;
+            feed_block<b>(blk[b], te, to);
+        });
+        F4 o;
+        o.lo = P0;
+        o.hi = P1;
+        return o;
+    }
     __device__ __forceinline__ void left(const float4 v, const float4 (&oL)[2], kfloats te, kfloats to)
     {
         float4 l[NBK];
@@ -422,7 +434,7 @@ struct XPass3 {
 };
 
 // CFG (tuning, see launch_long): bits 0-2 first y read group, bits 3-6 end of the second group, bit 7 halo table at
-// the end of the step instead of the start, bit 8 no priority raise for the wave that makes the halo table; 0 = the
+// the end of the step instead of the start, bit 8 no priority raise for the wave that makes the halo table, bit 9 x pass through LDS; 0 = the
 // defaults below.
 template <int W, bool SAME, bool DBG, int CFG = 0>
 __global__ void __launch_bounds__(kLongTY * 64)
@@ -434,6 +446,14 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     constexpr unsigned HY0 = kLongRawBytes;
     int *ztab = reinterpret_cast<int *>(smem + kLongRawBytes + kLongHyBytes);
     const int dbg = DBG ? p.dbg : 0;
+    // CFG bit 9: the x pass through LDS.  The pipelined y pass never reads plane i in step i, so three ring slots do; the
+    // fourth holds, twice (step parity), one record per wave: [8 halo floats][the wave's y-filtered row][8 halo floats].
+    // A wave stores its row, the wave that makes the halo table stores the halo blocks there, and the x window is five
+    // aligned 16-byte reads -- no lane shifts, no edge selects (24 + copies of the 136 VALU instructions per step).
+    constexpr bool kXlds = ((CFG >> 9) & 1) != 0;
+    constexpr int kSlots = kXlds ? 3 : kLongNB;
+    constexpr unsigned kXrow0 = 3u * kLongRowsMax * kLongRec;                   // byte offset of the x records (kXlds)
+    constexpr unsigned kXpar = (unsigned)kLongTY * kLongRec;                    // bytes per parity
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -483,6 +503,11 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     const unsigned hsrc = (unsigned)(lane >> 2) * kLongRec + 1024u + (unsigned)(lane & 3) * 16u;
     // this row's four y-filtered halo blocks in the table: far left, near left, near right, far right
     const unsigned hy_row = HY0 + (unsigned)wave * 64u;
+    // kXlds: where lane (row = lane / 4, block = lane % 4) of the halo pass stores: blocks 0, 1 in front of the row, blocks
+    // 2, 3 right behind its last valid float4
+    const unsigned hx_dst = kXrow0 + (unsigned)(lane >> 2) * kLongRec +
+                            ((lane & 3) < 2 ? (unsigned)(lane & 3) * 16u : 32u + 16u * (unsigned)nlanes + (unsigned)((lane & 3) - 2) * 16u);
+    const unsigned xr_own = kXrow0 + (unsigned)wave * kLongRec + (unsigned)lane * 16u;     // block -2 of this lane's window
     const unsigned ovoff = (wave < ty_act && lane < nlanes) ? (unsigned)((y0 + wave) * nx + x0 + 4 * lane) * 4u : kOOB;
     constexpr unsigned kPlane = kLongRowsMax * kLongRec;
 
@@ -553,7 +578,8 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     F4 yv = ypass(own);
     if (wave == 15) {
         const F4 hv = ypass(hsrc);
-        *reinterpret_cast<float4 *>(smem + HY0 + (unsigned)lane * 16u) = f4_to_float4(hv);
+        if constexpr (kXlds) *reinterpret_cast<float4 *>(smem + hx_dst) = f4_to_float4(hv);
+        else *reinterpret_cast<float4 *>(smem + HY0 + (unsigned)lane * 16u) = f4_to_float4(hv);
     }
 
     // Interval i (after barrier i): plane i + 1 has landed (each wave waited for its own DMAs of plane i + 1; those of
@@ -566,8 +592,9 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
             const int i = i0 + J;
             if (i < nsteps) {
                 if constexpr (!SAME) { launder(wyk); launder(wzk); launder(xte); launder(xto); }
-                const unsigned b1 = bi == (kLongNB - 1) * kPlane ? 0u : bi + kPlane;     // plane i + 1
-                const unsigned b3 = bi == 0u ? (kLongNB - 1) * kPlane : bi - kPlane;     // slot of plane i - 1
+                const unsigned b1 = bi == (kSlots - 1) * kPlane ? 0u : bi + kPlane;     // plane i + 1
+                // where plane i + 3 goes: the slot of plane i - 1 in the ring of four, of plane i in the ring of three
+                const unsigned b3 = kXlds ? bi : (bi == 0u ? (kLongNB - 1) * kPlane : bi - kPlane);
                 // In flight from this wave, oldest first: the 4 DMAs of plane i + 1, the store of step i - 2, the 4 DMAs
                 // of plane i + 2, the store of step i - 1 (a store is issued in EVERY step: before the first complete
                 // output it goes to a descriptor of zero records).  Plane i + 1 must have landed: vmcnt(5); step 0 has
@@ -583,7 +610,8 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                         // of the step, so that the extra work is shared out instead of left over at the barrier
                         if constexpr (((CFG >> 8) & 1) == 0) __builtin_amdgcn_s_setprio(3);
                         const F4 hv = ypass_batched(hsrc + b1);
-                        *reinterpret_cast<float4 *>(smem + HY0 + (kLongHyBytes / 2 - hyoff) + (unsigned)lane * 16u) = f4_to_float4(hv);
+                        if constexpr (kXlds) *reinterpret_cast<float4 *>(smem + hx_dst + (unsigned)((i + 1) & 1) * kXpar) = f4_to_float4(hv);
+                        else *reinterpret_cast<float4 *>(smem + HY0 + (kLongHyBytes / 2 - hyoff) + (unsigned)lane * 16u) = f4_to_float4(hv);
                     }
                 };
                 constexpr bool kHaloEnd = (CFG >> 7) & 1;
@@ -599,22 +627,41 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 constexpr int GB0 = CFG ? ((CFG >> 3) & 15) : (SAME && !DBG) ? 12 : 10;     // the re-loading variants keep more scalars alive
                 constexpr int GA = W < GA0 ? W : GA0, GB = W < GB0 ? W : GB0, ZH = W / 2;
                 const int wy_rows = (dbg & 1) ? 1 : W, wz_taps = (dbg & 4) ? 1 : W;
-                float4 oL[2], eR[2], R[W];
+                float4 R[W];
                 const char *ysrc = smem + own + b1;
                 issue(i + 3, b3);
-                oL[1] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff);
-                oL[0] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 16u);
-                __builtin_amdgcn_sched_barrier(0);
                 XPass3<W> xp;
                 const float4 yv4 = f4_to_float4(yv);
-                if (!(dbg & 2)) xp.left(yv4, oL, xte, xto);
-                eR[0] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 32u);
-                eR[1] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 48u);
+                F4 xy;
+                if constexpr (kXlds) {
+                    constexpr int NBK = XPass3<W>::NBK;
+                    float4 blk[2 * NBK + 1];
+                    char *xr = smem + xr_own + (unsigned)(i & 1) * kXpar;
+                    *reinterpret_cast<float4 *>(xr + 32) = yv4;                    // own block: behind the 8 halo floats
+                    // LDS operations of a wave are carried out in order: the reads below see the row
 #pragma unroll
-                for (int k = 0; k < GA; k++) if (k < wy_rows) R[k] = *reinterpret_cast<const float4 *>(ysrc + k * kLongRec);
-                __builtin_amdgcn_sched_barrier(0);
-                const F4 xy = (dbg & 2) ? yv : xp.right(yv4, eR, lane, last, xte, xto);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int b = 0; b < 2 * NBK + 1; b++)
+                        if (b != NBK) blk[b] = *reinterpret_cast<const float4 *>(xr + 32 + 16 * (b - NBK));
+                    blk[NBK] = yv4;
+#pragma unroll
+                    for (int k = 0; k < GA; k++) if (k < wy_rows) R[k] = *reinterpret_cast<const float4 *>(ysrc + k * kLongRec);
+                    __builtin_amdgcn_sched_barrier(0);
+                    xy = (dbg & 2) ? yv : xp.window(blk, xte, xto);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    float4 oL[2], eR[2];
+                    oL[1] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff);
+                    oL[0] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 16u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(dbg & 2)) xp.left(yv4, oL, xte, xto);
+                    eR[0] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 32u);
+                    eR[1] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 48u);
+#pragma unroll
+                    for (int k = 0; k < GA; k++) if (k < wy_rows) R[k] = *reinterpret_cast<const float4 *>(ysrc + k * kLongRec);
+                    __builtin_amdgcn_sched_barrier(0);
+                    xy = (dbg & 2) ? yv : xp.right(yv4, eR, lane, last, xte, xto);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 yv = f4_scale(wyk[0], f4_from(R[0]));
 #pragma unroll
                 for (int k = 1; k < GA; k++) if (k < wy_rows) yv = f4_fma(wyk[k], f4_from(R[k]), yv);
@@ -712,7 +759,7 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
                 note_kernel("mi::sep3d_long3_kernel<17,true,false,%d> grid=%d (tuning variant)", (C), total);    \
                 return long_launch_one(sep3d_long3_kernel<17, true, false, (C)>, attr_c, lds, total, in, out, p, s); \
             }
-            MI_LONG_CFG(4 | (12 << 3) | 256) MI_LONG_CFG(4 | (10 << 3))
+            MI_LONG_CFG(4 | (12 << 3) | 512) MI_LONG_CFG(4 | (10 << 3) | 512) MI_LONG_CFG(4 | (8 << 3) | 512)
 #undef MI_LONG_CFG
         }
 #endif

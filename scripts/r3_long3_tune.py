@@ -15,8 +15,8 @@ def t(fn, reps=60):
     for _ in range(reps): fn()
     e1.record(); ca.synchronize(); return e0.elapsed_ms(e1) / reps * 1e3
 def name(c):
-    return "product" if c == 0 else "GA%d GB%d halo %s%s" % (c & 7, (c >> 3) & 15, "end" if c & 128 else "start", " no setprio" if c & 256 else "")
-cfgs = [0, 4 | (12 << 3) | 256, 4 | (10 << 3)]
+    return "product" if c == 0 else "GA%d GB%d halo %s%s" % (c & 7, (c >> 3) & 15, "end" if c & 128 else "start", (" no setprio" if c & 256 else "") + (" x pass through LDS" if c & 512 else ""))
+cfgs = [0, 4 | (12 << 3) | 512, 4 | (10 << 3) | 512, 4 | (8 << 3) | 512]
 ref = None
 for c in cfgs:
     lib.mi_debug_set_long_cfg(c)
