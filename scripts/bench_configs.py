@@ -31,10 +31,21 @@ PEAK = 8000.0
 
 
 def timeit(fn, reps):
+    """sustained: seconds per call over `reps` back-to-back launches (at least 60 ms of them) after at least 30 ms of
+    the same launches -- the clocks of these boxes need 10-20 ms of load to settle (a 0.4 ms kernel measured 10 % slower
+    over launches 11-50 of a process than over launches 31-180: DESIGN.md section 0); first: the mean of the first five
+    launches after half a second of idling."""
+    e0, e1 = ca.Event(), ca.Event()
+    e0.record()
     for _ in range(10):
         fn()
+    e1.record()
     ca.synchronize()
-    e0, e1 = ca.Event(), ca.Event()
+    per_call = max(e0.elapsed_ms(e1) / 10, 1e-3)
+    for _ in range(max(0, int(30.0 / per_call) - 10)):
+        fn()
+    reps = max(reps, int(60.0 / per_call))
+    ca.synchronize()
     e0.record()
     for _ in range(reps):
         fn()

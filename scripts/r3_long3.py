@@ -42,12 +42,18 @@ print("long3 kernel: small-shape checks done, mismatches:", bad, flush=True)
 n = 512
 x = fs.volume_f32((n, n, n)); xd = ca.asarray(x); o = ca.empty((n, n, n), np.float32)
 def t(fn, reps=40):
+    """(mean of the first five launches after a pause, settled mean): the clocks of a box need ~ 40 ms of load to
+    settle (scripts/r3_clock_settle.py), so the settled figure is taken over >= 60 ms after >= 50 ms of the same launches"""
+    ca.synchronize(); time.sleep(0.3)
+    e0, e1, e2, e3 = ca.Event(), ca.Event(), ca.Event(), ca.Event(); e0.record()
     for _ in range(5): fn()
-    ca.synchronize(); e0, e1, e2 = ca.Event(), ca.Event(), ca.Event(); e0.record()
-    for _ in range(5): fn()
-    e1.record()
-    for _ in range(reps - 5): fn()
-    e2.record(); ca.synchronize(); return e0.elapsed_ms(e1) / 5 * 1e3, e0.elapsed_ms(e2) / reps * 1e3
+    e1.record(); ca.synchronize()
+    per = e0.elapsed_ms(e1) / 5
+    for _ in range(int(50.0 / per) + 1): fn()
+    n2 = max(reps, int(60.0 / per))
+    e2.record()
+    for _ in range(n2): fn()
+    e3.record(); ca.synchronize(); return per * 1e3, e2.elapsed_ms(e3) / n2 * 1e3
 lib.mi_debug_set_long_rows(0)
 ndi.gaussian_filter(xd, 2.0, output=o)
 print("full-size parity B (long3):", fs.check_filter_slabs(x, o, 8, 8, lambda s: sndi.gaussian_filter(s.astype(np.float64), sigma=2), fs.z_slabs(n, extra=(128, 256, 384))), flush=True)
@@ -55,19 +61,19 @@ for rows in (1, 0, 1, 0):
     lib.mi_debug_set_long_rows(rows)
     for sigma in (2.0, 1.5, 1.0):
         a, b = t(lambda: ndi.gaussian_filter(xd, sigma, output=o))
-        print("kernel=%s gaussian sigma=%g: first5 %.1f us sustained %.1f us (%.3f of 8 TB/s)" % ("r2" if rows else "r3", sigma, a, b, 8 * n**3 / b / 1e3 / 8000), flush=True)
+        print("kernel=%s gaussian sigma=%g: first5 %.1f us settled %.1f us (%.3f of 8 TB/s)" % ("r2" if rows else "r3", sigma, a, b, 8 * n**3 / b / 1e3 / 8000), flush=True)
         time.sleep(0.3)
 lib.mi_debug_set_long_rows(0)
 if not quick:
     for dbg in (0, 128, 64, 128, 64, 1, 2, 4, 8, 16, 32, 7, 24, 63):
         lib.mi_debug_set_long_dbg(dbg)
         a, b = t(lambda: ndi.gaussian_filter(xd, 2.0, output=o))
-        print("r3 kernel, sigma=2, dbg=%2d: first5 %.1f sustained %.1f" % (dbg, a, b), flush=True)
+        print("r3 kernel, sigma=2, dbg=%2d: first5 %.1f settled %.1f" % (dbg, a, b), flush=True)
     lib.mi_debug_set_long_dbg(0)
 del xd, o; ca.free_all_blocks()
 xe = fs.slab_volume_f32(fs.E_SLAB); ed = ca.asarray(xe); eo = ca.empty(fs.E_SLAB, np.float32)
 for rows in (1, 0, 1, 0):
     lib.mi_debug_set_long_rows(rows)
     a, b = t(lambda: ndi.uniform_filter(ed, size=9, output=eo), reps=15)
-    print("E-slab kernel=%s: first5 %.1f us sustained %.1f us (%.3f)" % ("r2" if rows else "r3", a, b, 8 * np.prod(fs.E_SLAB) / b / 1e3 / 8000), flush=True)
+    print("E-slab kernel=%s: first5 %.1f us settled %.1f us (%.3f)" % ("r2" if rows else "r3", a, b, 8 * np.prod(fs.E_SLAB) / b / 1e3 / 8000), flush=True)
 lib.mi_debug_set_long_rows(0)
