@@ -547,7 +547,7 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     // the same for the wave that makes the halo table on top of its own step: all reads in flight as early as the
     // registers allow (9, then 4 more as each 4 are consumed) -- what this pass costs the workgroup is its latency
     auto ypass_batched = [&](unsigned at) {
-        constexpr int H = W < 9 ? W : 9;
+        constexpr int H0 = DBG ? 5 : 9, H = W < H0 ? W : H0;
         float4 t[W];
         const int rows = (dbg & 1) ? 1 : W;
         const char *src = smem + at;
@@ -624,7 +624,7 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
 #define MI_LONG_GA 4
 #endif
                 constexpr int GA0 = CFG ? (CFG & 7) : MI_LONG_GA;
-                constexpr int GB0 = CFG ? ((CFG >> 3) & 15) : (SAME && !DBG) ? 12 : 10;     // the re-loading variants keep more scalars alive
+                constexpr int GB0 = CFG ? ((CFG >> 3) & 15) : DBG ? 8 : SAME ? 12 : 10;     // the re-loading variants keep more scalars alive, the ablation build its flags
                 constexpr int GA = W < GA0 ? W : GA0, GB = W < GB0 ? W : GB0, ZH = W / 2;
                 const int wy_rows = (dbg & 1) ? 1 : W, wz_taps = (dbg & 4) ? 1 : W;
                 float4 R[W];
