@@ -9,8 +9,9 @@ from helpers import fullsize as fs
 lib = _lib.load()
 n = 512
 x = fs.volume_f32((n, n, n)); xd = ca.asarray(x); o = ca.empty((n, n, n), np.float32)
-def t(fn, reps=60):
-    for _ in range(10): fn()
+def t(fn, reps=250):
+    # settled protocol: ~ 50 ms of the same launches first (scripts/r3_clock_settle.py), then ~ 70 ms measured
+    for _ in range(180): fn()
     ca.synchronize(); e0, e1 = ca.Event(), ca.Event(); e0.record()
     for _ in range(reps): fn()
     e1.record(); ca.synchronize(); return e0.elapsed_ms(e1) / reps * 1e3
