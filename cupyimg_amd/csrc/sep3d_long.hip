@@ -314,6 +314,236 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
 }
 
 
+#ifdef MI_LONG_TUNE
+// ---------------------------------------------------------------------------
+// r3 (tuning builds, MI_LONG_TUNE): the r2 stream with TWO output rows per wave (8 waves, 256 x 16 tile, same LDS ring and DMA scheme).
+// The y pass of rows j and j + 1 reads W + 1 raw rows instead of 2 W (the 17-tap kernel is bound by VALU issue and by
+// the LDS reads the y pass waits for: rocprofv3 showed the VALU 61 % busy and ~600 k cycles per CU for ~365 k cycles of
+// VALU work; ablations in DESIGN.md): 9.5 instead of 17 ds_read_b128 per output row, twice the independent FMA work
+// behind every LDS wait, two waves per SIMD (up to 256 VGPRs: the 2 x W z accumulators take 136).
+// ---------------------------------------------------------------------------
+template <int W, bool SAME, bool HAS_CONST>
+__global__ void __launch_bounds__(512)
+sep3d_long2_kernel(const float *__restrict__ in, float *__restrict__ out, const LongParams p)
+{
+    constexpr int NW = 8;                       // waves; wave w owns output rows 2 w, 2 w + 1
+    constexpr int ROWS = kLongTY + W - 1;
+    static_assert(W >= 3 && (W & 1) && ROWS <= kLongRowsMax && W / 2 <= 8, "long kernel: odd W, 3..17");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr unsigned HY0 = kLongRawBytes;
+    int *ztab = reinterpret_cast<int *>(smem + kLongRawBytes + kLongHyBytes);
+    float *cztab = reinterpret_cast<float *>(ztab + kLongMaxChunk + kStreamMaxTaps);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    int b = blockIdx.x;
+    const int total = p.nxt * p.nyt * p.nzc;
+    if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
+    const int per_chunk = p.nxt * p.nyt;
+    const int zci = b / per_chunk;
+    const int rem = b - zci * per_chunk;
+    const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
+
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int x0 = xt * p.tw, y0 = yt * kLongTY;
+    int zs, ze;
+    {
+        const bool second = zci >= p.nzc0;
+        const int zb = second ? p.zb1 : p.zb0, zn = second ? p.zn1 : p.zn0;
+        zs = zb + (second ? zci - p.nzc0 : zci) * p.zc;
+        ze = min(zs + p.zc, zb + zn);
+    }
+    const int ty_act = min(kLongTY, ny - y0);
+    const int rows_needed = ty_act + W - 1;
+    const int nlanes = min(p.tw >> 2, (nx - x0) >> 2);
+    const int last = nlanes - 1;
+    const int xe = x0 + 4 * nlanes;
+    const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
+    const int zi0 = zs - p.oz;
+    const int nsteps = ze - zs + W - 1;
+
+    for (int i = threadIdx.x; i < nsteps; i += NW * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
+    [[maybe_unused]] float cyv[2] = {0.f, 0.f};
+    [[maybe_unused]] F4 cxv = f4_splat(0.f);
+    if constexpr (HAS_CONST) {
+        for (int t = threadIdx.x; t < ze - zs; t += NW * 64) {
+            float c = 0.f;
+            for (int k = 0; k < W; k++) {
+                const int q = zs + t - p.oz + k;
+                c += (p.mz != MI_MODE_CONSTANT || (q >= 0 && q < nz)) ? p.wzv[2 * k] : 0.f;
+            }
+            cztab[t] = c;
+        }
+        float cx4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < W; k++) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int qy = y0 + 2 * wave + r - p.oy + k;
+                cyv[r] += (p.my != MI_MODE_CONSTANT || (qy >= 0 && qy < ny)) ? p.wyv[2 * k] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int qx = x0 + 4 * lane + c - W / 2 + k;
+                cx4[c] += (p.mx != MI_MODE_CONSTANT || (qx >= 0 && qx < nx)) ? p.wxs[k] : 0.f;
+            }
+        }
+        cxv.lo = (f32x2){cx4[0], cx4[1]};
+        cxv.hi = (f32x2){cx4[2], cx4[3]};
+    }
+    __syncthreads();
+
+    // raw rows this wave stages per plane: wave, wave + 8, wave + 16, wave + 24
+    unsigned vmain[4], vhalo[4];
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        const int r = wave + NW * h;
+        const int ys = bmap<int>(y0 - p.oy + r, ny, p.my);
+        const bool valid = r < rows_needed && ys >= 0;
+        vmain[h] = (valid && lane < nlanes) ? (unsigned)(ys * nx + x0 + 4 * lane) * 4u : kOOB;
+        const int j = lane & 15;
+        const int xsrc = bmap<int>(j < 8 ? x0 - 8 + j : xe + j - 8, nx, p.mx);
+        vhalo[h] = (valid && xsrc >= 0) ? (unsigned)(ys * nx + xsrc) * 4u : kOOB;
+    }
+    const unsigned own = (unsigned)(2 * wave) * kLongRec + (unsigned)lane * 16u;    // first raw record of output row 2 w
+    const unsigned hsrc = (unsigned)(lane >> 2) * kLongRec + 1024u + (unsigned)(lane & 3) * 16u;
+    unsigned hy_near[2], hy_far[2], ovoff[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int j = 2 * wave + r;
+        hy_near[r] = HY0 + (unsigned)j * 64u + (lane == 0 ? 16u : 32u);
+        hy_far[r] = HY0 + (unsigned)j * 64u + (lane == 0 ? 0u : 48u);
+        ovoff[r] = (j < ty_act && lane < nlanes) ? (unsigned)((y0 + j) * nx + x0 + 4 * lane) * 4u : kOOB;
+    }
+    constexpr unsigned kPlane = kLongRowsMax * kLongRec;
+
+    auto issue = [&](int i, unsigned bufoff) {
+        bool live = i < nsteps;
+        int zsrc = zi0 + i;
+        if ((unsigned)zsrc >= (unsigned)nz) zsrc = __builtin_amdgcn_readfirstlane(ztab[live ? i : 0]);
+        if constexpr (HAS_CONST) {
+            live = live && zsrc >= 0;
+            zsrc = max(zsrc, 0);
+        }
+        const unsigned long long a = (unsigned long long)in + (unsigned long long)(unsigned)zsrc * (unsigned long long)plane_bytes;
+        u32x4_t rin;
+        rin.x = (unsigned)a;
+        rin.y = (unsigned)(a >> 32);
+        rin.z = live ? plane_bytes : 0u;
+        rin.w = 0x00020000u;
+        if (!(p.dbg & 8)) {
+            dma_two_rows(rin, vmain[0], vhalo[0], vmain[2], vhalo[2], bufoff + (unsigned)wave * kLongRec);            // rows w, w + 16
+            dma_two_rows(rin, vmain[1], vhalo[1], vmain[3], vhalo[3], bufoff + (unsigned)(wave + NW) * kLongRec);     // rows w + 8, w + 24
+        }
+    };
+    constexpr int kArgBase = 2 * sizeof(void *);
+    kfloats wyk = kernarg_floats(kArgBase + offsetof(LongParams, wyv));
+    kfloats wzk = SAME ? wyk : kernarg_floats(kArgBase + offsetof(LongParams, wzv));
+    kfloats xt0 = kernarg_floats(kArgBase + offsetof(LongParams, xpair));
+    kfloats xt1 = xt0 + 2 * (kStreamMaxTaps / 2 + 2);
+
+    // y pass of ONE row (the halo table): W consecutive records starting at LDS byte address `at`
+    auto ypass = [&](unsigned at) {
+        const float4 t0 = *reinterpret_cast<const float4 *>(smem + at);
+        F4 yv = f4_scale2((f32x2){wyk[0], wyk[1]}, f4_from(t0));
+#pragma unroll
+        for (int k = 1; k < W; k++) {
+            const float4 t = *reinterpret_cast<const float4 *>(smem + at + k * kLongRec);
+            yv = f4_fma2((f32x2){wyk[2 * k], wyk[2 * k + 1]}, f4_from(t), yv);
+        }
+        return yv;
+    };
+    // y pass of rows j and j + 1 from the W + 1 records starting at `at`: raw row k is tap k of row j, tap k - 1 of row j + 1
+    auto ypass2 = [&](unsigned at, F4 &ya, F4 &yb) {
+        const float4 t0 = *reinterpret_cast<const float4 *>(smem + at);
+        ya = f4_scale2((f32x2){wyk[0], wyk[1]}, f4_from(t0));
+        if (p.dbg & 1) { yb = ya; return; }
+#pragma unroll
+        for (int k = 1; k < W; k++) {
+            const F4 t = f4_from(*reinterpret_cast<const float4 *>(smem + at + k * kLongRec));
+            ya = f4_fma2((f32x2){wyk[2 * k], wyk[2 * k + 1]}, t, ya);
+            if (k == 1) yb = f4_scale2((f32x2){wyk[0], wyk[1]}, t);
+            else yb = f4_fma2((f32x2){wyk[2 * k - 2], wyk[2 * k - 1]}, t, yb);
+        }
+        const F4 t = f4_from(*reinterpret_cast<const float4 *>(smem + at + W * kLongRec));
+        yb = f4_fma2((f32x2){wyk[2 * W - 2], wyk[2 * W - 1]}, t, yb);
+    };
+
+    F4 acc[2][W];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < W; k++) acc[r][k] = f4_splat(0.f);
+
+    issue(0, 0);
+    issue(1, kPlane);
+    issue(2, 2 * kPlane);
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    if (wave == NW - 1) {
+        const F4 hv = ypass(hsrc);
+        *reinterpret_cast<float4 *>(smem + HY0 + (unsigned)lane * 16u) = f4_to_float4(hv);
+    }
+
+    unsigned bi = 0;
+    for (int i0 = 0; i0 < nsteps; i0 += W) {
+        static_for<W>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                if constexpr (!SAME) { launder(wyk); launder(wzk); launder(xt0); launder(xt1); }
+                const unsigned b1 = bi == (kLongNB - 1) * kPlane ? 0u : bi + kPlane;
+                const unsigned b3 = bi == 0u ? (kLongNB - 1) * kPlane : bi - kPlane;
+                // in flight, oldest first: 8 DMAs of plane i + 1, 2 stores, 8 DMAs of plane i + 2, 2 stores (see the
+                // one-row kernel): plane i + 1 must have landed, the rest stays in flight
+                if (i >= W && !(p.dbg & 16)) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue(i + 3, b3);
+                const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
+                F4 yv[2];
+                ypass2(own + bi, yv[0], yv[1]);
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    float4 eL[2], eR[2];
+                    {
+                        const float4 n = *reinterpret_cast<const float4 *>(smem + hy_near[r] + hyoff);
+                        const float4 f = *reinterpret_cast<const float4 *>(smem + hy_far[r] + hyoff);
+                        eL[0] = n; eL[1] = f; eR[0] = n; eR[1] = f;
+                    }
+                    const F4 xy = (p.dbg & 2) ? yv[r] : xhops<W>(f4_to_float4(yv[r]), eL, eR, lane, last, xt0, xt1);
+                    acc[r][J] = f4_scale2((f32x2){wzk[0], wzk[1]}, xy);
+                    if (!(p.dbg & 4)) {
+#pragma unroll
+                        for (int k = 1; k < W; k++)
+                            acc[r][(J - k + W) % W] = f4_fma2((f32x2){wzk[2 * k], wzk[2 * k + 1]}, xy, acc[r][(J - k + W) % W]);
+                    }
+                }
+                if (i >= W - 1) {
+                    const unsigned long long oa = (unsigned long long)out +
+                                                  (unsigned long long)(unsigned)(zs + i - (W - 1)) * (unsigned long long)plane_bytes;
+                    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)oa, 0, (int)plane_bytes, 0x00020000);
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        F4 o = acc[r][(J + 1) % W];
+                        if constexpr (HAS_CONST) {
+                            const float g = -p.cval * cztab[i - (W - 1)] * cyv[r];
+                            o.lo = fma2(splat2(g), cxv.lo, o.lo + splat2(p.cval_sum));
+                            o.hi = fma2(splat2(g), cxv.hi, o.hi + splat2(p.cval_sum));
+                        }
+                        if (!(p.dbg & 16)) __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(o), rout, ovoff[r], 0, 2);
+                    }
+                }
+                if (i + 1 < nsteps && wave == (i & (NW - 1)) && !(p.dbg & 32)) {
+                    const F4 hv = ypass(hsrc + b1);
+                    *reinterpret_cast<float4 *>(smem + HY0 + (kLongHyBytes / 2 - hyoff) + (unsigned)lane * 16u) = f4_to_float4(hv);
+                }
+                bi = b1;
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // r3 kernel (`sep3d_long3_kernel`): same tile, ring, DMA and barrier scheme; what changed is the instruction stream,
 // after the ablations showed the 17-tap kernel bound by VALU issue (158 VALU instructions per wave and plane for 102
@@ -752,6 +982,17 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
         }
 #ifdef MI_LONG_TUNE
         if constexpr (W == 17 && SAME) {
+            if (g_long_rows == 2) {
+                static bool attr2 = false;
+                if (!attr2) {
+                    MI_HIP(hipFuncSetAttribute((const void *)sep3d_long2_kernel<17, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    attr2 = true;
+                }
+                note_kernel("mi::sep3d_long2_kernel<17,true,false> grid=%d (r2 stream, two rows per wave; tuning build)", total);
+                hipLaunchKernelGGL((sep3d_long2_kernel<17, true, false>), dim3(total), dim3(512), lds, s, in, out, p);
+                MI_HIP(hipGetLastError());
+                return MI_OK;
+            }
             const int cfg = g_long_cfg;
 #define MI_LONG_CFG(C)                                                                                           \
             if (cfg == (C)) {                                                                                    \
