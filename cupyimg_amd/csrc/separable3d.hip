@@ -832,7 +832,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     // 1024 x 128^2, but 4-6 % SLOWER on 300^3 and 200 x 500 x 760, whose rows do not fill its 256-voxel wave tiles, and
     // equal or 3 % slower where the launch is latency bound).  Constant mode stays on the lean kernel below 9 taps.
     const int64_t nvox_out = nz * ny * nx;      // of the whole array: plane-range launches of one filter call take the same kernel
-    const bool long_small = !any_const && w[0] >= 3 && w[0] <= 7 &&
+    const bool long_small = !any_const && w[0] >= 3 && w[0] <= 7 && nx >= 128 && ny >= 16 &&
                             (w[0] == 7 ? nvox_out >= ((int64_t)1 << 22)
                                        : nvox_out >= ((int64_t)1 << 23) && ((nx & 255) == 0 || nx == 128) && (ny & 15) == 0);
     if (cubic_w && g_sep3d_long != 1 && nx >= 16 &&
