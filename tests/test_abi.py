@@ -74,3 +74,26 @@ def test_device_ops_fail_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(Exception):
         ca.zeros((4, 4))
+
+
+def test_build_gate_sees_the_vmcnt_counting_kernels():
+    """`_build.NO_SCRATCH`: the kernels that wait on vmcnt by count must not touch scratch memory.  The gate runs at
+    build time; this checks that it still SEES those kernels in the objects of this tree (a toolchain that renamed the
+    fat-binary section or the disassembly format would silently turn it off) and that they are clean."""
+    import subprocess
+    import tempfile
+    from cupyimg_amd import _build
+    for src, fragment in _build.NO_SCRATCH.items():
+        obj = os.path.join(_build.OBJ, src.replace(".hip", ".o"))
+        if not os.path.exists(obj):
+            pytest.skip("objects not in tree (library built elsewhere)")
+        co = _build._device_code_object(obj)
+        assert co[:4] == b"\x7fELF"
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "dev.co")
+            with open(path, "wb") as f:
+                f.write(co)
+            text = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+        names = re.findall(r"^[0-9a-f]+ <(\S+)>:$", text, flags=re.M)
+        assert any(fragment in n for n in names), (src, names[:3])
+        assert _build._scratch_users(obj, fragment) == []
