@@ -19,3 +19,15 @@ def convolve_separable(x, w, axes=None, **kwargs):
     """n-D convolution as separable convolve1d passes (cupyimg/_misc.py:39-77)"""
     from ._misc import convolve_separable as impl
     return impl(x, w, axes, **kwargs)
+
+
+def last_kernel():
+    """Name (with grid) of the kernel the last separable-filter call of this thread dispatched, as the library recorded
+    it (`mi_debug_last_kernel`); a diagnostic for benchmarks and tests, empty before the first such call."""
+    import ctypes
+    from . import _lib
+    buf = ctypes.create_string_buffer(256)
+    fn = _lib.load().mi_debug_last_kernel
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    fn(buf, 256)
+    return buf.value.decode()

@@ -33,6 +33,21 @@ def test_H_uniform5_512(gpu, ndi, vol512):
     assert err <= 1e-6, err
 
 
+def test_H_neighbours_3_7_9_13_taps_512(gpu, ndi, vol512):
+    """The tap counts next to the headline's on the same volume: 3 and 7 taps (long kernel by the r3 dispatch rule), 9 and
+    13 taps, in `mirror` and `nearest` mode; chunk seams of the long kernel lie at multiples of 128 planes."""
+    x, xd = vol512
+    from cupyimg_amd import last_kernel
+    for size, mode in ((3, "mirror"), (7, "nearest"), (9, "mirror"), (13, "reflect")):
+        out = ndi.uniform_filter(xd, size=size, mode=mode)
+        assert "sep3d_long3_kernel<%d," % size in last_kernel(), last_kernel()
+        h = size // 2
+        err = fs.check_filter_slabs(x, out, h, h, lambda s: sndi.uniform_filter(s.astype(np.float64), size=size, mode=mode),
+                                    fs.z_slabs(fs.N_H, extra=(128, 256, 384)))
+        assert err <= 1e-6, (size, mode, err)
+        del out
+
+
 def test_B_gaussian_sigma2_512(gpu, ndi, vol512):
     x, xd = vol512
     out = ndi.gaussian_filter(xd, sigma=2)
