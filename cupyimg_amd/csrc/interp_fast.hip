@@ -536,14 +536,13 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
     const int rz0 = (int)__umulhi((unsigned)row0, q.by_magic), ry0 = row0 - rz0 * q.by;
     unsigned rel[kLdsRoundsMax];
     {
-        int c4 = c40, ry = ry0, rz = rz0;
+        const unsigned row_b = (unsigned)p.nx * 4u, plane_b = (unsigned)p.ny * row_b;
 #pragma unroll
         for (int j = 0; j < kLdsRoundsMax; j++) {
-            rel[j] = tid + (j << 9) < q.nchunks ? (unsigned)((rz * p.ny + ry) * p.nx + 4 * c4) * 4u : 0x80000000u;
-            c4 += q.dc4; ry += q.dry; rz += q.drz;
-            if (c4 >= cpr) { c4 -= cpr; ry++; }
-            if (ry >= q.by) { ry -= q.by; rz++; }
-            if (ry >= q.by) { ry -= q.by; rz++; }
+            const unsigned ch = (unsigned)tid + ((unsigned)j << 9);
+            const unsigned row = __umulhi(ch, q.cpr_magic), c4 = ch - row * (unsigned)cpr;
+            const unsigned rz = __umulhi(row, q.by_magic), ry = row - rz * (unsigned)q.by;
+            rel[j] = ch < (unsigned)q.nchunks ? rz * plane_b + ry * row_b + c4 * 16u : 0x80000000u;
         }
     }
     const int yrow = RW * wave + yy;
