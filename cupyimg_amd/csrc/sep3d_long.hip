@@ -666,12 +666,15 @@ struct XPass3 {
 // CFG (tuning, see launch_long): bits 0-2 first y read group, bits 3-6 end of the second group, bit 7 halo table at
 // the end of the step instead of the start, bit 8 no priority raise for the wave that makes the halo table, bit 9 x pass through LDS; 0 = the
 // defaults below.
-template <int W, bool SAME, bool DBG, int CFG = 0>
+// WZ: taps along z (the streamed axis); W: taps along y and x.  WZ != W serves volumes with anisotropic voxels
+// (gaussian sigma given in millimetres: fewer taps through the slices), where the in-plane kernels agree.
+template <int W, bool SAME, bool DBG, int CFG = 0, int WZ = W>
 __global__ void __launch_bounds__(kLongTY * 64)
 sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const LongParams p)
 {
     constexpr int ROWS = kLongTY + W - 1;
     static_assert(W >= 3 && (W & 1) && ROWS <= kLongRowsMax && W / 2 <= 8, "long kernel: odd W, 3..17");
+    static_assert(WZ >= 3 && (WZ & 1) && WZ <= kLongRowsMax / 2 + 1 && (WZ == W || !SAME), "long kernel: odd WZ, 3..17");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr unsigned HY0 = kLongRawBytes;
     int *ztab = reinterpret_cast<int *>(smem + kLongRawBytes + kLongHyBytes);
@@ -712,7 +715,7 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     const int xe = x0 + 4 * nlanes;
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
     const int zi0 = zs - p.oz;
-    const int nsteps = ze - zs + W - 1;
+    const int nsteps = ze - zs + WZ - 1;
 
     for (int i = threadIdx.x; i < nsteps; i += kLongTY * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
     __syncthreads();
@@ -796,9 +799,9 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
         return hv;
     };
 
-    F4 acc[W];
+    F4 acc[WZ];
 #pragma unroll
-    for (int k = 0; k < W; k++) acc[k] = f4_splat(0.f);
+    for (int k = 0; k < WZ; k++) acc[k] = f4_splat(0.f);
 
     // prologue: planes 0..2 in flight; plane 0 complete -> its y pass (every wave) and its halo table (wave 15)
     issue(0, 0);
@@ -816,8 +819,8 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     // plane i + 2 and the store behind them may be in flight), the halo table of plane i is complete, the y-filtered row
     // of plane i is in `yv`; nobody reads plane i - 1 any more (nor plane i): its slot takes plane i + 3.
     unsigned bi = 0;                    // LDS offset of plane i
-    for (int i0 = 0; i0 < nsteps; i0 += W) {
-        static_for<W>([&](auto JJ) {
+    for (int i0 = 0; i0 < nsteps; i0 += WZ) {
+        static_for<WZ>([&](auto JJ) {
             constexpr int J = decltype(JJ)::value;
             const int i = i0 + J;
             if (i < nsteps) {
@@ -855,8 +858,8 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
 #endif
                 constexpr int GA0 = CFG ? (CFG & 7) : MI_LONG_GA;
                 constexpr int GB0 = CFG ? ((CFG >> 3) & 15) : DBG ? 8 : SAME ? 12 : 10;     // the re-loading variants keep more scalars alive, the ablation build its flags
-                constexpr int GA = W < GA0 ? W : GA0, GB = W < GB0 ? W : GB0, ZH = W / 2;
-                const int wy_rows = (dbg & 1) ? 1 : W, wz_taps = (dbg & 4) ? 1 : W;
+                constexpr int GA = W < GA0 ? W : GA0, GB = W < GB0 ? W : GB0, ZH = WZ / 2;
+                const int wy_rows = (dbg & 1) ? 1 : W, wz_taps = (dbg & 4) ? 1 : WZ;
                 float4 R[W];
                 const char *ysrc = smem + own + b1;
                 issue(i + 3, b3);
@@ -901,7 +904,7 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 // z pass: scatter into the pending outputs; output i - k takes tap k
                 acc[J] = f4_scale(wzk[0], xy);
 #pragma unroll
-                for (int k = 1; k < ZH; k++) if (k < wz_taps) acc[(J - k + W) % W] = f4_fma(wzk[k], xy, acc[(J - k + W) % W]);
+                for (int k = 1; k < ZH; k++) if (k < wz_taps) acc[(J - k + WZ) % WZ] = f4_fma(wzk[k], xy, acc[(J - k + WZ) % WZ]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = GA; k < GB; k++) if (k < wy_rows) yv = f4_fma(wyk[k], f4_from(R[k]), yv);
@@ -909,16 +912,16 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 for (int k = GB; k < W; k++) if (k < wy_rows) R[k] = *reinterpret_cast<const float4 *>(ysrc + k * kLongRec);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = ZH < 1 ? 1 : ZH; k < W; k++) if (k < wz_taps) acc[(J - k + W) % W] = f4_fma(wzk[k], xy, acc[(J - k + W) % W]);
+                for (int k = ZH < 1 ? 1 : ZH; k < WZ; k++) if (k < wz_taps) acc[(J - k + WZ) % WZ] = f4_fma(wzk[k], xy, acc[(J - k + WZ) % WZ]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = GB; k < W; k++) if (k < wy_rows) yv = f4_fma(wyk[k], f4_from(R[k]), yv);
                 {
                     const unsigned long long oa = (unsigned long long)out +
-                                                  (unsigned long long)(unsigned)(zs + i - (W - 1)) * (unsigned long long)plane_bytes;
+                                                  (unsigned long long)(unsigned)(zs + i - (WZ - 1)) * (unsigned long long)plane_bytes;
                     const __amdgpu_buffer_rsrc_t rout =
-                        __builtin_amdgcn_make_buffer_rsrc((void *)oa, 0, i >= W - 1 ? (int)plane_bytes : 0, 0x00020000);
-                    const F4 o = acc[(J + 1) % W];
+                        __builtin_amdgcn_make_buffer_rsrc((void *)oa, 0, i >= WZ - 1 ? (int)plane_bytes : 0, 0x00020000);
+                    const F4 o = acc[(J + 1) % WZ];
                     if (!(dbg & 16)) __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(o), rout, ovoff, 0, 2);
                 }
                 if (kHaloEnd ? !(dbg & 64) : (dbg & 64) != 0) halo_job();
@@ -1023,17 +1026,35 @@ static int long_cus()
     return cus;
 }
 
+// (in-plane taps, z taps) pairs the r3 kernel is instantiated for besides the cubic ones: volumes with anisotropic
+// voxels, where a gaussian given in millimetres has fewer taps through the slices (each pair is one more kernel to
+// compile: the list is what sigma = 1 ... 2 voxels in the plane with 2-4 x thicker slices needs)
+#ifdef MI_LONG_DEV
+#define MI_LONG_ANISO_PAIRS(X) X(17, 9)
+#else
+#define MI_LONG_ANISO_PAIRS(X) X(9, 3) X(9, 5) X(9, 7) X(13, 3) X(13, 5) X(13, 7) X(13, 9) X(17, 3) X(17, 5) X(17, 7) X(17, 9) X(17, 13)
+#endif
+bool long_aniso_pair(int w, int wzn)
+{
+#define MI_LONG_ANISO_TEST(N, NZ) if (w == (N) && wzn == (NZ)) return true;
+    MI_LONG_ANISO_PAIRS(MI_LONG_ANISO_TEST)
+#undef MI_LONG_ANISO_TEST
+    return false;
+}
+
 static mi::Knob g_long_zchunks{0};     // test hook: number of z chunks (0 = cost model)
 static mi::Knob g_long_same{1};        // test hook: 0 = always the reloading variant
 
 // Fused long-kernel path: cubic odd W in 11..17 (9 behind the test hook), origins on y / z allowed, no constant mode.
 // Returns MI_ERR_UNSUPPORTED when the request is outside that (the caller runs the streaming passes).
-int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, const float *wx, const float *wy,
+int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, int wzn, const float *wx, const float *wy,
                    const float *wz, int oy, int oz, int mx, int my, int mz, float cval, const int64_t zb[2],
                    const int64_t zn[2], hipStream_t s)
 {
-    if (w < 3 || w > 17 || !(w & 1)) return MI_ERR_UNSUPPORTED;
+    // w: taps along y and x, wzn: taps along z (== w: the cubic kernels; a few (w, wzn) pairs with wzn < w besides)
+    if (w < 3 || w > 17 || !(w & 1) || wzn < 3 || wzn > 17 || !(wzn & 1)) return MI_ERR_UNSUPPORTED;
     const bool has_const = mx == MI_MODE_CONSTANT || my == MI_MODE_CONSTANT || mz == MI_MODE_CONSTANT;
+    if (wzn != w && (has_const || !long_aniso_pair(w, wzn))) return MI_ERR_UNSUPPORTED;
     if ((int64_t)ny * nx * 4 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
     LongParams p;
     memset(&p, 0, sizeof(p));
@@ -1046,11 +1067,15 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
     double sx = 0, sy = 0, sz = 0;
     for (int k = 0; k < w; k++) {
         p.wyv[2 * k] = p.wyv[2 * k + 1] = wy[k];
-        p.wzv[2 * k] = p.wzv[2 * k + 1] = wz[k];
         p.wxs[k] = wx[k];
-        p.wyp[k] = wy[k]; p.wzp[k] = wz[k]; p.wxe[k] = wx[k];
+        p.wyp[k] = wy[k]; p.wxe[k] = wx[k];
         p.wxo[k + 1] = wx[k];                               // wxo[2m] = wx[2m-1], wxo[2m+1] = wx[2m]
-        sx += wx[k]; sy += wy[k]; sz += wz[k];
+        sx += wx[k]; sy += wy[k];
+    }
+    for (int k = 0; k < wzn; k++) {
+        p.wzv[2 * k] = p.wzv[2 * k + 1] = wz[k];
+        p.wzp[k] = wz[k];
+        sz += wz[k];
     }
     p.dbg = g_long_dbg;
     p.cval = cval;
@@ -1077,7 +1102,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
         if (chunk > kLongMaxChunk) continue;
         const int real = (nzr + chunk - 1) / chunk;
         const double rounds = (double)(((int64_t)cols * real + ncu - 1) / ncu);
-        const double cost = rounds * (chunk + w - 1 + 3);
+        const double cost = rounds * (chunk + wzn - 1 + 3);
         if (cost < best) { best = cost; best_nzc = real; }
     }
     if (g_long_zchunks > 0) best_nzc = std::min((int)g_long_zchunks, nzr);
@@ -1086,6 +1111,19 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, c
     p.zb0 = (int)zb[0]; p.zn0 = (int)zn[0]; p.zb1 = (int)zb[1]; p.zn1 = (int)zn[1];
     p.nzc0 = (int)((zn[0] + p.zc - 1) / p.zc);
     p.nzc = p.nzc0 + (int)((zn[1] + p.zc - 1) / p.zc);
+    if (wzn != w) {
+#define MI_LONG_ANISO(N, NZ)                                                                                         \
+        if (w == (N) && wzn == (NZ)) {                                                                                \
+            const size_t lds = (size_t)kLongRawBytes + kLongHyBytes + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int); \
+            static bool attr_a = false;                                                                              \
+            note_kernel("mi::sep3d_long3_kernel<%d,false,false,0,%d> grid=%d (fused y/x/z separable pass, %d taps in the plane, %d along z)", \
+                        (N), (NZ), p.nxt * p.nyt * p.nzc, (N), (NZ));                                                 \
+            return long_launch_one(sep3d_long3_kernel<(N), false, false, 0, (NZ)>, attr_a, lds, p.nxt * p.nyt * p.nzc, in, out, p, s); \
+        }
+        MI_LONG_ANISO_PAIRS(MI_LONG_ANISO)
+#undef MI_LONG_ANISO
+        return MI_ERR_UNSUPPORTED;
+    }
     bool same = g_long_same != 0;
     for (int k = 0; k < w; k++) same = same && wx[k] == wy[k] && wy[k] == wz[k];
 #define MI_LONG_CASE(N)                                                                                   \

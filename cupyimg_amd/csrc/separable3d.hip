@@ -682,9 +682,10 @@ static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams 
 
 int run_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axis, const float *wav, int wa, int oa,
                     int ma, const float *wxv, int wx, int mx, float cval, hipStream_t s);   // stream3d.hip
-int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, const float *wx, const float *wy,
+int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, int wzn, const float *wx, const float *wy,
                    const float *wz, int oy, int oz, int mx, int my, int mz, float cval, const int64_t zb[2],
                    const int64_t zn[2], hipStream_t s);   // sep3d_long.hip
+bool long_aniso_pair(int w, int wzn);                     // sep3d_long.hip: (in-plane, z) tap pairs it is built for
 
 // Tile / z-chunk choice by a small cost model.  One workgroup per CU is
 // resident, so the launch runs in ceil(workgroups / CUs) rounds; a workgroup
@@ -839,7 +840,17 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
         ((w[0] >= 9 && w[0] <= 17) || (w[0] >= 3 && w[0] <= 7 && (g_sep3d_long == 2 || long_small)))) {
         // long cubic kernels: ONE launch with LDS-DMA staging and the z state in registers (sep3d_long.hip)
         const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
-        rc = run_sep3d_long((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w[0], wbuf[2], wbuf[1],
+        rc = run_sep3d_long((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w[0], w[0], wbuf[2], wbuf[1],
+                            wbuf[0], oy, oz, p.mx, p.my, p.mz, (float)cval, zb, zn, resolve_stream(stream));
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
+    }
+    // r3: anisotropic voxels -- the same kernel with fewer taps along z than in the plane (one launch at 8 B/voxel
+    // where the streaming passes below take two at 16), for the tap pairs it is instantiated for, on volumes that fill
+    // the chip; index-mapping boundary modes only
+    if (g_sep3d_long != 1 && !any_const && w[1] == w[2] && w[0] != w[1] && nx >= 128 && ny >= 16 &&
+        nvox_out >= ((int64_t)1 << 22) && mi::long_aniso_pair(w[1], w[0])) {
+        const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
+        rc = run_sep3d_long((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w[1], w[0], wbuf[2], wbuf[1],
                             wbuf[0], oy, oz, p.mx, p.my, p.mz, (float)cval, zb, zn, resolve_stream(stream));
         if (rc != MI_ERR_UNSUPPORTED) return rc;
     }

@@ -1478,3 +1478,32 @@ def test_long_kernel_generations_agree(gpu, ndi):
                 assert maxnorm_rel(c, orc.uniform_filter(x, size, mode=mode, cval=0.75, origin=[1, -1, 0])) <= 1e-6, (shape, mode, size)
             u = ndi.uniform_filter(xd, 11, mode=mode, origin=[2, -3, 0]).get()
             assert maxnorm_rel(u, orc.uniform_filter(x, 11, mode=mode, origin=[2, -3, 0])) <= 1e-6, (shape, mode)
+
+
+def test_long_kernel_anisotropic_tap_pairs(gpu, ndi):
+    """Volumes with anisotropic voxels: fewer taps along z than in the plane take ONE launch of the long kernel
+    (sep3d_long3_kernel<W, false, false, 0, WZ>) for the (W, WZ) pairs it is built for, on volumes of >= 4 Mvoxels;
+    every index-mapping mode, gaussian and uniform weights, an origin along z; `constant` mode and other pairs fall back
+    to the streaming passes and must agree as well."""
+    import cupyimg_amd as ca
+    rng = np.random.default_rng(77)
+    shape = (64, 256, 256)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xd = gpu.asarray(x)
+    for sig, taps in (([1.0, 2.0, 2.0], (17, 9)), ([0.5, 1.0, 1.0], (9, 5)), ([0.75, 1.5, 1.5], (13, 7)), ([0.5, 2.0, 2.0], (17, 5))):
+        for mode in ("reflect", "mirror", "nearest", "wrap"):
+            g = ndi.gaussian_filter(xd, sig, mode=mode).get()
+            assert "sep3d_long3_kernel<%d,false,false,0,%d>" % taps in ca.last_kernel(), (sig, ca.last_kernel())
+            assert maxnorm_rel(g, orc.gaussian_filter(x, sig, mode=mode)) <= 1e-6, (sig, mode)
+        g = ndi.gaussian_filter(xd, sig, mode="constant", cval=0.5).get()           # falls back
+        assert "sep3d_long3_kernel" not in ca.last_kernel()
+        assert maxnorm_rel(g, orc.gaussian_filter(x, sig, mode="constant", cval=0.5)) <= 1e-6, sig
+    for size, taps in (((3, 9, 9), (9, 3)), ((13, 17, 17), (17, 13)), ((7, 9, 9), (9, 7))):
+        u = ndi.uniform_filter(xd, size, mode="reflect").get()
+        assert "sep3d_long3_kernel<%d,false,false,0,%d>" % taps in ca.last_kernel(), (size, ca.last_kernel())
+        assert maxnorm_rel(u, orc.uniform_filter(x, size, mode="reflect")) <= 1e-6, size
+        u = ndi.uniform_filter(xd, size, mode="mirror", origin=[1, -2, 0]).get()
+        assert maxnorm_rel(u, orc.uniform_filter(x, size, mode="mirror", origin=[1, -2, 0])) <= 1e-6, size
+    u = ndi.uniform_filter(xd, (11, 17, 17)).get()                                  # not a built pair: streaming passes
+    assert "sep3d_long3_kernel" not in ca.last_kernel()
+    assert maxnorm_rel(u, orc.uniform_filter(x, (11, 17, 17))) <= 1e-6
