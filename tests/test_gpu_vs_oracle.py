@@ -1490,7 +1490,8 @@ def test_long_kernel_anisotropic_tap_pairs(gpu, ndi):
     shape = (64, 256, 256)
     x = rng.standard_normal(shape).astype(np.float32)
     xd = gpu.asarray(x)
-    for sig, taps in (([1.0, 2.0, 2.0], (17, 9)), ([0.5, 1.0, 1.0], (9, 5)), ([0.75, 1.5, 1.5], (13, 7)), ([0.5, 2.0, 2.0], (17, 5))):
+    for sig, taps in (([1.0, 2.0, 2.0], (17, 9)), ([0.5, 1.0, 1.0], (9, 5)), ([0.75, 1.5, 1.5], (13, 7)), ([0.5, 2.0, 2.0], (17, 5)),
+                      ([0.25, 0.5, 0.5], (5, 3)), ([0.625, 1.25, 1.25], (11, 7)), ([0.875, 1.75, 1.75], (15, 9)), ([0.375, 0.75, 0.75], (7, 5))):
         for mode in ("reflect", "mirror", "nearest", "wrap"):
             g = ndi.gaussian_filter(xd, sig, mode=mode).get()
             assert "sep3d_long3_kernel<%d,false,false,0,%d>" % taps in ca.last_kernel(), (sig, ca.last_kernel())
