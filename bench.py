@@ -105,6 +105,30 @@ def copy_kernel_ceiling(ca, xd, out):
     return 2 * xd.nbytes / best / 1e9, best_blocks
 
 
+def settle_device(ca, ms=40.0):
+    """~ `ms` of copy-kernel load on two scratch buffers.  The single-GPU headline path times its comparators before
+    the warm-up steps (~ 60 ms of load); the slab / multi-rank paths have no comparators, so every rank runs this
+    instead -- the same device state before the W warm-up steps for every N, otherwise the N = 1 line would be taken
+    with settled clocks and the N > 1 lines inside the slower first 30 ms of a process (profiles/r3_clock_settle.txt)."""
+    import ctypes
+    from cupyimg_amd import _lib
+    fn = _lib.load().mi_debug_copy_f32
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    a = ca.empty((1 << 25,), np.float32)
+    b = ca.empty((1 << 25,), np.float32)
+    a.fill(0.0)
+    e0, e1 = ca.Event(), ca.Event()
+    e0.record()
+    while True:
+        for _ in range(40):
+            fn(a.ptr, b.ptr, a.size, 2048, None)
+        e1.record()
+        ca.synchronize()
+        if e0.elapsed_ms(e1) >= ms:
+            break
+    del a, b
+
+
 def _allcores_worker(args):
     """One slab of the slab-parallel SciPy run (child process of the CPU-only helper)."""
     name_in, name_out, shape, z0, z1, lo, hi = args
@@ -370,6 +394,8 @@ def main():
         c1.record()
         ca.synchronize()
         comparators = (ck_gbs, ck_blocks, ALG_BYTES_PER_VOXEL * (N_SIDE ** 3) / (c0.elapsed_ms(c1) / 10 / 1e3) / 1e9)
+    else:
+        settle_device(ca)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -460,7 +486,9 @@ def main():
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "partition": partition, "device": ca.device_name()},
+            "config": {"workload": workload, "partition": partition, "device": ca.device_name(),
+                       "device_load_before_warmup": ("comparators of the roofline block (~60 ms)" if comparators is not None
+                                                     else "40 ms of the in-tree copy kernel on scratch buffers, every rank")},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
