@@ -229,19 +229,6 @@ def cpu_baseline(x, gpu_out):
     return res
 
 
-def _self_loop_plan(dist_, nz, lo, hi):
-    """SlabPlan of a closed chain of ONE rank: both neighbours are the rank itself (`--self-loop`)."""
-    plan = dist_.SlabPlan.__new__(dist_.SlabPlan)
-    plan.nz, plan.nranks, plan.rank = nz, 2, 0          # nranks > 1 selects the exchange path
-    plan.lo, plan.hi, plan.wrap = lo, hi, True
-    plan.z0, plan.z1, plan.n_local = 0, nz, nz
-    plan.counts = [nz]
-    plan.prev = plan.next = 0
-    plan.lo_present, plan.hi_present = lo, hi
-    plan.n_ext = lo + nz + hi
-    return plan
-
-
 E_SIDE = 2048
 E_SIZE = 9
 E_SEED = 20260
@@ -360,7 +347,7 @@ def main():
     else:
         lo, hi = dist_.halo_widths(size)
         if args.self_loop:
-            plan = _self_loop_plan(dist_, nz_total, lo, hi)
+            plan = dist_.SlabPlan.self_loop(nz_total, lo, hi)
             comm = quiet_c_stdout(lambda: dist_.HaloComm(1, 0, lambda uid: uid))
         else:
             plan = dist_.SlabPlan(nz_total, world, rank, lo, hi, wrap=False)

@@ -93,24 +93,54 @@ def _obj_deps_mtime(depfile, fallback):
     return newest
 
 
+def _llvm_tool(name):
+    """llvm-objdump / llvm-objcopy of the ROCm install hipcc belongs to (not a fixed /opt/rocm)."""
+    root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc())))
+    for cand in (os.path.join(root, "lib", "llvm", "bin", name), os.path.join(root, "llvm", "bin", name),
+                 os.path.join("/opt/rocm/lib/llvm/bin", name), shutil.which(name) or ""):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("{} not found next to {}: the scratch-spill check of the vmcnt-counting kernels cannot run"
+                       .format(name, hipcc()))
+
+
+def _flag_stamp(flags):
+    import hashlib
+    return hashlib.sha256(" ".join(COMMON + list(flags)).encode()).hexdigest()
+
+
 def _compile(args):
     src, flags, force, hdr_mtime = args
     s = os.path.join(CSRC, src)
     o = os.path.join(OBJ, src.replace(".hip", ".o"))
     d = o + ".d"
-    if (not force and os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(s)
+    stamp_file = o + ".flags"
+    stamp = _flag_stamp(flags)
+    try:
+        same_flags = open(stamp_file).read() == stamp       # e.g. MI_LONG_TUNE toggled: rebuild
+    except OSError:
+        same_flags = False
+    if (not force and same_flags and os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(s)
             and os.path.getmtime(o) >= _obj_deps_mtime(d, hdr_mtime)):
         return o, False
+    if os.path.exists(stamp_file):
+        os.unlink(stamp_file)
     cmd = [hipcc()] + COMMON + flags + ["-MMD", "-MF", d, "-c", s, "-o", o]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise RuntimeError("hipcc failed for {}:\n{}".format(src, proc.stdout))
     if src in NO_SCRATCH:
-        spilled = _scratch_users(o, NO_SCRATCH[src])
+        try:
+            spilled = _scratch_users(o, NO_SCRATCH[src])
+        except BaseException:
+            os.unlink(o)                 # an unchecked object must not look up to date to the next build
+            raise
         if spilled:
             os.unlink(o)
             raise RuntimeError("{}: kernels that count their vector-memory operations by hand (s_waitcnt vmcnt) were "
                                "compiled with scratch-memory accesses, which add uncounted ones: {}".format(src, spilled))
+    with open(stamp_file, "w") as f:     # written last: object compiled AND checked with these flags
+        f.write(stamp)
     if proc.stdout.strip():
         sys.stderr.write(proc.stdout)
     return o, True
@@ -126,9 +156,7 @@ def _device_code_object(obj):
     """The gfx950 code object out of a hipcc host object (section .hip_fatbin, clang offload bundle)."""
     import struct
     import tempfile
-    objcopy = os.path.join(os.path.dirname(os.path.realpath(hipcc())), "..", "lib", "llvm", "bin", "llvm-objcopy")
-    if not os.path.exists(objcopy):
-        objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    objcopy = _llvm_tool("llvm-objcopy")
     with tempfile.TemporaryDirectory() as tmp:
         fb = os.path.join(tmp, "fb.bin")
         subprocess.run([objcopy, "--dump-section", ".hip_fatbin=" + fb, obj], check=True)
@@ -147,10 +175,22 @@ def _device_code_object(obj):
     raise RuntimeError("no {} code object in {}".format(ARCH, obj))
 
 
+def _is_ablation_build(mangled):
+    """sep3d_long3_kernel<W, SAME, DBG = true, ...>: the ablation builds (timing aids behind a debug knob, not product
+    kernels) may spill.  Decided from the template arguments of the Itanium-mangled name -- `Lb1E` in third position --
+    not from one exact suffix, so that a new trailing parameter or a renamed parameter struct cannot silently turn the
+    exemption off (or on for a product kernel)."""
+    m = re.search(r"sep3d_long3_kernelI((?:L[a-z]n?\d+E)+)E", mangled)
+    if not m:
+        return False
+    targs = re.findall(r"L([a-z])(n?\d+)E", m.group(1))
+    return len(targs) >= 3 and targs[2] == ("b", "1")
+
+
 def _scratch_users(obj, fragment):
     """Kernels of `obj` whose name contains `fragment` and whose code has scratch_* instructions."""
     import tempfile
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    objdump = _llvm_tool("llvm-objdump")
     with tempfile.TemporaryDirectory() as tmp:
         co = os.path.join(tmp, "dev.co")
         with open(co, "wb") as f:
@@ -158,7 +198,7 @@ def _scratch_users(obj, fragment):
         text = subprocess.run([objdump, "-d", co], stdout=subprocess.PIPE, text=True, check=True).stdout
     bad, name, count = [], None, 0
     def close():
-        if name and count and fragment in name and not ("sep3d_long3_kernel" in name and name.endswith("ELb1ELi0EEEvPKfPfNS_10LongParamsE")):
+        if name and count and fragment in name and not _is_ablation_build(name):
             bad.append("{} ({} scratch instructions)".format(name, count))
     for line in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)

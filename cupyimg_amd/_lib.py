@@ -102,6 +102,7 @@ SIGNATURES = {
     "mi_separable3d_f32": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i, _vp],
     "mi_separable3d_f64": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _vp],
     "mi_separable3d_f32_planes": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i64p, _i, _vp],
+    "mi_separable3d_f32_supports": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i],
     "mi_correlate_nd": [_arr, _arr, _dp, _i64p, _ip, _i, _d, _i, _vp],
     "mi_minmax1d": [_arr, _arr, _i, _i, _i, _i, _d, _i, _vp],
     "mi_minmax3d_u8": [_arr, _arr, _ip, _ip, _ip, _i, _i, _vp],
@@ -135,6 +136,12 @@ SIGNATURES = {
     "mi_halo_exchange": [_vp, _vp, _sz, ctypes.c_int64, _i, _i, _i, _i, _vp],
     "mi_slab_separable3d_f32": [_vp, _arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i, _i, _i, _i, _i,
                                 _vp, _vp, _vp, _vp],
+    "mi_slab_pipe_create": [ctypes.POINTER(_vp), _vp, _i, ctypes.POINTER(_arr), _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d,
+                            _i, _i, _i, _i, _vp],
+    "mi_slab_pipe_destroy": [_vp],
+    "mi_slab_pipe_step": [_vp, _i, _i],
+    "mi_slab_pipe_run": [_vp, _i, _i],
+    "mi_slab_pipe_info": [_vp, _ip, _ip, _ip],
 }
 _RESTYPES = {"mi_last_error": ctypes.c_char_p}
 

@@ -278,15 +278,7 @@ static int launch_binary3(const unsigned char *in, unsigned char *out, const uns
     }
     p.nxt = (p.nx + 256 * ND - 1) / (256 * ND);
     p.nyt = (p.ny + kBnTY - 1) / kBnTY;
-    int cus = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        static int cached = 0;
-        if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cached = prop.multiProcessorCount;
-        if (cached > 0) cus = cached;
-    }
+    const int cus = device_cus();
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
     const int64_t slots = (int64_t)cus * per_cu, tiles = (int64_t)p.nxt * p.nyt;
     double best = 1e300;

@@ -47,6 +47,7 @@ struct Knob {
 
 // ------------------------------------------------------------------ runtime hooks
 hipStream_t resolve_stream(mi_stream s);   // NULL -> per-device default stream
+int device_cus();                          // compute units of the CURRENT device (cached per device, thread safe)
 // block for work on `stream` (NULL = the default stream); pool_free returns it to that stream's arena
 int pool_alloc(void **p, size_t n, hipStream_t stream);
 int pool_free(void *p);

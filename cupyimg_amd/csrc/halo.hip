@@ -9,7 +9,10 @@
 // group, each crossing one xGMI link; no all-reduce, no global collective.
 #include <rccl/rccl.h>
 
-#include "common.hpp"
+#include <memory>
+
+#include "sep_common.hpp"
+#include "stream3d.hpp"
 
 namespace mi {
 static int nccl_fail(ncclResult_t r, const char *what)
@@ -93,8 +96,16 @@ static constexpr size_t kOverlapMinHaloBytes = (size_t)8 << 20;   // per directi
 /* One filtering step of a slab rank with the exchange hidden behind the
  * interior planes (see include/mi355img.h).  Composition of the two entry
  * points above and mi_separable3d_f32_planes, kept native so that a step costs
- * one host call: at 8 ranks the per-rank kernel time is ~30 us and Python-side
- * marshalling of three calls would dominate it. */
+ * one host call: at 8 ranks the per-rank kernel time is ~25 us and Python-side
+ * marshalling of three calls would dominate it.
+ *
+ * Every refusal happens BEFORE anything is queued, and does not depend on which
+ * rank of the chain asks (r3 advisor finding: a rank without interior planes
+ * used to queue its exchange and only then learn from the edge launch that the
+ * kernel takes no plane ranges, while its neighbours refused up front -- the
+ * send / receive counts of the ranks then no longer paired): the kernels are
+ * asked first (dry run: mi_separable3d_f32_supports), with the request treated
+ * as a partial one whatever the rank's own ranges are. */
 int mi_slab_separable3d_f32(mi_comm comm, const mi_array *ext_in, const mi_array *ext_out,
                             const double *const weights[3], const int wlen[3], const int origin[3],
                             const int mode[3], double cval, int lo, int hi, int prev_rank, int next_rank,
@@ -129,15 +140,22 @@ int mi_slab_separable3d_f32(mi_comm comm, const mi_array *ext_in, const mi_array
     // Overlapping costs two cross-stream waits and a second (small) launch,
     // ~20 us on MI355X; it pays once the exchange itself takes longer than that.
     if (overlap < 0) overlap = (size_t)(lo > hi ? lo : hi) * plane_bytes >= kOverlapMinHaloBytes;
+    // ask the kernels before queuing anything
+    int rc = mi_separable3d_f32_supports(ext_in, ext_out, weights, wlen, origin, mode, cval, 1);
+    if (rc != MI_OK && rc != MI_ERR_UNSUPPORTED) return rc;
+    const bool planes_ok = rc == MI_OK;
+    if (overlap && !planes_ok) return MI_ERR_UNSUPPORTED;       // the caller may fall back to the plain schedule
+    if (!planes_ok) {
+        // kernels that take no plane ranges (streaming passes): they filter the halo planes too, which are scratch
+        rc = mi_separable3d_f32_supports(ext_in, ext_out, weights, wlen, origin, mode, cval, 0);
+        if (rc != MI_OK) return rc;
+    }
     if (!overlap) {
-        int rc = mi_halo_exchange(comm, base, plane_bytes, n_local, lo, hi, prev_rank, next_rank, stream);
+        rc = mi_halo_exchange(comm, base, plane_bytes, n_local, lo, hi, prev_rank, next_rank, stream);
         if (rc != MI_OK) return rc;
         const int64_t all[2] = {a, b};
-        rc = mi_separable3d_f32_planes(ext_in, ext_out, weights, wlen, origin, mode, cval, all, 1, stream);
-        // kernels that take no plane ranges (> 9 taps): filter the halo planes too, they are scratch
-        if (rc == MI_ERR_UNSUPPORTED)
-            rc = mi_separable3d_f32(ext_in, ext_out, weights, wlen, origin, mode, cval, 0, stream);
-        return rc;
+        if (planes_ok) return mi_separable3d_f32_planes(ext_in, ext_out, weights, wlen, origin, mode, cval, all, 1, stream);
+        return mi_separable3d_f32(ext_in, ext_out, weights, wlen, origin, mode, cval, 0, stream);
     }
     MI_REQUIRE(comm_stream && input_free && halos_ready, MI_ERR_INVALID_ARG,
                "comm stream and both events are required for the overlapped schedule");
@@ -150,16 +168,293 @@ int mi_slab_separable3d_f32(mi_comm comm, const mi_array *ext_in, const mi_array
     const bool has_interior = ib < ie;
     if (has_interior) {
         const int64_t interior[2] = {ib, ie};
-        int rc = mi_separable3d_f32_planes(ext_in, ext_out, weights, wlen, origin, mode, cval, interior, 1, stream);
-        if (rc != MI_OK) return rc;        // nothing else queued yet: the caller may fall back
+        rc = mi_separable3d_f32_planes(ext_in, ext_out, weights, wlen, origin, mode, cval, interior, 1, stream);
+        if (rc != MI_OK) return rc;
     }
     MI_HIP(hipStreamWaitEvent(cs, (hipEvent_t)input_free, 0));
-    int rc = mi_halo_exchange(comm, base, plane_bytes, n_local, lo, hi, prev_rank, next_rank, comm_stream);
+    rc = mi_halo_exchange(comm, base, plane_bytes, n_local, lo, hi, prev_rank, next_rank, comm_stream);
     if (rc != MI_OK) return rc;
     MI_HIP(hipEventRecord((hipEvent_t)halos_ready, cs));
     MI_HIP(hipStreamWaitEvent(s, (hipEvent_t)halos_ready, 0));
     const int64_t edges[4] = {a, has_interior ? ib : b, has_interior ? ie : b, b};
     return mi_separable3d_f32_planes(ext_in, ext_out, weights, wlen, origin, mode, cval, edges, 2, stream);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * r4: the PIPELINED slab schedule.  A rank that filters a sequence of volumes (or the same resident volume again and
+ * again, as bench.py does) does not have to finish the halo exchange of volume k + 1 before -- or split its launch
+ * around -- the filter of volume k: with two or three resident input slabs the exchange of the next slab runs on the
+ * comm stream underneath the ONE launch that filters the current slab,
+ *
+ *     comm stream : | X(k+1) ......... | X(k+2) ......... |
+ *     stream      : | filter(k) ...... | filter(k+1) ... |          (X(k+1) must be done before filter(k+1))
+ *
+ * so the exchange has a whole kernel time of slack, the two cross-stream dependencies of a step are satisfied long
+ * before anyone waits on them (nothing ever stalls on the ~9 us an event takes to cross streams on this chip), and the
+ * kernel is the single whole-slab launch of the plain schedule (no extra ramp planes, no second launch).  Steady state:
+ * step time = max(kernel, exchange).  mi_slab_pipe_step(submit, compute) queues "buffer `submit` is final: exchange its
+ * halos" and "filter buffer `compute`"; either may be -1.  mi_slab_pipe_run() rotates over the buffers and can replay
+ * a captured hipGraph of one rotation instead of queuing the 2 + 4 operations of every step one by one. */
+namespace mi {
+constexpr int kPipeMaxBuf = 4;
+struct SlabPipe {
+    ncclComm_t comm = nullptr;
+    int nbuf = 0;
+    mi_array in[kPipeMaxBuf];
+    mi_array out;
+    double w[3][kStreamMaxTaps];
+    const double *wp[3] = {nullptr, nullptr, nullptr};
+    int wlen[3], origin[3], mode[3];
+    double cval = 0.0;
+    int lo = 0, hi = 0, prev = -1, next = -1;
+    int64_t a = 0, b = 0, n_local = 0;      // local planes of the extended slab: [a, b)
+    size_t plane_bytes = 0;
+    bool planes_ok = true;                  // the kernel takes plane ranges (otherwise the halo planes are filtered too)
+    hipStream_t s = nullptr, cs = nullptr;
+    hipEvent_t input_final[kPipeMaxBuf] = {};   // recorded on `s` when a buffer is submitted
+    hipEvent_t halos_ready[kPipeMaxBuf] = {};   // recorded on `cs` after the exchange of a buffer
+    bool submitted[kPipeMaxBuf] = {};
+    int64_t next_submit = 0, next_compute = 0;  // rotation state of mi_slab_pipe_run
+    hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph = nullptr;
+    int graph_steps = 0;
+    int graph_state = 0;                        // 0 = not tried, 1 = usable, -1 = capture failed (direct queuing instead)
+    bool capturing = false;
+    bool captured_submit[kPipeMaxBuf] = {};     // during a capture: the buffer's exchange is part of the graph
+};
+
+static int pipe_submit(SlabPipe *p, int k)
+{
+    MI_REQUIRE(k >= 0 && k < p->nbuf, MI_ERR_INVALID_ARG, "buffer index out of range");
+    if (p->prev < 0 && p->next < 0) { p->submitted[k] = true; return MI_OK; }
+    // everything queued on the compute stream so far: the producers of the buffer's local planes and the last filter
+    // that read its halo planes
+    MI_HIP(hipEventRecord(p->input_final[k], p->s));
+    MI_HIP(hipStreamWaitEvent(p->cs, p->input_final[k], 0));
+    const int lo_p = p->prev >= 0 ? p->lo : 0;
+    char *base = (char *)p->in[k].data - (size_t)(p->lo - lo_p) * p->plane_bytes;
+    int rc = mi_halo_exchange((mi_comm)p->comm, base, p->plane_bytes, p->n_local, p->lo, p->hi, p->prev, p->next, (mi_stream)p->cs);
+    if (rc != MI_OK) return rc;
+    MI_HIP(hipEventRecord(p->halos_ready[k], p->cs));
+    p->submitted[k] = true;
+    p->captured_submit[k] = p->capturing;
+    return MI_OK;
+}
+
+static int pipe_compute(SlabPipe *p, int k)
+{
+    MI_REQUIRE(k >= 0 && k < p->nbuf, MI_ERR_INVALID_ARG, "buffer index out of range");
+    MI_REQUIRE(p->submitted[k], MI_ERR_INVALID_ARG, "the buffer was not submitted (its halos were never exchanged)");
+    // inside a capture only exchanges that belong to the graph become edges; a buffer submitted before the capture
+    // (by the previous replay, which joins the comm stream before it ends) is ordered by the stream itself
+    if ((p->prev >= 0 || p->next >= 0) && (!p->capturing || p->captured_submit[k]))
+        MI_HIP(hipStreamWaitEvent(p->s, p->halos_ready[k], 0));
+    p->submitted[k] = false;
+    const int64_t all[2] = {p->a, p->b};
+    if (p->planes_ok)
+        return mi_separable3d_f32_planes(&p->in[k], &p->out, p->wp, p->wlen, p->origin, p->mode, p->cval, all, 1, (mi_stream)p->s);
+    return mi_separable3d_f32(&p->in[k], &p->out, p->wp, p->wlen, p->origin, p->mode, p->cval, 0, (mi_stream)p->s);
+}
+
+// one step of the rotation: submit the buffer `depth` steps ahead, filter the current one
+static int pipe_rotate_once(SlabPipe *p)
+{
+    const int depth = p->nbuf - 1;
+    int rc;
+    while (p->next_submit <= p->next_compute + depth) {
+        if ((rc = pipe_submit(p, (int)(p->next_submit % p->nbuf)))) return rc;
+        p->next_submit++;
+    }
+    if ((rc = pipe_compute(p, (int)(p->next_compute % p->nbuf)))) return rc;
+    p->next_compute++;
+    return MI_OK;
+}
+
+static void pipe_drop_graph(SlabPipe *p)
+{
+    if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    p->gexec = nullptr;
+    p->graph = nullptr;
+    p->graph_steps = 0;
+}
+
+// Capture `steps` (a multiple of nbuf) steps of the steady-state rotation into a graph.  The rotation must be primed
+// (every buffer ahead submitted) and stays primed: the graph submits as many buffers as it filters.  The comm stream
+// joins the capture through the first submit's event and is joined back before the capture ends (the last exchange
+// of a replay therefore completes inside it -- for two buffers that is the dependency of the next step anyway).
+static void pipe_restore_flags(SlabPipe *p)
+{
+    for (int k = 0; k < p->nbuf; k++) p->submitted[k] = p->captured_submit[k] = false;
+    for (int64_t j = p->next_compute; j < p->next_submit; j++) p->submitted[j % p->nbuf] = true;
+}
+
+static int pipe_capture(SlabPipe *p, int steps)
+{
+    pipe_drop_graph(p);
+    hipError_t e = hipStreamBeginCapture(p->s, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { (void)hipGetLastError(); return MI_ERR_UNSUPPORTED; }
+    int rc = MI_OK;
+    const int64_t ns = p->next_submit, nc = p->next_compute;
+    p->capturing = true;
+    for (int k = 0; k < p->nbuf; k++) p->captured_submit[k] = false;
+    for (int i = 0; i < steps && rc == MI_OK; i++) rc = pipe_rotate_once(p);
+    if (rc == MI_OK && (p->prev >= 0 || p->next >= 0)) {
+        // join the comm stream: wait for the exchange submitted last
+        const int last = (int)((p->next_submit - 1) % p->nbuf);
+        if (hipStreamWaitEvent(p->s, p->halos_ready[last], 0) != hipSuccess) rc = MI_ERR_UNSUPPORTED;
+    }
+    p->capturing = false;
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(p->s, &g);
+    // the captured calls did not run: the rotation state is what it was
+    p->next_submit = ns;
+    p->next_compute = nc;
+    pipe_restore_flags(p);
+    if (rc != MI_OK || e != hipSuccess || !g) {
+        (void)hipGetLastError();
+        if (g) (void)hipGraphDestroy(g);
+        return MI_ERR_UNSUPPORTED;
+    }
+    hipGraphExec_t ge = nullptr;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (e != hipSuccess || !ge) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(g);
+        return MI_ERR_UNSUPPORTED;
+    }
+    p->graph = g;
+    p->gexec = ge;
+    p->graph_steps = steps;
+    return MI_OK;
+}
+}  // namespace mi
+
+int mi_slab_pipe_create(mi_slab_pipe *pipe, mi_comm comm, int nbuf, const mi_array *const ext_in[], const mi_array *ext_out,
+                        const double *const weights[3], const int wlen[3], const int origin[3], const int mode[3],
+                        double cval, int lo, int hi, int prev_rank, int next_rank, mi_stream stream)
+{
+    MI_REQUIRE(pipe && ext_in && ext_out && weights && wlen && origin && mode, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(nbuf >= 1 && nbuf <= kPipeMaxBuf, MI_ERR_INVALID_ARG, "1 .. 4 input slabs");
+    MI_REQUIRE(lo >= 0 && hi >= 0, MI_ERR_INVALID_ARG, "negative halo");
+    *pipe = nullptr;
+    const bool has_prev = prev_rank >= 0, has_next = next_rank >= 0;
+    MI_REQUIRE(comm || (!has_prev && !has_next), MI_ERR_INVALID_ARG, "a communicator is required when a neighbour exists");
+    std::unique_ptr<SlabPipe> p(new SlabPipe);
+    p->comm = (ncclComm_t)comm;
+    p->nbuf = nbuf;
+    for (int k = 0; k < nbuf; k++) {
+        MI_REQUIRE(ext_in[k] && ext_in[k]->ndim == 3, MI_ERR_INVALID_ARG, "slabs are 3-D");
+        MI_REQUIRE(same_shape(ext_in[k], ext_out), MI_ERR_INVALID_ARG, "input and output slabs differ in shape");
+        p->in[k] = *ext_in[k];
+    }
+    p->out = *ext_out;
+    for (int ax = 0; ax < 3; ax++) {
+        p->wlen[ax] = weights[ax] ? wlen[ax] : 0;
+        p->origin[ax] = origin[ax];
+        p->mode[ax] = mode[ax];
+        if (weights[ax]) {
+            MI_REQUIRE(wlen[ax] >= 1 && wlen[ax] <= kStreamMaxTaps, MI_ERR_UNSUPPORTED, "at most 33 taps per axis");
+            memcpy(p->w[ax], weights[ax], sizeof(double) * (size_t)wlen[ax]);
+            p->wp[ax] = p->w[ax];
+        }
+    }
+    p->cval = cval;
+    p->lo = lo; p->hi = hi; p->prev = prev_rank; p->next = next_rank;
+    const int64_t lo_p = has_prev ? lo : 0, hi_p = has_next ? hi : 0;
+    p->n_local = ext_out->shape[0] - lo_p - hi_p;
+    MI_REQUIRE(p->n_local >= 1 && p->n_local >= lo && p->n_local >= hi, MI_ERR_INVALID_ARG,
+               "slab is thinner than the halo it has to provide");
+    if (weights[0] && wlen[0] > 1) {
+        const int need_lo = wlen[0] / 2 + origin[0], need_hi = wlen[0] - 1 - need_lo;
+        MI_REQUIRE(need_lo >= 0 && need_hi >= 0, MI_ERR_INVALID_ARG, "invalid origin");
+        MI_REQUIRE((!has_prev || need_lo <= lo) && (!has_next || need_hi <= hi), MI_ERR_INVALID_ARG,
+                   "the axis-0 kernel reaches beyond the halo of the slab plan");
+    }
+    p->a = lo_p;
+    p->b = lo_p + p->n_local;
+    p->plane_bytes = (size_t)ext_out->strides[0];
+    int rc = mi_separable3d_f32_supports(&p->in[0], &p->out, p->wp, p->wlen, p->origin, p->mode, cval, 1);
+    if (rc != MI_OK && rc != MI_ERR_UNSUPPORTED) return rc;
+    p->planes_ok = rc == MI_OK;
+    if (!p->planes_ok && (rc = mi_separable3d_f32_supports(&p->in[0], &p->out, p->wp, p->wlen, p->origin, p->mode, cval, 0))) return rc;
+    p->s = resolve_stream(stream);
+    // the exchange kernels are small and have a step of slack: a high-priority queue lets them take the first CU a
+    // retiring filter workgroup frees instead of queuing behind the next filter launch
+    int pri_lo = 0, pri_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&pri_lo, &pri_hi);
+    MI_HIP(hipStreamCreateWithPriority(&p->cs, hipStreamNonBlocking, pri_hi));
+    for (int k = 0; k < nbuf; k++) {
+        MI_HIP(hipEventCreateWithFlags(&p->input_final[k], hipEventDisableTiming));
+        MI_HIP(hipEventCreateWithFlags(&p->halos_ready[k], hipEventDisableTiming));
+    }
+    *pipe = (mi_slab_pipe)p.release();
+    return MI_OK;
+}
+
+int mi_slab_pipe_destroy(mi_slab_pipe pipe)
+{
+    SlabPipe *p = (SlabPipe *)pipe;
+    if (!p) return MI_OK;
+    if (p->s) (void)hipStreamSynchronize(p->s);
+    if (p->cs) (void)hipStreamSynchronize(p->cs);
+    pipe_drop_graph(p);
+    for (int k = 0; k < p->nbuf; k++) {
+        if (p->input_final[k]) (void)hipEventDestroy(p->input_final[k]);
+        if (p->halos_ready[k]) (void)hipEventDestroy(p->halos_ready[k]);
+    }
+    if (p->cs) (void)hipStreamDestroy(p->cs);
+    delete p;
+    return MI_OK;
+}
+
+int mi_slab_pipe_step(mi_slab_pipe pipe, int submit, int compute)
+{
+    SlabPipe *p = (SlabPipe *)pipe;
+    MI_REQUIRE(p, MI_ERR_INVALID_ARG, "pipe is NULL");
+    int rc;
+    if (submit >= 0 && (rc = pipe_submit(p, submit))) return rc;
+    if (compute >= 0 && (rc = pipe_compute(p, compute))) return rc;
+    return MI_OK;
+}
+
+int mi_slab_pipe_run(mi_slab_pipe pipe, int nsteps, int use_graph)
+{
+    SlabPipe *p = (SlabPipe *)pipe;
+    MI_REQUIRE(p && nsteps >= 0, MI_ERR_INVALID_ARG, "bad argument");
+    int rc;
+    int done = 0;
+    if (use_graph > 0 && p->graph_state >= 0) {
+        const int per = use_graph > p->nbuf ? (use_graph / p->nbuf) * p->nbuf : p->nbuf;     // steps per replay
+        // one whole rotation queued directly first (RCCL sets up its connections lazily, the filter sets function
+        // attributes on its first launch), then up to a rotation boundary: the graph starts at buffer 0
+        while (done < nsteps && (p->next_compute < p->nbuf || p->next_compute % p->nbuf != 0)) {
+            if ((rc = pipe_rotate_once(p))) return rc;
+            done++;
+        }
+        if (nsteps - done >= per) {
+            if (p->graph_state == 0 || p->graph_steps != per) p->graph_state = pipe_capture(p, per) == MI_OK ? 1 : -1;
+            while (p->graph_state == 1 && nsteps - done >= per) {
+                MI_HIP(hipGraphLaunch(p->gexec, p->s));
+                p->next_submit += per;
+                p->next_compute += per;
+                done += per;
+            }
+        }
+    }
+    for (; done < nsteps; done++)
+        if ((rc = pipe_rotate_once(p))) return rc;
+    return MI_OK;
+}
+
+int mi_slab_pipe_info(mi_slab_pipe pipe, int *graph_state, int *graph_steps, int *planes_ok)
+{
+    SlabPipe *p = (SlabPipe *)pipe;
+    MI_REQUIRE(p, MI_ERR_INVALID_ARG, "pipe is NULL");
+    if (graph_state) *graph_state = p->graph_state;
+    if (graph_steps) *graph_steps = p->graph_steps;
+    if (planes_ok) *planes_ok = p->planes_ok ? 1 : 0;
+    return MI_OK;
 }
 
 }  // extern "C"

@@ -174,8 +174,14 @@ rank3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Geom3
 // than kMaxRankTaps samples, volumes beyond the 32-bit geometry): the window of a voxel is gathered into a scratch
 // column in device memory (element t of thread q at scratch[t * nthreads + q]: neighbouring threads touch
 // neighbouring addresses) and shell-sorted there, the counterpart of the reference's per-thread shell sort
-// (cupyimg/scipy/ndimage/filters.py:1753-1768, 1829-1835), which has no size limit either.  Values stay in the input
-// dtype (exact for 64-bit integers).  A correctness path: ~n log^2 n scratch accesses per voxel.
+// (cupyimg/scipy/ndimage/filters.py:1753-1768, 1829-1835), which has no size limit either.  The window is sorted in
+// the input dtype and the selected element is stored THROUGH double, on purpose: SciPy's NI_RankFilter (the parity
+// oracle, ni_filters.c) gathers the window into a double buffer and casts the selected double back, so 64-bit
+// integers beyond 2^53 come back rounded there, and rounding is monotonic -- the rank-th smallest of the rounded
+// samples is the rounded rank-th smallest -- so this kernel and rank3_kernel (double samples) agree with SciPy bit for
+// bit; the reference's native-dtype sort would differ from SciPy in exactly those elements (r3 advisor finding:
+// answered by keeping SciPy's behaviour; tests/test_gpu_vs_oracle.py::test_rank_filter_int64_beyond_2p53_follows_scipy).
+// A correctness path: ~n log^2 n scratch accesses per voxel.
 template <typename T, int ND>
 __global__ void __launch_bounds__(256)
 rank_nd_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, NdGeom g, TapTable tt, int64_t total, int mode,

@@ -200,17 +200,7 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-static int mm_long_cus()
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static int mm_long_cus() { return device_cus(); }
 
 template <int W, bool IS_MAX>
 static int launch_mm_long(const float *in, float *out, MmLongParams &p, hipStream_t s)

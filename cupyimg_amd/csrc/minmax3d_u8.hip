@@ -1344,16 +1344,7 @@ static int launch_u8_split(const uint8_t *in, uint8_t *out, U8FusedParams &p, bo
     }
     p.nxt = (p.nx + 511) / 512;
     p.nyt = (p.ny + TY - 1) / TY;
-    int cus = 256;
-    {
-        static int cached = 0;
-        if (!cached) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount;
-        }
-        if (cached > 0) cus = cached;
-    }
+    const int cus = device_cus();
     const int64_t tiles = (int64_t)p.nxt * p.nyt;
     double best = 1e300;
     int best_nzc = 1;

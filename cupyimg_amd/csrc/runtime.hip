@@ -4,6 +4,7 @@
 // cupyimg/__init__.py:23-28, _util.py:80) rebuilt as a thin HIP layer.
 #include <stdarg.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -53,6 +54,23 @@ hipStream_t resolve_stream(mi_stream s)
     hipStream_t d = nullptr;
     if (default_stream(&d) != MI_OK) return nullptr;   // falls back to the null stream
     return d;
+}
+
+// Compute units of the current device.  One entry per device: a process may drive differently partitioned devices
+// (SPX / CPX), and several threads may ask at once (relaxed atomics: every writer stores the same value).
+int device_cus()
+{
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        hipDeviceProp_t prop;
+        n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+        if (n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 // ------------------------------------------------------------------ pool

@@ -1014,17 +1014,7 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
     }
 }
 
-static int long_cus()
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static int long_cus() { return device_cus(); }
 
 // (in-plane taps, z taps) pairs the r3 kernel is instantiated for besides the cubic ones: volumes with anisotropic
 // voxels, where a gaussian given in millimetres has fewer taps through the slices (each pair is one more kernel to
@@ -1058,6 +1048,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, i
     const bool has_const = mx == MI_MODE_CONSTANT || my == MI_MODE_CONSTANT || mz == MI_MODE_CONSTANT;
     if (wzn != w && (has_const || !long_aniso_pair(w, wzn))) return MI_ERR_UNSUPPORTED;
     if ((int64_t)ny * nx * 4 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
+    if (t_dry_run) return MI_OK;          // every odd (w, w) in 3 .. 17 and every pair of long_aniso_pair() has an instance
     LongParams p;
     memset(&p, 0, sizeof(p));
     p.nx = nx; p.ny = ny; p.nz = nz;

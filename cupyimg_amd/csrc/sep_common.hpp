@@ -10,6 +10,17 @@ constexpr int kMaxTaps = 9;
 // the kernel it timed from this, not from a literal)
 void note_kernel(const char *fmt, ...);
 
+// Dry run (per host thread): separable3d_impl and run_sep3d_long walk their whole decision tree and return MI_OK where
+// they would launch, MI_ERR_UNSUPPORTED / MI_ERR_INVALID_ARG where they would refuse -- nothing is queued.  A request
+// that names plane ranges is treated as a partial one even when the ranges happen to cover the array, so that the
+// answer does not depend on which rank of a slab chain asks (mi_separable3d_f32_supports, mi_slab_separable3d_f32).
+extern thread_local bool t_dry_run;
+struct DryRun {
+    bool saved;
+    DryRun() : saved(t_dry_run) { t_dry_run = true; }
+    ~DryRun() { t_dry_run = saved; }
+};
+
 struct Sep3dParams {
     int nx, ny, nz;
     int wy;                 // taps along y (run-time loop)

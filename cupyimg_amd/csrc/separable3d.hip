@@ -40,6 +40,7 @@
 
 namespace mi {
 
+thread_local bool t_dry_run = false;
 static thread_local char t_last_kernel[160] = "";
 void note_kernel(const char *fmt, ...)
 {
@@ -692,19 +693,6 @@ bool long_aniso_pair(int w, int wzn);                     // sep3d_long.hip: (in
 // costs (chunk + w - 1) plane steps of (rows + fixed) row-units each.  Big
 // tiles (fewer halo rows) win on large volumes, small tiles keep every CU
 // busy on thin slabs (multi-GPU) and odd shapes.
-static int device_cus()
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
 static void choose_plan(int w, const int *cand_rows, const int *cand_cfg, int ncand, int wy, int64_t nz, int64_t ny,
                         int64_t nx, int *best_cfg, int *best_rows, int *best_nzc)
 {
@@ -823,7 +811,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
         }
         if (k == 0) return MI_OK;
     }
-    const bool whole = zb[0] == 0 && zn[0] == nz;
+    const bool whole = !(t_dry_run && planes) && zb[0] == 0 && zn[0] == nz;
     const int64_t nzr = zn[0] + zn[1];
 
     const bool cubic_w = w[0] == w[1] && w[1] == w[2];
@@ -876,6 +864,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
             const int64_t tail = nx & 255;
             if (w[2] > 1 && (nx < 4 * nb + 4 || (tail != 0 && tail < 4 * nb + 4))) UNSUP("x extent unsuitable for the streaming x pass");
         }
+        if (t_dry_run) return MI_OK;
         hipStream_t s = resolve_stream(stream);
         const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
         struct Pass { int axis, wa, oa, ma, wx; };
@@ -944,6 +933,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     p.nzc0 = (int)((zn[0] + p.zc - 1) / p.zc);
     p.nzc = p.nzc0 + (int)((zn[1] + p.zc - 1) / p.zc);
 
+    if (t_dry_run) return MI_OK;
     hipStream_t s = resolve_stream(stream);
     const float *ip = (const float *)in->data;
     float *op = (float *)out->data;
@@ -973,6 +963,16 @@ extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const
 {
     (void)is_box;
     return separable3d_impl(in, out, weights, wlen, origin, mode, cval, nullptr, 0, stream);
+}
+
+extern "C" int mi_separable3d_f32_supports(const mi_array *in, const mi_array *out, const double *const weights[3],
+                                           const int wlen[3], const int origin[3], const int mode[3], double cval,
+                                           int plane_ranges)
+{
+    mi::DryRun dry;
+    const int64_t some[2] = {0, in && in->ndim == 3 ? in->shape[0] : 0};
+    return separable3d_impl(in, out, weights, wlen, origin, mode, cval, plane_ranges ? some : nullptr, plane_ranges ? 1 : 0,
+                            nullptr);
 }
 
 extern "C" int mi_separable3d_f32_planes(const mi_array *in, const mi_array *out, const double *const weights[3],

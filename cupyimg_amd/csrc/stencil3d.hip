@@ -285,18 +285,7 @@ stencil3_kernel(const T *__restrict__ in, T *__restrict__ out, const Stencil3Par
     }
 }
 
-static int stencil_cus()
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static int stencil_cus() { return device_cus(); }
 
 template <int WX, int TY, typename Acc, bool DENSE, int OP = ST_CORR, typename T = float>
 static int launch_stencil3(const T *in, T *out, Stencil3Params &p, hipStream_t s)

@@ -20,6 +20,15 @@ in the unsplit volume.  ``wrap`` closes the chain (rank 0 <-> rank P-1).
 
 `SlabPlan` is pure host logic (tested on CPU with a gloo world of 2);
 `HaloComm` is the RCCL transport behind the C-ABI.
+
+Three schedules of a step (exchange + filter), all bit-identical in their result:
+
+    plain       exchange, then one launch over the local planes, one stream
+    overlapped  interior planes while the exchange is in flight, edge planes afterwards (two launches, two
+                cross-stream waits on the critical path: pays for large halos when every step depends on the last)
+    pipelined   `SlabPipeline` (r4): two or three resident input slabs, the exchange of the NEXT input underneath the
+                single launch of the current one -- for sequences of independent volumes (and benchmarks that filter
+                a resident volume repeatedly); step time = max(kernel, exchange)
 """
 import ctypes
 
@@ -61,6 +70,23 @@ class SlabPlan:
         self.lo_present = self.lo if self.prev >= 0 else 0
         self.hi_present = self.hi if self.next >= 0 else 0
         self.n_ext = self.lo_present + self.n_local + self.hi_present
+
+    @classmethod
+    def self_loop(cls, nz, lo, hi):
+        """Plan of a closed chain of ONE rank that is both neighbours of itself (a one-rank communicator): the halos
+        are the periodic continuation of the rank's own planes, i.e. `wrap` along axis 0.  What single-GPU tests and
+        `bench.py --self-loop` run the whole multi-rank code path on -- exchange, schedules, pipeline."""
+        plan = cls.__new__(cls)
+        plan.nz, plan.nranks, plan.rank = int(nz), 2, 0          # nranks > 1 selects the exchange path
+        plan.lo, plan.hi, plan.wrap = int(lo), int(hi), True
+        if nz < max(lo, hi, 1):
+            raise ValueError("slab thinner than the halo")
+        plan.z0, plan.z1, plan.n_local = 0, plan.nz, plan.nz
+        plan.counts = [plan.nz]
+        plan.prev = plan.next = 0
+        plan.lo_present, plan.hi_present = plan.lo, plan.hi
+        plan.n_ext = plan.lo + plan.nz + plan.hi
+        return plan
 
     # indices into the extended buffer
     @property
@@ -155,6 +181,136 @@ class HaloComm:
             pass
 
 
+class SlabPipeline:
+    """The pipelined schedule (r4, `mi_slab_pipe_*`): `nbuf` resident input slabs, ONE whole-slab launch per step, the
+    halo exchange of the next input on a high-priority comm stream underneath it.
+
+        comm stream : | X(k+1) ......... | X(k+2) ......... |
+        stream      : | filter(k) ...... | filter(k+1) ... |
+
+    For sequences of independent volumes: write the local planes of input j (`local_in(j)`), `submit(j)` -- its halo
+    exchange is queued behind everything written so far -- and later `compute(j)`; `run(n)` rotates over resident
+    inputs (benchmarks, repeated filtering).  Results are bit-identical to the plain schedule: the same kernel on the
+    same extended slab.  Created by `SlabFilter.pipeline(...)` / `.uniform_pipeline` / `.gaussian_pipeline`."""
+
+    def __init__(self, plan, comm, ext_ins, ext_out, weights, modes, cval, origins):
+        from .scipy.ndimage import _support as S
+        self.plan, self.comm = plan, comm
+        self.inputs, self.ext_out = list(ext_ins), ext_out
+        if weights[0] is not None and len(weights[0]) > 1:
+            plan.check_reach(len(weights[0]), origins[0])
+        modes = S.normalize_sequence(modes, 3)
+        for m in modes:
+            S.check_mode(m)
+        keep = [None if w is None else np.ascontiguousarray(w, dtype=np.float64) for w in weights]
+        dp = ctypes.POINTER(ctypes.c_double)
+        ptrs = (dp * 3)(*[ctypes.cast(None, dp) if w is None else w.ctypes.data_as(dp) for w in keep])
+        descs = [a._desc() for a in self.inputs]
+        arr_p = ctypes.POINTER(_lib.MiArray)
+        in_ptrs = (arr_p * len(descs))(*[ctypes.pointer(d) for d in descs])
+        out_desc = ext_out._desc()
+        self._pipe = ctypes.c_void_p()
+        _lib.check(_lib.load().mi_slab_pipe_create(
+            ctypes.byref(self._pipe), comm._comm if comm is not None else None, len(descs), in_ptrs, ctypes.byref(out_desc),
+            ptrs, S.c_ints([0 if w is None else len(w) for w in keep]), S.c_ints(origins),
+            S.c_ints([S.mode_code(m) for m in modes]), float(cval), plan.lo, plan.hi, plan.prev, plan.next, None))
+        self.nbuf = len(descs)
+        # for `measure` (the same launch without the pipe); also keeps the host buffers alive
+        self._kernel_args = (ptrs, S.c_ints([0 if w is None else len(w) for w in keep]), S.c_ints(origins),
+                             S.c_ints([S.mode_code(m) for m in modes]), float(cval))
+        self._keep = (keep, descs, out_desc)
+
+    def local_in(self, k):
+        return self.inputs[k][self.plan.local_slice]
+
+    @property
+    def local_out(self):
+        return self.ext_out[self.plan.local_slice]
+
+    def submit(self, k):
+        """Input k is final (as of everything queued on the default stream so far): exchange its halos."""
+        _lib.check(_lib.load().mi_slab_pipe_step(self._pipe, int(k), -1))
+
+    def compute(self, k):
+        """Filter input k (submitted before) into the output slab; returns this rank's output planes."""
+        _lib.check(_lib.load().mi_slab_pipe_step(self._pipe, -1, int(k)))
+        return self.local_out
+
+    def step(self, submit, compute):
+        """`submit(submit)` then `compute(compute)` in ONE native call (the steady-state step: submit the input
+        nbuf - 1 steps ahead, filter the current one)."""
+        _lib.check(_lib.load().mi_slab_pipe_step(self._pipe, int(submit), int(compute)))
+        return self.local_out
+
+    def run(self, nsteps, graph=0):
+        """`nsteps` steps of the rotation over the resident inputs; graph > 0: replay a captured hipGraph of one
+        rotation (graph = 1) or of `graph` steps where the capture works (`info()`), direct queuing otherwise."""
+        _lib.check(_lib.load().mi_slab_pipe_run(self._pipe, int(nsteps), int(graph)))
+        return self.local_out
+
+    def info(self):
+        g, n, pk = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().mi_slab_pipe_info(self._pipe, ctypes.byref(g), ctypes.byref(n), ctypes.byref(pk)))
+        return {"graph_state": g.value, "graph_steps": n.value, "planes_ok": bool(pk.value), "nbuf": self.nbuf}
+
+    def measure(self, reps=20):
+        """(kernel_us, exchange_us) of this rank: the filter launch alone and the RCCL exchange alone, each the
+        average of `reps` back-to-back repetitions on the default stream (HIP events); exchange_us is None without
+        neighbours.  Collective (it exchanges halos): every rank must call it, with the pipeline idle.  bench.py
+        prints both for every rank."""
+        core.synchronize()
+        k_us = self._kernel_only_us(reps)
+        ex_us = None
+        if self.comm is not None and self.plan.nranks > 1:
+            for _ in range(2):
+                self.comm.exchange(self.inputs[0], self.plan)
+            e0, e1 = core.Event(), core.Event()
+            e0.record()
+            for _ in range(reps):
+                self.comm.exchange(self.inputs[0], self.plan)
+            e1.record()
+            e1.synchronize()
+            ex_us = e0.elapsed_ms(e1) / reps * 1e3
+        core.synchronize()
+        return k_us, ex_us
+
+    def _kernel_only_us(self, reps):
+        from . import _lib as L
+        lib = L.load()
+        plan = self.plan
+        a = plan.lo_present
+        planes = (ctypes.c_int64 * 2)(a, a + plan.n_local)
+        info = self.info()
+        d_in, d_out = self.inputs[0]._desc(), self.ext_out._desc()
+        args = self._kernel_args
+        e0, e1 = core.Event(), core.Event()
+
+        def launch():
+            if info["planes_ok"]:
+                L.check(lib.mi_separable3d_f32_planes(ctypes.byref(d_in), ctypes.byref(d_out), *args, planes, 1, None))
+            else:
+                L.check(lib.mi_separable3d_f32(ctypes.byref(d_in), ctypes.byref(d_out), *args, 0, None))
+        for _ in range(3):
+            launch()
+        e0.record()
+        for _ in range(reps):
+            launch()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_ms(e1) / reps * 1e3
+
+    def close(self):
+        if getattr(self, "_pipe", None):
+            _lib.load().mi_slab_pipe_destroy(self._pipe)
+            self._pipe = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SlabFilter:
     """Runs ``fn(ext_in, ext_out)`` (any filter of this package, output given)
     on a rank's extended slab after a halo exchange.
@@ -170,14 +326,18 @@ class SlabFilter:
     exchange, and they are filtered in one small launch afterwards.
     """
 
-    def __init__(self, plan, plane_shape, dtype, comm=None):
+    def __init__(self, plan, plane_shape, dtype, comm=None, reduce_max=None):
+        """`reduce_max(list_of_floats) -> list_of_floats` (optional): element-wise maximum over the ranks (e.g. an
+        all-reduce on the host); with it the measured schedule choice is agreed by all ranks from the slowest rank's
+        timings instead of being taken by every rank on its own."""
         self.plan, self.comm = plan, comm
+        self.reduce_max = reduce_max
         self.ext_in = core.empty((plan.n_ext,) + tuple(plane_shape), dtype)
         self.ext_out = core.empty((plan.n_ext,) + tuple(plane_shape), dtype)
         self._comm_stream = None
         self._halos_ready = None      # exchange finished (recorded on the comm stream)
         self._input_free = None       # previous readers of ext_in finished (default stream)
-        self._overlap_ok = True
+        self._overlap_refused = set() # filters (keys) whose kernels take no plane ranges: plain schedule, not re-probed
         self._prepared = {}
         self._native_refused = set()  # filters mi_slab_separable3d_f32 answered UNSUPPORTED for (generic step instead)
         self._tuning = {}             # per filter: schedule measurements / choice (see _tuned_schedule)
@@ -206,17 +366,18 @@ class SlabFilter:
         fn(self.ext_in, self.ext_out)
         return self.local_out
 
-    def step_overlapped(self, fn):
+    def step_overlapped(self, fn, key=None):
         """Same result as `step` for the local planes, with the exchange
-        overlapped with the interior filtering.  `fn` must be a fused separable
-        filter call (uniform_filter / gaussian_filter / correlate1d chains on
-        3-D float32); anything else falls back to `step`."""
+        overlapped with the interior filtering.  `fn` must honour
+        `_support.output_planes` (the fused separable and min / max kernels do);
+        anything else raises Unsupported on its first plane-restricted call and the
+        step finishes on the plain schedule -- whichever launch refused, interior or
+        edge, on every rank alike: exactly one exchange has been queued by then, and
+        the refusal is remembered per filter (`key`), not for the whole SlabFilter."""
         from .scipy.ndimage import _support as S
-        if self.comm is None or self.plan.nranks == 1 or not self._overlap_ok:
+        if self.comm is None or self.plan.nranks == 1 or key in self._overlap_refused:
             return self.step(fn)
-        if self._comm_stream is None:
-            self._comm_stream = core.Stream()
-            self._halos_ready, self._input_free = core.Event(), core.Event()
+        self._streams()
         interior, edges = self.plan.plane_ranges()
         # the exchange overwrites the halo planes: it has to wait for whatever
         # was queued on the default stream so far (producers of the local
@@ -229,13 +390,12 @@ class SlabFilter:
             if interior:
                 with S.output_planes(interior):
                     fn(self.ext_in, self.ext_out)
-        except S.Unsupported:
-            self._overlap_ok = False
             core.default_stream_wait_event(self._halos_ready)
-            fn(self.ext_in, self.ext_out)
-            return self.local_out
-        core.default_stream_wait_event(self._halos_ready)
-        with S.output_planes(edges):
+            with S.output_planes(edges):
+                fn(self.ext_in, self.ext_out)
+        except S.Unsupported:
+            self._overlap_refused.add(key)
+            core.default_stream_wait_event(self._halos_ready)
             fn(self.ext_in, self.ext_out)
         return self.local_out
 
@@ -296,48 +456,48 @@ class SlabFilter:
             return self.step(fallback)
         return self.local_out
 
-    def _tuned_schedule(self, key, args, samples=3):
+    def _tuned_schedule(self, key, args, samples=3, burst=10):
         """Plain or overlapped schedule for this filter, measured instead of guessed: whether hiding the exchange
         behind the interior planes pays depends on the link (xGMI latency and bandwidth for THIS halo size) and on
         the cost of the cross-stream waits, and neither can be known from a one-GPU box.  The FIRST call of a filter
-        tunes: one warm step of each schedule, then `samples` timed steps of each, alternating (HIP events on the
-        default stream, host-synchronised -- which is why all of it happens inside that one call, `warm()`, and never
-        inside a later step); the medians decide.  Every probe performs exactly one exchange -- also when the
-        overlapped form is refused (kernels that take no plane ranges: the refusal comes before anything is queued,
-        and the plain step runs in its place) -- so ranks that decide differently still pair their sends and receives.
-        Returns the flag for mi_slab_separable3d_f32."""
+        tunes (`warm()`; never inside a later step): one warm step of each schedule, then `samples` bursts of `burst`
+        back-to-back steps of each, alternating, ONE host synchronisation per burst -- what a caller that issues steps
+        back to back sees (r3 timed single steps with a host sync after each, i.e. latency: in the plain schedule the
+        exchange of step k + 1 queues behind kernel k on one stream, in the overlapped one it runs under it).
+        With `reduce_max` the per-schedule medians are maximised over the ranks before the choice, so every rank takes
+        the SAME schedule, the one that is faster for the slowest rank; without it each rank decides alone (still
+        correct: every step performs exactly one exchange whatever the schedule).  Whether the overlapped form exists
+        is asked up front (mi_separable3d_f32_supports: same answer on every rank), so no probe ever queues an
+        exchange and then refuses.  Returns the flag for mi_slab_separable3d_f32."""
         st = self._tuning.get(key)
         if st is not None:
             return st["choice"]
         lib = _lib.load()
-        st = {"t": [[], []], "overlap_supported": True}
+        overlap_supported = lib.mi_separable3d_f32_supports(args[1], args[2], args[3], args[4], args[5], args[6], args[7], 1) == _lib.MI_OK
+        st = {"t": [[], []], "overlap_supported": overlap_supported, "burst": int(burst)}
+        flags = (0, 1) if overlap_supported else (0,)
 
-        def probe(flag):
-            if flag == 1 and not st["overlap_supported"]:
-                flag = 0
-            try:
+        def run(flag, n):
+            for _ in range(n):
                 _lib.check(lib.mi_slab_separable3d_f32(*args[:12], flag, *args[13:]))
-            except _lib.Unsupported:
-                if flag == 0:
-                    raise                         # not even the plain schedule: the caller falls back
-                st["overlap_supported"] = False
-                _lib.check(lib.mi_slab_separable3d_f32(*args[:12], 0, *args[13:]))
-            return flag
 
-        probe(0)
-        probe(1)
+        for flag in flags:
+            run(flag, 2)
         e0, e1 = core.Event(), core.Event()
         for _ in range(max(int(samples), 1)):
-            for flag in (0, 1):
+            for flag in flags:
                 e0.record()
-                used = probe(flag)
+                run(flag, st["burst"])
                 e1.record()
                 e1.synchronize()
-                if used == flag:
-                    st["t"][flag].append(e0.elapsed_ms(e1))
-        med = [float(np.median(t)) if t else float("inf") for t in st["t"]]
-        st["median_ms"] = med
-        st["choice"] = 1 if st["overlap_supported"] and med[1] < 0.97 * med[0] else 0
+                st["t"][flag].append(e0.elapsed_ms(e1) / st["burst"])
+        med = [float(np.median(t)) if t else 1e30 for t in st["t"]]
+        st["median_ms_local"] = list(med)
+        if self.reduce_max is not None:
+            med = [float(v) for v in self.reduce_max(med)]
+            st["agreed"] = True
+        st["median_ms"] = [None if v >= 1e30 else v for v in med]
+        st["choice"] = 1 if overlap_supported and med[1] < 0.97 * med[0] else 0
         self._tuning[key] = st
         return st["choice"]
 
@@ -354,8 +514,9 @@ class SlabFilter:
         with `key_prefix` (e.g. "uniform"), or None -- what bench.py prints as the partition label."""
         for k, st in self._tuning.items():
             if isinstance(k, tuple) and k and k[0] == key_prefix:
-                return {"choice": st["choice"], "median_ms": st.get("median_ms"),
-                        "overlap_supported": st["overlap_supported"]}
+                return {"choice": st["choice"], "median_ms": st.get("median_ms"), "median_ms_local": st.get("median_ms_local"),
+                        "overlap_supported": st["overlap_supported"], "agreed_across_ranks": bool(st.get("agreed")),
+                        "burst": st.get("burst")}
         return None
 
     def uniform_filter(self, size, mode="reflect", cval=0.0, overlap=None):
@@ -384,6 +545,34 @@ class SlabFilter:
                               fallback=lambda a, b: ndi.gaussian_filter(a, sigma, order=order, mode=mode, cval=cval,
                                                                         truncate=truncate, output=b))
 
+    # ---------------------------------------------------------------- pipelined schedule
+    def pipeline(self, weights, modes="reflect", cval=0.0, origins=(0, 0, 0), nbuf=2):
+        """`SlabPipeline` of a separable filter over `nbuf` resident input slabs (the first is this filter's `ext_in`,
+        the others are allocated here) writing `ext_out`.  Raises Unsupported when no fused / streaming float32 kernel
+        takes the request (callers then use `step`)."""
+        if self.ext_in.dtype != np.float32:
+            raise _lib.Unsupported("the pipelined schedule exists for the float32 separable filters")
+        nbuf = int(nbuf)
+        if not 1 <= nbuf <= 4:
+            raise ValueError("nbuf must be 1 .. 4")
+        ins = [self.ext_in] + [core.empty(self.ext_in.shape, self.ext_in.dtype) for _ in range(nbuf - 1)]
+        return SlabPipeline(self.plan, self.comm, ins, self.ext_out, weights, modes, cval, origins)
+
+    def uniform_pipeline(self, size, mode="reflect", cval=0.0, nbuf=2):
+        """Pipelined `uniform_filter(size)` of a sequence of distributed volumes."""
+        from .scipy.ndimage import _support as S
+        sizes = [int(v) for v in S.normalize_sequence(size, 3)]
+        weights = [np.full((sz,), 1.0 / sz) if sz > 1 else None for sz in sizes]
+        return self.pipeline(weights, mode, cval, nbuf=nbuf)
+
+    def gaussian_pipeline(self, sigma, order=0, mode="reflect", cval=0.0, truncate=4.0, nbuf=2):
+        """Pipelined `gaussian_filter(sigma)` of a sequence of distributed volumes."""
+        from .scipy.ndimage import _support as S
+        from .scipy.ndimage.filters import _gaussian_weights
+        sigmas, orders = S.normalize_sequence(sigma, 3), S.normalize_sequence(order, 3)
+        weights = [_gaussian_weights(sg, od, truncate) if sg > 1e-15 else None for sg, od in zip(sigmas, orders)]
+        return self.pipeline(weights, mode, cval, nbuf=nbuf)
+
     # ---------------------------------------------------------------- filters on the plain schedule
     # Everything below runs `step(fn)` by default: one exchange, then the package's own single-GPU kernel on the extended
     # slab (the halo planes are filtered too -- (lo + hi) / n_ext of wasted work, 3 % for config E -- and are scratch);
@@ -402,7 +591,8 @@ class SlabFilter:
         # overlap=True: interior planes while the exchange is in flight, the planes next to a neighbour afterwards
         # (mi_minmax3d_u8_planes / mi_minmax3d_f32_planes: uint8 cubic 3 / 5 / 7, float32 cubic 3 .. 9); what those
         # kernels do not take falls back to the plain schedule inside step_overlapped
-        return self.step_overlapped(call) if overlap else self.step(call)
+        key = (name, tuple(sizes), str(mode), float(cval), tuple(origins))
+        return self.step_overlapped(call, key) if overlap else self.step(call)
 
     def minimum_filter(self, size, mode="reflect", cval=0.0, origin=0, overlap=False):
         """minimum_filter(size=...) of the distributed volume; returns this rank's planes."""

@@ -814,7 +814,8 @@ def maximum_filter1d(input, size, axis=-1, output=None, mode="reflect", cval=0.0
 # ----------------------------------------------------------------------------
 # derivative filters: compositions of the 1-D passes (filters.py:828-1252)
 # ----------------------------------------------------------------------------
-def _derivative_then_smooth(input, axis, output, mode, cval, smooth):
+def _derivative_then_smooth(input, axis, output, mode, cval, smooth, dtype_mode="ndimage"):
+    S.acc_flag(dtype_mode)
     input = S.as_device(input)
     axis = S.normalize_axis(axis, input.ndim)
     output = S.get_output(output, input)
@@ -827,21 +828,23 @@ def _derivative_then_smooth(input, axis, output, mode, cval, smooth):
         res = _try_fused_3d(input, output, w, [0] * input.ndim, list(modes), cval, False)
         if res is not None:
             return res
-    correlate1d(input, [-1, 0, 1], axis, output, modes[axis], cval, 0, dtype_mode="ndimage")
+    correlate1d(input, [-1, 0, 1], axis, output, modes[axis], cval, 0, dtype_mode=dtype_mode)
     for ii in range(input.ndim):
         if ii != axis:
-            correlate1d(output, smooth, ii, output, modes[ii], cval, 0, dtype_mode="ndimage")
+            correlate1d(output, smooth, ii, output, modes[ii], cval, 0, dtype_mode=dtype_mode)
     return output
 
 
-def prewitt(input, axis=-1, output=None, mode="reflect", cval=0.0):
-    """Prewitt filter (filters.py:828-862): derivative along `axis`, [1, 1, 1] along the others."""
-    return _derivative_then_smooth(input, axis, output, mode, cval, [1, 1, 1])
+def prewitt(input, axis=-1, output=None, mode="reflect", cval=0.0, *, dtype_mode="ndimage"):
+    """Prewitt filter (filters.py:828-886): derivative along `axis`, [1, 1, 1] along the others; `dtype_mode` is
+    handed to every 1-D pass as in the reference (filters.py:835, 876-884)."""
+    return _derivative_then_smooth(input, axis, output, mode, cval, [1, 1, 1], dtype_mode)
 
 
-def sobel(input, axis=-1, output=None, mode="reflect", cval=0.0):
-    """Sobel filter (filters.py:865-899): derivative along `axis`, [1, 2, 1] along the others."""
-    return _derivative_then_smooth(input, axis, output, mode, cval, [1, 2, 1])
+def sobel(input, axis=-1, output=None, mode="reflect", cval=0.0, *, dtype_mode="ndimage"):
+    """Sobel filter (filters.py:889-940): derivative along `axis`, [1, 2, 1] along the others; `dtype_mode` as in
+    `prewitt` (filters.py:896)."""
+    return _derivative_then_smooth(input, axis, output, mode, cval, [1, 2, 1], dtype_mode)
 
 
 def generic_laplace(input, derivative2, output=None, mode="reflect", cval=0.0, extra_arguments=(),
@@ -862,10 +865,13 @@ def generic_laplace(input, derivative2, output=None, mode="reflect", cval=0.0, e
     return output
 
 
-def laplace(input, output=None, mode="reflect", cval=0.0):
-    """Laplace filter from [1, -2, 1] second differences (filters.py:1014-1043)."""
+def laplace(input, output=None, mode="reflect", cval=0.0, *, dtype_mode="ndimage"):
+    """Laplace filter from [1, -2, 1] second differences (filters.py:1041-1075; `dtype_mode` reaches the 1-D passes
+    through the derivative callback, filters.py:1067-1073)."""
+    S.acc_flag(dtype_mode)
+
     def derivative2(input, axis, output, mode, cval):
-        return correlate1d(input, [1, -2, 1], axis, output, mode, cval, 0, dtype_mode="ndimage")
+        return correlate1d(input, [1, -2, 1], axis, output, mode, cval, 0, dtype_mode=dtype_mode)
     input = S.as_device(input)
     if input.ndim in (2, 3) and input.dtype == np.float32 and isinstance(mode, str) and (
             output is None or (isinstance(output, core.ndarray) and output.dtype == np.float32)):

@@ -223,6 +223,14 @@ int mi_separable3d_f32_planes(const mi_array *in, const mi_array *out, const dou
                               const int wlen[3], const int origin[3], const int mode[3], double cval,
                               const int64_t *planes, int nranges, mi_stream stream);
 
+/* Would mi_separable3d_f32 (plane_ranges = 0) / mi_separable3d_f32_planes (plane_ranges != 0) take this request?
+ * MI_OK / MI_ERR_UNSUPPORTED / an argument error, decided by a dry run of the same dispatch code; nothing is
+ * queued.  A plane-range request is judged as a partial one whatever ranges a caller would pass, so every rank of a
+ * slab chain gets the same answer (r4; lets callers pick a schedule identically on all ranks). */
+int mi_separable3d_f32_supports(const mi_array *in, const mi_array *out, const double *const weights[3],
+                                const int wlen[3], const int origin[3], const int mode[3], double cval,
+                                int plane_ranges);
+
 /* Dense n-D stencil (filters.py:65-210 -> :441-495): weights is a host array
  * of prod(wshape) doubles in C order, already flipped for convolution by the
  * caller; zero weights are skipped (_filters_core.py:242-246). */
@@ -436,6 +444,30 @@ int mi_slab_separable3d_f32(mi_comm comm, const mi_array *ext_in, const mi_array
                             const int mode[3], double cval, int lo, int hi, int prev_rank, int next_rank,
                             int overlap, mi_stream comm_stream, mi_event input_free,
                             mi_event halos_ready, mi_stream stream);
+
+/* r4 -- the pipelined slab schedule: `nbuf` (2 or 3; 1 = serial) resident input slabs per rank, one output slab.
+ * The halo exchange of the NEXT input runs on an internal high-priority comm stream underneath the single launch that
+ * filters the current one (steady state: step time = max(kernel, exchange); no split launch, no wait on the critical
+ * path).  All slabs are extended buffers [lo halo | local planes | hi halo] of one shape.
+ *   mi_slab_pipe_step(pipe, submit, compute): "input `submit` is final -- as of the work queued on `stream` so far --
+ *       exchange its halos" and / or "filter input `compute` into the output slab" (-1 = nothing); a buffer must be
+ *       submitted before it is computed;
+ *   mi_slab_pipe_run(pipe, nsteps, use_graph): nsteps steps of the rotation 0, 1, .., nbuf-1, 0, .. with the
+ *       submits nbuf-1 steps ahead (resident inputs: benchmarks, repeated filtering); use_graph > 0 replays a captured
+ *       hipGraph of one rotation (or of `use_graph` steps, rounded down to whole rotations) where possible and queues
+ *       directly otherwise;
+ *   mi_slab_pipe_info: graph_state 0 not tried / 1 in use / -1 capture refused; planes_ok 0 = the kernel takes no plane
+ *       ranges and filters the halo planes of the output too (scratch).
+ * Every refusal (MI_ERR_UNSUPPORTED, argument errors) comes from mi_slab_pipe_create, before anything is queued. */
+typedef void *mi_slab_pipe;
+int mi_slab_pipe_create(mi_slab_pipe *pipe, mi_comm comm, int nbuf, const mi_array *const ext_in[],
+                        const mi_array *ext_out, const double *const weights[3], const int wlen[3],
+                        const int origin[3], const int mode[3], double cval, int lo, int hi, int prev_rank,
+                        int next_rank, mi_stream stream);
+int mi_slab_pipe_destroy(mi_slab_pipe pipe);
+int mi_slab_pipe_step(mi_slab_pipe pipe, int submit, int compute);
+int mi_slab_pipe_run(mi_slab_pipe pipe, int nsteps, int use_graph);
+int mi_slab_pipe_info(mi_slab_pipe pipe, int *graph_state, int *graph_steps, int *planes_ok);
 
 #ifdef __cplusplus
 }

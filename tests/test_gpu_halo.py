@@ -55,29 +55,11 @@ def test_plane_restriction_refuses_unfused_filters(gpu, ndi):
     ndi.uniform_filter(x, 3)        # scope is gone
 
 
-class _SelfLoopPlan:
-    """SlabPlan of a closed chain of ONE rank: both neighbours are the rank
-    itself, so the halos are the periodic continuation of its own planes."""
-
-    def __init__(self, nz, lo, hi):
-        self.nz, self.nranks, self.rank = nz, 2, 0      # nranks > 1 selects the exchange path
-        self.lo, self.hi, self.wrap = lo, hi, True
-        self.z0, self.z1, self.n_local = 0, nz, nz
-        self.prev = self.next = 0
-        self.lo_present, self.hi_present = lo, hi
-        self.n_ext = lo + nz + hi
-
-    @property
-    def local_slice(self):
-        return slice(self.lo, self.lo + self.nz)
-
-    def plane_ranges(self):
-        from cupyimg_amd.distributed import SlabPlan
-        return SlabPlan.plane_ranges(self)
-
-    def check_reach(self, size, origin=0):
-        from cupyimg_amd.distributed import SlabPlan
-        return SlabPlan.check_reach(self, size, origin)
+def _SelfLoopPlan(nz, lo, hi):
+    """SlabPlan of a closed chain of ONE rank: both neighbours are the rank itself, so the halos are the periodic
+    continuation of its own planes (distributed.SlabPlan.self_loop)."""
+    from cupyimg_amd.distributed import SlabPlan
+    return SlabPlan.self_loop(nz, lo, hi)
 
 
 @pytest.fixture(scope="module")
@@ -118,8 +100,8 @@ def test_overlapped_step_matches_plain_step_and_oracle(gpu, ndi, self_comm, size
     sf.ext_out[...] = gpu.asarray(np.zeros(sf.ext_out.shape, np.float32))
     # several steps back to back: the exchange of step k+1 must wait for the readers of step k
     for _ in range(3):
-        got = sf.step_overlapped(fn)
-    assert sf._overlap_ok
+        got = sf.step_overlapped(fn, key="u")
+    assert not sf._overlap_refused
     assert np.array_equal(got.get(), plain)
 
 
@@ -199,6 +181,115 @@ def test_slab_schedule_when_the_overlapped_form_is_refused(gpu, ndi, self_comm):
         assert len(sf._native_refused) == 1
 
 
+def test_refusals_come_before_anything_is_queued_and_do_not_depend_on_the_rank(gpu, ndi, self_comm):
+    """r3 advisor finding: with a 25-tap gaussian a rank WITHOUT interior planes (n_local <= lo + hi) used to queue its
+    exchange and only then learn from the edge launch that the kernel takes no plane ranges, while ranks with an
+    interior refused up front -- unequal exchange counts.  Now the kernels are asked first (dry run), with the same
+    answer whatever the plane ranges: mi_separable3d_f32_supports, and the overlapped native step of a thin and of a
+    thick slab both return Unsupported with an unchanged output slab."""
+    import ctypes
+    from cupyimg_amd import _lib
+    from cupyimg_amd.distributed import SlabFilter, SlabPlan, halo_widths
+    from cupyimg_amd.scipy.ndimage.filters import _gaussian_weights
+    w = _gaussian_weights(3.0, 0, 4.0)
+    assert len(w) == 25
+    lo, hi = halo_widths(25)
+    rng = np.random.default_rng(23)
+    dp = ctypes.POINTER(ctypes.c_double)
+    ptrs = (dp * 3)(*[w.ctypes.data_as(dp)] * 3)
+    ints = lambda v: (ctypes.c_int * 3)(*v)           # noqa: E731
+    lib = _lib.load()
+    for nz in (lo + hi, 3 * (lo + hi)):               # no interior planes / plenty
+        x = rng.standard_normal((nz, 24, 256)).astype(np.float32)
+        sf = SlabFilter(SlabPlan.self_loop(nz, lo, hi), x.shape[1:], np.float32, self_comm)
+        sf.local_in[...] = gpu.asarray(x)
+        a, b = sf.ext_in._desc(), sf.ext_out._desc()
+        args = (ctypes.byref(a), ctypes.byref(b), ptrs, ints([25] * 3), ints([0] * 3), ints([0] * 3), 0.0)
+        assert lib.mi_separable3d_f32_supports(*args, 1) == _lib.MI_ERR_UNSUPPORTED        # no plane ranges at 25 taps
+        assert lib.mi_separable3d_f32_supports(*args, 0) == _lib.MI_OK                     # the streaming passes take it
+        sf.ext_out.fill(-7.0)
+        sf._streams()
+        rc = lib.mi_slab_separable3d_f32(self_comm._comm, *args, lo, hi, 0, 0, 1, sf._comm_stream.handle, sf._input_free._e,
+                                         sf._halos_ready._e, None)
+        assert rc == _lib.MI_ERR_UNSUPPORTED
+        gpu.synchronize()
+        assert np.all(sf.ext_out.get() == -7.0)                                            # nothing ran
+        ref = orc.gaussian_filter(x, 3.0, mode=["wrap", "reflect", "reflect"])
+        for overlap in (True, None, False):           # overlap=True: refused up front, plain schedule in its place
+            got = sf.gaussian_filter(3.0, overlap=overlap).get()
+            assert maxnorm_rel(got, ref) <= 1e-6, (nz, overlap)
+        st = sf.schedule_of("gaussian")
+        assert st is not None and st["choice"] == 0 and not st["overlap_supported"]
+
+
+@pytest.mark.parametrize("nbuf", [2, 3])
+@pytest.mark.parametrize("size,mode", [(5, "reflect"), (9, "nearest"), (21, "mirror")])
+def test_pipelined_schedule_is_bit_identical_to_the_plain_one(gpu, ndi, self_comm, nbuf, size, mode):
+    """SlabPipeline (mi_slab_pipe_*): a SEQUENCE of different volumes streams through `nbuf` resident input slabs, the
+    exchange of volume j + nbuf - 1 queued before the filter of volume j; every result equals the plain step of the same
+    volume bit for bit and the oracle with `wrap` along z (self-loop chain).  21 taps: the kernel takes no plane ranges
+    (streaming passes on the whole extended slab)."""
+    from cupyimg_amd.distributed import SlabFilter, SlabPlan, halo_widths
+    rng = np.random.default_rng(50 + size)
+    nz = 40
+    lo, hi = halo_widths(size)
+    sf = SlabFilter(SlabPlan.self_loop(nz, lo, hi), (24, 256), np.float32, self_comm)
+    pipe = sf.uniform_pipeline(size, mode=mode, nbuf=nbuf)
+    assert pipe.info()["planes_ok"] == (size <= 17)
+    vols = [rng.standard_normal((nz, 24, 256)).astype(np.float32) for _ in range(7)]
+    want = []
+    for v in vols:
+        sf.local_in[...] = gpu.asarray(v)
+        want.append(sf.uniform_filter(size, mode=mode, overlap=False).get())
+    assert maxnorm_rel(want[0], orc.uniform_filter(vols[0], size, mode=["wrap", mode, mode])) <= 1e-6
+    depth = nbuf - 1
+    got = []
+    for j in range(len(vols) + depth):
+        if j < len(vols):
+            pipe.local_in(j % nbuf)[...] = gpu.asarray(vols[j])
+            pipe.submit(j % nbuf)
+        if j >= depth:
+            got.append(pipe.compute((j - depth) % nbuf).get())
+    assert len(got) == len(vols)
+    for j, (g, w_) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w_), j
+    with pytest.raises(RuntimeError):
+        pipe.compute(0)                    # never submitted again
+    pipe.close()
+
+
+@pytest.mark.parametrize("graph", [0, 1, 6])
+def test_pipelined_rotation_over_resident_inputs(gpu, ndi, self_comm, graph):
+    """mi_slab_pipe_run: the rotation bench.py times (resident inputs, submits one step ahead), queued directly or
+    replayed from a captured hipGraph of one / three rotations; odd step counts, repeated calls; the output is that
+    of the input filtered last."""
+    from cupyimg_amd.distributed import SlabFilter, SlabPlan, halo_widths
+    rng = np.random.default_rng(60)
+    nz, size = 36, 5
+    lo, hi = halo_widths(size)
+    sf = SlabFilter(SlabPlan.self_loop(nz, lo, hi), (32, 256), np.float32, self_comm)
+    pipe = sf.uniform_pipeline(size, nbuf=2)
+    vols = [rng.standard_normal((nz, 32, 256)).astype(np.float32) for _ in range(2)]
+    want = []
+    for k, v in enumerate(vols):
+        sf.local_in[...] = gpu.asarray(v)
+        want.append(sf.uniform_filter(size, overlap=False).get())
+    for k, v in enumerate(vols):
+        pipe.local_in(k)[...] = gpu.asarray(v)
+    total = 0
+    for n in (1, 2, 7, 12, 13, 1):
+        pipe.run(n, graph)
+        total += n
+        assert np.array_equal(pipe.local_out.get(), want[(total - 1) % 2]), (n, total)
+    info = pipe.info()
+    assert info["graph_state"] in ((0,) if graph == 0 else (1, -1))       # -1: capture refused by this RCCL: direct queuing took over
+    if info["graph_state"] == 1:
+        assert info["graph_steps"] == max(2, graph // 2 * 2)
+    k_us, ex_us = pipe.measure(reps=5)
+    assert k_us > 0 and ex_us > 0
+    pipe.close()
+
+
 def test_slab_step_refuses_kernels_wider_than_the_halo(gpu, ndi, self_comm):
     """A plan built for 5 taps refuses a 17-tap axis-0 kernel in Python (ValueError) and in C
     (MI_ERR_INVALID_ARG), instead of filtering across the slab edge."""
@@ -238,21 +329,22 @@ def test_overlapped_step_with_long_kernels(gpu, ndi, self_comm):
     sf.local_in[...] = gpu.asarray(x)
     fn = lambda a, b: ndi.uniform_filter(a, size=size, mode="nearest", output=b)   # noqa: E731
     plain = sf.step(fn).get()
-    got = sf.step_overlapped(fn).get()
-    assert sf._overlap_ok
+    got = sf.step_overlapped(fn, key="fn").get()
+    assert not sf._overlap_refused
     assert np.array_equal(got, plain)
     ref = orc.uniform_filter(x, size, mode=["wrap", "nearest", "nearest"])
     assert maxnorm_rel(got, ref) <= 1e-6
     fc = lambda a, b: ndi.uniform_filter(a, size=size, mode=["wrap", "constant", "constant"], cval=0.5, output=b)   # noqa: E731
-    got = sf.step_overlapped(fc).get()
-    assert sf._overlap_ok and np.array_equal(got, sf.step(fc).get())
+    got = sf.step_overlapped(fc, key="fc").get()
+    assert not sf._overlap_refused and np.array_equal(got, sf.step(fc).get())
     ref = orc.uniform_filter(x, size, mode=["wrap", "constant", "constant"], cval=0.5)
     assert maxnorm_rel(got, ref) <= 1e-6
     fm = lambda a, b: ndi.uniform_filter(a, size=(size, 5, 5), mode="nearest", output=b)   # noqa: E731
-    got = sf.step_overlapped(fm).get()
-    assert not sf._overlap_ok
+    got = sf.step_overlapped(fm, key="fm").get()
+    assert sf._overlap_refused == {"fm"}                       # remembered for THIS filter only (r3 advisor finding)
     ref = orc.uniform_filter(x, (size, 5, 5), mode=["wrap", "nearest", "nearest"])
     assert maxnorm_rel(got, ref) <= 1e-6
+    assert np.array_equal(sf.step_overlapped(fn, key="fn").get(), plain) and sf._overlap_refused == {"fm"}
 
 
 def test_arrays_differ(gpu):

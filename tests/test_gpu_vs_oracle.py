@@ -842,6 +842,34 @@ def test_derivative_and_morphological_composites_match_scipy(gpu, ndi, dtype):
     assert np.array_equal(ndi.binary_fill_holes(gpu.asarray(b)).get(), sndi.binary_fill_holes(b))
 
 
+def test_derivative_filters_take_dtype_mode(gpu, ndi):
+    """prewitt / sobel / laplace accept the reference's keyword-only `dtype_mode`
+    (cupyimg/scipy/ndimage/filters.py:828-838, 889-899, 1041-1043) and hand it to the
+    1-D passes: "ndimage" = SciPy's double accumulation (exact on integers),
+    "float" = float32 accumulation for <= 32-bit inputs; anything else is a ValueError."""
+    import scipy.ndimage as sndi
+    rng = np.random.default_rng(121)
+    xi = rng.integers(0, 100, size=(20, 33)).astype(np.int16)
+    xf = rng.standard_normal((9, 14, 16)).astype(np.float32)
+    for x, tol in [(xi, 0), (xf, 2e-6)]:
+        xd = gpu.asarray(x)
+        for dm in ("ndimage", "float"):
+            for got, ref in [(ndi.prewitt(xd, axis=0, dtype_mode=dm), sndi.prewitt(x, axis=0)),
+                             (ndi.sobel(xd, axis=1, mode="mirror", dtype_mode=dm), sndi.sobel(x, axis=1, mode="mirror")),
+                             (ndi.laplace(xd, mode="nearest", dtype_mode=dm), sndi.laplace(x, mode="nearest"))]:
+                got = got.get()
+                assert got.dtype == ref.dtype
+                if tol == 0:
+                    assert np.array_equal(got, ref), dm       # small integers: float32 sums are exact too
+                else:
+                    assert np.abs(got.astype(np.float64) - ref).max() <= tol * max(1.0, np.abs(ref).max()), dm
+        for fn in (ndi.prewitt, ndi.sobel, ndi.laplace):
+            with pytest.raises(ValueError):
+                fn(xd, dtype_mode="bogus")
+            with pytest.raises(TypeError):
+                fn(xd, None, None, "reflect", 0.0, "float") if fn is not ndi.laplace else fn(xd, None, "reflect", 0.0, "float")
+
+
 @pytest.mark.parametrize("dtype", ["float32", "uint8", "int16", "float64"])
 def test_rank_median_percentile_filters_match_scipy(gpu, ndi, dtype):
     import scipy.ndimage as sndi
@@ -1508,3 +1536,20 @@ def test_long_kernel_anisotropic_tap_pairs(gpu, ndi):
     u = ndi.uniform_filter(xd, (11, 17, 17)).get()                                  # not a built pair: streaming passes
     assert "sep3d_long3_kernel" not in ca.last_kernel()
     assert maxnorm_rel(u, orc.uniform_filter(x, (11, 17, 17))) <= 1e-6
+
+
+def test_rank_filter_int64_beyond_2p53_follows_scipy(gpu, ndi):
+    """SciPy's NI_RankFilter / NI_MinOrMaxFilter hold the window in doubles, so 64-bit integers beyond 2^53 come back
+    rounded; both rank kernels (registers: rank <= 3 arrays; scratch columns: rank 4 arrays / large footprints) and the
+    min / max kernels reproduce that bit for bit instead of returning the unrounded element."""
+    import scipy.ndimage as sndi
+    x = (np.arange(5 * 8 * 9, dtype=np.int64).reshape(5, 8, 9) * 3 + (1 << 60) + 1)
+    np.random.default_rng(5).shuffle(x.reshape(-1))
+    for dt in (np.int64, np.uint64):
+        v = x.astype(dt)
+        assert np.array_equal(ndi.median_filter(gpu.asarray(v), size=3).get(), sndi.median_filter(v, size=3))
+        assert np.array_equal(ndi.minimum_filter(gpu.asarray(v), size=3).get(), sndi.minimum_filter(v, size=3))
+        v4 = v.reshape(1, 5, 8, 9)
+        assert np.array_equal(ndi.rank_filter(gpu.asarray(v4), rank=5, size=(1, 3, 3, 3)).get(),
+                              sndi.rank_filter(v4, rank=5, size=(1, 3, 3, 3)))
+        assert np.array_equal(ndi.median_filter(gpu.asarray(v), size=(5, 5, 7)).get(), sndi.median_filter(v, size=(5, 5, 7)))

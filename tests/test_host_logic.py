@@ -169,3 +169,11 @@ def test_memoised_call_parameters():
     assert p2[0][0] == 1.0
     assert filters._cached_ints((1, 2, 3)) is filters._cached_ints((1, 2, 3))
     assert list(filters._cached_ints((4, 0, 1))) == [4, 0, 1]
+
+
+def test_derivative_filters_have_the_reference_dtype_mode_keyword():
+    """cupyimg/scipy/ndimage/filters.py:828-838, 889-899, 1041-1043: keyword-only, default "ndimage"."""
+    import inspect
+    for fn in (filters.prewitt, filters.sobel, filters.laplace):
+        prm = inspect.signature(fn).parameters["dtype_mode"]
+        assert prm.kind is inspect.Parameter.KEYWORD_ONLY and prm.default == "ndimage"
