@@ -195,6 +195,9 @@ int mi_slab_separable3d_f32(mi_comm comm, const mi_array *ext_in, const mi_array
  * step time = max(kernel, exchange).  mi_slab_pipe_step(submit, compute) queues "buffer `submit` is final: exchange its
  * halos" and "filter buffer `compute`"; either may be -1.  mi_slab_pipe_run() rotates over the buffers and can replay
  * a captured hipGraph of one rotation instead of queuing the 2 + 4 operations of every step one by one. */
+static mi::Knob g_pipe_normal_priority{0};     // test hook: 1 = the pipeline's comm stream at normal priority
+extern "C" int mi_debug_set_pipe_normal_priority(int k) { g_pipe_normal_priority = k; return MI_OK; }
+
 namespace mi {
 constexpr int kPipeMaxBuf = 4;
 struct SlabPipe {
@@ -210,7 +213,7 @@ struct SlabPipe {
     int64_t a = 0, b = 0, n_local = 0;      // local planes of the extended slab: [a, b)
     size_t plane_bytes = 0;
     bool planes_ok = true;                  // the kernel takes plane ranges (otherwise the halo planes are filtered too)
-    hipStream_t s = nullptr, cs = nullptr;
+    hipStream_t s = nullptr, cs = nullptr;      // caller's stream; comm stream
     hipEvent_t input_final[kPipeMaxBuf] = {};   // recorded on `s` when a buffer is submitted
     hipEvent_t halos_ready[kPipeMaxBuf] = {};   // recorded on `cs` after the exchange of a buffer
     bool submitted[kPipeMaxBuf] = {};
@@ -381,9 +384,13 @@ int mi_slab_pipe_create(mi_slab_pipe *pipe, mi_comm comm, int nbuf, const mi_arr
     p->s = resolve_stream(stream);
     // the exchange kernels are small and have a step of slack: a high-priority queue lets them take the first CU a
     // retiring filter workgroup frees instead of queuing behind the next filter launch
-    int pri_lo = 0, pri_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&pri_lo, &pri_hi);
-    MI_HIP(hipStreamCreateWithPriority(&p->cs, hipStreamNonBlocking, pri_hi));
+    {
+        // the exchange kernels are small and have a step of slack: a high-priority queue lets them take the first CU
+        // a retiring filter workgroup frees instead of queuing behind the next filter launch
+        int pri_lo = 0, pri_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&pri_lo, &pri_hi);
+        MI_HIP(hipStreamCreateWithPriority(&p->cs, hipStreamNonBlocking, g_pipe_normal_priority ? pri_lo : pri_hi));
+    }
     for (int k = 0; k < nbuf; k++) {
         MI_HIP(hipEventCreateWithFlags(&p->input_final[k], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&p->halos_ready[k], hipEventDisableTiming));

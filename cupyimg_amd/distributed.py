@@ -337,6 +337,7 @@ class SlabFilter:
         self._comm_stream = None
         self._halos_ready = None      # exchange finished (recorded on the comm stream)
         self._input_free = None       # previous readers of ext_in finished (default stream)
+        self._extra_inputs = []       # further resident input slabs of the pipelined schedule
         self._overlap_refused = set() # filters (keys) whose kernels take no plane ranges: plain schedule, not re-probed
         self._prepared = {}
         self._native_refused = set()  # filters mi_slab_separable3d_f32 answered UNSUPPORTED for (generic step instead)
@@ -440,15 +441,24 @@ class SlabFilter:
             prep = self._prepared[key] = (args, (keep, a, b))        # second item keeps the buffers alive
         if key in self._native_refused and fallback is not None:
             return self.step(fallback)             # the fused kernels do not take this request: remembered, not re-probed
+        args = prep[0]
+        lib = _lib.load()
         try:
-            args = prep[0]
             if overlap is not None:
-                mode_flag = int(bool(overlap))
+                mode_flag = int(bool(overlap)) if key not in self._overlap_refused else 0
             elif self.comm is None or plan.nranks == 1 or not self.autotune:
                 mode_flag = -1
             else:
                 mode_flag = self._tuned_schedule(key, args)
-            _lib.check(_lib.load().mi_slab_separable3d_f32(*args[:12], mode_flag, *args[13:]))
+            try:
+                _lib.check(lib.mi_slab_separable3d_f32(*args[:12], mode_flag, *args[13:]))
+            except _lib.Unsupported:
+                # refusals come before anything is queued (mi_slab_separable3d_f32): the overlapped form does not
+                # exist for this kernel (no plane ranges) -> the plain native schedule, remembered per filter
+                if mode_flag == 0:
+                    raise
+                self._overlap_refused.add(key)
+                _lib.check(lib.mi_slab_separable3d_f32(*args[:12], 0, *args[13:]))
         except _lib.Unsupported:
             if fallback is None:
                 raise
@@ -555,7 +565,9 @@ class SlabFilter:
         nbuf = int(nbuf)
         if not 1 <= nbuf <= 4:
             raise ValueError("nbuf must be 1 .. 4")
-        ins = [self.ext_in] + [core.empty(self.ext_in.shape, self.ext_in.dtype) for _ in range(nbuf - 1)]
+        while len(self._extra_inputs) < nbuf - 1:          # kept: a second pipeline of this filter reuses them
+            self._extra_inputs.append(core.empty(self.ext_in.shape, self.ext_in.dtype))
+        ins = [self.ext_in] + self._extra_inputs[:nbuf - 1]
         return SlabPipeline(self.plan, self.comm, ins, self.ext_out, weights, modes, cval, origins)
 
     def uniform_pipeline(self, size, mode="reflect", cval=0.0, nbuf=2):

@@ -65,6 +65,7 @@ int mi_debug_set_spline_chunk(int n);
 int mi_debug_set_spline_rows(int k);
 int mi_debug_set_cubic_separable(int on);
 int mi_debug_set_cubic_diag(int on);
+int mi_debug_set_pipe_normal_priority(int on); /* slab pipeline: comm stream at normal instead of high priority (read by mi_slab_pipe_create) */
 
 #ifdef __cplusplus
 }

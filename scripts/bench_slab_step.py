@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--side", type=int, default=512)
     ap.add_argument("--planes", type=int, default=0, help="local planes per rank (default side / ranks)")
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--graphs", type=int, default=0, help="1: also time the hipGraph replays of every pipelined variant")
     ap.add_argument("--single-gpu-us", type=float, default=0.0, help="single-GPU step of the whole volume (0: measure it when it fits)")
     a = ap.parse_args()
     import cupyimg_amd as ca
@@ -74,25 +75,34 @@ def main():
     res["plain_us"] = burst_us(ca, loop(lambda: sf.uniform_filter(a.size, overlap=False)), a.steps)
     res["overlapped_us"] = burst_us(ca, loop(lambda: sf.uniform_filter(a.size, overlap=True)), a.steps)
     ref = sf.uniform_filter(a.size, overlap=False).copy()
-    for nbuf in (2, 3):
-        pipe = sf.uniform_pipeline(a.size, nbuf=nbuf)
+    import ctypes
+    from cupyimg_amd import _lib
+    prio = _lib.load().mi_debug_set_pipe_normal_priority
+    prio.argtypes = [ctypes.c_int]
+    # (resident inputs, CUs reserved for the exchange kernels, comm stream priority)
+    variants = [(2, 0, "high"), (3, 0, "high"), (3, 0, "normal"), (2, 16, "high"), (3, 16, "high"), (3, 32, "high"), (3, 64, "high")]
+    for nbuf, reserve, pr in variants:
+        prio(1 if pr == "normal" else 0)
+        pipe = sf.uniform_pipeline(a.size, nbuf=nbuf, reserve_cus=reserve)
         for k in range(1, nbuf):
             pipe.inputs[k][...] = sf.ext_in
-        key = "pipelined_nbuf{}".format(nbuf)
+        key = "pipelined_nbuf{}_reserve{}{}".format(nbuf, reserve, "_normalprio" if pr == "normal" else "")
         res[key + "_direct_us"] = burst_us(ca, lambda n: pipe.run(n, 0), a.steps)
-        res[key + "_step_calls_us"] = burst_us(ca, lambda n: [pipe.run(1, 0) for _ in range(n)], a.steps)
-        try:
-            res[key + "_graph_us"] = burst_us(ca, lambda n: pipe.run(n, 1), a.steps)
-            res[key + "_graph8_us"] = burst_us(ca, lambda n: pipe.run(n, 8 * nbuf), a.steps // (8 * nbuf) * (8 * nbuf))
-            res[key + "_info"] = pipe.info()
-        except Exception as exc:             # a capture that fails inside RCCL: recorded, not fatal
-            res[key + "_graph_error"] = repr(exc)[:200]
+        if a.graphs:
+            try:
+                res[key + "_graph_us"] = burst_us(ca, lambda n: pipe.run(n, 1), a.steps)
+                per = 8 * nbuf
+                res[key + "_graph8_us"] = burst_us(ca, lambda n: pipe.run(n, per), max(a.steps // per, 1) * per)
+                res[key + "_info"] = pipe.info()
+            except Exception as exc:             # a capture that fails inside RCCL: recorded, not fatal
+                res[key + "_graph_error"] = repr(exc)[:200]
         ca.synchronize()
         res[key + "_bit_identical_to_plain"] = not ca.arrays_differ(pipe.local_out, ref)
         k_us, ex_us = pipe.measure()
         res[key + "_kernel_us"], res[key + "_exchange_us"] = round(k_us, 2), round(ex_us, 2)
         pipe.close()
         del pipe
+    prio(0)
     single = a.single_gpu_us
     if not single and a.side ** 3 * 8 < 8 << 30:
         xd = ca.empty((a.side,) * 3, np.float32)

@@ -1,7 +1,9 @@
 """Full-size parity legs for the BASELINE.json configs (last bullet / 8d): the GPU result of a
 whole 512^3 / 1024^3 / 264 x 2048^2 call is compared with scipy.ndimage on z sub-slabs (with the halo the filter
-needs), so a leg costs seconds of host time instead of the minutes SciPy needs for the whole volume.  At a global
-edge the sub-slab edge IS the volume edge, so index-mapping boundary modes are evaluated exactly as unsplit.
+needs).  At a global edge the sub-slab edge IS the volume edge, so index-mapping boundary modes are evaluated exactly
+as unsplit.  r4: the sub-slabs TILE THE WHOLE VOLUME (`whole_volume_*`): every plane of H, B, C, D, D' is compared, the
+slabs spread over the host cores by a fork pool (SciPy is single-threaded; 512^3 costs about a second on the 256-core
+GPU boxes, minutes on one core); `check_*_slabs` (a handful of sub-slabs) remain for the benchmark scripts.
 
 Test infrastructure: used by tests/test_gpu_baseline_full.py and scripts/bench_configs.py (`parity` field), never by
 the package.  Inputs follow SURVEY.md 8(d): N(0,1) float32 seed 0 (H, B, D), uint8 uniform seed 1 (C), the fixed
@@ -128,3 +130,99 @@ def check_affine_slabs(x, M, off, out_dev, slabs):
         got = out_dev[a:b].get().astype(np.float64)
         worst = max(worst, float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max())))
     return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# whole-volume legs: every output plane, z sub-slabs over a fork pool
+# ---------------------------------------------------------------------------------------------------------------------
+_G = {}          # what the forked workers read: set before the pool is created (copy-on-write, nothing is pickled)
+
+
+def _procs(procs=None):
+    import os
+    return max(1, min(procs or (os.cpu_count() or 1), 64))
+
+
+def _jobs(nz, planes, ranges=None):
+    out = []
+    for a0, b0 in (ranges or [(0, nz)]):
+        for a in range(a0, b0, planes):
+            out.append((a, min(a + planes, b0)))
+    return out
+
+
+def _run_pool(worker, jobs, procs):
+    """Workers are forked from this (GPU-initialised) process and only ever run NumPy / SciPy on arrays inherited
+    through `_G`; they leave through os._exit (multiprocessing's fork children do), so no HIP teardown runs in them."""
+    import multiprocessing as mp
+    n = _procs(procs)
+    if n == 1 or len(jobs) == 1:
+        return [worker(j) for j in jobs]
+    with mp.get_context("fork").Pool(min(n, len(jobs))) as pool:
+        return pool.map(worker, jobs, chunksize=1)
+
+
+def _filter_worker(job):
+    a, b = job
+    x, got, fn, lo, hi, exact = _G["x"], _G["got"], _G["fn"], _G["lo"], _G["hi"], _G["exact"]
+    ref = ref_on_slab(x, a, b, lo, hi, fn)
+    g = got[a:b]
+    if exact:
+        return float(np.count_nonzero(g != ref)), 0.0
+    e = np.asarray(ref, dtype=np.float64)
+    return float(np.abs(g.astype(np.float64) - e).max()), float(np.abs(e).max())
+
+
+def whole_volume_filter(x, got, lo, hi, fn, exact=False, planes=8, procs=None, ranges=None):
+    """Every plane of `got` (host array, result of the device call on `x`) against fn() on z sub-slabs of `planes`
+    planes with (lo, hi) planes of context.  Returns the number of differing voxels (`exact`) or
+    max|got - ref| / max|ref| over the WHOLE volume (the same norm as one comparison of the whole arrays).
+    `ranges`: plane ranges to cover instead of everything (E-slab: contiguous blocks across the byte-offset crossings)."""
+    assert got.shape == x.shape
+    _G.update(x=x, got=got, fn=fn, lo=lo, hi=hi, exact=exact)
+    try:
+        res = _run_pool(_filter_worker, _jobs(x.shape[0], planes, ranges), procs)
+    finally:
+        _G.clear()
+    if exact:
+        return int(sum(r[0] for r in res))
+    d, m = max(r[0] for r in res), max(r[1] for r in res)
+    return d / m if m > 0 else d
+
+
+def _map_worker(job):
+    import scipy.ndimage as sndi
+    a, b = job
+    x, got, coords = _G["x"], _G["got"], _G["coords"]
+    ref = sndi.map_coordinates(x, coords[:, a:b], output=np.float64, order=1, mode="constant", cval=0.0, prefilter=False)
+    return float(np.abs(got[a:b].astype(np.float64) - ref).max()), float(np.abs(ref).max())
+
+
+def whole_volume_map_coordinates(x, coords, got, planes=4, procs=None):
+    """max |got - ref| / max(1, max|ref|) of an order-1 `map_coordinates(mode="constant")` result, every output plane."""
+    _G.update(x=x, got=got, coords=coords)
+    try:
+        res = _run_pool(_map_worker, _jobs(got.shape[0], planes), procs)
+    finally:
+        _G.clear()
+    return max(r[0] for r in res) / max(1.0, max(r[1] for r in res))
+
+
+def _affine_worker(job):
+    import scipy.ndimage as sndi
+    a, b = job
+    x, got, M, off = _G["x"], _G["got"], _G["M"], _G["off"]
+    ref = sndi.affine_transform(x, M, off + M[:, 0] * a, output_shape=(b - a,) + x.shape[1:], output=np.float64, order=1,
+                                mode="constant", cval=0.0, prefilter=False)
+    return float(np.abs(got[a:b].astype(np.float64) - ref).max()), float(np.abs(ref).max())
+
+
+def whole_volume_affine(x, M, off, got, planes=4, procs=None):
+    """The same for `affine_transform(order=1, mode="constant")` (output planes a..b of the full call are the transform
+    with offset + M[:, 0] * a and output_shape (b - a, ny, nx)), every output plane."""
+    _G.update(x=x, got=got, M=M, off=off)
+    try:
+        res = _run_pool(_affine_worker, _jobs(got.shape[0], planes), procs)
+    finally:
+        _G.clear()
+    return max(r[0] for r in res) / max(1.0, max(r[1] for r in res))

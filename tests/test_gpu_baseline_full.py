@@ -1,6 +1,7 @@
-"""Every single-GPU BASELINE.json config at FULL size through the C-ABI, checked against scipy.ndimage on z sub-slabs
-(first / last planes, >= 3 interior slabs, byte-offset crossings) -- tests/helpers/fullsize.py.  Grid geometry
-(1024-wide tiles, 1.5 GiB coordinate arrays, 32-bit offset guards, > 4 GiB slabs) is only exercised at these sizes."""
+"""Every single-GPU BASELINE.json config at FULL size through the C-ABI, checked against scipy.ndimage on EVERY plane
+(r4: z sub-slabs that tile the whole volume, spread over the host cores -- tests/helpers/fullsize.py; the E-slab
+included: all 264 planes, across the 2 GiB and 4 GiB byte-offset crossings).  Grid geometry (1024-wide tiles,
+1.5 GiB coordinate arrays, 32-bit offset guards, > 4 GiB slabs) is only exercised at these sizes."""
 import numpy as np
 import pytest
 import scipy.ndimage as sndi
@@ -27,9 +28,8 @@ def vol512(gpu):
 
 def test_H_uniform5_512(gpu, ndi, vol512):
     x, xd = vol512
-    out = ndi.uniform_filter(xd, size=5)
-    err = fs.check_filter_slabs(x, out, 2, 2, lambda s: sndi.uniform_filter(s.astype(np.float64), size=5),
-                                fs.z_slabs(fs.N_H, extra=(64, 128, 448)))
+    out = ndi.uniform_filter(xd, size=5).get()
+    err = fs.whole_volume_filter(x, out, 2, 2, lambda s: sndi.uniform_filter(s.astype(np.float64), size=5))
     assert err <= 1e-6, err
 
 
@@ -41,19 +41,18 @@ def test_H_neighbours_3_7_9_13_taps_512(gpu, ndi, vol512):
     for size, mode in ((3, "mirror"), (7, "nearest"), (9, "mirror"), (13, "reflect")):
         out = ndi.uniform_filter(xd, size=size, mode=mode)
         assert "sep3d_long3_kernel<%d," % size in last_kernel(), last_kernel()
+        out = out.get()
         h = size // 2
-        err = fs.check_filter_slabs(x, out, h, h, lambda s: sndi.uniform_filter(s.astype(np.float64), size=size, mode=mode),
-                                    fs.z_slabs(fs.N_H, extra=(128, 256, 384)))
+        err = fs.whole_volume_filter(x, out, h, h, lambda s: sndi.uniform_filter(s.astype(np.float64), size=size, mode=mode))
         assert err <= 1e-6, (size, mode, err)
         del out
 
 
 def test_B_gaussian_sigma2_512(gpu, ndi, vol512):
     x, xd = vol512
-    out = ndi.gaussian_filter(xd, sigma=2)
-    # 17 taps per axis: halo 8; chunk seams of the long kernel lie at multiples of 128 planes
-    err = fs.check_filter_slabs(x, out, 8, 8, lambda s: sndi.gaussian_filter(s.astype(np.float64), sigma=2),
-                                fs.z_slabs(fs.N_H, extra=(128, 256, 384)))
+    out = ndi.gaussian_filter(xd, sigma=2).get()
+    # 17 taps per axis: halo 8
+    err = fs.whole_volume_filter(x, out, 8, 8, lambda s: sndi.gaussian_filter(s.astype(np.float64), sigma=2), planes=16)
     assert err <= 1e-6, err
 
 
@@ -63,8 +62,8 @@ def test_D_map_coordinates_order1_512(gpu, ndi, vol512):
     cd = gpu.asarray(coords)
     out = ndi.map_coordinates(xd, cd, order=1, mode="constant")
     assert out.dtype == np.float32 and out.shape == x.shape
-    err = fs.check_map_coordinates_slabs(x, coords, out, fs.z_slabs(fs.N_H, width=4))
     del cd
+    err = fs.whole_volume_map_coordinates(x, coords, out.get())
     assert err <= 2e-6, err
 
 
@@ -72,7 +71,7 @@ def test_Dprime_affine_transform_order1_512(gpu, ndi, vol512):
     x, xd = vol512
     M, off = fs.affine_case(fs.N_H)
     out = ndi.affine_transform(xd, M, off, order=1, mode="constant")
-    err = fs.check_affine_slabs(x, M, off, out, fs.z_slabs(fs.N_H, width=4))
+    err = fs.whole_volume_affine(x, M, off, out.get())
     assert err <= 2e-6, err
 
 
@@ -82,10 +81,10 @@ def test_C_grey_erosion7_1024_u8(gpu, ndi):
     ud = gpu.asarray(u)
     out = ndi.grey_erosion(ud, size=7)
     assert out.dtype == np.uint8
-    bad = fs.check_filter_slabs(u, out, 3, 3, lambda s: sndi.grey_erosion(s, size=7),
-                                fs.z_slabs(fs.N_C, extra=(256, 512, 768)), exact=True)
+    got = out.get()
     del ud, out
     gpu.free_all_blocks()
+    bad = fs.whole_volume_filter(u, got, 3, 3, lambda s: sndi.grey_erosion(s, size=7), exact=True, planes=16)
     assert bad == 0, bad
 
 
@@ -96,8 +95,9 @@ def test_E_slab_uniform9_264x2048x2048(gpu, ndi):
     xd = gpu.asarray(x)
     out = gpu.empty(x.shape, np.float32)
     ndi.uniform_filter(xd, size=9, output=out)
-    err = fs.check_filter_slabs(x, out, 4, 4, lambda s: sndi.uniform_filter(s.astype(np.float64), size=9),
-                                fs.z_slabs(fs.E_SLAB[0], width=4, extra=(128, 256)))
+    got = out.get()
     del xd, out
     gpu.free_all_blocks()
+    # every plane (the 2 GiB / 4 GiB byte-offset crossings at planes 128 / 256 and the kernel's 64-plane chunk seams included)
+    err = fs.whole_volume_filter(x, got, 4, 4, lambda s: sndi.uniform_filter(s.astype(np.float64), size=9), planes=4)
     assert err <= 1e-6, err

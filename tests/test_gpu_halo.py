@@ -220,6 +220,7 @@ def test_refusals_come_before_anything_is_queued_and_do_not_depend_on_the_rank(g
             assert maxnorm_rel(got, ref) <= 1e-6, (nz, overlap)
         st = sf.schedule_of("gaussian")
         assert st is not None and st["choice"] == 0 and not st["overlap_supported"]
+        assert not sf._native_refused and len(sf._overlap_refused) == 1      # native plain step, not the generic one
 
 
 @pytest.mark.parametrize("nbuf", [2, 3])
