@@ -13,9 +13,13 @@
 // Against SciPy's all-double arithmetic that is ~1e-7 relative; the stated
 // tolerance for float32 interpolation is 2e-6 * max|ref| (tests/test_gpu_*).
 // Anything else (other dtypes, ranks, float64 output) runs interp.hip.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace mi {
+
+void note_kernel(const char *fmt, ...);      // separable3d.hip: which kernel a call dispatched (mi_debug_last_kernel)
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -729,6 +733,7 @@ static int launch_affine_lds(const float *in, float *out, const LdsAffineParams 
         MI_HIP(hipFuncSetAttribute((const void *)affine3d_lds_kernel<TX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr_done = true;
     }
+    note_kernel("mi::affine3d_lds_kernel<%d> grid=%ux%ux%u (order-1 affine, %d x %d x %d box staged per tile)", TX, gl.x, gl.y, gl.z, q.bz, q.by, q.bx);
     hipLaunchKernelGGL(affine3d_lds_kernel<TX>, gl, dim3(512), lds, s, in, out, q);
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -1110,6 +1115,279 @@ affine3d_fast(const T *__restrict__ in, T *__restrict__ out, const FastInterpPar
         if (ok[k]) __builtin_nontemporal_store(finish<T>(t[k], (T)p.cval), out + o[k]);
 }
 
+// ---------------------------------------------------------------------------
+// r4: affine_transform, order 1, constant mode, float32 volumes whose matrix leaves axis 0 to itself
+// (m01 = m02 = m10 = m20 = 0: an in-plane rotation / shear / scaling of every slice plus a scaling / shift through the
+// slices -- BASELINE config D', `rotate(volume, angle, axes=(1, 2))`, slice-wise registration).  STREAMS ALONG z.
+//
+// Why a third kernel: affine3d_lds_kernel stages a 3-D bounding box per 8-plane tile (2.05 x the tile's samples from
+// L2, 2.03 x the input from HBM) and recomputes three float64 coordinates per voxel (49 VALU instructions per voxel,
+// profiles/r3_kernel_counters.txt) -- 337-348 us on config D', 0.39 of the roofline.  With axis 0 decoupled
+//   * the in-plane coordinates (cy, cx) of an output voxel do not depend on z: a thread computes the LDS address and
+//     the two weights of each of its eight (y, x) positions ONCE per workgroup and keeps them in registers while the
+//     workgroup walks down a chunk of output planes -- per voxel and plane what is left is two address adds, four
+//     ds_read2_b32 and the blend (~20 VALU instructions);
+//   * the z coordinate is the same for a whole output plane: its two input planes and their weights are wave-uniform;
+//   * input planes enter LDS once per (y, x) tile as the tile's in-plane bounding rectangle (RY rows of P = 80 samples,
+//     `buffer_load_dwordx4 ... lds`), in a ring of four slots indexed by (input plane & 3): the planes the NEXT output
+//     plane needs are fetched while the current one is interpolated (|m00| <= 2 keeps the four live planes in distinct
+//     slots).  No amplification along z (1.27 x in the box kernel), in-plane 1.3-1.6 x from L2, most of which the L2 /
+//     MALL serve: x-neighbouring tiles -- whose rectangles overlap -- are given to the same XCD.
+// Coordinates, splits, in-range tests and the blend (finish) are those of affine3d_c1_kernel in the oracle's summation
+// order (the zero terms of the decoupled matrix add exact zeros): results are bit-identical to the other order-1 kernels.
+// ---------------------------------------------------------------------------
+constexpr int kZsP = 80;                    // LDS row pitch (floats) of a staged plane rectangle = 20 sixteen-byte chunks
+constexpr int kZsRoundsMax = 8;             // staging rounds (NT chunks each) a plane rectangle can take
+
+struct ZStreamParams {
+    FastInterpParams f;
+    int ry;                  // rows of the staged rectangle
+    int nchunks;             // ry * 20
+    double cmin_y, cmin_x;   // minimum of cy / cx over a tile relative to its first voxel (see LdsAffineParams::cmin)
+    int zc, nzc;             // output planes per chunk, chunks
+    int ntx, nty;            // tiles along x / y
+    int dbg;
+};
+
+struct ZSplit { int i0; float w1; bool in; };
+__device__ __forceinline__ ZSplit zs_split(double m0, double m3, int z, int nz)
+{
+    const C1Split s = c1_split(m0 * (double)z + m3, nz);
+    ZSplit r;
+    r.i0 = __builtin_amdgcn_readfirstlane(s.i0);
+    r.w1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s.w1)));
+    r.in = __builtin_amdgcn_readfirstlane((int)s.in) != 0;
+    return r;
+}
+
+// Input plane `pl` into ring slot (pl & 3) unless it is resident or outside the volume; ROUNDS DMAs per thread.  The
+// resident planes are a contiguous range [rlo, rhi] of at most four (two scalars: a tag per slot would be indexed by a
+// run-time slot number, i.e. live in scratch memory -- whose accesses count in vmcnt and would break the kernel's
+// hand-counted waits); a plane next to the range extends it (dropping the far end beyond four), any other plane
+// restarts it.
+template <int NT>
+__device__ __forceinline__ void zs_ensure(const float *in, int vol_bytes, int pl, int nz, int &rlo, int &rhi,
+                                          const unsigned (&rel)[kZsRoundsMax], int rounds, unsigned plane_b, unsigned org_b,
+                                          unsigned slot_bytes, int wave, bool off)
+{
+    if (pl < 0 || pl >= nz) return;
+    if (pl >= rlo && pl <= rhi) return;
+    if (pl == rhi + 1 && rhi >= rlo) { rhi = pl; if (rhi - rlo > 3) rlo = rhi - 3; }
+    else if (pl == rlo - 1 && rhi >= rlo) { rlo = pl; if (rhi - rlo > 3) rhi = rlo + 3; }
+    else { rlo = rhi = pl; }
+    const int sl = pl & 3;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)pl * plane_b + org_b);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)sl * slot_bytes + (unsigned)(wave << 6) * 16u);
+#pragma unroll
+    for (int j = 0; j < kZsRoundsMax; j++)
+        if (j < rounds && !off) dma_16s(rin, rel[j], base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * NT) * 16u));
+}
+
+template <int TY>
+__global__ void __launch_bounds__(TY * 8)
+affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, const ZStreamParams q)
+{
+    constexpr int NT = TY * 8;                         // threads = TY / 8 waves; a wave owns 8 output rows of 64 voxels
+    constexpr int P = kZsP;
+    extern __shared__ __attribute__((aligned(16))) char smem_zs[];
+    const FastInterpParams &p = q.f;
+    const unsigned slot_bytes = (((unsigned)q.nchunks + NT - 1) / NT) * NT * 16u;       // whole rounds of NT chunks
+    float *tiles = reinterpret_cast<float *>(smem_zs + 4u * slot_bytes);                // [NW][8 rows][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (tile x, tile y, z chunk): consecutive block indices go round the XCDs, so block b is given the
+    // tile whose index in (chunk, ty, tx) order is (b % 8) * (total / 8) + b / 8 when the grid divides by 8 -- every XCD
+    // then holds runs of x-neighbouring tiles, whose rectangles overlap, of the same chunk
+    const int total = q.ntx * q.nty * q.nzc;
+    int t = blockIdx.x;
+    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
+    const int tx_i = t % q.ntx, ty_i = (t / q.ntx) % q.nty, zc_i = t / (q.ntx * q.nty);
+    const int x0 = tx_i * 64, y0 = ty_i * TY;
+    const int zs = zc_i * q.zc, ze = min(zs + q.zc, p.oz);
+
+    // ---- the rectangle: origin from the tile's first voxel (closed form, a hair below the true minimum, clamped
+    // into the volume, x aligned down to 16 bytes), chunk -> byte offset from the origin once per thread
+    int borg[2];
+#pragma unroll
+    for (int a = 1; a <= 2; a++) {
+        const double lo = (p.m[4 * a + 1] * (double)y0 + p.m[4 * a + 2] * (double)x0) + (p.m[4 * a + 3] + (a == 1 ? q.cmin_y : q.cmin_x));
+        const int n = a == 1 ? p.ny : p.nx;
+        double f = floor(lo - 1e-6 * (1.0 + fabs(lo)));
+        f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
+        borg[a - 1] = __builtin_amdgcn_readfirstlane(a == 2 ? ((int)f & ~3) : (int)f);
+    }
+    const int by0 = borg[0], bx0 = borg[1];
+    const int rounds = (q.nchunks + NT - 1) / NT;
+    unsigned rel[kZsRoundsMax];
+#pragma unroll
+    for (int j = 0; j < kZsRoundsMax; j++) {
+        const unsigned ch = (unsigned)tid + (unsigned)(j * NT);
+        const unsigned row = ch / 20u, c4 = ch - row * 20u;
+        // rows past the rectangle are not fetched (0x80000000 fails the descriptor's range check: zeros)
+        rel[j] = ch < (unsigned)q.nchunks ? row * (unsigned)p.nx * 4u + c4 * 16u : 0x80000000u;
+    }
+    const unsigned plane_b = (unsigned)p.ny * (unsigned)p.nx * 4u;
+    const unsigned org_b = ((unsigned)by0 * (unsigned)p.nx + (unsigned)bx0) * 4u;
+
+    // ---- per-thread, per-(y, x): LDS byte offset of the lower-left tap, weights, in-plane range test.  Voxel k of a
+    // lane: row y0 + 8 wave + k, column x0 + lane.
+    int a_[8];
+    float wy_[8], wx_[8];
+    unsigned inmask = 0;
+    {
+        const double dx = (double)(x0 + lane);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double dy = (double)(y0 + 8 * wave + k);
+            // the oracle's order ((m0 z + m1 y) + m2 x) + offset with m0 = 0 for these two rows
+            const C1Split sy = c1_split((p.m[5] * dy + p.m[6] * dx) + p.m[7], p.ny);
+            const C1Split sx = c1_split((p.m[9] * dy + p.m[10] * dx) + p.m[11], p.nx);
+            const bool in = sy.in & sx.in;
+            inmask |= in ? (1u << k) : 0u;
+            a_[k] = in ? ((sy.i0 - by0) * P + (sx.i0 - bx0)) * 4 : 0;
+            wy_[k] = sy.w1; wx_[k] = sx.w1;
+        }
+    }
+    float *tile = tiles + wave * 512;
+    const bool wide = x0 + 64 <= p.ox && y0 + TY <= p.oy;      // block-uniform: 16-byte stores through the wave's LDS tile
+
+    // ---- the plane ring: slot (plane & 3) holds input plane `plane` for the planes of [rlo, rhi]
+    int rlo = 0, rhi = -1;                    // resident input planes (empty)
+    const int nz_ = p.nz, vol_bytes = p.nz * p.ny * p.nx * 4;
+    const double m0_ = p.m[0], m3_ = p.m[3];
+    const bool no_dma = (q.dbg & 1) != 0;
+#define ZS_ENSURE(PL) zs_ensure<NT>(in, vol_bytes, (PL), nz_, rlo, rhi, rel, rounds, plane_b, org_b, slot_bytes, wave, no_dma)
+    ZSplit cur = zs_split(m0_, m3_, zs, nz_);
+    if (cur.in) { ZS_ENSURE(cur.i0); ZS_ENSURE(cur.i0 + 1); }
+    const float cval = (float)p.cval;
+
+#pragma unroll 1
+    for (int z = zs; z < ze; z++) {
+        // the planes of this step have landed (the stores of the previous step, issued after their DMAs, may still be
+        // in flight: two per thread on full tiles), and everyone has finished reading the previous step's planes
+        if (wide) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ZSplit nxt = cur;
+        if (z + 1 < ze) {
+            nxt = zs_split(m0_, m3_, z + 1, nz_);
+            if (nxt.in) { ZS_ENSURE(nxt.i0); ZS_ENSURE(nxt.i0 + 1); }
+        }
+        float r[8];
+        if (cur.in && !(q.dbg & 2)) {
+            const char *lo_p = smem_zs + (unsigned)(cur.i0 & 3) * slot_bytes;
+            const char *hi_p = smem_zs + (unsigned)((cur.i0 + 1) & 3) * slot_bytes;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float *A = reinterpret_cast<const float *>(lo_p + a_[k]);
+                const float *B = reinterpret_cast<const float *>(hi_p + a_[k]);
+                Taps<float> t;
+                t.v[0] = A[0]; t.v[1] = A[1]; t.v[2] = A[P]; t.v[3] = A[P + 1];
+                t.v[4] = B[0]; t.v[5] = B[1]; t.v[6] = B[P]; t.v[7] = B[P + 1];
+                t.wz1 = cur.w1; t.wy1 = wy_[k]; t.wx1 = wx_[k];
+                t.oobmask = 0;
+                t.outside = !((inmask >> k) & 1u);
+                r[k] = finish<float>(t, cval);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = cval;
+        }
+        if (!(q.dbg & 4)) {
+            if (wide) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) tile[k * 64 + lane] = r[k];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int i = lane >> 4, c = lane & 15;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const f32x4n v = *reinterpret_cast<const f32x4n *>(tile + (4 * h + i) * 64 + 4 * c);
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)z * p.oy + (y0 + 8 * wave + 4 * h + i)) * p.ox + x0 + 4 * c));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the tile is rewritten next step
+            } else {
+                const int x = x0 + lane;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int y = y0 + 8 * wave + k;
+                    if (x < p.ox && y < p.oy) __builtin_nontemporal_store(r[k], out + ((size_t)z * p.oy + y) * p.ox + x);
+                }
+            }
+        }
+        cur = nxt;
+    }
+#undef ZS_ENSURE
+}
+
+Knob g_affine_zstream{1};     // test hook: 0 = off (box / gather kernels), 1 = auto (TY by LDS budget), 32 / 64 = that tile height
+Knob g_affine_zchunks{0};     // test hook: z chunks of the streaming kernel (0 = planner)
+
+// plan for the z-streaming kernel; false when the matrix / sizes are outside what it takes
+template <int TY>
+static bool zstream_plan(const FastInterpParams &p, ZStreamParams *q)
+{
+    const double *m = p.m;
+    if (m[1] != 0.0 || m[2] != 0.0 || m[4] != 0.0 || m[8] != 0.0) return false;        // axis 0 decoupled
+    if (!(fabs(m[0]) <= 2.0)) return false;                                              // four ring slots suffice
+    for (int i = 0; i < 12; i++) if (!(fabs(m[i]) < 1e9)) return false;
+    const int T[2] = {TY - 1, 63};
+    double ey = fabs(m[5]) * T[0] + fabs(m[6]) * T[1], ex = fabs(m[9]) * T[0] + fabs(m[10]) * T[1];
+    if (!(ey < 4096.0 && ex < 4096.0)) return false;
+    // samples floor(min - hair) .. floor(max) + 1: at most floor(ext + hair) + 3 (LdsAffineParams); x: the origin is
+    // aligned down by up to 3 samples
+    const int ry = (int)floor(ey * (1.0 + 1e-6) + 2e-3) + 3;
+    const int rx = (int)floor(ex * (1.0 + 1e-6) + 2e-3) + 3 + 3;
+    if (rx > kZsP) return false;
+    constexpr int NT = TY * 8;
+    const int nchunks = ry * (kZsP / 4);
+    if ((nchunks + NT - 1) / NT > kZsRoundsMax) return false;
+    const size_t slot = (size_t)((nchunks + NT - 1) / NT) * NT * 16;
+    if (4 * slot + (size_t)(TY / 8) * 2048 > 150 * 1024) return false;
+    q->f = p;
+    q->ry = ry;
+    q->nchunks = nchunks;
+    double cy = 0.0, cx = 0.0;
+    for (int j = 0; j < 2; j++) {
+        const double e1 = m[5 + j] * T[j], e2 = m[9 + j] * T[j];
+        if (e1 < 0.0) cy += e1;
+        if (e2 < 0.0) cx += e2;
+    }
+    q->cmin_y = cy; q->cmin_x = cx;
+    q->ntx = (p.ox + 63) / 64;
+    q->nty = (p.oy + TY - 1) / TY;
+    q->dbg = g_affine_dbg;
+    return true;
+}
+
+template <int TY>
+static int launch_affine_zstream(const float *in, float *out, ZStreamParams &q, hipStream_t s)
+{
+    constexpr int NT = TY * 8;
+    const FastInterpParams &p = q.f;
+    const size_t slot = (size_t)((q.nchunks + NT - 1) / NT) * NT * 16;
+    const size_t lds = 4 * slot + (size_t)(TY / 8) * 2048;
+    // z chunks: fill the chip (workgroups per CU by LDS) with chunks of >= 16 output planes
+    const int ncu = device_cus();
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 1024)));
+    const int tiles = q.ntx * q.nty;
+    int nzc = g_affine_zchunks > 0 ? (int)g_affine_zchunks : (ncu * per_cu + tiles - 1) / tiles;
+    nzc = std::max(1, std::min(nzc, (p.oz + 15) / 16));
+    q.zc = (p.oz + nzc - 1) / nzc;
+    q.nzc = (p.oz + q.zc - 1) / q.zc;
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_done = true;
+    }
+    note_kernel("mi::affine3d_zstream_kernel<%d> grid=%d (order-1 affine, axis 0 decoupled: streams along z, %d rows x %d staged per plane, %d z chunks)",
+                TY, tiles * q.nzc, q.ry, kZsP, q.nzc);
+    hipLaunchKernelGGL(affine3d_zstream_kernel<TY>, dim3((unsigned)(tiles * q.nzc)), dim3(NT), lds, s, in, out, q);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
 Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads, 3 = r3 with z-major voxel ownership, 5 = r3 (L1 gathers) without the LDS-staged affine kernel; 1 (default) and 4 use the LDS-staged affine kernel when the box fits, 6 = row-major ownership for map_coordinates, 7 = pair-sharing map_coordinates kernel (4 = LDS-staged map_coordinates)
 
 static bool fast_ok(const mi_array *in, const mi_array *out, int order)
@@ -1219,6 +1497,13 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
         (int64_t)p.oz * p.oy * p.ox >= (1 << 18)) {
         // gathers out of LDS when a tile's bounding box is small enough (decided from the matrix alone): the tile shape
         // with the smaller box of 64 x 8 x 8 and 32 x 16 x 8
+        // r4: matrices that leave axis 0 to itself stream along z (affine3d_zstream_kernel)
+        if (g_affine_zstream != 0) {
+            ZStreamParams zq;
+            const int want = g_affine_zstream;
+            if (want != 64 && zstream_plan<32>(p, &zq)) return launch_affine_zstream<32>((const float *)in->data, (float *)out->data, zq, s);
+            if (want != 32 && zstream_plan<64>(p, &zq)) return launch_affine_zstream<64>((const float *)in->data, (float *)out->data, zq, s);
+        }
         LdsAffineParams q64, q32;
         const long long f64 = lds_affine_plan(p, 64, &q64), f32 = (p.ox & 31) == 0 || p.ox > 256 ? lds_affine_plan(p, 32, &q32) : 0;
         int rc = MI_ERR_UNSUPPORTED;
@@ -1230,6 +1515,7 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
         const float *ip = (const float *)in->data;
         float *op = (float *)out->data;
         const dim3 gridz((unsigned)((p.ox + 63) / 64), (unsigned)((p.oy + 3) / 4), (unsigned)((p.oz + 3) / 4));
+        note_kernel("mi::affine3d_c1_kernel (order-1 affine, L1 gathers)");
         if (var == 3 && gridz.y <= 65535 && gridz.z <= 65535) hipLaunchKernelGGL((affine3d_c1_kernel<true, true>), gridz, block, 0, s, ip, op, p);
         else if (var == 2) hipLaunchKernelGGL((affine3d_c1_kernel<false, false>), grid, block, 0, s, ip, op, p);
         else hipLaunchKernelGGL((affine3d_c1_kernel<true, false>), grid, block, 0, s, ip, op, p);
@@ -1243,6 +1529,7 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
         else                                                                                                               \
             hipLaunchKernelGGL((affine3d_fast<double, FC, ORD>), grid, block, 0, s, (const double *)in->data, (double *)out->data, p); \
     } while (0)
+    note_kernel("mi::affine3d_fast (order %d)", order);
     if (mode == MI_MODE_CONSTANT && order == 1) MI_AFF(true, 1);
     else if (order == 1) MI_AFF(false, 1);
     else MI_AFF(false, 0);
@@ -1256,3 +1543,5 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
 extern "C" int mi_debug_set_interp_c1(int k) { mi::g_interp_c1 = k; return MI_OK; }
 extern "C" int mi_debug_set_affine_dbg(int k) { mi::g_affine_dbg = k; return MI_OK; }
 extern "C" int mi_debug_set_affine_gz(int k) { mi::g_affine_gz = k; return MI_OK; }
+extern "C" int mi_debug_set_affine_zstream(int k) { mi::g_affine_zstream = k; return MI_OK; }
+extern "C" int mi_debug_set_affine_zchunks(int k) { mi::g_affine_zchunks = k; return MI_OK; }

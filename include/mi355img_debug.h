@@ -57,6 +57,8 @@ int mi_debug_set_rank_median(int on);
 int mi_debug_set_u8_fused(int k);
 int mi_debug_set_interp_generic(int on);
 int mi_debug_set_affine_gz(int k);            /* LDS-staged affine kernel: workgroups along z (0 = one per tile; fewer = each walks several tiles of its column) */
+int mi_debug_set_affine_zstream(int k);       /* z-streaming affine kernel (axis 0 decoupled): 0 off, 1 auto, 32 / 64 tile height */
+int mi_debug_set_affine_zchunks(int k);       /* its z chunks (0 = planner) */
 int mi_debug_set_affine_dbg(int k);           /* LDS-staged affine kernel ablations: 1 no box DMA, 2 no interpolation, 4 no stores (timing only) */
 int mi_debug_set_interp_c1(int k);            /* csrc/interp_fast.hip: 0 = round-2 order-1 constant-mode kernels, 1 = r3 (default), 2 = r3, narrow stores */
 int mi_debug_set_spline_gain_first(int on);

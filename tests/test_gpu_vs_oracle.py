@@ -1401,13 +1401,20 @@ def test_affine_lds_staged_kernel(gpu, ndi):
         xd = gpu.asarray(x)
         oshape = shape if oshape is None else oshape
         outs = {}
-        for var in (1, 5):
-            lib.mi_debug_set_interp_c1(var)
-            try:
-                outs[var] = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75).get()
-            finally:
-                lib.mi_debug_set_interp_c1(1)
+        lib.mi_debug_set_affine_zstream(0)             # r4: matrices that leave axis 0 to itself would stream along z instead
+        try:
+            for var in (1, 5):
+                lib.mi_debug_set_interp_c1(var)
+                try:
+                    outs[var] = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75).get()
+                finally:
+                    lib.mi_debug_set_interp_c1(1)
+        finally:
+            lib.mi_debug_set_affine_zstream(1)
         assert np.array_equal(outs[1], outs[5], equal_nan=True), (shape, np.abs(outs[1] - outs[5]).max())
+        zs = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75).get()
+        assert np.array_equal(zs, outs[5], equal_nan=True), (shape, "default dispatch")
+        lib.mi_debug_set_affine_zstream(0)
         # workgroups that walk several tiles of a column (next origin computed one tile ahead): same voxels
         for gz in (1, 3):
             lib.mi_debug_set_affine_gz(gz)
@@ -1416,6 +1423,7 @@ def test_affine_lds_staged_kernel(gpu, ndi):
             finally:
                 lib.mi_debug_set_affine_gz(0)
             assert np.array_equal(walked, outs[1], equal_nan=True), (shape, gz)
+        lib.mi_debug_set_affine_zstream(1)
         ref = orc.affine_transform(x, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75)
         ok = np.isfinite(ref)
         assert np.array_equal(np.isfinite(outs[1]), ok), shape
@@ -1553,3 +1561,65 @@ def test_rank_filter_int64_beyond_2p53_follows_scipy(gpu, ndi):
         assert np.array_equal(ndi.rank_filter(gpu.asarray(v4), rank=5, size=(1, 3, 3, 3)).get(),
                               sndi.rank_filter(v4, rank=5, size=(1, 3, 3, 3)))
         assert np.array_equal(ndi.median_filter(gpu.asarray(v), size=(5, 5, 7)).get(), sndi.median_filter(v, size=(5, 5, 7)))
+
+
+# ------------------------------------------------------------------ r4: affine_transform streaming along z (axis 0 decoupled)
+def test_affine_zstream_kernel(gpu, ndi):
+    """Matrices that leave axis 0 to itself (in-plane rotation / shear / scaling + a scaling / shift through the slices:
+    BASELINE config D') stream along z (affine3d_zstream_kernel: in-plane addresses and weights once per workgroup, input
+    planes through a ring of four LDS slots).  Bit-identical to the L1-gather kernel (knob 5) for both tile heights and
+    several z chunkings; rotations up to 45 deg, slice steps of 0 / 0.5 / 1.02 / 1.7 / 2 / -1 (2.5 falls back), shifts that
+    push part of the output outside (cval), partial tiles, output shapes unlike the input's, non-finite samples; within
+    2e-6 of the oracle."""
+    from cupyimg_amd import _lib, last_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(400)
+
+    def inplane(deg, sy=1.0, sx=1.0, shear=0.0):
+        a = np.deg2rad(deg); c, s = np.cos(a), np.sin(a)
+        return np.array([[c * sy, -s * sx + shear], [s * sy, c * sx]])
+
+    def mat(m0, A):
+        M = np.zeros((3, 3)); M[0, 0] = m0; M[1:, 1:] = A
+        return M
+
+    cases = [
+        ((40, 72, 136), mat(1.02, inplane(7)), np.array([0.5, -1.25, 2.0]), (66, 70, 132), True),
+        ((64, 64, 64), mat(1.0, np.eye(2)), np.array([0.0, 0.0, 0.0]), None, True),
+        ((64, 64, 64), mat(1.0, np.eye(2)), np.array([3.0, -2.0, 5.0]), None, True),                 # integer shifts: exact boundary hits
+        ((33, 100, 130), mat(0.5, inplane(-20)), np.array([2.0, 40.0, -30.0]), (70, 96, 128), (1, 32)),   # 64-row tiles: rectangle wider than the pitch
+        ((80, 90, 100), mat(1.7, inplane(45)), np.array([-3.0, 60.0, -20.0]), (50, 128, 128), (1, 32)),
+        ((80, 64, 200), mat(2.0, inplane(0, 0.8, 1.1)), np.array([0.25, 1.0, 2.0]), (40, 80, 164), True),
+        ((64, 64, 64), mat(-1.0, inplane(180)), np.array([63.0, 63.0, 63.0]), None, True),            # flips: coordinates hit 0 and n - 1
+        ((20, 70, 90), mat(0.0, inplane(3, shear=0.1)), np.array([7.3, 1.0, -4.0]), (64, 64, 64), True),   # every output plane samples z = 7.3
+        ((90, 64, 64), mat(2.5, inplane(5)), np.zeros(3), (36, 64, 128), False),                       # |m00| > 2: box / gather kernels
+        ((64, 64, 64), mat(1.0, inplane(0, 1.3, 1.3)), np.zeros(3), (64, 64, 64), False),              # rectangle wider than the pitch
+        ((3, 5, 8), mat(0.04, np.diag([0.07, 0.05])), np.zeros(3), (64, 64, 64), True),                # input smaller than a rectangle
+    ]
+    for shape, M, off, oshape, takes in cases:
+        x = rng.standard_normal(shape).astype(np.float32)
+        if min(shape) > 12:
+            x[10, 9, 11] = np.inf; x[11, 12, 10] = np.nan
+        xd = gpu.asarray(x)
+        oshape = shape if oshape is None else oshape
+        lib.mi_debug_set_interp_c1(5)
+        try:
+            want = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75).get()
+        finally:
+            lib.mi_debug_set_interp_c1(1)
+        for ty in (1, 32, 64):
+            for zc in (0, 1, 3):
+                lib.mi_debug_set_affine_zstream(ty)
+                lib.mi_debug_set_affine_zchunks(zc)
+                try:
+                    got = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75).get()
+                    expect = takes if isinstance(takes, bool) else ty in takes
+                    assert ("zstream" in last_kernel()) == expect, (shape, ty, last_kernel())
+                finally:
+                    lib.mi_debug_set_affine_zstream(1)
+                    lib.mi_debug_set_affine_zchunks(0)
+                assert np.array_equal(got, want, equal_nan=True), (shape, ty, zc, float(np.nanmax(np.abs(got - want))))
+        ref = orc.affine_transform(x, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75)
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(want), ok), shape
+        assert np.allclose(want[ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref[ok]).max())), shape
