@@ -134,6 +134,7 @@ SIGNATURES = {
     "mi_comm_init_rank": [ctypes.POINTER(_vp), _i, _i, ctypes.c_char_p],
     "mi_comm_destroy": [_vp],
     "mi_halo_exchange": [_vp, _vp, _sz, ctypes.c_int64, _i, _i, _i, _i, _vp],
+    "mi_comm_sendrecv": [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _ip, _ip, _vp],
     "mi_slab_separable3d_f32": [_vp, _arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i, _i, _i, _i, _i,
                                 _vp, _vp, _vp, _vp],
     "mi_slab_pipe_create": [ctypes.POINTER(_vp), _vp, _i, ctypes.POINTER(_arr), _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d,

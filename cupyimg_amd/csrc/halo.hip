@@ -91,6 +91,22 @@ int mi_halo_exchange(mi_comm comm, void *slab, size_t plane_bytes, int64_t n_loc
     return MI_OK;
 }
 
+int mi_comm_sendrecv(mi_comm comm, int n, void *const ptrs[], const size_t nbytes[], const int peers[], const int is_send[],
+                     mi_stream stream)
+{
+    MI_REQUIRE(comm && n >= 0 && (n == 0 || (ptrs && nbytes && peers && is_send)), MI_ERR_INVALID_ARG, "bad argument");
+    hipStream_t s = resolve_stream(stream);
+    ncclComm_t c = (ncclComm_t)comm;
+    MI_NCCL(ncclGroupStart());
+    for (int i = 0; i < n; i++) {
+        if (nbytes[i] == 0) continue;
+        if (is_send[i]) MI_NCCL(ncclSend(ptrs[i], nbytes[i], ncclUint8, peers[i], c, s));
+        else MI_NCCL(ncclRecv(ptrs[i], nbytes[i], ncclUint8, peers[i], c, s));
+    }
+    MI_NCCL(ncclGroupEnd());
+    return MI_OK;
+}
+
 static constexpr size_t kOverlapMinHaloBytes = (size_t)8 << 20;   // per direction
 
 /* One filtering step of a slab rank with the exchange hidden behind the

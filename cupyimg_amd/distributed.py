@@ -169,6 +169,23 @@ class HaloComm:
                                         plan.lo, plan.hi, plan.prev, plan.next,
                                         None if stream is None else stream.handle))
 
+    def sendrecv(self, ops, stream=None):
+        """`ops`: [(device_array_view, peer, is_send)] -- C-contiguous views; all transfers in one RCCL group
+        (mi_comm_sendrecv).  Between two ranks the sends of one must come in the order of the other's receives."""
+        ops = [(a, int(peer), bool(snd)) for a, peer, snd in ops if a.nbytes]
+        n = len(ops)
+        if n == 0:
+            return
+        for a, _, _ in ops:
+            if not a._is_c_contiguous():
+                raise ValueError("sendrecv needs C-contiguous views")
+        ptrs = (ctypes.c_void_p * n)(*[a.ptr for a, _, _ in ops])
+        sizes = (ctypes.c_size_t * n)(*[a.nbytes for a, _, _ in ops])
+        peers = (ctypes.c_int * n)(*[p_ for _, p_, _ in ops])
+        snd = (ctypes.c_int * n)(*[1 if s_ else 0 for _, _, s_ in ops])
+        _lib.check(_lib.load().mi_comm_sendrecv(self._comm, n, ptrs, sizes, peers, snd,
+                                                None if stream is None else stream.handle))
+
     def close(self):
         if self._comm:
             _lib.load().mi_comm_destroy(self._comm)
@@ -179,6 +196,178 @@ class HaloComm:
             self.close()
         except Exception:
             pass
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Output-sharded interpolation (last sentence): map_coordinates / affine_transform have no
+# neighbourhood structure to exchange halos for -- the OUTPUT (and the coordinates) are partitioned by z-slabs, every
+# rank gathers from the input.  Either the input is replicated (each rank holds the whole volume: nothing to send), or
+# it is slab-distributed and each rank fetches ONCE the input planes its output planes read -- the pre-image slab,
+# known from the matrix (affine) or from the min / max of the rank's coordinates -- with point-to-point RCCL transfers
+# from the ranks that own them.  No collective, nothing communicated per voxel.
+# ----------------------------------------------------------------------------------------------------------------
+def interp_reach(order):
+    """(below, above): taps of an order-0 / order-1 interpolation relative to floor(coordinate)."""
+    if order not in (0, 1):
+        raise ValueError("the pre-image of spline orders >= 2 is the whole line (the prefilter is recursive): replicate the "
+                         "input or prefilter it first")
+    return (1, 1) if order == 0 else (0, 1)      # order 0 rounds: floor(c + 0.5) is floor(c) or floor(c) + 1
+
+
+def preimage_planes(cmin, cmax, nz, order=1, mode="constant"):
+    """[a, b): input planes along axis 0 that coordinates in [cmin, cmax] (axis 0) read.  Index-mapping modes fold a
+    coordinate outside the volume back inside -- anywhere: the pre-image is then the whole axis."""
+    if not (np.isfinite(cmin) and np.isfinite(cmax)):
+        return 0, int(nz)
+    below, above = interp_reach(order)
+    hair = 1e-6 * (1.0 + max(abs(cmin), abs(cmax)))
+    a = int(np.floor(cmin - hair)) - below
+    b = int(np.floor(cmax + hair)) + above + 1
+    if mode not in ("constant", "nearest", "grid-constant") and (a < 0 or b > nz):
+        return 0, int(nz)
+    a, b = max(a, 0), min(b, int(nz))
+    if b <= a:                                   # everything outside: one plane keeps the call well-formed
+        a = min(max(a, 0), int(nz) - 1)
+        b = a + 1
+    return a, b
+
+
+def affine_axis0_range(matrix, offset, out_shape, z0, z1):
+    """(cmin, cmax) of the axis-0 input coordinate over output planes z0 .. z1 - 1 of an affine_transform."""
+    m = np.asarray(matrix, dtype=np.float64)
+    off = np.asarray(offset, dtype=np.float64)
+    if m.ndim == 1:
+        m = np.diag(m)
+    lo = hi = float(off[0])
+    ext = [(z0, z1 - 1)] + [(0, int(n) - 1) for n in out_shape[1:]]
+    for j, (e0, e1) in enumerate(ext):
+        v0, v1 = m[0, j] * e0, m[0, j] * e1
+        lo += min(v0, v1)
+        hi += max(v0, v1)
+    return lo, hi
+
+
+class ShardedInterp:
+    """Output-sharded `affine_transform` / `map_coordinates` over the ranks of one node.
+
+    `out_plan`: SlabPlan of the OUTPUT planes (halo 0).  `in_plan`: SlabPlan of the INPUT planes when the input is
+    slab-distributed (rank r holds input planes in_plan.z0 .. z1), None when every rank holds the whole input.
+    `allgather(list_of_ints) -> list of per-rank lists` (host, e.g. torch.distributed.all_gather_object): only needed
+    for map_coordinates on a distributed input (each rank's pre-image depends on its own coordinates)."""
+
+    def __init__(self, out_plan, comm=None, in_plan=None, allgather=None):
+        self.out_plan, self.comm, self.in_plan, self.allgather = out_plan, comm, in_plan, allgather
+        if in_plan is not None and in_plan.nranks != out_plan.nranks:
+            raise ValueError("input and output plans differ in the number of ranks")
+
+    # ---- what touches the device, in one place each (tests/test_distributed_gloo.py runs the partition / pre-image /
+    # pairing logic above these on host arrays, with gloo as the transport and the CPU oracle as the kernel)
+    def _alloc(self, shape, dtype):
+        return core.empty(shape, dtype)
+
+    def _run_affine(self, src, m, off, shape, output, order, mode, cval, prefilter):
+        from .scipy import ndimage as ndi
+        return ndi.affine_transform(src, m, off, output_shape=shape, output=output, order=order, mode=mode, cval=cval,
+                                    prefilter=prefilter)
+
+    def _run_map(self, src, coordinates, output, order, mode, cval, prefilter):
+        from .scipy import ndimage as ndi
+        return ndi.map_coordinates(src, coordinates, output=output, order=order, mode=mode, cval=cval, prefilter=prefilter)
+
+    def _axis0_min_max(self, coordinates):
+        from .scipy.ndimage import _support as S
+        return S.min_max(coordinates[0])
+
+    def _shift_axis0(self, coordinates, a):
+        """the coordinates with axis 0 shifted by -a, as a new array (exact: a is an integer below the coordinate)"""
+        from .scipy.ndimage import _support as S
+        c = coordinates.copy()
+        c[0] = S.scale_shift(c[0], 1.0, -float(a))
+        return c
+
+    # ---- the pre-image slab of a distributed input
+    def _gather(self, local_in, needs):
+        """`needs[q] = (a, b)`: input planes rank q reads.  Returns (sub, a): this rank's planes a .. b as one
+        contiguous device array, fetched from their owners (one RCCL group; own planes by a device copy)."""
+        ip, r = self.in_plan, self.in_plan.rank
+        a, b = needs[r]
+        starts = np.concatenate([[0], np.cumsum(ip.counts)])
+        plane_shape = tuple(local_in.shape[1:])
+        sub = self._alloc((b - a,) + plane_shape, local_in.dtype)
+        ops = []
+        for q in range(ip.nranks):                              # ascending peer order on both sides of every pair
+            if q == r:
+                continue
+            qa, qb = needs[q]
+            s0, s1 = max(qa, ip.z0), min(qb, ip.z1)             # what q needs of mine
+            if s1 > s0:
+                ops.append((local_in[s0 - ip.z0:s1 - ip.z0], q, True))
+            g0, g1 = max(a, int(starts[q])), min(b, int(starts[q + 1]))      # what I need of q's
+            if g1 > g0:
+                ops.append((sub[g0 - a:g1 - a], q, False))
+        o0, o1 = max(a, ip.z0), min(b, ip.z1)
+        if o1 > o0:
+            sub[o0 - a:o1 - a] = local_in[o0 - ip.z0:o1 - ip.z0]
+        if ops:
+            if self.comm is None:
+                raise ValueError("a communicator is required to fetch input planes from other ranks")
+            self.comm.sendrecv(ops)
+        return sub, a
+
+    def affine_transform(self, input, matrix, offset=0.0, output_shape=None, output=None, order=1, mode="constant",
+                         cval=0.0, prefilter=True):
+        """This rank's planes (out_plan.z0 .. z1) of ``affine_transform(whole_input, matrix, offset, output_shape)``.
+        `input`: the whole volume (replicated input) or this rank's input slab (`in_plan` given).  `output_shape` is
+        the shape of the WHOLE output (default: the whole input's).  Distributed inputs: orders 0 and 1."""
+        op = self.out_plan
+        m = np.array(matrix.get() if isinstance(matrix, core.ndarray) else matrix, dtype=np.float64)
+        nd = input.ndim
+        off = np.full(nd, float(offset)) if np.isscalar(offset) else np.array(
+            offset.get() if isinstance(offset, core.ndarray) else offset, dtype=np.float64)
+        if m.ndim == 1:
+            m = np.diag(m)
+        if m.shape == (nd, nd + 1) or m.shape == (nd + 1, nd + 1):
+            off, m = m[:nd, nd].copy(), m[:nd, :nd].copy()
+        nz_in = self.in_plan.nz if self.in_plan is not None else input.shape[0]
+        if output_shape is None:
+            output_shape = (nz_in,) + tuple(input.shape[1:])
+        if int(output_shape[0]) != op.nz:
+            raise ValueError("output_shape[0] = {} but the output plan partitions {} planes".format(output_shape[0], op.nz))
+        local_shape = (op.n_local,) + tuple(int(v) for v in output_shape[1:])
+        off_local = off + m[:, 0] * op.z0                          # output plane k of this rank is global plane z0 + k
+        if self.in_plan is None:
+            src, a = input, 0
+            if order <= 1:
+                # a view of the planes this rank reads: smaller gathers' working set, same result (preimage_planes)
+                a, b = preimage_planes(*affine_axis0_range(m, off, output_shape, op.z0, op.z1), nz_in, order, mode)
+                src = input[a:b]
+        else:
+            needs = []
+            starts = np.concatenate([[0], np.cumsum(op.counts)])
+            for q in range(op.nranks):
+                needs.append(preimage_planes(*affine_axis0_range(m, off, output_shape, int(starts[q]), int(starts[q + 1])),
+                                             nz_in, order, mode))
+            src, a = self._gather(input, needs)
+        off_local = off_local.copy()
+        off_local[0] -= a                                          # coordinates in the frame of the planes held
+        return self._run_affine(src, m, off_local, local_shape, output, order, mode, cval, prefilter)
+
+    def map_coordinates(self, input, coordinates, output=None, order=1, mode="constant", cval=0.0, prefilter=True):
+        """This rank's part of ``map_coordinates(whole_input, whole_coordinates)``: `coordinates` are THIS rank's slab
+        of the coordinate array (ndim, n_local, ...).  Replicated input: a plain local call.  Distributed input
+        (`in_plan`): the rank's pre-image planes are fetched first (min / max of its axis-0 coordinates, all-gathered on
+        the host as two ints per rank)."""
+        if self.in_plan is None:
+            return self._run_map(input, coordinates, output, order, mode, cval, prefilter)
+        if self.allgather is None and self.in_plan.nranks > 1:
+            raise ValueError("map_coordinates on a distributed input needs `allgather`")
+        lo, hi = self._axis0_min_max(coordinates)
+        mine = [int(v) for v in preimage_planes(float(lo), float(hi), self.in_plan.nz, order, mode)]
+        needs = [tuple(v) for v in self.allgather(mine)] if self.in_plan.nranks > 1 else [tuple(mine)]
+        sub, a = self._gather(input, needs)
+        if a:
+            coordinates = self._shift_axis0(coordinates, a)      # the frame of the planes held
+        return self._run_map(sub, coordinates, output, order, mode, cval, prefilter)
 
 
 class SlabPipeline:
@@ -590,35 +779,80 @@ class SlabFilter:
     # slab (the halo planes are filtered too -- (lo + hi) / n_ext of wasted work, 3 % for config E -- and are scratch);
     # the min / max family can overlap the exchange (`overlap=True`) through plane-restricted launches.
 
-    def _minmax(self, name, size, mode, cval, origin, overlap=False):
+    def _minmax(self, name, size, mode, cval, origin, overlap=False, footprint=None, structure=None):
         from .scipy import ndimage as ndi
         from .scipy.ndimage import _support as S
-        sizes = [int(v) for v in S.normalize_sequence(size, 3)]
-        origins = [int(v) for v in S.normalize_sequence(origin, 3)]
+        nd = self.ext_in.ndim
+        if footprint is not None or structure is not None:
+            # window shape from the footprint / structure (filters.py:1373-1419, morphology.py:1091-1118); no overlap:
+            # only the flat cubic kernels take plane ranges
+            fp = None if footprint is None else S.as_host(footprint).astype(bool)
+            st = None if structure is None else S.as_host(structure)
+            shape = (fp if fp is not None else st).shape
+            if len(shape) != nd:
+                raise RuntimeError("footprint / structure and input must have the same dimensionality")
+            sizes = [int(v) for v in shape]
+            kw = {}
+            if fp is not None:
+                kw["footprint"] = fp
+            if st is not None:
+                kw["structure"] = st
+            overlap = False
+        else:
+            sizes = [int(v) for v in S.normalize_sequence(size, nd)]
+            kw = {"size": tuple(sizes)}
+        origins = [int(v) for v in S.normalize_sequence(origin, nd)]
         # grey dilation mirrors the window: its reach along axis 0 is that of the flipped kernel
         o0 = origins[0] if name != "grey_dilation" else -origins[0] - (1 if sizes[0] % 2 == 0 else 0)
         self.check_reach(sizes[0], o0)
         fn = getattr(ndi, name)
-        call = lambda a, b: fn(a, size=tuple(sizes), mode=mode, cval=cval, origin=tuple(origins), output=b)   # noqa: E731
+        call = lambda a, b: fn(a, mode=mode, cval=cval, origin=tuple(origins), output=b, **kw)   # noqa: E731
         # overlap=True: interior planes while the exchange is in flight, the planes next to a neighbour afterwards
         # (mi_minmax3d_u8_planes / mi_minmax3d_f32_planes: uint8 cubic 3 / 5 / 7, float32 cubic 3 .. 9); what those
         # kernels do not take falls back to the plain schedule inside step_overlapped
         key = (name, tuple(sizes), str(mode), float(cval), tuple(origins))
         return self.step_overlapped(call, key) if overlap else self.step(call)
 
-    def minimum_filter(self, size, mode="reflect", cval=0.0, origin=0, overlap=False):
-        """minimum_filter(size=...) of the distributed volume; returns this rank's planes."""
-        return self._minmax("minimum_filter", size, mode, cval, origin, overlap)
+    def minimum_filter(self, size=None, footprint=None, mode="reflect", cval=0.0, origin=0, overlap=False):
+        """minimum_filter(size=... | footprint=...) of the distributed volume; returns this rank's planes.  The halo
+        comes from the window's extent along axis 0 and the origin (checked against the plan)."""
+        return self._minmax("minimum_filter", size, mode, cval, origin, overlap, footprint=footprint)
 
-    def maximum_filter(self, size, mode="reflect", cval=0.0, origin=0, overlap=False):
-        return self._minmax("maximum_filter", size, mode, cval, origin, overlap)
+    def maximum_filter(self, size=None, footprint=None, mode="reflect", cval=0.0, origin=0, overlap=False):
+        return self._minmax("maximum_filter", size, mode, cval, origin, overlap, footprint=footprint)
 
-    def grey_erosion(self, size, mode="reflect", cval=0.0, origin=0, overlap=False):
-        """grey_erosion(size=...) (BASELINE config C's operation) of the distributed volume."""
-        return self._minmax("grey_erosion", size, mode, cval, origin, overlap)
+    def grey_erosion(self, size=None, footprint=None, structure=None, mode="reflect", cval=0.0, origin=0, overlap=False):
+        """grey_erosion (BASELINE config C's operation: size=7) of the distributed volume; flat (`size` / `footprint`)
+        or with a `structure`."""
+        return self._minmax("grey_erosion", size, mode, cval, origin, overlap, footprint=footprint, structure=structure)
 
-    def grey_dilation(self, size, mode="reflect", cval=0.0, origin=0, overlap=False):
-        return self._minmax("grey_dilation", size, mode, cval, origin, overlap)
+    def grey_dilation(self, size=None, footprint=None, structure=None, mode="reflect", cval=0.0, origin=0, overlap=False):
+        return self._minmax("grey_dilation", size, mode, cval, origin, overlap, footprint=footprint, structure=structure)
+
+    def _dense(self, convolution, weights, mode, cval, origin):
+        from .scipy import ndimage as ndi
+        from .scipy.ndimage import _support as S
+        w = S.as_host(weights)
+        nd = self.ext_in.ndim
+        if w.ndim != nd:
+            raise RuntimeError("filter weights array has incorrect shape.")
+        origins = [int(v) for v in S.normalize_sequence(origin, nd)]
+        # axis-0 reach from the weights' extent + origin (offset rule _filters_core.py:10-11); a convolution is the
+        # correlation with the flipped kernel, whose origin is -origin (one less for even lengths, filters.py:441-462)
+        n0 = int(w.shape[0])
+        o0 = origins[0] if not convolution else -origins[0] - (1 if n0 % 2 == 0 else 0)
+        self.check_reach(n0, o0)
+        fn = ndi.convolve if convolution else ndi.correlate
+        return self.step(lambda a, b: fn(a, w, output=b, mode=mode, cval=cval, origin=tuple(origins)))
+
+    def correlate(self, weights, mode="reflect", cval=0.0, origin=0):
+        """Dense n-D `correlate` (filters.py:65-136) of the distributed volume: one exchange of the planes the weights'
+        axis-0 extent reaches, then the single-GPU stencil on the extended slab; returns this rank's planes."""
+        return self._dense(False, weights, mode, cval, origin)
+
+    def convolve(self, weights, mode="reflect", cval=0.0, origin=0):
+        """Dense n-D `convolve` (filters.py:139-210) of the distributed volume."""
+        return self._dense(True, weights, mode, cval, origin)
 
     def _binary(self, name, structure, iterations, border_value, origin, any_changed):
         from .scipy import ndimage as ndi

@@ -428,6 +428,13 @@ int mi_comm_destroy(mi_comm comm);
 int mi_halo_exchange(mi_comm comm, void *slab, size_t plane_bytes, int64_t n_local, int lo,
                      int hi, int prev_rank, int next_rank, mi_stream stream);
 
+/* n point-to-point transfers in ONE RCCL group: ptrs[i] / nbytes[i] sent to (is_send[i] != 0) or received from rank
+ * peers[i].  Between one pair of ranks the sends of one side must come in the order of the receives of the other
+ * (RCCL matches them by order).  Used once per call by the output-sharded interpolation to fetch the input planes a
+ * rank's output planes read (the pre-image slab) -- not a collective, nothing in a timed step. */
+int mi_comm_sendrecv(mi_comm comm, int n, void *const ptrs[], const size_t nbytes[], const int peers[],
+                     const int is_send[], mi_stream stream);
+
 /* One filtering step of a slab rank: fused separable filter of the extended
  * slab [lo halo | local planes | hi halo] (a side without neighbour has no
  * halo planes) with the exchange overlapped:

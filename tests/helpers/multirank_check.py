@@ -172,6 +172,72 @@ def main():
     same(sf.binary_erosion(iterations=0, any_changed=any_changed).get(), sndi.binary_erosion(b, iterations=0)[plan.z0:plan.z1],
          "binary_erosion until stable")
 
+    # ---- 5. dense correlate with an even, shifted kernel; footprint minimum
+    nz = 32 * world + 5
+    x = rng.standard_normal((nz, 24, 64)).astype(np.float32)
+    w = rng.standard_normal((4, 3, 5))
+    for conv, origin in ((False, (1, 0, -1)), (True, (-2, 1, 0))):
+        o0 = origin[0] if not conv else -origin[0] - 1
+        lo, hi = D.halo_widths(4, o0)
+        plan, sf = slab_filter(x, lo, hi)
+        got = (sf.convolve if conv else sf.correlate)(w, mode="mirror", origin=origin).get()
+        ref = (sndi.convolve if conv else sndi.correlate)(x.astype(np.float64), w, mode="mirror", origin=origin)[plan.z0:plan.z1]
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        checks.append(("dense {} origin {} vs scipy {:.1e}".format("convolve" if conv else "correlate", origin, err), err <= 1e-6))
+        assert err <= 1e-6, (rank, conv, origin, err)
+    fp = rng.random((5, 3, 3)) > 0.3
+    fp[0, 1, 1] = fp[4, 1, 1] = True
+    u = rng.integers(0, 200, size=(nz, 24, 64)).astype(np.uint8)
+    plan, sf = slab_filter(u, 2, 2)
+    same(sf.minimum_filter(footprint=fp, mode="nearest").get(), sndi.minimum_filter(u, footprint=fp, mode="nearest")[plan.z0:plan.z1],
+         "minimum_filter footprint")
+
+    # ---- 6. output-sharded interpolation: replicated input and slab-distributed input (pre-image planes fetched from
+    # their owners with one group of RCCL send / recv)
+    def allgather(vals):
+        if dist is None:
+            return [list(vals)]
+        box = [None] * world
+        dist.all_gather_object(box, list(vals))
+        return box
+
+    nz = 40 * world + 3
+    x = rng.standard_normal((nz, 48, 128)).astype(np.float32)
+    oshape = (36 * world + 2, 48, 128)
+    ang = np.deg2rad(7.0)
+    mats = [(np.diag([1.02, 1.0, 1.0]) @ np.array([[1, 0, 0], [0, np.cos(ang), -np.sin(ang)], [0, np.sin(ang), np.cos(ang)]]),
+             np.array([0.5, -1.25, 2.0])),
+            (np.array([[0.9, 0.05, -0.02], [0.02, 1.0, 0.0], [0.0, 0.03, 0.95]]), np.array([-3.0, 0.4, 0.2])),
+            (np.diag([-1.0, 1.0, 1.0]), np.array([nz - 1.0, 0.0, 0.0]))]                 # flip: every rank needs the far end
+    in_plan = D.SlabPlan(nz, world, rank, 0, 0)
+    out_plan = D.SlabPlan(oshape[0], world, rank, 0, 0)
+    xd_full = ca.asarray(x)
+    xd_mine = ca.asarray(x[in_plan.z0:in_plan.z1])
+    for mi, (M, off) in enumerate(mats):
+        for order, mode in ((1, "constant"), (0, "nearest"), (1, "reflect")):
+            ref = sndi.affine_transform(x.astype(np.float64), M, off, output_shape=oshape, order=order, mode=mode, cval=0.25,
+                                        prefilter=False)[out_plan.z0:out_plan.z1]
+            rep = D.ShardedInterp(out_plan).affine_transform(xd_full, M, off, output_shape=oshape, order=order, mode=mode, cval=0.25).get()
+            dis = D.ShardedInterp(out_plan, comm, in_plan).affine_transform(xd_mine, M, off, output_shape=oshape, order=order,
+                                                                          mode=mode, cval=0.25).get()
+            same(dis, rep, "sharded affine {} order {} {}: distributed input == replicated input".format(mi, order, mode))
+            if order == 1:
+                err = float(np.abs(rep - ref).max() / max(1.0, np.abs(ref).max()))
+                checks.append(("sharded affine {} {} vs scipy {:.1e}".format(mi, mode, err), err <= 2e-6))
+                assert err <= 2e-6, (rank, mi, mode, err)
+    idx = np.indices((out_plan.n_local,) + oshape[1:]).reshape(3, -1).astype(np.float64)
+    idx[0] += out_plan.z0
+    M, off = mats[1]
+    coords = (M @ idx + off[:, None]).reshape((3, out_plan.n_local) + oshape[1:])
+    coords += 0.3 * np.sin(coords)
+    cd = ca.asarray(coords.astype(np.float32))
+    rep = D.ShardedInterp(out_plan).map_coordinates(xd_full, cd, order=1, mode="constant").get()
+    dis = D.ShardedInterp(out_plan, comm, in_plan, allgather).map_coordinates(xd_mine, cd, order=1, mode="constant").get()
+    same(dis, rep, "sharded map_coordinates: distributed input == replicated input")
+    ref = sndi.map_coordinates(x.astype(np.float64), coords.astype(np.float32), order=1, mode="constant", prefilter=False)
+    err = float(np.abs(rep - ref).max() / max(1.0, np.abs(ref).max()))
+    assert err <= 2e-6, (rank, err)
+
     if dist is not None:
         dist.barrier()
     ca.synchronize()

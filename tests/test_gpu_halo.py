@@ -436,3 +436,92 @@ def test_minmax_plane_ranges_and_overlapped_slab_step(gpu, ndi, self_comm):
     plain = sff.maximum_filter(5, mode="mirror").get()
     assert np.array_equal(sff.maximum_filter(5, mode="mirror", overlap=True).get(), plain)
     assert np.array_equal(sff.minimum_filter((5, 3, 3), overlap=True).get(), sff.minimum_filter((5, 3, 3)).get())   # falls back
+
+
+def test_slab_dense_correlate_and_footprint_filters(gpu, ndi, self_comm):
+    """SlabFilter.correlate / convolve / minimum_filter(footprint=) / grey_erosion(structure=) / grey_dilation(footprint=):
+    the halo follows from the window's axis-0 extent and origin (mirrored for convolutions and dilations), checked
+    against the plan; results on a closed one-rank chain equal the oracle with `wrap` along axis 0."""
+    from cupyimg_amd.distributed import SlabFilter, SlabPlan, halo_widths
+    rng = np.random.default_rng(70)
+    nz = 30
+    x = rng.standard_normal((nz, 20, 64)).astype(np.float32)
+    w = rng.standard_normal((4, 3, 5))
+    for conv, origin in [(False, (0, 0, 0)), (False, (1, 0, -1)), (True, (0, 0, 0)), (True, (-2, 1, 0))]:
+        o0 = origin[0] if not conv else -origin[0] - 1           # 4 taps along axis 0: even
+        lo, hi = halo_widths(4, o0)
+        sf = SlabFilter(SlabPlan.self_loop(nz, lo, hi), x.shape[1:], np.float32, self_comm)
+        sf.local_in[...] = gpu.asarray(x)
+        got = (sf.convolve if conv else sf.correlate)(w, mode="mirror", origin=origin).get()
+        # reference: the periodic continuation along axis 0 made explicit (the dense filters take ONE mode), cropped
+        xp = np.concatenate([x[-4:], x, x[:4]])
+        ref = (orc.convolve if conv else orc.correlate)(xp, w, mode="mirror", origin=origin)[4:4 + nz]
+        assert maxnorm_rel(got, ref) <= 1e-6, (conv, origin)
+        if lo > 0:
+            thin = SlabFilter(SlabPlan.self_loop(nz, lo - 1, hi), x.shape[1:], np.float32, self_comm)
+            with pytest.raises(ValueError):
+                (thin.convolve if conv else thin.correlate)(w, mode="mirror", origin=origin)
+    u = rng.integers(0, 200, size=(nz, 24, 64)).astype(np.uint8)
+    fp = rng.random((5, 3, 3)) > 0.3
+    fp[0, 1, 1] = fp[4, 1, 1] = True
+    st = rng.integers(0, 9, size=(3, 3, 3)).astype(np.float64)
+    sf = SlabFilter(SlabPlan.self_loop(nz, 3, 3), u.shape[1:], np.uint8, self_comm)
+    sf.local_in[...] = gpu.asarray(u)
+    def periodic(fn):                        # the closed chain = the periodic continuation along axis 0, made explicit
+        up = np.concatenate([u[-4:], u, u[:4]])
+        return fn(up)[4:4 + nz]
+    assert np.array_equal(sf.minimum_filter(footprint=fp, mode="nearest").get(),
+                          periodic(lambda a: orc.minimum_filter(a, footprint=fp, mode="nearest")))
+    assert np.array_equal(sf.maximum_filter(footprint=fp, mode="nearest", origin=(-1, 0, 0)).get(),
+                          periodic(lambda a: orc.maximum_filter(a, footprint=fp, mode="nearest", origin=(-1, 0, 0))))
+    assert np.array_equal(sf.grey_dilation(footprint=fp, mode="nearest", origin=(1, 0, 0)).get(),
+                          periodic(lambda a: orc.grey_dilation(a, footprint=fp, mode="nearest", origin=(1, 0, 0))))
+    assert np.array_equal(sf.grey_erosion(structure=st, mode="nearest").get(),
+                          periodic(lambda a: orc.grey_erosion(a, structure=st, mode="nearest")))
+    with pytest.raises(ValueError):
+        sf.minimum_filter(footprint=np.ones((9, 1, 1), bool))       # reach 4 > halo 3
+
+
+def test_sharded_interpolation_on_virtual_ranks(gpu, ndi):
+    """ShardedInterp with a replicated input: the output planes of four virtual ranks, computed one after the other on
+    this GPU (offset + M[:, 0] z0, the pre-image planes as a view), tile the unsplit call to float32 rounding (the
+    coordinates are re-based: measured <= 1 ulp); map_coordinates is bit-identical; the pre-image of every rank is far
+    smaller than the volume for a near-identity warp.  More than one real rank: tests/helpers/multirank_check.py."""
+    from cupyimg_amd.distributed import ShardedInterp, SlabPlan, affine_axis0_range, preimage_planes
+    rng = np.random.default_rng(80)
+    x = rng.standard_normal((96, 64, 128)).astype(np.float32)
+    xd = gpu.asarray(x)
+    ang = np.deg2rad(7.0)
+    M = np.diag([1.02, 1.0, 1.0]) @ np.array([[1, 0, 0], [0, np.cos(ang), -np.sin(ang)], [0, np.sin(ang), np.cos(ang)]])
+    off = np.array([0.5, -1.25, 2.0])
+    oshape = (90, 64, 128)
+    for order, mode in [(1, "constant"), (0, "nearest"), (1, "mirror"), (3, "constant")]:
+        full = ndi.affine_transform(xd, M, off, output_shape=oshape, order=order, mode=mode, cval=0.5).get()
+        parts = []
+        for r in range(4):
+            plan = SlabPlan(oshape[0], 4, r, 0, 0)
+            parts.append(ShardedInterp(plan).affine_transform(xd, M, off, output_shape=oshape, order=order, mode=mode, cval=0.5).get())
+            if order <= 1 and mode == "constant":
+                a, b = preimage_planes(*affine_axis0_range(M, off, oshape, plan.z0, plan.z1), x.shape[0], order, mode)
+                assert b - a <= plan.n_local * 1.02 + 4
+        got = np.concatenate(parts)
+        assert np.allclose(got, full, rtol=0, atol=(2e-5 if order == 3 else 1e-6) * max(1.0, np.abs(full).max())), (order, mode)
+    idx = np.indices(oshape).reshape(3, -1).astype(np.float64)
+    coords = (M @ idx + off[:, None]).reshape((3,) + oshape).astype(np.float32)
+    cd = gpu.asarray(coords)
+    full = ndi.map_coordinates(xd, cd, order=1, mode="constant").get()
+    parts = [ShardedInterp(SlabPlan(oshape[0], 4, r, 0, 0)).map_coordinates(
+        xd, gpu.asarray(np.ascontiguousarray(coords[:, SlabPlan(oshape[0], 4, r, 0, 0).z0:SlabPlan(oshape[0], 4, r, 0, 0).z1])),
+        order=1, mode="constant").get() for r in range(4)]
+    assert np.array_equal(np.concatenate(parts), full)
+    # the gather path on ONE rank ("distributed" input, no peers): coordinates that read planes 30 .. 60 only -- the
+    # pre-image planes are copied out, axis 0 of the coordinates is re-based by an integer: bit-identical
+    sub = np.ascontiguousarray(coords[:, 31:58])
+    sub[0] = np.clip(sub[0], 30.25, 59.5)
+    one = ShardedInterp(SlabPlan(sub.shape[1], 1, 0, 0, 0), in_plan=SlabPlan(x.shape[0], 1, 0, 0, 0))
+    got = one.map_coordinates(xd, gpu.asarray(sub), order=1, mode="constant").get()
+    assert np.array_equal(got, ndi.map_coordinates(xd, gpu.asarray(sub), order=1, mode="constant").get())
+    Mz, offz = np.diag([0.25, 1.0, 1.0]), np.array([40.0, 0.0, 0.0])                 # output planes 0 .. 31 read input planes 40 .. 48
+    one = ShardedInterp(SlabPlan(32, 1, 0, 0, 0), in_plan=SlabPlan(x.shape[0], 1, 0, 0, 0))
+    got = one.affine_transform(xd, Mz, offz, output_shape=(32, 64, 128), order=1, mode="constant").get()
+    assert np.array_equal(got, ndi.affine_transform(xd, Mz, offz, output_shape=(32, 64, 128), order=1, mode="constant").get())
