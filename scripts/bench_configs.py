@@ -9,8 +9,9 @@ Timing: 10 warm launches, then `reps` (default 40) back-to-back launches between
 HIP events -- long enough that the clocks have settled to the power budget (DESIGN.md,
 throttling note), i.e. the SUSTAINED number; `first_ms` is the mean of the first five
 launches of a cold burst for comparison.  `parity` compares the result of the timed
-call with scipy.ndimage on z sub-slabs (tests/helpers/fullsize.py; same checks as
-tests/test_gpu_baseline_full.py), outside the timed region.
+call with scipy.ndimage on EVERY plane (r4: z sub-slabs that tile the volume, over the host
+cores; tests/helpers/fullsize.py, the same checks as tests/test_gpu_baseline_full.py), outside
+the timed region.
 """
 import argparse
 import json
@@ -87,28 +88,28 @@ def main():
         out = ca.empty(xd.shape, np.float32)
     if "H" in only:
         t, t1 = timeit(lambda: ndi.uniform_filter(xd, size=5, output=out), a.reps)
-        p = {"parity": {"maxnorm_rel_vs_scipy": fs.check_filter_slabs(
-            x, out, 2, 2, lambda s: sndi.uniform_filter(s.astype(np.float64), size=5), fs.z_slabs(n, extra=(64, 128, 448))),
+        p = {"parity": {"maxnorm_rel_vs_scipy": fs.whole_volume_filter(
+            x, out.get(), 2, 2, lambda s: sndi.uniform_filter(s.astype(np.float64), size=5)), "planes": "all",
             "tol": 1e-6}} if par else None
         report("H", "uniform_filter size=5, 512^3 float32", n ** 3, 8, t, t1, p)
     if "B" in only:
         t, t1 = timeit(lambda: ndi.gaussian_filter(xd, sigma=2, output=out), a.reps)
-        p = {"parity": {"maxnorm_rel_vs_scipy": fs.check_filter_slabs(
-            x, out, 8, 8, lambda s: sndi.gaussian_filter(s.astype(np.float64), sigma=2), fs.z_slabs(n, extra=(128, 256, 384))),
+        p = {"parity": {"maxnorm_rel_vs_scipy": fs.whole_volume_filter(
+            x, out.get(), 8, 8, lambda s: sndi.gaussian_filter(s.astype(np.float64), sigma=2), planes=16), "planes": "all",
             "tol": 1e-6}} if par else None
         report("B", "gaussian_filter sigma=2 (17 taps/axis), 512^3 float32", n ** 3, 8, t, t1, p)
     if "D" in only or "Daff" in only:
         M, off = fs.affine_case(n)
         if "Daff" in only:
             t, t1 = timeit(lambda: ndi.affine_transform(xd, M, off, order=1, mode="constant", output=out), a.reps)
-            p = {"parity": {"abs_err_over_max1_vs_scipy": fs.check_affine_slabs(x, M, off, out, fs.z_slabs(n, width=4)),
-                            "tol": 2e-6}} if par else None
+            p = {"parity": {"abs_err_over_max1_vs_scipy": fs.whole_volume_affine(x, M, off, out.get()), "planes": "all",
+                            "tol": 2e-6}, "kernel": ca.last_kernel()[:90]} if par else {"kernel": ca.last_kernel()[:90]}
             report("D-affine", "affine_transform order=1 3-D warp, 512^3 float32", n ** 3, 8, t, t1, p)
         if "D" in only:
             coords = fs.affine_coords_f32(n)
             cd = ca.asarray(coords)
             t, t1 = timeit(lambda: ndi.map_coordinates(xd, cd, order=1, mode="constant", output=out), a.reps)
-            p = {"parity": {"abs_err_over_max1_vs_scipy": fs.check_map_coordinates_slabs(x, coords, out, fs.z_slabs(n, width=4)),
+            p = {"parity": {"abs_err_over_max1_vs_scipy": fs.whole_volume_map_coordinates(x, coords, out.get()), "planes": "all",
                             "tol": 2e-6}} if par else None
             report("D", "map_coordinates order=1 3-D affine warp, 512^3 float32 (+1.5 GiB coords)", n ** 3, 20, t, t1, p)
             del cd, coords
@@ -121,9 +122,9 @@ def main():
         ed = ca.asarray(xe)
         eo = ca.empty(shape, np.float32)
         t, t1 = timeit(lambda: ndi.uniform_filter(ed, size=9, output=eo), max(5, a.reps // 2))
-        p = {"parity": {"maxnorm_rel_vs_scipy": fs.check_filter_slabs(
-            xe, eo, 4, 4, lambda s: sndi.uniform_filter(s.astype(np.float64), size=9),
-            fs.z_slabs(shape[0], width=4, extra=(128, 256))), "tol": 1e-6}} if par else None
+        p = {"parity": {"maxnorm_rel_vs_scipy": fs.whole_volume_filter(
+            xe, eo.get(), 4, 4, lambda s: sndi.uniform_filter(s.astype(np.float64), size=9), planes=4), "planes": "all",
+            "tol": 1e-6}} if par else None
         report("E-slab", "uniform_filter size=9 on one rank's 264x2048x2048 float32 slab of the 2048^3 volume",
                shape[0] * shape[1] * shape[2], 8, t, t1, p)
         ed = eo = xe = None
@@ -136,8 +137,8 @@ def main():
         ud = ca.asarray(u)
         uo = ca.empty(ud.shape, np.uint8)
         t, t1 = timeit(lambda: ndi.grey_erosion(ud, size=7, output=uo), max(5, a.reps // 2))
-        p = {"parity": {"voxels_differing_from_scipy": fs.check_filter_slabs(
-            u, uo, 3, 3, lambda s: sndi.grey_erosion(s, size=7), fs.z_slabs(m, extra=(256, 512, 768)), exact=True),
+        p = {"parity": {"voxels_differing_from_scipy": fs.whole_volume_filter(
+            u, uo.get(), 3, 3, lambda s: sndi.grey_erosion(s, size=7), exact=True, planes=16), "planes": "all",
             "tol": 0}} if par else None
         report("C", "grey_erosion size=7, 1024^3 uint8", m ** 3, 2, t, t1, p)
 
