@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 N_SIDE = 512
 SIZE = 5
-HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); best streaming copy measured here: 6450 (copy_bw.hip)
 ALG_BYTES_PER_VOXEL = 8        # read 4 + write 4
 
 
@@ -50,7 +50,7 @@ def synth(shape, seed=0):
 
 
 SETTLE_LAUNCHES = 220        # ~ 40 ms of the 2 x 512 MiB copy kernel before the comparators are timed
-TRAFFIC_FILES = ("r3_traffic.json", "r2_traffic.json")
+TRAFFIC_FILES = ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json")
 
 
 def measured_traffic(world, config):
@@ -80,29 +80,35 @@ def last_kernel():
 
 
 def copy_kernel_ceiling(ca, xd, out):
-    """The in-tree float4 copy kernel (csrc/separable3d.hip copy_f4_kernel) on the same 2 x 512 MiB, best grid size:
-    the practical HBM ceiling of THIS box for the same byte count (hipMemcpy is a weaker comparator)."""
+    """The in-tree float4 copy kernels on the same 2 x 512 MiB, best grid size each: the practical HBM ceiling of THIS
+    box for the same byte count.  Returns ((GB/s, blocks) of the r4 copy -- four 16-byte loads in flight per thread,
+    loads and stores non-temporal, scripts/diag/copy_bw.hip -- and (GB/s, blocks) of the plain grid-stride copy the
+    earlier rounds priced against; hipMemcpy is a weaker comparator than either)."""
     import ctypes
     from cupyimg_amd import _lib
-    fn = _lib.load().mi_debug_copy_f32
-    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
-    best, best_blocks = None, None
-    # the clocks of a box settle after ~ 40 ms of load (profiles/r3_clock_settle.txt): the ceiling is a settled figure
-    for _ in range(SETTLE_LAUNCHES):
-        fn(xd.ptr, out.ptr, xd.size, 1024, None)
-    for blocks in (1024, 2048, 4096, 8192, 16384):
-        for _ in range(3):
-            fn(xd.ptr, out.ptr, xd.size, blocks, None)
-        e0, e1 = ca.Event(), ca.Event()
-        e0.record()
-        for _ in range(20):
-            fn(xd.ptr, out.ptr, xd.size, blocks, None)
-        e1.record()
-        ca.synchronize()
-        t = e0.elapsed_ms(e1) / 20 / 1e3
-        if best is None or t < best:
-            best, best_blocks = t, blocks
-    return 2 * xd.nbytes / best / 1e9, best_blocks
+    res = []
+    for name, grids in (("mi_debug_copy_f32_nt", (2048, 4096, 8192, 16384)), ("mi_debug_copy_f32", (1024, 2048, 4096, 8192, 16384))):
+        fn = getattr(_lib.load(), name)
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+        best, best_blocks = None, None
+        # the clocks of a box settle after ~ 40 ms of load (profiles/r3_clock_settle.txt): the ceiling is a settled figure
+        if not res:
+            for _ in range(SETTLE_LAUNCHES):
+                fn(xd.ptr, out.ptr, xd.size, grids[0], None)
+        for blocks in grids:
+            for _ in range(3):
+                fn(xd.ptr, out.ptr, xd.size, blocks, None)
+            e0, e1 = ca.Event(), ca.Event()
+            e0.record()
+            for _ in range(20):
+                fn(xd.ptr, out.ptr, xd.size, blocks, None)
+            e1.record()
+            ca.synchronize()
+            t = e0.elapsed_ms(e1) / 20 / 1e3
+            if best is None or t < best:
+                best, best_blocks = t, blocks
+        res.append((2 * xd.nbytes / best / 1e9, best_blocks))
+    return res
 
 
 def settle_device(ca, ms=40.0):
@@ -451,7 +457,7 @@ def main():
     cold = None
     if rank == 0 and cfg == "H" and world == 1 and not args.self_loop:
         cold = timed_region()
-        ck_gbs, ck_blocks = copy_kernel_ceiling(ca, xd, out)
+        (ck_gbs, ck_blocks), (ck_plain_gbs, ck_plain_blocks) = copy_kernel_ceiling(ca, xd, out)
         for _ in range(3):
             out[...] = xd
         c0, c1 = ca.Event(), ca.Event()
@@ -460,7 +466,8 @@ def main():
             out[...] = xd
         c1.record()
         ca.synchronize()
-        comparators = (ck_gbs, ck_blocks, ALG_BYTES_PER_VOXEL * (N_SIDE ** 3) / (c0.elapsed_ms(c1) / 10 / 1e3) / 1e9)
+        comparators = (ck_gbs, ck_blocks, ALG_BYTES_PER_VOXEL * (N_SIDE ** 3) / (c0.elapsed_ms(c1) / 10 / 1e3) / 1e9,
+                       ck_plain_gbs, ck_plain_blocks)
     else:
         settle_device(ca)
     elapsed, dev_ms = timed_region()
@@ -521,10 +528,13 @@ def main():
             # the practical ceiling of this box for the same 2 x 512 MiB: the in-tree float4 copy kernel (best grid)
             # and, for continuity with earlier rounds, a hipMemcpy device-to-device copy (both measured before the
             # timed region, see above)
-            ck_gbs, ck_blocks, copy_gbs = comparators
+            ck_gbs, ck_blocks, copy_gbs, ck_plain_gbs, ck_plain_blocks = comparators
             roofline["copy_kernel_GBps_same_bytes"] = round(ck_gbs, 1)
+            roofline["copy_kernel"] = "copy_f4_nt_kernel: 4 x 16-byte loads in flight per thread, non-temporal loads and stores (r4)"
             roofline["copy_kernel_blocks"] = ck_blocks
             roofline["frac_of_copy_kernel"] = round(achieved / ck_gbs, 4)
+            roofline["plain_copy_kernel_GBps_same_bytes"] = round(ck_plain_gbs, 1)      # the comparator of rounds 1-3
+            roofline["frac_of_plain_copy_kernel"] = round(achieved / ck_plain_gbs, 4)
             roofline["d2d_copy_GBps_same_bytes"] = round(copy_gbs, 1)
             roofline["frac_of_d2d_copy"] = round(achieved / copy_gbs, 4)
             roofline["comparators_measured"] = "before the warm-up steps, on the same buffers, after {} settling launches of the copy kernel (~40 ms)".format(SETTLE_LAUNCHES)

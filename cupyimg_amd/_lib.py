@@ -148,7 +148,9 @@ _RESTYPES = {"mi_last_error": ctypes.c_char_p}
 
 
 def library_path():
-    return _build.LIB
+    """The in-tree library; MI355IMG_LIB names another build of it (A/B timing of kernel variants in separate
+    processes -- a tuning aid, never a fallback: a path that does not load is an error)."""
+    return os.environ.get("MI355IMG_LIB") or _build.LIB
 
 
 def load():

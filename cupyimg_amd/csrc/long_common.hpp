@@ -17,32 +17,59 @@ constexpr int kLongHyBytes = 2 * kLongTY * 64;     // y-filtered halo blocks: [2
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
+// r4: which loads may be NON-TEMPORAL.  scripts/diag/copy_bw.hip: a 512 MiB -> 512 MiB copy with `nt` on the stores only
+// moves 6.0 TB/s on this chip, with `nt` on the loads as well 6.45 TB/s.  Marking EVERY staged row nt made the stencil
+// kernels slower (D' 197 -> 282 us, E-slab 1.61 -> 1.92 ms, C 407 -> 424 us: rows that a neighbouring workgroup re-reads a
+// moment later were no longer found in the L2), so only rows that no other workgroup reads take the hint: of a tile's
+// 16 + W - 1 staged rows those with index W - 1 .. 15 (MI_STREAM_NT = 1; 0 = none, the round-3 policy) -- and only
+// for volumes that cannot live in the 256 MiB Infinity Cache anyway: 512^3 float32 gains 9-13 % at 3 .. 9 taps
+// (uniform 5: 186 -> 169 us), while 256^3 (128 MiB in + out, MALL-resident when filtered repeatedly) LOST 20 % and
+// 64 x 1024^2 / 200 x 500 x 760 (0.5-0.6 GiB) 3-9 % (profiles/r4_stream_nt.txt): stream_nt_for().
+#ifndef MI_STREAM_NT
+#define MI_STREAM_NT 1
+#endif
+constexpr long long kStreamNtMinBytes = 768ll << 20;       // input + output bytes from which the hint is given: 3 x the MALL
+extern Knob g_stream_nt;                                   // test hook: -1 = by size (default), 0 = never, 1 = always
+inline int stream_nt_for(long long in_plus_out_bytes)
+{
+    const int k = g_stream_nt;
+    return k < 0 ? (in_plus_out_bytes >= kStreamNtMinBytes ? 1 : 0) : (k != 0);
+}
+
 // The four LDS-DMAs a wave issues per plane, as ONE statement (M0 = wave-uniform LDS destination, saved and
 // restored around it): row A (16 bytes per lane, destination rec + 16 * lane), its halo (4 bytes per lane, lanes
 // 0..15 only, at rec + 1024), then the same for row B, whose record lies 16 records further.
-__device__ __forceinline__ void dma_two_rows(u32x4_t rsrc, unsigned va, unsigned vha, unsigned vb, unsigned vhb, unsigned rec)
+#define MI_DMA_TWO_ROWS(NT_A)                                                                                         \
+    asm volatile(                                                                                                    \
+        "s_mov_b32 %0, m0\n\t"                                                                                       \
+        "s_mov_b32 m0, %6\n\t"                                                                                       \
+        "s_nop 0\n\t"                                                                                                \
+        "buffer_load_dwordx4 %1, %5, 0 offen" NT_A " lds\n\t"                                                        \
+        "s_add_u32 m0, m0, 0x400\n\t"                                                                                \
+        "s_mov_b64 exec, 0xffff\n\t"                                                                                 \
+        "buffer_load_dword %2, %5, 0 offen lds\n\t"                                                                  \
+        "s_mov_b64 exec, -1\n\t"                                                                                     \
+        "s_add_u32 m0, m0, %7\n\t"                                                                                   \
+        "s_nop 0\n\t"                                                                                                \
+        "buffer_load_dwordx4 %3, %5, 0 offen lds\n\t"                                                                \
+        "s_add_u32 m0, m0, 0x400\n\t"                                                                                \
+        "s_mov_b64 exec, 0xffff\n\t"                                                                                 \
+        "buffer_load_dword %4, %5, 0 offen lds\n\t"                                                                  \
+        "s_mov_b64 exec, -1\n\t"                                                                                     \
+        "s_mov_b32 m0, %0"                                                                                           \
+        : "=&s"(keep)                                                                                                \
+        : "v"(va), "v"(vha), "v"(vb), "v"(vhb), "s"(rsrc), "s"(rec), "n"(16 * kLongRec - 1024)                        \
+        : "memory", "scc")
+
+// nt_a (wave-uniform): row A is read by this workgroup only -> non-temporal
+__device__ __forceinline__ void dma_two_rows(u32x4_t rsrc, unsigned va, unsigned vha, unsigned vb, unsigned vhb, unsigned rec,
+                                             bool nt_a = false)
 {
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %6\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %5, 0 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_mov_b64 exec, 0xffff\n\t"
-        "buffer_load_dword %2, %5, 0 offen lds\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_add_u32 m0, m0, %7\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %3, %5, 0 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_mov_b64 exec, 0xffff\n\t"
-        "buffer_load_dword %4, %5, 0 offen lds\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(va), "v"(vha), "v"(vb), "v"(vhb), "s"(rsrc), "s"(rec), "n"(16 * kLongRec - 1024)
-        : "memory", "scc");
+#if MI_STREAM_NT
+    if (nt_a) { MI_DMA_TWO_ROWS(" nt"); return; }
+#endif
+    MI_DMA_TWO_ROWS("");
 }
 
 __device__ __forceinline__ float4 dpp4_shr(const float4 keep, const float4 v)

@@ -17,6 +17,7 @@
 namespace mi {
 
 struct MmLongParams {
+    int nt;                 // 1 = exclusive rows staged non-temporally (long_common.hpp)
     int nx, ny, nz;
     int oy, oz;             // w/2 + origin along y and z (x: W/2)
     int mx, my, mz;         // boundary modes (never constant)
@@ -109,7 +110,8 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
         rin.y = (unsigned)(a >> 32);
         rin.z = live ? plane_bytes : 0u;
         rin.w = 0x00020000u;
-        dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec);
+        // rows W - 1 .. 15 of the tile are read by this workgroup only: non-temporal (long_common.hpp)
+        dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec, p.nt && wave >= W - 1);
     };
 
     // y window of W consecutive records starting at LDS byte address `at` (one float4 per lane)
@@ -238,6 +240,7 @@ int run_minmax3d_f32_fused_planes(const float *in, float *out, int nz, int ny, i
     MmLongParams p;
     memset(&p, 0, sizeof(p));
     p.nx = nx; p.ny = ny; p.nz = nz;
+    p.nt = stream_nt_for((long long)nz * ny * nx * 8);
     p.oy = oy; p.oz = oz;
     p.mx = mx; p.my = my; p.mz = mz;
     p.nxt = (nx + 255) / 256;

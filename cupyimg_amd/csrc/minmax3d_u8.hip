@@ -18,10 +18,10 @@
 // of E and O plus one v_alignbit; sliding windows along x are built by
 // doubling (2, 4, then W), along the streamed axis from a register ring of the
 // previous W-1 samples that is rotated by unrolling.
-#include "sep_common.hpp"
-#include "stream3d.hpp"
+#include "long_common.hpp"       // stream_nt_for (+ sep_common.hpp, stream3d.hpp)
 
 namespace mi {
+
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -1091,6 +1091,7 @@ struct U8FusedParams {
     unsigned cval4;
     int zc, nzc, nxt, nyt;
     int zb, zn;             // output planes to produce: [zb, zb + zn) (0 / 0 = the whole volume); boundary handling refers to nz
+    int nt;                 // 1 = rows no other workgroup reads are loaded non-temporally (long_common.hpp, stream_nt_for)
 };
 
 constexpr int kU8MaxChunk = 2048;
@@ -1218,6 +1219,8 @@ mm3u8_split_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
 
         struct Regs { u32x2 v[R]; unsigned e; bool zconst; };
         Regs S[2];
+        // (sizes 3 and 5 gain 3 % on 1024^3; size 7 is bound by its VALU work and lost 1 %: not there)
+        const bool nt_wave = W <= 5 && p.nt != 0 && wave * R >= W - 1 && wave * R + R <= TY;
         auto issue = [&](int i, Regs &s) {
             int zsrc = zi0 + i;
             if ((unsigned)zsrc >= (unsigned)nz) zsrc = ztab[i];
@@ -1226,8 +1229,15 @@ mm3u8_split_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, co
             const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(in + (unsigned long long)(unsigned)zsrc * (unsigned long long)plane_bytes), 0, (int)plane_bytes, 0x00020000);
             const bool skip = HAS_CONST && s.zconst;
+            // r4: rows W - 1 .. TY - 1 of the staged window are read by this workgroup only (the y-neighbours' windows
+            // end at row W - 2 / start at row TY): a wave whose R rows all lie there loads them non-temporally
+            if (nt_wave) {
 #pragma unroll
-            for (int r = 0; r < R; r++) s.v[r] = __builtin_amdgcn_raw_buffer_load_b64(rin, skip ? kOOB : voff[r], 0, 0);
+                for (int r = 0; r < R; r++) s.v[r] = __builtin_amdgcn_raw_buffer_load_b64(rin, skip ? kOOB : voff[r], 0, 2);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) s.v[r] = __builtin_amdgcn_raw_buffer_load_b64(rin, skip ? kOOB : voff[r], 0, 0);
+            }
             s.e = __builtin_amdgcn_raw_buffer_load_b32(rin, skip ? kOOB : eoffv, 0, 0);
         };
 
@@ -1344,6 +1354,7 @@ static int launch_u8_split(const uint8_t *in, uint8_t *out, U8FusedParams &p, bo
     }
     p.nxt = (p.nx + 511) / 512;
     p.nyt = (p.ny + TY - 1) / TY;
+    p.nt = stream_nt_for(2ll * p.nx * p.ny * p.nz);
     const int cus = device_cus();
     const int64_t tiles = (int64_t)p.nxt * p.nyt;
     double best = 1e300;

@@ -54,6 +54,7 @@ struct LongParams {
     // sep3d_long3_kernel: plain weights padded with a zero (pairs starting at an even tap); wxo[2k] = wx[2k-1],
     // wxo[2k+1] = wx[2k] (pairs starting at an odd tap; wxo[0] = 0)
     float wyp[kStreamMaxTaps + 1], wzp[kStreamMaxTaps + 1], wxe[kStreamMaxTaps + 1], wxo[kStreamMaxTaps + 1];
+    int nt;                 // 1 = rows no other workgroup reads are staged non-temporally (long_common.hpp, stream_nt_for)
     int dbg;                // tuning ablations (0 in production): 1 y pass reads one row, 2 no x pass, 4 no z scatter, 8 no DMA, 16 no stores, 32 no halo table,
                             // 64 halo table at the end of the step (r3 kernel), 128 nothing (selects the ablation build)
 };
@@ -756,7 +757,15 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
         rin.y = (unsigned)(a >> 32);       // stride 0: the upper 16 bits of a device address are zero
         rin.z = live ? plane_bytes : 0u;
         rin.w = 0x00020000u;
-        if (!(dbg & 8)) dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec);
+        // staged rows W - 1 .. 15 of the tile are read by no other workgroup (the neighbours' windows end at row W - 2 /
+        // start at row 16): non-temporal (long_common.hpp); chunk-ramp planes are re-read by the next z chunk, rarely
+        // (up to 9 taps: the kernels that wait for memory; the longer ones are bound by what a wave issues, and the second
+        // copy of the DMA statement cost the 17-tap kernel 6 %)
+        if constexpr (W <= 9) {
+            if (!(dbg & 8)) dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec, p.nt && wave >= W - 1);
+        } else {
+            if (!(dbg & 8)) dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec);
+        }
     };
     constexpr int kArgBase = 2 * sizeof(void *);
     kfloats wyk = kernarg_floats(kArgBase + offsetof(LongParams, wyp));
@@ -1034,6 +1043,7 @@ bool long_aniso_pair(int w, int wzn)
     return false;
 }
 
+Knob g_stream_nt{-1};                  // long_common.hpp
 static mi::Knob g_long_zchunks{0};     // test hook: number of z chunks (0 = cost model)
 static mi::Knob g_long_same{1};        // test hook: 0 = always the reloading variant
 
@@ -1071,6 +1081,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, i
         sz += wz[k];
     }
     p.dbg = g_long_dbg;
+    p.nt = stream_nt_for((long long)nz * ny * nx * 8);
     p.cval = cval;
     p.cval_sum = (float)((double)cval * sx * sy * sz);
     {
@@ -1136,6 +1147,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, i
 
 }  // namespace mi
 
+extern "C" int mi_debug_set_stream_nt(int k) { mi::g_stream_nt = k; return MI_OK; }
 extern "C" int mi_debug_set_long_zchunks(int n) { mi::g_long_zchunks = n; return MI_OK; }
 extern "C" int mi_debug_set_long_same(int n) { mi::g_long_same = n; return MI_OK; }
 extern "C" int mi_debug_set_long_dbg(int f) { mi::g_long_dbg = f; return MI_OK; }

@@ -630,11 +630,32 @@ static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool h
 // ---------------------------------------------------------------------------
 // host side: kernel / tile selection
 // ---------------------------------------------------------------------------
-// plain float4 copy: the practical HBM ceiling on this chip for the same byte count
+// float4 copies: the practical HBM ceiling on this chip for the same byte count.  copy_f4_kernel is the plain grid-stride
+// copy of rounds 1-3 (5.8 TB/s); copy_f4_nt_kernel (r4, scripts/diag/copy_bw.hip) keeps four 16-byte loads in flight per
+// thread and marks loads AND stores non-temporal: 6.4-6.5 TB/s, the best streaming copy found on this chip (read only:
+// 6.5 TB/s, write only: 4.7-5.6 TB/s -- a 1 : 1 read / write stream cannot do better than ~6.5).
 __global__ void __launch_bounds__(256) copy_f4_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t n4)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = in[i];
+}
+typedef float f32x4nt __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) copy_f4_nt_kernel(const f32x4nt *__restrict__ in, f32x4nt *__restrict__ out, int64_t n4)
+{
+    const int64_t span = (int64_t)blockDim.x * 4;
+    for (int64_t b = (int64_t)blockIdx.x * span; b < n4; b += (int64_t)gridDim.x * span) {
+        f32x4nt v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = b + (int64_t)u * blockDim.x + threadIdx.x;
+            if (i < n4) v[u] = __builtin_nontemporal_load(in + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = b + (int64_t)u * blockDim.x + threadIdx.x;
+            if (i < n4) __builtin_nontemporal_store(v[u], out + i);
+        }
+    }
 }
 
 // general kernel (any odd taps <= 9 per axis, per-axis origins on y/z, >= 2 GiB
@@ -750,6 +771,13 @@ extern "C" int mi_debug_copy_f32(const float *in, float *out, int64_t n, int blo
 {
     hipLaunchKernelGGL(copy_f4_kernel, dim3(blocks), dim3(256), 0, resolve_stream(stream), (const float4 *)in,
                        (float4 *)out, n / 4);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+extern "C" int mi_debug_copy_f32_nt(const float *in, float *out, int64_t n, int blocks, mi_stream stream)
+{
+    hipLaunchKernelGGL(copy_f4_nt_kernel, dim3(blocks), dim3(256), 0, resolve_stream(stream), (const f32x4nt *)in,
+                       (f32x4nt *)out, n / 4);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }

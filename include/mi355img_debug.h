@@ -39,6 +39,7 @@ int mi_debug_stream_pass(const float *in, float *out, int nz, int ny, int nx, in
                          int oa, int ma, const float *wxv, int wx, int mx, float cval, mi_stream stream);
 /* plain float4 copy kernel (grid-stride, `blocks` workgroups of 256): the practical HBM ceiling for a byte count */
 int mi_debug_copy_f32(const float *in, float *out, int64_t n, int blocks, mi_stream stream);
+int mi_debug_copy_f32_nt(const float *in, float *out, int64_t n, int blocks, mi_stream stream);   /* r4: 4 loads in flight, non-temporal loads and stores */
 /* name of the last kernel the calling thread's separable-filter call dispatched ("" if none), NUL terminated */
 int mi_debug_last_kernel(char *buf, size_t n);
 
@@ -67,6 +68,7 @@ int mi_debug_set_spline_chunk(int n);
 int mi_debug_set_spline_rows(int k);
 int mi_debug_set_cubic_separable(int on);
 int mi_debug_set_cubic_diag(int on);
+int mi_debug_set_stream_nt(int k);             /* non-temporal staging of rows no other workgroup reads (sep3d_long3 <= 9 taps, mm3f32_long, mm3u8_split <= 5): -1 by volume size (default), 0 never, 1 always */
 int mi_debug_set_pipe_normal_priority(int on); /* slab pipeline: comm stream at normal instead of high priority (read by mi_slab_pipe_create) */
 
 #ifdef __cplusplus

@@ -79,14 +79,14 @@ def main():
     from cupyimg_amd import _lib
     prio = _lib.load().mi_debug_set_pipe_normal_priority
     prio.argtypes = [ctypes.c_int]
-    # (resident inputs, CUs reserved for the exchange kernels, comm stream priority)
-    variants = [(2, 0, "high"), (3, 0, "high"), (3, 0, "normal"), (2, 16, "high"), (3, 16, "high"), (3, 32, "high"), (3, 64, "high")]
-    for nbuf, reserve, pr in variants:
+    # (resident inputs, comm stream priority)
+    variants = [(2, "high"), (3, "high"), (3, "normal")]
+    for nbuf, pr in variants:
         prio(1 if pr == "normal" else 0)
-        pipe = sf.uniform_pipeline(a.size, nbuf=nbuf, reserve_cus=reserve)
+        pipe = sf.uniform_pipeline(a.size, nbuf=nbuf)
         for k in range(1, nbuf):
             pipe.inputs[k][...] = sf.ext_in
-        key = "pipelined_nbuf{}_reserve{}{}".format(nbuf, reserve, "_normalprio" if pr == "normal" else "")
+        key = "pipelined_nbuf{}{}".format(nbuf, "_normalprio" if pr == "normal" else "")
         res[key + "_direct_us"] = burst_us(ca, lambda n: pipe.run(n, 0), a.steps)
         if a.graphs:
             try:

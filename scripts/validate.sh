@@ -1,0 +1,24 @@
+#!/bin/bash
+# End-of-round validation on a GPU box (run through gpurun): the whole GPU suite, the bench lines (driver flags, defaults,
+# self-loop dry run of the N > 1 path, config E on one GPU), the per-config table with whole-volume parity, rocprofv3
+# kernel stats of both, a mid-size differential fuzz.  usage: scripts/validate.sh <tag>   -> gpurun_out/<tag>/
+TAG=${1:-validate}
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/$TAG; mkdir -p $O
+timeout 2400 python -m pytest tests -m gpu -q --maxfail=12 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" $O/pytest.log | tail -6
+timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"
+timeout 400 python bench.py > $O/bench_line_50steps.json 2>> $O/bench.err
+timeout 400 python bench.py --self-loop --steps 48 --warmup 10 > $O/bench_selfloop_dryrun.json 2>> $O/bench.err
+timeout 600 python bench.py --config E --steps 5 --warmup 2 > $O/bench_config_E_n1.json 2>> $O/bench.err
+cut -c1-1500 $O/bench_line.json; echo
+timeout 900 python scripts/bench_configs.py > $O/configs_bench.jsonl 2> $O/configs.err; cat $O/configs_bench.jsonl
+export TMPDIR=/tmp
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/cfgstats -o c -- python3 $GRAFT_REPO_ROOT/scripts/bench_configs.py --no-parity --reps 12 > /dev/null 2>&1)
+cp $O/cfgstats/*kernel_stats.csv $O/configs_kernel_stats.csv 2>/dev/null; cut -d, -f1-7 $O/configs_kernel_stats.csv | head -14
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/benchstats -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2>/dev/null)
+cp $O/benchstats/*kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null; cut -d, -f1-7 $O/bench_kernel_stats.csv | head -6
+rm -rf $O/cfgstats $O/benchstats
+timeout 300 python scripts/bench_slab_step.py --ranks 8 --graphs 1 2>/dev/null | grep "^{" > $O/slab_step_8.json; cut -c1-900 $O/slab_step_8.json
+FUZZ_BIG=1 timeout 260 python scripts/fuzz_vs_scipy.py 200 31337 2>&1 | tail -3 | tee $O/fuzz_big.txt
+timeout 200 python scripts/fuzz_vs_scipy.py 150 2026 2>&1 | tail -3 | tee $O/fuzz_2026.txt
