@@ -639,22 +639,21 @@ __global__ void __launch_bounds__(256) copy_f4_kernel(const float4 *__restrict__
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = in[i];
 }
-typedef float f32x4nt __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) copy_f4_nt_kernel(const f32x4nt *__restrict__ in, f32x4nt *__restrict__ out, int64_t n4)
+typedef unsigned int u32x4cp __attribute__((ext_vector_type(4)));
+// (buffer instructions: the same copy with global_load / global_store and the nt hint moves 6.0-6.25 TB/s, copy_bw.hip)
+__global__ void __launch_bounds__(256) copy_f4_nt_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t n4)
 {
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)(n4 * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)(n4 * 16), 0x00020000);
     const int64_t span = (int64_t)blockDim.x * 4;
     for (int64_t b = (int64_t)blockIdx.x * span; b < n4; b += (int64_t)gridDim.x * span) {
-        f32x4nt v[4];
+        u32x4cp v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int64_t i = b + (int64_t)u * blockDim.x + threadIdx.x;
-            if (i < n4) v[u] = __builtin_nontemporal_load(in + i);
-        }
+        for (int u = 0; u < 4; u++)       // beyond the end: the descriptor's range check (reads zero, writes nothing)
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(ri, (unsigned)(b + (int64_t)u * blockDim.x + threadIdx.x) * 16u, 0, 2);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int64_t i = b + (int64_t)u * blockDim.x + threadIdx.x;
-            if (i < n4) __builtin_nontemporal_store(v[u], out + i);
-        }
+        for (int u = 0; u < 4; u++)
+            __builtin_amdgcn_raw_buffer_store_b128(v[u], ro, (unsigned)(b + (int64_t)u * blockDim.x + threadIdx.x) * 16u, 0, 2);
     }
 }
 
@@ -776,8 +775,8 @@ extern "C" int mi_debug_copy_f32(const float *in, float *out, int64_t n, int blo
 }
 extern "C" int mi_debug_copy_f32_nt(const float *in, float *out, int64_t n, int blocks, mi_stream stream)
 {
-    hipLaunchKernelGGL(copy_f4_nt_kernel, dim3(blocks), dim3(256), 0, resolve_stream(stream), (const f32x4nt *)in,
-                       (f32x4nt *)out, n / 4);
+    MI_REQUIRE(n >= 0 && n * 4 < ((int64_t)1 << 32), MI_ERR_UNSUPPORTED, "copy comparator: arrays below 4 GiB");
+    hipLaunchKernelGGL(copy_f4_nt_kernel, dim3(blocks), dim3(256), 0, resolve_stream(stream), in, out, n / 4);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
