@@ -1140,12 +1140,24 @@ constexpr int kZsP = 80;                    // LDS row pitch (floats) of a stage
 constexpr int kZsRoundsMax = 8;             // staging rounds (NT chunks each) a plane rectangle can take
 
 struct ZStreamParams {
-    FastInterpParams f;
+    // The STREAM axis S (0 or 1) is the one the matrix leaves to itself; the plane it is streamed through has the ROW
+    // axis R (the other of 0 / 1) and x.  S = 0: planes are (y, x) slices, consecutive planes nx ny samples apart;
+    // S = 1: planes are (z, x) slices -- rows nx ny samples apart, consecutive planes one row (nx) apart.
+    int stream_axis;
+    int nS, nR, nx;          // input extents along S, R, x
+    int oS, oR, ox;          // output extents
+    unsigned in_sS, in_sR;   // input strides in samples (x stride 1)
+    size_t out_sS, out_sR;   // output strides in samples
+    int vol_bytes;           // input bytes (buffer range)
+    double mS, offS;         // cS = mS s + offS
+    double mRR, mRx, offR;   // cR = (mRR r + mRx x) + offR      (the oracle's summation order: the decoupled axis adds exact zeros)
+    double mxR, mxx, offx;   // cx = (mxR r + mxx x) + offx
+    double cval;
     int ry;                  // rows of the staged rectangle
     int nchunks;             // ry * 20
-    double cmin_y, cmin_x;   // minimum of cy / cx over a tile relative to its first voxel (see LdsAffineParams::cmin)
+    double cmin_y, cmin_x;   // minimum of cR / cx over a tile relative to its first voxel (see LdsAffineParams::cmin)
     int zc, nzc;             // output planes per chunk, chunks
-    int ntx, nty;            // tiles along x / y
+    int ntx, nty;            // tiles along x / R
     int dbg;
 };
 
@@ -1184,14 +1196,13 @@ __device__ __forceinline__ void zs_ensure(const float *in, int vol_bytes, int pl
         if (j < rounds && !off) dma_16s(rin, rel[j], base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * NT) * 16u));
 }
 
-template <int TY>
+template <int TY, int SAX>
 __global__ void __launch_bounds__(TY * 8)
 affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, const ZStreamParams q)
 {
     constexpr int NT = TY * 8;                         // threads = TY / 8 waves; a wave owns 8 output rows of 64 voxels
     constexpr int P = kZsP;
     extern __shared__ __attribute__((aligned(16))) char smem_zs[];
-    const FastInterpParams &p = q.f;
     const unsigned slot_bytes = (((unsigned)q.nchunks + NT - 1) / NT) * NT * 16u;       // whole rounds of NT chunks
     float *tiles = reinterpret_cast<float *>(smem_zs + 4u * slot_bytes);                // [NW][8 rows][64]
 
@@ -1205,15 +1216,16 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
     if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
     const int tx_i = t % q.ntx, ty_i = (t / q.ntx) % q.nty, zc_i = t / (q.ntx * q.nty);
     const int x0 = tx_i * 64, y0 = ty_i * TY;
-    const int zs = zc_i * q.zc, ze = min(zs + q.zc, p.oz);
+    const int zs = zc_i * q.zc, ze = min(zs + q.zc, q.oS);
 
     // ---- the rectangle: origin from the tile's first voxel (closed form, a hair below the true minimum, clamped
     // into the volume, x aligned down to 16 bytes), chunk -> byte offset from the origin once per thread
     int borg[2];
 #pragma unroll
     for (int a = 1; a <= 2; a++) {
-        const double lo = (p.m[4 * a + 1] * (double)y0 + p.m[4 * a + 2] * (double)x0) + (p.m[4 * a + 3] + (a == 1 ? q.cmin_y : q.cmin_x));
-        const int n = a == 1 ? p.ny : p.nx;
+        const double lo = a == 1 ? (q.mRR * (double)y0 + q.mRx * (double)x0) + (q.offR + q.cmin_y)
+                                 : (q.mxR * (double)y0 + q.mxx * (double)x0) + (q.offx + q.cmin_x);
+        const int n = a == 1 ? q.nR : q.nx;
         double f = floor(lo - 1e-6 * (1.0 + fabs(lo)));
         f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
         borg[a - 1] = __builtin_amdgcn_readfirstlane(a == 2 ? ((int)f & ~3) : (int)f);
@@ -1226,10 +1238,10 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
         const unsigned ch = (unsigned)tid + (unsigned)(j * NT);
         const unsigned row = ch / 20u, c4 = ch - row * 20u;
         // rows past the rectangle are not fetched (0x80000000 fails the descriptor's range check: zeros)
-        rel[j] = ch < (unsigned)q.nchunks ? row * (unsigned)p.nx * 4u + c4 * 16u : 0x80000000u;
+        rel[j] = ch < (unsigned)q.nchunks ? row * q.in_sR * 4u + c4 * 16u : 0x80000000u;
     }
-    const unsigned plane_b = (unsigned)p.ny * (unsigned)p.nx * 4u;
-    const unsigned org_b = ((unsigned)by0 * (unsigned)p.nx + (unsigned)bx0) * 4u;
+    const unsigned plane_b = q.in_sS * 4u;
+    const unsigned org_b = ((unsigned)by0 * q.in_sR + (unsigned)bx0) * 4u;
 
     // ---- per-thread, per-(y, x): LDS byte offset of the lower-left tap, weights, in-plane range test.  Voxel k of a
     // lane: row y0 + 8 wave + k, column x0 + lane.
@@ -1242,8 +1254,8 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
         for (int k = 0; k < 8; k++) {
             const double dy = (double)(y0 + 8 * wave + k);
             // the oracle's order ((m0 z + m1 y) + m2 x) + offset with m0 = 0 for these two rows
-            const C1Split sy = c1_split((p.m[5] * dy + p.m[6] * dx) + p.m[7], p.ny);
-            const C1Split sx = c1_split((p.m[9] * dy + p.m[10] * dx) + p.m[11], p.nx);
+            const C1Split sy = c1_split((q.mRR * dy + q.mRx * dx) + q.offR, q.nR);
+            const C1Split sx = c1_split((q.mxR * dy + q.mxx * dx) + q.offx, q.nx);
             const bool in = sy.in & sx.in;
             inmask |= in ? (1u << k) : 0u;
             a_[k] = in ? ((sy.i0 - by0) * P + (sx.i0 - bx0)) * 4 : 0;
@@ -1251,17 +1263,18 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
         }
     }
     float *tile = tiles + wave * 512;
-    const bool wide = x0 + 64 <= p.ox && y0 + TY <= p.oy;      // block-uniform: 16-byte stores through the wave's LDS tile
+    const bool wide = x0 + 64 <= q.ox && y0 + TY <= q.oR;      // block-uniform: 16-byte stores through the wave's LDS tile
 
     // ---- the plane ring: slot (plane & 3) holds input plane `plane` for the planes of [rlo, rhi]
     int rlo = 0, rhi = -1;                    // resident input planes (empty)
-    const int nz_ = p.nz, vol_bytes = p.nz * p.ny * p.nx * 4;
-    const double m0_ = p.m[0], m3_ = p.m[3];
+    const int nz_ = q.nS, vol_bytes = q.vol_bytes;
+    const double m0_ = q.mS, m3_ = q.offS;
+    constexpr bool s0 = SAX == 0;
     const bool no_dma = (q.dbg & 1) != 0;
 #define ZS_ENSURE(PL) zs_ensure<NT>(in, vol_bytes, (PL), nz_, rlo, rhi, rel, rounds, plane_b, org_b, slot_bytes, wave, no_dma)
     ZSplit cur = zs_split(m0_, m3_, zs, nz_);
     if (cur.in) { ZS_ENSURE(cur.i0); ZS_ENSURE(cur.i0 + 1); }
-    const float cval = (float)p.cval;
+    const float cval = (float)q.cval;
 
 #pragma unroll 1
     for (int z = zs; z < ze; z++) {
@@ -1284,9 +1297,14 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
                 const float *A = reinterpret_cast<const float *>(lo_p + a_[k]);
                 const float *B = reinterpret_cast<const float *>(hi_p + a_[k]);
                 Taps<float> t;
-                t.v[0] = A[0]; t.v[1] = A[1]; t.v[2] = A[P]; t.v[3] = A[P + 1];
-                t.v[4] = B[0]; t.v[5] = B[1]; t.v[6] = B[P]; t.v[7] = B[P + 1];
-                t.wz1 = cur.w1; t.wy1 = wy_[k]; t.wx1 = wx_[k];
+                // v[(z << 2) | (y << 1) | x]: the stream axis selects the slot (A / B), the row axis the LDS row
+                const float a00 = A[0], a01 = A[1], a10 = A[P], a11 = A[P + 1];
+                const float b00 = B[0], b01 = B[1], b10 = B[P], b11 = B[P + 1];
+                t.v[0] = a00; t.v[1] = a01;
+                t.v[2] = s0 ? a10 : b00; t.v[3] = s0 ? a11 : b01;
+                t.v[4] = s0 ? b00 : a10; t.v[5] = s0 ? b01 : a11;
+                t.v[6] = b10; t.v[7] = b11;
+                t.wz1 = s0 ? cur.w1 : wy_[k]; t.wy1 = s0 ? wy_[k] : cur.w1; t.wx1 = wx_[k];
                 t.oobmask = 0;
                 t.outside = !((inmask >> k) & 1u);
                 r[k] = finish<float>(t, cval);
@@ -1304,7 +1322,7 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const f32x4n v = *reinterpret_cast<const f32x4n *>(tile + (4 * h + i) * 64 + 4 * c);
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)z * p.oy + (y0 + 8 * wave + 4 * h + i)) * p.ox + x0 + 4 * c));
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + (size_t)z * q.out_sS + (size_t)(y0 + 8 * wave + 4 * h + i) * q.out_sR + x0 + 4 * c));
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the tile is rewritten next step
             } else {
@@ -1312,7 +1330,7 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const int y = y0 + 8 * wave + k;
-                    if (x < p.ox && y < p.oy) __builtin_nontemporal_store(r[k], out + ((size_t)z * p.oy + y) * p.ox + x);
+                    if (x < q.ox && y < q.oR) __builtin_nontemporal_store(r[k], out + (size_t)z * q.out_sS + (size_t)y * q.out_sR + x);
                 }
             }
         }
@@ -1324,16 +1342,21 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
 Knob g_affine_zstream{1};     // test hook: 0 = off (box / gather kernels), 1 = auto (TY by LDS budget), 32 / 64 = that tile height
 Knob g_affine_zchunks{0};     // test hook: z chunks of the streaming kernel (0 = planner)
 
-// plan for the z-streaming kernel; false when the matrix / sizes are outside what it takes
+// plan for the z-streaming kernel; false when the matrix / sizes are outside what it takes.  S = the decoupled axis
+// (0 or 1): row and column S of the matrix are zero except the diagonal entry.
 template <int TY>
-static bool zstream_plan(const FastInterpParams &p, ZStreamParams *q)
+static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
 {
     const double *m = p.m;
-    if (m[1] != 0.0 || m[2] != 0.0 || m[4] != 0.0 || m[8] != 0.0) return false;        // axis 0 decoupled
-    if (!(fabs(m[0]) <= 2.0)) return false;                                              // four ring slots suffice
+    const int R = 1 - S;
     for (int i = 0; i < 12; i++) if (!(fabs(m[i]) < 1e9)) return false;
+    for (int j = 0; j < 3; j++)
+        if (j != S && (m[4 * S + j] != 0.0 || m[4 * j + S] != 0.0)) return false;          // axis S decoupled
+    if (!(fabs(m[4 * S + S]) <= 2.0)) return false;                                         // four ring slots suffice
+    const int nin[3] = {p.nz, p.ny, p.nx}, nout[3] = {p.oz, p.oy, p.ox};
+    const double mRR = m[4 * R + R], mRx = m[4 * R + 2], mxR = m[8 + R], mxx = m[10];
     const int T[2] = {TY - 1, 63};
-    double ey = fabs(m[5]) * T[0] + fabs(m[6]) * T[1], ex = fabs(m[9]) * T[0] + fabs(m[10]) * T[1];
+    const double ey = fabs(mRR) * T[0] + fabs(mRx) * T[1], ex = fabs(mxR) * T[0] + fabs(mxx) * T[1];
     if (!(ey < 4096.0 && ex < 4096.0)) return false;
     // samples floor(min - hair) .. floor(max) + 1: at most floor(ext + hair) + 3 (LdsAffineParams); x: the origin is
     // aligned down by up to 3 samples
@@ -1345,18 +1368,25 @@ static bool zstream_plan(const FastInterpParams &p, ZStreamParams *q)
     if ((nchunks + NT - 1) / NT > kZsRoundsMax) return false;
     const size_t slot = (size_t)((nchunks + NT - 1) / NT) * NT * 16;
     if (4 * slot + (size_t)(TY / 8) * 2048 > 150 * 1024) return false;
-    q->f = p;
+    q->stream_axis = S;
+    q->nS = nin[S]; q->nR = nin[R]; q->nx = p.nx;
+    q->oS = nout[S]; q->oR = nout[R]; q->ox = p.ox;
+    q->in_sS = S == 0 ? (unsigned)p.ny * (unsigned)p.nx : (unsigned)p.nx;
+    q->in_sR = R == 0 ? (unsigned)p.ny * (unsigned)p.nx : (unsigned)p.nx;
+    q->out_sS = S == 0 ? (size_t)p.oy * p.ox : (size_t)p.ox;
+    q->out_sR = R == 0 ? (size_t)p.oy * p.ox : (size_t)p.ox;
+    q->vol_bytes = p.nz * p.ny * p.nx * 4;
+    q->mS = m[4 * S + S]; q->offS = m[4 * S + 3];
+    q->mRR = mRR; q->mRx = mRx; q->offR = m[4 * R + 3];
+    q->mxR = mxR; q->mxx = mxx; q->offx = m[11];
+    q->cval = p.cval;
     q->ry = ry;
     q->nchunks = nchunks;
-    double cy = 0.0, cx = 0.0;
-    for (int j = 0; j < 2; j++) {
-        const double e1 = m[5 + j] * T[j], e2 = m[9 + j] * T[j];
-        if (e1 < 0.0) cy += e1;
-        if (e2 < 0.0) cx += e2;
-    }
-    q->cmin_y = cy; q->cmin_x = cx;
+    const double e[4] = {mRR * T[0], mRx * T[1], mxR * T[0], mxx * T[1]};
+    q->cmin_y = (e[0] < 0.0 ? e[0] : 0.0) + (e[1] < 0.0 ? e[1] : 0.0);
+    q->cmin_x = (e[2] < 0.0 ? e[2] : 0.0) + (e[3] < 0.0 ? e[3] : 0.0);
     q->ntx = (p.ox + 63) / 64;
-    q->nty = (p.oy + TY - 1) / TY;
+    q->nty = (q->oR + TY - 1) / TY;
     q->dbg = g_affine_dbg;
     return true;
 }
@@ -1365,25 +1395,26 @@ template <int TY>
 static int launch_affine_zstream(const float *in, float *out, ZStreamParams &q, hipStream_t s)
 {
     constexpr int NT = TY * 8;
-    const FastInterpParams &p = q.f;
     const size_t slot = (size_t)((q.nchunks + NT - 1) / NT) * NT * 16;
     const size_t lds = 4 * slot + (size_t)(TY / 8) * 2048;
-    // z chunks: fill the chip (workgroups per CU by LDS) with chunks of >= 16 output planes
+    // chunks along the stream axis: fill the chip (workgroups per CU by LDS) with chunks of >= 16 output planes
     const int ncu = device_cus();
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 1024)));
     const int tiles = q.ntx * q.nty;
     int nzc = g_affine_zchunks > 0 ? (int)g_affine_zchunks : (ncu * per_cu + tiles - 1) / tiles;
-    nzc = std::max(1, std::min(nzc, (p.oz + 15) / 16));
-    q.zc = (p.oz + nzc - 1) / nzc;
-    q.nzc = (p.oz + q.zc - 1) / q.zc;
+    nzc = std::max(1, std::min(nzc, (q.oS + 15) / 16));
+    q.zc = (q.oS + nzc - 1) / nzc;
+    q.nzc = (q.oS + q.zc - 1) / q.zc;
     static bool attr_done = false;
     if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_done = true;
     }
-    note_kernel("mi::affine3d_zstream_kernel<%d> grid=%d (order-1 affine, axis 0 decoupled: streams along z, %d rows x %d staged per plane, %d z chunks)",
-                TY, tiles * q.nzc, q.ry, kZsP, q.nzc);
-    hipLaunchKernelGGL(affine3d_zstream_kernel<TY>, dim3((unsigned)(tiles * q.nzc)), dim3(NT), lds, s, in, out, q);
+    note_kernel("mi::affine3d_zstream_kernel<%d,%d> grid=%d (order-1 affine, axis %d decoupled: streams along it, %d rows x %d staged per plane, %d chunks)",
+                TY, q.stream_axis, tiles * q.nzc, q.stream_axis, q.ry, kZsP, q.nzc);
+    if (q.stream_axis == 0) hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 0>), dim3((unsigned)(tiles * q.nzc)), dim3(NT), lds, s, in, out, q);
+    else hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 1>), dim3((unsigned)(tiles * q.nzc)), dim3(NT), lds, s, in, out, q);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -1497,12 +1528,14 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
         (int64_t)p.oz * p.oy * p.ox >= (1 << 18)) {
         // gathers out of LDS when a tile's bounding box is small enough (decided from the matrix alone): the tile shape
         // with the smaller box of 64 x 8 x 8 and 32 x 16 x 8
-        // r4: matrices that leave axis 0 to itself stream along z (affine3d_zstream_kernel)
+        // r4: matrices that leave axis 0 (or axis 1) to itself stream along it (affine3d_zstream_kernel)
         if (g_affine_zstream != 0) {
             ZStreamParams zq;
             const int want = g_affine_zstream;
-            if (want != 64 && zstream_plan<32>(p, &zq)) return launch_affine_zstream<32>((const float *)in->data, (float *)out->data, zq, s);
-            if (want != 32 && zstream_plan<64>(p, &zq)) return launch_affine_zstream<64>((const float *)in->data, (float *)out->data, zq, s);
+            for (int S = 0; S < 2; S++) {
+                if (want != 64 && zstream_plan<32>(p, S, &zq)) return launch_affine_zstream<32>((const float *)in->data, (float *)out->data, zq, s);
+                if (want != 32 && zstream_plan<64>(p, S, &zq)) return launch_affine_zstream<64>((const float *)in->data, (float *)out->data, zq, s);
+            }
         }
         LdsAffineParams q64, q32;
         const long long f64 = lds_affine_plan(p, 64, &q64), f32 = (p.ox & 31) == 0 || p.ox > 256 ? lds_affine_plan(p, 32, &q32) : 0;

@@ -1565,7 +1565,7 @@ def test_rank_filter_int64_beyond_2p53_follows_scipy(gpu, ndi):
 
 # ------------------------------------------------------------------ r4: affine_transform streaming along z (axis 0 decoupled)
 def test_affine_zstream_kernel(gpu, ndi):
-    """Matrices that leave axis 0 to itself (in-plane rotation / shear / scaling + a scaling / shift through the slices:
+    """Matrices that leave axis 0 (or axis 1: the second block of cases) to itself (in-plane rotation / shear / scaling + a scaling / shift through the slices:
     BASELINE config D') stream along z (affine3d_zstream_kernel: in-plane addresses and weights once per workgroup, input
     planes through a ring of four LDS slots).  Bit-identical to the L1-gather kernel (knob 5) for both tile heights and
     several z chunkings; rotations up to 45 deg, slice steps of 0 / 0.5 / 1.02 / 1.7 / 2 / -1 (2.5 falls back), shifts that
@@ -1595,6 +1595,19 @@ def test_affine_zstream_kernel(gpu, ndi):
         ((90, 64, 64), mat(2.5, inplane(5)), np.zeros(3), (36, 64, 128), False),                       # |m00| > 2: box / gather kernels
         ((64, 64, 64), mat(1.0, inplane(0, 1.3, 1.3)), np.zeros(3), (64, 64, 64), False),              # rectangle wider than the pitch
         ((3, 5, 8), mat(0.04, np.diag([0.07, 0.05])), np.zeros(3), (64, 64, 64), True),                # input smaller than a rectangle
+    ]
+    # the same with axis 1 as the axis the matrix leaves to itself (rotations in the (z, x) plane): the kernel streams
+    # along y through (z, x) slices
+    def mat1(m1, A):
+        M = np.zeros((3, 3)); M[1, 1] = m1
+        M[0, 0], M[0, 2], M[2, 0], M[2, 2] = A[0, 0], A[0, 1], A[1, 0], A[1, 1]
+        return M
+    cases += [
+        ((72, 40, 136), mat1(1.02, inplane(7)), np.array([-1.25, 0.5, 2.0]), (70, 66, 132), True),
+        ((100, 33, 130), mat1(0.5, inplane(-20)), np.array([40.0, 2.0, -30.0]), (96, 70, 128), (1, 32)),
+        ((64, 64, 64), mat1(-1.0, inplane(180)), np.array([63.0, 63.0, 63.0]), None, True),
+        ((64, 80, 200), mat1(2.0, inplane(0, 0.8, 1.1)), np.array([1.0, 0.25, 2.0]), (80, 40, 164), True),
+        ((64, 90, 64), mat1(2.5, inplane(5)), np.zeros(3), (64, 36, 128), False),
     ]
     for shape, M, off, oshape, takes in cases:
         x = rng.standard_normal(shape).astype(np.float32)
