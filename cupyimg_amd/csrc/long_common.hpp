@@ -29,16 +29,16 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #define MI_STREAM_NT 1
 #endif
 constexpr long long kStreamNtMinBytes = 768ll << 20;       // input + output bytes from which the hint is given: 3 x the MALL
-extern Knob g_stream_nt;                                   // test hook: -1 = by size (default), 0 = never, 1 = always
-inline int stream_nt_for(long long in_plus_out_bytes)
+extern Knob g_stream_nt;                                   // test hook: -1 = by size and row width (default), 0 = never, 1 = always
+// `x_tiles`: tiles a row is cut into.  A row is also read -- 8 floats at either end -- by the x-neighbouring tiles' halo
+// loads; with one or two tiles per row those run next to it on the same XCD and still find the line, with four or eight
+// (1024 / 2048-wide rows) they do not, and the hint costs 4-11 % (profiles/r4_stream_nt.txt, second table).
+inline int stream_nt_for(long long in_plus_out_bytes, int x_tiles)
 {
     const int k = g_stream_nt;
-    return k < 0 ? (in_plus_out_bytes >= kStreamNtMinBytes ? 1 : 0) : (k != 0);
+    return k < 0 ? (in_plus_out_bytes >= kStreamNtMinBytes && x_tiles <= 2 ? 1 : 0) : (k != 0);
 }
 
-// The four LDS-DMAs a wave issues per plane, as ONE statement (M0 = wave-uniform LDS destination, saved and
-// restored around it): row A (16 bytes per lane, destination rec + 16 * lane), its halo (4 bytes per lane, lanes
-// 0..15 only, at rec + 1024), then the same for row B, whose record lies 16 records further.
 #define MI_DMA_TWO_ROWS(NT_A)                                                                                         \
     asm volatile(                                                                                                    \
         "s_mov_b32 %0, m0\n\t"                                                                                       \

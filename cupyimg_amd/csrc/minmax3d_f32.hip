@@ -240,10 +240,10 @@ int run_minmax3d_f32_fused_planes(const float *in, float *out, int nz, int ny, i
     MmLongParams p;
     memset(&p, 0, sizeof(p));
     p.nx = nx; p.ny = ny; p.nz = nz;
-    p.nt = stream_nt_for((long long)nz * ny * nx * 8);
     p.oy = oy; p.oz = oz;
     p.mx = mx; p.my = my; p.mz = mz;
     p.nxt = (nx + 255) / 256;
+    p.nt = stream_nt_for((long long)nz * ny * nx * 8, p.nxt);
     p.tw = (((nx + p.nxt - 1) / p.nxt) + 3) & ~3;          // equal tiles (see separable3d.hip)
     p.nyt = (ny + kLongTY - 1) / kLongTY;
     const int ncu = mm_long_cus();

@@ -1354,7 +1354,7 @@ static int launch_u8_split(const uint8_t *in, uint8_t *out, U8FusedParams &p, bo
     }
     p.nxt = (p.nx + 511) / 512;
     p.nyt = (p.ny + TY - 1) / TY;
-    p.nt = stream_nt_for(2ll * p.nx * p.ny * p.nz);
+    p.nt = stream_nt_for(2ll * p.nx * p.ny * p.nz, p.nxt);
     const int cus = device_cus();
     const int64_t tiles = (int64_t)p.nxt * p.nyt;
     double best = 1e300;

@@ -1081,7 +1081,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, i
         sz += wz[k];
     }
     p.dbg = g_long_dbg;
-    p.nt = stream_nt_for((long long)nz * ny * nx * 8);
+    p.nt = stream_nt_for((long long)nz * ny * nx * 8, p.nxt);
     p.cval = cval;
     p.cval_sum = (float)((double)cval * sx * sy * sz);
     {
