@@ -1419,6 +1419,338 @@ static int launch_affine_zstream(const float *in, float *out, ZStreamParams &q, 
     return MI_OK;
 }
 
+// ---------------------------------------------------------------------------
+// r4: map_coordinates, order 1, constant mode, float32 volumes -- STREAMS ALONG z with the taps out of LDS (config D).
+//
+// map_coords3d_c1_kernel is bound by the L1's tag pipeline (four 8-byte gathers per voxel, >= 16 cycles of the texture
+// addresser per wave instruction whatever its width); the r3 attempt to stage a box per tile in LDS lost to it because
+// a tile's two long-latency phases -- read the coordinates, reduce them to a box, THEN fetch the box -- ran one after the
+// other.  Here a workgroup owns a (y, x) tile and walks down a chunk of output planes, and the phases of consecutive
+// planes overlap:
+//     step z:  coordinates of plane z + 1 (loaded during step z - 1) -> integer parts, weights, bounding box (wave
+//              reductions + six LDS atomics per wave) -> the input planes / rectangle plane z + 1 needs are fetched by
+//              LDS-DMA into a ring of four plane slots;  the coordinates of plane z + 2 are requested;  plane z is
+//              interpolated from LDS (four ds_read2_b32 per voxel) with the splits made one step earlier.
+// All resident planes share one rectangle origin (RY = 48 rows of 80 samples: a 32 x 64 tile under rotations up to ~10
+// degrees with slack for the drift from plane to plane); a plane whose taps leave the rectangle re-centres it (its planes
+// are fetched after the current plane's taps have been read: "late"), a plane whose taps do not fit a rectangle or four
+// z slots at all -- coordinates with no structure -- takes the L1 gathers for that step.  Same splits, same in-range
+// tests, same blend as the other order-1 kernels: bit-identical results.
+// ---------------------------------------------------------------------------
+constexpr int kMzTY = 32, kMzNT = 256, kMzRY = 48;
+constexpr int kMzSlotBytes = ((kMzRY * 20 + kMzNT - 1) / kMzNT) * kMzNT * 16;       // whole rounds of 256 chunks: 16 KiB
+constexpr int kMzRounds = kMzSlotBytes / (kMzNT * 16);
+
+struct MapZParams {
+    FastInterpParams f;
+    int zc, nzc, ntx, nty;
+    int dbg;                 // 1 = no DMA, 2 = every step takes the L1 gathers (timing / test aid)
+};
+
+// wave-wide minimum / maximum of a float, result as a wave-uniform scalar: four DPP row shifts inside each row of 16 lanes
+// (lanes without a source keep their own value), then the four row results by v_readlane
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_reduce_f32(float v)
+{
+#define MI_DPP_STEP(CTRL)                                                                                              \
+    {                                                                                                                  \
+        const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), (CTRL), 0xf, 0xf, false)); \
+        v = IS_MAX ? fmaxf(v, o) : fminf(v, o);                                                                        \
+    }
+    MI_DPP_STEP(0x111) MI_DPP_STEP(0x112) MI_DPP_STEP(0x114) MI_DPP_STEP(0x118)          // row_shr:1, 2, 4, 8: lane 15 of a row holds the row's result
+#undef MI_DPP_STEP
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return IS_MAX ? fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)) : fminf(fminf(r0, r1), fminf(r2, r3));
+}
+
+__global__ void __launch_bounds__(kMzNT)
+map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restrict__ coords, float *__restrict__ out, const MapZParams q)
+{
+    constexpr int P = kZsP, RY = kMzRY, NT = kMzNT, TY = kMzTY;
+    static_assert(kMzSlotBytes == 16384, "the ring is addressed by bit arithmetic: slot = address bits 14 .. 15");
+    extern __shared__ __attribute__((aligned(16))) char smem_mz[];
+    float *stage = reinterpret_cast<float *>(smem_mz + 4 * kMzSlotBytes);            // [4 waves][3 axes x 4 rows x 64]: coordinates in, results out
+    int *ctl = reinterpret_cast<int *>(smem_mz + 4 * kMzSlotBytes + 4 * 3072);       // [2][8]: min z, y, x, max z, y, x (order-preserving ints)
+
+    const int nz = q.f.nz, ny = q.f.ny, nx = q.f.nx, oz = q.f.oz, oy = q.f.oy, ox = q.f.ox;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = q.ntx * q.nty * q.nzc;
+    int t = blockIdx.x;
+    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);          // x-neighbouring tiles on one XCD
+    const int tx_i = t % q.ntx, ty_i = (t / q.ntx) % q.nty, zc_i = t / (q.ntx * q.nty);
+    const int x0 = tx_i * 64, y0 = ty_i * TY;
+    const int zs = zc_i * q.zc, ze = min(zs + q.zc, oz);
+    const size_t nout = (size_t)oz * oy * ox;
+    const bool wide = x0 + 64 <= ox && y0 + TY <= oy;
+    const int vol_bytes = nz * ny * nx * 4;
+    const unsigned plane_b = (unsigned)ny * (unsigned)nx * 4u, row_b = (unsigned)nx * 4u;
+    const float cval = (float)q.f.cval;
+    float *my_stage = stage + wave * 768;
+    // a partial tile's last lanes read their own column of the clamped 16-byte coordinate load
+    const int col = wide ? lane : min(x0 + lane, ox - 1) - min(x0 + 4 * (lane >> 2), ox - 4) + 4 * (lane >> 2);
+
+    unsigned rel[kMzRounds];
+#pragma unroll
+    for (int j = 0; j < kMzRounds; j++) {
+        const unsigned ch = (unsigned)tid + (unsigned)(j * NT);
+        const unsigned row = ch / 20u, c4 = ch - row * 20u;
+        rel[j] = ch < (unsigned)(RY * 20) ? row * row_b + c4 * 16u : 0x80000000u;
+    }
+    if (tid < 16) ctl[tid] = (tid & 7) < 3 ? 0x7fffffff : 0;              // both sets: minima, then maxima (all values are >= 0)
+
+    // ---- coordinates of one output plane's tile: 16-byte loads (lane -> row lane / 16 of a batch of four, x = 4 (lane % 16))
+    struct Raw { f32x4n v[2][3]; };
+    auto load_coords = [&](int z, Raw &r) {
+        const int i = lane >> 4, c = lane & 15;
+#pragma unroll
+        for (int bt = 0; bt < 2; bt++) {
+            const int y = min(y0 + 8 * wave + 4 * bt + i, oy - 1);
+            const int xq = min(x0 + 4 * c, ox - 4);
+            const size_t o = ((size_t)z * oy + y) * ox + xq;
+#pragma unroll
+            for (int a = 0; a < 3; a++) r.v[bt][a] = __builtin_nontemporal_load(reinterpret_cast<const f32x4n *>(coords + a * nout + o));
+        }
+    };
+    // what a plane's voxels need: integer parts until the rectangle is known, then ONE byte offset (LDS: slot in bits 14-15;
+    // L1 path: offset into the volume), weights, in-range bits
+    struct Step { int a[8]; float wz[8], wy[8], wx[8]; unsigned inmask; int lds; };
+
+    // resident planes [rlo, rhi] (<= 4, slot = plane & 3), all staged with the rectangle origin (org_y, org_x)
+    int rlo = 0, rhi = -1, org_y = 0, org_x = 0;
+    auto ensure = [&](int pl) {
+        if (pl < 0 || pl >= nz) return;
+        if (pl >= rlo && pl <= rhi) return;
+        if (pl == rhi + 1 && rhi >= rlo) { rhi = pl; if (rhi - rlo > 3) rlo = rhi - 3; }
+        else if (pl == rlo - 1 && rhi >= rlo) { rlo = pl; if (rhi - rlo > 3) rhi = rlo + 3; }
+        else { rlo = rhi = pl; }
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
+        const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)pl * plane_b + (unsigned)org_y * row_b + (unsigned)org_x * 4u);
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(pl & 3) * (unsigned)kMzSlotBytes + (unsigned)(wave << 6) * 16u);
+#pragma unroll
+        for (int j = 0; j < kMzRounds; j++)
+            if (!(q.dbg & 1)) dma_16s(rin, rel[j], base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * NT) * 16u));
+    };
+
+    // ---- phase A of a plane: raw coordinates -> integer parts / weights (into `st`) + the workgroup's bounding box of the
+    // lower tap corners.  The box is reduced on the COORDINATES (v_min3 / v_max3, DPP, one pair of LDS atomics per axis and
+    // wave) and clamped into the volume afterwards: a coordinate outside only stretches the box outwards, which the clamp
+    // removes again; NaNs are ignored by min / max (their voxels blend to NaN whatever they read).
+    int need_lo[3], need_hi[3];
+    int iz_[8], iy_[8], ix_[8];
+    auto analyse = [&](const Raw &r, Step &st, int set) {
+        const int i = lane >> 4, c = lane & 15;
+        st.inmask = 0;
+        float cz[8], cy[8], cx[8];
+#pragma unroll
+        for (int bt = 0; bt < 2; bt++) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) *reinterpret_cast<f32x4n *>(my_stage + (a * 4 + i) * 64 + 4 * c) = r.v[bt][a];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                cz[4 * bt + kk] = my_stage[(0 * 4 + kk) * 64 + col];
+                cy[4 * bt + kk] = my_stage[(1 * 4 + kk) * 64 + col];
+                cx[4 * bt + kk] = my_stage[(2 * 4 + kk) * 64 + col];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const C1Split sz = c1_split(cz[k], nz), sy = c1_split(cy[k], ny), sx = c1_split(cx[k], nx);
+            iz_[k] = sz.i0; iy_[k] = sy.i0; ix_[k] = sx.i0;
+            st.wz[k] = sz.w1; st.wy[k] = sy.w1; st.wx[k] = sx.w1;
+            st.inmask |= (sz.in & sy.in & sx.in) ? (1u << k) : 0u;
+        }
+        auto lo8 = [](const float (&v)[8]) { return fminf(__builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]) < __builtin_fminf(__builtin_fminf(v[3], v[4]), v[5]) ? __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]) : __builtin_fminf(__builtin_fminf(v[3], v[4]), v[5]), fminf(v[6], v[7])); };
+        auto hi8 = [](const float (&v)[8]) { return fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]) > __builtin_fmaxf(__builtin_fmaxf(v[3], v[4]), v[5]) ? __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]) : __builtin_fmaxf(__builtin_fmaxf(v[3], v[4]), v[5]), fmaxf(v[6], v[7])); };
+        float lo[3] = {lo8(cz), lo8(cy), lo8(cx)}, hi[3] = {hi8(cz), hi8(cy), hi8(cx)};
+        int *cs = ctl + 8 * set;
+        const int nn[3] = {nz, ny, nx};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            // clamped to [0, n - 1] and floored: the lower tap corner of the extreme coordinates (ints >= 0)
+            float l = wave_reduce_f32<false>(lo[a]), h = wave_reduce_f32<true>(hi[a]);
+            l = fminf(fmaxf(l, 0.f), (float)(nn[a] - 1));
+            h = fminf(fmaxf(h, 0.f), (float)(nn[a] - 1));
+            if (lane == 0) { atomicMin(&cs[a], (int)l); atomicMax(&cs[3 + a], (int)h); }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            need_lo[a] = __builtin_amdgcn_readfirstlane(cs[a]);
+            need_hi[a] = __builtin_amdgcn_readfirstlane(cs[3 + a]);
+        }
+        // re-arm the OTHER set: its readers finished a step ago, its next atomics come after the next top barrier
+        if (tid < 6) ctl[8 * (set ^ 1) + tid] = tid < 3 ? 0x7fffffff : 0;
+    };
+
+    // ---- phase B: where do this plane's taps come from?  Returns 0 = LDS, planes fetched now; 1 = LDS, planes fetched after
+    // the current plane has been read (re-centred rectangle, or its planes would land on slots in use); 2 = L1 gathers
+    auto place = [&](int cur_zlo, int cur_zhi, bool cur_lds) {
+        if (q.dbg & 2) return 2;
+        const int nyy = need_hi[1] + 2 - need_lo[1], nxx = need_hi[2] + 2 - need_lo[2], nzz = need_hi[0] + 2 - need_lo[0];
+        if (nyy > RY || nxx > P - 3 || nzz > 4) return 2;
+        const bool covered = need_lo[1] >= org_y && need_hi[1] + 1 < org_y + RY && need_lo[2] >= org_x && need_hi[2] + 1 < org_x + P;
+        bool late = !covered || rhi < rlo;
+        if (late) {
+            int oyy = need_lo[1] - (RY - nyy) / 2, oxx = (need_lo[2] - (P - nxx) / 2) & ~3;
+            org_y = oyy < 0 ? 0 : oyy;
+            org_x = oxx < 0 ? 0 : oxx;
+            rlo = 0; rhi = -1;                                                    // the resident planes have the old origin
+        }
+        if (cur_lds && cur_zhi >= cur_zlo) {
+            const int ulo = min(cur_zlo, need_lo[0]), uhi = max(cur_zhi, need_hi[0] + 1);
+            if (uhi - ulo > 3) late = true;                                       // would overwrite a slot the current plane reads
+        }
+        return late ? 1 : 0;
+    };
+    auto fetch = [&]() {
+        for (int pl = need_lo[0]; pl <= need_hi[0] + 1; pl++) ensure(pl);
+    };
+    auto addresses = [&](int how, Step &st) {
+        st.lds = how != 2 ? 1 : 0;
+        if (how != 2) {
+            // in-range taps lie inside the rectangle by construction; anything else (a NaN coordinate: "inside", integer
+            // part 0) reads offset 0 -- its value does not matter (NaN weights) but its address must exist
+            const int org = org_y * P + org_x;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int off = (iy_[k] * P + ix_[k] - org) * 4;
+                const bool ok = ((st.inmask >> k) & 1u) && (unsigned)off < (unsigned)(RY * P * 4 - 4 * (P + 1));
+                st.a[k] = ok ? (((iz_[k] & 3) << 14) | off) : 0;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) st.a[k] = ((st.inmask >> k) & 1u) ? ((iz_[k] * ny + iy_[k]) * nx + ix_[k]) * 4 : 0;
+        }
+    };
+
+    // ---- prologue: plane zs analysed and fetched, coordinates of plane zs + 1 requested
+    Raw raw;
+    Step cur;
+    load_coords(zs, raw);
+    __syncthreads();                                                              // ctl initialised
+    analyse(raw, cur, 0);
+    int how = place(0, -1, false);
+    if (how != 2) fetch();
+    addresses(how, cur);
+    int cur_zlo = need_lo[0], cur_zhi = need_hi[0] + 1;
+    if (zs + 1 < ze) load_coords(zs + 1, raw);
+
+#pragma unroll 1
+    for (int z = zs; z < ze; z++) {
+        // the planes of this step have landed and the coordinates of the next are here (the two stores of the previous step,
+        // issued after them, may still be in flight on full tiles); everyone has finished reading the previous planes
+        if (wide) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        Step nxt = cur;
+        int nhow = 0, nzlo = 0, nzhi = -1;
+        const bool more = z + 1 < ze;
+        if (more) {
+            analyse(raw, nxt, (z + 1 - zs) & 1);
+            nhow = place(cur_zlo, cur_zhi, cur.lds != 0);
+            if (nhow == 0) fetch();
+            addresses(nhow, nxt);
+            nzlo = need_lo[0]; nzhi = need_hi[0] + 1;
+            if (z + 2 < ze) load_coords(z + 2, raw);
+        }
+        // ---- interpolate plane z
+        float r[8];
+        if (cur.lds) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int a_lo = cur.a[k];
+                const int a_hi = (a_lo + kMzSlotBytes) & 0xFFFF;                         // plane iz + 1 lives in slot (iz + 1) & 3
+                const float *A = reinterpret_cast<const float *>(smem_mz + a_lo);
+                const float *B = reinterpret_cast<const float *>(smem_mz + a_hi);
+                Taps<float> t;
+                t.v[0] = A[0]; t.v[1] = A[1]; t.v[2] = A[P]; t.v[3] = A[P + 1];
+                t.v[4] = B[0]; t.v[5] = B[1]; t.v[6] = B[P]; t.v[7] = B[P + 1];
+                t.wz1 = cur.wz[k]; t.wy1 = cur.wy[k]; t.wx1 = cur.wx[k];
+                t.oobmask = 0;
+                t.outside = !((cur.inmask >> k) & 1u);
+                r[k] = finish<float>(t, cval);
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                Taps<float> t[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int k = 4 * h + kk;
+                    const unsigned base = (unsigned)cur.a[k];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) load_pair(rin, base + (m >> 1) * plane_b + (m & 1) * row_b, t[kk].v[2 * m], t[kk].v[2 * m + 1]);
+                    t[kk].wz1 = cur.wz[k]; t[kk].wy1 = cur.wy[k]; t[kk].wx1 = cur.wx[k];
+                    t[kk].oobmask = 0;
+                    t[kk].outside = !((cur.inmask >> k) & 1u);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) r[4 * h + kk] = finish<float>(t[kk], cval);
+            }
+        }
+        if (wide) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) my_stage[k * 64 + lane] = r[k];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int i = lane >> 4, c = lane & 15;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const f32x4n v = *reinterpret_cast<const f32x4n *>(my_stage + (4 * h + i) * 64 + 4 * c);
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)z * oy + (y0 + 8 * wave + 4 * h + i)) * ox + x0 + 4 * c));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            const int x = x0 + lane;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int y = y0 + 8 * wave + k;
+                if (x < ox && y < oy) __builtin_nontemporal_store(r[k], out + ((size_t)z * oy + y) * ox + x);
+            }
+        }
+        if (more && nhow == 1) {
+            // late fetch: nobody reads the old planes any more
+            __builtin_amdgcn_s_barrier();
+            fetch();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        cur = nxt;
+        cur_zlo = nzlo; cur_zhi = nzhi;
+    }
+}
+
+Knob g_map_zstream{1};        // test hook: 0 = off (L1-gather kernel), 1 = on, 2 = on with every step on the L1 gathers
+Knob g_map_zchunks{0};
+
+static int launch_map_zstream(const float *in, const float *coords, float *out, const FastInterpParams &p, hipStream_t s)
+{
+    MapZParams q;
+    q.f = p;
+    q.ntx = (p.ox + 63) / 64;
+    q.nty = (p.oy + kMzTY - 1) / kMzTY;
+    const size_t lds = 4 * (size_t)kMzSlotBytes + 4 * 3072 + 64;
+    const int ncu = device_cus();
+    const int tiles = q.ntx * q.nty;
+    int nzc = g_map_zchunks > 0 ? (int)g_map_zchunks : (4 * ncu + tiles - 1) / tiles;      // two workgroups per CU, two rounds (measured: 538 vs 547 us on config D)
+    nzc = std::max(1, std::min(nzc, (p.oz + 15) / 16));
+    q.zc = (p.oz + nzc - 1) / nzc;
+    q.nzc = (p.oz + q.zc - 1) / q.zc;
+    q.dbg = (g_affine_dbg & 1) | (g_map_zstream == 2 ? 2 : 0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI_HIP(hipFuncSetAttribute((const void *)map_coords3d_zstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_done = true;
+    }
+    note_kernel("mi::map_coords3d_zstream_kernel grid=%d (order-1 map_coordinates: streams along z, taps out of LDS, %d z chunks)", tiles * q.nzc, q.nzc);
+    hipLaunchKernelGGL(map_coords3d_zstream_kernel, dim3((unsigned)(tiles * q.nzc)), dim3(kMzNT), lds, s, in, coords, out, q);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
 Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads, 3 = r3 with z-major voxel ownership, 5 = r3 (L1 gathers) without the LDS-staged affine kernel; 1 (default) and 4 use the LDS-staged affine kernel when the box fits, 6 = row-major ownership for map_coordinates, 7 = pair-sharing map_coordinates kernel (4 = LDS-staged map_coordinates)
 
 static bool fast_ok(const mi_array *in, const mi_array *out, int order)
@@ -1463,6 +1795,9 @@ int map_coordinates_fast(const mi_array *in, const mi_array *coords, const mi_ar
         // knob 4 only: gathers out of an LDS-staged box found per workgroup (map_coords3d_lds_kernel).  Measured on config D:
         // 773 us against 608 us for the L1 gathers below -- two dependent long-latency phases per tile (coordinates, then
         // the box) with two workgroups per CU (118 VGPRs) leave the CU idle; kept for the record, not the default.
+        // r4: the z-streaming kernel (taps out of LDS, phases of consecutive planes overlapped)
+        if (g_map_zstream != 0 && (var == 1) && p.ox >= 64 && (int64_t)p.oz * p.oy * p.ox >= (1 << 18))
+            return launch_map_zstream(ip, cp, op, p, s);
         const dim3 gridl((unsigned)((p.ox + 31) / 32), (unsigned)((p.oy + 15) / 16), (unsigned)((p.oz + 7) / 8));
         if (var == 4 && (int64_t)p.oz * p.oy * p.ox >= (1 << 18) && gridl.y <= 65535 && gridl.z <= 65535) {
             hipLaunchKernelGGL(map_coords3d_lds_kernel, gridl, dim3(512), 0, s, ip, cp, op, p);
@@ -1576,5 +1911,7 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
 extern "C" int mi_debug_set_interp_c1(int k) { mi::g_interp_c1 = k; return MI_OK; }
 extern "C" int mi_debug_set_affine_dbg(int k) { mi::g_affine_dbg = k; return MI_OK; }
 extern "C" int mi_debug_set_affine_gz(int k) { mi::g_affine_gz = k; return MI_OK; }
+extern "C" int mi_debug_set_map_zstream(int k) { mi::g_map_zstream = k; return MI_OK; }
+extern "C" int mi_debug_set_map_zchunks(int k) { mi::g_map_zchunks = k; return MI_OK; }
 extern "C" int mi_debug_set_affine_zstream(int k) { mi::g_affine_zstream = k; return MI_OK; }
 extern "C" int mi_debug_set_affine_zchunks(int k) { mi::g_affine_zchunks = k; return MI_OK; }

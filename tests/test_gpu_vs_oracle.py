@@ -1636,3 +1636,65 @@ def test_affine_zstream_kernel(gpu, ndi):
         ok = np.isfinite(ref)
         assert np.array_equal(np.isfinite(want), ok), shape
         assert np.allclose(want[ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref[ok]).max())), shape
+
+
+# ------------------------------------------------------------------ r4: map_coordinates streaming along z (taps out of LDS)
+def test_map_coordinates_zstream_kernel(gpu, ndi):
+    """Outputs of >= 2^18 voxels with >= 64 columns take map_coords3d_zstream_kernel (order 1, `constant`, float32): a
+    workgroup walks down its chunk of output planes, the bounding box of every plane's taps is reduced from the
+    coordinates one plane ahead, the input planes come through a ring of four LDS slots with one shared rectangle.
+    Bit-identical to the L1-gather kernel (knob 0) for smooth warps (rotation, zoom in / out, drift that re-centres the
+    rectangle), for warps whose planes do not fit (every step falls back to the L1 gathers: tall rotations, z-mixing,
+    random coordinates), coordinates outside the volume on every side, NaN / inf coordinates, partial tiles, several z
+    chunkings; knob 2 forces the fallback path for every step."""
+    from cupyimg_amd import _lib, last_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(500)
+    shape = (40, 90, 150)
+    x = rng.standard_normal(shape).astype(np.float32)
+    x[7, 8, 9] = np.inf; x[11, 12, 13] = np.nan
+    xd = gpu.asarray(x)
+    oshape = (48, 70, 132)                                        # 132 = 2 x 64 + 4: partial tile; 70 = 2 x 32 + 6
+    idx = np.indices(oshape).reshape(3, -1).astype(np.float64)
+
+    def warp(M, off, extra=None):
+        c = (np.asarray(M) @ idx + np.asarray(off, dtype=np.float64)[:, None]).reshape((3,) + oshape)
+        if extra is not None:
+            c = c + extra(c)
+        return c.astype(np.float32)
+
+    ang = np.deg2rad(7.0); cs, sn = np.cos(ang), np.sin(ang)
+    cases = {
+        "rotation in the plane": warp([[1.02, 0, 0], [0, cs, -sn], [0, sn, cs]], [0.5, 3.0, -2.0]),
+        "identity, integer shift (exact boundary hits)": warp(np.eye(3), [2.0, -3.0, 5.0]),
+        "zoom in": warp(np.diag([0.6, 0.7, 0.8]), [0.3, 0.2, 0.1]),
+        "zoom out (rectangle too wide: L1 path)": warp(np.diag([0.8, 1.6, 1.7]), [0.0, 0.0, 0.0]),
+        "z mixes with y (planes drift: re-centring, late fetches)": warp([[1.0, 0.12, 0.0], [-0.12, 1.0, 0.0], [0, 0, 1.0]], [-2.0, 6.0, 1.0]),
+        "steep z mixing (more than four planes per step: L1 path)": warp([[0.9, 0.5, 0.3], [0.1, 1.0, 0.0], [0, 0, 1.0]], [0.0, 0.0, 0.0]),
+        "smooth non-affine": warp(np.eye(3), [1.0, 2.0, 3.0], lambda c: 1.5 * np.sin(c / 9.0)),
+        "mostly outside": warp(np.eye(3), [30.0, -60.0, 100.0]),
+        "random coordinates": (rng.random((3,) + oshape) * np.array(shape)[:, None, None, None]).astype(np.float32),
+    }
+    wild = cases["rotation in the plane"].copy()
+    wild[0, 5, 6, 7] = np.nan; wild[1, 9, 10, 11] = np.inf; wild[2, 20, 21, 22] = -np.inf; wild[:, 30, 40, 50] = 1e30
+    wild[0, 33] = -5.0                                            # a whole plane of coordinates outside
+    cases["NaN / inf / huge coordinates"] = wild
+    for name, c in cases.items():
+        cd = gpu.asarray(c)
+        lib.mi_debug_set_map_zstream(0)
+        try:
+            want = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
+        finally:
+            lib.mi_debug_set_map_zstream(1)
+        for knob, zc in ((1, 0), (1, 1), (1, 5), (2, 0)):
+            lib.mi_debug_set_map_zstream(knob); lib.mi_debug_set_map_zchunks(zc)
+            try:
+                got = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
+                assert "map_coords3d_zstream" in last_kernel()
+            finally:
+                lib.mi_debug_set_map_zstream(1); lib.mi_debug_set_map_zchunks(0)
+            assert np.array_equal(got, want, equal_nan=True), (name, knob, zc, int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want))))))
+        ref = orc.map_coordinates(x, c, order=1, mode="constant", cval=-0.75)
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(want), ok), name
+        assert np.allclose(want[ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref[ok]).max())), name
