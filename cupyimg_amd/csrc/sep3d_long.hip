@@ -1025,7 +1025,7 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
 
 static int long_cus() { return device_cus(); }
 
-// (in-plane taps, z taps) pairs the r3 kernel is instantiated for besides the cubic ones: volumes with anisotropic
+// (in-plane taps, z taps) pairs the r3 kernel is instantiated for besides the cubic ones (r4: with more z taps too): volumes with anisotropic
 // voxels, where a gaussian given in millimetres has fewer taps through the slices (each pair is one more kernel to
 // compile: the list is what sigma = 0.5 ... 2 voxels in the plane, in steps of a quarter, needs with 2-4 x thicker slices)
 #ifdef MI_LONG_DEV
@@ -1033,7 +1033,9 @@ static int long_cus() { return device_cus(); }
 #else
 #define MI_LONG_ANISO_PAIRS(X)                                                                             \
     X(5, 3) X(7, 3) X(7, 5) X(9, 3) X(9, 5) X(9, 7) X(11, 3) X(11, 5) X(11, 7) X(13, 3) X(13, 5) X(13, 7) X(13, 9)     \
-    X(15, 5) X(15, 7) X(15, 9) X(17, 3) X(17, 5) X(17, 7) X(17, 9) X(17, 13)
+    X(15, 5) X(15, 7) X(15, 9) X(17, 3) X(17, 5) X(17, 7) X(17, 9) X(17, 13)                                           \
+    /* r4: MORE taps along z than in the plane (sigma larger through the slices: gaussian (2, 1, 1) = 17 x 9 x 9) */     \
+    X(5, 9) X(5, 13) X(5, 17) X(7, 13) X(9, 13) X(9, 17) X(13, 17)
 #endif
 bool long_aniso_pair(int w, int wzn)
 {

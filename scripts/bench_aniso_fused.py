@@ -1,4 +1,4 @@
-"""r3: anisotropic gaussians on 512^3 -- the fused long kernel with fewer z taps against the streaming passes
+"""r3 / r4: anisotropic gaussians on 512^3 -- the fused long kernel with fewer z taps against the streaming passes
 (mi_debug_set_sep3d_long(1)), settled protocol."""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -20,7 +20,8 @@ def t(fn):
     e0.record()
     for _ in range(k): fn()
     e1.record(); ca.synchronize(); return e0.elapsed_ms(e1) / k * 1e3
-for sig in ([1.0, 2.0, 2.0], [0.5, 2.0, 2.0], [0.5, 1.0, 1.0], [0.75, 1.5, 1.5]):
+for sig in ([1.0, 2.0, 2.0], [0.5, 2.0, 2.0], [0.5, 1.0, 1.0], [0.75, 1.5, 1.5],
+            [2.0, 1.0, 1.0], [1.5, 1.0, 1.0], [2.0, 1.5, 1.5], [1.0, 0.5, 0.5], [1.5, 0.5, 0.5], [2.0, 0.5, 0.5], [1.5, 0.75, 0.75]):     # r4: more taps along z
     r = {}
     outs = {}
     for knob in (1, 0):

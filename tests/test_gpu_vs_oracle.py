@@ -1517,7 +1517,7 @@ def test_long_kernel_generations_agree(gpu, ndi):
 
 
 def test_long_kernel_anisotropic_tap_pairs(gpu, ndi):
-    """Volumes with anisotropic voxels: fewer taps along z than in the plane take ONE launch of the long kernel
+    """Volumes with anisotropic voxels: fewer (r4: or more) taps along z than in the plane take ONE launch of the long kernel
     (sep3d_long3_kernel<W, false, false, 0, WZ>) for the (W, WZ) pairs it is built for, on volumes of >= 4 Mvoxels;
     every index-mapping mode, gaussian and uniform weights, an origin along z; `constant` mode and other pairs fall back
     to the streaming passes and must agree as well."""
@@ -1527,7 +1527,10 @@ def test_long_kernel_anisotropic_tap_pairs(gpu, ndi):
     x = rng.standard_normal(shape).astype(np.float32)
     xd = gpu.asarray(x)
     for sig, taps in (([1.0, 2.0, 2.0], (17, 9)), ([0.5, 1.0, 1.0], (9, 5)), ([0.75, 1.5, 1.5], (13, 7)), ([0.5, 2.0, 2.0], (17, 5)),
-                      ([0.25, 0.5, 0.5], (5, 3)), ([0.625, 1.25, 1.25], (11, 7)), ([0.875, 1.75, 1.75], (15, 9)), ([0.375, 0.75, 0.75], (7, 5))):
+                      ([0.25, 0.5, 0.5], (5, 3)), ([0.625, 1.25, 1.25], (11, 7)), ([0.875, 1.75, 1.75], (15, 9)), ([0.375, 0.75, 0.75], (7, 5)),
+                      # r4: MORE taps along z than in the plane
+                      ([2.0, 1.0, 1.0], (9, 17)), ([1.5, 1.0, 1.0], (9, 13)), ([2.0, 1.5, 1.5], (13, 17)), ([1.0, 0.5, 0.5], (5, 9)),
+                      ([1.5, 0.5, 0.5], (5, 13)), ([2.0, 0.5, 0.5], (5, 17)), ([1.5, 0.75, 0.75], (7, 13))):
         for mode in ("reflect", "mirror", "nearest", "wrap"):
             g = ndi.gaussian_filter(xd, sig, mode=mode).get()
             assert "sep3d_long3_kernel<%d,false,false,0,%d>" % taps in ca.last_kernel(), (sig, ca.last_kernel())
@@ -1535,7 +1538,7 @@ def test_long_kernel_anisotropic_tap_pairs(gpu, ndi):
         g = ndi.gaussian_filter(xd, sig, mode="constant", cval=0.5).get()           # falls back
         assert "sep3d_long3_kernel" not in ca.last_kernel()
         assert maxnorm_rel(g, orc.gaussian_filter(x, sig, mode="constant", cval=0.5)) <= 1e-6, sig
-    for size, taps in (((3, 9, 9), (9, 3)), ((13, 17, 17), (17, 13)), ((7, 9, 9), (9, 7))):
+    for size, taps in (((3, 9, 9), (9, 3)), ((13, 17, 17), (17, 13)), ((7, 9, 9), (9, 7)), ((17, 9, 9), (9, 17)), ((13, 7, 7), (7, 13))):
         u = ndi.uniform_filter(xd, size, mode="reflect").get()
         assert "sep3d_long3_kernel<%d,false,false,0,%d>" % taps in ca.last_kernel(), (size, ca.last_kernel())
         assert maxnorm_rel(u, orc.uniform_filter(x, size, mode="reflect")) <= 1e-6, size
