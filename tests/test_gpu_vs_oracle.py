@@ -1701,3 +1701,57 @@ def test_map_coordinates_zstream_kernel(gpu, ndi):
         ok = np.isfinite(ref)
         assert np.array_equal(np.isfinite(want), ok), name
         assert np.allclose(want[ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref[ok]).max())), name
+
+
+def test_affine_rowblend_kernel(gpu, ndi):
+    """Matrices that leave the x axis to itself with unit step and an integral shift (a rotation / shear / scaling in the
+    (z, y) plane: `rotate(volume, angle)` with the default axes) blend four input ROWS per output row
+    (affine3d_rowblend_kernel: no gathers, no LDS).  Bit-identical to the L1-gather kernel; x shifts of both signs that push
+    columns outside, partial tiles along x / y / z, exact boundary hits, non-finite samples; a fractional x shift or a
+    non-unit x step is not taken; `rotate(order=1)` of a volume goes through it."""
+    from cupyimg_amd import _lib, last_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(600)
+
+    def zy(deg, s0=1.0, s1=1.0, shear=0.0):
+        a = np.deg2rad(deg); c, s = np.cos(a), np.sin(a)
+        M = np.eye(3)
+        M[0, 0], M[0, 1], M[1, 0], M[1, 1] = c * s0, -s * s1 + shear, s * s0, c * s1
+        return M
+
+    cases = [
+        ((64, 72, 264), zy(7), np.array([2.0, -3.5, 0.0]), None, True),
+        ((64, 72, 264), zy(-30, 1.1, 0.9), np.array([10.0, 20.0, 3.0]), (50, 90, 260), True),
+        ((40, 50, 132), zy(45, shear=0.2), np.array([-5.0, 30.0, -7.0]), (70, 66, 140), True),          # x shift pushes 7 columns outside, ox not a multiple of 4 x 64
+        ((64, 64, 64), zy(0, shear=1e-9), np.array([1.0, -2.0, 5.0]), None, True),                        # integer shifts: (all but) exact boundary hits
+        ((64, 64, 64), zy(180, shear=1e-9), np.array([63.0, 63.0, 0.0]), None, True),                     # flips
+        ((64, 64, 64), np.eye(3), np.array([1.0, -2.0, 5.0]), None, "zstream"),                          # diagonal: axis 0 is decoupled too, the z-streaming kernel comes first
+        ((64, 72, 264), zy(7), np.array([2.0, -3.5, 0.5]), None, False),                                 # fractional x shift
+        ((64, 72, 264), zy(7) @ np.diag([1.0, 1.0, 1.25]), np.array([2.0, -3.5, 0.0]), None, False),     # x step 1.25
+    ]
+    for shape, M, off, oshape, takes in cases:
+        x = rng.standard_normal(shape).astype(np.float32)
+        x[10, 9, 11] = np.inf; x[11, 12, 10] = np.nan
+        xd = gpu.asarray(x)
+        oshape = shape if oshape is None else oshape
+        lib.mi_debug_set_interp_c1(5)
+        try:
+            want = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75).get()
+        finally:
+            lib.mi_debug_set_interp_c1(1)
+        got = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75).get()
+        if isinstance(takes, str):
+            assert takes in last_kernel(), (shape, last_kernel())
+        else:
+            assert ("rowblend" in last_kernel()) == takes, (shape, last_kernel())
+        assert np.array_equal(got, want, equal_nan=True), (shape, float(np.nanmax(np.abs(got - want))))
+        ref = orc.affine_transform(x, M, off, output_shape=oshape, order=1, mode="constant", cval=-0.75)
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(want), ok), shape
+        assert np.allclose(want[ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref[ok]).max())), shape
+    import scipy.ndimage as sndi
+    v = rng.standard_normal((72, 80, 260)).astype(np.float32)
+    got = ndi.rotate(gpu.asarray(v), 11.0, reshape=False, order=1).get()
+    assert "rowblend" in last_kernel(), last_kernel()
+    ref = sndi.rotate(v.astype(np.float64), 11.0, reshape=False, order=1)
+    assert np.allclose(got, ref, rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max()))
