@@ -1444,7 +1444,7 @@ constexpr int kMzRounds = kMzSlotBytes / (kMzNT * 16);
 struct MapZParams {
     FastInterpParams f;
     int zc, nzc, ntx, nty;
-    int dbg;                 // 1 = no DMA, 2 = every step takes the L1 gathers (timing / test aid)
+    int dbg;                 // 1 = no DMA, 2 = every step takes the L1 gathers, 4 = no stores, 8 = no interpolation (timing / test aids)
 };
 
 // wave-wide minimum / maximum of a float, result as a wave-uniform scalar: four DPP row shifts inside each row of 16 lanes
@@ -1659,7 +1659,10 @@ map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restric
         }
         // ---- interpolate plane z
         float r[8];
-        if (cur.lds) {
+        if (q.dbg & 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = cur.wz[k] + (float)cur.a[k];
+        } else if (cur.lds) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int a_lo = cur.a[k];
@@ -1693,7 +1696,9 @@ map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restric
                 for (int kk = 0; kk < 4; kk++) r[4 * h + kk] = finish<float>(t[kk], cval);
             }
         }
-        if (wide) {
+        if (q.dbg & 4) {
+            if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] == 1.2345e-30f) out[0] = r[0];      // keeps the work alive
+        } else if (wide) {
 #pragma unroll
             for (int k = 0; k < 8; k++) my_stage[k * 64 + lane] = r[k];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1863,7 +1868,7 @@ static int launch_map_zstream(const float *in, const float *coords, float *out, 
     nzc = std::max(1, std::min(nzc, (p.oz + 15) / 16));
     q.zc = (p.oz + nzc - 1) / nzc;
     q.nzc = (p.oz + q.zc - 1) / q.zc;
-    q.dbg = (g_affine_dbg & 1) | (g_map_zstream == 2 ? 2 : 0);
+    q.dbg = (g_affine_dbg & 13) | (g_map_zstream == 2 ? 2 : 0);
     static bool attr_done = false;
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)map_coords3d_zstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
