@@ -139,6 +139,16 @@ def _compile(args):
             os.unlink(o)
             raise RuntimeError("{}: kernels that count their vector-memory operations by hand (s_waitcnt vmcnt) were "
                                "compiled with scratch-memory accesses, which add uncounted ones: {}".format(src, spilled))
+    if src in REG_BUDGET:
+        try:
+            over = _over_budget(o, REG_BUDGET[src])
+        except BaseException:
+            os.unlink(o)
+            raise
+        if over:
+            os.unlink(o)
+            raise RuntimeError("{}: kernels planned for a fixed number of waves per SIMD need more registers than that "
+                               "allows: {}".format(src, over))
     with open(stamp_file, "w") as f:     # written last: object compiled AND checked with these flags
         f.write(stamp)
     if proc.stdout.strip():
@@ -149,7 +159,40 @@ def _compile(args):
 # Sources whose kernels wait on vmcnt by count (LDS-DMA rings): the name fragment selects the kernels that must not
 # touch scratch memory (a spill store or reload is one more vector-memory operation in flight than the count assumes).
 # The ablation builds of the r3 long kernel (<W, SAME, DBG = true, 0>) are exempt: timing aids, not product kernels.
-NO_SCRATCH = {"sep3d_long.hip": "sep3d_long", "minmax3d_f32.hip": "mm3f32_long"}
+NO_SCRATCH = {"sep3d_long.hip": "sep3d_long", "minmax3d_f32.hip": "mm3f32_long", "interp_fast.hip": "zstream_kernel"}
+
+
+# Kernels whose occupancy is part of their design: (fragment of the mangled name, VGPRs + AGPRs per lane at most).
+# map_coords3d_zstream_kernel<true, 4, *>: 512 threads, two workgroups per CU = four waves per SIMD = 128 registers.
+REG_BUDGET = {"interp_fast.hip": [("map_coords3d_zstream_kernelILb1ELi4E", 128)]}
+
+
+def _over_budget(obj, budgets):
+    """[(kernel, registers)] of the kernels in `obj` that exceed their entry in `budgets` (from the code object's metadata
+    note: .vgpr_count counts the accumulation registers too on gfx90a+)."""
+    import tempfile
+    readelf = _llvm_tool("llvm-readelf")
+    with tempfile.TemporaryDirectory() as tmp:
+        co = os.path.join(tmp, "dev.co")
+        with open(co, "wb") as f:
+            f.write(_device_code_object(obj))
+        text = subprocess.run([readelf, "--notes", co], stdout=subprocess.PIPE, text=True, check=True).stdout
+    over, seen = [], set()
+    # the note is YAML; the fields of one kernel sit between two ".agpr_count" lines (first key of every entry)
+    for block in re.split(r"\n\s+- \.agpr_count:", text)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block)
+        regs = re.search(r"\.vgpr_count:\s+(\d+)", block)
+        if not name or not regs:
+            continue
+        for fragment, limit in budgets:
+            if fragment in name.group(1):
+                seen.add(fragment)
+                if int(regs.group(1)) > limit:
+                    over.append("{} ({} > {})".format(name.group(1), regs.group(1), limit))
+    missing = [f for f, _ in budgets if f not in seen]
+    if missing:
+        raise RuntimeError("register budget check: no kernel matches {} in {}".format(missing, obj))
+    return over
 
 
 def _device_code_object(obj):
@@ -199,13 +242,18 @@ def _scratch_users(obj, fragment):
     bad, name, count = [], None, 0
     def close():
         if name and count and fragment in name and not _is_ablation_build(name):
-            bad.append("{} ({} scratch instructions)".format(name, count))
+            bad.append("{} ({} scratch / compiler-made AGPR instructions)".format(name, count))
     for line in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
         if m:
             close()
             name, count = m.group(1), 0
         elif "\tscratch_" in line or " scratch_" in line:
+            count += 1
+        elif name and "map_coords3d_zstream" in name and re.search(r"\bv_accvgpr_(write|mov)", line):
+            # these kernels keep two planes of coordinates IN FLIGHT in a[0:50] (global_load -> AGPR, ds_write_b128 <- AGPR,
+            # hand-counted waits); the compiler must not put anything of its own there (a VGPR spilled into an AGPR
+            # could sit under a landing load): any AGPR write or move of the compiler's is refused like a scratch access
             count += 1
     close()
     return bad

@@ -14,6 +14,7 @@
 // tolerance for float32 interpolation is 2e-6 * max|ref| (tests/test_gpu_*).
 // Anything else (other dtypes, ranks, float64 output) runs interp.hip.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -1437,9 +1438,17 @@ static int launch_affine_zstream(const float *in, float *out, ZStreamParams &q, 
 // z slots at all -- coordinates with no structure -- takes the L1 gathers for that step.  Same splits, same in-range
 // tests, same blend as the other order-1 kernels: bit-identical results.
 // ---------------------------------------------------------------------------
-constexpr int kMzTY = 32, kMzNT = 256, kMzRY = 48;
-constexpr int kMzSlotBytes = ((kMzRY * 20 + kMzNT - 1) / kMzNT) * kMzNT * 16;       // whole rounds of 256 chunks: 16 KiB
-constexpr int kMzRounds = kMzSlotBytes / (kMzNT * 16);
+constexpr int kMzTY = 32, kMzRY = 48;
+constexpr int kMzSlotBytes = 16384;                         // RY x 20 chunks of 16 bytes, rounded up to whole rounds of 256 / 512 threads
+static_assert(kMzRY * 20 * 16 <= kMzSlotBytes, "slot holds the rectangle");
+// V = voxels per thread: 8 -> 256 threads (4 waves, 8 rows each), 4 -> 512 threads (8 waves, 4 rows each) per 32 x 64 tile.
+// Two workgroups per CU either way (LDS), i.e. 2 or 4 waves per SIMD: with V = 4 a wave's dependent chain per plane is
+// half as long and twice as many waves hide it (one workgroup per CU instead of two cost 740 against 522 us on config D:
+// the kernel is bound by that chain, not by bandwidth).
+template <int V> struct MzGeo {
+    static constexpr int NT = 2048 / V, NW = NT / 64, ROUNDS = kMzSlotBytes / (NT * 16), BT = V / 4;
+    static constexpr int STG = V == 8 ? 3072 : 2048;        // bytes of stage tile per wave: three axes of a batch at once / two, then one
+};
 
 struct MapZParams {
     FastInterpParams f;
@@ -1464,14 +1473,91 @@ __device__ __forceinline__ float wave_reduce_f32(float v)
     return IS_MAX ? fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)) : fminf(fminf(r0, r1), fminf(r2, r3));
 }
 
-__global__ void __launch_bounds__(kMzNT)
+// r4b: the coordinates of up to TWO planes are in flight per wave, in ACCUMULATION registers: with 8 voxels per thread set 0
+// = a[0:23] + a24 (the corner sample), set 1 = a[26:49] + a50; with 4 voxels per thread a[0:11] + a12 and a[14:25] + a26.  A compiler-visible load let only one plane travel (the compiler's counter logic
+// drained vmcnt to zero before the first use of a plane), loads issued by inline asm into ordinary registers were copied
+// by the register allocator while still in flight (loop-carried values), and LDS has no room for two planes of
+// coordinates per wave beside the ring.  AGPRs are outside the allocator's reach: global_load writes them, ds_write_b128
+// reads them (gfx90a+ take AGPRs as the data operand of memory instructions), nothing is copied, and the hand-counted
+// s_waitcnt at the top of a step is the only thing between the two.  The build refuses this file if the compiler itself
+// touches an AGPR in these kernels (_build.py NO_AGPR_MOVES: a VGPR spill into a[..] could land under an in-flight load).
+template <int V, int SET, int IDX> __device__ __forceinline__ void mz_coord_load(const float *addr);
+template <int V, int SET, int IDX> __device__ __forceinline__ void mz_coord_stage(unsigned lds_addr);      // 16 bytes per lane to lds_addr + the offset of (V, IDX)
+template <int V, int SET> __device__ __forceinline__ void mz_corner_load(const float *addr);
+template <int V, int SET> __device__ __forceinline__ float mz_corner_get();
+#define MI_MZ_COORD(V, SET, IDX, R0, R1, R2, R3, OFF)                                                                  \
+    template <> __device__ __forceinline__ void mz_coord_load<V, SET, IDX>(const float *addr)                          \
+    {                                                                                                                  \
+        asm volatile("global_load_dwordx4 a[" #R0 ":" #R3 "], %0, off nt" ::"v"(addr) : "memory", "a" #R0, "a" #R1, "a" #R2, "a" #R3); \
+    }                                                                                                                  \
+    template <> __device__ __forceinline__ void mz_coord_stage<V, SET, IDX>(unsigned lds_addr)                         \
+    {                                                                                                                  \
+        asm volatile("ds_write_b128 %0, a[" #R0 ":" #R3 "] offset:" #OFF ::"v"(lds_addr) : "memory");                   \
+    }
+#define MI_MZ_CORNER(V, SET, R)                                                                                        \
+    template <> __device__ __forceinline__ void mz_corner_load<V, SET>(const float *addr)                              \
+    {                                                                                                                  \
+        asm volatile("global_load_dword a" #R ", %0, off" ::"v"(addr) : "memory", "a" #R);                             \
+    }                                                                                                                  \
+    template <> __device__ __forceinline__ float mz_corner_get<V, SET>()                                               \
+    {                                                                                                                  \
+        float v;                                                                                                       \
+        asm volatile("v_accvgpr_read_b32 %0, a" #R : "=v"(v)::"memory");                                               \
+        return v;                                                                                                      \
+    }
+// V = 8: IDX = 3 batch + axis, the three axes of a batch staged side by side
+MI_MZ_COORD(8, 0, 0, 0, 1, 2, 3, 0)        MI_MZ_COORD(8, 0, 1, 4, 5, 6, 7, 1024)     MI_MZ_COORD(8, 0, 2, 8, 9, 10, 11, 2048)
+MI_MZ_COORD(8, 0, 3, 12, 13, 14, 15, 0)    MI_MZ_COORD(8, 0, 4, 16, 17, 18, 19, 1024) MI_MZ_COORD(8, 0, 5, 20, 21, 22, 23, 2048)
+MI_MZ_COORD(8, 1, 0, 26, 27, 28, 29, 0)    MI_MZ_COORD(8, 1, 1, 30, 31, 32, 33, 1024) MI_MZ_COORD(8, 1, 2, 34, 35, 36, 37, 2048)
+MI_MZ_COORD(8, 1, 3, 38, 39, 40, 41, 0)    MI_MZ_COORD(8, 1, 4, 42, 43, 44, 45, 1024) MI_MZ_COORD(8, 1, 5, 46, 47, 48, 49, 2048)
+MI_MZ_CORNER(8, 0, 24)
+MI_MZ_CORNER(8, 1, 50)
+// V = 4: IDX = axis; z and y staged side by side, x afterwards in the place of z (2 KiB of stage tile per wave)
+MI_MZ_COORD(4, 0, 0, 0, 1, 2, 3, 0)        MI_MZ_COORD(4, 0, 1, 4, 5, 6, 7, 1024)     MI_MZ_COORD(4, 0, 2, 8, 9, 10, 11, 0)
+MI_MZ_COORD(4, 1, 0, 14, 15, 16, 17, 0)    MI_MZ_COORD(4, 1, 1, 18, 19, 20, 21, 1024) MI_MZ_COORD(4, 1, 2, 22, 23, 24, 25, 0)
+MI_MZ_CORNER(4, 0, 12)
+MI_MZ_CORNER(4, 1, 26)
+template <int N> __device__ __forceinline__ void mz_wait_vm()
+{
+    static_assert(N >= 0 && N <= 9, "s_waitcnt strings below");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+}
+#undef MI_MZ_COORD
+#undef MI_MZ_CORNER
+template <int N, typename F> __device__ __forceinline__ void mz_static_for(F &&f)
+{
+    if constexpr (N > 0) {
+        mz_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// CORNER (r4b): the rectangle of a plane is placed from the coordinates of the tile's four corner voxels (every wave loads
+// the same twelve floats and reduces them with v_readlane + scalar min / max: no wave reductions over all voxels, no LDS
+// atomics, no second barrier per plane), and every voxel VERIFIES that its taps lie inside what was staged; a voxel that
+// does not (warps that bulge inside the tile, noise) takes four L1 gathers for itself.  For affine-like coordinates the
+// corner box is the exact box.  false = the exact reduction over all voxels (kept as the comparator, knob 3).
+// V: voxels per thread (MzGeo); DEEP: planes of coordinates in flight per wave (1 or 2).
+template <bool CORNER, int V, int DEEP>
+__global__ void __launch_bounds__(2048 / V)
 map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restrict__ coords, float *__restrict__ out, const MapZParams q)
 {
-    constexpr int P = kZsP, RY = kMzRY, NT = kMzNT, TY = kMzTY;
+    using G = MzGeo<V>;
+    constexpr int P = kZsP, RY = kMzRY, NT = G::NT, TY = kMzTY, kRounds = G::ROUNDS, BT = G::BT;
     static_assert(kMzSlotBytes == 16384, "the ring is addressed by bit arithmetic: slot = address bits 14 .. 15");
+    static_assert((V == 4 || V == 8) && (DEEP == 1 || DEEP == 2) && (CORNER || V == 8), "instances");
     extern __shared__ __attribute__((aligned(16))) char smem_mz[];
-    float *stage = reinterpret_cast<float *>(smem_mz + 4 * kMzSlotBytes);            // [4 waves][3 axes x 4 rows x 64]: coordinates in, results out
-    int *ctl = reinterpret_cast<int *>(smem_mz + 4 * kMzSlotBytes + 4 * 3072);       // [2][8]: min z, y, x, max z, y, x (order-preserving ints)
+    float *stage = reinterpret_cast<float *>(smem_mz + 4 * kMzSlotBytes);            // [waves][STG bytes]: coordinates in, results out
+    int *ctl = reinterpret_cast<int *>(smem_mz + 4 * kMzSlotBytes + G::NW * G::STG); // !CORNER: [2][8]: min z, y, x, max z, y, x (order-preserving ints)
 
     const int nz = q.f.nz, ny = q.f.ny, nx = q.f.nx, oz = q.f.oz, oy = q.f.oy, ox = q.f.ox;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1487,35 +1573,45 @@ map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restric
     const int vol_bytes = nz * ny * nx * 4;
     const unsigned plane_b = (unsigned)ny * (unsigned)nx * 4u, row_b = (unsigned)nx * 4u;
     const float cval = (float)q.f.cval;
-    float *my_stage = stage + wave * 768;
+    float *my_stage = stage + wave * (G::STG / 4);
     // a partial tile's last lanes read their own column of the clamped 16-byte coordinate load
     const int col = wide ? lane : min(x0 + lane, ox - 1) - min(x0 + 4 * (lane >> 2), ox - 4) + 4 * (lane >> 2);
 
-    unsigned rel[kMzRounds];
+    unsigned rel[kRounds];
 #pragma unroll
-    for (int j = 0; j < kMzRounds; j++) {
+    for (int j = 0; j < kRounds; j++) {
         const unsigned ch = (unsigned)tid + (unsigned)(j * NT);
         const unsigned row = ch / 20u, c4 = ch - row * 20u;
         rel[j] = ch < (unsigned)(RY * 20) ? row * row_b + c4 * 16u : 0x80000000u;
     }
-    if (tid < 16) ctl[tid] = (tid & 7) < 3 ? 0x7fffffff : 0;              // both sets: minima, then maxima (all values are >= 0)
+    if constexpr (!CORNER) { if (tid < 16) ctl[tid] = (tid & 7) < 3 ? 0x7fffffff : 0; }     // both sets: minima, then maxima (all values are >= 0)
+    // CORNER: lane -> (axis = (lane / 4) % 3, corner = lane % 4) of the tile's corner voxels (clamped into the output)
+    const int c_axis = (lane >> 2) % 3;
+    const size_t c_off = (size_t)c_axis * ((size_t)oz * oy * ox) +
+                         (size_t)((lane & 2) ? min(y0 + TY - 1, oy - 1) : y0) * ox + (size_t)((lane & 1) ? min(x0 + 63, ox - 1) : x0);
+    const float c_max = (float)((c_axis == 0 ? nz : c_axis == 1 ? ny : nx) - 1);
 
     // ---- coordinates of one output plane's tile: 16-byte loads (lane -> row lane / 16 of a batch of four, x = 4 (lane % 16))
-    struct Raw { f32x4n v[2][3]; };
-    auto load_coords = [&](int z, Raw &r) {
+    // into AGPR set SET (see mz_coord_load); the wait counts are derived at the top of `step`
+    auto load_coords = [&](int z, auto SS) {
+        constexpr int SET = decltype(SS)::value;
         const int i = lane >> 4, c = lane & 15;
-#pragma unroll
-        for (int bt = 0; bt < 2; bt++) {
-            const int y = min(y0 + 8 * wave + 4 * bt + i, oy - 1);
+        if constexpr (CORNER) mz_corner_load<V, SET>(coords + c_off + (size_t)z * oy * ox);
+        mz_static_for<BT>([&](auto BB) {
+            constexpr int bt = decltype(BB)::value;
+            const int y = min(y0 + V * wave + 4 * bt + i, oy - 1);
             const int xq = min(x0 + 4 * c, ox - 4);
             const size_t o = ((size_t)z * oy + y) * ox + xq;
-#pragma unroll
-            for (int a = 0; a < 3; a++) r.v[bt][a] = __builtin_nontemporal_load(reinterpret_cast<const f32x4n *>(coords + a * nout + o));
-        }
+            mz_static_for<3>([&](auto AA) {
+                constexpr int a = decltype(AA)::value;
+                mz_coord_load<V, SET, 3 * bt + a>(coords + a * nout + o);
+            });
+        });
     };
     // what a plane's voxels need: integer parts until the rectangle is known, then ONE byte offset (LDS: slot in bits 14-15;
     // L1 path: offset into the volume), weights, in-range bits
-    struct Step { int a[8]; float wz[8], wy[8], wx[8]; unsigned inmask; int lds; };
+    // CORNER: bit k of `bad` = voxel k's taps are not (all) in LDS; a[k] is then 0x80000000 | its byte offset in the volume
+    struct Step { int a[V]; float wz[V], wy[V], wx[V]; unsigned inmask; int lds; unsigned bad; };
 
     // resident planes [rlo, rhi] (<= 4, slot = plane & 3), all staged with the rectangle origin (org_y, org_x)
     int rlo = 0, rhi = -1, org_y = 0, org_x = 0;
@@ -1529,7 +1625,7 @@ map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restric
         const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)pl * plane_b + (unsigned)org_y * row_b + (unsigned)org_x * 4u);
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(pl & 3) * (unsigned)kMzSlotBytes + (unsigned)(wave << 6) * 16u);
 #pragma unroll
-        for (int j = 0; j < kMzRounds; j++)
+        for (int j = 0; j < kRounds; j++)
             if (!(q.dbg & 1)) dma_16s(rin, rel[j], base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * NT) * 16u));
     };
 
@@ -1538,52 +1634,86 @@ map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restric
     // wave) and clamped into the volume afterwards: a coordinate outside only stretches the box outwards, which the clamp
     // removes again; NaNs are ignored by min / max (their voxels blend to NaN whatever they read).
     int need_lo[3], need_hi[3];
-    int iz_[8], iy_[8], ix_[8];
-    auto analyse = [&](const Raw &r, Step &st, int set) {
-        const int i = lane >> 4, c = lane & 15;
+    int iz_[V], iy_[V], ix_[V];
+    // byte address of this lane's 16 bytes in the wave's stage tile (dynamic shared memory starts at LDS address 0: the
+    // kernel has no static __shared__ data, as the M0 arithmetic of the DMAs assumes already)
+    const unsigned stage_lds = (unsigned)(4 * kMzSlotBytes) + (unsigned)wave * (unsigned)G::STG + (unsigned)lane * 16u;
+    auto analyse = [&](auto SS, Step &st, int set) {
+        constexpr int SET = decltype(SS)::value;
         st.inmask = 0;
-        float cz[8], cy[8], cx[8];
+        float cz[V], cy[V], cx[V];
+        // (axis a, row i = lane / 16, x = 4 (lane % 16)) -> float (a * 4 + i) * 64 + 4 (lane % 16) = a KiB + 16 lane bytes
+        if constexpr (V == 8) {
+            mz_static_for<2>([&](auto BB) {
+                constexpr int bt = decltype(BB)::value;
+                mz_coord_stage<V, SET, 3 * bt>(stage_lds);
+                mz_coord_stage<V, SET, 3 * bt + 1>(stage_lds);
+                mz_coord_stage<V, SET, 3 * bt + 2>(stage_lds);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int bt = 0; bt < 2; bt++) {
-#pragma unroll
-            for (int a = 0; a < 3; a++) *reinterpret_cast<f32x4n *>(my_stage + (a * 4 + i) * 64 + 4 * c) = r.v[bt][a];
+                for (int kk = 0; kk < 4; kk++) {
+                    cz[4 * bt + kk] = my_stage[(0 * 4 + kk) * 64 + col];
+                    cy[4 * bt + kk] = my_stage[(1 * 4 + kk) * 64 + col];
+                    cx[4 * bt + kk] = my_stage[(2 * 4 + kk) * 64 + col];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            });
+        } else {
+            mz_coord_stage<V, SET, 0>(stage_lds);
+            mz_coord_stage<V, SET, 1>(stage_lds);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
-                cz[4 * bt + kk] = my_stage[(0 * 4 + kk) * 64 + col];
-                cy[4 * bt + kk] = my_stage[(1 * 4 + kk) * 64 + col];
-                cx[4 * bt + kk] = my_stage[(2 * 4 + kk) * 64 + col];
+                cz[kk] = my_stage[kk * 64 + col];
+                cy[kk] = my_stage[(4 + kk) * 64 + col];
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mz_coord_stage<V, SET, 2>(stage_lds);                    // x where z was (a wave's LDS operations are carried out in order)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) cx[kk] = my_stage[kk * 64 + col];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < V; k++) {
             const C1Split sz = c1_split(cz[k], nz), sy = c1_split(cy[k], ny), sx = c1_split(cx[k], nx);
             iz_[k] = sz.i0; iy_[k] = sy.i0; ix_[k] = sx.i0;
             st.wz[k] = sz.w1; st.wy[k] = sy.w1; st.wx[k] = sx.w1;
             st.inmask |= (sz.in & sy.in & sx.in) ? (1u << k) : 0u;
         }
-        auto lo8 = [](const float (&v)[8]) { return fminf(__builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]) < __builtin_fminf(__builtin_fminf(v[3], v[4]), v[5]) ? __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]) : __builtin_fminf(__builtin_fminf(v[3], v[4]), v[5]), fminf(v[6], v[7])); };
-        auto hi8 = [](const float (&v)[8]) { return fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]) > __builtin_fmaxf(__builtin_fmaxf(v[3], v[4]), v[5]) ? __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]) : __builtin_fmaxf(__builtin_fmaxf(v[3], v[4]), v[5]), fmaxf(v[6], v[7])); };
-        float lo[3] = {lo8(cz), lo8(cy), lo8(cx)}, hi[3] = {hi8(cz), hi8(cy), hi8(cx)};
-        int *cs = ctl + 8 * set;
-        const int nn[3] = {nz, ny, nx};
+        if constexpr (CORNER) {
+            // lower tap corner of the four corner voxels, clamped into the volume (a NaN clamps to 0): lanes 4 a .. 4 a + 3
+            const int ci = (int)fminf(fmaxf(mz_corner_get<V, SET>(), 0.f), c_max);
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            // clamped to [0, n - 1] and floored: the lower tap corner of the extreme coordinates (ints >= 0)
-            float l = wave_reduce_f32<false>(lo[a]), h = wave_reduce_f32<true>(hi[a]);
-            l = fminf(fmaxf(l, 0.f), (float)(nn[a] - 1));
-            h = fminf(fmaxf(h, 0.f), (float)(nn[a] - 1));
-            if (lane == 0) { atomicMin(&cs[a], (int)l); atomicMax(&cs[3 + a], (int)h); }
-        }
-        __syncthreads();
+            for (int a = 0; a < 3; a++) {
+                const int v0 = __builtin_amdgcn_readlane(ci, 4 * a), v1 = __builtin_amdgcn_readlane(ci, 4 * a + 1);
+                const int v2 = __builtin_amdgcn_readlane(ci, 4 * a + 2), v3 = __builtin_amdgcn_readlane(ci, 4 * a + 3);
+                need_lo[a] = min(min(v0, v1), min(v2, v3));
+                need_hi[a] = max(max(v0, v1), max(v2, v3));
+            }
+        } else if constexpr (V == 8) {
+            auto lo8 = [](const float (&v)[8]) { return fminf(__builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]) < __builtin_fminf(__builtin_fminf(v[3], v[4]), v[5]) ? __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]) : __builtin_fminf(__builtin_fminf(v[3], v[4]), v[5]), fminf(v[6], v[7])); };
+            auto hi8 = [](const float (&v)[8]) { return fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]) > __builtin_fmaxf(__builtin_fmaxf(v[3], v[4]), v[5]) ? __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]) : __builtin_fmaxf(__builtin_fmaxf(v[3], v[4]), v[5]), fmaxf(v[6], v[7])); };
+            float lo[3] = {lo8(cz), lo8(cy), lo8(cx)}, hi[3] = {hi8(cz), hi8(cy), hi8(cx)};
+            int *cs = ctl + 8 * set;
+            const int nn[3] = {nz, ny, nx};
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            need_lo[a] = __builtin_amdgcn_readfirstlane(cs[a]);
-            need_hi[a] = __builtin_amdgcn_readfirstlane(cs[3 + a]);
+            for (int a = 0; a < 3; a++) {
+                // clamped to [0, n - 1] and floored: the lower tap corner of the extreme coordinates (ints >= 0)
+                float l = wave_reduce_f32<false>(lo[a]), h = wave_reduce_f32<true>(hi[a]);
+                l = fminf(fmaxf(l, 0.f), (float)(nn[a] - 1));
+                h = fminf(fmaxf(h, 0.f), (float)(nn[a] - 1));
+                if (lane == 0) { atomicMin(&cs[a], (int)l); atomicMax(&cs[3 + a], (int)h); }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                need_lo[a] = __builtin_amdgcn_readfirstlane(cs[a]);
+                need_hi[a] = __builtin_amdgcn_readfirstlane(cs[3 + a]);
+            }
+            // re-arm the OTHER set: its readers finished a step ago, its next atomics come after the next top barrier
+            if (tid < 6) ctl[8 * (set ^ 1) + tid] = tid < 3 ? 0x7fffffff : 0;
         }
-        // re-arm the OTHER set: its readers finished a step ago, its next atomics come after the next top barrier
-        if (tid < 6) ctl[8 * (set ^ 1) + tid] = tid < 3 ? 0x7fffffff : 0;
     };
 
     // ---- phase B: where do this plane's taps come from?  Returns 0 = LDS, planes fetched now; 1 = LDS, planes fetched after
@@ -1611,60 +1741,125 @@ map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restric
     };
     auto addresses = [&](int how, Step &st) {
         st.lds = how != 2 ? 1 : 0;
+        st.bad = 0;
         if (how != 2) {
-            // in-range taps lie inside the rectangle by construction; anything else (a NaN coordinate: "inside", integer
-            // part 0) reads offset 0 -- its value does not matter (NaN weights) but its address must exist
             const int org = org_y * P + org_x;
+            if constexpr (CORNER) {
+                // a voxel's taps are in LDS when its lower tap corner lies in [org, org + (RY - 2, P - 2)] and in the planes
+                // staged for this step except the last; one whose do not takes the L1 gathers for itself (offset into the
+                // volume, flagged by the sign bit).  Anything not in range (cval whatever it reads) reads offset 0.
+                const int zl = need_lo[0];
+                const unsigned zn = (unsigned)(need_hi[0] + 1 - need_lo[0]);
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int off = (iy_[k] * P + ix_[k] - org) * 4;
-                const bool ok = ((st.inmask >> k) & 1u) && (unsigned)off < (unsigned)(RY * P * 4 - 4 * (P + 1));
-                st.a[k] = ok ? (((iz_[k] & 3) << 14) | off) : 0;
+                for (int k = 0; k < V; k++) {
+                    const bool in = (st.inmask >> k) & 1u;
+                    const bool here = ((unsigned)(iy_[k] - org_y) <= (unsigned)(RY - 2)) & ((unsigned)(ix_[k] - org_x) <= (unsigned)(P - 2)) &
+                                      ((unsigned)(iz_[k] - zl) < zn);
+                    const int off = (iy_[k] * P + ix_[k] - org) * 4;
+                    st.a[k] = (in & here) ? (((iz_[k] & 3) << 14) | off) : 0;
+                    st.bad |= (in & !here) ? (1u << k) : 0u;
+                }
+                if (__builtin_amdgcn_ballot_w64(st.bad != 0) != 0) {                      // rare: the offsets into the volume only then
+#pragma unroll
+                    for (int k = 0; k < V; k++)
+                        if ((st.bad >> k) & 1u) st.a[k] = (int)(0x80000000u | (unsigned)(((iz_[k] * ny + iy_[k]) * nx + ix_[k]) * 4));
+                }
+            } else {
+                // in-range taps lie inside the rectangle by construction; anything else (a NaN coordinate: "inside", integer
+                // part 0) reads offset 0 -- its value does not matter (NaN weights) but its address must exist
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    const int off = (iy_[k] * P + ix_[k] - org) * 4;
+                    const bool ok = ((st.inmask >> k) & 1u) && (unsigned)off < (unsigned)(RY * P * 4 - 4 * (P + 1));
+                    st.a[k] = ok ? (((iz_[k] & 3) << 14) | off) : 0;
+                }
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) st.a[k] = ((st.inmask >> k) & 1u) ? ((iz_[k] * ny + iy_[k]) * nx + ix_[k]) * 4 : 0;
+            for (int k = 0; k < V; k++) st.a[k] = ((st.inmask >> k) & 1u) ? ((iz_[k] * ny + iy_[k]) * nx + ix_[k]) * 4 : 0;
         }
     };
 
-    // ---- prologue: plane zs analysed and fetched, coordinates of plane zs + 1 requested
-    Raw raw;
-    Step cur;
-    load_coords(zs, raw);
+    // ---- prologue: plane zs analysed and fetched, coordinates of the next DEEP planes requested
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, DEEP - 1> S1{};                         // DEEP == 1: one set
+    constexpr int kLoads = 3 * BT + (CORNER ? 1 : 0), kStores = BT;               // vector-memory operations per plane and wave
+    Step stA, stB;
+    load_coords(zs, S0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                              // ctl initialised
-    analyse(raw, cur, 0);
+    analyse(S0, stA, 0);
     int how = place(0, -1, false);
     if (how != 2) fetch();
-    addresses(how, cur);
+    addresses(how, stA);
     int cur_zlo = need_lo[0], cur_zhi = need_hi[0] + 1;
-    if (zs + 1 < ze) load_coords(zs + 1, raw);
+    if (zs + 1 < ze) load_coords(zs + 1, S1);
+    if constexpr (DEEP == 2) { if (zs + 2 < ze) load_coords(zs + 2, S0); }
 
-#pragma unroll 1
-    for (int z = zs; z < ze; z++) {
-        // the planes of this step have landed and the coordinates of the next are here (the two stores of the previous step,
-        // issued after them, may still be in flight on full tiles); everyone has finished reading the previous planes
-        if (wide) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // one step; `cur` / `nxt` alternate between stA and stB and (DEEP == 2) the coordinates of plane z + 1 -- requested two
+    // steps ago; the set is re-loaded with plane z + 3 -- between AGPR sets 1 and 0: two copies of the body (handing `nxt`
+    // over by assignment cost 34 register moves per thread and plane)
+    auto step = [&](const int z, Step &cur, Step &nxt, auto SS) {
+        // The planes of this step (DMAs issued in the previous step BEFORE its coordinate loads) have landed and the
+        // coordinates of plane z + 1 are here.  DEEP == 2: the coordinate loads of plane z + 2 (kLoads) and the stores of the
+        // previous step (kStores), issued after them, may still be in flight on full tiles; DEEP == 1: the stores.  The
+        // first step has no stores behind it (and a two-plane chunk no younger loads).  Everyone has finished reading the
+        // previous planes.
+        if constexpr (DEEP == 2) {
+            if (wide && z > zs) {
+                if (z + 2 < ze) mz_wait_vm<kLoads + kStores>();
+                else mz_wait_vm<kStores>();
+            } else if (wide && z + 2 < ze) {
+                mz_wait_vm<3 * BT>();
+            } else {
+                mz_wait_vm<0>();
+            }
+        } else {
+            if (wide && z > zs) mz_wait_vm<kStores>();
+            else mz_wait_vm<0>();
+        }
         __builtin_amdgcn_s_barrier();
-        Step nxt = cur;
         int nhow = 0, nzlo = 0, nzhi = -1;
         const bool more = z + 1 < ze;
         if (more) {
-            analyse(raw, nxt, (z + 1 - zs) & 1);
+            analyse(SS, nxt, (z + 1 - zs) & 1);
             nhow = place(cur_zlo, cur_zhi, cur.lds != 0);
             if (nhow == 0) fetch();
             addresses(nhow, nxt);
             nzlo = need_lo[0]; nzhi = need_hi[0] + 1;
-            if (z + 2 < ze) load_coords(z + 2, raw);
+            if (z + 1 + DEEP < ze) load_coords(z + 1 + DEEP, SS);
         }
         // ---- interpolate plane z
-        float r[8];
+        float r[V];
         if (q.dbg & 8) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) r[k] = cur.wz[k] + (float)cur.a[k];
+            for (int k = 0; k < V; k++) r[k] = cur.wz[k] + (float)cur.a[k];
+        } else if (CORNER && cur.lds && __builtin_amdgcn_ballot_w64(cur.bad != 0) != 0) {
+            // some voxel of this wave verifies to "not staged": the same loop with a per-voxel choice of the source
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < V; k++) {                                                 // unrolled: a run-time index would put `cur` into scratch memory
+                Taps<float> t;
+                const int a_lo = cur.a[k];
+                if (a_lo < 0) {
+                    const unsigned base = (unsigned)a_lo & 0x7fffffffu;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) load_pair(rin, base + (m >> 1) * plane_b + (m & 1) * row_b, t.v[2 * m], t.v[2 * m + 1]);
+                } else {
+                    const int a_hi = (a_lo + kMzSlotBytes) & 0xFFFF;
+                    const float *A = reinterpret_cast<const float *>(smem_mz + a_lo);
+                    const float *B = reinterpret_cast<const float *>(smem_mz + a_hi);
+                    t.v[0] = A[0]; t.v[1] = A[1]; t.v[2] = A[P]; t.v[3] = A[P + 1];
+                    t.v[4] = B[0]; t.v[5] = B[1]; t.v[6] = B[P]; t.v[7] = B[P + 1];
+                }
+                t.wz1 = cur.wz[k]; t.wy1 = cur.wy[k]; t.wx1 = cur.wx[k];
+                t.oobmask = 0;
+                t.outside = !((cur.inmask >> k) & 1u);
+                r[k] = finish<float>(t, cval);
+            }
         } else if (cur.lds) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < V; k++) {
                 const int a_lo = cur.a[k];
                 const int a_hi = (a_lo + kMzSlotBytes) & 0xFFFF;                         // plane iz + 1 lives in slot (iz + 1) & 3
                 const float *A = reinterpret_cast<const float *>(smem_mz + a_lo);
@@ -1680,7 +1875,7 @@ map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restric
         } else {
             const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < BT; h++) {
                 Taps<float> t[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
@@ -1697,23 +1892,26 @@ map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restric
             }
         }
         if (q.dbg & 4) {
-            if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] == 1.2345e-30f) out[0] = r[0];      // keeps the work alive
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < V; k++) sum += r[k];
+            if (sum == 1.2345e-30f) out[0] = r[0];                                      // keeps the work alive
         } else if (wide) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) my_stage[k * 64 + lane] = r[k];
+            for (int k = 0; k < V; k++) my_stage[k * 64 + lane] = r[k];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int i = lane >> 4, c = lane & 15;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < BT; h++) {
                 const f32x4n v = *reinterpret_cast<const f32x4n *>(my_stage + (4 * h + i) * 64 + 4 * c);
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)z * oy + (y0 + 8 * wave + 4 * h + i)) * ox + x0 + 4 * c));
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)z * oy + (y0 + V * wave + 4 * h + i)) * ox + x0 + 4 * c));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
             const int x = x0 + lane;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int y = y0 + 8 * wave + k;
+            for (int k = 0; k < V; k++) {
+                const int y = y0 + V * wave + k;
                 if (x < ox && y < oy) __builtin_nontemporal_store(r[k], out + ((size_t)z * oy + y) * ox + x);
             }
         }
@@ -1723,8 +1921,12 @@ map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restric
             fetch();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        cur = nxt;
         cur_zlo = nzlo; cur_zhi = nzhi;
+    };
+#pragma unroll 1
+    for (int z = zs; z < ze; z += 2) {
+        step(z, stA, stB, S1);
+        if (z + 1 < ze) step(z + 1, stB, stA, S0);                                // DEEP == 1: S1 is S0
     }
 }
 
@@ -1852,8 +2054,27 @@ static int launch_affine_rowblend(const float *in, float *out, const RowBlendPar
     return MI_OK;
 }
 
-Knob g_map_zstream{1};        // test hook: 0 = off (L1-gather kernel), 1 = on, 2 = on with every step on the L1 gathers
+Knob g_map_zstream{1};        // test hook: 0 = off (L1-gather kernel), 1 = on, 2 = on with every step on the L1 gathers, 3 = on with the exact box reduction (the first r4 kernel)
 Knob g_map_zchunks{0};
+
+Knob g_map_zvariant{0};       // test hook: 10 V + DEEP of the kernel instance (81, 82, 41); 0 = default.  <true, 4, 2> needs 139 registers: one workgroup per CU
+template <bool CORNER, int V, int DEEP>
+static int launch_map_zstream_as(const float *in, const float *coords, float *out, MapZParams &q, int tiles, hipStream_t s)
+{
+    using G = MzGeo<V>;
+    size_t lds = 4 * (size_t)kMzSlotBytes + (size_t)G::NW * G::STG + (CORNER ? 0 : 64);
+    if (g_affine_dbg & 32) lds = 96 * 1024;                 // occupancy experiment: one workgroup per CU
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI_HIP(hipFuncSetAttribute((const void *)map_coords3d_zstream_kernel<CORNER, V, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_done = true;
+    }
+    note_kernel("mi::map_coords3d_zstream_kernel<%s,%d,%d> grid=%d (order-1 map_coordinates: streams along z, taps out of LDS, rectangle from %s, %d z chunks)",
+                CORNER ? "true" : "false", V, DEEP, tiles * q.nzc, CORNER ? "the tile corners + per-voxel check" : "the exact box", q.nzc);
+    hipLaunchKernelGGL((map_coords3d_zstream_kernel<CORNER, V, DEEP>), dim3((unsigned)(tiles * q.nzc)), dim3(G::NT), lds, s, in, coords, out, q);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
 
 static int launch_map_zstream(const float *in, const float *coords, float *out, const FastInterpParams &p, hipStream_t s)
 {
@@ -1861,23 +2082,20 @@ static int launch_map_zstream(const float *in, const float *coords, float *out, 
     q.f = p;
     q.ntx = (p.ox + 63) / 64;
     q.nty = (p.oy + kMzTY - 1) / kMzTY;
-    const size_t lds = 4 * (size_t)kMzSlotBytes + 4 * 3072 + 64;
     const int ncu = device_cus();
     const int tiles = q.ntx * q.nty;
-    int nzc = g_map_zchunks > 0 ? (int)g_map_zchunks : (4 * ncu + tiles - 1) / tiles;      // two workgroups per CU, two rounds (measured: 538 vs 547 us on config D)
+    int nzc = g_map_zchunks > 0 ? (int)g_map_zchunks : (8 * ncu + tiles - 1) / tiles;      // two workgroups per CU, four rounds (measured on config D: 501 against 511 us with two)
     nzc = std::max(1, std::min(nzc, (p.oz + 15) / 16));
     q.zc = (p.oz + nzc - 1) / nzc;
     q.nzc = (p.oz + q.zc - 1) / q.zc;
     q.dbg = (g_affine_dbg & 13) | (g_map_zstream == 2 ? 2 : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)map_coords3d_zstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr_done = true;
+    if (g_map_zstream == 3) return launch_map_zstream_as<false, 8, 1>(in, coords, out, q, tiles, s);
+    switch ((int)g_map_zvariant) {
+    case 81: return launch_map_zstream_as<true, 8, 1>(in, coords, out, q, tiles, s);
+    case 82: return launch_map_zstream_as<true, 8, 2>(in, coords, out, q, tiles, s);
+    case 41: return launch_map_zstream_as<true, 4, 1>(in, coords, out, q, tiles, s);
+    default: return launch_map_zstream_as<true, 8, 1>(in, coords, out, q, tiles, s);       // config D: 499 us; <true, 4, 1> 519 (but 779 against 917 us on a warp where a third of the voxels gather for themselves)
     }
-    note_kernel("mi::map_coords3d_zstream_kernel grid=%d (order-1 map_coordinates: streams along z, taps out of LDS, %d z chunks)", tiles * q.nzc, q.nzc);
-    hipLaunchKernelGGL(map_coords3d_zstream_kernel, dim3((unsigned)(tiles * q.nzc)), dim3(kMzNT), lds, s, in, coords, out, q);
-    MI_HIP(hipGetLastError());
-    return MI_OK;
 }
 
 Knob g_interp_c1{1};     // test hook: 0 = round-2 kernels for constant-mode order-1 float32 volumes, 1 = r3 kernels, 2 = r3 without the wide stores / loads, 3 = r3 with z-major voxel ownership, 5 = r3 (L1 gathers) without the LDS-staged affine kernel; 1 (default) and 4 use the LDS-staged affine kernel when the box fits, 6 = row-major ownership for map_coordinates, 7 = pair-sharing map_coordinates kernel (4 = LDS-staged map_coordinates)
@@ -2047,5 +2265,6 @@ extern "C" int mi_debug_set_affine_gz(int k) { mi::g_affine_gz = k; return MI_OK
 extern "C" int mi_debug_set_affine_rowblend(int k) { mi::g_affine_rowblend = k; return MI_OK; }
 extern "C" int mi_debug_set_map_zstream(int k) { mi::g_map_zstream = k; return MI_OK; }
 extern "C" int mi_debug_set_map_zchunks(int k) { mi::g_map_zchunks = k; return MI_OK; }
+extern "C" int mi_debug_set_map_zvariant(int k) { mi::g_map_zvariant = k; return MI_OK; }
 extern "C" int mi_debug_set_affine_zstream(int k) { mi::g_affine_zstream = k; return MI_OK; }
 extern "C" int mi_debug_set_affine_zchunks(int k) { mi::g_affine_zchunks = k; return MI_OK; }

@@ -59,8 +59,9 @@ int mi_debug_set_u8_fused(int k);
 int mi_debug_set_interp_generic(int on);
 int mi_debug_set_affine_gz(int k);            /* LDS-staged affine kernel: workgroups along z (0 = one per tile; fewer = each walks several tiles of its column) */
 int mi_debug_set_affine_rowblend(int k);      /* row-blend affine kernel (x axis untouched): 0 off, 1 on (default) */
-int mi_debug_set_map_zstream(int k);          /* z-streaming map_coordinates kernel: 0 off, 1 on (default), 2 on with every step on the L1 gathers */
+int mi_debug_set_map_zstream(int k);          /* z-streaming map_coordinates kernel: 0 off, 1 on (default), 2 on with every step on the L1 gathers, 3 on with the exact box reduction (first r4 kernel) */
 int mi_debug_set_map_zchunks(int k);          /* its z chunks (0 = planner) */
+int mi_debug_set_map_zvariant(int k);         /* its instance: 10 x voxels per thread + planes of coordinates in flight (81, 82, 41; 0 = default) */
 int mi_debug_set_affine_zstream(int k);       /* z-streaming affine kernel (axis 0 decoupled): 0 off, 1 auto, 32 / 64 tile height */
 int mi_debug_set_affine_zchunks(int k);       /* its z chunks (0 = planner) */
 int mi_debug_set_affine_dbg(int k);           /* LDS-staged affine kernel ablations: 1 no box DMA, 2 no interpolation, 4 no stores (timing only) */

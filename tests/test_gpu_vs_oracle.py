@@ -1677,6 +1677,12 @@ def test_map_coordinates_zstream_kernel(gpu, ndi):
         "smooth non-affine": warp(np.eye(3), [1.0, 2.0, 3.0], lambda c: 1.5 * np.sin(c / 9.0)),
         "mostly outside": warp(np.eye(3), [30.0, -60.0, 100.0]),
         "random coordinates": (rng.random((3,) + oshape) * np.array(shape)[:, None, None, None]).astype(np.float32),
+        # r4b: the rectangle is placed from the tile's corner voxels; voxels whose taps it does not hold gather for themselves
+        "bulge inside the tiles (corner box too small)": warp(np.eye(3), [1.0, 2.0, 3.0],
+                                                             lambda c: np.stack([3.0 * np.sin(c[1] / 5.0) * np.sin(c[2] / 7.0),
+                                                                                 14.0 * np.sin(c[2] / 10.0), 18.0 * np.sin(c[1] / 5.0)])),
+        "jitter of +-12 voxels around the identity": warp(np.eye(3), [0.0, 0.0, 0.0], lambda c: rng.uniform(-12, 12, c.shape)),
+        "jitter along z only": warp(np.eye(3), [0.0, 0.0, 0.0], lambda c: np.stack([rng.uniform(-3, 3, c.shape[1:]), 0 * c[1], 0 * c[2]])),
     }
     wild = cases["rotation in the plane"].copy()
     wild[0, 5, 6, 7] = np.nan; wild[1, 9, 10, 11] = np.inf; wild[2, 20, 21, 22] = -np.inf; wild[:, 30, 40, 50] = 1e30
@@ -1689,14 +1695,16 @@ def test_map_coordinates_zstream_kernel(gpu, ndi):
             want = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
         finally:
             lib.mi_debug_set_map_zstream(1)
-        for knob, zc in ((1, 0), (1, 1), (1, 5), (2, 0)):
-            lib.mi_debug_set_map_zstream(knob); lib.mi_debug_set_map_zchunks(zc)
+        # knob 3 = the exact box reduction (first r4 kernel); variant = 10 x voxels per thread + planes of coordinates in flight
+        for knob, zc, variant in ((1, 0, 0), (1, 1, 0), (1, 5, 0), (2, 0, 0), (3, 0, 0), (3, 5, 0), (1, 0, 81), (1, 5, 81), (1, 0, 82),
+                                  (1, 1, 82), (1, 5, 82), (1, 24, 82), (1, 24, 41), (2, 0, 82), (2, 0, 41)):
+            lib.mi_debug_set_map_zstream(knob); lib.mi_debug_set_map_zchunks(zc); lib.mi_debug_set_map_zvariant(variant)
             try:
                 got = ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=-0.75).get()
                 assert "map_coords3d_zstream" in last_kernel()
             finally:
-                lib.mi_debug_set_map_zstream(1); lib.mi_debug_set_map_zchunks(0)
-            assert np.array_equal(got, want, equal_nan=True), (name, knob, zc, int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want))))))
+                lib.mi_debug_set_map_zstream(1); lib.mi_debug_set_map_zchunks(0); lib.mi_debug_set_map_zvariant(0)
+            assert np.array_equal(got, want, equal_nan=True), (name, knob, zc, variant, int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want))))))
         ref = orc.map_coordinates(x, c, order=1, mode="constant", cval=-0.75)
         ok = np.isfinite(ref)
         assert np.array_equal(np.isfinite(want), ok), name
