@@ -223,7 +223,7 @@ def _is_ablation_build(mangled):
     kernels) may spill.  Decided from the template arguments of the Itanium-mangled name -- `Lb1E` in third position --
     not from one exact suffix, so that a new trailing parameter or a renamed parameter struct cannot silently turn the
     exemption off (or on for a product kernel)."""
-    m = re.search(r"sep3d_long3_kernelI((?:L[a-z]n?\d+E)+)E", mangled)
+    m = re.search(r"sep3d_long[34]_kernelI((?:L[a-z]n?\d+E)+)E", mangled)
     if not m:
         return False
     targs = re.findall(r"L([a-z])(n?\d+)E", m.group(1))

@@ -1214,7 +1214,7 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
     // then holds runs of x-neighbouring tiles, whose rectangles overlap, of the same chunk
     const int total = q.ntx * q.nty * q.nzc;
     int t = blockIdx.x;
-    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
+    if ((total & 7) == 0 && !(q.dbg & 64)) t = (t & 7) * (total >> 3) + (t >> 3);
     const int tx_i = t % q.ntx, ty_i = (t / q.ntx) % q.nty, zc_i = t / (q.ntx * q.nty);
     const int x0 = tx_i * 64, y0 = ty_i * TY;
     const int zs = zc_i * q.zc, ze = min(zs + q.zc, q.oS);
@@ -1281,7 +1281,10 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
     for (int z = zs; z < ze; z++) {
         // the planes of this step have landed (the stores of the previous step, issued after their DMAs, may still be
         // in flight: two per thread on full tiles), and everyone has finished reading the previous step's planes
-        if (wide) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // (r4b: the FIRST step has no stores behind the prologue's DMAs -- vmcnt(2) there let the last two chunks of a
+        // chunk's first plane be read before they had landed: a few wrong voxels in the first plane of a z chunk under
+        // back-to-back launches, found by the whole-volume check of scripts/bench_configs.py)
+        if (wide && z > zs) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         ZSplit nxt = cur;
@@ -1564,7 +1567,7 @@ map_coords3d_zstream_kernel(const float *__restrict__ in, const float *__restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int total = q.ntx * q.nty * q.nzc;
     int t = blockIdx.x;
-    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);          // x-neighbouring tiles on one XCD
+    if ((total & 7) == 0 && !(q.dbg & 64)) t = (t & 7) * (total >> 3) + (t >> 3);          // x-neighbouring tiles on one XCD
     const int tx_i = t % q.ntx, ty_i = (t / q.ntx) % q.nty, zc_i = t / (q.ntx * q.nty);
     const int x0 = tx_i * 64, y0 = ty_i * TY;
     const int zs = zc_i * q.zc, ze = min(zs + q.zc, oz);
@@ -2088,7 +2091,7 @@ static int launch_map_zstream(const float *in, const float *coords, float *out, 
     nzc = std::max(1, std::min(nzc, (p.oz + 15) / 16));
     q.zc = (p.oz + nzc - 1) / nzc;
     q.nzc = (p.oz + q.zc - 1) / q.zc;
-    q.dbg = (g_affine_dbg & 13) | (g_map_zstream == 2 ? 2 : 0);
+    q.dbg = (g_affine_dbg & (13 | 64)) | (g_map_zstream == 2 ? 2 : 0);
     if (g_map_zstream == 3) return launch_map_zstream_as<false, 8, 1>(in, coords, out, q, tiles, s);
     switch ((int)g_map_zvariant) {
     case 81: return launch_map_zstream_as<true, 8, 1>(in, coords, out, q, tiles, s);

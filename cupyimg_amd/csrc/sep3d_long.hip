@@ -602,12 +602,18 @@ struct XPass3 {
         constexpr int t = Q - BASE;
         if constexpr (t >= 0 && t <= W + 2) {
             const f32x2 ws = splat2(wq);
+            // The first and the last sample of a pair of outputs' windows belong to ONE of the two outputs: a packed FMA
+            // against (w[0], 0) / (0, w[W-1]) would multiply the other's accumulator with 0 x sample -- a NaN when the
+            // sample is not finite, one voxel beyond the taps, where an explicit sum over the taps stays finite.  Those
+            // four updates are scalar (same instruction count; r4b, found with non-finite samples in the volume).
             if constexpr (t <= W) {
-                if constexpr (t == 0) P0 = ws * xpair_rev<t>(te, to);
+                if constexpr (t == 0) P0 = (f32x2){wq * te[0], 0.f};
+                else if constexpr (t == W) P0.y = __builtin_fmaf(wq, te[W - 1], P0.y);
                 else P0 = fma2(ws, xpair_rev<t>(te, to), P0);
             }
             if constexpr (t >= 2) {
-                if constexpr (t == 2) P1 = ws * xpair_rev<t - 2>(te, to);
+                if constexpr (t == 2) P1 = (f32x2){wq * te[0], 0.f};
+                else if constexpr (t == W + 2) P1.y = __builtin_fmaf(wq, te[W - 1], P1.y);
                 else P1 = fma2(ws, xpair_rev<t - 2>(te, to), P1);
             }
         }
@@ -942,7 +948,224 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-static mi::Knob g_long_rows{0};        // kernel generation: 0 = auto (r3 pipelined kernel), 1 = the r2 kernel (kept for 9 / 13 / 17 taps as the comparator)
+// ---------------------------------------------------------------------------
+// r4b kernel (`sep3d_long4_kernel`): the y pass on the MATRIX cores.  The 13- / 17-tap kernels are bound by what a wave's
+// VALU issues (138 instructions per wave and plane for 102 packed FMAs, 68 % busy at the clock the chip holds), not by
+// memory; the matrix pipe sits idle next to it.  Along y the tile is a product with a banded Toeplitz matrix:
+//     Y[16 rows x 16 columns] = T[16 x 4 KS] . RAW[4 KS staged rows x 16 columns],   T[i][k] = wy[k - i] (0 outside the band)
+// i.e. KS = ROWS / 4 `v_mfma_f32_16x16x4_f32` per 16-column block (full fp32 products and sums).  Wave w owns column
+// block w of the tile (16 x 16 outputs): KS ds_read_b32 (lane -> staged row 4 kk + lane / 16, column 16 w + lane % 16:
+// conflict-free, the record stride is 272 words), KS MFMAs, four ds_write_b32 into a y-filtered plane `Y` in LDS (two
+// copies, by step parity; the raw ring needs three slots only because the y pass runs a plane ahead); the rotating wave
+// of the halo table does a 17th block (the 16 halo floats of the records).  One step later every wave reads ITS output
+// row of Y -- five aligned 16-byte reads, halo blocks in place: no DPP shifts, no edge selects -- for the x and z passes,
+// which stay on the VALU: 34 + 34 packed FMAs + ~15 other VALU instructions per wave and plane instead of 138, and
+// 17 x 16 = 272 bytes per lane of LDS reads instead of 17 x 16 + halos with 8.5 x less data.  The band's zeros multiply
+// samples OUTSIDE an output's window: a non-finite sample there would leak a NaN (0 x inf) into rows SciPy leaves
+// alone, so a block whose MFMA result holds a NaN is recomputed tap by tap (rare; exact semantics).
+// Same tile, DMA statement, barrier and vmcnt scheme as the r3 kernel; index-mapping boundary modes; W with ROWS % 4 == 0.
+// ---------------------------------------------------------------------------
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <int W, bool SAME, bool DBG = false, int WZ = W>
+__global__ void __launch_bounds__(kLongTY * 64)
+sep3d_long4_kernel(const float *__restrict__ in, float *__restrict__ out, const LongParams p)
+{
+    constexpr int ROWS = kLongTY + W - 1, KS = ROWS / 4;
+    const int dbg = DBG ? p.dbg : 0;         // ablations (timing aids): 1 no y pass, 2 no x pass, 4 no z scatter, 8 no DMA, 16 no stores
+    static_assert(W >= 5 && (W & 1) && ROWS <= kLongRowsMax && ROWS % 4 == 0, "long4 kernel: W = 5, 9, 13, 17");
+    static_assert(WZ >= 3 && (WZ & 1) && WZ <= 17 && (WZ == W || !SAME), "long4 kernel: odd WZ");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr unsigned kPlane = kLongRowsMax * kLongRec;
+    constexpr unsigned kY0 = 3u * kPlane;                                    // two y-filtered planes of 16 records
+    constexpr unsigned kYpar = (unsigned)kLongTY * kLongRec;
+    int *ztab = reinterpret_cast<int *>(smem + kY0 + 2u * kYpar);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    int b = blockIdx.x;
+    const int total = p.nxt * p.nyt * p.nzc;
+    if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
+    const int per_chunk = p.nxt * p.nyt;
+    const int zci = b / per_chunk;
+    const int rem = b - zci * per_chunk;
+    const int yt = rem / p.nxt, xt = rem - yt * p.nxt;
+
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int x0 = xt * p.tw, y0 = yt * kLongTY;
+    int zs, ze;
+    {
+        const bool second = zci >= p.nzc0;
+        const int zb = second ? p.zb1 : p.zb0, zn = second ? p.zn1 : p.zn0;
+        zs = zb + (second ? zci - p.nzc0 : zci) * p.zc;
+        ze = min(zs + p.zc, zb + zn);
+    }
+    const int ty_act = min(kLongTY, ny - y0);
+    const int rows_needed = ty_act + W - 1;
+    const int nlanes = min(p.tw >> 2, (nx - x0) >> 2);
+    const int xe = x0 + 4 * nlanes;
+    const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
+    const int zi0 = zs - p.oz;
+    const int nsteps = ze - zs + WZ - 1;
+
+    for (int i = threadIdx.x; i < nsteps; i += kLongTY * 64) ztab[i] = bmap<int>(zi0 + i, nz, p.mz);
+    __syncthreads();
+
+    unsigned vmain[2], vhalo[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int r = wave + 16 * h;
+        const int ys = bmap<int>(y0 - p.oy + r, ny, p.my);
+        const bool valid = r < rows_needed;
+        vmain[h] = (valid && lane < nlanes) ? (unsigned)(ys * nx + x0 + 4 * lane) * 4u : kOOB;
+        const int j = lane & 15;
+        const int xsrc = bmap<int>(j < 8 ? x0 - 8 + j : xe + j - 8, nx, p.mx);
+        vhalo[h] = (valid && xsrc >= 0) ? (unsigned)(ys * nx + xsrc) * 4u : kOOB;
+    }
+    const unsigned ovoff = (wave < ty_act && lane < nlanes) ? (unsigned)((y0 + wave) * nx + x0 + 4 * lane) * 4u : kOOB;
+
+    auto issue = [&](int i, unsigned bufoff) {
+        const bool live = i < nsteps;
+        int zsrc = zi0 + i;
+        if ((unsigned)zsrc >= (unsigned)nz) zsrc = __builtin_amdgcn_readfirstlane(ztab[live ? i : 0]);   // boundary planes only
+        const unsigned long long a = (unsigned long long)in + (unsigned long long)(unsigned)zsrc * (unsigned long long)plane_bytes;
+        u32x4_t rin;
+        rin.x = (unsigned)a;
+        rin.y = (unsigned)(a >> 32);
+        rin.z = live ? plane_bytes : 0u;
+        rin.w = 0x00020000u;
+        if (!(dbg & 8)) dma_two_rows(rin, vmain[0], vhalo[0], vmain[1], vhalo[1], bufoff + (unsigned)wave * kLongRec);
+    };
+    constexpr int kArgBase = 2 * sizeof(void *);
+    kfloats wyk = kernarg_floats(kArgBase + offsetof(LongParams, wyp));
+    kfloats wzk = SAME ? wyk : kernarg_floats(kArgBase + offsetof(LongParams, wzp));
+    kfloats xte = SAME ? wyk : kernarg_floats(kArgBase + offsetof(LongParams, wxe));
+    kfloats xto = kernarg_floats(kArgBase + offsetof(LongParams, wxo));
+
+    // ---- the band: A operand of step kk = T[i = lane % 16][k = 4 kk + lane / 16] = wy[k - i]
+    float Ta[KS];
+    {
+        const int ti = lane & 15, tg = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+            const int tap = 4 * kk + tg - ti;
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < W; k++) a = tap == k ? wyk[k] : a;
+            Ta[kk] = a;
+        }
+    }
+    // B operand / result geometry of a block: lane -> (staged row 4 kk + lane / 16, column 16 blk + lane % 16); the result
+    // registers r = 0 .. 3 are rows 4 (lane / 16) + r of column 16 blk + lane % 16
+    const unsigned rd_lane = (unsigned)(lane >> 4) * kLongRec + (unsigned)(lane & 15) * 4u;
+    const unsigned wr_row = (unsigned)(lane >> 4) * 4u * kLongRec;
+    // where the result goes in a Y record: [8 left halo floats][the row][8 right halo floats behind its last valid float4]
+    const int mycol = 16 * wave + (lane & 15);
+    const bool main_ok = mycol < 4 * nlanes;
+    const unsigned wr_main = wr_row + 32u + (unsigned)mycol * 4u;
+    const unsigned wr_halo = wr_row + ((lane & 15) < 8 ? (unsigned)(lane & 15) * 4u : 32u + 16u * (unsigned)nlanes + (unsigned)((lane & 15) - 8) * 4u);
+
+    // y pass of one 16-column block of the plane staged at `sb` -> Y plane at `yb`
+    auto yblock = [&](unsigned sb, unsigned yb, int blk, unsigned wr, bool ok) {
+        const char *src = smem + sb + rd_lane + (unsigned)blk * 64u;
+        float bv[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) bv[kk] = *reinterpret_cast<const float *>(src + (unsigned)(4 * kk) * kLongRec);
+        f32x4m d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(Ta[kk], bv[kk], d, 0, 0, 0);
+        const float chk = (d.x + d.y) + (d.z + d.w);
+        char *dst = smem + yb + wr;
+        if (__builtin_amdgcn_ballot_w64(chk != chk) != 0) {
+            // a NaN: either the window of one of these outputs holds a non-finite sample (then the tap-by-tap sum says what
+            // SciPy says) or a zero of the band met one outside it (then it must not show).  Row by row: few live registers.
+            const char *col = smem + sb + (unsigned)blk * 64u + (unsigned)(lane & 15) * 4u + wr_row;
+#pragma unroll 1
+            for (int r = 0; r < 4; r++) {                                    // rolled loops: this path is rare, its code should be small
+                float acc = 0.f;
+#pragma unroll 1
+                for (int k = 0; k < W; k++) acc = fmaf(wyk[k], *reinterpret_cast<const float *>(col + (unsigned)(r + k) * kLongRec), acc);
+                if (ok) *reinterpret_cast<float *>(dst + (unsigned)r * kLongRec) = acc;
+            }
+        } else if (ok) {
+            *reinterpret_cast<float *>(dst) = d.x;
+            *reinterpret_cast<float *>(dst + kLongRec) = d.y;
+            *reinterpret_cast<float *>(dst + 2 * kLongRec) = d.z;
+            *reinterpret_cast<float *>(dst + 3 * kLongRec) = d.w;
+        }
+    };
+    auto yplane = [&](int i, unsigned sb) {                                  // y pass of the plane of step i
+        const unsigned yb = kY0 + (unsigned)(i & 1) * kYpar;
+        yblock(sb, yb, wave, wr_main, main_ok);
+        if (wave == (i & 15)) yblock(sb, yb, 16, wr_halo, true);             // the 16 halo floats of the records: block 16
+    };
+
+    F4 acc[WZ];
+#pragma unroll
+    for (int k = 0; k < WZ; k++) acc[k] = f4_splat(0.f);
+
+    // prologue: planes 0..2 in flight; plane 0 complete -> its y pass
+    issue(0, 0);
+    issue(1, kPlane);
+    issue(2, 2 * kPlane);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    yplane(0, 0);
+
+    // Interval i (after barrier i): plane i + 1 has landed, Y(i) is complete (every wave waited for its LDS writes before
+    // the barrier), nobody reads Y(i - 1) or raw plane i any more: the slot of plane i takes plane i + 3, Y(i + 1) goes
+    // where Y(i - 1) was.
+    const unsigned xr_own = kY0 + (unsigned)wave * kLongRec + (unsigned)lane * 16u;       // block -2 of this lane's window in Y(i)
+    const bool vector_first = ((wave >> 2) & 1) != 0 && !(dbg & 64);
+    unsigned bi = 0;                    // LDS offset of raw plane i
+    for (int i0 = 0; i0 < nsteps; i0 += WZ) {
+        static_for<WZ>([&](auto JJ) {
+            constexpr int J = decltype(JJ)::value;
+            const int i = i0 + J;
+            if (i < nsteps) {
+                if constexpr (!SAME) { launder(wyk); launder(wzk); launder(xte); launder(xto); }
+                const unsigned b1 = bi == 2u * kPlane ? 0u : bi + kPlane;     // plane i + 1
+                // in flight from this wave, oldest first: the 4 DMAs of plane i + 1, the store of step i - 2, the 4 DMAs of
+                // plane i + 2, the store of step i - 1 (see sep3d_long3_kernel): plane i + 1 must have landed
+                if (J == 0 && i0 == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue(i + 3, bi);
+                // ---- x and z passes of plane i (VALU) and y pass of plane i + 1 (matrix cores): independent of each other.  The
+                // waves of a SIMD are w, w + 4, w + 8, w + 12: half of them take the matrix part first, half the vector part, so
+                // that the two pipes of a SIMD have work at the same time instead of one after the other.
+                auto xz = [&]() {
+                    // x pass of plane i out of Y(i): the window's blocks around (and including) the lane's own float4
+                    constexpr int NBK = XPass3<W>::NBK;
+                    float4 blk[2 * NBK + 1];
+                    const char *xr = smem + xr_own + (unsigned)(i & 1) * kYpar;
+#pragma unroll
+                    for (int q = 0; q < 2 * NBK + 1; q++) blk[q] = *reinterpret_cast<const float4 *>(xr + 32 + 16 * (q - NBK));
+                    XPass3<W> xp;
+                    const F4 xy = (dbg & 2) ? f4_from(blk[NBK]) : xp.window(blk, xte, xto);
+                    // z pass: scatter into the pending outputs; output i - k takes tap k
+                    acc[J] = f4_scale(wzk[0], xy);
+                    const int wz_taps = (dbg & 4) ? 1 : WZ;
+#pragma unroll
+                    for (int k = 1; k < WZ; k++) if (k < wz_taps) acc[(J - k + WZ) % WZ] = f4_fma(wzk[k], xy, acc[(J - k + WZ) % WZ]);
+                    const unsigned long long oa = (unsigned long long)out +
+                                                  (unsigned long long)(unsigned)(zs + i - (WZ - 1)) * (unsigned long long)plane_bytes;
+                    const __amdgpu_buffer_rsrc_t rout =
+                        __builtin_amdgcn_make_buffer_rsrc((void *)oa, 0, i >= WZ - 1 ? (int)plane_bytes : 0, 0x00020000);
+                    const F4 o = acc[(J + 1) % WZ];
+                    if (!(dbg & 16)) __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(o), rout, ovoff, 0, 2);
+                };
+                if (vector_first) xz();
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < nsteps && !(dbg & 1)) yplane(i + 1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!vector_first) xz();
+                bi = b1;
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static mi::Knob g_long_rows{0};        // kernel generation: 0 / 3 = the r3 pipelined kernel, 1 = the r2 kernel (kept for 9 / 13 / 17 taps as the comparator), 4 = the r4 kernel with the y pass on the matrix cores (9 / 13 / 17 taps; an experiment that did not pay)
 static mi::Knob g_long_dbg{0};         // tuning ablations, see LongParams::dbg
 static mi::Knob g_long_cfg{0};         // MI_LONG_TUNE builds: which tuning variant of the 17-tap kernel runs
 
@@ -986,7 +1209,7 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
                 return long_launch_one(sep3d_long_kernel<W, SAME, false>, attr_old, lds, total, in, out, p, s);
             }
             // the ablation flags exist in these instances only
-            if (p.dbg != 0) {
+            if (p.dbg != 0 && g_long_rows != 4) {
                 static bool attr_dbg = false;
                 note_kernel("mi::sep3d_long3_kernel<%d,%s,true> grid=%d (ablation build, dbg=%d)", W, SAME ? "true" : "false", total, p.dbg);
                 return long_launch_one(sep3d_long3_kernel<W, SAME, true>, attr_dbg, lds, total, in, out, p, s);
@@ -1016,6 +1239,21 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
 #undef MI_LONG_CFG
         }
 #endif
+        if constexpr (W == 9 || W == 13 || W == 17) {
+            if (g_long_rows == 4) {                 // not the default: 268 against 261 us on config B (fp32 MFMAs and the packed FMAs share one datapath)
+                static bool attr4 = false;
+                const size_t lds4 = 3 * (size_t)kLongRowsMax * kLongRec + 2 * (size_t)kLongTY * kLongRec + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int);
+                note_kernel("mi::sep3d_long4_kernel<%d,%s> grid=%d (fused y/x/z separable pass, LDS-DMA staged, y pass on the matrix cores)", W,
+                            SAME ? "true" : "false", total);
+                if constexpr (W == 17 && SAME) {
+                    if (p.dbg != 0) {
+                        static bool attr4d = false;
+                        return long_launch_one(sep3d_long4_kernel<W, SAME, true>, attr4d, lds4, total, in, out, p, s);
+                    }
+                }
+                return long_launch_one(sep3d_long4_kernel<W, SAME>, attr4, lds4, total, in, out, p, s);
+            }
+        }
         static bool attr_done = false;
         note_kernel("mi::sep3d_long3_kernel<%d,%s> grid=%d (fused y/x/z separable pass, LDS-DMA staged, y pass one plane ahead)", W,
                     SAME ? "true" : "false", total);

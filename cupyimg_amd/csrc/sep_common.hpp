@@ -185,9 +185,12 @@ __device__ __forceinline__ F4 xdot(const f32x2 (&A)[NP], const float *__restrict
         static_for<m1 - m0 + 1>([&](auto MM) {
             constexpr int m = m0 + decltype(MM)::value;
             constexpr int j0 = 2 * m - t0, j1 = j0 + 1;
-            const f32x2 wp = (f32x2){(j0 >= 0 && j0 < WX) ? wx[j0 >= 0 && j0 < WX ? j0 : 0] : 0.f,
-                                     (j1 >= 0 && j1 < WX) ? wx[j1 >= 0 && j1 < WX ? j1 : 0] : 0.f};
-            if constexpr (m == m0) acc = wp * A[m];
+            constexpr bool in0 = j0 >= 0 && j0 < WX, in1 = j1 >= 0 && j1 < WX;
+            const f32x2 wp = (f32x2){in0 ? wx[in0 ? j0 : 0] : 0.f, in1 ? wx[in1 ? j1 : 0] : 0.f};
+            // a sample outside the taps is not multiplied at all (0 x inf would be a NaN): see xdot_tab
+            if constexpr (m == m0 && !in0) acc = (f32x2){0.f, wp.y * A[m].y};
+            else if constexpr (m == m0) acc = wp * A[m];
+            else if constexpr (!in1) acc.x = __builtin_fmaf(wp.x, A[m].x, acc.x);
             else acc = fma2(wp, A[m], acc);
         });
         o[c] = acc.x + acc.y;
@@ -223,10 +226,17 @@ __device__ __forceinline__ F4 xdot_tab(const f32x2 (&A)[NP], kfloats tab0, kfloa
         static_assert(m1 < NP, "window too short");
         kfloats tab = (c & 1) ? tab1 : tab0;
         f32x2 acc;
+        // The first / last pair of the window holds a sample OUTSIDE the output's taps when the window starts at an odd / ends
+        // at an even index: its table entry is a zero, and 0 x inf (or NaN) would leak a NaN one voxel beyond the taps, where
+        // the reference (an explicit sum over the taps) stays finite.  Those two half-used pairs take a scalar multiply /
+        // FMA on the half that counts -- the same number of instructions (r4b; found with non-finite samples in the volume).
+        constexpr bool first_half = (t0 & 1) != 0, last_half = (t1 & 1) == 0;
         static_for<m1 - m0 + 1>([&](auto MM) {
             constexpr int u = decltype(MM)::value;
             const f32x2 wp = (f32x2){tab[2 * u], tab[2 * u + 1]};
-            if constexpr (u == 0) acc = wp * A[m0];
+            if constexpr (u == 0 && first_half) acc = (f32x2){0.f, wp.y * A[m0].y};
+            else if constexpr (u == 0) acc = wp * A[m0];
+            else if constexpr (u == m1 - m0 && last_half) acc.x = __builtin_fmaf(wp.x, A[m0 + u].x, acc.x);
             else acc = fma2(wp, A[m0 + u], acc);
         });
         o[c] = acc.x + acc.y;

@@ -27,7 +27,7 @@ int mi_debug_set_sep3d_box(int k);            /* 0 auto, 1 never the running-sum
 int mi_debug_set_long_zchunks(int n);
 int mi_debug_set_long_same(int on);
 int mi_debug_set_long_cfg(int k);             /* long kernel, builds with -DMI_LONG_TUNE only: tuning variant of the 17-tap kernel (0 = product) */
-int mi_debug_set_long_rows(int k);            /* long kernel: 0 auto (r3 kernel), 1 the r2 instruction stream (kept for 9 / 13 / 17 taps as the comparator), 2 (MI_LONG_TUNE builds, 17 taps) r2 stream with two rows per wave */
+int mi_debug_set_long_rows(int k);            /* long kernel: 0 auto (r3 kernel), 1 the r2 instruction stream (kept for 9 / 13 / 17 taps as the comparator), 2 (MI_LONG_TUNE builds, 17 taps) r2 stream with two rows per wave, 4 the r4 kernel with the y pass on the matrix cores (9 / 13 / 17 taps) */
 int mi_debug_set_long_dbg(int flags);         /* long kernel ablations: 1 y reads one row, 2 no x pass, 4 no z scatter, 8 no DMA, 16 no stores, 32 no halo table */
 int mi_debug_set_stream_fused_max(int taps);
 int mi_debug_set_xcd_swizzle(int k);

@@ -10,6 +10,20 @@ from helpers import fullsize as fs
 
 pytestmark = pytest.mark.gpu
 
+# r4b: what is checked is the result of the LAST of a burst of back-to-back launches, not of one launch on an idle GPU.  A
+# hand-counted `s_waitcnt vmcnt` that is one or two operations short (affine3d_zstream_kernel's first step was) reads
+# LDS-DMA data a few hundred nanoseconds early: invisible after a single cold launch, a handful of wrong voxels in the
+# first plane of a z chunk once the memory system is loaded -- which is how the benchmark runs the kernels.
+BURST = 24
+
+
+def burst(fn):
+    """fn(out) -> None launched BURST times back to back into the same output (allocated by the first call)."""
+    out = fn(None)
+    for _ in range(BURST - 1):
+        fn(out)
+    return out
+
 
 @pytest.fixture(scope="module")
 def ndi(gpu):
@@ -28,7 +42,7 @@ def vol512(gpu):
 
 def test_H_uniform5_512(gpu, ndi, vol512):
     x, xd = vol512
-    out = ndi.uniform_filter(xd, size=5).get()
+    out = burst(lambda o: ndi.uniform_filter(xd, size=5, output=o)).get()
     err = fs.whole_volume_filter(x, out, 2, 2, lambda s: sndi.uniform_filter(s.astype(np.float64), size=5))
     assert err <= 1e-6, err
 
@@ -39,7 +53,7 @@ def test_H_neighbours_3_7_9_13_taps_512(gpu, ndi, vol512):
     x, xd = vol512
     from cupyimg_amd import last_kernel
     for size, mode in ((3, "mirror"), (7, "nearest"), (9, "mirror"), (13, "reflect")):
-        out = ndi.uniform_filter(xd, size=size, mode=mode)
+        out = burst(lambda o: ndi.uniform_filter(xd, size=size, mode=mode, output=o))
         assert "sep3d_long3_kernel<%d," % size in last_kernel(), last_kernel()
         out = out.get()
         h = size // 2
@@ -50,7 +64,7 @@ def test_H_neighbours_3_7_9_13_taps_512(gpu, ndi, vol512):
 
 def test_B_gaussian_sigma2_512(gpu, ndi, vol512):
     x, xd = vol512
-    out = ndi.gaussian_filter(xd, sigma=2).get()
+    out = burst(lambda o: ndi.gaussian_filter(xd, sigma=2, output=o)).get()
     # 17 taps per axis: halo 8
     err = fs.whole_volume_filter(x, out, 8, 8, lambda s: sndi.gaussian_filter(s.astype(np.float64), sigma=2), planes=16)
     assert err <= 1e-6, err
@@ -60,7 +74,7 @@ def test_D_map_coordinates_order1_512(gpu, ndi, vol512):
     x, xd = vol512
     coords = fs.affine_coords_f32(fs.N_H)
     cd = gpu.asarray(coords)
-    out = ndi.map_coordinates(xd, cd, order=1, mode="constant")
+    out = burst(lambda o: ndi.map_coordinates(xd, cd, order=1, mode="constant", output=o))
     assert out.dtype == np.float32 and out.shape == x.shape
     del cd
     err = fs.whole_volume_map_coordinates(x, coords, out.get())
@@ -70,7 +84,7 @@ def test_D_map_coordinates_order1_512(gpu, ndi, vol512):
 def test_Dprime_affine_transform_order1_512(gpu, ndi, vol512):
     x, xd = vol512
     M, off = fs.affine_case(fs.N_H)
-    out = ndi.affine_transform(xd, M, off, order=1, mode="constant")
+    out = burst(lambda o: ndi.affine_transform(xd, M, off, order=1, mode="constant", output=o))
     err = fs.whole_volume_affine(x, M, off, out.get())
     assert err <= 2e-6, err
 
@@ -79,7 +93,7 @@ def test_C_grey_erosion7_1024_u8(gpu, ndi):
     gpu.free_all_blocks()
     u = fs.volume_u8((fs.N_C,) * 3, seed=1)
     ud = gpu.asarray(u)
-    out = ndi.grey_erosion(ud, size=7)
+    out = burst(lambda o: ndi.grey_erosion(ud, size=7, output=o))
     assert out.dtype == np.uint8
     got = out.get()
     del ud, out
@@ -94,7 +108,8 @@ def test_E_slab_uniform9_264x2048x2048(gpu, ndi):
     x = fs.slab_volume_f32(fs.E_SLAB)
     xd = gpu.asarray(x)
     out = gpu.empty(x.shape, np.float32)
-    ndi.uniform_filter(xd, size=9, output=out)
+    for _ in range(8):
+        ndi.uniform_filter(xd, size=9, output=out)
     got = out.get()
     del xd, out
     gpu.free_all_blocks()

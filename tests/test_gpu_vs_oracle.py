@@ -1711,6 +1711,63 @@ def test_map_coordinates_zstream_kernel(gpu, ndi):
         assert np.allclose(want[ok], ref[ok], rtol=0, atol=2e-6 * max(1.0, np.abs(ref[ok]).max())), name
 
 
+def test_separable_filters_keep_nonfinite_samples_inside_their_window(gpu, ndi):
+    """An inf / NaN sample makes exactly the outputs whose taps reach it non-finite -- what an explicit sum over the taps (the
+    reference's kernels; SciPy's correlate1d) gives.  r4b: the packed x passes of the fused long kernels and of the
+    streaming passes multiplied the sample next to a window with the zero that pads a weight pair (0 x inf = NaN one to
+    three voxels beyond the taps along x); the matrix-core y pass of the experimental r4 kernel multiplies whole tile
+    columns with the zeros of its band and recomputes a block tap by tap when that shows.  Reference: correlate1d per axis
+    in float64 (SciPy's uniform_filter itself keeps a RUNNING sum and turns the rest of a line into NaN after an inf)."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import _lib, last_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+
+    def explicit(v, weights, mode):
+        for ax, w in enumerate(weights):
+            v = sndi.correlate1d(v, w, axis=ax, mode=mode)
+        return v
+
+    def gauss_w(sigma):
+        r = int(4.0 * sigma + 0.5)
+        xs = np.arange(-r, r + 1)
+        w = np.exp(-0.5 * (xs / sigma) ** 2)
+        return w / w.sum()
+
+    seen = set()
+    for shape in [(40, 64, 256), (36, 50, 300), (24, 128, 1024)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        x[shape[0] // 4, shape[1] // 3, shape[2] // 5] = np.inf
+        x[shape[0] // 2, shape[1] // 2, (4 * shape[2]) // 5] = np.nan
+        x[-1, -1, -1] = -np.inf
+        x[1, 2, 3] = np.inf
+        xd = gpu.asarray(x)
+        cases = [("uniform", s, m) for s in (3, 5, 7, 9, 11, 13, 17, 21, 4) for m in ("reflect", "constant")]
+        cases += [("gaussian", s, "reflect") for s in (1.0, 1.5, 2.0, 2.6, (2, 1, 1), (1, 2, 1.5))]
+        for kind, par, mode in cases:
+            for rows in ((0, 4) if (kind == "gaussian" and par in (1.0, 1.5, 2.0)) or (kind == "uniform" and par in (9, 13, 17) and mode == "reflect") else (0,)):
+                lib.mi_debug_set_long_rows(rows)
+                try:
+                    if kind == "uniform":
+                        got = ndi.uniform_filter(xd, par, mode=mode).get()
+                        ws = [np.ones(par) / par] * 3
+                    else:
+                        got = ndi.gaussian_filter(xd, par, mode=mode).get()
+                        sig = par if isinstance(par, tuple) else (par,) * 3
+                        ws = [gauss_w(s) for s in sig]
+                finally:
+                    lib.mi_debug_set_long_rows(0)
+                seen.add(last_kernel().split("<")[0].replace("mi::", ""))
+                with np.errstate(all="ignore"):
+                    ref = explicit(x.astype(np.float64), ws, mode)
+                what = (shape, kind, par, mode, rows, last_kernel()[:48])
+                assert np.array_equal(np.isnan(got), np.isnan(ref)), what
+                assert np.array_equal(np.isposinf(got), np.isposinf(ref)) and np.array_equal(np.isneginf(got), np.isneginf(ref)), what
+                fin = np.isfinite(ref)
+                assert np.abs(got[fin] - ref[fin]).max() <= 1e-6 * np.abs(ref[fin]).max(), what
+    assert {"sep3d_long3_kernel", "sep3d_long4_kernel", "sep3d_long_kernel", "sep3d_lean_kernel", "stream_pass_kernel"} <= seen, seen
+
+
 def test_affine_rowblend_kernel(gpu, ndi):
     """Matrices that leave the x axis to itself with unit step and an integral shift (a rotation / shear / scaling in the
     (z, y) plane: `rotate(volume, angle)` with the default axes) blend four input ROWS per output row
