@@ -589,6 +589,13 @@ def main():
                             "roofline_frac": round(c_ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(c_dev / args.steps * 1e3, 2)}
         if sched_info is not None:
             line["schedule"] = sched_info
+        if cpu is not None:
+            # single-GPU line: the output of the LAST timed launch against the oracle (and SciPy) over the whole volume
+            errs = [cpu.get(k) for k in ("parity_vs_oracle_maxnorm_rel", "parity_vs_scipy_maxnorm_rel") if cpu.get(k) is not None]
+            if errs:
+                line["whole_volume_parity_maxnorm_rel"] = max(errs)
+                line["parity_tol"] = parity_tol
+                parity_ok = parity_ok and max(errs) <= parity_tol
         line["parity_ok"] = bool(parity_ok)
         if slab_ok is not None:
             line["slabs_bit_identical_to_single_gpu"] = slab_ok
