@@ -213,6 +213,7 @@ static int launch_mm_long(const float *in, float *out, MmLongParams &p, hipStrea
         MI_HIP(hipFuncSetAttribute((const void *)mm3f32_long_kernel<W, IS_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
+    note_kernel("mi::mm3f32_long_kernel<%d,%s> grid=%d (fused y/x/z flat min / max, LDS-DMA staged)", W, IS_MAX ? "max" : "min", p.nxt * p.nyt * p.nzc);
     hipLaunchKernelGGL((mm3f32_long_kernel<W, IS_MAX>), dim3(p.nxt * p.nyt * p.nzc), dim3(kLongTY * 64), lds, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;

@@ -1373,6 +1373,8 @@ static int launch_u8_split(const uint8_t *in, uint8_t *out, U8FusedParams &p, bo
     if (p.zc > kU8MaxChunk) p.zc = kU8MaxChunk;
     p.nzc = (zn + p.zc - 1) / p.zc;
     const int64_t total = tiles * p.nzc;
+    note_kernel("mi::mm3u8_split_kernel<%d,%s,%d,%d,%d,%d,%s> grid=%d (fused flat min / max of a uint8 volume: producer / consumer waves)", W, IS_MAX ? "max" : "min", NWP, NWC, R, TY,
+                has_const ? "true" : "false", (int)total);
     if (has_const)
         hipLaunchKernelGGL((mm3u8_split_kernel<W, IS_MAX, NWP, NWC, R, TY, true>), dim3((unsigned)total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
     else
