@@ -88,6 +88,8 @@ SIGNATURES = {
     "mi_event_sync": [_vp],
     "mi_event_elapsed_ms": [_vp, _vp, ctypes.POINTER(ctypes.c_float)],
     "mi_copy": [_arr, _arr, _i, _vp],
+    "mi_extend_rows": [_arr, _arr, _i, _i, _d, _vp],
+    "mi_crop_rows": [_arr, _arr, _i, _vp],
     "mi_fill": [_arr, _d, _vp],
     "mi_any_diff": [_arr, _arr, _vp, _vp],
     "mi_elementwise": [_i, _arr, _arr, _arr, _vp],

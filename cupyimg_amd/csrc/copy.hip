@@ -182,6 +182,69 @@ __global__ void __launch_bounds__(256) minmax_reduce_kernel(const T *__restrict_
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = slo[0]; part[2 * blockIdx.x + 1] = shi[0]; }
 }
 
+
+// ---------------------------------------------------------------------------
+// r4b: rows that are not a multiple of 16 bytes.  The fused kernels load rows 16 bytes at a time and need them 16-byte
+// aligned; volumes such as 181 x 217 x 181 are first EXTENDED along x -- `left` elements in front (a multiple of 16 bytes,
+// so the kept columns stay aligned), the boundary continuation behind, to a multiple of 16 bytes -- and the result's
+// columns are copied back.  Both are row copies, 16 bytes per thread: one side aligned, the other an unaligned 16-byte
+// access (legal on this target) when the whole vector lies inside the row, element by element at the row ends.
+// ---------------------------------------------------------------------------
+struct __attribute__((packed, aligned(1))) Unaligned16 { unsigned w[4]; };
+struct __attribute__((aligned(16))) Aligned16 { unsigned w[4]; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) extend_rows_kernel(const T *__restrict__ in, T *__restrict__ out, int64_t rows, int nx, int total, int left,
+                                                          int mode, T cval)
+{
+    constexpr int V = 16 / (int)sizeof(T);
+    const int q = total / V;                                     // 16-byte vectors per output row
+    const int64_t n = rows * q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / q;
+        const int c = (int)(i - row * q) * V;
+        const T *src = in + row * nx;
+        const int x0 = c - left;
+        Aligned16 r;
+        if (x0 >= 0 && x0 + V <= nx) {
+            const Unaligned16 u = *reinterpret_cast<const Unaligned16 *>(src + x0);
+            r.w[0] = u.w[0]; r.w[1] = u.w[1]; r.w[2] = u.w[2]; r.w[3] = u.w[3];
+        } else {
+            T *v = reinterpret_cast<T *>(&r);
+#pragma unroll
+            for (int e = 0; e < V; e++) {
+                const int x = x0 + e;
+                const int xs = (unsigned)x < (unsigned)nx ? x : bmap<int>(x, nx, mode);      // -1: constant fill
+                v[e] = xs >= 0 ? src[xs] : cval;
+            }
+        }
+        *reinterpret_cast<Aligned16 *>(out + row * total + c) = r;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) crop_rows_kernel(const T *__restrict__ in, T *__restrict__ out, int64_t rows, int nx, int total, int left)
+{
+    constexpr int V = 16 / (int)sizeof(T);
+    const int q = (nx + V - 1) / V;                              // vectors per kept row (the last one partial)
+    const int64_t n = rows * q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / q;
+        const int c = (int)(i - row * q) * V;
+        const Aligned16 r = *reinterpret_cast<const Aligned16 *>(in + row * total + left + c);      // left % V == 0, total % V == 0
+        T *dst = out + row * nx + c;
+        if (c + V <= nx) {
+            Unaligned16 u;
+            u.w[0] = r.w[0]; u.w[1] = r.w[1]; u.w[2] = r.w[2]; u.w[3] = r.w[3];
+            *reinterpret_cast<Unaligned16 *>(dst) = u;
+        } else {
+            const T *v = reinterpret_cast<const T *>(&r);
+#pragma unroll
+            for (int e = 0; e < V; e++) if (c + e < nx) dst[e] = v[e];
+        }
+    }
+}
+
 }  // namespace mi
 
 using namespace mi;
@@ -402,6 +465,82 @@ int mi_min_max(const mi_array *a, double *lo, double *hi, mi_stream stream)
     }
     pool_free(part);
     return rc;
+}
+
+/* out[..., x] = in[..., map(x - left)] for x in [0, out.shape[-1]): rows extended along the last axis by the boundary mode
+ * (filter semantics, include/mi355img.h mi_mode; MI_MODE_CONSTANT fills with cval).  1-, 2- and 4-byte dtypes, in and out
+ * of one dtype, C-contiguous, same leading shape; the output rows and `left` multiples of 16 bytes, out 16-byte aligned. */
+static int rows_common(const char *who, const mi_array *wide, const mi_array *narrow, int left, int64_t *rows, int *esize)
+{
+#define ROWS_REQUIRE(cond, code, msg) do { if (!(cond)) { set_error("%s: %s", who, msg); return (code); } } while (0)
+    ROWS_REQUIRE(wide->dtype == narrow->dtype && wide->ndim == narrow->ndim && wide->ndim >= 1, MI_ERR_INVALID_ARG, "arrays of one dtype and rank");
+    const int es = (int)dtype_size(wide->dtype);
+    ROWS_REQUIRE(es == 1 || es == 2 || es == 4, MI_ERR_UNSUPPORTED, "1-, 2- and 4-byte dtypes");
+    ROWS_REQUIRE(is_contiguous(wide) && is_contiguous(narrow), MI_ERR_NOT_CONTIGUOUS, "C-contiguous arrays");
+    const int nd = wide->ndim, v = 16 / es;
+    *rows = 1;
+    for (int d = 0; d < nd - 1; d++) {
+        ROWS_REQUIRE(wide->shape[d] == narrow->shape[d], MI_ERR_INVALID_ARG, "leading shapes differ");
+        *rows *= wide->shape[d];
+    }
+    const int64_t nx = narrow->shape[nd - 1], total = wide->shape[nd - 1];
+    ROWS_REQUIRE(left >= 0 && left % v == 0 && total % v == 0 && total >= left + (nx + v - 1) / v * v && nx >= 1 && total < ((int64_t)1 << 30),
+                 MI_ERR_INVALID_ARG, "`left` and the extended rows must be multiples of 16 bytes, the kept columns (rounded up to 16 bytes) inside a row");
+    ROWS_REQUIRE(((uintptr_t)wide->data & 15) == 0, MI_ERR_INVALID_ARG, "the extended array must be 16-byte aligned");
+#undef ROWS_REQUIRE
+    *esize = es;
+    return MI_OK;
+}
+
+int mi_extend_rows(const mi_array *in, const mi_array *out, int left, int mode, double cval, mi_stream stream)
+{
+    int rc, es;
+    int64_t rows;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    if ((rc = rows_common("mi_extend_rows", out, in, left, &rows, &es))) return rc;
+    if (rows == 0) return MI_OK;
+    const int nd = in->ndim;
+    const int nx = (int)in->shape[nd - 1], total = (int)out->shape[nd - 1];
+    dim3 grid;
+    grid_for(rows * (total / (16 / es)), 256, &grid);
+    hipStream_t s = resolve_stream(stream);
+    const int m = filter_mode(mode);
+    if (es == 4) {
+        // the fill value in the array's own 4-byte dtype
+        unsigned bits;
+        if (in->dtype == MI_F32) { const float f = (float)cval; memcpy(&bits, &f, 4); }
+        else bits = (unsigned)(int64_t)cval;
+        hipLaunchKernelGGL(extend_rows_kernel<unsigned>, grid, dim3(256), 0, s, (const unsigned *)in->data, (unsigned *)out->data, rows, nx, total, left, m, bits);
+    } else if (es == 2) {
+        hipLaunchKernelGGL(extend_rows_kernel<unsigned short>, grid, dim3(256), 0, s, (const unsigned short *)in->data, (unsigned short *)out->data, rows, nx, total,
+                           left, m, (unsigned short)(int64_t)cval);
+    } else {
+        hipLaunchKernelGGL(extend_rows_kernel<unsigned char>, grid, dim3(256), 0, s, (const unsigned char *)in->data, (unsigned char *)out->data, rows, nx, total,
+                           left, m, (unsigned char)(int64_t)cval);
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+/* out[..., x] = in[..., left + x]: the inverse of mi_extend_rows (same requirements, roles of in / out swapped). */
+int mi_crop_rows(const mi_array *in, const mi_array *out, int left, mi_stream stream)
+{
+    int rc, es;
+    int64_t rows;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    if ((rc = rows_common("mi_crop_rows", in, out, left, &rows, &es))) return rc;
+    if (rows == 0) return MI_OK;
+    const int nd = in->ndim;
+    const int total = (int)in->shape[nd - 1], nx = (int)out->shape[nd - 1];
+    const int v = 16 / es;
+    dim3 grid;
+    grid_for(rows * ((nx + v - 1) / v), 256, &grid);
+    hipStream_t s = resolve_stream(stream);
+    if (es == 4) hipLaunchKernelGGL(crop_rows_kernel<unsigned>, grid, dim3(256), 0, s, (const unsigned *)in->data, (unsigned *)out->data, rows, nx, total, left);
+    else if (es == 2) hipLaunchKernelGGL(crop_rows_kernel<unsigned short>, grid, dim3(256), 0, s, (const unsigned short *)in->data, (unsigned short *)out->data, rows, nx, total, left);
+    else hipLaunchKernelGGL(crop_rows_kernel<unsigned char>, grid, dim3(256), 0, s, (const unsigned char *)in->data, (unsigned char *)out->data, rows, nx, total, left);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
 }
 
 }  // extern "C"

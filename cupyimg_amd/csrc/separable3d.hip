@@ -848,9 +848,14 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     // 1024 x 128^2, but 4-6 % SLOWER on 300^3 and 200 x 500 x 760, whose rows do not fill its 256-voxel wave tiles, and
     // equal or 3 % slower where the launch is latency bound).  Constant mode stays on the lean kernel below 9 taps.
     const int64_t nvox_out = nz * ny * nx;      // of the whole array: plane-range launches of one filter call take the same kernel
+    // 3 / 5 taps (r4b, scripts/bench_long_rule.py -> profiles/r4_long_rule.txt): the long kernel also wins on rows that are not
+    // multiples of 256 as long as its 256-float wave tiles are reasonably full (512 x 512 x 500: 171 against 189 us, 600^3:
+    // 322 / 350, 512 x 500 x 512: 160 / 180; 300^3 with 150-float tiles: 46 against 42 -- not taken) and whatever ny is
+    const int64_t nxt_l = (nx + 255) / 256;
+    const bool tiles_full = nx * 10 >= nxt_l * 256 * 7;
     const bool long_small = !any_const && w[0] >= 3 && w[0] <= 7 && nx >= 128 && ny >= 16 &&
                             (w[0] == 7 ? nvox_out >= ((int64_t)1 << 22)
-                                       : nvox_out >= ((int64_t)1 << 23) && ((nx & 255) == 0 || nx == 128) && (ny & 15) == 0);
+                                       : nvox_out >= ((int64_t)1 << 23) && (tiles_full || nx == 128));
     if (cubic_w && g_sep3d_long != 1 && nx >= 16 &&
         ((w[0] >= 9 && w[0] <= 17) || (w[0] >= 3 && w[0] <= 7 && (g_sep3d_long == 2 || long_small)))) {
         // long cubic kernels: ONE launch with LDS-DMA staging and the z state in registers (sep3d_long.hip)

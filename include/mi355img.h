@@ -145,6 +145,14 @@ int mi_event_elapsed_ms(mi_event start, mi_event stop, float *ms);
  * _interp_kernels.py:580-583). */
 int mi_copy(const mi_array *src, const mi_array *dst, int round_half_even, mi_stream stream);
 int mi_fill(const mi_array *dst, double value, mi_stream stream);
+/* r4b: rows that are not a multiple of 16 bytes (181 x 217 x 181 ...): out[..., x] = in[..., map(x - left)] for
+ * x in [0, out.shape[-1]) -- every row extended along the last axis by a filter boundary mode (MI_MODE_CONSTANT: cval) --
+ * and its inverse out[..., x] = in[..., left + x].  1-, 2- and 4-byte dtypes, C-contiguous; the extended rows and `left`
+ * are multiples of 16 bytes and the extended array is 16-byte aligned (what the fused kernels need: the Python layer runs
+ * them on the extended volume and copies the columns back; the reference has no counterpart -- its kernels index
+ * element by element, _filters_core.py:190-348). */
+int mi_extend_rows(const mi_array *in, const mi_array *out, int left, int mode, double cval, mi_stream stream);
+int mi_crop_rows(const mi_array *in, const mi_array *out, int left, mi_stream stream);
 /* *flag_dev (device int32) |= any(a != b); a, b contiguous, same dtype/shape */
 int mi_any_diff(const mi_array *a, const mi_array *b, int32_t *flag_dev, mi_stream stream);
 /* out = a (op) b, elementwise, one dtype, C-contiguous; op: 0 add, 1 subtract,

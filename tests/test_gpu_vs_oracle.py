@@ -1768,6 +1768,60 @@ def test_separable_filters_keep_nonfinite_samples_inside_their_window(gpu, ndi):
     assert {"sep3d_long3_kernel", "sep3d_long4_kernel", "sep3d_long_kernel", "sep3d_lean_kernel", "stream_pass_kernel"} <= seen, seen
 
 
+def test_separable_filters_rows_not_a_multiple_of_four(gpu, ndi):
+    """Volumes / images whose rows are not a multiple of four floats (181 x 217 x 181, 91 x 109 x 91, ...) take the fused
+    kernels through an explicit extension of the rows along x (r4b: `_fused_3d_padded_rows`): every boundary mode, box and
+    gaussian weights, short and long kernels, origins along y / z, a cval; against SciPy at the filters' tolerance."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(321)
+    fused = ("sep3d_", "stream_pass_kernel", "box")
+    for shape in [(45, 54, 45), (33, 40, 101), (20, 37, 262), (1, 301, 403), (16, 16, 31)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        for mode in ("reflect", "mirror", "nearest", "wrap", "constant"):
+            for what in (("u", 3), ("u", 5), ("u", 9), ("u", (3, 5, 7)), ("g", 1.0), ("g", 2.0), ("g", (0.0, 1.5, 1.5))):
+                kw = dict(mode=mode, cval=1.25)
+                if what[0] == "u":
+                    got = ndi.uniform_filter(xd, what[1], **kw).get()
+                    ref = sndi.uniform_filter(x.astype(np.float64), what[1], **kw)
+                else:
+                    got = ndi.gaussian_filter(xd, what[1], **kw).get()
+                    ref = sndi.gaussian_filter(x.astype(np.float64), what[1], **kw)
+                assert any(f in last_kernel() for f in fused), (shape, mode, what, last_kernel())
+                assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (shape, mode, what, last_kernel())
+        # origins along z / y (x origins are not taken by the fused kernels), output into a view
+        got = ndi.uniform_filter(xd, 5, origin=(1 if shape[0] > 4 else 0, -1, 0)).get()
+        ref = sndi.uniform_filter(x.astype(np.float64), 5, origin=(1 if shape[0] > 4 else 0, -1, 0))
+        assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), shape
+    img = rng.standard_normal((301, 403)).astype(np.float32)
+    got = ndi.gaussian_filter(gpu.asarray(img), 1.5).get()
+    assert np.abs(got - sndi.gaussian_filter(img.astype(np.float64), 1.5)).max() <= 1e-6 * 4
+    # flat min / max and grey morphology: float32, uint8, int16 -- bit-exact
+    for shape in [(45, 54, 45), (20, 37, 262), (1, 301, 403), (33, 40, 101)]:
+        for dt in (np.float32, np.uint8, np.int16):
+            x = (rng.standard_normal(shape) * 40 + 100).astype(dt)
+            xd = gpu.asarray(x)
+            for mode in ("reflect", "mirror", "nearest", "wrap", "constant"):
+                for size in (3, 5, 7, (1, 3, 5) if shape[0] > 1 else (1, 5, 3)):
+                    for fn, rf in ((ndi.maximum_filter, sndi.maximum_filter), (ndi.minimum_filter, sndi.minimum_filter)):
+                        got = fn(xd, size, mode=mode, cval=7).get()
+                        assert np.array_equal(got, rf(x, size, mode=mode, cval=7)), (shape, dt, mode, size, fn.__name__, last_kernel())
+            assert np.array_equal(ndi.grey_erosion(xd, size=3).get(), sndi.grey_erosion(x, size=3))
+    # dense correlate / convolve (LDS-tiled stencil kernel: SciPy's summation order in double, bit-identical)
+    for shape in [(45, 54, 45), (20, 37, 262)]:
+        for dt in (np.float32, np.uint8, np.int16):
+            x = (rng.standard_normal(shape) * 40 + 100).astype(dt)
+            xd = gpu.asarray(x)
+            for wshape, origin in (((3, 3, 3), 0), ((3, 5, 7), (0, 1, -2)), ((1, 3, 4), (0, 0, 1))):
+                w = rng.standard_normal(wshape)
+                for mode in ("reflect", "wrap", "constant", "mirror", "nearest"):
+                    got = ndi.correlate(xd, w, mode=mode, cval=3, origin=origin).get()
+                    assert np.array_equal(got, sndi.correlate(x, w, mode=mode, cval=3, origin=origin)), (shape, dt, wshape, mode, "correlate")
+                    got = ndi.convolve(xd, w, mode=mode, cval=3, origin=origin).get()
+                    assert np.array_equal(got, sndi.convolve(x, w, mode=mode, cval=3, origin=origin)), (shape, dt, wshape, mode, "convolve")
+
+
 def test_affine_rowblend_kernel(gpu, ndi):
     """Matrices that leave the x axis to itself with unit step and an integral shift (a rotation / shear / scaling in the
     (z, y) plane: `rotate(volume, angle)` with the default axes) blend four input ROWS per output row
