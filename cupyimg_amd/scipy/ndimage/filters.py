@@ -261,9 +261,9 @@ def _run_on_extended_rows(input, output, left, right, mode_x, cval, run):
     path on the extended array, whose x boundary handling no kept output depends on any more; returns None when it does
     not take the request -- and copy the columns back (mi_crop_rows).  Three efficient launches at ~3 x the fused
     kernel's traffic instead of generic per-axis passes (181 x 217 x 181 float32, uniform_filter(5): 125 -> 48 us)."""
-    if left < 0 or right < 0 or input.size < (1 << 15) or input.dtype.itemsize not in (1, 2, 4):
+    if left < 0 or right < 0 or input.size < (1 << 15) or input.dtype.itemsize not in (1, 2, 4) or output.dtype.itemsize not in (1, 2, 4):
         return None
-    v = 16 // input.dtype.itemsize
+    v = 16 // min(input.dtype.itemsize, output.dtype.itemsize)      # rows of both arrays become multiples of 16 bytes
     nx = input.shape[-1]
     pl = -(-left // v) * v
     total = -(-(pl + -(-nx // v) * v + right) // v) * v          # the kept columns, rounded up to 16 bytes, lie inside a row

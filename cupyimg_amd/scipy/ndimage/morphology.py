@@ -125,7 +125,16 @@ def _binary_erosion(input, structure, iterations, mask, output, border_value, or
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     final = output if direct else core.empty(output.shape, output.dtype)
 
-    if iterations == 1:
+    if (iterations == 1 and mask is None and src.dtype.itemsize == 1 and src.ndim in (2, 3) and src.shape[-1] % 4
+            and max(structure.shape) <= 9):                     # (the tiled kernel takes rows that are multiples of four bytes)
+        # rows that are not a multiple of 16 bytes: the tiled kernel on rows extended by the border value (r4b, filters.py
+        # _run_on_extended_rows; an out-of-range sample IS the border value, whichever way `invert` reads it)
+        from .filters import _run_on_extended_rows
+        left = structure.shape[-1] // 2 + int(origin[-1])
+        if _run_on_extended_rows(src, final, left, structure.shape[-1] - 1 - left, "constant", int(bool(border_value)),
+                                 lambda e, o: (launch(e, o), o)[1]) is None:
+            launch(src, final)
+    elif iterations == 1:
         launch(src, final)
     else:
         # brute-force ping-pong (morphology.py:301-327) with an on-device

@@ -1808,6 +1808,15 @@ def test_separable_filters_rows_not_a_multiple_of_four(gpu, ndi):
                         got = fn(xd, size, mode=mode, cval=7).get()
                         assert np.array_equal(got, rf(x, size, mode=mode, cval=7)), (shape, dt, mode, size, fn.__name__, last_kernel())
             assert np.array_equal(ndi.grey_erosion(xd, size=3).get(), sndi.grey_erosion(x, size=3))
+    # binary erosion / dilation, one iteration: rows extended by the border value
+    for shape in [(45, 54, 45), (20, 37, 262), (301, 403)]:
+        b = rng.random(shape) > 0.4
+        bd = gpu.asarray(b)
+        for st in (sndi.generate_binary_structure(len(shape), 1), sndi.generate_binary_structure(len(shape), len(shape)), np.ones((3,) * (len(shape) - 1) + (5,), bool)):
+            for bv in (0, 1):
+                for origin in (0, (0,) * (len(shape) - 1) + (1,)):
+                    assert np.array_equal(ndi.binary_erosion(bd, st, border_value=bv, origin=origin).get(), sndi.binary_erosion(b, st, border_value=bv, origin=origin)), (shape, bv, origin)
+                    assert np.array_equal(ndi.binary_dilation(bd, st, border_value=bv, origin=origin).get(), sndi.binary_dilation(b, st, border_value=bv, origin=origin)), (shape, bv, origin)
     # dense correlate / convolve (LDS-tiled stencil kernel: SciPy's summation order in double, bit-identical)
     for shape in [(45, 54, 45), (20, 37, 262)]:
         for dt in (np.float32, np.uint8, np.int16):
