@@ -132,7 +132,7 @@ def _correlate_or_convolve(input, weights, output, mode, cval, origin, convoluti
                                         S.mode_code(mode), float(cval), acc, None))
 
     if (input.ndim == 3 and output.dtype == input.dtype and input.dtype in (np.float32, np.uint8, np.int8, np.uint16, np.int16)
-            and (input.shape[2] * input.dtype.itemsize) % 16 and max(weights.shape) <= 9 and S.current_planes() is None):
+            and input.shape[2] % 4 and max(weights.shape) <= 9 and S.current_planes() is None):       # (the stencil kernel takes rows of 4 k elements)
         # rows that are not a multiple of 16 bytes: the LDS-tiled stencil kernel on explicitly extended rows (r4b;
         # 181 x 217 x 181 float32, 3 x 3 x 3 weights: 219 -> see DESIGN.md)
         left = weights.shape[2] // 2 + int(origins[2])
