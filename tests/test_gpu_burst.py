@@ -11,8 +11,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-BURST = 40
-ROUNDS = 3
+import os
+
+BURST = int(os.environ.get("MI_TEST_BURST", "40"))
+ROUNDS = int(os.environ.get("MI_TEST_BURST_ROUNDS", "3"))
 
 
 @pytest.fixture(scope="module")
