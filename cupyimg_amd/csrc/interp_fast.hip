@@ -14,6 +14,7 @@
 // tolerance for float32 interpolation is 2e-6 * max|ref| (tests/test_gpu_*).
 // Anything else (other dtypes, ranks, float64 output) runs interp.hip.
 #include <algorithm>
+#include <vector>
 #include <type_traits>
 
 #include "common.hpp"
@@ -1154,13 +1155,60 @@ struct ZStreamParams {
     double mRR, mRx, offR;   // cR = (mRR r + mRx x) + offR      (the oracle's summation order: the decoupled axis adds exact zeros)
     double mxR, mxx, offx;   // cx = (mxR r + mxx x) + offx
     double cval;
-    int ry;                  // rows of the staged rectangle
-    int nchunks;             // ry * 20
+    int ry;                  // rows of the staged window
+    int P;                   // LDS row pitch in floats (a multiple of 4, <= kZsP): the widest span a staged row needs
+    int shear;               // 1 = every staged row starts at its own first needed column, 0 = bounding rectangle (pitch kZsP)
+    int nchunks;             // ry * P / 4
     double cmin_y, cmin_x;   // minimum of cR / cx over a tile relative to its first voxel (see LdsAffineParams::cmin)
     int zc, nzc;             // output planes per chunk, chunks
     int ntx, nty;            // tiles along x / R
     int dbg;
 };
+
+// r4b: the staged window of a plane is SHEARED.  A tile of TY x 64 output voxels reads, in one input plane, a parallelogram
+// (the in-plane part of the matrix applied to the tile); its bounding rectangle is 2.3 x the tile at 30 degrees and its
+// rows fill LDS (one workgroup per CU, 322 us against 202 us at 7 degrees).  Each staged input row now starts at its OWN
+// first needed column (aligned down to 16 bytes) and is as long as the widest row needs: zs_row_span() gives, for input
+// row iy, the columns read by the voxels whose lower or upper tap row it is -- the tile rectangle cut by the band
+// iy - 1 <= cR < iy + 1, extremes of cx over the cut polygon's vertices.  Chunks of a row beyond its own span are not
+// fetched at all (their DMA offset fails the descriptor's range check), so the traffic follows the parallelogram.
+struct ZsSpan { int lo, hi; bool any; };
+__host__ __device__ inline ZsSpan zs_row_span(double mRR, double mRx, double mxR, double mxx, double cR, double cx, int T0, int T1, int iy)
+{
+    const double h = 1e-6 * (2.0 + fabs((double)iy) + fabs(cR));
+    const double vlo = (double)iy - 1.0 - h, vhi = (double)iy + 1.0 + h;
+    double umin = 1e300, umax = -1e300;
+    auto take = [&](double y, double x) {
+        const double u = (mxR * y + mxx * x) + cx;
+        umin = u < umin ? u : umin;
+        umax = u > umax ? u : umax;
+    };
+    const double ys[2] = {0.0, (double)T0}, xs[2] = {0.0, (double)T1};
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) {
+            const double v = (mRR * ys[a] + mRx * xs[b]) + cR;
+            if (v >= vlo && v <= vhi) take(ys[a], xs[b]);
+        }
+    const double vb[2] = {vlo, vhi};
+    for (int e = 0; e < 2; e++) {
+        for (int b = 0; b < 2; b++) {
+            if (mRR != 0.0) {                                    // edges x = 0 / x = T1: where they cross the band's boundaries
+                const double y = (vb[e] - cR - mRx * xs[b]) / mRR;
+                if (y >= -1e-9 && y <= (double)T0 + 1e-9) take(y, xs[b]);
+            }
+            if (mRx != 0.0) {                                    // edges y = 0 / y = T0
+                const double x = (vb[e] - cR - mRR * ys[b]) / mRx;
+                if (x >= -1e-9 && x <= (double)T1 + 1e-9) take(ys[b], x);
+            }
+        }
+    }
+    ZsSpan s;
+    s.any = umax >= umin;
+    const double hu = 1e-6 * (2.0 + fabs(umin) + fabs(umax));
+    s.lo = s.any ? (int)floor(fmax(umin - hu, -1e9)) : 0;
+    s.hi = s.any ? (int)floor(fmin(umax + hu, 1e9)) + 1 : -1;
+    return s;
+}
 
 struct ZSplit { int i0; float w1; bool in; };
 __device__ __forceinline__ ZSplit zs_split(double m0, double m3, int z, int nz)
@@ -1197,12 +1245,15 @@ __device__ __forceinline__ void zs_ensure(const float *in, int vol_bytes, int pl
         if (j < rounds && !off) dma_16s(rin, rel[j], base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * NT) * 16u));
 }
 
-template <int TY, int SAX>
+// SHEAR = false: every staged row starts at the same column (the tile's bounding rectangle, pitch kZsP: the upper tap row is
+// an immediate offset away, two address registers per voxel instead of four -- 202 against 220 us on config D'), taken when
+// the rectangle fits LDS twice per CU; SHEAR = true: row starts of their own.
+template <int TY, int SAX, bool SHEAR>
 __global__ void __launch_bounds__(TY * 8)
 affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, const ZStreamParams q)
 {
     constexpr int NT = TY * 8;                         // threads = TY / 8 waves; a wave owns 8 output rows of 64 voxels
-    constexpr int P = kZsP;
+    const int P = SHEAR ? q.P : kZsP, PC = P >> 2;     // LDS row pitch of the staged window: floats / 16-byte chunks
     extern __shared__ __attribute__((aligned(16))) char smem_zs[];
     const unsigned slot_bytes = (((unsigned)q.nchunks + NT - 1) / NT) * NT * 16u;       // whole rounds of NT chunks
     float *tiles = reinterpret_cast<float *>(smem_zs + 4u * slot_bytes);                // [NW][8 rows][64]
@@ -1211,7 +1262,7 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroup -> (tile x, tile y, z chunk): consecutive block indices go round the XCDs, so block b is given the
     // tile whose index in (chunk, ty, tx) order is (b % 8) * (total / 8) + b / 8 when the grid divides by 8 -- every XCD
-    // then holds runs of x-neighbouring tiles, whose rectangles overlap, of the same chunk
+    // then holds runs of x-neighbouring tiles, whose windows overlap, of the same chunk
     const int total = q.ntx * q.nty * q.nzc;
     int t = blockIdx.x;
     if ((total & 7) == 0 && !(q.dbg & 64)) t = (t & 7) * (total >> 3) + (t >> 3);
@@ -1219,36 +1270,61 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
     const int x0 = tx_i * 64, y0 = ty_i * TY;
     const int zs = zc_i * q.zc, ze = min(zs + q.zc, q.oS);
 
-    // ---- the rectangle: origin from the tile's first voxel (closed form, a hair below the true minimum, clamped
-    // into the volume, x aligned down to 16 bytes), chunk -> byte offset from the origin once per thread
-    int borg[2];
-#pragma unroll
-    for (int a = 1; a <= 2; a++) {
-        const double lo = a == 1 ? (q.mRR * (double)y0 + q.mRx * (double)x0) + (q.offR + q.cmin_y)
-                                 : (q.mxR * (double)y0 + q.mxx * (double)x0) + (q.offx + q.cmin_x);
-        const int n = a == 1 ? q.nR : q.nx;
+    // ---- the window: first staged row from the tile's first voxel (closed form, a hair below the true minimum, clamped
+    // into the volume); per staged row its first column (aligned down to 16 bytes) and its last one, once per workgroup
+    const double cR0 = (q.mRR * (double)y0 + q.mRx * (double)x0) + q.offR, cx0 = (q.mxR * (double)y0 + q.mxx * (double)x0) + q.offx;
+    int by0;
+    {
+        const double lo = cR0 + q.cmin_y;
         double f = floor(lo - 1e-6 * (1.0 + fabs(lo)));
-        f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
-        borg[a - 1] = __builtin_amdgcn_readfirstlane(a == 2 ? ((int)f & ~3) : (int)f);
+        f = f < 0.0 ? 0.0 : (f > (double)(q.nR - 1) ? (double)(q.nR - 1) : f);
+        by0 = __builtin_amdgcn_readfirstlane((int)f);
     }
-    const int by0 = borg[0], bx0 = borg[1];
+    int *rowtab = reinterpret_cast<int *>(tiles);               // [2][ry] until the loop starts: first column, last column
+    if constexpr (SHEAR) {
+        for (int r = tid; r < q.ry; r += NT) {
+            const ZsSpan sp = zs_row_span(q.mRR, q.mRx, q.mxR, q.mxx, cR0, cx0, TY - 1, 63, by0 + r);
+            const int st = sp.lo < 0 ? 0 : (sp.lo > q.nx - 1 ? q.nx - 1 : sp.lo);
+            rowtab[r] = st & ~3;
+            rowtab[q.ry + r] = sp.any ? sp.hi : -1;
+        }
+    } else {
+        // one origin for all rows: the closed-form minimum of cx over the tile, a hair below, clamped, aligned down
+        const double lo = cx0 + q.cmin_x;
+        double f = floor(lo - 1e-6 * (1.0 + fabs(lo)));
+        f = f < 0.0 ? 0.0 : (f > (double)(q.nx - 1) ? (double)(q.nx - 1) : f);
+        const int bx0 = (int)f & ~3;
+        for (int r = tid; r < q.ry; r += NT) {
+            rowtab[r] = bx0;
+            rowtab[q.ry + r] = bx0 + P - 1;
+        }
+    }
+    __syncthreads();
     const int rounds = (q.nchunks + NT - 1) / NT;
     unsigned rel[kZsRoundsMax];
 #pragma unroll
     for (int j = 0; j < kZsRoundsMax; j++) {
         const unsigned ch = (unsigned)tid + (unsigned)(j * NT);
-        const unsigned row = ch / 20u, c4 = ch - row * 20u;
-        // rows past the rectangle are not fetched (0x80000000 fails the descriptor's range check: zeros)
-        rel[j] = ch < (unsigned)q.nchunks ? row * q.in_sR * 4u + c4 * 16u : 0x80000000u;
+        const unsigned row = ch / (unsigned)PC, c4 = ch - row * (unsigned)PC;
+        bool need = ch < (unsigned)q.nchunks;
+        int st = 0;
+        if (need) {
+            st = rowtab[row];
+            need = st + 4 * (int)c4 <= rowtab[q.ry + (int)row];
+        }
+        // chunks past a row's own span and rows past the window are not fetched (0x80000000 fails the descriptor's range check)
+        rel[j] = need ? (row * q.in_sR + (unsigned)st + 4u * c4) * 4u : 0x80000000u;
     }
-    const unsigned plane_b = q.in_sS * 4u;
-    const unsigned org_b = ((unsigned)by0 * q.in_sR + (unsigned)bx0) * 4u;
+    const unsigned plane_b = q.in_sS * 4u, row_b = q.in_sR * 4u;
+    const unsigned org_b = (unsigned)by0 * q.in_sR * 4u;
 
-    // ---- per-thread, per-(y, x): LDS byte offset of the lower-left tap, weights, in-plane range test.  Voxel k of a
-    // lane: row y0 + 8 wave + k, column x0 + lane.
-    int a_[8];
+    // ---- per-thread, per-(y, x): LDS byte offsets of the lower-left tap in its row and in the row above (the rows start
+    // at different columns), weights, in-plane range test.  Voxel k of a lane: row y0 + 8 wave + k, column x0 + lane.
+    // A voxel whose taps the window does not hold (the plan sizes P from sampled tile offsets: this is the net under it)
+    // keeps its in-plane offset into the VOLUME instead, flagged by the sign bit, and gathers for itself in every plane.
+    int a_[8], a2_[8];
     float wy_[8], wx_[8];
-    unsigned inmask = 0;
+    unsigned inmask = 0, bad = 0;
     {
         const double dx = (double)(x0 + lane);
 #pragma unroll
@@ -1259,10 +1335,19 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
             const C1Split sx = c1_split((q.mxR * dy + q.mxx * dx) + q.offx, q.nx);
             const bool in = sy.in & sx.in;
             inmask |= in ? (1u << k) : 0u;
-            a_[k] = in ? ((sy.i0 - by0) * P + (sx.i0 - bx0)) * 4 : 0;
+            const int r = sy.i0 - by0;
+            const bool rows_ok = in && r >= 0 && r + 1 < q.ry;
+            const int c0 = sx.i0 - rowtab[rows_ok ? r : 0], c1 = sx.i0 - rowtab[rows_ok ? r + 1 : 0];
+            const bool held = rows_ok && c0 >= 0 && c0 + 1 < P && c1 >= 0 && c1 + 1 < P &&
+                              sx.i0 + 1 <= rowtab[q.ry + r] && sx.i0 + 1 <= rowtab[q.ry + r + 1];
+            a_[k] = !in ? 0 : held ? (r * P + c0) * 4 : (int)(0x80000000u | ((unsigned)sy.i0 * q.in_sR + (unsigned)sx.i0) * 4u);
+            a2_[k] = (in && held) ? ((r + 1) * P + c1) * 4 : 0;
+            bad |= (in && !held) ? (1u << k) : 0u;
             wy_[k] = sy.w1; wx_[k] = sx.w1;
         }
     }
+    const bool any_bad = __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+    __syncthreads();                                            // the row table lives where the output tiles are staged
     float *tile = tiles + wave * 512;
     const bool wide = x0 + 64 <= q.ox && y0 + TY <= q.oR;      // block-uniform: 16-byte stores through the wave's LDS tile
 
@@ -1293,17 +1378,49 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
             if (nxt.in) { ZS_ENSURE(nxt.i0); ZS_ENSURE(nxt.i0 + 1); }
         }
         float r[8];
-        if (cur.in && !(q.dbg & 2)) {
+        if (cur.in && !(q.dbg & 2) && any_bad) {
+            // some voxel of this wave is not held by the window: the same blend with a per-voxel choice of the source
+            const char *lo_p = smem_zs + (unsigned)(cur.i0 & 3) * slot_bytes;
+            const char *hi_p = smem_zs + (unsigned)((cur.i0 + 1) & 3) * slot_bytes;
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
+            const unsigned pbase = (unsigned)cur.i0 * plane_b;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float a00, a01, a10, a11, b00, b01, b10, b11;
+                if (a_[k] < 0) {
+                    const unsigned base = pbase + ((unsigned)a_[k] & 0x7fffffffu);
+                    load_pair(rin, base, a00, a01);
+                    load_pair(rin, base + row_b, a10, a11);
+                    load_pair(rin, base + plane_b, b00, b01);
+                    load_pair(rin, base + plane_b + row_b, b10, b11);
+                } else {
+                    const float *A = reinterpret_cast<const float *>(lo_p + a_[k]), *A1 = reinterpret_cast<const float *>(lo_p + a2_[k]);
+                    const float *B = reinterpret_cast<const float *>(hi_p + a_[k]), *B1 = reinterpret_cast<const float *>(hi_p + a2_[k]);
+                    a00 = A[0]; a01 = A[1]; a10 = A1[0]; a11 = A1[1];
+                    b00 = B[0]; b01 = B[1]; b10 = B1[0]; b11 = B1[1];
+                }
+                Taps<float> t;
+                t.v[0] = a00; t.v[1] = a01;
+                t.v[2] = s0 ? a10 : b00; t.v[3] = s0 ? a11 : b01;
+                t.v[4] = s0 ? b00 : a10; t.v[5] = s0 ? b01 : a11;
+                t.v[6] = b10; t.v[7] = b11;
+                t.wz1 = s0 ? cur.w1 : wy_[k]; t.wy1 = s0 ? wy_[k] : cur.w1; t.wx1 = wx_[k];
+                t.oobmask = 0;
+                t.outside = !((inmask >> k) & 1u);
+                r[k] = finish<float>(t, cval);
+            }
+        } else if (cur.in && !(q.dbg & 2)) {
             const char *lo_p = smem_zs + (unsigned)(cur.i0 & 3) * slot_bytes;
             const char *hi_p = smem_zs + (unsigned)((cur.i0 + 1) & 3) * slot_bytes;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const float *A = reinterpret_cast<const float *>(lo_p + a_[k]);
-                const float *B = reinterpret_cast<const float *>(hi_p + a_[k]);
+                const float *A = reinterpret_cast<const float *>(lo_p + a_[k]), *B = reinterpret_cast<const float *>(hi_p + a_[k]);
+                const float *A1 = SHEAR ? reinterpret_cast<const float *>(lo_p + a2_[k]) : A + kZsP;
+                const float *B1 = SHEAR ? reinterpret_cast<const float *>(hi_p + a2_[k]) : B + kZsP;
                 Taps<float> t;
                 // v[(z << 2) | (y << 1) | x]: the stream axis selects the slot (A / B), the row axis the LDS row
-                const float a00 = A[0], a01 = A[1], a10 = A[P], a11 = A[P + 1];
-                const float b00 = B[0], b01 = B[1], b10 = B[P], b11 = B[P + 1];
+                const float a00 = A[0], a01 = A[1], a10 = A1[0], a11 = A1[1];
+                const float b00 = B[0], b01 = B[1], b10 = B1[0], b11 = B1[1];
                 t.v[0] = a00; t.v[1] = a01;
                 t.v[2] = s0 ? a10 : b00; t.v[3] = s0 ? a11 : b01;
                 t.v[4] = s0 ? b00 : a10; t.v[5] = s0 ? b01 : a11;
@@ -1365,12 +1482,87 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
     // samples floor(min - hair) .. floor(max) + 1: at most floor(ext + hair) + 3 (LdsAffineParams); x: the origin is
     // aligned down by up to 3 samples
     const int ry = (int)floor(ey * (1.0 + 1e-6) + 2e-3) + 3;
+    // r4b: the row pitch = the widest span a staged row needs (zs_row_span), sampled over the fractional positions a tile's
+    // first voxel can have against the input grid, + the up-to-3 samples the row start is aligned down by, + 1 of slack
+    // (a voxel the window then still misses gathers for itself: the kernel checks every voxel)
+    int span = 0;
+    {
+        const double e[4] = {mRR * T[0], mRx * T[1], mxR * T[0], mxx * T[1]};
+        const double cminy = (e[0] < 0.0 ? e[0] : 0.0) + (e[1] < 0.0 ? e[1] : 0.0);
+        for (int fy = 0; fy < 4; fy++)
+            for (int fx = 0; fx < 4; fx++) {
+                const double cR = 1000.0 + 0.25 * fy, cx = 1000.0 + 0.25 * fx;
+                const int b0 = (int)floor(cR + cminy - 1e-3);
+                for (int r = 0; r < ry; r++) {
+                    const ZsSpan sp = zs_row_span(mRR, mRx, mxR, mxx, cR, cx, T[0], T[1], b0 + r);
+                    if (sp.any && sp.hi - sp.lo + 1 > span) span = sp.hi - sp.lo + 1;
+                }
+            }
+    }
+    const int Pmin = (span + 3 + 1 + 3) & ~3;
+    // the bounding rectangle (one origin for all rows, pitch kZsP) when it fits LDS twice per CU: cheaper taps (SHEAR = false)
+    constexpr int NT_ = TY * 8;
     const int rx = (int)floor(ex * (1.0 + 1e-6) + 2e-3) + 3 + 3;
-    if (rx > kZsP) return false;
+    const size_t rect_lds = 4 * (size_t)(((ry * (kZsP / 4) + NT_ - 1) / NT_) * NT_ * 16) + (size_t)(TY / 8) * 2048;
+    const bool rect_fits = rx <= kZsP && (ry * (kZsP / 4) + NT_ - 1) / NT_ <= kZsRoundsMax && rect_lds <= 150 * 1024;
+    bool shear = !(rect_fits && 2 * (rect_lds + 1024) <= 160 * 1024);
+    if (shear && (Pmin > kZsP || Pmin < 8)) {
+        if (!rect_fits) return false;
+        shear = false;
+    }
+    // The pitch also decides the LDS bank conflicts of the tap reads: the 64 lanes of a wave read along a slanted line
+    // of the window -- every 1 / |sin| lanes the row changes and the address jumps by (first-column difference - P) --
+    // and a pitch that is congruent to that run length modulo the 32 banks puts whole runs on the same banks (7 degrees:
+    // runs of 8 lanes, P = 72 -> eight-way conflicts, 288 instead of 202 us; P = 80 none).  Simulated here for one wave
+    // with the row starts the kernel will compute: the candidate with the fewest serialised bank accesses wins.
+    int P = shear ? Pmin : kZsP;
+    if (shear) {
+        double best = 1e300;
+        const double cR = 1000.3, cx = 1000.3;
+        const double e[4] = {mRR * T[0], mRx * T[1], mxR * T[0], mxx * T[1]};
+        const double cminy = (e[0] < 0.0 ? e[0] : 0.0) + (e[1] < 0.0 ? e[1] : 0.0);
+        const int b0 = (int)floor(cR + cminy - 1e-3);
+        std::vector<int> start(ry + 1, 0);
+        for (int r = 0; r < ry; r++) {
+            const ZsSpan sp = zs_row_span(mRR, mRx, mxR, mxx, cR, cx, T[0], T[1], b0 + r);
+            start[r] = (sp.lo < 0 ? 0 : sp.lo) & ~3;
+        }
+        for (int cand = Pmin; cand <= kZsP; cand += 4) {
+            if ((size_t)(((ry * (cand / 4) + TY * 8 - 1) / (TY * 8)) * (TY * 8) * 16) * 4 + (size_t)(TY / 8) * 2048 > 150 * 1024) break;
+            double cost = 0;
+            for (int row = 0; row < TY; row += 5)                      // a few output rows of the tile
+                for (int half = 0; half < 2; half++) {
+                    int count[32] = {0};
+                    int seen[32][4];
+                    for (int l = 32 * half; l < 32 * half + 32; l++) {
+                        const double v = (mRR * row + mRx * l) + cR, u = (mxR * row + mxx * l) + cx;
+                        const int r = (int)floor(v) - b0, c = (int)floor(u) - start[r < 0 ? 0 : (r >= ry ? ry - 1 : r)];
+                        const int addr = r * cand + c, bank = ((addr % 32) + 32) % 32;
+                        bool dup = false;
+                        for (int j = 0; j < count[bank] && j < 4; j++) dup = dup || seen[bank][j] == addr;
+                        if (!dup) { if (count[bank] < 4) seen[bank][count[bank]] = addr; count[bank]++; }
+                    }
+                    int worst = 0;
+                    for (int bk = 0; bk < 32; bk++) worst = count[bk] > worst ? count[bk] : worst;
+                    cost += worst;
+                }
+            cost *= 1.0 + 0.004 * (cand - Pmin);                       // a wider pitch stages a little more: ties go to the narrow one
+            if (cost < best) { best = cost; P = cand; }
+        }
+    }
     constexpr int NT = TY * 8;
-    const int nchunks = ry * (kZsP / 4);
+    int nchunks = ry * (P / 4);
+    size_t slot = (size_t)((nchunks + NT - 1) / NT) * NT * 16;
+    if (shear && ((nchunks + NT - 1) / NT > kZsRoundsMax || 4 * slot + (size_t)(TY / 8) * 2048 > 150 * 1024 ||
+                  (rect_fits && 2 * (4 * slot + (size_t)(TY / 8) * 2048 + 1024) > 160 * 1024))) {
+        // the sheared window does not fit (or not twice per CU either): the rectangle, if it fits at all
+        if (!rect_fits) return false;
+        shear = false;
+        P = kZsP;
+        nchunks = ry * (P / 4);
+        slot = (size_t)((nchunks + NT - 1) / NT) * NT * 16;
+    }
     if ((nchunks + NT - 1) / NT > kZsRoundsMax) return false;
-    const size_t slot = (size_t)((nchunks + NT - 1) / NT) * NT * 16;
     if (4 * slot + (size_t)(TY / 8) * 2048 > 150 * 1024) return false;
     q->stream_axis = S;
     q->nS = nin[S]; q->nR = nin[R]; q->nx = p.nx;
@@ -1385,6 +1577,8 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
     q->mxR = mxR; q->mxx = mxx; q->offx = m[11];
     q->cval = p.cval;
     q->ry = ry;
+    q->P = P;
+    q->shear = shear ? 1 : 0;
     q->nchunks = nchunks;
     const double e[4] = {mRR * T[0], mRx * T[1], mxR * T[0], mxx * T[1]};
     q->cmin_y = (e[0] < 0.0 ? e[0] : 0.0) + (e[1] < 0.0 ? e[1] : 0.0);
@@ -1411,14 +1605,19 @@ static int launch_affine_zstream(const float *in, float *out, ZStreamParams &q, 
     q.nzc = (q.oS + q.zc - 1) / q.zc;
     static bool attr_done = false;
     if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_done = true;
     }
-    note_kernel("mi::affine3d_zstream_kernel<%d,%d> grid=%d (order-1 affine, axis %d decoupled: streams along it, %d rows x %d staged per plane, %d chunks)",
-                TY, q.stream_axis, tiles * q.nzc, q.stream_axis, q.ry, kZsP, q.nzc);
-    if (q.stream_axis == 0) hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 0>), dim3((unsigned)(tiles * q.nzc)), dim3(NT), lds, s, in, out, q);
-    else hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 1>), dim3((unsigned)(tiles * q.nzc)), dim3(NT), lds, s, in, out, q);
+    note_kernel("mi::affine3d_zstream_kernel<%d,%d,%s> grid=%d (order-1 affine, axis %d decoupled: streams along it, %d rows x %d staged per plane%s, %d chunks)",
+                TY, q.stream_axis, q.shear ? "true" : "false", tiles * q.nzc, q.stream_axis, q.ry, q.P, q.shear ? ", sheared" : "", q.nzc);
+    const dim3 grid((unsigned)(tiles * q.nzc)), block(NT);
+    if (q.stream_axis == 0 && !q.shear) hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 0, false>), grid, block, lds, s, in, out, q);
+    else if (q.stream_axis == 0) hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 0, true>), grid, block, lds, s, in, out, q);
+    else if (!q.shear) hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 1, false>), grid, block, lds, s, in, out, q);
+    else hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 1, true>), grid, block, lds, s, in, out, q);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }

@@ -1590,8 +1590,8 @@ def test_affine_zstream_kernel(gpu, ndi):
         ((40, 72, 136), mat(1.02, inplane(7)), np.array([0.5, -1.25, 2.0]), (66, 70, 132), True),
         ((64, 64, 64), mat(1.0, np.eye(2)), np.array([0.0, 0.0, 0.0]), None, True),
         ((64, 64, 64), mat(1.0, np.eye(2)), np.array([3.0, -2.0, 5.0]), None, True),                 # integer shifts: exact boundary hits
-        ((33, 100, 130), mat(0.5, inplane(-20)), np.array([2.0, 40.0, -30.0]), (70, 96, 128), (1, 32)),   # 64-row tiles: rectangle wider than the pitch
-        ((80, 90, 100), mat(1.7, inplane(45)), np.array([-3.0, 60.0, -20.0]), (50, 128, 128), (1, 32)),
+        ((33, 100, 130), mat(0.5, inplane(-20)), np.array([2.0, 40.0, -30.0]), (70, 96, 128), True),      # (until r4b the 64-row tiles' bounding rectangle was wider than the pitch: the window is sheared now)
+        ((80, 90, 100), mat(1.7, inplane(45)), np.array([-3.0, 60.0, -20.0]), (50, 128, 128), (1, 32)),   # 64-row tiles: the window does not fit LDS
         ((80, 64, 200), mat(2.0, inplane(0, 0.8, 1.1)), np.array([0.25, 1.0, 2.0]), (40, 80, 164), True),
         ((64, 64, 64), mat(-1.0, inplane(180)), np.array([63.0, 63.0, 63.0]), None, True),            # flips: coordinates hit 0 and n - 1
         ((20, 70, 90), mat(0.0, inplane(3, shear=0.1)), np.array([7.3, 1.0, -4.0]), (64, 64, 64), True),   # every output plane samples z = 7.3
@@ -1607,7 +1607,7 @@ def test_affine_zstream_kernel(gpu, ndi):
         return M
     cases += [
         ((72, 40, 136), mat1(1.02, inplane(7)), np.array([-1.25, 0.5, 2.0]), (70, 66, 132), True),
-        ((100, 33, 130), mat1(0.5, inplane(-20)), np.array([40.0, 2.0, -30.0]), (96, 70, 128), (1, 32)),
+        ((100, 33, 130), mat1(0.5, inplane(-20)), np.array([40.0, 2.0, -30.0]), (96, 70, 128), True),
         ((64, 64, 64), mat1(-1.0, inplane(180)), np.array([63.0, 63.0, 63.0]), None, True),
         ((64, 80, 200), mat1(2.0, inplane(0, 0.8, 1.1)), np.array([1.0, 0.25, 2.0]), (80, 40, 164), True),
         ((64, 90, 64), mat1(2.5, inplane(5)), np.zeros(3), (64, 36, 128), False),
@@ -1829,6 +1829,49 @@ def test_separable_filters_rows_not_a_multiple_of_four(gpu, ndi):
                     assert np.array_equal(got, sndi.correlate(x, w, mode=mode, cval=3, origin=origin)), (shape, dt, wshape, mode, "correlate")
                     got = ndi.convolve(xd, w, mode=mode, cval=3, origin=origin).get()
                     assert np.array_equal(got, sndi.convolve(x, w, mode=mode, cval=3, origin=origin)), (shape, dt, wshape, mode, "convolve")
+
+
+def test_affine_zstream_sheared_window_all_angles(gpu, ndi):
+    """r4b: the staged window of the z-streaming affine kernel is sheared (every staged input row starts at its own first
+    needed column), so in-plane rotations by ANY angle -- and shears, anisotropic scalings, flips -- fit LDS twice per CU.
+    Bit-identical to the gather kernel for rotations in steps of 7.5 degrees about both decoupled axes, with shears /
+    scalings on top, partial tiles, both tile heights; a voxel the window does not hold gathers for itself (covered by
+    the matrices whose row spans exceed the plan's sampled estimate by construction: none may differ either)."""
+    from cupyimg_amd import _lib, last_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(808)
+    shape = (40, 150, 200)
+    x = rng.standard_normal(shape).astype(np.float32)
+    x[3, 4, 5] = np.inf; x[20, 100, 150] = np.nan
+    xd = gpu.asarray(x)
+    ctr = (np.array(shape) - 1) / 2.0
+    took = 0
+    cases = []
+    for deg in np.arange(0.0, 360.0, 7.5):
+        a = np.deg2rad(deg); c, s = np.cos(a), np.sin(a)
+        cases.append((np.array([[1.03, 0, 0], [0, c, -s], [0, s, c]]), None))                          # rotation in (y, x): axis 0 streams
+        cases.append((np.array([[c, 0, -s], [0, 0.97, 0], [s, 0, c]]), None))                          # rotation in (z, x): axis 1 streams
+    for deg, sy, sx, sh in ((20, 1.3, 0.8, 0.2), (-50, 0.7, 1.2, -0.3), (75, 1.1, 1.1, 0.5), (135, 0.9, 1.4, 0.0), (10, 1.9, 0.6, 1.0)):
+        a = np.deg2rad(deg); c, s = np.cos(a), np.sin(a)
+        R = np.array([[c, -s], [s, c]]) @ np.array([[sy, sh], [0, sx]])
+        M = np.eye(3); M[1:, 1:] = R; M[0, 0] = -1.0                                                   # with a flip along the stream axis
+        cases.append((M, (44, 131, 190)))
+    for M, oshape in cases:
+        off = ctr - M @ (ctr if oshape is None else (np.array(oshape) - 1) / 2.0) + np.array([0.25, -1.5, 2.0])
+        lib.mi_debug_set_affine_zstream(0); lib.mi_debug_set_interp_c1(5)
+        try:
+            want = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-2.0).get()
+        finally:
+            lib.mi_debug_set_affine_zstream(1); lib.mi_debug_set_interp_c1(1)
+        for ty in (1, 64):
+            lib.mi_debug_set_affine_zstream(ty)
+            try:
+                got = ndi.affine_transform(xd, M, off, output_shape=oshape, order=1, mode="constant", cval=-2.0).get()
+                took += "affine3d_zstream_kernel" in last_kernel()
+            finally:
+                lib.mi_debug_set_affine_zstream(1)
+            assert np.array_equal(got, want, equal_nan=True), (M.tolist(), ty, last_kernel()[:60], int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want))))))
+    assert took >= len(cases), (took, len(cases))          # the streaming kernel took (at least) one tile height of every case
 
 
 def test_affine_rowblend_kernel(gpu, ndi):
