@@ -1158,6 +1158,7 @@ struct ZStreamParams {
     int ry;                  // rows of the staged window
     int P;                   // LDS row pitch in floats (a multiple of 4, <= kZsP): the widest span a staged row needs
     int shear;               // 1 = every staged row starts at its own first needed column, 0 = bounding rectangle (pitch kZsP)
+    int nslots;              // ring slots: 4, or 3 when |mS| <= 1 (an output plane and the next then read at most three input planes)
     int nchunks;             // ry * P / 4
     double cmin_y, cmin_x;   // minimum of cR / cx over a tile relative to its first voxel (see LdsAffineParams::cmin)
     int zc, nzc;             // output planes per chunk, chunks
@@ -1229,14 +1230,14 @@ __device__ __forceinline__ ZSplit zs_split(double m0, double m3, int z, int nz)
 template <int NT>
 __device__ __forceinline__ void zs_ensure(const float *in, int vol_bytes, int pl, int nz, int &rlo, int &rhi,
                                           const unsigned (&rel)[kZsRoundsMax], int rounds, unsigned plane_b, unsigned org_b,
-                                          unsigned slot_bytes, int wave, bool off)
+                                          unsigned slot_bytes, int wave, bool off, int nslots)
 {
     if (pl < 0 || pl >= nz) return;
     if (pl >= rlo && pl <= rhi) return;
-    if (pl == rhi + 1 && rhi >= rlo) { rhi = pl; if (rhi - rlo > 3) rlo = rhi - 3; }
-    else if (pl == rlo - 1 && rhi >= rlo) { rlo = pl; if (rhi - rlo > 3) rhi = rlo + 3; }
+    if (pl == rhi + 1 && rhi >= rlo) { rhi = pl; if (rhi - rlo > nslots - 1) rlo = rhi - (nslots - 1); }
+    else if (pl == rlo - 1 && rhi >= rlo) { rlo = pl; if (rhi - rlo > nslots - 1) rhi = rlo + (nslots - 1); }
     else { rlo = rhi = pl; }
-    const int sl = pl & 3;
+    const int sl = nslots == 4 ? (pl & 3) : pl % 3;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)pl * plane_b + org_b);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)sl * slot_bytes + (unsigned)(wave << 6) * 16u);
@@ -1256,7 +1257,8 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
     const int P = SHEAR ? q.P : kZsP, PC = P >> 2;     // LDS row pitch of the staged window: floats / 16-byte chunks
     extern __shared__ __attribute__((aligned(16))) char smem_zs[];
     const unsigned slot_bytes = (((unsigned)q.nchunks + NT - 1) / NT) * NT * 16u;       // whole rounds of NT chunks
-    float *tiles = reinterpret_cast<float *>(smem_zs + 4u * slot_bytes);                // [NW][8 rows][64]
+    const int NS = q.nslots;                                                            // ring slots (3 or 4), slot = plane mod NS
+    float *tiles = reinterpret_cast<float *>(smem_zs + (unsigned)NS * slot_bytes);     // [NW][8 rows][64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1357,7 +1359,8 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
     const double m0_ = q.mS, m3_ = q.offS;
     constexpr bool s0 = SAX == 0;
     const bool no_dma = (q.dbg & 1) != 0;
-#define ZS_ENSURE(PL) zs_ensure<NT>(in, vol_bytes, (PL), nz_, rlo, rhi, rel, rounds, plane_b, org_b, slot_bytes, wave, no_dma)
+#define ZS_ENSURE(PL) zs_ensure<NT>(in, vol_bytes, (PL), nz_, rlo, rhi, rel, rounds, plane_b, org_b, slot_bytes, wave, no_dma, NS)
+    auto slot_of = [&](int pl) { return (unsigned)(NS == 4 ? (pl & 3) : (pl % 3 + 3) % 3); };
     ZSplit cur = zs_split(m0_, m3_, zs, nz_);
     if (cur.in) { ZS_ENSURE(cur.i0); ZS_ENSURE(cur.i0 + 1); }
     const float cval = (float)q.cval;
@@ -1380,8 +1383,8 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
         float r[8];
         if (cur.in && !(q.dbg & 2) && any_bad) {
             // some voxel of this wave is not held by the window: the same blend with a per-voxel choice of the source
-            const char *lo_p = smem_zs + (unsigned)(cur.i0 & 3) * slot_bytes;
-            const char *hi_p = smem_zs + (unsigned)((cur.i0 + 1) & 3) * slot_bytes;
+            const char *lo_p = smem_zs + slot_of(cur.i0) * slot_bytes;
+            const char *hi_p = smem_zs + slot_of(cur.i0 + 1) * slot_bytes;
             const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
             const unsigned pbase = (unsigned)cur.i0 * plane_b;
 #pragma unroll
@@ -1410,8 +1413,8 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
                 r[k] = finish<float>(t, cval);
             }
         } else if (cur.in && !(q.dbg & 2)) {
-            const char *lo_p = smem_zs + (unsigned)(cur.i0 & 3) * slot_bytes;
-            const char *hi_p = smem_zs + (unsigned)((cur.i0 + 1) & 3) * slot_bytes;
+            const char *lo_p = smem_zs + slot_of(cur.i0) * slot_bytes;
+            const char *hi_p = smem_zs + slot_of(cur.i0 + 1) * slot_bytes;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const float *A = reinterpret_cast<const float *>(lo_p + a_[k]), *B = reinterpret_cast<const float *>(hi_p + a_[k]);
@@ -1503,7 +1506,8 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
     // the bounding rectangle (one origin for all rows, pitch kZsP) when it fits LDS twice per CU: cheaper taps (SHEAR = false)
     constexpr int NT_ = TY * 8;
     const int rx = (int)floor(ex * (1.0 + 1e-6) + 2e-3) + 3 + 3;
-    const size_t rect_lds = 4 * (size_t)(((ry * (kZsP / 4) + NT_ - 1) / NT_) * NT_ * 16) + (size_t)(TY / 8) * 2048;
+    const size_t NSl = fabs(m[4 * S + S]) <= 1.0 ? 3 : 4;                                    // ring slots
+    const size_t rect_lds = NSl * (size_t)(((ry * (kZsP / 4) + NT_ - 1) / NT_) * NT_ * 16) + (size_t)(TY / 8) * 2048;
     const bool rect_fits = rx <= kZsP && (ry * (kZsP / 4) + NT_ - 1) / NT_ <= kZsRoundsMax && rect_lds <= 150 * 1024;
     bool shear = !(rect_fits && 2 * (rect_lds + 1024) <= 160 * 1024);
     if (shear && (Pmin > kZsP || Pmin < 8)) {
@@ -1528,7 +1532,7 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
             start[r] = (sp.lo < 0 ? 0 : sp.lo) & ~3;
         }
         for (int cand = Pmin; cand <= kZsP; cand += 4) {
-            if ((size_t)(((ry * (cand / 4) + TY * 8 - 1) / (TY * 8)) * (TY * 8) * 16) * 4 + (size_t)(TY / 8) * 2048 > 150 * 1024) break;
+            if ((size_t)(((ry * (cand / 4) + TY * 8 - 1) / (TY * 8)) * (TY * 8) * 16) * NSl + (size_t)(TY / 8) * 2048 > 150 * 1024) break;
             double cost = 0;
             for (int row = 0; row < TY; row += 5)                      // a few output rows of the tile
                 for (int half = 0; half < 2; half++) {
@@ -1553,8 +1557,8 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
     constexpr int NT = TY * 8;
     int nchunks = ry * (P / 4);
     size_t slot = (size_t)((nchunks + NT - 1) / NT) * NT * 16;
-    if (shear && ((nchunks + NT - 1) / NT > kZsRoundsMax || 4 * slot + (size_t)(TY / 8) * 2048 > 150 * 1024 ||
-                  (rect_fits && 2 * (4 * slot + (size_t)(TY / 8) * 2048 + 1024) > 160 * 1024))) {
+    if (shear && ((nchunks + NT - 1) / NT > kZsRoundsMax || NSl * slot + (size_t)(TY / 8) * 2048 > 150 * 1024 ||
+                  (rect_fits && 2 * (NSl * slot + (size_t)(TY / 8) * 2048 + 1024) > 160 * 1024))) {
         // the sheared window does not fit (or not twice per CU either): the rectangle, if it fits at all
         if (!rect_fits) return false;
         shear = false;
@@ -1563,7 +1567,7 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
         slot = (size_t)((nchunks + NT - 1) / NT) * NT * 16;
     }
     if ((nchunks + NT - 1) / NT > kZsRoundsMax) return false;
-    if (4 * slot + (size_t)(TY / 8) * 2048 > 150 * 1024) return false;
+    if (NSl * slot + (size_t)(TY / 8) * 2048 > 150 * 1024) return false;
     q->stream_axis = S;
     q->nS = nin[S]; q->nR = nin[R]; q->nx = p.nx;
     q->oS = nout[S]; q->oR = nout[R]; q->ox = p.ox;
@@ -1579,6 +1583,7 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
     q->ry = ry;
     q->P = P;
     q->shear = shear ? 1 : 0;
+    q->nslots = (int)NSl;
     q->nchunks = nchunks;
     const double e[4] = {mRR * T[0], mRx * T[1], mxR * T[0], mxx * T[1]};
     q->cmin_y = (e[0] < 0.0 ? e[0] : 0.0) + (e[1] < 0.0 ? e[1] : 0.0);
@@ -1594,7 +1599,7 @@ static int launch_affine_zstream(const float *in, float *out, ZStreamParams &q, 
 {
     constexpr int NT = TY * 8;
     const size_t slot = (size_t)((q.nchunks + NT - 1) / NT) * NT * 16;
-    const size_t lds = 4 * slot + (size_t)(TY / 8) * 2048;
+    const size_t lds = (size_t)q.nslots * slot + (size_t)(TY / 8) * 2048;
     // chunks along the stream axis: fill the chip (workgroups per CU by LDS) with chunks of >= 16 output planes
     const int ncu = device_cus();
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 1024)));

@@ -11,12 +11,13 @@ from helpers import fullsize as fs
 from bench_configs import timeit
 lib = _lib.load()
 n = 512
+SC = float(os.environ.get("AFFINE_SCALE", "1.02"))        # step along the streamed axis (<= 1: three ring slots)
 x = fs.volume_f32((n,) * 3); xd = ca.asarray(x); out = ca.empty(x.shape, np.float32)
 ctr = np.array([(n - 1) / 2.0] * 3)
 for plane in ("yx", "zx"):
     for deg in (0, 3, 7, 15, 30, 45, 60, 75, 90, 120, 180):
         a = np.deg2rad(deg); c, s = np.cos(a), np.sin(a)
-        M = np.array([[1.02, 0, 0], [0, c, -s], [0, s, c]]) if plane == "yx" else np.array([[c, 0, -s], [0, 1.02, 0], [s, 0, c]])
+        M = np.array([[SC, 0, 0], [0, c, -s], [0, s, c]]) if plane == "yx" else np.array([[c, 0, -s], [0, SC, 0], [s, 0, c]])
         off = ctr - M @ ctr + np.array([0.5, -1.25, 2.0])
         row = {"plane": plane, "deg": deg}
         for knob, name in ((1, "auto"), (0, "without the streaming kernel")):
