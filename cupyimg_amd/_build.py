@@ -159,7 +159,7 @@ def _compile(args):
 # Sources whose kernels wait on vmcnt by count (LDS-DMA rings): the name fragment selects the kernels that must not
 # touch scratch memory (a spill store or reload is one more vector-memory operation in flight than the count assumes).
 # The ablation builds of the r3 long kernel (<W, SAME, DBG = true, 0>) are exempt: timing aids, not product kernels.
-NO_SCRATCH = {"sep3d_long.hip": "sep3d_long", "minmax3d_f32.hip": "mm3f32_long", "interp_fast.hip": "zstream_kernel"}
+NO_SCRATCH = {"sep3d_long.hip": "sep3d_long", "minmax3d_f32.hip": "mm3f32_long", "interp_fast.hip": ("zstream_kernel", "zrect_kernel")}
 
 
 # Kernels whose occupancy is part of their design: (fragment of the mangled name, VGPRs + AGPRs per lane at most).
@@ -241,7 +241,8 @@ def _scratch_users(obj, fragment):
         text = subprocess.run([objdump, "-d", co], stdout=subprocess.PIPE, text=True, check=True).stdout
     bad, name, count = [], None, 0
     def close():
-        if name and count and fragment in name and not _is_ablation_build(name):
+        frags = fragment if isinstance(fragment, tuple) else (fragment,)
+        if name and count and any(f in name for f in frags) and not _is_ablation_build(name):
             bad.append("{} ({} scratch / compiler-made AGPR instructions)".format(name, count))
     for line in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)

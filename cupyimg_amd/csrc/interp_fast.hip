@@ -1222,6 +1222,183 @@ __device__ __forceinline__ ZSplit zs_split(double m0, double m3, int z, int nz)
     return r;
 }
 
+// ---------------------------------------------------------------------------
+// The RECTANGLE form of the z-streaming affine kernel (r4, first half; config D'): every staged row starts at the same
+// column, four ring slots, the upper tap row an immediate offset away.  Kept as a kernel of its own: folded into the
+// sheared kernel below as a template variant it ran 7 % slower on config D' (214-219 against 202 us: the per-voxel
+// check, the gathering copy of the loop and the row table cost registers and code the loop does not need here).
+// Taken when the bounding rectangle fits LDS twice per CU with four slots; everything else goes to the sheared kernel.
+// ---------------------------------------------------------------------------
+// Input plane `pl` into ring slot (pl & 3) unless it is resident or outside the volume; ROUNDS DMAs per thread.  The
+// resident planes are a contiguous range [rlo, rhi] of at most four (two scalars: a tag per slot would be indexed by a
+// run-time slot number, i.e. live in scratch memory -- whose accesses count in vmcnt and would break the kernel's
+// hand-counted waits); a plane next to the range extends it (dropping the far end beyond four), any other plane
+// restarts it.
+template <int NT>
+__device__ __forceinline__ void zs_ensure_rect(const float *in, int vol_bytes, int pl, int nz, int &rlo, int &rhi,
+                                          const unsigned (&rel)[kZsRoundsMax], int rounds, unsigned plane_b, unsigned org_b,
+                                          unsigned slot_bytes, int wave, bool off)
+{
+    if (pl < 0 || pl >= nz) return;
+    if (pl >= rlo && pl <= rhi) return;
+    if (pl == rhi + 1 && rhi >= rlo) { rhi = pl; if (rhi - rlo > 3) rlo = rhi - 3; }
+    else if (pl == rlo - 1 && rhi >= rlo) { rlo = pl; if (rhi - rlo > 3) rhi = rlo + 3; }
+    else { rlo = rhi = pl; }
+    const int sl = pl & 3;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)pl * plane_b + org_b);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)sl * slot_bytes + (unsigned)(wave << 6) * 16u);
+#pragma unroll
+    for (int j = 0; j < kZsRoundsMax; j++)
+        if (j < rounds && !off) dma_16s(rin, rel[j], base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * NT) * 16u));
+}
+
+template <int TY, int SAX>
+__global__ void __launch_bounds__(TY * 8)
+affine3d_zrect_kernel(const float *__restrict__ in, float *__restrict__ out, const ZStreamParams q)
+{
+    constexpr int NT = TY * 8;                         // threads = TY / 8 waves; a wave owns 8 output rows of 64 voxels
+    constexpr int P = kZsP;
+    extern __shared__ __attribute__((aligned(16))) char smem_zs[];
+    const unsigned slot_bytes = (((unsigned)q.nchunks + NT - 1) / NT) * NT * 16u;       // whole rounds of NT chunks
+    float *tiles = reinterpret_cast<float *>(smem_zs + 4u * slot_bytes);                // [NW][8 rows][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (tile x, tile y, z chunk): consecutive block indices go round the XCDs, so block b is given the
+    // tile whose index in (chunk, ty, tx) order is (b % 8) * (total / 8) + b / 8 when the grid divides by 8 -- every XCD
+    // then holds runs of x-neighbouring tiles, whose rectangles overlap, of the same chunk
+    const int total = q.ntx * q.nty * q.nzc;
+    int t = blockIdx.x;
+    if ((total & 7) == 0 && !(q.dbg & 64)) t = (t & 7) * (total >> 3) + (t >> 3);
+    const int tx_i = t % q.ntx, ty_i = (t / q.ntx) % q.nty, zc_i = t / (q.ntx * q.nty);
+    const int x0 = tx_i * 64, y0 = ty_i * TY;
+    const int zs = zc_i * q.zc, ze = min(zs + q.zc, q.oS);
+
+    // ---- the rectangle: origin from the tile's first voxel (closed form, a hair below the true minimum, clamped
+    // into the volume, x aligned down to 16 bytes), chunk -> byte offset from the origin once per thread
+    int borg[2];
+#pragma unroll
+    for (int a = 1; a <= 2; a++) {
+        const double lo = a == 1 ? (q.mRR * (double)y0 + q.mRx * (double)x0) + (q.offR + q.cmin_y)
+                                 : (q.mxR * (double)y0 + q.mxx * (double)x0) + (q.offx + q.cmin_x);
+        const int n = a == 1 ? q.nR : q.nx;
+        double f = floor(lo - 1e-6 * (1.0 + fabs(lo)));
+        f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
+        borg[a - 1] = __builtin_amdgcn_readfirstlane(a == 2 ? ((int)f & ~3) : (int)f);
+    }
+    const int by0 = borg[0], bx0 = borg[1];
+    const int rounds = (q.nchunks + NT - 1) / NT;
+    unsigned rel[kZsRoundsMax];
+#pragma unroll
+    for (int j = 0; j < kZsRoundsMax; j++) {
+        const unsigned ch = (unsigned)tid + (unsigned)(j * NT);
+        const unsigned row = ch / 20u, c4 = ch - row * 20u;
+        // rows past the rectangle are not fetched (0x80000000 fails the descriptor's range check: zeros)
+        rel[j] = ch < (unsigned)q.nchunks ? row * q.in_sR * 4u + c4 * 16u : 0x80000000u;
+    }
+    const unsigned plane_b = q.in_sS * 4u;
+    const unsigned org_b = ((unsigned)by0 * q.in_sR + (unsigned)bx0) * 4u;
+
+    // ---- per-thread, per-(y, x): LDS byte offset of the lower-left tap, weights, in-plane range test.  Voxel k of a
+    // lane: row y0 + 8 wave + k, column x0 + lane.
+    int a_[8];
+    float wy_[8], wx_[8];
+    unsigned inmask = 0;
+    {
+        const double dx = (double)(x0 + lane);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double dy = (double)(y0 + 8 * wave + k);
+            // the oracle's order ((m0 z + m1 y) + m2 x) + offset with m0 = 0 for these two rows
+            const C1Split sy = c1_split((q.mRR * dy + q.mRx * dx) + q.offR, q.nR);
+            const C1Split sx = c1_split((q.mxR * dy + q.mxx * dx) + q.offx, q.nx);
+            const bool in = sy.in & sx.in;
+            inmask |= in ? (1u << k) : 0u;
+            a_[k] = in ? ((sy.i0 - by0) * P + (sx.i0 - bx0)) * 4 : 0;
+            wy_[k] = sy.w1; wx_[k] = sx.w1;
+        }
+    }
+    float *tile = tiles + wave * 512;
+    const bool wide = x0 + 64 <= q.ox && y0 + TY <= q.oR;      // block-uniform: 16-byte stores through the wave's LDS tile
+
+    // ---- the plane ring: slot (plane & 3) holds input plane `plane` for the planes of [rlo, rhi]
+    int rlo = 0, rhi = -1;                    // resident input planes (empty)
+    const int nz_ = q.nS, vol_bytes = q.vol_bytes;
+    const double m0_ = q.mS, m3_ = q.offS;
+    constexpr bool s0 = SAX == 0;
+    const bool no_dma = (q.dbg & 1) != 0;
+#define ZS_ENSURE(PL) zs_ensure_rect<NT>(in, vol_bytes, (PL), nz_, rlo, rhi, rel, rounds, plane_b, org_b, slot_bytes, wave, no_dma)
+    ZSplit cur = zs_split(m0_, m3_, zs, nz_);
+    if (cur.in) { ZS_ENSURE(cur.i0); ZS_ENSURE(cur.i0 + 1); }
+    const float cval = (float)q.cval;
+
+#pragma unroll 1
+    for (int z = zs; z < ze; z++) {
+        // the planes of this step have landed (the stores of the previous step, issued after their DMAs, may still be
+        // in flight: two per thread on full tiles), and everyone has finished reading the previous step's planes
+        // (r4b: the FIRST step has no stores behind the prologue's DMAs -- vmcnt(2) there let the last two chunks of a
+        // chunk's first plane be read before they had landed: a few wrong voxels in the first plane of a z chunk under
+        // back-to-back launches, found by the whole-volume check of scripts/bench_configs.py)
+        if (wide && z > zs) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ZSplit nxt = cur;
+        if (z + 1 < ze) {
+            nxt = zs_split(m0_, m3_, z + 1, nz_);
+            if (nxt.in) { ZS_ENSURE(nxt.i0); ZS_ENSURE(nxt.i0 + 1); }
+        }
+        float r[8];
+        if (cur.in && !(q.dbg & 2)) {
+            const char *lo_p = smem_zs + (unsigned)(cur.i0 & 3) * slot_bytes;
+            const char *hi_p = smem_zs + (unsigned)((cur.i0 + 1) & 3) * slot_bytes;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float *A = reinterpret_cast<const float *>(lo_p + a_[k]);
+                const float *B = reinterpret_cast<const float *>(hi_p + a_[k]);
+                Taps<float> t;
+                // v[(z << 2) | (y << 1) | x]: the stream axis selects the slot (A / B), the row axis the LDS row
+                const float a00 = A[0], a01 = A[1], a10 = A[P], a11 = A[P + 1];
+                const float b00 = B[0], b01 = B[1], b10 = B[P], b11 = B[P + 1];
+                t.v[0] = a00; t.v[1] = a01;
+                t.v[2] = s0 ? a10 : b00; t.v[3] = s0 ? a11 : b01;
+                t.v[4] = s0 ? b00 : a10; t.v[5] = s0 ? b01 : a11;
+                t.v[6] = b10; t.v[7] = b11;
+                t.wz1 = s0 ? cur.w1 : wy_[k]; t.wy1 = s0 ? wy_[k] : cur.w1; t.wx1 = wx_[k];
+                t.oobmask = 0;
+                t.outside = !((inmask >> k) & 1u);
+                r[k] = finish<float>(t, cval);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = cval;
+        }
+        if (!(q.dbg & 4)) {
+            if (wide) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) tile[k * 64 + lane] = r[k];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int i = lane >> 4, c = lane & 15;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const f32x4n v = *reinterpret_cast<const f32x4n *>(tile + (4 * h + i) * 64 + 4 * c);
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + (size_t)z * q.out_sS + (size_t)(y0 + 8 * wave + 4 * h + i) * q.out_sR + x0 + 4 * c));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the tile is rewritten next step
+            } else {
+                const int x = x0 + lane;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int y = y0 + 8 * wave + k;
+                    if (x < q.ox && y < q.oR) __builtin_nontemporal_store(r[k], out + (size_t)z * q.out_sS + (size_t)y * q.out_sR + x);
+                }
+            }
+        }
+        cur = nxt;
+    }
+#undef ZS_ENSURE
+}
+
 // Input plane `pl` into ring slot (pl & 3) unless it is resident or outside the volume; ROUNDS DMAs per thread.  The
 // resident planes are a contiguous range [rlo, rhi] of at most four (two scalars: a tag per slot would be indexed by a
 // run-time slot number, i.e. live in scratch memory -- whose accesses count in vmcnt and would break the kernel's
@@ -1246,9 +1423,7 @@ __device__ __forceinline__ void zs_ensure(const float *in, int vol_bytes, int pl
         if (j < rounds && !off) dma_16s(rin, rel[j], base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * NT) * 16u));
 }
 
-// SHEAR = false: every staged row starts at the same column (the tile's bounding rectangle, pitch kZsP: the upper tap row is
-// an immediate offset away, two address registers per voxel instead of four -- 202 against 220 us on config D'), taken when
-// the rectangle fits LDS twice per CU; SHEAR = true: row starts of their own.
+// SHEAR = true is what is instantiated (row starts of their own); the rectangle form lives in affine3d_zrect_kernel above.
 template <int TY, int SAX, bool SHEAR>
 __global__ void __launch_bounds__(TY * 8)
 affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, const ZStreamParams q)
@@ -1506,8 +1681,8 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
     // the bounding rectangle (one origin for all rows, pitch kZsP) when it fits LDS twice per CU: cheaper taps (SHEAR = false)
     constexpr int NT_ = TY * 8;
     const int rx = (int)floor(ex * (1.0 + 1e-6) + 2e-3) + 3 + 3;
-    const size_t NSl = fabs(m[4 * S + S]) <= 1.0 ? 3 : 4;                                    // ring slots
-    const size_t rect_lds = NSl * (size_t)(((ry * (kZsP / 4) + NT_ - 1) / NT_) * NT_ * 16) + (size_t)(TY / 8) * 2048;
+    size_t NSl = fabs(m[4 * S + S]) <= 1.0 ? 3 : 4;                                          // ring slots of the sheared kernel
+    const size_t rect_lds = 4 * (size_t)(((ry * (kZsP / 4) + NT_ - 1) / NT_) * NT_ * 16) + (size_t)(TY / 8) * 2048;   // (the rectangle kernel: four)
     const bool rect_fits = rx <= kZsP && (ry * (kZsP / 4) + NT_ - 1) / NT_ <= kZsRoundsMax && rect_lds <= 150 * 1024;
     bool shear = !(rect_fits && 2 * (rect_lds + 1024) <= 160 * 1024);
     if (shear && (Pmin > kZsP || Pmin < 8)) {
@@ -1520,6 +1695,7 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
     // runs of 8 lanes, P = 72 -> eight-way conflicts, 288 instead of 202 us; P = 80 none).  Simulated here for one wave
     // with the row starts the kernel will compute: the candidate with the fewest serialised bank accesses wins.
     int P = shear ? Pmin : kZsP;
+    if (!shear) NSl = 4;
     if (shear) {
         double best = 1e300;
         const double cR = 1000.3, cx = 1000.3;
@@ -1563,6 +1739,7 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
         if (!rect_fits) return false;
         shear = false;
         P = kZsP;
+        NSl = 4;
         nchunks = ry * (P / 4);
         slot = (size_t)((nchunks + NT - 1) / NT) * NT * 16;
     }
@@ -1610,18 +1787,22 @@ static int launch_affine_zstream(const float *in, float *out, ZStreamParams &q, 
     q.nzc = (q.oS + q.zc - 1) / q.zc;
     static bool attr_done = false;
     if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zrect_kernel<TY, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_zrect_kernel<TY, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         MI_HIP(hipFuncSetAttribute((const void *)affine3d_zstream_kernel<TY, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_done = true;
     }
-    note_kernel("mi::affine3d_zstream_kernel<%d,%d,%s> grid=%d (order-1 affine, axis %d decoupled: streams along it, %d rows x %d staged per plane%s, %d chunks)",
-                TY, q.stream_axis, q.shear ? "true" : "false", tiles * q.nzc, q.stream_axis, q.ry, q.P, q.shear ? ", sheared" : "", q.nzc);
+    if (q.shear)
+        note_kernel("mi::affine3d_zstream_kernel<%d,%d,true> grid=%d (order-1 affine, axis %d decoupled: streams along it, %d rows x %d staged per plane, sheared, %d slots, %d chunks)",
+                    TY, q.stream_axis, tiles * q.nzc, q.stream_axis, q.ry, q.P, q.nslots, q.nzc);
+    else
+        note_kernel("mi::affine3d_zrect_kernel<%d,%d> grid=%d (order-1 affine, axis %d decoupled: streams along it, %d rows x %d staged per plane, %d chunks)",
+                    TY, q.stream_axis, tiles * q.nzc, q.stream_axis, q.ry, q.P, q.nzc);
     const dim3 grid((unsigned)(tiles * q.nzc)), block(NT);
-    if (q.stream_axis == 0 && !q.shear) hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 0, false>), grid, block, lds, s, in, out, q);
+    if (q.stream_axis == 0 && !q.shear) hipLaunchKernelGGL((affine3d_zrect_kernel<TY, 0>), grid, block, lds, s, in, out, q);
     else if (q.stream_axis == 0) hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 0, true>), grid, block, lds, s, in, out, q);
-    else if (!q.shear) hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 1, false>), grid, block, lds, s, in, out, q);
+    else if (!q.shear) hipLaunchKernelGGL((affine3d_zrect_kernel<TY, 1>), grid, block, lds, s, in, out, q);
     else hipLaunchKernelGGL((affine3d_zstream_kernel<TY, 1, true>), grid, block, lds, s, in, out, q);
     MI_HIP(hipGetLastError());
     return MI_OK;

@@ -115,8 +115,8 @@ def test_interpolation_kernels_under_load(gpu, ndi, lib):
     a45 = np.deg2rad(50.0); c45, s45 = np.cos(a45), np.sin(a45)
     Myx45 = np.array([[1.02, 0, 0], [0, c45, -s45], [0, s45, c45]])                        # sheared window (r4b)
     Mzx45 = np.array([[c45, 0, -s45], [0, 1.0, 0], [s45, 0, c45]])
-    for M, knob_off, zc, tiles, kern in ((Myx, "affine_zstream", 0, 1, "affine3d_zstream_kernel<32,0,"), (Myx, "affine_zstream", 7, 1, "affine3d_zstream_kernel<32,0,"),
-                                         (Myx, "affine_zstream", 0, 64, "affine3d_zstream_kernel<64,0,"), (Mzx, "affine_zstream", 5, 1, "affine3d_zstream_kernel<32,1,"),
+    for M, knob_off, zc, tiles, kern in ((Myx, "affine_zstream", 0, 1, "affine3d_zrect_kernel<32,0>"), (Myx, "affine_zstream", 7, 1, "affine3d_zrect_kernel<32,0>"),
+                                         (Myx, "affine_zstream", 0, 64, "affine3d_z"), (Mzx, "affine_zstream", 5, 1, "affine3d_z"),
                                          (Mgen, "interp_c1", 0, 1, "affine3d_lds_kernel"),
                                          (Myx45, "affine_zstream", 0, 1, "affine3d_zstream_kernel<32,0,true>"), (Myx45, "affine_zstream", 6, 1, "affine3d_zstream_kernel<32,0,true>"),
                                          (Mzx45, "affine_zstream", 3, 1, "affine3d_zstream_kernel<32,1,true>")):
