@@ -263,6 +263,19 @@ def _run_on_extended_rows(input, output, left, right, mode_x, cval, run):
     kernel's traffic instead of generic per-axis passes (181 x 217 x 181 float32, uniform_filter(5): 125 -> 48 us)."""
     if left < 0 or right < 0 or input.size < (1 << 15) or input.dtype.itemsize not in (1, 2, 4) or output.dtype.itemsize not in (1, 2, 4):
         return None
+    if mode_x in ("constant", "grid-constant"):
+        # the fill value is written into the extended rows in the ARRAY's dtype; the kernels (like SciPy) use cval as a
+        # double: only values the dtype holds exactly may take this route
+        cv = float(cval)
+        if input.dtype.kind in "iub":
+            info = np.iinfo(input.dtype) if input.dtype.kind in "iu" else None
+            if not (np.isfinite(cv) and cv == int(cv) and (info is None and cv in (0.0, 1.0) or info is not None and info.min <= cv <= info.max)):
+                return None
+        elif input.dtype == np.float32:
+            if not (np.isnan(cv) or float(np.float32(cv)) == cv):
+                return None
+        else:
+            return None
     v = 16 // min(input.dtype.itemsize, output.dtype.itemsize)      # rows of both arrays become multiples of 16 bytes
     nx = input.shape[-1]
     pl = -(-left // v) * v

@@ -1808,6 +1808,15 @@ def test_separable_filters_rows_not_a_multiple_of_four(gpu, ndi):
                         got = fn(xd, size, mode=mode, cval=7).get()
                         assert np.array_equal(got, rf(x, size, mode=mode, cval=7)), (shape, dt, mode, size, fn.__name__, last_kernel())
             assert np.array_equal(ndi.grey_erosion(xd, size=3).get(), sndi.grey_erosion(x, size=3))
+    # a cval the array's dtype does not hold exactly (SciPy uses it as a double): still SciPy's result (generic route)
+    xi = (rng.standard_normal((20, 37, 101)) * 40 + 100).astype(np.uint8)
+    w3 = rng.standard_normal((3, 3, 3))
+    for cv in (3.7, -1.0, 300.0):
+        assert np.array_equal(ndi.correlate(gpu.asarray(xi), w3, mode="constant", cval=cv).get(), sndi.correlate(xi, w3, mode="constant", cval=cv)), cv
+    xf = rng.standard_normal((20, 37, 101)).astype(np.float32)
+    assert np.array_equal(ndi.correlate(gpu.asarray(xf), w3, mode="constant", cval=0.1).get(), sndi.correlate(xf, w3, mode="constant", cval=0.1))
+    got = ndi.uniform_filter(gpu.asarray(xf), 5, mode="constant", cval=0.1).get()
+    assert np.abs(got - sndi.uniform_filter(xf.astype(np.float64), 5, mode="constant", cval=0.1)).max() <= 1e-6 * 4
     # binary erosion / dilation, one iteration: rows extended by the border value
     for shape in [(45, 54, 45), (20, 37, 262), (301, 403)]:
         b = rng.random(shape) > 0.4
