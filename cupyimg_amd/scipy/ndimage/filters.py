@@ -253,7 +253,7 @@ def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
     return output
 
 
-def _run_on_extended_rows(input, output, left, right, mode_x, cval, run):
+def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_cval=True):
     """Rows whose length is not a multiple of 16 bytes (181 x 217 x 181, 91 x 109 x 91, ...: most volumes that were not
     acquired as powers of two) cannot take the fused kernels directly -- their 16-byte row accesses need aligned rows.
     r4b: extend every row explicitly along the last axis (what its boundary mode prescribes, at least the filter's reach
@@ -263,9 +263,10 @@ def _run_on_extended_rows(input, output, left, right, mode_x, cval, run):
     kernel's traffic instead of generic per-axis passes (181 x 217 x 181 float32, uniform_filter(5): 125 -> 48 us)."""
     if left < 0 or right < 0 or input.size < (1 << 15) or input.dtype.itemsize not in (1, 2, 4) or output.dtype.itemsize not in (1, 2, 4):
         return None
-    if mode_x in ("constant", "grid-constant"):
-        # the fill value is written into the extended rows in the ARRAY's dtype; the kernels (like SciPy) use cval as a
-        # double: only values the dtype holds exactly may take this route
+    if exact_cval and mode_x in ("constant", "grid-constant"):
+        # the fill value is written into the extended rows in the ARRAY's dtype; the bit-exact kernels (like SciPy) use cval
+        # as a double: only values the dtype holds exactly may take this route (the float32 separable kernels round it
+        # to float32 themselves: exact_cval = False)
         cv = float(cval)
         if input.dtype.kind in "iub":
             info = np.iinfo(input.dtype) if input.dtype.kind in "iu" else None
@@ -308,7 +309,8 @@ def _fused_3d_padded_rows(input, output, weights, origins, modes, cval, is_box):
         right = len(wx) - 1 - left
     # the x mode no longer matters for the columns that are kept; `nearest` is the cheapest for the kernels
     return _run_on_extended_rows(input, output, left, right, modes[2], cval,
-                                 lambda e, o: _fused_3d(e, o, weights, origins, [modes[0], modes[1], "nearest"], cval, is_box, None))
+                                 lambda e, o: _fused_3d(e, o, weights, origins, [modes[0], modes[1], "nearest"], cval, is_box, None),
+                                 exact_cval=False)
 
 
 def _fused_3d_f64(input, output, weights, origins, modes, cval):
