@@ -1158,7 +1158,8 @@ struct ZStreamParams {
     int ry;                  // rows of the staged window
     int P;                   // LDS row pitch in floats (a multiple of 4, <= kZsP): the widest span a staged row needs
     int shear;               // 1 = every staged row starts at its own first needed column, 0 = bounding rectangle (pitch kZsP)
-    int nslots;              // ring slots: 4, or 3 when |mS| <= 1 (an output plane and the next then read at most three input planes)
+    int nslots;              // ring slots: 4, or 3 when |mS| <= 1.3 (up to 1 an output plane and the next read at most three input planes;
+                             // beyond it a plane whose slot is still being read is fetched late)
     int nchunks;             // ry * P / 4
     double cmin_y, cmin_x;   // minimum of cR / cx over a tile relative to its first voxel (see LdsAffineParams::cmin)
     int zc, nzc;             // output planes per chunk, chunks
@@ -1538,6 +1539,7 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
     auto slot_of = [&](int pl) { return (unsigned)(NS == 4 ? (pl & 3) : (pl % 3 + 3) % 3); };
     ZSplit cur = zs_split(m0_, m3_, zs, nz_);
     if (cur.in) { ZS_ENSURE(cur.i0); ZS_ENSURE(cur.i0 + 1); }
+    bool drain = false;                       // the previous step issued DMAs after its stores
     const float cval = (float)q.cval;
 
 #pragma unroll 1
@@ -1547,13 +1549,27 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
         // (r4b: the FIRST step has no stores behind the prologue's DMAs -- vmcnt(2) there let the last two chunks of a
         // chunk's first plane be read before they had landed: a few wrong voxels in the first plane of a z chunk under
         // back-to-back launches, found by the whole-volume check of scripts/bench_configs.py)
-        if (wide && z > zs) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // (a step that fetched planes LATE -- after its stores, see below -- is followed by a full drain as well)
+        if (wide && z > zs && !drain) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        drain = false;
         ZSplit nxt = cur;
+        int late0 = -1, late1 = -1;
         if (z + 1 < ze) {
             nxt = zs_split(m0_, m3_, z + 1, nz_);
-            if (nxt.in) { ZS_ENSURE(nxt.i0); ZS_ENSURE(nxt.i0 + 1); }
+            if (nxt.in) {
+                // With THREE ring slots (1 < |mS| <= 1.3: the next output plane usually shares a plane with this one, now and
+                // then it does not) a plane whose slot one of this step's two planes occupies is fetched after they have been
+                // read: one extra barrier and a drained pipeline every 1 / (|mS| - 1) steps, against a third fewer LDS.
+                auto busy = [&](int pl) {
+                    if (NS != 3 || !cur.in || (pl >= rlo && pl <= rhi) || pl < 0 || pl >= nz_) return false;
+                    const int d0 = pl - cur.i0, d1 = pl - (cur.i0 + 1);
+                    return d0 % 3 == 0 || d1 % 3 == 0;
+                };
+                if (busy(nxt.i0)) late0 = nxt.i0; else ZS_ENSURE(nxt.i0);
+                if (busy(nxt.i0 + 1)) late1 = nxt.i0 + 1; else ZS_ENSURE(nxt.i0 + 1);
+            }
         }
         float r[8];
         if (cur.in && !(q.dbg & 2) && any_bad) {
@@ -1633,6 +1649,12 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
                 }
             }
         }
+        if (late0 >= 0 || late1 >= 0) {
+            __builtin_amdgcn_s_barrier();                        // everyone has read this step's planes
+            if (late0 >= 0) ZS_ENSURE(late0);
+            if (late1 >= 0) ZS_ENSURE(late1);
+            drain = true;
+        }
         cur = nxt;
     }
 #undef ZS_ENSURE
@@ -1681,7 +1703,7 @@ static bool zstream_plan(const FastInterpParams &p, int S, ZStreamParams *q)
     // the bounding rectangle (one origin for all rows, pitch kZsP) when it fits LDS twice per CU: cheaper taps (SHEAR = false)
     constexpr int NT_ = TY * 8;
     const int rx = (int)floor(ex * (1.0 + 1e-6) + 2e-3) + 3 + 3;
-    size_t NSl = fabs(m[4 * S + S]) <= 1.0 ? 3 : 4;                                          // ring slots of the sheared kernel
+    size_t NSl = fabs(m[4 * S + S]) <= 1.3 ? 3 : 4;                                          // ring slots of the sheared kernel (beyond 1: with late fetches)
     const size_t rect_lds = 4 * (size_t)(((ry * (kZsP / 4) + NT_ - 1) / NT_) * NT_ * 16) + (size_t)(TY / 8) * 2048;   // (the rectangle kernel: four)
     const bool rect_fits = rx <= kZsP && (ry * (kZsP / 4) + NT_ - 1) / NT_ <= kZsRoundsMax && rect_lds <= 150 * 1024;
     bool shear = !(rect_fits && 2 * (rect_lds + 1024) <= 160 * 1024);
