@@ -453,6 +453,14 @@ def uniform_filter(input, size=3, output=None, mode="reflect", cval=0.0, origin=
         res = _try_uniform_integer(input, output, sizes, origins, modes, cval)
         if res is not None:
             return res
+        if (input.shape[-1] * input.dtype.itemsize) % 16 and S.current_planes() is None and int(origins[-1]) == 0 and int(sizes[-1]) % 2:
+            # rows that are not a multiple of 16 bytes: the integer box kernels on explicitly extended rows (r4b)
+            reach = int(sizes[-1]) // 2
+            modes_x = list(modes[:-1]) + ["nearest"]
+            res = _run_on_extended_rows(input, output, reach, reach, modes[-1], cval,
+                                        lambda e, o: _try_uniform_integer(e, o, sizes, origins, modes_x, cval))
+            if res is not None:
+                return res
 
     if dtype_mode == "float":
         passes = [(lambda s, d, ax=ax, sz=sz, og=og, m=m:
@@ -1084,6 +1092,12 @@ def _rank_filter(input, rank, size, footprint, output, mode, cval, origin, opera
         res = _try_median3x3(input, output, mode, cval)
         if res is not None:
             return res
+        if input.dtype.itemsize in (1, 2, 4) and (input.shape[-1] * input.dtype.itemsize) % 16 and mode != "constant":
+            # rows that are not a multiple of 16 bytes (r4b).  Not for `constant`: the kernel takes ONE mode for both axes, and
+            # on the extended rows the x mode must be one that never supplies a value of its own
+            res = _run_on_extended_rows(input, output, 1, 1, mode, cval, lambda e, o: _try_median3x3(e, o, mode, cval))
+            if res is not None:
+                return res
     fpp = fp.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
     fsh = S.c_int64s(fp.shape)
     org = S.c_ints(origins)

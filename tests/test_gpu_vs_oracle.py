@@ -1808,6 +1808,17 @@ def test_separable_filters_rows_not_a_multiple_of_four(gpu, ndi):
                         got = fn(xd, size, mode=mode, cval=7).get()
                         assert np.array_equal(got, rf(x, size, mode=mode, cval=7)), (shape, dt, mode, size, fn.__name__, last_kernel())
             assert np.array_equal(ndi.grey_erosion(xd, size=3).get(), sndi.grey_erosion(x, size=3))
+    # integer box filters and the 3 x 3 median on such rows
+    for shape in [(301, 403), (20, 37, 262), (45, 54, 45)]:
+        for dt in (np.uint8, np.int16, np.float32):
+            xi = (rng.standard_normal(shape) * 40 + 100).astype(dt)
+            xid = gpu.asarray(xi)
+            for mode in ("reflect", "mirror", "nearest", "wrap", "constant"):
+                if dt != np.float32:
+                    for size in (3, 5, (1,) * (len(shape) - 2) + (3, 7)):
+                        assert np.array_equal(ndi.uniform_filter(xid, size, mode=mode, cval=9).get(), sndi.uniform_filter(xi, size, mode=mode, cval=9)), (shape, dt, mode, size)
+                fp = np.ones((1,) * (len(shape) - 2) + (3, 3), bool)
+                assert np.array_equal(ndi.median_filter(xid, footprint=fp, mode=mode, cval=9).get(), sndi.median_filter(xi, footprint=fp, mode=mode, cval=9)), (shape, dt, mode)
     # a cval the array's dtype does not hold exactly (SciPy uses it as a double): still SciPy's result (generic route)
     xi = (rng.standard_normal((20, 37, 101)) * 40 + 100).astype(np.uint8)
     w3 = rng.standard_normal((3, 3, 3))
