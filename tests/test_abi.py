@@ -95,5 +95,6 @@ def test_build_gate_sees_the_vmcnt_counting_kernels():
                 f.write(co)
             text = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", path], stdout=subprocess.PIPE, text=True, check=True).stdout
         names = re.findall(r"^[0-9a-f]+ <(\S+)>:$", text, flags=re.M)
-        assert any(fragment in n for n in names), (src, names[:3])
+        for frag in (fragment if isinstance(fragment, tuple) else (fragment,)):
+            assert any(frag in n for n in names), (src, frag, names[:3])
         assert _build._scratch_users(obj, fragment) == []
