@@ -159,7 +159,7 @@ def _compile(args):
 # Sources whose kernels wait on vmcnt by count (LDS-DMA rings): the name fragment selects the kernels that must not
 # touch scratch memory (a spill store or reload is one more vector-memory operation in flight than the count assumes).
 # The ablation builds of the r3 long kernel (<W, SAME, DBG = true, 0>) are exempt: timing aids, not product kernels.
-NO_SCRATCH = {"sep3d_long.hip": "sep3d_long", "minmax3d_f32.hip": "mm3f32_long", "interp_fast.hip": ("zstream_kernel", "zrect_kernel")}
+NO_SCRATCH = {"sep3d_long.hip": "sep3d_long", "minmax3d_f32.hip": "mm3f32_long", "interp_fast.hip": ("zstream_kernel", "zrect_kernel"), "interp.hip": "cubic3_zstream_kernel"}
 
 
 # Kernels whose occupancy is part of their design: (fragment of the mangled name, VGPRs + AGPRs per lane at most).

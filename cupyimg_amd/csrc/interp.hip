@@ -485,7 +485,18 @@ __device__ __forceinline__ int spline_tap32(int i, int n, int mode)
 
 // one axis of the tap selection: coordinate in double (as the double route), everything after the
 // integer / fraction split in 32 bits.  Returns true when the coordinate is beyond the array in constant mode.
-__device__ __forceinline__ bool cubic3_axis(int n, int stride, double cc, int mode, int npad, float (&w)[4], int (&off)[4])
+// the four weights of a fraction x in [0, 1)
+__device__ __forceinline__ void cubic3_weights(float x, float (&w)[4])
+{
+    const float y = 1.f - x;
+    w[1] = (x * x * (x - 2.f) * 3.f + 4.f) * (1.f / 6.f);
+    w[2] = (y * y * (y - 2.f) * 3.f + 4.f) * (1.f / 6.f);
+    w[0] = y * y * y * (1.f / 6.f);
+    w[3] = 1.f - w[0] - w[1] - w[2];
+}
+
+// taps of an axis and the fraction their weights are made of (cubic3_weights)
+__device__ __forceinline__ bool cubic3_axis_frac(int n, int stride, double cc, int mode, int npad, float &frac, int (&off)[4])
 {
     bool outside = false;
     cc += (double)npad;
@@ -499,11 +510,7 @@ __device__ __forceinline__ bool cubic3_axis(int n, int stride, double cc, int mo
     }
     const double fl = floor(cc);
     const int start = (int)fl - 1;
-    const float x = (float)(cc - fl), y = 1.f - x;
-    w[1] = (x * x * (x - 2.f) * 3.f + 4.f) * (1.f / 6.f);
-    w[2] = (y * y * (y - 2.f) * 3.f + 4.f) * (1.f / 6.f);
-    w[0] = y * y * y * (1.f / 6.f);
-    w[3] = 1.f - w[0] - w[1] - w[2];
+    frac = (float)(cc - fl);
     if (start >= 0 && start + 3 < n) {
 #pragma unroll
         for (int k = 0; k < 4; k++) off[k] = (start + k) * stride;
@@ -514,6 +521,14 @@ __device__ __forceinline__ bool cubic3_axis(int n, int stride, double cc, int mo
             off[k] = j < 0 ? -1 : j * stride;
         }
     }
+    return outside;
+}
+
+__device__ __forceinline__ bool cubic3_axis(int n, int stride, double cc, int mode, int npad, float (&w)[4], int (&off)[4])
+{
+    float x;
+    const bool outside = cubic3_axis_frac(n, stride, cc, mode, npad, x, off);
+    cubic3_weights(x, w);
     return outside;
 }
 
@@ -830,6 +845,450 @@ cubic3_diag_f32_kernel(const float *__restrict__ in, float *__restrict__ out, co
         res = cubic3_gather<NTZ, NTY>(rin, t, cval, mode);
     }
     if (live) __builtin_nontemporal_store(res, out + ((int64_t)z * oy + y) * ox + x);
+}
+
+// ---------------------------------------------------------------------------
+// r4b: cubic interpolation (float32 coefficients) for matrices that leave axis 0 to itself -- in-plane rotations, shears,
+// scalings of every (y, x) slice with a step of at most one plane through the slices: `rotate(volume, a, axes=(1, 2))`,
+// slice-wise registration -- STREAMING ALONG z like the order-1 kernels of interp_fast.hip.  cubic3_f32_kernel gathers
+// 16 x 16 bytes per voxel through the L1 (3.5 ms on 512^3); here a workgroup (256 threads, 32 x 64 tile, eight voxels per
+// thread) walks down a chunk of output planes, the in-plane taps of a voxel -- the LDS offset of its 4 x 4 block and its
+// eight weights -- are computed ONCE, input planes enter LDS once per tile as the tile's bounding rectangle (LDS-DMA, a ring
+// of five slots indexed by plane mod 5: four planes of the current output plane + the one the next needs), and a voxel
+// reads its 64 taps as 32 ds_read2_b32.  Tap selection (cubic3_axis), weights, products and the order of the sums are
+// those of cubic3_gather: bit-identical results.  A voxel whose 4 x 4 block is not a plain block inside the rectangle
+// (boundary folds, cval taps, anything the rectangle does not hold) and a plane with a cval tap along z take
+// cubic3_gather itself.
+// ---------------------------------------------------------------------------
+void note_kernel(const char *fmt, ...);        // runtime.hip (sep_common.hpp declares it for the filter sources)
+constexpr int kCzP = 80, kCzRoundsMax = 8, kCzSlots = 5, kCzTY = 32, kCzNT = 256;
+constexpr double kCzMinXStep = 0.09;    // |dx_in/dx_out| >= this x |dy_in/dx_out|: up to ~85 degrees (profiles/r4_cubic_zstream.txt: 3.4 ms against 4.1 ms there, 7.8 against 3.9 at 90)
+constexpr int kCzSlot = 14336;          // the fixed slot size (44 rows): five of them + the tiles fit a CU twice, 4 x kCzSlot is an immediate offset
+
+struct CubZParams {
+    int nz, ny, nx;              // coefficient array (padded by npad on every axis)
+    int oz, oy, ox;
+    double m00, m03, m11, m12, m13, m21, m22, m23;
+    double cmin_y, cmin_x;       // minimum of cy / cx over a tile relative to its first voxel
+    int ry, nchunks;             // rows of the staged rectangle, 16-byte chunks per plane (ry * 20)
+    int slot_bytes;              // kCzSlot when the rectangle fits it, else exactly the rectangle
+    int zc, nzc, ntx, nty;
+    int mode, npad;
+    float cval;
+    int dbg;
+};
+
+// lanes outside `mask` neither fetch nor write LDS (the last round of a plane: the slots are exactly as long as the rectangle)
+__device__ __forceinline__ void cz_dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_base, unsigned long long mask)
+{
+    unsigned keep;
+    unsigned long long keep_exec;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b64 %1, exec\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_mov_b64 exec, %6\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(keep_exec)
+        : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base), "s"(mask)
+        : "memory");
+}
+
+struct CzPlane { float w[4]; int off[4]; int pl[4]; bool outside, cvtap; };      // cvtap: the step takes cubic3_gather (a cval tap along z, or a slot clash)
+
+__global__ void __launch_bounds__(kCzNT, 2)
+cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, const CubZParams q)
+{
+    constexpr int P = kCzP, TY = kCzTY, NT = kCzNT, NS = kCzSlots;
+    extern __shared__ __attribute__((aligned(16))) char smem_cz[];
+    const unsigned slot_bytes = (unsigned)q.slot_bytes;                                 // the last DMA round of a plane is lane-masked: nothing beyond the rectangle is written
+    float *tiles = reinterpret_cast<float *>(smem_cz + max((unsigned)NS * slot_bytes, 4u * 24u * 64u * 4u));      // [4 waves][8 rows][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = q.ntx * q.nty * q.nzc;
+    int t = blockIdx.x;
+    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);          // x-neighbouring tiles on one XCD
+    const int tx_i = t % q.ntx, ty_i = (t / q.ntx) % q.nty, zc_i = t / (q.ntx * q.nty);
+    const int x0 = tx_i * 64, y0 = ty_i * TY;
+    const int zs = zc_i * q.zc, ze = min(zs + q.zc, q.oz);
+    const int nxy = q.ny * q.nx;
+    const int vol_bytes = q.nz * nxy * 4;
+    const unsigned plane_b = (unsigned)nxy * 4u, row_b = (unsigned)q.nx * 4u;
+
+    // ---- rectangle origin: the first tap row / column of the tile's smallest coordinates (a hair below, one tap to the
+    // left, + the padding of the coefficient array), clamped into the array, x aligned down to 16 bytes
+    int by0, bx0;
+    {
+        const double cy = ((q.m11 * (double)y0 + q.m12 * (double)x0) + q.m13) + q.cmin_y + (double)q.npad;
+        const double cx = ((q.m21 * (double)y0 + q.m22 * (double)x0) + q.m23) + q.cmin_x + (double)q.npad;
+        double fy = floor(cy - 1e-6 * (1.0 + fabs(cy))) - 1.0, fx = floor(cx - 1e-6 * (1.0 + fabs(cx))) - 1.0;
+        fy = fy < 0.0 ? 0.0 : (fy > (double)(q.ny - 1) ? (double)(q.ny - 1) : fy);
+        fx = fx < 0.0 ? 0.0 : (fx > (double)(q.nx - 1) ? (double)(q.nx - 1) : fx);
+        by0 = __builtin_amdgcn_readfirstlane((int)fy);
+        bx0 = __builtin_amdgcn_readfirstlane((int)fx & ~3);
+    }
+    const int rounds = (q.nchunks + NT - 1) / NT;
+    unsigned rel[kCzRoundsMax];
+    unsigned long long live[kCzRoundsMax];
+#pragma unroll
+    for (int j = 0; j < kCzRoundsMax; j++) {
+        const unsigned ch = (unsigned)tid + (unsigned)(j * NT);
+        const unsigned row = ch / 20u, c4 = ch - row * 20u;
+        rel[j] = ch < (unsigned)q.nchunks ? row * row_b + c4 * 16u : 0x80000000u;
+        live[j] = __builtin_amdgcn_ballot_w64(ch < (unsigned)q.nchunks);
+    }
+    const unsigned org_b = ((unsigned)by0 * (unsigned)q.nx + (unsigned)bx0) * 4u;
+
+    // ---- per voxel (row y0 + 8 wave + k, column x0 + lane), once: the in-plane taps.  a_[k] = row and column of the
+    // start the four taps per axis are counted from, relative to the rectangle, + 8 each, row in the high half.  A voxel is
+    //   plain   when the 4 x 4 taps are a block inside the rectangle (or the voxel is `outside`: its value is cval);
+    //   edge    when taps beyond the array come back by the cheap form of the boundary rule (czrule below: reflection about
+    //           the end / clamping, what spline_tap32 gives within a few samples of the array for every mode but the two
+    //           grid modes) and all sixteen are inside the rectangle -- CHECKED here against cubic3_axis's offsets;
+    //   far     otherwise (cval taps of grid-constant, the other side of the array under grid-wrap, ...).
+    // A wave with a far voxel takes cubic3_gather for its eight rows; every other wave reads the rectangle, rows and
+    // columns through czrule.
+    const int rule = q.mode == MI_MODE_NEAREST ? 2 : (q.mode == MI_MODE_REFLECT ? 1 : ((q.mode == MI_MODE_GRID_WRAP || q.mode == MI_MODE_GRID_CONSTANT) ? 3 : 0));
+    auto czrule = [&](int i, int n) {               // rule 3: never used for taps beyond the array (those voxels are far)
+        const int lo = rule == 2 ? 0 : -i - rule, hi = rule == 2 ? n - 1 : 2 * n - 2 + rule - i;
+        return i < 0 ? lo : (i >= n ? hi : i);
+    };
+    int a_[8];
+    float fy_[8], fx_[8];            // the fractions the eight in-plane weights of a voxel are made of
+    unsigned farmask = 0, outmask = 0;
+    auto inplane = [&](int k, float &fy, int (&offy)[4], float &fx, int (&offx)[4]) {
+        const double o1 = (double)(y0 + 8 * wave + k), o2 = (double)(x0 + lane);
+        // cubic3_f32_kernel's order: s = 0; s += m[d][0] z; s += m[d][1] y; s += m[d][2] x; c = s + m[d][3] (m[d][0] = 0 here)
+        double s1 = 0.0; s1 += q.m11 * o1; s1 += q.m12 * o2;
+        double s2 = 0.0; s2 += q.m21 * o1; s2 += q.m22 * o2;
+        const bool oy_ = cubic3_axis_frac(q.ny, q.nx, s1 + q.m13, q.mode, q.npad, fy, offy);
+        const bool ox_ = cubic3_axis_frac(q.nx, 1, s2 + q.m23, q.mode, q.npad, fx, offx);
+        return oy_ | ox_;
+    };
+    // a ROLLED loop (its body is the boundary arithmetic of every mode, twice): the three values of a voxel wait in the
+    // slot area, which no DMA has touched yet, and come back into registers below
+    float *park = reinterpret_cast<float *>(smem_cz) + wave * (24 * 64) + lane;
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        int offy[4], offx[4];
+        float fy, fx;
+        const bool outside = inplane(k, fy, offy, fx, offx);
+        bool block = offy[0] >= 0 && offx[0] >= 0;
+#pragma unroll
+        for (int j = 1; j < 4; j++) block = block && offy[j] == offy[0] + j * q.nx && offx[j] == offx[0] + j;
+        int r0 = offy[0] / q.nx - by0, c0 = offx[0] - bx0;
+        const bool held = block && r0 >= 0 && r0 + 3 < q.ry && c0 >= 0 && c0 + 3 < P;
+        bool edge = false;
+        if (!held && !outside && rule != 3) {
+            // the start the taps were counted from: a tap inside the array is its own image and gives it away; the candidate
+            // is taken when czrule reproduces all four of cubic3_axis's offsets from it
+            int sy = 0, sx = 0;
+            bool fy_ = false, fx_ = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!fy_ && offy[j] >= 0) {
+                    const int s = offy[j] / q.nx - j;
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) ok = ok && offy[i] == czrule(s + i, q.ny) * q.nx;
+                    if (ok) { sy = s; fy_ = true; }
+                }
+                if (!fx_ && offx[j] >= 0) {
+                    const int s = offx[j] - j;
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) ok = ok && offx[i] == czrule(s + i, q.nx);
+                    if (ok) { sx = s; fx_ = true; }
+                }
+            }
+            edge = fy_ && fx_ && sy - by0 >= -8 && sx - bx0 >= -8 && sy - by0 < 4096 && sx - bx0 < 4096;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ty = czrule(sy + j, q.ny) - by0, tx = czrule(sx + j, q.nx) - bx0;
+                edge = edge && ty >= 0 && ty < q.ry && tx >= 0 && tx < P;
+            }
+            r0 = sy - by0; c0 = sx - bx0;
+        }
+        park[(3 * k) * 64] = __int_as_float((held || edge) ? ((r0 + 8) << 16) | (c0 + 8) : (8 << 16) | 8);
+        park[(3 * k + 1) * 64] = fy;
+        park[(3 * k + 2) * 64] = fx;
+        farmask |= (held || edge || outside) ? 0u : (1u << k);
+        outmask |= outside ? (1u << k) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        a_[k] = __float_as_int(park[(3 * k) * 64]);
+        fy_[k] = park[(3 * k + 1) * 64];
+        fx_[k] = park[(3 * k + 2) * 64];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // before anyone's DMA lands on the parked values
+    float wy_[8][4], wx_[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { cubic3_weights(fy_[k], wy_[k]); cubic3_weights(fx_[k], wx_[k]); }
+    const bool any_far = __builtin_amdgcn_ballot_w64(farmask != 0u) != 0;
+    float *tile = tiles + wave * 512;
+    const bool wide = x0 + 64 <= q.ox && y0 + TY <= q.oy;
+
+    // ---- the plane ring: slot (plane mod 5), resident planes a contiguous range [rlo, rhi] of at most five
+    int rlo = 0, rhi = -1;
+    auto slot_of = [&](int pl) { return (unsigned)(((pl % NS) + NS) % NS); };
+    auto ensure = [&](int pl) {
+        if (pl < 0 || pl >= q.nz) return;
+        if (pl >= rlo && pl <= rhi) return;
+        if (pl == rhi + 1 && rhi >= rlo) { rhi = pl; if (rhi - rlo > NS - 1) rlo = rhi - (NS - 1); }
+        else if (pl == rlo - 1 && rhi >= rlo) { rlo = pl; if (rhi - rlo > NS - 1) rhi = rlo + (NS - 1); }
+        else { rlo = rhi = pl; }
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
+        const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)pl * plane_b + org_b);
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(slot_of(pl) * slot_bytes + (unsigned)(wave << 6) * 16u);
+#pragma unroll
+        for (int j = 0; j < kCzRoundsMax; j++)
+            if (j < rounds && live[j] != 0) cz_dma16(rin, rel[j], base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * NT) * 16u), live[j]);
+    };
+    auto zplane = [&](int z) {
+        CzPlane p;
+        double s0 = 0.0; s0 += q.m00 * (double)z;
+        float w[4]; int off[4];
+        p.outside = cubic3_axis(q.nz, nxy, s0 + q.m03, q.mode, q.npad, w, off);
+        p.cvtap = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            p.w[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(w[k])));
+            p.off[k] = __builtin_amdgcn_readfirstlane(off[k]);
+            p.pl[k] = p.off[k] < 0 ? -1 : p.off[k] / nxy;
+            p.cvtap = p.cvtap || p.off[k] < 0;
+        }
+        // two DIFFERENT planes of one step in the same ring slot (planes that wrap around the array, a multiple of five
+        // apart): the step cannot be served from the ring
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = i + 1; j < 4; j++)
+                p.cvtap = p.cvtap || (p.pl[i] >= 0 && p.pl[j] >= 0 && p.pl[i] != p.pl[j] && slot_of(p.pl[i]) == slot_of(p.pl[j]));
+        p.outside = __builtin_amdgcn_readfirstlane((int)p.outside) != 0;
+        return p;
+    };
+    CzPlane cur = zplane(zs);
+    if (!cur.outside)
+        for (int k = 0; k < 4; k++) ensure(cur.pl[k]);
+    bool drain = false;
+
+#pragma unroll 1
+    for (int z = zs; z < ze; z++) {
+        // the planes of this step have landed (the two stores of the previous step, issued after their DMAs, may still be in
+        // flight on full tiles -- not in the first step, and not after a step that fetched late)
+        if (wide && z > zs && !drain) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        drain = false;
+        CzPlane nxt = cur;
+        int late[4] = {-1, -1, -1, -1};
+        bool any_late = false;
+        if (z + 1 < ze) {
+            nxt = zplane(z + 1);
+            if (!nxt.outside) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int pl = nxt.pl[k];
+                    if (pl < 0 || pl >= q.nz || (pl >= rlo && pl <= rhi)) continue;
+                    bool busy = false;
+                    if (!cur.outside)
+                        for (int j = 0; j < 4; j++) busy = busy || (cur.pl[j] >= 0 && slot_of(cur.pl[j]) == slot_of(pl));
+                    if (busy) { late[k] = pl; any_late = true; }
+                    else ensure(pl);
+                }
+            }
+        }
+        // results go through the wave's LDS tile (full tiles: two 16-byte stores per lane afterwards).  ONE store target here:
+        // a choice between the tile and `out` would be compiled to flat stores, which the compiler orders against every
+        // LDS read with vmcnt(0) -- the end of the prefetch
+        auto emit = [&](int k, float v) { tile[k * 64 + lane] = v; };
+        if (cur.outside) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) emit(k, q.cval);
+        } else if (cur.cvtap || any_far || (q.dbg & 2)) {
+            // a cval tap along z, or some voxel of this wave whose in-plane block the rectangle does not hold: cubic3_gather,
+            // one voxel at a time in a rolled loop (this path must not set the kernel's register count)
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
+#pragma unroll 1
+            for (int k = 0; k < 8; k++) {
+                Cubic3 tt;
+                float fy, fx;
+                const bool outside = inplane(k, fy, tt.off[1], fx, tt.off[2]);
+                cubic3_weights(fy, tt.w[1]);
+                cubic3_weights(fx, tt.w[2]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { tt.w[0][j] = cur.w[j]; tt.off[0][j] = cur.off[j]; }
+                tt.ntap[0] = 4; tt.ntap[1] = 4;
+                tt.outside = outside;
+                emit(k, cubic3_gather<4, 4>(rin, tt, q.cval, q.mode));
+            }
+        } else {
+            // every tap addressed on its own, rows and columns by czrule (the identity inside the array): 64 ds_read_b32 per
+            // voxel.  (Reading a plain voxel's rows as 2 x ds_read2_b32 at immediate offsets measured SLOWER, 1.54 ms against
+            // 1.42 ms on 512^3 at 7 degrees.)  The sixteen (row, column) offsets of a voxel are added up once; the plane comes
+            // in as the IMMEDIATE offset of the read when the slots have the fixed size kCzSlot and the four planes follow
+            // each other (everywhere but at the ends of the array): slot (s + kz) mod 5 for the five values of s, five copies
+            // of the code.  All 64 reads of a voxel are issued before its arithmetic.
+            const bool consecutive = cur.pl[1] == cur.pl[0] + 1 && cur.pl[2] == cur.pl[0] + 2 && cur.pl[3] == cur.pl[0] + 3;
+            const int s0 = (int)slot_of(cur.pl[0]);
+            unsigned pb[4];
+#pragma unroll
+            for (int kz = 0; kz < 4; kz++) pb[kz] = slot_of(cur.pl[kz]) * slot_bytes;
+            auto voxels = [&](auto svar) {
+                constexpr int S = decltype(svar)::value;            // -1: slots by their run-time offsets
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    // (an opaque copy: the offsets derived from it are the same on every plane, and hoisted out of the loop
+                    // over the planes they would sit in sixty-odd registers)
+                    int ak = a_[k];
+                    asm volatile("" : "+v"(ak));
+                    const int sy = (ak >> 16) - 8 + by0, sx = (ak & 0xffff) - 8 + bx0;
+                    unsigned ro[4], co[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        // `outside` voxels: anything inside the slot (their value is replaced below)
+                        int ty = czrule(sy + j, q.ny) - by0, tx = czrule(sx + j, q.nx) - bx0;
+                        ty = min(max(ty, 0), q.ry - 1); tx = min(max(tx, 0), P - 1);
+                        ro[j] = (unsigned)ty * (unsigned)(P * 4); co[j] = (unsigned)tx * 4u;
+                    }
+                    float v[4][4][4];
+#pragma unroll
+                    for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 4; kx++) {
+                            const unsigned rc = ro[ky] + co[kx];
+#pragma unroll
+                            for (int kz = 0; kz < 4; kz++) {
+                                if constexpr (S >= 0) v[kz][ky][kx] = *reinterpret_cast<const float *>(smem_cz + rc + ((S + kz) % NS) * kCzSlot);
+                                else v[kz][ky][kx] = *reinterpret_cast<const float *>(smem_cz + (rc + pb[kz]));
+                            }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int kz = 0; kz < 4; kz++) {
+#pragma unroll
+                        for (int ky = 0; ky < 4; ky++) {
+                            const float wzy = cur.w[kz] * wy_[k][ky];
+                            float row = v[kz][ky][0] * wx_[k][0];
+                            row = fmaf(v[kz][ky][1], wx_[k][1], row);
+                            row = fmaf(v[kz][ky][2], wx_[k][2], row);
+                            row = fmaf(v[kz][ky][3], wx_[k][3], row);
+                            acc = fmaf(row, wzy, acc);
+                        }
+                    }
+                    emit(k, ((outmask >> k) & 1u) ? q.cval : acc);
+                    __builtin_amdgcn_sched_barrier(0);              // one voxel's taps at a time
+                }
+            };
+            if (slot_bytes == (unsigned)kCzSlot && consecutive) {
+                switch (s0) {
+                case 0: voxels(std::integral_constant<int, 0>{}); break;
+                case 1: voxels(std::integral_constant<int, 1>{}); break;
+                case 2: voxels(std::integral_constant<int, 2>{}); break;
+                case 3: voxels(std::integral_constant<int, 3>{}); break;
+                default: voxels(std::integral_constant<int, 4>{}); break;
+                }
+            } else {
+                voxels(std::integral_constant<int, -1>{});
+            }
+        }
+        if (wide) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int i = lane >> 4, c = lane & 15;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float4 v = *reinterpret_cast<const float4 *>(tile + (4 * h + i) * 64 + 4 * c);
+                typedef float f32x4c __attribute__((ext_vector_type(4)));
+                const f32x4c vv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(vv, reinterpret_cast<f32x4c *>(out + ((size_t)z * q.oy + (y0 + 8 * wave + 4 * h + i)) * q.ox + x0 + 4 * c));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            // edge tiles (they wait for vmcnt(0) at the top of every step)
+            const int x = x0 + lane;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int y = y0 + 8 * wave + k;
+                const float v = tile[k * 64 + lane];
+                if (x < q.ox && y < q.oy) __builtin_nontemporal_store(v, out + ((size_t)z * q.oy + y) * q.ox + x);
+            }
+        }
+        if (any_late) {
+            __builtin_amdgcn_s_barrier();                        // everyone has read this step's planes
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (late[k] >= 0) ensure(late[k]);
+            drain = true;
+        }
+        cur = nxt;
+    }
+}
+
+Knob g_cubic_zstream{1};      // test hook: 0 = the gather kernel for every non-diagonal matrix; 3 = the z-streaming kernel with every wave on cubic3_gather
+extern "C" int mi_debug_set_cubic_zstream(int on) { g_cubic_zstream = on; return MI_OK; }
+
+// plan + launch; false = not taken (the caller runs cubic3_f32_kernel)
+static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, const InterpGeom &g, int mode, double cval, int npad, hipStream_t s, int *rc)
+{
+    *rc = MI_OK;
+    if (!g_cubic_zstream || g.pad != 0) return false;
+    const double *m = g.mat;
+    for (int i = 0; i < 12; i++) if (!(fabs(m[i]) < 1e9)) return false;
+    if (m[1] != 0.0 || m[2] != 0.0 || m[4] != 0.0 || m[8] != 0.0) return false;            // axis 0 decoupled
+    if (!(fabs(m[0]) <= 1.0)) return false;                                                  // five ring slots suffice
+    // the lanes of a wave are neighbours along the output's x: their taps must be spread along the rows of the rectangle
+    // rather than down its columns (row pitch 80 floats: sixteen banks apart, a 16-way conflict at 90 degrees)
+    if (!(g_cubic_zstream & 4) && !(fabs(m[10]) >= kCzMinXStep * fabs(m[6]))) return false;
+    CubZParams q;
+    q.nz = (int)g.shape[0]; q.ny = (int)g.shape[1]; q.nx = (int)g.shape[2];
+    q.oz = (int)g.oshape[0]; q.oy = (int)g.oshape[1]; q.ox = (int)g.oshape[2];
+    if ((int64_t)q.oz * q.oy * q.ox < (1 << 18) || q.ox < 64 || q.nx < 8 || ((uintptr_t)out->data & 15) || ((uintptr_t)coef->data & 15) || (q.nx & 3)) return false;
+    if ((int64_t)q.nz * q.ny * q.nx * 4 >= ((int64_t)1 << 31)) return false;
+    q.m00 = m[0]; q.m03 = m[3];
+    q.m11 = m[5]; q.m12 = m[6]; q.m13 = m[7];
+    q.m21 = m[9]; q.m22 = m[10]; q.m23 = m[11];
+    const int T[2] = {kCzTY - 1, 63};
+    const double ey = fabs(q.m11) * T[0] + fabs(q.m12) * T[1], ex = fabs(q.m21) * T[0] + fabs(q.m22) * T[1];
+    if (!(ey < 4096.0 && ex < 4096.0)) return false;
+    // tap rows floor(min - hair) - 1 .. floor(max) + 2: floor(ext + hair) + 5 of them; x: + up to 3 for the alignment
+    const int ry = (int)floor(ey * (1.0 + 1e-6) + 2e-3) + 5;
+    const int rx = (int)floor(ex * (1.0 + 1e-6) + 2e-3) + 5 + 3;
+    if (rx > kCzP) return false;
+    q.ry = ry;
+    q.nchunks = ry * (kCzP / 4);
+    if ((q.nchunks + kCzNT - 1) / kCzNT > kCzRoundsMax) return false;
+    const size_t slot = (size_t)q.nchunks * 16 <= (size_t)kCzSlot ? (size_t)kCzSlot : (size_t)q.nchunks * 16;
+    q.slot_bytes = (int)slot;
+    const size_t lds = std::max(kCzSlots * slot, (size_t)4 * 24 * 64 * 4) + 4 * 2048;     // the slots (which also park the per-voxel values during the set-up) + the output tiles
+    if (lds + 1024 > 160 * 1024) return false;                                              // one workgroup per CU at the steepest angles (two up to ~10 degrees)
+    const double e[4] = {q.m11 * T[0], q.m12 * T[1], q.m21 * T[0], q.m22 * T[1]};
+    q.cmin_y = (e[0] < 0.0 ? e[0] : 0.0) + (e[1] < 0.0 ? e[1] : 0.0);
+    q.cmin_x = (e[2] < 0.0 ? e[2] : 0.0) + (e[3] < 0.0 ? e[3] : 0.0);
+    q.ntx = (q.ox + 63) / 64;
+    q.nty = (q.oy + kCzTY - 1) / kCzTY;
+    const int tiles = q.ntx * q.nty;
+    int nzc = (2 * device_cus() + tiles - 1) / tiles;
+    nzc = std::max(1, std::min(nzc, (q.oz + 15) / 16));
+    q.zc = (q.oz + nzc - 1) / nzc;
+    q.nzc = (q.oz + q.zc - 1) / q.zc;
+    q.mode = mode; q.npad = npad; q.cval = (float)cval;
+    q.dbg = g_cubic_zstream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e_ = hipFuncSetAttribute((const void *)cubic3_zstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        if (e_ != hipSuccess) { *rc = hip_fail(e_, "hipFuncSetAttribute(cubic3_zstream_kernel)"); return true; }
+        attr_done = true;
+    }
+    note_kernel("mi::cubic3_zstream_kernel grid=%d (order-3 affine on float32 coefficients, axis 0 decoupled: streams along it, %d rows x %d staged per plane, %d chunks)",
+                tiles * q.nzc, q.ry, kCzP, q.nzc);
+    hipLaunchKernelGGL(cubic3_zstream_kernel, dim3((unsigned)(tiles * q.nzc)), dim3(kCzNT), lds, s, (const float *)coef->data, (float *)out->data, q);
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) *rc = hip_fail(e2, "cubic3_zstream_kernel");
+    return true;
 }
 
 // output geometry of the cubic kernel: the output's own shape, rank-padded with leading ones
@@ -1986,6 +2445,12 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
         hipLaunchKernelGGL((cubic3_f32_kernel<float, true, NTZ, NTY>), cgrid, dim3(64, 4), 0, s,                        \
                            (const float *)coef->data, (const float *)nullptr, (float *)out->data, g, nout, numel(coef), \
                            mode, (float)cval, npad)
+        if (!diagonal) {
+            int zrc = MI_OK;
+            if (launch_cubic_zstream(coef, out, g, mode, cval, npad, s, &zrc)) return zrc;
+        }
+        note_kernel(diagonal ? "mi::cubic3_diag_f32_kernel (order-3 affine on float32 coefficients, diagonal matrix: tabulated taps)"
+                             : "mi::cubic3_f32_kernel (order-3 affine on float32 coefficients: 16 x 16-byte gathers per voxel)");
         if (g.pad == 0) { MI_CUBIC_AFF(4, 4); } else if (g.pad == 1) { MI_CUBIC_AFF(1, 4); } else { MI_CUBIC_AFF(1, 1); }
 #undef MI_CUBIC_AFF
         if (tab) pool_free(tab);       // stream-ordered pool: the block is reused only by later work on the stream

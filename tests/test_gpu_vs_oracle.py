@@ -1894,6 +1894,70 @@ def test_affine_zstream_sheared_window_all_angles(gpu, ndi):
     assert took >= len(cases), (took, len(cases))          # the streaming kernel took (at least) one tile height of every case
 
 
+def test_cubic_affine_zstream_in_plane(gpu, ndi):
+    """r4b: order-3 affine transforms on float32 coefficients whose matrix leaves axis 0 to itself (`rotate(volume, a,
+    axes=(1, 2))` with scipy's DEFAULT order) stream along z (cubic3_zstream_kernel: planes staged in LDS once per tile, a
+    ring of five).  Bit-identical to the gather kernel (cubic3_f32_kernel) in every mode -- taps beyond the array through
+    the rectangle (reflect / mirror / nearest / constant / wrap), through the gather path of a wave (grid-constant's cval
+    taps, grid-wrap's far side, planes that clash in the ring) --, with steps along z of both signs and below one, output
+    shapes that differ from the input's, partial tiles, non-finite coefficients; and within float32 accuracy of scipy."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import _lib, last_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(4242)
+    took = 0
+    for shape, oshape in (((40, 90, 152), None), ((33, 70, 132), (48, 70, 132)), ((20, 64, 64), (20, 100, 200)), ((64, 64, 64), None), ((37, 81, 100), (41, 97, 131))):
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        osh = shape if oshape is None else oshape
+        for deg, m00, sc in ((7, 1.0, 1.0), (3, 0.9, 1.1), (-10, -1.0, 0.95), (0, 0.5, 0.8), (12, 1.0, 1.0), (90, 1.0, 1.0), (180, 0.7, 1.0)):
+            a = np.deg2rad(deg); c, s = np.cos(a), np.sin(a)
+            M = np.array([[m00, 0, 0], [0, c * sc, -s], [0, s, c * sc]])
+            off = (np.array(shape) - 1) / 2 - M @ ((np.array(osh) - 1) / 2) + np.array([0.3, -1.7, 2.2])
+            for mode in ("constant", "nearest", "mirror", "reflect", "grid-wrap", "grid-constant", "wrap"):
+                for prefilter in ((True, False) if mode in ("constant", "mirror") and deg == 7 else (True,)):
+                    kw = dict(output_shape=osh, order=3, mode=mode, cval=0.5, prefilter=prefilter)
+                    lib.mi_debug_set_cubic_zstream(0)
+                    try:
+                        want = ndi.affine_transform(xd, M, off, **kw).get()
+                    finally:
+                        lib.mi_debug_set_cubic_zstream(1)
+                    got = ndi.affine_transform(xd, M, off, **kw).get()
+                    took += "cubic3_zstream_kernel" in last_kernel()
+                    assert np.array_equal(got, want, equal_nan=True), (shape, osh, deg, m00, mode, prefilter, last_kernel()[:40], int(np.sum(got != want)))
+                    if prefilter:
+                        ref = sndi.affine_transform(x.astype(np.float64), M, off, output_shape=osh, order=3, mode=mode, cval=0.5)
+                        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (shape, deg, mode)
+    assert took >= 100, took
+    # every wave on the kernel's gather path (the debug value 3): the same bits again
+    x = rng.standard_normal((40, 90, 152)).astype(np.float32); xd = gpu.asarray(x)
+    a = np.deg2rad(21.0); M = np.array([[1.0, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    off = np.array([0.0, 20.0, -14.0])
+    want = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
+    assert "cubic3_zstream_kernel" in last_kernel()
+    lib.mi_debug_set_cubic_zstream(3)
+    try:
+        got = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
+    finally:
+        lib.mi_debug_set_cubic_zstream(1)
+    assert np.array_equal(got, want)
+    # non-finite coefficients stay inside their 4 x 4 x 4 window in both kernels alike
+    x[5, 40, 70] = np.inf; x[30, 10, 100] = np.nan
+    xd = gpu.asarray(x)
+    got = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
+    lib.mi_debug_set_cubic_zstream(0)
+    try:
+        want = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
+    finally:
+        lib.mi_debug_set_cubic_zstream(1)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.isfinite(got).sum() > 0.99 * got.size
+    # a matrix that couples axis 0, a diagonal one and a float64 array are not taken
+    M2 = M.copy(); M2[0, 1] = 0.01
+    ndi.affine_transform(xd, M2, off, order=3, prefilter=False)
+    assert "cubic3_zstream_kernel" not in last_kernel()
+
+
 def test_affine_rowblend_kernel(gpu, ndi):
     """Matrices that leave the x axis to itself with unit step and an integral shift (a rotation / shear / scaling in the
     (z, y) plane: `rotate(volume, angle)` with the default axes) blend four input ROWS per output row
