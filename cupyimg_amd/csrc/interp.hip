@@ -1228,7 +1228,7 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
     }
 }
 
-Knob g_cubic_zstream{1};      // test hook: 0 = the gather kernel for every non-diagonal matrix; 3 = the z-streaming kernel with every wave on cubic3_gather
+Knob g_cubic_zstream{1};      // test hook: 0 = the gather kernel for every non-diagonal matrix; bit 2: every wave on cubic3_gather; bit 4: any x step; bit 8: the grid modes too
 extern "C" int mi_debug_set_cubic_zstream(int on) { g_cubic_zstream = on; return MI_OK; }
 
 // plan + launch; false = not taken (the caller runs cubic3_f32_kernel)
@@ -1236,6 +1236,10 @@ static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, cons
 {
     *rc = MI_OK;
     if (!g_cubic_zstream || g.pad != 0) return false;
+    // the two grid modes: a voxel with a tap beyond the array (cval / the far side) sends its whole wave to cubic3_gather, and
+    // the tiles along the edges then hold the launch up -- 4.97 ms against the gather kernel's 3.99 ms on 512^3, 7 degrees,
+    // grid-wrap (profiles/r4_cubic_zstream.txt).  Debug bit 8 takes them all the same (the tests of those paths).
+    if ((mode == MI_MODE_GRID_WRAP || mode == MI_MODE_GRID_CONSTANT) && !(g_cubic_zstream & 8)) return false;
     const double *m = g.mat;
     for (int i = 0; i < 12; i++) if (!(fabs(m[i]) < 1e9)) return false;
     if (m[1] != 0.0 || m[2] != 0.0 || m[4] != 0.0 || m[8] != 0.0) return false;            // axis 0 decoupled

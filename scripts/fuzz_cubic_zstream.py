@@ -41,7 +41,7 @@ for i in range(cases):
     xd = ca.asarray(x)
     lib.mi_debug_set_cubic_zstream(0)
     want = ndi.affine_transform(xd, M, off, **kw).get()
-    lib.mi_debug_set_cubic_zstream(1)
+    lib.mi_debug_set_cubic_zstream(1 + 4 + 8 if i % 2 else 1)          # odd cases: any angle and the grid modes too
     got = ndi.affine_transform(xd, M, off, **kw).get()
     took += "cubic3_zstream_kernel" in last_kernel()
     ok = np.array_equal(got, want, equal_nan=True)
@@ -51,5 +51,6 @@ for i in range(cases):
     if not ok:
         bad += 1
         print("MISMATCH", i, shape, osh, M.tolist(), off.tolist(), kw, last_kernel()[:40], int(np.sum(got != want)), flush=True)
+lib.mi_debug_set_cubic_zstream(1)
 print("fuzz_cubic_zstream: %d cases (seed %d), %d took the z-streaming kernel, %d failures" % (cases, seed, took, bad))
 sys.exit(1 if bad else 0)

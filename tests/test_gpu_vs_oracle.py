@@ -1922,8 +1922,12 @@ def test_cubic_affine_zstream_in_plane(gpu, ndi):
                         want = ndi.affine_transform(xd, M, off, **kw).get()
                     finally:
                         lib.mi_debug_set_cubic_zstream(1)
-                    got = ndi.affine_transform(xd, M, off, **kw).get()
-                    took += "cubic3_zstream_kernel" in last_kernel()
+                    lib.mi_debug_set_cubic_zstream(1 + 4 + 8)          # any angle, and the grid modes (not taken by default)
+                    try:
+                        got = ndi.affine_transform(xd, M, off, **kw).get()
+                        took += "cubic3_zstream_kernel" in last_kernel()
+                    finally:
+                        lib.mi_debug_set_cubic_zstream(1)
                     assert np.array_equal(got, want, equal_nan=True), (shape, osh, deg, m00, mode, prefilter, last_kernel()[:40], int(np.sum(got != want)))
                     if prefilter:
                         ref = sndi.affine_transform(x.astype(np.float64), M, off, output_shape=osh, order=3, mode=mode, cval=0.5)
@@ -1952,6 +1956,14 @@ def test_cubic_affine_zstream_in_plane(gpu, ndi):
         lib.mi_debug_set_cubic_zstream(1)
     assert np.array_equal(got, want, equal_nan=True)
     assert np.isfinite(got).sum() > 0.99 * got.size
+    # the defaults: a quarter turn (LDS bank conflicts down the columns) and the grid modes stay with the gather kernel
+    a = np.deg2rad(90.0); M9 = np.array([[1.0, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    ndi.affine_transform(xd, M9, np.array([0.0, 0.0, 89.0]), order=3, prefilter=False)
+    assert "cubic3_f32_kernel" in last_kernel()
+    ndi.affine_transform(xd, M, off, order=3, prefilter=False, mode="grid-wrap")
+    assert "cubic3_f32_kernel" in last_kernel()
+    ndi.affine_transform(xd, M, off, order=3, prefilter=False, mode="reflect")
+    assert "cubic3_zstream_kernel" in last_kernel()
     # a matrix that couples axis 0, a diagonal one and a float64 array are not taken
     M2 = M.copy(); M2[0, 1] = 0.01
     ndi.affine_transform(xd, M2, off, order=3, prefilter=False)
