@@ -1295,6 +1295,154 @@ static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, cons
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// r4b: cubic interpolation (float32 coefficients) for matrices that leave the x axis to itself with unit step and an
+// integral shift -- rotations / shears / scalings in the (z, y) plane: `rotate(volume, a)` with SciPy's DEFAULT axes and
+// DEFAULT order.  The sixteen (z, y) taps of a voxel are the same for a whole output row and its x taps are its
+// neighbours at the fraction 0: a wave takes (a 512-voxel piece of) one output row, computes the row's taps once, and
+// every lane blends four consecutive voxels from 16 rows x two 16-byte loads at a UNIFORM row base (scalar offset) -- 8
+// coalesced loads per voxel instead of cubic3_f32_kernel's 16 gathers at per-lane addresses.  Products, weights and the
+// order of the sums are cubic3_gather's: bit-identical.  Voxels whose x taps touch the ends of the row (and anything
+// else that is not four plain taps) are collected over the wave and take cubic3_gather itself, one voxel per lane.
+// ---------------------------------------------------------------------------
+struct CubRowParams {
+    int nz, ny, nx, oz, oy, ox;
+    double m00, m01, m03, m10, m11, m13;
+    int xs;                      // the integral x shift
+    int xsegs;                   // 512-voxel pieces per output row
+    int mode, npad;
+    float cval;
+};
+
+__global__ void __launch_bounds__(256)
+cubic3_rowblend_kernel(const float *__restrict__ in, float *__restrict__ out, const CubRowParams q)
+{
+    typedef float f32x4r __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x;
+    const int seg = blockIdx.x % q.xsegs, y = (blockIdx.x / q.xsegs) * 4 + (int)threadIdx.y, z = blockIdx.y;
+    if (y >= q.oy) return;
+    const int nxy = q.ny * q.nx;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, q.nz * nxy * 4, 0x00020000);
+    // the row's taps along z and y (cubic3_f32_kernel's order of the coordinate sums; the x terms are 0 * x).  (Four rows
+    // per wave with the taps of the four computed side by side in lanes 0-3 measured slower: 0.97 against 0.86 ms.)
+    Cubic3 t;
+    {
+        double s0 = 0.0; s0 += q.m00 * (double)z; s0 += q.m01 * (double)y;
+        double s1 = 0.0; s1 += q.m10 * (double)z; s1 += q.m11 * (double)y;
+        const bool o0 = cubic3_axis(q.nz, nxy, s0 + q.m03, q.mode, q.npad, t.w[0], t.off[0]);
+        const bool o1 = cubic3_axis(q.ny, q.nx, s1 + q.m13, q.mode, q.npad, t.w[1], t.off[1]);
+        t.outside = o0 | o1;
+        t.ntap[0] = 4; t.ntap[1] = 4;
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                t.w[d][k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t.w[d][k])));
+                t.off[d][k] = __builtin_amdgcn_readfirstlane(t.off[d][k]);
+            }
+    }
+    const bool row_outside = __builtin_amdgcn_readfirstlane((int)t.outside) != 0;
+    bool cvrow = false;                       // a cval tap along z or y (grid-constant): the row takes cubic3_gather
+#pragma unroll
+    for (int k = 0; k < 4; k++) cvrow = cvrow || t.off[0][k] < 0 || t.off[1][k] < 0;
+    float wx[4];
+    cubic3_weights(0.f, wx);
+    float *orow = out + ((size_t)z * q.oy + y) * q.ox;
+    unsigned long long slow[2];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const int x4 = seg * 512 + (g * 64 + lane) * 4;
+        const int start0 = x4 + q.xs + q.npad - 1;              // first tap of the first voxel, in the (padded) row
+        const bool live = x4 < q.ox;
+        const bool plain = live && x4 + 3 < q.ox && !cvrow && (row_outside || (start0 >= 0 && start0 + 6 < q.nx));
+        slow[g] = __builtin_amdgcn_ballot_w64(live && !plain);
+        if (!plain) continue;
+        f32x4r r;
+        if (row_outside) {
+            r = f32x4r{q.cval, q.cval, q.cval, q.cval};
+        } else {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kz = 0; kz < 4; kz++) {
+                u32x4 a[4], b[4];
+#pragma unroll
+                for (int ky = 0; ky < 4; ky++) {
+                    const unsigned base = (unsigned)(t.off[0][kz] + t.off[1][ky]) * 4u;
+                    a[ky] = __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)start0 * 4u, base, 0);
+                    b[ky] = __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)start0 * 4u + 16u, base, 0);
+                }
+#pragma unroll
+                for (int ky = 0; ky < 4; ky++) {
+                    const float f[8] = {__uint_as_float(a[ky].x), __uint_as_float(a[ky].y), __uint_as_float(a[ky].z), __uint_as_float(a[ky].w),
+                                        __uint_as_float(b[ky].x), __uint_as_float(b[ky].y), __uint_as_float(b[ky].z), __uint_as_float(b[ky].w)};
+                    const float wzy = t.w[0][kz] * t.w[1][ky];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float row = f[i] * wx[0];
+                        row = fmaf(f[i + 1], wx[1], row);
+                        row = fmaf(f[i + 2], wx[2], row);
+                        row = fmaf(f[i + 3], wx[3], row);
+                        acc[i] = fmaf(row, wzy, acc[i]);
+                    }
+                }
+            }
+            r = f32x4r{acc[0], acc[1], acc[2], acc[3]};
+        }
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4r *>(orow + x4));
+    }
+    // the other voxels: up to sixteen groups of four per round, one voxel per lane
+    unsigned long long m0 = slow[0], m1 = slow[1];
+    while ((m0 | m1) != 0) {
+        int mine = -1;
+#pragma unroll 1
+        for (int k = 0; k < 16 && (m0 | m1) != 0; k++) {
+            int gi;
+            if (m0 != 0) { gi = __builtin_ctzll(m0); m0 &= m0 - 1; }
+            else { gi = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+            if ((lane >> 2) == k) mine = gi;
+        }
+        const int x = seg * 512 + mine * 4 + (lane & 3);
+        if (mine >= 0 && x < q.ox) {
+            double s2 = 0.0; s2 += (double)x;                       // 0 * z + 0 * y + 1 * x
+            const bool o2 = cubic3_axis(q.nx, 1, s2 + (double)q.xs, q.mode, q.npad, t.w[2], t.off[2]);
+            Cubic3 tt = t;
+            tt.outside = t.outside | o2;
+            __builtin_nontemporal_store(cubic3_gather<4, 4>(rin, tt, q.cval, q.mode), orow + x);
+        }
+    }
+}
+
+Knob g_cubic_rowblend{1};      // test hook: 0 = the gather kernel
+extern "C" int mi_debug_set_cubic_rowblend(int on) { g_cubic_rowblend = on; return MI_OK; }
+
+// plan + launch; false = not taken (the caller runs cubic3_f32_kernel)
+static bool launch_cubic_rowblend(const mi_array *coef, const mi_array *out, const InterpGeom &g, int mode, double cval, int npad, hipStream_t s, int *rc)
+{
+    *rc = MI_OK;
+    if (!g_cubic_rowblend || g.pad != 0) return false;
+    const double *m = g.mat;
+    for (int i = 0; i < 12; i++) if (!(fabs(m[i]) < 1e9)) return false;
+    if (m[2] != 0.0 || m[6] != 0.0 || m[8] != 0.0 || m[9] != 0.0 || m[10] != 1.0) return false;       // x to itself, unit step
+    if (m[11] != floor(m[11]) || fabs(m[11]) > 1048576.0) return false;                                // integral shift
+    CubRowParams q;
+    q.nz = (int)g.shape[0]; q.ny = (int)g.shape[1]; q.nx = (int)g.shape[2];
+    q.oz = (int)g.oshape[0]; q.oy = (int)g.oshape[1]; q.ox = (int)g.oshape[2];
+    if ((int64_t)q.oz * q.oy * q.ox < (1 << 16) || q.ox < 64 || (q.ox & 3) || q.nx < 8 || ((uintptr_t)out->data & 15) || q.oz > 65535) return false;
+    if ((int64_t)q.nz * q.ny * q.nx * 4 >= ((int64_t)1 << 31)) return false;
+    q.m00 = m[0]; q.m01 = m[1]; q.m03 = m[3];
+    q.m10 = m[4]; q.m11 = m[5]; q.m13 = m[7];
+    q.xs = (int)m[11];
+    q.xsegs = (q.ox + 511) / 512;
+    q.mode = mode; q.npad = npad; q.cval = (float)cval;
+    const long long blocks = (long long)q.xsegs * ((q.oy + 3) / 4);
+    if (blocks > 0x7fffffffLL) return false;
+    note_kernel("mi::cubic3_rowblend_kernel grid=%lldx%d (order-3 affine on float32 coefficients, x axis to itself: 16 rows x two 16-byte loads per four voxels)", blocks, q.oz);
+    hipLaunchKernelGGL(cubic3_rowblend_kernel, dim3((unsigned)blocks, (unsigned)q.oz), dim3(64, 4), 0, s, (const float *)coef->data, (float *)out->data, q);
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) *rc = hip_fail(e2, "cubic3_rowblend_kernel");
+    return true;
+}
+
 // output geometry of the cubic kernel: the output's own shape, rank-padded with leading ones
 static bool cubic3_grid(const mi_array *out, InterpGeom *g, dim3 *grid)
 {
@@ -2452,6 +2600,7 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
         if (!diagonal) {
             int zrc = MI_OK;
             if (launch_cubic_zstream(coef, out, g, mode, cval, npad, s, &zrc)) return zrc;
+            if (launch_cubic_rowblend(coef, out, g, mode, cval, npad, s, &zrc)) return zrc;
         }
         note_kernel(diagonal ? "mi::cubic3_diag_f32_kernel (order-3 affine on float32 coefficients, diagonal matrix: tabulated taps)"
                              : "mi::cubic3_f32_kernel (order-3 affine on float32 coefficients: 16 x 16-byte gathers per voxel)");

@@ -1,5 +1,5 @@
 """Order-3 affine transforms of a 512^3 float32 volume whose matrix leaves axis 0 to itself (`rotate(volume, a, axes=(1, 2))`
-with scipy's default order): the z-streaming kernel (cubic3_zstream_kernel) against the gather kernel it replaces
+with scipy's default order) or the x axis (`rotate(volume, a)`, cubic3_rowblend_kernel, at the end): the z-streaming kernel (cubic3_zstream_kernel) against the gather kernel it replaces
 (cubic3_f32_kernel, debug knob 0), with and without the prefilter, per angle and for the boundary modes that pad the
 coefficient array.  One JSON line per case.  usage: python scripts/bench_cubic_affine.py [--quick]"""
 import os, sys, json
@@ -43,5 +43,23 @@ for mode in ("mirror", "nearest", "grid-wrap"):
         row["%s kernel" % name] = last_kernel()[4:26]
     lib.mi_debug_set_cubic_zstream(1)
     print(json.dumps(row), flush=True)
+# the x axis to itself: rotations in the (z, y) plane, SciPy's default axes for `rotate` (cubic3_rowblend_kernel)
+for deg in ((7.0,) if quick else (7.0, 30.0, 90.0)):
+    a = np.deg2rad(deg); M = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    off = ctr - M @ ctr
+    row = {"plane": "(z, y)", "deg": deg}
+    for knob, name in ((0, "gather"), (1, "default")):
+        lib.mi_debug_set_cubic_rowblend(knob)
+        s_, _ = timeit(lambda: ndi.affine_transform(xd, M, off, order=3, prefilter=False, output=out), 5)
+        row["%s us (prefilter=False)" % name] = round(s_ * 1e6, 1)
+        row["%s kernel" % name] = last_kernel()[4:26]
+        s_, _ = timeit(lambda: ndi.affine_transform(xd, M, off, order=3, output=out), 4)
+        row["%s us (with prefilter)" % name] = round(s_ * 1e6, 1)
+    lib.mi_debug_set_cubic_rowblend(1)
+    row["hbm roofline frac (prefilter=False)"] = round(2 * x.nbytes / 8e12 / (row["default us (prefilter=False)"] * 1e-6), 3)
+    print(json.dumps(row), flush=True)
+for mode in ("constant", "mirror", "nearest"):
+    s_, _ = timeit(lambda: ndi.rotate(xd, 7.0, reshape=False, mode=mode, output=out), 4)
+    print(json.dumps({"what": "rotate(volume, 7, reshape=False, mode=%r): SciPy's default axes (1, 0) and order 3" % mode, "us": round(s_ * 1e6, 1), "kernel": last_kernel()[4:26]}), flush=True)
 s_, _ = timeit(lambda: ndi.rotate(xd, 7.0, axes=(1, 2), reshape=False, output=out), 4)
 print(json.dumps({"what": "rotate(volume, 7, axes=(1, 2), reshape=False), scipy's default order 3", "us": round(s_ * 1e6, 1), "kernel": last_kernel()[4:26]}), flush=True)

@@ -1970,6 +1970,61 @@ def test_cubic_affine_zstream_in_plane(gpu, ndi):
     assert "cubic3_zstream_kernel" not in last_kernel()
 
 
+def test_cubic_affine_rowblend_default_rotate(gpu, ndi):
+    """r4b: order-3 affine transforms on float32 coefficients whose matrix leaves the x axis to itself (unit step, integral
+    shift) -- `rotate(volume, a)` with SciPy's DEFAULT axes and order -- blend sixteen input rows per output row at a
+    uniform row base (cubic3_rowblend_kernel).  Bit-identical to the gather kernel in every mode, for shifts along x of
+    both signs that push columns outside, rows longer than a wave's 512 voxels, output shapes that differ from the
+    input's; within float32 accuracy of SciPy; `rotate` with the defaults goes through it."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import _lib, last_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(777)
+    took = 0
+    for shape, oshape in (((40, 90, 152), None), ((33, 70, 132), (48, 75, 132)), ((20, 64, 64), (30, 100, 64)), ((30, 50, 1100), None), ((37, 81, 100), (41, 97, 100))):
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        osh = shape if oshape is None else oshape
+        for deg, sc, xs in ((7, 1.0, 0), (3, 1.1, 2), (-10, 0.95, -3), (45, 0.8, 0), (90, 1.0, 1), (170, 1.0, -60), (12, 1.0, 200)):
+            a = np.deg2rad(deg); c, s = np.cos(a), np.sin(a)
+            M = np.array([[c * sc, -s, 0], [s, c * sc, 0], [0, 0, 1.0]])
+            off = (np.array(shape) - 1) / 2 - M @ ((np.array(osh) - 1) / 2) + np.array([0.3, -1.7, 0.0])
+            off[2] = xs
+            for mode in ("constant", "nearest", "mirror", "reflect", "grid-wrap", "grid-constant", "wrap"):
+                kw = dict(output_shape=osh, order=3, mode=mode, cval=0.5)
+                lib.mi_debug_set_cubic_rowblend(0)
+                try:
+                    want = ndi.affine_transform(xd, M, off, **kw).get()
+                finally:
+                    lib.mi_debug_set_cubic_rowblend(1)
+                got = ndi.affine_transform(xd, M, off, **kw).get()
+                took += "cubic3_rowblend_kernel" in last_kernel()
+                assert np.array_equal(got, want, equal_nan=True), (shape, osh, deg, xs, mode, last_kernel()[:40], int(np.sum(got != want)))
+                if deg in (7, 170):
+                    ref = sndi.affine_transform(x.astype(np.float64), M, off, output_shape=osh, order=3, mode=mode, cval=0.5)
+                    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (shape, deg, mode)
+    assert took == 5 * 7 * 7, took
+    v = rng.standard_normal((48, 120, 96)).astype(np.float32)
+    v[7, 30, 40] = np.nan
+    vd = gpu.asarray(v)
+    got = ndi.rotate(vd, 17.0, reshape=False).get()
+    assert "cubic3_rowblend_kernel" in last_kernel()
+    lib.mi_debug_set_cubic_rowblend(0)
+    try:
+        want = ndi.rotate(vd, 17.0, reshape=False).get()
+    finally:
+        lib.mi_debug_set_cubic_rowblend(1)
+    assert np.array_equal(got, want, equal_nan=True)
+    v[7, 30, 40] = 0.25
+    ref = sndi.rotate(v.astype(np.float64), 17.0, reshape=False)
+    assert np.abs(ndi.rotate(gpu.asarray(v), 17.0, reshape=False).get() - ref).max() <= 2e-5 * np.abs(ref).max()
+    # a fractional shift along x, a non-unit x step and a matrix that mixes x in are not taken
+    M = np.array([[np.cos(0.2), -np.sin(0.2), 0], [np.sin(0.2), np.cos(0.2), 0], [0, 0, 1.0]])
+    for Mx, offx in ((M, 0.5), (M * np.array([1, 1, 1.01]), 0.0), (M + np.array([[0, 0, 0.01], [0, 0, 0], [0, 0, 0]]), 0.0)):
+        ndi.affine_transform(vd, Mx, np.array([1.0, -2.0, offx]), order=3, prefilter=False)
+        assert "cubic3_rowblend_kernel" not in last_kernel(), (Mx.tolist(), offx)
+
+
 def test_affine_rowblend_kernel(gpu, ndi):
     """Matrices that leave the x axis to itself with unit step and an integral shift (a rotation / shear / scaling in the
     (z, y) plane: `rotate(volume, angle)` with the default axes) blend four input ROWS per output row
