@@ -866,8 +866,13 @@ constexpr double kCzMinXStep = 0.09;    // |dx_in/dx_out| >= this x |dy_in/dx_ou
 constexpr int kCzSlot = 14336;          // the fixed slot size (44 rows): five of them + the tiles fit a CU twice, 4 x kCzSlot is an immediate offset
 
 struct CubZParams {
-    int nz, ny, nx;              // coefficient array (padded by npad on every axis)
+    // names as for SAX = 0 (the stream axis is z, a plane's rows run along y); for SAX = 1 `z` is the array's axis 1 and `y`
+    // its axis 0 -- lengths, strides (in elements) and matrix entries are filled in accordingly by the launch
+    int nz, ny, nx;              // coefficient array (padded by npad on every axis): stream axis, row axis, x
     int oz, oy, ox;
+    int ss, sr;                  // input strides of the stream axis and of the row axis
+    int oss, osr;                // the same of the output
+    int vol_bytes;
     double m00, m03, m11, m12, m13, m21, m22, m23;
     double cmin_y, cmin_x;       // minimum of cy / cx over a tile relative to its first voxel
     int ry, nchunks;             // rows of the staged rectangle, 16-byte chunks per plane (ry * 20)
@@ -898,6 +903,7 @@ __device__ __forceinline__ void cz_dma16(const __amdgpu_buffer_rsrc_t rsrc, unsi
 
 struct CzPlane { float w[4]; int off[4]; int pl[4]; bool outside, cvtap; };      // cvtap: the step takes cubic3_gather (a cval tap along z, or a slot clash)
 
+template <int SAX>
 __global__ void __launch_bounds__(kCzNT, 2)
 cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, const CubZParams q)
 {
@@ -913,9 +919,8 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
     const int tx_i = t % q.ntx, ty_i = (t / q.ntx) % q.nty, zc_i = t / (q.ntx * q.nty);
     const int x0 = tx_i * 64, y0 = ty_i * TY;
     const int zs = zc_i * q.zc, ze = min(zs + q.zc, q.oz);
-    const int nxy = q.ny * q.nx;
-    const int vol_bytes = q.nz * nxy * 4;
-    const unsigned plane_b = (unsigned)nxy * 4u, row_b = (unsigned)q.nx * 4u;
+    const int vol_bytes = q.vol_bytes;
+    const unsigned plane_b = (unsigned)q.ss * 4u, row_b = (unsigned)q.sr * 4u;
 
     // ---- rectangle origin: the first tap row / column of the tile's smallest coordinates (a hair below, one tap to the
     // left, + the padding of the coefficient array), clamped into the array, x aligned down to 16 bytes
@@ -939,7 +944,7 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
         rel[j] = ch < (unsigned)q.nchunks ? row * row_b + c4 * 16u : 0x80000000u;
         live[j] = __builtin_amdgcn_ballot_w64(ch < (unsigned)q.nchunks);
     }
-    const unsigned org_b = ((unsigned)by0 * (unsigned)q.nx + (unsigned)bx0) * 4u;
+    const unsigned org_b = ((unsigned)by0 * (unsigned)q.sr + (unsigned)bx0) * 4u;
 
     // ---- per voxel (row y0 + 8 wave + k, column x0 + lane), once: the in-plane taps.  a_[k] = row and column of the
     // start the four taps per axis are counted from, relative to the rectangle, + 8 each, row in the high half.  A voxel is
@@ -963,7 +968,7 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
         // cubic3_f32_kernel's order: s = 0; s += m[d][0] z; s += m[d][1] y; s += m[d][2] x; c = s + m[d][3] (m[d][0] = 0 here)
         double s1 = 0.0; s1 += q.m11 * o1; s1 += q.m12 * o2;
         double s2 = 0.0; s2 += q.m21 * o1; s2 += q.m22 * o2;
-        const bool oy_ = cubic3_axis_frac(q.ny, q.nx, s1 + q.m13, q.mode, q.npad, fy, offy);
+        const bool oy_ = cubic3_axis_frac(q.ny, q.sr, s1 + q.m13, q.mode, q.npad, fy, offy);
         const bool ox_ = cubic3_axis_frac(q.nx, 1, s2 + q.m23, q.mode, q.npad, fx, offx);
         return oy_ | ox_;
     };
@@ -977,8 +982,8 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
         const bool outside = inplane(k, fy, offy, fx, offx);
         bool block = offy[0] >= 0 && offx[0] >= 0;
 #pragma unroll
-        for (int j = 1; j < 4; j++) block = block && offy[j] == offy[0] + j * q.nx && offx[j] == offx[0] + j;
-        int r0 = offy[0] / q.nx - by0, c0 = offx[0] - bx0;
+        for (int j = 1; j < 4; j++) block = block && offy[j] == offy[0] + j * q.sr && offx[j] == offx[0] + j;
+        int r0 = offy[0] / q.sr - by0, c0 = offx[0] - bx0;
         const bool held = block && r0 >= 0 && r0 + 3 < q.ry && c0 >= 0 && c0 + 3 < P;
         bool edge = false;
         if (!held && !outside && rule != 3) {
@@ -989,10 +994,10 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (!fy_ && offy[j] >= 0) {
-                    const int s = offy[j] / q.nx - j;
+                    const int s = offy[j] / q.sr - j;
                     bool ok = true;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) ok = ok && offy[i] == czrule(s + i, q.ny) * q.nx;
+                    for (int i = 0; i < 4; i++) ok = ok && offy[i] == czrule(s + i, q.ny) * q.sr;
                     if (ok) { sy = s; fy_ = true; }
                 }
                 if (!fx_ && offx[j] >= 0) {
@@ -1052,13 +1057,13 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
         CzPlane p;
         double s0 = 0.0; s0 += q.m00 * (double)z;
         float w[4]; int off[4];
-        p.outside = cubic3_axis(q.nz, nxy, s0 + q.m03, q.mode, q.npad, w, off);
+        p.outside = cubic3_axis(q.nz, q.ss, s0 + q.m03, q.mode, q.npad, w, off);
         p.cvtap = false;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             p.w[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(w[k])));
             p.off[k] = __builtin_amdgcn_readfirstlane(off[k]);
-            p.pl[k] = p.off[k] < 0 ? -1 : p.off[k] / nxy;
+            p.pl[k] = p.off[k] < 0 ? -1 : p.off[k] / q.ss;
             p.cvtap = p.cvtap || p.off[k] < 0;
         }
         // two DIFFERENT planes of one step in the same ring slot (planes that wrap around the array, a multiple of five
@@ -1115,13 +1120,13 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
             const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
 #pragma unroll 1
             for (int k = 0; k < 8; k++) {
-                Cubic3 tt;
+                Cubic3 tt;                                         // [0]: the array's axis 0 = the stream axis (SAX 0) / the row axis (SAX 1)
                 float fy, fx;
-                const bool outside = inplane(k, fy, tt.off[1], fx, tt.off[2]);
-                cubic3_weights(fy, tt.w[1]);
+                const bool outside = inplane(k, fy, tt.off[1 - SAX], fx, tt.off[2]);
+                cubic3_weights(fy, tt.w[1 - SAX]);
                 cubic3_weights(fx, tt.w[2]);
 #pragma unroll
-                for (int j = 0; j < 4; j++) { tt.w[0][j] = cur.w[j]; tt.off[0][j] = cur.off[j]; }
+                for (int j = 0; j < 4; j++) { tt.w[SAX][j] = cur.w[j]; tt.off[SAX][j] = cur.off[j]; }
                 tt.ntap[0] = 4; tt.ntap[1] = 4;
                 tt.outside = outside;
                 emit(k, cubic3_gather<4, 4>(rin, tt, q.cval, q.mode));
@@ -1168,12 +1173,14 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
                             }
                         }
                     __builtin_amdgcn_sched_barrier(0);
+                    // cubic3_gather's order: the taps of the array's axis 0 outermost (its weight the first factor)
                     float acc = 0.f;
 #pragma unroll
-                    for (int kz = 0; kz < 4; kz++) {
+                    for (int ka = 0; ka < 4; ka++) {
 #pragma unroll
-                        for (int ky = 0; ky < 4; ky++) {
-                            const float wzy = cur.w[kz] * wy_[k][ky];
+                        for (int kb = 0; kb < 4; kb++) {
+                            const int kz = SAX == 0 ? ka : kb, ky = SAX == 0 ? kb : ka;
+                            const float wzy = SAX == 0 ? cur.w[kz] * wy_[k][ky] : wy_[k][ky] * cur.w[kz];
                             float row = v[kz][ky][0] * wx_[k][0];
                             row = fmaf(v[kz][ky][1], wx_[k][1], row);
                             row = fmaf(v[kz][ky][2], wx_[k][2], row);
@@ -1205,7 +1212,7 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
                 const float4 v = *reinterpret_cast<const float4 *>(tile + (4 * h + i) * 64 + 4 * c);
                 typedef float f32x4c __attribute__((ext_vector_type(4)));
                 const f32x4c vv = {v.x, v.y, v.z, v.w};
-                __builtin_nontemporal_store(vv, reinterpret_cast<f32x4c *>(out + ((size_t)z * q.oy + (y0 + 8 * wave + 4 * h + i)) * q.ox + x0 + 4 * c));
+                __builtin_nontemporal_store(vv, reinterpret_cast<f32x4c *>(out + ((size_t)z * q.oss + (size_t)(y0 + 8 * wave + 4 * h + i) * q.osr + x0 + 4 * c)));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
@@ -1215,7 +1222,7 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
             for (int k = 0; k < 8; k++) {
                 const int y = y0 + 8 * wave + k;
                 const float v = tile[k * 64 + lane];
-                if (x < q.ox && y < q.oy) __builtin_nontemporal_store(v, out + ((size_t)z * q.oy + y) * q.ox + x);
+                if (x < q.ox && y < q.oy) __builtin_nontemporal_store(v, out + ((size_t)z * q.oss + (size_t)y * q.osr + x));
             }
         }
         if (any_late) {
@@ -1242,19 +1249,28 @@ static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, cons
     if ((mode == MI_MODE_GRID_WRAP || mode == MI_MODE_GRID_CONSTANT) && !(g_cubic_zstream & 8)) return false;
     const double *m = g.mat;
     for (int i = 0; i < 12; i++) if (!(fabs(m[i]) < 1e9)) return false;
-    if (m[1] != 0.0 || m[2] != 0.0 || m[4] != 0.0 || m[8] != 0.0) return false;            // axis 0 decoupled
-    if (!(fabs(m[0]) <= 1.0)) return false;                                                  // five ring slots suffice
+    // the axis that streams: axis 0 when the matrix leaves it to itself (rotations in the (y, x) plane), else axis 1
+    // (rotations in the (z, x) plane)
+    int sax;
+    if (m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0) sax = 0;
+    else if (m[1] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[9] == 0.0) sax = 1;
+    else return false;
+    const int ra = 1 - sax;                                                                     // the axis a plane's rows run along
+    if (!(fabs(m[sax * 4 + sax]) <= 1.0)) return false;                                       // five ring slots suffice
+    CubZParams q;
+    q.nz = (int)g.shape[sax]; q.ny = (int)g.shape[ra]; q.nx = (int)g.shape[2];
+    q.oz = (int)g.oshape[sax]; q.oy = (int)g.oshape[ra]; q.ox = (int)g.oshape[2];
+    if ((int64_t)q.oz * q.oy * q.ox < (1 << 18) || q.ox < 64 || q.nx < 8 || ((uintptr_t)out->data & 15) || ((uintptr_t)coef->data & 15) || (q.nx & 3)) return false;
+    if ((int64_t)q.nz * q.ny * q.nx * 4 >= ((int64_t)1 << 31) || (int64_t)q.oz * q.oy * q.ox >= ((int64_t)1 << 31)) return false;
+    q.vol_bytes = q.nz * q.ny * q.nx * 4;
+    q.ss = sax == 0 ? q.ny * q.nx : q.nx; q.sr = sax == 0 ? q.nx : q.nz * q.nx;
+    q.oss = sax == 0 ? q.oy * q.ox : q.ox; q.osr = sax == 0 ? q.ox : q.oz * q.ox;
+    q.m00 = m[sax * 4 + sax]; q.m03 = m[sax * 4 + 3];
+    q.m11 = m[ra * 4 + ra]; q.m12 = m[ra * 4 + 2]; q.m13 = m[ra * 4 + 3];
+    q.m21 = m[8 + ra]; q.m22 = m[10]; q.m23 = m[11];
     // the lanes of a wave are neighbours along the output's x: their taps must be spread along the rows of the rectangle
     // rather than down its columns (row pitch 80 floats: sixteen banks apart, a 16-way conflict at 90 degrees)
-    if (!(g_cubic_zstream & 4) && !(fabs(m[10]) >= kCzMinXStep * fabs(m[6]))) return false;
-    CubZParams q;
-    q.nz = (int)g.shape[0]; q.ny = (int)g.shape[1]; q.nx = (int)g.shape[2];
-    q.oz = (int)g.oshape[0]; q.oy = (int)g.oshape[1]; q.ox = (int)g.oshape[2];
-    if ((int64_t)q.oz * q.oy * q.ox < (1 << 18) || q.ox < 64 || q.nx < 8 || ((uintptr_t)out->data & 15) || ((uintptr_t)coef->data & 15) || (q.nx & 3)) return false;
-    if ((int64_t)q.nz * q.ny * q.nx * 4 >= ((int64_t)1 << 31)) return false;
-    q.m00 = m[0]; q.m03 = m[3];
-    q.m11 = m[5]; q.m12 = m[6]; q.m13 = m[7];
-    q.m21 = m[9]; q.m22 = m[10]; q.m23 = m[11];
+    if (!(g_cubic_zstream & 4) && !(fabs(q.m22) >= kCzMinXStep * fabs(q.m12))) return false;
     const int T[2] = {kCzTY - 1, 63};
     const double ey = fabs(q.m11) * T[0] + fabs(q.m12) * T[1], ex = fabs(q.m21) * T[0] + fabs(q.m22) * T[1];
     if (!(ey < 4096.0 && ex < 4096.0)) return false;
@@ -1283,13 +1299,15 @@ static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, cons
     q.dbg = g_cubic_zstream;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e_ = hipFuncSetAttribute((const void *)cubic3_zstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        hipError_t e_ = hipFuncSetAttribute((const void *)cubic3_zstream_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        if (e_ == hipSuccess) e_ = hipFuncSetAttribute((const void *)cubic3_zstream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (e_ != hipSuccess) { *rc = hip_fail(e_, "hipFuncSetAttribute(cubic3_zstream_kernel)"); return true; }
         attr_done = true;
     }
-    note_kernel("mi::cubic3_zstream_kernel grid=%d (order-3 affine on float32 coefficients, axis 0 decoupled: streams along it, %d rows x %d staged per plane, %d chunks)",
-                tiles * q.nzc, q.ry, kCzP, q.nzc);
-    hipLaunchKernelGGL(cubic3_zstream_kernel, dim3((unsigned)(tiles * q.nzc)), dim3(kCzNT), lds, s, (const float *)coef->data, (float *)out->data, q);
+    note_kernel("mi::cubic3_zstream_kernel<%d> grid=%d (order-3 affine on float32 coefficients, axis %d decoupled: streams along it, %d rows x %d staged per plane, %d chunks)",
+                sax, tiles * q.nzc, sax, q.ry, kCzP, q.nzc);
+    if (sax == 0) hipLaunchKernelGGL(cubic3_zstream_kernel<0>, dim3((unsigned)(tiles * q.nzc)), dim3(kCzNT), lds, s, (const float *)coef->data, (float *)out->data, q);
+    else hipLaunchKernelGGL(cubic3_zstream_kernel<1>, dim3((unsigned)(tiles * q.nzc)), dim3(kCzNT), lds, s, (const float *)coef->data, (float *)out->data, q);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) *rc = hip_fail(e2, "cubic3_zstream_kernel");
     return true;

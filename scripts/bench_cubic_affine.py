@@ -43,6 +43,21 @@ for mode in ("mirror", "nearest", "grid-wrap"):
         row["%s kernel" % name] = last_kernel()[4:26]
     lib.mi_debug_set_cubic_zstream(1)
     print(json.dumps(row), flush=True)
+# axis 1 to itself: rotations in the (z, x) plane (cubic3_zstream_kernel<1>, streams along y)
+for deg in ((7.0,) if quick else (7.0, 30.0, 80.0)):
+    a = np.deg2rad(deg); M = np.array([[np.cos(a), 0, -np.sin(a)], [0, 1.0, 0], [np.sin(a), 0, np.cos(a)]])
+    off = ctr - M @ ctr
+    row = {"plane": "(z, x)", "deg": deg}
+    for knob, name in ((0, "gather"), (1, "default")):
+        lib.mi_debug_set_cubic_zstream(knob)
+        s_, _ = timeit(lambda: ndi.affine_transform(xd, M, off, order=3, prefilter=False, output=out), 5)
+        row["%s us (prefilter=False)" % name] = round(s_ * 1e6, 1)
+        row["%s kernel" % name] = last_kernel()[4:29]
+        s_, _ = timeit(lambda: ndi.affine_transform(xd, M, off, order=3, output=out), 4)
+        row["%s us (with prefilter)" % name] = round(s_ * 1e6, 1)
+    lib.mi_debug_set_cubic_zstream(1)
+    row["hbm roofline frac (prefilter=False)"] = round(2 * x.nbytes / 8e12 / (row["default us (prefilter=False)"] * 1e-6), 3)
+    print(json.dumps(row), flush=True)
 # the x axis to itself: rotations in the (z, y) plane, SciPy's default axes for `rotate` (cubic3_rowblend_kernel)
 for deg in ((7.0,) if quick else (7.0, 30.0, 90.0)):
     a = np.deg2rad(deg); M = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])

@@ -1,6 +1,6 @@
 """Differential fuzz of the z-streaming cubic affine kernel (cubic3_zstream_kernel) against the gather kernel it replaces:
-random volumes, random matrices that leave axis 0 to itself (rotation x shear x anisotropic scale x flips in the (y, x)
-plane, any step along z up to one plane), random offsets that push parts of the output outside, output shapes that differ
+random volumes, random matrices that leave axis 0 or axis 1 to itself (rotation x shear x anisotropic scale x flips in the
+(y, x) / (z, x) plane, any step along the free axis up to one plane), random offsets that push parts of the output outside, output shapes that differ
 from the input's, every boundary mode, prefilter on / off.  The two kernels must agree bit for bit; every 8th case is also
 checked against scipy in float64.  usage: python scripts/fuzz_cubic_zstream.py [cases] [seed]"""
 import os, sys
@@ -35,6 +35,8 @@ for i in range(cases):
         R[:, 1] *= -1
     M = np.eye(3); M[1:, 1:] = R
     M[0, 0] = rng.choice([1.0, -1.0, 0.5, rng.uniform(-1, 1)])
+    if rng.random() < 0.4:                       # the same in the (z, x) plane: axis 1 streams
+        Pm = np.array([[0, 1, 0], [1, 0, 0], [0, 0, 1.0]]); M = Pm @ M @ Pm
     off = (np.array(shape) - 1) / 2 - M @ ((np.array(osh) - 1) / 2) + rng.uniform(-6, 6, 3) * (rng.random() < 0.7)
     mode = MODES[int(rng.integers(len(MODES)))]
     kw = dict(output_shape=osh, order=3, mode=mode, cval=float(rng.uniform(-1, 1)), prefilter=bool(rng.random() < 0.6))

@@ -1912,9 +1912,12 @@ def test_cubic_affine_zstream_in_plane(gpu, ndi):
         osh = shape if oshape is None else oshape
         for deg, m00, sc in ((7, 1.0, 1.0), (3, 0.9, 1.1), (-10, -1.0, 0.95), (0, 0.5, 0.8), (12, 1.0, 1.0), (90, 1.0, 1.0), (180, 0.7, 1.0)):
             a = np.deg2rad(deg); c, s = np.cos(a), np.sin(a)
-            M = np.array([[m00, 0, 0], [0, c * sc, -s], [0, s, c * sc]])
-            off = (np.array(shape) - 1) / 2 - M @ ((np.array(osh) - 1) / 2) + np.array([0.3, -1.7, 2.2])
-            for mode in ("constant", "nearest", "mirror", "reflect", "grid-wrap", "grid-constant", "wrap"):
+            for M in (np.array([[m00, 0, 0], [0, c * sc, -s], [0, s, c * sc]]),              # in the (y, x) plane: axis 0 streams
+                      np.array([[c * sc, 0, -s], [0, m00, 0], [s, 0, c * sc]])):             # in the (z, x) plane: axis 1 streams
+              off = (np.array(shape) - 1) / 2 - M @ ((np.array(osh) - 1) / 2) + np.array([0.3, -1.7, 2.2])
+              for mode in ("constant", "nearest", "mirror", "reflect", "grid-wrap", "grid-constant", "wrap"):
+                if M[0, 2] != 0 and mode in ("reflect", "wrap") and deg not in (7, -10):
+                    continue
                 for prefilter in ((True, False) if mode in ("constant", "mirror") and deg == 7 else (True,)):
                     kw = dict(output_shape=osh, order=3, mode=mode, cval=0.5, prefilter=prefilter)
                     lib.mi_debug_set_cubic_zstream(0)
@@ -1932,19 +1935,21 @@ def test_cubic_affine_zstream_in_plane(gpu, ndi):
                     if prefilter:
                         ref = sndi.affine_transform(x.astype(np.float64), M, off, output_shape=osh, order=3, mode=mode, cval=0.5)
                         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (shape, deg, mode)
-    assert took >= 100, took
-    # every wave on the kernel's gather path (the debug value 3): the same bits again
+    assert took >= 250, took
+    # every wave on the kernel's gather path (the debug value 3): the same bits again, for both stream axes
     x = rng.standard_normal((40, 90, 152)).astype(np.float32); xd = gpu.asarray(x)
     a = np.deg2rad(21.0); M = np.array([[1.0, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
     off = np.array([0.0, 20.0, -14.0])
-    want = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
-    assert "cubic3_zstream_kernel" in last_kernel()
-    lib.mi_debug_set_cubic_zstream(3)
-    try:
-        got = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
-    finally:
-        lib.mi_debug_set_cubic_zstream(1)
-    assert np.array_equal(got, want)
+    for Mg, og, name in ((np.array([[np.cos(a), 0, -np.sin(a)], [0, 0.9, 0], [np.sin(a), 0, np.cos(a)]]), np.array([9.0, 2.0, -5.0]), "cubic3_zstream_kernel<1>"),
+                         (M, off, "cubic3_zstream_kernel<0>")):
+        want = ndi.affine_transform(xd, Mg, og, order=3, prefilter=False).get()
+        assert name in last_kernel(), last_kernel()
+        lib.mi_debug_set_cubic_zstream(3)
+        try:
+            got = ndi.affine_transform(xd, Mg, og, order=3, prefilter=False).get()
+        finally:
+            lib.mi_debug_set_cubic_zstream(1)
+        assert np.array_equal(got, want)
     # non-finite coefficients stay inside their 4 x 4 x 4 window in both kernels alike
     x[5, 40, 70] = np.inf; x[30, 10, 100] = np.nan
     xd = gpu.asarray(x)
