@@ -1445,7 +1445,9 @@ static bool launch_cubic_rowblend(const mi_array *coef, const mi_array *out, con
     CubRowParams q;
     q.nz = (int)g.shape[0]; q.ny = (int)g.shape[1]; q.nx = (int)g.shape[2];
     q.oz = (int)g.oshape[0]; q.oy = (int)g.oshape[1]; q.ox = (int)g.oshape[2];
-    if ((int64_t)q.oz * q.oy * q.ox < (1 << 16) || q.ox < 64 || (q.ox & 3) || q.nx < 8 || ((uintptr_t)out->data & 15) || q.oz > 65535) return false;
+    // (rows of any length: the 16-byte loads and stores are element-aligned only, the last ox % 4 voxels of a row take the
+    // per-voxel path)
+    if ((int64_t)q.oz * q.oy * q.ox < (1 << 16) || q.ox < 64 || q.nx < 8 || ((uintptr_t)out->data & 3) || q.oz > 65535) return false;
     if ((int64_t)q.nz * q.ny * q.nx * 4 >= ((int64_t)1 << 31)) return false;
     q.m00 = m[0]; q.m01 = m[1]; q.m03 = m[3];
     q.m10 = m[4]; q.m11 = m[5]; q.m13 = m[7];
