@@ -1535,6 +1535,12 @@ struct CoefLine {
     __device__ __forceinline__ Ref operator[](int64_t i) const { return Ref{p + i}; }
 };
 
+// one line of the prefilter: every pole's causal start, causal sweep, anti-causal start and sweep, on whatever memory the
+// accessors point at (the array itself, or a copy of the line in LDS: spline_filter_rows_lds_kernel)
+template <typename CF>
+__device__ __forceinline__ void spline_line_body(const CoefLine<CF> c, const CoefLine<CF> first, int64_t n, int64_t st, int order,
+                                                 int smode, int gain_first, const SplPow &pw);
+
 template <typename CF>
 __global__ void __launch_bounds__(64)
 spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_t n, int64_t inner, int64_t nlines, int order,
@@ -1546,7 +1552,14 @@ spline_filter1d_kernel(CF *__restrict__ data, const CF *__restrict__ src, int64_
     const CoefLine<CF> c{data + line_off};
     // out of place: the first pole's causal phase reads the source, everything else the coefficients
     const CoefLine<CF> first{src ? const_cast<CF *>(src) + line_off : data + line_off};
-    const int64_t st = inner;
+    spline_line_body<CF>(c, first, n, inner, order, smode, gain_first, pw);
+}
+
+// (defined below the kernel that was its only user until r4b; declared above it)
+template <typename CF>
+__device__ __forceinline__ void spline_line_body(const CoefLine<CF> c, const CoefLine<CF> first, int64_t n, int64_t st, int order,
+                                                 int smode, int gain_first, const SplPow &pw)
+{
     double zs[2];
     int np = 1;
     switch (order) {
@@ -1815,6 +1828,64 @@ spline_filter_rows_kernel(CF *__restrict__ data, int64_t n, int64_t nlines, int 
         }
         __threadfence();
     }
+}
+
+// r4b: contiguous lines that fit LDS WHOLE (twelve lines per wave, see the launch): the tiled kernel above moves every sample through memory twice per pole (causal sweep out, anti-causal sweep back
+// in: 0.94 ms per 512^3 pass against 0.41 ms for the strided axes); here a wave loads its lines once (LDS-DMA,
+// consecutive lines are consecutive in memory), lanes 0 .. lines-1 run spline_line_body -- the one-thread-per-line
+// kernel's own code, hence its exact results -- on the copy (row pitch n + 1: the lanes' samples in different banks), and
+// the wave stores the lines once.
+// one dword per lane from memory straight into LDS (M0 = LDS byte address of lane 0's dword); lanes outside `mask` idle
+__device__ __forceinline__ void spl_dma4(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_base, unsigned long long mask)
+{
+    unsigned keep;
+    unsigned long long keep_exec;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b64 %1, exec\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_mov_b64 exec, %6\n\t"
+        "buffer_load_dword %2, %3, %4 offen lds\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(keep_exec)
+        : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base), "s"(mask)
+        : "memory");
+}
+
+template <typename CF>
+__global__ void __launch_bounds__(64)
+spline_filter_rows_lds_kernel(CF *__restrict__ data, int n, int64_t nlines, int lpb, int order, int smode, int gain_first, SplPow pw)
+{
+    extern __shared__ __attribute__((aligned(16))) char spl_smem[];
+    CF *tile = reinterpret_cast<CF *>(spl_smem);
+    constexpr int DW = sizeof(CF) / 4;                  // dwords per coefficient
+    const int lane = threadIdx.x, pitch = n + 1;
+    const int64_t line0 = (int64_t)blockIdx.x * lpb;
+    const int nrows = __builtin_amdgcn_readfirstlane((int)((nlines - line0 < lpb) ? nlines - line0 : lpb));
+    CF *base = data + line0 * n;
+    // ---- in: LDS-DMA, one dword per lane and instruction, a row in pieces of 64 dwords -- every load of the block in flight
+    // at once, no registers involved (eight scalar loads per lane at a time made the load phase a chain of 32 round trips)
+    {
+        const int rowdw = n * DW;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, nrows * rowdw * 4, 0x00020000);
+        const int pieces = (rowdw + 63) / 64;
+        for (int r = 0; r < nrows; r++)
+            for (int j = 0; j < pieces; j++) {
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(64 * j + lane < rowdw);
+                spl_dma4(rsrc, (unsigned)lane * 4u, (unsigned)(r * rowdw + 64 * j) * 4u, (unsigned)(r * pitch * DW + 64 * j) * 4u, mask);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (lane < nrows) {
+        const CoefLine<CF> c{tile + lane * pitch};
+        spline_line_body<CF>(c, c, n, 1, order, smode, gain_first, pw);
+    }
+    __syncthreads();
+    // ---- out: coalesced rows
+    for (int r = 0; r < nrows; r++)
+        for (int x = lane; x < n; x += 64) base[(int64_t)r * n + x] = tile[r * pitch + x];
 }
 
 // ---------------------------------------------------------------------------
@@ -2118,6 +2189,8 @@ extern "C" int mi_debug_set_cubic_separable(int on) { g_cubic_separable_off = !o
 static mi::Knob g_cubic_diag_off{0};    // test hook: 1 = diagonal transforms use the gather kernel too
 extern "C" int mi_debug_set_cubic_diag(int on) { g_cubic_diag_off = !on; return MI_OK; }
 static mi::Knob g_spline_rows_force{0}; // test hook: 2 = tiled kernel whatever the line count
+static mi::Knob g_spline_rows_lds{1};   // test hook: 0 = never the LDS-resident lines kernel (the tiled kernel instead)
+extern "C" int mi_debug_set_spline_rows_lds(int on) { g_spline_rows_lds = on; return MI_OK; }
 extern "C" int mi_debug_set_spline_rows(int on) { g_spline_rows_off = on == 0; g_spline_rows_force = on == 2; return MI_OK; }
 extern "C" int mi_debug_set_interp_generic(int v) { g_interp_generic = v; return MI_OK; }
 
@@ -2342,6 +2415,33 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
         return MI_OK;
     }
     // enough lines to fill the chip with one wave per 64 lines; images with few, long lines keep one thread per line
+    if (src == dst && inner == 1 && n >= 2 * kSplTile && (nlines >= 16384 || g_spline_rows_force) && !g_spline_rows_off && g_spline_rows_lds) {
+        const size_t esz = shape->dtype == MI_F64 ? 8 : 4;
+        const size_t cap = 72 * 1024;                                   // two waves per CU
+        // lines per wave: TWELVE (512 float32 coefficients: 24 KiB, six waves per CU) -- the phases of a wave (loads in
+        // flight, a latency-bound recursion, stores) overlap with those of its neighbours on the CU, not with each other:
+        // 2.26 / 2.22 / 2.31 / 2.36 / 2.29 / 2.42 ms for a default `rotate` of 512^3 at 8 / 12 / 16 / 20 / 24 / 32 lines,
+        // 2.65 ms with the tiled kernel (profiles/r4_cubic_zstream.txt)
+        int lpb = (int)std::min<size_t>(12, cap / ((size_t)(n + 1) * esz));
+        if (lpb < 4) lpb = 0;
+        if (g_spline_rows_lds >= 4 && g_spline_rows_lds <= 64 && (size_t)g_spline_rows_lds * (size_t)(n + 1) * esz <= cap) lpb = g_spline_rows_lds;
+        if (lpb && n < (1 << 20)) {
+            const size_t lds = (size_t)lpb * (size_t)(n + 1) * esz;
+            static bool attr_done = false;
+            if (!attr_done) {
+                MI_HIP(hipFuncSetAttribute((const void *)spline_filter_rows_lds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap));
+                MI_HIP(hipFuncSetAttribute((const void *)spline_filter_rows_lds_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap));
+                attr_done = true;
+            }
+            const dim3 grid((unsigned)((nlines + lpb - 1) / lpb));
+            if (shape->dtype == MI_F64)
+                hipLaunchKernelGGL(spline_filter_rows_lds_kernel<double>, grid, dim3(64), lds, s, (double *)dst, (int)n, nlines, lpb, order, spline_mode, g_spline_gain_first, pw);
+            else
+                hipLaunchKernelGGL(spline_filter_rows_lds_kernel<float>, grid, dim3(64), lds, s, (float *)dst, (int)n, nlines, lpb, order, spline_mode, g_spline_gain_first, pw);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        }
+    }
     if (src == dst && inner == 1 && n >= 2 * kSplTile && (nlines >= 16384 || g_spline_rows_force) && !g_spline_rows_off && rows_ok) {
         const dim3 grid((unsigned)((nlines + kSplTile - 1) / kSplTile));
         if (shape->dtype == MI_F64)

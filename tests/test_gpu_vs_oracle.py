@@ -942,34 +942,43 @@ def test_float32_cubic_route_matches_scipy(gpu, ndi):
 
 
 def test_spline_prefilter_contiguous_lines_kernel(gpu, ndi):
-    """Lines along the last axis go through the LDS-tiled kernel (>= 128 samples): same results as
-    the one-thread-per-line kernel and as SciPy, every order and boundary rule, ragged sizes."""
+    """Lines along the last axis (>= 128 samples) go through the kernel that holds whole lines in LDS (r4b: twelve per
+    wave, the one-thread-per-line kernel's own code on the copy -- bit-identical to it) or, when they do not fit / with
+    the debug knob at 0, the LDS-tiled kernel: same results as the one-thread-per-line kernel and as SciPy, every order and
+    boundary rule, ragged sizes, float64 and float32 coefficients, other line counts per wave."""
     import ctypes
     import scipy.ndimage as sndi
     from cupyimg_amd import _lib
     hook = _lib.load().mi_debug_set_spline_rows
     hook.argtypes = [ctypes.c_int]
+    lds_hook = _lib.load().mi_debug_set_spline_rows_lds
     rng = np.random.default_rng(171)
-    hook(2)         # the kernel is normally chosen for >= 16384 lines; force it for the small cases
+    hook(2)         # the kernels are normally chosen for >= 16384 lines; force them for the small cases
     try:
-        for shape in [(70, 130), (3, 5, 257), (129,), (64, 128)]:
-            x = rng.standard_normal(shape)
-            for order in (2, 3, 4, 5):
-                for mode in ("mirror", "reflect", "grid-wrap", "nearest", "constant", "wrap"):
-                    want = sndi.spline_filter1d(x, order, axis=-1, mode=mode)
-                    got = ndi.spline_filter1d(gpu.asarray(x), order, axis=-1, mode=mode).get()
-                    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12, err_msg=str((shape, order, mode)))
-                    hook(0)
-                    old = ndi.spline_filter1d(gpu.asarray(x), order, axis=-1, mode=mode).get()
-                    hook(2)
-                    np.testing.assert_allclose(got, old, rtol=1e-14, atol=1e-14, err_msg=str((shape, order, mode)))
-            xf = x.astype(np.float32)
-            got = ndi.spline_filter(gpu.asarray(xf), 3, output=np.float32, allow_float32=True)
-            assert got.dtype == np.float32
-            np.testing.assert_allclose(got.get(), sndi.spline_filter(xf.astype(np.float64), 3), rtol=0,
-                                       atol=2e-6 * np.abs(xf).max())
+        for lds in (0, 1, 5, 64):
+            lds_hook(lds)
+            for shape in [(70, 130), (3, 5, 257), (129,), (64, 128)]:
+                x = rng.standard_normal(shape)
+                for order in (2, 3, 4, 5):
+                    for mode in ("mirror", "reflect", "grid-wrap", "nearest", "constant", "wrap"):
+                        want = sndi.spline_filter1d(x, order, axis=-1, mode=mode)
+                        got = ndi.spline_filter1d(gpu.asarray(x), order, axis=-1, mode=mode).get()
+                        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12, err_msg=str((shape, order, mode)))
+                        hook(0)
+                        old = ndi.spline_filter1d(gpu.asarray(x), order, axis=-1, mode=mode).get()
+                        hook(2)
+                        if lds:
+                            assert np.array_equal(got, old), (lds, shape, order, mode)
+                        else:
+                            np.testing.assert_allclose(got, old, rtol=1e-14, atol=1e-14, err_msg=str((shape, order, mode)))
+                xf = x.astype(np.float32)
+                got = ndi.spline_filter(gpu.asarray(xf), 3, output=np.float32, allow_float32=True)
+                assert got.dtype == np.float32
+                np.testing.assert_allclose(got.get(), sndi.spline_filter(xf.astype(np.float64), 3), rtol=0,
+                                           atol=2e-6 * np.abs(xf).max())
     finally:
         hook(1)
+        lds_hook(1)
     # the default choice on a volume with many lines
     v = rng.standard_normal((130, 130, 140)).astype(np.float32)
     got = ndi.spline_filter(gpu.asarray(v), 3, output=np.float64)
