@@ -16,6 +16,14 @@ rng = np.random.default_rng(0)
 n = 512
 x = rng.standard_normal((n,) * 3).astype(np.float32); xd = ca.asarray(x); out = ca.empty(x.shape, np.float32)
 quick = "--quick" in sys.argv
+if "--counters" in sys.argv:
+    # for scripts/pmc_configs.sh: the default kernels only, 7 degrees in each of the three planes, with the prefilter
+    ctr = np.array([(n - 1) / 2] * 3); a = np.deg2rad(7.0); c, s = np.cos(a), np.sin(a)
+    for M in (np.array([[1.0, 0, 0], [0, c, -s], [0, s, c]]), np.array([[c, 0, -s], [0, 1.0, 0], [s, 0, c]]), np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])):
+        for _ in range(6):
+            ndi.affine_transform(xd, M, ctr - M @ ctr, order=3, output=out)
+    out.get()
+    sys.exit(0)
 angles = (7.0, 30.0) if quick else (0.5, 2.0, 4.0, 7.0, 10.0, 15.0, 30.0, 45.0, 60.0, 75.0, 80.0, 85.0, 88.0, 90.0, 135.0, 180.0, 187.0)
 for deg in angles:
     a = np.deg2rad(deg); M = np.array([[1.0, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])

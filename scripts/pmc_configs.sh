@@ -9,11 +9,12 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-ARGS="--no-parity --reps 6 $@"
-timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -d $O/pmc1 -o s -- python3 $R/scripts/bench_configs.py $ARGS > /dev/null 2>&1
-timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM -d $O/pmc2 -o s -- python3 $R/scripts/bench_configs.py $ARGS > /dev/null 2>&1
-timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc3 -o s -- python3 $R/scripts/bench_configs.py $ARGS > /dev/null 2>&1
-timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc4 -o s -- python3 $R/scripts/bench_configs.py $ARGS > /dev/null 2>&1
+PROG=${PMC_PROG:-scripts/bench_configs.py}              # PMC_PROG=scripts/bench_cubic_affine.py PMC_ARGS=--counters: another program
+ARGS=${PMC_ARGS:-"--no-parity --reps 6 $@"}
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -d $O/pmc1 -o s -- python3 $R/$PROG $ARGS > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM -d $O/pmc2 -o s -- python3 $R/$PROG $ARGS > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc3 -o s -- python3 $R/$PROG $ARGS > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc4 -o s -- python3 $R/$PROG $ARGS > /dev/null 2>&1
 cd $O && python3 - <<'PY' | tee counters.txt
 import csv, glob, collections
 rows = collections.OrderedDict()
