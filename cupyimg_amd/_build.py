@@ -18,6 +18,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmi355img.so")
+# the same library with every hand-counted `s_waitcnt vmcnt(n)` turned into vmcnt(0) (csrc/common.hpp MI_VMCNT): a TEST
+# artefact -- tests/test_gpu_burst.py compares the two under load, bit for bit; nothing in the product loads it
+LIB_STRICT = os.path.join(HERE, "libmi355img_strict.so")
+STRICT_SOURCES = ("sep3d_long.hip", "minmax3d_f32.hip", "interp_fast.hip", "interp.hip")     # the files that use MI_VMCNT
 ARCH = "gfx950"
 
 # (source, extra flags).  The generic kernels are built without FMA contraction
@@ -52,6 +56,7 @@ SOURCES = [
     ("binary3d.hip", []),
     ("interp.hip", ["-ffp-contract=off"]),
     ("interp_fast.hip", ["-ffp-contract=off"]),
+    ("spline_fast.hip", []),
     ("halo.hip", []),
     ("metrics.hip", ["-ffp-contract=off"]),
 ]
@@ -110,9 +115,12 @@ def _flag_stamp(flags):
 
 
 def _compile(args):
-    src, flags, force, hdr_mtime = args
+    src, flags, force, hdr_mtime = args[:4]
+    strict = len(args) > 4 and args[4]
     s = os.path.join(CSRC, src)
-    o = os.path.join(OBJ, src.replace(".hip", ".o"))
+    o = os.path.join(OBJ, src.replace(".hip", ".strict.o" if strict else ".o"))
+    if strict:
+        flags = list(flags) + ["-DMI_STRICT_WAITS"]
     d = o + ".d"
     stamp_file = o + ".flags"
     stamp = _flag_stamp(flags)
@@ -260,32 +268,35 @@ def _scratch_users(obj, fragment):
     return bad
 
 
-def build(force=False, jobs=None, verbose=True):
+def build(force=False, jobs=None, verbose=True, strict=False):
     """Compile and link under an exclusive file lock: N ranks importing the
     package at once (torchrun) build once, the others wait and find the library
     up to date.  The link goes to a temporary name and is moved into place, so a
-    concurrent dlopen never sees a half-written file."""
+    concurrent dlopen never sees a half-written file.  strict=True builds
+    LIB_STRICT (the vmcnt(0) twin, a test artefact) from the same objects
+    except the STRICT_SOURCES, which are compiled again with -DMI_STRICT_WAITS."""
     import fcntl
     os.makedirs(OBJ, exist_ok=True)
     with open(os.path.join(OBJ, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            return _build_locked(force, jobs, verbose)
+            return _build_locked(force, jobs, verbose, strict)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(force, jobs, verbose):
+def _build_locked(force, jobs, verbose, strict=False):
     present = [(s, f) for s, f in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     missing = [s for s, _ in SOURCES if not os.path.exists(os.path.join(CSRC, s))]
     if missing:
         raise RuntimeError("missing kernel sources: {}".format(missing))
     hdr = _deps_mtime()
     jobs = jobs or min(8, os.cpu_count() or 1)
+    LIB = LIB_STRICT if strict else globals()["LIB"]
     with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
-        results = list(ex.map(_compile, [(s, f, force, hdr) for s, f in present]))
+        results = list(ex.map(_compile, [(s, f, force, hdr, strict and s in STRICT_SOURCES) for s, f in present]))
     objs = [o for o, _ in results]
-    rebuilt = any(r for _, r in results)
+    rebuilt = any(r for _, r in results) or (os.path.exists(LIB) and any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs))
     if rebuilt or not os.path.exists(LIB):
         tmp = "{}.{}.tmp".format(LIB, os.getpid())
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs + [
@@ -307,5 +318,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--strict", action="store_true", help="build libmi355img_strict.so (every counted wait = vmcnt(0)) too")
     a = ap.parse_args()
     build(force=a.force, jobs=a.jobs)
+    if a.strict:
+        build(force=a.force, jobs=a.jobs, strict=True)

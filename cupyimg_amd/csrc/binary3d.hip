@@ -270,7 +270,7 @@ static int launch_binary3(const unsigned char *in, unsigned char *out, const uns
                           int32_t *changed, hipStream_t s)
 {
     const size_t lds = (size_t)(p.wz + 1) * (kBnTY + p.wy - 1) * bn_pitch(ND);
-    static bool attr = false;
+    static PerDeviceOnce attr;
     if (!attr) {
         MI_HIP(hipFuncSetAttribute((const void *)binary3_tiled_kernel<WX, HAS_MASK, ND>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));

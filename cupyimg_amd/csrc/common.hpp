@@ -34,6 +34,19 @@ int hip_fail(hipError_t e, const char *what);
         }                                \
     } while (0)
 
+// ------------------------------------------------------------------ hand-counted waits
+// Every `s_waitcnt vmcnt(n)` with n > 0 in this tree is written MI_VMCNT(n): the kernel leaves n younger vector-memory
+// operations (LDS-DMA of the plane after next, the stores of the previous step) in flight across the wait.  A count that
+// is too generous by one is a timing race no single launch on an idle GPU shows (round 4: affine3d_zstream_kernel).  The
+// STRICT build (`python -m cupyimg_amd._build --strict` -> libmi355img_strict.so, -DMI_STRICT_WAITS on the files that
+// count) turns every one of them into vmcnt(0); tests/test_gpu_burst.py runs both libraries under back-to-back load and
+// requires bit-identical outputs -- one test for the whole class of kernels.
+#ifdef MI_STRICT_WAITS
+#define MI_VMCNT(n) "s_waitcnt vmcnt(0)"
+#else
+#define MI_VMCNT(n) "s_waitcnt vmcnt(" #n ")"
+#endif
+
 // ------------------------------------------------------------------ test / tuning knobs
 // Process-wide switches behind the mi_debug_set_* entry points (include/mi355img_debug.h): relaxed atomics, so a
 // thread flipping one while other threads dispatch is a benign race (each call reads a knob once and sees either
@@ -48,6 +61,19 @@ struct Knob {
 // ------------------------------------------------------------------ runtime hooks
 hipStream_t resolve_stream(mi_stream s);   // NULL -> per-device default stream
 int device_cus();                          // compute units of the CURRENT device (cached per device, thread safe)
+int current_device_slot();                 // hipGetDevice() folded into 0 .. 63 (0 when it cannot be asked)
+
+// "done once" flag of something that is PER DEVICE -- hipFuncSetAttribute(MaxDynamicSharedMemorySize) above all: a process
+// that drives a second device must set it there too (r4 advisor finding: one process-wide `static bool` left the second
+// device launching 96-159 KiB of dynamic LDS without the attribute), and two host threads may ask at once (relaxed
+// atomics: every writer stores the same value; the attribute call itself is idempotent).
+struct PerDeviceOnce {
+    std::atomic<bool> done[64] = {};
+    bool get() const { return done[current_device_slot()].load(std::memory_order_relaxed); }
+    void set() { done[current_device_slot()].store(true, std::memory_order_relaxed); }
+    explicit operator bool() const { return get(); }
+    PerDeviceOnce &operator=(bool v) { done[current_device_slot()].store(v, std::memory_order_relaxed); return *this; }
+};
 // block for work on `stream` (NULL = the default stream); pool_free returns it to that stream's arena
 int pool_alloc(void **p, size_t n, hipStream_t stream);
 int pool_free(void *p);

@@ -28,6 +28,17 @@ static int nccl_fail(ncclResult_t r, const char *what)
         if (r__ != ncclSuccess) return mi::nccl_fail(r__, #call); \
     } while (0)
 
+// inside ncclGroupStart / ncclGroupEnd: a failing call must not leave the thread's group open (every later RCCL call of
+// the thread would be deferred silently) -- close it, ignore what the close says, report the first error
+#define MI_NCCL_IN_GROUP(call)                                    \
+    do {                                                          \
+        ncclResult_t r__ = (call);                                \
+        if (r__ != ncclSuccess) {                                 \
+            (void)ncclGroupEnd();                                 \
+            return mi::nccl_fail(r__, #call);                     \
+        }                                                         \
+    } while (0)
+
 using namespace mi;
 
 extern "C" {
@@ -79,13 +90,13 @@ int mi_halo_exchange(mi_comm comm, void *slab, size_t plane_bytes, int64_t n_loc
     // next), then everything flowing "upwards".
     MI_NCCL(ncclGroupStart());
     if (hi > 0) {
-        if (prev_rank >= 0) MI_NCCL(ncclSend(local0, (size_t)hi * plane_bytes, ncclUint8, prev_rank, c, s));
-        if (next_rank >= 0) MI_NCCL(ncclRecv(local_end, (size_t)hi * plane_bytes, ncclUint8, next_rank, c, s));
+        if (prev_rank >= 0) MI_NCCL_IN_GROUP(ncclSend(local0, (size_t)hi * plane_bytes, ncclUint8, prev_rank, c, s));
+        if (next_rank >= 0) MI_NCCL_IN_GROUP(ncclRecv(local_end, (size_t)hi * plane_bytes, ncclUint8, next_rank, c, s));
     }
     if (lo > 0) {
-        if (next_rank >= 0) MI_NCCL(ncclSend(local_end - (size_t)lo * plane_bytes, (size_t)lo * plane_bytes,
-                                             ncclUint8, next_rank, c, s));
-        if (prev_rank >= 0) MI_NCCL(ncclRecv(base, (size_t)lo * plane_bytes, ncclUint8, prev_rank, c, s));
+        if (next_rank >= 0) MI_NCCL_IN_GROUP(ncclSend(local_end - (size_t)lo * plane_bytes, (size_t)lo * plane_bytes,
+                                                      ncclUint8, next_rank, c, s));
+        if (prev_rank >= 0) MI_NCCL_IN_GROUP(ncclRecv(base, (size_t)lo * plane_bytes, ncclUint8, prev_rank, c, s));
     }
     MI_NCCL(ncclGroupEnd());
     return MI_OK;
@@ -100,8 +111,8 @@ int mi_comm_sendrecv(mi_comm comm, int n, void *const ptrs[], const size_t nbyte
     MI_NCCL(ncclGroupStart());
     for (int i = 0; i < n; i++) {
         if (nbytes[i] == 0) continue;
-        if (is_send[i]) MI_NCCL(ncclSend(ptrs[i], nbytes[i], ncclUint8, peers[i], c, s));
-        else MI_NCCL(ncclRecv(ptrs[i], nbytes[i], ncclUint8, peers[i], c, s));
+        if (is_send[i]) MI_NCCL_IN_GROUP(ncclSend(ptrs[i], nbytes[i], ncclUint8, peers[i], c, s));
+        else MI_NCCL_IN_GROUP(ncclRecv(ptrs[i], nbytes[i], ncclUint8, peers[i], c, s));
     }
     MI_NCCL(ncclGroupEnd());
     return MI_OK;
@@ -240,6 +251,8 @@ struct SlabPipe {
     int graph_state = 0;                        // 0 = not tried, 1 = usable, -1 = capture failed (direct queuing instead)
     bool capturing = false;
     bool captured_submit[kPipeMaxBuf] = {};     // during a capture: the buffer's exchange is part of the graph
+    bool needs_join = false;                    // an exchange was queued DIRECTLY on the comm stream since the last replay: the next
+                                                // replay must first wait for it on `s` (the graph's own edges start at its own nodes)
 };
 
 static int pipe_submit(SlabPipe *p, int k)
@@ -257,6 +270,7 @@ static int pipe_submit(SlabPipe *p, int k)
     MI_HIP(hipEventRecord(p->halos_ready[k], p->cs));
     p->submitted[k] = true;
     p->captured_submit[k] = p->capturing;
+    if (!p->capturing) p->needs_join = true;
     return MI_OK;
 }
 
@@ -399,19 +413,23 @@ int mi_slab_pipe_create(mi_slab_pipe *pipe, mi_comm comm, int nbuf, const mi_arr
     if (!p->planes_ok && (rc = mi_separable3d_f32_supports(&p->in[0], &p->out, p->wp, p->wlen, p->origin, p->mode, cval, 0))) return rc;
     p->s = resolve_stream(stream);
     // the exchange kernels are small and have a step of slack: a high-priority queue lets them take the first CU a
-    // retiring filter workgroup frees instead of queuing behind the next filter launch
-    {
-        // the exchange kernels are small and have a step of slack: a high-priority queue lets them take the first CU
-        // a retiring filter workgroup frees instead of queuing behind the next filter launch
+    // retiring filter workgroup frees instead of queuing behind the next filter launch.  From here on the struct owns HIP
+    // objects: a failure goes through mi_slab_pipe_destroy (which skips what was never created).
+    SlabPipe *raw = p.release();
+    raw->s = nullptr;                       // destroy() synchronises the streams it finds: not the caller's on a failed create
+    auto made = [&]() -> int {
         int pri_lo = 0, pri_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&pri_lo, &pri_hi);
-        MI_HIP(hipStreamCreateWithPriority(&p->cs, hipStreamNonBlocking, g_pipe_normal_priority ? pri_lo : pri_hi));
-    }
-    for (int k = 0; k < nbuf; k++) {
-        MI_HIP(hipEventCreateWithFlags(&p->input_final[k], hipEventDisableTiming));
-        MI_HIP(hipEventCreateWithFlags(&p->halos_ready[k], hipEventDisableTiming));
-    }
-    *pipe = (mi_slab_pipe)p.release();
+        MI_HIP(hipStreamCreateWithPriority(&raw->cs, hipStreamNonBlocking, g_pipe_normal_priority ? pri_lo : pri_hi));
+        for (int k = 0; k < nbuf; k++) {
+            MI_HIP(hipEventCreateWithFlags(&raw->input_final[k], hipEventDisableTiming));
+            MI_HIP(hipEventCreateWithFlags(&raw->halos_ready[k], hipEventDisableTiming));
+        }
+        return MI_OK;
+    }();
+    if (made != MI_OK) { (void)mi_slab_pipe_destroy((mi_slab_pipe)raw); return made; }
+    raw->s = resolve_stream(stream);
+    *pipe = (mi_slab_pipe)raw;
     return MI_OK;
 }
 
@@ -456,8 +474,21 @@ int mi_slab_pipe_run(mi_slab_pipe pipe, int nsteps, int use_graph)
             done++;
         }
         if (nsteps - done >= per) {
-            if (p->graph_state == 0 || p->graph_steps != per) p->graph_state = pipe_capture(p, per) == MI_OK ? 1 : -1;
+            // The streaming multi-pass path (kernels that take no plane ranges: 19 .. 33 taps) draws whole-volume scratch
+            // from the pool inside the call and returns it right after queuing: a graph would keep those addresses in its
+            // kernel nodes while the pool hands the blocks to someone else.  Never captured (r4 advisor finding).
+            if (!p->planes_ok) p->graph_state = -1;
+            else if (p->graph_state == 0 || p->graph_steps != per) p->graph_state = pipe_capture(p, per) == MI_OK ? 1 : -1;
             while (p->graph_state == 1 && nsteps - done >= per) {
+                // A replay's first filter node reads a buffer whose exchange was queued BEFORE the graph.  After a replay the
+                // comm stream has been joined inside the graph; after directly queued steps (the first rotation, a tail of a
+                // previous run, mi_slab_pipe_step) nothing on `s` waits for the exchanges still in flight on the comm stream,
+                // and the graph's own exchange node could run beside them on the same communicator: join first.  The comm
+                // stream is in order, so the exchange submitted last covers the earlier ones (r4 advisor finding).
+                if (p->needs_join && (p->prev >= 0 || p->next >= 0)) {
+                    MI_HIP(hipStreamWaitEvent(p->s, p->halos_ready[(p->next_submit - 1) % p->nbuf], 0));
+                }
+                p->needs_join = false;
                 MI_HIP(hipGraphLaunch(p->gexec, p->s));
                 p->next_submit += per;
                 p->next_compute += per;

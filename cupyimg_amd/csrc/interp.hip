@@ -861,6 +861,7 @@ cubic3_diag_f32_kernel(const float *__restrict__ in, float *__restrict__ out, co
 // cubic3_gather itself.
 // ---------------------------------------------------------------------------
 void note_kernel(const char *fmt, ...);        // runtime.hip (sep_common.hpp declares it for the filter sources)
+bool spline_pass_fast(const mi_array *shape, const void *src, int src_dtype, void *dst, int axis, int order, int spline_mode, hipStream_t s, int *rc);   // spline_fast.hip
 constexpr int kCzP = 80, kCzRoundsMax = 8, kCzSlots = 5, kCzTY = 32, kCzNT = 256;
 constexpr double kCzMinXStep = 0.09;    // |dx_in/dx_out| >= this x |dy_in/dx_out|: up to ~85 degrees (profiles/r4_cubic_zstream.txt: 3.4 ms against 4.1 ms there, 7.8 against 3.9 at 90)
 constexpr int kCzSlot = 14336;          // the fixed slot size (44 rows): five of them + the tiles fit a CU twice, 4 x kCzSlot is an immediate offset
@@ -1085,7 +1086,7 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
     for (int z = zs; z < ze; z++) {
         // the planes of this step have landed (the two stores of the previous step, issued after their DMAs, may still be in
         // flight on full tiles -- not in the first step, and not after a step that fetched late)
-        if (wide && z > zs && !drain) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (wide && z > zs && !drain) asm volatile(MI_VMCNT(2) ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         drain = false;
@@ -1256,7 +1257,10 @@ static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, cons
     else if (m[1] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[9] == 0.0) sax = 1;
     else return false;
     const int ra = 1 - sax;                                                                     // the axis a plane's rows run along
-    if (!(fabs(m[sax * 4 + sax]) <= 1.0)) return false;                                       // five ring slots suffice
+    // up to one plane per step the five ring slots hold the four planes of a step + the one the next needs; beyond that (the
+    // BASELINE matrix steps 1.02 planes) every 1 / (|m| - 1) steps need TWO new planes, the second of which lands on a slot the
+    // current step still reads: it is fetched late (after the step's reads, one more barrier, the next wait drains) -- r5
+    if (!(fabs(m[sax * 4 + sax]) <= 1.3)) return false;
     CubZParams q;
     q.nz = (int)g.shape[sax]; q.ny = (int)g.shape[ra]; q.nx = (int)g.shape[2];
     q.oz = (int)g.oshape[sax]; q.oy = (int)g.oshape[ra]; q.ox = (int)g.oshape[2];
@@ -1297,7 +1301,7 @@ static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, cons
     q.nzc = (q.oz + q.zc - 1) / q.zc;
     q.mode = mode; q.npad = npad; q.cval = (float)cval;
     q.dbg = g_cubic_zstream;
-    static bool attr_done = false;
+    static PerDeviceOnce attr_done;
     if (!attr_done) {
         hipError_t e_ = hipFuncSetAttribute((const void *)cubic3_zstream_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (e_ == hipSuccess) e_ = hipFuncSetAttribute((const void *)cubic3_zstream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -2353,6 +2357,12 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
 {
     const int64_t total = numel(shape);
     if (total == 0) return MI_OK;
+    // r5: volumes (many lines, single-pole orders, mirror / reflect ends, no bit-exactness request) at one memory sweep per
+    // axis -- csrc/spline_fast.hip; the blocked kernels below keep the images (few long lines)
+    if (spline_chunk_len(shape, axis, order, spline_mode) == 0) {
+        int frc;
+        if (spline_pass_fast(shape, src, shape->dtype, dst, axis, order, spline_mode, s, &frc)) return frc;
+    }
     int64_t inner = 1;
     for (int d = axis + 1; d < shape->ndim; d++) inner *= shape->shape[d];
     const int64_t n = shape->shape[axis], nlines = total / n;
@@ -2429,7 +2439,7 @@ static int spline_pass(const mi_array *shape, const void *src, void *dst, int ax
         if (g_spline_rows_lds >= 4 && g_spline_rows_lds <= 64 && (size_t)g_spline_rows_lds * (size_t)(n + 1) * esz <= cap) lpb = g_spline_rows_lds;
         if (lpb && n < (1 << 20)) {
             const size_t lds = (size_t)lpb * (size_t)(n + 1) * esz;
-            static bool attr_done = false;
+            static PerDeviceOnce attr_done;
             if (!attr_done) {
                 MI_HIP(hipFuncSetAttribute((const void *)spline_filter_rows_lds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap));
                 MI_HIP(hipFuncSetAttribute((const void *)spline_filter_rows_lds_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap));
@@ -2497,6 +2507,17 @@ int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int 
     const bool direct = npad == 0 && in->dtype == out->dtype && same_shape(in, out) && is_contiguous(in) && is_contiguous(out)
                         && first >= 0 && inner_first > 1;
     hipStream_t s = resolve_stream(stream);
+    // r5: float32 samples -> float64 coefficients (the public spline_filter's default output) without the conversion copy:
+    // the streaming kernel of the first axis reads the float32 input itself; the other axes follow in place
+    if (!direct && npad == 0 && in->dtype == MI_F32 && out->dtype == MI_F64 && same_shape(in, out) && is_contiguous(in) && is_contiguous(out)
+        && first >= 0 && inner_first > 1 && spline_chunk_len(out, first, order, spline_mode) == 0) {
+        int frc;
+        if (spline_pass_fast(out, in->data, MI_F32, out->data, first, order, spline_mode, s, &frc)) {
+            for (int d = first + 1; d < out->ndim && frc == MI_OK; d++)
+                if (out->shape[d] > 1) frc = spline_pass(out, out->data, out->data, d, order, spline_mode, s);
+            return frc;
+        }
+    }
     // Passes of the blocked kernel work out of place, the others in place: the data hops between `out` and one
     // temporary, laid out so that the last hop lands in `out` (K blocked passes: start in `out` when K is even).
     int nblocked = 0;

@@ -730,7 +730,7 @@ static int launch_affine_lds(const float *in, float *out, const LdsAffineParams 
     const dim3 gl((unsigned)((p.ox + TX - 1) / TX), (unsigned)((p.oy + TY - 1) / TY), gz);
     if (gl.y > 65535 || gl.z > 65535) return MI_ERR_UNSUPPORTED;
     const size_t lds = (((size_t)q.nchunks * 16 + 8191) & ~(size_t)8191) + kLdsTZ * TY * 3 * sizeof(double) + 8 * 256 * sizeof(float) + 2 * 4 * sizeof(int);
-    static bool attr_done = false;
+    static PerDeviceOnce attr_done;
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)affine3d_lds_kernel<TX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr_done = true;
@@ -1341,7 +1341,7 @@ affine3d_zrect_kernel(const float *__restrict__ in, float *__restrict__ out, con
         // (r4b: the FIRST step has no stores behind the prologue's DMAs -- vmcnt(2) there let the last two chunks of a
         // chunk's first plane be read before they had landed: a few wrong voxels in the first plane of a z chunk under
         // back-to-back launches, found by the whole-volume check of scripts/bench_configs.py)
-        if (wide && z > zs) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (wide && z > zs) asm volatile(MI_VMCNT(2) ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         ZSplit nxt = cur;
@@ -1550,7 +1550,7 @@ affine3d_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, c
         // chunk's first plane be read before they had landed: a few wrong voxels in the first plane of a z chunk under
         // back-to-back launches, found by the whole-volume check of scripts/bench_configs.py)
         // (a step that fetched planes LATE -- after its stores, see below -- is followed by a full drain as well)
-        if (wide && z > zs && !drain) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (wide && z > zs && !drain) asm volatile(MI_VMCNT(2) ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         drain = false;
@@ -1807,7 +1807,7 @@ static int launch_affine_zstream(const float *in, float *out, ZStreamParams &q, 
     nzc = std::max(1, std::min(nzc, (q.oS + 15) / 16));
     q.zc = (q.oS + nzc - 1) / nzc;
     q.nzc = (q.oS + q.zc - 1) / q.zc;
-    static bool attr_done = false;
+    static PerDeviceOnce attr_done;
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)affine3d_zrect_kernel<TY, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         MI_HIP(hipFuncSetAttribute((const void *)affine3d_zrect_kernel<TY, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1931,15 +1931,15 @@ template <int N> __device__ __forceinline__ void mz_wait_vm()
 {
     static_assert(N >= 0 && N <= 9, "s_waitcnt strings below");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile(MI_VMCNT(1) " lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile(MI_VMCNT(2) " lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile(MI_VMCNT(3) " lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile(MI_VMCNT(4) " lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile(MI_VMCNT(5) " lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile(MI_VMCNT(6) " lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 7) asm volatile(MI_VMCNT(7) " lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile(MI_VMCNT(8) " lgkmcnt(0)" ::: "memory");
+    else asm volatile(MI_VMCNT(9) " lgkmcnt(0)" ::: "memory");
 }
 #undef MI_MZ_COORD
 #undef MI_MZ_CORNER
@@ -2474,7 +2474,7 @@ static int launch_map_zstream_as(const float *in, const float *coords, float *ou
     using G = MzGeo<V>;
     size_t lds = 4 * (size_t)kMzSlotBytes + (size_t)G::NW * G::STG + (CORNER ? 0 : 64);
     if (g_affine_dbg & 32) lds = 96 * 1024;                 // occupancy experiment: one workgroup per CU
-    static bool attr_done = false;
+    static PerDeviceOnce attr_done;
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)map_coords3d_zstream_kernel<CORNER, V, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_done = true;

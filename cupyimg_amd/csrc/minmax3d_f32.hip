@@ -132,7 +132,7 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     issue(0, 0);
     issue(1, kPlane);
     issue(2, 2 * kPlane);
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    asm volatile(MI_VMCNT(8) "\n\ts_barrier" ::: "memory");
     if (wave == 15) {
         const float4 hv = ypass(hsrc);
         *reinterpret_cast<float4 *>(smem + HY0 + (unsigned)lane * 16u) = hv;
@@ -153,8 +153,8 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 // in flight: vmcnt(5) once stores have begun.  (r2 waited vmcnt(4) throughout, i.e. for the first DMA of
                 // the plane issued one step earlier: a prefetch distance of one plane, not two -- removing the DMAs
                 // altogether saved 86 us of 358 on config B, the waves were stalling on them.)
-                if (i >= W) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (i >= W) asm volatile(MI_VMCNT(5) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile(MI_VMCNT(4) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue(i + 3, b3);
                 const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
                 // ---- y window of output row `wave`, then its x window in registers
@@ -208,7 +208,7 @@ template <int W, bool IS_MAX>
 static int launch_mm_long(const float *in, float *out, MmLongParams &p, hipStream_t s)
 {
     const size_t lds = (size_t)kLongRawBytes + kLongHyBytes + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int);
-    static bool attr_done = false;
+    static PerDeviceOnce attr_done;
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)mm3f32_long_kernel<W, IS_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;

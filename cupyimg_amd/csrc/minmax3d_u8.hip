@@ -1344,7 +1344,7 @@ static int launch_u8_split(const uint8_t *in, uint8_t *out, U8FusedParams &p, bo
     constexpr int G = (TY + NWC - 1) / NWC;
     constexpr int LROWS = (NWC * G + W - 1) > NWP * R ? (NWC * G + W - 1) : NWP * R;
     const size_t lds = (size_t)2 * LROWS * 1024 + (size_t)(kU8MaxChunk + 8) * sizeof(int);
-    static bool attr_done = false;
+    static PerDeviceOnce attr_done;
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)mm3u8_split_kernel<W, IS_MAX, NWP, NWC, R, TY, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -56,6 +56,13 @@ hipStream_t resolve_stream(mi_stream s)
     return d;
 }
 
+int current_device_slot()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+    return dev & 63;
+}
+
 // Compute units of the current device.  One entry per device: a process may drive differently partitioned devices
 // (SPX / CPX), and several threads may ask at once (relaxed atomics: every writer stores the same value).
 int device_cus()

@@ -246,7 +246,7 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
     issue(0, 0);
     issue(1, kPlane);
     issue(2, 2 * kPlane);
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    asm volatile(MI_VMCNT(8) "\n\ts_barrier" ::: "memory");
     if (wave == 15) {
         const F4 hv = ypass(hsrc);
         *reinterpret_cast<float4 *>(smem + HY0 + (unsigned)lane * 16u) = f4_to_float4(hv);
@@ -270,8 +270,8 @@ sep3d_long_kernel(const float *__restrict__ in, float *__restrict__ out, const L
                 // in flight: vmcnt(5) once stores have begun.  (r2 waited vmcnt(4) throughout, i.e. for the first DMA of
                 // the plane issued one step earlier: a prefetch distance of one plane, not two -- removing the DMAs
                 // altogether saved 86 us of 358 on config B, the waves were stalling on them.)
-                if (i >= W && !(p.dbg & 16)) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (i >= W && !(p.dbg & 16)) asm volatile(MI_VMCNT(5) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile(MI_VMCNT(4) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue(i + 3, b3);
                 const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
                 // ---- y pass of output row `wave`, then its x pass in registers
@@ -479,7 +479,7 @@ sep3d_long2_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     issue(0, 0);
     issue(1, kPlane);
     issue(2, 2 * kPlane);
-    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    asm volatile(MI_VMCNT(16) "\n\ts_barrier" ::: "memory");
     if (wave == NW - 1) {
         const F4 hv = ypass(hsrc);
         *reinterpret_cast<float4 *>(smem + HY0 + (unsigned)lane * 16u) = f4_to_float4(hv);
@@ -496,8 +496,8 @@ sep3d_long2_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 const unsigned b3 = bi == 0u ? (kLongNB - 1) * kPlane : bi - kPlane;
                 // in flight, oldest first: 8 DMAs of plane i + 1, 2 stores, 8 DMAs of plane i + 2, 2 stores (see the
                 // one-row kernel): plane i + 1 must have landed, the rest stays in flight
-                if (i >= W && !(p.dbg & 16)) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (i >= W && !(p.dbg & 16)) asm volatile(MI_VMCNT(10) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile(MI_VMCNT(8) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue(i + 3, b3);
                 const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
                 F4 yv[2];
@@ -822,7 +822,7 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     issue(0, 0);
     issue(1, kPlane);
     issue(2, 2 * kPlane);
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    asm volatile(MI_VMCNT(8) "\n\ts_barrier" ::: "memory");
     F4 yv = ypass(own);
     if (wave == 15) {
         const F4 hv = ypass(hsrc);
@@ -847,8 +847,8 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 // of plane i + 2, the store of step i - 1 (a store is issued in EVERY step: before the first complete
                 // output it goes to a descriptor of zero records).  Plane i + 1 must have landed: vmcnt(5); step 0 has
                 // only the 8 DMAs of the prologue behind it: vmcnt(4).
-                if ((J == 0 && i0 == 0) || (dbg & 16)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if ((J == 0 && i0 == 0) || (dbg & 16)) asm volatile(MI_VMCNT(4) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile(MI_VMCNT(5) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
                 // ---- halo table of plane i + 1 (the wave changes every plane).  First thing in the step: its reads travel
                 // while the other waves of the SIMD have their whole step to issue.
@@ -1108,7 +1108,7 @@ sep3d_long4_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     issue(0, 0);
     issue(1, kPlane);
     issue(2, 2 * kPlane);
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    asm volatile(MI_VMCNT(8) "\n\ts_barrier" ::: "memory");
     yplane(0, 0);
 
     // Interval i (after barrier i): plane i + 1 has landed, Y(i) is complete (every wave waited for its LDS writes before
@@ -1126,8 +1126,8 @@ sep3d_long4_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 const unsigned b1 = bi == 2u * kPlane ? 0u : bi + kPlane;     // plane i + 1
                 // in flight from this wave, oldest first: the 4 DMAs of plane i + 1, the store of step i - 2, the 4 DMAs of
                 // plane i + 2, the store of step i - 1 (see sep3d_long3_kernel): plane i + 1 must have landed
-                if (J == 0 && i0 == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (J == 0 && i0 == 0) asm volatile(MI_VMCNT(4) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile(MI_VMCNT(5) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue(i + 3, bi);
                 // ---- x and z passes of plane i (VALU) and y pass of plane i + 1 (matrix cores): independent of each other.  The
                 // waves of a SIMD are w, w + 4, w + 8, w + 12: half of them take the matrix part first, half the vector part, so
@@ -1176,7 +1176,7 @@ static mi::Knob g_long_cfg{0};         // MI_LONG_TUNE builds: which tuning vari
 #endif
 
 template <typename K>
-static int long_launch_one(K kernel, bool &attr_done, size_t lds, int total, const float *in, float *out, const LongParams &p, hipStream_t s)
+static int long_launch_one(K kernel, PerDeviceOnce &attr_done, size_t lds, int total, const float *in, float *out, const LongParams &p, hipStream_t s)
 {
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1196,21 +1196,21 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
     if constexpr (HAS_CONST) {
         // constant mode keeps the r2 kernel: its correction terms (five more live registers) do not fit beside the r3
         // kernel's read groups without spilling, and a spill is a vector-memory operation the vmcnt arithmetic does not count
-        static bool attr_c = false;
+        static PerDeviceOnce attr_c;
         note_kernel("mi::sep3d_long_kernel<%d,%s,true> grid=%d (fused y/x/z separable pass, LDS-DMA staged, constant mode)", W,
                     SAME ? "true" : "false", total);
         return long_launch_one(sep3d_long_kernel<W, SAME, true>, attr_c, lds, total, in, out, p, s);
     } else {
         if constexpr (MI_LONG_OLD(W)) {
             if (g_long_rows == 1) {
-                static bool attr_old = false;
+                static PerDeviceOnce attr_old;
                 note_kernel("mi::sep3d_long_kernel<%d,%s,false> grid=%d (fused y/x/z separable pass, LDS-DMA staged, r2 instruction stream)", W,
                             SAME ? "true" : "false", total);
                 return long_launch_one(sep3d_long_kernel<W, SAME, false>, attr_old, lds, total, in, out, p, s);
             }
             // the ablation flags exist in these instances only
             if (p.dbg != 0 && g_long_rows != 4) {
-                static bool attr_dbg = false;
+                static PerDeviceOnce attr_dbg;
                 note_kernel("mi::sep3d_long3_kernel<%d,%s,true> grid=%d (ablation build, dbg=%d)", W, SAME ? "true" : "false", total, p.dbg);
                 return long_launch_one(sep3d_long3_kernel<W, SAME, true>, attr_dbg, lds, total, in, out, p, s);
             }
@@ -1218,7 +1218,7 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
 #ifdef MI_LONG_TUNE
         if constexpr (W == 17 && SAME) {
             if (g_long_rows == 2) {
-                static bool attr2 = false;
+                static PerDeviceOnce attr2;
                 if (!attr2) {
                     MI_HIP(hipFuncSetAttribute((const void *)sep3d_long2_kernel<17, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     attr2 = true;
@@ -1231,7 +1231,7 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
             const int cfg = g_long_cfg;
 #define MI_LONG_CFG(C)                                                                                           \
             if (cfg == (C)) {                                                                                    \
-                static bool attr_c = false;                                                                      \
+                static PerDeviceOnce attr_c;                                                                      \
                 note_kernel("mi::sep3d_long3_kernel<17,true,false,%d> grid=%d (tuning variant)", (C), total);    \
                 return long_launch_one(sep3d_long3_kernel<17, true, false, (C)>, attr_c, lds, total, in, out, p, s); \
             }
@@ -1241,20 +1241,20 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
 #endif
         if constexpr (W == 9 || W == 13 || W == 17) {
             if (g_long_rows == 4) {                 // not the default: 268 against 261 us on config B (fp32 MFMAs and the packed FMAs share one datapath)
-                static bool attr4 = false;
+                static PerDeviceOnce attr4;
                 const size_t lds4 = 3 * (size_t)kLongRowsMax * kLongRec + 2 * (size_t)kLongTY * kLongRec + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int);
                 note_kernel("mi::sep3d_long4_kernel<%d,%s> grid=%d (fused y/x/z separable pass, LDS-DMA staged, y pass on the matrix cores)", W,
                             SAME ? "true" : "false", total);
                 if constexpr (W == 17 && SAME) {
                     if (p.dbg != 0) {
-                        static bool attr4d = false;
+                        static PerDeviceOnce attr4d;
                         return long_launch_one(sep3d_long4_kernel<W, SAME, true>, attr4d, lds4, total, in, out, p, s);
                     }
                 }
                 return long_launch_one(sep3d_long4_kernel<W, SAME>, attr4, lds4, total, in, out, p, s);
             }
         }
-        static bool attr_done = false;
+        static PerDeviceOnce attr_done;
         note_kernel("mi::sep3d_long3_kernel<%d,%s> grid=%d (fused y/x/z separable pass, LDS-DMA staged, y pass one plane ahead)", W,
                     SAME ? "true" : "false", total);
         return long_launch_one(sep3d_long3_kernel<W, SAME, false>, attr_done, lds, total, in, out, p, s);
@@ -1359,7 +1359,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, i
 #define MI_LONG_ANISO(N, NZ)                                                                                         \
         if (w == (N) && wzn == (NZ)) {                                                                                \
             const size_t lds = (size_t)kLongRawBytes + kLongHyBytes + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int); \
-            static bool attr_a = false;                                                                              \
+            static PerDeviceOnce attr_a;                                                                              \
             note_kernel("mi::sep3d_long3_kernel<%d,false,false,0,%d> grid=%d (fused y/x/z separable pass, %d taps in the plane, %d along z)", \
                         (N), (NZ), p.nxt * p.nyt * p.nzc, (N), (NZ));                                                 \
             return long_launch_one(sep3d_long3_kernel<(N), false, false, 0, (NZ)>, attr_a, lds, p.nxt * p.nyt * p.nzc, in, out, p, s); \

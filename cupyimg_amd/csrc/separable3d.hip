@@ -300,7 +300,7 @@ template <int WX, int WZ, int NWP, int NWC, int R>
 static int launch_sep3d_ws(const float *in, float *out, const Sep3dParams &p, hipStream_t s)
 {
     const size_t lds = (size_t)2 * NWP * R * 64 * sizeof(float4) + (size_t)(kMaxChunk + kMaxTaps) * sizeof(int);
-    static bool attr_done = false;
+    static PerDeviceOnce attr_done;
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)sep3d_ws_kernel<WX, WZ, NWP, NWC, R>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -607,7 +607,7 @@ static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool h
     constexpr int G = (TY + NWC - 1) / NWC;
     constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
     const size_t lds = (size_t)2 * LROWS * 1024 + (size_t)(kMaxChunk + kMaxTaps) * sizeof(int);
-    static bool attr_done = false;
+    static PerDeviceOnce attr_done;
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -137,7 +137,7 @@ def _correlate_or_convolve(input, weights, output, mode, cval, origin, convoluti
         # 181 x 217 x 181 float32, 3 x 3 x 3 weights: 219 -> see DESIGN.md)
         left = weights.shape[2] // 2 + int(origins[2])
         res = _run_on_extended_rows(input, output, left, weights.shape[2] - 1 - left, mode, cval,
-                                    lambda e, o: (launch(e, o), o)[1])
+                                    lambda e, o: (launch(e, o), o)[1])        # (the launch raises or succeeds: nothing to remember)
         if res is not None:
             return res
     return S.run_kernel(input, output, launch)
@@ -253,14 +253,24 @@ def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
     return output
 
 
-def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_cval=True):
+_EXT_REFUSED = set()      # requests the fused path behind _run_on_extended_rows refused: (tag, dtypes, shape, parameters)
+
+
+def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_cval=True, key=None):
     """Rows whose length is not a multiple of 16 bytes (181 x 217 x 181, 91 x 109 x 91, ...: most volumes that were not
     acquired as powers of two) cannot take the fused kernels directly -- their 16-byte row accesses need aligned rows.
     r4b: extend every row explicitly along the last axis (what its boundary mode prescribes, at least the filter's reach
     (`left`, `right`) on either side, to a multiple of 16 bytes: mi_extend_rows), call `run(ext_in, ext_out)` -- the fused
     path on the extended array, whose x boundary handling no kept output depends on any more; returns None when it does
     not take the request -- and copy the columns back (mi_crop_rows).  Three efficient launches at ~3 x the fused
-    kernel's traffic instead of generic per-axis passes (181 x 217 x 181 float32, uniform_filter(5): 125 -> 48 us)."""
+    kernel's traffic instead of generic per-axis passes (181 x 217 x 181 float32, uniform_filter(5): 125 -> 48 us).
+    `key`: what the fused path's answer depends on besides the data (r4 advisor finding: a request it refuses -- large
+    windows, ranks it does not handle -- paid two allocations and a full-volume copy before falling back to the generic
+    passes, on every call): a refusal is remembered and the next call with the same key returns at once."""
+    if key is not None:
+        key = (key, str(input.dtype), str(output.dtype), tuple(input.shape), left, right, mode_x)
+        if key in _EXT_REFUSED:
+            return None
     if left < 0 or right < 0 or input.size < (1 << 15) or input.dtype.itemsize not in (1, 2, 4) or output.dtype.itemsize not in (1, 2, 4):
         return None
     if exact_cval and mode_x in ("constant", "grid-constant"):
@@ -290,6 +300,10 @@ def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_c
     a, b = src._desc(), ext._desc()
     S.check(S.lib().mi_extend_rows(ctypes.byref(a), ctypes.byref(b), pl, S.mode_code(mode_x), float(cval), None))
     if run(ext, tmp) is None:
+        if key is not None:
+            if len(_EXT_REFUSED) > 1024:
+                _EXT_REFUSED.clear()
+            _EXT_REFUSED.add(key)
         return None
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     dst = output if direct else core.empty(output.shape, output.dtype)
@@ -310,7 +324,8 @@ def _fused_3d_padded_rows(input, output, weights, origins, modes, cval, is_box):
     # the x mode no longer matters for the columns that are kept; `nearest` is the cheapest for the kernels
     return _run_on_extended_rows(input, output, left, right, modes[2], cval,
                                  lambda e, o: _fused_3d(e, o, weights, origins, [modes[0], modes[1], "nearest"], cval, is_box, None),
-                                 exact_cval=False)
+                                 exact_cval=False,
+                                 key=("sep3d", tuple(None if w is None else len(w) for w in weights), tuple(int(o) for o in origins), tuple(modes[:2]), bool(is_box)))
 
 
 def _fused_3d_f64(input, output, weights, origins, modes, cval):
@@ -458,7 +473,8 @@ def uniform_filter(input, size=3, output=None, mode="reflect", cval=0.0, origin=
             reach = int(sizes[-1]) // 2
             modes_x = list(modes[:-1]) + ["nearest"]
             res = _run_on_extended_rows(input, output, reach, reach, modes[-1], cval,
-                                        lambda e, o: _try_uniform_integer(e, o, sizes, origins, modes_x, cval))
+                                        lambda e, o: _try_uniform_integer(e, o, sizes, origins, modes_x, cval),
+                                        key=("box-int", tuple(int(v) for v in sizes), tuple(int(v) for v in origins), tuple(modes_x), float(cval)))
             if res is not None:
                 return res
 
@@ -822,7 +838,8 @@ def _min_or_max_filter(input, size, ftprnt, structure, output, mode, cval, origi
             reach = int(sizes[-1]) // 2
             modes_x = list(modes[:-1]) + ["nearest"]
             res = _run_on_extended_rows(input, output, reach, reach, modes[-1], cval,
-                                        lambda e, o: fused(e, o, sizes, origins, modes_x, cval, is_max))
+                                        lambda e, o: fused(e, o, sizes, origins, modes_x, cval, is_max),
+                                        key=("minmax", tuple(int(v) for v in sizes), tuple(int(v) for v in origins), tuple(modes_x), float(cval), bool(is_max)))
             if res is not None:
                 return res
         passes = [(lambda s, d, ax=ax, sz=sz, og=og, m=m: _launch_minmax1d(s, d, ax, sz, og, m, cval, is_max))
@@ -1095,7 +1112,8 @@ def _rank_filter(input, rank, size, footprint, output, mode, cval, origin, opera
         if input.dtype.itemsize in (1, 2, 4) and (input.shape[-1] * input.dtype.itemsize) % 16 and mode != "constant":
             # rows that are not a multiple of 16 bytes (r4b).  Not for `constant`: the kernel takes ONE mode for both axes, and
             # on the extended rows the x mode must be one that never supplies a value of its own
-            res = _run_on_extended_rows(input, output, 1, 1, mode, cval, lambda e, o: _try_median3x3(e, o, mode, cval))
+            res = _run_on_extended_rows(input, output, 1, 1, mode, cval, lambda e, o: _try_median3x3(e, o, mode, cval),
+                                        key=("median3x3", float(cval)))
             if res is not None:
                 return res
     fpp = fp.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))

@@ -95,7 +95,7 @@ def _spline_output(output, input):
     return core.empty(input.shape, np.dtype(output))
 
 
-def spline_filter1d(input, order=3, axis=-1, output=np.float64, mode="mirror", *, allow_float32=False):
+def spline_filter1d(input, order=3, axis=-1, output=np.float64, mode="mirror", *, allow_float32=True):
     """B-spline prefilter along one axis (interpolation.py:105-182)."""
     if order < 0 or order > 5:
         raise RuntimeError("spline order not supported")
@@ -117,7 +117,7 @@ def spline_filter1d(input, order=3, axis=-1, output=np.float64, mode="mirror", *
     return ret
 
 
-def spline_filter(input, order=3, output=np.float64, mode="mirror", *, allow_float32=False):
+def spline_filter(input, order=3, output=np.float64, mode="mirror", *, allow_float32=True):
     """Multidimensional B-spline prefilter (interpolation.py:185-268)."""
     if order < 2 or order > 5:
         raise RuntimeError("spline order not supported")

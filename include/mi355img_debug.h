@@ -73,6 +73,7 @@ int mi_debug_set_spline_rows(int k);
 int mi_debug_set_cubic_separable(int on);
 int mi_debug_set_cubic_diag(int on);
 int mi_debug_set_spline_rows_lds(int on);     /* spline prefilter along the contiguous axis: 0 = the tiled kernel (lines through memory twice per pole), 1 = whole lines in LDS when they fit (default), 4 .. 64 = that with so many lines per wave */
+int mi_debug_set_spline_fast(int k);          /* r5 prefilter kernels (csrc/spline_fast.hip: one memory sweep per axis): 0 = never, 1 = volumes with >= 16384 lines (default), 2 = any line count */
 int mi_debug_set_cubic_rowblend(int on);      /* order-3 affine on float32 coefficients, x axis to itself: 0 = the gather kernel, 1 = the row-blend kernel (default) */
 int mi_debug_set_cubic_zstream(int on);       /* order-3 affine on float32 coefficients, axis 0 decoupled: 0 = the gather kernel, 1 = the z-streaming kernel (default), bits on top of 1: 2 = every wave on its gather path, 4 = no limit on the angle, 8 = grid-wrap / grid-constant too */
 int mi_debug_set_stream_nt(int k);             /* non-temporal staging of rows no other workgroup reads (sep3d_long3 <= 9 taps, mm3f32_long, mm3u8_split <= 5): -1 by volume size (default), 0 never, 1 always */

@@ -226,3 +226,54 @@ def whole_volume_affine(x, M, off, got, planes=4, procs=None):
     finally:
         _G.clear()
     return max(r[0] for r in res) / max(1.0, max(r[1] for r in res))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# r5: order 3 -- SciPy's (and the reference's, interpolation.py:275,403,582,705,823) DEFAULT spline order
+# ---------------------------------------------------------------------------------------------------------------------
+def _affine3_worker(job):
+    import scipy.ndimage as sndi
+    a, b = job
+    coef, got, M, off, mode, cval = _G["coef"], _G["got"], _G["M"], _G["off"], _G["mode"], _G["cval"]
+    ref = sndi.affine_transform(coef, M, off + M[:, 0] * a, output_shape=(b - a,) + got.shape[1:], output=np.float64, order=3,
+                                mode=mode, cval=cval, prefilter=False)
+    return float(np.abs(got[a:b].astype(np.float64) - ref).max()), float(np.abs(ref).max())
+
+
+def whole_volume_affine_order3(x, M, off, got, mode="constant", cval=0.0, planes=4, procs=None):
+    """`affine_transform(x, M, off, order=3, mode=mode)` (prefilter included), every output plane: the B-spline coefficients
+    of the WHOLE volume are SciPy's own (`spline_filter` in float64, one pass per axis, single-threaded: ~10 s for 512^3),
+    the interpolation runs on z sub-slabs of the output over the fork pool.  Modes that SciPy pads before the prefilter
+    (`nearest`, `grid-constant`) are not handled here."""
+    import scipy.ndimage as sndi
+    assert mode in ("constant", "mirror", "reflect", "wrap", "grid-wrap")
+    coef = sndi.spline_filter(x.astype(np.float64), order=3, output=np.float64, mode=mode)
+    _G.update(coef=coef, got=got, M=M, off=off, mode=mode, cval=cval)
+    try:
+        res = _run_pool(_affine3_worker, _jobs(got.shape[0], planes), procs)
+    finally:
+        _G.clear()
+    return max(r[0] for r in res) / max(1.0, max(r[1] for r in res))
+
+
+def _rotate_worker(job):
+    import scipy.ndimage as sndi
+    a, b = job
+    x, got, angle, kw = _G["x"], _G["got"], _G["angle"], _G["kw"]
+    ref = sndi.rotate(x[:, :, a:b].astype(np.float64), angle, **kw)
+    g = got[:, :, a:b]
+    assert g.shape == ref.shape, (g.shape, ref.shape)
+    return float(np.abs(g.astype(np.float64) - ref).max()), float(np.abs(ref).max())
+
+
+def whole_volume_rotate_default_axes(x, angle, got, planes=4, procs=None, **kw):
+    """`rotate(x, angle, **kw)` with SciPy's default axes (1, 0): SciPy rotates every (z, y) plane of the volume on its own
+    (ndimage/_interpolation.py rotate: a loop of 2-D affine transforms over the remaining axis), so the reference is exact
+    on x sub-slabs -- every voxel of the output is compared."""
+    assert "axes" not in kw
+    _G.update(x=x, got=got, angle=angle, kw=kw)
+    try:
+        res = _run_pool(_rotate_worker, _jobs(x.shape[2], planes), procs)
+    finally:
+        _G.clear()
+    return max(r[0] for r in res) / max(1.0, max(r[1] for r in res))

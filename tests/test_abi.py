@@ -93,7 +93,7 @@ def test_build_gate_sees_the_vmcnt_counting_kernels():
             path = os.path.join(tmp, "dev.co")
             with open(path, "wb") as f:
                 f.write(co)
-            text = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+            text = subprocess.run([_build._llvm_tool("llvm-objdump"), "-d", path], stdout=subprocess.PIPE, text=True, check=True).stdout
         names = re.findall(r"^[0-9a-f]+ <(\S+)>:$", text, flags=re.M)
         for frag in (fragment if isinstance(fragment, tuple) else (fragment,)):
             assert any(frag in n for n in names), (src, frag, names[:3])

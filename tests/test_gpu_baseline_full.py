@@ -89,6 +89,28 @@ def test_Dprime_affine_transform_order1_512(gpu, ndi, vol512):
     assert err <= 2e-6, err
 
 
+def test_order3_default_rotate_and_affine_512(gpu, ndi, vol512):
+    """r5: order 3 is the DEFAULT of `rotate` / `affine_transform` (the reference's interpolation.py:275,403,582).  Whole-volume
+    legs for the two calls the r4b kernels were written for, each the last of a burst: `rotate(vol512, 7)` with every default
+    (axes (1, 0): prefilter rows_lds + two strided passes, cubic3_rowblend_kernel; reshape=True, so the output is larger than
+    the input) and `affine_transform(order=3)` with the BASELINE matrix (cubic3_zstream_kernel<0>, step 1.02 along z).
+    Tolerance 2e-5 . max(1, max|ref|): float32 coefficients and weights against SciPy's double (the reference's
+    `allow_float32` route, interpolation.py:330-335)."""
+    from cupyimg_amd import last_kernel
+    x, xd = vol512
+    out = burst(lambda o: ndi.rotate(xd, 7.0, output=o))
+    assert "cubic3_rowblend_kernel" in last_kernel(), last_kernel()
+    assert out.dtype == np.float32
+    err = fs.whole_volume_rotate_default_axes(x, 7.0, out.get())
+    assert err <= 2e-5, err
+    del out
+    M, off = fs.affine_case(fs.N_H)
+    out = burst(lambda o: ndi.affine_transform(xd, M, off, order=3, output=o))
+    assert "cubic3_zstream_kernel<0>" in last_kernel(), last_kernel()
+    err = fs.whole_volume_affine_order3(x, M, off, out.get())
+    assert err <= 2e-5, err
+
+
 def test_C_grey_erosion7_1024_u8(gpu, ndi):
     gpu.free_all_blocks()
     u = fs.volume_u8((fs.N_C,) * 3, seed=1)

@@ -1,0 +1,177 @@
+"""r5: the one-sweep B-spline prefilter kernels (csrc/spline_fast.hip) -- `spline_stream_kernel` (strided axes: register chunks
+with a restarted anti-causal sweep) and `spline_rows_scan_kernel` (contiguous axis: prefix scans over the lanes) -- against
+SciPy (the reference's own oracle for interpolation.py:105-268) and against the sequential kernels they replace.
+
+Tolerances: float64 coefficients 1e-11 (the restart truncates at |z|^32 < 5e-19 of the data range; the sequential kernels are
+held to 1e-11 / 1e-12 in tests/test_gpu_vs_oracle.py), float32 coefficients 2e-6 of the data range (rounding of the stored
+type: 6e-8 per pass, three passes, gain 1.5 per pass)."""
+import numpy as np
+import pytest
+import scipy.ndimage as sndi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ndi(gpu):
+    from cupyimg_amd.scipy import ndimage
+    return ndimage
+
+
+@pytest.fixture(scope="module")
+def lib(gpu):
+    from cupyimg_amd import _lib
+    return _lib.load()
+
+
+def _took(fragment):
+    from cupyimg_amd import last_kernel
+    return fragment in last_kernel()
+
+
+def test_stream_and_scan_kernels_every_line_length(gpu, ndi, lib):
+    """Line lengths around every structural boundary of the two kernels: the chunk sizes (28 float32 / 12 float64), the
+    look-ahead (20 / 32), n = k C + 1 (the tail chunk starts ON the last sample: its mirror end condition needs c+ of the
+    chunk before), n = k C + H (the full chunk that ends the line), 256-sample scan segments, rows of 16 lanes; orders 2 and
+    3, mirror and reflect ends (the modes that do not pad), strided and contiguous axes, float32 and float64 coefficients,
+    float32 samples read into float64 coefficients.  Forced with the knob at 2 (the default rule wants >= 16384 lines)."""
+    rng = np.random.default_rng(5)
+    lib.mi_debug_set_spline_fast(2)
+    try:
+        lengths = [64, 65, 67, 68, 76, 84, 85, 96, 100, 104, 113, 124, 128, 132, 133, 140, 141, 197, 252, 256, 260, 300, 512, 516, 1020, 1024, 2048]
+        for n in lengths:
+            for axis_last in (False, True):
+                if axis_last and n % 4:
+                    continue
+                shape = (3, 70, n) if axis_last else (n, 5, 72)
+                axis = 2 if axis_last else 0
+                x = rng.standard_normal(shape)
+                x[..., 0] += 3.0                      # ends that matter
+                for dt, tol in ((np.float64, 1e-11), (np.float32, 2e-6)):
+                    xs = x.astype(dt)
+                    xd = gpu.asarray(xs)
+                    for order in (2, 3):
+                        for mode in ("mirror", "reflect"):
+                            want = sndi.spline_filter1d(xs.astype(np.float64), order, axis=axis, mode=mode)
+                            got = ndi.spline_filter1d(xd, order, axis=axis, output=dt, mode=mode)
+                            assert _took("spline_rows_scan_kernel" if axis_last else "spline_stream_kernel"), (n, axis, dt)
+                            err = np.abs(got.get().astype(np.float64) - want).max() / np.abs(want).max()
+                            assert err <= tol, (n, axis, dt.__name__, order, mode, err)
+                # float32 samples, float64 coefficients
+                xs = x.astype(np.float32)
+                want = sndi.spline_filter1d(xs.astype(np.float64), 3, axis=axis, mode="mirror")
+                got = ndi.spline_filter1d(gpu.asarray(xs), 3, axis=axis, output=np.float64, mode="mirror").get()
+                assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max(), (n, axis)
+    finally:
+        lib.mi_debug_set_spline_fast(1)
+
+
+def test_volume_prefilter_takes_the_fast_kernels_and_matches_scipy(gpu, ndi, lib):
+    """The default rule on volumes with many lines: spline_filter (all three axes; float32 -> float64 without the conversion
+    copy; float32 -> float32), shapes whose lines are not multiples of anything, and agreement with the sequential kernels
+    (knob 0) to rounding.  What the fast kernels do NOT take keeps the sequential ones: orders 4 / 5, grid-wrap ends, the
+    bit-exact request behind integer outputs, lines shorter than 64 samples."""
+    rng = np.random.default_rng(6)
+    for shape in ((130, 132, 140), (64, 300, 68), (200, 66, 96), (97, 131, 260)):
+        v = rng.standard_normal(shape).astype(np.float32)
+        vd = gpu.asarray(v)
+        for order in (3, 2):
+            for mode in ("mirror", "reflect"):
+                ref = sndi.spline_filter(v.astype(np.float64), order, mode=mode)
+                got64 = ndi.spline_filter(vd, order, output=np.float64, mode=mode)
+                np.testing.assert_allclose(got64.get(), ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+                got32 = ndi.spline_filter(vd, order, output=np.float32, mode=mode)
+                np.testing.assert_allclose(got32.get(), ref, rtol=0, atol=2e-6 * np.abs(ref).max())
+                lib.mi_debug_set_spline_fast(0)
+                try:
+                    old64 = ndi.spline_filter(vd, order, output=np.float64, mode=mode).get()
+                    old32 = ndi.spline_filter(vd, order, output=np.float32, mode=mode).get()
+                finally:
+                    lib.mi_debug_set_spline_fast(1)
+                np.testing.assert_allclose(got64.get(), old64, rtol=0, atol=1e-12 * np.abs(ref).max())
+                np.testing.assert_allclose(got32.get(), old32, rtol=0, atol=1e-6 * np.abs(ref).max())
+    v = rng.standard_normal((130, 132, 140)).astype(np.float32)
+    vd = gpu.asarray(v)
+    ndi.spline_filter(vd, 3)
+    assert _took("spline_rows_scan_kernel")           # the last pass of the default call
+    for order, mode in ((4, "mirror"), (5, "reflect"), (3, "grid-wrap")):
+        ndi.spline_filter(vd, order, mode=mode)
+        assert not _took("spline_rows_scan_kernel") and not _took("spline_stream_kernel"), (order, mode)
+    # the bit-exact request (behind integer outputs: SciPy's arithmetic operation for operation decides exact .5 ties) never
+    # takes the restarted recursion: spline mode | 0x100 through the C-ABI
+    import ctypes
+    ndi.uniform_filter(vd, 3)                          # something else in last_kernel()
+    c = gpu.asarray(v.astype(np.float64))
+    d = c._desc()
+    for axis in (0, 2):
+        assert lib.mi_spline_filter1d(ctypes.byref(d), axis, 3, 0 | 0x100, None) == 0
+        assert not _took("spline_rows_scan_kernel") and not _took("spline_stream_kernel"), axis
+    want = v.astype(np.float64)
+    for axis in (0, 2):
+        want = sndi.spline_filter1d(want, 3, axis=axis, mode="mirror")
+    np.testing.assert_allclose(c.get(), want, rtol=1e-12, atol=1e-12)
+
+
+def test_default_order3_calls_on_a_volume_match_scipy(gpu, ndi):
+    """End to end with every default (order 3, prefilter, float32 route): rotate about each axis pair, zoom, shift and a
+    general affine_transform on a 160^3-class volume, against SciPy in double: 2e-5 max(1, max|ref|)."""
+    rng = np.random.default_rng(8)
+    v = rng.standard_normal((144, 160, 152)).astype(np.float32)
+    vd = gpu.asarray(v)
+    v64 = v.astype(np.float64)
+    tol = lambda ref: 2e-5 * max(1.0, float(np.abs(ref).max()))
+    for axes in ((1, 0), (2, 1), (0, 2)):
+        for reshape in (True, False):
+            got = ndi.rotate(vd, 11.0, axes=axes, reshape=reshape).get()
+            ref = sndi.rotate(v64, 11.0, axes=axes, reshape=reshape)
+            assert got.shape == ref.shape
+            assert np.abs(got - ref).max() <= tol(ref), (axes, reshape, np.abs(got - ref).max())
+    for mode in ("constant", "mirror", "reflect", "nearest"):
+        got = ndi.rotate(vd, -23.0, mode=mode, reshape=False).get()
+        ref = sndi.rotate(v64, -23.0, mode=mode, reshape=False)
+        assert np.abs(got - ref).max() <= tol(ref), (mode, np.abs(got - ref).max())
+    got = ndi.zoom(vd, (1.25, 0.8, 1.1)).get()
+    ref = sndi.zoom(v64, (1.25, 0.8, 1.1))
+    assert np.abs(got - ref).max() <= tol(ref)
+    got = ndi.shift(vd, (2.5, -3.25, 0.75)).get()
+    ref = sndi.shift(v64, (2.5, -3.25, 0.75))
+    assert np.abs(got - ref).max() <= tol(ref)
+    a, b = np.deg2rad(9.0), np.deg2rad(-14.0)
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+    M = Rz @ Rx
+    ctr = (np.array(v.shape) - 1) / 2
+    off = ctr - M @ ctr
+    got = ndi.affine_transform(vd, M, off).get()
+    ref = sndi.affine_transform(v64, M, off)
+    assert np.abs(got - ref).max() <= tol(ref)
+
+
+def test_prefilter_passes_under_load_512(gpu, ndi, lib):
+    """Each pass of a 512^3 float32 prefilter on its own, last of 30 back-to-back launches: whole lines of the result against
+    SciPy's spline_filter1d in double on sampled blocks (2e-6 of the data range), and the whole volume against the
+    sequential kernel (1e-6: both round to float32).  The whole-volume SciPy leg of the composed calls is
+    tests/test_gpu_baseline_full.py::test_order3_default_rotate_and_affine_512."""
+    rng = np.random.default_rng(9)
+    n = 512
+    v = rng.standard_normal((n, n, n), dtype=np.float32)
+    vd = gpu.asarray(v)
+    out = gpu.empty(v.shape, np.float32)
+    for axis, kern in ((0, "spline_stream_kernel"), (1, "spline_stream_kernel"), (2, "spline_rows_scan_kernel")):
+        for _ in range(30):
+            ndi.spline_filter1d(vd, 3, axis=axis, output=out)
+        assert _took(kern), axis
+        got = out.get()
+        lib.mi_debug_set_spline_fast(0)
+        try:
+            old = ndi.spline_filter1d(vd, 3, axis=axis, output=np.float32).get()
+        finally:
+            lib.mi_debug_set_spline_fast(1)
+        scale = float(np.abs(old).max())
+        assert np.abs(got - old).max() <= 1e-6 * scale, (axis, np.abs(got - old).max() / scale)
+        del old
+        for lo in (0, 255, 509):
+            sl = [slice(None)] * 3
+            sl[(axis + 1) % 3] = slice(lo, lo + 3)
+            ref = sndi.spline_filter1d(v[tuple(sl)].astype(np.float64), 3, axis=axis)
+            assert np.abs(got[tuple(sl)] - ref).max() <= 2e-6 * np.abs(ref).max(), (axis, lo)
