@@ -21,7 +21,7 @@ LIB = os.path.join(HERE, "libmi355img.so")
 # the same library with every hand-counted `s_waitcnt vmcnt(n)` turned into vmcnt(0) (csrc/common.hpp MI_VMCNT): a TEST
 # artefact -- tests/test_gpu_burst.py compares the two under load, bit for bit; nothing in the product loads it
 LIB_STRICT = os.path.join(HERE, "libmi355img_strict.so")
-STRICT_SOURCES = ("sep3d_long.hip", "minmax3d_f32.hip", "interp_fast.hip", "interp.hip")     # the files that use MI_VMCNT
+STRICT_SOURCES = ("sep3d_long.hip", "minmax3d_f32.hip", "interp_fast.hip", "interp.hip", "cubic_fast.hip")     # the files that use MI_VMCNT
 ARCH = "gfx950"
 
 # (source, extra flags).  The generic kernels are built without FMA contraction
@@ -57,6 +57,7 @@ SOURCES = [
     ("interp.hip", ["-ffp-contract=off"]),
     ("interp_fast.hip", ["-ffp-contract=off"]),
     ("spline_fast.hip", []),
+    ("cubic_fast.hip", ["-ffp-contract=off"]),
     ("halo.hip", []),
     ("metrics.hip", ["-ffp-contract=off"]),
 ]
@@ -167,7 +168,7 @@ def _compile(args):
 # Sources whose kernels wait on vmcnt by count (LDS-DMA rings): the name fragment selects the kernels that must not
 # touch scratch memory (a spill store or reload is one more vector-memory operation in flight than the count assumes).
 # The ablation builds of the r3 long kernel (<W, SAME, DBG = true, 0>) are exempt: timing aids, not product kernels.
-NO_SCRATCH = {"sep3d_long.hip": "sep3d_long", "minmax3d_f32.hip": "mm3f32_long", "interp_fast.hip": ("zstream_kernel", "zrect_kernel"), "interp.hip": "cubic3_zstream_kernel"}
+NO_SCRATCH = {"sep3d_long.hip": "sep3d_long", "minmax3d_f32.hip": "mm3f32_long", "interp_fast.hip": ("zstream_kernel", "zrect_kernel"), "interp.hip": "cubic3_zstream_kernel", "cubic_fast.hip": "cubic3_zfactor_kernel"}
 
 
 # Kernels whose occupancy is part of their design: (fragment of the mangled name, VGPRs + AGPRs per lane at most).

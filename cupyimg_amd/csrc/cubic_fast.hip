@@ -1,0 +1,708 @@
+// cubic_fast.hip -- r5: order-3 (cubic B-spline) affine transforms on float32 coefficients whose matrix leaves the stream axis
+// to itself, evaluated PLANE BY PLANE.
+//
+// Reference: the 4 x 4 x 4 tap loop of cupyimg/scipy/ndimage/_interp_kernels.py:473-549 behind affine_transform / rotate
+// (interpolation.py:397-709, order 3 = the default).
+//
+// cubic3_zstream_kernel (interp.hip, r4b) stages the input planes of a tile in LDS once, but still evaluates every output voxel
+// as 64 taps: 64 ds_read_b32 + 80 FMA + ~170 other VALU instructions per voxel -- issue bound at 0.10 of the HBM roofline.
+// When the matrix couples only the two in-plane axes, the in-plane part of a voxel (its 4 x 4 taps, the eight weights) does
+// not depend on the output plane, and the interpolated value factors:
+//
+//     out(z, y, x) = sum_kz wz[z][kz] * Q_p(kz)(y, x),      Q_p(y, x) = sum_ky wy[ky] sum_kx wx[kx] c[p][ty + ky][tx + kx]
+//
+// Q_p -- the in-plane interpolation of INPUT plane p at the voxel's in-plane position -- is the same for every output plane
+// that reads plane p: four of them at a step of one plane.  A thread keeps Q of the four planes of the current step for its
+// eight voxels in registers (a ring indexed by plane mod 4), evaluates Q once per input plane and voxel (16 LDS reads at
+// IMMEDIATE offsets from one base address per voxel, 20 FMA) and blends four values per output voxel: 16 reads + 24 FMA per
+// voxel instead of 64 + 80, no per-plane address arithmetic.  Staging, ring, chunking and the hand-counted waits are those
+// of cubic3_zstream_kernel (same CubZParams, same plan: launch_cubic_zstream in interp.hip).
+//
+// CONTRACT.  The sums are taken in another order than cubic3_gather's (in-plane first, then along the stream axis): results
+// agree with the gather kernel to float32 rounding (<= 2e-6 of the coefficient range in the tests), not bit for bit; the
+// bound that matters is SciPy's: 2e-5 max(1, max|ref|) for this float32 route (tests/test_gpu_baseline_full.py, every plane
+// of 512^3).  Voxels / steps the factored form does not cover -- taps that fold at the array ends in ways the rectangle
+// does not hold, cval taps along the stream axis, two planes of a step in one ring slot -- take cubic3_gather itself, as in
+// the r4b kernel.
+#include "interp_common.hpp"
+
+namespace mi {
+
+// cubic3_gather's taps, products and order of sums (bit-identical to it), with the four rows of ONE stream-axis tap in flight
+// at a time: the fallback of a kernel that keeps ~130 registers of per-voxel state (cubic3_gather itself holds all 64 taps:
+// the kernel spilled, which a kernel that counts its vector-memory operations must not)
+__device__ __forceinline__ float cubic3_gather_lean(const __amdgpu_buffer_rsrc_t rin, const Cubic3 &t, float cval)
+{
+    const bool consec = t.off[2][0] >= 0 && t.off[2][3] == t.off[2][0] + 3;
+    float acc = 0.f;
+#pragma unroll
+    for (int kz = 0; kz < 4; kz++) {
+        __builtin_amdgcn_sched_barrier(0);          // (unrolled: a rolled loop would index the tap arrays at run time -- scratch)
+        float v[4][4];
+#pragma unroll
+        for (int ky = 0; ky < 4; ky++) {
+            const bool oob_zy = t.off[0][kz] < 0 || t.off[1][ky] < 0;
+            const int base = oob_zy ? 0 : t.off[0][kz] + t.off[1][ky];
+            if (consec) {
+                const u32x4 qv = __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)(base + t.off[2][0]) * 4u, 0, 0);
+                v[ky][0] = oob_zy ? cval : __uint_as_float(qv.x); v[ky][1] = oob_zy ? cval : __uint_as_float(qv.y);
+                v[ky][2] = oob_zy ? cval : __uint_as_float(qv.z); v[ky][3] = oob_zy ? cval : __uint_as_float(qv.w);
+            } else {
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) {
+                    const bool oob = oob_zy || t.off[2][kx] < 0;
+                    const float qv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rin, oob ? 0u : (unsigned)(base + t.off[2][kx]) * 4u, 0, 0));
+                    v[ky][kx] = oob ? cval : qv;
+                }
+            }
+        }
+#pragma unroll
+        for (int ky = 0; ky < 4; ky++) {
+            const float wzy = t.w[0][kz] * t.w[1][ky];
+            float row = v[ky][0] * t.w[2][0];
+            row = fmaf(v[ky][1], t.w[2][1], row);
+            row = fmaf(v[ky][2], t.w[2][2], row);
+            row = fmaf(v[ky][3], t.w[2][3], row);
+            acc = fmaf(row, wzy, acc);
+        }
+    }
+    return t.outside ? cval : acc;
+}
+
+// the taps of output plane z along the stream axis (wave-uniform).  Away from the array ends (all four planes inside, whatever the
+// mode) they follow from floor() alone; the boundary arithmetic of cubic3_axis (coordinate folding with divisions, per-tap
+// maps) runs only in the steps that need it.  Shared by the streaming kernel and the fix-up kernel: the two must agree on which
+// steps the streaming kernel leaves out.
+struct ZTaps { float w[4]; int pl[4]; bool outside, cvtap, plain; };      // plain: four consecutive planes inside the array (pl[k] = pl[0] + k)
+__device__ __forceinline__ ZTaps cz_ztaps(const CubZParams &q, int z)
+{
+    ZTaps p;
+    double s0 = 0.0; s0 += q.m00 * (double)z;
+    const double cz = s0 + q.m03;
+    const double cc = cz + (double)q.npad;
+    const double fl = floor(cc);
+    const bool plain = __builtin_amdgcn_readfirstlane((int)(fl >= 1.0 && fl + 2.0 <= (double)(q.nz - 1))) != 0;
+    float w[4]; int pl[4];
+    bool outside = false, cv = false;
+    if (plain) {
+        cubic3_weights((float)(cc - fl), w);
+        const int st = (int)fl - 1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) pl[k] = st + k;
+    } else {
+        int off[4];
+        int nz_ = q.nz, mode_ = q.mode;          // (opaque: keeps the loop-invariant doubles of the boundary arithmetic out of the loop's registers)
+        asm volatile("" : "+s"(nz_), "+s"(mode_));
+        outside = cubic3_axis(nz_, 1, cz, mode_, q.npad, w, off);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { pl[k] = off[k]; cv = cv || off[k] < 0; }
+    }
+    if (q.sident) {
+        // the stream axis holds samples (its prefilter pass was skipped) at an integral coordinate: the tap AT the coordinate
+        // is the second of the four and the only one -- one plane per step, weight one
+        cv = pl[1] < 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { pl[k] = pl[1]; w[k] = k == 1 ? 1.f : 0.f; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        p.w[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(w[k])));
+        p.pl[k] = __builtin_amdgcn_readfirstlane(pl[k]);
+    }
+    // two DIFFERENT planes of one step in the same slot of the register ring (plane mod 4): planes that wrap around the array
+    // (four consecutive planes never do) -- the step is left to the fix-up kernel
+    if (!plain) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = i + 1; j < 4; j++)
+                cv = cv || (p.pl[i] >= 0 && p.pl[j] >= 0 && p.pl[i] != p.pl[j] && (p.pl[i] & 3) == (p.pl[j] & 3));
+    }
+    p.cvtap = __builtin_amdgcn_readfirstlane((int)cv) != 0;
+    p.outside = __builtin_amdgcn_readfirstlane((int)outside) != 0;
+    p.plain = plain && !q.sident;
+    return p;
+}
+
+// FIX-UP: the voxels the streaming kernel leaves out -- waves with a voxel whose in-plane taps the staged rectangle does not
+// hold (flag per tile and wave, written by the streaming kernel), and whole steps with a cval tap along the stream axis or
+// two planes in one ring slot -- by the gather routine, one wave per (tile, wave, output plane); almost all of them return
+// after reading one flag.  Out of the streaming kernel since r5: with the gather code inline its register allocation was
+// that of the fallback (256 registers and spills in the hot loop).
+constexpr int kCzFixPlanes = 16;        // output planes per fix-up workgroup (one per plane: 262 144 workgroups on 512^3, 75 us of dispatch)
+
+template <int SAX>
+__global__ void __launch_bounds__(64)
+cubic3_zfix_kernel(const float *__restrict__ in, float *__restrict__ out, const CubZParams q, const int *__restrict__ far_flags)
+{
+    const int tw = blockIdx.x;
+    const int wave = tw & 3, tile = tw >> 2;
+    const int lane = threadIdx.x;
+    const bool far = far_flags[tw] != 0 || (q.dbg & 2);
+    const int tx_i = tile % q.ntx, ty_i = tile / q.ntx;
+    const int x = tx_i * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, q.vol_bytes, 0x00020000);
+    const int z1 = min((int)(blockIdx.y + 1) * kCzFixPlanes, q.oz);
+#pragma unroll 1
+    for (int z = blockIdx.y * kCzFixPlanes; z < z1; z++) {
+        double s0 = 0.0; s0 += q.m00 * (double)z;
+        if (!far) {
+            // four plain planes inside the array: nothing for this wave to do (the cheap half of cz_ztaps)
+            const double fl = floor((s0 + q.m03) + (double)q.npad);
+            if (fl >= 1.0 && fl + 2.0 <= (double)(q.nz - 1)) continue;
+        }
+        const ZTaps zt = cz_ztaps(q, z);
+        if (zt.outside) continue;                                          // the streaming kernel wrote cval
+        if (!(far || zt.cvtap)) continue;
+        if (x >= q.ox) continue;
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+            const int y = ty_i * kCzTY + 8 * wave + k;
+            if (y >= q.oy) break;
+            Cubic3 tt;
+            const double o1 = (double)y, o2 = (double)x;
+            double s1 = 0.0; s1 += q.m11 * o1; s1 += q.m12 * o2;
+            double s2 = 0.0; s2 += q.m21 * o1; s2 += q.m22 * o2;
+            bool outside = cubic3_axis(q.ny, q.sr, s1 + q.m13, q.mode, q.npad, tt.w[1 - SAX], tt.off[1 - SAX]);
+            outside |= cubic3_axis(q.nx, 1, s2 + q.m23, q.mode, q.npad, tt.w[2], tt.off[2]);
+            (void)cubic3_axis(q.nz, q.ss, s0 + q.m03, q.mode, q.npad, tt.w[SAX], tt.off[SAX]);
+            if (q.sident) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { tt.off[SAX][j] = tt.off[SAX][1]; tt.w[SAX][j] = j == 1 ? 1.f : 0.f; }
+            }
+            tt.ntap[0] = 4; tt.ntap[1] = 4;
+            tt.outside = outside;
+            __builtin_nontemporal_store(cubic3_gather_lean(rin, tt, q.cval), out + ((size_t)z * q.oss + (size_t)y * q.osr + x));
+        }
+    }
+}
+
+template <int SAX>
+__global__ void __launch_bounds__(kCzNT, 2)
+cubic3_zfactor_kernel(const float *__restrict__ in, float *__restrict__ out, const CubZParams q, int *__restrict__ far_flags)
+{
+    constexpr int P = kCzP, TY = kCzTY, NT = kCzNT, NS = kCzSlots;
+    extern __shared__ __attribute__((aligned(16))) char smem_cz[];
+    const unsigned slot_bytes = (unsigned)q.slot_bytes;
+    float *tiles = reinterpret_cast<float *>(smem_cz + max((unsigned)NS * slot_bytes, 4u * 24u * 64u * 4u));      // [4 waves][8 rows][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = q.ntx * q.nty * q.nzc;
+    int t = blockIdx.x;
+    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);          // x-neighbouring tiles on one XCD
+    const int tx_i = t % q.ntx, ty_i = (t / q.ntx) % q.nty, zc_i = t / (q.ntx * q.nty);
+    const int x0 = tx_i * 64, y0 = ty_i * TY;
+    const int zs = zc_i * q.zc, ze = min(zs + q.zc, q.oz);
+    const int vol_bytes = q.vol_bytes;
+    const unsigned plane_b = (unsigned)q.ss * 4u, row_b = (unsigned)q.sr * 4u;
+
+    // ---- rectangle origin (as cubic3_zstream_kernel)
+    int by0, bx0;
+    {
+        const double cy = ((q.m11 * (double)y0 + q.m12 * (double)x0) + q.m13) + q.cmin_y + (double)q.npad;
+        const double cx = ((q.m21 * (double)y0 + q.m22 * (double)x0) + q.m23) + q.cmin_x + (double)q.npad;
+        double fy = floor(cy - 1e-6 * (1.0 + fabs(cy))) - 1.0, fx = floor(cx - 1e-6 * (1.0 + fabs(cx))) - 1.0;
+        fy = fy < 0.0 ? 0.0 : (fy > (double)(q.ny - 1) ? (double)(q.ny - 1) : fy);
+        fx = fx < 0.0 ? 0.0 : (fx > (double)(q.nx - 1) ? (double)(q.nx - 1) : fx);
+        by0 = __builtin_amdgcn_readfirstlane((int)fy);
+        bx0 = __builtin_amdgcn_readfirstlane((int)fx & ~3);
+    }
+    const int rounds = (q.nchunks + NT - 1) / NT;
+    unsigned rel[kCzRoundsMax];
+#pragma unroll
+    for (int j = 0; j < kCzRoundsMax; j++) {
+        const unsigned ch = (unsigned)tid + (unsigned)(j * NT);
+        const unsigned row = ch / 20u, c4 = ch - row * 20u;
+        rel[j] = ch < (unsigned)q.nchunks ? row * row_b + c4 * 16u : 0x80000000u;
+    }
+    // lanes of round j that hold a chunk (the r4b kernel kept the eight masks in sixteen scalar registers; here they are
+    // recomputed where a plane is staged: one compare per DMA instruction)
+    auto live_of = [&](int j) { return __builtin_amdgcn_ballot_w64(rel[j] != 0x80000000u); };
+    // rounds in which THIS wave has any chunk: the wave's first chunk of round j is chunk 64 wave + 256 j
+    int ndma = 0;                                            // DMA instructions of this wave per plane
+#pragma unroll
+    for (int j = 0; j < kCzRoundsMax; j++) ndma += (j < rounds && (unsigned)(64 * wave + NT * j) < (unsigned)q.nchunks) ? 1 : 0;
+    const unsigned org_b = ((unsigned)by0 * (unsigned)q.sr + (unsigned)bx0) * 4u;
+
+    // ---- per voxel (row y0 + 8 wave + k, column x0 + lane), once: the in-plane taps -- plain / edge / far exactly as in
+    // cubic3_zstream_kernel (see there); an edge voxel additionally sets bit 31 of its packed start
+    const int rule = q.mode == MI_MODE_NEAREST ? 2 : (q.mode == MI_MODE_REFLECT ? 1 : ((q.mode == MI_MODE_GRID_WRAP || q.mode == MI_MODE_GRID_CONSTANT) ? 3 : 0));
+    auto czrule = [&](int i, int n) {
+        const int lo = rule == 2 ? 0 : -i - rule, hi = rule == 2 ? n - 1 : 2 * n - 2 + rule - i;
+        return i < 0 ? lo : (i >= n ? hi : i);
+    };
+    int a_[8];
+    float fy_[8], fx_[8];
+    unsigned farmask = 0, outmask = 0, edgemask = 0;
+    auto inplane = [&](int k, float &fy, int (&offy)[4], float &fx, int (&offx)[4]) {
+        const double o1 = (double)(y0 + 8 * wave + k), o2 = (double)(x0 + lane);
+        double s1 = 0.0; s1 += q.m11 * o1; s1 += q.m12 * o2;
+        double s2 = 0.0; s2 += q.m21 * o1; s2 += q.m22 * o2;
+        const bool oy_ = cubic3_axis_frac(q.ny, q.sr, s1 + q.m13, q.mode, q.npad, fy, offy);
+        const bool ox_ = cubic3_axis_frac(q.nx, 1, s2 + q.m23, q.mode, q.npad, fx, offx);
+        return oy_ | ox_;
+    };
+    float *park = reinterpret_cast<float *>(smem_cz) + wave * (24 * 64) + lane;
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        int offy[4], offx[4];
+        float fy, fx;
+        const bool outside = inplane(k, fy, offy, fx, offx);
+        bool block = offy[0] >= 0 && offx[0] >= 0;
+#pragma unroll
+        for (int j = 1; j < 4; j++) block = block && offy[j] == offy[0] + j * q.sr && offx[j] == offx[0] + j;
+        int r0 = offy[0] / q.sr - by0, c0 = offx[0] - bx0;
+        const bool held = block && r0 >= 0 && r0 + 3 < q.ry && c0 >= 0 && c0 + 3 < P;
+        bool edge = false;
+        if (!held && !outside && rule != 3) {
+            int sy = 0, sx = 0;
+            bool fy_ok = false, fx_ok = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!fy_ok && offy[j] >= 0) {
+                    const int s = offy[j] / q.sr - j;
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) ok = ok && offy[i] == czrule(s + i, q.ny) * q.sr;
+                    if (ok) { sy = s; fy_ok = true; }
+                }
+                if (!fx_ok && offx[j] >= 0) {
+                    const int s = offx[j] - j;
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) ok = ok && offx[i] == czrule(s + i, q.nx);
+                    if (ok) { sx = s; fx_ok = true; }
+                }
+            }
+            edge = fy_ok && fx_ok && sy - by0 >= -8 && sx - bx0 >= -8 && sy - by0 < 4096 && sx - bx0 < 4096;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ty = czrule(sy + j, q.ny) - by0, tx = czrule(sx + j, q.nx) - bx0;
+                edge = edge && ty >= 0 && ty < q.ry && tx >= 0 && tx < P;
+            }
+            r0 = sy - by0; c0 = sx - bx0;
+        }
+        park[(3 * k) * 64] = __int_as_float((held || edge) ? ((r0 + 8) << 16) | (c0 + 8) : (8 << 16) | 8);
+        park[(3 * k + 1) * 64] = fy;
+        park[(3 * k + 2) * 64] = fx;
+        farmask |= (held || edge || outside) ? 0u : (1u << k);
+        outmask |= outside ? (1u << k) : 0u;
+        edgemask |= (edge && !held) ? (1u << k) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        a_[k] = __float_as_int(park[(3 * k) * 64]);
+        fy_[k] = park[(3 * k + 1) * 64];
+        fx_[k] = park[(3 * k + 2) * 64];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // before anyone's DMA lands on the parked values
+    float wy_[8][4], wx_[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        cubic3_weights(fy_[k], wy_[k]);
+        cubic3_weights(fx_[k], wx_[k]);
+    }
+    const bool any_far = __builtin_amdgcn_ballot_w64(farmask != 0u) != 0;
+    // (every z chunk of the tile writes the same value: the flag depends on the in-plane geometry only)
+    if (lane == 0) far_flags[(ty_i * q.ntx + tx_i) * 4 + wave] = any_far ? 1 : 0;
+    const bool any_edge = __builtin_amdgcn_ballot_w64(edgemask != 0u) != 0;
+    const bool imm_candidate = slot_bytes == (unsigned)kCzSlot && !any_edge;      // every voxel of the wave a plain block, slots of the fixed size: immediate offsets
+    float *tile = tiles + wave * 512;
+    const bool wide = x0 + 64 <= q.ox && y0 + TY <= q.oy;
+
+    // ---- the plane ring in LDS.  Unlike the r4b kernel, a plane is READ from LDS in one step only (the step that evaluates its
+    // in-plane values into the register ring); afterwards its slot is free.  So the five slots are a prefetch QUEUE, filled
+    // round robin (`head`; a plane's slot is found by content, not by plane mod 5): planes of the next kLook steps are
+    // requested as soon as the slot at the head holds a plane that has been evaluated -- at the r4b kernel's depth of one
+    // step a step now ends (16 reads + 24 FMA per voxel) long before its successor's plane has crossed the memory system.
+    //
+    // Bookkeeping (wave-uniform scalars, IDENTICAL in every wave of the workgroup -- each wave stages its share of every plane,
+    // so all must take the same decisions; nothing below depends on a wave's own voxels):
+    //   res[s]   plane in slot s (or none);  mark[s]  value of `issued` right after this wave's DMAs for it;
+    //   issued   vector-memory instructions this wave has CERTAINLY issued: its DMAs and the two stores of a full-tile step.
+    // The wait before a step needs the DMAs of the planes it evaluates: every vector-memory operation up to max(mark) must be
+    // complete, i.e. at most N = issued - max(mark) younger ones may be in flight (they retire in order): s_waitcnt vmcnt(N')
+    // with N' the largest encodable choice <= N.  Instructions the count does not know (stores of partial tiles) only make N
+    // an UNDER-estimate of what may legally be in flight: the wait is then longer, never shorter.
+    constexpr int kLook = 3;
+    constexpr int kNone = -0x7fffffff;
+    int res0 = kNone, res1 = kNone, res2 = kNone, res3 = kNone, res4 = kNone;
+    int mark0 = 0, mark1 = 0, mark2 = 0, mark3 = 0, mark4 = 0;
+    int issued = 0;
+    int head = 0;                                            // the slot the next plane goes to
+    auto find = [&](int pl) { return res0 == pl ? 0 : (res1 == pl ? 1 : (res2 == pl ? 2 : (res3 == pl ? 3 : (res4 == pl ? 4 : -1)))); };
+    auto res_at = [&](int sl) { return sl == 0 ? res0 : (sl == 1 ? res1 : (sl == 2 ? res2 : (sl == 3 ? res3 : res4))); };
+    auto mark_at = [&](int sl) { return sl == 0 ? mark0 : (sl == 1 ? mark1 : (sl == 2 ? mark2 : (sl == 3 ? mark3 : mark4))); };
+    auto fetch = [&](int pl, int sl) {                       // stage plane pl (0 <= pl < nz) into slot sl
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
+        const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)pl * plane_b + org_b);
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)sl * slot_bytes + (unsigned)(wave << 6) * 16u);
+#pragma unroll
+        for (int j = 0; j < kCzRoundsMax; j++)
+            if (j < ndma) cz_dma16(rin, rel[j], base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * NT) * 16u), live_of(j));
+        issued += ndma;
+        // (selects, not a switch: a switch over by-reference captures makes the compiler keep the ten scalars as an indexed
+        // array in scratch memory -- whose accesses are vector-memory operations of their own)
+        res0 = sl == 0 ? pl : res0; res1 = sl == 1 ? pl : res1; res2 = sl == 2 ? pl : res2; res3 = sl == 3 ? pl : res3; res4 = sl == 4 ? pl : res4;
+        mark0 = sl == 0 ? issued : mark0; mark1 = sl == 1 ? issued : mark1; mark2 = sl == 2 ? issued : mark2; mark3 = sl == 3 ? issued : mark3;
+        mark4 = sl == 4 ? issued : mark4;
+        head = sl == 4 ? 0 : sl + 1;
+    };
+    auto zplane = [&](int z) { return cz_ztaps(q, z); };
+
+    // ---- Q ring: in-plane values of the planes of the current step, slot (plane & 3); the tags are wave-uniform
+    float Q[4][8];
+    int qtag0 = -0x7fffffff, qtag1 = -0x7fffffff, qtag2 = -0x7fffffff, qtag3 = -0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) Q[s][k] = 0.f;
+
+    // in-plane interpolation of the plane in LDS slot `sl` for the eight voxels
+    auto eval_imm = [&](auto svar, float (&T)[8]) {
+        constexpr int S = decltype(svar)::value;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            // plain voxels: byte offset of the block's first tap in a slot (from the packed start: three instructions, no register held)
+            const char *b = smem_cz + (unsigned)((((a_[k] >> 16) - 8) * P + ((a_[k] & 0xffff) - 8)) * 4);
+            float v[4][4];
+#pragma unroll
+            for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) v[ky][kx] = *reinterpret_cast<const float *>(b + (S * kCzSlot + ky * (P * 4) + kx * 4));
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 4; ky++) {
+                float row = v[ky][0] * wx_[k][0];
+                row = fmaf(v[ky][1], wx_[k][1], row);
+                row = fmaf(v[ky][2], wx_[k][2], row);
+                row = fmaf(v[ky][3], wx_[k][3], row);
+                acc = ky == 0 ? row * wy_[k][0] : fmaf(row, wy_[k][ky], acc);
+            }
+            T[k] = acc;
+            __builtin_amdgcn_sched_barrier(0);              // one voxel's sixteen reads at a time (all eight at once: 128 registers)
+        }
+    };
+    // waves with an edge voxel (tiles along the array's borders: a third of the tiles of 512^3) and rectangles that do not fit
+    // the fixed slot: every tap at its own row / column offset in the rectangle.  The eight offsets of a voxel are computed
+    // ONCE (here) and kept as four packed registers -- recomputing them per plane through czrule, as the r4b kernel does, cost
+    // 1 340 instructions per plane against the immediate form's 335 and set the time of the whole launch.
+    unsigned rop_[8][2], cop_[8][2];
+    if (!imm_candidate) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int sy = (a_[k] >> 16) - 8 + by0, sx = (a_[k] & 0xffff) - 8 + bx0;
+            unsigned ro[4], co[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // `outside` voxels: anything inside the slot (their value is replaced)
+                int ty = czrule(sy + j, q.ny) - by0, tx = czrule(sx + j, q.nx) - bx0;
+                ty = min(max(ty, 0), q.ry - 1); tx = min(max(tx, 0), P - 1);
+                ro[j] = (unsigned)ty * (unsigned)(P * 4); co[j] = (unsigned)tx * 4u;
+            }
+            rop_[k][0] = ro[0] | (ro[1] << 16); rop_[k][1] = ro[2] | (ro[3] << 16);
+            cop_[k][0] = co[0] | (co[1] << 16); cop_[k][1] = co[2] | (co[3] << 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { rop_[k][0] = rop_[k][1] = cop_[k][0] = cop_[k][1] = 0u; }
+    }
+    auto eval_general = [&](unsigned pbase, float (&T)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned rb[4] = {pbase + (rop_[k][0] & 0xffffu), pbase + (rop_[k][0] >> 16), pbase + (rop_[k][1] & 0xffffu), pbase + (rop_[k][1] >> 16)};
+            const unsigned co[4] = {cop_[k][0] & 0xffffu, cop_[k][0] >> 16, cop_[k][1] & 0xffffu, cop_[k][1] >> 16};
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 4; ky++) {
+                float v[4];
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) v[kx] = *reinterpret_cast<const float *>(smem_cz + (rb[ky] + co[kx]));
+                float row = v[0] * wx_[k][0];
+                row = fmaf(v[1], wx_[k][1], row);
+                row = fmaf(v[2], wx_[k][2], row);
+                row = fmaf(v[3], wx_[k][3], row);
+                acc = ky == 0 ? row * wy_[k][0] : fmaf(row, wy_[k][ky], acc);
+            }
+            T[k] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const bool imm_ok = imm_candidate;
+    auto eval_plane = [&](int pl, float (&T)[8]) {
+        const unsigned sl = (unsigned)find(pl);
+        if (imm_ok) {
+            switch (sl) {
+            case 0: eval_imm(std::integral_constant<int, 0>{}, T); break;
+            case 1: eval_imm(std::integral_constant<int, 1>{}, T); break;
+            case 2: eval_imm(std::integral_constant<int, 2>{}, T); break;
+            case 3: eval_imm(std::integral_constant<int, 3>{}, T); break;
+            default: eval_imm(std::integral_constant<int, 4>{}, T); break;
+            }
+        } else {
+            eval_general(sl * slot_bytes, T);
+        }
+    };
+
+    // at most N vector-memory operations of this wave may stay in flight
+    auto wait_vm_le = [&](int n) {
+        if (n >= 24) asm volatile(MI_VMCNT(24) ::: "memory");
+        else if (n >= 18) asm volatile(MI_VMCNT(18) ::: "memory");
+        else if (n >= 14) asm volatile(MI_VMCNT(14) ::: "memory");
+        else if (n >= 12) asm volatile(MI_VMCNT(12) ::: "memory");
+        else if (n >= 10) asm volatile(MI_VMCNT(10) ::: "memory");
+        else if (n >= 8) asm volatile(MI_VMCNT(8) ::: "memory");
+        else if (n >= 6) asm volatile(MI_VMCNT(6) ::: "memory");
+        else if (n >= 4) asm volatile(MI_VMCNT(4) ::: "memory");
+        else if (n >= 2) asm volatile(MI_VMCNT(2) ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto in_q = [&](int pl) { const int s_ = pl & 3; return (s_ == 0 ? qtag0 : (s_ == 1 ? qtag1 : (s_ == 2 ? qtag2 : qtag3))) == pl; };
+    // first plane of the four taps of output plane z when they are four plain planes inside the array (else kNone): the cheap
+    // form of cubic3_axis for looking ahead -- a wrong guess costs time (the plane is then fetched at its own step), never data
+    auto plain_start = [&](int z) {
+        double s0 = 0.0; s0 += q.m00 * (double)z;
+        const double cc = (s0 + q.m03) + (double)q.npad;
+        const double fl = floor(cc);
+        const bool ok = fl >= 1.0 && fl + 2.0 <= (double)(q.nz - 1) && cc >= 0.0 && cc <= (double)(q.nz - 1);
+        return __builtin_amdgcn_readfirstlane(ok ? (int)fl - 1 : kNone);
+    };
+    const int kfirst = q.sident ? 1 : 0, klast = q.sident ? 1 : 3;      // the taps of a step that exist (one, when the stream axis holds samples)
+
+    ZTaps cur = zplane(zs);
+    int pf = zs + 1;                                             // look-ahead: the first step whose planes have not been requested
+
+#pragma unroll 1
+    for (int z = zs; z < ze; z++) {
+        const bool lds_step = !cur.outside && !cur.cvtap && !(q.dbg & 2);      // the step reads planes from LDS (workgroup-uniform)
+        // ---- (1) the planes this step evaluates: fetch what the look-ahead did not bring, then wait for them
+        int need_mark = 0;
+        bool missing = false;
+        unsigned need_slots = 0, newmask = 0;                   // newmask: taps whose plane the register ring does not hold yet
+        if (lds_step) {
+#pragma unroll
+            for (int kz = 0; kz < 4; kz++) {
+                const int pl = cur.pl[kz];
+                if (in_q(pl)) continue;
+                if (!cur.plain) {                                // (four consecutive planes have no twins)
+                    bool dup = false;
+#pragma unroll
+                    for (int j = 0; j < kz; j++) dup = dup || cur.pl[j] == pl;
+                    if (dup) continue;
+                }
+                newmask |= 1u << kz;
+                const int sl = find(pl);
+                if (sl < 0) { missing = true; continue; }
+                need_mark = max(need_mark, mark_at(sl));
+                need_slots |= 1u << sl;
+            }
+        }
+        const bool any_need = newmask != 0;
+        if (missing) {
+            // a plane the look-ahead did not bring (the first step of a chunk, steps at the array ends): nobody may still be
+            // reading the slot it goes to -- barrier, stage (into slots that hold no plane of this step), wait for everything,
+            // barrier
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int kz = 0; kz < 4; kz++) {
+                const int pl = cur.pl[kz];
+                if (in_q(pl) || find(pl) >= 0) continue;          // (a duplicate tap finds the plane its twin has just staged)
+                int sl = head;
+#pragma unroll
+                for (int t_ = 0; t_ < 4; t_++) sl = ((need_slots >> sl) & 1u) ? (sl == 4 ? 0 : sl + 1) : sl;
+                fetch(pl, sl);
+                need_slots |= 1u << sl;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (!missing) {
+            if (any_need) wait_vm_le(issued - need_mark);
+            __builtin_amdgcn_s_barrier();        // the planes of this step are in LDS for every wave; every wave has left the previous step's reads
+        }
+        // ---- (2) look ahead: request the planes of the next steps into slots whose plane has been evaluated.  `pf` is the
+        // first step whose planes have not been requested: usually one step and one plane per iteration of the z loop.
+        ZTaps nxt = cur;
+        if (z + 1 < ze) nxt = zplane(z + 1);
+        if (pf <= z) pf = z + 1;
+        {
+            int lo = 0x7fffffff, hi = -0x7fffffff;           // the planes between this step and the step looked at
+            if (lds_step) {
+                lo = min(min(cur.pl[0], cur.pl[1]), min(cur.pl[2], cur.pl[3]));
+                hi = max(max(cur.pl[0], cur.pl[1]), max(cur.pl[2], cur.pl[3]));
+            }
+#pragma unroll 1
+            while (pf < ze && pf <= z + kLook) {
+                const int st = plain_start(pf);
+                if (st == kNone) { pf++; continue; }                                       // a step at the array ends: fetched at its own top
+                {
+                    // planes are requested in the order the steps need them: when the tap at the far end of this step is there
+                    // (or evaluated), so are the others
+                    const int far_pl = st + (q.m00 >= 0.0 ? klast : kfirst);
+                    if (in_q(far_pl) || find(far_pl) >= 0) { pf++; continue; }
+                }
+                lo = min(lo, st + kfirst); hi = max(hi, st + klast);
+                bool blocked = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k < kfirst || k > klast || blocked) continue;
+                    const int pl = st + k;
+                    if (in_q(pl) || find(pl) >= 0) continue;                              // evaluated already, or there
+                    const int occ = res_at(head);
+                    if (((need_slots >> head) & 1u) ||                                    // the slot is being read in this step
+                        (occ != kNone && occ >= lo && occ <= hi && !in_q(occ))) {         // its plane is still to be evaluated
+                        blocked = true;
+                        continue;
+                    }
+                    fetch(pl, head);
+                }
+                if (blocked) break;
+                pf++;
+            }
+        }
+        // ---- (3) this step's output
+        auto emit = [&](int k, float v) { tile[k * 64 + lane] = v; };
+        bool skip_store = false;
+        if (cur.outside) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) emit(k, q.cval);
+        } else if (!lds_step || any_far) {
+            if (lds_step) {
+                // a wave with a far voxel: the same bookkeeping as its neighbours (the tags decide what everybody fetches), no values
+#pragma unroll
+                for (int kz = 0; kz < 4; kz++) {
+                    const int pl = cur.pl[kz];
+                    const int s_ = pl & 3;
+                    qtag0 = s_ == 0 ? pl : qtag0; qtag1 = s_ == 1 ? pl : qtag1; qtag2 = s_ == 2 ? pl : qtag2; qtag3 = s_ == 3 ? pl : qtag3;
+                }
+            }
+            skip_store = true;                                   // cubic3_zfix_kernel writes these voxels
+        } else {
+            // (A) the in-plane values of this step's planes that the register ring does not hold yet: one plane per step at a
+            // step of up to one plane, four at the start of a chunk
+#pragma unroll
+            for (int kz = 0; kz < 4; kz++) {
+                if (!((newmask >> kz) & 1u)) continue;
+                const int pl = cur.pl[kz];
+                const int s = pl & 3;
+                float T[8];
+                eval_plane(pl, T);
+                switch (s) {
+                case 0: qtag0 = pl;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) Q[0][k] = T[k];
+                    break;
+                case 1: qtag1 = pl;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) Q[1][k] = T[k];
+                    break;
+                case 2: qtag2 = pl;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) Q[2][k] = T[k];
+                    break;
+                default: qtag3 = pl;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) Q[3][k] = T[k];
+                    break;
+                }
+            }
+            // (B) four values per voxel
+            if (cur.plain) {
+                // four consecutive planes: tap kz sits in ring slot (pl[0] + kz) & 3 -- one of four rotations, no weights to sort
+                auto blend = [&](auto rvar) {
+                    constexpr int R = decltype(rvar)::value;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        float acc = Q[R][k] * cur.w[0];
+                        acc = fmaf(Q[(R + 1) & 3][k], cur.w[1], acc);
+                        acc = fmaf(Q[(R + 2) & 3][k], cur.w[2], acc);
+                        acc = fmaf(Q[(R + 3) & 3][k], cur.w[3], acc);
+                        emit(k, ((outmask >> k) & 1u) ? q.cval : acc);
+                    }
+                };
+                switch (cur.pl[0] & 3) {
+                case 0: blend(std::integral_constant<int, 0>{}); break;
+                case 1: blend(std::integral_constant<int, 1>{}); break;
+                case 2: blend(std::integral_constant<int, 2>{}); break;
+                default: blend(std::integral_constant<int, 3>{}); break;
+                }
+            } else {
+                // the array's ends (a plane read twice at a reflecting end), a stream axis that holds samples: weights per ring
+                // slot.  A slot without a plane of this step holds an OLDER plane: it must not enter the sum even with weight
+                // 0 (0 x inf = NaN for non-finite coefficients)
+                float W0 = 0.f, W1 = 0.f, W2 = 0.f, W3 = 0.f;
+                unsigned used = 0;
+#pragma unroll
+                for (int kz = 0; kz < 4; kz++) {
+                    const int s = cur.pl[kz] & 3;
+                    const float wk = cur.w[kz];
+                    W0 += s == 0 ? wk : 0.f; W1 += s == 1 ? wk : 0.f; W2 += s == 2 ? wk : 0.f; W3 += s == 3 ? wk : 0.f;
+                    used |= 1u << s;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    float acc = 0.f;
+                    if (used & 1u) acc = fmaf(Q[0][k], W0, acc);
+                    if (used & 2u) acc = fmaf(Q[1][k], W1, acc);
+                    if (used & 4u) acc = fmaf(Q[2][k], W2, acc);
+                    if (used & 8u) acc = fmaf(Q[3][k], W3, acc);
+                    emit(k, ((outmask >> k) & 1u) ? q.cval : acc);
+                }
+            }
+        }
+        if (skip_store) {
+        } else if (wide) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int i = lane >> 4, c = lane & 15;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float4 v = *reinterpret_cast<const float4 *>(tile + (4 * h + i) * 64 + 4 * c);
+                typedef float f32x4c __attribute__((ext_vector_type(4)));
+                const f32x4c vv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(vv, reinterpret_cast<f32x4c *>(out + ((size_t)z * q.oss + (size_t)(y0 + 8 * wave + 4 * h + i) * q.osr + x0 + 4 * c)));
+            }
+            issued += 2;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            // partial tiles: stores the count does not know (it only under-estimates what may be in flight: see above)
+            const int x = x0 + lane;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int y = y0 + 8 * wave + k;
+                const float v = tile[k * 64 + lane];
+                if (x < q.ox && y < q.oy) __builtin_nontemporal_store(v, out + ((size_t)z * q.oss + (size_t)y * q.osr + x));
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// launch with the plan of launch_cubic_zstream (interp.hip): same parameters, same dynamic LDS; MI_ERR_UNSUPPORTED = not taken
+int launch_cubic_zfactor(int sax, const float *in, float *out, const CubZParams &q, size_t lds, int blocks, hipStream_t s)
+{
+    const long long tw = (long long)q.ntx * q.nty * 4;
+    if (tw > 0x7fffffffLL || (q.oz + kCzFixPlanes - 1) / kCzFixPlanes > 65535) return MI_ERR_UNSUPPORTED;
+    static PerDeviceOnce attr_done;
+    if (!attr_done) {
+        MI_HIP(hipFuncSetAttribute((const void *)cubic3_zfactor_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)cubic3_zfactor_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        attr_done = true;
+    }
+    void *flags = nullptr;
+    int rc = pool_alloc(&flags, (size_t)tw * sizeof(int), s);
+    if (rc) return rc;
+    if (sax == 0) {
+        hipLaunchKernelGGL(cubic3_zfactor_kernel<0>, dim3((unsigned)blocks), dim3(kCzNT), lds, s, in, out, q, (int *)flags);
+        hipLaunchKernelGGL(cubic3_zfix_kernel<0>, dim3((unsigned)tw, (unsigned)((q.oz + kCzFixPlanes - 1) / kCzFixPlanes)), dim3(64), 0, s, in, out, q, (const int *)flags);
+    } else {
+        hipLaunchKernelGGL(cubic3_zfactor_kernel<1>, dim3((unsigned)blocks), dim3(kCzNT), lds, s, in, out, q, (int *)flags);
+        hipLaunchKernelGGL(cubic3_zfix_kernel<1>, dim3((unsigned)tw, (unsigned)((q.oz + kCzFixPlanes - 1) / kCzFixPlanes)), dim3(64), 0, s, in, out, q, (const int *)flags);
+    }
+    const hipError_t e = hipGetLastError();
+    pool_free(flags);                    // stream-ordered pool: reused only by later work on the stream
+    MI_HIP(e);
+    return MI_OK;
+}
+
+}  // namespace mi

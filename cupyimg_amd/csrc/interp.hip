@@ -16,62 +16,9 @@
 // tests/test_interpolation.py:362-364).
 //
 // Geometry is padded with leading unit axes to a compile-time rank (3 or 8).
-#include "common.hpp"
+#include "interp_common.hpp"
 
 namespace mi {
-
-struct InterpGeom {
-    int64_t shape[MI_MAX_NDIM];    // input, padded
-    int64_t stride[MI_MAX_NDIM];   // input, elements
-    int64_t oshape[MI_MAX_NDIM];   // output, padded (affine)
-    double mat[MI_MAX_NDIM * (MI_MAX_NDIM + 1)];   // affine, padded (ND x (ND+1))
-    int pad;                        // number of leading unit axes
-};
-
-__device__ __forceinline__ double wrap_coord(double c, int64_t n)
-{
-    if (n <= 1) return 0.0;
-    const double s = (double)(n - 1);
-    if (c < 0) c += s * ((double)(int64_t)(-c / s) + 1.0);
-    else if (c > s) c -= s * (double)(int64_t)(c / s);
-    return c;
-}
-
-// SciPy's map_coordinate(): fold a float coordinate into the array
-__device__ __forceinline__ double fold_coord(double c, int64_t n, int mode)
-{
-    if (n <= 1) return 0.0;
-    const double dn = (double)n;
-    switch (mode) {
-    case MI_MODE_MIRROR: {
-        const double p = 2.0 * dn - 2.0;
-        if (c < 0) { c = p * (double)(int64_t)(-c / p) + c; c = c <= 1.0 - dn ? c + p : -c; }
-        else if (c > dn - 1.0) { c -= p * (double)(int64_t)(c / p); if (c >= dn) c = p - c; }
-        return c;
-    }
-    case MI_MODE_REFLECT: {
-        const double p = 2.0 * dn;
-        if (c < 0) {
-            if (c < -p) c = p * (double)(int64_t)(-c / p) + c;
-            c = c < -dn ? c + p : (c > -1e-15 ? 1e-15 : -c) - 1.0;
-        } else if (c > dn - 1.0) {
-            c -= p * (double)(int64_t)(c / p);
-            if (c >= dn) c = p - c - 1.0;
-        }
-        return c;
-    }
-    case MI_MODE_WRAP:
-        return wrap_coord(c, n);
-    case MI_MODE_GRID_WRAP:
-        if (c < 0) c += dn * ((double)(int64_t)((-1.0 - c) / dn) + 1.0);
-        else if (c > dn - 1.0) c -= dn * (double)(int64_t)((c + 1.0) / dn);
-        return c;
-    case MI_MODE_NEAREST:
-        return c < 0 ? 0.0 : (c > dn - 1.0 ? dn - 1.0 : c);
-    default:
-        return c;
-    }
-}
 
 template <typename T, int ND>
 __device__ __forceinline__ double interp_point(const T *__restrict__ in, const InterpGeom &g,
@@ -454,100 +401,6 @@ spline_affine_nd_kernel(const double *__restrict__ in, void *__restrict__ out, i
     }
 }
 
-// ---------------------------------------------------------------------------
-// Cubic interpolation on float32 coefficients (float32 in / out, the reference's
-// `allow_float32` route, interpolation.py:330-335): same tap selection as
-// spline_point_t<3> (double coordinate arithmetic), float weights and float
-// accumulation, and the four x taps of a (z, y) pair fetched with one 16-byte gather
-// whenever they are consecutive in memory -- 16 gathers per voxel instead of 64.
-// ---------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr unsigned kOobOffset = 0x80000000u;   // beyond any buffer: the load returns 0 without touching memory
-
-struct Cubic3 {
-    float w[3][4];
-    int off[3][4];      // element offset along the axis, -1: the tap reads cval
-    int ntap[2];        // taps on z and y (1 on rank-padding axes)
-    bool outside;       // constant mode, coordinate beyond the array: the voxel is cval
-};
-
-// 32-bit tap index outside [0, n): the symmetry the coefficients were computed with (spline_tap in int)
-__device__ __forceinline__ int spline_tap32(int i, int n, int mode)
-{
-    if (i >= 0 && i < n) return i;
-    if (mode == MI_MODE_GRID_CONSTANT) return -1;
-    if (mode == MI_MODE_REFLECT) return bmap<int>(i, n, MI_MODE_REFLECT);
-    if (mode == MI_MODE_NEAREST) return i < 0 ? 0 : n - 1;
-    if (mode == MI_MODE_GRID_WRAP) return bmap<int>(i, n, MI_MODE_GRID_WRAP);
-    return bmap<int>(i, n, MI_MODE_MIRROR);
-}
-
-// one axis of the tap selection: coordinate in double (as the double route), everything after the
-// integer / fraction split in 32 bits.  Returns true when the coordinate is beyond the array in constant mode.
-// the four weights of a fraction x in [0, 1)
-__device__ __forceinline__ void cubic3_weights(float x, float (&w)[4])
-{
-    const float y = 1.f - x;
-    w[1] = (x * x * (x - 2.f) * 3.f + 4.f) * (1.f / 6.f);
-    w[2] = (y * y * (y - 2.f) * 3.f + 4.f) * (1.f / 6.f);
-    w[0] = y * y * y * (1.f / 6.f);
-    w[3] = 1.f - w[0] - w[1] - w[2];
-}
-
-// taps of an axis and the fraction their weights are made of (cubic3_weights)
-__device__ __forceinline__ bool cubic3_axis_frac(int n, int stride, double cc, int mode, int npad, float &frac, int (&off)[4])
-{
-    bool outside = false;
-    cc += (double)npad;
-    if (mode == MI_MODE_CONSTANT) {
-        if (cc < 0 || cc > (double)(n - 1)) { outside = true; cc = 0.0; }
-    } else if (mode != MI_MODE_GRID_CONSTANT && mode != MI_MODE_NEAREST) {
-        cc = fold_coord(cc, n, mode);
-    } else {
-        // taps are mapped one by one below; keep the integer part inside 32 bits for far-away coordinates
-        cc = cc < -1.0e9 ? -1.0e9 : (cc > 1.0e9 ? 1.0e9 : cc);
-    }
-    const double fl = floor(cc);
-    const int start = (int)fl - 1;
-    frac = (float)(cc - fl);
-    if (start >= 0 && start + 3 < n) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) off[k] = (start + k) * stride;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = spline_tap32(start + k, n, mode);
-            off[k] = j < 0 ? -1 : j * stride;
-        }
-    }
-    return outside;
-}
-
-__device__ __forceinline__ bool cubic3_axis(int n, int stride, double cc, int mode, int npad, float (&w)[4], int (&off)[4])
-{
-    float x;
-    const bool outside = cubic3_axis_frac(n, stride, cc, mode, npad, x, off);
-    cubic3_weights(x, w);
-    return outside;
-}
-
-__device__ __forceinline__ void cubic3_setup(const InterpGeom &g, const double (&c)[3], int mode, int npad, Cubic3 &t)
-{
-    t.outside = false;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        if (d < g.pad) {
-            if (d < 2) t.ntap[d] = 1;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { t.w[d][k] = 1.f; t.off[d][k] = 0; }
-            continue;
-        }
-        if (d < 2) t.ntap[d] = 4;
-        t.outside |= cubic3_axis((int)g.shape[d], (int)g.stride[d], c[d], mode, npad, t.w[d], t.off[d]);
-    }
-}
-
 // Diagonal transforms: taps and weights of an axis depend on the output index along that axis only, so
 // they are tabulated once per call (oz + oy + ox entries) instead of once per voxel.
 struct AxisTaps { float w[4]; int off[4]; int outside; int pad_[3]; };
@@ -662,70 +515,6 @@ cubic_resample_rows4_kernel(const float4 *__restrict__ in, float4 *__restrict__ 
         if (ozy | tx[3].outside) r.w = cval;
     }
     out[((size_t)z * d1 + y) * (size_t)d2q + xq] = r;
-}
-
-// CVTAPS: taps may read cval (grid-constant only); otherwise no tap offset is ever negative
-template <int NTZ, int NTY, bool CVTAPS>
-__device__ __forceinline__ float cubic3_gather_t(const __amdgpu_buffer_rsrc_t rin, const Cubic3 &t, float cval)
-{
-    const bool consec = t.off[2][0] >= 0 && t.off[2][3] == t.off[2][0] + 3;
-    float v[NTZ][NTY][4];
-    if (consec) {
-        u32x4 q[NTZ][NTY];
-#pragma unroll
-        for (int kz = 0; kz < NTZ; kz++)
-#pragma unroll
-            for (int ky = 0; ky < NTY; ky++) {
-                const bool oob_zy = CVTAPS && (t.off[0][kz] < 0 || t.off[1][ky] < 0);
-                const int base = oob_zy ? 0 : t.off[0][kz] + t.off[1][ky];
-                q[kz][ky] = __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)(base + t.off[2][0]) * 4u, 0, 0);
-            }
-#pragma unroll
-        for (int kz = 0; kz < NTZ; kz++)
-#pragma unroll
-            for (int ky = 0; ky < NTY; ky++) {
-                const bool oob_zy = CVTAPS && (t.off[0][kz] < 0 || t.off[1][ky] < 0);
-                v[kz][ky][0] = oob_zy ? cval : __uint_as_float(q[kz][ky].x);
-                v[kz][ky][1] = oob_zy ? cval : __uint_as_float(q[kz][ky].y);
-                v[kz][ky][2] = oob_zy ? cval : __uint_as_float(q[kz][ky].z);
-                v[kz][ky][3] = oob_zy ? cval : __uint_as_float(q[kz][ky].w);
-            }
-    } else {
-#pragma unroll
-        for (int kz = 0; kz < NTZ; kz++)
-#pragma unroll
-            for (int ky = 0; ky < NTY; ky++) {
-                const bool oob_zy = CVTAPS && (t.off[0][kz] < 0 || t.off[1][ky] < 0);
-                const int base = oob_zy ? 0 : t.off[0][kz] + t.off[1][ky];
-#pragma unroll
-                for (int kx = 0; kx < 4; kx++) {
-                    const bool oob = CVTAPS && (oob_zy || t.off[2][kx] < 0);
-                    const float q = __uint_as_float(
-                        __builtin_amdgcn_raw_buffer_load_b32(rin, oob ? 0u : (unsigned)(base + t.off[2][kx]) * 4u, 0, 0));
-                    v[kz][ky][kx] = oob ? cval : q;
-                }
-            }
-    }
-    float acc = 0.f;
-#pragma unroll
-    for (int kz = 0; kz < NTZ; kz++)
-#pragma unroll
-        for (int ky = 0; ky < NTY; ky++) {
-            const float wzy = t.w[0][kz] * t.w[1][ky];
-            float row = v[kz][ky][0] * t.w[2][0];
-            row = fmaf(v[kz][ky][1], t.w[2][1], row);
-            row = fmaf(v[kz][ky][2], t.w[2][2], row);
-            row = fmaf(v[kz][ky][3], t.w[2][3], row);
-            acc = fmaf(row, wzy, acc);
-        }
-    return t.outside ? cval : acc;
-}
-
-template <int NTZ, int NTY>
-__device__ __forceinline__ float cubic3_gather(const __amdgpu_buffer_rsrc_t rin, const Cubic3 &t, float cval, int mode)
-{
-    if (mode == MI_MODE_GRID_CONSTANT) return cubic3_gather_t<NTZ, NTY, true>(rin, t, cval);
-    return cubic3_gather_t<NTZ, NTY, false>(rin, t, cval);
 }
 
 // block (64, 4): 64 lanes along the output x axis, so that the gathers of a wave touch neighbouring
@@ -860,50 +649,6 @@ cubic3_diag_f32_kernel(const float *__restrict__ in, float *__restrict__ out, co
 // (boundary folds, cval taps, anything the rectangle does not hold) and a plane with a cval tap along z take
 // cubic3_gather itself.
 // ---------------------------------------------------------------------------
-void note_kernel(const char *fmt, ...);        // runtime.hip (sep_common.hpp declares it for the filter sources)
-bool spline_pass_fast(const mi_array *shape, const void *src, int src_dtype, void *dst, int axis, int order, int spline_mode, hipStream_t s, int *rc);   // spline_fast.hip
-constexpr int kCzP = 80, kCzRoundsMax = 8, kCzSlots = 5, kCzTY = 32, kCzNT = 256;
-constexpr double kCzMinXStep = 0.09;    // |dx_in/dx_out| >= this x |dy_in/dx_out|: up to ~85 degrees (profiles/r4_cubic_zstream.txt: 3.4 ms against 4.1 ms there, 7.8 against 3.9 at 90)
-constexpr int kCzSlot = 14336;          // the fixed slot size (44 rows): five of them + the tiles fit a CU twice, 4 x kCzSlot is an immediate offset
-
-struct CubZParams {
-    // names as for SAX = 0 (the stream axis is z, a plane's rows run along y); for SAX = 1 `z` is the array's axis 1 and `y`
-    // its axis 0 -- lengths, strides (in elements) and matrix entries are filled in accordingly by the launch
-    int nz, ny, nx;              // coefficient array (padded by npad on every axis): stream axis, row axis, x
-    int oz, oy, ox;
-    int ss, sr;                  // input strides of the stream axis and of the row axis
-    int oss, osr;                // the same of the output
-    int vol_bytes;
-    double m00, m03, m11, m12, m13, m21, m22, m23;
-    double cmin_y, cmin_x;       // minimum of cy / cx over a tile relative to its first voxel
-    int ry, nchunks;             // rows of the staged rectangle, 16-byte chunks per plane (ry * 20)
-    int slot_bytes;              // kCzSlot when the rectangle fits it, else exactly the rectangle
-    int zc, nzc, ntx, nty;
-    int mode, npad;
-    float cval;
-    int dbg;
-};
-
-// lanes outside `mask` neither fetch nor write LDS (the last round of a plane: the slots are exactly as long as the rectangle)
-__device__ __forceinline__ void cz_dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_base, unsigned long long mask)
-{
-    unsigned keep;
-    unsigned long long keep_exec;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b64 %1, exec\n\t"
-        "s_mov_b32 m0, %5\n\t"
-        "s_mov_b64 exec, %6\n\t"
-        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b64 exec, %1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&s"(keep_exec)
-        : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base), "s"(mask)
-        : "memory");
-}
-
-struct CzPlane { float w[4]; int off[4]; int pl[4]; bool outside, cvtap; };      // cvtap: the step takes cubic3_gather (a cval tap along z, or a slot clash)
-
 template <int SAX>
 __global__ void __launch_bounds__(kCzNT, 2)
 cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, const CubZParams q)
@@ -1236,14 +981,18 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
     }
 }
 
+Knob g_cubic_zfactor{1};      // test hook: 0 = cubic3_zstream_kernel (r4b: 64 taps per voxel, bit-identical to the gather kernel) instead of cubic3_zfactor_kernel
+extern "C" int mi_debug_set_cubic_zfactor(int on) { g_cubic_zfactor = on; return MI_OK; }
+int launch_cubic_zfactor(int sax, const float *in, float *out, const CubZParams &q, size_t lds, int blocks, hipStream_t s);      // cubic_fast.hip
 Knob g_cubic_zstream{1};      // test hook: 0 = the gather kernel for every non-diagonal matrix; bit 2: every wave on cubic3_gather; bit 4: any x step; bit 8: the grid modes too
 extern "C" int mi_debug_set_cubic_zstream(int on) { g_cubic_zstream = on; return MI_OK; }
 
 // plan + launch; false = not taken (the caller runs cubic3_f32_kernel)
-static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, const InterpGeom &g, int mode, double cval, int npad, hipStream_t s, int *rc)
+static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, const InterpGeom &g, int mode, double cval, int npad, int ident, hipStream_t s, int *rc)
 {
     *rc = MI_OK;
     if (!g_cubic_zstream || g.pad != 0) return false;
+    if (ident && !g_cubic_zfactor) return false;                 // the r4b kernel has no single-tap form of the stream axis
     // the two grid modes: a voxel with a tap beyond the array (cval / the far side) sends its whole wave to cubic3_gather, and
     // the tiles along the edges then hold the launch up -- 4.97 ms against the gather kernel's 3.99 ms on 512^3, 7 degrees,
     // grid-wrap (profiles/r4_cubic_zstream.txt).  Debug bit 8 takes them all the same (the tests of those paths).
@@ -1257,6 +1006,8 @@ static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, cons
     else if (m[1] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[9] == 0.0) sax = 1;
     else return false;
     const int ra = 1 - sax;                                                                     // the axis a plane's rows run along
+    if (ident && ident != (1 << sax)) return false;                                             // the unfiltered axis must be the one that streams
+    if (ident && !(m[sax * 4 + sax] == 1.0 && m[sax * 4 + 3] == floor(m[sax * 4 + 3]))) return false;
     // up to one plane per step the five ring slots hold the four planes of a step + the one the next needs; beyond that (the
     // BASELINE matrix steps 1.02 planes) every 1 / (|m| - 1) steps need TWO new planes, the second of which lands on a slot the
     // current step still reads: it is fetched late (after the step's reads, one more barrier, the next wait drains) -- r5
@@ -1301,12 +1052,22 @@ static bool launch_cubic_zstream(const mi_array *coef, const mi_array *out, cons
     q.nzc = (q.oz + q.zc - 1) / q.zc;
     q.mode = mode; q.npad = npad; q.cval = (float)cval;
     q.dbg = g_cubic_zstream;
+    q.sident = ident ? 1 : 0;
     static PerDeviceOnce attr_done;
     if (!attr_done) {
         hipError_t e_ = hipFuncSetAttribute((const void *)cubic3_zstream_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (e_ == hipSuccess) e_ = hipFuncSetAttribute((const void *)cubic3_zstream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (e_ != hipSuccess) { *rc = hip_fail(e_, "hipFuncSetAttribute(cubic3_zstream_kernel)"); return true; }
         attr_done = true;
+    }
+    if (g_cubic_zfactor) {
+        // r5: the same plan, evaluated plane by plane (csrc/cubic_fast.hip: in-plane values once per input plane, four-term blend
+        // per voxel) -- float32 rounding away from the gather kernel, not bit-identical; knob 0 keeps the r4b kernel
+        note_kernel("mi::cubic3_zfactor_kernel<%d> grid=%d (order-3 affine on float32 coefficients, axis %d decoupled: streams along it, in-plane values once per input plane, %d rows x %d staged per plane, %d chunks)",
+                    sax, tiles * q.nzc, sax, q.ry, kCzP, q.nzc);
+        const int frc = launch_cubic_zfactor(sax, (const float *)coef->data, (float *)out->data, q, lds, tiles * q.nzc, s);
+        if (frc != MI_ERR_UNSUPPORTED) { *rc = frc; return true; }
+        if (ident) return false;             // (more than 65535 output planes: the r4b kernel, which has no single-tap form)
     }
     note_kernel("mi::cubic3_zstream_kernel<%d> grid=%d (order-3 affine on float32 coefficients, axis %d decoupled: streams along it, %d rows x %d staged per plane, %d chunks)",
                 sax, tiles * q.nzc, sax, q.ry, kCzP, q.nzc);
@@ -1334,6 +1095,7 @@ struct CubRowParams {
     int xsegs;                   // 512-voxel pieces per output row
     int mode, npad;
     float cval;
+    int xident;                  // r5: the x axis holds SAMPLES (its prefilter pass was skipped): the x taps are the one sample at the voxel's column
 };
 
 __global__ void __launch_bounds__(256)
@@ -1378,12 +1140,33 @@ cubic3_rowblend_kernel(const float *__restrict__ in, float *__restrict__ out, co
         const int x4 = seg * 512 + (g * 64 + lane) * 4;
         const int start0 = x4 + q.xs + q.npad - 1;              // first tap of the first voxel, in the (padded) row
         const bool live = x4 < q.ox;
-        const bool plain = live && x4 + 3 < q.ox && !cvrow && (row_outside || (start0 >= 0 && start0 + 6 < q.nx));
+        const bool plain = live && x4 + 3 < q.ox && !cvrow &&
+                           (row_outside || (q.xident ? (start0 + 1 >= 0 && start0 + 4 < q.nx) : (start0 >= 0 && start0 + 6 < q.nx)));
         slow[g] = __builtin_amdgcn_ballot_w64(live && !plain);
         if (!plain) continue;
         f32x4r r;
         if (row_outside) {
             r = f32x4r{q.cval, q.cval, q.cval, q.cval};
+        } else if (q.xident) {
+            // the x axis holds samples: one 16-byte load per input row, the row IS the x sum (sixteen loads and FMAs per four
+            // voxels instead of 32 and 80)
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kz = 0; kz < 4; kz++) {
+                u32x4 a[4];
+#pragma unroll
+                for (int ky = 0; ky < 4; ky++)
+                    a[ky] = __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)(start0 + 1) * 4u, (unsigned)(t.off[0][kz] + t.off[1][ky]) * 4u, 0);
+#pragma unroll
+                for (int ky = 0; ky < 4; ky++) {
+                    const float wzy = t.w[0][kz] * t.w[1][ky];
+                    acc[0] = fmaf(__uint_as_float(a[ky].x), wzy, acc[0]);
+                    acc[1] = fmaf(__uint_as_float(a[ky].y), wzy, acc[1]);
+                    acc[2] = fmaf(__uint_as_float(a[ky].z), wzy, acc[2]);
+                    acc[3] = fmaf(__uint_as_float(a[ky].w), wzy, acc[3]);
+                }
+            }
+            r = f32x4r{acc[0], acc[1], acc[2], acc[3]};
         } else {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1431,6 +1214,12 @@ cubic3_rowblend_kernel(const float *__restrict__ in, float *__restrict__ out, co
             const bool o2 = cubic3_axis(q.nx, 1, s2 + (double)q.xs, q.mode, q.npad, t.w[2], t.off[2]);
             Cubic3 tt = t;
             tt.outside = t.outside | o2;
+            if (q.xident) {
+                // the tap AT the (integral) coordinate is the second of the four; the others do not exist for this axis
+                const int at = tt.off[2][1];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { tt.off[2][k] = at; tt.w[2][k] = k == 1 ? 1.f : 0.f; }
+            }
             __builtin_nontemporal_store(cubic3_gather<4, 4>(rin, tt, q.cval, q.mode), orow + x);
         }
     }
@@ -1440,7 +1229,7 @@ Knob g_cubic_rowblend{1};      // test hook: 0 = the gather kernel
 extern "C" int mi_debug_set_cubic_rowblend(int on) { g_cubic_rowblend = on; return MI_OK; }
 
 // plan + launch; false = not taken (the caller runs cubic3_f32_kernel)
-static bool launch_cubic_rowblend(const mi_array *coef, const mi_array *out, const InterpGeom &g, int mode, double cval, int npad, hipStream_t s, int *rc)
+static bool launch_cubic_rowblend(const mi_array *coef, const mi_array *out, const InterpGeom &g, int mode, double cval, int npad, bool xident, hipStream_t s, int *rc)
 {
     *rc = MI_OK;
     if (!g_cubic_rowblend || g.pad != 0) return false;
@@ -1460,9 +1249,11 @@ static bool launch_cubic_rowblend(const mi_array *coef, const mi_array *out, con
     q.xs = (int)m[11];
     q.xsegs = (q.ox + 511) / 512;
     q.mode = mode; q.npad = npad; q.cval = (float)cval;
+    q.xident = xident ? 1 : 0;
     const long long blocks = (long long)q.xsegs * ((q.oy + 3) / 4);
     if (blocks > 0x7fffffffLL) return false;
-    note_kernel("mi::cubic3_rowblend_kernel grid=%lldx%d (order-3 affine on float32 coefficients, x axis to itself: 16 rows x two 16-byte loads per four voxels)", blocks, q.oz);
+    note_kernel("mi::cubic3_rowblend_kernel grid=%lldx%d (order-3 affine on float32 coefficients, x axis to itself: 16 rows x %s per four voxels)", blocks, q.oz,
+                xident ? "ONE 16-byte load (x holds samples)" : "two 16-byte loads");
     hipLaunchKernelGGL(cubic3_rowblend_kernel, dim3((unsigned)blocks, (unsigned)q.oz), dim3(64, 4), 0, s, (const float *)coef->data, (float *)out->data, q);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) *rc = hip_fail(e2, "cubic3_rowblend_kernel");
@@ -2494,14 +2285,20 @@ int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int 
     int rc;
     if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
     MI_REQUIRE(order >= 2 && order <= 5, MI_ERR_INVALID_ARG, "spline order is not supported");
-    MI_REQUIRE((spline_mode & 0xff) >= 0 && (spline_mode & 0xff) <= 2 && (spline_mode & ~(0xff | kSplExact)) == 0, MI_ERR_INVALID_ARG,
+    MI_REQUIRE((spline_mode & 0xff) >= 0 && (spline_mode & 0xff) <= 2 && (spline_mode & ~(0xff | kSplExact | (0xff << 9))) == 0, MI_ERR_INVALID_ARG,
                "bad spline boundary mode");
     MI_REQUIRE(out->dtype == MI_F64 || out->dtype == MI_F32, MI_ERR_INVALID_ARG, "coefficients are float64 or float32");
+    // r5: bit 9 + d = leave axis d unfiltered (MI_SPLINE_SKIP_AXIS(d)): an affine transform that maps an axis onto itself with
+    // an integral shift evaluates the spline at the samples of that axis, where it returns them -- the pass and the taps
+    // along it cancel (SciPy's own `rotate` never filters the axes outside the rotation plane: ndimage/_interpolation.py)
+    const int skip = (spline_mode >> 9) & 0xff;
+    spline_mode &= 0xff | kSplExact;
+    auto filtered = [&](int d) { return out->shape[d] > 1 && !((skip >> d) & 1); };
     MI_REQUIRE(in->data != out->data, MI_ERR_INVALID_ARG, "mi_spline_prefilter works out of place");
     // the first filtered axis can read the source directly when no padding or conversion is asked for
     int first = -1;
     for (int d = 0; d < out->ndim && first < 0; d++)
-        if (out->shape[d] > 1) first = d;
+        if (filtered(d)) first = d;
     int64_t inner_first = 1;
     for (int d = first + 1; first >= 0 && d < out->ndim; d++) inner_first *= out->shape[d];
     const bool direct = npad == 0 && in->dtype == out->dtype && same_shape(in, out) && is_contiguous(in) && is_contiguous(out)
@@ -2514,7 +2311,7 @@ int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int 
         int frc;
         if (spline_pass_fast(out, in->data, MI_F32, out->data, first, order, spline_mode, s, &frc)) {
             for (int d = first + 1; d < out->ndim && frc == MI_OK; d++)
-                if (out->shape[d] > 1) frc = spline_pass(out, out->data, out->data, d, order, spline_mode, s);
+                if (filtered(d)) frc = spline_pass(out, out->data, out->data, d, order, spline_mode, s);
             return frc;
         }
     }
@@ -2522,7 +2319,7 @@ int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int 
     // temporary, laid out so that the last hop lands in `out` (K blocked passes: start in `out` when K is even).
     int nblocked = 0;
     for (int d = 0; d < out->ndim; d++)
-        if (out->shape[d] > 1 && spline_chunk_len(out, d, order, spline_mode) > 0) nblocked++;
+        if (filtered(d) && spline_chunk_len(out, d, order, spline_mode) > 0) nblocked++;
     void *tmp = nullptr;
     if (nblocked > 0 && (rc = pool_alloc(&tmp, (size_t)numel(out) * dtype_size(out->dtype), s))) return rc;
     auto other = [&](const void *p) { return p == out->data ? tmp : out->data; };
@@ -2537,7 +2334,7 @@ int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int 
     }
     int left = nblocked;
     for (int d = 0; d < out->ndim && rc == MI_OK; d++) {
-        if (out->shape[d] <= 1) continue;
+        if (!filtered(d)) continue;
         const bool blocked = spline_chunk_len(out, d, order, spline_mode) > 0;
         void *dst;
         if (blocked) {
@@ -2548,6 +2345,11 @@ int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int 
         }
         rc = spline_pass(out, cur, dst, d, order, spline_mode, s);
         cur = dst;
+    }
+    if (rc == MI_OK && cur == in->data) {
+        // nothing was filtered (every axis skipped or of length one): the coefficients are the samples
+        hipError_t err = hipMemcpyAsync(out->data, in->data, (size_t)numel(out) * dtype_size(out->dtype), hipMemcpyDeviceToDevice, s);
+        if (err != hipSuccess) rc = (int)err;
     }
     if (rc == MI_OK && cur != out->data && cur != in->data) {
         hipError_t err = hipMemcpyAsync(out->data, cur, (size_t)numel(out) * dtype_size(out->dtype), hipMemcpyDeviceToDevice, s);
@@ -2640,6 +2442,12 @@ int mi_spline_map_coordinates(const mi_array *coef, const mi_array *coords, cons
 int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const double *matrix, int order, int mode,
                                double cval, int npad, mi_stream stream)
 {
+    // r5: order | MI_SPLINE_SAMPLES_AXIS(d) (bit 8 + d): axis d of `coef` holds SAMPLES (mi_spline_prefilter skipped it) and the
+    // matrix maps it onto itself with an integral shift.  Only the kernels that evaluate such an axis as the single tap it is
+    // take the call (order 3, float32 coefficients, one such axis); anything else answers MI_ERR_UNSUPPORTED and the caller
+    // filters the axis after all (mi_spline_filter1d: the passes commute) and calls again without the flag.
+    const int ident = (order >> 8) & 0xff;
+    order &= 0xff;
     int rc = check_spline(coef, out, order, mode, npad);
     if (rc) return rc;
     MI_REQUIRE(matrix, MI_ERR_INVALID_ARG, "matrix is NULL");
@@ -2660,6 +2468,10 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
     dim3 grid;
     grid_for(nout, 256, &grid);
     hipStream_t s = resolve_stream(stream);
+    if (ident && !(n == 3 && coef->dtype == MI_F32 && order == 3 && (ident == 1 || ident == 2 || ident == 4))) {
+        set_error("no kernel for this transform with unfiltered axes (mask %d)", ident);
+        return MI_ERR_UNSUPPORTED;
+    }
     if (n > 3) {
         hipLaunchKernelGGL(spline_affine_nd_kernel, grid, dim3(256), 0, s, (const double *)coef->data, out->data, out->dtype, g,
                            nout, order, mode, cval, round_out, npad);
@@ -2671,7 +2483,7 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
         MI_REQUIRE(is_contiguous(out), MI_ERR_NOT_CONTIGUOUS, "needs a C-contiguous output");
         dim3 cgrid;
         MI_REQUIRE(cubic3_grid(out, &g, &cgrid), MI_ERR_UNSUPPORTED, "float32 cubic route: output too large");
-        bool diagonal = !g_cubic_diag_off;
+        bool diagonal = !g_cubic_diag_off && !ident;
         for (int d = 0; d < n; d++)
             for (int k = 0; k < n; k++)
                 if (d != k && matrix[d * (n + 1) + k] != 0.0) diagonal = false;
@@ -2742,8 +2554,9 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
                            mode, (float)cval, npad)
         if (!diagonal) {
             int zrc = MI_OK;
-            if (launch_cubic_zstream(coef, out, g, mode, cval, npad, s, &zrc)) return zrc;
-            if (launch_cubic_rowblend(coef, out, g, mode, cval, npad, s, &zrc)) return zrc;
+            if (ident != 4 && launch_cubic_zstream(coef, out, g, mode, cval, npad, ident, s, &zrc)) return zrc;
+            if ((ident == 0 || ident == 4) && launch_cubic_rowblend(coef, out, g, mode, cval, npad, ident == 4, s, &zrc)) return zrc;
+            if (ident) { set_error("no kernel for this transform with unfiltered axes (mask %d)", ident); return MI_ERR_UNSUPPORTED; }
         }
         note_kernel(diagonal ? "mi::cubic3_diag_f32_kernel (order-3 affine on float32 coefficients, diagonal matrix: tabulated taps)"
                              : "mi::cubic3_f32_kernel (order-3 affine on float32 coefficients: 16 x 16-byte gathers per voxel)");

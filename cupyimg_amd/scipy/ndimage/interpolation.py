@@ -57,7 +57,12 @@ def _float32_route(src, out_dtype, order, allow_float32):
             and src.ndim <= 3 and src.size < (1 << 28))
 
 
-def _to_coefficients(input, order, mode, cval, prefilter, f32=False, exact=False):
+_IDENT_AXES = True              # test hook: False = every axis is filtered and interpolated (the route before round 5)
+_SPLINE_SKIP_AXIS0 = 0x200      # csrc/interp.hip: spline_mode bit 9 + d leaves axis d unfiltered
+_SPLINE_SAMPLES_AXIS0 = 0x100   # order bit 8 + d: axis d of the coefficient array holds samples
+
+
+def _to_coefficients(input, order, mode, cval, prefilter, f32=False, exact=False, skip_axis=None):
     """(device array of B-spline coefficients, npad) for orders 2-5: float64, or float32
     on the float32 cubic route (the recursion itself always runs in double).
     SciPy pads by 12 samples for `nearest` / `grid-constant` before filtering;
@@ -75,7 +80,8 @@ def _to_coefficients(input, order, mode, cval, prefilter, f32=False, exact=False
     lib = S.lib()
     if prefilter:
         S.check(lib.mi_spline_prefilter(ctypes.byref(a), ctypes.byref(b), int(order),
-                                        _spline_mode_code(mode) | (_SPLINE_EXACT if exact else 0), npad, pad_mode, float(cval), None))
+                                        _spline_mode_code(mode) | (_SPLINE_EXACT if exact else 0)
+                                        | (0 if skip_axis is None else _SPLINE_SKIP_AXIS0 << skip_axis), npad, pad_mode, float(cval), None))
     else:
         S.check(lib.mi_spline_pad(ctypes.byref(a), ctypes.byref(b), npad, pad_mode, float(cval), None))
     return coef, npad
@@ -271,11 +277,38 @@ def _affine(input, m, out, order, mode, cval, prefilter, allow_float32=True):
     src = core.ascontiguousarray(input)
     lib = S.lib()
     if order > 1:
-        coef, npad = _to_coefficients(src, order, mode, cval, prefilter, _float32_route(src, out.dtype, order, allow_float32),
-                                      exact=out.dtype.kind in "iub")
+        f32 = _float32_route(src, out.dtype, order, allow_float32)
+        exact = out.dtype.kind in "iub"
+        # r5: an axis the matrix maps onto itself with an integral shift is evaluated at its samples, where the spline returns
+        # them: its prefilter pass and its taps cancel (SciPy's own `rotate` filters the two axes of the rotation plane only).
+        # The kernels that evaluate such an axis as ONE tap take it unfiltered (x: cubic3_rowblend_kernel -- `rotate` with the
+        # default axes; the stream axis of cubic3_zfactor_kernel -- `rotate(axes=(1, 2))` / `(0, 2)`); anything else refuses
+        # and the pass is made up for below.
+        nd = src.ndim
+        ident = None
+        if _IDENT_AXES and f32 and prefilter and nd == 3 and order == 3 and out._is_c_contiguous() and min(src.shape) > 1:
+            lin = m[:, :nd]
+            if np.count_nonzero(lin - np.diag(np.diag(lin))):          # diagonal matrices take the separable resampling passes
+                for d in (2, 0, 1):
+                    row = np.zeros(nd)
+                    row[d] = 1.0
+                    if np.array_equal(lin[d], row) and float(m[d, nd]).is_integer() and abs(m[d, nd]) < 2 ** 20:
+                        ident = d
+                        break
+        coef, npad = _to_coefficients(src, order, mode, cval, prefilter, f32, exact=exact, skip_axis=ident)
         if coef is src and core.shares_memory(out, src):
             coef = src.copy()
         ca_ = coef._desc()
+        if ident is not None:
+            b = out._desc()
+            rc = lib.mi_spline_affine_transform(ctypes.byref(ca_), ctypes.byref(b), mp, order | (_SPLINE_SAMPLES_AXIS0 << ident),
+                                                S.MODE_CODES[mode], float(cval), npad, None)
+            if rc == 0:
+                return out
+            if rc != S._lib.MI_ERR_UNSUPPORTED:
+                S.check(rc, ValueError)
+            # no single-tap kernel for this matrix: filter the axis after all (the passes commute)
+            S.check(lib.mi_spline_filter1d(ctypes.byref(ca_), ident, int(order), _spline_mode_code(mode), None))
 
         def launch_spline(dst):
             b = dst._desc()

@@ -407,7 +407,20 @@ int mi_affine_transform(const mi_array *in, const mi_array *out, const double *m
  * spline_mode | 0x100 (mi_spline_filter1d, mi_spline_prefilter): only the kernels whose
  * arithmetic is SciPy's operation for operation (no blocked recursion) -- pass it when the
  * interpolated result will be rounded to an integer dtype, where the last bit of a
- * coefficient decides exact .5 ties. */
+ * coefficient decides exact .5 ties.
+ * r5 -- axes that hold SAMPLES.  An affine transform that maps an axis onto itself with an
+ * integral shift evaluates the spline at the samples of that axis, where it returns them: the
+ * prefilter pass along the axis and the taps along it cancel (SciPy's `rotate` filters the two
+ * axes of the rotation plane only; the reference's `rotate`, interpolation.py:576-709, filters
+ * all of them -- the results agree to rounding).  mi_spline_prefilter with
+ * spline_mode | MI_SPLINE_SKIP_AXIS(d) leaves axis d unfiltered;
+ * mi_spline_affine_transform with order | MI_SPLINE_SAMPLES_AXIS(d) interpolates such an array
+ * (order 3, float32 coefficients, rank 3, ONE such axis: x -- `rotate` with the default axes --
+ * or the axis the streaming kernel walks along) and answers MI_ERR_UNSUPPORTED when no kernel
+ * evaluates the axis as a single tap: the caller then filters it after all
+ * (mi_spline_filter1d; the passes commute) and calls again without the flag. */
+#define MI_SPLINE_SKIP_AXIS(d) (0x200 << (d))
+#define MI_SPLINE_SAMPLES_AXIS(d) (0x100 << (d))
 int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mode, double cval,
                   mi_stream stream);
 int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mode, mi_stream stream);

@@ -99,33 +99,53 @@ class Cases:
         cd = self.gpu.asarray(coords)
         return (lambda o: self.ndi.map_coordinates(xd, cd, order=1, mode="constant", cval=0.25, output=o)), x.shape, np.float32, "map_coords3d_zstream_kernel"
 
-    # ---- order 3 on float32 coefficients (n_cubic^3; prefilter=False: the interpolation kernel alone)
-    def _cubic(self, plane, deg, step, kern, mode="constant"):
+    # ---- order 3 on float32 coefficients (n_cubic^3; prefilter=False: the interpolation kernel alone).  r4b = True: the
+    # 64-tap kernel of round 4 (cubic3_zstream_kernel, bit-identical to the gather kernel) instead of the r5 default
+    # (cubic3_zfactor_kernel: same staging, ring and waits, in-plane values once per input plane)
+    def _cubic(self, plane, deg, step, kern, mode="constant", r4b=False):
         n = self.n_cubic
         x, xd = self.vol((n, n, n), 5)
         M, off = _rot(plane, deg, n, step)
-        return (lambda o: self.ndi.affine_transform(xd, M, off, order=3, mode=mode, cval=0.25, prefilter=False, output=o)), x.shape, np.float32, kern
+        if r4b:
+            kern = kern.replace("cubic3_zfactor_kernel", "cubic3_zstream_kernel")
+
+        def fn(o):
+            self.lib.mi_debug_set_cubic_zfactor(0 if r4b else 1)
+            try:
+                self.ndi.affine_transform(xd, M, off, order=3, mode=mode, cval=0.25, prefilter=False, output=o)
+            finally:
+                self.lib.mi_debug_set_cubic_zfactor(1)
+        return fn, x.shape, np.float32, kern
 
     def case_cubic_zstream0_7(self):
-        return self._cubic((1, 2), 7.0, 1.0, "cubic3_zstream_kernel<0>")
+        return self._cubic((1, 2), 7.0, 1.0, "cubic3_zfactor_kernel<0>")
 
     def case_cubic_zstream0_7_step102(self):
-        return self._cubic((1, 2), 7.0, 1.02, "cubic3_zstream_kernel<0>")                # the BASELINE matrix: every 50th step fetches a plane late
+        return self._cubic((1, 2), 7.0, 1.02, "cubic3_zfactor_kernel<0>")                # the BASELINE matrix: every 50th step fetches a plane late
 
     def case_cubic_zstream0_30(self):
-        return self._cubic((1, 2), 30.0, 1.0, "cubic3_zstream_kernel<0>")
+        return self._cubic((1, 2), 30.0, 1.0, "cubic3_zfactor_kernel<0>")
 
     def case_cubic_zstream0_80_mirror(self):
-        return self._cubic((1, 2), 80.0, 0.97, "cubic3_zstream_kernel<0>", "mirror")
+        return self._cubic((1, 2), 80.0, 0.97, "cubic3_zfactor_kernel<0>", "mirror")
 
     def case_cubic_zstream1_7(self):
-        return self._cubic((0, 2), 7.0, 1.0, "cubic3_zstream_kernel<1>")
+        return self._cubic((0, 2), 7.0, 1.0, "cubic3_zfactor_kernel<1>")
 
     def case_cubic_zstream1_30(self):
-        return self._cubic((0, 2), 30.0, 1.02, "cubic3_zstream_kernel<1>")
+        return self._cubic((0, 2), 30.0, 1.02, "cubic3_zfactor_kernel<1>")
 
     def case_cubic_zstream1_80(self):
-        return self._cubic((0, 2), 80.0, 1.0, "cubic3_zstream_kernel<1>")
+        return self._cubic((0, 2), 80.0, 1.0, "cubic3_zfactor_kernel<1>")
+
+    def case_cubic_r4b_zstream0_7_step102(self):
+        return self._cubic((1, 2), 7.0, 1.02, "cubic3_zfactor_kernel<0>", r4b=True)
+
+    def case_cubic_r4b_zstream0_30(self):
+        return self._cubic((1, 2), 30.0, 1.0, "cubic3_zfactor_kernel<0>", r4b=True)
+
+    def case_cubic_r4b_zstream1_80(self):
+        return self._cubic((0, 2), 80.0, 1.0, "cubic3_zfactor_kernel<1>", r4b=True)
 
     def case_cubic_rowblend_7(self):
         return self._cubic((0, 1), 7.0, 1.0, "cubic3_rowblend_kernel")

@@ -93,7 +93,7 @@ def test_order3_default_rotate_and_affine_512(gpu, ndi, vol512):
     """r5: order 3 is the DEFAULT of `rotate` / `affine_transform` (the reference's interpolation.py:275,403,582).  Whole-volume
     legs for the two calls the r4b kernels were written for, each the last of a burst: `rotate(vol512, 7)` with every default
     (axes (1, 0): prefilter rows_lds + two strided passes, cubic3_rowblend_kernel; reshape=True, so the output is larger than
-    the input) and `affine_transform(order=3)` with the BASELINE matrix (cubic3_zstream_kernel<0>, step 1.02 along z).
+    the input) and `affine_transform(order=3)` with the BASELINE matrix (cubic3_zfactor_kernel<0>, step 1.02 along z).
     Tolerance 2e-5 . max(1, max|ref|): float32 coefficients and weights against SciPy's double (the reference's
     `allow_float32` route, interpolation.py:330-335)."""
     from cupyimg_amd import last_kernel
@@ -106,7 +106,7 @@ def test_order3_default_rotate_and_affine_512(gpu, ndi, vol512):
     del out
     M, off = fs.affine_case(fs.N_H)
     out = burst(lambda o: ndi.affine_transform(xd, M, off, order=3, output=o))
-    assert "cubic3_zstream_kernel<0>" in last_kernel(), last_kernel()
+    assert "cubic3_zfactor_kernel<0>" in last_kernel(), last_kernel()
     err = fs.whole_volume_affine_order3(x, M, off, out.get())
     assert err <= 2e-5, err
 

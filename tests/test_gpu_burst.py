@@ -158,14 +158,15 @@ def test_interpolation_kernels_under_load(gpu, ndi, lib):
 # r5: the kernels added after the first burst test (r4b) -- and one test for the whole class
 # ---------------------------------------------------------------------------------------------------------------------
 def test_cubic_kernels_under_load_512(gpu, ndi, lib):
-    """cubic3_zstream_kernel<0 / 1> (five-slot LDS-DMA ring, `vmcnt(2)` at the top of a step, late fetches) at 7 / 30 / 80
-    degrees and with the BASELINE matrix's step of 1.02 planes, and cubic3_rowblend_kernel, on 512^3 (full tiles: the `wide`
-    path; four z chunks per tile column): the last of BURST back-to-back launches is bit-identical to cubic3_f32_kernel (the
-    L1-gather kernel, which counts nothing by hand)."""
+    """cubic3_zfactor_kernel<0 / 1> (r5) and cubic3_zstream_kernel<0 / 1> (r4b) -- the same five-slot LDS-DMA ring, `vmcnt(2)` at
+    the top of a step, late fetches -- at 7 / 30 / 80 degrees and with the BASELINE matrix's step of 1.02 planes, and
+    cubic3_rowblend_kernel, on 512^3 (full tiles: the `wide` path; four z chunks per tile column): the last of BURST
+    back-to-back launches against cubic3_f32_kernel (the L1-gather kernel, which counts nothing by hand) -- bit-identical for
+    the r4b and row-blend kernels, 1e-6 max-norm for the factored kernel (another order of the sums: csrc/cubic_fast.hip)."""
     from helpers.burst_cases import Cases
     cases = Cases(gpu, ndi, lib, n_cubic=512)
     names = [n for n in cases.names() if n.startswith("case_cubic_")]
-    assert len(names) >= 8
+    assert len(names) >= 11
     for name in names:
         fn, shape, dtype, kern = getattr(cases, name)()
         ref = gpu.empty(shape, dtype)
@@ -178,15 +179,16 @@ def test_cubic_kernels_under_load_512(gpu, ndi, lib):
         finally:
             lib.mi_debug_set_cubic_zstream(1); lib.mi_debug_set_cubic_rowblend(1)
         del ref
-        check(gpu, fn, shape, dtype, want, True, kern)
+        check(gpu, fn, shape, dtype, want if "zfactor" not in kern else want.astype(np.float64), "zfactor" not in kern, kern)
         del fn, want
 
 
 def test_spline_prefilter_lds_rows_under_load(gpu, ndi, lib):
     """spline_filter_rows_lds_kernel (lines loaded by LDS-DMA, `vmcnt(0)` before the recursion): 512- and 536-sample lines
-    (the padded modes' length), orders 2 - 5, float32 and float64 coefficients -- last of a burst bit-identical to the tiled
-    kernel of round 2 (spline_filter_rows_kernel: plain loads and stores).  The r5 one-sweep kernels are switched off for
-    this test (they would take orders 2 / 3)."""
+    (the padded modes' length), orders 2 - 5, float32 and float64 coefficients -- last of a burst bit-identical to the
+    one-thread-per-line kernel (spline_filter1d_kernel: plain loads and stores, the same line code; the tiled kernel of round 2
+    applies the gain at the other end and agrees to 1e-14 only).  The r5 one-sweep kernels are switched off for this test (they
+    would take orders 2 / 3)."""
     rng = np.random.default_rng(11)
     lib.mi_debug_set_spline_fast(0)
     try:
@@ -195,11 +197,11 @@ def test_spline_prefilter_lds_rows_under_load(gpu, ndi, lib):
             xd = gpu.asarray(x)
             for order in (2, 3, 4, 5):
                 for mode in (("mirror", "reflect") if order == 3 else ("mirror",)):
-                    lib.mi_debug_set_spline_rows_lds(0)
+                    lib.mi_debug_set_spline_rows(0)
                     try:
                         want = ndi.spline_filter1d(xd, order, axis=-1, output=dt, mode=mode).get()
                     finally:
-                        lib.mi_debug_set_spline_rows_lds(1)
+                        lib.mi_debug_set_spline_rows(1)
                     out = gpu.empty(x.shape, dt)
                     for r in range(ROUNDS):
                         for _ in range(BURST):
@@ -217,7 +219,8 @@ def test_strict_wait_build_is_bit_identical_under_load(gpu):
     """ONE test for every hand-counted wait in the tree: libmi355img_strict.so is the same source with each
     `s_waitcnt vmcnt(n)`, n > 0, compiled as vmcnt(0) (csrc/common.hpp MI_VMCNT, `python -m cupyimg_amd._build --strict`).  Both
     libraries run the burst cases of tests/helpers/burst_cases.py -- sep3d_long3 / long, mm3f32_long, affine zrect / zstream
-    (both stream axes), map_coordinates zstream, cubic3_zstream<0 / 1> incl. the late-fetch step, row-blend -- in their own
+    (both stream axes), map_coordinates zstream, cubic3_zfactor<0 / 1> and cubic3_zstream<0 / 1> incl. the late-fetch step,
+    row-blend -- in their own
     processes, BURST launches back to back, twice over; the SHA-256 of every last output must agree.  A count that is an
     operation short shows here whichever kernel it is in, also in kernels added later (they only have to use MI_VMCNT)."""
     import json
@@ -242,7 +245,7 @@ def test_strict_wait_build_is_bit_identical_under_load(gpu):
             assert proc.returncode == 0, proc.stdout[-3000:]
             res[tag] = json.load(open(out))
     assert res["strict"]["library"].endswith("libmi355img_strict.so") and res["product"]["library"].endswith("libmi355img.so")
-    assert len(res["product"]["cases"]) >= 18
+    assert len(res["product"]["cases"]) >= 20
     for name, c in res["product"]["cases"].items():
         s = res["strict"]["cases"][name]
         assert c["expected"] in c["kernel"], (name, c["kernel"])

@@ -37,6 +37,7 @@ def test_stream_and_scan_kernels_every_line_length(gpu, ndi, lib):
     float32 samples read into float64 coefficients.  Forced with the knob at 2 (the default rule wants >= 16384 lines)."""
     rng = np.random.default_rng(5)
     lib.mi_debug_set_spline_fast(2)
+    lib.mi_debug_set_spline_chunk(-1)                 # few long lines are the blocked kernels' by default: not here
     try:
         lengths = [64, 65, 67, 68, 76, 84, 85, 96, 100, 104, 113, 124, 128, 132, 133, 140, 141, 197, 252, 256, 260, 300, 512, 516, 1020, 1024, 2048]
         for n in lengths:
@@ -64,6 +65,7 @@ def test_stream_and_scan_kernels_every_line_length(gpu, ndi, lib):
                 assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max(), (n, axis)
     finally:
         lib.mi_debug_set_spline_fast(1)
+        lib.mi_debug_set_spline_chunk(0)
 
 
 def test_volume_prefilter_takes_the_fast_kernels_and_matches_scipy(gpu, ndi, lib):
@@ -95,6 +97,7 @@ def test_volume_prefilter_takes_the_fast_kernels_and_matches_scipy(gpu, ndi, lib
     ndi.spline_filter(vd, 3)
     assert _took("spline_rows_scan_kernel")           # the last pass of the default call
     for order, mode in ((4, "mirror"), (5, "reflect"), (3, "grid-wrap")):
+        ndi.uniform_filter(vd, 3)                      # something else in last_kernel() (the sequential passes leave no note)
         ndi.spline_filter(vd, order, mode=mode)
         assert not _took("spline_rows_scan_kernel") and not _took("spline_stream_kernel"), (order, mode)
     # the bit-exact request (behind integer outputs: SciPy's arithmetic operation for operation decides exact .5 ties) never
@@ -145,6 +148,58 @@ def test_default_order3_calls_on_a_volume_match_scipy(gpu, ndi):
     got = ndi.affine_transform(vd, M, off).get()
     ref = sndi.affine_transform(v64, M, off)
     assert np.abs(got - ref).max() <= tol(ref)
+
+
+def test_axes_that_hold_samples(gpu, ndi, lib):
+    """r5: a rotation leaves the third axis to itself (unit step, integral shift): the spline is evaluated AT the samples of
+    that axis, its prefilter pass and its taps cancel.  `rotate` with the default axes takes cubic3_rowblend_kernel with one
+    load per row ("x holds samples"), rotations in the other two planes cubic3_zfactor_kernel with ONE plane per step;
+    results against SciPy (whose own rotate filters the rotation plane only) and against the route that filters and
+    interpolates every axis (interpolation._IDENT_AXES = False): float32 rounding.  Padded modes, output shapes that differ,
+    shifts along the identity axis that push planes / columns outside; a matrix no single-tap kernel takes (identity axis
+    but |step| > 1.3 in the plane ... ) falls back by filtering the axis after all."""
+    from cupyimg_amd import last_kernel
+    from cupyimg_amd.scipy.ndimage import interpolation as I
+    rng = np.random.default_rng(21)
+    v = rng.standard_normal((150, 140, 164)).astype(np.float32)
+    vd = gpu.asarray(v)
+    v64 = v.astype(np.float64)
+    for axes, frag in (((1, 0), "x holds samples"), ((2, 1), "cubic3_zfactor_kernel<0>"), ((2, 0), "cubic3_zfactor_kernel<1>")):
+        for mode in ("constant", "mirror", "nearest", "reflect"):
+            for reshape in (False, True):
+                got = ndi.rotate(vd, 17.0, axes=axes, reshape=reshape, mode=mode, cval=0.5).get()
+                assert frag in last_kernel(), (axes, mode, last_kernel())
+                ref = sndi.rotate(v64, 17.0, axes=axes, reshape=reshape, mode=mode, cval=0.5)
+                assert got.shape == ref.shape
+                assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (axes, mode, reshape, np.abs(got - ref).max())
+                I._IDENT_AXES = False
+                try:
+                    full = ndi.rotate(vd, 17.0, axes=axes, reshape=reshape, mode=mode, cval=0.5).get()
+                finally:
+                    I._IDENT_AXES = True
+                assert "holds samples" not in last_kernel()
+                assert np.abs(got - full).max() <= 4e-6 * max(1.0, np.abs(full).max()), (axes, mode, reshape, np.abs(got - full).max())
+    # integral shifts along the identity axis (planes / columns pushed outside), another output shape
+    a = np.deg2rad(-9.0); c, s_ = np.cos(a), np.sin(a)
+    for d, M in ((2, np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]])), (0, np.array([[1.0, 0, 0], [0, c, -s_], [0, s_, c]])), (1, np.array([[c, 0, -s_], [0, 1.0, 0], [s_, 0, c]]))):
+        for shift in (-7.0, 5.0):
+            off = np.array([3.3, -2.1, 4.7]); off[d] = shift
+            osh = (160, 150, 172)
+            got = ndi.affine_transform(vd, M, off, output_shape=osh, mode="constant", cval=-1.0).get()
+            assert ("holds samples" in last_kernel()) or ("cubic3_zfactor_kernel" in last_kernel()), last_kernel()
+            ref = sndi.affine_transform(v64, M, off, output_shape=osh, mode="constant", cval=-1.0)
+            assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (d, shift, np.abs(got - ref).max())
+    # a fractional shift along the axis: no identity, the ordinary route
+    M = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]])
+    got = ndi.affine_transform(vd, M, np.array([1.0, 2.0, 0.5])).get()
+    assert "holds samples" not in last_kernel()
+    ref = sndi.affine_transform(v64, M, np.array([1.0, 2.0, 0.5]))
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    # identity axis, but an in-plane scale the streaming kernels refuse (rows too wide for the rectangle): the axis is filtered after all
+    M = np.array([[1.0, 0, 0], [0, 2.6 * c, -2.6 * s_], [0, 2.6 * s_, 2.6 * c]])
+    got = ndi.affine_transform(vd, M, np.array([0.0, 5.0, 9.0])).get()
+    ref = sndi.affine_transform(v64, M, np.array([0.0, 5.0, 9.0]))
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
 def test_prefilter_passes_under_load_512(gpu, ndi, lib):

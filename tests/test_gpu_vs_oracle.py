@@ -1903,16 +1903,42 @@ def test_affine_zstream_sheared_window_all_angles(gpu, ndi):
     assert took >= len(cases), (took, len(cases))          # the streaming kernel took (at least) one tile height of every case
 
 
-def test_cubic_affine_zstream_in_plane(gpu, ndi):
+@pytest.mark.parametrize("zfactor", [1, 0])
+def test_cubic_affine_zstream_in_plane(gpu, ndi, zfactor):
     """r4b: order-3 affine transforms on float32 coefficients whose matrix leaves axis 0 to itself (`rotate(volume, a,
     axes=(1, 2))` with scipy's DEFAULT order) stream along z (cubic3_zstream_kernel: planes staged in LDS once per tile, a
     ring of five).  Bit-identical to the gather kernel (cubic3_f32_kernel) in every mode -- taps beyond the array through
     the rectangle (reflect / mirror / nearest / constant / wrap), through the gather path of a wave (grid-constant's cval
     taps, grid-wrap's far side, planes that clash in the ring) --, with steps along z of both signs and below one, output
-    shapes that differ from the input's, partial tiles, non-finite coefficients; and within float32 accuracy of scipy."""
+    shapes that differ from the input's, partial tiles, non-finite coefficients; and within float32 accuracy of scipy.
+    r5, zfactor = 1 (the default): cubic3_zfactor_kernel evaluates the in-plane part once per INPUT plane and blends four
+    values per voxel -- another order of the sums, so it agrees with the gather kernel to float32 rounding (2e-6 of the
+    coefficient range) instead of bit for bit, with the SAME set of non-finite voxels; zfactor = 0 is the r4b kernel."""
     import scipy.ndimage as sndi
     from cupyimg_amd import _lib, last_kernel
     lib = _lib.load()
+    lib.mi_debug_set_cubic_zfactor(zfactor)
+    try:
+        _cubic_zstream_in_plane_body(gpu, ndi, lib, "cubic3_zfactor_kernel" if zfactor else "cubic3_zstream_kernel", not zfactor)
+    finally:
+        lib.mi_debug_set_cubic_zfactor(1)
+
+
+def _same_cubic(got, want, exact):
+    if exact:
+        return np.array_equal(got, want, equal_nan=True)
+    fin = np.isfinite(want)
+    if not np.array_equal(fin, np.isfinite(got)):
+        return False
+    if not np.array_equal(np.isnan(got), np.isnan(want)):
+        return False
+    scale = max(1.0, float(np.abs(want[fin]).max())) if fin.any() else 1.0
+    return bool(np.abs(got[fin] - want[fin]).max() <= 2e-6 * scale) and np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)])
+
+
+def _cubic_zstream_in_plane_body(gpu, ndi, lib, KERN, exact):
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
     rng = np.random.default_rng(4242)
     took = 0
     for shape, oshape in (((40, 90, 152), None), ((33, 70, 132), (48, 70, 132)), ((20, 64, 64), (20, 100, 200)), ((64, 64, 64), None), ((37, 81, 100), (41, 97, 131))):
@@ -1937,10 +1963,10 @@ def test_cubic_affine_zstream_in_plane(gpu, ndi):
                     lib.mi_debug_set_cubic_zstream(1 + 4 + 8)          # any angle, and the grid modes (not taken by default)
                     try:
                         got = ndi.affine_transform(xd, M, off, **kw).get()
-                        took += "cubic3_zstream_kernel" in last_kernel()
+                        took += KERN in last_kernel()
                     finally:
                         lib.mi_debug_set_cubic_zstream(1)
-                    assert np.array_equal(got, want, equal_nan=True), (shape, osh, deg, m00, mode, prefilter, last_kernel()[:40], int(np.sum(got != want)))
+                    assert _same_cubic(got, want, exact), (shape, osh, deg, m00, mode, prefilter, last_kernel()[:40], int(np.sum(got != want)))
                     if prefilter:
                         ref = sndi.affine_transform(x.astype(np.float64), M, off, output_shape=osh, order=3, mode=mode, cval=0.5)
                         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (shape, deg, mode)
@@ -1949,8 +1975,8 @@ def test_cubic_affine_zstream_in_plane(gpu, ndi):
     x = rng.standard_normal((40, 90, 152)).astype(np.float32); xd = gpu.asarray(x)
     a = np.deg2rad(21.0); M = np.array([[1.0, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
     off = np.array([0.0, 20.0, -14.0])
-    for Mg, og, name in ((np.array([[np.cos(a), 0, -np.sin(a)], [0, 0.9, 0], [np.sin(a), 0, np.cos(a)]]), np.array([9.0, 2.0, -5.0]), "cubic3_zstream_kernel<1>"),
-                         (M, off, "cubic3_zstream_kernel<0>")):
+    for Mg, og, name in ((np.array([[np.cos(a), 0, -np.sin(a)], [0, 0.9, 0], [np.sin(a), 0, np.cos(a)]]), np.array([9.0, 2.0, -5.0]), KERN + "<1>"),
+                         (M, off, KERN + "<0>")):
         want = ndi.affine_transform(xd, Mg, og, order=3, prefilter=False).get()
         assert name in last_kernel(), last_kernel()
         lib.mi_debug_set_cubic_zstream(3)
@@ -1958,7 +1984,7 @@ def test_cubic_affine_zstream_in_plane(gpu, ndi):
             got = ndi.affine_transform(xd, Mg, og, order=3, prefilter=False).get()
         finally:
             lib.mi_debug_set_cubic_zstream(1)
-        assert np.array_equal(got, want)
+        assert _same_cubic(got, want, exact)
     # non-finite coefficients stay inside their 4 x 4 x 4 window in both kernels alike
     x[5, 40, 70] = np.inf; x[30, 10, 100] = np.nan
     xd = gpu.asarray(x)
@@ -1968,7 +1994,7 @@ def test_cubic_affine_zstream_in_plane(gpu, ndi):
         want = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
     finally:
         lib.mi_debug_set_cubic_zstream(1)
-    assert np.array_equal(got, want, equal_nan=True)
+    assert _same_cubic(got, want, exact)
     assert np.isfinite(got).sum() > 0.99 * got.size
     # the defaults: a quarter turn (LDS bank conflicts down the columns) and the grid modes stay with the gather kernel
     a = np.deg2rad(90.0); M9 = np.array([[1.0, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
@@ -1977,11 +2003,11 @@ def test_cubic_affine_zstream_in_plane(gpu, ndi):
     ndi.affine_transform(xd, M, off, order=3, prefilter=False, mode="grid-wrap")
     assert "cubic3_f32_kernel" in last_kernel()
     ndi.affine_transform(xd, M, off, order=3, prefilter=False, mode="reflect")
-    assert "cubic3_zstream_kernel" in last_kernel()
+    assert KERN in last_kernel()
     # a matrix that couples axis 0, a diagonal one and a float64 array are not taken
     M2 = M.copy(); M2[0, 1] = 0.01
     ndi.affine_transform(xd, M2, off, order=3, prefilter=False)
-    assert "cubic3_zstream_kernel" not in last_kernel()
+    assert KERN not in last_kernel()
 
 
 def test_cubic_affine_rowblend_default_rotate(gpu, ndi):
@@ -1990,6 +2016,17 @@ def test_cubic_affine_rowblend_default_rotate(gpu, ndi):
     uniform row base (cubic3_rowblend_kernel).  Bit-identical to the gather kernel in every mode, for shifts along x of
     both signs that push columns outside, rows longer than a wave's 512 voxels, output shapes that differ from the
     input's; within float32 accuracy of SciPy; `rotate` with the defaults goes through it."""
+    # (r5: with prefilter=True the x axis is now left unfiltered and read as one tap -- tests/test_gpu_spline_fast.py::
+    # test_axes_that_hold_samples; the bit-identity to the gather kernel below is that of the FULL route: every axis filtered)
+    from cupyimg_amd.scipy.ndimage import interpolation as _I
+    _I._IDENT_AXES = False
+    try:
+        _rowblend_full_route_body(gpu, ndi)
+    finally:
+        _I._IDENT_AXES = True
+
+
+def _rowblend_full_route_body(gpu, ndi):
     import scipy.ndimage as sndi
     from cupyimg_amd import _lib, last_kernel
     lib = _lib.load()
