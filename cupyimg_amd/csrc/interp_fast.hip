@@ -464,10 +464,14 @@ map_coords3d_c1_kernel(const float *__restrict__ in, const float *__restrict__ c
 // Transforms whose box exceeds that budget (large rotations about z / y with this tile, down-scaling by > 2) keep the
 // L1 gather kernel -- the choice is made on the host from the matrix.
 // ---------------------------------------------------------------------------
-constexpr int kLdsTZ = 8;                                   // tile: TX x (512 / TX) x 8 output voxels, TX = 64 or 32
-constexpr int kLdsBoxBytesMax = 36 * 1024;                  // box budget per workgroup: three or four workgroups per CU.  Bigger
-                                                            // boxes (amplification > ~2.2, two workgroups per CU) measured SLOWER
-                                                            // than the L1 gathers (config D' with the 64-wide tile: 443 vs 414 us)
+constexpr int kLdsVox = 4096;                               // output voxels per tile: TX x TY x (4096 / (TX TY)): 64 x 8 x 8, 32 x 16 x 8, 16 x 32 x 8,
+                                                            // and (r5) the cube 16 x 16 x 16, whose bounding box under a rotation about a
+                                                            // general axis is the smallest of all (37 KiB at 10 degrees about (1, 1, 1)
+                                                            // against 46 - 77 KiB: profiles/r5_affine_general.txt)
+constexpr int kLdsBoxBytesMax = 64 * 1024;                  // box budget per workgroup: two workgroups per CU.  (r3 / r4: 36 KiB -- with the
+                                                            // 64-wide tile a bigger box lost to the L1 gathers on config D'; with the cube
+                                                            // it wins up to ~25 degrees, where the gathers have fallen to 0.2 of the roofline.)
+Knob g_affine_box_kib{0};                                   // test hook: box budget in KiB (0 = kLdsBoxBytesMax)
 
 struct LdsAffineParams {
     FastInterpParams f;
@@ -483,7 +487,7 @@ struct LdsAffineParams {
     int dbg;                 // tuning ablations (0 in production): 1 no box DMA, 2 no interpolation (stores only), 4 no stores
 };
 
-constexpr int kLdsRoundsMax = 5;                            // staging rounds of 512 chunks (8 KiB) a box can take
+constexpr int kLdsRoundsMax = 16;                           // staging rounds of 512 chunks (8 KiB) a box can take
 
 // the same with a scalar byte offset added to every lane's
 __device__ __forceinline__ void dma_16s(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_base)
@@ -514,12 +518,14 @@ __device__ __forceinline__ void dma_16(const __amdgpu_buffer_rsrc_t rsrc, unsign
         : "memory");
 }
 
-template <int TX>
+template <int TX, int TY>
 __global__ void __launch_bounds__(512)
 affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const LdsAffineParams q)
 {
     constexpr int RW = 64 / TX;              // output rows per wave
-    constexpr int TY = 8 * RW, TZ = kLdsTZ;
+    constexpr int WY = TY / RW;              // waves along y; the other 8 / WY along z, eight planes each
+    constexpr int TZ = kLdsVox / (TX * TY);
+    static_assert(TY % RW == 0 && 8 % WY == 0 && TZ == 8 * (8 / WY), "tile = 8 waves x 64 lanes x 8 planes");
     extern __shared__ __attribute__((aligned(16))) char smem_lds[];
     const FastInterpParams &p = q.f;
     float *box = reinterpret_cast<float *>(smem_lds);
@@ -551,7 +557,8 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
             rel[j] = ch < (unsigned)q.nchunks ? rz * plane_b + ry * row_b + c4 * 16u : 0x80000000u;
         }
     }
-    const int yrow = RW * wave + yy;
+    const int wy = wave % WY, wz = wave / WY;
+    const int yrow = RW * wy + yy;
     const double dx = (double)(x0w + lx);
     const double xz_ = p.m[2] * dx, xy_ = p.m[6] * dx, xx_ = p.m[10] * dx;
     const int plane_f = q.by * q.bx;
@@ -605,8 +612,8 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
             if (ry >= q.by) { ry -= q.by; rz++; }
         }
     }
-    if (tid < TZ * TY * 3) {
-        const int rr = tid / 3, a = tid - 3 * rr;                  // rr = TY k + row  <->  plane z0 + k, row y0 + row
+    for (int e = tid; e < TZ * TY * 3; e += 512) {
+        const int rr = e / 3, a = e - 3 * rr;                      // rr = TY k + row  <->  plane z0 + k, row y0 + row
         ptab[rr][a] = p.m[4 * a] * (double)(z0 + rr / TY) + p.m[4 * a + 1] * (double)(y0 + rr % TY);
     }
     if (more && tid < 3) org[slot][tid] = origin(tz + (int)gridDim.z, tid);
@@ -622,7 +629,7 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
         if (!(q.dbg & 2))
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-            const int k = 4 * bt + kk;
+            const int k = 8 * wz + 4 * bt + kk;
             const int rr = TY * k + yrow;
             const C1Split sz = c1_split((ptab[rr][0] + xz_) + p.m[3], p.nz);
             const C1Split sy = c1_split((ptab[rr][1] + xy_) + p.m[7], p.ny);
@@ -653,14 +660,14 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int i = lane >> 4, c = lane & 15;                 // plane of the batch, 16-byte chunk of the wave's 64 voxels
             const f32x4n v = *reinterpret_cast<const f32x4n *>(tile + i * 64 + 4 * c);
-            const int orow = y0 + RW * wave + (4 * c) / TX, ox4 = x0w + ((4 * c) & (TX - 1));
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)(z0 + 4 * bt + i) * p.oy + orow) * p.ox + ox4));
+            const int orow = y0 + RW * wy + (4 * c) / TX, ox4 = x0w + ((4 * c) & (TX - 1));
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4n *>(out + ((size_t)(z0 + 8 * wz + 4 * bt + i) * p.oy + orow) * p.ox + ox4));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
             const int x = x0w + lx, y = y0 + yrow;
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
-                const int z = z0 + 4 * bt + kk;
+                const int z = z0 + 8 * wz + 4 * bt + kk;
                 if (x < p.ox && y < p.oy && z < p.oz) __builtin_nontemporal_store(r[kk], out + ((size_t)z * p.oy + y) * p.ox + x);
             }
         }
@@ -673,14 +680,15 @@ affine3d_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const
     }
 }
 
+extern "C" int mi_debug_set_affine_box_kib(int k) { g_affine_box_kib = k; return MI_OK; }
 Knob g_affine_dbg{0};     // tuning ablations of affine3d_lds_kernel, see LdsAffineParams::dbg
 Knob g_affine_gz{0};      // test hook: workgroups along z of affine3d_lds_kernel (0 = auto; the number of z tiles = one tile per workgroup)
 
 // box dimensions of a TZ x TY x TX output tile under the matrix (upper bound from |M|); returns the number of floats,
 // or 0 when the box does not fit the LDS budget
-static long long lds_affine_plan(const FastInterpParams &p, int tx, LdsAffineParams *q)
+static long long lds_affine_plan(const FastInterpParams &p, int tx, int ty, LdsAffineParams *q)
 {
-    const int T[3] = {kLdsTZ - 1, 8 * (64 / tx) - 1, tx - 1};
+    const int T[3] = {kLdsVox / (tx * ty) - 1, ty - 1, tx - 1};
     int dim[3];
     for (int a = 0; a < 3; a++) {
         double ext = 0.0;
@@ -695,7 +703,8 @@ static long long lds_affine_plan(const FastInterpParams &p, int tx, LdsAffinePar
     for (int a = 0; a < 2; a++) if (dim[a] > n[a]) dim[a] = n[a];
     if (dim[2] > ((n[2] + 3) & ~3) + 4) dim[2] = ((n[2] + 3) & ~3) + 4;
     const long long floats = (long long)dim[0] * dim[1] * dim[2];
-    if (floats * 4 > kLdsBoxBytesMax || (floats / 4 + 511) / 512 > kLdsRoundsMax) return 0;
+    const long long budget = (g_affine_box_kib % 1000) > 0 ? (long long)(g_affine_box_kib % 1000) * 1024 : (long long)kLdsBoxBytesMax;
+    if (floats * 4 > budget || (floats / 4 + 511) / 512 > kLdsRoundsMax) return 0;
     q->f = p;
     q->bz = dim[0]; q->by = dim[1]; q->bx = dim[2];
     q->nchunks = (int)(floats / 4);
@@ -715,10 +724,10 @@ static long long lds_affine_plan(const FastInterpParams &p, int tx, LdsAffinePar
     return floats;
 }
 
-template <int TX>
+template <int TX, int TY>
 static int launch_affine_lds(const float *in, float *out, const LdsAffineParams &q, hipStream_t s)
 {
-    constexpr int TY = 8 * (64 / TX);
+    constexpr int kLdsTZ = kLdsVox / (TX * TY);
     const FastInterpParams &p = q.f;
     // Workgroups along z: one per tile by default.  The kernel can walk several tiles of a column (gz < ntz), which
     // measured slower on config D' (346 us with one tile each; 360-405 us with 3 ... 12 tiles each: the tiles of a
@@ -732,11 +741,12 @@ static int launch_affine_lds(const float *in, float *out, const LdsAffineParams 
     const size_t lds = (((size_t)q.nchunks * 16 + 8191) & ~(size_t)8191) + kLdsTZ * TY * 3 * sizeof(double) + 8 * 256 * sizeof(float) + 2 * 4 * sizeof(int);
     static PerDeviceOnce attr_done;
     if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)affine3d_lds_kernel<TX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)affine3d_lds_kernel<TX, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_done = true;
     }
-    note_kernel("mi::affine3d_lds_kernel<%d> grid=%ux%ux%u (order-1 affine, %d x %d x %d box staged per tile)", TX, gl.x, gl.y, gl.z, q.bz, q.by, q.bx);
-    hipLaunchKernelGGL(affine3d_lds_kernel<TX>, gl, dim3(512), lds, s, in, out, q);
+    note_kernel("mi::affine3d_lds_kernel<%d,%d> grid=%ux%ux%u (order-1 affine, tile %d x %d x %d, %d x %d x %d box staged per tile)", TX, TY, gl.x, gl.y, gl.z,
+                TX, TY, kLdsTZ, q.bz, q.by, q.bx);
+    hipLaunchKernelGGL((affine3d_lds_kernel<TX, TY>), gl, dim3(512), lds, s, in, out, q);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -2633,11 +2643,34 @@ int affine_transform_fast(const mi_array *in, const mi_array *out, const double 
             RowBlendParams rq;
             if (rowblend_plan(p, &rq)) return launch_affine_rowblend((const float *)in->data, (float *)out->data, rq, s);
         }
-        LdsAffineParams q64, q32;
-        const long long f64 = lds_affine_plan(p, 64, &q64), f32 = (p.ox & 31) == 0 || p.ox > 256 ? lds_affine_plan(p, 32, &q32) : 0;
+        // the tile shape with the smallest box: 64 x 8 x 8, 32 x 16 x 8, and for matrices that couple all three axes the
+        // cube 16 x 16 x 16 / 16 x 32 x 8 (r5)
+        LdsAffineParams qs[4];
+        long long fl[4];
+        fl[0] = lds_affine_plan(p, 64, 8, &qs[0]);
+        fl[1] = (p.ox & 31) == 0 || p.ox > 256 ? lds_affine_plan(p, 32, 16, &qs[1]) : 0;
+        fl[2] = (p.ox & 15) == 0 || p.ox > 256 ? lds_affine_plan(p, 16, 16, &qs[2]) : 0;
+        fl[3] = (p.ox & 15) == 0 || p.ox > 256 ? lds_affine_plan(p, 16, 32, &qs[3]) : 0;
+        int best = -1;
+        if (g_affine_box_kib >= 1000) {              // test hook: + 1000 x (1 + shape) forces a tile shape
+            const int force = g_affine_box_kib / 1000 - 1;
+            for (int i = 0; i < 4; i++) if (i != force) fl[i] = 0;
+        }
+        // the smaller box of the two wide tiles when one fits; the cube (then 16 x 32 x 8) only when neither does: at equal
+        // LDS occupancy the 16-wide tiles lose 10-15 % to their 64-byte store rows (profiles/r5_affine_general.txt: 10
+        // degrees about (1, 1, 1): 416 us with 32 x 16 x 8 / 46 KiB, 480 us with the cube / 37 KiB), and every shape collapses
+        // once its box leaves room for one workgroup per CU only (780 - 930 us: the budget stays at 64 KiB)
+        if (fl[0] && (!fl[1] || fl[0] <= fl[1])) best = 0;
+        else if (fl[1]) best = 1;
+        else if (fl[2]) best = 2;
+        else if (fl[3]) best = 3;
         int rc = MI_ERR_UNSUPPORTED;
-        if (f64 && (!f32 || f64 <= f32)) rc = launch_affine_lds<64>((const float *)in->data, (float *)out->data, q64, s);
-        else if (f32) rc = launch_affine_lds<32>((const float *)in->data, (float *)out->data, q32, s);
+        const float *ip_ = (const float *)in->data;
+        float *op_ = (float *)out->data;
+        if (best == 0) rc = launch_affine_lds<64, 8>(ip_, op_, qs[0], s);
+        else if (best == 1) rc = launch_affine_lds<32, 16>(ip_, op_, qs[1], s);
+        else if (best == 2) rc = launch_affine_lds<16, 16>(ip_, op_, qs[2], s);
+        else if (best == 3) rc = launch_affine_lds<16, 32>(ip_, op_, qs[3], s);
         if (rc != MI_ERR_UNSUPPORTED) return rc;
     }
     if (mode == MI_MODE_CONSTANT && order == 1 && var && !p.two_d && in->dtype == MI_F32 && (p.ox & 3) == 0) {

@@ -64,6 +64,7 @@ int mi_debug_set_map_zchunks(int k);          /* its z chunks (0 = planner) */
 int mi_debug_set_map_zvariant(int k);         /* its instance: 10 x voxels per thread + planes of coordinates in flight (81, 82, 41; 0 = default) */
 int mi_debug_set_affine_zstream(int k);       /* z-streaming affine kernel (axis 0 decoupled): 0 off, 1 auto, 32 / 64 tile height */
 int mi_debug_set_affine_zchunks(int k);       /* its z chunks (0 = planner) */
+int mi_debug_set_affine_box_kib(int k);       /* LDS-staged affine kernel: box budget per workgroup in KiB (0 = default 64; 36 = the r3 / r4 rule) */
 int mi_debug_set_affine_dbg(int k);           /* LDS-staged affine kernel ablations: 1 no box DMA, 2 no interpolation, 4 no stores (timing only) */
 int mi_debug_set_interp_c1(int k);            /* csrc/interp_fast.hip: 0 = round-2 order-1 constant-mode kernels, 1 = r3 (default), 2 = r3, narrow stores */
 int mi_debug_set_spline_gain_first(int on);

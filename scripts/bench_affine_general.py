@@ -6,7 +6,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import cupyimg_amd as ca
-from cupyimg_amd import last_kernel
+from cupyimg_amd import last_kernel, _lib
+lib = _lib.load()
 from cupyimg_amd.scipy import ndimage as ndi
 from helpers import fullsize as fs
 from bench_configs import timeit
@@ -18,8 +19,20 @@ def rot(axis, deg):
     K = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0]])
     return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
 for axis in ((1, 1, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0)):
-    for deg in (1, 2, 3, 5, 7, 10, 15, 20, 30, 45):
+    for deg in ((2, 5, 7, 10, 15, 20, 25, 30, 45) if "--quick" not in sys.argv else (7, 15, 30)):
         M = rot(axis, deg)
         off = ctr - M @ ctr + np.array([0.5, -1.25, 2.0])
+        row = {"axis": axis, "deg": deg}
+        for kib, name in ((36, "r4 rule (36 KiB boxes, 64 / 32-wide tiles)"), (0, "r5")):
+            # (r5: cube tiles and 64 KiB boxes; the r4 rule is emulated by the budget alone -- the cube then rarely wins)
+            lib.mi_debug_set_affine_box_kib(kib)
+            s_, f = timeit(lambda: ndi.affine_transform(xd, M, off, order=1, mode="constant", output=out), 10)
+            row[name + " us"] = round(s_ * 1e6, 1)
+            row[name + " frac"] = round(8 * n ** 3 / s_ / 8e12, 3)
+            row[name + " kernel"] = last_kernel()[4:100]
+        lib.mi_debug_set_affine_box_kib(0)
+        lib.mi_debug_set_interp_c1(5)          # the L1-gather kernel, for reference
         s_, f = timeit(lambda: ndi.affine_transform(xd, M, off, order=1, mode="constant", output=out), 10)
-        print(json.dumps({"axis": axis, "deg": deg, "us": round(s_ * 1e6, 1), "frac": round(8 * n ** 3 / s_ / 8e12, 3), "kernel": last_kernel()[4:80]}), flush=True)
+        lib.mi_debug_set_interp_c1(1)
+        row["L1 gathers us"] = round(s_ * 1e6, 1)
+        print(json.dumps(row), flush=True)

@@ -2129,3 +2129,44 @@ def test_affine_rowblend_kernel(gpu, ndi):
     assert "rowblend" in last_kernel(), last_kernel()
     ref = sndi.rotate(v.astype(np.float64), 11.0, reshape=False, order=1)
     assert np.allclose(got, ref, rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max()))
+
+
+def test_affine_lds_box_kernel_tile_shapes(gpu, ndi):
+    """r5: the LDS-staged order-1 affine kernel (matrices that couple all three axes) on every tile shape -- 64 x 8 x 8,
+    32 x 16 x 8, the cube 16 x 16 x 16 and 16 x 32 x 8 -- and with boxes up to the 64 KiB budget (rotations up to ~25 degrees
+    about a general axis, where the L1-gather kernel has fallen to 0.2 of the roofline): bit-identical to the gather kernel
+    (same splits, same blend), volumes that are not multiples of the tile, output shapes that differ, partial boxes at the
+    array's faces; the default rule takes the LDS kernel there."""
+    from cupyimg_amd import _lib, last_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(99)
+
+    def rot(axis, deg):
+        a = np.deg2rad(deg); u = np.asarray(axis, float); u /= np.linalg.norm(u)
+        K = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0]])
+        return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+
+    for shape, oshape in (((96, 112, 128), None), ((70, 90, 144), (80, 100, 160)), ((64, 64, 256), None)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        osh = shape if oshape is None else oshape
+        for axis, deg in (((1, 1, 1), 12.0), ((1, 1, 0), 22.0), ((1, 0, 1), 5.0), ((0.3, 1, -0.5), 18.0)):
+            M = rot(axis, deg) @ np.diag([1.03, 0.97, 1.0])
+            off = (np.array(shape) - 1) / 2 - M @ ((np.array(osh) - 1) / 2) + np.array([0.4, -1.3, 2.2])
+            kw = dict(output_shape=osh, order=1, mode="constant", cval=0.75)
+            lib.mi_debug_set_interp_c1(5)
+            try:
+                want = ndi.affine_transform(xd, M, off, **kw).get()
+                assert "affine3d_c1_kernel" in last_kernel(), last_kernel()
+            finally:
+                lib.mi_debug_set_interp_c1(1)
+            took = 0
+            for knob in (0, 1064, 2064, 3064, 4064, 3128):
+                lib.mi_debug_set_affine_box_kib(knob)
+                try:
+                    got = ndi.affine_transform(xd, M, off, **kw).get()
+                    took += "affine3d_lds_kernel" in last_kernel()
+                finally:
+                    lib.mi_debug_set_affine_box_kib(0)
+                assert np.array_equal(got, want), (shape, osh, axis, deg, knob, last_kernel()[:70], int(np.sum(got != want)))
+            assert took >= 3, (shape, axis, deg, took)
