@@ -24,6 +24,8 @@
 // of 512^3).  Voxels / steps the factored form does not cover -- taps that fold at the array ends in ways the rectangle
 // does not hold, cval taps along the stream axis, two planes of a step in one ring slot -- take cubic3_gather itself, as in
 // the r4b kernel.
+#include <algorithm>
+
 #include "interp_common.hpp"
 
 namespace mi {
@@ -676,6 +678,242 @@ cubic3_zfactor_kernel(const float *__restrict__ in, float *__restrict__ out, con
         }
         cur = nxt;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// r5: the separable resampling passes of DIAGONAL order-3 transforms (zoom, shift -- the commonest order-3 calls; the
+// reference's zoom / shift kernel, _interp_kernels.py:655-688).  The r3 passes (interp.hip) read every tap from memory:
+// along x four scalar gathers per output (540 us for 512^3: the L1 serves the overlapping windows of a wave's lanes one
+// request at a time), along z four whole-plane reads per output plane (430 us).  Here
+//   * x: a wave stages the span of the input row its 256 outputs read in LDS (coalesced loads, four rows in flight) and takes
+//     EVERY tap from there, the folded ones at the ends of a row included (540 -> 250 us);
+//   * z: a thread walks along z with the four input planes of its window in registers (and the next one on its way): every
+//     input plane is read once.
+// Products and order of the sums are those of the r3 kernels: bit-identical results (tests/test_gpu_spline_fast.py).  Along z,
+// outputs whose taps are not four consecutive planes (array ends: reflected / cval taps) read memory directly, as before.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kRxOut = 256, kRxSpan = 640, kRxRows = 32;      // outputs per wave and row; staged input samples per row; rows per wave
+
+__global__ void __launch_bounds__(256)
+cubic_resample_x_lds_kernel(const float *__restrict__ in, float *__restrict__ out, const AxisTaps *__restrict__ tabx, long long nrows, int ox, int nx,
+                            float cval)
+{
+    __shared__ float rowbuf[4][4][kRxSpan];          // [wave][row of the group][sample]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int x0 = blockIdx.x * kRxOut;
+    const int nout = min(kRxOut, ox - x0);
+    // this lane's four outputs: weights and first tap (kept for every row of the wave)
+    float w[4][4];
+    int off[4][4];
+    bool mine[4];
+    {
+        // the segment's 256 table entries (48 bytes each) through LDS: coalesced dwords in, one entry per output out -- read per
+        // lane from memory they were 48 strided loads per lane, more L1 traffic than the sixteen rows of data behind them
+        // (the first version of this kernel ran at the r3 pass's 530 us for that reason alone)
+        int *tl = reinterpret_cast<int *>(&rowbuf[0][0][0]);
+        const int *tg = reinterpret_cast<const int *>(tabx + x0);
+        for (int i = threadIdx.x; i < nout * 12; i += 256) tl[i] = tg[i];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xo = 4 * lane + k;
+            mine[k] = xo < nout;
+            const int *e = tl + 12 * (mine[k] ? xo : 0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { w[k][j] = __int_as_float(e[j]); off[k][j] = e[4 + j]; }
+        }
+        __syncthreads();                                          // the buffer becomes the waves' row buffers
+    }
+    // the span of the row the wave's taps lie in: [lo, hi] over every tap that reads the array (cval taps are -1) -- at the ends
+    // of a row the taps fold back by a few samples, under the wrapping modes to the other end (the span is then the whole
+    // row, which is staged when it fits).  (First version: only the outputs with four consecutive taps read LDS, the others
+    // memory -- one dependent round trip per row for the wave that holds the end of a row: 1.7 us per row.)
+    int lo = 0x7fffffff, hi = -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (mine[k] && off[k][j] >= 0) { lo = min(lo, off[k][j]); hi = max(hi, off[k][j]); }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { lo = min(lo, __shfl_xor(lo, m, 64)); hi = max(hi, __shfl_xor(hi, m, 64)); }
+    const int s0 = lo & ~3;                                       // (aligned down: whole dwords anyway, friendlier to the loads)
+    const bool staged = hi >= 0 && hi < nx && hi - s0 + 1 <= kRxSpan;
+    const int span = staged ? hi - s0 + 1 : 0;
+    constexpr int NL = kRxSpan / 64;                              // loads per lane and row at most
+    constexpr int G = 4;                                          // rows in flight per wave: with one (1 KiB) the pass ran at the latency of
+                                                                  // memory, 2 TB/s -- no faster than the gathers it replaces
+    const long long row0 = ((long long)blockIdx.y * 4 + wave) * kRxRows;
+    float *buf = rowbuf[wave][0];
+#pragma unroll 1
+    for (int i0 = 0; i0 < kRxRows; i0 += G) {
+        if (row0 + i0 >= nrows) break;
+        if (staged) {
+            float raw[G][NL];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const long long row = min(row0 + i0 + g, nrows - 1);
+                const float *src = in + row * nx + s0;
+#pragma unroll
+                for (int j = 0; j < NL; j++) raw[g][j] = (64 * j + lane < span) ? src[64 * j + lane] : 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int j = 0; j < NL; j++) if (64 * j < span) buf[g * kRxSpan + 64 * j + lane] = raw[g][j];
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // the wave's own LDS writes (no other wave touches this buffer)
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const long long row = row0 + i0 + g;
+                float r[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = buf[g * kRxSpan + (off[k][j] < 0 ? 0 : off[k][j] - s0)];
+                    float a = (off[k][0] < 0 ? cval : v[0]) * w[k][0];
+#pragma unroll
+                    for (int j = 1; j < 4; j++) a = fmaf(off[k][j] < 0 ? cval : v[j], w[k][j], a);
+                    r[k] = a;
+                }
+                if (row < nrows) {
+                    float *dst = out + row * ox + x0 + 4 * lane;
+                    if (mine[3] && (ox & 3) == 0) {
+                        typedef float f32x4x __attribute__((ext_vector_type(4)));
+                        *reinterpret_cast<f32x4x *>(dst) = f32x4x{r[0], r[1], r[2], r[3]};
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) if (mine[k]) dst[k] = r[k];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // reads done before the next group overwrites the buffer
+        } else {
+#pragma unroll 1
+            for (int g = 0; g < G; g++) {
+                const long long row = row0 + i0 + g;
+                if (row >= nrows) break;
+                const float *src = in + row * nx;
+                float r[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = src[off[k][j] < 0 ? 0 : off[k][j]];
+                    float a = (off[k][0] < 0 ? cval : v[0]) * w[k][0];
+#pragma unroll
+                    for (int j = 1; j < 4; j++) a = fmaf(off[k][j] < 0 ? cval : v[j], w[k][j], a);
+                    r[k] = a;
+                }
+                float *dst = out + row * ox + x0 + 4 * lane;
+                if (mine[3] && (ox & 3) == 0) {
+                    typedef float f32x4x __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<f32x4x *>(dst) = f32x4x{r[0], r[1], r[2], r[3]};
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (mine[k]) dst[k] = r[k];
+                }
+            }
+        }
+    }
+}
+
+// z pass, four x-consecutive samples per thread: in (nz, d1, 4 d2q) -> out (oz, d1, 4 d2q); the LAST pass of a 3-D transform:
+// voxels whose coordinate lies beyond the array along any axis (constant mode) become cval
+__global__ void __launch_bounds__(256)
+cubic_resample_zstream_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, const AxisTaps *__restrict__ all_tabs, int oz, int oy, int d2q,
+                              int nz, float cval, int zchunk)
+{
+    const int xq = blockIdx.x * 64 + threadIdx.x;
+    const int y = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + threadIdx.y));
+    if (y >= oy || xq >= d2q) return;
+    const size_t plane = (size_t)oy * d2q;
+    const float4 *col = in + (size_t)y * d2q + xq;
+    const int out_y = all_tabs[oz + y].outside;
+    bool out_x[4];
+    {
+        const AxisTaps *tx = all_tabs + oz + oy + 4 * xq;
+#pragma unroll
+        for (int k = 0; k < 4; k++) out_x[k] = tx[k].outside != 0;
+    }
+    constexpr int kNoBase = -0x40000000;
+    float4 R[4] = {};
+    float4 ahead = {};                       // plane base + 4, requested one step early
+    int base = kNoBase;
+    bool have_ahead = false;
+    const int z1 = min((int)(blockIdx.z + 1) * zchunk, oz);
+#pragma unroll 1
+    for (int z = blockIdx.z * zchunk; z < z1; z++) {
+        const AxisTaps e = all_tabs[z];          // wave-uniform: scalar loads
+        const int o0 = __builtin_amdgcn_readfirstlane(e.off[0]);
+        const bool regular = o0 >= 0 && e.off[1] == o0 + 1 && e.off[2] == o0 + 2 && e.off[3] == o0 + 3 && o0 + 3 < nz;
+        float4 v[4];
+        if (__builtin_amdgcn_readfirstlane((int)regular)) {
+            const int d = o0 - base;
+            if (d == 0) {
+            } else if (d == 1 && have_ahead) {
+                R[0] = R[1]; R[1] = R[2]; R[2] = R[3]; R[3] = ahead;
+            } else if (d == 2 && have_ahead) {
+                R[0] = R[2]; R[1] = R[3]; R[2] = ahead; R[3] = col[(size_t)(o0 + 3) * plane];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) R[k] = col[(size_t)(o0 + k) * plane];
+            }
+            if (d != 0) {
+                base = o0;
+                have_ahead = o0 + 4 < nz;
+                if (have_ahead) ahead = col[(size_t)(o0 + 4) * plane];     // used when the window moves on
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = R[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = col[(size_t)(e.off[k] < 0 ? 0 : e.off[k]) * plane];
+        }
+        float4 r;
+        {
+            const bool c0 = e.off[0] < 0;
+            r.x = (c0 ? cval : v[0].x) * e.w[0]; r.y = (c0 ? cval : v[0].y) * e.w[0];
+            r.z = (c0 ? cval : v[0].z) * e.w[0]; r.w = (c0 ? cval : v[0].w) * e.w[0];
+        }
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            const bool c = e.off[k] < 0;
+            r.x = fmaf(c ? cval : v[k].x, e.w[k], r.x); r.y = fmaf(c ? cval : v[k].y, e.w[k], r.y);
+            r.z = fmaf(c ? cval : v[k].z, e.w[k], r.z); r.w = fmaf(c ? cval : v[k].w, e.w[k], r.w);
+        }
+        const bool ozy = (e.outside | out_y) != 0;
+        if (ozy || out_x[0]) r.x = cval;
+        if (ozy || out_x[1]) r.y = cval;
+        if (ozy || out_x[2]) r.z = cval;
+        if (ozy || out_x[3]) r.w = cval;
+        out[((size_t)z * oy + y) * (size_t)d2q + xq] = r;
+    }
+}
+
+int launch_resample_x_lds(const float *in, float *out, const AxisTaps *tabx, long long nrows, int ox, int nx, float cval, hipStream_t s)
+{
+    const long long gy = (nrows + 4 * kRxRows - 1) / (4 * kRxRows);
+    if (gy > 65535) return MI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cubic_resample_x_lds_kernel, dim3((unsigned)((ox + kRxOut - 1) / kRxOut), (unsigned)gy), dim3(256), 0, s, in, out, tabx, nrows, ox, nx, cval);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int launch_resample_zstream(const float *in, float *out, const AxisTaps *all_tabs, int oz, int oy, int oxq, int nz, float cval, hipStream_t s)
+{
+    if ((oy + 3) / 4 > 65535) return MI_ERR_UNSUPPORTED;
+    // z chunks: enough workgroups for a few waves per SIMD; every chunk starts with four plane loads of its own
+    const long long cols = (long long)((oxq + 63) / 64) * ((oy + 3) / 4);
+    int nch = (int)std::max<long long>(1, std::min<long long>((4LL * 4 * device_cus() + cols - 1) / cols, (oz + 31) / 32));
+    const int zchunk = (oz + nch - 1) / nch;
+    nch = (oz + zchunk - 1) / zchunk;
+    hipLaunchKernelGGL(cubic_resample_zstream_kernel, dim3((unsigned)((oxq + 63) / 64), (unsigned)((oy + 3) / 4), (unsigned)nch), dim3(64, 4), 0, s,
+                       (const float4 *)in, (float4 *)out, all_tabs, oz, oy, oxq, nz, cval, zchunk);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
 }
 
 // launch with the plan of launch_cubic_zstream (interp.hip): same parameters, same dynamic LDS; MI_ERR_UNSUPPORTED = not taken

@@ -403,7 +403,7 @@ spline_affine_nd_kernel(const double *__restrict__ in, void *__restrict__ out, i
 
 // Diagonal transforms: taps and weights of an axis depend on the output index along that axis only, so
 // they are tabulated once per call (oz + oy + ox entries) instead of once per voxel.
-struct AxisTaps { float w[4]; int off[4]; int outside; int pad_[3]; };
+// (struct AxisTaps: interp_common.hpp)
 
 __global__ void __launch_bounds__(256)
 cubic3_axis_table_kernel(AxisTaps *__restrict__ tab, InterpGeom g, int mode, int npad, int unit_stride)
@@ -981,6 +981,10 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
     }
 }
 
+Knob g_resample_fast{1};      // test hook: 0 = the r3 separable resampling passes for diagonal order-3 transforms
+extern "C" int mi_debug_set_resample_fast(int on) { g_resample_fast = on; return MI_OK; }
+int launch_resample_x_lds(const float *in, float *out, const AxisTaps *tabx, long long nrows, int ox, int nx, float cval, hipStream_t s);          // cubic_fast.hip
+int launch_resample_zstream(const float *in, float *out, const AxisTaps *all_tabs, int oz, int oy, int oxq, int nz, float cval, hipStream_t s);   // cubic_fast.hip
 Knob g_cubic_zfactor{1};      // test hook: 0 = cubic3_zstream_kernel (r4b: 64 taps per voxel, bit-identical to the gather kernel) instead of cubic3_zfactor_kernel
 extern "C" int mi_debug_set_cubic_zfactor(int on) { g_cubic_zfactor = on; return MI_OK; }
 int launch_cubic_zfactor(int sax, const float *in, float *out, const CubZParams &q, size_t lds, int blocks, hipStream_t s);      // cubic_fast.hip
@@ -2514,6 +2518,10 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
                     dst_y = (float *)bufB;
                 }
                 const dim3 blk(64, 4);
+                // r5 (csrc/cubic_fast.hip): x from an LDS-staged row span, z with the window of planes in registers -- volumes only
+                // (x is then never the last pass); mi_debug_set_resample_fast(0) keeps the r3 passes (bit-identical)
+                const bool fast3 = g_resample_fast && do_y && do_z;
+                if (!(fast3 && launch_resample_x_lds((const float *)coef->data, dst_x, T + oz + oy, (long long)nz * ny, ox, nx, (float)cval, s) == MI_OK))
                 hipLaunchKernelGGL(cubic_resample_axis_kernel<2>, dim3((ox + 63) / 64, (ny + 3) / 4, nz), blk, 0, s,
                                    (const float *)coef->data, dst_x, T + oz + oy, nz, ny, ox, nx, (float)cval, T, oz, oy,
                                    do_y ? 0 : 1);
@@ -2530,7 +2538,9 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
                                            do_z ? 0 : 1);
                 }
                 if (do_z) {
-                    if (quad)
+                    if (quad && fast3 && launch_resample_zstream((const float *)bufB, (float *)out->data, T, oz, oy, oxq, nz, (float)cval, s) == MI_OK) {
+                        note_kernel("mi::cubic_resample_zstream_kernel (order-3 diagonal transform: x from LDS-staged row spans, y, z with the plane window in registers)");
+                    } else if (quad)
                         hipLaunchKernelGGL(cubic_resample_rows4_kernel<0>, dim3((oxq + 63) / 64, (oy + 3) / 4, oz), blk, 0, s,
                                            (const float4 *)bufB, (float4 *)out->data, T, oz, oy, oxq, nz, (float)cval, T, oz, oy, 1);
                     else

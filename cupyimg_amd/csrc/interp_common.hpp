@@ -219,6 +219,11 @@ __device__ __forceinline__ float cubic3_gather(const __amdgpu_buffer_rsrc_t rin,
 }
 
 
+// Diagonal transforms (zoom, shift): taps and weights of an axis depend on the output index along that axis only, so they are
+// tabulated once per call (cubic3_axis_table_kernel, interp.hip).  In the separable passes `off` holds plain indices along the
+// axis, -1 = the tap reads cval.
+struct AxisTaps { float w[4]; int off[4]; int outside; int pad_[3]; };
+
 void note_kernel(const char *fmt, ...);        // runtime.hip (sep_common.hpp declares it for the filter sources)
 bool spline_pass_fast(const mi_array *shape, const void *src, int src_dtype, void *dst, int axis, int order, int spline_mode, hipStream_t s, int *rc);   // spline_fast.hip
 constexpr int kCzP = 80, kCzRoundsMax = 8, kCzSlots = 5, kCzTY = 32, kCzNT = 256;

@@ -230,3 +230,35 @@ def test_prefilter_passes_under_load_512(gpu, ndi, lib):
             sl[(axis + 1) % 3] = slice(lo, lo + 3)
             ref = sndi.spline_filter1d(v[tuple(sl)].astype(np.float64), 3, axis=axis)
             assert np.abs(got[tuple(sl)] - ref).max() <= 2e-6 * np.abs(ref).max(), (axis, lo)
+
+
+def test_zoom_shift_resampling_passes(gpu, ndi, lib):
+    """r5: the separable resampling passes of diagonal order-3 transforms on volumes -- x from LDS-staged row spans
+    (cubic_resample_x_lds_kernel), z with the window of planes in registers (cubic_resample_zstream_kernel) -- bit-identical to
+    the r3 passes (mi_debug_set_resample_fast(0): same products, same order of the sums) for zooms in and out, anisotropic
+    zooms, shifts beyond the array, every mode (array ends: reflected and cval taps take the direct path), rows that are not
+    multiples of four or of the 256-output segments; and within float32 accuracy of SciPy."""
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(31)
+    took = 0
+    for shape in ((64, 80, 128), (50, 61, 300), (40, 44, 515), (130, 70, 72)):
+        v = rng.standard_normal(shape).astype(np.float32)
+        vd = gpu.asarray(v)
+        calls = [("zoom", (1.3, 1.1, 1.25)), ("zoom", (0.7, 1.9, 0.55)), ("zoom", 2.0), ("shift", (0.5, -0.25, 0.75)), ("shift", (-3.2, 40.5, -70.1))]
+        for name, arg in calls:
+            for mode in ("constant", "mirror", "nearest", "reflect", "grid-wrap", "wrap", "grid-constant"):
+                fn = getattr(ndi, name)
+                got = fn(vd, arg, mode=mode, cval=0.5)
+                took += "cubic_resample_zstream_kernel" in last_kernel()
+                lib.mi_debug_set_resample_fast(0)
+                try:
+                    old = fn(vd, arg, mode=mode, cval=0.5).get()
+                finally:
+                    lib.mi_debug_set_resample_fast(1)
+                got = got.get()
+                assert np.array_equal(got, old, equal_nan=True), (shape, name, arg, mode, int(np.sum(got != old)))
+                if mode in ("constant", "mirror", "nearest"):
+                    ref = getattr(sndi, name)(v.astype(np.float64), arg, mode=mode, cval=0.5)
+                    assert got.shape == ref.shape
+                    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (shape, name, arg, mode)
+    assert took >= 60, took
