@@ -916,6 +916,238 @@ int launch_resample_zstream(const float *in, float *out, const AxisTaps *all_tab
     return MI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// r5: order-3 affine transforms whose matrix couples all three axes (registration resampling: a few degrees about a general
+// axis) -- the taps out of an LDS-staged BOX.  cubic3_f32_kernel gathers 16 x 16 bytes per voxel through the L1 (4.5 ms on
+// 512^3, 0.03 of the roofline).  Here a workgroup (512 threads) owns a 16 x 16 x 16 cube of output voxels -- the tile shape whose
+// pre-image has the smallest bounding box under a general rotation -- stages that box (+ the three extra samples a cubic tap
+// block needs per axis) with LDS-DMA exactly as affine3d_lds_kernel (interp_fast.hip) does for order 1, and reads a voxel's
+// 64 taps as 32 ds_read2_b32 from sixteen row addresses.  Tap selection, weights, products and the order of the sums are
+// cubic3_gather's (cubic3_f32_kernel's): bit-identical results.  Voxels whose taps are not a plain 4 x 4 x 4 block inside
+// the array (coordinates within a sample or two of its faces, folded or cval taps) and voxels beyond the array take
+// cubic3_gather itself; matrices whose box exceeds 64 KiB (beyond ~12 degrees) stay with the gather kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kBoxT = 16;                                   // the cube's edge
+constexpr int kBoxBytesMax = 64 * 1024, kBoxRoundsMax = 8;  // box budget (two workgroups per CU); staging rounds of 512 chunks
+
+struct CubBoxParams {
+    int nz, ny, nx, oz, oy, ox;
+    double m[12];
+    int bz, by, bx, nchunks;
+    unsigned cpr_magic, by_magic;
+    int drow, dc4, drz, dry;
+    double cmin[3];
+    int mode, npad;
+    float cval;
+};
+
+__global__ void __launch_bounds__(512, 4)          // four waves per SIMD = two workgroups per CU (one computes while the other's box is in flight)
+cubic3_box_kernel(const float *__restrict__ in, float *__restrict__ out, const CubBoxParams q)
+{
+    constexpr int T = kBoxT, RW = 4, WY = 4;                 // lanes: 16 x by 4 rows; waves: 4 along y, 2 along z (8 planes each)
+    extern __shared__ __attribute__((aligned(16))) char smem_box[];
+    float *box = reinterpret_cast<float *>(smem_box);
+    const unsigned box_bytes = ((unsigned)q.nchunks * 16u + 8191u) & ~8191u;
+    double (*ptab)[3] = reinterpret_cast<double (*)[3]>(smem_box + box_bytes);        // [T * T][3]: the z and y terms of a row's coordinates
+    float *tiles = reinterpret_cast<float *>(smem_box + box_bytes + T * T * 3 * sizeof(double));   // [8 waves][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lx = lane & (T - 1), yy = lane / T;
+    const int wy = wave % WY, wz = wave / WY;
+    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T, z0 = blockIdx.z * T;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, q.nz * q.ny * q.nx * 4, 0x00020000);
+    // ---- box origin: first tap of the smallest coordinate over the tile (a hair below it; + the padding of the coefficient array)
+    int b0[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double lo = ((q.m[4 * a] * (double)z0 + q.m[4 * a + 1] * (double)y0) + q.m[4 * a + 2] * (double)x0) + (q.m[4 * a + 3] + q.cmin[a]) + (double)q.npad;
+        const int n = a == 0 ? q.nz : (a == 1 ? q.ny : q.nx);
+        double f = floor(lo - 1e-6 * (1.0 + fabs(lo))) - 1.0;
+        f = f < 0.0 ? 0.0 : (f > (double)(n - 1) ? (double)(n - 1) : f);
+        b0[a] = __builtin_amdgcn_readfirstlane(a == 2 ? ((int)f & ~3) : (int)f);
+    }
+    // ---- stage the box (chunk -> plane, row, 16-byte piece by multiply-high; chunks beyond the volume read zeros)
+    {
+        const int cpr = q.bx >> 2;
+        const int rounds = (q.nchunks + 511) >> 9;
+        const unsigned row_b = (unsigned)q.nx * 4u, plane_b = (unsigned)q.ny * row_b;
+        const bool inside = b0[0] + q.bz <= q.nz && b0[1] + q.by <= q.ny && b0[2] + q.bx <= q.nx;
+        const unsigned base = (unsigned)((b0[0] * q.ny + b0[1]) * q.nx + b0[2]) * 4u;
+#pragma unroll
+        for (int j = 0; j < kBoxRoundsMax; j++) {
+            if (j >= rounds) break;
+            const unsigned ch = (unsigned)tid + ((unsigned)j << 9);
+            const unsigned row = __umulhi(ch, q.cpr_magic), c4 = ch - row * (unsigned)cpr;
+            const unsigned rz = __umulhi(row, q.by_magic), ry = row - rz * (unsigned)q.by;
+            bool ok = ch < (unsigned)q.nchunks;
+            if (!inside) ok = ok && b0[0] + (int)rz < q.nz && b0[1] + (int)ry < q.ny && b0[2] + 4 * (int)c4 < q.nx;
+            const unsigned voff = ok ? rz * plane_b + ry * row_b + c4 * 16u : 0x80000000u;
+            cz_dma16(rin, voff, base, (unsigned)((wave << 6) + (j << 9)) * 16u, ~0ull);
+        }
+    }
+    for (int e = tid; e < T * T * 3; e += 512) {
+        const int rr = e / 3, a = e - 3 * rr;                      // rr = T k + row  <->  plane z0 + k, row y0 + row
+        ptab[rr][a] = q.m[4 * a] * (double)(z0 + rr / T) + q.m[4 * a + 1] * (double)(y0 + rr % T);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int yrow = RW * wy + yy;
+    const double dx = (double)(x0 + lx);
+    const double xz_ = q.m[2] * dx, xy_ = q.m[6] * dx, xx_ = q.m[10] * dx;
+    const int plane_f = q.by * q.bx;
+    float *tile = tiles + wave * 256;
+    const bool wide = x0 + T <= q.ox && y0 + T <= q.oy && z0 + T <= q.oz;
+    const int nxy = q.ny * q.nx;
+    unsigned todo = 0;                                       // this thread's voxels (bit 4 bt + kk) that are not plain blocks inside the box
+    auto k_local = [](int bt, int kk) { return 4 * bt + kk; };
+#pragma unroll 1
+    for (int bt = 0; bt < 2; bt++) {
+        float r[4];
+#pragma unroll 1
+        for (int kk = 0; kk < 4; kk++) {
+            const int k = 8 * wz + 4 * bt + kk;
+            const int rr = T * k + yrow;
+            // cubic3_f32_kernel's coordinate sums: s = m0 z; s += m1 y; s += m2 x; c = s + m3
+            const double c0 = (ptab[rr][0] + xz_) + q.m[3], c1 = (ptab[rr][1] + xy_) + q.m[7], c2 = (ptab[rr][2] + xx_) + q.m[11];
+            // the plain case: all three tap blocks inside the array (whatever the mode: no folding there)
+            const double p0 = c0 + (double)q.npad, p1 = c1 + (double)q.npad, p2 = c2 + (double)q.npad;
+            const double f0 = floor(p0), f1 = floor(p1), f2 = floor(p2);
+            const bool plain = f0 >= 1.0 && f0 + 2.0 <= (double)(q.nz - 1) && f1 >= 1.0 && f1 + 2.0 <= (double)(q.ny - 1) && f2 >= 1.0 && f2 + 2.0 <= (double)(q.nx - 1);
+            const int sz = (int)f0 - 1 - b0[0], sy = (int)f1 - 1 - b0[1], sx = (int)f2 - 1 - b0[2];
+            const bool held = plain && sz >= 0 && sz + 3 < q.bz && sy >= 0 && sy + 3 < q.by && sx >= 0 && sx + 3 < q.bx;
+            float val;
+            if (held) {
+                float wz_[4], wy_[4], wx_[4];
+                cubic3_weights((float)(p0 - f0), wz_);
+                cubic3_weights((float)(p1 - f1), wy_);
+                cubic3_weights((float)(p2 - f2), wx_);
+                const float *b = box + (sz * q.by + sy) * q.bx + sx;
+                float acc = 0.f;
+#pragma unroll
+                for (int kz = 0; kz < 4; kz++) {
+                    float v[4][4];
+#pragma unroll
+                    for (int ky = 0; ky < 4; ky++) {
+                        const float *t = b + kz * plane_f + ky * q.bx;
+#pragma unroll
+                        for (int kx = 0; kx < 4; kx++) v[ky][kx] = t[kx];
+                    }
+#pragma unroll
+                    for (int ky = 0; ky < 4; ky++) {
+                        const float wzy = wz_[kz] * wy_[ky];
+                        float row = v[ky][0] * wx_[0];
+                        row = fmaf(v[ky][1], wx_[1], row);
+                        row = fmaf(v[ky][2], wx_[2], row);
+                        row = fmaf(v[ky][3], wx_[3], row);
+                        acc = fmaf(row, wzy, acc);
+                    }
+                }
+                val = acc;
+            } else {
+                val = 0.f;
+                todo |= 1u << k_local(bt, kk);                       // second phase below
+            }
+            r[kk] = val;
+        }
+        if (wide) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) tile[kk * 64 + lane] = r[kk];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int i = lane >> 4, c = lane & 15;                 // plane of the batch, 16-byte chunk of the wave's 64 voxels (4 rows x 16)
+            typedef float f32x4b __attribute__((ext_vector_type(4)));
+            const f32x4b v = *reinterpret_cast<const f32x4b *>(tile + i * 64 + 4 * c);
+            const int orow = y0 + RW * wy + (4 * c) / T, ox4 = x0 + ((4 * c) & (T - 1));
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4b *>(out + ((size_t)(z0 + 8 * wz + 4 * bt + i) * q.oy + orow) * q.ox + ox4));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            const int x = x0 + lx, y = y0 + yrow;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int z = z0 + 8 * wz + 4 * bt + kk;
+                if (x < q.ox && y < q.oy && z < q.oz) __builtin_nontemporal_store(r[kk], out + ((size_t)z * q.oy + y) * q.ox + x);
+            }
+        }
+    }
+    // ---- second phase: the voxels whose taps fold at the array's faces, read cval or lie beyond the array -- cubic3_gather itself
+    // (kept out of the loop above: its registers would be that loop's).  Their place in the output was written (as zeros) by
+    // OTHER lanes of the wave in the transposed 16-byte stores above: those stores are complete before the values follow.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (todo != 0u) {
+#pragma unroll 1
+        for (int kl = 0; kl < 8; kl++) {
+            if (!((todo >> kl) & 1u)) continue;
+            const int z = z0 + 8 * wz + kl, y = y0 + yrow, x = x0 + lx;
+            if (x >= q.ox || y >= q.oy || z >= q.oz) continue;
+            const int rr = T * (8 * wz + kl) + yrow;
+            const double c0 = (ptab[rr][0] + xz_) + q.m[3], c1 = (ptab[rr][1] + xy_) + q.m[7], c2 = (ptab[rr][2] + xx_) + q.m[11];
+            Cubic3 tt;
+            bool outside = cubic3_axis(q.nz, nxy, c0, q.mode, q.npad, tt.w[0], tt.off[0]);
+            outside |= cubic3_axis(q.ny, q.nx, c1, q.mode, q.npad, tt.w[1], tt.off[1]);
+            outside |= cubic3_axis(q.nx, 1, c2, q.mode, q.npad, tt.w[2], tt.off[2]);
+            tt.ntap[0] = 4; tt.ntap[1] = 4;
+            tt.outside = outside;
+            out[((size_t)z * q.oy + y) * q.ox + x] = cubic3_gather_lean(rin, tt, q.cval);
+        }
+    }
+}
+
+// plan + launch; false = not taken (diagonal / decoupled matrices have better kernels; box too large; small outputs)
+bool launch_cubic_box(const float *in, float *out, const int shape[3], const int oshape[3], const double *mat, int mode, double cval, int npad,
+                      hipStream_t s, int *rc)
+{
+    *rc = MI_OK;
+    CubBoxParams q;
+    q.nz = shape[0]; q.ny = shape[1]; q.nx = shape[2];
+    q.oz = oshape[0]; q.oy = oshape[1]; q.ox = oshape[2];
+    if ((long long)q.oz * q.oy * q.ox < (1 << 18) || (q.ox & 3) || ((uintptr_t)out & 15) || ((uintptr_t)in & 15) || (q.nx & 3)) return false;
+    if ((long long)q.nz * q.ny * q.nx * 4 >= (1LL << 31)) return false;
+    for (int i = 0; i < 12; i++) { if (!(fabs(mat[i]) < 1e9)) return false; q.m[i] = mat[i]; }
+    int dim[3];
+    for (int a = 0; a < 3; a++) {
+        double ext = 0.0;
+        for (int j = 0; j < 3; j++) ext += fabs(q.m[4 * a + j]) * (kBoxT - 1);
+        if (!(ext < 4096.0)) return false;
+        // taps floor(min - hair) - 1 .. floor(max) + 2: at most floor(ext + hair) + 6 of them
+        dim[a] = (int)floor(ext * (1.0 + 1e-6) + 2e-3) + 6;
+    }
+    dim[2] = (dim[2] + 3 + 3) & ~3;                 // origin aligned down by up to 3, length a multiple of 4
+    const int n[3] = {q.nz, q.ny, q.nx};
+    for (int a = 0; a < 2; a++) if (dim[a] > n[a]) dim[a] = n[a];
+    if (dim[2] > ((n[2] + 3) & ~3) + 4) dim[2] = ((n[2] + 3) & ~3) + 4;
+    const long long floats = (long long)dim[0] * dim[1] * dim[2];
+    if (floats * 4 > kBoxBytesMax || (floats / 4 + 511) / 512 > kBoxRoundsMax) return false;
+    q.bz = dim[0]; q.by = dim[1]; q.bx = dim[2];
+    q.nchunks = (int)(floats / 4);
+    {
+        const unsigned cpr = (unsigned)dim[2] / 4u, by = (unsigned)dim[1];
+        q.cpr_magic = (unsigned)((((unsigned long long)1 << 32) + cpr - 1) / cpr);
+        q.by_magic = (unsigned)((((unsigned long long)1 << 32) + by - 1) / by);
+        q.drow = q.dc4 = q.drz = q.dry = 0;
+    }
+    for (int a = 0; a < 3; a++) {
+        double c = 0.0;
+        for (int j = 0; j < 3; j++) { const double e = q.m[4 * a + j] * (kBoxT - 1); if (e < 0.0) c += e; }
+        q.cmin[a] = c;
+    }
+    q.mode = mode; q.npad = npad; q.cval = (float)cval;
+    const dim3 grid((unsigned)((q.ox + kBoxT - 1) / kBoxT), (unsigned)((q.oy + kBoxT - 1) / kBoxT), (unsigned)((q.oz + kBoxT - 1) / kBoxT));
+    if (grid.y > 65535 || grid.z > 65535) return false;
+    const size_t lds = (((size_t)q.nchunks * 16 + 8191) & ~(size_t)8191) + kBoxT * kBoxT * 3 * sizeof(double) + 8 * 256 * sizeof(float);
+    static PerDeviceOnce attr_done;
+    if (!attr_done) {
+        const hipError_t e = hipFuncSetAttribute((const void *)cubic3_box_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) { *rc = (int)e; return true; }
+        attr_done = true;
+    }
+    note_kernel("mi::cubic3_box_kernel grid=%ux%ux%u (order-3 affine on float32 coefficients, all axes coupled: %d x %d x %d box staged per 16^3 tile)", grid.x, grid.y, grid.z,
+                q.bz, q.by, q.bx);
+    hipLaunchKernelGGL(cubic3_box_kernel, grid, dim3(512), lds, s, in, out, q);
+    const hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) *rc = (int)e2;
+    return true;
+}
+
 // launch with the plan of launch_cubic_zstream (interp.hip): same parameters, same dynamic LDS; MI_ERR_UNSUPPORTED = not taken
 int launch_cubic_zfactor(int sax, const float *in, float *out, const CubZParams &q, size_t lds, int blocks, hipStream_t s)
 {
