@@ -76,14 +76,19 @@ __device__ __forceinline__ float cubic3_gather_lean(const __amdgpu_buffer_rsrc_t
 // maps) runs only in the steps that need it.  Shared by the streaming kernel and the fix-up kernel: the two must agree on which
 // steps the streaming kernel leaves out.
 struct ZTaps { float w[4]; int pl[4]; bool outside, cvtap, plain; };      // plain: four consecutive planes inside the array (pl[k] = pl[0] + k)
-__device__ __forceinline__ ZTaps cz_ztaps(const CubZParams &q, int z)
+// the table entry of an output plane (cubic3_ztaps_kernel): what the taps of a step are does not depend on the tile -- one
+// thread per output plane computes them once per launch, the streaming kernel and the fix-up kernel read a record per step with
+// scalar loads (r5b: computed per step by every wave -- double arithmetic on the vector unit, a dozen readfirstlanes -- they were
+// a quarter of the streaming kernel's per-step instructions)
+struct ZRec { float w[4]; int pl[4]; int flags; int pad_[3]; };           // flags: 1 outside, 2 cvtap, 4 plain
+__device__ __forceinline__ ZRec cz_ztaps_lane(const CubZParams &q, int z)
 {
-    ZTaps p;
+    ZRec p;
     double s0 = 0.0; s0 += q.m00 * (double)z;
     const double cz = s0 + q.m03;
     const double cc = cz + (double)q.npad;
     const double fl = floor(cc);
-    const bool plain = __builtin_amdgcn_readfirstlane((int)(fl >= 1.0 && fl + 2.0 <= (double)(q.nz - 1))) != 0;
+    const bool plain = fl >= 1.0 && fl + 2.0 <= (double)(q.nz - 1);
     float w[4]; int pl[4];
     bool outside = false, cv = false;
     if (plain) {
@@ -93,9 +98,7 @@ __device__ __forceinline__ ZTaps cz_ztaps(const CubZParams &q, int z)
         for (int k = 0; k < 4; k++) pl[k] = st + k;
     } else {
         int off[4];
-        int nz_ = q.nz, mode_ = q.mode;          // (opaque: keeps the loop-invariant doubles of the boundary arithmetic out of the loop's registers)
-        asm volatile("" : "+s"(nz_), "+s"(mode_));
-        outside = cubic3_axis(nz_, 1, cz, mode_, q.npad, w, off);
+        outside = cubic3_axis(q.nz, 1, cz, q.mode, q.npad, w, off);
 #pragma unroll
         for (int k = 0; k < 4; k++) { pl[k] = off[k]; cv = cv || off[k] < 0; }
     }
@@ -106,11 +109,6 @@ __device__ __forceinline__ ZTaps cz_ztaps(const CubZParams &q, int z)
 #pragma unroll
         for (int k = 0; k < 4; k++) { pl[k] = pl[1]; w[k] = k == 1 ? 1.f : 0.f; }
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        p.w[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(w[k])));
-        p.pl[k] = __builtin_amdgcn_readfirstlane(pl[k]);
-    }
     // two DIFFERENT planes of one step in the same slot of the register ring (plane mod 4): planes that wrap around the array
     // (four consecutive planes never do) -- the step is left to the fix-up kernel
     if (!plain) {
@@ -118,11 +116,34 @@ __device__ __forceinline__ ZTaps cz_ztaps(const CubZParams &q, int z)
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = i + 1; j < 4; j++)
-                cv = cv || (p.pl[i] >= 0 && p.pl[j] >= 0 && p.pl[i] != p.pl[j] && (p.pl[i] & 3) == (p.pl[j] & 3));
+                cv = cv || (pl[i] >= 0 && pl[j] >= 0 && pl[i] != pl[j] && (pl[i] & 3) == (pl[j] & 3));
     }
-    p.cvtap = __builtin_amdgcn_readfirstlane((int)cv) != 0;
-    p.outside = __builtin_amdgcn_readfirstlane((int)outside) != 0;
-    p.plain = plain && !q.sident;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { p.w[k] = w[k]; p.pl[k] = pl[k]; }
+    p.flags = (outside ? 1 : 0) | (cv ? 2 : 0) | ((plain && !q.sident) ? 4 : 0);
+    p.pad_[0] = p.pad_[1] = p.pad_[2] = 0;
+    return p;
+}
+
+__global__ void __launch_bounds__(64)
+cubic3_ztaps_kernel(ZRec *__restrict__ tab, const CubZParams q)
+{
+    const int z = blockIdx.x * 64 + threadIdx.x;
+    if (z < q.oz) tab[z] = cz_ztaps_lane(q, z);
+}
+
+// a record as wave-uniform values (z is uniform: the loads are scalar)
+__device__ __forceinline__ ZTaps cz_ztaps(const ZRec *__restrict__ tab, int z)
+{
+    const ZRec r = tab[z];
+    ZTaps p;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        p.w[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.w[k])));
+        p.pl[k] = __builtin_amdgcn_readfirstlane(r.pl[k]);
+    }
+    const int f = __builtin_amdgcn_readfirstlane(r.flags);
+    p.outside = (f & 1) != 0; p.cvtap = (f & 2) != 0; p.plain = (f & 4) != 0;
     return p;
 }
 
@@ -135,7 +156,7 @@ constexpr int kCzFixPlanes = 16;        // output planes per fix-up workgroup (o
 
 template <int SAX>
 __global__ void __launch_bounds__(64)
-cubic3_zfix_kernel(const float *__restrict__ in, float *__restrict__ out, const CubZParams q, const int *__restrict__ far_flags)
+cubic3_zfix_kernel(const float *__restrict__ in, float *__restrict__ out, const CubZParams q, const int *__restrict__ far_flags, const ZRec *__restrict__ ztab)
 {
     const int tw = blockIdx.x;
     const int wave = tw & 3, tile = tw >> 2;
@@ -148,12 +169,8 @@ cubic3_zfix_kernel(const float *__restrict__ in, float *__restrict__ out, const 
 #pragma unroll 1
     for (int z = blockIdx.y * kCzFixPlanes; z < z1; z++) {
         double s0 = 0.0; s0 += q.m00 * (double)z;
-        if (!far) {
-            // four plain planes inside the array: nothing for this wave to do (the cheap half of cz_ztaps)
-            const double fl = floor((s0 + q.m03) + (double)q.npad);
-            if (fl >= 1.0 && fl + 2.0 <= (double)(q.nz - 1)) continue;
-        }
-        const ZTaps zt = cz_ztaps(q, z);
+        const ZTaps zt = cz_ztaps(ztab, z);
+        if (!far && zt.plain) continue;                                    // four plain planes inside the array: nothing for this wave to do
         if (zt.outside) continue;                                          // the streaming kernel wrote cval
         if (!(far || zt.cvtap)) continue;
         if (x >= q.ox) continue;
@@ -181,7 +198,7 @@ cubic3_zfix_kernel(const float *__restrict__ in, float *__restrict__ out, const 
 
 template <int SAX>
 __global__ void __launch_bounds__(kCzNT, 2)
-cubic3_zfactor_kernel(const float *__restrict__ in, float *__restrict__ out, const CubZParams q, int *__restrict__ far_flags)
+cubic3_zfactor_kernel(const float *__restrict__ in, float *__restrict__ out, const CubZParams q, int *__restrict__ far_flags, const ZRec *__restrict__ ztab)
 {
     constexpr int P = kCzP, TY = kCzTY, NT = kCzNT, NS = kCzSlots;
     extern __shared__ __attribute__((aligned(16))) char smem_cz[];
@@ -329,13 +346,19 @@ cubic3_zfactor_kernel(const float *__restrict__ in, float *__restrict__ out, con
     // an UNDER-estimate of what may legally be in flight: the wait is then longer, never shorter.
     constexpr int kLook = 3;
     constexpr int kNone = -0x7fffffff;
-    int res0 = kNone, res1 = kNone, res2 = kNone, res3 = kNone, res4 = kNone;
-    int mark0 = 0, mark1 = 0, mark2 = 0, mark3 = 0, mark4 = 0;
+    // the tables live in the LANES of one vector register (wave-uniform content, the same in every wave): lanes 0-4 res[], 8-12
+    // mark[], 16-19 the tags of the register ring -- an element is one v_readlane (v_cndmask to write) with the index in a scalar, a
+    // search one compare + ballot.  (As fourteen scalars selected by ?: chains the compiler built branch trees: 460 scalar
+    // instructions per step.)
+    int bk = lane < 5 ? kNone : (lane >= 16 && lane < 20 ? kNone : 0);
     int issued = 0;
     int head = 0;                                            // the slot the next plane goes to
-    auto find = [&](int pl) { return res0 == pl ? 0 : (res1 == pl ? 1 : (res2 == pl ? 2 : (res3 == pl ? 3 : (res4 == pl ? 4 : -1)))); };
-    auto res_at = [&](int sl) { return sl == 0 ? res0 : (sl == 1 ? res1 : (sl == 2 ? res2 : (sl == 3 ? res3 : res4))); };
-    auto mark_at = [&](int sl) { return sl == 0 ? mark0 : (sl == 1 ? mark1 : (sl == 2 ? mark2 : (sl == 3 ? mark3 : mark4))); };
+    auto find = [&](int pl) {
+        const unsigned m = (unsigned)__builtin_amdgcn_ballot_w64(bk == pl) & 0x1fu;
+        return m ? (int)__builtin_ctz(m) : -1;
+    };
+    auto res_at = [&](int sl) { return __builtin_amdgcn_readlane(bk, sl); };
+    auto mark_at = [&](int sl) { return __builtin_amdgcn_readlane(bk, 8 + sl); };
     auto fetch = [&](int pl, int sl) {                       // stage plane pl (0 <= pl < nz) into slot sl
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, vol_bytes, 0x00020000);
         const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)pl * plane_b + org_b);
@@ -344,18 +367,13 @@ cubic3_zfactor_kernel(const float *__restrict__ in, float *__restrict__ out, con
         for (int j = 0; j < kCzRoundsMax; j++)
             if (j < ndma) cz_dma16(rin, rel[j], base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * NT) * 16u), live_of(j));
         issued += ndma;
-        // (selects, not a switch: a switch over by-reference captures makes the compiler keep the ten scalars as an indexed
-        // array in scratch memory -- whose accesses are vector-memory operations of their own)
-        res0 = sl == 0 ? pl : res0; res1 = sl == 1 ? pl : res1; res2 = sl == 2 ? pl : res2; res3 = sl == 3 ? pl : res3; res4 = sl == 4 ? pl : res4;
-        mark0 = sl == 0 ? issued : mark0; mark1 = sl == 1 ? issued : mark1; mark2 = sl == 2 ? issued : mark2; mark3 = sl == 3 ? issued : mark3;
-        mark4 = sl == 4 ? issued : mark4;
+        bk = lane == sl ? pl : (lane == 8 + sl ? issued : bk);
         head = sl == 4 ? 0 : sl + 1;
     };
-    auto zplane = [&](int z) { return cz_ztaps(q, z); };
+    auto zplane = [&](int z) { return cz_ztaps(ztab, z); };
 
     // ---- Q ring: in-plane values of the planes of the current step, slot (plane & 3); the tags are wave-uniform
     float Q[4][8];
-    int qtag0 = -0x7fffffff, qtag1 = -0x7fffffff, qtag2 = -0x7fffffff, qtag3 = -0x7fffffff;
 #pragma unroll
     for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -460,15 +478,16 @@ cubic3_zfactor_kernel(const float *__restrict__ in, float *__restrict__ out, con
         else if (n >= 2) asm volatile(MI_VMCNT(2) ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    auto in_q = [&](int pl) { const int s_ = pl & 3; return (s_ == 0 ? qtag0 : (s_ == 1 ? qtag1 : (s_ == 2 ? qtag2 : qtag3))) == pl; };
+    auto in_q = [&](int pl) { return __builtin_amdgcn_readlane(bk, 16 + (pl & 3)) == pl; };
+    auto set_tag = [&](int pl) { bk = lane == 16 + (pl & 3) ? pl : bk; };
     // first plane of the four taps of output plane z when they are four plain planes inside the array (else kNone): the cheap
     // form of cubic3_axis for looking ahead -- a wrong guess costs time (the plane is then fetched at its own step), never data
     auto plain_start = [&](int z) {
-        double s0 = 0.0; s0 += q.m00 * (double)z;
-        const double cc = (s0 + q.m03) + (double)q.npad;
-        const double fl = floor(cc);
-        const bool ok = fl >= 1.0 && fl + 2.0 <= (double)(q.nz - 1) && cc >= 0.0 && cc <= (double)(q.nz - 1);
-        return __builtin_amdgcn_readfirstlane(ok ? (int)fl - 1 : kNone);
+        const int f = __builtin_amdgcn_readfirstlane(ztab[z].flags);
+        const int p1 = __builtin_amdgcn_readfirstlane(ztab[z].pl[1]);
+        // (a step whose taps are four plain planes, or -- stream axis of samples -- one plane inside the array)
+        const bool ok = (f & 4) != 0 || (q.sident && !(f & 3) && p1 >= 0);
+        return ok ? p1 - 1 : kNone;
     };
     const int kfirst = q.sident ? 1 : 0, klast = q.sident ? 1 : 3;      // the taps of a step that exist (one, when the stream axis holds samples)
 
@@ -575,8 +594,7 @@ cubic3_zfactor_kernel(const float *__restrict__ in, float *__restrict__ out, con
 #pragma unroll
                 for (int kz = 0; kz < 4; kz++) {
                     const int pl = cur.pl[kz];
-                    const int s_ = pl & 3;
-                    qtag0 = s_ == 0 ? pl : qtag0; qtag1 = s_ == 1 ? pl : qtag1; qtag2 = s_ == 2 ? pl : qtag2; qtag3 = s_ == 3 ? pl : qtag3;
+                    set_tag(pl);
                 }
             }
             skip_store = true;                                   // cubic3_zfix_kernel writes these voxels
@@ -590,20 +608,21 @@ cubic3_zfactor_kernel(const float *__restrict__ in, float *__restrict__ out, con
                 const int s = pl & 3;
                 float T[8];
                 eval_plane(pl, T);
+                set_tag(pl);
                 switch (s) {
-                case 0: qtag0 = pl;
+                case 0:
 #pragma unroll
                     for (int k = 0; k < 8; k++) Q[0][k] = T[k];
                     break;
-                case 1: qtag1 = pl;
+                case 1:
 #pragma unroll
                     for (int k = 0; k < 8; k++) Q[1][k] = T[k];
                     break;
-                case 2: qtag2 = pl;
+                case 2:
 #pragma unroll
                     for (int k = 0; k < 8; k++) Q[2][k] = T[k];
                     break;
-                default: qtag3 = pl;
+                default:
 #pragma unroll
                     for (int k = 0; k < 8; k++) Q[3][k] = T[k];
                     break;
@@ -1160,14 +1179,19 @@ int launch_cubic_zfactor(int sax, const float *in, float *out, const CubZParams 
         attr_done = true;
     }
     void *flags = nullptr;
-    int rc = pool_alloc(&flags, (size_t)tw * sizeof(int), s);
+    // one block: the far flag of every (tile, wave) + the table of z taps (one record per output plane)
+    const size_t flag_bytes = ((size_t)tw * sizeof(int) + 255) & ~(size_t)255;
+    int rc = pool_alloc(&flags, flag_bytes + (size_t)q.oz * sizeof(ZRec), s);
     if (rc) return rc;
+    ZRec *ztab = reinterpret_cast<ZRec *>((char *)flags + flag_bytes);
+    hipLaunchKernelGGL(cubic3_ztaps_kernel, dim3((unsigned)((q.oz + 63) / 64)), dim3(64), 0, s, ztab, q);
+    const dim3 fgrid((unsigned)tw, (unsigned)((q.oz + kCzFixPlanes - 1) / kCzFixPlanes));
     if (sax == 0) {
-        hipLaunchKernelGGL(cubic3_zfactor_kernel<0>, dim3((unsigned)blocks), dim3(kCzNT), lds, s, in, out, q, (int *)flags);
-        hipLaunchKernelGGL(cubic3_zfix_kernel<0>, dim3((unsigned)tw, (unsigned)((q.oz + kCzFixPlanes - 1) / kCzFixPlanes)), dim3(64), 0, s, in, out, q, (const int *)flags);
+        hipLaunchKernelGGL(cubic3_zfactor_kernel<0>, dim3((unsigned)blocks), dim3(kCzNT), lds, s, in, out, q, (int *)flags, (const ZRec *)ztab);
+        hipLaunchKernelGGL(cubic3_zfix_kernel<0>, fgrid, dim3(64), 0, s, in, out, q, (const int *)flags, (const ZRec *)ztab);
     } else {
-        hipLaunchKernelGGL(cubic3_zfactor_kernel<1>, dim3((unsigned)blocks), dim3(kCzNT), lds, s, in, out, q, (int *)flags);
-        hipLaunchKernelGGL(cubic3_zfix_kernel<1>, dim3((unsigned)tw, (unsigned)((q.oz + kCzFixPlanes - 1) / kCzFixPlanes)), dim3(64), 0, s, in, out, q, (const int *)flags);
+        hipLaunchKernelGGL(cubic3_zfactor_kernel<1>, dim3((unsigned)blocks), dim3(kCzNT), lds, s, in, out, q, (int *)flags, (const ZRec *)ztab);
+        hipLaunchKernelGGL(cubic3_zfix_kernel<1>, fgrid, dim3(64), 0, s, in, out, q, (const int *)flags, (const ZRec *)ztab);
     }
     const hipError_t e = hipGetLastError();
     pool_free(flags);                    // stream-ordered pool: reused only by later work on the stream

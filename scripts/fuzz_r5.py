@@ -1,0 +1,100 @@
+"""r5: targeted differential fuzz of the default-order (3) routes against scipy.ndimage on volumes large enough to take the round-5
+kernels (one-sweep prefilter, cubic3_zfactor / zfix, row-blend with an unfiltered axis, the resampling passes, the LDS box affine
+on cube tiles): random shapes, matrices, modes, output shapes.  float32 in / out: 2e-5 max(1, max|ref|); float64 prefilter: 1e-11.
+usage: python scripts/fuzz_r5.py [seconds] [seed]  -> profiles/r5_fuzz_summary.txt"""
+import os, sys, time, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import scipy.ndimage as sndi
+import cupyimg_amd as ca
+from cupyimg_amd import last_kernel
+from cupyimg_amd.scipy import ndimage as ndi
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+MODES = ["constant", "mirror", "nearest", "reflect", "grid-wrap", "wrap", "grid-constant"]
+kernels = collections.Counter()
+fails = []
+cases = 0
+
+
+def rshape():
+    return (int(rng.integers(64, 150)), int(rng.integers(64, 170)), int(rng.choice([64, 68, 96, 100, 128, 132, 192, 256, 260])))
+
+
+def rot(axis, deg):
+    a = np.deg2rad(deg); u = np.asarray(axis, float); u /= np.linalg.norm(u)
+    K = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+
+
+def check(name, got, ref, tol, info):
+    global cases
+    cases += 1
+    kernels[last_kernel()[4:].split(" ")[0].split("(")[0]] += 1
+    if got.shape != ref.shape:
+        fails.append((name, "shape", got.shape, ref.shape, info)); return
+    err = float(np.abs(got.astype(np.float64) - ref).max()) / max(1.0, float(np.abs(ref).max()))
+    if not (err <= tol):
+        fails.append((name, err, info))
+
+
+t_end = time.time() + budget
+while time.time() < t_end:
+    shape = rshape()
+    v = rng.standard_normal(shape).astype(np.float32)
+    vd = ca.asarray(v)
+    v64 = v.astype(np.float64)
+    mode = str(rng.choice(MODES))
+    op = int(rng.integers(0, 8))
+    try:
+        if op == 0:
+            order = int(rng.choice([2, 3, 3]))
+            m = str(rng.choice(["mirror", "reflect", "constant", "nearest"]))
+            check("spline_filter64", ndi.spline_filter(vd, order, mode=m).get(), sndi.spline_filter(v64, order, mode=m), 1e-11, (shape, order, m))
+            check("spline_filter32", ndi.spline_filter(vd, order, output=np.float32, mode=m).get(), sndi.spline_filter(v64, order, mode=m), 2e-6, (shape, order, m))
+        elif op == 1:
+            axes = [(1, 0), (2, 1), (2, 0)][int(rng.integers(0, 3))]
+            ang = float(rng.uniform(-180, 180)); reshape = bool(rng.integers(0, 2))
+            check("rotate", ndi.rotate(vd, ang, axes=axes, reshape=reshape, mode=mode, cval=0.3).get(),
+                  sndi.rotate(v64, ang, axes=axes, reshape=reshape, mode=mode, cval=0.3), 2e-5, (shape, axes, ang, reshape, mode))
+        elif op == 2:
+            z = [float(rng.uniform(0.6, 1.8)) for _ in range(3)]
+            check("zoom", ndi.zoom(vd, z, mode=mode, cval=0.3).get(), sndi.zoom(v64, z, mode=mode, cval=0.3), 2e-5, (shape, z, mode))
+        elif op == 3:
+            sh = [float(rng.uniform(-20, 20)) for _ in range(3)]
+            check("shift", ndi.shift(vd, sh, mode=mode, cval=0.3).get(), sndi.shift(v64, sh, mode=mode, cval=0.3), 2e-5, (shape, sh, mode))
+        elif op in (4, 5):
+            # in-plane rotation + step along the stream axis (zfactor / zfix), random output shape
+            pl = [(1, 2), (0, 2)][int(rng.integers(0, 2))]
+            a = np.deg2rad(rng.uniform(-80, 80)); c, s_ = np.cos(a), np.sin(a)
+            M = np.eye(3); i, j = pl
+            M[i, i], M[i, j], M[j, i], M[j, j] = c, -s_, s_, c
+            k = 3 - i - j
+            M[k, k] = float(rng.choice([1.0, 1.02, 0.97, -1.0, 0.5, 1.25]))
+            osh = tuple(int(n + rng.integers(-10, 20)) for n in shape)
+            off = (np.array(shape) - 1) / 2 - M @ ((np.array(osh) - 1) / 2) + rng.uniform(-3, 3, 3)
+            if rng.random() < 0.3:
+                off[k] = np.round(off[k])
+            check("affine3-plane", ndi.affine_transform(vd, M, off, output_shape=osh, mode=mode, cval=0.3).get(),
+                  sndi.affine_transform(v64, M, off, output_shape=osh, mode=mode, cval=0.3), 2e-5, (shape, osh, pl, float(np.rad2deg(a)), M[k, k], mode))
+        elif op == 6:
+            M = rot(rng.standard_normal(3), float(rng.uniform(-30, 30))); off = (np.array(shape) - 1) / 2 - M @ ((np.array(shape) - 1) / 2) + rng.uniform(-3, 3, 3)
+            order = int(rng.choice([1, 3]))
+            check("affine-general-o%d" % order, ndi.affine_transform(vd, M, off, order=order, mode="constant", cval=0.3).get(),
+                  sndi.affine_transform(v64, M, off, order=order, mode="constant", cval=0.3), 2e-5 if order == 3 else 4e-6, (shape, order))
+        else:
+            M = rot((0, 0, 1), float(rng.uniform(-40, 40)))      # rotation in the (z, y) plane: x to itself (row-blend)
+            off = (np.array(shape) - 1) / 2 - M @ ((np.array(shape) - 1) / 2)
+            off[2] = float(rng.integers(-5, 6))
+            check("affine3-rowblend", ndi.affine_transform(vd, M, off, mode=mode, cval=0.3).get(),
+                  sndi.affine_transform(v64, M, off, mode=mode, cval=0.3), 2e-5, (shape, mode, off[2]))
+    except Exception as exc:      # noqa
+        fails.append(("exception", repr(exc)[:200], (shape, op, mode)))
+print("r5 targeted fuzz: seed %d, %d cases in %.0f s, %d failures" % (seed, cases, budget, len(fails)))
+for k, n in kernels.most_common():
+    print("   %5d  %s" % (n, k))
+for f in fails[:20]:
+    print("FAIL", f)
+sys.exit(1 if fails else 0)
