@@ -943,11 +943,13 @@ int launch_resample_zstream(const float *in, float *out, const AxisTaps *all_tab
 // block needs per axis) with LDS-DMA exactly as affine3d_lds_kernel (interp_fast.hip) does for order 1, and reads a voxel's
 // 64 taps as 32 ds_read2_b32 from sixteen row addresses.  Tap selection, weights, products and the order of the sums are
 // cubic3_gather's (cubic3_f32_kernel's): bit-identical results.  Voxels whose taps are not a plain 4 x 4 x 4 block inside
-// the array (coordinates within a sample or two of its faces, folded or cval taps) and voxels beyond the array take
-// cubic3_gather itself; matrices whose box exceeds 64 KiB (beyond ~12 degrees) stay with the gather kernel.
+// the array (coordinates within a sample or two of its faces, folded or cval taps) take cubic3_gather itself in a second
+// phase over a workgroup-wide queue; voxels beyond the array (constant mode) are cval at once; matrices whose box exceeds
+// 128 KiB (down-scaling by more than ~1.5) stay with the gather kernel.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kBoxT = 16;                                   // the cube's edge
-constexpr int kBoxBytesMax = 64 * 1024, kBoxRoundsMax = 8;  // box budget (two workgroups per CU); staging rounds of 512 chunks
+constexpr int kBoxBytesMax = 128 * 1024, kBoxRoundsMax = 16; // box budget; staging rounds of 512 chunks.  Up to 64 KiB two workgroups share a CU (1.1-1.6 ms on
+                                                            // 512^3, rotations up to ~12 degrees); beyond, one (1.9-2.1 ms up to 45 degrees) -- the gathers take 4.2-5.7 ms there
 
 struct CubBoxParams {
     int nz, ny, nx, oz, oy, ox;
@@ -958,6 +960,7 @@ struct CubBoxParams {
     double cmin[3];
     int mode, npad;
     float cval;
+    int dbg;                     // timing ablations (0 in production): 2 = no second phase, 4 = no taps, 8 = no box DMA
 };
 
 __global__ void __launch_bounds__(512, 4)          // four waves per SIMD = two workgroups per CU (one computes while the other's box is in flight)
@@ -1001,7 +1004,7 @@ cubic3_box_kernel(const float *__restrict__ in, float *__restrict__ out, const C
             bool ok = ch < (unsigned)q.nchunks;
             if (!inside) ok = ok && b0[0] + (int)rz < q.nz && b0[1] + (int)ry < q.ny && b0[2] + 4 * (int)c4 < q.nx;
             const unsigned voff = ok ? rz * plane_b + ry * row_b + c4 * 16u : 0x80000000u;
-            cz_dma16(rin, voff, base, (unsigned)((wave << 6) + (j << 9)) * 16u, ~0ull);
+            if (!(q.dbg & 8)) cz_dma16(rin, voff, base, (unsigned)((wave << 6) + (j << 9)) * 16u, ~0ull);
         }
     }
     for (int e = tid; e < T * T * 3; e += 512) {
@@ -1035,8 +1038,16 @@ cubic3_box_kernel(const float *__restrict__ in, float *__restrict__ out, const C
             const bool plain = f0 >= 1.0 && f0 + 2.0 <= (double)(q.nz - 1) && f1 >= 1.0 && f1 + 2.0 <= (double)(q.ny - 1) && f2 >= 1.0 && f2 + 2.0 <= (double)(q.nx - 1);
             const int sz = (int)f0 - 1 - b0[0], sy = (int)f1 - 1 - b0[1], sx = (int)f2 - 1 - b0[2];
             const bool held = plain && sz >= 0 && sz + 3 < q.bz && sy >= 0 && sy + 3 < q.by && sx >= 0 && sx + 3 < q.bx;
+            // constant mode: a coordinate beyond the array gives cval (cubic3_axis_frac's test) -- decided here: whole tiles of a
+            // rotated volume's corners lie outside, and through the second phase they cost 3.5 of the launch's 4.5 ms
+            const bool out_c = q.mode == MI_MODE_CONSTANT && (p0 < 0.0 || p0 > (double)(q.nz - 1) || p1 < 0.0 || p1 > (double)(q.ny - 1) ||
+                                                             p2 < 0.0 || p2 > (double)(q.nx - 1));
             float val;
-            if (held) {
+            if (out_c) {
+                val = q.cval;
+            } else if (held && (q.dbg & 4)) {
+                val = (float)(p0 + p1 + p2);
+            } else if (held) {
                 float wz_[4], wy_[4], wx_[4];
                 cubic3_weights((float)(p0 - f0), wz_);
                 cubic3_weights((float)(p1 - f1), wy_);
@@ -1088,32 +1099,50 @@ cubic3_box_kernel(const float *__restrict__ in, float *__restrict__ out, const C
             }
         }
     }
-    // ---- second phase: the voxels whose taps fold at the array's faces, read cval or lie beyond the array -- cubic3_gather itself
-    // (kept out of the loop above: its registers would be that loop's).  Their place in the output was written (as zeros) by
-    // OTHER lanes of the wave in the transposed 16-byte stores above: those stores are complete before the values follow.
+    // ---- second phase: the voxels whose taps fold at the array's faces or read cval (a shell of two samples along the six faces:
+    // ~2 % of the voxels, spread over a fifth of the tiles) -- cubic3_gather itself.  The flagged voxels of the WORKGROUP are
+    // collected in a queue (LDS, where the box was) and worked off 512 at a time: run by the wave that owns them, every wave with
+    // one such lane paid the gather routine's full latency up to eight times (1.5 ms of a 2.6 ms launch).
+    // Their place in the output was written (as zeros) by OTHER lanes of the wave in the transposed 16-byte stores above: those
+    // stores are complete before the values follow.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (todo != 0u) {
+    __syncthreads();                                         // everybody has left the box
+    unsigned short *queue = reinterpret_cast<unsigned short *>(smem_box);
+    int *qcount = reinterpret_cast<int *>(tiles);
+    if (tid == 0) *qcount = 0;
+    __syncthreads();
+    if (todo != 0u && !(q.dbg & 2)) {
 #pragma unroll 1
         for (int kl = 0; kl < 8; kl++) {
             if (!((todo >> kl) & 1u)) continue;
-            const int z = z0 + 8 * wz + kl, y = y0 + yrow, x = x0 + lx;
-            if (x >= q.ox || y >= q.oy || z >= q.oz) continue;
-            const int rr = T * (8 * wz + kl) + yrow;
-            const double c0 = (ptab[rr][0] + xz_) + q.m[3], c1 = (ptab[rr][1] + xy_) + q.m[7], c2 = (ptab[rr][2] + xx_) + q.m[11];
-            Cubic3 tt;
-            bool outside = cubic3_axis(q.nz, nxy, c0, q.mode, q.npad, tt.w[0], tt.off[0]);
-            outside |= cubic3_axis(q.ny, q.nx, c1, q.mode, q.npad, tt.w[1], tt.off[1]);
-            outside |= cubic3_axis(q.nx, 1, c2, q.mode, q.npad, tt.w[2], tt.off[2]);
-            tt.ntap[0] = 4; tt.ntap[1] = 4;
-            tt.outside = outside;
-            out[((size_t)z * q.oy + y) * q.ox + x] = cubic3_gather_lean(rin, tt, q.cval);
+            const int slot = atomicAdd(qcount, 1);
+            queue[slot] = (unsigned short)(((8 * wz + kl) << 8) | (yrow << 4) | lx);
         }
+    }
+    __syncthreads();
+    const int nq = *qcount;
+#pragma unroll 1
+    for (int e = tid; e < nq; e += 512) {
+        const int id = queue[e];
+        const int kz_ = id >> 8, ky_ = (id >> 4) & 15, kx_ = id & 15;
+        const int z = z0 + kz_, y = y0 + ky_, x = x0 + kx_;
+        if (x >= q.ox || y >= q.oy || z >= q.oz) continue;
+        const int rr = T * kz_ + ky_;
+        const double dxe = (double)x;
+        const double c0 = (ptab[rr][0] + q.m[2] * dxe) + q.m[3], c1 = (ptab[rr][1] + q.m[6] * dxe) + q.m[7], c2 = (ptab[rr][2] + q.m[10] * dxe) + q.m[11];
+        Cubic3 tt;
+        bool outside = cubic3_axis(q.nz, nxy, c0, q.mode, q.npad, tt.w[0], tt.off[0]);
+        outside |= cubic3_axis(q.ny, q.nx, c1, q.mode, q.npad, tt.w[1], tt.off[1]);
+        outside |= cubic3_axis(q.nx, 1, c2, q.mode, q.npad, tt.w[2], tt.off[2]);
+        tt.ntap[0] = 4; tt.ntap[1] = 4;
+        tt.outside = outside;
+        out[((size_t)z * q.oy + y) * q.ox + x] = cubic3_gather_lean(rin, tt, q.cval);
     }
 }
 
 // plan + launch; false = not taken (diagonal / decoupled matrices have better kernels; box too large; small outputs)
 bool launch_cubic_box(const float *in, float *out, const int shape[3], const int oshape[3], const double *mat, int mode, double cval, int npad,
-                      hipStream_t s, int *rc)
+                      hipStream_t s, int *rc, int dbg)
 {
     *rc = MI_OK;
     CubBoxParams q;
@@ -1135,7 +1164,8 @@ bool launch_cubic_box(const float *in, float *out, const int shape[3], const int
     for (int a = 0; a < 2; a++) if (dim[a] > n[a]) dim[a] = n[a];
     if (dim[2] > ((n[2] + 3) & ~3) + 4) dim[2] = ((n[2] + 3) & ~3) + 4;
     const long long floats = (long long)dim[0] * dim[1] * dim[2];
-    if (floats * 4 > kBoxBytesMax || (floats / 4 + 511) / 512 > kBoxRoundsMax) return false;
+    const long long budget = (dbg >> 4) > 0 ? (long long)(dbg >> 4) * 1024 : (long long)kBoxBytesMax;       // test hook: knob >> 4 = budget in KiB
+    if (floats * 4 > budget || (floats / 4 + 511) / 512 > kBoxRoundsMax) return false;
     q.bz = dim[0]; q.by = dim[1]; q.bx = dim[2];
     q.nchunks = (int)(floats / 4);
     {
@@ -1150,12 +1180,13 @@ bool launch_cubic_box(const float *in, float *out, const int shape[3], const int
         q.cmin[a] = c;
     }
     q.mode = mode; q.npad = npad; q.cval = (float)cval;
+    q.dbg = dbg & 14;
     const dim3 grid((unsigned)((q.ox + kBoxT - 1) / kBoxT), (unsigned)((q.oy + kBoxT - 1) / kBoxT), (unsigned)((q.oz + kBoxT - 1) / kBoxT));
     if (grid.y > 65535 || grid.z > 65535) return false;
     const size_t lds = (((size_t)q.nchunks * 16 + 8191) & ~(size_t)8191) + kBoxT * kBoxT * 3 * sizeof(double) + 8 * 256 * sizeof(float);
     static PerDeviceOnce attr_done;
     if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute((const void *)cubic3_box_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        const hipError_t e = hipFuncSetAttribute((const void *)cubic3_box_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { *rc = (int)e; return true; }
         attr_done = true;
     }

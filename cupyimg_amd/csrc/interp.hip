@@ -981,12 +981,10 @@ cubic3_zstream_kernel(const float *__restrict__ in, float *__restrict__ out, con
     }
 }
 
-Knob g_cubic_box{0};          // 1 = cubic3_box_kernel (taps out of an LDS-staged box) for matrices that couple all three axes.  OFF by default: correct
-                              // (bit-identical to the gather kernel, tests/test_gpu_spline_fast.py) but measured SLOWER than it on 512^3 --
-                              // 4.0-5.9 ms against 2.2-3.9 ms at 1-12 degrees (profiles/r5_cubic_general.txt): one voxel's 64 dependent LDS
-                              // reads at a time per thread against the L1's good hit rate at small angles; kept for the next round's tuning
+Knob g_cubic_box{1};          // 0 = the gather kernel for matrices that couple all three axes; 1 = cubic3_box_kernel (taps out of an LDS-staged box) when the
+                              // box fits; bits 2 / 4 / 8: timing ablations (no second phase / no taps / no box DMA)
 extern "C" int mi_debug_set_cubic_box(int on) { g_cubic_box = on; return MI_OK; }
-bool launch_cubic_box(const float *in, float *out, const int shape[3], const int oshape[3], const double *mat, int mode, double cval, int npad, hipStream_t s, int *rc);   // cubic_fast.hip
+bool launch_cubic_box(const float *in, float *out, const int shape[3], const int oshape[3], const double *mat, int mode, double cval, int npad, hipStream_t s, int *rc, int dbg);   // cubic_fast.hip
 Knob g_resample_fast{1};      // test hook: 0 = the r3 separable resampling passes for diagonal order-3 transforms
 extern "C" int mi_debug_set_resample_fast(int on) { g_resample_fast = on; return MI_OK; }
 int launch_resample_x_lds(const float *in, float *out, const AxisTaps *tabx, long long nrows, int ox, int nx, float cval, hipStream_t s);          // cubic_fast.hip
@@ -2576,7 +2574,7 @@ int mi_spline_affine_transform(const mi_array *coef, const mi_array *out, const 
             // r5: all three axes coupled (small rotations about a general axis): taps out of an LDS-staged box (csrc/cubic_fast.hip)
             if (g_cubic_box && g.pad == 0) {
                 const int shp[3] = {(int)g.shape[0], (int)g.shape[1], (int)g.shape[2]}, osh[3] = {(int)g.oshape[0], (int)g.oshape[1], (int)g.oshape[2]};
-                if (launch_cubic_box((const float *)coef->data, (float *)out->data, shp, osh, g.mat, mode, cval, npad, s, &zrc)) return zrc;
+                if (launch_cubic_box((const float *)coef->data, (float *)out->data, shp, osh, g.mat, mode, cval, npad, s, &zrc, g_cubic_box)) return zrc;
             }
         }
         note_kernel(diagonal ? "mi::cubic3_diag_f32_kernel (order-3 affine on float32 coefficients, diagonal matrix: tabulated taps)"

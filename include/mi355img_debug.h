@@ -77,7 +77,7 @@ int mi_debug_set_spline_rows_lds(int on);     /* spline prefilter along the cont
 int mi_debug_set_spline_fast(int k);          /* r5 prefilter kernels (csrc/spline_fast.hip: one memory sweep per axis): 0 = never, 1 = volumes with >= 16384 lines (default), 2 = any line count */
 int mi_debug_set_cubic_rowblend(int on);      /* order-3 affine on float32 coefficients, x axis to itself: 0 = the gather kernel, 1 = the row-blend kernel (default) */
 int mi_debug_set_cubic_zstream(int on);       /* order-3 affine on float32 coefficients, axis 0 decoupled: 0 = the gather kernel, 1 = the z-streaming kernel (default), bits on top of 1: 2 = every wave on its gather path, 4 = no limit on the angle, 8 = grid-wrap / grid-constant too */
-int mi_debug_set_cubic_box(int on);           /* order-3 affine, all three axes coupled: 1 = taps out of an LDS-staged box when it fits (r5 experiment: bit-identical but slower than the gathers), 0 = the gather kernel (default) */
+int mi_debug_set_cubic_box(int on);           /* order-3 affine, all three axes coupled: 1 = taps out of an LDS-staged box when it fits (r5, default), 0 = the gather kernel; bits 2 / 4 / 8: timing ablations */
 int mi_debug_set_resample_fast(int on);       /* diagonal order-3 transforms on volumes (zoom, shift): 1 = r5 passes (x from LDS-staged spans, z with the plane window in registers), 0 = r3 passes (bit-identical) */
 int mi_debug_set_cubic_zfactor(int on);       /* order-3 affine, stream axis decoupled: 1 = cubic3_zfactor_kernel (r5: in-plane values once per input plane; float32 rounding away from the gather kernel), 0 = cubic3_zstream_kernel (r4b: bit-identical to the gather kernel) */
 int mi_debug_set_stream_nt(int k);             /* non-temporal staging of rows no other workgroup reads (sep3d_long3 <= 9 taps, mm3f32_long, mm3u8_split <= 5): -1 by volume size (default), 0 never, 1 always */

@@ -18,7 +18,7 @@ def rot(axis, deg):
     K = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0]])
     return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
 for axis in ((1, 1, 1), (1, 0, 1), (0.3, 1, -0.5)):
-    for deg in (1, 3, 5, 7, 10, 12, 15):
+    for deg in (1, 3, 5, 7, 10, 15, 20, 30, 45):
         M = rot(axis, deg); off = ctr - M @ ctr + np.array([0.5, -1.25, 2.0])
         row = {"axis": axis, "deg": deg}
         for knob, name in ((1, "box kernel"), (0, "gather")):
@@ -26,7 +26,7 @@ for axis in ((1, 1, 1), (1, 0, 1), (0.3, 1, -0.5)):
             t, _ = timeit(lambda: ndi.affine_transform(xd, M, off, order=3, prefilter=False, output=out), 4)
             row[name + " us"] = round(t * 1e6, 1)
             if knob: row["kernel"] = last_kernel()[4:24]; row["of 8 TB/s"] = round(2 * x.nbytes / 8e12 / t, 3)
-        lib.mi_debug_set_cubic_box(0)
+        lib.mi_debug_set_cubic_box(1)
         t, _ = timeit(lambda: ndi.affine_transform(xd, M, off, order=3, output=out), 4)
         row["whole call with prefilter us"] = round(t * 1e6, 1)
         print(json.dumps(row), flush=True)

@@ -265,13 +265,12 @@ def test_zoom_shift_resampling_passes(gpu, ndi, lib):
 
 
 def test_cubic_box_kernel_general_matrices(gpu, ndi, lib):
-    """r5 (experimental, behind mi_debug_set_cubic_box(1): measured slower than the gather kernel, profiles/r5_cubic_general.txt):
-    order-3 affine transforms whose matrix couples all three axes take their taps out of an LDS-staged box
-    (cubic3_box_kernel: 16^3 output cube per workgroup) when the box fits 64 KiB (up to ~12 degrees about a general axis):
+    """r5: order-3 affine transforms whose matrix couples all three axes take their taps out of an LDS-staged box
+    (cubic3_box_kernel: 16^3 output cube per workgroup) when the box fits 128 KiB (any rotation; two workgroups per CU up to 64 KiB):
     bit-identical to the gather kernel (cubic3_f32_kernel: same taps, weights, products, order of the sums) in every mode --
     voxels at the array's faces go through the kernel's second phase --, for volumes that are not multiples of the tile,
-    other output shapes, padded modes, non-finite coefficients; within float32 accuracy of SciPy; larger angles keep the
-    gather kernel."""
+    other output shapes, padded modes, non-finite coefficients; within float32 accuracy of SciPy; matrices that shrink
+    the volume by more than ~1.5 (box beyond the budget) keep the gather kernel."""
     from cupyimg_amd import last_kernel
     rng = np.random.default_rng(77)
 
@@ -285,36 +284,36 @@ def test_cubic_box_kernel_general_matrices(gpu, ndi, lib):
         x = rng.standard_normal(shape).astype(np.float32)
         xd = gpu.asarray(x)
         osh = shape if oshape is None else oshape
-        for axis, deg in (((1, 1, 1), 6.0), ((0.3, 1, -0.5), 9.0), ((1, 0.2, 1), -4.0)):
+        for axis, deg in (((1, 1, 1), 6.0), ((0.3, 1, -0.5), 9.0), ((1, 0.2, 1), -4.0), ((1, 1, 1), 38.0)):
             M = rot(axis, deg) @ np.diag([1.02, 0.98, 1.0])
             off = (np.array(shape) - 1) / 2 - M @ ((np.array(osh) - 1) / 2) + np.array([0.4, -1.3, 2.2])
             for mode in ("constant", "mirror", "nearest", "reflect", "grid-wrap", "grid-constant", "wrap"):
                 for prefilter in ((True, False) if mode == "constant" else (True,)):
                     kw = dict(output_shape=osh, order=3, mode=mode, cval=0.5, prefilter=prefilter)
-                    want = ndi.affine_transform(xd, M, off, **kw).get()
-                    assert "cubic3_f32_kernel" in last_kernel(), last_kernel()
-                    lib.mi_debug_set_cubic_box(1)
+                    lib.mi_debug_set_cubic_box(0)
                     try:
-                        got = ndi.affine_transform(xd, M, off, **kw).get()
-                        took += "cubic3_box_kernel" in last_kernel()
+                        want = ndi.affine_transform(xd, M, off, **kw).get()
+                        assert "cubic3_f32_kernel" in last_kernel(), last_kernel()
                     finally:
-                        lib.mi_debug_set_cubic_box(0)
+                        lib.mi_debug_set_cubic_box(1)
+                    got = ndi.affine_transform(xd, M, off, **kw).get()
+                    took += "cubic3_box_kernel" in last_kernel()
                     assert np.array_equal(got, want, equal_nan=True), (shape, osh, axis, deg, mode, prefilter, last_kernel()[:50], int(np.sum(got != want)))
                     if prefilter and mode in ("constant", "mirror", "nearest"):
                         ref = sndi.affine_transform(x.astype(np.float64), M, off, output_shape=osh, order=3, mode=mode, cval=0.5)
                         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (shape, axis, deg, mode)
-    assert took >= 60, took
+    assert took >= 80, took
     x = rng.standard_normal((80, 96, 112)).astype(np.float32)
     x[20, 30, 40] = np.inf; x[60, 70, 80] = np.nan
     xd = gpu.asarray(x)
     M = rot((1, 1, 1), 5.0); off = np.array([1.5, -2.0, 0.7])
-    want = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
-    lib.mi_debug_set_cubic_box(1)
+    got = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
+    assert "cubic3_box_kernel" in last_kernel()
+    ndi.affine_transform(xd, rot((1, 1, 1), 40.0) * 2.5, off, order=3, prefilter=False)
+    assert "cubic3_f32_kernel" in last_kernel()
+    lib.mi_debug_set_cubic_box(0)
     try:
-        got = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
-        assert "cubic3_box_kernel" in last_kernel()
-        ndi.affine_transform(xd, rot((1, 1, 1), 40.0), off, order=3, prefilter=False)
-        assert "cubic3_f32_kernel" in last_kernel()
+        want = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
     finally:
-        lib.mi_debug_set_cubic_box(0)
+        lib.mi_debug_set_cubic_box(1)
     assert np.array_equal(got, want, equal_nan=True)
