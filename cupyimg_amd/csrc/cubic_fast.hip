@@ -30,6 +30,8 @@
 
 namespace mi {
 
+constexpr int kBoxT = 16;          // edge of the output cube a workgroup of the box kernels owns (cubic3_box_kernel, cubic3_mapbox_kernel)
+
 // cubic3_gather's taps, products and order of sums (bit-identical to it), with the four rows of ONE stream-axis tap in flight
 // at a time: the fallback of a kernel that keeps ~130 registers of per-voxel state (cubic3_gather itself holds all 64 taps:
 // the kernel spilled, which a kernel that counts its vector-memory operations must not)
@@ -700,6 +702,239 @@ cubic3_zfactor_kernel(const float *__restrict__ in, float *__restrict__ out, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// r5: map_coordinates, ORDER 3 (its default: interpolation.py:275) on float32 coefficients -- the taps out of a box the
+// workgroup sizes from ITS OWN coordinates.  cubic3_f32_kernel gathers through the L1: 3.4 ms on 512^3 against 0.49 ms for order 1
+// (the largest cliff left on the path).  As cubic3_box_kernel: a 16^3 cube of output voxels per workgroup; here the bounding
+// box of the tap blocks is reduced from the workgroup's coordinates (per thread over its eight voxels, DPP / shuffle per wave, six
+// LDS atomics per wave -- only voxels whose three tap blocks are plain blocks inside the array count), staged by LDS-DMA when it
+// fits 64 KiB (smooth warps: it does), and the taps come out of LDS.  Everything else -- voxels at the array's faces, non-finite
+// coordinates, tiles whose box does not fit (noise, folds) -- goes through the workgroup-wide queue to cubic3_gather.  Tap
+// selection, weights, products, order of the sums: cubic3_gather's -- bit-identical to the gather kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+struct MapBoxParams {
+    int nz, ny, nx, oz, oy, ox;
+    int mode, npad;
+    float cval;
+    int dbg;
+};
+
+constexpr int kMapBoxBytes = 64 * 1024;
+
+template <typename C>
+__global__ void __launch_bounds__(512, 4)
+cubic3_mapbox_kernel(const float *__restrict__ in, const C *__restrict__ coords, float *__restrict__ out, const MapBoxParams q)
+{
+    constexpr int T = kBoxT, RW = 4, WY = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_mb[];
+    float *box = reinterpret_cast<float *>(smem_mb);
+    int *red = reinterpret_cast<int *>(smem_mb + kMapBoxBytes);              // [0..2] min start, [3..5] max end, [6] queue count
+    float *tiles = reinterpret_cast<float *>(smem_mb + kMapBoxBytes + 64);   // [8 waves][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lx = lane & (T - 1), yy = lane / T;
+    const int wy = wave % WY, wz = wave / WY;
+    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T, z0 = blockIdx.z * T;
+    const int yrow = RW * wy + yy;
+    const int x = x0 + lx, y = y0 + yrow;
+    const bool col_ok = x < q.ox && y < q.oy;
+    const size_t nvox = (size_t)q.oz * q.oy * q.ox;
+    const int nxy = q.ny * q.nx;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, q.nz * nxy * 4, 0x00020000);
+    if (tid < 3) red[tid] = 0x7fffffff;
+    else if (tid < 6) red[tid] = -0x7fffffff;
+    else if (tid == 6) red[6] = 0;
+    // ---- this thread's eight coordinates (planes z0 + 8 wz + k) and their tap blocks
+    C cz[8], cy[8], cx[8];
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+    unsigned plainmask = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int z = z0 + 8 * wz + k;
+        const bool ok = col_ok && z < q.oz;
+        const size_t i = ((size_t)(ok ? z : 0) * q.oy + (ok ? y : 0)) * q.ox + (ok ? x : 0);
+        cz[k] = __builtin_nontemporal_load(coords + i);
+        cy[k] = __builtin_nontemporal_load(coords + nvox + i);
+        cx[k] = __builtin_nontemporal_load(coords + 2 * nvox + i);
+        const double p0 = (double)cz[k] + (double)q.npad, p1 = (double)cy[k] + (double)q.npad, p2 = (double)cx[k] + (double)q.npad;
+        const double f0 = floor(p0), f1 = floor(p1), f2 = floor(p2);
+        const bool plain = ok && f0 >= 1.0 && f0 + 2.0 <= (double)(q.nz - 1) && f1 >= 1.0 && f1 + 2.0 <= (double)(q.ny - 1) && f2 >= 1.0 && f2 + 2.0 <= (double)(q.nx - 1);
+        if (plain) {
+            plainmask |= 1u << k;
+            const int s0 = (int)f0 - 1, s1 = (int)f1 - 1, s2 = (int)f2 - 1;
+            lo[0] = min(lo[0], s0); hi[0] = max(hi[0], s0 + 3);
+            lo[1] = min(lo[1], s1); hi[1] = max(hi[1], s1 + 3);
+            lo[2] = min(lo[2], s2); hi[2] = max(hi[2], s2 + 3);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { lo[a] = min(lo[a], __shfl_xor(lo[a], m, 64)); hi[a] = max(hi[a], __shfl_xor(hi[a], m, 64)); }
+    __syncthreads();                                         // red[] initialised
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { atomicMin(&red[a], lo[a]); atomicMax(&red[3 + a], hi[a]); }
+    }
+    __syncthreads();
+    const int b0z = red[0], b0y = red[1], b0x = red[2] & ~3;
+    const int bz = red[3] - b0z + 1, by = red[4] - b0y + 1, bx = (red[5] - b0x + 1 + 3) & ~3;
+    const bool any_plain = red[3] >= red[0];
+    const long long floats = any_plain ? (long long)bz * by * bx : 0;
+    const bool fits = any_plain && floats * 4 <= (long long)kMapBoxBytes && !(q.dbg & 2);
+    // ---- stage the box
+    if (fits) {
+        const unsigned cpr = (unsigned)bx >> 2;
+        const unsigned nchunks = (unsigned)(floats >> 2);
+        const unsigned cpr_magic = (unsigned)((((unsigned long long)1 << 32) + cpr - 1) / cpr);
+        const unsigned by_magic = (unsigned)((((unsigned long long)1 << 32) + (unsigned)by - 1) / (unsigned)by);
+        const unsigned row_b = (unsigned)q.nx * 4u, plane_b = (unsigned)q.ny * row_b;
+        const unsigned base = (unsigned)((b0z * q.ny + b0y) * q.nx + b0x) * 4u;
+        const int rounds = (int)((nchunks + 511u) >> 9);
+#pragma unroll 1
+        for (int j = 0; j < rounds; j++) {
+            const unsigned ch = (unsigned)tid + ((unsigned)j << 9);
+            // (a box ONE 16-byte chunk wide -- a tile whose only plain voxels touch the array's last column -- has the divisor 1,
+            // whose magic number does not fit 32 bits)
+            const unsigned row = cpr == 1u ? ch : __umulhi(ch, cpr_magic), c4 = ch - row * cpr;
+            const unsigned rz = __umulhi(row, by_magic), ry = row - rz * (unsigned)by;
+            const bool ok = ch < nchunks && b0x + 4 * (int)c4 < q.nx;      // (rows and planes of a box of plain blocks lie inside the array)
+            const unsigned voff = ok ? rz * plane_b + ry * row_b + c4 * 16u : 0x80000000u;
+            cz_dma16(rin, voff, base, __builtin_amdgcn_readfirstlane((unsigned)((wave << 6) + (j << 9)) * 16u), ~0ull);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int plane_f = by * bx;
+    float *tile = tiles + wave * 256;
+    const bool wide = x0 + T <= q.ox && y0 + T <= q.oy && z0 + T <= q.oz;
+    unsigned todo = 0;
+#pragma unroll
+    for (int bt = 0; bt < 2; bt++) {              // (unrolled: a rolled loop would index the coordinate registers at run time -- scratch)
+        float r[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int k = 4 * bt + kk;
+            const double p0 = (double)cz[k] + (double)q.npad, p1 = (double)cy[k] + (double)q.npad, p2 = (double)cx[k] + (double)q.npad;
+            const double f0 = floor(p0), f1 = floor(p1), f2 = floor(p2);
+            // constant mode: a coordinate beyond the array gives cval (cubic3_axis_frac's test)
+            const bool out_c = q.mode == MI_MODE_CONSTANT && (p0 < 0.0 || p0 > (double)(q.nz - 1) || p1 < 0.0 || p1 > (double)(q.ny - 1) ||
+                                                             p2 < 0.0 || p2 > (double)(q.nx - 1));
+            float val = 0.f;
+            if (out_c) {
+                val = q.cval;
+            } else if (fits && ((plainmask >> k) & 1u)) {
+                float wz_[4], wy_[4], wx_[4];
+                cubic3_weights((float)(p0 - f0), wz_);
+                cubic3_weights((float)(p1 - f1), wy_);
+                cubic3_weights((float)(p2 - f2), wx_);
+                const float *b = box + (((int)f0 - 1 - b0z) * by + ((int)f1 - 1 - b0y)) * bx + ((int)f2 - 1 - b0x);
+                float acc = 0.f;
+#pragma unroll
+                for (int kz = 0; kz < 4; kz++) {
+                    float v[4][4];
+#pragma unroll
+                    for (int ky = 0; ky < 4; ky++) {
+                        const float *t = b + kz * plane_f + ky * bx;
+#pragma unroll
+                        for (int kx = 0; kx < 4; kx++) v[ky][kx] = t[kx];
+                    }
+#pragma unroll
+                    for (int ky = 0; ky < 4; ky++) {
+                        const float wzy = wz_[kz] * wy_[ky];
+                        float row = v[ky][0] * wx_[0];
+                        row = fmaf(v[ky][1], wx_[1], row);
+                        row = fmaf(v[ky][2], wx_[2], row);
+                        row = fmaf(v[ky][3], wx_[3], row);
+                        acc = fmaf(row, wzy, acc);
+                    }
+                }
+                val = acc;
+            } else {
+                todo |= 1u << k;
+            }
+            r[kk] = val;
+        }
+        if (wide) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) tile[kk * 64 + lane] = r[kk];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int i = lane >> 4, c = lane & 15;
+            typedef float f32x4m __attribute__((ext_vector_type(4)));
+            const f32x4m v = *reinterpret_cast<const f32x4m *>(tile + i * 64 + 4 * c);
+            const int orow = y0 + RW * wy + (4 * c) / T, ox4 = x0 + ((4 * c) & (T - 1));
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4m *>(out + ((size_t)(z0 + 8 * wz + 4 * bt + i) * q.oy + orow) * q.ox + ox4));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int z = z0 + 8 * wz + 4 * bt + kk;
+                if (col_ok && z < q.oz) __builtin_nontemporal_store(r[kk], out + ((size_t)z * q.oy + y) * q.ox + x);
+            }
+        }
+    }
+    // ---- second phase (see cubic3_box_kernel): the flagged voxels of the workgroup through a queue, 512 at a time
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned short *queue = reinterpret_cast<unsigned short *>(smem_mb);
+    if (todo != 0u) {
+#pragma unroll 1
+        for (int kl = 0; kl < 8; kl++) {
+            if (!((todo >> kl) & 1u)) continue;
+            const int slot = atomicAdd(&red[6], 1);
+            queue[slot] = (unsigned short)(((8 * wz + kl) << 8) | (yrow << 4) | lx);
+        }
+    }
+    __syncthreads();
+    const int nq = red[6];
+#pragma unroll 1
+    for (int e = tid; e < nq; e += 512) {
+        const int id = queue[e];
+        const int zz = z0 + (id >> 8), yq = y0 + ((id >> 4) & 15), xq = x0 + (id & 15);
+        if (xq >= q.ox || yq >= q.oy || zz >= q.oz) continue;
+        const size_t i = ((size_t)zz * q.oy + yq) * q.ox + xq;
+        const double c0 = (double)coords[i], c1 = (double)coords[nvox + i], c2 = (double)coords[2 * nvox + i];
+        Cubic3 tt;
+        bool outside = cubic3_axis(q.nz, nxy, c0, q.mode, q.npad, tt.w[0], tt.off[0]);
+        outside |= cubic3_axis(q.ny, q.nx, c1, q.mode, q.npad, tt.w[1], tt.off[1]);
+        outside |= cubic3_axis(q.nx, 1, c2, q.mode, q.npad, tt.w[2], tt.off[2]);
+        tt.ntap[0] = 4; tt.ntap[1] = 4;
+        tt.outside = outside;
+        out[i] = cubic3_gather_lean(rin, tt, q.cval);
+    }
+}
+
+// false = not taken (small outputs, rows that are not whole 16-byte vectors, volumes beyond 32-bit offsets)
+bool launch_cubic_mapbox(const float *in, const void *coords, int coords_f64, float *out, const int shape[3], const int oshape[3], int mode, double cval, int npad,
+                         hipStream_t s, int *rc, int dbg)
+{
+    *rc = MI_OK;
+    MapBoxParams q;
+    q.nz = shape[0]; q.ny = shape[1]; q.nx = shape[2];
+    q.oz = oshape[0]; q.oy = oshape[1]; q.ox = oshape[2];
+    if ((long long)q.oz * q.oy * q.ox < (1 << 18) || (q.ox & 3) || ((uintptr_t)out & 15) || ((uintptr_t)in & 15) || (q.nx & 3)) return false;
+    if ((long long)q.nz * q.ny * q.nx * 4 >= (1LL << 31)) return false;
+    q.mode = mode; q.npad = npad; q.cval = (float)cval; q.dbg = dbg & 14;
+    const dim3 grid((unsigned)((q.ox + kBoxT - 1) / kBoxT), (unsigned)((q.oy + kBoxT - 1) / kBoxT), (unsigned)((q.oz + kBoxT - 1) / kBoxT));
+    if (grid.y > 65535 || grid.z > 65535) return false;
+    const size_t lds = kMapBoxBytes + 64 + 8 * 256 * sizeof(float);
+    static PerDeviceOnce attr_done;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)cubic3_mapbox_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)cubic3_mapbox_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) { *rc = (int)e; return true; }
+        attr_done = true;
+    }
+    note_kernel("mi::cubic3_mapbox_kernel<%s> grid=%ux%ux%u (order-3 map_coordinates on float32 coefficients: per 16^3 tile the box of its own coordinates staged in LDS)",
+                coords_f64 ? "double" : "float", grid.x, grid.y, grid.z);
+    if (coords_f64) hipLaunchKernelGGL(cubic3_mapbox_kernel<double>, grid, dim3(512), lds, s, in, (const double *)coords, out, q);
+    else hipLaunchKernelGGL(cubic3_mapbox_kernel<float>, grid, dim3(512), lds, s, in, (const float *)coords, out, q);
+    const hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) *rc = (int)e2;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // r5: the separable resampling passes of DIAGONAL order-3 transforms (zoom, shift -- the commonest order-3 calls; the
 // reference's zoom / shift kernel, _interp_kernels.py:655-688).  The r3 passes (interp.hip) read every tap from memory:
 // along x four scalar gathers per output (540 us for 512^3: the L1 serves the overlapping windows of a wave's lanes one
@@ -947,7 +1182,6 @@ int launch_resample_zstream(const float *in, float *out, const AxisTaps *all_tab
 // phase over a workgroup-wide queue; voxels beyond the array (constant mode) are cval at once; matrices whose box exceeds
 // 128 KiB (down-scaling by more than ~1.5) stay with the gather kernel.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kBoxT = 16;                                   // the cube's edge
 constexpr int kBoxBytesMax = 128 * 1024, kBoxRoundsMax = 16; // box budget; staging rounds of 512 chunks.  Up to 64 KiB two workgroups share a CU (1.1-1.6 ms on
                                                             // 512^3, rotations up to ~12 degrees); beyond, one (1.9-2.1 ms up to 45 degrees) -- the gathers take 4.2-5.7 ms there
 

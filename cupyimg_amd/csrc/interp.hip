@@ -985,6 +985,8 @@ Knob g_cubic_box{1};          // 0 = the gather kernel for matrices that couple 
                               // box fits; bits 2 / 4 / 8: timing ablations (no second phase / no taps / no box DMA)
 extern "C" int mi_debug_set_cubic_box(int on) { g_cubic_box = on; return MI_OK; }
 bool launch_cubic_box(const float *in, float *out, const int shape[3], const int oshape[3], const double *mat, int mode, double cval, int npad, hipStream_t s, int *rc, int dbg);   // cubic_fast.hip
+bool launch_cubic_mapbox(const float *in, const void *coords, int coords_f64, float *out, const int shape[3], const int oshape[3], int mode, double cval, int npad,
+                         hipStream_t s, int *rc, int dbg);   // cubic_fast.hip
 Knob g_resample_fast{1};      // test hook: 0 = the r3 separable resampling passes for diagonal order-3 transforms
 extern "C" int mi_debug_set_resample_fast(int on) { g_resample_fast = on; return MI_OK; }
 int launch_resample_x_lds(const float *in, float *out, const AxisTaps *tabx, long long nrows, int ox, int nx, float cval, hipStream_t s);          // cubic_fast.hip
@@ -2424,6 +2426,14 @@ int mi_spline_map_coordinates(const mi_array *coef, const mi_array *coords, cons
     if (g.pad == 0) MI_CUBIC_MAP(C, 4, 4);                                     \
     else if (g.pad == 1) MI_CUBIC_MAP(C, 1, 4);                                \
     else MI_CUBIC_MAP(C, 1, 1)
+        // r5: volumes take their taps out of a box the workgroup sizes from its own coordinates (csrc/cubic_fast.hip)
+        if (g_cubic_box && g.pad == 0 && out->ndim == 3) {
+            const int shp[3] = {(int)g.shape[0], (int)g.shape[1], (int)g.shape[2]}, osh[3] = {(int)out->shape[0], (int)out->shape[1], (int)out->shape[2]};
+            int mrc = MI_OK;
+            if (launch_cubic_mapbox((const float *)coef->data, coords->data, coords->dtype == MI_F64, (float *)out->data, shp, osh, mode, cval, npad, s, &mrc, g_cubic_box))
+                return mrc;
+        }
+        note_kernel("mi::cubic3_f32_kernel (order-3 map_coordinates on float32 coefficients: 16 x 16-byte gathers per voxel)");
         if (coords->dtype == MI_F32) { MI_CUBIC_MAP_RANK(float); } else { MI_CUBIC_MAP_RANK(double); }
 #undef MI_CUBIC_MAP_RANK
 #undef MI_CUBIC_MAP

@@ -47,7 +47,7 @@ while time.time() < t_end:
     vd = ca.asarray(v)
     v64 = v.astype(np.float64)
     mode = str(rng.choice(MODES))
-    op = int(rng.integers(0, 8))
+    op = int(rng.integers(0, 9))
     try:
         if op == 0:
             order = int(rng.choice([2, 3, 3]))
@@ -84,6 +84,18 @@ while time.time() < t_end:
             order = int(rng.choice([1, 3]))
             check("affine-general-o%d" % order, ndi.affine_transform(vd, M, off, order=order, mode="constant", cval=0.3).get(),
                   sndi.affine_transform(v64, M, off, order=order, mode="constant", cval=0.3), 2e-5 if order == 3 else 4e-6, (shape, order))
+        elif op == 8:
+            # map_coordinates with its default order: smooth warp + optional jitter, float32 / float64 coordinates
+            osh = tuple(int(n + rng.integers(-10, 20)) for n in shape)
+            idx = np.indices(osh, dtype=np.float64)
+            M = rot(rng.standard_normal(3), float(rng.uniform(-25, 25)))
+            co = np.tensordot(M, idx, axes=1) + ((np.array(shape) - 1) / 2 - M @ ((np.array(osh) - 1) / 2) + rng.uniform(-3, 3, 3))[:, None, None, None]
+            co += float(rng.uniform(0, 3)) * np.sin(idx[::-1] / float(rng.uniform(6, 20)))
+            if rng.random() < 0.3:
+                co += rng.uniform(-2, 2, co.shape)
+            co = co.astype(np.float32 if rng.random() < 0.6 else np.float64)
+            check("map_coordinates3", ndi.map_coordinates(vd, ca.asarray(co), mode=mode, cval=0.3).get(),
+                  sndi.map_coordinates(v64, co.astype(np.float64), mode=mode, cval=0.3), 2e-5, (shape, osh, mode, str(co.dtype)))
         else:
             M = rot((0, 0, 1), float(rng.uniform(-40, 40)))      # rotation in the (z, y) plane: x to itself (row-blend)
             off = (np.array(shape) - 1) / 2 - M @ ((np.array(shape) - 1) / 2)

@@ -317,3 +317,48 @@ def test_cubic_box_kernel_general_matrices(gpu, ndi, lib):
     finally:
         lib.mi_debug_set_cubic_box(1)
     assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_cubic_mapbox_kernel(gpu, ndi, lib):
+    """r5: map_coordinates with its DEFAULT order (3) on float32 volumes takes the taps out of a box every workgroup sizes from its
+    own coordinates (cubic3_mapbox_kernel): bit-identical to the gather kernel (same taps, weights, products, order of the
+    sums) for affine-like coordinates, smooth warps, coordinates with a bulge, +-6-voxel jitter (boxes that do not fit: the
+    tile takes the gather routine), NaN / inf / 1e30 coordinates, planes wholly outside, float32 and float64 coordinates,
+    every mode, prefilter on / off, shapes that are not multiples of the tile; within float32 accuracy of SciPy."""
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(123)
+    took = 0
+    for shape, oshape in (((64, 80, 96), (64, 80, 96)), ((50, 70, 100), (72, 66, 132))):
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        idx = np.indices(oshape, dtype=np.float64)
+        a = np.deg2rad(8.0)
+        R = np.array([[np.cos(a), -np.sin(a), 0.1], [np.sin(a), np.cos(a), -0.05], [0.02, 0.03, 0.97]])
+        base = np.tensordot(R, idx, axes=1) + np.array([1.5, -3.0, 2.25])[:, None, None, None]
+        fams = {"affine": base,
+                "smooth": base + 2.0 * np.sin(idx[::-1] / 9.0),
+                "bulge": base + 10.0 * np.exp(-((idx[0] - 30) ** 2 + (idx[1] - 30) ** 2 + (idx[2] - 40) ** 2) / 200.0)[None],
+                "jitter": base + rng.uniform(-6, 6, base.shape),
+                "outside": base + np.array([200.0, 0, 0])[:, None, None, None]}
+        bad = base.copy()
+        bad[0, 5, 6, 7] = np.nan; bad[1, 9, 9, 9] = np.inf; bad[2, 11, 3, 60] = 1e30; bad[0, 20, 21, 22] = -np.inf
+        fams["nonfinite"] = bad
+        for name, co in fams.items():
+            for cdt in (np.float32, np.float64):
+                cd = gpu.asarray(co.astype(cdt))
+                for mode in (("constant", "mirror", "nearest", "reflect", "grid-wrap", "grid-constant", "wrap") if name in ("affine", "bulge") and cdt == np.float32 else ("constant", "nearest")):
+                    for prefilter in ((True, False) if mode == "constant" else (True,)):
+                        kw = dict(order=3, mode=mode, cval=0.5, prefilter=prefilter)
+                        lib.mi_debug_set_cubic_box(0)
+                        try:
+                            want = ndi.map_coordinates(xd, cd, **kw).get()
+                            assert "cubic3_f32_kernel" in last_kernel(), last_kernel()
+                        finally:
+                            lib.mi_debug_set_cubic_box(1)
+                        got = ndi.map_coordinates(xd, cd, **kw).get()
+                        took += "cubic3_mapbox_kernel" in last_kernel()
+                        assert np.array_equal(got, want, equal_nan=True), (shape, oshape, name, cdt.__name__, mode, prefilter, int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want))))))
+                        if prefilter and name in ("affine", "smooth") and mode in ("constant", "nearest"):
+                            ref = sndi.map_coordinates(x.astype(np.float64), co.astype(cdt).astype(np.float64), order=3, mode=mode, cval=0.5)
+                            assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (shape, name, mode)
+    assert took >= 60, took
