@@ -50,7 +50,7 @@ def synth(shape, seed=0):
 
 
 SETTLE_LAUNCHES = 220        # ~ 40 ms of the 2 x 512 MiB copy kernel before the comparators are timed
-TRAFFIC_FILES = ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json")
+TRAFFIC_FILES = ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json")
 
 
 def measured_traffic(world, config):

@@ -170,14 +170,14 @@ def test_cubic_kernels_under_load_512(gpu, ndi, lib):
     for name in names:
         fn, shape, dtype, kern = getattr(cases, name)()
         ref = gpu.empty(shape, dtype)
-        lib.mi_debug_set_cubic_zstream(0); lib.mi_debug_set_cubic_rowblend(0)
+        lib.mi_debug_set_cubic_zstream(0); lib.mi_debug_set_cubic_rowblend(0); lib.mi_debug_set_cubic_box(0)
         try:
             fn(ref)
             from cupyimg_amd import last_kernel
             assert "cubic3_f32_kernel" in last_kernel(), (name, last_kernel())
             want = ref.get()
         finally:
-            lib.mi_debug_set_cubic_zstream(1); lib.mi_debug_set_cubic_rowblend(1)
+            lib.mi_debug_set_cubic_zstream(1); lib.mi_debug_set_cubic_rowblend(1); lib.mi_debug_set_cubic_box(1)
         del ref
         check(gpu, fn, shape, dtype, want if "zfactor" not in kern else want.astype(np.float64), "zfactor" not in kern, kern)
         del fn, want

@@ -1955,11 +1955,11 @@ def _cubic_zstream_in_plane_body(gpu, ndi, lib, KERN, exact):
                     continue
                 for prefilter in ((True, False) if mode in ("constant", "mirror") and deg == 7 else (True,)):
                     kw = dict(output_shape=osh, order=3, mode=mode, cval=0.5, prefilter=prefilter)
-                    lib.mi_debug_set_cubic_zstream(0)
+                    lib.mi_debug_set_cubic_zstream(0); lib.mi_debug_set_cubic_box(0)          # the comparator: the gather kernel
                     try:
                         want = ndi.affine_transform(xd, M, off, **kw).get()
                     finally:
-                        lib.mi_debug_set_cubic_zstream(1)
+                        lib.mi_debug_set_cubic_zstream(1); lib.mi_debug_set_cubic_box(1)
                     lib.mi_debug_set_cubic_zstream(1 + 4 + 8)          # any angle, and the grid modes (not taken by default)
                     try:
                         got = ndi.affine_transform(xd, M, off, **kw).get()
@@ -1989,19 +1989,20 @@ def _cubic_zstream_in_plane_body(gpu, ndi, lib, KERN, exact):
     x[5, 40, 70] = np.inf; x[30, 10, 100] = np.nan
     xd = gpu.asarray(x)
     got = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
-    lib.mi_debug_set_cubic_zstream(0)
+    lib.mi_debug_set_cubic_zstream(0); lib.mi_debug_set_cubic_box(0)
     try:
         want = ndi.affine_transform(xd, M, off, order=3, prefilter=False).get()
     finally:
-        lib.mi_debug_set_cubic_zstream(1)
+        lib.mi_debug_set_cubic_zstream(1); lib.mi_debug_set_cubic_box(1)
     assert _same_cubic(got, want, exact)
     assert np.isfinite(got).sum() > 0.99 * got.size
-    # the defaults: a quarter turn (LDS bank conflicts down the columns) and the grid modes stay with the gather kernel
+    # the defaults: a quarter turn (LDS bank conflicts down the columns) and the grid modes are not streamed: they take the box
+    # kernel (r5: the LDS-staged box per 16^3 tile takes what the streaming kernels refuse) or the gather kernel
     a = np.deg2rad(90.0); M9 = np.array([[1.0, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
     ndi.affine_transform(xd, M9, np.array([0.0, 0.0, 89.0]), order=3, prefilter=False)
-    assert "cubic3_f32_kernel" in last_kernel()
+    assert "cubic3_f32_kernel" in last_kernel() or "cubic3_box_kernel" in last_kernel()
     ndi.affine_transform(xd, M, off, order=3, prefilter=False, mode="grid-wrap")
-    assert "cubic3_f32_kernel" in last_kernel()
+    assert "cubic3_f32_kernel" in last_kernel() or "cubic3_box_kernel" in last_kernel()
     ndi.affine_transform(xd, M, off, order=3, prefilter=False, mode="reflect")
     assert KERN in last_kernel()
     # a matrix that couples axis 0, a diagonal one and a float64 array are not taken
@@ -2044,11 +2045,11 @@ def _rowblend_full_route_body(gpu, ndi):
             off[2] = xs
             for mode in ("constant", "nearest", "mirror", "reflect", "grid-wrap", "grid-constant", "wrap"):
                 kw = dict(output_shape=osh, order=3, mode=mode, cval=0.5)
-                lib.mi_debug_set_cubic_rowblend(0)
+                lib.mi_debug_set_cubic_rowblend(0); lib.mi_debug_set_cubic_box(0)          # the comparator: the gather kernel
                 try:
                     want = ndi.affine_transform(xd, M, off, **kw).get()
                 finally:
-                    lib.mi_debug_set_cubic_rowblend(1)
+                    lib.mi_debug_set_cubic_rowblend(1); lib.mi_debug_set_cubic_box(1)
                 got = ndi.affine_transform(xd, M, off, **kw).get()
                 took += "cubic3_rowblend_kernel" in last_kernel()
                 assert np.array_equal(got, want, equal_nan=True), (shape, osh, deg, xs, mode, last_kernel()[:40], int(np.sum(got != want)))
