@@ -49,6 +49,11 @@ SOURCES = [
     ("rank_sorted_p64b.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p64c.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p64d.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p128a.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p128b.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p128c.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p128d.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p128e.hip", ["-ffp-contract=off"]),
     ("minmax3d_u8.hip", []),
     ("median2d.hip", []),
     ("minmax_16.hip", []),

@@ -12,6 +12,7 @@
 //     tap in the input dtype (unsigned types wrap), then compares as double.
 #include "nd_common.hpp"
 
+namespace mi { void note_kernel(const char *fmt, ...); }      // runtime.hip
 namespace mi {
 
 template <typename T, typename I>
@@ -400,6 +401,7 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
             else if constexpr (std::is_same<T, uint64_t>::value) cv = cval >= 0 ? (uint64_t)cval : (uint64_t)(-(int64_t)(uint64_t)(-cval));
             else cv = (T)(int64_t)cval;
             const dim3 grid((unsigned)(nthreads / 256));
+            note_kernel("mi::rank_nd_kernel ntaps=%d rank=%d threads=%d (window in a scratch column)", (int)nset, rank, (int)nthreads);
             if (tb.g.ndim == 3)
                 hipLaunchKernelGGL((rank_nd_kernel<T, 3>), grid, dim3(256), 0, s, (const T *)in->data, out->data, out->dtype, tb.g, tt,
                                    total, mode, cv, rank, (T *)scratch, nthreads);
@@ -432,7 +434,8 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
                                    std::is_same<T, uint32_t>::value;
         if constexpr (as_float || as_double) {
             using V = std::conditional_t<as_float, float, double>;
-            if (tt3.ntaps <= 64 && out->dtype == in->dtype && g_rank_sorted) {
+            // 65..128 samples (r5: 5 x 5 x 5, 9 x 9, 11 x 11): 128 value registers -- float-valued types only (doubles would spill)
+            if (tt3.ntaps <= (as_float ? 128 : 64) && out->dtype == in->dtype && g_rank_sorted) {
                 const T *ip = (const T *)in->data;
                 T *op = (T *)out->data;
                 if constexpr (std::is_same<T, float>::value || std::is_same<T, uint8_t>::value || std::is_same<T, uint16_t>::value ||
@@ -441,11 +444,15 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
                     if (g_rank_median && tt3.ntaps == 25 && rank == 12) return run_median_sorted<T, V, 25>(ip, op, t3.g, tt3, mode, (V)cv, s);
                     if (g_rank_median && tt3.ntaps == 27 && rank == 13) return run_median_sorted<T, V, 27>(ip, op, t3.g, tt3, mode, (V)cv, s);
                 }
+                note_kernel("mi::rank3_sorted_kernel<%s,%d,> ntaps=%d rank=%d (register sorting network)", sizeof(V) == 4 ? "float" : "double",
+                            tt3.ntaps <= 16 ? 16 : (tt3.ntaps <= 32 ? 32 : (tt3.ntaps <= 64 ? 64 : 128)), tt3.ntaps, rank);
                 if (tt3.ntaps <= 16) return run_rank_sorted<T, V, 16>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
                 if (tt3.ntaps <= 32) return run_rank_sorted<T, V, 32>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
-                return run_rank_sorted<T, V, 64>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
+                if (tt3.ntaps <= 64) return run_rank_sorted<T, V, 64>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
+                if constexpr (as_float) return run_rank_sorted<T, V, 128>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
             }
         }
+        note_kernel("mi::rank3_kernel ntaps=%d rank=%d (selection in a per-thread array)", tt3.ntaps, rank);
         hipLaunchKernelGGL((rank3_kernel<T>), grid3(t3.g), dim3(64, 4, 1), taps3_lds_bytes(tt3), s, (const T *)in->data, out->data,
                            out->dtype, t3.g, tt3, mode, cv, rank);
         MI_HIP(hipGetLastError());

@@ -53,7 +53,7 @@ rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps
         });
     }
     // stage s of the network: block size k = 2 << (stage row), distance j; every index is a compile-time constant
-    constexpr int LOGP = P == 16 ? 4 : (P == 32 ? 5 : 6);
+    constexpr int LOGP = P == 16 ? 4 : (P == 32 ? 5 : (P == 64 ? 6 : 7));
     rank_static_for<LOGP>([&](auto KK) {
         constexpr int k = 2 << decltype(KK)::value;
         rank_static_for<decltype(KK)::value + 1>([&](auto JJ) {

@@ -377,7 +377,12 @@ __device__ __forceinline__ F4 xpass_packed(const F4 v, const float (&sL)[NE], co
     return o;
 }
 
-template <int W, int NWP, int NWC, int R, int DEPTH, bool HAS_CONST>
+// RAGGED (r5): rows of any length >= 16 (181 x 217 x 181: 724-byte rows).  Rows then start on 4-byte boundaries only -- the
+// 16-byte buffer loads and stores do not mind -- and the LAST lane of the last x tile holds `tail` (1..3) floats of its row
+// followed by the head of the next one: those are replaced by the row's boundary continuation E[0], E[1], ... before the
+// x pass (E[0..7] come with the edge load: lanes 32 + r and 48 + r, four floats each), the floats right of the tile are
+// E[4 - tail ..], and the last lane stores `tail` floats.  No mi_extend_rows / mi_crop_rows copies around the launch.
+template <int W, int NWP, int NWC, int R, int DEPTH, bool HAS_CONST, bool RAGGED = false>
 __global__ void __launch_bounds__((NWP + NWC) * 64)
 sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const Sep3dParams p)
 {
@@ -386,7 +391,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
     constexpr int G = (TY + NWC - 1) / NWC;              // output rows per consumer wave
     constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
     constexpr int RX = W / 2;
-    constexpr int NE = RX <= 2 ? 2 : 4;
+    constexpr int NE = RAGGED ? 4 : (RX <= 2 ? 2 : 4);
     constexpr int RINGN = W - 1;                          // even (W odd), >= 2
     static_assert(W >= 3 && W <= 7 && (W & 1), "lean kernel: odd W, 3 .. 7 (9 .. 17: sep3d_long.hip)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -410,8 +415,10 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
     chunk_planes(p, zci, &zs, &ze);
     const int ty_act = min(TY, ny - y0);
     const int rows_needed = ty_act + W - 1;
-    const int nlanes = min(p.tw >> 2, (nx - x0) >> 2);
+    const int width = min(p.tw, nx - x0);
+    const int nlanes = RAGGED ? (width + 3) >> 2 : min(p.tw >> 2, (nx - x0) >> 2);
     const int last = nlanes - 1;
+    const int tail = RAGGED ? width - 4 * last : 4;       // floats of its row the last lane holds
     // one buffer descriptor per plane (base = plane start, range = one plane):
     // offsets stay 32-bit inside a plane, the volume itself may exceed 4 GiB
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
@@ -438,11 +445,16 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
         // with v_readlane into scalars.
         int es0, ek0, es1, ek1;
         edge_desc(0, x0, x0 + 4 * nlanes, nx, p.mx, &es0, &ek0);
-        edge_desc(1, x0, x0 + 4 * nlanes, nx, p.mx, &es1, &ek1);
+        edge_desc(1, x0, x0 + width, nx, p.mx, &es1, &ek1);
         const bool left_side = lane < 32;
-        const int erow = left_side ? lane : lane - 32;          // row this lane fetches the edge of
+        const int erow = left_side ? lane : (RAGGED ? (lane & 15) : lane - 32);     // row this lane fetches the edge of
         const int ekind = left_side ? ek0 : ek1;
         int eoff = left_side ? es0 : es1;
+        // RAGGED: lanes 32 + r fetch what replaces floats 1..3 of the last lane (slot j = E[j - tail]: the standard four floats
+        // E[0..3], re-indexed below), lanes 48 + r the floats right of the row as the x pass wants them (slot j = E[4 - tail + j]:
+        // the load moved by 4 - tail floats) -- everything that depends on `tail` is settled here, once per workgroup
+        if constexpr (RAGGED)
+            if (lane >= 48) eoff += ekind == EDGE_FWD ? 4 - tail : (ekind == EDGE_REV ? tail - 4 : 0);
         if (left_side) {
             if (ekind == EDGE_FWD) eoff += 4 - NE;
         } else {
@@ -451,8 +463,14 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
         }
         int eidx[NE];
 #pragma unroll
-        for (int k = 0; k < NE; k++)
+        for (int k = 0; k < NE; k++) {
             eidx[k] = ekind == EDGE_FWD ? k : (ekind == EDGE_REV ? NE - 1 - k : (left_side ? 0 : NE - 1));
+            if constexpr (RAGGED)
+                if (lane >= 32 && lane < 48 && ekind != EDGE_SPLAT)
+                    eidx[k] = ekind == EDGE_FWD ? max(k - tail, 0) : min(NE - 1 - k + tail, NE - 1);
+        }
+        const bool patch1 = RAGGED && lane == last && tail < 2, patch2 = RAGGED && lane == last && tail < 3,
+                   patch3 = RAGGED && lane == last && tail < 4;
 
         unsigned voff[R];
         unsigned eoffv = kOOB;
@@ -541,6 +559,13 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
                             sL[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), r));
                             sR[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), 32 + r));
                         }
+                        if constexpr (RAGGED) {
+                            v.lo.y = patch1 ? sR[1] : v.lo.y;
+                            v.hi.x = patch2 ? sR[2] : v.hi.x;
+                            v.hi.y = patch3 ? sR[3] : v.hi.y;
+#pragma unroll
+                            for (int k = 0; k < RX; k++) sR[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), 48 + r));
+                        }
                         xf[r] = xpass_packed<W, NE>(v, sL, sR, lane, last, p.wx);
                     }
                     if (i + DEPTH < nsteps) issue(i + DEPTH, s);
@@ -577,6 +602,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
 #pragma unroll
         for (int g = 0; g < G; g++)
             ovoff[g] = (j0 + g < ty_act && lane < nlanes) ? (unsigned)((y0 + j0 + g) * nx + x0 + 4 * lane) * 4u : kOOB;
+        const bool part = RAGGED && lane == last && tail < 4;      // this lane stores `tail` floats
         for (int i = 0; i < nsteps; i++) {
             __syncthreads();
             if (i < W - 1) continue;
@@ -593,13 +619,26 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
 #pragma unroll
                 for (int k = 1; k < W; k++) a = f4_fma(p.wyv[k], win[g + k], a);
                 // written once, never read back by this launch: non-temporal (measured 1.2 % on config H)
-                __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(a), rout, ovoff[g], 0, 2);
+                if constexpr (RAGGED) {
+                    const u32x4 q = f4_to_u32(a);
+                    if (!part) {
+                        __builtin_amdgcn_raw_buffer_store_b128(q, rout, ovoff[g], 0, 2);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(q.x, rout, ovoff[g], 0, 2);
+                        if (tail > 1) __builtin_amdgcn_raw_buffer_store_b32(q.y, rout, ovoff[g] + 4u, 0, 2);
+                        if (tail > 2) __builtin_amdgcn_raw_buffer_store_b32(q.z, rout, ovoff[g] + 8u, 0, 2);
+                    }
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(a), rout, ovoff[g], 0, 2);
+                }
             }
         }
     }
 }
 
-template <int W, int NWP, int NWC, int R, int DEPTH = 2>
+static Knob g_sep3d_ragged{1};    // r5: 1 = the lean kernel takes rows that are not a multiple of 4 floats itself, 0 = refuse (callers extend the rows), 2 = the ragged build for every row length (measurement)
+// RG: the tile shape is also built for rows that are not a multiple of 4 floats (the shapes choose_plan picks by itself)
+template <int W, int NWP, int NWC, int R, int DEPTH = 2, bool RG = false>
 static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool has_const, hipStream_t s)
 {
     constexpr int ROWS = NWP * R;
@@ -617,6 +656,29 @@ static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool h
     }
     if (p.ty != TY) { set_error("internal: lean tile mismatch"); return MI_ERR_INTERNAL; }
     const int total = p.nxt * p.nyt * p.nzc;
+    if ((p.nx & 3) || (RG && g_sep3d_ragged == 2)) {
+        if constexpr (RG) {
+            static PerDeviceOnce rg_done;
+            if (!rg_done) {
+                MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, false, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                rg_done = true;
+            }
+            note_kernel("mi::sep3d_lean_kernel<%d,%d,%d,%d,%d,%s,ragged> grid=%d (fused x/z/y separable pass, rows of any length)", W, NWP, NWC,
+                        R, DEPTH, has_const ? "true" : "false", total);
+            if (has_const)
+                hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true, true>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+            else
+                hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, false, true>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        } else {
+            set_error("separable3d: this tile shape needs rows that are a multiple of 4 floats");
+            return MI_ERR_UNSUPPORTED;
+        }
+    }
     note_kernel("mi::sep3d_lean_kernel<%d,%d,%d,%d,%d,%s> grid=%d (fused x/z/y separable pass)", W, NWP, NWC, R, DEPTH,
                 has_const ? "true" : "false", total);
     if (has_const)
@@ -685,19 +747,19 @@ static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams 
     switch (w) {
     case 3:
         if (cfg == 1) return launch_sep3d_lean<3, 8, 4, 4>(in, out, p, hc, s);
-        if (cfg == 5) return launch_sep3d_lean<3, 10, 4, 2>(in, out, p, hc, s);
-        return launch_sep3d_lean<3, 12, 4, 3>(in, out, p, hc, s);
+        if (cfg == 5) return launch_sep3d_lean<3, 10, 4, 2, 2, true>(in, out, p, hc, s);
+        return launch_sep3d_lean<3, 12, 4, 3, 2, true>(in, out, p, hc, s);
     case 5:
         if (cfg == 1) return launch_sep3d_lean<5, 9, 3, 4>(in, out, p, hc, s);
         if (cfg == 2) return launch_sep3d_lean<5, 8, 4, 3>(in, out, p, hc, s);
         if (cfg == 3) return launch_sep3d_lean<5, 10, 2, 3>(in, out, p, hc, s);
         if (cfg == 4) return launch_sep3d_lean<5, 10, 2, 2>(in, out, p, hc, s);
-        if (cfg == 5) return launch_sep3d_lean<5, 10, 4, 2>(in, out, p, hc, s);
+        if (cfg == 5) return launch_sep3d_lean<5, 10, 4, 2, 2, true>(in, out, p, hc, s);
         if (cfg == 6) return launch_sep3d_lean<5, 10, 6, 2>(in, out, p, hc, s);
         if (cfg == 8) return launch_sep3d_lean<5, 12, 4, 3, 2>(in, out, p, hc, s);
-        return launch_sep3d_lean<5, 12, 4, 3, 1>(in, out, p, hc, s);   // measured best: 1 WG/CU, 16 waves
+        return launch_sep3d_lean<5, 12, 4, 3, 1, true>(in, out, p, hc, s);   // measured best: 1 WG/CU, 16 waves
     default:
-        return launch_sep3d_lean<7, 8, 4, 3>(in, out, p, hc, s);
+        return launch_sep3d_lean<7, 8, 4, 3, 2, true>(in, out, p, hc, s);
     }
 }
 
@@ -759,6 +821,7 @@ extern "C" int mi_debug_set_sep3d_zchunks(int n) { g_sep3d_zchunks = n; return M
 extern "C" int mi_debug_set_sep3d_dbg(int f) { g_sep3d_dbg = f; return MI_OK; }
 extern "C" int mi_debug_set_sep3d_kernel(int k) { g_sep3d_kernel = k; return MI_OK; }
 static mi::Knob g_sep3d_box{0};       // 0 = auto (running-sum box kernel where it applies), 1 = off
+extern "C" int mi_debug_set_sep3d_ragged(int k) { g_sep3d_ragged = k; return MI_OK; }
 extern "C" int mi_debug_set_sep3d_box(int k) { g_sep3d_box = k; return MI_OK; }
 extern "C" int mi_debug_last_kernel(char *buf, size_t n)
 {
@@ -796,7 +859,9 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
     if (in->data == out->data) UNSUP("in-place");
     const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
-    if (nz < 1 || ny < 1 || nx < 8 || (nx & 3)) UNSUP("x extent must be a multiple of 4, >= 8");
+    // r5: rows that are not a multiple of 4 floats are taken by the lean kernel's ragged build (3 / 5 / 7 cubic taps, below)
+    const bool ragged = (nx & 3) != 0;
+    if (nz < 1 || ny < 1 || nx < 8 || (ragged && (nx < 16 || !g_sep3d_ragged))) UNSUP("x extent must be a multiple of 4, >= 8");
     if (nz * ny * nx >= ((int64_t)1 << 40) || nx > (1 << 24) || ny > (1 << 24) || nz > (1 << 24)) UNSUP("too large");
     if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
 
@@ -842,6 +907,9 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     const int64_t nzr = zn[0] + zn[1];
 
     const bool cubic_w = w[0] == w[1] && w[1] == w[2];
+    if (ragged && !(cubic_w && w[0] >= 3 && w[0] <= 7 && g_sep3d_kernel != 1 && g_sep3d_cfg == 0 && ny * nx * 4 < ((int64_t)1 << 31) &&
+                    (weights[0] ? origin[0] : 0) == 0 && (weights[1] ? origin[1] : 0) == 0))
+        UNSUP("rows that are not a multiple of 4 floats: cubic kernels of 3 / 5 / 7 taps without origins only");
     // r3: with its re-scheduled instruction stream (sep3d_long3_kernel) the LDS-DMA kernel also beats the lean kernel
     // below 9 taps on volumes that fill the chip (profiles/r3_long3_small_taps.txt, sustained, lean -> long: 7 taps
     // 15-31 % faster on every shape of 4 Mvoxels and more; 5 and 3 taps 3-5 % faster on 512^3, 256^3, 64 x 1024^2 and
@@ -856,7 +924,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     const bool long_small = !any_const && w[0] >= 3 && w[0] <= 7 && nx >= 128 && ny >= 16 &&
                             (w[0] == 7 ? nvox_out >= ((int64_t)1 << 22)
                                        : nvox_out >= ((int64_t)1 << 23) && (tiles_full || nx == 128));
-    if (cubic_w && g_sep3d_long != 1 && nx >= 16 &&
+    if (cubic_w && !ragged && g_sep3d_long != 1 && nx >= 16 &&
         ((w[0] >= 9 && w[0] <= 17) || (w[0] >= 3 && w[0] <= 7 && (g_sep3d_long == 2 || long_small)))) {
         // long cubic kernels: ONE launch with LDS-DMA staging and the z state in registers (sep3d_long.hip)
         const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
@@ -867,7 +935,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     // r3: anisotropic voxels -- the same kernel with fewer taps along z than in the plane (one launch at 8 B/voxel
     // where the streaming passes below take two at 16), for the tap pairs it is instantiated for, on volumes that fill
     // the chip; index-mapping boundary modes only
-    if (g_sep3d_long != 1 && !any_const && w[1] == w[2] && w[0] != w[1] && nx >= 128 && ny >= 16 &&
+    if (g_sep3d_long != 1 && !ragged && !any_const && w[1] == w[2] && w[0] != w[1] && nx >= 128 && ny >= 16 &&
         nvox_out >= ((int64_t)1 << 22) && mi::long_aniso_pair(w[1], w[0])) {
         const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
         rc = run_sep3d_long((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w[1], w[0], wbuf[2], wbuf[1],

@@ -222,9 +222,8 @@ def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
         return None
     if input.size == 0:
         return None
-    if input.shape[2] % 4 and input.shape[2] >= 8 and planes is None and input.size >= (1 << 15):
-        return _fused_3d_padded_rows(input, output, weights, origins, modes, cval, is_box)
-    if input.shape[2] < 8 or input.shape[2] % 4:
+    ragged = input.shape[2] % 4 != 0
+    if input.shape[2] < 8 or (ragged and input.shape[2] < 16 and planes is not None):
         return None
     if planes is not None and not (input._is_c_contiguous() and output._is_c_contiguous()
                                    and not core.shares_memory(output, input)):
@@ -233,6 +232,8 @@ def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     dst = output if direct else core.empty(output.shape, output.dtype)
     if src.ptr % 16 or dst.ptr % 16:
+        if ragged and planes is None and input.size >= (1 << 15):
+            return _fused_3d_padded_rows(input, output, weights, origins, modes, cval, is_box)
         return None
     keep, ptrs, wlen = _marshal_weights(weights)
     org = _cached_ints(tuple(origins))
@@ -247,6 +248,10 @@ def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
             S.check(S.lib().mi_separable3d_f32_planes(ctypes.byref(a), ctypes.byref(b), ptrs, wlen, org, mds,
                                                       float(cval), flat, len(planes), None))
     except S.Unsupported:
+        # r5: rows that are not a multiple of 16 bytes go to the library first (the 3 / 5 / 7-tap kernel takes them as they
+        # are); what it refuses runs on explicitly extended rows
+        if ragged and planes is None and input.size >= (1 << 15):
+            return _fused_3d_padded_rows(input, output, weights, origins, modes, cval, is_box)
         return None
     if not direct:
         output[...] = dst

@@ -1,0 +1,168 @@
+"""r5: rows that are not a multiple of four floats go through the 3 / 5 / 7-tap fused kernel as they are
+(sep3d_lean_kernel<..., ragged>: csrc/separable3d.hip) -- no mi_extend_rows / mi_crop_rows copies around the launch -- and
+rank filters with 65 .. 128 samples (5 x 5 x 5, 9 x 9, 11 x 11) take the register sorting network (rank_sorted_p128*.hip)
+instead of the scratch-array selection kernel.  Spec: /root/reference/cupyimg/scipy/ndimage/filters.py:549-665 (separable
+passes), :1373-1557 (rank filters)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MODES = ("reflect", "mirror", "nearest", "wrap", "constant")
+
+
+@pytest.fixture(scope="module")
+def ndi(gpu):
+    from cupyimg_amd.scipy import ndimage
+    return ndimage
+
+
+@pytest.fixture(scope="module")
+def lib(gpu):
+    from cupyimg_amd import _lib
+    return _lib.load()
+
+
+def _shapes():
+    # last lane holds 1, 2, 3 floats; one and two x tiles; rows shorter than a wave's 256 floats and just beyond; ny, nz that
+    # leave partial y tiles and one-plane chunks
+    return [(24, 37, 181), (17, 30, 301), (9, 40, 253), (9, 21, 255), (12, 19, 257), (10, 18, 17), (8, 33, 19), (5, 20, 511),
+            (40, 7, 66), (3, 3, 18), (1, 64, 129)]
+
+
+@pytest.mark.parametrize("taps", [3, 5, 7])
+def test_ragged_rows_every_mode_against_scipy_and_the_extended_rows_route(gpu, ndi, lib, taps):
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(500 + taps)
+    seen_tails = set()
+    for shape in _shapes():
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        for mode in MODES:
+            kw = dict(mode=mode, cval=-0.75)
+            got = ndi.uniform_filter(xd, taps, **kw).get()
+            k = last_kernel()
+            assert "ragged" in k and "sep3d_lean_kernel<%d," % taps in k, (shape, mode, k)
+            ref = sndi.uniform_filter(x.astype(np.float64), taps, **kw)
+            assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (shape, mode, k)
+            seen_tails.add(shape[2] & 3)
+            # the same kernel on explicitly extended rows (the r4b route): the same sums in the same order
+            if x.size >= (1 << 15):
+                lib.mi_debug_set_sep3d_ragged(0)
+                try:
+                    via = ndi.uniform_filter(xd, taps, **kw).get()
+                    kv = last_kernel()
+                finally:
+                    lib.mi_debug_set_sep3d_ragged(1)
+                assert "ragged" not in kv, kv
+                if "sep3d_lean_kernel" in kv:
+                    assert np.array_equal(got, via), (shape, mode, k, kv)
+                else:
+                    assert np.abs(got - via).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (shape, mode, k, kv)
+        # a gaussian of the same tap count (weights that are not all equal: the order of the continuation matters)
+        sigma = {3: 0.25, 5: 0.5, 7: 0.75}[taps]
+        for mode in MODES:
+            got = ndi.gaussian_filter(xd, sigma, mode=mode, cval=2.5).get()
+            assert "ragged" in last_kernel(), (shape, mode, last_kernel())
+            ref = sndi.gaussian_filter(x.astype(np.float64), sigma, mode=mode, cval=2.5)
+            assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (shape, mode, sigma)
+    assert seen_tails == {1, 2, 3}
+
+
+def test_ragged_rows_non_finite_values_and_caller_outputs(gpu, ndi, lib):
+    """NaN / inf next to the row ends (they spread over the window and no further), output into a caller's array, rows one,
+    two and three floats past a multiple of four on either side of the 256-float tile width"""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(77)
+    for nx in (181, 182, 183, 185, 253, 254, 255, 257, 258, 259):
+        x = rng.standard_normal((11, 23, nx)).astype(np.float32)
+        x[3, 5, nx - 1] = np.inf
+        x[4, 6, nx - 2] = np.nan
+        x[5, 7, 0] = -np.inf
+        xd = gpu.asarray(x)
+        out = gpu.empty(x.shape, np.float32)
+        for taps in (3, 5, 7):
+            for mode in MODES:
+                r = ndi.uniform_filter(xd, taps, mode=mode, cval=0.5, output=out)
+                assert r is out and "ragged" in last_kernel(), last_kernel()
+                g = out.get()
+                # SciPy's uniform_filter1d is a running sum (a NaN poisons the rest of its line): the reference for where the
+                # non-finite values land is the same kernel on explicitly extended rows
+                lib.mi_debug_set_sep3d_ragged(0)
+                try:
+                    via = ndi.uniform_filter(xd, taps, mode=mode, cval=0.5).get()
+                    kv = last_kernel()
+                finally:
+                    lib.mi_debug_set_sep3d_ragged(1)
+                assert "ragged" not in kv and "sep3d_lean_kernel" in kv, kv
+                assert np.array_equal(g, via, equal_nan=True), (nx, taps, mode)
+                assert 0 < np.isnan(g).sum() <= taps ** 3 + (taps ** 3 if mode == "wrap" else 0), (nx, taps, mode, int(np.isnan(g).sum()))
+                xf = np.where(np.isfinite(x), x, 0.0).astype(np.float64)
+                want = sndi.uniform_filter(xf, taps, mode=mode, cval=0.5)
+                fin = np.isfinite(g)
+                # finite outputs saw no non-finite input: they agree with SciPy on the volume with those voxels zeroed
+                assert np.abs(g[fin] - want[fin]).max() <= 1e-6 * max(1.0, np.abs(want).max()), (nx, taps, mode)
+
+
+def test_ragged_rows_whole_mni_volume_last_of_a_burst(gpu, ndi, lib):
+    """181 x 217 x 181 (the MNI152 1 mm grid): the last launch of a burst, every plane against SciPy"""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((181, 217, 181)).astype(np.float32)
+    xd = gpu.asarray(x)
+    out = gpu.empty(x.shape, np.float32)
+    for size, mode in ((5, "reflect"), (3, "mirror"), (7, "constant")):
+        for _ in range(30):
+            ndi.uniform_filter(xd, size, mode=mode, cval=1.5, output=out)
+        assert "ragged" in last_kernel(), last_kernel()
+        ref = sndi.uniform_filter(x.astype(np.float64), size, mode=mode, cval=1.5)
+        g = out.get()
+        err = np.abs(g - ref).reshape(181, -1).max(axis=1)
+        assert err.max() <= 1e-6 * np.abs(ref).max(), (size, mode, int(err.argmax()), float(err.max()))
+
+
+def test_rank_filters_of_65_to_128_samples_take_the_sorting_network(gpu, ndi, lib):
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(4242)
+    vol = (rng.standard_normal((14, 19, 70)) * 60 + 100)
+    img = (rng.standard_normal((61, 135)) * 60 + 100)
+    for dt in (np.float32, np.uint8, np.int16, np.uint16, np.int8):
+        for x in (vol, img):
+            x = np.clip(x, np.iinfo(dt).min, np.iinfo(dt).max).astype(dt) if np.dtype(dt).kind in "iu" else x.astype(dt)
+            xd = gpu.asarray(x)
+            sizes = [5] if x.ndim == 3 else [9, 11]
+            for size in sizes:
+                n = size ** x.ndim
+                for mode in ("reflect", "constant", "wrap"):
+                    got = ndi.median_filter(xd, size=size, mode=mode, cval=3).get()
+                    assert "rank3_sorted_kernel" in last_kernel() and ",128," in last_kernel(), last_kernel()
+                    assert np.array_equal(got, sndi.median_filter(x, size=size, mode=mode, cval=3)), (dt, size, mode)
+                for rank in (0, 1, n // 3, n - 2, n - 1):
+                    got = ndi.rank_filter(xd, rank, size=size, mode="mirror").get()
+                    assert np.array_equal(got, sndi.rank_filter(x, rank, size=size, mode="mirror")), (dt, size, rank)
+                got = ndi.percentile_filter(xd, 30, size=size, mode="nearest").get()
+                assert np.array_equal(got, sndi.percentile_filter(x, 30, size=size, mode="nearest")), (dt, size)
+            # footprints with holes: 65 and 128 samples exactly, an origin
+            shape_fp = (5, 5, 6) if x.ndim == 3 else (10, 13)
+            for nset in (65, 100, 128):
+                fp = np.zeros(int(np.prod(shape_fp)), bool)
+                fp[rng.permutation(fp.size)[:nset]] = True
+                fp = fp.reshape(shape_fp)
+                org = (1, -1, 0) if x.ndim == 3 else (-2, 3)
+                got = ndi.rank_filter(xd, nset // 2, footprint=fp, origin=org, mode="reflect").get()
+                assert "rank3_sorted_kernel" in last_kernel(), last_kernel()
+                assert np.array_equal(got, sndi.rank_filter(x, nset // 2, footprint=fp, origin=org, mode="reflect")), (dt, nset)
+    # infinities sort like any other value
+    x = vol.astype(np.float32)
+    x[3, 4, 5] = np.inf
+    x[7, 8, 9] = -np.inf
+    assert np.array_equal(ndi.median_filter(gpu.asarray(x), size=5).get(), sndi.median_filter(x, size=5))
+    # float64 / int32 keep the selection kernel beyond 64 samples
+    xd64 = gpu.asarray(vol)
+    got = ndi.median_filter(xd64, size=5).get()
+    assert "rank3_sorted_kernel" not in last_kernel()
+    assert np.array_equal(got, sndi.median_filter(vol, size=5))
