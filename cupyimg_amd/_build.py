@@ -54,6 +54,8 @@ SOURCES = [
     ("rank_sorted_p128c.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p128d.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p128e.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p128f.hip", ["-ffp-contract=off"]),
+    ("rank_sorted_p128g.hip", ["-ffp-contract=off"]),
     ("minmax3d_u8.hip", []),
     ("median2d.hip", []),
     ("minmax_16.hip", []),

@@ -221,6 +221,8 @@ rank_nd_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, NdG
     }
 }
 
+static Knob g_rank_zb{0};            // planes a workgroup of the sorting-network kernel walks (0 = rule in rank_sorted.hpp)
+int rank_zb_knob() { return g_rank_zb; }
 // sorting-network rank kernel: rank_sorted.hpp, instantiated in rank_sorted_*.hip
 template <typename T, typename V, int P>
 int run_rank_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, int rank, hipStream_t s);
@@ -434,8 +436,9 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
                                    std::is_same<T, uint32_t>::value;
         if constexpr (as_float || as_double) {
             using V = std::conditional_t<as_float, float, double>;
-            // 65..128 samples (r5: 5 x 5 x 5, 9 x 9, 11 x 11): 128 value registers -- float-valued types only (doubles would spill)
-            if (tt3.ntaps <= (as_float ? 128 : 64) && out->dtype == in->dtype && g_rank_sorted) {
+            // 65..128 samples (r5: 5 x 5 x 5, 9 x 9, 11 x 11): 128 key registers -- every type with 32-bit keys (float64 would spill)
+            constexpr bool key32 = !std::is_same<T, double>::value;
+            if (tt3.ntaps <= (key32 ? 128 : 64) && out->dtype == in->dtype && g_rank_sorted) {
                 const T *ip = (const T *)in->data;
                 T *op = (T *)out->data;
                 if constexpr (std::is_same<T, float>::value || std::is_same<T, uint8_t>::value || std::is_same<T, uint16_t>::value ||
@@ -449,7 +452,7 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
                 if (tt3.ntaps <= 16) return run_rank_sorted<T, V, 16>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
                 if (tt3.ntaps <= 32) return run_rank_sorted<T, V, 32>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
                 if (tt3.ntaps <= 64) return run_rank_sorted<T, V, 64>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
-                if constexpr (as_float) return run_rank_sorted<T, V, 128>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
+                if constexpr (key32) return run_rank_sorted<T, V, 128>(ip, op, t3.g, tt3, mode, (V)cv, rank, s);
             }
         }
         note_kernel("mi::rank3_kernel ntaps=%d rank=%d (selection in a per-thread array)", tt3.ntaps, rank);
@@ -461,3 +464,4 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
 }
 
 }  // extern "C"
+extern "C" int mi_debug_set_rank_zb(int k) { mi::g_rank_zb = k; return MI_OK; }

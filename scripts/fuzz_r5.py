@@ -1,6 +1,6 @@
 """r5: targeted differential fuzz of the default-order (3) routes against scipy.ndimage on volumes large enough to take the round-5
 kernels (one-sweep prefilter, cubic3_zfactor / zfix, row-blend with an unfiltered axis, the resampling passes, the LDS box affine
-on cube tiles): random shapes, matrices, modes, output shapes.  float32 in / out: 2e-5 max(1, max|ref|); float64 prefilter: 1e-11.
+on cube tiles), of the ragged-row build of the 3 / 5 / 7-tap filter kernel and of the 128-sample rank network: random shapes, matrices, modes, output shapes.  float32 in / out: 2e-5 max(1, max|ref|); float64 prefilter: 1e-11.
 usage: python scripts/fuzz_r5.py [seconds] [seed]  -> profiles/r5_fuzz_summary.txt"""
 import os, sys, time, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -47,7 +47,7 @@ while time.time() < t_end:
     vd = ca.asarray(v)
     v64 = v.astype(np.float64)
     mode = str(rng.choice(MODES))
-    op = int(rng.integers(0, 9))
+    op = int(rng.integers(0, 11))
     try:
         if op == 0:
             order = int(rng.choice([2, 3, 3]))
@@ -96,6 +96,33 @@ while time.time() < t_end:
             co = co.astype(np.float32 if rng.random() < 0.6 else np.float64)
             check("map_coordinates3", ndi.map_coordinates(vd, ca.asarray(co), mode=mode, cval=0.3).get(),
                   sndi.map_coordinates(v64, co.astype(np.float64), mode=mode, cval=0.3), 2e-5, (shape, osh, mode, str(co.dtype)))
+        elif op == 9:
+            # rows that are not a multiple of four floats through the 3 / 5 / 7-tap fused kernel (ragged build)
+            sh = (int(rng.integers(3, 60)), int(rng.integers(3, 80)), int(rng.choice([17, 19, 66, 101, 181, 253, 255, 257, 301, 511, 515])) + int(rng.integers(0, 3)) * 4)
+            w = rng.standard_normal(sh).astype(np.float32); wd = ca.asarray(w)
+            m = str(rng.choice(["reflect", "mirror", "nearest", "wrap", "constant"]))
+            if rng.random() < 0.5:
+                size = int(rng.choice([3, 5, 7]))
+                check("uniform-ragged", ndi.uniform_filter(wd, size, mode=m, cval=0.3).get(), sndi.uniform_filter(w.astype(np.float64), size, mode=m, cval=0.3), 1e-6, (sh, size, m))
+            else:
+                sg = float(rng.choice([0.25, 0.4, 0.5, 0.6, 0.75, 0.8]))
+                check("gaussian-ragged", ndi.gaussian_filter(wd, sg, mode=m, cval=0.3).get(), sndi.gaussian_filter(w.astype(np.float64), sg, mode=m, cval=0.3), 1e-6, (sh, sg, m))
+        elif op == 10:
+            # rank filters with 65 .. 128 samples (sorting network on 128 registers): bit-exact
+            dt = [np.float32, np.uint8, np.int16, np.uint16, np.int8][int(rng.integers(0, 5))]
+            nd = int(rng.choice([2, 3]))
+            sh = (int(rng.integers(6, 24)), int(rng.integers(6, 40)), int(rng.integers(8, 140)))[3 - nd:]
+            w = (rng.standard_normal(sh) * 50).astype(dt); wd = ca.asarray(w)
+            fshape = tuple(int(rng.integers(3, 7)) for _ in range(nd)) if nd == 3 else tuple(int(rng.integers(7, 13)) for _ in range(nd))
+            fp = rng.random(fshape) < float(rng.uniform(0.5, 1.0))
+            nset = int(fp.sum())
+            if not (65 <= nset <= 128):
+                continue
+            rank = int(rng.integers(0, nset))
+            m = str(rng.choice(["reflect", "mirror", "nearest", "wrap", "constant"]))
+            org = tuple(int(rng.integers(-(f // 2), f // 2 + (f & 1))) if rng.random() < 0.3 else 0 for f in fshape)
+            check("rank-128", ndi.rank_filter(wd, rank, footprint=fp, mode=m, cval=3, origin=org).get(), sndi.rank_filter(w, rank, footprint=fp, mode=m, cval=3, origin=org), 0.0,
+                  (sh, str(np.dtype(dt)), fshape, nset, rank, m, org))
         else:
             M = rot((0, 0, 1), float(rng.uniform(-40, 40)))      # rotation in the (z, y) plane: x to itself (row-blend)
             off = (np.array(shape) - 1) / 2 - M @ ((np.array(shape) - 1) / 2)

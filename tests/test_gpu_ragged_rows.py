@@ -130,7 +130,7 @@ def test_rank_filters_of_65_to_128_samples_take_the_sorting_network(gpu, ndi, li
     rng = np.random.default_rng(4242)
     vol = (rng.standard_normal((14, 19, 70)) * 60 + 100)
     img = (rng.standard_normal((61, 135)) * 60 + 100)
-    for dt in (np.float32, np.uint8, np.int16, np.uint16, np.int8):
+    for dt in (np.float32, np.uint8, np.int16, np.uint16, np.int8, np.int32, np.uint32):
         for x in (vol, img):
             x = np.clip(x, np.iinfo(dt).min, np.iinfo(dt).max).astype(dt) if np.dtype(dt).kind in "iu" else x.astype(dt)
             xd = gpu.asarray(x)
@@ -161,8 +161,35 @@ def test_rank_filters_of_65_to_128_samples_take_the_sorting_network(gpu, ndi, li
     x[3, 4, 5] = np.inf
     x[7, 8, 9] = -np.inf
     assert np.array_equal(ndi.median_filter(gpu.asarray(x), size=5).get(), sndi.median_filter(x, size=5))
-    # float64 / int32 keep the selection kernel beyond 64 samples
+    # float64 keeps the selection kernel beyond 64 samples
     xd64 = gpu.asarray(vol)
     got = ndi.median_filter(xd64, size=5).get()
     assert "rank3_sorted_kernel" not in last_kernel()
     assert np.array_equal(got, sndi.median_filter(vol, size=5))
+
+
+def test_rank_network_orders_nans_and_signed_zeros_like_numpy_sort(gpu, ndi, lib):
+    """r5: the sorting network works on integer keys (a total order): NaNs (sign bit clear, what arithmetic produces) sort above
+    +inf -- where numpy.sort puts them, so a rank filter equals sorted(window)[rank] -- and -0.0 below +0.0.  SciPy's own
+    selection leaves the result with NaNs to the order of its comparisons; the reference's kernels likewise."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal((6, 9, 70)).astype(np.float32)
+    x[rng.random(x.shape) < 0.05] = np.nan
+    x[rng.random(x.shape) < 0.03] = np.inf
+    x[rng.random(x.shape) < 0.03] = -np.inf
+    x[rng.random(x.shape) < 0.05] = 0.0
+    x[rng.random(x.shape) < 0.05] = -0.0
+    xd = gpu.asarray(x)
+    # (ranks 0 and n - 1 are minimum_filter / maximum_filter calls, as in the reference: not this kernel)
+    for size, ranks in ((3, (1, 8, 13, 20, 25)), ((1, 3, 3), (1, 4, 7)), ((1, 5, 5), (12,)), (5, (62, 100, 123))):
+        n = int(np.prod(size)) if isinstance(size, tuple) else size ** 3
+        for rank in ranks:
+            got = ndi.rank_filter(xd, rank, size=size, mode="reflect").get()
+            assert "rank3_sorted_kernel" in last_kernel() or n in (25, 27), last_kernel()
+            want = sndi.generic_filter(x.astype(np.float64), lambda w: np.sort(w)[rank], size=size, mode="reflect").astype(np.float32)
+            assert np.array_equal(got, want, equal_nan=True), (size, rank)
+    got = ndi.median_filter(xd, size=3).get()
+    want = sndi.generic_filter(x.astype(np.float64), lambda w: np.sort(w)[13], size=3, mode="reflect").astype(np.float32)
+    assert np.array_equal(got, want, equal_nan=True)
