@@ -733,10 +733,12 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
         const int r = wave + 16 * h;
         const int ys = bmap<int>(y0 - p.oy + r, ny, p.my);
         const bool valid = r < rows_needed;
-        vmain[h] = (valid && lane < nlanes) ? (unsigned)(ys * nx + x0 + 4 * lane) * 4u : kOOB;
+        // (r5: `constant` with a zero fill value -- a row, a halo column or (below) a plane beyond the array is simply not
+        // fetched: what the DMA leaves in LDS for an out-of-range lane is the zero the mode prescribes)
+        vmain[h] = (valid && ys >= 0 && lane < nlanes) ? (unsigned)(ys * nx + x0 + 4 * lane) * 4u : kOOB;
         const int j = lane & 15;
         const int xsrc = bmap<int>(j < 8 ? x0 - 8 + j : xe + j - 8, nx, p.mx);
-        vhalo[h] = (valid && xsrc >= 0) ? (unsigned)(ys * nx + xsrc) * 4u : kOOB;
+        vhalo[h] = (valid && ys >= 0 && xsrc >= 0) ? (unsigned)(ys * nx + xsrc) * 4u : kOOB;
     }
     const unsigned own = (unsigned)wave * kLongRec + (unsigned)lane * 16u;      // this lane's block of record `wave`
     // halo pass (one wave per plane): lane -> (row = lane / 4, block = lane % 4) of the record's 64 halo bytes
@@ -757,11 +759,11 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
         const bool live = i < nsteps;
         int zsrc = zi0 + i;
         if ((unsigned)zsrc >= (unsigned)nz) zsrc = __builtin_amdgcn_readfirstlane(ztab[live ? i : 0]);   // boundary planes only
-        const unsigned long long a = (unsigned long long)in + (unsigned long long)(unsigned)zsrc * (unsigned long long)plane_bytes;
+        const unsigned long long a = (unsigned long long)in + (unsigned long long)(unsigned)max(zsrc, 0) * (unsigned long long)plane_bytes;
         u32x4_t rin;
         rin.x = (unsigned)a;
         rin.y = (unsigned)(a >> 32);       // stride 0: the upper 16 bits of a device address are zero
-        rin.z = live ? plane_bytes : 0u;
+        rin.z = (live && zsrc >= 0) ? plane_bytes : 0u;
         rin.w = 0x00020000u;
         // staged rows W - 1 .. 15 of the tile are read by no other workgroup (the neighbours' windows end at row W - 2 /
         // start at row 16): non-temporal (long_common.hpp); chunk-ramp planes are re-read by the next z chunk, rarely
@@ -1167,6 +1169,7 @@ sep3d_long4_kernel(const float *__restrict__ in, float *__restrict__ out, const 
 
 static mi::Knob g_long_rows{0};        // kernel generation: 0 / 3 = the r3 pipelined kernel, 1 = the r2 kernel (kept for 9 / 13 / 17 taps as the comparator), 4 = the r4 kernel with the y pass on the matrix cores (9 / 13 / 17 taps; an experiment that did not pay)
 static mi::Knob g_long_dbg{0};         // tuning ablations, see LongParams::dbg
+static mi::Knob g_long_const0{1};     // r5: 1 = constant mode with cval == 0 takes the r3 kernel (zero fill by the staging), 0 = the r2 kernel with its correction
 static mi::Knob g_long_cfg{0};         // MI_LONG_TUNE builds: which tuning variant of the 17-tap kernel runs
 
 #ifdef MI_LONG_DEV
@@ -1194,7 +1197,15 @@ static int launch_long(const float *in, float *out, LongParams &p, hipStream_t s
                        (HAS_CONST ? (size_t)kLongMaxChunk * sizeof(float) : 0);
     const int total = p.nxt * p.nyt * p.nzc;
     if constexpr (HAS_CONST) {
-        // constant mode keeps the r2 kernel: its correction terms (five more live registers) do not fit beside the r3
+        // r5: a zero fill value needs no correction at all -- zero fill is what the staging leaves for whatever lies beyond
+        // the array -- and takes the r3 kernel like every other mode
+        if (p.cval == 0.0f && g_long_const0) {
+            static PerDeviceOnce attr_z;
+            note_kernel("mi::sep3d_long3_kernel<%d,%s> grid=%d (fused y/x/z separable pass, LDS-DMA staged, y pass one plane ahead; constant mode, zero fill)",
+                        W, SAME ? "true" : "false", total);
+            return long_launch_one(sep3d_long3_kernel<W, SAME, false>, attr_z, lds, total, in, out, p, s);
+        }
+        // any other fill value keeps the r2 kernel: its correction terms (five more live registers) do not fit beside the r3
         // kernel's read groups without spilling, and a spill is a vector-memory operation the vmcnt arithmetic does not count
         static PerDeviceOnce attr_c;
         note_kernel("mi::sep3d_long_kernel<%d,%s,true> grid=%d (fused y/x/z separable pass, LDS-DMA staged, constant mode)", W,
@@ -1296,7 +1307,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, i
     // w: taps along y and x, wzn: taps along z (== w: the cubic kernels; a few (w, wzn) pairs with wzn < w besides)
     if (w < 3 || w > 17 || !(w & 1) || wzn < 3 || wzn > 17 || !(wzn & 1)) return MI_ERR_UNSUPPORTED;
     const bool has_const = mx == MI_MODE_CONSTANT || my == MI_MODE_CONSTANT || mz == MI_MODE_CONSTANT;
-    if (wzn != w && (has_const || !long_aniso_pair(w, wzn))) return MI_ERR_UNSUPPORTED;
+    if (wzn != w && ((has_const && !(cval == 0.0f && g_long_const0)) || !long_aniso_pair(w, wzn))) return MI_ERR_UNSUPPORTED;
     if ((int64_t)ny * nx * 4 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
     if (t_dry_run) return MI_OK;          // every odd (w, w) in 3 .. 17 and every pair of long_aniso_pair() has an instance
     LongParams p;
@@ -1393,3 +1404,4 @@ extern "C" int mi_debug_set_long_same(int n) { mi::g_long_same = n; return MI_OK
 extern "C" int mi_debug_set_long_dbg(int f) { mi::g_long_dbg = f; return MI_OK; }
 extern "C" int mi_debug_set_long_rows(int k) { mi::g_long_rows = k; return MI_OK; }
 extern "C" int mi_debug_set_long_cfg(int k) { mi::g_long_cfg = k; return MI_OK; }
+extern "C" int mi_debug_set_long_const0(int k) { mi::g_long_const0 = k; return MI_OK; }

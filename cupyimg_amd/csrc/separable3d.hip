@@ -935,7 +935,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     // r3: anisotropic voxels -- the same kernel with fewer taps along z than in the plane (one launch at 8 B/voxel
     // where the streaming passes below take two at 16), for the tap pairs it is instantiated for, on volumes that fill
     // the chip; index-mapping boundary modes only
-    if (g_sep3d_long != 1 && !ragged && !any_const && w[1] == w[2] && w[0] != w[1] && nx >= 128 && ny >= 16 &&
+    if (g_sep3d_long != 1 && !ragged && (!any_const || (float)cval == 0.0f) && w[1] == w[2] && w[0] != w[1] && nx >= 128 && ny >= 16 &&
         nvox_out >= ((int64_t)1 << 22) && mi::long_aniso_pair(w[1], w[0])) {
         const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
         rc = run_sep3d_long((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w[1], w[0], wbuf[2], wbuf[1],

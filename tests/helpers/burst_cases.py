@@ -54,9 +54,9 @@ class Cases:
         return [n for n in dir(self) if n.startswith("case_")]
 
     # ---- separable / min-max (192 x 256 x 512)
-    def _sep(self, size, mode):
+    def _sep(self, size, mode, cval=0.0):
         x, xd = self.vol((192, 256, 512), 1)
-        return (lambda o: self.ndi.uniform_filter(xd, size, mode=mode, output=o)), x.shape, np.float32, "sep3d_long"
+        return (lambda o: self.ndi.uniform_filter(xd, size, mode=mode, cval=cval, output=o)), x.shape, np.float32, "sep3d_long"
 
     def case_long3_5(self):
         return self._sep(5, "reflect")
@@ -68,7 +68,10 @@ class Cases:
         return self._sep(17, "nearest")
 
     def case_long_const_13(self):
-        return self._sep(13, "constant")
+        return self._sep(13, "constant", 0.25)               # a fill value: the r2 stream with its coverage correction
+
+    def case_long3_const0_13(self):
+        return self._sep(13, "constant")                     # r5: zero fill on the r3 kernel
 
     def case_mm3f32_5(self):
         x, xd = self.vol((192, 256, 512), 1)

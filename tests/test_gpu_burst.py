@@ -53,14 +53,16 @@ def test_separable_long_kernels_under_load(gpu, ndi, lib):
     rng = np.random.default_rng(1)
     x = rng.standard_normal((192, 256, 512)).astype(np.float32)
     xd = gpu.asarray(x)
-    for size, mode, kern in ((5, "reflect", "sep3d_long3_kernel<5"), (9, "mirror", "sep3d_long3_kernel<9"), (17, "nearest", "sep3d_long3_kernel<17"),
-                             (9, "constant", "sep3d_long_kernel<9"), (13, "constant", "sep3d_long_kernel<13")):
+    # (r5: `constant` with a zero fill value runs on the r3 kernel -- nothing fetched beyond the array --, any other on the r2 kernel)
+    for size, mode, cv, kern in ((5, "reflect", 0.0, "sep3d_long3_kernel<5"), (9, "mirror", 0.0, "sep3d_long3_kernel<9"), (17, "nearest", 0.0, "sep3d_long3_kernel<17"),
+                                 (9, "constant", 0.5, "sep3d_long_kernel<9"), (13, "constant", -1.25, "sep3d_long_kernel<13"),
+                                 (9, "constant", 0.0, "sep3d_long3_kernel<9"), (17, "constant", 0.0, "sep3d_long3_kernel<17")):
         lib.mi_debug_set_sep3d_long(1)                      # comparator: lean / streaming kernels
         try:
-            ref = ndi.uniform_filter(xd, size, mode=mode).get().astype(np.float64)
+            ref = ndi.uniform_filter(xd, size, mode=mode, cval=cv).get().astype(np.float64)
         finally:
             lib.mi_debug_set_sep3d_long(0)
-        check(gpu, lambda o: ndi.uniform_filter(xd, size, mode=mode, output=o), x.shape, np.float32, ref, False, kern)
+        check(gpu, lambda o: ndi.uniform_filter(xd, size, mode=mode, cval=cv, output=o), x.shape, np.float32, ref, False, kern)
     # several z chunks (the prologue of a chunk is where a first-step wait matters), the experimental matrix-core kernel
     for rows, zc, kern in ((0, 6, "sep3d_long3_kernel<9"), (4, 6, "sep3d_long4_kernel<9"), (4, 0, "sep3d_long4_kernel<17")):
         size = 17 if "17" in kern else 9
@@ -245,7 +247,7 @@ def test_strict_wait_build_is_bit_identical_under_load(gpu):
             assert proc.returncode == 0, proc.stdout[-3000:]
             res[tag] = json.load(open(out))
     assert res["strict"]["library"].endswith("libmi355img_strict.so") and res["product"]["library"].endswith("libmi355img.so")
-    assert len(res["product"]["cases"]) >= 20
+    assert len(res["product"]["cases"]) >= 21
     for name, c in res["product"]["cases"].items():
         s = res["strict"]["cases"][name]
         assert c["expected"] in c["kernel"], (name, c["kernel"])

@@ -1,7 +1,8 @@
-"""r5: rows that are not a multiple of four floats go through the 3 / 5 / 7-tap fused kernel as they are
+"""r5 additions to the filter kernels.  Rows that are not a multiple of four floats go through the 3 / 5 / 7-tap fused kernel as they are
 (sep3d_lean_kernel<..., ragged>: csrc/separable3d.hip) -- no mi_extend_rows / mi_crop_rows copies around the launch -- and
 rank filters with 65 .. 128 samples (5 x 5 x 5, 9 x 9, 11 x 11) take the register sorting network (rank_sorted_p128*.hip)
-instead of the scratch-array selection kernel.  Spec: /root/reference/cupyimg/scipy/ndimage/filters.py:549-665 (separable
+instead of the scratch-array selection kernel; `constant` mode with a zero fill value on the LDS-DMA kernel of 9 .. 17 taps
+(sep3d_long3_kernel: zero fill is what its staging leaves for lanes beyond the array).  Spec: /root/reference/cupyimg/scipy/ndimage/filters.py:549-665 (separable
 passes), :1373-1557 (rank filters)."""
 import numpy as np
 import pytest
@@ -193,3 +194,61 @@ def test_rank_network_orders_nans_and_signed_zeros_like_numpy_sort(gpu, ndi, lib
     got = ndi.median_filter(xd, size=3).get()
     want = sndi.generic_filter(x.astype(np.float64), lambda w: np.sort(w)[13], size=3, mode="reflect").astype(np.float32)
     assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_constant_mode_with_zero_fill_on_the_long_kernel(gpu, ndi, lib):
+    """mode="constant", cval=0 (SciPy's default fill): one launch of sep3d_long3_kernel -- rows, halo columns and planes
+    beyond the array are not fetched -- against SciPy and against the r2 kernel with its coverage correction; mixed modes per
+    axis, plane ranges through partial tiles, the anisotropic (W, WZ) pairs; any other fill value keeps the r2 kernel."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(808)
+    for shape in ((40, 50, 256), (37, 45, 300), (19, 33, 64), (70, 18, 516)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        x64 = x.astype(np.float64)
+        for size in (9, 13, 17):
+            got = ndi.uniform_filter(xd, size, mode="constant").get()
+            k = last_kernel()
+            assert "sep3d_long3_kernel<%d," % size in k and "zero fill" in k, k
+            ref = sndi.uniform_filter(x64, size, mode="constant")
+            assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (shape, size)
+            lib.mi_debug_set_long_const0(0)
+            try:
+                old = ndi.uniform_filter(xd, size, mode="constant").get()
+                assert "sep3d_long_kernel<%d," % size in last_kernel(), last_kernel()
+            finally:
+                lib.mi_debug_set_long_const0(1)
+            assert np.abs(got - old).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (shape, size)
+            # a fill value: the r2 kernel
+            got = ndi.uniform_filter(xd, size, mode="constant", cval=1.5).get()
+            assert "sep3d_long_kernel<%d," % size in last_kernel(), last_kernel()
+            assert np.abs(got - sndi.uniform_filter(x64, size, mode="constant", cval=1.5)).max() <= 1e-6 * 4
+        for sigma in (1.0, 1.5, 2.0):
+            for modes in ("constant", ("constant", "reflect", "mirror"), ("nearest", "constant", "wrap"), ("wrap", "mirror", "constant")):
+                got = ndi.gaussian_filter(xd, sigma, mode=modes).get()
+                assert "sep3d_long3_kernel" in last_kernel(), (shape, sigma, modes, last_kernel())
+                ref = sndi.gaussian_filter(x64, sigma, mode=modes)
+                assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (shape, sigma, modes)
+    # anisotropic voxels: fewer taps along z than in the plane (one launch for the pairs the kernel is built for)
+    x = rng.standard_normal((64, 256, 260)).astype(np.float32)
+    xd = gpu.asarray(x)
+    got = ndi.gaussian_filter(xd, (1.0, 2.0, 2.0), mode="constant").get()
+    assert "sep3d_long3_kernel<17,false,false,0,9>" in last_kernel(), last_kernel()
+    ref = sndi.gaussian_filter(x.astype(np.float64), (1.0, 2.0, 2.0), mode="constant")
+    assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_constant_zero_fill_512_every_plane_last_of_a_burst(gpu, ndi, lib):
+    """gaussian_filter(sigma=2, mode="constant") on 512^3: the last launch of a burst, every plane against SciPy"""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    x = np.random.default_rng(31).standard_normal((512, 512, 512)).astype(np.float32)
+    xd = gpu.asarray(x)
+    out = gpu.empty(x.shape, np.float32)
+    for _ in range(30):
+        ndi.gaussian_filter(xd, 2.0, mode="constant", output=out)
+    assert "sep3d_long3_kernel<17," in last_kernel() and "zero fill" in last_kernel(), last_kernel()
+    ref = sndi.gaussian_filter(x, 2.0, mode="constant")
+    err = np.abs(out.get() - ref).reshape(512, -1).max(axis=1)
+    assert err.max() <= 1e-6 * np.abs(ref).max() + 2e-7, (int(err.argmax()), float(err.max()))

@@ -1732,9 +1732,9 @@ def test_separable_filters_keep_nonfinite_samples_inside_their_window(gpu, ndi):
     lib = _lib.load()
     rng = np.random.default_rng(77)
 
-    def explicit(v, weights, mode):
+    def explicit(v, weights, mode, cval=0.0):
         for ax, w in enumerate(weights):
-            v = sndi.correlate1d(v, w, axis=ax, mode=mode)
+            v = sndi.correlate1d(v, w, axis=ax, mode=mode, cval=cval)
         return v
 
     def gauss_w(sigma):
@@ -1751,25 +1751,29 @@ def test_separable_filters_keep_nonfinite_samples_inside_their_window(gpu, ndi):
         x[-1, -1, -1] = -np.inf
         x[1, 2, 3] = np.inf
         xd = gpu.asarray(x)
-        cases = [("uniform", s, m) for s in (3, 5, 7, 9, 11, 13, 17, 21, 4) for m in ("reflect", "constant")]
+        # ("constant", a fill value): r5 -- a zero fill value runs on the r3 long kernel, any other on the r2 kernel with its correction
+        cases = [("uniform", s, m) for s in (3, 5, 7, 9, 11, 13, 17, 21, 4) for m in ("reflect", "constant", ("constant", 0.75))]
         cases += [("gaussian", s, "reflect") for s in (1.0, 1.5, 2.0, 2.6, (2, 1, 1), (1, 2, 1.5))]
         for kind, par, mode in cases:
+            cv = 0.0
+            if isinstance(mode, tuple):
+                mode, cv = mode
             for rows in ((0, 4) if (kind == "gaussian" and par in (1.0, 1.5, 2.0)) or (kind == "uniform" and par in (9, 13, 17) and mode == "reflect") else (0,)):
                 lib.mi_debug_set_long_rows(rows)
                 try:
                     if kind == "uniform":
-                        got = ndi.uniform_filter(xd, par, mode=mode).get()
+                        got = ndi.uniform_filter(xd, par, mode=mode, cval=cv).get()
                         ws = [np.ones(par) / par] * 3
                     else:
-                        got = ndi.gaussian_filter(xd, par, mode=mode).get()
+                        got = ndi.gaussian_filter(xd, par, mode=mode, cval=cv).get()
                         sig = par if isinstance(par, tuple) else (par,) * 3
                         ws = [gauss_w(s) for s in sig]
                 finally:
                     lib.mi_debug_set_long_rows(0)
                 seen.add(last_kernel().split("<")[0].replace("mi::", ""))
                 with np.errstate(all="ignore"):
-                    ref = explicit(x.astype(np.float64), ws, mode)
-                what = (shape, kind, par, mode, rows, last_kernel()[:48])
+                    ref = explicit(x.astype(np.float64), ws, mode, cv)
+                what = (shape, kind, par, mode, cv, rows, last_kernel()[:48])
                 assert np.array_equal(np.isnan(got), np.isnan(ref)), what
                 assert np.array_equal(np.isposinf(got), np.isposinf(ref)) and np.array_equal(np.isneginf(got), np.isneginf(ref)), what
                 fin = np.isfinite(ref)
