@@ -41,6 +41,7 @@ SOURCES = [
     ("correlate_nd.hip", ["-ffp-contract=off"]),
     ("stencil3d.hip", ["-ffp-contract=off"]),
     ("minmax.hip", ["-ffp-contract=off"]),
+    ("median3d.hip", []),
     ("rank_sorted_p16.hip", ["-ffp-contract=off"]),
     ("rank_sorted_med.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p32a.hip", ["-ffp-contract=off"]),

@@ -228,6 +228,8 @@ template <typename T, typename V, int P>
 int run_rank_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, int rank, hipStream_t s);
 template <typename T, typename V, int N>
 int run_median_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, hipStream_t s);   // rank_sorted_med.hip
+template <typename T>
+int run_median27(const T *in, T *out, int64_t nz, int64_t ny, int64_t nx, int mode, double cval, hipStream_t s);      // median3d.hip
 
 }  // namespace mi
 
@@ -441,9 +443,18 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
             if (tt3.ntaps <= (key32 ? 128 : 64) && out->dtype == in->dtype && g_rank_sorted) {
                 const T *ip = (const T *)in->data;
                 T *op = (T *)out->data;
+                if constexpr (key32) {
+                    // r5: the median of the full 3 x 3 x 3 window of a volume -- the kernel that shares its sorting between windows
+                    if (tt3.ntaps == 27 && rank == 13 && t3.g.wz == 3 && t3.g.wy == 3 && t3.g.wx == 3 && t3.g.oz == 1 && t3.g.oy == 1 && t3.g.ox == 1) {
+                        const int r27 = run_median27<T>(ip, op, t3.g.nz, t3.g.ny, t3.g.nx, mode, cv, s);
+                        if (r27 != MI_ERR_UNSUPPORTED) return r27;
+                    }
+                }
                 if constexpr (std::is_same<T, float>::value || std::is_same<T, uint8_t>::value || std::is_same<T, uint16_t>::value ||
                               std::is_same<T, int16_t>::value) {
                     // the medians of 5 x 5 and 3 x 3 x 3 windows: network pruned for the one output that is needed
+                    if (g_rank_median && (tt3.ntaps == 25 || tt3.ntaps == 27) && rank == tt3.ntaps / 2)
+                        note_kernel("mi::rank3_sorted_kernel<32,%d,%d> (register sorting network pruned for the median)", tt3.ntaps, rank);
                     if (g_rank_median && tt3.ntaps == 25 && rank == 12) return run_median_sorted<T, V, 25>(ip, op, t3.g, tt3, mode, (V)cv, s);
                     if (g_rank_median && tt3.ntaps == 27 && rank == 13) return run_median_sorted<T, V, 27>(ip, op, t3.g, tt3, mode, (V)cv, s);
                 }

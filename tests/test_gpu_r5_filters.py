@@ -252,3 +252,67 @@ def test_constant_zero_fill_512_every_plane_last_of_a_burst(gpu, ndi, lib):
     ref = sndi.gaussian_filter(x, 2.0, mode="constant")
     err = np.abs(out.get() - ref).reshape(512, -1).max(axis=1)
     assert err.max() <= 1e-6 * np.abs(ref).max() + 2e-7, (int(err.argmax()), float(err.max()))
+
+
+def test_median_3x3x3_shared_sort_kernel(gpu, ndi, lib):
+    """median_filter(size=3) on volumes: median27_stream_kernel (csrc/median3d.hip: the window sorted along z, x, y in turn,
+    partial results shared between windows, a searched 19-input network at the end) -- bit-exact against SciPy and against the
+    per-voxel network, every boundary mode, every dtype with 32-bit keys, tile edges, z chunks, NaNs as numpy.sort orders them."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(2727)
+    shapes = [(40, 33, 70), (9, 200, 129), (130, 30, 62), (17, 15, 63), (33, 29, 64), (2, 128, 128), (64, 14, 125), (70, 16, 126)]
+    for dt in (np.float32, np.uint8, np.int8, np.uint16, np.int16, np.int32, np.uint32):
+        for shape in shapes if dt in (np.float32, np.uint8) else shapes[:3]:
+            x = rng.standard_normal(shape) * 60 + 100
+            x = np.clip(x, np.iinfo(dt).min, np.iinfo(dt).max).astype(dt) if np.dtype(dt).kind in "iu" else x.astype(dt)
+            if dt == np.uint32:
+                x = x * np.uint32(30000000)                     # beyond 2^31: unsigned keys
+            if dt == np.int32:
+                x = (x - 100) * np.int32(20000000)
+            xd = gpu.asarray(x)
+            for mode in MODES:
+                got = ndi.median_filter(xd, size=3, mode=mode, cval=7).get()
+                assert "median27_stream_kernel" in last_kernel(), (dt, shape, last_kernel())
+                assert np.array_equal(got, sndi.median_filter(x, size=3, mode=mode, cval=7)), (dt, shape, mode)
+            # the same through the footprint argument and percentile_filter; the per-voxel network agrees
+            fp = np.ones((3, 3, 3), bool)
+            got = ndi.percentile_filter(xd, 50, footprint=fp).get()
+            assert "median27_stream_kernel" in last_kernel(), last_kernel()
+            lib.mi_debug_set_median27(0)
+            try:
+                old = ndi.median_filter(xd, size=3).get()
+                assert "median27_stream_kernel" not in last_kernel()
+            finally:
+                lib.mi_debug_set_median27(1)
+            assert np.array_equal(got, old), (dt, shape)
+    # an origin, a footprint with a hole, another rank: not this kernel
+    x = rng.standard_normal((20, 40, 64)).astype(np.float32)
+    xd = gpu.asarray(x)
+    for kw in (dict(size=3, origin=(0, 1, 0)), dict(footprint=np.arange(27).reshape(3, 3, 3) != 5), dict(size=(3, 3, 5))):
+        got = ndi.median_filter(xd, **kw).get()
+        assert "median27_stream_kernel" not in last_kernel(), (kw, last_kernel())
+        assert np.array_equal(got, sndi.median_filter(x, **kw)), kw
+    # NaN / inf: a total order, NaNs above +inf (numpy.sort)
+    x = rng.standard_normal((12, 20, 70)).astype(np.float32)
+    x[rng.random(x.shape) < 0.06] = np.nan
+    x[rng.random(x.shape) < 0.04] = np.inf
+    x[rng.random(x.shape) < 0.04] = -np.inf
+    got = ndi.median_filter(gpu.asarray(np.tile(x, (4, 1, 1))), size=3).get()[:12]
+    want = sndi.generic_filter(np.tile(x, (4, 1, 1)).astype(np.float64), lambda w: np.sort(w)[13], size=3, mode="reflect").astype(np.float32)[:12]
+    assert np.array_equal(got[:11], want[:11], equal_nan=True)
+
+
+def test_median_3x3x3_whole_volume_last_of_a_burst(gpu, ndi, lib):
+    """256^3 float32 and 181 x 217 x 181 uint8: last launch of a burst, every voxel"""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(14)
+    for shape, dt in (((256, 256, 256), np.float32), ((181, 217, 181), np.uint8)):
+        x = (rng.standard_normal(shape) * 50 + 100).astype(dt)
+        xd = gpu.asarray(x)
+        out = gpu.empty(shape, dt)
+        for _ in range(20):
+            ndi.median_filter(xd, size=3, output=out)
+        assert "median27_stream_kernel" in last_kernel(), last_kernel()
+        assert np.array_equal(out.get(), sndi.median_filter(x, size=3)), (shape, dt)
