@@ -2,7 +2,7 @@
 // z-streaming kernel that SHARES its sorting work between neighbouring voxels (r5).
 //
 // Reference path replaced: median_filter -> rank_filter -> one thread per voxel sorting its own 27 samples
-// (cupyimg/scipy/ndimage/filters.py:1373-1557, _filters_optimal_medians.py).  The register sorting network of rank_sorted.hpp
+// (cupyimg/scipy/ndimage/filters.py:1612-1650 median_filter, 1712-1850 _rank_filter / _get_rank_kernel: shell sort or the selection networks of _filters_optimal_medians.py per voxel).  The register sorting network of rank_sorted.hpp
 // does the same per voxel: 27 gathers and ~270 min / max per voxel plus their addressing -- 700 vector instructions per wave
 // and voxel, instruction bound (profiles/r5_rank_filters.txt).
 //
@@ -93,7 +93,8 @@ median27_stream_kernel(const T *__restrict__ in, T *__restrict__ out, const Med2
 
     auto fetch = [&](int s) -> int {
         // the sample of this thread's column in the plane of step s, as a key
-        const int zsrc = bmap<int>(zs - 1 + s, nz, p.mz);
+        int zsrc = zs - 1 + s;
+        if ((unsigned)zsrc >= (unsigned)nz) zsrc = bmap<int>(zsrc, nz, p.mz);         // the first and the last plane only: the index map's divisions are scalar code every wave would run every step
         const int zz = __builtin_amdgcn_readfirstlane(max(zsrc, 0));
         const __amdgpu_buffer_rsrc_t rin =
             __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)zz * plane_elems), 0, (int)plane_bytes, 0x00020000);

@@ -47,7 +47,7 @@ while time.time() < t_end:
     vd = ca.asarray(v)
     v64 = v.astype(np.float64)
     mode = str(rng.choice(MODES))
-    op = int(rng.integers(0, 11))
+    op = int(rng.integers(0, 12))
     try:
         if op == 0:
             order = int(rng.choice([2, 3, 3]))
@@ -123,6 +123,15 @@ while time.time() < t_end:
             org = tuple(int(rng.integers(-(f // 2), f // 2 + (f & 1))) if rng.random() < 0.3 else 0 for f in fshape)
             check("rank-128", ndi.rank_filter(wd, rank, footprint=fp, mode=m, cval=3, origin=org).get(), sndi.rank_filter(w, rank, footprint=fp, mode=m, cval=3, origin=org), 0.0,
                   (sh, str(np.dtype(dt)), fshape, nset, rank, m, org))
+        elif op == 11:
+            # the 3 x 3 x 3 median on the kernel that shares its sorting between windows: bit-exact
+            dt = [np.float32, np.uint8, np.int16, np.uint16, np.int8, np.int32, np.uint32][int(rng.integers(0, 7))]
+            sh = (int(rng.integers(2, 70)), int(rng.integers(2, 90)), int(rng.integers(8, 300)))
+            if sh[0] * sh[1] * sh[2] < 4096:
+                continue
+            w = (rng.standard_normal(sh) * 50).astype(dt); wd = ca.asarray(w)
+            m = str(rng.choice(["reflect", "mirror", "nearest", "wrap", "constant"]))
+            check("median27", ndi.median_filter(wd, size=3, mode=m, cval=-3).get(), sndi.median_filter(w, size=3, mode=m, cval=-3), 0.0, (sh, str(np.dtype(dt)), m))
         else:
             M = rot((0, 0, 1), float(rng.uniform(-40, 40)))      # rotation in the (z, y) plane: x to itself (row-blend)
             off = (np.array(shape) - 1) / 2 - M @ ((np.array(shape) - 1) / 2)

@@ -3,7 +3,7 @@
 rank filters with 65 .. 128 samples (5 x 5 x 5, 9 x 9, 11 x 11) take the register sorting network (rank_sorted_p128*.hip)
 instead of the scratch-array selection kernel; `constant` mode with a zero fill value on the LDS-DMA kernel of 9 .. 17 taps
 (sep3d_long3_kernel: zero fill is what its staging leaves for lanes beyond the array).  Spec: /root/reference/cupyimg/scipy/ndimage/filters.py:549-665 (separable
-passes), :1373-1557 (rank filters)."""
+passes), :1560-1850 (rank / median / percentile filters)."""
 import numpy as np
 import pytest
 
