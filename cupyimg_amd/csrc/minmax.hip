@@ -221,8 +221,6 @@ rank_nd_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, NdG
     }
 }
 
-static Knob g_rank_zb{0};            // planes a workgroup of the sorting-network kernel walks (0 = rule in rank_sorted.hpp)
-int rank_zb_knob() { return g_rank_zb; }
 // sorting-network rank kernel: rank_sorted.hpp, instantiated in rank_sorted_*.hip
 template <typename T, typename V, int P>
 int run_rank_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, int rank, hipStream_t s);
@@ -475,4 +473,3 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
 }
 
 }  // extern "C"
-extern "C" int mi_debug_set_rank_zb(int k) { mi::g_rank_zb = k; return MI_OK; }

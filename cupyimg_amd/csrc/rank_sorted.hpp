@@ -21,13 +21,15 @@ __device__ __forceinline__ void rank_static_for(F &&f)
 // reference picks per-size selection networks (_filters_optimal_medians.py); one network per padded size covers every rank.
 // r5: the network sorts KEYS (RankKey below): 32-bit integers for everything but float64 -- the integer types as they are, float32
 // through the order-preserving map of its bit pattern -- so a compare-exchange is v_min_i32 + v_max_i32.  On float values it was
-// v_cmp_lt_f32, two wait states for VCC, two v_cndmask (a < b ? a : b is not v_min_f32 when NaNs may be about): 4.4 -> 2 ms for the
-// 3 x 3 x 3 median of 512^3.  The keys are totally ordered: -0 sorts below +0, NaNs with the sign bit clear sort above +inf (where
-// numpy.sort puts them), those with it set below -inf.
+// v_cmp_lt_f32, two wait states for VCC, two v_cndmask (a < b ? a : b is not v_min_f32 when NaNs may be about).  The keys are
+// totally ordered: -0 sorts below +0, NaNs with the sign bit clear sort above +inf (where numpy.sort puts them), those with it set
+// below -inf.  (The 3 x 3 x 3 median of a volume has a kernel of its own that shares its sorting between windows: median3d.hip.)
 template <typename T>
 struct RankKey {                       // the integer types up to 32 bits
     using K = std::conditional_t<std::is_same<T, uint32_t>::value, unsigned, int>;
     static __device__ __forceinline__ K pad() { return std::is_same<T, uint32_t>::value ? (K)0xffffffffu : (K)0x7fffffff; }
+    static __device__ __forceinline__ K raw(T v) { return (K)v; }
+    static __device__ __forceinline__ K finish(K r) { return r; }
     static __device__ __forceinline__ K key(T v) { return (K)v; }
     static __device__ __forceinline__ T value(K k) { return (T)k; }
 };
@@ -35,13 +37,19 @@ template <>
 struct RankKey<float> {
     using K = int;
     static __device__ __forceinline__ K pad() { return 0x7fffffff; }
-    static __device__ __forceinline__ K key(float v) { const int b = __float_as_int(v); return b ^ ((b >> 31) & 0x7fffffff); }
+    // raw(): the sample as it is loaded (no arithmetic: nothing in the loop that issues the loads waits for memory);
+    // finish(): raw -> key, applied to all samples at once afterwards.  finish(pad()) == pad().
+    static __device__ __forceinline__ K raw(float v) { return __float_as_int(v); }
+    static __device__ __forceinline__ K finish(K b) { return b ^ ((b >> 31) & 0x7fffffff); }
+    static __device__ __forceinline__ K key(float v) { return finish(raw(v)); }
     static __device__ __forceinline__ float value(K k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
 };
 template <>
 struct RankKey<double> {               // no 64-bit integer min / max: compare and select on the values
     using K = double;
     static __device__ __forceinline__ K pad() { return (double)INFINITY; }
+    static __device__ __forceinline__ K raw(double v) { return v; }
+    static __device__ __forceinline__ K finish(K r) { return r; }
     static __device__ __forceinline__ K key(double v) { return v; }
     static __device__ __forceinline__ double value(K k) { return k; }
 };
@@ -51,46 +59,41 @@ struct RankKey<double> {               // no 64-bit integer min / max: compare a
 // padding folds away and every compare-exchange that cannot reach output RANK is dead code.
 template <typename T, typename V, int P, int N = 0, int RANK = -1>
 __global__ void __launch_bounds__(256)
-rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps3 tt, int mode, V cval, int rank, int zb)
+rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps3 tt, int mode, V cval, int rank)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LdsTaps lt = stage_taps(tt, smem);
-    // r5: a workgroup walks `zb` planes (one voxel per thread and plane): the tap table is staged once, and two of the three
-    // (wz - 1 of wz) planes a step reads are the ones the step before left in the L1
-    Vox3 v = locate3(g);
+    // (r5, measured and dropped: a workgroup walking 16 planes so that the tap table is staged once -- 10 % on uint8, but the loop
+    // keeps the geometry and the tap descriptors live and spilled 73 scalar registers; one plane per workgroup)
+    const Vox3 v = locate3(g);
     if (!v.valid) return;
-    const int z_first = blockIdx.z * zb, z_end = min(z_first + zb, g.nz);
-  for (int z = z_first; z < z_end; z++) {
-    v.z = z;
-    v.lin = (z * g.ny + v.y) * g.nx + v.x;
-    {
-        const int cz = z - g.oz, cy = v.y - g.oy, cx = v.x - g.ox;
-        v.interior = cz >= 0 && cz + g.wz <= g.nz && cy >= 0 && cy + g.wy <= g.ny && cx >= 0 && cx + g.wx <= g.nx;
-    }
     const __amdgpu_buffer_rsrc_t rin =
         __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)((unsigned)g.nz * g.ny * g.nx * sizeof(T)), 0x00020000);
     using RK = RankKey<T>;
     using K = typename RK::K;
     K vals[P];
-    const K ckey = RK::key((T)cval);
+    const K craw = RK::raw((T)cval);
     const int n = N > 0 ? N : tt.ntaps;
     if (v.interior) {
         const unsigned base = (unsigned)v.lin * (unsigned)sizeof(T);
         rank_static_for<P>([&](auto TT) {
             constexpr int t = decltype(TT)::value;
-            vals[t] = t < n ? RK::key(buf_load<T>(rin, base + (unsigned)(lt.lin[t] * (int)sizeof(T)))) : RK::pad();
+            vals[t] = t < n ? RK::raw(buf_load<T>(rin, base + (unsigned)(lt.lin[t] * (int)sizeof(T)))) : RK::pad();
         });
     } else {
         rank_static_for<P>([&](auto TT) {
             constexpr int t = decltype(TT)::value;
             if (t < n) {
                 const int pos = tap_pos3(g, v, lt, t, mode);
-                vals[t] = pos < 0 ? ckey : RK::key(buf_load<T>(rin, (unsigned)pos * (unsigned)sizeof(T)));
+                vals[t] = pos < 0 ? craw : RK::raw(buf_load<T>(rin, (unsigned)pos * (unsigned)sizeof(T)));
             } else {
                 vals[t] = RK::pad();
             }
         });
     }
+    // raw samples -> keys, all at once: with the conversion inside the loops above -- one basic block per tap when the tap count is
+    // a run-time number -- every load was followed by a wait for memory (r5: the float32 kernels ran 1.5 x the uint8 ones)
+    rank_static_for<P>([&](auto TT) { vals[decltype(TT)::value] = RK::finish(vals[decltype(TT)::value]); });
     // stage s of the network: block size k = 2 << (stage row), distance j; every index is a compile-time constant
     constexpr int LOGP = P == 16 ? 4 : (P == 32 ? 5 : (P == 64 ? 6 : 7));
     rank_static_for<LOGP>([&](auto KK) {
@@ -119,27 +122,12 @@ rank3_sorted_kernel(const T *__restrict__ in, T *__restrict__ out, Geom3 g, Taps
         });
     }
     out[v.lin] = RK::value(res);
-  }
 }
-
-// planes per workgroup: as many as keep >= 8 workgroups per CU in the launch, at most 16
-int rank_zb_knob();      // minmax.hip: mi_debug_set_rank_zb (0 = the rule below)
-static inline int rank_planes_per_block(const Geom3 &g)
-{
-    if (rank_zb_knob() > 0) return rank_zb_knob();
-    const int64_t per_plane = (int64_t)((g.nx + 63) / 64) * ((g.ny + 3) / 4);
-    int zb = 16;
-    while (zb > 1 && per_plane * ((g.nz + zb - 1) / zb) < (int64_t)8 * 256) zb >>= 1;
-    return zb;
-}
-static inline dim3 rank_grid(const Geom3 &g, int zb) { return dim3((unsigned)((g.nx + 63) / 64), (unsigned)((g.ny + 3) / 4), (unsigned)((g.nz + zb - 1) / zb)); }
-
 
 template <typename T, typename V, int P>
 int run_rank_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, int rank, hipStream_t s)
 {
-    const int zb = rank_planes_per_block(g);
-    hipLaunchKernelGGL((rank3_sorted_kernel<T, V, P>), rank_grid(g, zb), dim3(64, 4, 1), taps3_lds_bytes(tt), s, in, out, g, tt, mode, cval, rank, zb);
+    hipLaunchKernelGGL((rank3_sorted_kernel<T, V, P>), grid3(g), dim3(64, 4, 1), taps3_lds_bytes(tt), s, in, out, g, tt, mode, cval, rank);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -148,9 +136,8 @@ int run_rank_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mo
 template <typename T, typename V, int N>
 int run_median_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, hipStream_t s)
 {
-    const int zb = rank_planes_per_block(g);
-    hipLaunchKernelGGL((rank3_sorted_kernel<T, V, 32, N, N / 2>), rank_grid(g, zb), dim3(64, 4, 1), taps3_lds_bytes(tt), s, in, out, g, tt, mode,
-                       cval, N / 2, zb);
+    hipLaunchKernelGGL((rank3_sorted_kernel<T, V, 32, N, N / 2>), grid3(g), dim3(64, 4, 1), taps3_lds_bytes(tt), s, in, out, g, tt, mode,
+                       cval, N / 2);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
