@@ -42,6 +42,8 @@ SOURCES = [
     ("stencil3d.hip", ["-ffp-contract=off"]),
     ("minmax.hip", ["-ffp-contract=off"]),
     ("median3d.hip", []),
+    ("median3d_u8.hip", []),
+    ("median3d_16.hip", []),
     ("rank_sorted_p16.hip", ["-ffp-contract=off"]),
     ("rank_sorted_med.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p32a.hip", ["-ffp-contract=off"]),

@@ -227,7 +227,7 @@ int run_rank_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mo
 template <typename T, typename V, int N>
 int run_median_sorted(const T *in, T *out, const Geom3 &g, const Taps3 &tt, int mode, V cval, hipStream_t s);   // rank_sorted_med.hip
 template <typename T>
-int run_median27(const T *in, T *out, int64_t nz, int64_t ny, int64_t nx, int mode, double cval, hipStream_t s);      // median3d.hip
+int run_rank27(const T *in, T *out, int64_t nz, int64_t ny, int64_t nx, int mode, double cval, int rank, hipStream_t s);      // median3d*.hip
 
 }  // namespace mi
 
@@ -443,8 +443,8 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
                 T *op = (T *)out->data;
                 if constexpr (key32) {
                     // r5: the median of the full 3 x 3 x 3 window of a volume -- the kernel that shares its sorting between windows
-                    if (tt3.ntaps == 27 && rank == 13 && t3.g.wz == 3 && t3.g.wy == 3 && t3.g.wx == 3 && t3.g.oz == 1 && t3.g.oy == 1 && t3.g.ox == 1) {
-                        const int r27 = run_median27<T>(ip, op, t3.g.nz, t3.g.ny, t3.g.nx, mode, cv, s);
+                    if (tt3.ntaps == 27 && t3.g.wz == 3 && t3.g.wy == 3 && t3.g.wx == 3 && t3.g.oz == 1 && t3.g.oy == 1 && t3.g.ox == 1) {
+                        const int r27 = run_rank27<T>(ip, op, t3.g.nz, t3.g.ny, t3.g.nx, mode, cv, rank, s);
                         if (r27 != MI_ERR_UNSUPPORTED) return r27;
                     }
                 }

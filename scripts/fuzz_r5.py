@@ -131,7 +131,11 @@ while time.time() < t_end:
                 continue
             w = (rng.standard_normal(sh) * 50).astype(dt); wd = ca.asarray(w)
             m = str(rng.choice(["reflect", "mirror", "nearest", "wrap", "constant"]))
-            check("median27", ndi.median_filter(wd, size=3, mode=m, cval=-3).get(), sndi.median_filter(w, size=3, mode=m, cval=-3), 0.0, (sh, str(np.dtype(dt)), m))
+            if rng.random() < 0.5:
+                check("median27", ndi.median_filter(wd, size=3, mode=m, cval=-3).get(), sndi.median_filter(w, size=3, mode=m, cval=-3), 0.0, (sh, str(np.dtype(dt)), m))
+            else:
+                rk = int(rng.integers(1, 26))
+                check("rank27", ndi.rank_filter(wd, rk, size=3, mode=m, cval=-3).get(), sndi.rank_filter(w, rk, size=3, mode=m, cval=-3), 0.0, (sh, str(np.dtype(dt)), m, rk))
         else:
             M = rot((0, 0, 1), float(rng.uniform(-40, 40)))      # rotation in the (z, y) plane: x to itself (row-blend)
             off = (np.array(shape) - 1) / 2 - M @ ((np.array(shape) - 1) / 2)

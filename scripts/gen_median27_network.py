@@ -9,11 +9,15 @@ the window is the MEDIAN OF THOSE 19.  The network that takes it is found here: 
     commutes with min / max and keeps the order) these are the 980 monotone 0/1 labelings of the 3 x 3 x 3 poset;
   * comparators with a padding wire turned into renames;
   * every min / max dropped that cannot reach the output;
-and the placement of the candidates on the wires chosen by annealing on the instruction count (WIRES below: 62 min / max).
+and the placement of the candidates on the wires chosen by annealing on the instruction count (rank27_wires.json; the median: 62
+min / max).
 The emitted code is checked against every labeling and against random windows before it is written.
 
-usage: python scripts/gen_median27_network.py            (writes the header from WIRES)
-       python scripts/gen_median27_network.py --search SECONDS SEED   (anneals, prints a placement)"""
+The same argument gives every other rank r of the window (percentile_filter / rank_filter with the full 3 x 3 x 3 footprint):
+the candidates are the positions with at most r samples known below and at most 26 - r known above, 3 ... 19 of them.
+
+usage: python scripts/gen_median27_network.py            (writes the header from scripts/rank27_wires.json)
+       python scripts/gen_median27_network.py --search SECONDS [WORKERS]   (anneals every rank, keeps the better placement)"""
 import itertools
 import math
 import os
@@ -22,10 +26,34 @@ import sys
 import time
 
 CELLS = [(i, j, k) for i in range(3) for j in range(3) for k in range(3)]
-CAND = [c for c in CELLS if (c[0] + 1) * (c[1] + 1) * (c[2] + 1) <= 14 and (3 - c[0]) * (3 - c[1]) * (3 - c[2]) <= 14]
 N = 32
-OUT_WIRE = 15            # 6 wires at -inf below the 19 candidates: their median (rank 9) is position 15
-WIRES = [-2, -2, 0, 7, 13, 15, 11, -1, 16, -1, -2, 12, 2, -2, 10, -1, 3, -2, 4, -2, -1, 6, -1, 14, 1, 5, 8, 18, 9, 17, -1, -1]       # --search 1100 6 (62 instructions)
+OUT_WIRE = 15            # r = 13: 6 wires at -inf below the 19 candidates, their median (rank 9) is position 15
+RANK = 13                # the rank the module-level CAND / tests() / verify() refer to (set_rank())
+
+
+def candidates(r):
+    """positions of the sorted cube that can hold the sample of rank r (0 = smallest), and how many positions are known below it"""
+    cand = [c for c in CELLS if (c[0] + 1) * (c[1] + 1) * (c[2] + 1) - 1 <= r and (3 - c[0]) * (3 - c[1]) * (3 - c[2]) - 1 <= 26 - r]
+    below = [c for c in CELLS if (3 - c[0]) * (3 - c[1]) * (3 - c[2]) - 1 > 26 - r]
+    return cand, len(below)
+
+
+CAND, NBELOW = candidates(RANK)
+
+
+def set_rank(r):
+    global RANK, CAND, NBELOW
+    RANK = r
+    CAND, NBELOW = candidates(r)
+
+
+def start_wires(r):
+    """candidates, then pads: the wanted sample (rank r - NBELOW among the candidates) comes out on OUT_WIRE"""
+    cand, nb = candidates(r)
+    lo = OUT_WIRE - (r - nb)
+    hi = N - len(cand) - lo
+    assert lo >= 0 and hi >= 0
+    return list(range(len(cand))) + [-2] * lo + [-1] * hi
 
 
 def labelings():
@@ -42,7 +70,7 @@ def tests():
     idx = {c: n for n, c in enumerate(CELLS)}
     t = set()
     for f in labelings():
-        t.add((tuple(f[idx[c]] for c in CAND), 1 if sum(f) >= 14 else 0))
+        t.add((tuple(f[idx[c]] for c in CAND), 1 if sum(f) >= 27 - RANK else 0))
     return sorted(t)
 
 
@@ -111,10 +139,11 @@ def reduce_network(net, wires, tvecs):
     return ops, kept
 
 
-def anneal(seconds, seed):
+def anneal(seconds, seed, rank=13):
+    set_rank(rank)
     random.seed(seed)
     net, tv = batcher(N), tests()
-    wires = list(range(19)) + [-2] * 6 + [-1] * 7
+    wires = start_wires(rank)
     cur = None
     while cur is None:
         random.shuffle(wires)
@@ -130,11 +159,10 @@ def anneal(seconds, seed):
             cur = ops
             if ops < best[0]:
                 best = (ops, list(wires))
-                print("instructions", ops, flush=True)
         else:
             wires[a], wires[b] = wires[b], wires[a]
         T = max(0.3, T * 0.999)
-    print("WIRES =", best[1])
+    return best
 
 
 def straight_line(kept, wires):
@@ -172,9 +200,9 @@ def run_code(code, result, c):
 def verify(code, result):
     idx = {c: n for n, c in enumerate(CELLS)}
     for f in labelings():
-        assert run_code(code, result, [f[idx[c]] for c in CAND]) == (1 if sum(f) >= 14 else 0)
+        assert run_code(code, result, [f[idx[c]] for c in CAND]) == (1 if sum(f) >= 27 - RANK else 0)
     rng = random.Random(5)
-    for trial in range(20000):
+    for trial in range(4000):
         w = [rng.randint(0, 9) if trial % 2 else rng.random() for _ in range(27)]
         cube = [[[w[(i * 3 + j) * 3 + k] for k in range(3)] for j in range(3)] for i in range(3)]
         for axis in range(3):                      # sort along z, x, y in turn (any order of the axes gives a monotone cube)
@@ -192,53 +220,101 @@ def verify(code, result):
                         col = sorted(cube[u][v][t] for t in range(3))
                         for t in range(3):
                             cube[u][v][t] = col[t]
-        assert run_code(code, result, [cube[i][j][k] for (i, j, k) in CAND]) == sorted(w)[13], trial
+        assert run_code(code, result, [cube[i][j][k] for (i, j, k) in CAND]) == sorted(w)[RANK], trial
 
 
-def emit(path):
-    ops, kept = reduce_network(batcher(N), WIRES, tests())
-    assert ops is not None
-    code, result = straight_line(kept, WIRES)
+WIRES_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank27_wires.json")
+
+
+def load_wires():
+    import json
+    d = json.load(open(WIRES_FILE))
+    return {int(k): v for k, v in d.items()}
+
+
+def network_for(r, wires):
+    set_rank(r)
+    ops, kept = reduce_network(batcher(N), wires, tests())
+    assert ops is not None, r
+    code, result = straight_line(kept, wires)
     assert len(code) == ops
-    verify(code, result)
+    return code, result
+
+
+def emit(path, check=True):
+    placements = load_wires()
     L = []
-    L.append("// median27_net.hpp -- GENERATED by scripts/gen_median27_network.py; do not edit.")
-    L.append("// The 19 positions (i, j, k) of a 3 x 3 x 3 window sorted along its three axes that can hold the median, and the")
-    L.append("// %d-instruction min / max network that takes the median of those 19 (see the generator for the derivation)." % ops)
+    L.append("// median27_net.hpp -- GENERATED by scripts/gen_median27_network.py from scripts/rank27_wires.json; do not edit.")
+    L.append("// Rank27Net<U, R>: the positions (i, j, k) of a 3 x 3 x 3 window sorted along its three axes that can hold the sample of")
+    L.append("// rank R (0 = smallest; 13 = the median), and the min / max network that takes it from those (see the generator).")
     L.append("#pragma once")
     L.append("namespace mi {")
     L.append("")
-    L.append("// up / dn: the nine x-sorted values [i * 3 + j] of the rows above and below in LDS (64 ints apart), q: this row's, in registers")
-    L.append("template <bool U>")
-    L.append("__device__ __forceinline__ void median27_candidates(const int *up, const int (&q)[9], const int *dn, int (&c)[19])")
-    L.append("{")
-    for comp in range(9):
-        ks = [k for (i, j, k) in CAND if i * 3 + j == comp]
+    L.append("template <bool U, int R> struct Rank27Net;")
+    summary = []
+    for r in range(1, 26):
+        code, result = network_for(r, placements[r])
+        if check:
+            verify(code, result)
+        nc = len(CAND)
+        summary.append((r, nc, len(code)))
+        L.append("")
+        L.append("// rank %d: %d candidates (%d positions known below), %d min / max instructions" % (r, nc, NBELOW, len(code)))
+        L.append("template <bool U> struct Rank27Net<U, %d> {" % r)
+        L.append("    static constexpr int NC = %d;" % nc)
+        L.append("    // up / dn: the nine x-sorted values [i * 3 + j] of the rows above and below in LDS (64 ints apart), q: this row's, in registers")
+        L.append("    static __device__ __forceinline__ void candidates(const int *up, const int (&q)[9], const int *dn, int (&c)[NC])")
         L.append("    {")
-        L.append("        const int a = up[%d * 64], b = q[%d], d = dn[%d * 64];" % (comp, comp, comp))
-        for n, (i, j, k) in enumerate(CAND):
-            if i * 3 + j == comp:
-                L.append("        c[%d] = %s<U>(a, b, d);      // (%d, %d, %d)" % (n, ("k_min3", "k_med3", "k_max3")[k], i, j, k))
+        for comp in range(9):
+            if not any(i * 3 + j == comp for (i, j, k) in CAND):
+                continue
+            L.append("        {")
+            L.append("            const int a = up[%d * 64], b = q[%d], d = dn[%d * 64];" % (comp, comp, comp))
+            for n, (i, j, k) in enumerate(CAND):
+                if i * 3 + j == comp:
+                    L.append("            c[%d] = %s<U>(a, b, d);      // (%d, %d, %d)" % (n, ("k_min3", "k_med3", "k_max3")[k], i, j, k))
+            L.append("        }")
         L.append("    }")
-    L.append("}")
-    L.append("")
-    L.append("template <bool U>")
-    L.append("__device__ __forceinline__ int median27_of_candidates(const int (&c)[19])")
-    L.append("{")
-    L.append("    using K = std::conditional_t<U, unsigned, int>;")
-    L.append("    const K " + ", ".join("c%d = (K)c[%d]" % (n, n) for n in range(19)) + ";")
-    for dst, op, a, b in code:
-        L.append("    const K %s = %s %s %s ? %s : %s;" % (dst, a, "<" if op == "min" else ">", b, a, b))
-    L.append("    return (int)%s;" % result)
-    L.append("}")
+        L.append("    static __device__ __forceinline__ int select(const int (&c)[NC])")
+        L.append("    {")
+        L.append("        using K = std::conditional_t<U, unsigned, int>;")
+        L.append("        const K " + ", ".join("c%d = (K)c[%d]" % (n, n) for n in range(nc)) + ";")
+        for dst, op, a, b in code:
+            L.append("        const K %s = %s %s %s ? %s : %s;" % (dst, a, "<" if op == "min" else ">", b, a, b))
+        L.append("        return (int)%s;" % result)
+        L.append("    }")
+        L.append("};")
     L.append("")
     L.append("}  // namespace mi")
     open(path, "w").write("\n".join(L) + "\n")
-    print("wrote", path, "-", ops, "min / max instructions,", len(CAND), "candidates")
+    print("wrote", path)
+    for r, nc, ops in summary:
+        print("  rank %2d: %2d candidates, %3d instructions" % (r, nc, ops))
+
+
+def search_all(seconds, workers):
+    import json
+    from concurrent.futures import ProcessPoolExecutor
+    placements = load_wires() if os.path.exists(WIRES_FILE) else {}
+    jobs = [(seconds, 100 + r, r) for r in range(1, 26)]
+    with ProcessPoolExecutor(workers) as ex:
+        for (secs, seed, r), best in zip(jobs, ex.map(_anneal_job, jobs)):
+            old = None
+            if r in placements:
+                set_rank(r)
+                old, _ = reduce_network(batcher(N), placements[r], tests())
+            if old is None or best[0] < old:
+                placements[r] = best[1]
+            print("rank", r, "instructions", best[0], "(kept %s)" % old if old is not None and old <= best[0] else "", flush=True)
+    json.dump({str(k): v for k, v in sorted(placements.items())}, open(WIRES_FILE, "w"))
+
+
+def _anneal_job(job):
+    return anneal(*job)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--search":
-        anneal(float(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+        search_all(float(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 8)
     else:
         emit(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cupyimg_amd", "csrc", "median27_net.hpp"))

@@ -316,3 +316,44 @@ def test_median_3x3x3_whole_volume_last_of_a_burst(gpu, ndi, lib):
             ndi.median_filter(xd, size=3, output=out)
         assert "median27_stream_kernel" in last_kernel(), last_kernel()
         assert np.array_equal(out.get(), sndi.median_filter(x, size=3)), (shape, dt)
+
+
+def test_every_rank_of_the_3x3x3_window_on_the_shared_sort_kernel(gpu, ndi, lib):
+    """rank_filter / percentile_filter with the full 3 x 3 x 3 footprint: ranks 1 .. 25 each have their own candidate set and
+    searched network (median27_net.hpp: Rank27Net<U, R>); float32 / uint8 / int16 / uint16 take it for every rank, the other
+    32-bit-key dtypes for the median only.  Bit-exact against SciPy; ranks 0 and 26 are minimum / maximum filters."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(272727)
+    for dt in (np.float32, np.uint8, np.int16, np.uint16):
+        for shape in ((23, 31, 70), (5, 64, 130)):
+            x = (rng.standard_normal(shape) * 60 + 100)
+            x = np.clip(x, np.iinfo(dt).min, np.iinfo(dt).max).astype(dt) if np.dtype(dt).kind in "iu" else x.astype(dt)
+            xd = gpu.asarray(x)
+            for rank in range(0, 27):
+                mode = MODES[rank % 5]
+                got = ndi.rank_filter(xd, rank, size=3, mode=mode, cval=5).get()
+                k = last_kernel()
+                if 1 <= rank <= 25:
+                    assert "median27_stream_kernel<%d>" % rank in k, (dt, rank, k)
+                assert np.array_equal(got, sndi.rank_filter(x, rank, size=3, mode=mode, cval=5)), (dt, shape, rank, mode)
+            for pct in (10, 25, 75, 90):
+                got = ndi.percentile_filter(xd, pct, size=3).get()
+                assert "median27_stream_kernel" in last_kernel(), last_kernel()
+                assert np.array_equal(got, sndi.percentile_filter(x, pct, size=3)), (dt, shape, pct)
+            assert np.array_equal(ndi.rank_filter(xd, -5, size=3).get(), sndi.rank_filter(x, -5, size=3))
+    # the other dtypes: the median on this kernel, other ranks on the per-voxel network
+    x = (rng.standard_normal((20, 30, 70)) * 50).astype(np.int32)
+    xd = gpu.asarray(x)
+    got = ndi.rank_filter(xd, 7, size=3).get()
+    assert "rank3_sorted_kernel" in last_kernel(), last_kernel()
+    assert np.array_equal(got, sndi.rank_filter(x, 7, size=3))
+    # NaNs: numpy.sort's order for every rank
+    x = rng.standard_normal((8, 20, 70)).astype(np.float32)
+    x[rng.random(x.shape) < 0.08] = np.nan
+    x[rng.random(x.shape) < 0.05] = -np.inf
+    xd = gpu.asarray(np.tile(x, (4, 1, 1)))
+    for rank in (1, 6, 12, 14, 20, 25):
+        got = ndi.rank_filter(xd, rank, size=3).get()[:7]
+        want = sndi.generic_filter(np.tile(x, (4, 1, 1)).astype(np.float64), lambda w: np.sort(w)[rank], size=3, mode="reflect").astype(np.float32)[:7]
+        assert np.array_equal(got, want, equal_nan=True), rank
