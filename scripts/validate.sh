@@ -23,7 +23,7 @@ timeout 300 python scripts/bench_slab_step.py --ranks 8 --graphs 1 2>/dev/null |
 FUZZ_BIG=1 timeout 260 python scripts/fuzz_vs_scipy.py 200 31337 2>&1 | tail -3 | tee $O/fuzz_big.txt
 timeout 200 python scripts/fuzz_vs_scipy.py 150 2026 2>&1 | tail -3 | tee $O/fuzz_2026.txt
 # r5: the targeted fuzz of the round-5 routes and the tables of the kernels added this round
-timeout 260 python scripts/fuzz_r5.py 200 505 2>&1 | tail -30 | tee $O/fuzz_r5.txt
+timeout 260 python scripts/fuzz_r5.py 200 505 2>&1 | tail -60 | tee $O/fuzz_r5.txt
 timeout 300 python scripts/bench_ragged_rows.py > $O/ragged_rows.txt 2>&1
 timeout 300 python scripts/bench_constant_mode.py > $O/constant_mode.txt 2>&1
 timeout 600 python scripts/probe_median.py > $O/rank_filters.txt 2>&1; tail -4 $O/rank_filters.txt
