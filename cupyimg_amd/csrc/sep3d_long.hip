@@ -1308,6 +1308,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, i
     if (w < 3 || w > 17 || !(w & 1) || wzn < 3 || wzn > 17 || !(wzn & 1)) return MI_ERR_UNSUPPORTED;
     const bool has_const = mx == MI_MODE_CONSTANT || my == MI_MODE_CONSTANT || mz == MI_MODE_CONSTANT;
     if (wzn != w && ((has_const && !(cval == 0.0f && g_long_const0)) || !long_aniso_pair(w, wzn))) return MI_ERR_UNSUPPORTED;
+    if (has_const && w <= 7 && !(cval == 0.0f && g_long_const0)) return MI_ERR_UNSUPPORTED;      // below 9 taps only the zero-fill form runs here (r5); the lean kernel has the fill values
     if ((int64_t)ny * nx * 4 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
     if (t_dry_run) return MI_OK;          // every odd (w, w) in 3 .. 17 and every pair of long_aniso_pair() has an instance
     LongParams p;

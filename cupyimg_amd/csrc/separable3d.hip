@@ -921,7 +921,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     // 322 / 350, 512 x 500 x 512: 160 / 180; 300^3 with 150-float tiles: 46 against 42 -- not taken) and whatever ny is
     const int64_t nxt_l = (nx + 255) / 256;
     const bool tiles_full = nx * 10 >= nxt_l * 256 * 7;
-    const bool long_small = !any_const && w[0] >= 3 && w[0] <= 7 && nx >= 128 && ny >= 16 &&
+    const bool long_small = (!any_const || (float)cval == 0.0f) && w[0] >= 3 && w[0] <= 7 && nx >= 128 && ny >= 16 &&      // r5: `constant` with a zero fill value is a mode like the others for that kernel
                             (w[0] == 7 ? nvox_out >= ((int64_t)1 << 22)
                                        : nvox_out >= ((int64_t)1 << 23) && (tiles_full || nx == 128));
     if (cubic_w && !ragged && g_sep3d_long != 1 && nx >= 16 &&

@@ -15,6 +15,9 @@ xd = ca.asarray(x); out = ca.empty(x.shape, np.float32)
 for name, fn in (("gaussian_filter sigma 2 (17 taps)", lambda m, **kw: ndi.gaussian_filter(xd, 2.0, mode=m, output=out, **kw)),
                  ("gaussian_filter sigma 1.5 (13 taps)", lambda m, **kw: ndi.gaussian_filter(xd, 1.5, mode=m, output=out, **kw)),
                  ("uniform_filter 9", lambda m, **kw: ndi.uniform_filter(xd, 9, mode=m, output=out, **kw)),
+                 ("uniform_filter 5", lambda m, **kw: ndi.uniform_filter(xd, 5, mode=m, output=out, **kw)),
+                 ("uniform_filter 3", lambda m, **kw: ndi.uniform_filter(xd, 3, mode=m, output=out, **kw)),
+                 ("gaussian_filter sigma 0.75 (7 taps)", lambda m, **kw: ndi.gaussian_filter(xd, 0.75, mode=m, output=out, **kw)),
                  ("gaussian_filter sigma (1, 2, 2) (9 / 17 / 17 taps)", lambda m, **kw: ndi.gaussian_filter(xd, (1.0, 2.0, 2.0), mode=m, output=out, **kw))):
     row = {"call": name}
     t, _ = timeit(lambda: fn("reflect"), 20); row["reflect us"] = round(t * 1e6, 1)

@@ -357,3 +357,29 @@ def test_every_rank_of_the_3x3x3_window_on_the_shared_sort_kernel(gpu, ndi, lib)
         got = ndi.rank_filter(xd, rank, size=3).get()[:7]
         want = sndi.generic_filter(np.tile(x, (4, 1, 1)).astype(np.float64), lambda w: np.sort(w)[rank], size=3, mode="reflect").astype(np.float32)[:7]
         assert np.array_equal(got, want, equal_nan=True), rank
+
+
+def test_constant_zero_fill_below_nine_taps_on_large_volumes(gpu, ndi, lib):
+    """3 / 5 / 7 taps, mode="constant", cval=0 on volumes large enough for the LDS-DMA kernel: the same kernel as the other
+    modes; a fill value keeps the lean kernel.  Against SciPy, every plane."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    x = np.random.default_rng(55).standard_normal((160, 256, 256)).astype(np.float32)
+    xd = gpu.asarray(x)
+    x64 = x.astype(np.float64)
+    for size in (3, 5, 7):
+        got = ndi.uniform_filter(xd, size, mode="constant").get()
+        assert "sep3d_long3_kernel<%d," % size in last_kernel() and "zero fill" in last_kernel(), last_kernel()
+        ref = sndi.uniform_filter(x64, size, mode="constant")
+        err = np.abs(got - ref).reshape(160, -1).max(axis=1)
+        assert err.max() <= 1e-6 * np.abs(ref).max(), (size, int(err.argmax()))
+        got = ndi.uniform_filter(xd, size, mode="constant", cval=2.0).get()
+        assert "sep3d_lean_kernel" in last_kernel(), last_kernel()
+        assert np.abs(got - sndi.uniform_filter(x64, size, mode="constant", cval=2.0)).max() <= 1e-6 * 4
+    lib.mi_debug_set_long_const0(0)
+    try:
+        got = ndi.uniform_filter(xd, 5, mode="constant").get()
+        assert "sep3d_lean_kernel" in last_kernel(), last_kernel()
+    finally:
+        lib.mi_debug_set_long_const0(1)
+    assert np.abs(got - sndi.uniform_filter(x64, 5, mode="constant")).max() <= 1e-6 * 4
