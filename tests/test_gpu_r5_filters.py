@@ -383,3 +383,30 @@ def test_constant_zero_fill_below_nine_taps_on_large_volumes(gpu, ndi, lib):
     finally:
         lib.mi_debug_set_long_const0(1)
     assert np.abs(got - sndi.uniform_filter(x64, 5, mode="constant")).max() <= 1e-6 * 4
+
+
+@pytest.mark.parametrize("size,mode,cval", [(3, "reflect", 0.0), (5, "constant", 0.5), (5, "wrap", 0.0), (7, "mirror", 0.0), (7, "constant", 0.0)])
+def test_ragged_rows_plane_restricted_launches_tile_the_full_result(gpu, ndi, lib, size, mode, cval):
+    """the slab path (output planes given by the caller: distributed.SlabFilter) on rows that are not a multiple of four
+    floats: the 3 / 5 / 7-tap kernel takes them as they are, plane ranges included"""
+    from cupyimg_amd import last_kernel
+    from cupyimg_amd.scipy.ndimage import _support as S
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((70, 45, 301)).astype(np.float32)
+    xd = gpu.asarray(x)
+    full = ndi.uniform_filter(xd, size, mode=mode, cval=cval).get()
+    assert "ragged" in last_kernel(), last_kernel()
+    sentinel = np.float32(-12345.0)
+    out = gpu.asarray(np.full(x.shape, sentinel, np.float32))
+    with S.output_planes([(4, 31)]):
+        ndi.uniform_filter(xd, size, mode=mode, cval=cval, output=out)
+    assert "ragged" in last_kernel(), last_kernel()
+    got = out.get()
+    assert np.array_equal(got[4:31], full[4:31])
+    assert np.all(got[:4] == sentinel) and np.all(got[31:] == sentinel)     # nothing else written
+    with S.output_planes([(0, 4), (31, 70)]):
+        ndi.uniform_filter(xd, size, mode=mode, cval=cval, output=out)
+    assert np.array_equal(out.get(), full)
+    with S.output_planes([(0, 0), (69, 70)]):                               # empty + one plane
+        ndi.uniform_filter(xd, size, mode=mode, cval=cval, output=out)
+    assert np.array_equal(out.get(), full)
