@@ -34,44 +34,80 @@ struct Med27Params {
 
 constexpr int kM27Rows = 16, kM27OutRows = kM27Rows - 2, kM27OutCols = 62;
 
-template <bool U> __device__ __forceinline__ int k_min3(int a, int b, int c)
-{
-    int r;
-    if constexpr (U) asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    else asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-template <bool U> __device__ __forceinline__ int k_med3(int a, int b, int c)
-{
-    int r;
-    if constexpr (U) asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    else asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-template <bool U> __device__ __forceinline__ int k_max3(int a, int b, int c)
-{
-    int r;
-    if constexpr (U) asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    else asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// key operations of the kernel: 32-bit integer keys (RankKey of rank_sorted.hpp: every dtype but float64; U: compared unsigned)
+template <bool U>
+struct KeyOps32 {
+    using K = int;
+    static __device__ __forceinline__ int min3(int a, int b, int c)
+    {
+        int r;
+        if constexpr (U) asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        else asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    }
+    static __device__ __forceinline__ int med3(int a, int b, int c)
+    {
+        int r;
+        if constexpr (U) asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        else asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    }
+    static __device__ __forceinline__ int max3(int a, int b, int c)
+    {
+        int r;
+        if constexpr (U) asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        else asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    }
+    using C = std::conditional_t<U, unsigned, int>;
+    static __device__ __forceinline__ int mn(int a, int b) { return (C)a < (C)b ? a : b; }
+    static __device__ __forceinline__ int mx(int a, int b) { return (C)a > (C)b ? a : b; }
+    static __device__ __forceinline__ int left(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+    static __device__ __forceinline__ int right(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+};
+// float64: the values themselves with v_min_f64 / v_max_f64 (IEEE minNum / maxNum: a NaN in the window is passed over -- there
+// are no 64-bit integer min / max instructions for an order-preserving key as float32 has); the three order statistics of a
+// triple share their first two instructions (common subexpressions): 6 for all three
+struct KeyOps64 {
+    using K = double;
+    static __device__ __forceinline__ double mn(double a, double b) { return __builtin_fmin(a, b); }
+    static __device__ __forceinline__ double mx(double a, double b) { return __builtin_fmax(a, b); }
+    static __device__ __forceinline__ double min3(double a, double b, double c) { return mn(mn(a, b), c); }
+    static __device__ __forceinline__ double max3(double a, double b, double c) { return mx(mx(a, b), c); }
+    static __device__ __forceinline__ double med3(double a, double b, double c) { return mx(mn(a, b), mn(mx(a, b), c)); }
+    static __device__ __forceinline__ double shift(double v, bool to_right)
+    {
+        const long long b = __builtin_bit_cast(long long, v);
+        int lo = (int)b, hi = (int)(b >> 32);
+        if (to_right) {
+            lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+            hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+        } else {
+            lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+            hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+        }
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    }
+    static __device__ __forceinline__ double left(double v) { return shift(v, false); }
+    static __device__ __forceinline__ double right(double v) { return shift(v, true); }
+};
+template <typename T>
+using KeyOpsFor = std::conditional_t<std::is_same<T, double>::value, KeyOps64, KeyOps32<std::is_same<T, uint32_t>::value>>;
 
 }  // namespace mi
 #include "median27_net.hpp"
 namespace mi {
 
-__device__ __forceinline__ int lane_left(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
-__device__ __forceinline__ int lane_right(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
-
 template <typename T, int R>
 __global__ void __launch_bounds__(kM27Rows * 64)
 median27_stream_kernel(const T *__restrict__ in, T *__restrict__ out, const Med27Params p)
 {
-    using Net = Rank27Net<std::is_same<T, uint32_t>::value, R>;
+    using KO = KeyOpsFor<T>;
+    using K = typename KO::K;
+    using Net = Rank27Net<KO, R>;
     using RK = RankKey<T>;
-    constexpr bool U = std::is_same<T, uint32_t>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *lds = reinterpret_cast<int *>(smem);                  // [2][rows][9][64]
+    K *lds = reinterpret_cast<K *>(smem);                      // [2][rows][9][64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -89,11 +125,11 @@ median27_stream_kernel(const T *__restrict__ in, T *__restrict__ out, const Med2
     const bool have = xsrc >= 0 && ysrc >= 0;
     const unsigned off = have ? (unsigned)(ysrc * nx + xsrc) * (unsigned)sizeof(T) : kOOB;
     const bool is_out = lane >= 1 && lane <= kM27OutCols && wave >= 1 && wave <= kM27OutRows && x < nx && y < ny;
-    const int ckey = (int)RK::key((T)p.cval);
+    const K ckey = (K)RK::key((T)p.cval);
     const size_t plane_elems = (size_t)ny * (size_t)nx;
     const unsigned plane_bytes = (unsigned)(plane_elems * sizeof(T));
 
-    auto fetch = [&](int s) -> int {
+    auto fetch = [&](int s) -> K {
         // the sample of this thread's column in the plane of step s, as a key
         int zsrc = zs - 1 + s;
         if ((unsigned)zsrc >= (unsigned)nz) zsrc = bmap<int>(zsrc, nz, p.mz);         // the first and the last plane only: the index map's divisions are scalar code every wave would run every step
@@ -101,32 +137,32 @@ median27_stream_kernel(const T *__restrict__ in, T *__restrict__ out, const Med2
         const __amdgpu_buffer_rsrc_t rin =
             __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)zz * plane_elems), 0, (int)plane_bytes, 0x00020000);
         const T v = buf_load<T>(rin, zsrc >= 0 ? off : kOOB);
-        return (have && zsrc >= 0) ? (int)RK::key(v) : ckey;
+        return (have && zsrc >= 0) ? (K)RK::key(v) : ckey;
     };
 
     const int nsteps = ze - zs + 2;
-    int k0 = 0, k1 = fetch(0), k2 = fetch(1);
-    int nxt = nsteps > 2 ? fetch(2) : 0;
-    int *wr = lds + (wave * 9) * 64 + lane;
+    K k0 = 0, k1 = fetch(0), k2 = fetch(1);
+    K nxt = nsteps > 2 ? fetch(2) : (K)0;
+    K *wr = lds + (wave * 9) * 64 + lane;
     for (int s = 2; s < nsteps; s++) {
         k0 = k1; k1 = k2; k2 = nxt;
         if (s + 1 < nsteps) nxt = fetch(s + 1);
         // z
-        const int L = k_min3<U>(k0, k1, k2), M = k_med3<U>(k0, k1, k2), H = k_max3<U>(k0, k1, k2);
+        const K L = KO::min3(k0, k1, k2), M = KO::med3(k0, k1, k2), H = KO::max3(k0, k1, k2);
         // x: Q[i][j] = the j-th along x of the i-th along z
-        const int Ll = lane_left(L), Lr = lane_right(L), Ml = lane_left(M), Mr = lane_right(M), Hl = lane_left(H), Hr = lane_right(H);
-        int *w = wr + (s & 1) * (kM27Rows * 9 * 64);
-        const int q[9] = {k_min3<U>(Ll, L, Lr), k_med3<U>(Ll, L, Lr), k_max3<U>(Ll, L, Lr),
-                          k_min3<U>(Ml, M, Mr), k_med3<U>(Ml, M, Mr), k_max3<U>(Ml, M, Mr),
-                          k_min3<U>(Hl, H, Hr), k_med3<U>(Hl, H, Hr), k_max3<U>(Hl, H, Hr)};
+        const K Ll = KO::left(L), Lr = KO::right(L), Ml = KO::left(M), Mr = KO::right(M), Hl = KO::left(H), Hr = KO::right(H);
+        K *w = wr + (s & 1) * (kM27Rows * 9 * 64);
+        const K q[9] = {KO::min3(Ll, L, Lr), KO::med3(Ll, L, Lr), KO::max3(Ll, L, Lr),
+                        KO::min3(Ml, M, Mr), KO::med3(Ml, M, Mr), KO::max3(Ml, M, Mr),
+                        KO::min3(Hl, H, Hr), KO::med3(Hl, H, Hr), KO::max3(Hl, H, Hr)};
 #pragma unroll
         for (int t = 0; t < 9; t++) w[t * 64] = q[t];
         __syncthreads();
         if (wave >= 1 && wave <= kM27OutRows) {
-            int c[Net::NC];
+            K c[Net::NC];
             // the candidates (i, j, k) of rank R: i = rank along z, j along x, k along y; the rows above and below: -+ 9 * 64 ints
             Net::candidates(w - 9 * 64, q, w + 9 * 64, c);
-            const int med = Net::select(c);
+            const K med = Net::select(c);
             if (is_out) out[(size_t)(zs + s - 2) * plane_elems + (size_t)(y * nx + x)] = RK::value((typename RK::K)med);
         }
     }
@@ -144,7 +180,7 @@ static int launch_median27(const T *in, T *out, int nz, int ny, int nx, int mx, 
     int nzc = (int)std::min<int64_t>(std::max<int64_t>(1, (2 * (int64_t)device_cus() + tiles - 1) / tiles), std::max(1, nz / 8));
     p.zc = (nz + nzc - 1) / nzc;
     p.nzc = (nz + p.zc - 1) / p.zc;
-    const size_t lds = (size_t)2 * kM27Rows * 9 * 64 * sizeof(int);
+    const size_t lds = (size_t)2 * kM27Rows * 9 * 64 * sizeof(typename KeyOpsFor<T>::K);
     static PerDeviceOnce attr_done;
     if (!attr_done) {
         MI_HIP(hipFuncSetAttribute((const void *)median27_stream_kernel<T, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

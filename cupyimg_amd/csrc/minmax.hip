@@ -441,8 +441,8 @@ int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footp
             if (tt3.ntaps <= (key32 ? 128 : 64) && out->dtype == in->dtype && g_rank_sorted) {
                 const T *ip = (const T *)in->data;
                 T *op = (T *)out->data;
-                if constexpr (key32) {
-                    // r5: the median of the full 3 x 3 x 3 window of a volume -- the kernel that shares its sorting between windows
+                {
+                    // r5: the ranks of the full 3 x 3 x 3 window of a volume -- the kernel that shares its sorting between windows
                     if (tt3.ntaps == 27 && t3.g.wz == 3 && t3.g.wy == 3 && t3.g.wx == 3 && t3.g.oz == 1 && t3.g.oy == 1 && t3.g.ox == 1) {
                         const int r27 = run_rank27<T>(ip, op, t3.g.nz, t3.g.ny, t3.g.nx, mode, cv, rank, s);
                         if (r27 != MI_ERR_UNSUPPORTED) return r27;

@@ -245,12 +245,13 @@ def emit(path, check=True):
     placements = load_wires()
     L = []
     L.append("// median27_net.hpp -- GENERATED by scripts/gen_median27_network.py from scripts/rank27_wires.json; do not edit.")
-    L.append("// Rank27Net<U, R>: the positions (i, j, k) of a 3 x 3 x 3 window sorted along its three axes that can hold the sample of")
+    L.append("// Rank27Net<KO, R>: the positions (i, j, k) of a 3 x 3 x 3 window sorted along its three axes that can hold the sample of")
     L.append("// rank R (0 = smallest; 13 = the median), and the min / max network that takes it from those (see the generator).")
+    L.append("// KO: the key operations (median3d_impl.hpp): KO::K, KO::min3 / med3 / max3 (a, b, c), KO::mn / mx (a, b).")
     L.append("#pragma once")
     L.append("namespace mi {")
     L.append("")
-    L.append("template <bool U, int R> struct Rank27Net;")
+    L.append("template <class KO, int R> struct Rank27Net;")
     summary = []
     for r in range(1, 26):
         code, result = network_for(r, placements[r])
@@ -260,28 +261,28 @@ def emit(path, check=True):
         summary.append((r, nc, len(code)))
         L.append("")
         L.append("// rank %d: %d candidates (%d positions known below), %d min / max instructions" % (r, nc, NBELOW, len(code)))
-        L.append("template <bool U> struct Rank27Net<U, %d> {" % r)
+        L.append("template <class KO> struct Rank27Net<KO, %d> {" % r)
+        L.append("    using K = typename KO::K;")
         L.append("    static constexpr int NC = %d;" % nc)
-        L.append("    // up / dn: the nine x-sorted values [i * 3 + j] of the rows above and below in LDS (64 ints apart), q: this row's, in registers")
-        L.append("    static __device__ __forceinline__ void candidates(const int *up, const int (&q)[9], const int *dn, int (&c)[NC])")
+        L.append("    // up / dn: the nine x-sorted values [i * 3 + j] of the rows above and below in LDS (64 keys apart), q: this row's, in registers")
+        L.append("    static __device__ __forceinline__ void candidates(const K *up, const K (&q)[9], const K *dn, K (&c)[NC])")
         L.append("    {")
         for comp in range(9):
             if not any(i * 3 + j == comp for (i, j, k) in CAND):
                 continue
             L.append("        {")
-            L.append("            const int a = up[%d * 64], b = q[%d], d = dn[%d * 64];" % (comp, comp, comp))
+            L.append("            const K a = up[%d * 64], b = q[%d], d = dn[%d * 64];" % (comp, comp, comp))
             for n, (i, j, k) in enumerate(CAND):
                 if i * 3 + j == comp:
-                    L.append("            c[%d] = %s<U>(a, b, d);      // (%d, %d, %d)" % (n, ("k_min3", "k_med3", "k_max3")[k], i, j, k))
+                    L.append("            c[%d] = KO::%s(a, b, d);      // (%d, %d, %d)" % (n, ("min3", "med3", "max3")[k], i, j, k))
             L.append("        }")
         L.append("    }")
-        L.append("    static __device__ __forceinline__ int select(const int (&c)[NC])")
+        L.append("    static __device__ __forceinline__ K select(const K (&c)[NC])")
         L.append("    {")
-        L.append("        using K = std::conditional_t<U, unsigned, int>;")
-        L.append("        const K " + ", ".join("c%d = (K)c[%d]" % (n, n) for n in range(nc)) + ";")
+        L.append("        const K " + ", ".join("c%d = c[%d]" % (n, n) for n in range(nc)) + ";")
         for dst, op, a, b in code:
-            L.append("        const K %s = %s %s %s ? %s : %s;" % (dst, a, "<" if op == "min" else ">", b, a, b))
-        L.append("        return (int)%s;" % result)
+            L.append("        const K %s = KO::%s(%s, %s);" % (dst, "mn" if op == "min" else "mx", a, b))
+        L.append("        return %s;" % result)
         L.append("    }")
         L.append("};")
     L.append("")

@@ -262,8 +262,8 @@ def test_median_3x3x3_shared_sort_kernel(gpu, ndi, lib):
     from cupyimg_amd import last_kernel
     rng = np.random.default_rng(2727)
     shapes = [(40, 33, 70), (9, 200, 129), (130, 30, 62), (17, 15, 63), (33, 29, 64), (2, 128, 128), (64, 14, 125), (70, 16, 126)]
-    for dt in (np.float32, np.uint8, np.int8, np.uint16, np.int16, np.int32, np.uint32):
-        for shape in shapes if dt in (np.float32, np.uint8) else shapes[:3]:
+    for dt in (np.float32, np.uint8, np.int8, np.uint16, np.int16, np.int32, np.uint32, np.float64):
+        for shape in shapes if dt in (np.float32, np.uint8, np.float64) else shapes[:3]:
             x = rng.standard_normal(shape) * 60 + 100
             x = np.clip(x, np.iinfo(dt).min, np.iinfo(dt).max).astype(dt) if np.dtype(dt).kind in "iu" else x.astype(dt)
             if dt == np.uint32:
@@ -308,7 +308,7 @@ def test_median_3x3x3_whole_volume_last_of_a_burst(gpu, ndi, lib):
     import scipy.ndimage as sndi
     from cupyimg_amd import last_kernel
     rng = np.random.default_rng(14)
-    for shape, dt in (((256, 256, 256), np.float32), ((181, 217, 181), np.uint8)):
+    for shape, dt in (((256, 256, 256), np.float32), ((181, 217, 181), np.uint8), ((150, 200, 250), np.float64)):
         x = (rng.standard_normal(shape) * 50 + 100).astype(dt)
         xd = gpu.asarray(x)
         out = gpu.empty(shape, dt)
@@ -320,12 +320,12 @@ def test_median_3x3x3_whole_volume_last_of_a_burst(gpu, ndi, lib):
 
 def test_every_rank_of_the_3x3x3_window_on_the_shared_sort_kernel(gpu, ndi, lib):
     """rank_filter / percentile_filter with the full 3 x 3 x 3 footprint: ranks 1 .. 25 each have their own candidate set and
-    searched network (median27_net.hpp: Rank27Net<U, R>); float32 / uint8 / int16 / uint16 take it for every rank, the other
-    32-bit-key dtypes for the median only.  Bit-exact against SciPy; ranks 0 and 26 are minimum / maximum filters."""
+    searched network (median27_net.hpp: Rank27Net<KO, R>); float32 / float64 / uint8 / int16 / uint16 take it for every rank, the
+    other dtypes with 32-bit keys for the median only.  Bit-exact against SciPy; ranks 0 and 26 are minimum / maximum filters."""
     import scipy.ndimage as sndi
     from cupyimg_amd import last_kernel
     rng = np.random.default_rng(272727)
-    for dt in (np.float32, np.uint8, np.int16, np.uint16):
+    for dt in (np.float32, np.uint8, np.int16, np.uint16, np.float64):
         for shape in ((23, 31, 70), (5, 64, 130)):
             x = (rng.standard_normal(shape) * 60 + 100)
             x = np.clip(x, np.iinfo(dt).min, np.iinfo(dt).max).astype(dt) if np.dtype(dt).kind in "iu" else x.astype(dt)
@@ -348,6 +348,12 @@ def test_every_rank_of_the_3x3x3_window_on_the_shared_sort_kernel(gpu, ndi, lib)
     got = ndi.rank_filter(xd, 7, size=3).get()
     assert "rank3_sorted_kernel" in last_kernel(), last_kernel()
     assert np.array_equal(got, sndi.rank_filter(x, 7, size=3))
+    # float64: infinities sort like any value (NaNs are passed over by v_min_f64 / v_max_f64: no contract)
+    x = rng.standard_normal((9, 20, 70))
+    x[rng.random(x.shape) < 0.06] = np.inf
+    x[rng.random(x.shape) < 0.06] = -np.inf
+    for rank in (3, 13, 22):
+        assert np.array_equal(ndi.rank_filter(gpu.asarray(x), rank, size=3).get(), sndi.rank_filter(x, rank, size=3)), rank
     # NaNs: numpy.sort's order for every rank
     x = rng.standard_normal((8, 20, 70)).astype(np.float32)
     x[rng.random(x.shape) < 0.08] = np.nan
