@@ -297,17 +297,19 @@ def build(force=False, jobs=None, verbose=True, strict=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(force, jobs, verbose, strict=False):
-    present = [(s, f) for s, f in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    missing = [s for s, _ in SOURCES if not os.path.exists(os.path.join(CSRC, s))]
-    if missing:
-        raise RuntimeError("missing kernel sources: {}".format(missing))
-    hdr = _deps_mtime()
-    jobs = jobs or min(8, os.cpu_count() or 1)
-    LIB = LIB_STRICT if strict else globals()["LIB"]
-    with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
-        results = list(ex.map(_compile, [(s, f, force, hdr, strict and s in STRICT_SOURCES) for s, f in present]))
-    objs = [o for o, _ in results]
+# sources that take minutes each: compiled first, so that a from-scratch build does not end on one of them alone
+_HEAVY = ("rank_sorted_p128", "sep3d_long", "interp.hip", "cubic_fast", "interp_fast", "rank_sorted_p64", "minmax3d", "separable3d", "rank_sorted_p32",
+          "median3d")
+
+
+def _weight(src):
+    for n, frag in enumerate(_HEAVY):
+        if frag in src:
+            return n
+    return len(_HEAVY)
+
+
+def _link(LIB, objs, results, verbose):
     rebuilt = any(r for _, r in results) or (os.path.exists(LIB) and any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs))
     if rebuilt or not os.path.exists(LIB):
         tmp = "{}.{}.tmp".format(LIB, os.getpid())
@@ -324,6 +326,39 @@ def _build_locked(force, jobs, verbose, strict=False):
     elif verbose:
         print("up to date:", LIB)
     return LIB
+
+
+def _build_locked(force, jobs, verbose, strict=False):
+    """strict: False = the product library, True = the strict twin, "both" = both from ONE pool of compile jobs (the twin's five
+    objects start while the product's long compilations still run: what __graft_entry__.build() uses)"""
+    present = [(s, f) for s, f in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    missing = [s for s, _ in SOURCES if not os.path.exists(os.path.join(CSRC, s))]
+    if missing:
+        raise RuntimeError("missing kernel sources: {}".format(missing))
+    hdr = _deps_mtime()
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    want_product = strict in (False, "both")
+    want_strict = strict in (True, "both")
+    tasks = [(s, f, force, hdr, False) for s, f in present]            # the twin links the product's objects for everything else
+    if want_strict:
+        tasks += [(s, f, force, hdr, True) for s, f in present if s in STRICT_SOURCES]
+    order = sorted(range(len(tasks)), key=lambda i: (_weight(tasks[i][0]), i))
+    with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
+        done = list(ex.map(_compile, [tasks[i] for i in order]))
+    results = [None] * len(tasks)
+    for i, r in zip(order, done):
+        results[i] = r
+    plain = {tasks[i][0]: results[i] for i in range(len(present))}
+    twin = {tasks[i][0]: results[i] for i in range(len(present), len(tasks))}
+    lib = None
+    if want_product:
+        res = [plain[s] for s, _ in present]
+        lib = _link(globals()["LIB"], [o for o, _ in res], res, verbose)
+    if want_strict:
+        res = [twin.get(s, plain[s]) for s, _ in present]
+        lib_s = _link(LIB_STRICT, [o for o, _ in res], res, verbose)
+        lib = lib if want_product else lib_s
+    return lib
 
 
 if __name__ == "__main__":
