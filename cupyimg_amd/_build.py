@@ -44,6 +44,7 @@ SOURCES = [
     ("median3d.hip", []),
     ("median3d_u8.hip", []),
     ("median3d_16.hip", []),
+    ("median3d_i.hip", []),
     ("median3d_f64.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p16.hip", ["-ffp-contract=off"]),
     ("rank_sorted_med.hip", ["-ffp-contract=off"]),

@@ -320,8 +320,7 @@ def test_median_3x3x3_whole_volume_last_of_a_burst(gpu, ndi, lib):
 
 def test_every_rank_of_the_3x3x3_window_on_the_shared_sort_kernel(gpu, ndi, lib):
     """rank_filter / percentile_filter with the full 3 x 3 x 3 footprint: ranks 1 .. 25 each have their own candidate set and
-    searched network (median27_net.hpp: Rank27Net<KO, R>); float32 / float64 / uint8 / int16 / uint16 take it for every rank, the
-    other dtypes with 32-bit keys for the median only.  Bit-exact against SciPy; ranks 0 and 26 are minimum / maximum filters."""
+    searched network (median27_net.hpp: Rank27Net<KO, R>); every dtype with 32-bit keys and float64 take it for every rank.  Bit-exact against SciPy; ranks 0 and 26 are minimum / maximum filters."""
     import scipy.ndimage as sndi
     from cupyimg_amd import last_kernel
     rng = np.random.default_rng(272727)
@@ -342,12 +341,14 @@ def test_every_rank_of_the_3x3x3_window_on_the_shared_sort_kernel(gpu, ndi, lib)
                 assert "median27_stream_kernel" in last_kernel(), last_kernel()
                 assert np.array_equal(got, sndi.percentile_filter(x, pct, size=3)), (dt, shape, pct)
             assert np.array_equal(ndi.rank_filter(xd, -5, size=3).get(), sndi.rank_filter(x, -5, size=3))
-    # the other dtypes: the median on this kernel, other ranks on the per-voxel network
-    x = (rng.standard_normal((20, 30, 70)) * 50).astype(np.int32)
-    xd = gpu.asarray(x)
-    got = ndi.rank_filter(xd, 7, size=3).get()
-    assert "rank3_sorted_kernel" in last_kernel(), last_kernel()
-    assert np.array_equal(got, sndi.rank_filter(x, 7, size=3))
+    # the remaining dtypes with 32-bit keys (uint32 beyond 2^31: compared unsigned)
+    for dt, scale in ((np.int8, 1), (np.int32, 20000000), (np.uint32, 30000000)):
+        x = np.clip(rng.standard_normal((20, 30, 70)) * 40 + 60, 0 if dt == np.uint32 else -100, 120).astype(dt) * dt(scale)
+        xd = gpu.asarray(x)
+        for rank in (2, 7, 13, 19, 24):
+            got = ndi.rank_filter(xd, rank, size=3, mode="mirror").get()
+            assert "median27_stream_kernel<%d>" % rank in last_kernel(), last_kernel()
+            assert np.array_equal(got, sndi.rank_filter(x, rank, size=3, mode="mirror")), (dt, rank)
     # float64: infinities sort like any value (NaNs are passed over by v_min_f64 / v_max_f64: no contract)
     x = rng.standard_normal((9, 20, 70))
     x[rng.random(x.shape) < 0.06] = np.inf
