@@ -468,14 +468,14 @@ int mi_min_max(const mi_array *a, double *lo, double *hi, mi_stream stream)
 }
 
 /* out[..., x] = in[..., map(x - left)] for x in [0, out.shape[-1]): rows extended along the last axis by the boundary mode
- * (filter semantics, include/mi355img.h mi_mode; MI_MODE_CONSTANT fills with cval).  1-, 2- and 4-byte dtypes, in and out
+ * (filter semantics, include/mi355img.h mi_mode; MI_MODE_CONSTANT fills with cval).  1-, 2-, 4- and 8-byte dtypes, in and out
  * of one dtype, C-contiguous, same leading shape; the output rows and `left` multiples of 16 bytes, out 16-byte aligned. */
 static int rows_common(const char *who, const mi_array *wide, const mi_array *narrow, int left, int64_t *rows, int *esize)
 {
 #define ROWS_REQUIRE(cond, code, msg) do { if (!(cond)) { set_error("%s: %s", who, msg); return (code); } } while (0)
     ROWS_REQUIRE(wide->dtype == narrow->dtype && wide->ndim == narrow->ndim && wide->ndim >= 1, MI_ERR_INVALID_ARG, "arrays of one dtype and rank");
     const int es = (int)dtype_size(wide->dtype);
-    ROWS_REQUIRE(es == 1 || es == 2 || es == 4, MI_ERR_UNSUPPORTED, "1-, 2- and 4-byte dtypes");
+    ROWS_REQUIRE(es == 1 || es == 2 || es == 4 || es == 8, MI_ERR_UNSUPPORTED, "1-, 2-, 4- and 8-byte dtypes");
     ROWS_REQUIRE(is_contiguous(wide) && is_contiguous(narrow), MI_ERR_NOT_CONTIGUOUS, "C-contiguous arrays");
     const int nd = wide->ndim, v = 16 / es;
     *rows = 1;
@@ -505,7 +505,14 @@ int mi_extend_rows(const mi_array *in, const mi_array *out, int left, int mode, 
     grid_for(rows * (total / (16 / es)), 256, &grid);
     hipStream_t s = resolve_stream(stream);
     const int m = filter_mode(mode);
-    if (es == 4) {
+    if (es == 8) {
+        // r5: float64 / 64-bit integers (rows of an odd number of doubles: 181 x 217 x 181 as nibabel's get_fdata() hands it out)
+        unsigned long long bits;
+        if (in->dtype == MI_F64) memcpy(&bits, &cval, 8);
+        else bits = (unsigned long long)(int64_t)cval;
+        hipLaunchKernelGGL(extend_rows_kernel<unsigned long long>, grid, dim3(256), 0, s, (const unsigned long long *)in->data, (unsigned long long *)out->data, rows, nx,
+                           total, left, m, bits);
+    } else if (es == 4) {
         // the fill value in the array's own 4-byte dtype
         unsigned bits;
         if (in->dtype == MI_F32) { const float f = (float)cval; memcpy(&bits, &f, 4); }
@@ -536,7 +543,8 @@ int mi_crop_rows(const mi_array *in, const mi_array *out, int left, mi_stream st
     dim3 grid;
     grid_for(rows * ((nx + v - 1) / v), 256, &grid);
     hipStream_t s = resolve_stream(stream);
-    if (es == 4) hipLaunchKernelGGL(crop_rows_kernel<unsigned>, grid, dim3(256), 0, s, (const unsigned *)in->data, (unsigned *)out->data, rows, nx, total, left);
+    if (es == 8) hipLaunchKernelGGL(crop_rows_kernel<unsigned long long>, grid, dim3(256), 0, s, (const unsigned long long *)in->data, (unsigned long long *)out->data, rows, nx, total, left);
+    else if (es == 4) hipLaunchKernelGGL(crop_rows_kernel<unsigned>, grid, dim3(256), 0, s, (const unsigned *)in->data, (unsigned *)out->data, rows, nx, total, left);
     else if (es == 2) hipLaunchKernelGGL(crop_rows_kernel<unsigned short>, grid, dim3(256), 0, s, (const unsigned short *)in->data, (unsigned short *)out->data, rows, nx, total, left);
     else hipLaunchKernelGGL(crop_rows_kernel<unsigned char>, grid, dim3(256), 0, s, (const unsigned char *)in->data, (unsigned char *)out->data, rows, nx, total, left);
     MI_HIP(hipGetLastError());

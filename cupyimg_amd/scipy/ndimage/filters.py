@@ -276,7 +276,7 @@ def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_c
         key = (key, str(input.dtype), str(output.dtype), tuple(input.shape), left, right, mode_x)
         if key in _EXT_REFUSED:
             return None
-    if left < 0 or right < 0 or input.size < (1 << 15) or input.dtype.itemsize not in (1, 2, 4) or output.dtype.itemsize not in (1, 2, 4):
+    if left < 0 or right < 0 or input.size < (1 << 15) or input.dtype.itemsize not in (1, 2, 4, 8) or output.dtype.itemsize not in (1, 2, 4, 8):
         return None
     if exact_cval and mode_x in ("constant", "grid-constant"):
         # the fill value is written into the extended rows in the ARRAY's dtype; the bit-exact kernels (like SciPy) use cval
@@ -290,7 +290,7 @@ def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_c
         elif input.dtype == np.float32:
             if not (np.isnan(cv) or float(np.float32(cv)) == cv):
                 return None
-        else:
+        elif input.dtype != np.float64:
             return None
     v = 16 // min(input.dtype.itemsize, output.dtype.itemsize)      # rows of both arrays become multiples of 16 bytes
     nx = input.shape[-1]
@@ -340,8 +340,17 @@ def _fused_3d_f64(input, output, weights, origins, modes, cval):
     for w in weights:
         if w is not None and (len(w) > 33 or len(w) % 2 == 0):
             return None
-    if (weights[2] is not None and origins[2] != 0) or input.shape[2] < 4 or input.shape[2] % 2:
+    if (weights[2] is not None and origins[2] != 0) or input.shape[2] < 4:
         return None
+    if input.shape[2] % 2:
+        # r5: rows of an odd number of doubles (181 x 217 x 181 as nibabel's get_fdata() hands it out): extended to whole 16-byte
+        # vectors, filtered by the streaming kernels, cropped -- instead of the generic passes
+        wx = weights[2]
+        left = 0 if wx is None else len(wx) // 2 + int(origins[2])
+        right = 0 if wx is None else len(wx) - 1 - left
+        return _run_on_extended_rows(input, output, left, right, modes[2], cval,
+                                     lambda e, o: _fused_3d_f64(e, o, weights, origins, [modes[0], modes[1], "nearest"], cval),
+                                     key=("sep3d64", tuple(None if w is None else len(w) for w in weights), tuple(int(o) for o in origins), tuple(modes[:2])))
     src = core.ascontiguousarray(input)
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     dst = output if direct else core.empty(output.shape, output.dtype)

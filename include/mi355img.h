@@ -147,7 +147,7 @@ int mi_copy(const mi_array *src, const mi_array *dst, int round_half_even, mi_st
 int mi_fill(const mi_array *dst, double value, mi_stream stream);
 /* r4b: rows that are not a multiple of 16 bytes (181 x 217 x 181 ...): out[..., x] = in[..., map(x - left)] for
  * x in [0, out.shape[-1]) -- every row extended along the last axis by a filter boundary mode (MI_MODE_CONSTANT: cval) --
- * and its inverse out[..., x] = in[..., left + x].  1-, 2- and 4-byte dtypes, C-contiguous; the extended rows and `left`
+ * and its inverse out[..., x] = in[..., left + x].  1-, 2-, 4- and 8-byte dtypes (r5: 8), C-contiguous; the extended rows and `left`
  * are multiples of 16 bytes and the extended array is 16-byte aligned (what the fused kernels need: the Python layer runs
  * them on the extended volume and copies the columns back; the reference has no counterpart -- its kernels index
  * element by element, _filters_core.py:190-348). */

@@ -417,3 +417,50 @@ def test_ragged_rows_plane_restricted_launches_tile_the_full_result(gpu, ndi, li
     with S.output_planes([(0, 0), (69, 70)]):                               # empty + one plane
         ndi.uniform_filter(xd, size, mode=mode, cval=cval, output=out)
     assert np.array_equal(out.get(), full)
+
+
+def test_float64_volumes_with_rows_of_an_odd_number_of_doubles(gpu, ndi, lib):
+    """float64 volumes (what nibabel's get_fdata() hands out) whose rows are an odd number of doubles: extended to whole 16-byte
+    vectors (mi_extend_rows / mi_crop_rows on 8-byte elements, r5), filtered by the float64 streaming kernels, cropped -- every
+    boundary mode, a fill value, origins along z / y, gaussian and uniform; against SciPy at float64 tolerance."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(64)
+    for shape in ((45, 54, 45), (33, 40, 101), (20, 37, 263), (181, 217, 181)):
+        x = rng.standard_normal(shape)
+        xd = gpu.asarray(x)
+        for mode in MODES:
+            for what in (("u", 3), ("u", 5), ("g", 1.0), ("g", 2.0)) if shape[0] < 100 else (("u", 5), ("g", 2.0)):
+                kw = dict(mode=mode, cval=-0.75)
+                if what[0] == "u":
+                    got = ndi.uniform_filter(xd, what[1], **kw).get()
+                    ref = sndi.uniform_filter(x, what[1], **kw)
+                else:
+                    got = ndi.gaussian_filter(xd, what[1], **kw).get()
+                    ref = sndi.gaussian_filter(x, what[1], **kw)
+                assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (shape, mode, what, float(np.abs(got - ref).max()))
+        got = ndi.uniform_filter(xd, 5, origin=(1, -1, 0)).get()
+        assert np.abs(got - sndi.uniform_filter(x, 5, origin=(1, -1, 0))).max() <= 1e-12 * 4
+        # the route itself: the fused float64 path takes the request (it answered None for odd rows before r5)
+        from cupyimg_amd.scipy.ndimage import filters as F
+        if x.size >= (1 << 15):
+            w = [np.full(5, 0.2)] * 3
+            assert F._fused_3d_f64(xd, gpu.empty(shape, np.float64), w, [0, 0, 0], ["reflect"] * 3, 0.0) is not None, shape
+    # the row copies themselves on 8-byte elements (int64 too): extend by every mode, crop back
+    import ctypes
+    from cupyimg_amd import core
+    from cupyimg_amd.scipy.ndimage import _support as S
+    for dt in (np.float64, np.int64):
+        a = (rng.standard_normal((7, 9, 37)) * 1000).astype(dt)
+        ad = gpu.asarray(a)
+        for mode in MODES:
+            ext = core.empty((7, 9, 2 + 38 + 4), dt)
+            da, de = ad._desc(), ext._desc()
+            S.check(lib.mi_extend_rows(ctypes.byref(da), ctypes.byref(de), 2, S.mode_code(mode), 5.0, None))
+            want = np.pad(a, ((0, 0), (0, 0), (2, 5)), mode={"reflect": "symmetric", "mirror": "reflect", "nearest": "edge", "wrap": "wrap", "constant": "constant"}[mode],
+                          **({"constant_values": 5} if mode == "constant" else {}))
+            assert np.array_equal(ext.get(), want), (dt, mode)
+            back = core.empty(a.shape, dt)
+            db = back._desc()
+            S.check(lib.mi_crop_rows(ctypes.byref(de), ctypes.byref(db), 2, None))
+            assert np.array_equal(back.get(), a), (dt, mode)
