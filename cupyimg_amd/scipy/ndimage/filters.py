@@ -845,10 +845,10 @@ def _min_or_max_filter(input, size, ftprnt, structure, output, mode, cval, origi
             if res is not None:
                 return res
         if (input.ndim in (2, 3) and S.current_planes() is None and output.dtype == input.dtype and int(origins[-1]) == 0
-                and input.dtype in (np.uint8, np.uint16, np.int16, np.float32)
+                and input.dtype in (np.uint8, np.uint16, np.int16, np.float32, np.float64)
                 and (input.shape[-1] * input.dtype.itemsize) % 16 and all(int(sz) % 2 == 1 for sz in sizes)):
-            # rows that are not a multiple of 16 bytes: the fused kernels on explicitly extended rows (r4b)
-            fused = _try_stream_minmax_f32 if input.dtype == np.float32 else _try_fused_minmax_u8
+            # rows that are not a multiple of 16 bytes: the fused kernels on explicitly extended rows (r4b; r5: float64 too)
+            fused = _try_stream_minmax_f32 if input.dtype in (np.float32, np.float64) else _try_fused_minmax_u8
             reach = int(sizes[-1]) // 2
             modes_x = list(modes[:-1]) + ["nearest"]
             res = _run_on_extended_rows(input, output, reach, reach, modes[-1], cval,

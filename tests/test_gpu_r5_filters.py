@@ -446,6 +446,16 @@ def test_float64_volumes_with_rows_of_an_odd_number_of_doubles(gpu, ndi, lib):
         if x.size >= (1 << 15):
             w = [np.full(5, 0.2)] * 3
             assert F._fused_3d_f64(xd, gpu.empty(shape, np.float64), w, [0, 0, 0], ["reflect"] * 3, 0.0) is not None, shape
+    # flat min / max and grey morphology on such rows: bit-exact
+    for shape in ((45, 54, 45), (20, 37, 263), (91, 109, 91)):
+        x = rng.standard_normal(shape) * 40
+        xd = gpu.asarray(x)
+        for mode in MODES:
+            for size in (3, 5, (1, 3, 5)):
+                for fn, rf in ((ndi.maximum_filter, sndi.maximum_filter), (ndi.minimum_filter, sndi.minimum_filter)):
+                    assert np.array_equal(fn(xd, size, mode=mode, cval=7).get(), rf(x, size, mode=mode, cval=7)), (shape, mode, size, fn.__name__)
+        assert np.array_equal(ndi.grey_erosion(xd, size=3).get(), sndi.grey_erosion(x, size=3))
+        assert np.array_equal(ndi.grey_dilation(xd, size=5).get(), sndi.grey_dilation(x, size=5))
     # the row copies themselves on 8-byte elements (int64 too): extend by every mode, crop back
     import ctypes
     from cupyimg_amd import core
