@@ -393,7 +393,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
     constexpr int RX = W / 2;
     constexpr int NE = RAGGED ? 4 : (RX <= 2 ? 2 : 4);
     constexpr int RINGN = W - 1;                          // even (W odd), >= 2
-    static_assert(W >= 3 && W <= 7 && (W & 1), "lean kernel: odd W, 3 .. 7 (9 .. 17: sep3d_long.hip)");
+    static_assert(W >= 3 && W <= 9 && (W & 1) && (W <= 7 || RAGGED), "lean kernel: odd W, 3 .. 7 (9 .. 17: sep3d_long.hip; r5: 9 for ragged rows)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *lds = reinterpret_cast<float4 *>(smem);                     // [2][LROWS][64]
     int *ztab = reinterpret_cast<int *>(smem + (size_t)2 * LROWS * 1024); // source plane per step
@@ -646,13 +646,16 @@ static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool h
     constexpr int G = (TY + NWC - 1) / NWC;
     constexpr int LROWS = (NWC * G + W - 1) > ROWS ? (NWC * G + W - 1) : ROWS;
     const size_t lds = (size_t)2 * LROWS * 1024 + (size_t)(kMaxChunk + kMaxTaps) * sizeof(int);
+    constexpr bool kAligned = W <= 7;            // 9 taps: the ragged build only (aligned rows take sep3d_long.hip)
     static PerDeviceOnce attr_done;
-    if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+    if constexpr (kAligned) {
+        if (!attr_done) {
+            MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
     }
     if (p.ty != TY) { set_error("internal: lean tile mismatch"); return MI_ERR_INTERNAL; }
     const int total = p.nxt * p.nyt * p.nzc;
@@ -679,14 +682,19 @@ static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool h
             return MI_ERR_UNSUPPORTED;
         }
     }
-    note_kernel("mi::sep3d_lean_kernel<%d,%d,%d,%d,%d,%s> grid=%d (fused x/z/y separable pass)", W, NWP, NWC, R, DEPTH,
-                has_const ? "true" : "false", total);
-    if (has_const)
-        hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
-    else
-        hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, false>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
-    MI_HIP(hipGetLastError());
-    return MI_OK;
+    if constexpr (kAligned) {
+        note_kernel("mi::sep3d_lean_kernel<%d,%d,%d,%d,%d,%s> grid=%d (fused x/z/y separable pass)", W, NWP, NWC, R, DEPTH,
+                    has_const ? "true" : "false", total);
+        if (has_const)
+            hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+        else
+            hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, false>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    } else {
+        set_error("separable3d: this tap count runs here on ragged rows only");
+        return MI_ERR_UNSUPPORTED;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -738,6 +746,7 @@ static int lean_rows(int w, int cfg)
     case 3: return cfg == 1 ? 32 : (cfg == 5 ? 20 : 36);
     case 5: return cfg == 2 ? 24 : (cfg == 3 ? 30 : (cfg >= 4 && cfg <= 6 ? 20 : 36));
     case 7: return 24;
+    case 9: return 18;
     default: return 24;
     }
 }
@@ -758,6 +767,10 @@ static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams 
         if (cfg == 6) return launch_sep3d_lean<5, 10, 6, 2>(in, out, p, hc, s);
         if (cfg == 8) return launch_sep3d_lean<5, 12, 4, 3, 2>(in, out, p, hc, s);
         return launch_sep3d_lean<5, 12, 4, 3, 1, true>(in, out, p, hc, s);   // measured best: 1 WG/CU, 16 waves
+    case 9:
+        // r5: rows that are not a multiple of four floats only (gaussian sigma 1 on 181 x 217 x 181: aligned rows take sep3d_long.hip)
+        if (!(p.nx & 3)) { set_error("separable3d: 9 taps on aligned rows belong to the long kernel"); return MI_ERR_UNSUPPORTED; }
+        return launch_sep3d_lean<9, 9, 3, 2, 2, true>(in, out, p, hc, s);        // 12 waves: 168 registers a lane (16 waves: 21 spilled)
     default:
         return launch_sep3d_lean<7, 8, 4, 3, 2, true>(in, out, p, hc, s);
     }
@@ -907,9 +920,9 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     const int64_t nzr = zn[0] + zn[1];
 
     const bool cubic_w = w[0] == w[1] && w[1] == w[2];
-    if (ragged && !(cubic_w && w[0] >= 3 && w[0] <= 7 && g_sep3d_kernel != 1 && g_sep3d_cfg == 0 && ny * nx * 4 < ((int64_t)1 << 31) &&
+    if (ragged && !(cubic_w && w[0] >= 3 && w[0] <= 9 && g_sep3d_kernel != 1 && g_sep3d_cfg == 0 && ny * nx * 4 < ((int64_t)1 << 31) &&
                     (weights[0] ? origin[0] : 0) == 0 && (weights[1] ? origin[1] : 0) == 0))
-        UNSUP("rows that are not a multiple of 4 floats: cubic kernels of 3 / 5 / 7 taps without origins only");
+        UNSUP("rows that are not a multiple of 4 floats: cubic kernels of 3 / 5 / 7 / 9 taps without origins only");
     // r3: with its re-scheduled instruction stream (sep3d_long3_kernel) the LDS-DMA kernel also beats the lean kernel
     // below 9 taps on volumes that fill the chip (profiles/r3_long3_small_taps.txt, sustained, lean -> long: 7 taps
     // 15-31 % faster on every shape of 4 Mvoxels and more; 5 and 3 taps 3-5 % faster on 512^3, 256^3, 64 x 1024^2 and
@@ -1007,7 +1020,7 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
 
     const int cfg = g_sep3d_cfg;
     const bool cubic = w[0] == w[1] && w[1] == w[2] && w[0] >= 3 && p.oz == w[0] / 2 && p.oy == w[1] / 2;
-    const bool lean = cubic && w[0] <= 7 && g_sep3d_kernel != 1 && ny * nx * 4 < ((int64_t)1 << 31);    // 9 taps: sep3d_long.hip
+    const bool lean = cubic && (w[0] <= 7 || (ragged && w[0] == 9)) && g_sep3d_kernel != 1 && ny * nx * 4 < ((int64_t)1 << 31);    // 9 taps: sep3d_long.hip (ragged rows: here)
     int cfg_use = cfg, rows = 0, nzc = 1;
     if (lean && cfg == 0) {
         // candidates: the big tile and (3 / 5 taps) a small one
