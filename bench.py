@@ -34,6 +34,12 @@ import os
 import sys
 import time
 
+# RCCL between PROCESSES (one rank per GPU) needs dmabuf IPC on this driver: without it the first ncclSend / ncclRecv fails
+# with `hipIpcGetMemHandle: invalid argument`.  HSA reads the variable when the runtime initialises (the first HIP call),
+# so it is set here, before anything can have touched a device -- never by re-executing the process.  cupyimg_amd._lib.load()
+# does the same for every other program that uses the library ("Multi-process launches").
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -50,19 +56,45 @@ def synth(shape, seed=0):
 
 
 SETTLE_LAUNCHES = 220        # ~ 40 ms of the 2 x 512 MiB copy kernel before the comparators are timed
-TRAFFIC_FILES = ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json")
+TRAFFIC_FILES = ("r6_traffic.json", "r5_traffic.json")
 
 
-def measured_traffic(world, config):
+def kernel_signature(name):
+    """("sep3d_long3_kernel", ["5", "true"]) from either spelling of a kernel: rocprofv3's demangled
+    `void mi::sep3d_long3_kernel<5, true, false, 0, 5>(float const*, ...)` or the library's own
+    `mi::sep3d_long3_kernel<5,true> grid=256 (...)` (mi_debug_last_kernel)."""
+    import re
+    m = re.search(r"([A-Za-z_][A-Za-z_0-9]*)\s*(?:<([^>]*)>)?", name.replace("void ", "").replace("mi::", ""))
+    if not m:
+        return None, []
+    targs = [a.strip() for a in (m.group(2) or "").split(",") if a.strip()]
+    return m.group(1), targs
+
+
+def same_kernel(a, b):
+    """True when the two names are the same kernel template and the shorter template-argument list is a prefix of the
+    longer one (the library prints the arguments that select the instantiation, rocprofv3 all of them)."""
+    (na, ta), (nb, tb) = kernel_signature(a), kernel_signature(b)
+    n = min(len(ta), len(tb))
+    return na is not None and na == nb and ta[:n] == tb[:n]
+
+
+def measured_traffic(world, config, kernel_name):
     """(HBM bytes per launch, source) from the rocprofv3 PMC passes of this same command (profiles/r*_traffic.json:
     2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied).  Counters cannot be read from inside the process, so this
-    is the committed measurement -- labelled as such in the JSON line -- valid for the single-GPU headline workload."""
+    is the committed measurement -- labelled as such in the JSON line -- valid for the single-GPU headline workload.
+    REFUSED (traffic null, the reason in the source field) when the kernel the counters were collected on is not the
+    kernel this run dispatched (mi_debug_last_kernel()): a committed constant must not outlive its kernel."""
     if world != 1 or config != "H":
         return None, None
     for name in TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["hbm_bytes_per_launch"], "profiles/{} (rocprofv3 PMC passes of this command, not live)".format(name)
+                rec = json.load(f)
+            if not same_kernel(rec.get("kernel", ""), kernel_name):
+                return None, ("refused: profiles/{} was collected on `{}`, this run dispatched `{}` -- re-run scripts/profile_bench.sh"
+                              .format(name, rec.get("kernel"), kernel_name[:80]))
+            return rec["hbm_bytes_per_launch"], "profiles/{} (rocprofv3 PMC passes of this command, not live; kernel name checked against this run's)".format(name)
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -235,6 +267,112 @@ def cpu_baseline(x, gpu_out):
     return res
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The other single-GPU BASELINE.json configs ("plus the four other configs"), timed AFTER the headline's
+# timed region and reported in the same JSON line under "configs".  Workloads, inputs and tolerances are those of
+# tests/test_gpu_baseline_full.py (tests/helpers/fullsize.py builds them; scipy.ndimage on z sub-slabs over the host
+# cores is the comparator: every plane of every output, outside every timed region).
+# ---------------------------------------------------------------------------------------------------------------------
+CONFIG_MIN_MS = 40.0         # at least this much back-to-back load per timed burst (clocks settle after ~40 ms)
+
+
+def _time_launches(ca, fn, min_reps=10):
+    """Seconds per call: 5 warm launches to size the burst, one untimed burst, one timed burst of >= CONFIG_MIN_MS
+    between two HIP events on the library's stream."""
+    e0, e1 = ca.Event(), ca.Event()
+    e0.record()
+    for _ in range(5):
+        fn()
+    e1.record()
+    ca.synchronize()
+    per = max(e0.elapsed_ms(e1) / 5, 1e-3)
+    reps = max(min_reps, int(CONFIG_MIN_MS / per) + 1)
+    for _ in range(reps):
+        fn()
+    ca.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    ca.synchronize()
+    return e0.elapsed_ms(e1) / reps / 1e3, reps
+
+
+def other_configs(ca, ndi, x_host, xd, out, parity=True):
+    """{"B": {...}, "C": ..., "D": ..., "Dprime": ..., "E_slab": ...}: ms per launch (HIP events), fraction of 8 TB/s on
+    the ALGORITHMIC bytes, the kernel the library dispatched, and whole-volume parity against scipy.ndimage.  Returns
+    (table, all_parity_ok).  `xd` / `out` are the headline's 512^3 buffers (same N(0,1) seed-0 volume); they are dropped
+    before the two large configs are staged."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scipy.ndimage as sndi
+    from helpers import fullsize as fs
+    table, ok = {}, True
+
+    def entry(name, workload, voxels, bpv, secs, reps, kernel, par_key, par_val, tol):
+        nonlocal ok
+        gbs = voxels * bpv / secs / 1e9
+        e = {"workload": workload, "ms": round(secs * 1e3, 4), "launches_timed": reps, "Mvoxels_per_s": round(voxels / secs / 1e6, 1),
+             "alg_bytes_per_voxel": bpv, "achieved_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4),
+             "kernel": kernel[:110]}
+        if par_key is not None:
+            good = bool(par_val <= tol)
+            e["parity"] = {par_key: par_val, "tol": tol, "planes": "all", "ok": good}
+            ok = ok and good
+        table[name] = e
+
+    n = N_SIDE
+    t, reps = _time_launches(ca, lambda: ndi.gaussian_filter(xd, sigma=2, output=out))
+    k = ca.last_kernel()
+    err = fs.whole_volume_filter(x_host, out.get(), 8, 8, lambda s: sndi.gaussian_filter(s.astype(np.float64), sigma=2),
+                                 planes=16) if parity else None
+    entry("B", "gaussian_filter sigma=2 (17 taps/axis) on 512^3 float32", n ** 3, 8, t, reps, k,
+          "maxnorm_rel_vs_scipy" if parity else None, err, 1e-6)
+
+    M, off = fs.affine_case(n)
+    t, reps = _time_launches(ca, lambda: ndi.affine_transform(xd, M, off, order=1, mode="constant", output=out))
+    k = ca.last_kernel()
+    err = fs.whole_volume_affine(x_host, M, off, out.get()) if parity else None
+    entry("Dprime", "affine_transform order=1 (the same 3-D warp as a 3x4 matrix) on 512^3 float32", n ** 3, 8, t, reps, k,
+          "abs_err_over_max1_vs_scipy" if parity else None, err, 2e-6)
+
+    coords = fs.affine_coords_f32(n)
+    cd = ca.asarray(coords)
+    t, reps = _time_launches(ca, lambda: ndi.map_coordinates(xd, cd, order=1, mode="constant", output=out))
+    k = ca.last_kernel()
+    err = fs.whole_volume_map_coordinates(x_host, coords, out.get()) if parity else None
+    entry("D", "map_coordinates order=1 3-D affine warp on 512^3 float32 (+1.5 GiB float32 coordinates)", n ** 3, 20, t, reps, k,
+          "abs_err_over_max1_vs_scipy" if parity else None, err, 2e-6)
+    del cd, coords
+
+    # E-slab: one rank's share of config 4 (2048^3 over 8 GPUs = 256 planes + 4 halo planes either side)
+    ca.free_all_blocks()
+    shape = fs.E_SLAB
+    xe = fs.slab_volume_f32(shape)
+    ed = ca.asarray(xe)
+    eo = ca.empty(shape, np.float32)
+    t, reps = _time_launches(ca, lambda: ndi.uniform_filter(ed, size=9, output=eo), min_reps=8)
+    k = ca.last_kernel()
+    err = fs.whole_volume_filter(xe, eo.get(), 4, 4, lambda s: sndi.uniform_filter(s.astype(np.float64), size=9),
+                                 planes=4) if parity else None
+    entry("E_slab", "uniform_filter size=9 on one rank's 264x2048x2048 float32 slab of the 2048^3 volume (config 4 at 8 GPUs)",
+          shape[0] * shape[1] * shape[2], 8, t, reps, k, "maxnorm_rel_vs_scipy" if parity else None, err, 1e-6)
+    del ed, eo, xe
+    ca.free_all_blocks()
+
+    m = fs.N_C
+    u = fs.volume_u8((m, m, m), seed=1)
+    ud = ca.asarray(u)
+    uo = ca.empty(ud.shape, np.uint8)
+    t, reps = _time_launches(ca, lambda: ndi.grey_erosion(ud, size=7, output=uo), min_reps=8)
+    k = ca.last_kernel()
+    bad = fs.whole_volume_filter(u, uo.get(), 3, 3, lambda s: sndi.grey_erosion(s, size=7), exact=True, planes=16) if parity else None
+    entry("C", "grey_erosion size=7 on 1024^3 uint8", m ** 3, 2, t, reps, k,
+          "voxels_differing_from_scipy" if parity else None, bad, 0)
+    del ud, uo, u
+    ca.free_all_blocks()
+    return table, ok
+
+
 PIPE_NBUF = 3                # resident input slabs of the pipelined schedule (scripts/bench_slab_step.py: 3 beats 2)
 GRAPH_ROTATIONS = 8          # rotations per hipGraph replay of the pipelined_graph candidate
 TUNE_BURST = 30              # steps per burst when the schedules are timed
@@ -297,6 +435,8 @@ def main():
                     help="config H with N > 1: the 512^3 volume split over the ranks (strong, default) or one 512^3 slab "
                          "per rank (weak)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N = 1, config H: skip the `configs` block (BASELINE configs B, C, D, D', E-slab timed after the headline)")
     ap.add_argument("--schedule", choices=["auto", "plain", "overlapped", "pipelined", "pipelined_graph"], default="auto",
                     help="N > 1 (and --self-loop): schedule of a step (exchange + filter).  auto (default): every candidate is "
                          "timed in bursts of back-to-back steps inside the untimed set-up, the slowest rank's figure decides, "
@@ -324,8 +464,13 @@ def main():
 
     if not ca.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible")
-    # one rank per GPU; on a box with fewer GPUs than ranks (functional dry runs only) ranks share devices
-    ca.set_device(local_rank % max(ca.device_count(), 1))
+    # one rank per GPU.  RCCL refuses a communicator with two ranks on one device ("Duplicate GPU detected",
+    # ncclInvalidUsage), so fewer GPUs than ranks is an error here, not a dry run (the one-GPU dry run is --self-loop)
+    if world > 1 and ca.device_count() < world:
+        raise SystemExit("bench.py --gpus {}: {} ranks need {} GPUs, this box shows {} (RCCL does not accept two ranks "
+                         "on one device; use --self-loop for a one-GPU dry run of the exchange path)".format(
+                             args.gpus, world, world, ca.device_count()))
+    ca.set_device(local_rank)
 
     dist = None
     if world > 1:
@@ -520,7 +665,7 @@ def main():
         kernel_s = dev_ms / 1e3 / args.steps          # HIP-event time per step on the launch stream (max over ranks)
         per_gpu_voxels = voxels / world
         achieved = ALG_BYTES_PER_VOXEL * per_gpu_voxels / kernel_s / 1e9
-        traffic, traffic_source = measured_traffic(world, cfg) if not args.self_loop else (None, None)
+        traffic, traffic_source = measured_traffic(world, cfg, kernel_name) if not args.self_loop else (None, None)
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -589,6 +734,13 @@ def main():
                             "roofline_frac": round(c_ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(c_dev / args.steps * 1e3, 2)}
         if sched_info is not None:
             line["schedule"] = sched_info
+        if cfg == "H" and world == 1 and not args.self_loop and not args.no_configs:
+            # the headline's buffers are reused for B / D' / D and dropped before E-slab and C are staged
+            line["configs"], cfg_ok = other_configs(ca, ndi, x_host, xd, out, parity=not args.no_cpu)
+            line["configs_note"] = ("timed after the headline's timed region (which they do not touch): >= {:.0f} ms of back-to-back launches "
+                                    "each between two HIP events, after an equal untimed burst; parity = every plane against scipy.ndimage"
+                                    .format(CONFIG_MIN_MS))
+            parity_ok = parity_ok and cfg_ok
         if cpu is not None:
             # single-GPU line: the output of the LAST timed launch against the oracle (and SciPy) over the whole volume
             errs = [cpu.get(k) for k in ("parity_vs_oracle_maxnorm_rel", "parity_vs_scipy_maxnorm_rel") if cpu.get(k) is not None]

@@ -155,6 +155,15 @@ def library_path():
     return os.environ.get("MI355IMG_LIB") or _build.LIB
 
 
+def process_env_defaults():
+    """Environment the HIP / HSA runtime must see when it initialises (its first call in the process), set with
+    `setdefault` so that an explicit choice of the caller wins.  HSA_ENABLE_IPC_MODE_LEGACY=0: dmabuf IPC -- what RCCL
+    between PROCESSES (one rank per GPU, distributed.HaloComm) needs on this driver; with the legacy mode the first
+    send / recv fails with `hipIpcGetMemHandle: invalid argument`.  Harmless for single-process use.  Called by load()
+    before the library (and with it the HIP runtime) is mapped; bench.py sets the same default at its top."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
 def load():
     """Return the loaded CDLL, building it first if it is not there."""
     global _lib
@@ -163,6 +172,7 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        process_env_defaults()
         path = library_path()
         if not os.path.exists(path):
             _build.build(verbose=False)

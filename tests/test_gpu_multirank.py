@@ -22,8 +22,11 @@ def _free_port():
 
 
 def _env():
+    """The children get NO private environment: HSA_ENABLE_IPC_MODE_LEGACY (dmabuf IPC, which RCCL across processes needs
+    on this driver) is REMOVED here, so what the ranks run with is the default cupyimg_amd._lib.load() sets before the
+    first HIP call -- the same mechanism bench.py and any other program using the library gets."""
     env = dict(os.environ)
-    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
     env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
     return env
 
