@@ -66,6 +66,7 @@ SOURCES = [
     ("minmax_16.hip", []),
     ("binary.hip", []),
     ("binary3d.hip", []),
+    ("bitmorph3d.hip", []),
     ("interp.hip", ["-ffp-contract=off"]),
     ("interp_fast.hip", ["-ffp-contract=off"]),
     ("spline_fast.hip", []),

@@ -93,6 +93,8 @@ namespace mi {
 int binary3_tiled(const mi_array *in, const mi_array *out, const uint8_t *structure, const int64_t *sshape,
                   const int *origins, const mi_array *mask, int border_value, int invert, int32_t *changed,
                   hipStream_t s);   // binary3d.hip
+int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure, const int64_t *sshape, const int *origins,
+              const mi_array *mask, int border_value, int invert, int k, int32_t *flags, hipStream_t s);   // bitmorph3d.hip
 }
 
 using namespace mi;
@@ -100,6 +102,40 @@ using namespace mi;
 // test hook (not part of the C-ABI): 0 = never use the LDS-tiled kernel
 static mi::Knob g_binary_tiled{1};
 extern "C" int mi_debug_set_binary_tiled(int enabled) { g_binary_tiled = enabled; return MI_OK; }
+
+static int check_binary_args(const mi_array *in, const mi_array *out, const uint8_t *structure, const int64_t *sshape,
+                             const int *origins, const mi_array *mask)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(in->ndim >= 1, MI_ERR_INVALID_ARG, "input must have at least one dimension");
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    MI_REQUIRE(structure && sshape && origins, MI_ERR_INVALID_ARG, "NULL argument");
+    MI_REQUIRE(is_contiguous(in) && is_contiguous(out), MI_ERR_NOT_CONTIGUOUS,
+               "binary morphology needs C-contiguous arrays");
+    MI_REQUIRE(in->data != out->data, MI_ERR_INVALID_ARG, "output and input may not overlap in memory");
+    if (mask) {
+        if ((rc = check_array(mask, "mask"))) return rc;
+        MI_REQUIRE(same_shape(in, mask), MI_ERR_INVALID_ARG, "mask and input must have equal sizes");
+        MI_REQUIRE(is_contiguous(mask) && dtype_size(mask->dtype) == 1, MI_ERR_NOT_CONTIGUOUS,
+                   "mask must be a C-contiguous 1-byte array");
+    }
+    return MI_OK;
+}
+
+// `iterations` erosions (dilations with invert) in ONE launch: the k intermediate volumes never exist in HBM
+// (bitmorph3d.hip).  The reference runs one launch and one host synchronisation per iteration (morphology.py:292-322).
+extern "C" int mi_binary_erosion_fused(const mi_array *in, const mi_array *out, const uint8_t *structure,
+                                       const int64_t *sshape, const int *origins, const mi_array *mask,
+                                       int border_value, int invert, int iterations, int32_t *changed_dev, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_binary_args(in, out, structure, sshape, origins, mask))) return rc;
+    MI_REQUIRE(iterations >= 1, MI_ERR_INVALID_ARG, "iterations must be >= 1");
+    if (numel(in) == 0) return MI_OK;
+    return bitmorph3(in, out, structure, sshape, origins, mask, border_value, invert, iterations, changed_dev,
+                     resolve_stream(stream));
+}
 
 extern "C" int mi_binary_erosion(const mi_array *in, const mi_array *out, const uint8_t *structure,
                                  const int64_t *sshape, const int *origins, const mi_array *mask,
@@ -123,6 +159,8 @@ extern "C" int mi_binary_erosion(const mi_array *in, const mi_array *out, const 
     if (total == 0) return MI_OK;
     hipStream_t s = resolve_stream(stream);
     if (g_binary_tiled) {
+        rc = bitmorph3(in, out, structure, sshape, origins, mask, border_value, invert, 1, changed_dev, s);
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
         rc = binary3_tiled(in, out, structure, sshape, origins, mask, border_value, invert, changed_dev, s);
         if (rc != MI_ERR_UNSUPPORTED) return rc;
     }

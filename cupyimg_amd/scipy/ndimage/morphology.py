@@ -17,7 +17,7 @@ import operator
 
 import numpy as np
 
-from ... import core
+from ... import _lib, core
 from . import _support as S
 from . import filters
 
@@ -27,6 +27,9 @@ __all__ = [
     "morphological_gradient", "morphological_laplace", "white_tophat", "black_tophat",
     "generate_binary_structure", "iterate_structure",
 ]
+
+
+_MAX_FUSED = 4      # iterations per launch of mi_binary_erosion_fused (the halo of a tile grows with it; <= MI_BINARY_MAX_FUSED)
 
 
 def generate_binary_structure(rank, connectivity):
@@ -137,29 +140,59 @@ def _binary_erosion(input, structure, iterations, mask, output, border_value, or
     elif iterations == 1:
         launch(src, final)
     else:
-        # brute-force ping-pong (morphology.py:301-327) with an on-device
-        # "changed" flag; buffers are arranged so the last write hits `final`
-        # whenever the iteration count is known.
-        flag = core.zeros((1,), np.int32)
+        # brute-force ping-pong (morphology.py:301-327) with an on-device "changed" flag per iteration; buffers are
+        # arranged so the last write hits `final` whenever the number of launches is known.  r6: up to _MAX_FUSED
+        # iterations run inside ONE launch on a bit-packed tile (mi_binary_erosion_fused, csrc/bitmorph3d.hip) -- the
+        # intermediate volumes never reach HBM; shapes / dtypes outside that kernel's envelope iterate one launch each.
+        def launch_fused(src_, dst_, k, flag_ptr):
+            a, b = src_._desc(), dst_._desc()
+            rc = lib.mi_binary_erosion_fused(ctypes.byref(a), ctypes.byref(b), stp, sshape, org,
+                                             ctypes.byref(mdesc) if mdesc is not None else None,
+                                             int(bool(border_value)), int(invert), int(k), flag_ptr, None)
+            if rc == _lib.MI_ERR_UNSUPPORTED:
+                return False
+            S.check(rc)
+            return True
+
         other = core.empty(final.shape, final.dtype)
         bufs = [final, other]
-        which = 0 if (iterations >= 1 and iterations & 1) else 1
         cur = src
-        it = 0
-        while True:
-            dst = bufs[which]
-            need_flag = iterations < 1
-            if need_flag:
-                flag.fill(0)
-            launch(cur, dst, ctypes.c_void_p(flag.ptr) if need_flag else None)
-            it += 1
-            cur = dst
-            which ^= 1
-            if iterations >= 1:
-                if it >= iterations:
-                    break
+        if iterations >= 1:
+            sizes = [_MAX_FUSED] * (iterations // _MAX_FUSED) + ([iterations % _MAX_FUSED] if iterations % _MAX_FUSED else [])
+            which = 0 if len(sizes) & 1 else 1
+            fused_ok = launch_fused(cur, bufs[which], sizes[0], None)
+            if fused_ok:
+                cur = bufs[which]
+                for k in sizes[1:]:
+                    which ^= 1
+                    if not launch_fused(cur, bufs[which], k, None):        # the envelope only shrinks with k: cannot happen
+                        raise RuntimeError("mi_binary_erosion_fused refused {} iterations after accepting {}".format(k, sizes[0]))
+                    cur = bufs[which]
             else:
-                if int(flag.get()[0]) == 0:
+                which = 0 if iterations & 1 else 1
+                for _ in range(iterations):
+                    launch(cur, bufs[which])
+                    cur = bufs[which]
+                    which ^= 1
+        else:
+            # until nothing changes: one host read of the flags per batch of _MAX_FUSED iterations (the reference: one
+            # full-volume comparison + synchronisation per iteration, morphology.py:313,321); the first iteration that
+            # changes nothing ends the run, and the later iterations of its batch reproduce the same volume
+            flags = core.zeros((_MAX_FUSED,), np.int32)
+            which = 1
+            fused_ok = True
+            while True:
+                dst = bufs[which]
+                flags.fill(0)
+                if fused_ok and launch_fused(cur, dst, _MAX_FUSED, ctypes.c_void_p(flags.ptr)):
+                    stable = not flags.get().all()
+                else:
+                    fused_ok = False
+                    launch(cur, dst, ctypes.c_void_p(flags.ptr))
+                    stable = int(flags.get()[0]) == 0
+                cur = dst
+                which ^= 1
+                if stable:
                     break
         if cur is not final:
             final[...] = cur

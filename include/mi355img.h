@@ -380,6 +380,18 @@ int mi_binary_erosion(const mi_array *in, const mi_array *out, const uint8_t *st
                       const int64_t *sshape, const int *origins, const mi_array *mask,
                       int border_value, int invert, int32_t *changed_dev, mi_stream stream);
 
+/* `iterations` (1 .. MI_BINARY_MAX_FUSED) iterations of the same erosion / dilation in ONE launch -- the host loop of
+ * morphology.py:301-327 (one launch and one host synchronisation per iteration) folded into the tile residency: the
+ * volume is staged as 1 bit per voxel and the intermediate results never reach HBM (csrc/bitmorph3d.hip).  The result
+ * is that of `iterations` calls of mi_binary_erosion (mask, border_value, origins applied in every iteration).
+ * changed_dev: NULL or a device int32[iterations]; element j is OR-ed with 1 when iteration j + 1 changed a voxel
+ * (so a run "until stable" stops at the first zero).  3-D volumes of 1-byte voxels with rows that are a multiple of
+ * 16 bytes; anything else returns MI_ERR_UNSUPPORTED with nothing queued and the caller iterates mi_binary_erosion. */
+#define MI_BINARY_MAX_FUSED 8
+int mi_binary_erosion_fused(const mi_array *in, const mi_array *out, const uint8_t *structure,
+                            const int64_t *sshape, const int *origins, const mi_array *mask,
+                            int border_value, int invert, int iterations, int32_t *changed_dev, mi_stream stream);
+
 /* ------------------------------------------------------------------ */
 /* K5: interpolation, spline order 0 and 1                              */
 /* ------------------------------------------------------------------ */

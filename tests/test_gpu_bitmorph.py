@@ -1,0 +1,161 @@
+"""Bit-packed binary morphology with fused iterations (csrc/bitmorph3d.hip, mi_binary_erosion_fused; reference loop
+morphology.py:292-322, kernel :41-128): bit-exact against the CPU oracle and scipy.ndimage -- structures, origins,
+border values, masks, iteration counts that split into several fused launches, runs until stable, tile / chunk seams
+(forced small tiles), rows wider than one x tile, volumes whose rows are not a multiple of 32 voxels."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.ndimage as sndi
+
+from oracle import ndimage as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ndi(gpu):
+    from cupyimg_amd.scipy import ndimage
+    return ndimage
+
+
+@pytest.fixture()
+def knob(gpu):
+    from cupyimg_amd import _lib
+    fn = _lib.load().mi_debug_set_bitmorph
+    fn.argtypes = [ctypes.c_int] * 3
+    yield fn
+    fn(1, 0, 0)
+
+
+def _ball(r):
+    g = np.indices((2 * r + 1,) * 3) - r
+    return (g ** 2).sum(0) <= r * r
+
+
+STRUCTS = {
+    "cross": None,
+    "cube3": np.ones((3, 3, 3), bool),
+    "rand537": np.random.default_rng(5).random((5, 3, 7)) > 0.4,
+    "even243": np.ones((2, 4, 3), bool),
+    "rand399": np.random.default_rng(6).random((3, 9, 9)) > 0.5,
+    "ball2": _ball(2),
+    "line_x": np.ones((1, 1, 5), bool),
+    "line_z": np.ones((3, 1, 1), bool),
+    "nocentre": np.array([[[0, 1, 0]], [[1, 0, 1]], [[0, 1, 0]]], bool),
+}
+
+
+@pytest.mark.parametrize("shape", [(20, 37, 64), (9, 50, 1040), (33, 18, 2064), (12, 21, 528), (40, 70, 96)])
+@pytest.mark.parametrize("sname", list(STRUCTS))
+def test_bitmorph_matches_oracle(gpu, ndi, knob, shape, sname):
+    from cupyimg_amd import last_kernel
+    st = STRUCTS[sname]
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr((shape, sname)).encode()))
+    x = rng.random(shape) > 0.3
+    m = rng.random(shape) > 0.3
+    xd, md = gpu.asarray(x), gpu.asarray(m)
+    smin = 3 if st is None else min(st.shape)
+    cases = [dict(), dict(border_value=1), dict(iterations=2), dict(iterations=3, border_value=1), dict(iterations=5),
+             dict(mask=True), dict(mask=True, iterations=3), dict(mask=True, iterations=6, border_value=1),
+             dict(origin=1 if smin >= 3 else 0), dict(origin=(-1, 0, 1) if smin >= 3 else 0, iterations=2)]
+    for tiles in [(2, 0, 0), (2, 5, 3)]:               # the planner's tiles; 5 output rows per tile, 3 z chunks
+        knob(*tiles)
+        for fn, ofn in [(ndi.binary_erosion, orc.binary_erosion), (ndi.binary_dilation, orc.binary_dilation)]:
+            for kw in cases:
+                kg, ko = dict(kw), dict(kw)
+                if kw.get("mask"):
+                    kg["mask"], ko["mask"] = md, m
+                got = fn(xd, st, **kg).get()
+                assert "bitmorph3_kernel" in last_kernel(), last_kernel()
+                ref = ofn(x, st, **ko)
+                assert np.array_equal(got, ref), (fn.__name__, sname, kw, tiles, int((got != ref).sum()))
+
+
+def test_bitmorph_until_stable_propagation_fill_holes(gpu, ndi, knob):
+    knob(2, 0, 0)
+    rng = np.random.default_rng(77)
+    shape = (24, 40, 96)
+    u = (rng.random(shape) > 0.2).astype(np.uint8) * rng.integers(1, 255, size=shape, dtype=np.uint8)   # bytes other than 0 / 1
+    assert np.array_equal(ndi.binary_erosion(gpu.asarray(u), iterations=-1).get(), orc.binary_erosion(u, iterations=-1))
+    assert np.array_equal(ndi.binary_fill_holes(gpu.asarray(u)).get(), sndi.binary_fill_holes(u))
+    seed = rng.random(shape) > 0.995
+    mask = rng.random(shape) > 0.35
+    got = ndi.binary_propagation(gpu.asarray(seed), mask=gpu.asarray(mask)).get()
+    assert np.array_equal(got, sndi.binary_propagation(seed, mask=mask))
+    got = ndi.binary_propagation(gpu.asarray(seed), structure=np.ones((3, 3, 3)), mask=gpu.asarray(mask), border_value=1).get()
+    assert np.array_equal(got, sndi.binary_propagation(seed, structure=np.ones((3, 3, 3)), mask=mask, border_value=1))
+    # opening / closing with iterations: erosion batches then dilation batches
+    x = rng.random(shape) > 0.25
+    for fn, sfn in [(ndi.binary_opening, sndi.binary_opening), (ndi.binary_closing, sndi.binary_closing)]:
+        for it in (1, 2, 3):
+            assert np.array_equal(fn(gpu.asarray(x), iterations=it).get(), sfn(x, iterations=it)), (fn.__name__, it)
+
+
+def test_bitmorph_output_forms_and_dtypes(gpu, ndi, knob):
+    """int8 / uint8 inputs (any nonzero byte is true), uint8 output arrays, output given, input untouched."""
+    knob(2, 0, 0)
+    rng = np.random.default_rng(3)
+    shape = (16, 24, 80)
+    for dt in (np.uint8, np.int8, np.bool_):
+        x = ((rng.random(shape) > 0.3) * rng.integers(1, 120, size=shape)).astype(dt)
+        xd = gpu.asarray(x)
+        out = gpu.empty(shape, np.uint8)
+        assert ndi.binary_dilation(xd, iterations=3, output=out) is out
+        assert np.array_equal(out.get(), sndi.binary_dilation(x, iterations=3).astype(np.uint8))
+        assert np.array_equal(xd.get(), x)
+        got = ndi.binary_erosion(xd, iterations=2)
+        assert got.dtype == np.bool_ and np.array_equal(got.get(), sndi.binary_erosion(x, iterations=2))
+
+
+def test_fused_abi_flags_and_refusals(gpu, knob):
+    """mi_binary_erosion_fused directly: one flag per iteration; MI_ERR_UNSUPPORTED (nothing written) outside the envelope."""
+    from cupyimg_amd import _lib
+    knob(2, 0, 0)
+    lib = _lib.load()
+    shape = (12, 20, 64)
+    x = np.zeros(shape, bool)
+    x[4:8, 6:14, 20:40] = True                  # a 4 x 8 x 20 box: the cross erodes it away in 2 iterations
+    xd = gpu.asarray(x)
+    out = gpu.empty(shape, np.bool_)
+    flags = gpu.zeros((4,), np.int32)
+    st = np.ascontiguousarray(sndi.generate_binary_structure(3, 1), dtype=np.uint8)
+    a, b = xd._desc(), out._desc()
+    rc = lib.mi_binary_erosion_fused(ctypes.byref(a), ctypes.byref(b), st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                     (ctypes.c_int64 * 3)(3, 3, 3), (ctypes.c_int * 3)(0, 0, 0), None, 0, 0, 4,
+                                     ctypes.c_void_p(flags.ptr), None)
+    assert rc == 0
+    assert not out.get().any()
+    assert list(flags.get()) == [1, 1, 0, 0]
+    # float volumes are not this kernel's
+    fd = gpu.asarray(x.astype(np.float32))
+    a = fd._desc()
+    rc = lib.mi_binary_erosion_fused(ctypes.byref(a), ctypes.byref(b), st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                     (ctypes.c_int64 * 3)(3, 3, 3), (ctypes.c_int * 3)(0, 0, 0), None, 0, 0, 2, None, None)
+    assert rc == _lib.MI_ERR_UNSUPPORTED
+    a = xd._desc()
+    rc = lib.mi_binary_erosion_fused(ctypes.byref(a), ctypes.byref(b), st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                     (ctypes.c_int64 * 3)(3, 3, 3), (ctypes.c_int * 3)(0, 0, 0), None, 0, 0, 0, None, None)
+    assert rc == _lib.MI_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("n,iterations", [(512, 1), (512, 3), (256, 7)])
+def test_bitmorph_full_size_every_plane(gpu, ndi, n, iterations):
+    """n^3 bool, default structure: every plane against scipy.ndimage on z sub-slabs (halo = iterations planes; at a
+    global edge the slab edge is the volume edge and border_value applies as unsplit), last launch of a burst."""
+    from helpers import fullsize as fs
+    from cupyimg_amd import last_kernel
+    gpu.free_all_blocks()
+    x = np.random.default_rng(11).random((n, n, n)) > 0.2
+    xd = gpu.asarray(x)
+    for fn, sfn in [(ndi.binary_erosion, sndi.binary_erosion), (ndi.binary_dilation, sndi.binary_dilation)]:
+        out = gpu.empty(x.shape, np.bool_)
+        for _ in range(6):
+            fn(xd, iterations=iterations, output=out)
+        assert "bitmorph3_kernel" in last_kernel(), last_kernel()
+        bad = fs.whole_volume_filter(x, out.get(), iterations, iterations, lambda s: sfn(s, iterations=iterations), exact=True,
+                                     planes=16)
+        assert bad == 0, (fn.__name__, bad)
+    del xd, out
+    gpu.free_all_blocks()
