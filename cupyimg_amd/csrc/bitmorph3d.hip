@@ -25,6 +25,9 @@
 // eroded border).  HBM traffic: 2 B/voxel for any k (+1 with a mask).
 #include "nd_common.hpp"
 #include "sep_common.hpp"
+#include <algorithm>
+#include <cstddef>
+#include <vector>
 
 namespace mi {
 
@@ -37,15 +40,16 @@ struct BitMorphParams {
     int nx, ny, nz;
     int wz, oz, hz;         // structure extent along z, lo reach (w/2 + origin), hi reach
     int oy, hy, ox;
-    int nrows, k;
+    int nrows, k;           // nrows: table entries (even; rows of one dx-mask are consecutive, padded by repetition)
     int border, invert;
     int ty, gy;             // output rows per tile, staged rows = ty + k (oy + hy)
     int txw, gxw, hlw;      // output words (32 voxels) per tile row, staged words per row, halo words on the left
     int pitch;              // LDS words per staged row: 1 pad + gxw + 1 pad (+ skew)
     int zc, nzc, nxt, nyt;
     int ns, nms;            // ring slots per stage (wz + 1), slots of the mask ring
-    unsigned short rowpos[kBmMaxRows];   // tz | ty << 8
-    unsigned rowmask[kBmMaxRows];        // bit tx set = structure[tz][ty][tx]
+    int pad_[3];
+    // per structure row (dz, dy) with a tap: { tz | last-of-its-group << 8, dx mask (bit tx), (ty - oy) * pitch * 4, 0 }
+    alignas(16) int rows[kBmMaxRows][4];
 };
 
 // 16 bytes -> 16 bits, bit i = (byte i != 0)
@@ -71,14 +75,59 @@ __device__ __forceinline__ u32x4 unpack16(const unsigned w)
     return r;
 }
 
-// NL = 16-byte granules a thread stages per plane (at most); a thread owns at most NW = NL / 2 words per stage
-template <bool HAS_MASK, int NL>
-__global__ void __launch_bounds__(kBmNT)
+// Structures known at compile time (origin 0): the stage is straight-line code -- every LDS read of a word is issued
+// before the first is consumed, no scalar loop, no table.  KIND 0 = the run-time table (any structure, any origin).
+struct BmCross {      // generate_binary_structure(3, 1): the default structure
+    static constexpr int n = 5;
+    static constexpr int tz[5] = {0, 1, 1, 1, 2}, ty[5] = {1, 0, 1, 2, 1};
+    static constexpr unsigned m[5] = {2, 2, 7, 2, 2};
+};
+struct BmConn18 {     // generate_binary_structure(3, 2)
+    static constexpr int n = 9;
+    static constexpr int tz[9] = {0, 0, 0, 1, 1, 1, 2, 2, 2}, ty[9] = {0, 1, 2, 0, 1, 2, 0, 1, 2};
+    static constexpr unsigned m[9] = {2, 7, 2, 7, 7, 7, 2, 7, 2};
+};
+struct BmCube3 {      // generate_binary_structure(3, 3) = ones((3, 3, 3))
+    static constexpr int n = 9;
+    static constexpr int tz[9] = {0, 0, 0, 1, 1, 1, 2, 2, 2}, ty[9] = {0, 1, 2, 0, 1, 2, 0, 1, 2};
+    static constexpr unsigned m[9] = {7, 7, 7, 7, 7, 7, 7, 7, 7};
+};
+
+// one word of a fixed 3 x 3 x 3 structure: `c` = byte address of the word in the CENTRE row of slot 0 of the source
+// ring; so[tz] = byte offset of the slot that holds plane z - 1 + tz; pitch4 = bytes per staged row
+template <typename S>
+__device__ __forceinline__ unsigned bm_fixed_word(const char *c, const int (&so)[3], int pitch4)
+{
+    unsigned C[S::n], L[S::n], R[S::n];
+#pragma unroll
+    for (int r = 0; r < S::n; r++) {
+        const unsigned *a = reinterpret_cast<const unsigned *>(c + so[S::tz[r]] + (S::ty[r] - 1) * pitch4);
+        C[r] = a[0];
+        if (S::m[r] & 1u) L[r] = a[-1];
+        if (S::m[r] & 4u) R[r] = a[1];
+    }
+    unsigned aC = 0xffffffffu, aL = 0xffffffffu, aR = 0xffffffffu, plain = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < S::n; r++) {
+        if (S::m[r] == 2u) plain &= C[r];                   // centre tap only
+        else { aC &= C[r]; aL &= L[r]; aR &= R[r]; }        // all three taps (the fixed structures have no other rows)
+    }
+    return plain & aC & __builtin_amdgcn_alignbit(aR, aC, 1u) & __builtin_amdgcn_alignbit(aC, aL, 31u);
+}
+
+// LDS (words): [oy rows of slack][ring 0 .. ring k: ns slots x gy rows x pitch][mask ring: nms slots][hy rows of slack]
+// [NT dump words].  A tap row above / below the staged rows reads the neighbouring slot or the slack: anything may be
+// there -- such outputs lie in the halo this tile recomputes for nobody.  Threads without a granule / word of their own
+// write to their dump word, so that no stage needs a divergent branch.
+//
+// NL = 16-byte granules a thread stages per plane (at most); a thread owns at most NW = ceil(NL / 2) words per stage
+template <bool HAS_MASK, int NL, int NT, int KIND>
+__global__ void __launch_bounds__(NT)
 bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict__ out, const unsigned char *__restrict__ msk,
                  const BitMorphParams p, int32_t *flags)
 {
-    constexpr int NW = NL > 1 ? NL / 2 : 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    constexpr int NW = (NL + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_raw[];
 
     const int tid = threadIdx.x;
     int b = blockIdx.x;
@@ -97,18 +146,20 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
     const int ngx = 2 * gxw;                               // granules per staged row
     const int slot_words = gy * pitch;
     const int stage_words = ns * slot_words;
+    unsigned *lds = lds_raw + p.oy * pitch;
     unsigned *mring = lds + (k + 1) * stage_words;         // HAS_MASK: nms slots
+    const int dump = ((k + 1) * ns + (HAS_MASK ? p.nms : 0)) * slot_words + p.hy * pitch + tid;   // word index
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx;
     const size_t plane_elems = (size_t)ny * (size_t)nx;
     const unsigned inv16 = p.invert ? 0xffffu : 0u;
     const unsigned border32 = p.border ? 0xffffffffu : 0u;
 
-    // ---- staging recipe: granule g = tid + 256 i of the gy x ngx staged granules
+    // ---- staging recipe: granule g = tid + NT i of the gy x ngx staged granules
     unsigned voff[NL];
-    int ldsb[NL];                                          // byte offset inside a slot, -1 = nothing to stage
+    int ldsb[NL];                                          // byte offset inside a slot (the dump word: nothing to stage)
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-        const int g = tid + kBmNT * i;
+        const int g = tid + NT * i;
         const int row = g / ngx, col = g - row * ngx;
         const int y = row_first + row, xg = 2 * xw_first + col;
         const bool staged = g < gy * ngx;
@@ -116,63 +167,65 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
         voff[i] = inside ? (unsigned)(y * nx + 16 * xg) : kOOB;
         ldsb[i] = staged ? (row * pitch + 1) * 4 + 2 * col : -1;
     }
-    // ---- stage recipe: word q = tid + 256 i of the gy x gxw staged words
-    int woff[NW], wrow[NW];
+    // ---- stage recipe: word q = tid + NT i of the gy x gxw staged words
+    int woff[NW];                                          // word offset inside a slot, -1 = none
+    int wrd[NW];                                           // the same for reads (a thread without a word reads word 0 of the slot)
     unsigned wvalid[NW];                                   // bits of the word that lie inside the array (0: row / word outside)
-    bool wown[NW];                                         // the word belongs to this tile's OUTPUT region (changed flags)
+    unsigned wown[NW];                                     // all ones: the word belongs to this tile's OUTPUT region (changed flags)
 #pragma unroll
     for (int i = 0; i < NW; i++) {
-        const int q = tid + kBmNT * i;
+        const int q = tid + NT * i;
         const int row = q / gxw, wc = q - row * gxw;
         const int y = row_first + row;
         const int xbit = 32 * (xw_first + wc);
         const bool staged = q < gy * gxw;
         woff[i] = staged ? row * pitch + 1 + wc : -1;
-        wrow[i] = row;
+        wrd[i] = staged ? woff[i] : 1;
         unsigned vm = 0;
         if (staged && y >= 0 && y < ny && xbit >= 0 && xbit < nx)
             vm = nx - xbit >= 32 ? 0xffffffffu : ((1u << (nx - xbit)) - 1u);
         wvalid[i] = vm;
-        wown[i] = staged && row >= k * p.oy && row < k * p.oy + p.ty && wc >= p.hlw && wc < p.hlw + p.txw;
+        wown[i] = (staged && row >= k * p.oy && row < k * p.oy + p.ty && wc >= p.hlw && wc < p.hlw + p.txw) ? 0xffffffffu : 0u;
     }
-    // ---- output recipe: granule g = tid + 256 i of the ty x (2 txw) output granules
+    // ---- output recipe: granule g = tid + NT i of the ty x (2 txw) output granules
     const int ogx = 2 * p.txw;
     unsigned ovoff[NL];
     int olds[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-        const int g = tid + kBmNT * i;
+        const int g = tid + NT * i;
         const int row = g / ogx, col = g - row * ogx;
         const int y = y0 + row, xg = 2 * xw0 + col;
         const bool live = g < p.ty * ogx && y < ny && 16 * xg < nx;
-        ovoff[i] = live ? (unsigned)(y * nx + 16 * xg) : kOOB;
-        olds[i] = ((k * p.oy + row) * pitch + 1 + p.hlw) * 4 + 2 * col;
-        if (!(g < p.ty * ogx)) olds[i] = 0;
+        ovoff[i] = live ? (unsigned)(y * nx + 16 * xg) : kOOB;                 // a store at kOOB is dropped by the descriptor
+        olds[i] = g < p.ty * ogx ? ((k * p.oy + row) * pitch + 1 + p.hlw) * 4 + 2 * col : 0;
     }
 
     // the pad words either side of every staged row hold the border bit for good (a tile edge that is not an array
     // edge may read anything there: its outermost k * reach columns are recomputed by the neighbour)
     {
         const int nrows_all = ((k + 1) * ns + (HAS_MASK ? p.nms : 0)) * gy;
-        for (int r = tid; r < nrows_all; r += kBmNT) {
+        for (int r = tid; r < nrows_all; r += NT) {
             lds[r * pitch] = border32;
             lds[r * pitch + gxw + 1] = border32;
         }
     }
 
-    u32x4 pin[NL], pmk[NL];
-    bool pin_out = false;
-    auto fetch = [&](int s) {
+    const int last_fetch = nout - 1 + k * (wz - 1);         // the last k + 1 steps of a chunk only drain the stages
+    // Every path through a step issues the SAME number of vector-memory operations (planes that are not there are
+    // fetched at kOOB offsets, which the descriptor answers with zeros without touching memory; stores at kOOB are
+    // dropped): the compiler's s_waitcnt insertion can then count how many younger operations may stay in flight when a
+    // plane is consumed -- with conditional fetches it has to assume none and every step would wait for the write
+    // acknowledgements of the step before it.
+    auto fetch = [&](int s, u32x4 (&pin)[NL], u32x4 (&pmk)[NL], bool &pout) {
         // input plane A0(s) = zs - k oz + s; mask plane A0(s) - hz (what stage 1 works on in the NEXT step)
-        // (the last k + 1 steps of a chunk only drain the stages: nothing any output depends on is left to fetch)
         int zsrc = zs - k * p.oz + s;
-        pin_out = (unsigned)zsrc >= (unsigned)nz || s > nout - 1 + k * (wz - 1);
-        zsrc = pin_out ? 0 : zsrc;
+        pout = (unsigned)zsrc >= (unsigned)nz || s > last_fetch;
+        zsrc = pout ? 0 : zsrc;
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(in + (size_t)zsrc * plane_elems), 0, (int)plane_bytes, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NL; i++)
-            if (!pin_out) pin[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, voff[i], 0, 0);
+        for (int i = 0; i < NL; i++) pin[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, pout ? kOOB : voff[i], 0, 0);
         if constexpr (HAS_MASK) {
             int zm = zs - k * p.oz + s - p.hz;
             const bool mout = (unsigned)zm >= (unsigned)nz || zm > ze - 1 + (k - 1) * p.hz;
@@ -180,37 +233,35 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
             const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(msk + (size_t)zm * plane_elems), 0, (int)plane_bytes, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < NL; i++)
-                pmk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, mout ? kOOB : voff[i], 0, 0);
+            for (int i = 0; i < NL; i++) pmk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, mout ? kOOB : voff[i], 0, 0);
         }
     };
 
     unsigned chg = 0;                                       // bit j - 1: iteration j changed a voxel of this tile
-    const int nsteps = nout + k * wz + 1;
-    fetch(0);
-    __syncthreads();
-    for (int s = 0; s < nsteps; s++) {
-        const int wslot = s % ns;
-        // ---- stage 0: the plane fetched during the previous step, as bits
+    const int nsteps = (nout + k * wz + 1 + 1) & ~1;       // even: the loop body is two steps; a step too many stores nothing
+    int wslot = 0, pslot = ns - 1, mslot = 0;               // s % ns, (s - 1) % ns, s % nms
+
+    auto step = [&](int s, u32x4 (&pin)[NL], u32x4 (&pmk)[NL], bool &pout) {
+        // ---- stage 0: the plane fetched two steps ago, as bits
         {
             unsigned char *slot = reinterpret_cast<unsigned char *>(lds + wslot * slot_words);
+            unsigned char *dumpb = reinterpret_cast<unsigned char *>(lds + dump);
 #pragma unroll
             for (int i = 0; i < NL; i++) {
-                if (ldsb[i] < 0) continue;
-                const bool o = pin_out || voff[i] == kOOB;
-                const unsigned g16 = o ? border32 : (pack16(pin[i]) ^ inv16);
-                *reinterpret_cast<unsigned short *>(slot + ldsb[i]) = (unsigned short)g16;
+                // no branch: a granule outside the array (or a plane that is not there) packs the zeros its kOOB load
+                // returned and is replaced by the border bits with one select
+                const unsigned om = (pout || voff[i] == kOOB) ? 0xffffffffu : 0u;
+                const unsigned g16 = ((pack16(pin[i]) ^ inv16) & ~om) | (border32 & om);
+                *reinterpret_cast<unsigned short *>(ldsb[i] < 0 ? dumpb : slot + ldsb[i]) = (unsigned short)g16;
             }
             if constexpr (HAS_MASK) {
-                unsigned char *mslot = reinterpret_cast<unsigned char *>(mring + (s % p.nms) * slot_words);
+                unsigned char *mslotp = reinterpret_cast<unsigned char *>(mring + mslot * slot_words);
 #pragma unroll
-                for (int i = 0; i < NL; i++) {
-                    if (ldsb[i] < 0) continue;
-                    *reinterpret_cast<unsigned short *>(mslot + ldsb[i]) = (unsigned short)pack16(pmk[i]);
-                }
+                for (int i = 0; i < NL; i++)
+                    *reinterpret_cast<unsigned short *>(ldsb[i] < 0 ? dumpb : mslotp + ldsb[i]) = (unsigned short)pack16(pmk[i]);
             }
         }
-        if (s + 1 < nsteps) fetch(s + 1);
+        fetch(s + 2, pin, pmk, pout);
 
         // ---- stages 1 .. k: plane A0(s) - j (1 + hz) from the ring of stage j - 1 (written in earlier steps)
         for (int j = 1; j <= k; j++) {
@@ -218,76 +269,140 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
             const unsigned *src = lds + (j - 1) * stage_words;
             unsigned *dst = lds + j * stage_words + wslot * slot_words;
             const bool plane_in = (unsigned)zj < (unsigned)nz;          // uniform
-            unsigned acc[NW];
+            unsigned res[NW];
 #pragma unroll
-            for (int i = 0; i < NW; i++) acc[i] = 0xffffffffu;
-            if (plane_in) {
-                for (int r = 0; r < p.nrows; r++) {
-                    const int tz = p.rowpos[r] & 255, ty = p.rowpos[r] >> 8;
-                    const unsigned m = p.rowmask[r];
-                    const unsigned *sl = src + ((s + 1 + tz) % ns) * slot_words;
-                    const bool sides = (m & ~(1u << p.ox)) != 0;
+            for (int i = 0; i < NW; i++) res[i] = 0xffffffffu;
+            if (plane_in && KIND != 0) {
+                int so[3];
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    int sl = wslot + 1 + t;
+                    sl -= sl >= ns ? ns : 0;
+                    so[t] = sl * slot_words * 4;
+                }
+#pragma unroll
+                for (int i = 0; i < NW; i++) {
+                    const char *c = reinterpret_cast<const char *>(src) + wrd[i] * 4;
+                    if constexpr (KIND == 1) res[i] = bm_fixed_word<BmCross>(c, so, pitch * 4);
+                    else if constexpr (KIND == 2) res[i] = bm_fixed_word<BmConn18>(c, so, pitch * 4);
+                    else res[i] = bm_fixed_word<BmCube3>(c, so, pitch * 4);
+                }
+            }
+            if (plane_in && KIND == 0) {
+                unsigned aL[NW], aC[NW], aR[NW];
+#pragma unroll
+                for (int i = 0; i < NW; i++) aL[i] = aC[i] = aR[i] = 0xffffffffu;
+                for (int r = 0; r < p.nrows; r += 2) {
+                    const int e0 = p.rows[r][0], m = p.rows[r][1], ro0 = p.rows[r][2];
+                    const int e1 = p.rows[r + 1][0], ro1 = p.rows[r + 1][2];
+                    int s0 = wslot + 1 + (e0 & 255), s1 = wslot + 1 + (e1 & 255);
+                    s0 -= s0 >= ns ? ns : 0;
+                    s1 -= s1 >= ns ? ns : 0;
+                    const char *b0 = reinterpret_cast<const char *>(src + s0 * slot_words) + ro0;
+                    const char *b1 = reinterpret_cast<const char *>(src + s1 * slot_words) + ro1;
+                    const bool sides = ((unsigned)m & ~(1u << p.ox)) != 0;
+                    unsigned c0[NW], c1[NW], l0[NW], l1[NW], r0[NW], r1[NW];
 #pragma unroll
                     for (int i = 0; i < NW; i++) {
-                        if (woff[i] < 0) continue;
-                        const int rr = min(max(wrow[i] + ty - p.oy, 0), gy - 1);
-                        const unsigned *a = sl + woff[i] + (rr - wrow[i]) * pitch;
-                        const unsigned C = a[0];
-                        unsigned L = 0, R = 0;
-                        if (sides) { L = a[-1]; R = a[1]; }
-                        unsigned mm = m;
+                        const int wo = wrd[i] * 4;
+                        const unsigned *a0 = reinterpret_cast<const unsigned *>(b0 + wo);
+                        const unsigned *a1 = reinterpret_cast<const unsigned *>(b1 + wo);
+                        c0[i] = a0[0];
+                        c1[i] = a1[0];
+                        if (sides) { l0[i] = a0[-1]; r0[i] = a0[1]; l1[i] = a1[-1]; r1[i] = a1[1]; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NW; i++) {
+                        aC[i] &= c0[i] & c1[i];
+                        if (sides) { aL[i] &= l0[i] & l1[i]; aR[i] &= r0[i] & r1[i]; }
+                    }
+                    if (e1 & 256) {                         // last pair of the rows that share this dx mask
+                        unsigned mm = (unsigned)m;
                         while (mm) {
                             const int tx = __builtin_ctz(mm);
                             mm &= mm - 1;
                             const int dx = tx - p.ox;
-                            unsigned v;
-                            if (dx == 0) v = C;
-                            else if (dx > 0) v = __builtin_amdgcn_alignbit(R, C, (unsigned)dx);
-                            else v = __builtin_amdgcn_alignbit(C, L, (unsigned)(32 + dx));
-                            acc[i] &= v;
+#pragma unroll
+                            for (int i = 0; i < NW; i++) {
+                                unsigned v;
+                                if (dx == 0) v = aC[i];
+                                else if (dx > 0) v = __builtin_amdgcn_alignbit(aR[i], aC[i], (unsigned)dx);
+                                else v = __builtin_amdgcn_alignbit(aC[i], aL[i], (unsigned)(32 + dx));
+                                res[i] &= v;
+                            }
                         }
+#pragma unroll
+                        for (int i = 0; i < NW; i++) aL[i] = aC[i] = aR[i] = 0xffffffffu;
                     }
                 }
             }
             // centre word of the previous stage (mask blend, changed flag): plane zj is tz = oz of the window
-            const unsigned *cs = src + ((s + 1 + p.oz) % ns) * slot_words;
-            const bool count = plane_in && zj >= zs && zj < ze;
+            int cslot = wslot + 1 + p.oz;
+            cslot -= cslot >= ns ? ns : 0;
+            const unsigned *cs = src + cslot * slot_words;
+            const unsigned count = (plane_in && zj >= zs && zj < ze) ? 0xffffffffu : 0u;
+            int mj = 0;
+            if constexpr (HAS_MASK) {
+                mj = mslot + p.hz - j * (1 + p.hz);         // mask plane zj was staged at step s' with A0(s') - hz = zj
+                mj += mj < 0 ? p.nms : 0;
+            }
 #pragma unroll
             for (int i = 0; i < NW; i++) {
-                if (woff[i] < 0) continue;
-                unsigned res = acc[i];
+                const int wo = wrd[i];
+                unsigned r = border32;
                 if (plane_in) {
-                    const unsigned cur = cs[woff[i]];
+                    const unsigned cur = cs[wo];
+                    r = res[i];
                     if constexpr (HAS_MASK) {
-                        // mask plane zj was staged at step s' with A0(s') - hz = zj
-                        const unsigned mk = mring[((s - j * (1 + p.hz) + p.hz + 2 * p.nms * 64) % p.nms) * slot_words + woff[i]];
-                        res = (res & mk) | (cur & ~mk);
+                        const unsigned mk = mring[mj * slot_words + wo];
+                        r = (r & mk) | (cur & ~mk);
                     }
-                    if (count && wown[i]) chg |= ((res ^ cur) & wvalid[i]) ? (1u << (j - 1)) : 0u;
-                    res = (res & wvalid[i]) | (border32 & ~wvalid[i]);
-                } else {
-                    res = border32;
+                    chg |= ((r ^ cur) & wvalid[i] & wown[i] & count) ? (1u << (j - 1)) : 0u;
+                    r = (r & wvalid[i]) | (border32 & ~wvalid[i]);
                 }
-                dst[woff[i]] = res;
+                dst[woff[i] < 0 ? dump - wslot * slot_words - j * stage_words : woff[i]] = r;
             }
         }
 
         // ---- output: plane A0(s) - 1 - k (1 + hz), finished by stage k in the previous step
         {
             const int zo = zs + s - 1 - k * wz;
-            if (zo >= zs && zo < ze) {
-                const unsigned char *slot = reinterpret_cast<const unsigned char *>(lds + k * stage_words + ((s - 1) % ns) * slot_words);
-                const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-                    (void *)(out + (size_t)zo * plane_elems), 0, (int)plane_bytes, 0x00020000);
+            const bool live = zo >= zs && zo < ze;
+            const unsigned char *slot = reinterpret_cast<const unsigned char *>(lds + k * stage_words + pslot * slot_words);
+            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(out + (size_t)(live ? zo : 0) * plane_elems), 0, (int)plane_bytes, 0x00020000);
+            unsigned w[NL];
 #pragma unroll
-                for (int i = 0; i < NL; i++) {
-                    if (ovoff[i] == kOOB) continue;
-                    const unsigned w = *reinterpret_cast<const unsigned short *>(slot + olds[i]);
-                    __builtin_amdgcn_raw_buffer_store_b128(unpack16(w ^ inv16), rout, ovoff[i], 0, 0);
-                }
-            }
+            for (int i = 0; i < NL; i++) w[i] = *reinterpret_cast<const unsigned short *>(slot + olds[i]);
+#pragma unroll
+            for (int i = 0; i < NL; i++)
+                __builtin_amdgcn_raw_buffer_store_b128(unpack16(w[i] ^ inv16), rout, live ? ovoff[i] : kOOB, 0, 0);
         }
+        pslot = wslot;
+        wslot = wslot + 1 == ns ? 0 : wslot + 1;
+        if constexpr (HAS_MASK) mslot = mslot + 1 == p.nms ? 0 : mslot + 1;
         __syncthreads();
+    };
+
+    // two planes in flight per thread: buffer A holds the planes of the even steps, B those of the odd ones
+    u32x4 pinA[NL], pinB[NL], pmkA[HAS_MASK ? NL : 1], pmkB[HAS_MASK ? NL : 1];
+    bool outA = true, outB = true;
+    if constexpr (HAS_MASK) {
+        fetch(0, pinA, pmkA, outA);
+        fetch(1, pinB, pmkB, outB);
+    } else {
+        fetch(0, pinA, pinA, outA);
+        fetch(1, pinB, pinB, outB);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; s += 2) {
+        if constexpr (HAS_MASK) {
+            step(s, pinA, pmkA, outA);
+            step(s + 1, pinB, pmkB, outB);
+        } else {
+            step(s, pinA, pinA, outA);
+            step(s + 1, pinB, pinB, outB);
+        }
     }
     if (flags) {
         for (int j = 0; j < k; j++)
@@ -296,23 +411,23 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
 }
 
 // test / tuning hook: on = 0 never, 1 the production rule, 2 also on small volumes; (ty, nzc) of the next launches, 0 = the planner's
-static Knob g_bm_ty{0}, g_bm_nzc{0}, g_bm_on{1};
+static Knob g_bm_ty{0}, g_bm_nzc{0}, g_bm_on{1}, g_bm_kind0{0};
 
-template <bool HAS_MASK, int NL>
+template <bool HAS_MASK, int NL, int NT, int KIND>
 static int launch_bitmorph(const unsigned char *in, unsigned char *out, const unsigned char *msk, const BitMorphParams &p,
                            size_t lds, int32_t *flags, hipStream_t s)
 {
     static PerDeviceOnce attr;
     if (!attr) {
-        MI_HIP(hipFuncSetAttribute((const void *)bitmorph3_kernel<HAS_MASK, NL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        MI_HIP(hipFuncSetAttribute((const void *)bitmorph3_kernel<HAS_MASK, NL, NT, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kBmMaxLds));
         attr = true;
     }
     const int64_t total = (int64_t)p.nxt * p.nyt * p.nzc;
-    hipLaunchKernelGGL((bitmorph3_kernel<HAS_MASK, NL>), dim3((unsigned)total), dim3(kBmNT), lds, s, in, out, msk, p, flags);
+    hipLaunchKernelGGL((bitmorph3_kernel<HAS_MASK, NL, NT, KIND>), dim3((unsigned)total), dim3(NT), lds, s, in, out, msk, p, flags);
     MI_HIP(hipGetLastError());
-    note_kernel("mi::bitmorph3_kernel<%s,%d> grid=%lld k=%d tile=%dx%d rows, %d planes (1 bit per voxel, %d fused iteration%s per launch)",
-                HAS_MASK ? "mask" : "nomask", NL, (long long)total, p.k, p.ty, p.txw * 32, p.zc, p.k, p.k == 1 ? "" : "s");
+    note_kernel("mi::bitmorph3_kernel<%s,%d,%d,%s> grid=%lld k=%d tile=%dx%d rows, %d planes (1 bit per voxel, %d fused iteration%s per launch)",
+                HAS_MASK ? "mask" : "nomask", NL, NT, KIND == 0 ? "table" : KIND == 1 ? "cross" : KIND == 2 ? "conn18" : "cube3", (long long)total, p.k, p.ty, p.txw * 32, p.zc, p.k, p.k == 1 ? "" : "s");
     return MI_OK;
 }
 
@@ -348,20 +463,36 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     p.k = k;
     p.invert = invert != 0;
     p.border = invert ? !border_value : (border_value != 0);
-    // rows of the structure that hold a tap; the reach along each axis is that of the SET taps' bounding box only as far
-    // as the halo goes, the extents themselves stay (an all-false outer row costs a staged row, nothing else)
-    int nrows = 0;
-    for (int tz = 0; tz < w[0]; tz++)
-        for (int ty = 0; ty < w[1]; ty++) {
-            unsigned m = 0;
-            for (int tx = 0; tx < w[2]; tx++)
-                if (structure[((int64_t)tz * w[1] + ty) * w[2] + tx]) m |= 1u << tx;
-            if (!m) continue;
-            if (nrows == kBmMaxRows) NOPE("structure has too many rows");
-            p.rowpos[nrows] = (unsigned short)(tz | ty << 8);
-            p.rowmask[nrows++] = m;
+    // rows (dz, dy) of the structure that hold a tap, grouped by their dx mask (the kernel ANDs the rows of a group word
+    // by word and shifts once per group); a group is padded to an even count by repeating its last row (AND is idempotent)
+    {
+        struct Row { int tz, ty; unsigned m; };
+        std::vector<Row> rows;
+        for (int tz = 0; tz < w[0]; tz++)
+            for (int ty = 0; ty < w[1]; ty++) {
+                unsigned m = 0;
+                for (int tx = 0; tx < w[2]; tx++)
+                    if (structure[((int64_t)tz * w[1] + ty) * w[2] + tx]) m |= 1u << tx;
+                if (m) rows.push_back({tz, ty, m});
+            }
+        std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.m < b.m; });
+        int n = 0;
+        for (size_t i = 0; i < rows.size();) {
+            size_t j = i;
+            while (j < rows.size() && rows[j].m == rows[i].m) j++;
+            const size_t cnt = j - i, padded = cnt + (cnt & 1);
+            if (n + (int)padded > kBmMaxRows) NOPE("structure has too many rows");
+            for (size_t q = 0; q < padded; q++) {
+                const Row &r = rows[i + std::min(q, cnt - 1)];
+                p.rows[n][0] = r.tz | (q + 1 == padded ? 256 : 0);
+                p.rows[n][1] = (int)r.m;
+                p.rows[n][2] = r.ty - off[1];               // x pitch x 4 once the pitch is known
+                n++;
+            }
+            i = j;
         }
-    p.nrows = nrows;                                        // 0: an empty structure erodes nothing (output = true)
+        p.nrows = n;                                        // 0: an empty structure erodes nothing (output = true)
+    }
     p.ns = p.wz + 1;
     p.nms = mask ? k * (1 + p.hz) - p.hz + 1 : 0;
 
@@ -377,26 +508,55 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     }
     p.pitch = p.gxw + 2;
     if (!(p.pitch & 1)) p.pitch++;                          // odd pitch: the rows of a column of words fall into different banks
+    for (int r = 0; r < p.nrows; r++) p.rows[r][2] *= p.pitch * 4;
     const int halo_y = k * (p.oy + p.hy);
     const int ngx = 2 * p.gxw;
-    const int max_gy = std::min(8 * kBmNT / ngx, (int)(kBmMaxLds / 4 / ((size_t)((k + 1) * p.ns + p.nms) * p.pitch)));
+    const int nt = kBmNT;
+    const int lds_fixed = (p.oy + p.hy) * p.pitch + nt;      // slack rows + dump words
+    const int max_gy = std::min(8 * nt / ngx, (int)((kBmMaxLds / 4 - lds_fixed) / ((size_t)((k + 1) * p.ns + p.nms) * p.pitch)));
     if (max_gy - halo_y < 2) NOPE("structure / iteration count too large for one tile");
     const int cus = device_cus();
     const int64_t slots = 2 * (int64_t)cus;                 // two resident workgroups per CU saturate the memory system
-    double best = 1e300;
     int best_ty = 0, best_nzc = 1;
     const int ty_hi = (int)std::min<int64_t>(max_gy - halo_y, ny);
-    for (int ty = std::min(ty_hi, 2); ty <= ty_hi; ty++) {
-        const int gy = ty + halo_y;
-        const int64_t nyt = (ny + ty - 1) / ty;
-        const double step = (double)gy * ngx * (mask ? 2 : 1) + (double)ty * 2 * p.txw + 192.0 + 96.0 * k;
-        for (int nzc = 1; nzc <= std::min<int64_t>(nz, 256); nzc++) {
-            const int chunk = (int)((nz + nzc - 1) / nzc);
-            const int real = (int)((nz + chunk - 1) / chunk);
-            const int64_t wgs = nyt * p.nxt * real;
-            const double rounds = (double)((wgs + slots - 1) / slots);
-            const double cost = rounds * (chunk + k * p.wz + 1) * step;
-            if (cost < best) { best = cost; best_ty = ty; best_nzc = real; }
+    {
+        // the search is a few hundred candidates; one remembered plan per host thread makes a repeated call free (a
+        // 256^3 call is ~15 us of GPU time: the search must not cost more than the launch)
+        struct Key { int64_t nx, ny, nz; int k, w0, w1, w2, o0, o1, o2, mask, nt, cus, ty, nzc; };
+        static thread_local Key last_key = {};
+        static thread_local bool have = false;
+        const Key key = {nx, ny, nz, k, w[0], w[1], w[2], off[0], off[1], off[2], mask ? 1 : 0, nt, cus, 0, 0};
+        if (have && !memcmp(&key, &last_key, offsetof(Key, ty))) {
+            best_ty = last_key.ty;
+            best_nzc = last_key.nzc;
+        } else {
+            double best = 1e300;
+            for (int ty = std::min(ty_hi, 2); ty <= ty_hi; ty++) {
+                const int gy = ty + halo_y;
+                const int64_t tiles = ((ny + ty - 1) / ty) * p.nxt;
+                // what a step costs is what its threads issue: the staged granules rounded up to whole rounds of the
+                // workgroup (and to an instantiated NL), the same for the output granules, a fixed part per stage
+                int nlr = (gy * ngx + nt - 1) / nt;
+                nlr = nlr == 7 ? 8 : nlr;
+                const int nor = (ty * 2 * p.txw + nt - 1) / nt;
+                const double step = (double)nlr * nt * (mask ? 1.6 : 1.0) + 0.7 * nor * nt + 192.0 + 96.0 * k;
+                for (int64_t rounds = 1; rounds <= 8; rounds++) {
+                    // the largest chunk count that still fits `rounds` waves of workgroups, and one chunk fewer planes
+                    const int64_t fit = std::max<int64_t>(1, std::min<int64_t>(nz, slots * rounds / tiles));
+                    for (int64_t nzc : {fit, std::min<int64_t>(nz, fit + 1)}) {
+                        const int chunk = (int)((nz + nzc - 1) / nzc);
+                        const int real = (int)((nz + chunk - 1) / chunk);
+                        const int64_t wgs = tiles * real;
+                        const double cost = (double)((wgs + slots - 1) / slots) * (chunk + k * p.wz + 1) * step;
+                        if (cost < best) { best = cost; best_ty = ty; best_nzc = real; }
+                    }
+                    if (fit >= nz) break;
+                }
+            }
+            last_key = key;
+            last_key.ty = best_ty;
+            last_key.nzc = best_nzc;
+            have = true;
         }
     }
     if (g_bm_ty > 0 && g_bm_ty <= ty_hi) best_ty = g_bm_ty;
@@ -407,23 +567,54 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     p.zc = (int)((nz + best_nzc - 1) / best_nzc);
     p.nzc = (int)((nz + p.zc - 1) / p.zc);
     if ((int64_t)p.nxt * p.nyt * p.nzc > 0x7fffffff) NOPE("too many tiles");
-    const size_t lds = (size_t)((k + 1) * p.ns + p.nms) * p.gy * p.pitch * 4;
+    const size_t lds = ((size_t)((k + 1) * p.ns + p.nms) * p.gy * p.pitch + lds_fixed) * 4;
     if (lds > (size_t)kBmMaxLds) NOPE("does not fit LDS");
-    const int nl = (p.gy * ngx + kBmNT - 1) / kBmNT;
+    const int nl = (p.gy * ngx + nt - 1) / nt;
 
     const unsigned char *ip = (const unsigned char *)in->data;
     unsigned char *op = (unsigned char *)out->data;
     const unsigned char *mp = mask ? (const unsigned char *)mask->data : nullptr;
-#define GO(NLV) return mp ? launch_bitmorph<true, NLV>(ip, op, mp, p, lds, flags, s) : launch_bitmorph<false, NLV>(ip, op, mp, p, lds, flags, s)
+    // a structure the kernel has straight-line code for (origin 0)?
+    int kind = 0;
+    if (w[0] == 3 && w[1] == 3 && w[2] == 3 && off[0] == 1 && off[1] == 1 && off[2] == 1) {
+        int cnt[4] = {0, 0, 0, 0};                          // set taps by city-block distance from the centre
+        bool shells = true;
+        for (int t = 0; t < 27; t++) {
+            const int d = abs(t / 9 - 1) + abs(t / 3 % 3 - 1) + abs(t % 3 - 1);
+            if (structure[t]) cnt[d]++;
+        }
+        const int full[4] = {1, 6, 12, 8};
+        for (int d = 0; d < 4; d++) shells = shells && (cnt[d] == 0 || cnt[d] == full[d]);
+        if (shells && cnt[0] == 1 && cnt[1] == 6) {
+            if (cnt[2] == 0 && cnt[3] == 0) kind = 1;
+            else if (cnt[2] == 12 && cnt[3] == 0) kind = 2;
+            else if (cnt[2] == 12 && cnt[3] == 8) kind = 3;
+        }
+    }
+    if (mp && kind > 1) kind = 0;                           // masked runs: the default structure and the table only
+    if (g_bm_kind0) kind = 0;
+#define GO3(NLV, KV) return mp ? launch_bitmorph<true, NLV, 256, (KV) <= 1 ? (KV) : 0>(ip, op, mp, p, lds, flags, s) \
+                               : launch_bitmorph<false, NLV, 256, KV>(ip, op, mp, p, lds, flags, s)
+#define GO(NLV) do { if (kind == 1) { GO3(NLV, 1); } else if (kind == 2) { GO3(NLV, 2); } else if (kind == 3) { GO3(NLV, 3); } else { GO3(NLV, 0); } } while (0)
+    if (nl <= 1) { GO(1); }
     if (nl <= 2) { GO(2); }
+    if (nl <= 3) { GO(3); }
     if (nl <= 4) { GO(4); }
+    if (nl <= 5) { GO(5); }
     if (nl <= 6) { GO(6); }
     GO(8);
 #undef GO
+#undef GO3
 #undef NOPE
 }
 
 }  // namespace mi
+
+extern "C" int mi_debug_set_bitmorph_table(int on)      // 1: the run-time structure table even for the built-in structures
+{
+    mi::g_bm_kind0 = on;
+    return MI_OK;
+}
 
 extern "C" int mi_debug_set_bitmorph(int on, int ty, int nzc)
 {

@@ -22,10 +22,13 @@ def ndi(gpu):
 @pytest.fixture()
 def knob(gpu):
     from cupyimg_amd import _lib
-    fn = _lib.load().mi_debug_set_bitmorph
+    lib = _lib.load()
+    fn = lib.mi_debug_set_bitmorph
     fn.argtypes = [ctypes.c_int] * 3
+    lib.mi_debug_set_bitmorph_table.argtypes = [ctypes.c_int]
     yield fn
     fn(1, 0, 0)
+    lib.mi_debug_set_bitmorph_table(0)
 
 
 def _ball(r):
@@ -36,6 +39,7 @@ def _ball(r):
 STRUCTS = {
     "cross": None,
     "cube3": np.ones((3, 3, 3), bool),
+    "conn18": sndi.generate_binary_structure(3, 2),
     "rand537": np.random.default_rng(5).random((5, 3, 7)) > 0.4,
     "even243": np.ones((2, 4, 3), bool),
     "rand399": np.random.default_rng(6).random((3, 9, 9)) > 0.5,
@@ -60,8 +64,12 @@ def test_bitmorph_matches_oracle(gpu, ndi, knob, shape, sname):
     cases = [dict(), dict(border_value=1), dict(iterations=2), dict(iterations=3, border_value=1), dict(iterations=5),
              dict(mask=True), dict(mask=True, iterations=3), dict(mask=True, iterations=6, border_value=1),
              dict(origin=1 if smin >= 3 else 0), dict(origin=(-1, 0, 1) if smin >= 3 else 0, iterations=2)]
-    for tiles in [(2, 0, 0), (2, 5, 3)]:               # the planner's tiles; 5 output rows per tile, 3 z chunks
-        knob(*tiles)
+    from cupyimg_amd import _lib
+    # the planner's tiles; 5 output rows per tile and 3 z chunks; the built-in structures once more through the run-time table
+    for tiles in [(2, 0, 0), (2, 5, 3)] + ([(2, 0, 0, "table")] if sname in ("cross", "cube3", "conn18") else []):
+        knob(*tiles[:3])
+        _lib.load().mi_debug_set_bitmorph_table(int(len(tiles) > 3))
+        want = "table" if (len(tiles) > 3 or sname not in ("cross", "cube3", "conn18")) else sname
         for fn, ofn in [(ndi.binary_erosion, orc.binary_erosion), (ndi.binary_dilation, orc.binary_dilation)]:
             for kw in cases:
                 kg, ko = dict(kw), dict(kw)
@@ -69,6 +77,8 @@ def test_bitmorph_matches_oracle(gpu, ndi, knob, shape, sname):
                     kg["mask"], ko["mask"] = md, m
                 got = fn(xd, st, **kg).get()
                 assert "bitmorph3_kernel" in last_kernel(), last_kernel()
+                if not (kw.get("mask") and want in ("cube3", "conn18")) and not kw.get("origin"):
+                    assert "," + want + ">" in last_kernel(), (want, last_kernel())
                 ref = ofn(x, st, **ko)
                 assert np.array_equal(got, ref), (fn.__name__, sname, kw, tiles, int((got != ref).sum()))
 
