@@ -496,6 +496,26 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     p.ns = p.wz + 1;
     p.nms = mask ? k * (1 + p.hz) - p.hz + 1 : 0;
 
+    // a structure the kernel has straight-line code for (origin 0)?
+    int kind = 0;
+    if (w[0] == 3 && w[1] == 3 && w[2] == 3 && off[0] == 1 && off[1] == 1 && off[2] == 1) {
+        int cnt[4] = {0, 0, 0, 0};                          // set taps by city-block distance from the centre
+        bool shells = true;
+        for (int t = 0; t < 27; t++) {
+            const int d = abs(t / 9 - 1) + abs(t / 3 % 3 - 1) + abs(t % 3 - 1);
+            if (structure[t]) cnt[d]++;
+        }
+        const int full[4] = {1, 6, 12, 8};
+        for (int d = 0; d < 4; d++) shells = shells && (cnt[d] == 0 || cnt[d] == full[d]);
+        if (shells && cnt[0] == 1 && cnt[1] == 6) {
+            if (cnt[2] == 0 && cnt[3] == 0) kind = 1;
+            else if (cnt[2] == 12 && cnt[3] == 0) kind = 2;
+            else if (cnt[2] == 12 && cnt[3] == 8) kind = 3;
+        }
+    }
+    if (mask && kind > 1) kind = 0;                           // masked runs: the default structure and the table only
+    if (g_bm_kind0) kind = 0;
+
     // ---- tile geometry
     const int words = (int)((nx + 31) / 32);
     const int hx = w[2] - 1 - off[2];
@@ -515,17 +535,23 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     const int lds_fixed = (p.oy + p.hy) * p.pitch + nt;      // slack rows + dump words
     const int max_gy = std::min(8 * nt / ngx, (int)((kBmMaxLds / 4 - lds_fixed) / ((size_t)((k + 1) * p.ns + p.nms) * p.pitch)));
     if (max_gy - halo_y < 2) NOPE("structure / iteration count too large for one tile");
+    // at most three (else four) granules per thread -- 7 (5) resident waves per SIMD; 1024^3: 8-row tiles with NL 3 run
+    // 384-400 us, 29-row tiles with NL 8 408 us -- while that leaves tiles at least as tall as their halo
+    // (the run-time table pays a fixed scalar cost per step: large tiles amortise it -- ball(2) on 1024^3: 497 us on
+    // 27-row tiles, 862 us on 8-row tiles)
+    const int min_ty = std::max(halo_y, 4);
+    const int max_gy4 = kind == 0 ? max_gy : 3 * nt / ngx - halo_y >= 4 * halo_y ? 3 * nt / ngx : 4 * nt / ngx;
     const int cus = device_cus();
     const int64_t slots = 2 * (int64_t)cus;                 // two resident workgroups per CU saturate the memory system
     int best_ty = 0, best_nzc = 1;
-    const int ty_hi = (int)std::min<int64_t>(max_gy - halo_y, ny);
+    const int ty_hi = (int)std::min<int64_t>((max_gy4 - halo_y >= min_ty ? std::min(max_gy, max_gy4) : max_gy) - halo_y, ny);
     {
         // the search is a few hundred candidates; one remembered plan per host thread makes a repeated call free (a
         // 256^3 call is ~15 us of GPU time: the search must not cost more than the launch)
-        struct Key { int64_t nx, ny, nz; int k, w0, w1, w2, o0, o1, o2, mask, nt, cus, ty, nzc; };
+        struct Key { int64_t nx, ny, nz; int k, w0, w1, w2, o0, o1, o2, mask, nt, cus, kind, ty, nzc; };
         static thread_local Key last_key = {};
         static thread_local bool have = false;
-        const Key key = {nx, ny, nz, k, w[0], w[1], w[2], off[0], off[1], off[2], mask ? 1 : 0, nt, cus, 0, 0};
+        const Key key = {nx, ny, nz, k, w[0], w[1], w[2], off[0], off[1], off[2], mask ? 1 : 0, nt, cus, kind, 0, 0};
         if (have && !memcmp(&key, &last_key, offsetof(Key, ty))) {
             best_ty = last_key.ty;
             best_nzc = last_key.nzc;
@@ -539,7 +565,11 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
                 int nlr = (gy * ngx + nt - 1) / nt;
                 nlr = nlr == 7 ? 8 : nlr;
                 const int nor = (ty * 2 * p.txw + nt - 1) / nt;
-                const double step = (double)nlr * nt * (mask ? 1.6 : 1.0) + 0.7 * nor * nt + 192.0 + 96.0 * k;
+                // more than four granules per thread cost registers, i.e. resident waves (NL 3: 7 waves per SIMD, 4: 5,
+                // 6: 4, 8: 3); the halo rows a small tile re-reads come out of the L2 (measured: 1024^3 runs 6 % faster
+                // on 8-row tiles with NL 3 than on 29-row tiles with NL 8)
+                const double occ = nlr <= 4 ? 1.0 : nlr <= 6 ? 1.12 : 1.25;
+                const double step = ((double)nlr * nt * (mask ? 1.6 : 1.0) + 0.7 * nor * nt + 192.0 + 96.0 * k) * occ;
                 for (int64_t rounds = 1; rounds <= 8; rounds++) {
                     // the largest chunk count that still fits `rounds` waves of workgroups, and one chunk fewer planes
                     const int64_t fit = std::max<int64_t>(1, std::min<int64_t>(nz, slots * rounds / tiles));
@@ -574,25 +604,6 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     const unsigned char *ip = (const unsigned char *)in->data;
     unsigned char *op = (unsigned char *)out->data;
     const unsigned char *mp = mask ? (const unsigned char *)mask->data : nullptr;
-    // a structure the kernel has straight-line code for (origin 0)?
-    int kind = 0;
-    if (w[0] == 3 && w[1] == 3 && w[2] == 3 && off[0] == 1 && off[1] == 1 && off[2] == 1) {
-        int cnt[4] = {0, 0, 0, 0};                          // set taps by city-block distance from the centre
-        bool shells = true;
-        for (int t = 0; t < 27; t++) {
-            const int d = abs(t / 9 - 1) + abs(t / 3 % 3 - 1) + abs(t % 3 - 1);
-            if (structure[t]) cnt[d]++;
-        }
-        const int full[4] = {1, 6, 12, 8};
-        for (int d = 0; d < 4; d++) shells = shells && (cnt[d] == 0 || cnt[d] == full[d]);
-        if (shells && cnt[0] == 1 && cnt[1] == 6) {
-            if (cnt[2] == 0 && cnt[3] == 0) kind = 1;
-            else if (cnt[2] == 12 && cnt[3] == 0) kind = 2;
-            else if (cnt[2] == 12 && cnt[3] == 8) kind = 3;
-        }
-    }
-    if (mp && kind > 1) kind = 0;                           // masked runs: the default structure and the table only
-    if (g_bm_kind0) kind = 0;
 #define GO3(NLV, KV) return mp ? launch_bitmorph<true, NLV, 256, (KV) <= 1 ? (KV) : 0>(ip, op, mp, p, lds, flags, s) \
                                : launch_bitmorph<false, NLV, 256, KV>(ip, op, mp, p, lds, flags, s)
 #define GO(NLV) do { if (kind == 1) { GO3(NLV, 1); } else if (kind == 2) { GO3(NLV, 2); } else if (kind == 3) { GO3(NLV, 3); } else { GO3(NLV, 0); } } while (0)

@@ -40,11 +40,15 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 
 def build(force=False):
-    """Compile liboracle.so with gcc (oracle/Makefile)."""
-    so = os.path.join(_HERE, "liboracle.so")
+    """Compile liboracle.so with gcc (oracle/Makefile).  ORACLE_LIB=liboracle_asan.so in the environment selects the
+    AddressSanitizer + UBSan build instead (tests/test_oracle_sanitizer.py; the process must have libasan preloaded)."""
+    name = os.environ.get("ORACLE_LIB", "liboracle.so")
+    if name not in ("liboracle.so", "liboracle_asan.so"):
+        raise RuntimeError("ORACLE_LIB must be liboracle.so or liboracle_asan.so")
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "ndimage_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", name])
     return so
 
 

@@ -42,7 +42,10 @@ def vol512(gpu):
 
 def test_H_uniform5_512(gpu, ndi, vol512):
     x, xd = vol512
-    out = burst(lambda o: ndi.uniform_filter(xd, size=5, output=o)).get()
+    from cupyimg_amd import last_kernel
+    out = burst(lambda o: ndi.uniform_filter(xd, size=5, output=o))
+    assert "sep3d_long3_kernel<5," in last_kernel(), last_kernel()
+    out = out.get()
     err = fs.whole_volume_filter(x, out, 2, 2, lambda s: sndi.uniform_filter(s.astype(np.float64), size=5))
     assert err <= 1e-6, err
 
@@ -63,8 +66,11 @@ def test_H_neighbours_3_7_9_13_taps_512(gpu, ndi, vol512):
 
 
 def test_B_gaussian_sigma2_512(gpu, ndi, vol512):
+    from cupyimg_amd import last_kernel
     x, xd = vol512
-    out = burst(lambda o: ndi.gaussian_filter(xd, sigma=2, output=o)).get()
+    out = burst(lambda o: ndi.gaussian_filter(xd, sigma=2, output=o))
+    assert "sep3d_long3_kernel<17," in last_kernel(), last_kernel()      # r6: a dispatch regression must fail, not just run slower
+    out = out.get()
     # 17 taps per axis: halo 8
     err = fs.whole_volume_filter(x, out, 8, 8, lambda s: sndi.gaussian_filter(s.astype(np.float64), sigma=2), planes=16)
     assert err <= 1e-6, err
@@ -74,7 +80,9 @@ def test_D_map_coordinates_order1_512(gpu, ndi, vol512):
     x, xd = vol512
     coords = fs.affine_coords_f32(fs.N_H)
     cd = gpu.asarray(coords)
+    from cupyimg_amd import last_kernel
     out = burst(lambda o: ndi.map_coordinates(xd, cd, order=1, mode="constant", output=o))
+    assert "map_coords3d_zstream_kernel" in last_kernel(), last_kernel()
     assert out.dtype == np.float32 and out.shape == x.shape
     del cd
     err = fs.whole_volume_map_coordinates(x, coords, out.get())
@@ -84,7 +92,9 @@ def test_D_map_coordinates_order1_512(gpu, ndi, vol512):
 def test_Dprime_affine_transform_order1_512(gpu, ndi, vol512):
     x, xd = vol512
     M, off = fs.affine_case(fs.N_H)
+    from cupyimg_amd import last_kernel
     out = burst(lambda o: ndi.affine_transform(xd, M, off, order=1, mode="constant", output=o))
+    assert "affine3d_zrect_kernel" in last_kernel(), last_kernel()
     err = fs.whole_volume_affine(x, M, off, out.get())
     assert err <= 2e-6, err
 
@@ -115,7 +125,9 @@ def test_C_grey_erosion7_1024_u8(gpu, ndi):
     gpu.free_all_blocks()
     u = fs.volume_u8((fs.N_C,) * 3, seed=1)
     ud = gpu.asarray(u)
+    from cupyimg_amd import last_kernel
     out = burst(lambda o: ndi.grey_erosion(ud, size=7, output=o))
+    assert "mm3u8_split_kernel<7,min" in last_kernel(), last_kernel()
     assert out.dtype == np.uint8
     got = out.get()
     del ud, out
@@ -130,8 +142,10 @@ def test_E_slab_uniform9_264x2048x2048(gpu, ndi):
     x = fs.slab_volume_f32(fs.E_SLAB)
     xd = gpu.asarray(x)
     out = gpu.empty(x.shape, np.float32)
+    from cupyimg_amd import last_kernel
     for _ in range(8):
         ndi.uniform_filter(xd, size=9, output=out)
+    assert "sep3d_long3_kernel<9," in last_kernel(), last_kernel()
     got = out.get()
     del xd, out
     gpu.free_all_blocks()

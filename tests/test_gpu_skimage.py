@@ -215,6 +215,73 @@ def test_ssim_gradient_and_multichannel(gpu, metrics):
         metrics.structural_similarity(gpu.asarray(xc), gpu.asarray(yc))
 
 
+def test_ssim_reference_identities(gpu, metrics):
+    """The assertions the reference's own SSIM tests make that need no image file
+    (skimage/metrics/tests/test_structural_similarity.py: patch_range :25-33, image :36-58, grad :63-95, dtype :98-112,
+    multichannel :115-160, nD :163-172): ssim(X, X) == 1 exactly, decorrelated noise scores low, the full map / the
+    gradient have the image's shape, `full` does not change the mean, three identical channels score like one, the
+    multichannel mean is the mean of the channels, 1-D ... 4-D inputs work.  The reference draws from CuPy's RandomState;
+    the thresholds are statistical, so NumPy's RandomState with the same seeds serves."""
+    ssim = metrics.structural_similarity
+    rs = np.random.RandomState(1234)
+    N = 51
+    X = gpu.asarray((rs.rand(N, N) * 255).astype(np.uint8))
+    Y = gpu.asarray((rs.rand(N, N) * 255).astype(np.uint8))
+    assert ssim(X, Y, win_size=N) < 0.1                       # :31-33
+    assert ssim(X, X, win_size=N) == 1
+    N = 100
+    Xh, Yh = (rs.rand(N, N) * 255).astype(np.uint8), (rs.rand(N, N) * 255).astype(np.uint8)
+    X, Y = gpu.asarray(Xh), gpu.asarray(Yh)
+    assert ssim(X, X, win_size=3) == 1                        # :42-43
+    assert ssim(X, Y, win_size=3) < 0.3
+    assert ssim(X, Y, win_size=11, gaussian_weights=True) < 0.3
+    mssim0, S3 = ssim(X, Y, full=True)
+    assert S3.shape == X.shape                                # :51-54
+    assert mssim0 == ssim(X, Y)
+    assert ssim(X, X) == 1.0                                  # :57
+    for seed in (1, 2, 3, 5, 8, 13):                          # :63-95
+        rnd = np.random.RandomState(seed)
+        A, B = gpu.asarray(rnd.rand(N, N) * 255), gpu.asarray(rnd.rand(N, N) * 255)
+        f = ssim(A, B, data_range=255)
+        g = ssim(A, B, data_range=255, gradient=True)
+        assert f < 0.05 and g[0] < 0.05 and (g[1].get() < 0.05).all()
+        mssim, grad, smap = ssim(A, B, data_range=255, gradient=True, full=True)
+        assert (grad.get() < 0.05).all() and grad.shape == A.shape and smap.shape == A.shape
+    rs = np.random.RandomState(1234)                          # dtype :98-112
+    Xf, Yf = rs.rand(30, 30), rs.rand(30, 30)
+    assert ssim(gpu.asarray(Xf), gpu.asarray(Yf)) < 0.15
+    X8 = (Xf * 255).astype(np.uint8)
+    Y8 = (X8 * 255).astype(np.uint8)                          # (sic: the reference builds Y from X here)
+    assert ssim(gpu.asarray(X8), gpu.asarray(Y8)) < 0.15
+    S1 = ssim(X, Y, win_size=3)                               # multichannel :115-160
+    Xc, Yc = gpu.asarray(np.tile(Xh[..., None], (1, 1, 3))), gpu.asarray(np.tile(Yh[..., None], (1, 1, 3)))
+    S2 = ssim(Xc, Yc, multichannel=True, win_size=3)
+    assert abs(S1 - S2) < 1e-7
+    m, S3 = ssim(Xc, Yc, multichannel=True, full=True)
+    assert S3.shape == Xc.shape
+    m, grad = ssim(Xc, Yc, multichannel=True, gradient=True)
+    assert grad.shape == Xc.shape
+    m, grad, S3 = ssim(Xc, Yc, multichannel=True, full=True, gradient=True)
+    assert grad.shape == Xc.shape and S3.shape == Xc.shape
+    mssim = ssim(Xc, Yc, multichannel=True)
+    sep = [float(ssim(gpu.asarray(np.ascontiguousarray(Yc.get()[..., c])), gpu.asarray(np.ascontiguousarray(Xc.get()[..., c]))))
+           for c in range(3)]
+    assert abs(mssim - np.mean(sep)) < 1e-7
+    assert ssim(Xc, Xc, multichannel=True) == 1.0
+    with pytest.raises(ValueError):
+        ssim(Xc, Yc, win_size=7, multichannel=False)
+    rs = np.random.RandomState(7)                             # nD :163-172
+    for ndim in range(1, 5):
+        # the reference's loop builds [N] * 5 whatever `ndim` is (its xsize does not use the loop variable): 10^5 voxels in 5-D
+        A = gpu.asarray((rs.rand(*([10] * 5)) * 255).astype(np.uint8))
+        B = gpu.asarray((rs.rand(*([10] * 5)) * 255).astype(np.uint8))
+        assert ssim(A, B, win_size=3) < 0.05
+        # ... and what it meant to build: 1-D ... 4-D (10 ... 10^4 samples: a loose bound)
+        A = gpu.asarray((rs.rand(*([10] * ndim)) * 255).astype(np.uint8))
+        B = gpu.asarray((rs.rand(*([10] * ndim)) * 255).astype(np.uint8))
+        assert ssim(A, B, win_size=3) < 0.6, ndim
+
+
 def test_ssim_errors_and_warnings(gpu, metrics):
     X = gpu.zeros((9, 9), np.float64)
     with pytest.raises(ValueError):
