@@ -40,6 +40,7 @@ SOURCES = [
     ("minmax3d_f32.hip", []),
     ("correlate_nd.hip", ["-ffp-contract=off"]),
     ("stencil3d.hip", ["-ffp-contract=off"]),
+    ("stencil3s.hip", ["-ffp-contract=off"]),
     ("minmax.hip", ["-ffp-contract=off"]),
     ("median3d.hip", []),
     ("median3d_u8.hip", []),

@@ -74,6 +74,8 @@ corr3_kernel(const T *__restrict__ in, void *__restrict__ out, int out_dt, Geom3
 namespace mi {
 int stencil3_tiled(const mi_array *in, const mi_array *out, const double *weights, const int64_t *wshape,
                  const int *origins, int mode, double cval, bool acc_f32, hipStream_t s);   // stencil3d.hip
+int stencil3_scatter(const mi_array *in, const mi_array *out, const double *weights, const int64_t *wshape,
+                     const int *origins, int mode, double cval, bool acc_f32, hipStream_t s);   // stencil3s.hip
 }
 
 using namespace mi;
@@ -102,6 +104,8 @@ extern "C" int mi_correlate_nd(const mi_array *in, const mi_array *out, const do
     const bool f32ok = in->dtype == MI_F32 || in->dtype == MI_BOOL || dtype_size(in->dtype) <= 2;
     const bool use_f32 = acc_f32 && f32ok;
     if (g_stencil_enabled && in->dtype == out->dtype) {
+        rc = stencil3_scatter(in, out, weights, wshape, origins, mode, cval, use_f32, s);
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
         rc = stencil3_tiled(in, out, weights, wshape, origins, mode, cval, use_f32, s);
         if (rc != MI_ERR_UNSUPPORTED) return rc;
     }

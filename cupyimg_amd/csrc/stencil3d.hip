@@ -318,6 +318,8 @@ static int launch_stencil3(const T *in, T *out, Stencil3Params &p, hipStream_t s
     if (total > 0x7fffffff) { set_error("stencil: too many tiles"); return MI_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL((stencil3_kernel<WX, TY, Acc, DENSE, OP, T>), dim3((unsigned)total), dim3(kStNW * 64), lds, s, in, out, p);
     MI_HIP(hipGetLastError());
+    note_kernel("mi::stencil3_kernel<%d,%d,%s,%s,%s> grid=%lld (window planes in an LDS ring)", WX, TY, sizeof(Acc) == 8 ? "double" : "float",
+                DENSE ? "dense" : "mask", OP == ST_CORR ? "correlate" : OP == ST_MIN ? "min" : "max", (long long)total);
     return MI_OK;
 }
 

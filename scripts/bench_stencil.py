@@ -8,6 +8,7 @@ from cupyimg_amd.scipy import ndimage as ndi
 
 lib = _lib.load()
 lib.mi_debug_set_stencil.argtypes = [ctypes.c_int]
+lib.mi_debug_set_stencil_scatter.argtypes = [ctypes.c_int]
 
 def timeit(fn, reps=5):
     for _ in range(2): fn()
@@ -24,8 +25,16 @@ for n in (256, 512):
     o = ca.empty(x.shape, np.float32)
     for wshape in [(3, 3, 3), (5, 5, 5), (7, 7, 7), (3, 3, 1), (1, 5, 5)]:
         w = rng.standard_normal(wshape)
-        for dm in ("ndimage", "float"):
+        for dm in ("ndimage", "float", "ndimage/f32-weights"):
+            if dm.endswith("f32-weights"):
+                if wshape not in ((3, 3, 3), (5, 5, 5)):
+                    continue
+                w = w.astype(np.float32)                # float32-valued weights: exact products, v_fma_f64 (stencil3s.hip)
+                dm = "ndimage"
             res = []
+            lib.mi_debug_set_stencil_scatter(0)
+            ring = timeit(lambda: ndi.correlate(x, w, output=o, dtype_mode=dm), 3)
+            lib.mi_debug_set_stencil_scatter(1)
             for en in (1, 0):
                 if en == 0 and (n == 512 and np.prod(wshape) > 27):
                     res.append(float("nan")); continue
@@ -33,9 +42,9 @@ for n in (256, 512):
                 res.append(timeit(lambda: ndi.correlate(x, w, output=o, dtype_mode=dm), 3))
             lib.mi_debug_set_stencil(1)
             t = res[0]
-            print("correlate %s f32 %d^3 acc=%-7s tiled %8.3f ms (%6.0f GB/s alg, %4.1f%% of 8 TB/s)   generic %8.3f ms" % (
+            print("correlate %s f32 %d^3 acc=%-7s %8.3f ms (%6.0f GB/s alg, %4.1f%% of 8 TB/s)   LDS-ring kernel %8.3f ms   generic %8.3f ms   %s" % (
                 "x".join(map(str, wshape)), n, "f64" if dm == "ndimage" else "f32", t, 8 * n ** 3 / t / 1e6,
-                8 * n ** 3 / t / 1e6 / 80, res[1]), flush=True)
+                8 * n ** 3 / t / 1e6 / 80, ring, res[1], ca.last_kernel()[:34]), flush=True)
     x = o = None
     ca.free_all_blocks()
 x2 = ca.asarray(rng.standard_normal((8192, 8192), dtype=np.float32)); o2 = ca.empty(x2.shape, np.float32)
