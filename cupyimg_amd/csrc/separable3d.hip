@@ -377,12 +377,68 @@ __device__ __forceinline__ F4 xpass_packed(const F4 v, const float (&sL)[NE], co
     return o;
 }
 
+// r6: OP 1 / 2 = flat minimum / maximum instead of the weighted sum (the ragged build only: grey erosion / dilation and
+// min / max filters with a cubic `size` on rows that are not a multiple of 16 bytes used to run on explicitly extended
+// rows -- mi_extend_rows + the LDS-DMA kernel + mi_crop_rows, 55 us on 181 x 217 x 181 where uniform_filter(3) takes 16).
+// A pass is the compare-select form of the generic kernels (`x < best ? x : best` in ascending tap order, first tap
+// taken as is) evaluated as a v_min3 / v_max3 chain plus the first-tap NaN fix-up of minmax3d_f32.hip.
+template <bool IS_MAX, int N>
+__device__ __forceinline__ float lean_win(const float (&t)[N])
+{
+    float r = t[0];
+    static_for<(N - 1) / 2>([&](auto KK) {
+        constexpr int k = decltype(KK)::value;
+        r = IS_MAX ? __builtin_fmaxf(__builtin_fmaxf(r, t[1 + 2 * k]), t[2 + 2 * k]) : __builtin_fminf(__builtin_fminf(r, t[1 + 2 * k]), t[2 + 2 * k]);
+    });
+    if constexpr ((N - 1) % 2 == 1) r = IS_MAX ? __builtin_fmaxf(r, t[N - 1]) : __builtin_fminf(r, t[N - 1]);
+    return t[0] != t[0] ? t[0] : r;
+}
+template <bool IS_MAX, int N>
+__device__ __forceinline__ F4 lean_win4(const F4 (&t)[N])
+{
+    float a[N], b[N], c[N], d[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) { a[k] = t[k].lo.x; b[k] = t[k].lo.y; c[k] = t[k].hi.x; d[k] = t[k].hi.y; }
+    F4 o;
+    o.lo = (f32x2){lean_win<IS_MAX, N>(a), lean_win<IS_MAX, N>(b)};
+    o.hi = (f32x2){lean_win<IS_MAX, N>(c), lean_win<IS_MAX, N>(d)};
+    return o;
+}
+template <int WX, int NE, bool IS_MAX>
+__device__ __forceinline__ F4 xpass_minmax(const F4 v, const float (&sL)[NE], const float (&sR)[NE], int lane, int last)
+{
+    constexpr int RX = WX / 2;
+    const float c[4] = {v.lo.x, v.lo.y, v.hi.x, v.hi.y};
+    float e[4 + 2 * RX];
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[RX + j] = c[j];
+#pragma unroll
+    for (int j = 0; j < RX; j++) {
+        const float l = dpp_from_left(0.f, c[4 - RX + j]);
+        const float r = dpp_from_right(0.f, c[j]);
+        e[j] = lane == 0 ? sL[NE - RX + j] : l;
+        e[RX + 4 + j] = lane == last ? sR[j] : r;
+    }
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float t[WX];
+#pragma unroll
+        for (int k = 0; k < WX; k++) t[k] = e[q + k];
+        o[q] = lean_win<IS_MAX, WX>(t);
+    }
+    F4 r;
+    r.lo = (f32x2){o[0], o[1]};
+    r.hi = (f32x2){o[2], o[3]};
+    return r;
+}
+
 // RAGGED (r5): rows of any length >= 16 (181 x 217 x 181: 724-byte rows).  Rows then start on 4-byte boundaries only -- the
 // 16-byte buffer loads and stores do not mind -- and the LAST lane of the last x tile holds `tail` (1..3) floats of its row
 // followed by the head of the next one: those are replaced by the row's boundary continuation E[0], E[1], ... before the
 // x pass (E[0..7] come with the edge load: lanes 32 + r and 48 + r, four floats each), the floats right of the tile are
 // E[4 - tail ..], and the last lane stores `tail` floats.  No mi_extend_rows / mi_crop_rows copies around the launch.
-template <int W, int NWP, int NWC, int R, int DEPTH, bool HAS_CONST, bool RAGGED = false>
+template <int W, int NWP, int NWC, int R, int DEPTH, bool HAS_CONST, bool RAGGED = false, int OP = 0>
 __global__ void __launch_bounds__((NWP + NWC) * 64)
 sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const Sep3dParams p)
 {
@@ -566,14 +622,27 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
 #pragma unroll
                             for (int k = 0; k < RX; k++) sR[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eg[k]), 48 + r));
                         }
-                        xf[r] = xpass_packed<W, NE>(v, sL, sR, lane, last, p.wx);
+                        if constexpr (OP == 0) xf[r] = xpass_packed<W, NE>(v, sL, sR, lane, last, p.wx);
+                        else xf[r] = xpass_minmax<W, NE, OP == 2>(v, sL, sR, lane, last);
                     }
                     if (i + DEPTH < nsteps) issue(i + DEPTH, s);
                     if (emit) {
 #pragma unroll
                         for (int r = 0; r < R; r++) {
                             F4 a;
-                            if (rev) {          // the newest plane is the lowest: tap 0 first, the ring newest to oldest
+                            if constexpr (OP != 0) {
+                                F4 t[W];          // the W planes of the window in ascending z
+                                if (rev) {
+                                    t[0] = xf[r];
+#pragma unroll
+                                    for (int k = 1; k < W; k++) t[k] = ring[(J + RINGN - k) % RINGN][r];
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < RINGN; k++) t[k] = ring[(J + k) % RINGN][r];
+                                    t[W - 1] = xf[r];
+                                }
+                                a = lean_win4<OP == 2, W>(t);
+                            } else if (rev) {          // the newest plane is the lowest: tap 0 first, the ring newest to oldest
                                 a = f4_scale(p.wz[0], xf[r]);
 #pragma unroll
                                 for (int k = 1; k < W; k++) a = f4_fma(p.wz[k], ring[(J + RINGN - k) % RINGN][r], a);
@@ -615,9 +684,17 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
             for (int k = 0; k < G + W - 1; k++) win[k] = f4_from(rbuf[k * 64]);
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                F4 a = f4_scale(p.wyv[0], win[g]);
+                F4 a;
+                if constexpr (OP != 0) {
+                    F4 t[W];
 #pragma unroll
-                for (int k = 1; k < W; k++) a = f4_fma(p.wyv[k], win[g + k], a);
+                    for (int k = 0; k < W; k++) t[k] = win[g + k];
+                    a = lean_win4<OP == 2, W>(t);
+                } else {
+                    a = f4_scale(p.wyv[0], win[g]);
+#pragma unroll
+                    for (int k = 1; k < W; k++) a = f4_fma(p.wyv[k], win[g + k], a);
+                }
                 // written once, never read back by this launch: non-temporal (measured 1.2 % on config H)
                 if constexpr (RAGGED) {
                     const u32x4 q = f4_to_u32(a);
@@ -639,7 +716,7 @@ sep3d_lean_kernel(const float *__restrict__ in, float *__restrict__ out, const S
 static Knob g_sep3d_ragged{1};    // r5: 1 = the lean kernel takes rows that are not a multiple of 4 floats itself, 0 = refuse (callers extend the rows), 2 = the ragged build for every row length (measurement)
 // RG: the tile shape is also built for rows that are not a multiple of 4 floats (the shapes choose_plan picks by itself)
 template <int W, int NWP, int NWC, int R, int DEPTH = 2, bool RG = false>
-static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool has_const, hipStream_t s)
+static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool has_const, hipStream_t s, int op = 0)
 {
     constexpr int ROWS = NWP * R;
     constexpr int TY = ROWS - (W - 1);
@@ -659,6 +736,30 @@ static int launch_sep3d_lean(const float *in, float *out, Sep3dParams &p, bool h
     }
     if (p.ty != TY) { set_error("internal: lean tile mismatch"); return MI_ERR_INTERNAL; }
     const int total = p.nxt * p.nyt * p.nzc;
+    if (op != 0) {
+        // flat min / max (r6): the ragged build with every boundary test compiled in (HAS_CONST), rows of any length
+        if constexpr (RG) {
+            static PerDeviceOnce mm_done;
+            if (!mm_done) {
+                MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true, true, 1>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                MI_HIP(hipFuncSetAttribute((const void *)sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true, true, 2>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                mm_done = true;
+            }
+            note_kernel("mi::sep3d_lean_kernel<%d,%d,%d,%d,%d,true,ragged,%s> grid=%d (fused x/z/y flat %s of %d^3 samples, rows of any length)",
+                        W, NWP, NWC, R, DEPTH, op == 2 ? "max" : "min", total, op == 2 ? "maximum" : "minimum", W);
+            if (op == 2)
+                hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true, true, 2>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+            else
+                hipLaunchKernelGGL((sep3d_lean_kernel<W, NWP, NWC, R, DEPTH, true, true, 1>), dim3(total), dim3((NWP + NWC) * 64), lds, s, in, out, p);
+            MI_HIP(hipGetLastError());
+            return MI_OK;
+        } else {
+            set_error("separable3d: min / max runs on the ragged tile shapes only");
+            return MI_ERR_UNSUPPORTED;
+        }
+    }
     if ((p.nx & 3) || (RG && g_sep3d_ragged == 2)) {
         if constexpr (RG) {
             static PerDeviceOnce rg_done;
@@ -751,8 +852,15 @@ static int lean_rows(int w, int cfg)
     }
 }
 
-static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams &p, bool hc, hipStream_t s)
+static int launch_lean(int w, int cfg, const float *in, float *out, Sep3dParams &p, bool hc, hipStream_t s, int op = 0)
 {
+    if (op != 0) {            // flat min / max: the tile shapes that have a ragged build
+        switch (w) {
+        case 3: return cfg == 5 ? launch_sep3d_lean<3, 10, 4, 2, 2, true>(in, out, p, hc, s, op) : launch_sep3d_lean<3, 12, 4, 3, 2, true>(in, out, p, hc, s, op);
+        case 5: return cfg == 5 ? launch_sep3d_lean<5, 10, 4, 2, 2, true>(in, out, p, hc, s, op) : launch_sep3d_lean<5, 12, 4, 3, 1, true>(in, out, p, hc, s, op);
+        default: return launch_sep3d_lean<7, 8, 4, 3, 2, true>(in, out, p, hc, s, op);
+        }
+    }
     switch (w) {
     case 3:
         if (cfg == 1) return launch_sep3d_lean<3, 8, 4, 4>(in, out, p, hc, s);
@@ -1069,6 +1177,47 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
 #undef CASE_Z
 #undef UNSUP
 }
+
+// Flat minimum / maximum of a cubic window (size w = 3 / 5 / 7 / 9, origins 0) through the lean kernel's ragged build:
+// what mi_minmax3d_f32 (stream3d.hip) calls for rows that are not a multiple of four floats.  MI_ERR_UNSUPPORTED with
+// nothing queued outside that envelope.
+namespace mi {
+int run_sep3d_lean_minmax(const mi_array *in, const mi_array *out, int w, const int mode[3], double cval, bool is_max, hipStream_t s)
+{
+#define UNSUP(msg) do { set_error("separable3d min/max: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
+    if (!g_sep3d_ragged || g_sep3d_kernel == 1 || g_sep3d_cfg != 0) UNSUP("ragged build switched off");
+    // 9 samples per axis: 163 us here against 142 us through extended rows + the LDS-DMA kernel on 300 x 300 x 301
+    // (profiles/r6_ragged_minmax.txt); 3 / 5 / 7 win everywhere (181 x 217 x 181: 58 -> 21 / 28 / 33 us)
+    if (w < 3 || w > 7 || !(w & 1)) UNSUP("cubic sizes 3 / 5 / 7");
+    if (nx < 16 || ny * nx * 4 >= ((int64_t)1 << 31) || nz * ny * nx >= ((int64_t)1 << 40)) UNSUP("row / plane extent");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
+    Sep3dParams p;
+    memset(&p, 0, sizeof(p));
+    p.mz = filter_mode(mode[0]); p.my = filter_mode(mode[1]); p.mx = filter_mode(mode[2]);
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.wy = w;
+    p.oz = w / 2; p.oy = w / 2;
+    p.cval = (float)cval;
+    p.zrev = g_sep3d_zrev;
+    int cfg_use = 0, rows = 0, nzc = 1;
+    const int big = lean_rows(w, 0), small = lean_rows(w, 5);
+    const int cand_rows[2] = {big, small}, cand_cfg[2] = {0, 5};
+    choose_plan(w, cand_rows, cand_cfg, (w <= 5 && small != big) ? 2 : 1, w, nz, ny, nx, &cfg_use, &rows, &nzc);
+    p.ty = rows - (w - 1);
+    if (p.ty < 1) UNSUP("window too long for the tile");
+    p.nxt = (int)((nx + 255) / 256);
+    p.tw = (int)((((nx + p.nxt - 1) / p.nxt) + 3) & ~(int64_t)3);
+    p.nyt = (int)((ny + p.ty - 1) / p.ty);
+    if ((nz + nzc - 1) / nzc > kMaxChunk) nzc = (int)((nz + kMaxChunk - 1) / kMaxChunk);
+    p.zc = (int)((nz + nzc - 1) / nzc);
+    p.zb0 = 0; p.zn0 = (int)nz; p.zb1 = 0; p.zn1 = 0;
+    p.nzc0 = (int)((nz + p.zc - 1) / p.zc);
+    p.nzc = p.nzc0;
+    return launch_lean(w, cfg_use, (const float *)in->data, (float *)out->data, p, true, s, is_max ? 2 : 1);
+#undef UNSUP
+}
+}  // namespace mi
 
 extern "C" int mi_separable3d_f32(const mi_array *in, const mi_array *out, const double *const weights[3],
                                   const int wlen[3], const int origin[3], const int mode[3], double cval,

@@ -505,6 +505,8 @@ int run_stream_minmax_pass(const float *in, float *out, int nz, int ny, int nx, 
 namespace mi {
 int run_minmax3d_f32_fused(const float *in, float *out, int nz, int ny, int nx, int w, int oy, int oz, int mx, int my, int mz,
                            bool is_max, hipStream_t s);     // minmax3d_f32.hip
+int run_sep3d_lean_minmax(const mi_array *in, const mi_array *out, int w, const int mode[3], double cval, bool is_max,
+                          hipStream_t s);                   // separable3d.hip (r6: rows of any length)
 }
 
 using namespace mi;
@@ -533,6 +535,13 @@ extern "C" int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const in
     if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
     if (in->data == out->data) UNSUP("in-place");
     const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
+    if ((nx & 3) && nz >= 1 && ny >= 1) {
+        // r6: rows that are not a multiple of four floats -- cubic sizes without origins in ONE launch on the rows as they
+        // are (the lean kernel's ragged build with min / max for its three passes); anything else: the caller extends the rows
+        if (size[0] == size[1] && size[1] == size[2] && !origin[0] && !origin[1] && !origin[2])
+            return run_sep3d_lean_minmax(in, out, size[0], mode, cval, is_max != 0, resolve_stream(stream));
+        UNSUP("rows that are not a multiple of 4 floats: cubic sizes 3 / 5 / 7 without origins only");
+    }
     if (nz < 1 || ny < 1 || nx < 8 || (nx & 3)) UNSUP("x extent must be a multiple of 4, >= 8");
     if (nz * ny * nx * 4 >= ((int64_t)1 << 31)) UNSUP("needs a volume < 2 GiB");
     if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");

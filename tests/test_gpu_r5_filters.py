@@ -474,3 +474,75 @@ def test_float64_volumes_with_rows_of_an_odd_number_of_doubles(gpu, ndi, lib):
             db = back._desc()
             S.check(lib.mi_crop_rows(ctypes.byref(de), ctypes.byref(db), 2, None))
             assert np.array_equal(back.get(), a), (dt, mode)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# r6: flat min / max (grey erosion / dilation, minimum / maximum filters with a cubic size) on rows that are not a multiple
+# of four floats -- the same ragged kernel with min / max for its three passes (sep3d_lean_kernel<..., ragged, min | max>),
+# no mi_extend_rows / mi_crop_rows around an LDS-DMA launch (filters.py:1373-1419, morphology.py:769-884)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size", [3, 5, 7])
+def test_ragged_rows_minmax_every_mode_against_scipy(gpu, ndi, lib, size):
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(600 + size)
+    seen_tails = set()
+    for shape in _shapes():
+        if min(shape) < size and shape != (1, 64, 129):
+            pass                                                    # windows longer than an axis: the boundary maps still apply
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        for mode in MODES:
+            for fn, sfn, tag in ((ndi.minimum_filter, sndi.minimum_filter, "min"), (ndi.maximum_filter, sndi.maximum_filter, "max")):
+                got = fn(xd, size=size, mode=mode, cval=0.25).get()
+                k = last_kernel()
+                assert "ragged,%s>" % tag in k and "sep3d_lean_kernel<%d," % size in k, (shape, mode, k)
+                assert np.array_equal(got, sfn(x, size=size, mode=mode, cval=0.25)), (shape, mode, tag)
+        seen_tails.add(shape[2] & 3)
+        assert np.array_equal(ndi.grey_erosion(xd, size=size).get(), sndi.grey_erosion(x, size=size)), shape
+        assert "ragged,min>" in last_kernel()
+        assert np.array_equal(ndi.grey_dilation(xd, size=size).get(), sndi.grey_dilation(x, size=size)), shape
+        assert "ragged,max>" in last_kernel()
+        # origins and non-cubic sizes are not this kernel's: still SciPy's numbers through the extended-rows route
+        if min(shape) >= size:
+            assert np.array_equal(ndi.minimum_filter(xd, size=size, origin=(1, 0, 0)).get(), sndi.minimum_filter(x, size=size, origin=(1, 0, 0)))
+    assert seen_tails == {1, 2, 3}
+
+
+def test_ragged_rows_minmax_non_finite_values_and_mni_burst(gpu, ndi, lib):
+    """inf / -inf / signed zeros follow SciPy; a NaN makes an output NaN exactly where the compare-select passes do (first tap of
+    a pass) -- the same contract as the fused kernel on aligned rows (test_fused_float32_minmax); 181 x 217 x 181 as the last
+    launch of a burst."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(61)
+    x = rng.standard_normal((181, 217, 181)).astype(np.float32)
+    xd = gpu.asarray(x)
+    out = gpu.empty(x.shape, np.float32)
+    for size, mode in ((3, "reflect"), (5, "mirror"), (7, "constant")):
+        for _ in range(30):
+            ndi.grey_erosion(xd, size=size, mode=mode, cval=-0.5, output=out)
+        assert "ragged,min>" in last_kernel(), last_kernel()
+        assert np.array_equal(out.get(), sndi.grey_erosion(x, size=size, mode=mode, cval=-0.5)), (size, mode)
+    w = rng.standard_normal((19, 33, 183)).astype(np.float32)
+    idx = rng.integers(0, w.size, size=w.size // 40)
+    w.flat[idx[1::4]] = np.inf
+    w.flat[idx[2::4]] = -np.inf
+    w.flat[idx[3::4]] = -0.0
+    wd = gpu.asarray(w)
+    for fn, ref in ((ndi.minimum_filter, sndi.minimum_filter), (ndi.maximum_filter, sndi.maximum_filter)):
+        assert np.array_equal(fn(wd, size=5, mode="mirror").get(), ref(w, size=5, mode="mirror")), ref.__name__
+        assert "ragged" in last_kernel()
+    w.flat[idx[0::4]] = np.nan
+    wd = gpu.asarray(w)
+    clean = sndi.maximum_filter(np.isnan(w).astype(np.uint8), size=5, mode="mirror") == 0
+    for fn, ref in ((ndi.minimum_filter, sndi.minimum_filter), (ndi.maximum_filter, sndi.maximum_filter)):
+        got = fn(wd, size=5, mode="mirror").get()
+        assert "ragged" in last_kernel()
+        lib.mi_debug_set_sep3d_ragged(0)                          # the extended-rows route: LDS-DMA kernel, same per-pass semantics
+        try:
+            via = fn(wd, size=5, mode="mirror").get()
+        finally:
+            lib.mi_debug_set_sep3d_ragged(1)
+        assert np.array_equal(np.isnan(got), np.isnan(via)), ref.__name__
+        assert np.array_equal(got[clean], ref(np.where(np.isnan(w), np.float32(0), w), size=5, mode="mirror")[clean]), ref.__name__
