@@ -51,11 +51,20 @@ int hip_fail(hipError_t e, const char *what);
 // Process-wide switches behind the mi_debug_set_* entry points (include/mi355img_debug.h): relaxed atomics, so a
 // thread flipping one while other threads dispatch is a benign race (each call reads a knob once and sees either
 // value), never a data race.  They exist for tests and tuning sweeps; production code never writes them.
+// Every write bumps g_knob_generation (mi_debug_generation()): host-side caches of the library's refusals (the Python
+// layer's _EXT_REFUSED) carry it in their keys, so a refusal recorded while a test had a knob flipped does not outlive
+// the flip (r5 advisor finding).
+extern std::atomic<int> g_knob_generation;
 struct Knob {
     std::atomic<int> v;
     constexpr explicit Knob(int x) : v(x) {}
     operator int() const { return v.load(std::memory_order_relaxed); }
-    Knob &operator=(int x) { v.store(x, std::memory_order_relaxed); return *this; }
+    Knob &operator=(int x)
+    {
+        v.store(x, std::memory_order_relaxed);
+        g_knob_generation.fetch_add(1, std::memory_order_relaxed);
+        return *this;
+    }
 };
 
 // ------------------------------------------------------------------ runtime hooks

@@ -251,6 +251,7 @@ struct SlabPipe {
     int graph_state = 0;                        // 0 = not tried, 1 = usable, -1 = capture failed (direct queuing instead)
     bool capturing = false;
     bool captured_submit[kPipeMaxBuf] = {};     // during a capture: the buffer's exchange is part of the graph
+    hipEvent_t join_ev = nullptr;               // recorded on `cs` right before a replay, NEVER inside a capture (see mi_slab_pipe_run)
     bool needs_join = false;                    // an exchange was queued DIRECTLY on the comm stream since the last replay: the next
                                                 // replay must first wait for it on `s` (the graph's own edges start at its own nodes)
 };
@@ -424,6 +425,7 @@ int mi_slab_pipe_create(mi_slab_pipe *pipe, mi_comm comm, int nbuf, const mi_arr
         for (int k = 0; k < nbuf; k++) {
             MI_HIP(hipEventCreateWithFlags(&raw->input_final[k], hipEventDisableTiming));
             MI_HIP(hipEventCreateWithFlags(&raw->halos_ready[k], hipEventDisableTiming));
+            if (!raw->join_ev) MI_HIP(hipEventCreateWithFlags(&raw->join_ev, hipEventDisableTiming));
         }
         return MI_OK;
     }();
@@ -444,6 +446,7 @@ int mi_slab_pipe_destroy(mi_slab_pipe pipe)
         if (p->input_final[k]) (void)hipEventDestroy(p->input_final[k]);
         if (p->halos_ready[k]) (void)hipEventDestroy(p->halos_ready[k]);
     }
+    if (p->join_ev) (void)hipEventDestroy(p->join_ev);
     if (p->cs) (void)hipStreamDestroy(p->cs);
     delete p;
     return MI_OK;
@@ -484,9 +487,13 @@ int mi_slab_pipe_run(mi_slab_pipe pipe, int nsteps, int use_graph)
                 // comm stream has been joined inside the graph; after directly queued steps (the first rotation, a tail of a
                 // previous run, mi_slab_pipe_step) nothing on `s` waits for the exchanges still in flight on the comm stream,
                 // and the graph's own exchange node could run beside them on the same communicator: join first.  The comm
-                // stream is in order, so the exchange submitted last covers the earlier ones (r4 advisor finding).
+                // stream is in order, so ONE event recorded on it now covers every direct submit, including those of
+                // mi_slab_pipe_step (which do not advance next_submit).  r5 advisor finding: the join used to wait on
+                // halos_ready[...], whose LATEST record may be the one made inside pipe_capture() -- waiting on an event
+                // last recorded in a capture is implementation defined; join_ev is never recorded in a capture.
                 if (p->needs_join && (p->prev >= 0 || p->next >= 0)) {
-                    MI_HIP(hipStreamWaitEvent(p->s, p->halos_ready[(p->next_submit - 1) % p->nbuf], 0));
+                    MI_HIP(hipEventRecord(p->join_ev, p->cs));
+                    MI_HIP(hipStreamWaitEvent(p->s, p->join_ev, 0));
                 }
                 p->needs_join = false;
                 MI_HIP(hipGraphLaunch(p->gexec, p->s));

@@ -13,6 +13,8 @@
 #include "common.hpp"
 
 namespace mi {
+std::atomic<int> g_knob_generation{0};
+
 
 static thread_local char g_err[512] = "";
 
@@ -389,3 +391,6 @@ int mi_event_elapsed_ms(mi_event start, mi_event stop, float *ms)
 }
 
 }  // extern "C"
+
+/* test / tuning support: a counter that every mi_debug_set_* call advances (common.hpp Knob) */
+extern "C" int mi_debug_generation(void) { return mi::g_knob_generation.load(std::memory_order_relaxed); }

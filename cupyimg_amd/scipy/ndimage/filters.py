@@ -16,6 +16,7 @@ Where the reference deviates from SciPy the implementation follows SciPy
 (SURVEY.md section 8c): float64 weights, sum-then-divide box means (exact for
 integer images), min/max `cval` converted to the input dtype.
 """
+import collections
 import ctypes
 import warnings
 
@@ -258,7 +259,27 @@ def _fused_3d(input, output, weights, origins, modes, cval, is_box, planes):
     return output
 
 
-_EXT_REFUSED = set()      # requests the fused path behind _run_on_extended_rows refused: (tag, dtypes, shape, parameters)
+# requests the fused path behind _run_on_extended_rows refused: (tag, dtypes, shape, parameters, knob generation), oldest first
+_EXT_REFUSED = collections.OrderedDict()
+_EXT_REFUSED_MAX = 1024
+
+
+def _refusal_key(key, input, output, left, right, mode_x):
+    """What a refusal of the fused path depends on.  r5 advisor findings: the library's debug knobs are part of it (their
+    generation counter, mi_debug_generation: a refusal recorded while a test had a kernel switched off must not outlive the
+    switch), and a NaN anywhere in the parameters must compare equal to itself."""
+    def norm(v):
+        if isinstance(v, float) and v != v:
+            return "nan"
+        if isinstance(v, (tuple, list)):
+            return tuple(norm(x) for x in v)
+        return v
+    return (norm(key), str(input.dtype), str(output.dtype), tuple(input.shape), left, right, mode_x,
+            int(S.lib().mi_debug_generation()))
+
+
+def _reset_ext_refused():
+    _EXT_REFUSED.clear()
 
 
 def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_cval=True, key=None):
@@ -273,8 +294,9 @@ def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_c
     windows, ranks it does not handle -- paid two allocations and a full-volume copy before falling back to the generic
     passes, on every call): a refusal is remembered and the next call with the same key returns at once."""
     if key is not None:
-        key = (key, str(input.dtype), str(output.dtype), tuple(input.shape), left, right, mode_x)
+        key = _refusal_key(key, input, output, left, right, mode_x)
         if key in _EXT_REFUSED:
+            _EXT_REFUSED.move_to_end(key)
             return None
     if left < 0 or right < 0 or input.size < (1 << 15) or input.dtype.itemsize not in (1, 2, 4, 8) or output.dtype.itemsize not in (1, 2, 4, 8):
         return None
@@ -306,9 +328,9 @@ def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_c
     S.check(S.lib().mi_extend_rows(ctypes.byref(a), ctypes.byref(b), pl, S.mode_code(mode_x), float(cval), None))
     if run(ext, tmp) is None:
         if key is not None:
-            if len(_EXT_REFUSED) > 1024:
-                _EXT_REFUSED.clear()
-            _EXT_REFUSED.add(key)
+            _EXT_REFUSED[key] = True
+            while len(_EXT_REFUSED) > _EXT_REFUSED_MAX:
+                _EXT_REFUSED.popitem(last=False)          # least recently used first
         return None
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     dst = output if direct else core.empty(output.shape, output.dtype)
