@@ -94,7 +94,7 @@ int binary3_tiled(const mi_array *in, const mi_array *out, const uint8_t *struct
                   const int *origins, const mi_array *mask, int border_value, int invert, int32_t *changed,
                   hipStream_t s);   // binary3d.hip
 int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure, const int64_t *sshape, const int *origins,
-              const mi_array *mask, int border_value, int invert, int k, int32_t *flags, hipStream_t s);   // bitmorph3d.hip
+              const mi_array *mask, int border_value, int invert, int k, int32_t *flags, hipStream_t s, int open_close = 0);   // bitmorph3d.hip
 }
 
 using namespace mi;
@@ -135,6 +135,21 @@ extern "C" int mi_binary_erosion_fused(const mi_array *in, const mi_array *out, 
     if (numel(in) == 0) return MI_OK;
     return bitmorph3(in, out, structure, sshape, origins, mask, border_value, invert, iterations, changed_dev,
                      resolve_stream(stream));
+}
+
+// Opening (erosions, then dilations) or closing (dilations, then erosions), `iterations` of each, in ONE launch: the
+// intermediate volume of morphology.py:464-613 (`tmp = binary_erosion(...)`) never exists.
+extern "C" int mi_binary_open_close_fused(const mi_array *in, const mi_array *out, const uint8_t *structure,
+                                          const int64_t *sshape, const mi_array *mask, int border_value, int closing,
+                                          int iterations, mi_stream stream)
+{
+    int rc;
+    const int zero[MI_MAX_NDIM] = {0};
+    if ((rc = check_binary_args(in, out, structure, sshape, zero, mask))) return rc;
+    MI_REQUIRE(iterations >= 1, MI_ERR_INVALID_ARG, "iterations must be >= 1");
+    if (numel(in) == 0) return MI_OK;
+    return bitmorph3(in, out, structure, sshape, zero, mask, border_value, 0, iterations, nullptr, resolve_stream(stream),
+                     closing ? 2 : 1);
 }
 
 extern "C" int mi_binary_erosion(const mi_array *in, const mi_array *out, const uint8_t *structure,

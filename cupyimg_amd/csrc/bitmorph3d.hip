@@ -47,7 +47,12 @@ struct BitMorphParams {
     int pitch;              // LDS words per staged row: 1 pad + gxw + 1 pad (+ skew)
     int zc, nzc, nxt, nyt;
     int ns, nms;            // ring slots per stage (wz + 1), slots of the mask ring
-    int pad_[3];
+    // opening / closing in one launch: stages 1 .. kflip are the first operation, stage kflip writes the COMPLEMENT of its
+    // result (the erosion's result seen as the dilation-of-the-complement's input, or the other way round), stages
+    // kflip + 1 .. k the second one with the mirrored structure (table entries nrows .. nrows + nrows2 - 1) and the
+    // complemented border; the output is complemented once more than the input.  0 = k iterations of one operation.
+    int kflip, nrows2;
+    int pad_[1];
     // per structure row (dz, dy) with a tap: { tz | last-of-its-group << 8, dx mask (bit tx), (ty - oy) * pitch * 4, 0 }
     alignas(16) int rows[kBmMaxRows][4];
 };
@@ -152,6 +157,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx;
     const size_t plane_elems = (size_t)ny * (size_t)nx;
     const unsigned inv16 = p.invert ? 0xffffu : 0u;
+    const unsigned inv16out = (p.invert != 0) != (p.kflip != 0) ? 0xffffu : 0u;
     const unsigned border32 = p.border ? 0xffffffffu : 0u;
 
     // ---- staging recipe: granule g = tid + NT i of the gy x ngx staged granules
@@ -205,9 +211,11 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
     // edge may read anything there: its outermost k * reach columns are recomputed by the neighbour)
     {
         const int nrows_all = ((k + 1) * ns + (HAS_MASK ? p.nms : 0)) * gy;
+        const int flip_row = p.kflip ? p.kflip * ns * gy : nrows_all;        // rings kflip .. k hold the second operation's bits
         for (int r = tid; r < nrows_all; r += NT) {
-            lds[r * pitch] = border32;
-            lds[r * pitch + gxw + 1] = border32;
+            const unsigned bpad = r >= flip_row ? ~border32 : border32;
+            lds[r * pitch] = bpad;
+            lds[r * pitch + gxw + 1] = bpad;
         }
     }
 
@@ -269,6 +277,10 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
             const unsigned *src = lds + (j - 1) * stage_words;
             unsigned *dst = lds + j * stage_words + wslot * slot_words;
             const bool plane_in = (unsigned)zj < (unsigned)nz;          // uniform
+            const bool second = p.kflip != 0 && j > p.kflip;            // the second operation of an opening / closing
+            const unsigned bst = second ? ~border32 : border32;         // what a tap outside the array sees in this stage
+            const unsigned wflip = j == p.kflip ? 0xffffffffu : 0u;     // the first operation's last stage hands over the complement
+            const int rfirst = second ? p.nrows : 0, rlast = second ? p.nrows + p.nrows2 : p.nrows;
             unsigned res[NW];
 #pragma unroll
             for (int i = 0; i < NW; i++) res[i] = 0xffffffffu;
@@ -292,7 +304,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
                 unsigned aL[NW], aC[NW], aR[NW];
 #pragma unroll
                 for (int i = 0; i < NW; i++) aL[i] = aC[i] = aR[i] = 0xffffffffu;
-                for (int r = 0; r < p.nrows; r += 2) {
+                for (int r = rfirst; r < rlast; r += 2) {
                     const int e0 = p.rows[r][0], m = p.rows[r][1], ro0 = p.rows[r][2];
                     const int e1 = p.rows[r + 1][0], ro1 = p.rows[r + 1][2];
                     int s0 = wslot + 1 + (e0 & 255), s1 = wslot + 1 + (e1 & 255);
@@ -349,7 +361,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
 #pragma unroll
             for (int i = 0; i < NW; i++) {
                 const int wo = wrd[i];
-                unsigned r = border32;
+                unsigned r = bst;
                 if (plane_in) {
                     const unsigned cur = cs[wo];
                     r = res[i];
@@ -358,9 +370,9 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
                         r = (r & mk) | (cur & ~mk);
                     }
                     chg |= ((r ^ cur) & wvalid[i] & wown[i] & count) ? (1u << (j - 1)) : 0u;
-                    r = (r & wvalid[i]) | (border32 & ~wvalid[i]);
+                    r = (r & wvalid[i]) | (bst & ~wvalid[i]);
                 }
-                dst[woff[i] < 0 ? dump - wslot * slot_words - j * stage_words : woff[i]] = r;
+                dst[woff[i] < 0 ? dump - wslot * slot_words - j * stage_words : woff[i]] = r ^ wflip;
             }
         }
 
@@ -376,7 +388,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
             for (int i = 0; i < NL; i++) w[i] = *reinterpret_cast<const unsigned short *>(slot + olds[i]);
 #pragma unroll
             for (int i = 0; i < NL; i++)
-                __builtin_amdgcn_raw_buffer_store_b128(unpack16(w[i] ^ inv16), rout, live ? ovoff[i] : kOOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(unpack16(w[i] ^ inv16out), rout, live ? ovoff[i] : kOOB, 0, 0);
         }
         pslot = wslot;
         wslot = wslot + 1 == ns ? 0 : wslot + 1;
@@ -426,17 +438,26 @@ static int launch_bitmorph(const unsigned char *in, unsigned char *out, const un
     const int64_t total = (int64_t)p.nxt * p.nyt * p.nzc;
     hipLaunchKernelGGL((bitmorph3_kernel<HAS_MASK, NL, NT, KIND>), dim3((unsigned)total), dim3(NT), lds, s, in, out, msk, p, flags);
     MI_HIP(hipGetLastError());
-    note_kernel("mi::bitmorph3_kernel<%s,%d,%d,%s> grid=%lld k=%d tile=%dx%d rows, %d planes (1 bit per voxel, %d fused iteration%s per launch)",
-                HAS_MASK ? "mask" : "nomask", NL, NT, KIND == 0 ? "table" : KIND == 1 ? "cross" : KIND == 2 ? "conn18" : "cube3", (long long)total, p.k, p.ty, p.txw * 32, p.zc, p.k, p.k == 1 ? "" : "s");
+    note_kernel("mi::bitmorph3_kernel<%s,%d,%d,%s> grid=%lld k=%d%s tile=%dx%d rows, %d planes (1 bit per voxel, %d fused iteration%s per launch)",
+                HAS_MASK ? "mask" : "nomask", NL, NT, KIND == 0 ? "table" : KIND == 1 ? "cross" : KIND == 2 ? "conn18" : "cube3", (long long)total, p.k, p.kflip ? (p.invert ? " (closing)" : " (opening)") : "", p.ty, p.txw * 32, p.zc, p.k, p.k == 1 ? "" : "s");
     return MI_OK;
 }
 
 // k fused iterations on a 3-D volume of 1-byte voxels; MI_ERR_UNSUPPORTED (nothing launched) outside the envelope.
 int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure, const int64_t *sshape, const int *origins,
-              const mi_array *mask, int border_value, int invert, int k, int32_t *flags, hipStream_t s)
+              const mi_array *mask, int border_value, int invert, int k, int32_t *flags, hipStream_t s, int open_close)
 {
+    // open_close: 0 = k iterations of one operation (`invert` says which); 1 = opening, 2 = closing with k iterations of
+    // each half in ONE launch (2 k stages; `invert` is ignored)
 #define NOPE(msg) do { set_error("bitmorph3: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
     if (!g_bm_on) NOPE("switched off (mi_debug_set_bitmorph)");
+    const int kiter = k;
+    if (open_close) {
+        invert = open_close == 2;                           // closing starts with the dilation
+        k = 2 * k;
+        for (int d = 0; d < in->ndim && d < 3; d++)
+            if (!(sshape[d] & 1) || origins[d] != 0) NOPE("opening / closing in one launch: odd structure extents, origin 0");
+    }
     if (dtype_size(in->dtype) != 1 || dtype_size(out->dtype) != 1) NOPE("1-byte volumes only");
     if (in->ndim != 3) NOPE("3-D only");
     if (k < 1 || k > kBmMaxK) NOPE("1 .. 8 fused iterations");
@@ -461,37 +482,48 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     p.oy = off[1]; p.hy = w[1] - 1 - off[1];
     p.ox = off[2];
     p.k = k;
+    p.kflip = open_close ? kiter : 0;
     p.invert = invert != 0;
     p.border = invert ? !border_value : (border_value != 0);
     // rows (dz, dy) of the structure that hold a tap, grouped by their dx mask (the kernel ANDs the rows of a group word
     // by word and shifts once per group); a group is padded to an even count by repeating its last row (AND is idempotent)
     {
         struct Row { int tz, ty; unsigned m; };
-        std::vector<Row> rows;
-        for (int tz = 0; tz < w[0]; tz++)
-            for (int ty = 0; ty < w[1]; ty++) {
-                unsigned m = 0;
-                for (int tx = 0; tx < w[2]; tx++)
-                    if (structure[((int64_t)tz * w[1] + ty) * w[2] + tx]) m |= 1u << tx;
-                if (m) rows.push_back({tz, ty, m});
-            }
-        std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.m < b.m; });
         int n = 0;
-        for (size_t i = 0; i < rows.size();) {
-            size_t j = i;
-            while (j < rows.size() && rows[j].m == rows[i].m) j++;
-            const size_t cnt = j - i, padded = cnt + (cnt & 1);
-            if (n + (int)padded > kBmMaxRows) NOPE("structure has too many rows");
-            for (size_t q = 0; q < padded; q++) {
-                const Row &r = rows[i + std::min(q, cnt - 1)];
-                p.rows[n][0] = r.tz | (q + 1 == padded ? 256 : 0);
-                p.rows[n][1] = (int)r.m;
-                p.rows[n][2] = r.ty - off[1];               // x pitch x 4 once the pitch is known
-                n++;
+        // pass 0: the structure as the first operation takes it; pass 1 (opening / closing): the other orientation.  The
+        // caller's structure is the EROSION's; a dilation is the erosion of the complement by the mirrored structure.
+        for (int pass = 0; pass < (open_close ? 2 : 1); pass++) {
+            const bool mirrored = open_close ? (pass == 0) == (open_close == 2) : false;
+            std::vector<Row> rows;
+            for (int tz = 0; tz < w[0]; tz++)
+                for (int ty = 0; ty < w[1]; ty++) {
+                    unsigned m = 0;
+                    for (int tx = 0; tx < w[2]; tx++) {
+                        const int64_t idx = mirrored ? ((int64_t)(w[0] - 1 - tz) * w[1] + (w[1] - 1 - ty)) * w[2] + (w[2] - 1 - tx)
+                                                     : ((int64_t)tz * w[1] + ty) * w[2] + tx;
+                        if (structure[idx]) m |= 1u << tx;
+                    }
+                    if (m) rows.push_back({tz, ty, m});
+                }
+            std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.m < b.m; });
+            const int n0 = n;
+            for (size_t i = 0; i < rows.size();) {
+                size_t j = i;
+                while (j < rows.size() && rows[j].m == rows[i].m) j++;
+                const size_t cnt = j - i, padded = cnt + (cnt & 1);
+                if (n + (int)padded > kBmMaxRows) NOPE("structure has too many rows");
+                for (size_t q = 0; q < padded; q++) {
+                    const Row &r = rows[i + std::min(q, cnt - 1)];
+                    p.rows[n][0] = r.tz | (q + 1 == padded ? 256 : 0);
+                    p.rows[n][1] = (int)r.m;
+                    p.rows[n][2] = r.ty - off[1];           // x pitch x 4 once the pitch is known
+                    n++;
+                }
+                i = j;
             }
-            i = j;
+            if (pass == 0) p.nrows = n;                     // 0: an empty structure erodes nothing (output = true)
+            else p.nrows2 = n - n0;
         }
-        p.nrows = n;                                        // 0: an empty structure erodes nothing (output = true)
     }
     p.ns = p.wz + 1;
     p.nms = mask ? k * (1 + p.hz) - p.hz + 1 : 0;
@@ -528,7 +560,7 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     }
     p.pitch = p.gxw + 2;
     if (!(p.pitch & 1)) p.pitch++;                          // odd pitch: the rows of a column of words fall into different banks
-    for (int r = 0; r < p.nrows; r++) p.rows[r][2] *= p.pitch * 4;
+    for (int r = 0; r < p.nrows + p.nrows2; r++) p.rows[r][2] *= p.pitch * 4;
     const int halo_y = k * (p.oy + p.hy);
     const int ngx = 2 * p.gxw;
     const int nt = kBmNT;
@@ -551,7 +583,7 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
         struct Key { int64_t nx, ny, nz; int k, w0, w1, w2, o0, o1, o2, mask, nt, cus, kind, ty, nzc; };
         static thread_local Key last_key = {};
         static thread_local bool have = false;
-        const Key key = {nx, ny, nz, k, w[0], w[1], w[2], off[0], off[1], off[2], mask ? 1 : 0, nt, cus, kind, 0, 0};
+        const Key key = {nx, ny, nz, k, w[0], w[1], w[2], off[0], off[1], off[2], (mask ? 1 : 0) + 2 * open_close, nt, cus, kind, 0, 0};
         if (have && !memcmp(&key, &last_key, offsetof(Key, ty))) {
             best_ty = last_key.ty;
             best_nzc = last_key.nzc;

@@ -388,6 +388,13 @@ int mi_binary_erosion(const mi_array *in, const mi_array *out, const uint8_t *st
  * (so a run "until stable" stops at the first zero).  3-D volumes of 1-byte voxels with rows that are a multiple of
  * 16 bytes; anything else returns MI_ERR_UNSUPPORTED with nothing queued and the caller iterates mi_binary_erosion. */
 #define MI_BINARY_MAX_FUSED 8
+/* binary_opening (closing = 0) / binary_closing (closing = 1) with `iterations` iterations of each half in ONE launch
+ * (morphology.py:464-613 run the two halves as separate calls with a temporary volume): stages 1 .. iterations are the
+ * first operation, the rest the second with the mirrored structure; 2 * iterations <= MI_BINARY_MAX_FUSED, odd structure
+ * extents, origin 0; otherwise MI_ERR_UNSUPPORTED with nothing queued (the caller runs the two halves). */
+int mi_binary_open_close_fused(const mi_array *in, const mi_array *out, const uint8_t *structure,
+                               const int64_t *sshape, const mi_array *mask, int border_value, int closing,
+                               int iterations, mi_stream stream);
 int mi_binary_erosion_fused(const mi_array *in, const mi_array *out, const uint8_t *structure,
                             const int64_t *sshape, const int *origins, const mi_array *mask,
                             int border_value, int invert, int iterations, int32_t *changed_dev, mi_stream stream);

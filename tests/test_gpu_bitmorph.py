@@ -103,6 +103,45 @@ def test_bitmorph_until_stable_propagation_fill_holes(gpu, ndi, knob):
             assert np.array_equal(fn(gpu.asarray(x), iterations=it).get(), sfn(x, iterations=it)), (fn.__name__, it)
 
 
+@pytest.mark.parametrize("shape", [(24, 40, 96), (13, 50, 1040), (40, 33, 2064)])
+def test_opening_closing_in_one_launch(gpu, ndi, knob, shape):
+    """binary_opening / binary_closing (morphology.py:464-613) as ONE launch: k erosion stages, the complement, k dilation
+    stages with the mirrored structure (or the other way round) -- against SciPy; structures that are not symmetric,
+    masks, border values, iteration counts up to the stage limit and beyond it (two launches per half then)."""
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(shape[2])
+    x = rng.random(shape) > 0.35
+    m = rng.random(shape) > 0.25
+    xd, md = gpu.asarray(x), gpu.asarray(m)
+    structs = [None, np.ones((3, 3, 3), bool), rng.random((5, 3, 7)) > 0.4, _ball(2), np.array([[[1, 1, 0]], [[0, 1, 0]], [[0, 1, 1]]], bool)]
+    for tiles in [(2, 0, 0), (2, 6, 3)]:
+        knob(*tiles)
+        for st in structs:
+            for fn, sfn, tag in [(ndi.binary_opening, sndi.binary_opening, "opening"), (ndi.binary_closing, sndi.binary_closing, "closing")]:
+                for kw in [dict(), dict(iterations=2), dict(iterations=4), dict(border_value=1), dict(mask=True, iterations=2),
+                           dict(mask=True, border_value=1, iterations=3)]:
+                    kg, ko = dict(kw), dict(kw)
+                    if kw.get("mask"):
+                        kg["mask"], ko["mask"] = md, m
+                    got = fn(xd, st, **kg).get()
+                    # four stages at most in one launch (more: two launches per call); large structures on x-tiled rows may not
+                    # fit one tile with four stages and fall back the same way
+                    if kw.get("iterations", 1) <= 2 and (st is None or st.shape == (3, 3, 3)):
+                        assert "(%s)" % tag in last_kernel(), last_kernel()
+                    ref = sfn(x, st, **ko)
+                    assert np.array_equal(got, ref), (tag, None if st is None else st.shape, kw, tiles, int((got != ref).sum()))
+    knob(2, 0, 0)
+    # beyond the stage limit, even structures, origins: the two halves as separate (fused-iteration) calls
+    for kw in [dict(iterations=5), dict(origin=1), dict(structure=np.ones((2, 3, 3), bool))]:
+        st = kw.pop("structure", None)
+        assert np.array_equal(ndi.binary_opening(xd, st, **kw).get(), sndi.binary_opening(x, st, **kw)), kw
+        assert "opening" not in last_kernel()
+        assert np.array_equal(ndi.binary_closing(xd, st, **kw).get(), sndi.binary_closing(x, st, **kw)), kw
+    out = gpu.empty(shape, np.bool_)
+    assert ndi.binary_closing(xd, iterations=2, output=out) is out
+    assert np.array_equal(out.get(), sndi.binary_closing(x, iterations=2))
+
+
 def test_bitmorph_output_forms_and_dtypes(gpu, ndi, knob):
     """int8 / uint8 inputs (any nonzero byte is true), uint8 output arrays, output given, input untouched."""
     knob(2, 0, 0)
