@@ -10,14 +10,14 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-ARGS="$R/bench.py --steps 20 --warmup 5 --no-cpu"
+ARGS="$R/bench.py --steps 20 --warmup 5 --no-cpu --no-configs"      # the headline alone: the counters are averaged per kernel NAME, and configs B / E-slab run other instantiations of it
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $ARGS > $O/bench_stats.json 2> $O/stats.err
 timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o b -- python3 $ARGS > /dev/null 2>&1
 timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $O/pmc_write -o b -- python3 $ARGS > /dev/null 2>&1
 timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU -d $O/pmc_sq -o b -- python3 $ARGS > /dev/null 2>&1
 cd $O && python3 - <<'PY' > summary.txt
 import csv, glob, collections
-print("# rocprofv3 summary for: python3 bench.py --steps 20 --warmup 5 --no-cpu")
+print("# rocprofv3 summary for: python3 bench.py --steps 20 --warmup 5 --no-cpu --no-configs")
 for f in glob.glob('stats/*kernel_stats.csv'):
     print("## kernel stats (rocprofv3 --kernel-trace --stats)")
     print(open(f).read())
@@ -40,18 +40,18 @@ def avg(pattern, counter):
     v = []
     for f in glob.glob(pattern):
         for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter and ('sep3d_lean_kernel' in r['Kernel_Name'] or 'sep3d_long3_kernel' in r['Kernel_Name']):
+            if r['Counter_Name'] == counter and ('sep3d_lean_kernel<5' in r['Kernel_Name'] or 'sep3d_long3_kernel<5' in r['Kernel_Name']):
                 v.append(float(r['Counter_Value']))
     return sum(v) / len(v) if v else None
 name, ns = None, None
 for f in glob.glob('stats/*kernel_stats.csv'):
     for r in csv.DictReader(open(f)):
-        if 'sep3d_lean_kernel' in r['Name'] or 'sep3d_long3_kernel' in r['Name']:
+        if 'sep3d_lean_kernel<5' in r['Name'] or 'sep3d_long3_kernel<5' in r['Name']:
             name, ns = r['Name'], float(r['AverageNs'])
 fetch, write = avg('pmc_fetch/*counter_collection.csv', 'FETCH_SIZE'), avg('pmc_write/*counter_collection.csv', 'WRITE_SIZE')
 rd, wr = int(2 * fetch * 1024), int(write * 1024)
 print(json.dumps({
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE ... -- python3 bench.py --steps 20 --warmup 5 --no-cpu",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE ... -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-configs",
     "kernel": name, "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
     "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
     "algorithmic_bytes_per_launch": 512 ** 3 * 8,

@@ -22,6 +22,15 @@ rm -rf $O/cfgstats $O/benchstats
 timeout 300 python scripts/bench_slab_step.py --ranks 8 --graphs 1 2>/dev/null | grep "^{" > $O/slab_step_8.json; cut -c1-900 $O/slab_step_8.json
 FUZZ_BIG=1 timeout 260 python scripts/fuzz_vs_scipy.py 200 31337 2>&1 | tail -3 | tee $O/fuzz_big.txt
 timeout 200 python scripts/fuzz_vs_scipy.py 150 2026 2>&1 | tail -3 | tee $O/fuzz_2026.txt
+# r6: the kernels added this round -- bit-packed binary morphology, the dense 3^3 / 5^3 stencil, min / max on ragged rows --
+# their rocprofv3 kernel statistics and counters, and the headline's traffic counters (profiles/r6_traffic.json)
+timeout 300 python scripts/bench_bitmorph.py > $O/bitmorph_bench.txt 2>&1; grep "shape\|cross  \|3^3\|ball2\|x3\|masked\|opening cross " $O/bitmorph_bench.txt | head -20
+timeout 300 python scripts/bench_stencil.py > $O/stencil_bench.txt 2>&1; grep "3x3x3\|5x5x5" $O/stencil_bench.txt
+timeout 300 python scripts/bench_ragged_minmax.py > $O/ragged_minmax.txt 2>&1; head -4 $O/ragged_minmax.txt
+bash scripts/kstat_any.sh $TAG/binary_stats scripts/prof_bitmorph.py > $O/binary_kstat.txt 2>&1; cat $O/binary_kstat.txt
+timeout 600 bash scripts/pmc_script.sh $TAG/binary_pmc scripts/prof_bitmorph.py > $O/binary_pmc.txt 2>&1; tail -30 $O/binary_pmc.txt
+timeout 900 bash scripts/profile_bench.sh $TAG/headline_prof > $O/headline_prof.txt 2>&1; tail -14 $O/headline_prof.txt
+cd $GRAFT_REPO_ROOT
 # r5: the targeted fuzz of the round-5 routes and the tables of the kernels added this round
 timeout 260 python scripts/fuzz_r5.py 200 505 2>&1 | tail -60 | tee $O/fuzz_r5.txt
 timeout 300 python scripts/bench_ragged_rows.py > $O/ragged_rows.txt 2>&1
