@@ -352,7 +352,12 @@ int mi_minmax_nd(const mi_array *in, const mi_array *out, const uint8_t *footpri
  * most 128 set elements take register kernels (sorting networks / partial selection);
  * anything else -- rank 4..8, larger footprints -- a scratch-column shell sort (r3; the
  * reference's shell-sort path, filters.py:1753-1768, has no limit either; scratch from the
- * pool, at most 256 MiB).  cval is converted to the input dtype like SciPy does. */
+ * pool, at most 256 MiB).  cval is converted to the input dtype like SciPy does.
+ * NaN contract (r5 advisor finding): float32 windows are sorted on order-preserving integer keys -- NaNs with a clear
+ * sign bit sort above +inf, with a set sign bit below -inf, and -0 below +0 (what numpy.sort does for the positive
+ * NaNs NumPy produces); float64 windows use compare-select / v_min_f64 / v_max_f64, which pass over NaNs: a float64
+ * volume that holds NaNs has NO guaranteed rank-filter result (SciPy's own depends on its partial sort), finite data
+ * and infinities are exact for both dtypes. */
 int mi_rank_filter(const mi_array *in, const mi_array *out, const uint8_t *footprint,
                    const int64_t *fshape, const int *origins, int rank, int mode, double cval,
                    mi_stream stream);
@@ -445,7 +450,13 @@ int mi_spline_pad(const mi_array *in, const mi_array *out, int npad, int pad_mod
 int mi_spline_filter1d(const mi_array *data, int axis, int order, int spline_mode, mi_stream stream);
 /* mi_spline_pad followed by mi_spline_filter1d along every axis longer than one sample, in one call
  * (the loop of spline_filter, interpolation.py:185-268); without padding and conversion the first
- * pass reads `in` directly instead of copying it first. */
+ * pass reads `in` directly instead of copying it first.
+ * Precision of the streaming passes (orders 2 / 3 on volumes of >= 16384 lines: the default route; r5 advisor
+ * finding): the causal sweep's running values stay in the COEFFICIENT type between the two sweeps -- rounded to
+ * float32 on the float32 route -- and a line starts from a 20-term truncated sum; the one-thread-per-line kernels
+ * keep them in double.  Bound: 1 ulp of a float32 coefficient (the whole-volume order-3 tests hold 2e-5 against
+ * SciPy's double); strided and contiguous axes round differently.  spline_mode | 0x100 (exact) selects the
+ * double-state kernels. */
 int mi_spline_prefilter(const mi_array *in, const mi_array *out, int order, int spline_mode, int npad,
                         int pad_mode, double cval, mi_stream stream);
 int mi_spline_map_coordinates(const mi_array *coef, const mi_array *coords, const mi_array *out,
