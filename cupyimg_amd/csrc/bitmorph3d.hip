@@ -423,7 +423,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
 }
 
 // test / tuning hook: on = 0 never, 1 the production rule, 2 also on small volumes; (ty, nzc) of the next launches, 0 = the planner's
-static Knob g_bm_ty{0}, g_bm_nzc{0}, g_bm_on{1}, g_bm_kind0{0};
+static Knob g_bm_ty{0}, g_bm_nzc{0}, g_bm_on{1}, g_bm_kind0{0}, g_bm_2d{1};
 
 template <bool HAS_MASK, int NL, int NT, int KIND>
 static int launch_bitmorph(const unsigned char *in, unsigned char *out, const unsigned char *msk, const BitMorphParams &p,
@@ -459,16 +459,24 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
             if (!(sshape[d] & 1) || origins[d] != 0) NOPE("opening / closing in one launch: odd structure extents, origin 0");
     }
     if (dtype_size(in->dtype) != 1 || dtype_size(out->dtype) != 1) NOPE("1-byte volumes only");
-    if (in->ndim != 3) NOPE("3-D only");
+    if (in->ndim != 3 && !(in->ndim == 2 && g_bm_2d)) NOPE("3-D volumes (and 2-D images) only");
     if (k < 1 || k > kBmMaxK) NOPE("1 .. 8 fused iterations");
-    const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
-    int w[3], off[3];
-    for (int d = 0; d < 3; d++) {
+    // a 2-D image is a one-plane volume with a one-plane structure: the y tiles (x tiles beyond 1024 columns) are the
+    // parallelism, every workgroup a one-plane "stream" -- no plane pipeline, many short workgroups
+    const int pad = 3 - in->ndim;
+    const int64_t nz = pad ? 1 : in->shape[0], ny = in->shape[1 - pad], nx = in->shape[2 - pad];
+    int w[3] = {1, 1, 1}, off[3] = {0, 0, 0};
+    for (int d = 0; d < in->ndim; d++) {
         if (sshape[d] < 1 || sshape[d] > 31) NOPE("structure extent > 31");
-        w[d] = (int)sshape[d];
-        off[d] = (int)(sshape[d] / 2 + origins[d]);
-        if (off[d] < 0 || off[d] >= sshape[d]) { set_error("invalid origin"); return MI_ERR_INVALID_ARG; }
+        w[pad + d] = (int)sshape[d];
+        off[pad + d] = (int)(sshape[d] / 2 + origins[d]);
+        if (off[pad + d] < 0 || off[pad + d] >= sshape[d]) { set_error("invalid origin"); return MI_ERR_INVALID_ARG; }
     }
+    // images: one launch of the byte kernel is as fast or faster (13-15 us, host bound; 8192^2: 27 against 44 us); what the
+    // bit kernel saves there are LAUNCHES -- fused iterations up to ~12 Mpixels (2048^2 x 4 iterations: 40 -> 21 us) and
+    // opening / closing at every size (50 -> 16-21 us; profiles/r6_binary_images.txt)
+    if (pad && g_bm_2d != 2 && !(open_close || (k >= 2 && ny * nx <= (int64_t)12 << 20)))
+        NOPE("images: single iterations (and long fused runs on large images) stay on the byte kernel");
     if (nx < 64 || (nx & 15)) NOPE("rows must be a multiple of 16 bytes, >= 64");
     if (ny * nx >= ((int64_t)1 << 31) || nz > (1 << 24) || ny > (1 << 24)) NOPE("plane too large");
     if (g_bm_on != 2 && nz * ny * nx < (1 << 18)) NOPE("small volume: the byte kernel's launch is as fast");
@@ -652,6 +660,12 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
 }
 
 }  // namespace mi
+
+extern "C" int mi_debug_set_bitmorph_2d(int on)         // 0: 2-D images keep the byte kernel; 2: every image call the bit kernel can take
+{
+    mi::g_bm_2d = on;
+    return MI_OK;
+}
 
 extern "C" int mi_debug_set_bitmorph_table(int on)      // 1: the run-time structure table even for the built-in structures
 {

@@ -238,13 +238,13 @@ def _open_close_fused(input, structure, iterations, output, origin, mask, border
         iterations = operator.index(iterations)
     except TypeError:
         return None                                   # the two-call path raises the reference's TypeError
-    if (input.ndim != 3 or input.dtype.itemsize != 1 or iterations < 1 or 2 * iterations > _MAX_FUSED_STAGES
+    if (input.ndim not in (2, 3) or input.dtype.itemsize != 1 or iterations < 1 or 2 * iterations > _MAX_FUSED_STAGES
             or input.size == 0):
         return None
     st = S.as_host(structure).astype(bool)
-    if st.ndim != 3 or st.size < 1 or any(int(n) % 2 == 0 for n in st.shape):
+    if st.ndim != input.ndim or st.size < 1 or any(int(n) % 2 == 0 for n in st.shape):
         return None
-    if any(int(o) != 0 for o in S.fix_sequence_arg(origin, 3, "origin", int)):
+    if any(int(o) != 0 for o in S.fix_sequence_arg(origin, input.ndim, "origin", int)):
         return None
     if mask is not None:
         mask = S.as_device(mask)

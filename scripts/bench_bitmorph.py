@@ -44,32 +44,37 @@ def cases(b, bo, m):
             ("opening cross x3", lambda: ndi.binary_opening(b, iterations=3, output=bo))]
 
 
-sweep = "--sweep" in sys.argv
-for shape in [(512, 512, 512), (1024, 1024, 1024), (256, 256, 256), (176, 256, 256)]:
-    rng = np.random.default_rng(0)
-    b = ca.asarray(rng.random(shape) > 0.3); bo = ca.empty(shape, bool); m = ca.asarray(rng.random(shape) > 0.3)
-    n = float(np.prod(shape))
-    print("shape", shape, flush=True)
-    for name, fn in cases(b, bo, m):
-        knob(0, 0, 0); t0 = timeit(fn)
-        knob(1, 0, 0); t1 = timeit(fn)
-        print("   %-22s byte kernel %8.1f us (%.3f)   bit kernel %8.1f us (%.3f of 8 TB/s)   %s" % (
-            name, t0, 2 * n / t0 / 1e6 / 8, t1, 2 * n / t1 / 1e6 / 8, ca.last_kernel()[24:80]), flush=True)
-    if sweep and shape[0] >= 512:
-        for name, fn in cases(b, bo, m)[:1] + cases(b, bo, m)[4:5]:
-            for nt in (256,):
-                res = []
-                for ty in (8, 16, 24, 30, 32, 40, 48, 62, 64, 80, 100, 126):
-                    for nzc in (2, 4, 8, 12, 16, 24, 32, 48, 64):
-                        knob(1, ty, nzc)
-                        try:
-                            t = timeit(fn, 6.0)
-                            if ("tile=%dx" % ty) in ca.last_kernel():
-                                res.append((t, ty, nzc))
-                        except Exception as e:
-                            pass
-                res.sort()
-                print("   sweep nt=%4d %-18s best (us, ty, nzc): %s" % (nt, name, ["%.1f/%d/%d" % r for r in res[:8]]), flush=True)
-        knob(1, 0, 0)
-    b = bo = m = None
-    ca.free_all_blocks()
+def main():
+    sweep = "--sweep" in sys.argv
+    for shape in [(512, 512, 512), (1024, 1024, 1024), (256, 256, 256), (176, 256, 256)]:
+        rng = np.random.default_rng(0)
+        b = ca.asarray(rng.random(shape) > 0.3); bo = ca.empty(shape, bool); m = ca.asarray(rng.random(shape) > 0.3)
+        n = float(np.prod(shape))
+        print("shape", shape, flush=True)
+        for name, fn in cases(b, bo, m):
+            knob(0, 0, 0); t0 = timeit(fn)
+            knob(1, 0, 0); t1 = timeit(fn)
+            print("   %-22s byte kernel %8.1f us (%.3f)   bit kernel %8.1f us (%.3f of 8 TB/s)   %s" % (
+                name, t0, 2 * n / t0 / 1e6 / 8, t1, 2 * n / t1 / 1e6 / 8, ca.last_kernel()[24:80]), flush=True)
+        if sweep and shape[0] >= 512:
+            for name, fn in cases(b, bo, m)[:1] + cases(b, bo, m)[4:5]:
+                for nt in (256,):
+                    res = []
+                    for ty in (8, 16, 24, 30, 32, 40, 48, 62, 64, 80, 100, 126):
+                        for nzc in (2, 4, 8, 12, 16, 24, 32, 48, 64):
+                            knob(1, ty, nzc)
+                            try:
+                                t = timeit(fn, 6.0)
+                                if ("tile=%dx" % ty) in ca.last_kernel():
+                                    res.append((t, ty, nzc))
+                            except Exception as e:
+                                pass
+                    res.sort()
+                    print("   sweep nt=%4d %-18s best (us, ty, nzc): %s" % (nt, name, ["%.1f/%d/%d" % r for r in res[:8]]), flush=True)
+            knob(1, 0, 0)
+        b = bo = m = None
+        ca.free_all_blocks()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,6 +142,44 @@ def test_opening_closing_in_one_launch(gpu, ndi, knob, shape):
     assert np.array_equal(out.get(), sndi.binary_closing(x, iterations=2))
 
 
+@pytest.mark.parametrize("shape", [(300, 1040), (77, 2064), (1000, 96), (50, 4096)])
+def test_bitmorph_images(gpu, ndi, knob, shape):
+    """2-D images (one-plane volumes for the same kernel): erosion / dilation with iterations, masks, origins, opening /
+    closing, until-stable -- against SciPy."""
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(shape[1])
+    x = rng.random(shape) > 0.3
+    m = rng.random(shape) > 0.3
+    xd, md = gpu.asarray(x), gpu.asarray(m)
+    disk = (np.indices((5, 5)) - 2)
+    disk = (disk ** 2).sum(0) <= 4
+    from cupyimg_amd import _lib
+    _lib.load().mi_debug_set_bitmorph_2d.argtypes = [ctypes.c_int]
+    _lib.load().mi_debug_set_bitmorph_2d(2)             # every image call the kernel can take (production: fused runs only)
+    for tiles in [(2, 0, 0), (2, 7, 1)]:
+        knob(*tiles)
+        for st in [None, np.ones((3, 3), bool), disk, np.ones((2, 3), bool), rng.random((3, 7)) > 0.4]:
+            for fn, sfn in [(ndi.binary_erosion, sndi.binary_erosion), (ndi.binary_dilation, sndi.binary_dilation)]:
+                for kw in [dict(), dict(iterations=3), dict(border_value=1, iterations=2), dict(mask=True, iterations=2),
+                           dict(origin=(0, 1) if st is None or st.shape[1] >= 3 else 0)]:
+                    kg, ko = dict(kw), dict(kw)
+                    if kw.get("mask"):
+                        kg["mask"], ko["mask"] = md, m
+                    got = fn(xd, st, **kg).get()
+                    assert "bitmorph3_kernel" in last_kernel(), last_kernel()
+                    assert np.array_equal(got, sfn(x, st, **ko)), (fn.__name__, None if st is None else st.shape, kw, tiles)
+            if st is None or all(n % 2 for n in st.shape):
+                for fn, sfn in [(ndi.binary_opening, sndi.binary_opening), (ndi.binary_closing, sndi.binary_closing)]:
+                    assert np.array_equal(fn(xd, st, iterations=2).get(), sfn(x, st, iterations=2)), (fn.__name__, tiles)
+    knob(2, 0, 0)
+    _lib.load().mi_debug_set_bitmorph_2d(1)
+    assert np.array_equal(ndi.binary_erosion(xd, iterations=2).get(), sndi.binary_erosion(x, iterations=2))   # the production rule
+    assert "bitmorph3_kernel" in last_kernel()
+    assert np.array_equal(ndi.binary_fill_holes(xd).get(), sndi.binary_fill_holes(x))
+    seed = rng.random(shape) > 0.995
+    assert np.array_equal(ndi.binary_propagation(gpu.asarray(seed), mask=md).get(), sndi.binary_propagation(seed, mask=m))
+
+
 def test_bitmorph_output_forms_and_dtypes(gpu, ndi, knob):
     """int8 / uint8 inputs (any nonzero byte is true), uint8 output arrays, output given, input untouched."""
     knob(2, 0, 0)
