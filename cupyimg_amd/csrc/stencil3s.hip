@@ -18,8 +18,9 @@
 //   * an input row is read ONCE per plane (one 16-byte read per lane; the W/2 neighbours either side come from the
 //     adjacent lanes by DPP, the tile's own halo by one small read in the edge lanes) and feeds W rows x W planes x W taps;
 //   * weights are kernel arguments of the accumulator's type, addressed with compile-time indices: scalar registers
-//     (the 125 of the 5^3 window do not fit -- as pairs for v_pk_fma_f32 they would need 250 -- and are partly re-read
-//     through v_readlane from spill lanes; LDS-resident weights were tried and lost: profiles/r6_stencil.txt);
+//     (the 125 of the 5^3 window do not fit -- as pairs for v_pk_fma_f32 they would need 250: in float mode they live in the
+//     lanes of two vector registers and are read with one v_readlane per weight and plane; LDS-resident weights were tried
+//     and lost: profiles/r6_stencil.txt);
 //   * float32 accumulation uses v_pk_fma_f32 on x-pairs; float64 accumulation is v_mul_f64 + v_add_f64 in the order
 //     (z, y, x) of the window -- the plane-by-plane scatter adds the taps of one output in exactly that order, so the
 //     result is bit-identical to stencil3_kernel / corr3_kernel / SciPy's NI_Correlate.
@@ -59,6 +60,7 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
     constexpr int RPW = (ROWS + kSsNW - 1) / kSsNW;       // staged rows per wave
     constexpr int SLOT = ROWS * kSsPitch;
     constexpr bool F32 = std::is_same<Acc, float>::value;
+    constexpr bool LANEW = W == 5 && F32;                 // weights in the lanes of two registers (see the tap loop)
     __shared__ __attribute__((aligned(16))) float ring[2 * SLOT];
 
     const int lane = threadIdx.x & 63;
@@ -144,6 +146,11 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
 #pragma unroll
             for (int c = 0; c < 4; c++) A[a][rr][c] = (Acc)0;
 
+    float wlane[2] = {0.f, 0.f};
+    if constexpr (LANEW) {
+        wlane[0] = p.w[lane];
+        wlane[1] = lane + 64 < W * W * W ? p.w[lane + 64] : 0.f;
+    }
     const int nsteps = nout + W - 1;
     fetch(0);
     stage(0);
@@ -188,7 +195,40 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
                 d[7] = last_lane ? hr.y : r1v;
             }
         };
-        {
+        if constexpr (LANEW) {
+            // 5^3, float accumulation: the 125 weights live in the LANES of two registers (lane k of wlane[k >> 6] = w[k]) and
+            // come out by v_readlane where they are used -- ONE per weight and plane: the window is walked one row ty at a
+            // time with the RW input rows that share it live, so the four packed FMAs of a weight stand together.  As
+            // kernel arguments they were 250 scalar registers (pairs for v_pk_fma_f32): spilled to lanes by the compiler and
+            // read back 3 700 times per 2 500 FMAs.  (The registers pass through an empty asm per plane: the reads must not
+            // be hoisted out of the plane loop, where they would be 125 live scalars again.)
+            unsigned wb0 = __float_as_uint(wlane[0]), wb1 = __float_as_uint(wlane[1]);
+            asm volatile("" : "+v"(wb0), "+v"(wb1));
+            float dr[RW + W - 1][4 + 2 * RX];
+#pragma unroll
+            for (int i = 0; i < RW - 1; i++) read_row(i, dr[i]);
+#pragma unroll
+            for (int ty = 0; ty < W; ty++) {
+                read_row(ty + RW - 1, dr[ty + RW - 1]);
+#pragma unroll
+                for (int tz = 0; tz < W; tz++) {
+                    const int a = (PH - tz + 2 * W) % W;   // compile time: the set of output plane q - tz
+                    __builtin_amdgcn_sched_barrier(0);     // five weights at a time: the scheduler would read all 125 up front and spill them back to lanes
+#pragma unroll
+                    for (int tx = 0; tx < W; tx++) {
+                        const int k = (tz * W + ty) * W + tx;
+                        const f32x2 w2 = splat2(__uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(k < 64 ? wb0 : wb1), k & 63)));
+#pragma unroll
+                        for (int rr = 0; rr < RW; rr++) {
+                            const float (&d)[4 + 2 * RX] = dr[rr + ty];
+                            const f32x2 lo = fma2((f32x2){d[tx], d[tx + 1]}, w2, (f32x2){A[a][rr][0], A[a][rr][1]});
+                            const f32x2 hi = fma2((f32x2){d[tx + 2], d[tx + 3]}, w2, (f32x2){A[a][rr][2], A[a][rr][3]});
+                            A[a][rr][0] = lo.x; A[a][rr][1] = lo.y; A[a][rr][2] = hi.x; A[a][rr][3] = hi.y;
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < RW + W - 1; i++) {
                 float d[4 + 2 * RX];
@@ -331,7 +371,7 @@ int stencil3_scatter(const mi_array *in, const mi_array *out, const double *weig
                     : run_scatter<3, double, 2>(in, out, weights, off, mode, cval, s);
     }
     if (acc_f32) return run_scatter<5, float, 2>(in, out, weights, off, mode, cval, s);
-    if (f32w) return run_scatter<5, double, 2, true>(in, out, weights, off, mode, cval, s);
+    if (f32w && nz * ny * nx >= ((int64_t)1 << 25)) return run_scatter<5, double, 2, true>(in, out, weights, off, mode, cval, s);   // 256^3: the ring kernel is 10 % faster
     // 250 f64 mul + add per voxel: bound by the FP64 pipe either way, and the LDS-ring kernel is as fast (1.66 vs 1.68 ms
     // on 512^3, faster on 256^3)
     set_error("stencil3s: 5 x 5 x 5 with float64 weights and float64 accumulation stays on the LDS-ring kernel");
