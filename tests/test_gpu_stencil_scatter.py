@@ -69,7 +69,8 @@ def test_scatter_float32_valued_weights_use_fma_and_stay_exact(gpu, ndi, knob, W
     for w in (rng.standard_normal((W, W, W)).astype(np.float32), rng.integers(1, 9, size=(W, W, W)).astype(np.float64),
               np.full((W, W, W), 0.125)):
         got = ndi.correlate(xd, w, mode="mirror")
-        assert "stencil3s_kernel<%d,double" % W in last_kernel() and "fma" in last_kernel(), last_kernel()
+        if W == 3:                                           # 5^3: from 2^25 voxels (test_scatter_full_size_512_every_plane)
+            assert "stencil3s_kernel<3,double" in last_kernel() and "fma" in last_kernel(), last_kernel()
         got = got.get()
         knob(0)
         ring = ndi.correlate(xd, w, mode="mirror").get()
@@ -121,6 +122,13 @@ def test_scatter_full_size_512_every_plane(gpu, ndi, W):
     assert ("stencil3s_kernel<%d,double" % W in last_kernel()) == (W == 3), last_kernel()
     bad = fs.whole_volume_filter(x, out.get(), W // 2, W // 2, lambda s: sndi.correlate(s.astype(np.float64), w).astype(np.float32),
                                  exact=True, planes=8)
+    assert bad == 0, bad
+    w32 = w.astype(np.float32)                              # float32-valued weights: v_fma_f64 with exact products
+    for _ in range(6):
+        ndi.correlate(xd, w32, output=out)
+    assert "stencil3s_kernel<%d,double" % W in last_kernel() and "fma" in last_kernel(), last_kernel()
+    bad = fs.whole_volume_filter(x, out.get(), W // 2, W // 2,
+                                 lambda s: sndi.correlate(s.astype(np.float64), w32.astype(np.float64)).astype(np.float32), exact=True, planes=8)
     assert bad == 0, bad
     for _ in range(6):
         ndi.correlate(xd, w, output=out, dtype_mode="float")
