@@ -169,9 +169,17 @@ def _binary_erosion(input, structure, iterations, mask, output, border_value, or
                 cur = bufs[which]
                 for k in sizes[1:]:
                     which ^= 1
-                    if not launch_fused(cur, bufs[which], k, None):        # the envelope only shrinks with k: cannot happen
-                        raise RuntimeError("mi_binary_erosion_fused refused {} iterations after accepting {}".format(k, sizes[0]))
-                    cur = bufs[which]
+                    if launch_fused(cur, bufs[which], k, None):
+                        cur = bufs[which]
+                        continue
+                    # a shorter tail may be refused where the full batch was taken (images: single iterations belong to the
+                    # byte kernel): one launch per iteration between the two buffers; `cur` may end in either, the copy
+                    # below puts it where it belongs
+                    for _ in range(k):
+                        launch(cur, bufs[which])
+                        cur = bufs[which]
+                        which ^= 1
+                    which ^= 1
             else:
                 which = 0 if iterations & 1 else 1
                 for _ in range(iterations):

@@ -31,6 +31,7 @@ bash scripts/kstat_any.sh $TAG/binary_stats scripts/prof_bitmorph.py > $O/binary
 timeout 600 bash scripts/pmc_script.sh $TAG/binary_pmc scripts/prof_bitmorph.py > $O/binary_pmc.txt 2>&1; tail -30 $O/binary_pmc.txt
 timeout 900 bash scripts/profile_bench.sh $TAG/headline_prof > $O/headline_prof.txt 2>&1; tail -14 $O/headline_prof.txt
 cd $GRAFT_REPO_ROOT
+timeout 400 python scripts/fuzz_r6.py 240 606 2>&1 | grep -v "_kernel" | tail -8 | tee $O/fuzz_r6.txt
 # r5: the targeted fuzz of the round-5 routes and the tables of the kernels added this round
 timeout 260 python scripts/fuzz_r5.py 200 505 2>&1 | tail -60 | tee $O/fuzz_r5.txt
 timeout 300 python scripts/bench_ragged_rows.py > $O/ragged_rows.txt 2>&1

@@ -175,6 +175,9 @@ def test_bitmorph_images(gpu, ndi, knob, shape):
     _lib.load().mi_debug_set_bitmorph_2d(1)
     assert np.array_equal(ndi.binary_erosion(xd, iterations=2).get(), sndi.binary_erosion(x, iterations=2))   # the production rule
     assert "bitmorph3_kernel" in last_kernel()
+    # a fused batch of four, then a tail the kernel refuses for images (single iterations: byte kernel) -- found by scripts/fuzz_r6.py
+    for it in (5, 6, 9):
+        assert np.array_equal(ndi.binary_dilation(xd, iterations=it).get(), sndi.binary_dilation(x, iterations=it)), it
     assert np.array_equal(ndi.binary_fill_holes(xd).get(), sndi.binary_fill_holes(x))
     seed = rng.random(shape) > 0.995
     assert np.array_equal(ndi.binary_propagation(gpu.asarray(seed), mask=md).get(), sndi.binary_propagation(seed, mask=m))
