@@ -126,7 +126,13 @@ __device__ __forceinline__ unsigned bm_fixed_word(const char *c, const int (&so)
 // write to their dump word, so that no stage needs a divergent branch.
 //
 // NL = 16-byte granules a thread stages per plane (at most); a thread owns at most NW = ceil(NL / 2) words per stage
-template <bool HAS_MASK, int NL, int NT, int KIND>
+// RG (r6): rows of ANY length >= 64 bytes (181 x 217 x 181 masks ...).  16-byte buffer loads and stores take any byte
+// alignment on this chip, so a row is staged from wherever it starts; what differs is the LAST granule of a row, which holds
+// nx % 16 voxels of its row followed by the head of the next one: stage 0 replaces those bits by the border bit (taps beyond
+// the row end see border_value, like every other out-of-array position), the output stores that granule in 8 / 4 / 2 / 1-byte
+// pieces, and the load descriptors reach 16 bytes past a plane (the host has checked that the allocation does: a 16-byte
+// access that straddles num_records loses its straddling DWORD, in-range bytes included).
+template <bool HAS_MASK, int NL, int NT, int KIND, bool RG = false>
 __global__ void __launch_bounds__(NT)
 bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict__ out, const unsigned char *__restrict__ msk,
                  const BitMorphParams p, int32_t *flags)
@@ -163,6 +169,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
     // ---- staging recipe: granule g = tid + NT i of the gy x ngx staged granules
     unsigned voff[NL];
     int ldsb[NL];                                          // byte offset inside a slot (the dump word: nothing to stage)
+    unsigned gvalid[RG ? NL : 1];                          // RG: the bits of the granule that belong to its row
 #pragma unroll
     for (int i = 0; i < NL; i++) {
         const int g = tid + NT * i;
@@ -172,6 +179,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
         const bool inside = staged && y >= 0 && y < ny && xg >= 0 && 16 * xg < nx;
         voff[i] = inside ? (unsigned)(y * nx + 16 * xg) : kOOB;
         ldsb[i] = staged ? (row * pitch + 1) * 4 + 2 * col : -1;
+        if constexpr (RG) gvalid[i] = !inside ? 0u : (nx - 16 * xg >= 16 ? 0xffffu : ((1u << (nx - 16 * xg)) - 1u));
     }
     // ---- stage recipe: word q = tid + NT i of the gy x gxw staged words
     int woff[NW];                                          // word offset inside a slot, -1 = none
@@ -197,6 +205,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
     const int ogx = 2 * p.txw;
     unsigned ovoff[NL];
     int olds[NL];
+    int otail[RG ? NL : 1];                                // RG: voxels of the granule that belong to its row (16: a whole one)
 #pragma unroll
     for (int i = 0; i < NL; i++) {
         const int g = tid + NT * i;
@@ -205,6 +214,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
         const bool live = g < p.ty * ogx && y < ny && 16 * xg < nx;
         ovoff[i] = live ? (unsigned)(y * nx + 16 * xg) : kOOB;                 // a store at kOOB is dropped by the descriptor
         olds[i] = g < p.ty * ogx ? ((k * p.oy + row) * pitch + 1 + p.hlw) * 4 + 2 * col : 0;
+        if constexpr (RG) otail[i] = live ? min(nx - 16 * xg, 16) : 16;
     }
 
     // the pad words either side of every staged row hold the border bit for good (a tile edge that is not an array
@@ -231,7 +241,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
         pout = (unsigned)zsrc >= (unsigned)nz || s > last_fetch;
         zsrc = pout ? 0 : zsrc;
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(in + (size_t)zsrc * plane_elems), 0, (int)plane_bytes, 0x00020000);
+            (void *)(in + (size_t)zsrc * plane_elems), 0, (int)plane_bytes + (RG ? 16 : 0), 0x00020000);
 #pragma unroll
         for (int i = 0; i < NL; i++) pin[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, pout ? kOOB : voff[i], 0, 0);
         if constexpr (HAS_MASK) {
@@ -239,7 +249,7 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
             const bool mout = (unsigned)zm >= (unsigned)nz || zm > ze - 1 + (k - 1) * p.hz;
             zm = mout ? 0 : zm;
             const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(msk + (size_t)zm * plane_elems), 0, (int)plane_bytes, 0x00020000);
+                (void *)(msk + (size_t)zm * plane_elems), 0, (int)plane_bytes + (RG ? 16 : 0), 0x00020000);
 #pragma unroll
             for (int i = 0; i < NL; i++) pmk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, mout ? kOOB : voff[i], 0, 0);
         }
@@ -258,7 +268,9 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
             for (int i = 0; i < NL; i++) {
                 // no branch: a granule outside the array (or a plane that is not there) packs the zeros its kOOB load
                 // returned and is replaced by the border bits with one select
-                const unsigned om = (pout || voff[i] == kOOB) ? 0xffffffffu : 0u;
+                unsigned om;
+                if constexpr (RG) om = pout ? 0xffffffffu : ~gvalid[i];
+                else om = (pout || voff[i] == kOOB) ? 0xffffffffu : 0u;
                 const unsigned g16 = ((pack16(pin[i]) ^ inv16) & ~om) | (border32 & om);
                 *reinterpret_cast<unsigned short *>(ldsb[i] < 0 ? dumpb : slot + ldsb[i]) = (unsigned short)g16;
             }
@@ -387,8 +399,28 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
 #pragma unroll
             for (int i = 0; i < NL; i++) w[i] = *reinterpret_cast<const unsigned short *>(slot + olds[i]);
 #pragma unroll
-            for (int i = 0; i < NL; i++)
-                __builtin_amdgcn_raw_buffer_store_b128(unpack16(w[i] ^ inv16out), rout, live ? ovoff[i] : kOOB, 0, 0);
+            for (int i = 0; i < NL; i++) {
+                const u32x4 v = unpack16(w[i] ^ inv16out);
+                if constexpr (!RG) {
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rout, live ? ovoff[i] : kOOB, 0, 0);
+                } else {
+                    // a whole granule, or the 1 .. 15 voxels of a row's last one as 8 + 4 + 2 + 1 bytes (every store is issued,
+                    // at kOOB when it has nothing to write: the operation count of a step stays the same on every path)
+                    const int nv = otail[i];
+                    const unsigned o = live ? ovoff[i] : kOOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rout, nv == 16 ? o : kOOB, 0, 0);
+                    const bool part = nv < 16 && o != kOOB;
+                    const unsigned o4 = (nv & 8) ? 8u : 0u, o2 = o4 + ((nv & 4) ? 4u : 0u), o1 = o2 + ((nv & 2) ? 2u : 0u);
+                    const unsigned d4 = (nv & 8) ? v.z : v.x;
+                    const unsigned d2s = o2 >= 8 ? (o2 >= 12 ? v.w : v.z) : (o2 >= 4 ? v.y : v.x);
+                    const unsigned d1w = o1 >= 8 ? (o1 >= 12 ? v.w : v.z) : (o1 >= 4 ? v.y : v.x);
+                    const unsigned d1 = d1w >> (8 * (o1 & 3u));
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){v.x, v.y}, rout, (part && (nv & 8)) ? o : kOOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(d4, rout, (part && (nv & 4)) ? o + o4 : kOOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)d2s, rout, (part && (nv & 2)) ? o + o2 : kOOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)d1, rout, (part && (nv & 1)) ? o + o1 : kOOB, 0, 0);
+                }
+            }
         }
         pslot = wslot;
         wslot = wslot + 1 == ns ? 0 : wslot + 1;
@@ -423,23 +455,23 @@ bitmorph3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict
 }
 
 // test / tuning hook: on = 0 never, 1 the production rule, 2 also on small volumes; (ty, nzc) of the next launches, 0 = the planner's
-static Knob g_bm_ty{0}, g_bm_nzc{0}, g_bm_on{1}, g_bm_kind0{0}, g_bm_2d{1};
+static Knob g_bm_ty{0}, g_bm_nzc{0}, g_bm_on{1}, g_bm_kind0{0}, g_bm_2d{1}, g_bm_ragged{1};
 
-template <bool HAS_MASK, int NL, int NT, int KIND>
+template <bool HAS_MASK, int NL, int NT, int KIND, bool RG>
 static int launch_bitmorph(const unsigned char *in, unsigned char *out, const unsigned char *msk, const BitMorphParams &p,
                            size_t lds, int32_t *flags, hipStream_t s)
 {
     static PerDeviceOnce attr;
     if (!attr) {
-        MI_HIP(hipFuncSetAttribute((const void *)bitmorph3_kernel<HAS_MASK, NL, NT, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        MI_HIP(hipFuncSetAttribute((const void *)bitmorph3_kernel<HAS_MASK, NL, NT, KIND, RG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kBmMaxLds));
         attr = true;
     }
     const int64_t total = (int64_t)p.nxt * p.nyt * p.nzc;
-    hipLaunchKernelGGL((bitmorph3_kernel<HAS_MASK, NL, NT, KIND>), dim3((unsigned)total), dim3(NT), lds, s, in, out, msk, p, flags);
+    hipLaunchKernelGGL((bitmorph3_kernel<HAS_MASK, NL, NT, KIND, RG>), dim3((unsigned)total), dim3(NT), lds, s, in, out, msk, p, flags);
     MI_HIP(hipGetLastError());
-    note_kernel("mi::bitmorph3_kernel<%s,%d,%d,%s> grid=%lld k=%d%s tile=%dx%d rows, %d planes (1 bit per voxel, %d fused iteration%s per launch)",
-                HAS_MASK ? "mask" : "nomask", NL, NT, KIND == 0 ? "table" : KIND == 1 ? "cross" : KIND == 2 ? "conn18" : "cube3", (long long)total, p.k, p.kflip ? (p.invert ? " (closing)" : " (opening)") : "", p.ty, p.txw * 32, p.zc, p.k, p.k == 1 ? "" : "s");
+    note_kernel("mi::bitmorph3_kernel<%s,%d,%d,%s%s> grid=%lld k=%d%s tile=%dx%d rows, %d planes (1 bit per voxel, %d fused iteration%s per launch)",
+                HAS_MASK ? "mask" : "nomask", NL, NT, KIND == 0 ? "table" : KIND == 1 ? "cross" : KIND == 2 ? "conn18" : "cube3", RG ? ",ragged" : "", (long long)total, p.k, p.kflip ? (p.invert ? " (closing)" : " (opening)") : "", p.ty, p.txw * 32, p.zc, p.k, p.k == 1 ? "" : "s");
     return MI_OK;
 }
 
@@ -477,7 +509,25 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     // opening / closing at every size (50 -> 16-21 us; profiles/r6_binary_images.txt)
     if (pad && g_bm_2d != 2 && !(open_close || (k >= 2 && ny * nx <= (int64_t)12 << 20)))
         NOPE("images: single iterations (and long fused runs on large images) stay on the byte kernel");
-    if (nx < 64 || (nx & 15)) NOPE("rows must be a multiple of 16 bytes, >= 64");
+    if (nx < 64) NOPE("rows of at least 64 bytes");
+    const bool ragged = (nx & 15) != 0;
+    if (ragged) {
+        // the ragged build reads up to 16 bytes past the last row of a plane (masked out): past the last plane that is past
+        // the array -- only taken when the allocation the array lies in (ours or anybody's) has those bytes
+        if (!g_bm_ragged) NOPE("rows that are not a multiple of 16 bytes: switched off");
+        const mi_array *arrs[2] = {in, mask};
+        for (const mi_array *a : arrs) {
+            if (!a) continue;
+            void *base = nullptr;
+            size_t size = 0;
+            if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)a->data) != hipSuccess) {
+                (void)hipGetLastError();
+                NOPE("rows that are not a multiple of 16 bytes: the extent of the allocation is unknown");
+            }
+            const uintptr_t end = (uintptr_t)a->data + (size_t)(nz * ny * nx);
+            if ((uintptr_t)base + size < end + 16) NOPE("rows that are not a multiple of 16 bytes: no 16 readable bytes after the array");
+        }
+    }
     if (ny * nx >= ((int64_t)1 << 31) || nz > (1 << 24) || ny > (1 << 24)) NOPE("plane too large");
     if (g_bm_on != 2 && nz * ny * nx < (1 << 18)) NOPE("small volume: the byte kernel's launch is as fast");
     if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15) || (mask && ((uintptr_t)mask->data & 15)))
@@ -644,8 +694,9 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     const unsigned char *ip = (const unsigned char *)in->data;
     unsigned char *op = (unsigned char *)out->data;
     const unsigned char *mp = mask ? (const unsigned char *)mask->data : nullptr;
-#define GO3(NLV, KV) return mp ? launch_bitmorph<true, NLV, 256, (KV) <= 1 ? (KV) : 0>(ip, op, mp, p, lds, flags, s) \
-                               : launch_bitmorph<false, NLV, 256, KV>(ip, op, mp, p, lds, flags, s)
+#define GO4(NLV, KV, RGV) return mp ? launch_bitmorph<true, NLV, 256, (KV) <= 1 ? (KV) : 0, RGV>(ip, op, mp, p, lds, flags, s) \
+                                    : launch_bitmorph<false, NLV, 256, KV, RGV>(ip, op, mp, p, lds, flags, s)
+#define GO3(NLV, KV) do { if (ragged) { GO4(NLV, KV, true); } else { GO4(NLV, KV, false); } } while (0)
 #define GO(NLV) do { if (kind == 1) { GO3(NLV, 1); } else if (kind == 2) { GO3(NLV, 2); } else if (kind == 3) { GO3(NLV, 3); } else { GO3(NLV, 0); } } while (0)
     if (nl <= 1) { GO(1); }
     if (nl <= 2) { GO(2); }
@@ -656,10 +707,17 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
     GO(8);
 #undef GO
 #undef GO3
+#undef GO4
 #undef NOPE
 }
 
 }  // namespace mi
+
+extern "C" int mi_debug_set_bitmorph_ragged(int on)     // 0: rows that are not a multiple of 16 bytes keep the extended-rows / generic routes
+{
+    mi::g_bm_ragged = on;
+    return MI_OK;
+}
 
 extern "C" int mi_debug_set_bitmorph_2d(int on)         // 0: 2-D images keep the byte kernel; 2: every image call the bit kernel can take
 {

@@ -33,6 +33,8 @@ __all__ = [
 # tile's halo grows with the stage count: six stages on 1024^3 run 1.50 ms in one launch against 0.95 ms as two launches of
 # three fused iterations each (profiles/r6_binary.txt); two and four stages win (512^3 opening: 103 -> 58 us)
 _MAX_FUSED_STAGES = 4
+_MAX_FUSED_UNTIL_STABLE = 4     # runs until nothing changes: iterations per launch (eight were measured: the wider tile halo costs more than the launches saved)
+_MAX_GROUP = 4                  # ... and the flags of up to four launches are read at once (host round trips, not launches, are what a batch costs)
 _MAX_FUSED = 4      # iterations per launch of mi_binary_erosion_fused (the halo of a tile grows with it; <= MI_BINARY_MAX_FUSED)
 
 
@@ -132,7 +134,20 @@ def _binary_erosion(input, structure, iterations, mask, output, border_value, or
     direct = output._is_c_contiguous() and not core.shares_memory(output, src)
     final = output if direct else core.empty(output.shape, output.dtype)
 
-    if (iterations == 1 and mask is None and src.dtype.itemsize == 1 and src.ndim in (2, 3) and src.shape[-1] % 4
+    def launch_fused(src_, dst_, k, flag_ptr):
+        a, b = src_._desc(), dst_._desc()
+        rc = lib.mi_binary_erosion_fused(ctypes.byref(a), ctypes.byref(b), stp, sshape, org,
+                                         ctypes.byref(mdesc) if mdesc is not None else None,
+                                         int(bool(border_value)), int(invert), int(k), flag_ptr, None)
+        if rc == _lib.MI_ERR_UNSUPPORTED:
+            return False
+        S.check(rc)
+        return True
+
+    if (iterations == 1 and src.dtype.itemsize == 1 and src.ndim == 3 and src.shape[-1] % 16 and final.dtype.itemsize == 1
+            and launch_fused(src, final, 1, None)):
+        pass                    # r6: rows of any length straight through the bit kernel (no extended copy)
+    elif (iterations == 1 and mask is None and src.dtype.itemsize == 1 and src.ndim in (2, 3) and src.shape[-1] % 4
             and max(structure.shape) <= 9):                     # (the tiled kernel takes rows that are multiples of four bytes)
         # rows that are not a multiple of 16 bytes: the tiled kernel on rows extended by the border value (r4b, filters.py
         # _run_on_extended_rows; an out-of-range sample IS the border value, whichever way `invert` reads it)
@@ -148,16 +163,6 @@ def _binary_erosion(input, structure, iterations, mask, output, border_value, or
         # arranged so the last write hits `final` whenever the number of launches is known.  r6: up to _MAX_FUSED
         # iterations run inside ONE launch on a bit-packed tile (mi_binary_erosion_fused, csrc/bitmorph3d.hip) -- the
         # intermediate volumes never reach HBM; shapes / dtypes outside that kernel's envelope iterate one launch each.
-        def launch_fused(src_, dst_, k, flag_ptr):
-            a, b = src_._desc(), dst_._desc()
-            rc = lib.mi_binary_erosion_fused(ctypes.byref(a), ctypes.byref(b), stp, sshape, org,
-                                             ctypes.byref(mdesc) if mdesc is not None else None,
-                                             int(bool(border_value)), int(invert), int(k), flag_ptr, None)
-            if rc == _lib.MI_ERR_UNSUPPORTED:
-                return False
-            S.check(rc)
-            return True
-
         other = core.empty(final.shape, final.dtype)
         bufs = [final, other]
         cur = src
@@ -190,22 +195,41 @@ def _binary_erosion(input, structure, iterations, mask, output, border_value, or
             # until nothing changes: one host read of the flags per batch of _MAX_FUSED iterations (the reference: one
             # full-volume comparison + synchronisation per iteration, morphology.py:313,321); the first iteration that
             # changes nothing ends the run, and the later iterations of its batch reproduce the same volume
-            flags = core.zeros((_MAX_FUSED,), np.int32)
+            # r6: the flags are read once per GROUP of batches (1, 2, then 4 batches): a propagation through a 200-voxel volume
+            # is 50 batches, and what a batch costs is the host round trip, not its 25-us launch; batches queued after the volume
+            # became stable reproduce it (the same buffers ping-pong), so reading late changes nothing but the count.
+            group = 1
+            kb = _MAX_FUSED_UNTIL_STABLE               # iterations per launch: the library's limit first, then the usual batch
+            flags = core.zeros((_MAX_GROUP, _MAX_FUSED_UNTIL_STABLE), np.int32)
             which = 1
             fused_ok = True
             while True:
-                dst = bufs[which]
                 flags.fill(0)
-                if fused_ok and launch_fused(cur, dst, _MAX_FUSED, ctypes.c_void_p(flags.ptr)):
-                    stable = not flags.get().all()
+                stable = False
+                launched = 0
+                for g in range(group if fused_ok else 1):
+                    dst = bufs[which]
+                    fptr = ctypes.c_void_p(flags.ptr + 4 * _MAX_FUSED_UNTIL_STABLE * g)
+                    ok = fused_ok and launch_fused(cur, dst, kb, fptr)
+                    if not ok and fused_ok and g == 0 and kb > _MAX_FUSED:
+                        kb = _MAX_FUSED                # eight stages do not fit a tile here: four
+                        ok = launch_fused(cur, dst, kb, fptr)
+                    if not ok:
+                        if fused_ok and g > 0:
+                            break                      # (cannot happen: the first batch of the run decides; keep the rows consistent)
+                        fused_ok = False
+                        launch(cur, dst, fptr)
+                    cur = dst
+                    which ^= 1
+                    launched += 1
+                got = flags.get()
+                if fused_ok:
+                    stable = not got[:launched, :kb].all()
                 else:
-                    fused_ok = False
-                    launch(cur, dst, ctypes.c_void_p(flags.ptr))
-                    stable = int(flags.get()[0]) == 0
-                cur = dst
-                which ^= 1
+                    stable = int(got[0, 0]) == 0
                 if stable:
                     break
+                group = min(_MAX_GROUP, group * 2)
         if cur is not final:
             final[...] = cur
     if not direct:

@@ -68,7 +68,7 @@ while time.time() < t_end:
         if op <= 4:
             # ---- binary morphology
             nd = 3 if rng.random() < 0.8 else 2
-            nx = int(rng.choice([64, 80, 96, 128, 176, 256, 512, 1040, 2064]))
+            nx = int(rng.choice([64, 80, 96, 128, 176, 256, 512, 1040, 2064, 65, 71, 90, 181, 183, 255, 301, 1043, 2070]))      # r6: rows of any length
             if nd == 3:
                 shape = (int(rng.integers(3, 60)), int(rng.integers(3, 90)), nx)
             else:

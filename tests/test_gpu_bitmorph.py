@@ -183,6 +183,47 @@ def test_bitmorph_images(gpu, ndi, knob, shape):
     assert np.array_equal(ndi.binary_propagation(gpu.asarray(seed), mask=md).get(), sndi.binary_propagation(seed, mask=m))
 
 
+@pytest.mark.parametrize("shape", [(24, 37, 181), (17, 30, 301), (40, 21, 1043), (9, 40, 70), (30, 33, 2070), (12, 19, 184)])
+def test_bitmorph_ragged_rows(gpu, ndi, knob, shape):
+    """Rows that are not a multiple of 16 bytes (181 x 217 x 181 masks): staged from wherever they start, the last granule's
+    foreign bits replaced by the border bit, stored in 8 / 4 / 2 / 1-byte pieces -- every tail length, one and several x
+    tiles; the voxels behind the array (the next allocation) must stay untouched."""
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(shape[2])
+    x = rng.random(shape) > 0.3
+    m = rng.random(shape) > 0.3
+    xd, md = gpu.asarray(x), gpu.asarray(m)
+    for tiles in [(2, 0, 0), (2, 5, 2)]:
+        knob(*tiles)
+        for st in [None, np.ones((3, 3, 3), bool), rng.random((3, 5, 7)) > 0.4, _ball(2)]:
+            for fn, sfn in [(ndi.binary_erosion, sndi.binary_erosion), (ndi.binary_dilation, sndi.binary_dilation)]:
+                for kw in [dict(), dict(border_value=1), dict(iterations=3), dict(iterations=6, border_value=1), dict(mask=True, iterations=2),
+                           dict(origin=(0, 1, -1), iterations=2)]:
+                    kg, ko = dict(kw), dict(kw)
+                    if kw.get("mask"):
+                        kg["mask"], ko["mask"] = md, m
+                    if kw.get("iterations", 1) != 1:
+                        ko["brute_force"] = True           # SciPy's coordinate-list path corrupts its heap on some of these
+                    got = fn(xd, st, **kg).get()
+                    assert "ragged> " in last_kernel(), last_kernel()
+                    assert np.array_equal(got, sfn(x, st, **ko)), (fn.__name__, None if st is None else st.shape, kw, tiles)
+        for fn, sfn in [(ndi.binary_opening, sndi.binary_opening), (ndi.binary_closing, sndi.binary_closing)]:
+            assert np.array_equal(fn(xd, iterations=2).get(), sfn(x, iterations=2)), (fn.__name__, tiles)
+            assert "ragged> " in last_kernel() and "ing)" in last_kernel(), last_kernel()
+    knob(2, 0, 0)
+    # output into the middle of a larger buffer: the bytes either side of it keep their pattern
+    big = gpu.asarray(np.full(x.size + 64, 7, np.uint8))
+    out = big[32:32 + x.size].reshape(shape)
+    assert ndi.binary_dilation(xd, iterations=2, output=out) is out
+    assert "ragged> " in last_kernel(), last_kernel()
+    h = big.get()
+    assert (h[:32] == 7).all() and (h[32 + x.size:] == 7).all()
+    assert np.array_equal(h[32:32 + x.size].reshape(shape).astype(bool), sndi.binary_dilation(x, iterations=2))
+    assert np.array_equal(ndi.binary_fill_holes(xd).get(), sndi.binary_fill_holes(x))
+    seed = rng.random(shape) > 0.99
+    assert np.array_equal(ndi.binary_propagation(gpu.asarray(seed), mask=md).get(), sndi.binary_propagation(seed, mask=m))
+
+
 def test_bitmorph_output_forms_and_dtypes(gpu, ndi, knob):
     """int8 / uint8 inputs (any nonzero byte is true), uint8 output arrays, output given, input untouched."""
     knob(2, 0, 0)
