@@ -69,6 +69,31 @@ def iterate_structure(structure, iterations, origin=None):
     return out, origin
 
 
+_ROOTS = {}
+
+
+def _minkowski_root(structure):
+    """(small, r): `structure` (bool, cubic odd extent 2 r + 1 >= 5) equals r iterations of the 3 x 3 x 3 structure `small`
+    (the cube or the 6-connected cross), else (None, 1).  Memoised on the structure's bytes."""
+    shape = structure.shape
+    if len(shape) != 3 or shape[0] != shape[1] or shape[1] != shape[2] or shape[0] < 5 or shape[0] % 2 == 0 or shape[0] > 31:
+        return None, 1
+    key = (shape, structure.tobytes())
+    if key not in _ROOTS:
+        if len(_ROOTS) > 64:
+            _ROOTS.clear()
+        r = shape[0] // 2
+        found = (None, 1)
+        if structure.all():
+            found = (np.ones((3, 3, 3), bool), r)
+        else:
+            g = np.abs(np.indices(shape) - r).sum(axis=0)
+            if np.array_equal(structure, g <= r):
+                found = (generate_binary_structure(3, 1), r)
+        _ROOTS[key] = found
+    return _ROOTS[key]
+
+
 def _binary_erosion(input, structure, iterations, mask, output, border_value, origin, invert,
                     brute_force=True):
     """morphology.py:204-331"""
@@ -116,6 +141,17 @@ def _binary_erosion(input, structure, iterations, mask, output, border_value, or
     # brute_force=False when the structure centre is set (morphology.py:297-300).
     # SciPy returns the same result either way, so every iteration simply
     # re-evaluates all voxels here (the "brute force" schedule).
+
+    # r6: a structure that is the r-fold Minkowski sum of a 3 x 3 x 3 one -- ones((2 r + 1,) * 3) = r x ones((3, 3, 3)), the
+    # octahedron of radius r = r x the 6-connected cross (iterate_structure) -- runs as r times as many iterations of the
+    # small one: those have straight-line code in the bit kernel and fuse (a 5 x 5 x 5 cube on an MNI-grid mask: 45 -> 22 us).
+    # Exact with either border value: erosion by B + B is erosion by B twice on the zero- / one-extended volume, and every voxel
+    # a dilation by B + B reaches is reached through an intermediate voxel inside the array's box (B convex, axis-symmetric).
+    # Not with a mask (the mask then applies per iteration), not for runs until stable (same fixed point, but let the count be).
+    if mask is None and iterations >= 1 and input.ndim == 3 and input.dtype.itemsize == 1 and not any(origin):
+        small, r = _minkowski_root(structure)
+        if small is not None and iterations * r <= 64:
+            structure, iterations = small, iterations * r
 
     st = np.ascontiguousarray(structure, dtype=np.uint8)
     stp = st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))

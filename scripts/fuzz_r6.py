@@ -47,9 +47,12 @@ def close(name, got, ref, tol, info):
 
 
 def rstruct(nd):
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 7))
     if kind == 0:
         return None
+    if kind == 6 and nd == 3:                      # r-fold Minkowski sums of a 3 x 3 x 3 structure: run as iterations of the root
+        r = int(rng.integers(2, 4))
+        return np.ones((2 * r + 1,) * 3, bool) if rng.random() < 0.5 else np.abs(np.indices((2 * r + 1,) * 3) - r).sum(0) <= r
     if kind == 1:
         return sndi.generate_binary_structure(nd, int(rng.integers(1, nd + 1)))
     if kind == 2:

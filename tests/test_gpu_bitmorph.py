@@ -224,6 +224,34 @@ def test_bitmorph_ragged_rows(gpu, ndi, knob, shape):
     assert np.array_equal(ndi.binary_propagation(gpu.asarray(seed), mask=md).get(), sndi.binary_propagation(seed, mask=m))
 
 
+@pytest.mark.parametrize("shape", [(30, 44, 96), (25, 37, 181), (9, 11, 80)])
+def test_cubes_and_octahedra_run_as_iterations_of_their_3x3x3_root(gpu, ndi, knob, shape):
+    """ones((2r+1,)*3) = r iterations of ones((3,3,3)), the octahedron of radius r = r iterations of the cross: exact with
+    either border value, also where the structure is larger than the array, and iterations multiply."""
+    from cupyimg_amd import last_kernel
+    knob(2, 0, 0)
+    rng = np.random.default_rng(shape[2])
+    for density in (0.1, 0.5, 0.9):
+        x = rng.random(shape) > density
+        xd = gpu.asarray(x)
+        for r in (2, 3, 4):
+            cube = np.ones((2 * r + 1,) * 3, bool)
+            octa = np.abs(np.indices((2 * r + 1,) * 3) - r).sum(0) <= r
+            for st, tag in ((cube, "cube3"), (octa, "cross")):
+                for fn, sfn in [(ndi.binary_erosion, sndi.binary_erosion), (ndi.binary_dilation, sndi.binary_dilation)]:
+                    for kw in (dict(), dict(border_value=1), dict(iterations=2)):
+                        got = fn(xd, st, **kw).get()
+                        assert "," + tag in last_kernel(), (tag, last_kernel())
+                        assert np.array_equal(got, sfn(x, st, brute_force=True, **kw)), (fn.__name__, tag, r, kw, density)
+                assert np.array_equal(ndi.binary_opening(xd, st).get(), sndi.binary_opening(x, st)), (tag, r)
+                assert np.array_equal(ndi.binary_closing(xd, st, border_value=1).get(), sndi.binary_closing(x, st, border_value=1)), (tag, r)
+        # with a mask the big structure stays what it is
+        m = rng.random(shape) > 0.3
+        got = ndi.binary_dilation(xd, np.ones((5, 5, 5), bool), mask=gpu.asarray(m)).get()
+        assert ",table" in last_kernel(), last_kernel()
+        assert np.array_equal(got, sndi.binary_dilation(x, np.ones((5, 5, 5), bool), mask=m))
+
+
 def test_bitmorph_output_forms_and_dtypes(gpu, ndi, knob):
     """int8 / uint8 inputs (any nonzero byte is true), uint8 output arrays, output given, input untouched."""
     knob(2, 0, 0)
