@@ -299,7 +299,7 @@ def test_fused_abi_flags_and_refusals(gpu, knob):
     assert rc == _lib.MI_ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("n,iterations", [(512, 1), (512, 3), (256, 7)])
+@pytest.mark.parametrize("n,iterations", [(512, 1), (512, 3), (256, 7), (1024, 2)])
 def test_bitmorph_full_size_every_plane(gpu, ndi, n, iterations):
     """n^3 bool, default structure: every plane against scipy.ndimage on z sub-slabs (halo = iterations planes; at a
     global edge the slab edge is the volume edge and border_value applies as unsplit), last launch of a burst."""

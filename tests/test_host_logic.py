@@ -198,3 +198,28 @@ def test_interpolation_signatures_follow_the_reference():
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mi355img.h")).read()
     assert "#define MI_SPLINE_SKIP_AXIS(d) (0x200 << (d))" in hdr and I._SPLINE_SKIP_AXIS0 == 0x200
     assert "#define MI_SPLINE_SAMPLES_AXIS(d) (0x100 << (d))" in hdr and I._SPLINE_SAMPLES_AXIS0 == 0x100
+
+
+def test_minkowski_root_of_cubes_and_octahedra():
+    """r6 (morphology._minkowski_root): ones((2r+1,)*3) and the octahedron of radius r are r-fold Minkowski sums of a
+    3 x 3 x 3 structure -- and SciPy agrees that iterating the root gives the same erosion / dilation, with either border
+    value, on arrays smaller than the structure too; anything else is left alone."""
+    rng = np.random.default_rng(3)
+    for r in (2, 3, 5):
+        cube = np.ones((2 * r + 1,) * 3, bool)
+        octa = np.abs(np.indices((2 * r + 1,) * 3) - r).sum(0) <= r
+        for st, root in ((cube, np.ones((3, 3, 3), bool)), (octa, sndi.generate_binary_structure(3, 1))):
+            small, k = morphology._minkowski_root(st)
+            assert k == r and np.array_equal(small, root)
+            assert np.array_equal(sndi.iterate_structure(root, r), st)
+            for shape in ((12, 9, 14), (3, 4, 20)):
+                x = rng.random(shape) > 0.4
+                for bv in (0, 1):
+                    assert np.array_equal(sndi.binary_dilation(x, st, border_value=bv),
+                                          sndi.binary_dilation(x, root, iterations=r, border_value=bv, brute_force=True))
+                    assert np.array_equal(sndi.binary_erosion(x, st, border_value=bv),
+                                          sndi.binary_erosion(x, root, iterations=r, border_value=bv, brute_force=True))
+    ball = (np.indices((5, 5, 5)) - 2)
+    ball = (ball ** 2).sum(0) <= 4
+    for st in (ball, np.ones((3, 3, 3), bool), np.ones((5, 5, 3), bool), np.ones((4, 4, 4), bool), np.ones((5, 5), bool)):
+        assert morphology._minkowski_root(st) == (None, 1)
