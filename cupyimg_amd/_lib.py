@@ -127,6 +127,7 @@ SIGNATURES = {
     "mi_binary_erosion": [_arr, _arr, _u8p, _i64p, _ip, _arr, _i, _i, _vp, _vp],
     "mi_binary_erosion_fused": [_arr, _arr, _u8p, _i64p, _ip, _arr, _i, _i, _i, _vp, _vp],
     "mi_binary_open_close_fused": [_arr, _arr, _u8p, _i64p, _arr, _i, _i, _i, _vp],
+    "mi_binary_propagation_step": [_arr, _arr, _u8p, _i64p, _ip, _arr, _i, _vp, _vp],
     "mi_map_coordinates": [_arr, _arr, _arr, _i, _i, _d, _vp],
     "mi_affine_transform": [_arr, _arr, _dp, _i, _i, _d, _vp],
     "mi_spline_pad": [_arr, _arr, _i, _i, _d, _vp],

@@ -95,6 +95,8 @@ int binary3_tiled(const mi_array *in, const mi_array *out, const uint8_t *struct
                   hipStream_t s);   // binary3d.hip
 int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure, const int64_t *sshape, const int *origins,
               const mi_array *mask, int border_value, int invert, int k, int32_t *flags, hipStream_t s, int open_close = 0);   // bitmorph3d.hip
+int bitfill3(const mi_array *in, const mi_array *out, const uint8_t *structure, const int64_t *sshape, const int *origins,
+             const mi_array *mask, int border_value, int32_t *flag, hipStream_t s);                                            // bitmorph3d.hip
 }
 
 using namespace mi;
@@ -135,6 +137,19 @@ extern "C" int mi_binary_erosion_fused(const mi_array *in, const mi_array *out, 
     if (numel(in) == 0) return MI_OK;
     return bitmorph3(in, out, structure, sshape, origins, mask, border_value, invert, iterations, changed_dev,
                      resolve_stream(stream));
+}
+
+// One launch of a masked DILATION's block-wise fill towards its fixed point (binary_propagation / binary_fill_holes): see
+// bitfill3_kernel.  The caller ping-pongs two buffers until *changed_dev stays 0.
+extern "C" int mi_binary_propagation_step(const mi_array *in, const mi_array *out, const uint8_t *structure,
+                                          const int64_t *sshape, const int *origins, const mi_array *mask,
+                                          int border_value, int32_t *changed_dev, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_binary_args(in, out, structure, sshape, origins, mask))) return rc;
+    MI_REQUIRE(mask, MI_ERR_INVALID_ARG, "mask is NULL");
+    if (numel(in) == 0) return MI_OK;
+    return bitfill3(in, out, structure, sshape, origins, mask, border_value, changed_dev, resolve_stream(stream));
 }
 
 // Opening (erosions, then dilations) or closing (dilations, then erosions), `iterations` of each, in ONE launch: the

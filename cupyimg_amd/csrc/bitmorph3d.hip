@@ -475,6 +475,274 @@ static int launch_bitmorph(const unsigned char *in, unsigned char *out, const un
     return MI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bitfill3_kernel (r6): masked dilation UNTIL STABLE -- binary_propagation, binary_fill_holes (morphology.py:684-766; the
+// reference: one launch, one full-volume comparison and one host synchronisation per ITERATION).  The operator
+// s' = s | (mask & OR of the structure's taps of s) is monotone when the structure holds its centre, so ANY fair order of
+// local updates reaches the same least fixed point.  A workgroup takes a block of BZ planes x BY rows x whole rows (+ halo of
+// the structure's reach) as bits in LDS; every thread owns ONE ROW and per sweep (1) ORs the taps of the neighbouring rows
+// into it, (2) FILLS along x: inside a run of mask bits everything above / below a set bit is set in one pass, by the carry
+// of an addition (u = m + (s & m) + carry: the bits a carry ran through are the filled ones; down: the same on bit-reversed
+// words) -- what x-adjacent taps would need one iteration per voxel for.  Sweeps repeat until the block is stable (a row
+// step per sweep along y / z), its halo being what the neighbours held when the launch began; the host repeats launches
+// (ping-pong) until no block changed.  A plain block relaxation without the fill was measured first and was no faster than
+// the fused iterations (profiles/r6_relaxation_experiment.txt): a sweep then moves information one voxel, like an iteration.
+// True space (bit = voxel set); outside the array a tap sees border_value.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kFillNT = 256;
+constexpr int kFillSweeps = 64;
+
+struct FillParams {
+    int nx, ny, nz;
+    int oz, oy, ox;         // lo reach (w/2 + origin)
+    int hz, hy;             // hi reach
+    int nrows;
+    int border;             // true-space bit outside the array
+    int bz, by;             // block: planes x rows (bz * by <= 256: one row per thread)
+    int gxw, pitch;         // words per row (whole rows), LDS words per row (1 pad + gxw + 1 pad)
+    int nyt, nzt;
+    int fill_up, fill_down; // the centre row holds the tap at dx = -1 / dx = +1
+    alignas(16) int rows[kBmMaxRows][4];      // { tz, dx mask, ty, 0 }
+};
+
+template <bool RG>
+__global__ void __launch_bounds__(kFillNT)
+bitfill3_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict__ out, const unsigned char *__restrict__ msk,
+                const FillParams p, int32_t *flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    __shared__ int sweep_changed, any_changed;
+    const int tid = threadIdx.x;
+    const int zt = blockIdx.x / p.nyt, yt = blockIdx.x - zt * p.nyt;
+    const int nx = p.nx, ny = p.ny, nz = p.nz, gxw = p.gxw, pitch = p.pitch;
+    const int z0 = zt * p.bz, y0 = yt * p.by;
+    const int gz = p.bz + p.oz + p.hz, gy = p.by + p.oy + p.hy;          // staged planes / rows
+    const int zf = z0 - p.oz, yf = y0 - p.oy;                             // array plane / row of staged plane / row 0
+    const int ngx = 2 * gxw;
+    const int plane_words = gy * pitch;
+    unsigned *S = lds, *M = lds + gz * plane_words;
+    const size_t plane_elems = (size_t)ny * (size_t)nx;
+    const unsigned plane_bytes = (unsigned)ny * (unsigned)nx;
+    const unsigned border32 = p.border ? 0xffffffffu : 0u;
+    if (tid == 0) { sweep_changed = 0; any_changed = 0; }
+
+    // ---- stage the block (+ halo): state and mask as bits; out-of-array positions hold the border bit / mask 0
+    for (int r = tid; r < gz * gy; r += kFillNT) {
+        S[r * pitch] = border32;
+        S[r * pitch + gxw + 1] = border32;
+        M[r * pitch] = 0u;
+        M[r * pitch + gxw + 1] = 0u;
+    }
+    const int ngran = gz * gy * ngx;
+    for (int g = tid; g < ngran; g += kFillNT) {
+        const int zi = g / (gy * ngx), rem = g - zi * (gy * ngx);
+        const int yi = rem / ngx, col = rem - yi * ngx;
+        const int z = zf + zi, y = yf + yi;
+        const bool inside = (unsigned)z < (unsigned)nz && (unsigned)y < (unsigned)ny && 16 * col < nx;
+        unsigned s16 = border32, m16 = 0u;
+        if (inside) {
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(in + (size_t)z * plane_elems), 0, (int)plane_bytes + (RG ? 16 : 0), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(msk + (size_t)z * plane_elems), 0, (int)plane_bytes + (RG ? 16 : 0), 0x00020000);
+            const unsigned off = (unsigned)(y * nx + 16 * col);
+            const unsigned valid = nx - 16 * col >= 16 ? 0xffffu : ((1u << (nx - 16 * col)) - 1u);
+            s16 = (pack16(__builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0)) & valid) | (border32 & ~valid);
+            m16 = pack16(__builtin_amdgcn_raw_buffer_load_b128(rm, off, 0, 0)) & valid;
+        }
+        const int bo = ((zi * gy + yi) * pitch + 1) * 4 + 2 * col;
+        *reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(S) + bo) = (unsigned short)s16;
+        *reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(M) + bo) = (unsigned short)m16;
+    }
+    __syncthreads();
+
+    // ---- this thread's row: block plane zi, block row yi
+    const int zi = tid / p.by, yi = tid - zi * p.by;
+    const bool own = zi < p.bz && z0 + zi < nz && y0 + yi < ny;
+    const int rbase = ((zi + p.oz) * gy + yi + p.oy) * pitch + 1;
+    for (int sweep = 0; sweep < kFillSweeps; sweep++) {
+        bool mine = false;
+        if (own) {
+            // (1) the taps of the window's rows
+            for (int wc = 0; wc < gxw; wc++) {
+                const int c = rbase + wc;
+                const unsigned old = S[c], mk = M[c];
+                if ((mk & ~old) == 0u) continue;                 // nothing left to set in this word
+                unsigned acc = 0u;
+                for (int r = 0; r < p.nrows; r++) {
+                    const int tz = p.rows[r][0], ty = p.rows[r][2];
+                    unsigned mm = (unsigned)p.rows[r][1];
+                    const unsigned *a = S + c + ((tz - p.oz) * gy + (ty - p.oy)) * pitch;
+                    const unsigned C = a[0];
+                    unsigned L = 0, R = 0;
+                    if (mm & ~(1u << p.ox)) { L = a[-1]; R = a[1]; }
+                    while (mm) {
+                        const int tx = __builtin_ctz(mm);
+                        mm &= mm - 1;
+                        const int dx = tx - p.ox;
+                        acc |= dx == 0 ? C : dx > 0 ? __builtin_amdgcn_alignbit(R, C, (unsigned)dx) : __builtin_amdgcn_alignbit(C, L, (unsigned)(32 + dx));
+                    }
+                }
+                const unsigned nw = old | (acc & mk);
+                if (nw != old) { S[c] = nw; mine = true; }
+            }
+            // (2) fill along x inside the runs of the mask: upwards (towards larger x) ...
+            if (p.fill_up) {
+                unsigned cin = 0u;
+                for (int wc = 0; wc < gxw; wc++) {
+                    const int c = rbase + wc;
+                    const unsigned s = S[c], mk = M[c], t = s & mk;
+                    const unsigned long long U = (unsigned long long)mk + t + cin;
+                    const unsigned u = (unsigned)U;
+                    cin = (unsigned)(U >> 32);
+                    const unsigned nw = s | (mk & (~u | t));
+                    if (nw != s) { S[c] = nw; mine = true; }
+                }
+            }
+            // ... and downwards: the same on bit-reversed words, from the last word to the first
+            if (p.fill_down) {
+                unsigned cin = 0u;
+                for (int wc = gxw - 1; wc >= 0; wc--) {
+                    const int c = rbase + wc;
+                    const unsigned s = S[c], mk = __builtin_bitreverse32(M[c]), t = __builtin_bitreverse32(s) & mk;
+                    const unsigned long long U = (unsigned long long)mk + t + cin;
+                    const unsigned u = (unsigned)U;
+                    cin = (unsigned)(U >> 32);
+                    const unsigned nw = s | __builtin_bitreverse32(mk & (~u | t));
+                    if (nw != s) { S[c] = nw; mine = true; }
+                }
+            }
+        }
+        if (mine) sweep_changed = 1;
+        __syncthreads();
+        const int ch = sweep_changed;
+        __syncthreads();
+        if (!ch) break;
+        if (tid == 0) { sweep_changed = 0; any_changed = 1; }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- write the block back (every voxel of the volume belongs to exactly one block)
+    const int ogran = p.bz * p.by * ngx;
+    for (int g = tid; g < ogran; g += kFillNT) {
+        const int zo = g / (p.by * ngx), rem = g - zo * (p.by * ngx);
+        const int yo = rem / ngx, col = rem - yo * ngx;
+        const int z = z0 + zo, y = y0 + yo;
+        if (z >= nz || y >= ny || 16 * col >= nx) continue;
+        const unsigned w = *reinterpret_cast<const unsigned short *>(
+            reinterpret_cast<const unsigned char *>(S) + (((zo + p.oz) * gy + yo + p.oy) * pitch + 1) * 4 + 2 * col);
+        const u32x4 v = unpack16(w);
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(out + (size_t)z * plane_elems), 0, (int)plane_bytes, 0x00020000);
+        const unsigned o = (unsigned)(y * nx + 16 * col);
+        const int nv = min(nx - 16 * col, 16);
+        if (!RG || nv == 16) {
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, o, 0, 0);
+        } else {
+            const unsigned o4 = (nv & 8) ? 8u : 0u, o2 = o4 + ((nv & 4) ? 4u : 0u), o1 = o2 + ((nv & 2) ? 2u : 0u);
+            const unsigned d4 = (nv & 8) ? v.z : v.x;
+            const unsigned d2s = o2 >= 8 ? (o2 >= 12 ? v.w : v.z) : (o2 >= 4 ? v.y : v.x);
+            const unsigned d1w = o1 >= 8 ? (o1 >= 12 ? v.w : v.z) : (o1 >= 4 ? v.y : v.x);
+            if (nv & 8) __builtin_amdgcn_raw_buffer_store_b64((u32x2){v.x, v.y}, rout, o, 0, 0);
+            if (nv & 4) __builtin_amdgcn_raw_buffer_store_b32(d4, rout, o + o4, 0, 0);
+            if (nv & 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)d2s, rout, o + o2, 0, 0);
+            if (nv & 1) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(d1w >> (8 * (o1 & 3u))), rout, o + o1, 0, 0);
+        }
+    }
+    if (tid == 0 && any_changed && flag) atomicOr(flag, 1);
+}
+
+static Knob g_fill_on{1};
+
+// One launch of the masked dilation's block-wise fill towards its fixed point (see bitfill3_kernel).  `structure` /
+// `origins` in the erosion form mi_binary_erosion takes with invert = 1 (the Python layer has mirrored the structure).
+// MI_ERR_UNSUPPORTED (nothing launched) outside the envelope.
+int bitfill3(const mi_array *in, const mi_array *out, const uint8_t *structure, const int64_t *sshape, const int *origins,
+             const mi_array *mask, int border_value, int32_t *flag, hipStream_t s)
+{
+#define NOPE(msg) do { set_error("bitfill3: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)
+    if (!g_fill_on || !g_bm_on) NOPE("switched off");
+    if (!mask) NOPE("needs a mask (an unmasked dilation until stable fills the volume)");
+    if (in->ndim != 3 || dtype_size(in->dtype) != 1 || dtype_size(out->dtype) != 1) NOPE("3-D 1-byte volumes only");
+    const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
+    if (nx < 64 || nx > 2048) NOPE("rows of 64 .. 2048 voxels");
+    if (ny * nx >= ((int64_t)1 << 31) || nz > (1 << 24) || ny > (1 << 24)) NOPE("plane too large");
+    if (g_bm_on != 2 && nz * ny * nx < (1 << 18)) NOPE("small volume");
+    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15) || ((uintptr_t)mask->data & 15)) NOPE("needs 16-byte aligned data");
+    FillParams p;
+    memset(&p, 0, sizeof(p));
+    int w[3], off[3];
+    for (int d = 0; d < 3; d++) {
+        if (sshape[d] < 1 || sshape[d] > 9) NOPE("structure extent > 9");
+        w[d] = (int)sshape[d];
+        off[d] = (int)(sshape[d] / 2 + origins[d]);
+        if (off[d] < 0 || off[d] >= sshape[d]) { set_error("invalid origin"); return MI_ERR_INVALID_ARG; }
+    }
+    // monotone only when a voxel's own value is among its taps: the tap at offset 0 is structure[off]
+    if (!structure[((int64_t)off[0] * w[1] + off[1]) * w[2] + off[2]]) NOPE("the structure does not hold its own centre: the iteration is not monotone");
+    const bool ragged = (nx & 15) != 0;
+    if (ragged) {
+        if (!g_bm_ragged) NOPE("rows that are not a multiple of 16 bytes: switched off");
+        const mi_array *arrs[2] = {in, mask};
+        for (const mi_array *a : arrs) {
+            void *base = nullptr;
+            size_t size = 0;
+            if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)a->data) != hipSuccess) {
+                (void)hipGetLastError();
+                NOPE("the extent of the allocation is unknown");
+            }
+            if ((uintptr_t)base + size < (uintptr_t)a->data + (size_t)(nz * ny * nx) + 16) NOPE("no 16 readable bytes after the array");
+        }
+    }
+    p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+    p.oz = off[0]; p.oy = off[1]; p.ox = off[2];
+    p.hz = w[0] - 1 - off[0]; p.hy = w[1] - 1 - off[1];
+    p.border = border_value != 0;
+    int n = 0;
+    for (int tz = 0; tz < w[0]; tz++)
+        for (int ty = 0; ty < w[1]; ty++) {
+            unsigned m = 0;
+            for (int tx = 0; tx < w[2]; tx++)
+                if (structure[((int64_t)tz * w[1] + ty) * w[2] + tx]) m |= 1u << tx;
+            if (!m) continue;
+            if (n == kBmMaxRows) NOPE("structure has too many rows");
+            p.rows[n][0] = tz; p.rows[n][1] = (int)m; p.rows[n][2] = ty; n++;
+            if (tz == off[0] && ty == off[1]) {
+                p.fill_up = off[2] >= 1 && (m >> (off[2] - 1) & 1u);       // tap at dx = -1: x takes x - 1's value
+                p.fill_down = off[2] + 1 < w[2] && (m >> (off[2] + 1) & 1u);
+            }
+        }
+    p.nrows = n;
+    p.gxw = (int)((nx + 31) / 32);
+    p.pitch = p.gxw + 2;
+    if (!(p.pitch & 1)) p.pitch++;
+    // block: 16 x 16 rows (one per thread), fewer planes when whole rows of bits are long (state + mask <= 60 KiB)
+    p.by = (int)std::min<int64_t>(16, ny);
+    p.bz = (int)std::min<int64_t>(kFillNT / p.by, nz);
+    auto lds_bytes = [&](int bz) { return (size_t)2 * (bz + p.oz + p.hz) * (p.by + p.oy + p.hy) * p.pitch * 4; };
+    while (p.bz > 1 && lds_bytes(p.bz) > 60 * 1024) p.bz--;
+    if (lds_bytes(p.bz) > 60 * 1024) NOPE("rows too wide for a block");
+    p.nzt = (int)((nz + p.bz - 1) / p.bz); p.nyt = (int)((ny + p.by - 1) / p.by);
+    const size_t lds = lds_bytes(p.bz);
+    const unsigned char *ip = (const unsigned char *)in->data, *mp = (const unsigned char *)mask->data;
+    unsigned char *op = (unsigned char *)out->data;
+    static PerDeviceOnce attr;
+    if (!attr) {
+        MI_HIP(hipFuncSetAttribute((const void *)bitfill3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        MI_HIP(hipFuncSetAttribute((const void *)bitfill3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr = true;
+    }
+    const unsigned grid = (unsigned)(p.nzt * p.nyt);
+    if (ragged) hipLaunchKernelGGL((bitfill3_kernel<true>), dim3(grid), dim3(kFillNT), lds, s, ip, op, mp, p, flag);
+    else hipLaunchKernelGGL((bitfill3_kernel<false>), dim3(grid), dim3(kFillNT), lds, s, ip, op, mp, p, flag);
+    MI_HIP(hipGetLastError());
+    note_kernel("mi::bitfill3_kernel<%s> grid=%u block=%dx%d rows x planes (masked dilation filled to its fixed point block by block: row fills by carry, 1 bit per voxel)",
+                ragged ? "ragged" : "aligned", grid, p.by, p.bz);
+    return MI_OK;
+#undef NOPE
+}
+
 // k fused iterations on a 3-D volume of 1-byte voxels; MI_ERR_UNSUPPORTED (nothing launched) outside the envelope.
 int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure, const int64_t *sshape, const int *origins,
               const mi_array *mask, int border_value, int invert, int k, int32_t *flags, hipStream_t s, int open_close)
@@ -712,6 +980,12 @@ int bitmorph3(const mi_array *in, const mi_array *out, const uint8_t *structure,
 }
 
 }  // namespace mi
+
+extern "C" int mi_debug_set_bitfill(int on)             // 0: runs until stable iterate the global operator (batches of fused iterations)
+{
+    mi::g_fill_on = on;
+    return MI_OK;
+}
 
 extern "C" int mi_debug_set_bitmorph_ragged(int on)     // 0: rows that are not a multiple of 16 bytes keep the extended-rows / generic routes
 {

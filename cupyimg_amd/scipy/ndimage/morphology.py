@@ -234,35 +234,55 @@ def _binary_erosion(input, structure, iterations, mask, output, border_value, or
             # r6: the flags are read once per GROUP of batches (1, 2, then 4 batches): a propagation through a 200-voxel volume
             # is 50 batches, and what a batch costs is the host round trip, not its 25-us launch; batches queued after the volume
             # became stable reproduce it (the same buffers ping-pong), so reading late changes nothing but the count.
+            # Three ways to take a step, decided by the first launch of the run: (1) r6, masked dilations (binary_propagation,
+            # binary_fill_holes): a block-wise FILL launch -- every workgroup sweeps a block of the volume in place until nothing
+            # inside it changes, whole runs of mask bits along x per sweep (mi_binary_propagation_step: the operator is monotone,
+            # any order of local updates reaches the same fixed point), so a launch carries information across a whole block
+            # instead of one voxel; (2) a batch of fused iterations; (3) one iteration per launch.
+            def launch_fill(src_, dst_, flag_ptr):
+                a, b = src_._desc(), dst_._desc()
+                rc = lib.mi_binary_propagation_step(ctypes.byref(a), ctypes.byref(b), stp, sshape, org, ctypes.byref(mdesc),
+                                                    int(bool(border_value)), flag_ptr, None)
+                if rc == _lib.MI_ERR_UNSUPPORTED:
+                    return False
+                S.check(rc)
+                return True
+
             group = 1
-            kb = _MAX_FUSED_UNTIL_STABLE               # iterations per launch: the library's limit first, then the usual batch
+            kb = _MAX_FUSED_UNTIL_STABLE
             flags = core.zeros((_MAX_GROUP, _MAX_FUSED_UNTIL_STABLE), np.int32)
             which = 1
-            fused_ok = True
+            mode = None                                   # "fill" | "fused" | "single"
             while True:
                 flags.fill(0)
-                stable = False
                 launched = 0
-                for g in range(group if fused_ok else 1):
+                for g in range(group if mode != "single" else 1):
                     dst = bufs[which]
                     fptr = ctypes.c_void_p(flags.ptr + 4 * _MAX_FUSED_UNTIL_STABLE * g)
-                    ok = fused_ok and launch_fused(cur, dst, kb, fptr)
-                    if not ok and fused_ok and g == 0 and kb > _MAX_FUSED:
-                        kb = _MAX_FUSED                # eight stages do not fit a tile here: four
-                        ok = launch_fused(cur, dst, kb, fptr)
-                    if not ok:
-                        if fused_ok and g > 0:
-                            break                      # (cannot happen: the first batch of the run decides; keep the rows consistent)
-                        fused_ok = False
+                    if mode is None:
+                        if invert and mdesc is not None and launch_fill(cur, dst, fptr):
+                            mode = "fill"
+                        elif launch_fused(cur, dst, kb, fptr):
+                            mode = "fused"
+                        else:
+                            mode = "single"
+                            launch(cur, dst, fptr)
+                    elif mode == "fill":
+                        if not launch_fill(cur, dst, fptr):
+                            break                          # (cannot happen: same arrays, same answer)
+                    elif mode == "fused":
+                        if not launch_fused(cur, dst, kb, fptr):
+                            break
+                    else:
                         launch(cur, dst, fptr)
                     cur = dst
                     which ^= 1
                     launched += 1
                 got = flags.get()
-                if fused_ok:
+                if mode == "fused":
                     stable = not got[:launched, :kb].all()
                 else:
-                    stable = int(got[0, 0]) == 0
+                    stable = not got[:launched, 0].all()
                 if stable:
                     break
                 group = min(_MAX_GROUP, group * 2)

@@ -400,6 +400,17 @@ int mi_binary_erosion(const mi_array *in, const mi_array *out, const uint8_t *st
 int mi_binary_open_close_fused(const mi_array *in, const mi_array *out, const uint8_t *structure,
                                const int64_t *sshape, const mi_array *mask, int border_value, int closing,
                                int iterations, mi_stream stream);
+/* One launch of a masked dilation's block-wise fill towards its fixed point -- binary_propagation / binary_fill_holes
+ * (morphology.py:684-766: dilation with iterations = -1 inside a mask).  Every workgroup sweeps a block of the volume IN
+ * PLACE (bits in LDS; whole runs of mask bits along x filled per sweep by the carry of an addition) until nothing inside
+ * the block changes, its halo being what the neighbours held when the launch began; the operator is monotone, so repeating
+ * launches (in -> out, ping-pong) until *changed_dev stays 0 reaches exactly the fixed point the reference's
+ * one-iteration-per-launch loop reaches.  structure / origins in the form mi_binary_erosion takes with invert = 1
+ * (already mirrored).  MI_ERR_UNSUPPORTED outside the envelope (3-D byte volumes with a byte mask, rows of 64 .. 2048
+ * voxels, a structure that holds its centre): the caller iterates mi_binary_erosion_fused. */
+int mi_binary_propagation_step(const mi_array *in, const mi_array *out, const uint8_t *structure,
+                               const int64_t *sshape, const int *origins, const mi_array *mask,
+                               int border_value, int32_t *changed_dev, mi_stream stream);
 int mi_binary_erosion_fused(const mi_array *in, const mi_array *out, const uint8_t *structure,
                             const int64_t *sshape, const int *origins, const mi_array *mask,
                             int border_value, int invert, int iterations, int32_t *changed_dev, mi_stream stream);

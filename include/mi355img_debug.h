@@ -56,6 +56,7 @@ int mi_debug_pool_probe(size_t nbytes, mi_stream stream, void **block);
 int mi_debug_generation(void);                /* advances with every mi_debug_set_* call: part of the keys of host-side refusal caches */
 int mi_debug_set_stencil_scatter(int on);     /* csrc/stencil3s.hip: 0 = dense 3^3 / 5^3 windows stay on stencil3_kernel */
 int mi_debug_set_binary_tiled(int on);        /* csrc/binary.hip: 0 = generic binary erosion kernel */
+int mi_debug_set_bitfill(int on);                     /* 0: runs until stable iterate the global operator (no block-wise fill) */
 int mi_debug_set_bitmorph_ragged(int on);             /* 0: rows that are not a multiple of 16 bytes keep the extended-rows / generic routes */
 int mi_debug_set_bitmorph_2d(int on);                 /* 0: 2-D images keep the byte kernel (binary3d.hip) */
 int mi_debug_set_bitmorph_table(int on);              /* 1: the run-time structure table even for the built-in 3 x 3 x 3 structures */

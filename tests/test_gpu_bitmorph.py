@@ -252,6 +252,50 @@ def test_cubes_and_octahedra_run_as_iterations_of_their_3x3x3_root(gpu, ndi, kno
         assert np.array_equal(got, sndi.binary_dilation(x, np.ones((5, 5, 5), bool), mask=m))
 
 
+@pytest.mark.parametrize("shape", [(40, 64, 96), (33, 50, 181), (70, 45, 1040), (20, 30, 2000), (64, 64, 64)])
+def test_propagation_and_fill_holes_by_block_fill(gpu, ndi, knob, shape):
+    """binary_propagation / binary_fill_holes (morphology.py:684-766) through bitfill3_kernel: blocks swept in place until
+    stable with whole mask runs filled along x per sweep, launches repeated until no block changes -- the same fixed point
+    as SciPy's one-iteration loop: random masks (tortuous paths across many blocks), smooth masks, structures with and
+    without x-adjacent / diagonal taps, origins, border_value 1, ragged rows; a structure without its centre is not
+    monotone and must take the iterating path."""
+    from cupyimg_amd import last_kernel
+    knob(2, 0, 0)
+    rng = np.random.default_rng(shape[2] + shape[0])
+    g = np.indices(shape).astype(np.float32)
+    r2 = sum(((g[i] - (shape[i] - 1) / 2) / (0.42 * shape[i])) ** 2 for i in range(3))
+    smooth = (r2 < 1.0) & (r2 > 0.4) & (rng.random(shape) > 0.02)
+    assert np.array_equal(ndi.binary_fill_holes(gpu.asarray(smooth)).get(), sndi.binary_fill_holes(smooth))
+    assert "bitfill3_kernel" in last_kernel(), last_kernel()
+    yline = np.zeros((3, 3, 3), bool); yline[1, :, 1] = True        # no x-adjacent tap: no row fill, sweeps only
+    xup = np.zeros((3, 3, 3), bool); xup[1, 1, 1] = xup[1, 1, 0] = xup[0, 1, 1] = True     # fills towards larger x only
+    for density in (0.35, 0.6):
+        mask = rng.random(shape) > density
+        seed = (rng.random(shape) > 0.997) & mask
+        sd, md = gpu.asarray(seed), gpu.asarray(mask)
+        for st in [None, np.ones((3, 3, 3), bool), sndi.generate_binary_structure(3, 2), rng.random((3, 5, 3)) > 0.3, yline, xup]:
+            if st is not None and not st[tuple(n // 2 for n in st.shape)]:
+                st = st.copy()
+                st[tuple(n // 2 for n in st.shape)] = True
+            for bv in (0, 1):
+                got = ndi.binary_propagation(sd, structure=st, mask=md, border_value=bv).get()
+                assert "bitfill3_kernel" in last_kernel(), last_kernel()
+                ref = sndi.binary_propagation(seed, structure=st, mask=mask, border_value=bv)
+                assert np.array_equal(got, ref), (shape, density, None if st is None else st.shape, bv, int((got != ref).sum()))
+        x = rng.random(shape) > density
+        assert np.array_equal(ndi.binary_fill_holes(gpu.asarray(x)).get(), sndi.binary_fill_holes(x)), (shape, density)
+        assert "bitfill3_kernel" in last_kernel(), last_kernel()
+        got = ndi.binary_propagation(sd, mask=md, origin=(0, 1, 0)).get()                  # offsets that are not centred
+        assert np.array_equal(got, sndi.binary_propagation(seed, mask=mask, origin=(0, 1, 0)))
+        got = ndi.binary_propagation(sd, structure=np.ones((3, 3, 3)), mask=md, origin=(0, 0, 1)).get()
+        assert np.array_equal(got, sndi.binary_propagation(seed, structure=np.ones((3, 3, 3)), mask=mask, origin=(0, 0, 1)))
+    nocentre = np.array([[[0, 1, 0]], [[1, 0, 1]], [[0, 1, 0]]], bool)
+    x = rng.random(shape) > 0.5
+    m = rng.random(shape) > 0.3
+    got = ndi.binary_dilation(gpu.asarray(x), nocentre, iterations=3, mask=gpu.asarray(m)).get()      # (a finite count: SciPy would oscillate forever)
+    assert np.array_equal(got, sndi.binary_dilation(x, nocentre, iterations=3, mask=m, brute_force=True))
+
+
 def test_bitmorph_output_forms_and_dtypes(gpu, ndi, knob):
     """int8 / uint8 inputs (any nonzero byte is true), uint8 output arrays, output given, input untouched."""
     knob(2, 0, 0)
