@@ -146,6 +146,11 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
 #pragma unroll
             for (int c = 0; c < 4; c++) A[a][rr][c] = (Acc)0;
 
+    f32x2 B[W][RW][2];                                     // LANEW: the same sets as register PAIRS (what the asm tap loop updates)
+#pragma unroll
+    for (int a = 0; a < W; a++)
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) B[a][rr][0] = B[a][rr][1] = (f32x2){0.f, 0.f};
     float wlane[2] = {0.f, 0.f};
     if constexpr (LANEW) {
         wlane[0] = p.w[lane];
@@ -165,6 +170,8 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
         for (int rr = 0; rr < RW; rr++)
 #pragma unroll
             for (int c = 0; c < 4; c++) A[PH][rr][c] = (Acc)0;
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) B[PH][rr][0] = B[PH][rr][1] = (f32x2){0.f, 0.f};
         const float *slot = ring + (q & 1) * SLOT + 4 + 4 * lane;
         // the 4 + 2 RX samples a lane needs of staged row r0 + i: its own four, RX either side from the neighbouring lanes
         // (DPP), the tile halo in the edge lanes
@@ -204,30 +211,65 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
             // be hoisted out of the plane loop, where they would be 125 live scalars again.)
             unsigned wb0 = __float_as_uint(wlane[0]), wb1 = __float_as_uint(wlane[1]);
             asm volatile("" : "+v"(wb0), "+v"(wb1));
-            float dr[RW + W - 1][4 + 2 * RX];
+            static_assert(!LANEW || RW == 2, "the lane-weight tap loop is written for two rows per wave");
+            // pairs of a staged row: P[j] = (d[j], d[j + 1]) -- what v_pk_fma_f32 takes for the output pairs (0, 1) [tap tx: j = tx]
+            // and (2, 3) [j = tx + 2]
+            f32x2 P[RW + W - 1][7];
+            auto read_pairs = [&](auto II) {
+                constexpr int i = decltype(II)::value;
+                float d[4 + 2 * RX];
+                read_row(i, d);
 #pragma unroll
-            for (int i = 0; i < RW - 1; i++) read_row(i, dr[i]);
-#pragma unroll
-            for (int ty = 0; ty < W; ty++) {
-                read_row(ty + RW - 1, dr[ty + RW - 1]);
-#pragma unroll
-                for (int tz = 0; tz < W; tz++) {
-                    const int a = (PH - tz + 2 * W) % W;   // compile time: the set of output plane q - tz
-                    __builtin_amdgcn_sched_barrier(0);     // five weights at a time: the scheduler would read all 125 up front and spill them back to lanes
-#pragma unroll
-                    for (int tx = 0; tx < W; tx++) {
-                        const int k = (tz * W + ty) * W + tx;
-                        const f32x2 w2 = splat2(__uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(k < 64 ? wb0 : wb1), k & 63)));
-#pragma unroll
-                        for (int rr = 0; rr < RW; rr++) {
-                            const float (&d)[4 + 2 * RX] = dr[rr + ty];
-                            const f32x2 lo = fma2((f32x2){d[tx], d[tx + 1]}, w2, (f32x2){A[a][rr][0], A[a][rr][1]});
-                            const f32x2 hi = fma2((f32x2){d[tx + 2], d[tx + 3]}, w2, (f32x2){A[a][rr][2], A[a][rr][3]});
-                            A[a][rr][0] = lo.x; A[a][rr][1] = lo.y; A[a][rr][2] = hi.x; A[a][rr][3] = hi.y;
-                        }
-                    }
-                }
-            }
+                for (int j = 0; j < 7; j++) P[i][j] = (f32x2){d[j], d[j + 1]};
+            };
+            static_for<RW - 1>([&](auto II) { read_pairs(II); });
+            static_for<W>([&](auto TY) {
+                constexpr int ty = decltype(TY)::value;
+                read_pairs(std::integral_constant<int, ty + RW - 1>{});
+                static_for<W>([&](auto TZ) {
+                    constexpr int tz = decltype(TZ)::value;
+                    constexpr int a = (PH - tz + 2 * W) % W;      // the set of output plane q - tz
+                    constexpr int k0 = (tz * W + ty) * W;
+                    // The five weights of window row (tz, ty) and their twenty packed FMAs as ONE statement: a weight is ONE
+                    // v_readlane into the low half of a scalar pair (op_sel_hi 0 on that operand: both halves of the packed
+                    // product take the low dword, the high scalar is never read), two pairs in turn, so that the 2 wait states a
+                    // VALU-written scalar needs before a VALU reads it are filled with the previous weight's FMAs.  Written in
+                    // C++ (readlane builtin + splat) the compiler hoisted all 125 reads, spilled the 250 scalars back into
+                    // lanes and fetched each with two v_readlane + s_nop: 1 300 issue slots per plane for 500 FMAs.
+                    // (asm operands inside a lambda do not capture: name the registers first)
+                    f32x2 &a0 = B[a][0][0], &a1 = B[a][0][1], &b0 = B[a][1][0], &b1 = B[a][1][1];
+                    const f32x2 pa0 = P[ty][0], pa1 = P[ty][1], pa2 = P[ty][2], pa3 = P[ty][3], pa4 = P[ty][4], pa5 = P[ty][5], pa6 = P[ty][6];
+                    const f32x2 pb0 = P[ty + 1][0], pb1 = P[ty + 1][1], pb2 = P[ty + 1][2], pb3 = P[ty + 1][3], pb4 = P[ty + 1][4],
+                                pb5 = P[ty + 1][5], pb6 = P[ty + 1][6];
+                    const unsigned w0 = k0 < 64 ? wb0 : wb1, w1 = k0 + 1 < 64 ? wb0 : wb1, w2 = k0 + 2 < 64 ? wb0 : wb1,
+                                   w3 = k0 + 3 < 64 ? wb0 : wb1, w4 = k0 + 4 < 64 ? wb0 : wb1;
+#define MI_S5_FMA4(S, LO, HI)                                                   \
+    "v_pk_fma_f32 %[a0], %[pa" #LO "], " S ", %[a0] op_sel_hi:[1,0,1]\n\t"      \
+    "v_pk_fma_f32 %[a1], %[pa" #HI "], " S ", %[a1] op_sel_hi:[1,0,1]\n\t"      \
+    "v_pk_fma_f32 %[b0], %[pb" #LO "], " S ", %[b0] op_sel_hi:[1,0,1]\n\t"      \
+    "v_pk_fma_f32 %[b1], %[pb" #HI "], " S ", %[b1] op_sel_hi:[1,0,1]\n\t"
+                    asm volatile(
+                        "v_readlane_b32 s90, %[w0], %[k0]\n\t"
+                        "v_readlane_b32 s92, %[w1], %[k1]\n\t"
+                        "s_nop 0\n\t"
+                        MI_S5_FMA4("s[90:91]", 0, 2)
+                        "v_readlane_b32 s90, %[w2], %[k2]\n\t"
+                        MI_S5_FMA4("s[92:93]", 1, 3)
+                        "v_readlane_b32 s92, %[w3], %[k3]\n\t"
+                        MI_S5_FMA4("s[90:91]", 2, 4)
+                        "v_readlane_b32 s90, %[w4], %[k4]\n\t"
+                        MI_S5_FMA4("s[92:93]", 3, 5)
+                        MI_S5_FMA4("s[90:91]", 4, 6)
+                        : [a0] "+v"(a0), [a1] "+v"(a1), [b0] "+v"(b0), [b1] "+v"(b1)
+                        : [pa0] "v"(pa0), [pa1] "v"(pa1), [pa2] "v"(pa2), [pa3] "v"(pa3), [pa4] "v"(pa4), [pa5] "v"(pa5), [pa6] "v"(pa6),
+                          [pb0] "v"(pb0), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3), [pb4] "v"(pb4), [pb5] "v"(pb5), [pb6] "v"(pb6),
+                          [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [w4] "v"(w4),
+                          [k0] "n"(k0 & 63), [k1] "n"((k0 + 1) & 63), [k2] "n"((k0 + 2) & 63), [k3] "n"((k0 + 3) & 63),
+                          [k4] "n"((k0 + 4) & 63)
+                        : "s90", "s91", "s92", "s93");
+#undef MI_S5_FMA4
+                });
+            });
         } else {
 #pragma unroll
             for (int i = 0; i < RW + W - 1; i++) {
@@ -273,8 +315,13 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
 #pragma unroll
             for (int rr = 0; rr < RW; rr++) {
                 u32x4 u;
-                u.x = __float_as_uint((float)A[a][rr][0]); u.y = __float_as_uint((float)A[a][rr][1]);
-                u.z = __float_as_uint((float)A[a][rr][2]); u.w = __float_as_uint((float)A[a][rr][3]);
+                if constexpr (LANEW) {
+                    u.x = __float_as_uint(B[a][rr][0].x); u.y = __float_as_uint(B[a][rr][0].y);
+                    u.z = __float_as_uint(B[a][rr][1].x); u.w = __float_as_uint(B[a][rr][1].y);
+                } else {
+                    u.x = __float_as_uint((float)A[a][rr][0]); u.y = __float_as_uint((float)A[a][rr][1]);
+                    u.z = __float_as_uint((float)A[a][rr][2]); u.w = __float_as_uint((float)A[a][rr][3]);
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(u, rout, live ? ovoff[rr] : kOOB, 0, 0);
             }
         }
