@@ -1,4 +1,4 @@
-// stencil3s.hip -- dense 3 x 3 x 3 / 5 x 5 x 5 correlate of float32 volumes, z taken as a SCATTER over register
+// stencil3s.hip -- dense 3 x 3 x 3 / 5 x 5 x 5 (/ 7 x 7 x 7 with float accumulation) correlate of float32 volumes, z taken as a SCATTER over register
 // accumulators ("each plane is read from LDS once").
 //
 // Reference path replaced: correlate / convolve with a small dense kernel, cupyimg/scipy/ndimage/filters.py:65-210 ->
@@ -25,7 +25,7 @@
 //     (z, y, x) of the window -- the plane-by-plane scatter adds the taps of one output in exactly that order, so the
 //     result is bit-identical to stencil3_kernel / corr3_kernel / SciPy's NI_Correlate.
 //
-// Envelope: float32 in and out, 3-D, window 3^3 or 5^3 with no zero weight (a zero weight is SKIPPED by the reference, which
+// Envelope: float32 in and out, 3-D, window 3^3 or 5^3 (7^3: float accumulation only) with no zero weight (a zero weight is SKIPPED by the reference, which
 // matters for non-finite samples: those windows stay on stencil3_kernel's mask path), origin 0 along x.
 #include "nd_common.hpp"
 #include "sep_common.hpp"
@@ -43,7 +43,7 @@ struct ScatterParams {
     float cval;
     int zc, nzc, nxt, nyt;
     int pad_;
-    Acc w[125];                 // [tz][ty][tx]
+    Acc w[343];                 // [tz][ty][tx] (W^3 of them)
 };
 
 // FMA64: float64 accumulation with v_fma_f64 -- chosen by the host only when every weight is a float32 value: the
@@ -60,7 +60,10 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
     constexpr int RPW = (ROWS + kSsNW - 1) / kSsNW;       // staged rows per wave
     constexpr int SLOT = ROWS * kSsPitch;
     constexpr bool F32 = std::is_same<Acc, float>::value;
-    constexpr bool LANEW = W == 5 && F32;                 // weights in the lanes of two registers (see the tap loop)
+    constexpr bool LANEW = W >= 5 && F32;                 // weights in the lanes of vector registers (see the tap loop)
+    // lane layout of the weights: 5^3 -- lane k & 63 of register k >> 6; 7^3 -- window row g = tz * 7 + ty in register g / 9,
+    // lanes 7 (g % 9) .. + 6 (a row's seven weights in ONE register: the asm statement of a row has 30 operands as it is)
+    constexpr int NWR = W == 5 ? 2 : W == 7 ? 6 : 1;
     __shared__ __attribute__((aligned(16))) float ring[2 * SLOT];
 
     const int lane = threadIdx.x & 63;
@@ -151,10 +154,19 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
     for (int a = 0; a < W; a++)
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) B[a][rr][0] = B[a][rr][1] = (f32x2){0.f, 0.f};
-    float wlane[2] = {0.f, 0.f};
-    if constexpr (LANEW) {
+    float wlane[NWR];
+#pragma unroll
+    for (int r = 0; r < NWR; r++) wlane[r] = 0.f;
+    if constexpr (LANEW && W == 5) {
         wlane[0] = p.w[lane];
         wlane[1] = lane + 64 < W * W * W ? p.w[lane + 64] : 0.f;
+    }
+    if constexpr (LANEW && W == 7) {
+#pragma unroll
+        for (int r = 0; r < NWR; r++) {
+            const int g = 9 * r + lane / 7;
+            wlane[r] = (lane < 63 && g < W * W) ? p.w[g * 7 + lane % 7] : 0.f;
+        }
     }
     const int nsteps = nout + W - 1;
     fetch(0);
@@ -188,6 +200,18 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
                 const float r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(C.x), 0x130, 0xf, 0xf, false));
                 d[0] = first_lane ? hl : l;
                 d[5] = last_lane ? hr : r;
+            } else if constexpr (RX == 3) {
+                float hl[3] = {0.f, 0.f, 0.f}, hr[3] = {0.f, 0.f, 0.f};
+                if (first_lane) { hl[0] = rowp[-3]; hl[1] = rowp[-2]; hl[2] = rowp[-1]; }
+                if (last_lane) { hr[0] = rowp[4]; hr[1] = rowp[5]; hr[2] = rowp[6]; }
+                const float cv[4] = {C.x, C.y, C.z, C.w};
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const float l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cv[1 + j]), 0x138, 0xf, 0xf, false));
+                    const float r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cv[j]), 0x130, 0xf, 0xf, false));
+                    d[j] = first_lane ? hl[j] : l;
+                    d[7 + j] = last_lane ? hr[j] : r;
+                }
             } else {
                 float2 hl = make_float2(0.f, 0.f), hr = make_float2(0.f, 0.f);
                 if (first_lane) hl = *reinterpret_cast<const float2 *>(rowp - 2);
@@ -209,18 +233,23 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
             // kernel arguments they were 250 scalar registers (pairs for v_pk_fma_f32): spilled to lanes by the compiler and
             // read back 3 700 times per 2 500 FMAs.  (The registers pass through an empty asm per plane: the reads must not
             // be hoisted out of the plane loop, where they would be 125 live scalars again.)
-            unsigned wb0 = __float_as_uint(wlane[0]), wb1 = __float_as_uint(wlane[1]);
-            asm volatile("" : "+v"(wb0), "+v"(wb1));
+            unsigned wb[NWR];
+#pragma unroll
+            for (int r = 0; r < NWR; r++) {
+                wb[r] = __float_as_uint(wlane[r]);
+                asm volatile("" : "+v"(wb[r]));
+            }
             static_assert(!LANEW || RW == 2, "the lane-weight tap loop is written for two rows per wave");
             // pairs of a staged row: P[j] = (d[j], d[j + 1]) -- what v_pk_fma_f32 takes for the output pairs (0, 1) [tap tx: j = tx]
             // and (2, 3) [j = tx + 2]
-            f32x2 P[RW + W - 1][7];
+            constexpr int NP = 3 + 2 * RX;
+            f32x2 P[RW + W - 1][NP];
             auto read_pairs = [&](auto II) {
                 constexpr int i = decltype(II)::value;
                 float d[4 + 2 * RX];
                 read_row(i, d);
 #pragma unroll
-                for (int j = 0; j < 7; j++) P[i][j] = (f32x2){d[j], d[j + 1]};
+                for (int j = 0; j < NP; j++) P[i][j] = (f32x2){d[j], d[j + 1]};
             };
             static_for<RW - 1>([&](auto II) { read_pairs(II); });
             static_for<W>([&](auto TY) {
@@ -229,45 +258,76 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
                 static_for<W>([&](auto TZ) {
                     constexpr int tz = decltype(TZ)::value;
                     constexpr int a = (PH - tz + 2 * W) % W;      // the set of output plane q - tz
-                    constexpr int k0 = (tz * W + ty) * W;
-                    // The five weights of window row (tz, ty) and their twenty packed FMAs as ONE statement: a weight is ONE
+                    // The W weights of window row (tz, ty) and their 4 W packed FMAs as ONE statement: a weight is ONE
                     // v_readlane into the low half of a scalar pair (op_sel_hi 0 on that operand: both halves of the packed
                     // product take the low dword, the high scalar is never read), two pairs in turn, so that the 2 wait states a
                     // VALU-written scalar needs before a VALU reads it are filled with the previous weight's FMAs.  Written in
-                    // C++ (readlane builtin + splat) the compiler hoisted all 125 reads, spilled the 250 scalars back into
-                    // lanes and fetched each with two v_readlane + s_nop: 1 300 issue slots per plane for 500 FMAs.
+                    // C++ (readlane builtin + splat) the compiler hoisted all 125 reads of the 5^3 window, spilled the 250 scalars
+                    // back into lanes and fetched each with two v_readlane + s_nop: 1 300 issue slots per plane for 500 FMAs.
                     // (asm operands inside a lambda do not capture: name the registers first)
                     f32x2 &a0 = B[a][0][0], &a1 = B[a][0][1], &b0 = B[a][1][0], &b1 = B[a][1][1];
                     const f32x2 pa0 = P[ty][0], pa1 = P[ty][1], pa2 = P[ty][2], pa3 = P[ty][3], pa4 = P[ty][4], pa5 = P[ty][5], pa6 = P[ty][6];
                     const f32x2 pb0 = P[ty + 1][0], pb1 = P[ty + 1][1], pb2 = P[ty + 1][2], pb3 = P[ty + 1][3], pb4 = P[ty + 1][4],
                                 pb5 = P[ty + 1][5], pb6 = P[ty + 1][6];
-                    const unsigned w0 = k0 < 64 ? wb0 : wb1, w1 = k0 + 1 < 64 ? wb0 : wb1, w2 = k0 + 2 < 64 ? wb0 : wb1,
-                                   w3 = k0 + 3 < 64 ? wb0 : wb1, w4 = k0 + 4 < 64 ? wb0 : wb1;
-#define MI_S5_FMA4(S, LO, HI)                                                   \
+#define MI_SS_FMA4(S, LO, HI)                                                   \
     "v_pk_fma_f32 %[a0], %[pa" #LO "], " S ", %[a0] op_sel_hi:[1,0,1]\n\t"      \
     "v_pk_fma_f32 %[a1], %[pa" #HI "], " S ", %[a1] op_sel_hi:[1,0,1]\n\t"      \
     "v_pk_fma_f32 %[b0], %[pb" #LO "], " S ", %[b0] op_sel_hi:[1,0,1]\n\t"      \
     "v_pk_fma_f32 %[b1], %[pb" #HI "], " S ", %[b1] op_sel_hi:[1,0,1]\n\t"
-                    asm volatile(
-                        "v_readlane_b32 s90, %[w0], %[k0]\n\t"
-                        "v_readlane_b32 s92, %[w1], %[k1]\n\t"
-                        "s_nop 0\n\t"
-                        MI_S5_FMA4("s[90:91]", 0, 2)
-                        "v_readlane_b32 s90, %[w2], %[k2]\n\t"
-                        MI_S5_FMA4("s[92:93]", 1, 3)
-                        "v_readlane_b32 s92, %[w3], %[k3]\n\t"
-                        MI_S5_FMA4("s[90:91]", 2, 4)
-                        "v_readlane_b32 s90, %[w4], %[k4]\n\t"
-                        MI_S5_FMA4("s[92:93]", 3, 5)
-                        MI_S5_FMA4("s[90:91]", 4, 6)
-                        : [a0] "+v"(a0), [a1] "+v"(a1), [b0] "+v"(b0), [b1] "+v"(b1)
-                        : [pa0] "v"(pa0), [pa1] "v"(pa1), [pa2] "v"(pa2), [pa3] "v"(pa3), [pa4] "v"(pa4), [pa5] "v"(pa5), [pa6] "v"(pa6),
-                          [pb0] "v"(pb0), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3), [pb4] "v"(pb4), [pb5] "v"(pb5), [pb6] "v"(pb6),
-                          [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [w4] "v"(w4),
-                          [k0] "n"(k0 & 63), [k1] "n"((k0 + 1) & 63), [k2] "n"((k0 + 2) & 63), [k3] "n"((k0 + 3) & 63),
-                          [k4] "n"((k0 + 4) & 63)
-                        : "s90", "s91", "s92", "s93");
-#undef MI_S5_FMA4
+                    if constexpr (W == 5) {
+                        constexpr int k0 = (tz * W + ty) * W;
+                        const unsigned w0 = wb[k0 >> 6], w1 = wb[(k0 + 1) >> 6], w2 = wb[(k0 + 2) >> 6], w3 = wb[(k0 + 3) >> 6],
+                                       w4 = wb[(k0 + 4) >> 6];
+                        asm volatile(
+                            "v_readlane_b32 s90, %[w0], %[k0]\n\t"
+                            "v_readlane_b32 s92, %[w1], %[k1]\n\t"
+                            "s_nop 0\n\t"
+                            MI_SS_FMA4("s[90:91]", 0, 2)
+                            "v_readlane_b32 s90, %[w2], %[k2]\n\t"
+                            MI_SS_FMA4("s[92:93]", 1, 3)
+                            "v_readlane_b32 s92, %[w3], %[k3]\n\t"
+                            MI_SS_FMA4("s[90:91]", 2, 4)
+                            "v_readlane_b32 s90, %[w4], %[k4]\n\t"
+                            MI_SS_FMA4("s[92:93]", 3, 5)
+                            MI_SS_FMA4("s[90:91]", 4, 6)
+                            : [a0] "+v"(a0), [a1] "+v"(a1), [b0] "+v"(b0), [b1] "+v"(b1)
+                            : [pa0] "v"(pa0), [pa1] "v"(pa1), [pa2] "v"(pa2), [pa3] "v"(pa3), [pa4] "v"(pa4), [pa5] "v"(pa5), [pa6] "v"(pa6),
+                              [pb0] "v"(pb0), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3), [pb4] "v"(pb4), [pb5] "v"(pb5), [pb6] "v"(pb6),
+                              [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [w4] "v"(w4),
+                              [k0] "n"(k0 & 63), [k1] "n"((k0 + 1) & 63), [k2] "n"((k0 + 2) & 63), [k3] "n"((k0 + 3) & 63),
+                              [k4] "n"((k0 + 4) & 63)
+                            : "s90", "s91", "s92", "s93");
+                    } else {
+                        constexpr int g = tz * W + ty, k0 = 7 * (g % 9);
+                        const f32x2 pa7 = P[ty][NP - 2], pa8 = P[ty][NP - 1], pb7 = P[ty + 1][NP - 2], pb8 = P[ty + 1][NP - 1];
+                        const unsigned w0 = wb[g / 9 < NWR ? g / 9 : 0];
+                        asm volatile(
+                            "v_readlane_b32 s90, %[w0], %[k0]\n\t"
+                            "v_readlane_b32 s92, %[w0], %[k1]\n\t"
+                            "s_nop 0\n\t"
+                            MI_SS_FMA4("s[90:91]", 0, 2)
+                            "v_readlane_b32 s90, %[w0], %[k2]\n\t"
+                            MI_SS_FMA4("s[92:93]", 1, 3)
+                            "v_readlane_b32 s92, %[w0], %[k3]\n\t"
+                            MI_SS_FMA4("s[90:91]", 2, 4)
+                            "v_readlane_b32 s90, %[w0], %[k4]\n\t"
+                            MI_SS_FMA4("s[92:93]", 3, 5)
+                            "v_readlane_b32 s92, %[w0], %[k5]\n\t"
+                            MI_SS_FMA4("s[90:91]", 4, 6)
+                            "v_readlane_b32 s90, %[w0], %[k6]\n\t"
+                            MI_SS_FMA4("s[92:93]", 5, 7)
+                            MI_SS_FMA4("s[90:91]", 6, 8)
+                            : [a0] "+v"(a0), [a1] "+v"(a1), [b0] "+v"(b0), [b1] "+v"(b1)
+                            : [pa0] "v"(pa0), [pa1] "v"(pa1), [pa2] "v"(pa2), [pa3] "v"(pa3), [pa4] "v"(pa4), [pa5] "v"(pa5), [pa6] "v"(pa6),
+                              [pa7] "v"(pa7), [pa8] "v"(pa8),
+                              [pb0] "v"(pb0), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3), [pb4] "v"(pb4), [pb5] "v"(pb5), [pb6] "v"(pb6),
+                              [pb7] "v"(pb7), [pb8] "v"(pb8),
+                              [w0] "v"(w0),
+                              [k0] "n"(k0), [k1] "n"(k0 + 1), [k2] "n"(k0 + 2), [k3] "n"(k0 + 3), [k4] "n"(k0 + 4), [k5] "n"(k0 + 5),
+                              [k6] "n"(k0 + 6)
+                            : "s90", "s91", "s92", "s93");
+                    }
+#undef MI_SS_FMA4
                 });
             });
         } else {
@@ -393,7 +453,8 @@ int stencil3_scatter(const mi_array *in, const mi_array *out, const double *weig
     if (!g_scatter_on) NOPE("switched off (mi_debug_set_stencil_scatter)");
     if (in->dtype != MI_F32 || out->dtype != MI_F32 || in->ndim != 3) NOPE("3-D float32 volumes only");
     const int W = (int)wshape[0];
-    if ((W != 3 && W != 5) || wshape[1] != W || wshape[2] != W) NOPE("3 x 3 x 3 or 5 x 5 x 5 windows only");
+    if ((W != 3 && W != 5 && W != 7) || wshape[1] != W || wshape[2] != W) NOPE("3 x 3 x 3, 5 x 5 x 5 or 7 x 7 x 7 windows only");
+    if (W == 7 && !acc_f32) NOPE("7 x 7 x 7: float accumulation only (the float64 window is bound by the FP64 pipe on either kernel)");
     int off[3];
     for (int d = 0; d < 3; d++) {
         off[d] = W / 2 + origins[d];
@@ -417,6 +478,7 @@ int stencil3_scatter(const mi_array *in, const mi_array *out, const double *weig
         return f32w ? run_scatter<3, double, 2, true>(in, out, weights, off, mode, cval, s)
                     : run_scatter<3, double, 2>(in, out, weights, off, mode, cval, s);
     }
+    if (W == 7) return run_scatter<7, float, 2>(in, out, weights, off, mode, cval, s);
     if (acc_f32) return run_scatter<5, float, 2>(in, out, weights, off, mode, cval, s);
     if (f32w && nz * ny * nx >= ((int64_t)1 << 25)) return run_scatter<5, double, 2, true>(in, out, weights, off, mode, cval, s);   // 256^3: the ring kernel is 10 % faster
     // 250 f64 mul + add per voxel: bound by the FP64 pipe either way, and the LDS-ring kernel is as fast (1.66 vs 1.68 ms

@@ -1,4 +1,4 @@
-"""Dense 3 x 3 x 3 / 5 x 5 x 5 correlate / convolve on float32 volumes through stencil3s_kernel (csrc/stencil3s.hip;
+"""Dense 3 x 3 x 3 / 5 x 5 x 5 (/ 7 x 7 x 7 in float mode) correlate / convolve on float32 volumes through stencil3s_kernel (csrc/stencil3s.hip;
 reference filters.py:65-210, dtype_mode :470-487): the default mode (float64 accumulation in window order) is bit-identical
 to the LDS-ring kernel, the generic kernel and SciPy's correlate on float64 input rounded to float32; dtype_mode="float"
 (float32 accumulation, FMA) is within 1e-6 max-norm of SciPy.  Boundary modes, origins along z / y, ragged tile edges,
@@ -135,5 +135,52 @@ def test_scatter_full_size_512_every_plane(gpu, ndi, W):
     assert "stencil3s_kernel<%d,float" % W in last_kernel(), last_kernel()
     err = fs.whole_volume_filter(x, out.get(), W // 2, W // 2, lambda s: sndi.correlate(s.astype(np.float64), w), planes=8)
     assert err <= 1e-6, err
+    del xd, out
+    gpu.free_all_blocks()
+
+
+@pytest.mark.parametrize("shape", [(40, 48, 256), (19, 37, 520), (64, 130, 72), (9, 9, 1032)])
+def test_scatter_7x7x7_float_mode(gpu, ndi, knob, shape):
+    """7 x 7 x 7 in dtype_mode="float": the lane-weight tap rows (343 weights in six registers); the default mode stays on the
+    LDS-ring kernel (FP64 pipe bound either way).  Tolerance 2e-6 of the max-norm: 343 float32 products summed in float32 -- what
+    the reference's own float mode does (filters.py:470-487) -- sit at 7-9e-7 of SciPy's float64 sum on these volumes."""
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(7000 + shape[2])
+    x = rng.standard_normal(shape).astype(np.float32)
+    xd = gpu.asarray(x)
+    w = rng.standard_normal((7, 7, 7))
+    for mode, cval, origin in [("reflect", 0.0, 0), ("constant", 1.5, 0), ("nearest", 0.0, (1, -1, 0)), ("mirror", 0.0, (-3, 0, 0)),
+                               ("wrap", 0.0, (0, 3, 0)), ("constant", 0.0, (3, -3, 0))]:
+        for fn, sfn in [(ndi.correlate, sndi.correlate), (ndi.convolve, sndi.convolve)]:
+            knob(1)
+            gotf = fn(xd, w, mode=mode, cval=cval, origin=origin, dtype_mode="float")
+            assert "stencil3s_kernel<7,float" in last_kernel(), last_kernel()
+            ref = sfn(x.astype(np.float64), w, mode=mode, cval=cval, origin=origin)
+            assert maxnorm_rel(gotf.get(), ref) <= 2e-6, (fn.__name__, mode, origin)
+            got = fn(xd, w, mode=mode, cval=cval, origin=origin)
+            assert "stencil3s_kernel" not in last_kernel(), last_kernel()
+            assert np.array_equal(got.get(), ref.astype(np.float32)), (fn.__name__, mode, origin)
+    # every weight distinct and in its place: a delta volume returns the mirrored window
+    d = np.zeros((21, 21, 256), np.float32)
+    d[10, 10, 100] = 1.0
+    w32 = rng.standard_normal((7, 7, 7)).astype(np.float32)
+    got = ndi.correlate(gpu.asarray(d), w32, dtype_mode="float").get()
+    assert "stencil3s_kernel<7,float" in last_kernel(), last_kernel()
+    assert np.array_equal(got[7:14, 7:14, 97:104], w32[::-1, ::-1, ::-1])
+
+
+def test_scatter_7x7x7_full_size_512(gpu, ndi):
+    from helpers import fullsize as fs
+    from cupyimg_amd import last_kernel
+    gpu.free_all_blocks()
+    x = fs.volume_f32((512,) * 3, seed=0)
+    xd = gpu.asarray(x)
+    w = np.random.default_rng(7).standard_normal((7, 7, 7))
+    out = gpu.empty(x.shape, np.float32)
+    for _ in range(4):
+        ndi.correlate(xd, w, output=out, dtype_mode="float")
+    assert "stencil3s_kernel<7,float" in last_kernel(), last_kernel()
+    err = fs.whole_volume_filter(x, out.get(), 3, 3, lambda s: sndi.correlate(s.astype(np.float64), w), planes=8)
+    assert err <= 2e-6, err                                 # 343 float32 terms: see test_scatter_7x7x7_float_mode
     del xd, out
     gpu.free_all_blocks()
