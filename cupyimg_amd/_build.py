@@ -63,6 +63,7 @@ SOURCES = [
     ("rank_sorted_p128f.hip", ["-ffp-contract=off"]),
     ("rank_sorted_p128g.hip", ["-ffp-contract=off"]),
     ("minmax3d_u8.hip", []),
+    ("minmax3d_u8r.hip", []),
     ("median2d.hip", []),
     ("minmax_16.hip", []),
     ("binary.hip", []),

@@ -1448,6 +1448,11 @@ extern "C" int mi_minmax3d_u8_planes(const mi_array *in, const mi_array *out, co
 #undef UNSUP
 }
 
+namespace mi {
+int minmax3d_u8_ragged(const mi_array *in, const mi_array *out, const int size[3], const int mode[3], int cval, int is_max,
+                       hipStream_t s);   // minmax3d_u8r.hip
+}
+
 extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int size[3],
                               const int origin[3], const int mode[3], int cval, int is_max,
                               mi_stream stream)
@@ -1461,8 +1466,13 @@ extern "C" int mi_minmax3d_u8(const mi_array *in, const mi_array *out, const int
     if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
     if (in->data == out->data) UNSUP("in-place");
     const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
-    if (nz < 1 || ny < 1 || nx < 32 || (nx & 15) || (nx & 1023) == 16) UNSUP("x extent must be a multiple of 16, >= 32");
     if (nz * ny * nx >= ((int64_t)1 << 31)) UNSUP("needs a volume < 2 GiB");
+    if (nz >= 1 && ny >= 1 && (nx & 15) && cval >= 0 && cval <= 255 && !origin[0] && !origin[1] && !origin[2]) {
+        // r6: rows that are not a multiple of 16 bytes as they lie (cubic 3 / 5 / 7, volumes the caches hold)
+        rc = minmax3d_u8_ragged(in, out, size, mode, cval, is_max, resolve_stream(stream));
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
+    }
+    if (nz < 1 || ny < 1 || nx < 32 || (nx & 15) || (nx & 1023) == 16) UNSUP("x extent must be a multiple of 16, >= 32");
     if (ny * nx >= ((int64_t)1 << 31)) UNSUP("plane too large");
     if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
     for (int a = 0; a < 3; a++) {
@@ -1585,8 +1595,8 @@ extern "C" int mi_minmax_runs3d_u8(const mi_array *in, const mi_array *out, cons
     if (!is_contiguous(in) || !is_contiguous(out)) UNSUP("needs C-contiguous arrays");
     if (in->data == out->data) UNSUP("in-place");
     const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
-    if (nz < 1 || ny < 1 || nx < 32 || (nx & 15) || (nx & 1023) == 16) UNSUP("x extent must be a multiple of 16, >= 32");
     if (nz * ny * nx >= ((int64_t)1 << 31)) UNSUP("needs a volume < 2 GiB");
+    if (nz < 1 || ny < 1 || nx < 32 || (nx & 15) || (nx & 1023) == 16) UNSUP("x extent must be a multiple of 16, >= 32");
     if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) UNSUP("needs 16-byte aligned data");
     if (cval < 0 || cval > 255) UNSUP("cval outside uint8");
     U8Run3Params p;

@@ -136,13 +136,17 @@ while time.time() < t_end:
             # ---- flat min / max on ragged rows
             nx = int(rng.choice([17, 19, 66, 181, 183, 253, 255, 257, 301, 511, 514]))
             shape = (int(rng.integers(1, 60)), int(rng.integers(3, 70)), nx)
-            x = rng.standard_normal(shape).astype(np.float32)
+            if rng.random() < 0.5:                # uint8: mm3u8_ragged_kernel (rows as they lie) from 2^15 voxels, other routes below
+                x = rng.integers(0, 256, size=shape).astype(np.uint8)
+            else:
+                x = rng.standard_normal(shape).astype(np.float32)
             xd = ca.asarray(x)
             size = int(rng.choice([3, 5, 7]))
             mode = str(rng.choice(FMODES))
             fn, sfn = ((ndi.minimum_filter, sndi.minimum_filter), (ndi.maximum_filter, sndi.maximum_filter), (ndi.grey_erosion, sndi.grey_erosion),
                        (ndi.grey_dilation, sndi.grey_dilation))[int(rng.integers(0, 4))]
-            exact(fn.__name__, fn(xd, size=size, mode=mode, cval=-0.25).get(), sfn(x, size=size, mode=mode, cval=-0.25), (shape, size, mode))
+            cv = -0.25 if x.dtype == np.float32 else 9
+            exact(fn.__name__, fn(xd, size=size, mode=mode, cval=cv).get(), sfn(x, size=size, mode=mode, cval=cv), (shape, size, mode, str(x.dtype)))
     except Exception as exc:      # a refusal that is not mirrored by SciPy, or a crash: a failure either way
         fails.append(("exception", repr(exc)[:200], op))
     ca.free_all_blocks() if cases % 50 == 0 else None

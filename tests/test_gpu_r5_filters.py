@@ -4,6 +4,8 @@ rank filters with 65 .. 128 samples (5 x 5 x 5, 9 x 9, 11 x 11) take the registe
 instead of the scratch-array selection kernel; `constant` mode with a zero fill value on the LDS-DMA kernel of 9 .. 17 taps
 (sep3d_long3_kernel: zero fill is what its staging leaves for lanes beyond the array).  Spec: /root/reference/cupyimg/scipy/ndimage/filters.py:549-665 (separable
 passes), :1560-1850 (rank / median / percentile filters)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -546,3 +548,82 @@ def test_ragged_rows_minmax_non_finite_values_and_mni_burst(gpu, ndi, lib):
             lib.mi_debug_set_sep3d_ragged(1)
         assert np.array_equal(np.isnan(got), np.isnan(via)), ref.__name__
         assert np.array_equal(got[clean], ref(np.where(np.isnan(w), np.float32(0), w), size=5, mode="mirror")[clean]), ref.__name__
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# r6: uint8 cubic min / max on rows that are not a multiple of 16 bytes, as they lie (csrc/minmax3d_u8r.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def _u8_ragged_shapes():
+    # nx % 16 = 5, 13, 15, 1, 2, 1, 3, 15, 15 (64 granules), 9 (one granule per row), 8, 14, 11, 12, 6, 7, 10, 4; ny that leaves
+    # partial blocks of four rows; one and a few planes
+    return [(24, 37, 181), (17, 30, 301), (9, 21, 255), (12, 19, 257), (40, 30, 66), (64, 70, 17), (50, 60, 19), (5, 20, 511),
+            (3, 40, 1023), (70, 64, 9), (33, 47, 24), (11, 33, 190), (41, 43, 27), (9, 31, 172), (37, 35, 38), (1, 200, 183),
+            (2, 403, 42), (47, 41, 20)]
+
+
+@pytest.mark.parametrize("size", [3, 5, 7])
+def test_u8_ragged_rows_minmax_every_mode_against_scipy(gpu, ndi, lib, size):
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    lib.mi_debug_set_u8_ragged.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(6600 + size)
+    tails = set()
+    for shape in _u8_ragged_shapes():
+        if shape[0] * shape[1] * shape[2] % 256 > 240:
+            continue                                                  # (an array that may end within 16 bytes of its pool block: see the next test)
+        x = rng.integers(0, 256, size=shape).astype(np.uint8)
+        if shape[2] == 181:
+            x[rng.random(shape) < 0.3] = 0                           # plateaus and both extremes
+            x[rng.random(shape) < 0.1] = 255
+        xd = gpu.asarray(x)
+        for mode in MODES:
+            for fn, sfn, tag in ((ndi.minimum_filter, sndi.minimum_filter, "min"), (ndi.maximum_filter, sndi.maximum_filter, "max")):
+                got = fn(xd, size=size, mode=mode, cval=7).get()
+                k = last_kernel()
+                assert "mm3u8_ragged_kernel<%d,%s>" % (size, tag) in k, (shape, mode, k)
+                ref = sfn(x, size=size, mode=mode, cval=7)
+                assert np.array_equal(got, ref), (shape, mode, tag, int((got != ref).sum()))
+        tails.add(shape[2] % 16)
+        assert np.array_equal(ndi.grey_erosion(xd, size=size).get(), sndi.grey_erosion(x, size=size)), shape
+        assert "mm3u8_ragged_kernel<%d,min>" % size in last_kernel()
+        assert np.array_equal(ndi.grey_dilation(xd, size=size).get(), sndi.grey_dilation(x, size=size)), shape
+        assert "mm3u8_ragged_kernel<%d,max>" % size in last_kernel()
+        # mixed modes per axis; a user-provided output; what the kernel does not take (origins, non-cubic sizes) keeps SciPy's numbers
+        modes = ("constant", "wrap", "mirror")
+        out = gpu.empty(shape, np.uint8)
+        ndi.minimum_filter(xd, size=size, mode=modes, cval=200, output=out)
+        assert "mm3u8_ragged_kernel" in last_kernel()
+        assert np.array_equal(out.get(), sndi.minimum_filter(x, size=size, mode=modes, cval=200)), shape
+        assert np.array_equal(ndi.maximum_filter(xd, size=size, origin=(0, 1, 0)).get(), sndi.maximum_filter(x, size=size, origin=(0, 1, 0)))
+        assert np.array_equal(ndi.minimum_filter(xd, size=(size, 3, size)).get(), sndi.minimum_filter(x, size=(size, 3, size)))
+        lib.mi_debug_set_u8_ragged(0)
+        try:
+            via = ndi.grey_erosion(xd, size=size).get()
+            assert shape[2] < 32 or "mm3u8_ragged_kernel" not in last_kernel()      # (the per-axis passes of tiny rows leave no note)
+        finally:
+            lib.mi_debug_set_u8_ragged(1)
+        assert np.array_equal(via, sndi.grey_erosion(x, size=size)), shape
+    assert len(tails) >= 12
+
+
+def test_u8_ragged_rows_mni_burst_and_views(gpu, ndi, lib):
+    """181 x 217 x 181 as the last launch of a burst; an array that ends exactly at the end of its allocation has no 16 readable
+    bytes behind it and must take the other route with the same result; a view into a larger buffer has them."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(66)
+    x = rng.integers(0, 256, size=(181, 217, 181)).astype(np.uint8)
+    xd = gpu.asarray(x)
+    out = gpu.empty(x.shape, np.uint8)
+    for size, mode in ((3, "reflect"), (5, "mirror"), (7, "constant")):
+        for _ in range(30):
+            ndi.grey_erosion(xd, size=size, mode=mode, cval=3, output=out)
+        assert "mm3u8_ragged_kernel<%d,min>" % size in last_kernel(), last_kernel()
+        assert np.array_equal(out.get(), sndi.grey_erosion(x, size=size, mode=mode, cval=3)), (size, mode)
+    big = gpu.asarray(rng.integers(0, 256, size=(40, 50, 77)).astype(np.uint8))
+    sub = big[3:35]                                                   # contiguous, 5 planes of the buffer behind it
+    got = ndi.grey_dilation(sub, size=3).get()
+    assert "mm3u8_ragged_kernel" in last_kernel(), last_kernel()
+    assert np.array_equal(got, sndi.grey_dilation(big.get()[3:35], size=3))
+    tail = big[8:]                                                    # ends where the buffer ends (or at the pool block's end: either is fine)
+    assert np.array_equal(ndi.grey_dilation(tail, size=3).get(), sndi.grey_dilation(big.get()[8:], size=3))
