@@ -675,10 +675,17 @@ struct XPass3 {
 // defaults below.
 // WZ: taps along z (the streamed axis); W: taps along y and x.  WZ != W serves volumes with anisotropic voxels
 // (gaussian sigma given in millimetres: fewer taps through the slices), where the in-plane kernels agree.
-template <int W, bool SAME, bool DBG, int CFG = 0, int WZ = W>
+// RG (r6): rows of any length >= 16 floats.  The LDS-DMA takes 16-byte records from addresses that are only 4-byte aligned
+// (probed: scratch/unal_dma.hip), so a row is staged from wherever it starts; the LAST lane of a row's last x tile then holds
+// `tail` = 1 .. 3 floats of its row followed by the head of the next row (zeros beyond the plane): before the x pass those
+// floats are replaced by the first y-filtered halo floats right of the row -- the halo DMA starts at the row's true end -- and
+// the two right-hand halo blocks move up by 4 - tail floats; the lane stores `tail` floats (one 8-byte and one 4-byte store
+// that every lane issues with an out-of-range offset, so that the vmcnt arithmetic stays uniform: three stores per step).
+template <int W, bool SAME, bool DBG, int CFG = 0, int WZ = W, bool RG = false>
 __global__ void __launch_bounds__(kLongTY * 64)
 sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const LongParams p)
 {
+    static_assert(!RG || (CFG == 0 && !DBG), "the ragged build is the production variant only");
     constexpr int ROWS = kLongTY + W - 1;
     static_assert(W >= 3 && (W & 1) && ROWS <= kLongRowsMax && W / 2 <= 8, "long kernel: odd W, 3..17");
     static_assert(WZ >= 3 && (WZ & 1) && WZ <= kLongRowsMax / 2 + 1 && (WZ == W || !SAME), "long kernel: odd WZ, 3..17");
@@ -717,9 +724,11 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     }
     const int ty_act = min(kLongTY, ny - y0);
     const int rows_needed = ty_act + W - 1;
-    const int nlanes = min(p.tw >> 2, (nx - x0) >> 2);
+    const int width = min(p.tw, nx - x0);                                   // RG: floats of the row in this tile
+    const int nlanes = RG ? (width + 3) >> 2 : min(p.tw >> 2, (nx - x0) >> 2);
     const int last = nlanes - 1;
-    const int xe = x0 + 4 * nlanes;
+    const int tail = RG ? width - 4 * last : 4;                             // floats of its row the last lane holds
+    const int xe = RG ? x0 + width : x0 + 4 * nlanes;
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
     const int zi0 = zs - p.oz;
     const int nsteps = ze - zs + WZ - 1;
@@ -750,7 +759,12 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     const unsigned hx_dst = kXrow0 + (unsigned)(lane >> 2) * kLongRec +
                             ((lane & 3) < 2 ? (unsigned)(lane & 3) * 16u : 32u + 16u * (unsigned)nlanes + (unsigned)((lane & 3) - 2) * 16u);
     const unsigned xr_own = kXrow0 + (unsigned)wave * kLongRec + (unsigned)lane * 16u;     // block -2 of this lane's window
-    const unsigned ovoff = (wave < ty_act && lane < nlanes) ? (unsigned)((y0 + wave) * nx + x0 + 4 * lane) * 4u : kOOB;
+    const bool rg_last = RG && lane == last && tail < 4;                     // stores `tail` floats in pieces
+    const bool rg_p1 = rg_last && tail < 2, rg_p2 = rg_last && tail < 3, rg_p3 = rg_last;     // floats 1 / 2 / 3 of its block are the row's continuation
+    const unsigned ovoff0 = (unsigned)((y0 + wave) * nx + x0 + 4 * lane) * 4u;
+    const unsigned ovoff = (wave < ty_act && lane < nlanes && !rg_last) ? ovoff0 : kOOB;
+    const unsigned ovoff2 = (wave < ty_act && rg_last && (tail & 2)) ? ovoff0 : kOOB;                           // floats 0, 1
+    const unsigned ovoff1 = (wave < ty_act && rg_last && (tail & 1)) ? ovoff0 + ((tail & 2) ? 8u : 0u) : kOOB;  // float 2 or 0
     constexpr unsigned kPlane = kLongRowsMax * kLongRec;
 
     auto issue = [&](int i, unsigned bufoff) {
@@ -850,6 +864,7 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 // output it goes to a descriptor of zero records).  Plane i + 1 must have landed: vmcnt(5); step 0 has
                 // only the 8 DMAs of the prologue behind it: vmcnt(4).
                 if ((J == 0 && i0 == 0) || (dbg & 16)) asm volatile(MI_VMCNT(4) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else if constexpr (RG) asm volatile(MI_VMCNT(7) " lgkmcnt(0)\n\ts_barrier" ::: "memory");    // three stores per step
                 else asm volatile(MI_VMCNT(5) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
                 // ---- halo table of plane i + 1 (the wave changes every plane).  First thing in the step: its reads travel
@@ -881,7 +896,7 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 const char *ysrc = smem + own + b1;
                 issue(i + 3, b3);
                 XPass3<W> xp;
-                const float4 yv4 = f4_to_float4(yv);
+                float4 yv4 = f4_to_float4(yv);
                 F4 xy;
                 if constexpr (kXlds) {
                     constexpr int NBK = XPass3<W>::NBK;
@@ -902,10 +917,25 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                     float4 oL[2], eR[2];
                     oL[1] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff);
                     oL[0] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 16u);
+                    if constexpr (RG) {
+                        // the row's continuation h0 .. h7 (the y-filtered halo floats from the row's true end: blocks 2, 3 of the
+                        // table row) moves into the last lane's block behind its `tail` floats, and the two right-hand blocks
+                        // start 4 - tail floats later: twelve consecutive floats of the table row from float 8 - tail on (dword
+                        // reads: the address is only 4-byte aligned; past h7 they are another row's, wanted by no stored output)
+                        const float *hp = reinterpret_cast<const float *>(smem + hy_row + hyoff + 32u - 4u * (unsigned)tail);
+                        const float u1 = hp[1], u2 = hp[2], u3 = hp[3];
+                        eR[0] = make_float4(hp[4], hp[5], hp[6], hp[7]);
+                        eR[1] = make_float4(hp[8], hp[9], hp[10], hp[11]);
+                        yv4.y = rg_p1 ? u1 : yv4.y;
+                        yv4.z = rg_p2 ? u2 : yv4.z;
+                        yv4.w = rg_p3 ? u3 : yv4.w;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(dbg & 2)) xp.left(yv4, oL, xte, xto);
-                    eR[0] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 32u);
-                    eR[1] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 48u);
+                    if constexpr (!RG) {
+                        eR[0] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 32u);
+                        eR[1] = *reinterpret_cast<const float4 *>(smem + hy_row + hyoff + 48u);
+                    }
 #pragma unroll
                     for (int k = 0; k < GA; k++) if (k < wy_rows) R[k] = *reinterpret_cast<const float4 *>(ysrc + k * kLongRec);
                     __builtin_amdgcn_sched_barrier(0);
@@ -940,6 +970,11 @@ sep3d_long3_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                         __builtin_amdgcn_make_buffer_rsrc((void *)oa, 0, i >= WZ - 1 ? (int)plane_bytes : 0, 0x00020000);
                     const F4 o = acc[(J + 1) % WZ];
                     if (!(dbg & 16)) __builtin_amdgcn_raw_buffer_store_b128(f4_to_u32(o), rout, ovoff, 0, 2);
+                    if constexpr (RG) {
+                        const u32x4 ou = f4_to_u32(o);
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){ou.x, ou.y}, rout, ovoff2, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b32((tail & 2) ? ou.z : ou.x, rout, ovoff1, 0, 2);
+                    }
                 }
                 if (kHaloEnd ? !(dbg & 64) : (dbg & 64) != 0) halo_job();
                 if constexpr (((CFG >> 8) & 1) == 0) __builtin_amdgcn_s_setprio(0);
@@ -1302,10 +1337,12 @@ static mi::Knob g_long_same{1};        // test hook: 0 = always the reloading va
 // Returns MI_ERR_UNSUPPORTED when the request is outside that (the caller runs the streaming passes).
 int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, int wzn, const float *wx, const float *wy,
                    const float *wz, int oy, int oz, int mx, int my, int mz, float cval, const int64_t zb[2],
-                   const int64_t zn[2], hipStream_t s)
+                   const int64_t zn[2], hipStream_t s, bool ragged)
 {
     // w: taps along y and x, wzn: taps along z (== w: the cubic kernels; a few (w, wzn) pairs with wzn < w besides)
     if (w < 3 || w > 17 || !(w & 1) || wzn < 3 || wzn > 17 || !(wzn & 1)) return MI_ERR_UNSUPPORTED;
+    // rows that are not a multiple of 4 floats (r6): the cubic kernels of 11 .. 17 taps, index-mapping modes or a zero fill value
+    if (ragged && (wzn != w || w < 11 || nx < 16)) return MI_ERR_UNSUPPORTED;
     const bool has_const = mx == MI_MODE_CONSTANT || my == MI_MODE_CONSTANT || mz == MI_MODE_CONSTANT;
     if (wzn != w && ((has_const && !(cval == 0.0f && g_long_const0)) || !long_aniso_pair(w, wzn))) return MI_ERR_UNSUPPORTED;
     if (has_const && w <= 7 && !(cval == 0.0f && g_long_const0)) return MI_ERR_UNSUPPORTED;      // below 9 taps only the zero-fill form runs here (r5); the lean kernel has the fill values
@@ -1378,6 +1415,26 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, i
         }
         MI_LONG_ANISO_PAIRS(MI_LONG_ANISO)
 #undef MI_LONG_ANISO
+        return MI_ERR_UNSUPPORTED;
+    }
+    if (ragged) {
+        if (has_const && !(cval == 0.0f && g_long_const0)) return MI_ERR_UNSUPPORTED;
+        // (the three axes share one weight vector -- isotropic gaussian_filter, uniform_filter: the variant whose scalars stay
+        // resident; the re-loading variant has no registers left for the ragged edge and would spill)
+        for (int k = 0; k < w; k++)
+            if (!(wx[k] == wy[k] && wy[k] == wz[k])) return MI_ERR_UNSUPPORTED;
+        const size_t lds = (size_t)kLongRawBytes + kLongHyBytes + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int);
+        const int total = p.nxt * p.nyt * p.nzc;
+#define MI_LONG_RAGGED(N)                                                                                                 \
+        case N: {                                                                                                         \
+            static PerDeviceOnce attr_r;                                                                                  \
+            note_kernel("mi::sep3d_long3_kernel<%d,true,ragged> grid=%d (fused y/x/z separable pass, LDS-DMA staged, rows of any length)", (N), total); \
+            return long_launch_one(sep3d_long3_kernel<(N), true, false, 0, (N), true>, attr_r, lds, total, in, out, p, s); \
+        }
+        switch (w) {
+            MI_LONG_RAGGED(11) MI_LONG_RAGGED(13) MI_LONG_RAGGED(15) MI_LONG_RAGGED(17)
+        }
+#undef MI_LONG_RAGGED
         return MI_ERR_UNSUPPORTED;
     }
     bool same = g_long_same != 0;

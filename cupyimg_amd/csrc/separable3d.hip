@@ -888,7 +888,7 @@ int run_stream_pass(const float *in, float *out, int nz, int ny, int nx, int axi
                     int ma, const float *wxv, int wx, int mx, float cval, hipStream_t s);   // stream3d.hip
 int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, int wzn, const float *wx, const float *wy,
                    const float *wz, int oy, int oz, int mx, int my, int mz, float cval, const int64_t zb[2],
-                   const int64_t zn[2], hipStream_t s);   // sep3d_long.hip
+                   const int64_t zn[2], hipStream_t s, bool ragged = false);   // sep3d_long.hip
 bool long_aniso_pair(int w, int wzn);                     // sep3d_long.hip: (in-plane, z) tap pairs it is built for
 
 // Tile / z-chunk choice by a small cost model.  One workgroup per CU is
@@ -1028,9 +1028,20 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     const int64_t nzr = zn[0] + zn[1];
 
     const bool cubic_w = w[0] == w[1] && w[1] == w[2];
-    if (ragged && !(cubic_w && w[0] >= 3 && w[0] <= 9 && g_sep3d_kernel != 1 && g_sep3d_cfg == 0 && ny * nx * 4 < ((int64_t)1 << 31) &&
-                    (weights[0] ? origin[0] : 0) == 0 && (weights[1] ? origin[1] : 0) == 0))
-        UNSUP("rows that are not a multiple of 4 floats: cubic kernels of 3 / 5 / 7 / 9 taps without origins only");
+    // r6: 11 .. 17 cubic taps on such rows through the LDS-DMA kernel's ragged build (origins along y / z allowed there)
+    const bool ragged_long = ragged && cubic_w && w[0] >= 11 && w[0] <= 17 && g_sep3d_ragged && g_sep3d_long != 1 &&
+                             (!any_const || (float)cval == 0.0f) && ny * nx * 4 < ((int64_t)1 << 31);
+    if (ragged && !ragged_long &&
+        !(cubic_w && w[0] >= 3 && w[0] <= 9 && g_sep3d_kernel != 1 && g_sep3d_cfg == 0 && ny * nx * 4 < ((int64_t)1 << 31) &&
+          (weights[0] ? origin[0] : 0) == 0 && (weights[1] ? origin[1] : 0) == 0))
+        UNSUP("rows that are not a multiple of 4 floats: cubic kernels of 3 .. 17 taps only (3 .. 9: without origins)");
+    if (ragged_long) {
+        const int oz = w[0] / 2 + (weights[0] ? origin[0] : 0), oy = w[1] / 2 + (weights[1] ? origin[1] : 0);
+        rc = run_sep3d_long((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w[0], w[0], wbuf[2], wbuf[1],
+                            wbuf[0], oy, oz, p.mx, p.my, p.mz, (float)cval, zb, zn, resolve_stream(stream), true);
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
+        UNSUP("rows that are not a multiple of 4 floats: the long kernel's ragged build refused");
+    }
     // r3: with its re-scheduled instruction stream (sep3d_long3_kernel) the LDS-DMA kernel also beats the lean kernel
     // below 9 taps on volumes that fill the chip (profiles/r3_long3_small_taps.txt, sustained, lean -> long: 7 taps
     // 15-31 % faster on every shape of 4 Mvoxels and more; 5 and 3 taps 3-5 % faster on 512^3, 256^3, 64 x 1024^2 and

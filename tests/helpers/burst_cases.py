@@ -73,6 +73,15 @@ class Cases:
     def case_long3_const0_13(self):
         return self._sep(13, "constant")                     # r5: zero fill on the r3 kernel
 
+    # r6: the ragged build (rows of any length, three stores per step: its own wait counts), one and two x tiles
+    def case_long3_ragged_17(self):
+        x, xd = self.vol((181, 217, 181), 5)
+        return (lambda o: self.ndi.gaussian_filter(xd, 2.0, mode="mirror", output=o)), x.shape, np.float32, "ragged"
+
+    def case_long3_ragged_13_two_tiles(self):
+        x, xd = self.vol((96, 130, 301), 6)
+        return (lambda o: self.ndi.uniform_filter(xd, 13, mode="wrap", output=o)), x.shape, np.float32, "ragged"
+
     def case_mm3f32_5(self):
         x, xd = self.vol((192, 256, 512), 1)
         return (lambda o: self.ndi.maximum_filter(xd, 5, output=o)), x.shape, np.float32, "mm3f32_long_kernel"

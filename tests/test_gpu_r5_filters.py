@@ -627,3 +627,66 @@ def test_u8_ragged_rows_mni_burst_and_views(gpu, ndi, lib):
     assert np.array_equal(got, sndi.grey_dilation(big.get()[3:35], size=3))
     tail = big[8:]                                                    # ends where the buffer ends (or at the pool block's end: either is fine)
     assert np.array_equal(ndi.grey_dilation(tail, size=3).get(), sndi.grey_dilation(big.get()[8:], size=3))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# r6: 11 .. 17 cubic taps on rows that are not a multiple of four floats through the LDS-DMA kernel (sep3d_long3_kernel<..., ragged>)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("taps", [11, 13, 15, 17])
+def test_ragged_rows_long_kernels_against_scipy_and_the_extended_rows_route(gpu, ndi, lib, taps):
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(1700 + taps)
+    sigma = {11: 1.3, 13: 1.5, 15: 1.8, 17: 2.0}[taps]
+    tails = set()
+    # nx % 4 = 1, 2, 3; one tile and two tiles per row (the second one ragged); rows just beyond a multiple of 256; ny, nz that
+    # leave partial y tiles and chunks shorter than the window
+    for shape in [(24, 37, 181), (17, 30, 301), (9, 40, 253), (20, 21, 255), (12, 19, 257), (33, 18, 18), (8, 33, 19), (5, 20, 511),
+                  (40, 17, 66), (19, 64, 129)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        for mode in MODES:
+            got = ndi.uniform_filter(xd, taps, mode=mode).get()
+            k = last_kernel()
+            assert "sep3d_long3_kernel<%d,true,ragged>" % taps in k, (shape, mode, k)
+            ref = sndi.uniform_filter(x.astype(np.float64), taps, mode=mode)
+            assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (shape, mode)
+            got = ndi.gaussian_filter(xd, sigma, mode=mode).get()
+            assert "sep3d_long3_kernel<%d,true,ragged>" % taps in last_kernel(), (shape, mode, last_kernel())
+            ref = sndi.gaussian_filter(x.astype(np.float64), sigma, mode=mode)
+            assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (shape, mode, "gaussian")
+        tails.add(shape[2] & 3)
+        # against the extended-rows route (the same kernel on rows extended to multiples of 16 bytes): same taps, same order
+        lib.mi_debug_set_sep3d_ragged(0)
+        try:
+            via = ndi.uniform_filter(xd, taps, mode="reflect").get()
+            assert x.size < (1 << 15) or "ragged" not in last_kernel()    # (small volumes: per-axis passes, which leave no note)
+        finally:
+            lib.mi_debug_set_sep3d_ragged(1)
+        got = ndi.uniform_filter(xd, taps, mode="reflect").get()
+        assert np.abs(got - via).max() <= 2e-6 * max(1.0, np.abs(via).max()), shape
+        # origins along z / y; a non-zero fill value and per-axis sigmas are not this build's: still SciPy's numbers
+        if min(shape[:2]) > taps:
+            got = ndi.uniform_filter(xd, taps, mode="nearest", origin=(2, -3, 0)).get()
+            assert "ragged" in last_kernel(), last_kernel()
+            ref = sndi.uniform_filter(x.astype(np.float64), taps, mode="nearest", origin=(2, -3, 0))
+            assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (shape, "origin")
+        got = ndi.uniform_filter(xd, taps, mode="constant", cval=1.5).get()
+        ref = sndi.uniform_filter(x.astype(np.float64), taps, mode="constant", cval=1.5)
+        assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (shape, "cval")
+    assert tails == {1, 2, 3}
+
+
+def test_ragged_rows_long_kernel_mni_every_plane_after_a_burst(gpu, ndi, lib):
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    x = np.random.default_rng(17).standard_normal((181, 217, 181)).astype(np.float32)
+    xd = gpu.asarray(x)
+    out = gpu.empty(x.shape, np.float32)
+    for sigma, taps in ((2.0, 17), (1.5, 13)):
+        for _ in range(30):
+            ndi.gaussian_filter(xd, sigma, output=out)
+        assert "sep3d_long3_kernel<%d,true,ragged>" % taps in last_kernel(), last_kernel()
+        ref = sndi.gaussian_filter(x.astype(np.float64), sigma)
+        err = np.abs(out.get() - ref).reshape(181, -1).max(axis=1)
+        assert err.max() <= 1e-6 * np.abs(ref).max(), (sigma, int(err.argmax()), float(err.max()))
