@@ -274,7 +274,7 @@ def _refusal_key(key, input, output, left, right, mode_x):
         if isinstance(v, (tuple, list)):
             return tuple(norm(x) for x in v)
         return v
-    return (norm(key), str(input.dtype), str(output.dtype), tuple(input.shape), left, right, mode_x,
+    return (norm(key), input.dtype.char, output.dtype.char, tuple(input.shape), left, right, mode_x,
             int(S.lib().mi_debug_generation()))
 
 
@@ -293,7 +293,8 @@ def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_c
     `key`: what the fused path's answer depends on besides the data (r4 advisor finding: a request it refuses -- large
     windows, ranks it does not handle -- paid two allocations and a full-volume copy before falling back to the generic
     passes, on every call): a refusal is remembered and the next call with the same key returns at once."""
-    if key is not None:
+    raw_key = key
+    if key is not None and _EXT_REFUSED:                  # (nothing recorded: nothing to look up -- the key is made when a refusal is stored)
         key = _refusal_key(key, input, output, left, right, mode_x)
         if key in _EXT_REFUSED:
             _EXT_REFUSED.move_to_end(key)
@@ -327,7 +328,8 @@ def _run_on_extended_rows(input, output, left, right, mode_x, cval, run, exact_c
     a, b = src._desc(), ext._desc()
     S.check(S.lib().mi_extend_rows(ctypes.byref(a), ctypes.byref(b), pl, S.mode_code(mode_x), float(cval), None))
     if run(ext, tmp) is None:
-        if key is not None:
+        if raw_key is not None:
+            key = _refusal_key(raw_key, input, output, left, right, mode_x)
             _EXT_REFUSED[key] = True
             while len(_EXT_REFUSED) > _EXT_REFUSED_MAX:
                 _EXT_REFUSED.popitem(last=False)          # least recently used first
