@@ -106,6 +106,7 @@ SIGNATURES = {
     "mi_separable3d_f32_planes": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i64p, _i, _vp],
     "mi_separable3d_f32_supports": [_arr, _arr, ctypes.POINTER(_dp), _ip, _ip, _ip, _d, _i],
     "mi_correlate_nd": [_arr, _arr, _dp, _i64p, _ip, _i, _d, _i, _vp],
+    "mi_correlate3_dense": [_arr, _arr, _dp, _i64p, _ip, _i, _d, _i, _vp],
     "mi_minmax1d": [_arr, _arr, _i, _i, _i, _i, _d, _i, _vp],
     "mi_minmax3d_u8": [_arr, _arr, _ip, _ip, _ip, _i, _i, _vp],
     "mi_minmax3d_f32": [_arr, _arr, _ip, _ip, _ip, _d, _i, _vp],

@@ -84,6 +84,25 @@ using namespace mi;
 static mi::Knob g_stencil_enabled{1};
 extern "C" int mi_debug_set_stencil(int enabled) { g_stencil_enabled = enabled; return MI_OK; }
 
+// The dense 3 / 5 / 7-cubed window on a float32 volume through stencil3s_kernel ONLY -- the one stencil kernel that takes rows of any
+// length -- or nothing at all: what the Python layer asks first for rows that are not a multiple of 16 bytes, before it
+// extends them for the tiled kernel (mi_correlate_nd itself never refuses: it ends at the generic gather kernel).
+extern "C" int mi_correlate3_dense(const mi_array *in, const mi_array *out, const double *weights,
+                                   const int64_t *wshape, const int *origins, int mode, double cval,
+                                   int acc_f32, mi_stream stream)
+{
+    int rc;
+    if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
+    MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    MI_REQUIRE(weights && wshape && origins, MI_ERR_INVALID_ARG, "NULL argument");
+    if (in->ndim != 3 || !is_contiguous(in) || !is_contiguous(out) || in->data == out->data || in->dtype != out->dtype || !g_stencil_enabled) {
+        set_error("correlate3_dense: contiguous, distinct 3-D arrays of one dtype only");
+        return MI_ERR_UNSUPPORTED;
+    }
+    if (numel(in) == 0) return MI_OK;
+    return stencil3_scatter(in, out, weights, wshape, origins, filter_mode(mode), cval, acc_f32 && in->dtype == MI_F32, resolve_stream(stream));
+}
+
 extern "C" int mi_correlate_nd(const mi_array *in, const mi_array *out, const double *weights,
                                const int64_t *wshape, const int *origins, int mode, double cval,
                                int acc_f32, mi_stream stream)

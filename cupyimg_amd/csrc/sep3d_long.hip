@@ -1341,8 +1341,8 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, i
 {
     // w: taps along y and x, wzn: taps along z (== w: the cubic kernels; a few (w, wzn) pairs with wzn < w besides)
     if (w < 3 || w > 17 || !(w & 1) || wzn < 3 || wzn > 17 || !(wzn & 1)) return MI_ERR_UNSUPPORTED;
-    // rows that are not a multiple of 4 floats (r6): the cubic kernels of 11 .. 17 taps, index-mapping modes or a zero fill value
-    if (ragged && (wzn != w || w < 11 || nx < 16)) return MI_ERR_UNSUPPORTED;
+    // rows that are not a multiple of 4 floats (r6): the cubic kernels of 9 .. 17 taps, index-mapping modes or a zero fill value
+    if (ragged && (wzn != w || w < 9 || nx < 16)) return MI_ERR_UNSUPPORTED;
     const bool has_const = mx == MI_MODE_CONSTANT || my == MI_MODE_CONSTANT || mz == MI_MODE_CONSTANT;
     if (wzn != w && ((has_const && !(cval == 0.0f && g_long_const0)) || !long_aniso_pair(w, wzn))) return MI_ERR_UNSUPPORTED;
     if (has_const && w <= 7 && !(cval == 0.0f && g_long_const0)) return MI_ERR_UNSUPPORTED;      // below 9 taps only the zero-fill form runs here (r5); the lean kernel has the fill values
@@ -1432,7 +1432,7 @@ int run_sep3d_long(const float *in, float *out, int nz, int ny, int nx, int w, i
             return long_launch_one(sep3d_long3_kernel<(N), true, false, 0, (N), true>, attr_r, lds, total, in, out, p, s); \
         }
         switch (w) {
-            MI_LONG_RAGGED(11) MI_LONG_RAGGED(13) MI_LONG_RAGGED(15) MI_LONG_RAGGED(17)
+            MI_LONG_RAGGED(9) MI_LONG_RAGGED(11) MI_LONG_RAGGED(13) MI_LONG_RAGGED(15) MI_LONG_RAGGED(17)
         }
 #undef MI_LONG_RAGGED
         return MI_ERR_UNSUPPORTED;

@@ -1028,8 +1028,8 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
     const int64_t nzr = zn[0] + zn[1];
 
     const bool cubic_w = w[0] == w[1] && w[1] == w[2];
-    // r6: 11 .. 17 cubic taps on such rows through the LDS-DMA kernel's ragged build (origins along y / z allowed there)
-    const bool ragged_long = ragged && cubic_w && w[0] >= 11 && w[0] <= 17 && g_sep3d_ragged && g_sep3d_long != 1 &&
+    // r6: 9 .. 17 cubic taps on such rows through the LDS-DMA kernel's ragged build (origins along y / z allowed there)
+    const bool ragged_long = ragged && cubic_w && w[0] >= 9 && w[0] <= 17 && g_sep3d_ragged && g_sep3d_long != 1 &&
                              (!any_const || (float)cval == 0.0f) && ny * nx * 4 < ((int64_t)1 << 31);
     if (ragged && !ragged_long &&
         !(cubic_w && w[0] >= 3 && w[0] <= 9 && g_sep3d_kernel != 1 && g_sep3d_cfg == 0 && ny * nx * 4 < ((int64_t)1 << 31) &&
@@ -1040,7 +1040,9 @@ static int separable3d_impl(const mi_array *in, const mi_array *out, const doubl
         rc = run_sep3d_long((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, w[0], w[0], wbuf[2], wbuf[1],
                             wbuf[0], oy, oz, p.mx, p.my, p.mz, (float)cval, zb, zn, resolve_stream(stream), true);
         if (rc != MI_ERR_UNSUPPORTED) return rc;
-        UNSUP("rows that are not a multiple of 4 floats: the long kernel's ragged build refused");
+        // (per-axis weight vectors: 9 taps go on to the lean kernel's ragged build below, longer ones to the extended-rows route)
+        if (!(w[0] == 9 && g_sep3d_kernel != 1 && g_sep3d_cfg == 0 && (weights[0] ? origin[0] : 0) == 0 && (weights[1] ? origin[1] : 0) == 0))
+            UNSUP("rows that are not a multiple of 4 floats: the long kernel's ragged build refused");
     }
     // r3: with its re-scheduled instruction stream (sep3d_long3_kernel) the LDS-DMA kernel also beats the lean kernel
     // below 9 taps on volumes that fill the chip (profiles/r3_long3_small_taps.txt, sustained, lean -> long: 7 taps

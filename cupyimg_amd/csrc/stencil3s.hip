@@ -50,7 +50,7 @@ struct ScatterParams {
 // product of a float32 sample and such a weight is EXACT in float64 (24 + 24 significant bits), so the fused operation
 // rounds once exactly where mul + add round once, and the result is still bit-identical to SciPy's; v_mul_f64 + v_add_f64
 // cost 16 cycles per wave, v_fma_f64 8 (FP64 runs at half the FP32 rate on CDNA4), and the default mode is bound by them.
-template <int W, typename Acc, int RW, bool FMA64 = false>
+template <int W, typename Acc, int RW, bool FMA64 = false, bool RG = false>
 __global__ void __launch_bounds__(kSsNW * 64)
 stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const ScatterParams<Acc> p)
 {
@@ -81,7 +81,13 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
     const int zs = zci * p.zc, ze = min(zs + p.zc, nz);
     const int nout = ze - zs;
     const int ty_act = min(TY, ny - y0);
-    const int nlanes = min(64, (nx - x0) >> 2);
+    // RG -- rows of any length (r6, late; a build of its own: the aligned one keeps its registers): 16-byte buffer loads need
+    // 4-byte alignment only, so a row is staged from wherever it starts; the last lane of a row's last tile holds `tail` floats of
+    // its row followed by the head of the next one (zeros beyond the plane), which the right-hand halo floats -- written at the
+    // row's true end, after the row -- overwrite in LDS
+    const int width = RG ? min(256, nx - x0) : 4 * min(64, (nx - x0) >> 2);
+    const int nlanes = (width + 3) >> 2;
+    const int tail = RG ? width - 4 * (nlanes - 1) : 4;   // floats of its row the last lane holds (4: a whole float4)
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
     const size_t plane_elems = (size_t)ny * (size_t)nx;
 
@@ -90,9 +96,9 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
     bool row_const[RPW];
     int lds_row[RPW];
     const bool halo_lane = lane < 8;
-    const int xh = lane < 4 ? x0 - 4 + lane : x0 + 4 * nlanes + (lane - 4);
+    const int xh = lane < 4 ? x0 - 4 + lane : x0 + width + (lane - 4);
     const int xsrc = halo_lane ? bmap_near<int>(xh, nx, mode) : -1;
-    const int halo_pos = lane < 4 ? lane : 4 + 4 * nlanes + (lane - 4);
+    const int halo_pos = lane < 4 ? lane : 4 + width + (lane - 4);
 #pragma unroll
     for (int k = 0; k < RPW; k++) {
         const int j = wave + kSsNW * k;
@@ -382,7 +388,16 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
                     u.x = __float_as_uint((float)A[a][rr][0]); u.y = __float_as_uint((float)A[a][rr][1]);
                     u.z = __float_as_uint((float)A[a][rr][2]); u.w = __float_as_uint((float)A[a][rr][3]);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(u, rout, live ? ovoff[rr] : kOOB, 0, 0);
+                if (!RG || tail == 4) {                       // (uniform)
+                    __builtin_amdgcn_raw_buffer_store_b128(u, rout, live ? ovoff[rr] : kOOB, 0, 0);
+                } else {
+                    // the last lane stores `tail` floats in pieces; every lane issues every store, with an out-of-range offset
+                    // where it has nothing to write (no divergent control flow around the stores)
+                    const unsigned o = live ? ovoff[rr] : kOOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(u, rout, last_lane ? kOOB : o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){u.x, u.y}, rout, (last_lane && (tail & 2)) ? o : kOOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((tail & 2) ? u.z : u.x, rout, (last_lane && (tail & 1) && o != kOOB) ? o + ((tail & 2) ? 8u : 0u) : kOOB, 0, 0);
+                }
             }
         }
         if (q + 1 < nsteps) stage(q + 1);                 // the other slot: nobody reads it in this step
@@ -397,9 +412,12 @@ stencil3s_kernel(const float *__restrict__ in, float *__restrict__ out, const Sc
     }
 }
 
-template <int W, typename Acc, int RW, bool FMA64>
+template <int W, typename Acc, int RW, bool FMA64, bool RG = false>
 static int launch_scatter(const float *in, float *out, ScatterParams<Acc> &p, hipStream_t s)
 {
+    if constexpr (!RG) {
+        if (p.nx & 3) return launch_scatter<W, Acc, RW, FMA64, true>(in, out, p, s);
+    }
     constexpr int TY = kSsNW * RW;
     const size_t lds = (size_t)2 * (TY + W - 1) * kSsPitch * sizeof(float);
     p.nxt = (p.nx + 255) / 256;
@@ -420,10 +438,10 @@ static int launch_scatter(const float *in, float *out, ScatterParams<Acc> &p, hi
     p.nzc = (p.nz + p.zc - 1) / p.zc;
     const int64_t total = tiles * p.nzc;
     if (total > 0x7fffffff) { set_error("stencil3s: too many tiles"); return MI_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL((stencil3s_kernel<W, Acc, RW, FMA64>), dim3((unsigned)total), dim3(kSsNW * 64), 0, s, in, out, p);
+    hipLaunchKernelGGL((stencil3s_kernel<W, Acc, RW, FMA64, RG>), dim3((unsigned)total), dim3(kSsNW * 64), 0, s, in, out, p);
     MI_HIP(hipGetLastError());
-    note_kernel("mi::stencil3s_kernel<%d,%s,%d> grid=%lld (dense %dx%dx%d correlate, z scattered over register accumulators, %s)",
-                W, std::is_same<Acc, float>::value ? "float" : "double", RW, (long long)total, W, W, W,
+    note_kernel("mi::stencil3s_kernel<%d,%s,%d%s> grid=%lld (dense %dx%dx%d correlate, z scattered over register accumulators, %s)",
+                W, std::is_same<Acc, float>::value ? "float" : "double", RW, RG ? ",ragged" : "", (long long)total, W, W, W,
                 std::is_same<Acc, float>::value ? "v_pk_fma_f32" : FMA64 ? "f64 fma in window order: float32-valued weights, exact products"
                                                                          : "f64 mul + add in window order");
     return MI_OK;
@@ -464,11 +482,11 @@ int stencil3_scatter(const mi_array *in, const mi_array *out, const double *weig
     for (int k = 0; k < W * W * W; k++)
         if (weights[k] == 0.0 || (acc_f32 && (float)weights[k] == 0.0f)) NOPE("a zero weight is skipped by the reference: mask path");
     const int64_t nz = in->shape[0], ny = in->shape[1], nx = in->shape[2];
-    if (nx < 8 || (nx & 3)) NOPE("x extent must be a multiple of 4, >= 8");
+    if (nx < 8) NOPE("rows of at least 8 samples");
     if (ny * nx * 4 >= ((int64_t)1 << 31) || nz > (1 << 24) || ny > (1 << 24)) NOPE("plane too large");
     if (W > nz || W > ny) NOPE("window longer than the array");
     if (nz * ny * nx < (1 << 16)) NOPE("small volume");
-    if (((uintptr_t)in->data & 15) || ((uintptr_t)out->data & 15)) NOPE("needs 16-byte aligned data");
+    if (((uintptr_t)in->data & 3) || ((uintptr_t)out->data & 3)) NOPE("needs 4-byte aligned data");
     if (mode == MI_MODE_CONSTANT && (double)(float)cval != cval && !std::isnan(cval)) NOPE("cval is not a float32 value");
 #undef NOPE
     bool f32w = true;                                      // every weight a float32 value: exact products (see FMA64)

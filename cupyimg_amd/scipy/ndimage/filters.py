@@ -136,6 +136,15 @@ def _correlate_or_convolve(input, weights, output, mode, cval, origin, convoluti
             and input.shape[2] % 4 and max(weights.shape) <= 9 and S.current_planes() is None):       # (the stencil kernel takes rows of 4 k elements)
         # rows that are not a multiple of 16 bytes: the LDS-tiled stencil kernel on explicitly extended rows (r4b;
         # 181 x 217 x 181 float32, 3 x 3 x 3 weights: 219 -> see DESIGN.md)
+        if (input.dtype == np.float32 and weights.shape in ((3, 3, 3), (5, 5, 5), (7, 7, 7)) and input._is_c_contiguous()
+                and output._is_c_contiguous() and not core.shares_memory(output, input)):
+            # r6: the scatter kernel takes rows of any length -- asked first; a refusal queues nothing
+            a, b = input._desc(), output._desc()
+            try:
+                S.check(S.lib().mi_correlate3_dense(ctypes.byref(a), ctypes.byref(b), wp, wshape, org, S.mode_code(mode), float(cval), acc, None))
+                return output
+            except S.Unsupported:
+                pass
         left = weights.shape[2] // 2 + int(origins[2])
         res = _run_on_extended_rows(input, output, left, weights.shape[2] - 1 - left, mode, cval,
                                     lambda e, o: (launch(e, o), o)[1])        # (the launch raises or succeeds: nothing to remember)

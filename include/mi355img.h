@@ -245,6 +245,12 @@ int mi_separable3d_f32_supports(const mi_array *in, const mi_array *out, const d
 int mi_correlate_nd(const mi_array *in, const mi_array *out, const double *weights,
                     const int64_t *wshape, const int *origins, int mode, double cval,
                     int acc_f32, mi_stream stream);
+/* The dense 3 x 3 x 3 / 5 x 5 x 5 (with acc_f32: 7 x 7 x 7) window without zero weights on a float32 volume through stencil3s_kernel only
+ * -- rows of ANY length, x origin 0 -- or MI_ERR_UNSUPPORTED with nothing queued (mi_correlate_nd never refuses: it ends at the
+ * generic gather kernel).  For callers that would otherwise extend ragged rows for the tiled kernel (filters.py:65-210). */
+int mi_correlate3_dense(const mi_array *in, const mi_array *out, const double *weights,
+                        const int64_t *wshape, const int *origins, int mode, double cval,
+                        int acc_f32, mi_stream stream);
 
 /* ------------------------------------------------------------------ */
 /* K2: min / max family (grey morphology)                               */

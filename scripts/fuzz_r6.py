@@ -116,7 +116,7 @@ while time.time() < t_end:
         elif op <= 7:
             # ---- dense 3^3 / 5^3 / 7^3 correlate (7^3: the scatter kernel in float mode, the ring kernel otherwise)
             W = int(rng.choice([3, 5, 7]))
-            shape = (int(rng.integers(W, 70)), int(rng.integers(W, 90)), int(rng.choice([64, 72, 128, 256, 264, 520, 1032])))
+            shape = (int(rng.integers(W, 70)), int(rng.integers(W, 90)), int(rng.choice([64, 72, 128, 181, 183, 253, 256, 258, 264, 301, 520, 1032])))       # (rows of any length since the late round)
             if np.prod(shape) < (1 << 16):
                 shape = (shape[0] + 40, shape[1] + 40, shape[2])
             x = (rng.standard_normal(shape) * rng.choice([1.0, 1e3])).astype(np.float32)

@@ -46,7 +46,10 @@ def test_ragged_rows_every_mode_against_scipy_and_the_extended_rows_route(gpu, n
             kw = dict(mode=mode, cval=-0.75)
             got = ndi.uniform_filter(xd, taps, **kw).get()
             k = last_kernel()
-            assert "ragged" in k and "sep3d_lean_kernel<%d," % taps in k, (shape, mode, k)
+            if taps == 9 and mode != "constant":          # r6: nine taps with one weight vector take the LDS-DMA kernel's ragged build (a fill value keeps the lean one)
+                assert "sep3d_long3_kernel<9,true,ragged>" in k, (shape, mode, k)
+            else:
+                assert "ragged" in k and "sep3d_lean_kernel<%d," % taps in k, (shape, mode, k)
             ref = sndi.uniform_filter(x.astype(np.float64), taps, **kw)
             assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (shape, mode, k)
             seen_tails.add(shape[2] & 3)

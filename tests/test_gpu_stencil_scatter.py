@@ -184,3 +184,45 @@ def test_scatter_7x7x7_full_size_512(gpu, ndi):
     assert err <= 2e-6, err                                 # 343 float32 terms: see test_scatter_7x7x7_float_mode
     del xd, out
     gpu.free_all_blocks()
+
+
+@pytest.mark.parametrize("W", [3, 5, 7])
+def test_scatter_rows_of_any_length(gpu, ndi, knob, W):
+    """Rows that are not a multiple of four floats (r6, late): the scatter kernel stages them as they lie (mi_correlate3_dense, asked
+    before the rows are extended for the tiled kernel); one tile and two tiles per row, every tail, every mode; what the kernel
+    refuses on such rows (zero weights, x origins) still gives SciPy's numbers through the extended-rows route."""
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(4400 + W)
+    tails = set()
+    for shape in [(24, 37, 181), (17, 30, 301), (12, 40, 253), (20, 21, 255), (16, 19, 257), (70, 64, 18), (64, 33, 35), (9, 20, 511),
+                  (181, 217, 181)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        xd = gpu.asarray(x)
+        w = rng.standard_normal((W, W, W))
+        modes = [("reflect", 0.0, 0), ("constant", 1.5, 0), ("nearest", 0.0, (1, -1, 0)), ("mirror", 0.0, 0), ("wrap", 0.0, (0, 1, 0))]
+        for mode, cval, origin in (modes if shape[0] < 100 else modes[:2]):
+            for fn, sfn in [(ndi.correlate, sndi.correlate), (ndi.convolve, sndi.convolve)]:
+                ref = sfn(x.astype(np.float64), w, mode=mode, cval=cval, origin=origin)
+                gotf = fn(xd, w, mode=mode, cval=cval, origin=origin, dtype_mode="float")
+                assert "stencil3s_kernel<%d,float" % W in last_kernel(), (shape, last_kernel())
+                assert maxnorm_rel(gotf.get(), ref) <= (2e-6 if W == 7 else 1e-6), (shape, mode, origin)
+                if W == 3:
+                    got = fn(xd, w, mode=mode, cval=cval, origin=origin)
+                    assert "stencil3s_kernel<3,double" in last_kernel(), (shape, last_kernel())
+                    assert np.array_equal(got.get(), ref.astype(np.float32)), (shape, mode, origin)
+        tails.add(shape[2] & 3)
+        w0 = w.copy()
+        w0[0, 1, 1] = 0.0
+        assert np.array_equal(ndi.correlate(xd, w0).get(), sndi.correlate(x.astype(np.float64), w0).astype(np.float32)), shape
+        assert "stencil3s_kernel" not in last_kernel()
+        got = ndi.correlate(xd, w, origin=(0, 0, 1), dtype_mode="float").get()
+        assert maxnorm_rel(got, sndi.correlate(x.astype(np.float64), w, origin=(0, 0, 1))) <= 2e-6, shape
+    assert tails == {1, 2, 3}
+    # an output the caller provides, a view that starts inside a buffer (4-byte aligned only)
+    big = gpu.asarray(rng.standard_normal((40, 50, 77)).astype(np.float32))
+    sub = big[3:35]
+    out = gpu.empty(sub.shape, np.float32)
+    w = rng.standard_normal((W, W, W))
+    ndi.correlate(sub, w, output=out, dtype_mode="float")
+    assert "stencil3s_kernel" in last_kernel()
+    assert maxnorm_rel(out.get(), sndi.correlate(big.get()[3:35].astype(np.float64), w)) <= 2e-6
