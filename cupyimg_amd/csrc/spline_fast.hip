@@ -252,7 +252,7 @@ template <> struct Vec4<float> { typedef float type __attribute__((ext_vector_ty
 template <> struct Vec4<double> { typedef double type __attribute__((ext_vector_type(4))); };
 
 struct SplRows {
-    int n;                   // samples per line (a multiple of 4)
+    int n;                   // samples per line (>= 64)
     long long nlines;
     int smode;
     double z, gain;
@@ -289,11 +289,14 @@ spline_rows_scan_kernel(const SRC *src, CF *dst, const SplRows p)
 #pragma unroll
     for (int s = 0; s < NSEG; s++) {
         const int i0 = s * 256 + lane * 4;
-        if (i0 < n) {
+        if (i0 + 3 < n) {
+            // (lines of any length, r6: a line then starts on an element boundary only -- vector accesses need no more)
             const SV q = *reinterpret_cast<const SV *>(rd + i0);
             v[s][0] = (double)q.x * p.gain; v[s][1] = (double)q.y * p.gain; v[s][2] = (double)q.z * p.gain; v[s][3] = (double)q.w * p.gain;
         } else {
-            v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0.0;
+            // the lane that holds the end of the line (n % 4 samples of it), and the lanes beyond
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[s][j] = i0 + j < n ? (double)rd[i0 + j] * p.gain : 0.0;
         }
     }
     // ---- c+[0]: the boundary sum over the first 64 samples (lanes 0 .. 15 of segment 0; z^64 ends the series)
@@ -313,17 +316,27 @@ spline_rows_scan_kernel(const SRC *src, CF *dst, const SplRows p)
 #pragma unroll
     for (int s = 0; s < NSEG; s++) carry = scan_fwd<WIDE>(v[s], carry, w, zf);
     // ---- the anti-causal input: u[i] = -z c+[i] below the last sample, the end condition at it, nothing beyond
-    const int last = n - 1;                          // = 4 m + 3
+    const int last = n - 1;
+    // c+[last] and c+[last - 1] wherever they sit (segment, lane, element: the same in every line)
+    double cl = 0.0, cp = 0.0;
+    const int prv = last - 1;
+#pragma unroll
+    for (int s = 0; s < NSEG; s++) {
+        if ((last >> 8) == s) {
+            const int e = last & 3;
+            cl = lane_read(e == 0 ? v[s][0] : (e == 1 ? v[s][1] : (e == 2 ? v[s][2] : v[s][3])), (last & 255) >> 2);
+        }
+        if ((prv >> 8) == s) {
+            const int e = prv & 3;
+            cp = lane_read(e == 0 ? v[s][0] : (e == 1 ? v[s][1] : (e == 2 ? v[s][2] : v[s][3])), (prv & 255) >> 2);
+        }
+    }
+    const double end = p.smode == 0 ? fma(z, cp, cl) * (z / (z * z - 1.0)) : cl * (z / (z - 1.0));
 #pragma unroll
     for (int s = 0; s < NSEG; s++) {
         const int i0 = s * 256 + lane * 4;
-        const double end = p.smode == 0 ? fma(z, v[s][2], v[s][3]) * (z / (z * z - 1.0)) : v[s][3] * (z / (z - 1.0));
-        const bool is_last = i0 + 3 == last;
-        const bool beyond = i0 > last;
-        v[s][0] = beyond ? 0.0 : -z * v[s][0];
-        v[s][1] = beyond ? 0.0 : -z * v[s][1];
-        v[s][2] = beyond ? 0.0 : -z * v[s][2];
-        v[s][3] = beyond ? 0.0 : (is_last ? end : -z * v[s][3]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[s][j] = i0 + j > last ? 0.0 : (i0 + j == last ? end : -z * v[s][j]);
     }
     carry = 0.0;
 #pragma unroll
@@ -331,10 +344,14 @@ spline_rows_scan_kernel(const SRC *src, CF *dst, const SplRows p)
 #pragma unroll
     for (int s = 0; s < NSEG; s++) {
         const int i0 = s * 256 + lane * 4;
-        if (i0 < n) {
+        if (i0 + 3 < n) {
             CV q;
             q.x = (CF)v[s][0]; q.y = (CF)v[s][1]; q.z = (CF)v[s][2]; q.w = (CF)v[s][3];
             *reinterpret_cast<CV *>(wr + i0) = q;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (i0 + j < n) wr[i0 + j] = (CF)v[s][j];
         }
     }
 }
@@ -390,8 +407,8 @@ bool spline_pass_fast(const mi_array *shape, const void *src, int src_dtype, voi
     const double gain = (1.0 - z) * (1.0 - 1.0 / z);
     const bool f64 = shape->dtype == MI_F64, sf64 = src_dtype == MI_F64;
     if (inner == 1) {
-        const size_t align = f64 ? 32 : 16;                                        // four coefficients per lane and access
-        if ((n & 3) || n > 2048 || ((uintptr_t)src & (sf64 ? 31 : 15)) || ((uintptr_t)dst & (align - 1))) return false;
+        // four coefficients per lane and access; lines of any length (r6): element alignment is all the vector accesses need
+        if (n > 2048 || ((uintptr_t)src & (sf64 ? 7 : 3)) || ((uintptr_t)dst & (f64 ? 7 : 3))) return false;
         if ((nlines + 3) / 4 > 0x7fffffffLL) return false;
         SplRows p;
         p.n = (int)n; p.nlines = nlines; p.smode = spline_mode & 0xff; p.z = z; p.gain = gain;
