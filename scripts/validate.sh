@@ -27,6 +27,7 @@ timeout 200 python scripts/fuzz_vs_scipy.py 150 2026 2>&1 | tail -3 | tee $O/fuz
 timeout 300 python scripts/bench_bitmorph.py > $O/bitmorph_bench.txt 2>&1; grep "shape\|cross  \|3^3\|ball2\|x3\|masked\|opening cross " $O/bitmorph_bench.txt | head -20
 timeout 300 python scripts/bench_stencil.py > $O/stencil_bench.txt 2>&1; grep "3x3x3\|5x5x5" $O/stencil_bench.txt
 timeout 300 python scripts/bench_fill_holes.py > $O/fill_holes.txt 2>&1; head -5 $O/fill_holes.txt | cut -c1-120
+timeout 200 python scripts/survey_mni.py > $O/mni_survey.txt 2>&1
 timeout 300 python scripts/bench_ragged_long.py > $O/ragged_long.txt 2>&1; head -3 $O/ragged_long.txt | cut -c1-140
 timeout 300 python scripts/bench_ragged_minmax.py > $O/ragged_minmax.txt 2>&1; head -4 $O/ragged_minmax.txt
 bash scripts/kstat_any.sh $TAG/binary_stats scripts/prof_bitmorph.py > $O/binary_kstat.txt 2>&1; cat $O/binary_kstat.txt
