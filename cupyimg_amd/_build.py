@@ -64,6 +64,7 @@ SOURCES = [
     ("rank_sorted_p128g.hip", ["-ffp-contract=off"]),
     ("minmax3d_u8.hip", []),
     ("minmax3d_u8r.hip", []),
+    ("minmax3d_16r.hip", []),
     ("median2d.hip", []),
     ("minmax_16.hip", []),
     ("binary.hip", []),

@@ -735,6 +735,11 @@ int run_median3x3_16(const mi_array *in, const mi_array *out, int mx, int my, do
 using namespace mi;
 
 /* Separable flat min / max on a uint16 / int16 image or volume (declared in include/mi355img.h). */
+namespace mi {
+int minmax3d_16_ragged(const mi_array *in, const mi_array *out, const int size[3], const int mode[3], int cval, int is_max,
+                       hipStream_t s);   // minmax3d_16r.hip
+}
+
 extern "C" int mi_minmax3d_16(const mi_array *in, const mi_array *out, const int size[3], const int origin[3],
                               const int mode[3], int cval, int is_max, mi_stream stream)
 {
@@ -742,6 +747,13 @@ extern "C" int mi_minmax3d_16(const mi_array *in, const mi_array *out, const int
     if ((rc = check_array(in, "in")) || (rc = check_array(out, "out"))) return rc;
     MI_REQUIRE(size && origin && mode, MI_ERR_INVALID_ARG, "NULL argument");
     MI_REQUIRE(same_shape(in, out), MI_ERR_INVALID_ARG, "output shape is not correct");
+    // r6: rows that are not a multiple of 16 bytes as they lie (cubic 3 / 5 / 7, volumes the caches hold)
+    if (in->ndim == 3 && in->dtype == out->dtype && (in->dtype == MI_U16 || in->dtype == MI_I16) && is_contiguous(in) && is_contiguous(out) &&
+        in->data != out->data && (in->shape[2] & 7) && !origin[0] && !origin[1] && !origin[2] &&
+        cval >= (in->dtype == MI_I16 ? -32768 : 0) && cval <= (in->dtype == MI_I16 ? 32767 : 65535)) {
+        rc = minmax3d_16_ragged(in, out, size, mode, cval, is_max, resolve_stream(stream));
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
+    }
     int64_t nz, ny, nx;
     if ((rc = geometry16(in, out, "minmax3d_16", &nz, &ny, &nx))) return rc;
 #define UNSUP(msg) do { set_error("minmax3d_16: %s", msg); return MI_ERR_UNSUPPORTED; } while (0)

@@ -58,6 +58,7 @@ int mi_debug_set_stencil_scatter(int on);     /* csrc/stencil3s.hip: 0 = dense 3
 int mi_debug_set_binary_tiled(int on);        /* csrc/binary.hip: 0 = generic binary erosion kernel */
 int mi_debug_set_bitfill(int on);                     /* 0: runs until stable iterate the global operator (no block-wise fill) */
 int mi_debug_set_u8_ragged(int on);           /* 0: uint8 cubic min / max on rows that are not a multiple of 16 bytes goes back to the extended-rows route (mm3u8_ragged_kernel off) */
+int mi_debug_set_s16_ragged(int on);          /* the same switch for the uint16 / int16 kernel (mm3s16_ragged_kernel) */
 int mi_debug_set_bitmorph_ragged(int on);             /* 0: rows that are not a multiple of 16 bytes keep the extended-rows / generic routes */
 int mi_debug_set_bitmorph_2d(int on);                 /* 0: 2-D images keep the byte kernel (binary3d.hip) */
 int mi_debug_set_bitmorph_table(int on);              /* 1: the run-time structure table even for the built-in 3 x 3 x 3 structures */

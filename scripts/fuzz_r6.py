@@ -136,8 +136,11 @@ while time.time() < t_end:
             # ---- flat min / max on ragged rows
             nx = int(rng.choice([17, 19, 66, 181, 183, 253, 255, 257, 301, 511, 514]))
             shape = (int(rng.integers(1, 60)), int(rng.integers(3, 70)), nx)
-            if rng.random() < 0.5:                # uint8: mm3u8_ragged_kernel (rows as they lie) from 2^15 voxels, other routes below
+            u = rng.random()
+            if u < 0.35:                          # uint8: mm3u8_ragged_kernel (rows as they lie) from 2^15 voxels, other routes below
                 x = rng.integers(0, 256, size=shape).astype(np.uint8)
+            elif u < 0.6:                         # int16 / uint16: mm3s16_ragged_kernel
+                x = rng.integers(-3000, 3000, size=shape).astype(np.int16) if u < 0.5 else rng.integers(0, 65536, size=shape).astype(np.uint16)
             else:
                 x = rng.standard_normal(shape).astype(np.float32)
             xd = ca.asarray(x)

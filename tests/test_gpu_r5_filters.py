@@ -693,3 +693,55 @@ def test_ragged_rows_long_kernel_mni_every_plane_after_a_burst(gpu, ndi, lib):
         ref = sndi.gaussian_filter(x.astype(np.float64), sigma)
         err = np.abs(out.get() - ref).reshape(181, -1).max(axis=1)
         assert err.max() <= 1e-6 * np.abs(ref).max(), (sigma, int(err.argmax()), float(err.max()))
+
+
+@pytest.mark.parametrize("size", [3, 5, 7])
+@pytest.mark.parametrize("dtype", [np.int16, np.uint16])
+def test_16bit_ragged_rows_minmax_every_mode_against_scipy(gpu, ndi, lib, size, dtype):
+    """uint16 / int16 volumes whose rows are not a multiple of 16 bytes (what a scanner hands out on the MNI grid), rows as they lie:
+    mm3s16_ragged_kernel (csrc/minmax3d_16r.hip), every tail nx % 8, every mode, mixed modes, against SciPy bit for bit."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    lib.mi_debug_set_s16_ragged.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(1600 + size + (7 if dtype == np.int16 else 0))
+    info = np.iinfo(dtype)
+    tails = set()
+    for shape in [(24, 37, 181), (17, 30, 301), (9, 21, 255), (12, 19, 257), (40, 30, 66), (64, 70, 17), (50, 60, 19), (5, 20, 511),
+                  (70, 64, 9), (33, 47, 28), (11, 33, 190), (9, 31, 172), (37, 35, 38), (47, 41, 20), (30, 40, 29)]:
+        if shape[0] * shape[1] * shape[2] * 2 % 256 > 240:
+            continue
+        x = rng.integers(info.min, int(info.max) + 1, size=shape).astype(dtype)
+        if shape[2] == 181:
+            x[rng.random(shape) < 0.3] = info.min
+            x[rng.random(shape) < 0.1] = info.max
+        xd = gpu.asarray(x)
+        cv = -7 if dtype == np.int16 else 40000
+        for mode in MODES:
+            for fn, sfn, tag in ((ndi.minimum_filter, sndi.minimum_filter, "min"), (ndi.maximum_filter, sndi.maximum_filter, "max")):
+                got = fn(xd, size=size, mode=mode, cval=cv).get()
+                k = last_kernel()
+                assert "mm3s16_ragged_kernel<%d,%s,%s>" % (size, tag, "int16" if dtype == np.int16 else "uint16") in k, (shape, mode, k)
+                ref = sfn(x, size=size, mode=mode, cval=cv)
+                assert np.array_equal(got, ref), (shape, mode, tag, int((got != ref).sum()))
+        tails.add(shape[2] % 8)
+        assert np.array_equal(ndi.grey_erosion(xd, size=size).get(), sndi.grey_erosion(x, size=size)), shape
+        assert np.array_equal(ndi.grey_dilation(xd, size=size).get(), sndi.grey_dilation(x, size=size)), shape
+        assert "mm3s16_ragged_kernel" in last_kernel()
+        modes = ("constant", "wrap", "mirror")
+        assert np.array_equal(ndi.minimum_filter(xd, size=size, mode=modes, cval=cv).get(), sndi.minimum_filter(x, size=size, mode=modes, cval=cv)), shape
+        assert np.array_equal(ndi.maximum_filter(xd, size=size, origin=(0, 1, 0)).get(), sndi.maximum_filter(x, size=size, origin=(0, 1, 0)))
+        lib.mi_debug_set_s16_ragged(0)
+        try:
+            via = ndi.grey_erosion(xd, size=size).get()
+        finally:
+            lib.mi_debug_set_s16_ragged(1)
+        assert np.array_equal(via, sndi.grey_erosion(x, size=size)), shape
+    assert len(tails) >= 6
+    if size == 3:
+        x = rng.integers(info.min, int(info.max) + 1, size=(181, 217, 181)).astype(dtype)
+        xd = gpu.asarray(x)
+        out = gpu.empty(x.shape, dtype)
+        for _ in range(20):
+            ndi.grey_dilation(xd, size=3, output=out)
+        assert "mm3s16_ragged_kernel" in last_kernel(), last_kernel()
+        assert np.array_equal(out.get(), sndi.grey_dilation(x, size=3))
