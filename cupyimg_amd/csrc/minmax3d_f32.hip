@@ -44,7 +44,10 @@ __device__ __forceinline__ float win(const float (&t)[N])
     return t[0] != t[0] ? t[0] : r;
 }
 
-template <int W, bool IS_MAX>
+// RG (r6): rows of any length, as sep3d_long3_kernel's ragged build (sep3d_long.hip): 4-byte-aligned LDS-DMA records, the halo
+// from the row's true end, the last lane's floats beyond its `tail` replaced by the y-filtered continuation, `tail` floats
+// stored in pieces (three stores per step from the first complete output on: vmcnt(7) where the aligned build has vmcnt(5)).
+template <int W, bool IS_MAX, bool RG = false>
 __global__ void __launch_bounds__(kLongTY * 64)
 mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const MmLongParams p)
 {
@@ -73,9 +76,11 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     const int zs = p.zb + zci * p.zc, ze = min(zs + p.zc, p.zb + p.zn);
     const int ty_act = min(kLongTY, ny - y0);
     const int rows_needed = ty_act + W - 1;
-    const int nlanes = min(p.tw >> 2, (nx - x0) >> 2);
+    const int width = min(p.tw, nx - x0);
+    const int nlanes = RG ? (width + 3) >> 2 : min(p.tw >> 2, (nx - x0) >> 2);
     const int last = nlanes - 1;
-    const int xe = x0 + 4 * nlanes;
+    const int tail = RG ? width - 4 * last : 4;             // floats of its row the last lane holds
+    const int xe = RG ? x0 + width : x0 + 4 * nlanes;
     const unsigned plane_bytes = (unsigned)ny * (unsigned)nx * 4u;
     const int zi0 = zs - p.oz;
     const int nsteps = ze - zs + W - 1;
@@ -97,7 +102,12 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
     const unsigned own = (unsigned)wave * kLongRec + (unsigned)lane * 16u;
     const unsigned hsrc = (unsigned)(lane >> 2) * kLongRec + 1024u + (unsigned)(lane & 3) * 16u;
     const unsigned hy_near = HY0 + (unsigned)wave * 64u + (lane == 0 ? 16u : 32u);     // lane 0: block x0-4..x0-1; others: xe..xe+3
-    const unsigned ovoff = (wave < ty_act && lane < nlanes) ? (unsigned)((y0 + wave) * nx + x0 + 4 * lane) * 4u : kOOB;
+    const bool rg_last = RG && lane == last && tail < 4;
+    const bool rg_p1 = rg_last && tail < 2, rg_p2 = rg_last && tail < 3, rg_p3 = rg_last;
+    const unsigned ovoff0 = (unsigned)((y0 + wave) * nx + x0 + 4 * lane) * 4u;
+    const unsigned ovoff = (wave < ty_act && lane < nlanes && !rg_last) ? ovoff0 : kOOB;
+    const unsigned ovoff2 = (wave < ty_act && rg_last && (tail & 2)) ? ovoff0 : kOOB;
+    const unsigned ovoff1 = (wave < ty_act && rg_last && (tail & 1)) ? ovoff0 + ((tail & 2) ? 8u : 0u) : kOOB;
     constexpr unsigned kPlane = kLongRowsMax * kLongRec;
 
     auto issue = [&](int i, unsigned bufoff) {
@@ -153,16 +163,28 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                 // in flight: vmcnt(5) once stores have begun.  (r2 waited vmcnt(4) throughout, i.e. for the first DMA of
                 // the plane issued one step earlier: a prefetch distance of one plane, not two -- removing the DMAs
                 // altogether saved 86 us of 358 on config B, the waves were stalling on them.)
-                if (i >= W) asm volatile(MI_VMCNT(5) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile(MI_VMCNT(4) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (i >= W) {
+                    if constexpr (RG) asm volatile(MI_VMCNT(7) " lgkmcnt(0)\n\ts_barrier" ::: "memory");     // three stores per step
+                    else asm volatile(MI_VMCNT(5) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else asm volatile(MI_VMCNT(4) " lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue(i + 3, b3);
                 const unsigned hyoff = (unsigned)(i & 1) * (kLongHyBytes / 2);
                 // ---- y window of output row `wave`, then its x window in registers
-                const float4 yv = ypass(own + bi);
+                float4 yv = ypass(own + bi);
                 const float4 eg = *reinterpret_cast<const float4 *>(smem + hy_near + hyoff);
+                float4 eright = eg;
+                if constexpr (RG) {
+                    // the row's continuation (near-right block h0 .. h3 of the table row, from the row's true end) behind the last
+                    // lane's `tail` floats; what follows it: eight dword reads from float 8 - tail of the table row on
+                    const float *hp = reinterpret_cast<const float *>(smem + HY0 + (unsigned)wave * 64u + hyoff + 32u - 4u * (unsigned)tail);
+                    yv.y = rg_p1 ? hp[1] : yv.y;
+                    yv.z = rg_p2 ? hp[2] : yv.z;
+                    yv.w = rg_p3 ? hp[3] : yv.w;
+                    eright = make_float4(hp[4], hp[5], hp[6], hp[7]);
+                }
                 const float4 l = dpp4_shr(eg, yv);
                 const float4 rr = dpp4_shl(eg, yv);
-                const float4 r = lane == last ? eg : rr;
+                const float4 r = lane == last ? eright : rr;
                 const float e[12] = {l.x, l.y, l.z, l.w, yv.x, yv.y, yv.z, yv.w, r.x, r.y, r.z, r.w};
                 float o[4];
 #pragma unroll
@@ -188,6 +210,10 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
                     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)oa, 0, (int)plane_bytes, 0x00020000);
                     __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(res.x), __float_as_uint(res.y), __float_as_uint(res.z),
                                                                    __float_as_uint(res.w)}, rout, ovoff, 0, 2);
+                    if constexpr (RG) {
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(res.x), __float_as_uint(res.y)}, rout, ovoff2, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b32((tail & 2) ? __float_as_uint(res.z) : __float_as_uint(res.x), rout, ovoff1, 0, 2);
+                    }
                 }
                 ring[J % RINGN] = xy;
                 // ---- halo table of plane i + 1 (the wave changes every plane)
@@ -204,17 +230,18 @@ mm3f32_long_kernel(const float *__restrict__ in, float *__restrict__ out, const 
 
 static int mm_long_cus() { return device_cus(); }
 
-template <int W, bool IS_MAX>
+template <int W, bool IS_MAX, bool RG = false>
 static int launch_mm_long(const float *in, float *out, MmLongParams &p, hipStream_t s)
 {
     const size_t lds = (size_t)kLongRawBytes + kLongHyBytes + (size_t)(kLongMaxChunk + kStreamMaxTaps) * sizeof(int);
     static PerDeviceOnce attr_done;
     if (!attr_done) {
-        MI_HIP(hipFuncSetAttribute((const void *)mm3f32_long_kernel<W, IS_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MI_HIP(hipFuncSetAttribute((const void *)mm3f32_long_kernel<W, IS_MAX, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    note_kernel("mi::mm3f32_long_kernel<%d,%s> grid=%d (fused y/x/z flat min / max, LDS-DMA staged)", W, IS_MAX ? "max" : "min", p.nxt * p.nyt * p.nzc);
-    hipLaunchKernelGGL((mm3f32_long_kernel<W, IS_MAX>), dim3(p.nxt * p.nyt * p.nzc), dim3(kLongTY * 64), lds, s, in, out, p);
+    note_kernel("mi::mm3f32_long_kernel<%d,%s%s> grid=%d (fused y/x/z flat min / max, LDS-DMA staged%s)", W, IS_MAX ? "max" : "min", RG ? ",ragged" : "",
+                p.nxt * p.nyt * p.nzc, RG ? ", rows of any length" : "");
+    hipLaunchKernelGGL((mm3f32_long_kernel<W, IS_MAX, RG>), dim3(p.nxt * p.nyt * p.nzc), dim3(kLongTY * 64), lds, s, in, out, p);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -263,6 +290,10 @@ int run_minmax3d_f32_fused_planes(const float *in, float *out, int nz, int ny, i
     p.zc = (zn + best_nzc - 1) / best_nzc;
     if (p.zc > kLongMaxChunk) p.zc = kLongMaxChunk;
     p.nzc = (zn + p.zc - 1) / p.zc;
+    if (nx & 3) {                 // r6: rows of any length -- size 9 (3 / 5 / 7 on such rows take the lean kernel's ragged build, which is faster there)
+        if (w != 9) return MI_ERR_UNSUPPORTED;
+        return is_max ? launch_mm_long<9, true, true>(in, out, p, s) : launch_mm_long<9, false, true>(in, out, p, s);
+    }
 #define MI_MM_CASE(N) case N: return is_max ? launch_mm_long<N, true>(in, out, p, s) : launch_mm_long<N, false>(in, out, p, s);
     switch (w) { MI_MM_CASE(3) MI_MM_CASE(5) MI_MM_CASE(7) MI_MM_CASE(9) }
 #undef MI_MM_CASE

@@ -538,9 +538,14 @@ extern "C" int mi_minmax3d_f32(const mi_array *in, const mi_array *out, const in
     if ((nx & 3) && nz >= 1 && ny >= 1) {
         // r6: rows that are not a multiple of four floats -- cubic sizes without origins in ONE launch on the rows as they
         // are (the lean kernel's ragged build with min / max for its three passes); anything else: the caller extends the rows
-        if (size[0] == size[1] && size[1] == size[2] && !origin[0] && !origin[1] && !origin[2])
-            return run_sep3d_lean_minmax(in, out, size[0], mode, cval, is_max != 0, resolve_stream(stream));
-        UNSUP("rows that are not a multiple of 4 floats: cubic sizes 3 / 5 / 7 without origins only");
+        if (size[0] == size[1] && size[1] == size[2] && !origin[0] && !origin[1] && !origin[2]) {
+            rc = run_sep3d_lean_minmax(in, out, size[0], mode, cval, is_max != 0, resolve_stream(stream));
+            if (rc != MI_ERR_UNSUPPORTED || size[0] != 9 || !g_minmax_f32_fused || nx < 16 || nz * ny * nx * 4 >= ((int64_t)1 << 31)) return rc;
+            // size 9: the LDS-DMA kernel's ragged build (index-mapping modes; it refuses the rest)
+            return run_minmax3d_f32_fused((const float *)in->data, (float *)out->data, (int)nz, (int)ny, (int)nx, 9, 4, 4,
+                                          filter_mode(mode[2]), filter_mode(mode[1]), filter_mode(mode[0]), is_max != 0, resolve_stream(stream));
+        }
+        UNSUP("rows that are not a multiple of 4 floats: cubic sizes 3 / 5 / 7 / 9 without origins only");
     }
     if (nz < 1 || ny < 1 || nx < 8 || (nx & 3)) UNSUP("x extent must be a multiple of 4, >= 8");
     if (nz * ny * nx * 4 >= ((int64_t)1 << 31)) UNSUP("needs a volume < 2 GiB");

@@ -82,6 +82,10 @@ class Cases:
         x, xd = self.vol((96, 130, 301), 6)
         return (lambda o: self.ndi.uniform_filter(xd, 13, mode="wrap", output=o)), x.shape, np.float32, "ragged"
 
+    def case_mm3f32_ragged_9(self):
+        x, xd = self.vol((181, 217, 181), 5)
+        return (lambda o: self.ndi.grey_erosion(xd, size=9, mode="mirror", output=o)), x.shape, np.float32, "mm3f32_long_kernel<9,min,ragged>"
+
     def case_mm3f32_5(self):
         x, xd = self.vol((192, 256, 512), 1)
         return (lambda o: self.ndi.maximum_filter(xd, 5, output=o)), x.shape, np.float32, "mm3f32_long_kernel"

@@ -745,3 +745,34 @@ def test_16bit_ragged_rows_minmax_every_mode_against_scipy(gpu, ndi, lib, size, 
             ndi.grey_dilation(xd, size=3, output=out)
         assert "mm3s16_ragged_kernel" in last_kernel(), last_kernel()
         assert np.array_equal(out.get(), sndi.grey_dilation(x, size=3))
+
+
+def test_ragged_rows_minmax_size_9_through_the_lds_dma_kernel(gpu, ndi, lib):
+    """float32 min / max of size 9 on rows that are not a multiple of four floats: mm3f32_long_kernel<9,...,ragged> (r6, late) for the
+    index-mapping modes; `constant` keeps the extended-rows route; bit-exact against SciPy either way, every tail, one and two x
+    tiles, non-finite samples included."""
+    import scipy.ndimage as sndi
+    from cupyimg_amd import last_kernel
+    rng = np.random.default_rng(909)
+    tails = set()
+    for shape in [(24, 37, 181), (17, 30, 301), (12, 40, 253), (20, 21, 255), (16, 19, 257), (33, 18, 18), (9, 33, 19), (9, 20, 511), (181, 217, 181)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        if shape[2] == 253:
+            idx = rng.integers(0, x.size, size=x.size // 50)
+            x.flat[idx[0::2]] = np.inf
+            x.flat[idx[1::2]] = -np.inf
+        xd = gpu.asarray(x)
+        for mode in (MODES if shape[0] < 100 else MODES[:2]):
+            for fn, sfn, tag in ((ndi.minimum_filter, sndi.minimum_filter, "min"), (ndi.maximum_filter, sndi.maximum_filter, "max")):
+                got = fn(xd, size=9, mode=mode, cval=0.5).get()
+                if mode != "constant":
+                    assert "mm3f32_long_kernel<9,%s,ragged>" % tag in last_kernel(), (shape, mode, last_kernel())
+                assert np.array_equal(got, sfn(x, size=9, mode=mode, cval=0.5)), (shape, mode, tag)
+        tails.add(shape[2] & 3)
+        assert np.array_equal(ndi.grey_dilation(xd, size=9).get(), sndi.grey_dilation(x, size=9)), shape
+        assert "mm3f32_long_kernel<9,max,ragged>" in last_kernel()
+    assert tails == {1, 2, 3}
+    out = gpu.empty((181, 217, 181), np.float32)
+    for _ in range(30):
+        ndi.grey_erosion(xd, size=9, output=out)
+    assert np.array_equal(out.get(), sndi.grey_erosion(x, size=9))
