@@ -24,7 +24,7 @@ int mi_debug_set_sep3d_zrev(int on);          /* 0 = every z chunk streams upwar
 int mi_debug_set_sep3d_image2d(int on);       /* 0 = images take the tiled volume kernel */
 int mi_debug_set_sep3d_long(int k);           /* 0 auto (9..17 taps, and 3..7 taps on large volumes with full tiles), 1 never the long kernel, 2 long kernel for all of 3..17 taps */
 int mi_debug_set_sep3d_box(int k);            /* 0 auto, 1 never the running-sum box kernel */
-int mi_debug_set_sep3d_ragged(int k);         /* r5: 1 (default) the 3 / 5 / 7-tap kernel takes rows that are not a multiple of 4 floats, 0 refuse them */
+int mi_debug_set_sep3d_ragged(int k);         /* r5: 1 (default) the 3 / 5 / 7-tap kernel takes rows that are not a multiple of 4 floats, 0 refuse them (r6: the switch also covers the 9 .. 17-tap LDS-DMA kernel's ragged build) */
 int mi_debug_set_median27(int k);             /* r5: 1 (default) 3 x 3 x 3 medians of volumes on the shared-sort streaming kernel, 0 the per-voxel network */
 int mi_debug_set_long_const0(int k);          /* r5: 1 (default) constant mode with cval == 0 on the r3 long kernel, 0 the r2 kernel */
 int mi_debug_set_long_zchunks(int n);
